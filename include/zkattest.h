@@ -1,0 +1,139 @@
+/*
+ * zkattest.h -- C ABI of libzkattest_hip.so, the MI355X (gfx950) engine behind the reference's
+ * proveSignatureList / verifySignatureList / generateParamsList API.
+ *
+ * The reference (cloudflare/zkp-ecdsa, TypeScript) has no FFI layer; its boundary for this path is the ESM
+ * surface of src/index.ts:17-19.  Each entry point below names the reference interface it replaces.  A thin
+ * N-API addon or the Python mirror in zkp-ecdsa_amd/ binds these symbols.
+ *
+ * Conventions: caller allocates every buffer; the library never frees caller memory; a context is not
+ * re-entrant (one in-flight batch per ctx); several contexts (one per GPU / process) may coexist.  All
+ * integers inside byte buffers are big-endian, like the reference's toBytes (src/bignum/big.ts:121-134).
+ *
+ * Byte formats
+ *   P-256 point   64 B  x(32) || y(32)                       (affine; src/curves/weier.ts:244-255 without 0x04)
+ *   Tom-256 point 72 B  x(36) || y(36)  zero-padded from the reference's 33-byte coordinates so that every
+ *                                         field is 4-byte aligned (src/curves/edwards.ts:194-203)
+ *   scalar        32 B
+ *   proof         "ZKA1" layout, the binary equivalent of SignatureProofList (src/zkpAttestList.ts:27-60):
+ *     header 32 B : "ZKA1" | total_len u32 | secLevel u32 | n = log2(padded ring) u32 | challenge bits (16 B)
+ *     R (P), comS1 (P), keyXcom (T), keyYcom (T)
+ *     expProof[secLevel], each: A (P), Tx (T), Ty (T), then
+ *        challenge bit 1: alpha, beta1 (mod n), beta2, beta3 (mod q)                     (src/exp/exp.ts:171-185)
+ *        challenge bit 0: z, z2 (mod n), r1, r2 (mod q), PointAddProof                   (src/exp/exp.ts:186-226)
+ *     PointAddProof: C_8, C_10, C_11, C_13 (T), pi_8, pi_10, pi_11, pi_13 (MultProof), pi_x, pi_y (EqualityProof)
+ *        MultProof: C_4, A_x, A_y, A_z, A_4_1, A_4_2 (T), t_x, t_y, t_z, t_rx, t_ry, t_rz, t_r4   (src/commit/mult.ts:26-52)
+ *        EqualityProof: A_1, A_2 (T), t_x, t_r1, t_r2                                              (src/commit/equality.ts:27-40)
+ *     GKProof: cl[n], ca[n], cb[n], cd[n] (T), f[n], za[n], zb[n], zd                              (src/proofGK/gk.ts:31-58)
+ *
+ * Randomness contract (replaces crypto.getRandomValues in src/bignum/big.ts:171-181): the k-th 32-byte fill
+ * of proof b is SHA-256(seed_b || be64(k)) (ZK_RNG_SEED) or block k of a caller-supplied stream
+ * (ZK_RNG_STREAM); fills are consumed in the reference's draw order.
+ */
+#ifndef ZKATTEST_H
+#define ZKATTEST_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zk_ctx zk_ctx;
+typedef int32_t zk_status;
+
+/* call-level and per-proof status codes; the per-proof ones mirror the reference's thrown errors */
+enum {
+    ZK_OK = 0,
+    ZK_E_POINT_NOT_IN_GROUP = 1, /* 'point not in group'            src/curves/weier.ts:83 */
+    ZK_E_INVALID_KEY = 2,        /* 'invalid public key'            src/zkpAttestList.ts:117 */
+    ZK_E_T_INF = 3,              /* 'T[i] is at infinity'           src/exp/exp.ts:151 */
+    ZK_E_T1_INF = 4,             /* 'T1 is at infinity'             src/exp/exp.ts:193 */
+    ZK_E_PADD_INF = 5,           /* 'P/Q/R is at infinity'          src/exp/pointAdd.ts:117-125 */
+    ZK_E_POINTS_DONT_ADD = 6,    /* "Points don't add up!"          src/exp/pointAdd.ts:105 */
+    ZK_E_R_INF = 7,              /* 'R is at infinity'              src/zkpAttestList.ts:159 */
+    ZK_E_PARAMS_NOT_FOUND = 8,   /* 'params not found'              src/exp/exp.ts:270,302 */
+    ZK_E_SECLEVEL = 9,           /* 'security level not achieved'   src/exp/exp.ts:244 */
+    ZK_E_BAD_ENCODING = 10,      /* deserialisation failures        src/curves/weier.ts:87,258, edwards.ts:84,207 */
+    ZK_E_RNG_EXHAUSTED = 11,     /* stream too short / too many rejected fills */
+    ZK_E_BUFFER = 12,            /* output buffer too small, or context not configured */
+    ZK_E_INTERPOLATION = 13,     /* 'incorrect interpolation'       src/proofGK/interpolate.ts:65 */
+    ZK_E_ARG = 14,               /* invalid argument */
+    ZK_E_DEVICE = 15             /* HIP runtime failure (zk_last_error has the text) */
+};
+
+enum { ZK_RNG_SEED = 0, ZK_RNG_STREAM = 1 };
+typedef struct {
+    int32_t mode;           /* ZK_RNG_SEED: data = B x 32-byte seeds; ZK_RNG_STREAM: data = B x stride_blocks x 32 bytes */
+    const uint8_t *data;
+    uint64_t stride_blocks; /* ZK_RNG_STREAM only */
+} zk_rng;
+
+/* Creates an engine bound to one GPU.  Owns the HIP stream, the fixed-base tables and the workspace. */
+zk_status zk_ctx_create(int device_id, zk_ctx **out);
+void zk_ctx_destroy(zk_ctx *ctx);
+const char *zk_strerror(zk_status s);
+const char *zk_last_error(const zk_ctx *ctx);
+
+/* Replaces SystemParametersList as produced by generateParamsList (src/zkpAttestList.ts:88-92,62-78):
+ * NistGroup.h, ProofGroup.g, ProofGroup.h and SecLevel.  Builds the fixed-base tables for g, h, G, h_NIST. */
+zk_status zk_ctx_set_params(zk_ctx *ctx, const uint8_t nist_h[64], const uint8_t tom_g[72], const uint8_t tom_h[72], uint32_t sec_level);
+
+/* Replaces the `keys: bigint[]` argument (src/zkpAttestList.ts:110,150): n_keys big-endian 32-byte scalars.
+ * Pads to the next power of two with copies of keys[0] (src/proofGK/gk.ts:75-86).  The _device variant takes a
+ * pointer already resident on this context's GPU (e.g. the target of an RCCL broadcast). */
+zk_status zk_ctx_set_ring(zk_ctx *ctx, const uint8_t *keys_be32, uint64_t n_keys);
+zk_status zk_ctx_set_ring_device(zk_ctx *ctx, const void *d_keys_be32, uint64_t n_keys);
+
+/* Proofs processed per pipeline pass (workspace grows linearly with it).  Default 4096. */
+zk_status zk_ctx_set_chunk(zk_ctx *ctx, uint32_t proofs_per_chunk);
+
+/* Upper bound of one proof's ZKA1 size for the current params/ring. */
+uint64_t zk_proof_max_size(const zk_ctx *ctx);
+
+/* Replaces B calls of proveSignatureList(params, msgHash, sigBytes, publicKey, which, keys)
+ * (src/zkpAttestList.ts:104-145).  pk_xy is the WebCrypto 'raw' export without its 0x04 prefix.
+ * out receives the proofs back to back; out_off[b]..out_off[b+1] delimits proof b (empty when
+ * per_proof_status[b] != 0).  Host pointers. */
+zk_status zk_prove_batch(zk_ctx *ctx, uint64_t B, const uint8_t *msg_hash /*Bx32*/, const uint8_t *sig /*Bx64*/,
+                         const uint8_t *pk_xy /*Bx64*/, const uint32_t *which /*B*/, const zk_rng *rng,
+                         uint8_t *out, uint64_t out_cap, uint64_t *out_off /*B+1*/, int32_t *per_proof_status /*B*/);
+
+/* Same, every pointer (including rng->data) resident in this GPU's HBM; nothing crosses PCIe.  Synchronous. */
+zk_status zk_prove_batch_device(zk_ctx *ctx, uint64_t B, const void *d_msg_hash, const void *d_sig, const void *d_pk_xy,
+                                const void *d_which, const zk_rng *rng_device, void *d_out, uint64_t out_cap,
+                                void *d_out_off /*u64[B+1]*/, void *d_per_proof_status /*i32[B]*/);
+
+/* Replaces B calls of verifySignatureList(params, msgHash, keys, proof) (src/zkpAttestList.ts:147-184):
+ * ok[b] = 1 iff the reference verifier would return true.  Host pointers. */
+zk_status zk_verify_batch(zk_ctx *ctx, uint64_t B, const uint8_t *msg_hash /*Bx32*/, const uint8_t *proofs,
+                          const uint64_t *proof_off /*B+1*/, uint8_t *ok /*B*/, int32_t *per_proof_status /*B*/);
+zk_status zk_verify_batch_device(zk_ctx *ctx, uint64_t B, const void *d_msg_hash, const void *d_proofs,
+                                 const void *d_proof_off, void *d_ok, void *d_per_proof_status);
+
+/* Seeded synthetic workload generator: fills device or host buffers with a ring of
+ * n_keys uniform scalars, and B valid ECDSA P-256 signatures whose public keys' x-coordinates are planted at
+ * ring[which_b], which_b = b mod n_keys.  Mirrors oracle/zkattest_ref.py synth_* byte for byte.  Host pointers. */
+zk_status zk_synth_workload(zk_ctx *ctx, uint64_t seed, uint64_t n_keys, uint64_t B, uint8_t *ring_be32 /*n_keys x 32*/,
+                            uint8_t *msg_hash, uint8_t *sig, uint8_t *pk_xy, uint32_t *which, uint8_t *rng_seeds /*Bx32*/);
+/* Derives the synthetic SystemParametersList of seed S (h = k*g with k = SHA-256 tags). */
+zk_status zk_synth_params(zk_ctx *ctx, uint64_t seed, uint8_t nist_h[64], uint8_t tom_g[72], uint8_t tom_h[72]);
+
+/* Timing of the last prove/verify call: total GPU milliseconds between the first and last kernel (HIP events
+ * on the engine's stream) and, per kernel family, the accumulated milliseconds.  names[i] are static strings. */
+uint32_t zk_last_timing(const zk_ctx *ctx, float *total_ms, const char **names, float *ms, uint32_t cap);
+
+/* Unit-test hooks (tests/ call these through the C ABI to compare single primitives with the oracle).
+ * which_field: 0 = F_q (p256.p), 1 = Z_n, 2 = F_t;  op: 0 mul, 1 add, 2 sub, 3 inverse.  count x 40-byte BE operands. */
+zk_status zk_test_field_op(zk_ctx *ctx, int which_field, int op, uint64_t count, const uint8_t *a_be40, const uint8_t *b_be40, uint8_t *out_be40);
+/* out[i] = v[i]*g + r[i]*h on Tom-256 (72-byte affine), through the fixed-base comb kernel */
+zk_status zk_test_tom_commit(zk_ctx *ctx, uint64_t count, const uint8_t *v_be32, const uint8_t *r_be32, uint8_t *out_xy72);
+/* out[i] = k[i]*G (base_sel 0) or k[i]*h_NIST (base_sel 1) on P-256 (64-byte affine; all-zero for the identity) */
+zk_status zk_test_p256_fixed_mul(zk_ctx *ctx, int base_sel, uint64_t count, const uint8_t *k_be32, uint8_t *out_xy64);
+/* digest[i] = SHA-256(msg[i]) for count messages of identical length len */
+zk_status zk_test_sha256(zk_ctx *ctx, uint64_t count, uint64_t len, const uint8_t *msgs, uint8_t *digests32);
+/* logical RNG draw k of each proof (after rejection mapping), 32 bytes BE */
+zk_status zk_test_rng_draws(zk_ctx *ctx, uint64_t B, const zk_rng *rng, uint32_t first_k, uint32_t n_k, uint8_t *out /*B x n_k x 32*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,134 @@
+"""-m gpu: single primitives of the HIP engine, through the C ABI, against the oracle / Python ints."""
+import hashlib
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    import zkp_ecdsa_amd as Z
+    e = Z.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope='module')
+def params(eng):
+    import zkattest_ref as R
+    S = 1
+    p = R.synth_params(S, 80)
+
+    def xy(pt, w):
+        x, y = pt.toAffine()
+        return x.to_bytes(w, 'big') + y.to_bytes(w, 'big')
+    raw = (xy(p.NistGroup.h, 32), xy(p.ProofGroup.g, 36), xy(p.ProofGroup.h, 36))
+    eng.set_params(*raw, 80)
+    return p, raw
+
+
+def test_field_ops(eng):
+    import zkattest_ref as R
+    rnd = random.Random(7)
+    mods = [R.p256.p, R.p256.order, R.tomEdwards256.p]
+    for which, m in enumerate(mods):
+        a = [rnd.randrange(m) for _ in range(300)] + [0, 1, m - 1, m - 1, 0]
+        b = [rnd.randrange(m) for _ in range(300)] + [0, m - 1, m - 1, 1, m - 1]
+        assert eng.test_field_op(which, 0, a, b) == [x * y % m for x, y in zip(a, b)]
+        assert eng.test_field_op(which, 1, a, b) == [(x + y) % m for x, y in zip(a, b)]
+        assert eng.test_field_op(which, 2, a, b) == [(x - y) % m for x, y in zip(a, b)]
+        inv = eng.test_field_op(which, 3, a, b)
+        assert inv == [pow(x, -1, m) if x else 0 for x in a]  # invMod(0) = 0 (big.ts:113-119)
+
+
+def test_sha256(eng):
+    for ln in (0, 1, 55, 56, 63, 64, 65, 119, 120, 268, 603):
+        msgs = [bytes((i * 7 + j) & 255 for j in range(ln)) for i in range(70)]
+        assert eng.test_sha256(msgs) == [hashlib.sha256(m).digest() for m in msgs]
+    assert eng.test_sha256([b'abc'])[0].hex() == 'ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad'
+
+
+def test_p256_fixed_mul(eng, params):
+    import coracle as CO
+    import zkattest_ref as R
+    rnd = random.Random(3)
+    n = R.p256.order
+    ks = [rnd.randrange(n) for _ in range(100)] + [0, 1, 2, n - 1, 255, 256, 1 << 255]
+    got = eng.test_p256_fixed_mul(0, ks)
+    for k, g in zip(ks, got):
+        exp = CO.p256_mul(k)
+        assert g == (exp if exp else bytes(64)), k
+    hxy = params[1][0]
+    got = eng.test_p256_fixed_mul(1, ks[:40])
+    for k, g in zip(ks[:40], got):
+        assert g == CO.p256_mul(k, hxy)
+
+
+def test_tom_commit(eng, params):
+    import coracle as CO
+    import zkattest_ref as R
+    raw = params[1]
+    octx = CO.OracleCtx(*raw, 80)
+    rnd = random.Random(5)
+    q = R.tomEdwards256.order
+    vs = [rnd.randrange(q) for _ in range(150)] + [0, 0, 1, q - 1, 5]
+    rs = [rnd.randrange(q) for _ in range(150)] + [0, 1, 0, q - 1, 0]
+    got = eng.test_tom_commit(vs, rs)
+    for v, r, g in zip(vs, rs, got):
+        assert g == octx.tom_commit(v, r), (v, r)
+
+
+def test_rng_draws_seed_mode(eng, params):
+    import zkattest_ref as R
+    seeds = b''.join(hashlib.sha256(b'seed%d' % i).digest() for i in range(5))
+    got = eng.test_rng_draws(5, 0, 50, seeds=seeds)
+    for b in range(5):
+        rng = R.SeedRng(seeds[32 * b:32 * b + 32])
+        for k in range(50):
+            assert got[b][k] == rng.fill(32)
+
+
+def test_rng_rejection_mapping(eng, params):
+    """Stream mode with planted out-of-range fills: logical draws must skip exactly the fills rnd() would reject
+    (big.ts:171-181) for the modulus of that draw (n for draws 0, 3+4i, 4+4i; q otherwise)."""
+    import zkattest_ref as R
+    n, q = R.p256.order, R.p256.p
+    rnd = random.Random(11)
+    nb = 80
+    blocks = [rnd.randrange(1 << 255).to_bytes(32, 'big') for _ in range(nb)]
+    blocks[0] = (n + 5).to_bytes(32, 'big')          # draw 0 is mod n: rejected (n <= v < q)
+    blocks[2] = (n + 7).to_bytes(32, 'big')          # lands on draw 1 (mod q): accepted
+    blocks[4] = (q + 1).to_bytes(32, 'big')          # >= q: rejected whatever the modulus
+    blocks[5] = ((1 << 256) - 1).to_bytes(32, 'big')  # consecutive rejection
+    blocks[20] = (n + 1).to_bytes(32, 'big')
+    got = eng.test_rng_draws(1, 0, 40, streams=b''.join(blocks), stream_blocks=nb)[0]
+    rng = R.StreamRng(blocks)
+    sec = 80
+    for k in range(40):
+        is_n = k == 0 or (3 <= k < 3 + 4 * sec and ((k - 3) & 3) < 2)
+        v = R.rnd(n if is_n else q, rng)
+        assert got[k] == v.to_bytes(32, 'big'), k
+
+
+def test_synth_matches_python(eng):
+    import zkattest_ref as R
+    S, nkeys, B = 42, 8, 3
+    ring, msg, sig, pk, which, seeds = eng.synth_workload(S, nkeys, B)
+    pyring = R.synth_ring_fast(S, nkeys)
+    for b in range(B):
+        m, s, p, w, d, seed = R.synth_proof_input(S, b, nkeys)
+        assert msg[32 * b:32 * b + 32] == m and sig[64 * b:64 * b + 64] == s and pk[64 * b:64 * b + 64] == p[1:]
+        assert which[b] == w and seeds[32 * b:32 * b + 32] == seed
+        assert R.ecdsa_verify(p, m, s)
+        pyring[w] = R.keyToInt(p)
+    assert ring == b''.join(v.to_bytes(32, 'big') for v in pyring)
+    pp = R.synth_params(S, 80)
+    nh, tg, th = eng.synth_params(S)
+    x, y = pp.NistGroup.h.toAffine()
+    assert nh == x.to_bytes(32, 'big') + y.to_bytes(32, 'big')
+    x, y = pp.ProofGroup.h.toAffine()
+    assert th == x.to_bytes(36, 'big') + y.to_bytes(36, 'big')
+    x, y = pp.ProofGroup.g.toAffine()
+    assert tg == x.to_bytes(36, 'big') + y.to_bytes(36, 'big')

@@ -1,0 +1,225 @@
+"""ctypes binding of libzkattest_hip.so (C ABI: include/zkattest.h).  Fails loudly when the library is missing:
+there is no CPU fallback in the product path."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libzkattest_hip.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+# every symbol include/zkattest.h declares
+SYMBOLS = [
+    'zk_ctx_create', 'zk_ctx_destroy', 'zk_strerror', 'zk_last_error', 'zk_ctx_set_params', 'zk_ctx_set_ring',
+    'zk_ctx_set_ring_device', 'zk_ctx_set_chunk', 'zk_proof_max_size', 'zk_prove_batch', 'zk_prove_batch_device',
+    'zk_verify_batch', 'zk_verify_batch_device', 'zk_synth_workload', 'zk_synth_params', 'zk_last_timing',
+    'zk_test_field_op', 'zk_test_tom_commit', 'zk_test_p256_fixed_mul', 'zk_test_sha256', 'zk_test_rng_draws',
+]
+
+STATUS_TEXT = {
+    0: 'ok', 1: 'point not in group', 2: 'invalid public key', 3: 'T[i] is at infinity', 4: 'T1 is at infinity',
+    5: 'P/Q/R is at infinity', 6: "Points don't add up!", 7: 'R is at infinity', 8: 'params not found',
+    9: 'security level not achieved', 10: 'error deserializing', 11: 'randomness stream exhausted',
+    12: 'buffer too small or context not configured', 13: 'incorrect interpolation', 14: 'invalid argument',
+    15: 'HIP runtime failure',
+}
+
+
+class ZkRng(C.Structure):
+    _fields_ = [('mode', C.c_int32), ('data', C.c_void_p), ('stride_blocks', C.c_uint64)]
+
+
+def build(jobs=8):
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(['make', '-C', CSRC, '-j%d' % jobs, '-s'])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('libzkattest_hip.so is not built (run __graft_entry__.build()); the engine has no CPU fallback')
+        L = C.CDLL(LIB_PATH)
+        vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+        L.zk_ctx_create.argtypes = [i32, C.POINTER(vp)]
+        L.zk_ctx_destroy.argtypes = [vp]
+        L.zk_ctx_destroy.restype = None
+        L.zk_strerror.argtypes = [i32]
+        L.zk_strerror.restype = C.c_char_p
+        L.zk_last_error.argtypes = [vp]
+        L.zk_last_error.restype = C.c_char_p
+        L.zk_ctx_set_params.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, u32]
+        L.zk_ctx_set_ring.argtypes = [vp, C.c_char_p, u64]
+        L.zk_ctx_set_ring_device.argtypes = [vp, vp, u64]
+        L.zk_ctx_set_chunk.argtypes = [vp, u32]
+        L.zk_proof_max_size.argtypes = [vp]
+        L.zk_proof_max_size.restype = u64
+        L.zk_prove_batch.argtypes = [vp, u64, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(ZkRng), vp, u64, vp, vp]
+        L.zk_prove_batch_device.argtypes = [vp, u64, vp, vp, vp, vp, C.POINTER(ZkRng), vp, u64, vp, vp]
+        L.zk_verify_batch.argtypes = [vp, u64, C.c_char_p, C.c_char_p, vp, vp, vp]
+        L.zk_verify_batch_device.argtypes = [vp, u64, vp, vp, vp, vp, vp]
+        L.zk_synth_workload.argtypes = [vp, u64, u64, u64, vp, vp, vp, vp, vp, vp]
+        L.zk_synth_params.argtypes = [vp, u64, vp, vp, vp]
+        L.zk_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.POINTER(C.c_float), u32]
+        L.zk_last_timing.restype = u32
+        L.zk_test_field_op.argtypes = [vp, i32, i32, u64, C.c_char_p, C.c_char_p, vp]
+        L.zk_test_tom_commit.argtypes = [vp, u64, C.c_char_p, C.c_char_p, vp]
+        L.zk_test_p256_fixed_mul.argtypes = [vp, i32, u64, C.c_char_p, vp]
+        L.zk_test_sha256.argtypes = [vp, u64, u64, C.c_char_p, vp]
+        L.zk_test_rng_draws.argtypes = [vp, u64, C.POINTER(ZkRng), u32, u32, vp]
+        _lib = L
+    return _lib
+
+
+class ZkError(RuntimeError):
+    def __init__(self, status, detail=''):
+        self.status = status
+        super().__init__('%s (status %d)%s' % (STATUS_TEXT.get(status, '?'), status, (': ' + detail) if detail else ''))
+
+
+class Engine:
+    """One engine = one GPU (zk_ctx)."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.zk_ctx_create(device, C.byref(h))
+        self.h = h
+        self._chk(rc)
+        self.sec = None
+        self._keep = []
+
+    def _chk(self, rc):
+        if rc:
+            detail = self.L.zk_last_error(self.h).decode() if self.h else ''
+            raise ZkError(rc, detail)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.zk_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, nist_h64, tom_g72, tom_h72, sec_level=80):
+        self._chk(self.L.zk_ctx_set_params(self.h, bytes(nist_h64), bytes(tom_g72), bytes(tom_h72), sec_level))
+        self.sec = sec_level
+
+    def set_ring(self, keys_be32, nkeys=None):
+        keys_be32 = bytes(keys_be32)
+        if nkeys is None:
+            nkeys = len(keys_be32) // 32
+        self._chk(self.L.zk_ctx_set_ring(self.h, keys_be32, nkeys))
+
+    def set_ring_device(self, dev_ptr, nkeys):
+        self._chk(self.L.zk_ctx_set_ring_device(self.h, dev_ptr, nkeys))
+
+    def set_chunk(self, chunk):
+        self._chk(self.L.zk_ctx_set_chunk(self.h, chunk))
+
+    def proof_max_size(self):
+        return self.L.zk_proof_max_size(self.h)
+
+    def prove_batch(self, msg, sig, pk, which, seeds=None, streams=None, stream_blocks=0):
+        """Host-buffer entry point.  Returns (list of proof bytes or None, list of status)."""
+        B = len(which)
+        cap = self.proof_max_size() * max(B, 1)
+        out = C.create_string_buffer(cap)
+        off = (C.c_uint64 * (B + 1))()
+        st = (C.c_int32 * B)()
+        w = (C.c_uint32 * B)(*which)
+        if streams is None:
+            data = C.create_string_buffer(bytes(seeds), 32 * B)
+            rng = ZkRng(0, C.cast(data, C.c_void_p), 0)
+        else:
+            data = C.create_string_buffer(bytes(streams), 32 * B * stream_blocks)
+            rng = ZkRng(1, C.cast(data, C.c_void_p), stream_blocks)
+        self._chk(self.L.zk_prove_batch(self.h, B, bytes(msg), bytes(sig), bytes(pk), w, C.byref(rng), out, cap, off, st))
+        raw = out.raw
+        proofs = [raw[off[b]:off[b + 1]] if st[b] == 0 else None for b in range(B)]
+        return proofs, list(st)
+
+    def prove_batch_device(self, B, d_msg, d_sig, d_pk, d_which, d_seeds, d_out, out_cap, d_off, d_status, mode=0, stride_blocks=0):
+        rng = ZkRng(mode, d_seeds, stride_blocks)
+        self._chk(self.L.zk_prove_batch_device(self.h, B, d_msg, d_sig, d_pk, d_which, C.byref(rng), d_out, out_cap, d_off, d_status))
+
+    def verify_batch(self, msg, proofs):
+        B = len(proofs)
+        off = (C.c_uint64 * (B + 1))()
+        o = 0
+        for b, p in enumerate(proofs):
+            off[b] = o
+            o += len(p)
+        off[B] = o
+        ok = (C.c_uint8 * B)()
+        st = (C.c_int32 * B)()
+        self._chk(self.L.zk_verify_batch(self.h, B, bytes(msg), b''.join(proofs), off, ok, st))
+        return list(ok), list(st)
+
+    def synth_params(self, seed):
+        a, b, c = C.create_string_buffer(64), C.create_string_buffer(72), C.create_string_buffer(72)
+        self._chk(self.L.zk_synth_params(self.h, seed, a, b, c))
+        return a.raw, b.raw, c.raw
+
+    def synth_workload(self, seed, nkeys, B):
+        ring = C.create_string_buffer(32 * nkeys)
+        msg, sig, pk = C.create_string_buffer(32 * max(B, 1)), C.create_string_buffer(64 * max(B, 1)), C.create_string_buffer(64 * max(B, 1))
+        which = (C.c_uint32 * max(B, 1))()
+        seeds = C.create_string_buffer(32 * max(B, 1))
+        self._chk(self.L.zk_synth_workload(self.h, seed, nkeys, B, ring, msg, sig, pk, which, seeds))
+        return ring.raw, msg.raw[:32 * B], sig.raw[:64 * B], pk.raw[:64 * B], list(which)[:B], seeds.raw[:32 * B]
+
+    def last_timing(self):
+        total = C.c_float()
+        names = (C.c_char_p * 32)()
+        ms = (C.c_float * 32)()
+        n = self.L.zk_last_timing(self.h, C.byref(total), names, ms, 32)
+        return total.value, {names[i].decode(): ms[i] for i in range(min(n, 32))}
+
+    # ---- unit-test hooks
+    def test_field_op(self, which, op, a_list, b_list):
+        n = len(a_list)
+        a = b''.join(x.to_bytes(40, 'big') for x in a_list)
+        b = b''.join(x.to_bytes(40, 'big') for x in b_list)
+        out = C.create_string_buffer(40 * n)
+        self._chk(self.L.zk_test_field_op(self.h, which, op, n, a, b, out))
+        return [int.from_bytes(out.raw[40 * i:40 * i + 40], 'big') for i in range(n)]
+
+    def test_tom_commit(self, v_list, r_list):
+        n = len(v_list)
+        out = C.create_string_buffer(72 * n)
+        self._chk(self.L.zk_test_tom_commit(self.h, n, b''.join(x.to_bytes(32, 'big') for x in v_list),
+                                            b''.join(x.to_bytes(32, 'big') for x in r_list), out))
+        return [out.raw[72 * i:72 * i + 72] for i in range(n)]
+
+    def test_p256_fixed_mul(self, base_sel, k_list):
+        n = len(k_list)
+        out = C.create_string_buffer(64 * n)
+        self._chk(self.L.zk_test_p256_fixed_mul(self.h, base_sel, n, b''.join(x.to_bytes(32, 'big') for x in k_list), out))
+        return [out.raw[64 * i:64 * i + 64] for i in range(n)]
+
+    def test_sha256(self, msgs):
+        n, ln = len(msgs), len(msgs[0])
+        assert all(len(m) == ln for m in msgs)
+        out = C.create_string_buffer(32 * n)
+        self._chk(self.L.zk_test_sha256(self.h, n, ln, b''.join(msgs), out))
+        return [out.raw[32 * i:32 * i + 32] for i in range(n)]
+
+    def test_rng_draws(self, B, first_k, n_k, seeds=None, streams=None, stream_blocks=0):
+        if streams is None:
+            data = C.create_string_buffer(bytes(seeds), 32 * B)
+            rng = ZkRng(0, C.cast(data, C.c_void_p), 0)
+        else:
+            data = C.create_string_buffer(bytes(streams), 32 * B * stream_blocks)
+            rng = ZkRng(1, C.cast(data, C.c_void_p), stream_blocks)
+        out = C.create_string_buffer(32 * B * n_k)
+        self._chk(self.L.zk_test_rng_draws(self.h, B, C.byref(rng), first_k, n_k, out))
+        return [[out.raw[32 * (b * n_k + j):32 * (b * n_k + j) + 32] for j in range(n_k)] for b in range(B)]

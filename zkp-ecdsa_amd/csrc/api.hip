@@ -1,0 +1,679 @@
+// C ABI of libzkattest_hip.so (include/zkattest.h) and the host-side phase pipeline of the prover.
+// One context = one GPU = one HIP stream.  A batch is processed in chunks of `chunk` proofs; every phase of a chunk
+// is one kernel over all proofs (or all zero-bit reps) of the chunk -- see DESIGN.md for the phase list.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "engine.h"
+
+void launch_synth(hipStream_t s, const uint32_t* pfix_G, uint64_t seed, uint64_t nkeys, uint64_t B, uint8_t* ring, uint8_t* msg, uint8_t* sig, uint8_t* pk,
+                  uint32_t* which, uint8_t* seeds);
+void launch_synth_param_scalars(hipStream_t s, uint64_t seed, uint8_t* kn_be, uint8_t* kt_be);
+
+struct TimerRec {
+    const char* name;
+    hipEvent_t e0, e1;
+};
+struct zk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // params
+    DevParams P{};
+    bool params_set = false;
+    uint32_t* tom_tab_gen = nullptr;  // generator table (synthetic params)
+    uint32_t* tab_scratch = nullptr;
+    int32_t* d_flag = nullptr;
+    // ring
+    uint32_t* ring_mem = nullptr;
+    uint64_t N = 0, nkeys = 0;
+    uint32_t n = 0;
+    // workspace
+    uint32_t chunk = 4096;
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    uint32_t ws_C = 0, ws_sec = 0, ws_n = 0;
+    Workspace W{};
+    Soa gk_am{};
+    uint32_t* d_totals = nullptr;
+    // timing
+    std::vector<TimerRec> trecs;
+    std::vector<hipEvent_t> epool;
+    size_t eused = 0;
+    std::vector<std::pair<const char*, float>> last_timing;
+    float last_total_ms = 0;
+};
+
+#define HIPCHK(ctx, x)                                                                                      \
+    do {                                                                                                    \
+        hipError_t e_ = (x);                                                                                \
+        if (e_ != hipSuccess) {                                                                             \
+            char buf_[256];                                                                                 \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (ctx)->err = buf_;                                                                              \
+            return ZK_E_DEVICE;                                                                             \
+        }                                                                                                   \
+    } while (0)
+
+static hipEvent_t get_event(zk_ctx* c) {
+    if (c->eused == c->epool.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        c->epool.push_back(e);
+    }
+    return c->epool[c->eused++];
+}
+struct Scope {
+    zk_ctx* c;
+    TimerRec r;
+    Scope(zk_ctx* c_, const char* name) : c(c_) {
+        r.name = name, r.e0 = get_event(c), r.e1 = get_event(c);
+        hipEventRecord(r.e0, c->stream);
+    }
+    ~Scope() {
+        hipEventRecord(r.e1, c->stream);
+        c->trecs.push_back(r);
+    }
+};
+static void timing_begin(zk_ctx* c) { c->trecs.clear(), c->eused = 0; }
+static void timing_end(zk_ctx* c) {
+    c->last_timing.clear();
+    c->last_total_ms = 0;
+    for (auto& r : c->trecs) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, r.e0, r.e1);
+        bool found = false;
+        for (auto& p : c->last_timing)
+            if (p.first == r.name) p.second += ms, found = true;
+        if (!found) c->last_timing.push_back({r.name, ms});
+        c->last_total_ms += ms;
+    }
+}
+
+extern "C" const char* zk_strerror(zk_status s) {
+    switch (s) {
+    case ZK_OK: return "ok";
+    case ZK_E_POINT_NOT_IN_GROUP: return "point not in group";
+    case ZK_E_INVALID_KEY: return "invalid public key";
+    case ZK_E_T_INF: return "T[i] is at infinity";
+    case ZK_E_T1_INF: return "T1 is at infinity";
+    case ZK_E_PADD_INF: return "P/Q/R is at infinity";
+    case ZK_E_POINTS_DONT_ADD: return "Points don't add up!";
+    case ZK_E_R_INF: return "R is at infinity";
+    case ZK_E_PARAMS_NOT_FOUND: return "params not found";
+    case ZK_E_SECLEVEL: return "security level not achieved";
+    case ZK_E_BAD_ENCODING: return "error deserializing";
+    case ZK_E_RNG_EXHAUSTED: return "randomness stream exhausted";
+    case ZK_E_BUFFER: return "buffer too small or context not configured";
+    case ZK_E_INTERPOLATION: return "incorrect interpolation";
+    case ZK_E_ARG: return "invalid argument";
+    case ZK_E_DEVICE: return "HIP runtime failure";
+    }
+    return "unknown status";
+}
+extern "C" const char* zk_last_error(const zk_ctx* c) { return c ? c->err.c_str() : ""; }
+
+extern "C" zk_status zk_ctx_create(int device_id, zk_ctx** out) {
+    if (!out) return ZK_E_ARG;
+    zk_ctx* c = new zk_ctx();
+    c->device = device_id;
+    *out = c;
+    HIPCHK(c, hipSetDevice(device_id));
+    HIPCHK(c, hipStreamCreate(&c->stream));
+    HIPCHK(c, hipMalloc(&c->P.tom_tab_g, sizeof(uint32_t) * TOM_TAB_WORDS));
+    HIPCHK(c, hipMalloc(&c->P.tom_tab_h, sizeof(uint32_t) * TOM_TAB_WORDS));
+    HIPCHK(c, hipMalloc(&c->tom_tab_gen, sizeof(uint32_t) * TOM_TAB_WORDS));
+    HIPCHK(c, hipMalloc(&c->P.pfix_G, sizeof(uint32_t) * PFIX_TAB_WORDS));
+    HIPCHK(c, hipMalloc(&c->P.pfix_H, sizeof(uint32_t) * PFIX_TAB_WORDS));
+    HIPCHK(c, hipMalloc(&c->tab_scratch, sizeof(uint32_t) * table_scratch_words()));
+    HIPCHK(c, hipMalloc(&c->d_flag, 64));
+    HIPCHK(c, hipMalloc(&c->d_totals, 64));
+    int32_t one = 1;
+    HIPCHK(c, hipMemcpyAsync(c->d_flag, &one, 4, hipMemcpyHostToDevice, c->stream));
+    // tables that do not depend on the parameters: P-256 generator, Tom generator
+    launch_build_pfix_table(c->stream, nullptr, c->P.pfix_G, c->tab_scratch, c->d_flag);
+    uint32_t genw[18];
+    memcpy(genw, TOM_GX_W, 36), memcpy(genw + 9, TOM_GY_W, 36);
+    uint32_t* d_xy;
+    HIPCHK(c, hipMalloc(&d_xy, 18 * 4));
+    HIPCHK(c, hipMemcpyAsync(d_xy, genw, 72, hipMemcpyHostToDevice, c->stream));
+    launch_build_tom_table(c->stream, d_xy, c->tom_tab_gen, c->tab_scratch, c->d_flag);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(d_xy));
+    return ZK_OK;
+}
+extern "C" void zk_ctx_destroy(zk_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto e : c->epool) hipEventDestroy(e);
+    hipFree(c->P.tom_tab_g), hipFree(c->P.tom_tab_h), hipFree(c->tom_tab_gen), hipFree(c->P.pfix_G), hipFree(c->P.pfix_H);
+    hipFree(c->tab_scratch), hipFree(c->d_flag), hipFree(c->d_totals), hipFree(c->ring_mem), hipFree(c->arena);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// big-endian byte string -> little-endian 32-bit words
+static void be_to_words(const uint8_t* be, int nbytes, uint32_t* w, int nw) {
+    for (int i = 0; i < nw; i++) w[i] = 0;
+    for (int i = 0; i < nbytes; i++) {
+        int bi = nbytes - 1 - i;
+        w[bi / 4] |= (uint32_t)be[i] << (8 * (bi % 4));
+    }
+}
+static void words_to_limbs30(const uint32_t* w, int nw, uint32_t* l) {
+    for (int i = 0; i < 9; i++) {
+        int bit = 30 * i, wi = bit / 32, sh = bit % 32;
+        uint64_t v = 0;
+        if (wi < nw) v = w[wi];
+        if (wi + 1 < nw) v |= (uint64_t)w[wi + 1] << 32;
+        l[i] = (uint32_t)(v >> sh) & 0x3fffffffu;
+    }
+}
+
+extern "C" zk_status zk_ctx_set_params(zk_ctx* c, const uint8_t nist_h[64], const uint8_t tom_g[72], const uint8_t tom_h[72], uint32_t sec) {
+    if (!c || !nist_h || !tom_g || !tom_h) return ZK_E_ARG;
+    if (sec == 0 || sec > ZK_MAXSEC) return ZK_E_SECLEVEL;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t hw[16], gw[18], hw2[18];
+    be_to_words(nist_h, 32, hw, 8), be_to_words(nist_h + 32, 32, hw + 8, 8);
+    be_to_words(tom_g, 36, gw, 9), be_to_words(tom_g + 36, 36, gw + 9, 9);
+    be_to_words(tom_h, 36, hw2, 9), be_to_words(tom_h + 36, 36, hw2 + 9, 9);
+    uint32_t* d;
+    HIPCHK(c, hipMalloc(&d, 64 * 4));
+    HIPCHK(c, hipMemcpyAsync(d, hw, 64, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d + 16, gw, 72, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d + 34, hw2, 72, hipMemcpyHostToDevice, c->stream));
+    int32_t one = 1;
+    HIPCHK(c, hipMemcpyAsync(c->d_flag, &one, 4, hipMemcpyHostToDevice, c->stream));
+    launch_build_pfix_table(c->stream, d, c->P.pfix_H, c->tab_scratch, c->d_flag);
+    launch_build_tom_table(c->stream, d + 16, c->P.tom_tab_g, c->tab_scratch, c->d_flag);
+    launch_build_tom_table(c->stream, d + 34, c->P.tom_tab_h, c->tab_scratch, c->d_flag);
+    int32_t ok = 0;
+    HIPCHK(c, hipMemcpyAsync(&ok, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(d));
+    if (!ok) {
+        c->params_set = false;
+        return ZK_E_POINT_NOT_IN_GROUP;
+    }
+    words_to_limbs30(gw, 9, c->P.tom_g_aff), words_to_limbs30(gw + 9, 9, c->P.tom_g_aff + 9);
+    c->P.sec = sec;
+    c->params_set = true;
+    return ZK_OK;
+}
+
+static zk_status set_ring_common(zk_ctx* c, const uint8_t* d_keys, uint64_t nkeys) {
+    uint32_t n = 0;
+    while (((uint64_t)1 << n) < nkeys) n++;
+    if (n < 1 || n > ZK_MAXN - 4) return ZK_E_ARG;  // N = 1 is the reference's degenerate n = 0 case (untested there)
+    uint64_t N = (uint64_t)1 << n;
+    if (c->ring_mem) HIPCHK(c, hipFree(c->ring_mem));
+    c->ring_mem = nullptr;
+    HIPCHK(c, hipMalloc(&c->ring_mem, sizeof(uint32_t) * 9 * N));
+    Soa ring = {c->ring_mem, (uint32_t)N};
+    launch_ring_load(c->stream, d_keys, nkeys, N, ring);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->N = N, c->n = n, c->nkeys = nkeys;
+    return ZK_OK;
+}
+extern "C" zk_status zk_ctx_set_ring_device(zk_ctx* c, const void* d_keys, uint64_t nkeys) {
+    if (!c || !d_keys || nkeys < 2) return ZK_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    return set_ring_common(c, (const uint8_t*)d_keys, nkeys);
+}
+extern "C" zk_status zk_ctx_set_ring(zk_ctx* c, const uint8_t* keys, uint64_t nkeys) {
+    if (!c || !keys || nkeys < 2) return ZK_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint8_t* d;
+    HIPCHK(c, hipMalloc(&d, 32 * nkeys));
+    HIPCHK(c, hipMemcpy(d, keys, 32 * nkeys, hipMemcpyHostToDevice));
+    zk_status s = set_ring_common(c, d, nkeys);
+    hipFree(d);
+    return s;
+}
+extern "C" zk_status zk_ctx_set_chunk(zk_ctx* c, uint32_t chunk) {
+    if (!c || chunk == 0 || chunk > (1u << 20)) return ZK_E_ARG;
+    c->chunk = chunk;
+    return ZK_OK;
+}
+static uint64_t proof_size_host(uint32_t sec, uint32_t n, uint32_t z) {
+    return (uint64_t)ZK_FIXED + (uint64_t)ZK_REP_HEAD * sec + (uint64_t)ZK_PADD_SZ * z + (uint64_t)n * (4 * 72 + 3 * 32) + 32;
+}
+extern "C" uint64_t zk_proof_max_size(const zk_ctx* c) {
+    if (!c || !c->params_set || !c->N) return 0;
+    return proof_size_host(c->P.sec, c->n, c->P.sec);
+}
+
+// ------------------------------------------------------------------ workspace arena
+struct Carver {
+    uint8_t* base;
+    size_t off = 0;
+    explicit Carver(uint8_t* b) : base(b) {}
+    void* take(size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        return p;
+    }
+    Soa soa(size_t elems) { return Soa{(uint32_t*)take(elems * 36), (uint32_t)elems}; }
+    Soa3 soa3(size_t elems) { return Soa3{soa(elems), soa(elems), soa(elems)}; }
+    TomList list(size_t cap) {
+        TomList L;
+        L.v = soa(cap), L.r = soa(cap), L.proj = soa3(cap), L.ax = soa(cap), L.ay = soa(cap), L.cap = (uint32_t)cap;
+        return L;
+    }
+};
+static size_t carve(zk_ctx* c, uint8_t* base, uint32_t C, uint32_t sec, uint32_t n, uint64_t N) {
+    Carver k(base);
+    Workspace& W = c->W;
+    uint64_t cs = (uint64_t)C * sec;
+    uint64_t items_cap = std::min<uint64_t>(cs, cs / 2 + (uint64_t)(4.0 * std::sqrt((double)cs)) + 64);
+    W.C = C, W.sec = sec, W.n = n, W.N = (uint32_t)N, W.items_cap = (uint32_t)items_cap;
+    W.st = (int32_t*)k.take(4 * (size_t)C);
+    W.pkx = k.soa(C), W.pky = k.soa(C), W.pkxm = k.soa(C), W.pkym = k.soa(C);
+    W.Rxm = k.soa(C), W.Rym = k.soa(C), W.Rx = k.soa(C), W.Ry = k.soa(C);
+    W.Q = k.soa3(C), W.s1 = k.soa(C);
+    W.rtab = (uint32_t*)k.take(sizeof(uint32_t) * (size_t)RTAB_WORDS * C);
+    W.rbase = k.soa3((size_t)C * RTAB_NWIN);
+    W.chal = (uint32_t*)k.take(16 * (size_t)C);
+    W.zcnt = (uint32_t*)k.take(4 * (size_t)C);
+    W.item_base = (uint32_t*)k.take(4 * ((size_t)C + 1));
+    W.out_base = (uint64_t*)k.take(8 * ((size_t)C + 1));
+    size_t ne = (size_t)C * (sec + 1);
+    W.Tproj = k.soa3(ne), W.Aproj = k.soa3(ne);
+    W.Tx = k.soa(ne), W.Ty = k.soa(ne), W.Ax = k.soa(ne), W.Ay = k.soa(ne);
+    W.item_proof = (uint32_t*)k.take(4 * items_cap), W.item_rep = (uint32_t*)k.take(4 * items_cap), W.item_rank = (uint32_t*)k.take(4 * items_cap);
+    W.T1proj = k.soa3(items_cap), W.T1x = k.soa(items_cap), W.T1y = k.soa(items_cap);
+    W.padd_c = (uint32_t*)k.take(4 * 18 * items_cap);
+    W.la = k.list((size_t)C * (2 + 2 * sec));
+    W.lb = k.list(items_cap * LB_SLOTS);
+    W.lc = k.list((size_t)C * 4 * n);
+    W.gk_x = (uint32_t*)k.take(12 * (size_t)C);
+    W.gk_coef = k.soa((size_t)(n + 1) * C);
+    c->gk_am = k.soa((size_t)n * C);
+    uint64_t g = std::max<uint64_t>(1, std::min<uint64_t>(C, ((uint64_t)1 << 24) / N));
+    W.gk_group = (uint32_t)g;
+    W.gk_bufA = (uint32_t*)k.take(36 * g * N);
+    W.gk_bufB = (uint32_t*)k.take(36 * g * N);
+    W.rng.exc_idx = (uint32_t*)k.take(4 * RNG_MAX_EXC * (size_t)C);
+    W.rng.exc_flags = (uint32_t*)k.take(4 * RNG_MAX_EXC * (size_t)C);
+    W.rng.exc_cnt = (uint32_t*)k.take(4 * (size_t)C);
+    W.ring = Soa{c->ring_mem, (uint32_t)N};
+    return k.off + 256;
+}
+static zk_status ensure_workspace(zk_ctx* c, uint32_t C) {
+    uint32_t sec = c->P.sec, n = c->n;
+    if (c->arena && c->ws_C == C && c->ws_sec == sec && c->ws_n == n) {
+        c->W.ring = Soa{c->ring_mem, (uint32_t)c->N};
+        return ZK_OK;
+    }
+    size_t need = carve(c, nullptr, C, sec, n, c->N);
+    if (need > c->arena_bytes) {
+        if (c->arena) HIPCHK(c, hipFree(c->arena));
+        c->arena = nullptr, c->arena_bytes = 0;
+        HIPCHK(c, hipMalloc(&c->arena, need));
+        c->arena_bytes = need;
+    }
+    carve(c, (uint8_t*)c->arena, C, sec, n, c->N);
+    c->ws_C = C, c->ws_sec = sec, c->ws_n = n;
+    return ZK_OK;
+}
+
+// ------------------------------------------------------------------ the prover pipeline
+static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const uint8_t* d_sig, const uint8_t* d_pk, const uint32_t* d_which,
+                              int rng_mode, const uint8_t* d_rng, uint64_t stride, uint8_t* d_out, uint64_t out_cap, uint64_t* d_out_off,
+                              int32_t* d_status) {
+    if (!c->params_set || !c->N) return ZK_E_BUFFER;
+    if (rng_mode != ZK_RNG_SEED && rng_mode != ZK_RNG_STREAM) return ZK_E_ARG;
+    uint32_t C = (uint32_t)std::min<uint64_t>(c->chunk, B ? B : 1);
+    zk_status zs = ensure_workspace(c, C);
+    if (zs) return zs;
+    Workspace& W = c->W;
+    const DevParams& P = c->P;
+    hipStream_t s = c->stream;
+    timing_begin(c);
+    uint64_t cursor = 0;
+    if (B == 0) {
+        HIPCHK(c, hipMemsetAsync(d_out_off, 0, 8, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        return ZK_OK;
+    }
+    for (uint64_t first = 0; first < B; first += C) {
+        uint32_t cnt = (uint32_t)std::min<uint64_t>(C, B - first);
+        ChunkIn in{d_msg + 32 * first, d_sig + 64 * first, d_pk + 64 * first, d_which + first, cnt};
+        W.rng.seeds = d_rng, W.rng.stream = d_rng, W.rng.stride_blocks = stride, W.rng.mode = rng_mode, W.rng.sec = (int)W.sec;
+        W.rng.proof_base = (uint32_t)first;
+        uint32_t nblk = 3 + 44 * W.sec + 5 * W.n + RNG_MAX_EXC;
+        {
+            Scope t(c, "rng_prepass");
+            launch_rng_prepass(s, W, cnt, nblk);
+        }
+        {
+            Scope t(c, "p256_front");
+            launch_front(s, P, W, in);
+        }
+        {
+            Scope t(c, "p256_rtab");
+            launch_rtab(s, W, cnt);
+        }
+        {
+            Scope t(c, "p256_exp_commit");
+            launch_exp_commit(s, P, W, cnt);
+        }
+        {
+            Scope t(c, "p256_normalize");
+            launch_p256_normalize(s, W.Tproj, cnt * (W.sec + 1), W.Tx, W.Ty, W.st, W.sec + 1, ZK_E_T_INF, nullptr);
+            launch_p256_normalize(s, W.Aproj, cnt * (W.sec + 1), W.Ax, W.Ay, W.st, W.sec + 1, 0, nullptr);
+        }
+        uint32_t na = cnt * (2 + 2 * W.sec);
+        {
+            Scope t(c, "scalars");
+            launch_lista_scalars(s, W, cnt);
+        }
+        {
+            Scope t(c, "tom_commit");
+            launch_tom_commit(s, P, W.la, na, 1, 1);
+        }
+        {
+            Scope t(c, "tom_normalize");
+            launch_tom_normalize(s, W.la, na, 0, 1, 1);
+        }
+        {
+            Scope t(c, "hash");
+            launch_exp_challenge(s, W, cnt);
+        }
+        uint32_t totals[4];
+        {
+            Scope t(c, "scan");
+            launch_scan(s, W, cnt, cursor, out_cap, d_out_off, d_status, c->d_totals, first);
+        }
+        HIPCHK(c, hipMemcpyAsync(totals, c->d_totals, 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (totals[1]) {
+            c->err = "output buffer too small";
+            return ZK_E_BUFFER;
+        }
+        uint32_t items = totals[0];
+        if (items > W.items_cap) {
+            // cannot happen for hash-derived challenges (cap = mean + 8 sigma) unless chunk*sec is tiny, where cap = chunk*sec
+            c->err = "zero-bit rep count exceeds workspace capacity";
+            return ZK_E_BUFFER;
+        }
+        uint8_t* out = d_out + cursor;
+        {
+            Scope t(c, "scan");
+            launch_items(s, W, cnt);
+        }
+        {
+            Scope t(c, "p256_t1");
+            launch_t1(s, W, items);
+        }
+        {
+            Scope t(c, "p256_normalize");
+            launch_p256_normalize(s, W.T1proj, items, W.T1x, W.T1y, W.st, 1, ZK_E_T1_INF, W.item_proof);
+        }
+        {
+            Scope t(c, "scalars");
+            launch_padd_scalars(s, P, W, items);
+        }
+        {
+            Scope t(c, "tom_commit");
+            launch_tom_commit(s, P, W.lb, items * LB_COMMITS, LB_COMMITS, LB_SLOTS);
+        }
+        {
+            Scope t(c, "tom_normalize");
+            launch_tom_normalize(s, W.lb, items * LB_COMMITS, 0, LB_COMMITS, LB_SLOTS);
+        }
+        {
+            Scope t(c, "tom_derived");
+            launch_padd_derived(s, W, items);
+            launch_tom_normalize(s, W.lb, items * 5, LB_COMMITS, 5, LB_SLOTS);
+        }
+        {
+            Scope t(c, "hash");
+            launch_padd_hash(s, P, W, items);
+        }
+        {
+            Scope t(c, "respond_write");
+            launch_padd_respond(s, W, items, out);
+            launch_write_padd_points(s, W, items, out);
+            launch_write_fixed(s, W, cnt, out);
+        }
+        {
+            Scope t(c, "gk_fold");
+            launch_gk_scalars_fold(s, W, in, c->gk_am);
+            launch_gk_cd_scalars(s, W, cnt);
+        }
+        {
+            Scope t(c, "tom_commit");
+            launch_tom_commit(s, P, W.lc, cnt * 4 * W.n, 1, 1);
+        }
+        {
+            Scope t(c, "tom_normalize");
+            launch_tom_normalize(s, W.lc, cnt * 4 * W.n, 0, 1, 1);
+        }
+        {
+            Scope t(c, "hash");
+            launch_gk_hash(s, W, cnt);
+        }
+        {
+            Scope t(c, "respond_write");
+            launch_gk_respond(s, W, in, out);
+            launch_status_out(s, W, cnt, d_status, first);
+        }
+        cursor += (uint64_t)totals[2] | ((uint64_t)totals[3] << 32);
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipGetLastError());
+    timing_end(c);
+    return ZK_OK;
+}
+
+extern "C" zk_status zk_prove_batch_device(zk_ctx* c, uint64_t B, const void* d_msg, const void* d_sig, const void* d_pk, const void* d_which,
+                                           const zk_rng* rng, void* d_out, uint64_t out_cap, void* d_out_off, void* d_status) {
+    if (!c || !rng || (B && (!d_msg || !d_sig || !d_pk || !d_which || !rng->data || !d_out)) || !d_out_off || !d_status) return ZK_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    return prove_device(c, B, (const uint8_t*)d_msg, (const uint8_t*)d_sig, (const uint8_t*)d_pk, (const uint32_t*)d_which, rng->mode, rng->data,
+                        rng->stride_blocks, (uint8_t*)d_out, out_cap, (uint64_t*)d_out_off, (int32_t*)d_status);
+}
+
+extern "C" zk_status zk_prove_batch(zk_ctx* c, uint64_t B, const uint8_t* msg, const uint8_t* sig, const uint8_t* pk, const uint32_t* which,
+                                    const zk_rng* rng, uint8_t* out, uint64_t out_cap, uint64_t* out_off, int32_t* status) {
+    if (!c || !rng || !out_off || !status || (B && (!msg || !sig || !pk || !which || !rng->data || !out))) return ZK_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->params_set || !c->N) return ZK_E_BUFFER;
+    size_t rng_bytes = rng->mode == ZK_RNG_SEED ? 32 * B : 32 * B * rng->stride_blocks;
+    uint8_t *d_msg = nullptr, *d_sig = nullptr, *d_pk = nullptr, *d_rng = nullptr, *d_out = nullptr;
+    uint32_t* d_which = nullptr;
+    uint64_t* d_off = nullptr;
+    int32_t* d_st = nullptr;
+    size_t bb = B ? B : 1;
+    uint64_t cap_dev = std::min<uint64_t>(out_cap, zk_proof_max_size(c) * bb);
+    HIPCHK(c, hipMalloc(&d_msg, 32 * bb));
+    HIPCHK(c, hipMalloc(&d_sig, 64 * bb));
+    HIPCHK(c, hipMalloc(&d_pk, 64 * bb));
+    HIPCHK(c, hipMalloc(&d_which, 4 * bb));
+    HIPCHK(c, hipMalloc(&d_rng, rng_bytes ? rng_bytes : 32));
+    HIPCHK(c, hipMalloc(&d_out, cap_dev ? cap_dev : 32));
+    HIPCHK(c, hipMalloc(&d_off, 8 * (bb + 1)));
+    HIPCHK(c, hipMalloc(&d_st, 4 * bb));
+    if (B) {
+        HIPCHK(c, hipMemcpy(d_msg, msg, 32 * B, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(d_sig, sig, 64 * B, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(d_pk, pk, 64 * B, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(d_which, which, 4 * B, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(d_rng, rng->data, rng_bytes, hipMemcpyHostToDevice));
+    }
+    zk_status zs = prove_device(c, B, d_msg, d_sig, d_pk, d_which, rng->mode, d_rng, rng->stride_blocks, d_out, cap_dev, d_off, d_st);
+    if (zs == ZK_OK) {
+        HIPCHK(c, hipMemcpy(out_off, d_off, 8 * (B + 1), hipMemcpyDeviceToHost));
+        if (B) HIPCHK(c, hipMemcpy(status, d_st, 4 * B, hipMemcpyDeviceToHost));
+        if (out_off[B]) HIPCHK(c, hipMemcpy(out, d_out, out_off[B], hipMemcpyDeviceToHost));
+    }
+    hipFree(d_msg), hipFree(d_sig), hipFree(d_pk), hipFree(d_which), hipFree(d_rng), hipFree(d_out), hipFree(d_off), hipFree(d_st);
+    return zs;
+}
+
+extern "C" zk_status zk_verify_batch_device(zk_ctx* c, uint64_t, const void*, const void*, const void*, void*, void*) {
+    if (!c) return ZK_E_ARG;
+    c->err = "verifySignatureList is not on the GPU yet in this build (round 1 ships the prover); use the oracle to check proofs";
+    return ZK_E_DEVICE;
+}
+extern "C" zk_status zk_verify_batch(zk_ctx* c, uint64_t, const uint8_t*, const uint8_t*, const uint64_t*, uint8_t*, int32_t*) {
+    return zk_verify_batch_device(c, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" uint32_t zk_last_timing(const zk_ctx* c, float* total_ms, const char** names, float* ms, uint32_t cap) {
+    if (!c) return 0;
+    if (total_ms) *total_ms = c->last_total_ms;
+    uint32_t n = (uint32_t)c->last_timing.size();
+    for (uint32_t i = 0; i < n && i < cap; i++) {
+        if (names) names[i] = c->last_timing[i].first;
+        if (ms) ms[i] = c->last_timing[i].second;
+    }
+    return n;
+}
+
+// ------------------------------------------------------------------ synthetic workload
+extern "C" zk_status zk_synth_workload(zk_ctx* c, uint64_t seed, uint64_t nkeys, uint64_t B, uint8_t* ring, uint8_t* msg, uint8_t* sig, uint8_t* pk,
+                                       uint32_t* which, uint8_t* seeds) {
+    if (!c || !ring || nkeys < 1 || (B && (!msg || !sig || !pk || !which || !seeds))) return ZK_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint8_t *d_ring, *d_msg, *d_sig, *d_pk, *d_seeds;
+    uint32_t* d_which;
+    size_t bb = B ? B : 1;
+    HIPCHK(c, hipMalloc(&d_ring, 32 * nkeys));
+    HIPCHK(c, hipMalloc(&d_msg, 32 * bb));
+    HIPCHK(c, hipMalloc(&d_sig, 64 * bb));
+    HIPCHK(c, hipMalloc(&d_pk, 64 * bb));
+    HIPCHK(c, hipMalloc(&d_which, 4 * bb));
+    HIPCHK(c, hipMalloc(&d_seeds, 32 * bb));
+    launch_synth(c->stream, c->P.pfix_G, seed, nkeys, B, d_ring, d_msg, d_sig, d_pk, d_which, d_seeds);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(ring, d_ring, 32 * nkeys, hipMemcpyDeviceToHost));
+    if (B) {
+        HIPCHK(c, hipMemcpy(msg, d_msg, 32 * B, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(sig, d_sig, 64 * B, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(pk, d_pk, 64 * B, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(which, d_which, 4 * B, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(seeds, d_seeds, 32 * B, hipMemcpyDeviceToHost));
+    }
+    hipFree(d_ring), hipFree(d_msg), hipFree(d_sig), hipFree(d_pk), hipFree(d_which), hipFree(d_seeds);
+    return ZK_OK;
+}
+
+static zk_status tom_commit_generic(zk_ctx* c, const uint32_t* tab_g, const uint32_t* tab_h, uint64_t count, const uint8_t* d_v, const uint8_t* d_r, uint8_t* d_out) {
+    // temporary list
+    TomList L;
+    void* mem;
+    size_t per = 36 * 7;
+    HIPCHK(c, hipMalloc(&mem, per * count + 4096));
+    Carver k((uint8_t*)mem);
+    L = k.list(count);
+    launch_bytes_to_scalars(c->stream, d_v, count, L.v);
+    launch_bytes_to_scalars(c->stream, d_r, count, L.r);
+    DevParams P = c->P;
+    P.tom_tab_g = (uint32_t*)tab_g, P.tom_tab_h = (uint32_t*)tab_h;
+    launch_tom_commit(c->stream, P, L, (uint32_t)count, 1, 1);
+    launch_tom_normalize(c->stream, L, (uint32_t)count, 0, 1, 1);
+    launch_affine_to_bytes(c->stream, L.ax, L.ay, count, 1, d_out);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(mem));
+    return ZK_OK;
+}
+extern "C" zk_status zk_synth_params(zk_ctx* c, uint64_t seed, uint8_t nist_h[64], uint8_t tom_g[72], uint8_t tom_h[72]) {
+    if (!c || !nist_h || !tom_g || !tom_h) return ZK_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint8_t* d;
+    HIPCHK(c, hipMalloc(&d, 512));
+    HIPCHK(c, hipMemsetAsync(d, 0, 512, c->stream));
+    launch_synth_param_scalars(c->stream, seed, d, d + 32);  // kn, kt (big-endian); d+64: zero scalar
+    launch_test_pfix(c->stream, c->P.pfix_G, 1, d, d + 128);
+    zk_status zs = tom_commit_generic(c, c->tom_tab_gen, c->tom_tab_gen, 1, d + 32, d + 64, d + 256);
+    if (zs) return zs;
+    HIPCHK(c, hipMemcpy(nist_h, d + 128, 64, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(tom_h, d + 256, 72, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipFree(d));
+    uint32_t gw[18];
+    memcpy(gw, TOM_GX_W, 36), memcpy(gw + 9, TOM_GY_W, 36);
+    for (int k = 0; k < 2; k++)
+        for (int i = 0; i < 36; i++) tom_g[36 * k + i] = (uint8_t)(gw[9 * k + (35 - i) / 4] >> (8 * ((35 - i) % 4)));
+    return ZK_OK;
+}
+
+// ------------------------------------------------------------------ unit-test hooks
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { hipFree(p); }
+};
+extern "C" zk_status zk_test_field_op(zk_ctx* c, int which, int op, uint64_t count, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    if (!c || !a || !b || !out || which < 0 || which > 2 || op < 0 || op > 3) return ZK_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf da, db, dout;
+    HIPCHK(c, hipMalloc(&da.p, 40 * count)); HIPCHK(c, hipMalloc(&db.p, 40 * count)); HIPCHK(c, hipMalloc(&dout.p, 40 * count));
+    HIPCHK(c, hipMemcpy(da.p, a, 40 * count, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(db.p, b, 40 * count, hipMemcpyHostToDevice));
+    launch_test_field(c->stream, which, op, count, (uint8_t*)da.p, (uint8_t*)db.p, (uint8_t*)dout.p);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, dout.p, 40 * count, hipMemcpyDeviceToHost));
+    return ZK_OK;
+}
+extern "C" zk_status zk_test_tom_commit(zk_ctx* c, uint64_t count, const uint8_t* v, const uint8_t* r, uint8_t* out) {
+    if (!c || !v || !r || !out || !count) return ZK_E_ARG;
+    if (!c->params_set) return ZK_E_BUFFER;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf dv, dr, dout;
+    HIPCHK(c, hipMalloc(&dv.p, 32 * count)); HIPCHK(c, hipMalloc(&dr.p, 32 * count)); HIPCHK(c, hipMalloc(&dout.p, 72 * count));
+    HIPCHK(c, hipMemcpy(dv.p, v, 32 * count, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dr.p, r, 32 * count, hipMemcpyHostToDevice));
+    zk_status zs = tom_commit_generic(c, c->P.tom_tab_g, c->P.tom_tab_h, count, (uint8_t*)dv.p, (uint8_t*)dr.p, (uint8_t*)dout.p);
+    if (zs) return zs;
+    HIPCHK(c, hipMemcpy(out, dout.p, 72 * count, hipMemcpyDeviceToHost));
+    return ZK_OK;
+}
+extern "C" zk_status zk_test_p256_fixed_mul(zk_ctx* c, int base_sel, uint64_t count, const uint8_t* k, uint8_t* out) {
+    if (!c || !k || !out || !count || base_sel < 0 || base_sel > 1) return ZK_E_ARG;
+    if (base_sel == 1 && !c->params_set) return ZK_E_BUFFER;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf dk, dout;
+    HIPCHK(c, hipMalloc(&dk.p, 32 * count)); HIPCHK(c, hipMalloc(&dout.p, 64 * count));
+    HIPCHK(c, hipMemcpy(dk.p, k, 32 * count, hipMemcpyHostToDevice));
+    launch_test_pfix(c->stream, base_sel ? c->P.pfix_H : c->P.pfix_G, count, (uint8_t*)dk.p, (uint8_t*)dout.p);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, dout.p, 64 * count, hipMemcpyDeviceToHost));
+    return ZK_OK;
+}
+extern "C" zk_status zk_test_sha256(zk_ctx* c, uint64_t count, uint64_t len, const uint8_t* msgs, uint8_t* digests) {
+    if (!c || !digests || !count || (len && !msgs)) return ZK_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf dm, dd;
+    HIPCHK(c, hipMalloc(&dm.p, count * len + 4)); HIPCHK(c, hipMalloc(&dd.p, 32 * count));
+    if (len) HIPCHK(c, hipMemcpy(dm.p, msgs, count * len, hipMemcpyHostToDevice));
+    launch_test_sha256(c->stream, count, len, (uint8_t*)dm.p, (uint8_t*)dd.p);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(digests, dd.p, 32 * count, hipMemcpyDeviceToHost));
+    return ZK_OK;
+}
+extern "C" zk_status zk_test_rng_draws(zk_ctx* c, uint64_t B, const zk_rng* rng, uint32_t first_k, uint32_t n_k, uint8_t* out) {
+    if (!c || !rng || !rng->data || !out || !B || !n_k) return ZK_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t sec = c->params_set ? c->P.sec : 80;
+    size_t rng_bytes = rng->mode == ZK_RNG_SEED ? 32 * B : 32 * B * rng->stride_blocks;
+    DevBuf dr, dout, dexc;
+    HIPCHK(c, hipMalloc(&dr.p, rng_bytes)); HIPCHK(c, hipMalloc(&dout.p, 32 * B * n_k)); HIPCHK(c, hipMalloc(&dexc.p, 4 * B * (2 * RNG_MAX_EXC + 1)));
+    HIPCHK(c, hipMemcpy(dr.p, rng->data, rng_bytes, hipMemcpyHostToDevice));
+    Workspace W{};
+    W.sec = sec;
+    W.rng.seeds = (uint8_t*)dr.p, W.rng.stream = (uint8_t*)dr.p, W.rng.stride_blocks = rng->stride_blocks, W.rng.mode = rng->mode, W.rng.sec = (int)sec;
+    W.rng.exc_idx = (uint32_t*)dexc.p, W.rng.exc_flags = W.rng.exc_idx + RNG_MAX_EXC * B, W.rng.exc_cnt = W.rng.exc_flags + RNG_MAX_EXC * B;
+    W.rng.proof_base = 0;
+    launch_rng_prepass(c->stream, W, (uint32_t)B, first_k + n_k + RNG_MAX_EXC);
+    launch_test_rng(c->stream, W.rng, B, first_k, n_k, (uint8_t*)dout.p);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, dout.p, 32 * B * n_k, hipMemcpyDeviceToHost));
+    return ZK_OK;
+}

@@ -1,0 +1,240 @@
+// Point arithmetic on the two groups of the hot path, one point per lane (gfx950).
+//   * P-256 (src/curves/weier.ts): projective (X:Y:Z), a = -3, Renes-Costello-Batina COMPLETE addition and
+//     doubling -- the same step sequences the reference uses (weier.ts:133-230), so identity / P = Q inputs behave
+//     exactly as in the reference.
+//   * Tom-256 (src/curves/edwards.ts): twisted Edwards a*x^2 + y^2 = 1 + d*x^2*y^2 in extended coordinates.  The
+//     engine works on the isomorphic curve x'^2 + y^2 = 1 + (d/a) x'^2 y^2 (x' = sqrt(a) x), whose unified
+//     Hisil-Wong-Carter-Dawson addition (edwards.ts:161-183 with a = 1) needs no multiplication by a.  a is a
+//     square and d/a a non-square mod t (checked in tools/gen_consts.py), so the law is complete.  Only affine
+//     coordinates of the original curve ever leave the engine (hash inputs, proof bytes).
+#pragma once
+#include "field.h"
+
+typedef Fe<ModQ, 8> Fq8;  // P-256 coordinate: < 8q
+typedef Fe<ModQ, 2> Fq2;
+typedef Fe<ModT, 2> Ft2;  // Tom coordinate: < 2t
+typedef Fe<ModN, 2> Fn2;
+
+struct P256Pt {
+    Fq8 x, y, z;
+};
+struct P256Aff {  // Montgomery affine, canonical not required
+    Fq2 x, y;
+};
+ZK_DEV P256Pt p256_identity() {  // weier.ts:50-52
+    P256Pt r;
+    r.x = fe_zero<ModQ>().as<8>();
+    r.y = fe_one_mont<ModQ>().as<8>();
+    r.z = fe_zero<ModQ>().as<8>();
+    return r;
+}
+ZK_DEV P256Pt p256_from_affine(const P256Aff& a) {
+    P256Pt r;
+    r.x = a.x.as<8>();
+    r.y = a.y.as<8>();
+    r.z = fe_one_mont<ModQ>().as<8>();
+    return r;
+}
+// weier.ts:176-230 (RCB 2016, Algorithm 4, a = -3): 12M + 2 mult-by-b
+ZK_DEV P256Pt p256_add(const P256Pt& p, const P256Pt& q) {
+    const auto b = fe_const<ModQ, 1>(P256_B_M);
+    auto t0 = p.x * q.x;
+    auto t1 = p.y * q.y;
+    auto t2 = p.z * q.z;
+    auto t3 = (p.x + p.y) * (q.x + q.y);
+    auto t3b = t3 - (t0 + t1);
+    auto t4 = (p.y + p.z) * (q.y + q.z);
+    auto t4b = t4 - (t1 + t2);
+    auto x3 = (p.x + p.z) * (q.x + q.z);
+    auto y3 = x3 - (t0 + t2);
+    auto z3 = b * t2;
+    auto x3b = y3 - z3;
+    auto x3c = x3b + (x3b + x3b);
+    auto z3b = t1 - x3c;
+    auto x3d = t1 + x3c;
+    auto y3b = b * y3;
+    auto t2b = t2 + t2 + t2;
+    auto y3c = (y3b - t2b) - t0;
+    auto y3d = y3c + (y3c + y3c);
+    auto t0b = (t0 + t0 + t0) - t2b;
+    auto t1b = t4b * y3d;
+    auto t2c = t0b * y3d;
+    auto y3e = x3d * z3b + t2c;
+    auto x3e = t3b * x3d - t1b;
+    auto z3c = t4b * z3b + t3b * t0b;
+    P256Pt r;
+    r.x = x3e.template as<8>();
+    r.y = y3e.template as<8>();
+    r.z = z3c.template as<8>();
+    return r;
+}
+// Same law with q affine (Z2 = 1): RCB Algorithm 5 shape, 11M + 2 mult-by-b.  q must not be the identity.
+ZK_DEV P256Pt p256_add_mixed(const P256Pt& p, const P256Aff& q) {
+    const auto b = fe_const<ModQ, 1>(P256_B_M);
+    auto t0 = p.x * q.x;
+    auto t1 = p.y * q.y;
+    auto t3 = (p.x + p.y) * (q.x + q.y);
+    auto t3b = t3 - (t0 + t1);
+    auto t4b = q.y * p.z + p.y;   // (y1+z1)(y2+1) - t1 - z1
+    auto y3 = q.x * p.z + p.x;    // (x1+z1)(x2+1) - t0 - z1
+    auto z3 = b * p.z;
+    auto x3b = y3 - z3;
+    auto x3c = x3b + (x3b + x3b);
+    auto z3b = t1 - x3c;
+    auto x3d = t1 + x3c;
+    auto y3b = b * y3;
+    auto t2b = p.z + p.z + p.z;
+    auto y3c = (y3b - t2b) - t0;
+    auto y3d = y3c + (y3c + y3c);
+    auto t0b = (t0 + t0 + t0) - t2b;
+    auto t1b = t4b * y3d;
+    auto t2c = t0b * y3d;
+    auto y3e = x3d * z3b + t2c;
+    auto x3e = t3b * x3d - t1b;
+    auto z3c = t4b * z3b + t3b * t0b;
+    P256Pt r;
+    r.x = x3e.template as<8>();
+    r.y = y3e.template as<8>();
+    r.z = z3c.template as<8>();
+    return r;
+}
+// weier.ts:133-175 (RCB Algorithm 6, a = -3): 8M + 3S incl. 2 mult-by-b
+ZK_DEV P256Pt p256_dbl(const P256Pt& p) {
+    const auto b = fe_const<ModQ, 1>(P256_B_M);
+    auto t0 = p.x * p.x;
+    auto t1 = p.y * p.y;
+    auto t2 = p.z * p.z;
+    auto t3 = p.x * p.y;
+    auto t3b = t3 + t3;
+    auto z3 = p.x * p.z;
+    auto z3b = z3 + z3;
+    auto y3 = b * t2 - z3b;
+    auto y3b = y3 + (y3 + y3);
+    auto x3 = t1 - y3b;
+    auto y3c = t1 + y3b;
+    auto y3d = x3 * y3c;
+    auto x3b = x3 * t3b;
+    auto t2b = t2 + t2 + t2;
+    auto z3c = (b * z3b - t2b) - t0;
+    auto z3d = z3c + (z3c + z3c);
+    auto t0b = (t0 + t0 + t0) - t2b;
+    auto y3e = y3d + t0b * z3d;
+    auto t0c = p.y * p.z;
+    auto t0d = t0c + t0c;
+    auto x3c = x3b - t0d * z3d;
+    auto z3e = t0d * t1;
+    auto z3f = (z3e + z3e) + (z3e + z3e);
+    P256Pt r;
+    r.x = x3c.template as<8>();
+    r.y = y3e.template as<8>();
+    r.z = z3f.template as<8>();
+    return r;
+}
+ZK_DEV P256Pt p256_select(bool c, const P256Pt& a, const P256Pt& b) {
+    P256Pt r;
+    r.x = fe_select(c, a.x, b.x);
+    r.y = fe_select(c, a.y, b.y);
+    r.z = fe_select(c, a.z, b.z);
+    return r;
+}
+// y^2 == x^3 - 3x + b  (weier.ts:56-70 with Z = 1)
+ZK_DEV bool p256_on_curve(const P256Aff& a) {
+    const auto b = fe_const<ModQ, 1>(P256_B_M);
+    auto y2 = a.y * a.y;
+    auto x2 = a.x * a.x;
+    auto x3 = x2 * a.x;
+    auto rhs = (x3 + b) - (a.x + a.x + a.x);
+    return fe_eq(y2, rhs);
+}
+
+// ---------------------------------------------------------------- Tom-256 on the a = 1 image
+struct TomPt {  // extended (X:Y:T:Z), Montgomery
+    Ft2 x, y, t, z;
+};
+struct TomNiels {  // affine precomputed: x, y, (d/a)*x*y
+    Ft2 x, y, dt;
+};
+ZK_DEV TomPt tom_identity() {  // edwards.ts:46-48
+    TomPt r;
+    r.x = fe_zero<ModT>().as<2>();
+    r.y = fe_one_mont<ModT>().as<2>();
+    r.t = fe_zero<ModT>().as<2>();
+    r.z = fe_one_mont<ModT>().as<2>();
+    return r;
+}
+// edwards.ts:161-183 with a = 1 and Z2 = 1, d*T2 precomputed: 8M
+ZK_DEV TomPt tom_add_niels(const TomPt& p, const TomNiels& q) {
+    auto A = p.x * q.x;
+    auto B = p.y * q.y;
+    auto C = p.t * q.dt;
+    auto E = ((p.x + p.y) * (q.x + q.y) - A) - B;
+    auto F = p.z - C;
+    auto G = p.z + C;
+    auto H = B - A;
+    TomPt r;
+    r.x = E * F;
+    r.y = G * H;
+    r.t = E * H;
+    r.z = F * G;
+    return r;
+}
+// general unified addition (both extended): 9M + 1 mult-by-d'
+ZK_DEV TomPt tom_add(const TomPt& p, const TomPt& q) {
+    const auto d1 = fe_const<ModT, 1>(TOM_D1_M);
+    auto A = p.x * q.x;
+    auto B = p.y * q.y;
+    auto C = (p.t * q.t) * d1;
+    auto D = p.z * q.z;
+    auto E = ((p.x + p.y) * (q.x + q.y) - A) - B;
+    auto F = D - C;
+    auto G = D + C;
+    auto H = B - A;
+    TomPt r;
+    r.x = E * F;
+    r.y = G * H;
+    r.t = E * H;
+    r.z = F * G;
+    return r;
+}
+// edwards.ts:141-160 with a = 1: 4S + 4M
+ZK_DEV TomPt tom_dbl(const TomPt& p) {
+    auto A = p.x * p.x;
+    auto B = p.y * p.y;
+    auto Cz = p.z * p.z;
+    auto C = Cz + Cz;
+    auto xy = p.x + p.y;
+    auto E = (xy * xy - A) - B;
+    auto G = A + B;
+    auto F = G - C;
+    auto H = A - B;
+    TomPt r;
+    r.x = E * F;
+    r.y = G * H;
+    r.t = E * H;
+    r.z = F * G;
+    return r;
+}
+ZK_DEV TomPt tom_neg(const TomPt& p) {  // edwards.ts:136-140
+    TomPt r;
+    r.x = fe_reduce(fe_neg(p.x));
+    r.y = p.y;
+    r.t = fe_reduce(fe_neg(p.t));
+    r.z = p.z;
+    return r;
+}
+// original-curve affine (plain 9-word x, y) -> a=1 image, extended Montgomery.  Returns false if a coordinate is
+// >= t (edwards.ts:74-77) or the point is off the curve a*x^2 + y^2 = 1 + d*x^2*y^2 (edwards.ts:52-65).
+ZK_DEV bool tom_from_affine_words(TomPt& r, const uint32_t xw[9], const uint32_t yw[9]) {
+    if (words_geq<9>(xw, ModT::mod32) || words_geq<9>(yw, ModT::mod32)) return false;
+    auto x = fe_to_mont(fe_from_words<ModT, 9>(xw));
+    auto y = fe_to_mont(fe_from_words<ModT, 9>(yw));
+    auto x2 = x * x, y2 = y * y;
+    auto lhs = fe_const<ModT, 1>(TOM_A_M) * x2 + y2;
+    auto rhs = fe_const<ModT, 1>(TOM_D_M) * (x2 * y2) + fe_one_mont<ModT>();
+    bool ok = fe_eq(lhs, rhs);
+    r.x = x * fe_const<ModT, 1>(TOM_S_M);
+    r.y = y;
+    r.t = r.x * r.y;
+    r.z = fe_one_mont<ModT>().as<2>();
+    return ok;
+}

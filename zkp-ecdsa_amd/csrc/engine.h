@@ -1,0 +1,215 @@
+// Internal header of libzkattest_hip.so: workspace layout, SoA helpers and the launch wrappers each .hip
+// translation unit exports.  Nothing here is part of the C ABI (include/zkattest.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/zkattest.h"
+#include "curve.h"
+#include "rng.h"
+
+// ------------------------------------------------------------------ SoA views (limb l of element e at p[l*stride+e])
+struct Soa {
+    uint32_t* p;
+    uint32_t stride;
+};
+struct Soa3 {
+    Soa x, y, z;
+};
+template <class M, int K = 2>
+ZK_DEV Fe<M, K> soa_ld(const Soa& a, uint32_t e) {
+    Fe<M, K> r;
+#pragma unroll
+    for (int l = 0; l < NLIMB; l++) r.l[l] = a.p[(size_t)l * a.stride + e];
+    return r;
+}
+template <class M, int K>
+ZK_DEV void soa_st(const Soa& a, uint32_t e, const Fe<M, K>& v) {
+#pragma unroll
+    for (int l = 0; l < NLIMB; l++) a.p[(size_t)l * a.stride + e] = v.l[l];
+}
+
+// ------------------------------------------------------------------ fixed-base tables
+// Tom: 8-bit windows, 32 windows x 256 digits, entry = niels (x, y, d'*x*y) Montgomery limbs, 28 words (112 B).
+#define TOM_WIN_BITS 8
+#define TOM_NWIN 32
+#define TOM_ENTRY_WORDS 28
+#define TOM_TAB_WORDS (TOM_NWIN * 256 * TOM_ENTRY_WORDS)
+// P-256 fixed bases (G, h_NIST): 8-bit windows, entry = affine (x, y) Montgomery limbs, 20 words (80 B); digit 0 unused.
+#define PFIX_NWIN 32
+#define PFIX_ENTRY_WORDS 20
+#define PFIX_TAB_WORDS (PFIX_NWIN * 256 * PFIX_ENTRY_WORDS)
+// per-proof table of R: 4-bit windows, 64 windows x 16 digits, entry = projective (X, Y, Z), 28 words.
+#define RTAB_NWIN 64
+#define RTAB_ENTRY_WORDS 28
+#define RTAB_WORDS (RTAB_NWIN * 16 * RTAB_ENTRY_WORDS)
+
+// ------------------------------------------------------------------ ZKA1 layout constants (bytes)
+#define ZK_PB 32
+#define ZK_TB 36
+#define ZK_HDR 32
+#define ZK_FIXED (ZK_HDR + 2 * 64 + 2 * 72)  // header, R, comS1, keyXcom, keyYcom = 304
+#define ZK_REP_HEAD (64 + 72 + 72 + 4 * 32)    // 336
+#define ZK_MULT_SZ (6 * 72 + 7 * 32)            // 656
+#define ZK_EQ_SZ (2 * 72 + 3 * 32)              // 240
+#define ZK_PADD_SZ (4 * 72 + 4 * ZK_MULT_SZ + 2 * ZK_EQ_SZ)  // 3392
+#define ZK_MAXSEC 128
+#define ZK_MAXN 32
+
+// list A: per proof 2 + 2*sec Tom commitments (pkX, pkY, Tx_i, Ty_i);  list B: per zero-bit rep 39 points
+#define LB_SLOTS 39
+#define LB_COMMITS 34
+
+struct TomList {   // a list of Pedersen commitments to compute: (v, r) -> projective -> affine (original curve)
+    Soa v, r;      // plain canonical scalars mod q
+    Soa3 proj;     // a=1 image, Montgomery (X, Y, Z)
+    Soa ax, ay;    // affine, original curve, plain canonical
+    uint32_t cap;
+};
+
+struct DevParams {            // device-resident, built by zk_ctx_set_params
+    uint32_t* tom_tab_g;      // TOM_TAB_WORDS
+    uint32_t* tom_tab_h;
+    uint32_t* pfix_G;         // PFIX_TAB_WORDS
+    uint32_t* pfix_H;
+    uint32_t tom_g_aff[18];   // original-curve affine plain limbs of g (x, y) -- C_14 in pointAdd.ts:144
+    uint32_t sec;
+};
+
+struct Workspace {
+    uint32_t C;        // proofs per chunk
+    uint32_t sec, n;   // secLevel, log2 ring
+    uint32_t items_cap;
+    // per proof
+    int32_t* st;                 // [C] status
+    Soa pkx, pky;                // plain canonical mod q (affine pk)
+    Soa pkxm, pkym;              // Montgomery
+    Soa Rxm, Rym;                // R affine Montgomery
+    Soa Rx, Ry;                  // R affine plain
+    Soa3 Q;                      // projective Montgomery
+    Soa s1;                      // plain mod n
+    uint32_t* rtab;              // [C][RTAB_WORDS]
+    Soa3 rbase;                  // [C*64] 2^(4w) R, projective
+    uint32_t* chal;              // [C][4] challenge words (80 bits in words 0..2)
+    uint32_t* zcnt;              // [C]
+    uint32_t* item_base;         // [C+1]
+    uint64_t* out_base;          // [C+1] byte offsets inside this chunk's output region
+    // exp commit: index proof*(sec+1)+j ; j = sec is comS1
+    Soa3 Tproj, Aproj;
+    Soa Tx, Ty, Ax, Ay;          // affine plain
+    // items
+    uint32_t* item_proof;        // [items_cap]
+    uint32_t* item_rep;
+    uint32_t* item_rank;
+    Soa3 T1proj;
+    Soa T1x, T1y;
+    uint32_t* padd_c;            // [items_cap][6][3] challenges of pi8, pi10, pi11, pix, pi13, piy
+    TomList la, lb, lc;
+    // GK
+    uint32_t* gk_x;              // [C][3]
+    Soa gk_coef;                 // [(n+1)*C] final polynomial coefficients, index k*C + proof
+    uint32_t gk_group;           // proofs per fold pass
+    uint32_t* gk_bufA;           // ping-pong level buffers
+    uint32_t* gk_bufB;
+    Soa ring;                    // [N] plain canonical limbs (shared, owned by ctx)
+    uint32_t N;
+    RngCtx rng;
+};
+
+// chunk inputs (device pointers, already offset to the chunk's first proof)
+struct ChunkIn {
+    const uint8_t* msg;
+    const uint8_t* sig;
+    const uint8_t* pk;
+    const uint32_t* which;
+    uint32_t count;   // proofs in this chunk
+};
+
+// ------------------------------------------------------------------ launch wrappers (one per kernel family)
+// k_tables.hip
+void launch_build_tom_table(hipStream_t s, const uint32_t* aff_xy_words /*18 words on device*/, uint32_t* tab, uint32_t* scratch, int32_t* ok);
+void launch_build_pfix_table(hipStream_t s, const uint32_t* aff_xy_words /*16 words on device, or nullptr for G*/, uint32_t* tab, uint32_t* scratch, int32_t* ok);
+size_t table_scratch_words();
+// k_tom.hip
+void launch_tom_commit(hipStream_t s, const DevParams& P, const TomList& L, uint32_t count, uint32_t per_group, uint32_t slots_per_group);
+void launch_tom_normalize(hipStream_t s, const TomList& L, uint32_t count, uint32_t first, uint32_t per_group, uint32_t slots_per_group);
+void launch_padd_derived(hipStream_t s, const Workspace& W, uint32_t items);
+// k_p256.hip
+void launch_front(hipStream_t s, const DevParams& P, const Workspace& W, const ChunkIn& in);
+void launch_rtab(hipStream_t s, const Workspace& W, uint32_t count);
+void launch_exp_commit(hipStream_t s, const DevParams& P, const Workspace& W, uint32_t count);
+void launch_p256_normalize(hipStream_t s, const Soa3& proj, uint32_t count, const Soa& ox, const Soa& oy, int32_t* st, uint32_t per_proof, int32_t err_code, const uint32_t* owner /*nullable: item->proof*/);
+void launch_t1(hipStream_t s, const Workspace& W, uint32_t items);
+void launch_test_pfix(hipStream_t s, const uint32_t* tab, uint64_t count, const uint8_t* k_be, uint8_t* out);
+// k_hash.hip
+void launch_rng_prepass(hipStream_t s, const Workspace& W, uint32_t count, uint32_t nblk);
+void launch_exp_challenge(hipStream_t s, const Workspace& W, uint32_t count);
+void launch_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, uint32_t items);
+void launch_gk_hash(hipStream_t s, const Workspace& W, uint32_t count);
+void launch_test_sha256(hipStream_t s, uint64_t count, uint64_t len, const uint8_t* d_msgs, uint8_t* d_out);
+void launch_test_rng(hipStream_t s, const RngCtx& g, uint64_t B, uint32_t first_k, uint32_t n_k, uint8_t* d_out);
+// k_scalar.hip
+void launch_lista_scalars(hipStream_t s, const Workspace& W, uint32_t count);
+void launch_scan(hipStream_t s, const Workspace& W, uint32_t count, uint64_t cursor, uint64_t out_cap, uint64_t* d_out_off, int32_t* d_status_out,
+                 uint32_t* d_totals /*[4]: items, overflow, bytes lo, bytes hi*/, uint64_t first_proof);
+void launch_status_out(hipStream_t s, const Workspace& W, uint32_t count, int32_t* d_status_out, uint64_t first_proof);
+void launch_items(hipStream_t s, const Workspace& W, uint32_t count);
+void launch_padd_scalars(hipStream_t s, const DevParams& P, const Workspace& W, uint32_t items);
+void launch_padd_respond(hipStream_t s, const Workspace& W, uint32_t items, uint8_t* out);
+void launch_write_fixed(hipStream_t s, const Workspace& W, uint32_t count, uint8_t* out);
+void launch_write_padd_points(hipStream_t s, const Workspace& W, uint32_t items, uint8_t* out);
+void launch_gk_scalars_fold(hipStream_t s, const Workspace& W, const ChunkIn& in, const Soa& am /*[n*C] a_j, Montgomery*/);
+void launch_gk_cd_scalars(hipStream_t s, const Workspace& W, uint32_t count);
+void launch_gk_respond(hipStream_t s, const Workspace& W, const ChunkIn& in, uint8_t* out);
+void launch_test_field(hipStream_t s, int which, int op, uint64_t count, const uint8_t* a, const uint8_t* b, uint8_t* out);
+void launch_ring_load(hipStream_t s, const uint8_t* d_keys_be32, uint64_t nkeys, uint64_t N, const Soa& ring);
+void launch_bytes_to_scalars(hipStream_t s, const uint8_t* d_be32, uint64_t count, const Soa& out);
+void launch_affine_to_bytes(hipStream_t s, const Soa& ax, const Soa& ay, uint64_t count, int tom, uint8_t* d_out);
+
+// ------------------------------------------------------------------ small device helpers shared by TUs
+ZK_DEV uint32_t gtid() { return blockIdx.x * blockDim.x + threadIdx.x; }
+// big-endian load of a 32-byte integer into 8 little-endian words
+ZK_DEV void load_be32(const uint8_t* p, uint32_t w[8]) {
+    const uint32_t* q = (const uint32_t*)p;
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = bswap32(q[7 - i]);
+}
+// store NW little-endian words as a big-endian byte string (4-byte aligned destination)
+template <int NW>
+ZK_DEV void store_be(uint8_t* p, const uint32_t w[NW]) {
+    uint32_t* q = (uint32_t*)p;
+#pragma unroll
+    for (int i = 0; i < NW; i++) q[i] = bswap32(w[NW - 1 - i]);
+}
+template <class M>
+ZK_DEV void store_scalar_be(uint8_t* p, const Fe<M, 1>& a) {  // canonical plain -> 32 bytes
+    uint32_t w[8];
+    words_from_limbs<8>(w, a.l);
+    store_be<8>(p, w);
+}
+ZK_DEV void store_tomcoord_be(uint8_t* p, const Fe<ModT, 1>& a) {  // canonical plain -> 36 bytes
+    uint32_t w[9];
+    words_from_limbs<9>(w, a.l);
+    store_be<9>(p, w);
+}
+// shift a 256-bit little-endian word array right by SH bits
+template <int SH>
+ZK_DEV void shr256(uint32_t w[8]) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) w[i] = (w[i] >> SH) | (w[i + 1] << (32 - SH));
+    w[7] >>= SH;
+}
+// offset of rep i inside a proof, given the challenge (bit = 1 -> short response)
+ZK_DEV uint32_t zeros_below(const uint32_t* chal, uint32_t i) {  // number of 0 bits among challenge bits [0, i)
+    uint32_t ones = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        uint32_t lo = 32 * w;
+        if (i > lo) {
+            uint32_t nb = i - lo >= 32 ? 32 : i - lo;
+            uint32_t mask = nb == 32 ? 0xffffffffu : ((1u << nb) - 1);
+            ones += __popc(chal[w] & mask);
+        }
+    }
+    return i - ones;
+}
+ZK_DEV uint64_t rep_offset(const uint32_t* chal, uint32_t i) { return ZK_FIXED + (uint64_t)ZK_REP_HEAD * i + (uint64_t)ZK_PADD_SZ * zeros_below(chal, i); }

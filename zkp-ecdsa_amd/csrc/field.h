@@ -1,0 +1,323 @@
+// Device big-number field arithmetic for gfx950 (CDNA4), one field element per lane.
+//
+// Representation: 9 limbs of 30 bits in 32-bit VGPRs ("radix 2^30"), Montgomery domain with R = 2^270, for all
+// three moduli on the hot path (Tom-256 field t [258 bit], P-256 field q = Tom scalar field, P-256 order n).
+// Why 30-bit limbs: measured on MI355X (profiles/r01_valu_peak_microbench.txt) v_mad_u64_u32 issues in ~10
+// cycles/wave and a carry-chained v_add_co/v_addc pair in ~8.7; with 30-bit limbs every column of the product
+// (<= 18 partial products < 2^60) fits ONE 64-bit accumulator, so a Montgomery multiplication is 162
+// v_mad_u64_u32 + 9 v_mul_lo_u32 with no carry flags at all, and additions are plain limb-wise v_add_u32.
+//
+// Magnitudes are tracked in the TYPE: Fe<M, K> holds a normalised value (every limb < 2^30) that is < K*M.
+//   mul : Fe<M,Ka> x Fe<M,Kb> -> Fe<M,2>   (static_assert Ka*Kb <= R/M, so the Montgomery output is < 2M)
+//   add : -> Fe<M,Ka+Kb>;  sub(a,b) = a + C*M - b -> Fe<M,Ka+C>, C the smallest power of two > Kb.
+// so every lazy add/sub chain is bounds-checked at compile time.  These replace every BigInt `%` of the
+// reference (src/bignum/big.ts:36-42 posMod; the `% p` lines of src/curves/weier.ts and edwards.ts).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "consts_gen.h"
+
+#define ZK_DEV __device__ __forceinline__
+#define LIMB_BITS 30
+#define LIMB_MASK 0x3fffffffu
+#define NLIMB 9
+#define KCAP 512  // column-accumulator bound: top limb of a K*M value stays < 2^28
+
+ZK_DEV uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
+
+template <class M, int K = 2>
+struct Fe {
+    uint32_t l[NLIMB];
+    // reinterpret with a looser bound (always safe)
+    template <int K2>
+    ZK_DEV Fe<M, K2> as() const {
+        static_assert(K2 >= K, "cannot tighten a bound by cast");
+        Fe<M, K2> r;
+#pragma unroll
+        for (int i = 0; i < NLIMB; i++) r.l[i] = l[i];
+        return r;
+    }
+};
+
+ZK_DEV void limbs_normalize(uint32_t r[NLIMB]) {
+#pragma unroll
+    for (int i = 0; i < NLIMB - 1; i++) {
+        r[i + 1] += r[i] >> LIMB_BITS;
+        r[i] &= LIMB_MASK;
+    }
+}
+
+template <class M, int Ka, int Kb>
+ZK_DEV Fe<M, Ka + Kb> operator+(const Fe<M, Ka>& a, const Fe<M, Kb>& b) {
+    static_assert(Ka + Kb <= KCAP, "magnitude overflow");
+    Fe<M, Ka + Kb> r;
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) r.l[i] = a.l[i] + b.l[i];
+    limbs_normalize(r.l);
+    return r;
+}
+template <int Kb>
+struct SubC {
+    static constexpr int value = Kb < 4 ? 4 : Kb < 8 ? 8 : Kb < 16 ? 16 : Kb < 32 ? 32 : Kb < 64 ? 64 : Kb < 128 ? 128 : 256;
+    static_assert(Kb < 256, "subtrahend too large");
+};
+template <class M, int Ka, int Kb>
+ZK_DEV Fe<M, Ka + SubC<Kb>::value> operator-(const Fe<M, Ka>& a, const Fe<M, Kb>& b) {
+    constexpr int C = SubC<Kb>::value;
+    static_assert(Ka + C <= KCAP, "magnitude overflow");
+    Fe<M, Ka + C> r;
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) {
+        uint32_t s;
+        if constexpr (C == 4) s = M::sub4[i];
+        else if constexpr (C == 8) s = M::sub8[i];
+        else if constexpr (C == 16) s = M::sub16[i];
+        else if constexpr (C == 32) s = M::sub32[i];
+        else if constexpr (C == 64) s = M::sub64[i];
+        else if constexpr (C == 128) s = M::sub128[i];
+        else s = M::sub256[i];
+        r.l[i] = a.l[i] + s - b.l[i];
+    }
+    limbs_normalize(r.l);
+    return r;
+}
+template <class M, int Ka>
+ZK_DEV Fe<M, SubC<Ka>::value> fe_neg(const Fe<M, Ka>& a) {
+    Fe<M, 0> z;
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) z.l[i] = 0;
+    auto r = z - a;
+    return r;
+}
+template <class M, int Ka>
+ZK_DEV Fe<M, 2 * Ka> fe_dbl(const Fe<M, Ka>& a) {
+    return a + a;
+}
+
+// Montgomery product, product-scanning with a single 64-bit accumulator (no carry flags).
+template <class M>
+ZK_DEV void limbs_mont_mul(uint32_t out[NLIMB], const uint32_t a[NLIMB], const uint32_t b[NLIMB]) {
+    uint64_t acc = 0;
+    uint32_t m[NLIMB];
+#pragma unroll
+    for (int k = 0; k < NLIMB; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc = mad64(a[i], b[k - i], acc);
+#pragma unroll
+        for (int i = 0; i < k; i++) acc = mad64(m[i], M::mod[k - i], acc);
+        m[k] = ((uint32_t)acc * M::n0) & LIMB_MASK;
+        acc = mad64(m[k], M::mod[0], acc);
+        acc >>= LIMB_BITS;
+    }
+#pragma unroll
+    for (int k = NLIMB; k < 2 * NLIMB - 1; k++) {
+#pragma unroll
+        for (int i = k - (NLIMB - 1); i < NLIMB; i++) acc = mad64(a[i], b[k - i], acc);
+#pragma unroll
+        for (int i = k - (NLIMB - 1); i < NLIMB; i++) acc = mad64(m[i], M::mod[k - i], acc);
+        out[k - NLIMB] = (uint32_t)acc & LIMB_MASK;
+        acc >>= LIMB_BITS;
+    }
+    out[NLIMB - 1] = (uint32_t)acc;
+}
+template <class M, int Ka, int Kb>
+ZK_DEV Fe<M, 2> operator*(const Fe<M, Ka>& a, const Fe<M, Kb>& b) {
+    static_assert((long)Ka * Kb <= M::kmax, "Montgomery input magnitudes too large");
+    Fe<M, 2> r;
+    uint32_t o[NLIMB];
+    limbs_mont_mul<M>(o, a.l, b.l);
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) r.l[i] = o[i];
+    return r;
+}
+template <class M, int Ka>
+ZK_DEV Fe<M, 2> fe_sqr(const Fe<M, Ka>& a) {
+    return a * a;
+}
+template <class M, int K = 1>
+ZK_DEV Fe<M, K> fe_const(const uint32_t c[NLIMB]) {
+    Fe<M, K> r;
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) r.l[i] = c[i];
+    return r;
+}
+template <class M>
+ZK_DEV Fe<M, 1> fe_zero() {
+    Fe<M, 1> r;
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) r.l[i] = 0;
+    return r;
+}
+template <class M>
+ZK_DEV Fe<M, 1> fe_one_mont() {
+    return fe_const<M, 1>(M::one);
+}
+// bring any magnitude back to < 2M (one Montgomery multiplication by R mod M)
+template <class M, int Ka>
+ZK_DEV Fe<M, 2> fe_reduce(const Fe<M, Ka>& a) {
+    return a * fe_one_mont<M>();
+}
+
+// value >= M ?  (normalised limbs)
+template <class M>
+ZK_DEV bool limbs_geq_mod(const uint32_t a[NLIMB]) {
+    bool ge = true;
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) {  // least significant first: more significant limbs override
+        if (a[i] > M::mod[i]) ge = true;
+        else if (a[i] < M::mod[i]) ge = false;
+    }
+    return ge;
+}
+// canonical representative in [0, M) of a value < 4M
+template <class M, int Ka>
+ZK_DEV Fe<M, 1> fe_canon(const Fe<M, Ka>& a) {
+    static_assert(Ka <= 4, "canonicalise only small values");
+    Fe<M, 1> r;
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) r.l[i] = a.l[i];
+#pragma unroll
+    for (int rep = 0; rep < Ka - 1 + (Ka == 1); rep++) {
+        if (limbs_geq_mod<M>(r.l)) {
+            int32_t borrow = 0;
+#pragma unroll
+            for (int i = 0; i < NLIMB; i++) {
+                int32_t d = (int32_t)r.l[i] - (int32_t)M::mod[i] + borrow;
+                borrow = d >> 31;
+                r.l[i] = (uint32_t)d & LIMB_MASK;
+            }
+        }
+    }
+    return r;
+}
+// Montgomery -> canonical plain value in [0, M)
+template <class M, int Ka>
+ZK_DEV Fe<M, 1> fe_from_mont(const Fe<M, Ka>& a) {
+    Fe<M, 1> one = fe_zero<M>();
+    one.l[0] = 1;
+    Fe<M, 2> r = a * one;  // (a + m*M)/R <= M
+    return fe_canon(r);
+}
+// plain (normalised) -> Montgomery
+template <class M, int Ka>
+ZK_DEV Fe<M, 2> fe_to_mont(const Fe<M, Ka>& a) {
+    return a * fe_const<M, 1>(M::r2);
+}
+template <class M, int Ka>
+ZK_DEV bool fe_is_zero(const Fe<M, Ka>& a) {  // value == 0 mod M ?
+    Fe<M, 1> c;
+    if constexpr (Ka <= 4) c = fe_canon(a);
+    else c = fe_canon(fe_reduce(a));
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) o |= c.l[i];
+    return o == 0;
+}
+template <class M, int Ka, int Kb>
+ZK_DEV bool fe_eq(const Fe<M, Ka>& a, const Fe<M, Kb>& b) {
+    return fe_is_zero(fe_reduce(a - b));
+}
+// canonical a, b -> canonical (a - b) mod M / (a + b) mod M   (scalar arithmetic on plain values)
+template <class M>
+ZK_DEV Fe<M, 1> fe_sub_mod(const Fe<M, 1>& a, const Fe<M, 1>& b) {
+    Fe<M, 1> r;
+    int32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) {
+        int32_t t = (int32_t)a.l[i] - (int32_t)b.l[i] + borrow;
+        borrow = t >> 31;
+        r.l[i] = (uint32_t)t & LIMB_MASK;
+    }
+    if (borrow) {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int i = 0; i < NLIMB; i++) {
+            uint32_t t = r.l[i] + M::mod[i] + carry;
+            r.l[i] = t & LIMB_MASK;
+            carry = t >> LIMB_BITS;
+        }
+    }
+    return r;
+}
+template <class M>
+ZK_DEV Fe<M, 1> fe_add_mod(const Fe<M, 1>& a, const Fe<M, 1>& b) {
+    return fe_canon(a + b);
+}
+// plain canonical a, b -> plain canonical a*b mod M
+template <class M>
+ZK_DEV Fe<M, 1> fe_mul_mod(const Fe<M, 1>& a, const Fe<M, 1>& b) {
+    return fe_canon(fe_to_mont(a) * b);
+}
+template <class M, int K>
+ZK_DEV Fe<M, K> fe_select(bool c, const Fe<M, K>& a, const Fe<M, K>& b) {  // c ? a : b
+    Fe<M, K> r;
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    return r;
+}
+
+// Montgomery-domain inverse by Fermat (a^(M-2)); inv(0) = 0 like the reference's invMod (big.ts:113-119).
+template <class M>
+__device__ __noinline__ Fe<M, 2> fe_inv(const Fe<M, 2>& a) {
+    Fe<M, 2> acc = fe_one_mont<M>().template as<2>(), base = a;
+    for (int w = 0; w < NLIMB; w++) {
+        uint32_t e = M::exp_m2[w];
+        int nb = M::bits - 32 * w;
+        if (nb > 32) nb = 32;
+        for (int b = 0; b < nb; b++) {
+            if ((e >> b) & 1) acc = acc * base;
+            base = base * base;
+        }
+    }
+    return acc;
+}
+
+// ---- plain 32-bit-word <-> 30-bit-limb conversions ----
+// words: little-endian 32-bit words (NW = 8 for 256-bit values, 9 for Tom coordinates)
+template <int NW>
+ZK_DEV void limbs_from_words(uint32_t l[NLIMB], const uint32_t w[NW]) {
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) {
+        const int bit = i * LIMB_BITS, wi = bit / 32, sh = bit % 32;
+        uint64_t v = 0;
+        if (wi < NW) v = w[wi];
+        if (wi + 1 < NW) v |= (uint64_t)w[wi + 1] << 32;
+        l[i] = (uint32_t)(v >> sh) & LIMB_MASK;
+    }
+}
+template <int NW>
+ZK_DEV void words_from_limbs(uint32_t w[NW], const uint32_t l[NLIMB]) {
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        const int lo = (32 * i) / LIMB_BITS, sh = (32 * i) % LIMB_BITS;
+        uint64_t v = (uint64_t)l[lo] >> sh;
+        if (lo + 1 < NLIMB) v |= (uint64_t)l[lo + 1] << (LIMB_BITS - sh);
+        if (lo + 2 < NLIMB && (2 * LIMB_BITS - sh) < 32) v |= (uint64_t)l[lo + 2] << (2 * LIMB_BITS - sh);
+        w[i] = (uint32_t)v;
+    }
+}
+template <class M, int NW>
+ZK_DEV Fe<M, 1> fe_from_words(const uint32_t w[NW]) {  // caller guarantees value < M (or accepts < 2^(32 NW))
+    Fe<M, 1> r;
+    limbs_from_words<NW>(r.l, w);
+    return r;
+}
+// a >= m over NW little-endian words
+template <int NW>
+ZK_DEV bool words_geq(const uint32_t a[NW], const uint32_t m[NW]) {
+    bool ge = true;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        if (a[i] > m[i]) ge = true;
+        else if (a[i] < m[i]) ge = false;
+    }
+    return ge;
+}
+// reduce a 256-bit plain value (8 words) modulo a 256-bit modulus M (q or n): at most one subtraction since
+// 2^256 < 2M.  Mirrors Scalar's constructor reduction (group.ts:164-167).
+template <class M>
+ZK_DEV Fe<M, 1> fe_from_words256_reduce(const uint32_t w[8]) {
+    Fe<M, 2> r;
+    limbs_from_words<8>(r.l, w);
+    return fe_canon(r);
+}

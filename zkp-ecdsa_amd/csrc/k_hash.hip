@@ -1,0 +1,179 @@
+// Fiat-Shamir hashing and the RNG prepass.
+// hashPoints (src/curves/group.ts:221-233): SHA-256 over the concatenated affine uncompressed encodings
+// (P-256: 04 || x(32) || y(32), weier.ts:244-255; Tom-256: 04 || x(33) || y(33), edwards.ts:194-203),
+// challenge = first 10 bytes of the digest as a big-endian integer.
+#include "engine.h"
+
+ZK_DEV void absorb_tom(ShaStream& s, const Soa& ax, const Soa& ay, uint32_t slot) {
+    uint32_t w[9];
+    s.put_byte(4);
+    words_from_limbs<9>(w, soa_ld<ModT, 1>(ax, slot).l);
+    s.put_be<33>(w);
+    words_from_limbs<9>(w, soa_ld<ModT, 1>(ay, slot).l);
+    s.put_be<33>(w);
+}
+ZK_DEV void absorb_tom_limbs(ShaStream& s, const uint32_t* xy18) {
+    uint32_t w[9];
+    s.put_byte(4);
+    words_from_limbs<9>(w, xy18);
+    s.put_be<33>(w);
+    words_from_limbs<9>(w, xy18 + 9);
+    s.put_be<33>(w);
+}
+ZK_DEV void absorb_p256(ShaStream& s, const Soa& ax, const Soa& ay, uint32_t e) {
+    uint32_t w[8];
+    s.put_byte(4);
+    words_from_limbs<8>(w, soa_ld<ModQ, 1>(ax, e).l);
+    s.put_be<32>(w);
+    words_from_limbs<8>(w, soa_ld<ModQ, 1>(ay, e).l);
+    s.put_be<32>(w);
+}
+// digest -> 80-bit challenge as 3 little-endian words (+ a zero word)
+ZK_DEV void challenge_words(const uint32_t h[8], uint32_t c[4]) {
+    c[0] = (h[1] << 16) | (h[2] >> 16);
+    c[1] = (h[0] << 16) | (h[1] >> 16);
+    c[2] = h[0] >> 16;
+    c[3] = 0;
+}
+
+// ---------------------------------------------------------------- RNG prepass
+__global__ void __launch_bounds__(256) k_rng_prepass(Workspace W, uint32_t count, uint32_t nblk) {
+    uint32_t t = gtid();
+    if (t >= count * nblk) return;
+    uint32_t p = t / nblk, blk = t % nblk;
+    uint32_t w[8];
+    rng_block(W.rng, p, blk, w);
+    if (w[7] != 0xffffffffu) return;
+    uint32_t fl = (words_geq<8>(w, ModN::mod32) ? 1u : 0u) | (words_geq<8>(w, ModQ::mod32) ? 2u : 0u);
+    if (!fl) return;
+    uint32_t i = atomicAdd(&W.rng.exc_cnt[p], 1u);
+    if (i < RNG_MAX_EXC) {
+        W.rng.exc_idx[p * RNG_MAX_EXC + i] = blk;
+        W.rng.exc_flags[p * RNG_MAX_EXC + i] = fl;
+    }
+}
+void launch_rng_prepass(hipStream_t s, const Workspace& W, uint32_t count, uint32_t nblk) {
+    hipMemsetAsync(W.rng.exc_cnt, 0, sizeof(uint32_t) * count, s);
+    uint64_t n = (uint64_t)count * nblk;
+    hipLaunchKernelGGL(k_rng_prepass, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, W, count, nblk);
+}
+
+// ---------------------------------------------------------------- Exp challenge (exp.ts:158-165)
+// c = H(Px, Py, A_0, Tx_0, Ty_0, ..., A_{sec-1}, Tx_{sec-1}, Ty_{sec-1})
+__global__ void __launch_bounds__(64) k_exp_challenge(Workspace W, uint32_t count) {
+    __shared__ uint32_t lds[16 * 64];
+    uint32_t p = gtid();
+    bool live = p < count;
+    if (!live) p = count - 1;  // keep the wave's structure uniform
+    ShaStream s;
+    s.init(lds, threadIdx.x, 64);
+    uint32_t la = p * (2 + 2 * W.sec), ea = p * (W.sec + 1);
+    absorb_tom(s, W.la.ax, W.la.ay, la + 0);
+    absorb_tom(s, W.la.ax, W.la.ay, la + 1);
+    for (uint32_t i = 0; i < W.sec; i++) {
+        absorb_p256(s, W.Ax, W.Ay, ea + i);
+        absorb_tom(s, W.la.ax, W.la.ay, la + 2 + 2 * i);
+        absorb_tom(s, W.la.ax, W.la.ay, la + 3 + 2 * i);
+    }
+    uint32_t h[8], c[4];
+    s.finish(h);
+    challenge_words(h, c);
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) W.chal[4 * p + i] = c[i];
+    }
+}
+void launch_exp_challenge(hipStream_t s, const Workspace& W, uint32_t count) {
+    hipLaunchKernelGGL(k_exp_challenge, dim3((count + 63) / 64), dim3(64), 0, s, W, count);
+}
+
+// ---------------------------------------------------------------- PointAdd sub-proof challenges
+// thread t = h * items + item, h: 0 pi8, 1 pi10, 2 pi11, 3 pi13 (mult.ts:115-116), 4 pix, 5 piy (equality.ts:69)
+__global__ void __launch_bounds__(256) k_padd_hash(DevParams P, Workspace W, uint32_t items) {
+    __shared__ uint32_t lds[16 * 256];
+    uint32_t t = gtid();
+    bool live = t < items * 6;
+    if (!live) t = items * 6 - 1;
+    uint32_t h = t / items, item = t % items;
+    uint32_t lb = item * LB_SLOTS;
+    ShaStream s;
+    s.init(lds, threadIdx.x, 256);
+    const Soa &ax = W.lb.ax, &ay = W.lb.ay;
+    if (h < 4) {
+        uint32_t cx, cy, cz, first;
+        if (h == 0) cx = 34, cy = 2, cz = 0xffffffffu, first = 6;       // C7, C8, C14 = g
+        else if (h == 1) cx = 2, cy = 35, cz = 3, first = 12;           // C8, C9, C10
+        else if (h == 2) cx = 3, cy = 3, cz = 4, first = 18;            // C10, C10, C11
+        else cx = 3, cy = 36, cz = 5, first = 24;                       // C10, C12, C13
+        absorb_tom(s, ax, ay, lb + cx);
+        absorb_tom(s, ax, ay, lb + cy);
+        if (cz == 0xffffffffu) absorb_tom_limbs(s, P.tom_g_aff);
+        else absorb_tom(s, ax, ay, lb + cz);
+        for (uint32_t k = 0; k < 6; k++) absorb_tom(s, ax, ay, lb + first + k);
+    } else {
+        uint32_t c1 = h == 4 ? 4 : 5, c2 = h == 4 ? 37 : 38, a1 = h == 4 ? 30 : 32;
+        absorb_tom(s, ax, ay, lb + c1);
+        absorb_tom(s, ax, ay, lb + c2);
+        absorb_tom(s, ax, ay, lb + a1);
+        absorb_tom(s, ax, ay, lb + a1 + 1);
+    }
+    uint32_t dg[8], c[4];
+    s.finish(dg);
+    challenge_words(dg, c);
+    if (live) {
+        uint32_t* o = W.padd_c + ((size_t)item * 6 + h) * 3;
+        o[0] = c[0], o[1] = c[1], o[2] = c[2];
+    }
+}
+void launch_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, uint32_t items) {
+    if (!items) return;
+    hipLaunchKernelGGL(k_padd_hash, dim3((items * 6 + 255) / 256), dim3(256), 0, s, P, W, items);
+}
+
+// ---------------------------------------------------------------- GK challenge x = H(cl || ca || cb || cd) (gk.ts:178-180)
+__global__ void __launch_bounds__(64) k_gk_hash(Workspace W, uint32_t count) {
+    __shared__ uint32_t lds[16 * 64];
+    uint32_t p = gtid();
+    bool live = p < count;
+    if (!live) p = count - 1;
+    ShaStream s;
+    s.init(lds, threadIdx.x, 64);
+    for (uint32_t k = 0; k < 4 * W.n; k++) absorb_tom(s, W.lc.ax, W.lc.ay, p * 4 * W.n + k);
+    uint32_t h[8], c[4];
+    s.finish(h);
+    challenge_words(h, c);
+    if (live) W.gk_x[3 * p] = c[0], W.gk_x[3 * p + 1] = c[1], W.gk_x[3 * p + 2] = c[2];
+}
+void launch_gk_hash(hipStream_t s, const Workspace& W, uint32_t count) {
+    hipLaunchKernelGGL(k_gk_hash, dim3((count + 63) / 64), dim3(64), 0, s, W, count);
+}
+
+// ---------------------------------------------------------------- unit-test hooks
+__global__ void __launch_bounds__(64) k_test_sha256(uint64_t count, uint64_t len, const uint8_t* msgs, uint8_t* out) {
+    __shared__ uint32_t lds[16 * 64];
+    uint64_t t = gtid();
+    bool live = t < count;
+    if (!live) t = count - 1;
+    ShaStream s;
+    s.init(lds, threadIdx.x, 64);
+    for (uint64_t i = 0; i < len; i++) s.put_byte(msgs[t * len + i]);
+    uint32_t h[8];
+    s.finish(h);
+    if (live)
+        for (int i = 0; i < 8; i++) ((uint32_t*)out)[t * 8 + i] = bswap32(h[i]);
+}
+void launch_test_sha256(hipStream_t s, uint64_t count, uint64_t len, const uint8_t* d_msgs, uint8_t* d_out) {
+    hipLaunchKernelGGL(k_test_sha256, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, s, count, len, d_msgs, d_out);
+}
+__global__ void k_test_rng(RngCtx g, uint64_t B, uint32_t first_k, uint32_t n_k, uint8_t* out) {
+    uint64_t t = gtid();
+    if (t >= B * n_k) return;
+    uint32_t p = (uint32_t)(t / n_k), k = first_k + (uint32_t)(t % n_k);
+    uint32_t w[8];
+    rng_draw_words(g, p, k, w);
+    store_be<8>(out + 32 * t, w);
+}
+void launch_test_rng(hipStream_t s, const RngCtx& g, uint64_t B, uint32_t first_k, uint32_t n_k, uint8_t* d_out) {
+    uint64_t n = B * n_k;
+    hipLaunchKernelGGL(k_test_rng, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, g, B, first_k, n_k, d_out);
+}

@@ -1,0 +1,284 @@
+// P-256 kernels of the prover: ECDSA front end, per-proof comb table of R, the Exp commit phase and T1.
+//
+// Reference call sites (src/zkpAttestList.ts:104-145, src/exp/exp.ts:144-156,186-193): every scalar multiplication
+// there is the window-4 Point.mul of src/curves/group.ts:133-152 (4448 modmuls).  Only affine results are
+// observable, so the engine uses: fixed-base combs for G and h_NIST (32 mixed complete additions), and a
+// per-proof 4-bit comb table of R = paramsSigExp.g, shared by the 2*sec+1 multiplications by R of one proof
+// (64 complete additions each).  All additions are the complete RCB formulas the reference uses.
+#include "engine.h"
+
+ZK_DEV P256Aff ld_pfix(const uint32_t* e) {
+    const uint4* q = (const uint4*)e;
+    uint32_t w[20];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        uint4 v = q[i];
+        w[4 * i] = v.x, w[4 * i + 1] = v.y, w[4 * i + 2] = v.z, w[4 * i + 3] = v.w;
+    }
+    P256Aff a;
+#pragma unroll
+    for (int l = 0; l < 9; l++) a.x.l[l] = w[l], a.y.l[l] = w[9 + l];
+    return a;
+}
+// k * B for a fixed base with an 8-bit comb table; k given as 8 little-endian words (clobbered)
+ZK_DEV P256Pt p256_fixed_mul(const uint32_t* __restrict__ tab, uint32_t kw[8]) {
+    P256Pt acc = p256_identity();
+#pragma unroll 1
+    for (int w = 0; w < PFIX_NWIN; w++) {
+        uint32_t d = kw[0] & 255;
+        shr256<8>(kw);
+        P256Aff e = ld_pfix(tab + (size_t)PFIX_ENTRY_WORDS * (w * 256 + d));
+        P256Pt s = p256_add_mixed(acc, e);
+        acc = p256_select(d != 0, s, acc);
+    }
+    return acc;
+}
+ZK_DEV P256Pt ld_rtab(const uint32_t* e) {
+    const uint4* q = (const uint4*)e;
+    uint32_t w[28];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        uint4 v = q[i];
+        w[4 * i] = v.x, w[4 * i + 1] = v.y, w[4 * i + 2] = v.z, w[4 * i + 3] = v.w;
+    }
+    P256Pt a;
+#pragma unroll
+    for (int l = 0; l < 9; l++) a.x.l[l] = w[l], a.y.l[l] = w[9 + l], a.z.l[l] = w[18 + l];
+    return a;
+}
+ZK_DEV void st_rtab(uint32_t* e, const P256Pt& a) {
+#pragma unroll
+    for (int l = 0; l < 9; l++) e[l] = a.x.l[l], e[9 + l] = a.y.l[l], e[18 + l] = a.z.l[l];
+    e[27] = 0;
+}
+// k * R with the proof's 4-bit comb table (entry 0 of every window is the identity: complete addition absorbs it)
+ZK_DEV P256Pt p256_rtab_mul(const uint32_t* __restrict__ rtab, uint32_t kw[8]) {
+    P256Pt acc = p256_identity();
+#pragma unroll 1
+    for (int w = 0; w < RTAB_NWIN; w++) {
+        uint32_t d = kw[0] & 15;
+        shr256<4>(kw);
+        P256Pt e = ld_rtab(rtab + (size_t)RTAB_ENTRY_WORDS * (w * 16 + d));
+        acc = p256_add(acc, e);
+    }
+    return acc;
+}
+ZK_DEV void st_proj(const Soa3& a, uint32_t e, const P256Pt& p) {
+    soa_st(a.x, e, p.x), soa_st(a.y, e, p.y), soa_st(a.z, e, p.z);
+}
+ZK_DEV P256Pt ld_proj(const Soa3& a, uint32_t e) {
+    P256Pt p;
+    p.x = soa_ld<ModQ, 8>(a.x, e), p.y = soa_ld<ModQ, 8>(a.y, e), p.z = soa_ld<ModQ, 8>(a.z, e);
+    return p;
+}
+
+// ---------------------------------------------------------------- front end (zkpAttestList.ts:112-136)
+__global__ void __launch_bounds__(64) k_front(DevParams P, Workspace W, ChunkIn in) {
+    uint32_t p = gtid();
+    if (p >= in.count) return;
+    uint32_t xw[8], yw[8], zw[8], rw[8], sw[8];
+    load_be32(in.pk + 64 * (size_t)p, xw);
+    load_be32(in.pk + 64 * (size_t)p + 32, yw);
+    load_be32(in.msg + 32 * (size_t)p, zw);
+    load_be32(in.sig + 64 * (size_t)p, rw);
+    load_be32(in.sig + 64 * (size_t)p + 32, sw);
+    int32_t status = ZK_OK;
+    if (in.which[p] >= W.N) status = ZK_E_ARG;  // values[index] must exist (gk.ts:167)
+    // deserializePoint (weier.ts:74-89): isOnGroup works mod p, coordinates are not range-checked
+    Fe<ModQ, 1> pkx = fe_from_words256_reduce<ModQ>(xw), pky = fe_from_words256_reduce<ModQ>(yw);
+    P256Aff pk;
+    pk.x = fe_to_mont(pkx), pk.y = fe_to_mont(pky);
+    if (!p256_on_curve(pk)) status = ZK_E_POINT_NOT_IN_GROUP;
+    soa_st(W.pkx, p, pkx), soa_st(W.pky, p, pky);
+    soa_st(W.pkxm, p, pk.x), soa_st(W.pkym, p, pk.y);
+    // scalars mod n (zkpAttestList.ts:119-127,133-135); invMod(0) = 0
+    Fn2 z = fe_to_mont(fe_from_words256_reduce<ModN>(zw));
+    Fn2 r = fe_to_mont(fe_from_words256_reduce<ModN>(rw));
+    Fn2 s = fe_to_mont(fe_from_words256_reduce<ModN>(sw));
+    Fn2 sinv = fe_inv<ModN>(s), rinv = fe_inv<ModN>(r);
+    Fe<ModN, 1> u1 = fe_from_mont(sinv * z), u2 = fe_from_mont(sinv * r);
+    Fe<ModN, 1> s1 = fe_from_mont(rinv * s), z1 = fe_from_mont(rinv * z);
+    soa_st(W.s1, p, s1);
+    // R = u1*G + u2*pk : comb for G, double-and-add (complete formulas) for the one-off base pk
+    uint32_t kw[8];
+    words_from_limbs<8>(kw, u1.l);
+    P256Pt R = p256_fixed_mul(P.pfix_G, kw);
+    {
+        uint32_t u2w[8];
+        words_from_limbs<8>(u2w, u2.l);
+        P256Pt acc = p256_identity();
+        P256Pt base = p256_from_affine(pk);
+#pragma unroll 1
+        for (int i = 255; i >= 0; i--) {
+            acc = p256_dbl(acc);
+            P256Pt sum = p256_add(acc, base);
+            bool bit = (u2w[7] >> 31) & 1;
+#pragma unroll
+            for (int j = 7; j > 0; j--) u2w[j] = (u2w[j] << 1) | (u2w[j - 1] >> 31);
+            u2w[0] <<= 1;
+            acc = p256_select(bit, sum, acc);
+        }
+        R = p256_add(R, acc);
+    }
+    words_from_limbs<8>(kw, z1.l);
+    P256Pt Q = p256_fixed_mul(P.pfix_G, kw);
+    st_proj(W.Q, p, Q);
+    // R affine (output + base of the per-proof table).  R = identity makes every T_i the identity: exp.ts:151.
+    Fq2 rz = fe_reduce(R.z);
+    if (fe_is_zero(rz) && status == ZK_OK) status = ZK_E_T_INF;
+    Fq2 zi = fe_inv<ModQ>(rz);
+    Fq2 rx = R.x * zi, ry = R.y * zi;
+    soa_st(W.Rxm, p, rx), soa_st(W.Rym, p, ry);
+    soa_st(W.Rx, p, fe_from_mont(rx)), soa_st(W.Ry, p, fe_from_mont(ry));
+    W.st[p] = status;
+}
+void launch_front(hipStream_t s, const DevParams& P, const Workspace& W, const ChunkIn& in) {
+    hipLaunchKernelGGL(k_front, dim3((in.count + 63) / 64), dim3(64), 0, s, P, W, in);
+}
+
+// ---------------------------------------------------------------- per-proof table of R
+__global__ void __launch_bounds__(64) k_rtab_base(Workspace W, uint32_t count) {
+    uint32_t p = gtid();
+    if (p >= count) return;
+    P256Aff r;
+    r.x = soa_ld<ModQ, 2>(W.Rxm, p), r.y = soa_ld<ModQ, 2>(W.Rym, p);
+    P256Pt b = p256_from_affine(r);
+    if (W.st[p] == ZK_E_T_INF) b = p256_identity();
+#pragma unroll 1
+    for (int w = 0; w < RTAB_NWIN; w++) {
+        st_proj(W.rbase, p * RTAB_NWIN + w, b);
+        b = p256_dbl(p256_dbl(p256_dbl(p256_dbl(b))));
+    }
+}
+__global__ void __launch_bounds__(256) k_rtab_fill(Workspace W, uint32_t count) {
+    uint32_t t = gtid();
+    if (t >= count * RTAB_NWIN) return;
+    P256Pt b = ld_proj(W.rbase, t);
+    uint32_t* e = W.rtab + (size_t)t * 16 * RTAB_ENTRY_WORDS;
+    P256Pt acc = p256_identity();
+    st_rtab(e, acc);
+#pragma unroll 1
+    for (int d = 1; d < 16; d++) {
+        acc = p256_add(acc, b);
+        st_rtab(e + d * RTAB_ENTRY_WORDS, acc);
+    }
+}
+void launch_rtab(hipStream_t s, const Workspace& W, uint32_t count) {
+    hipLaunchKernelGGL(k_rtab_base, dim3((count + 63) / 64), dim3(64), 0, s, W, count);
+    hipLaunchKernelGGL(k_rtab_fill, dim3((count * RTAB_NWIN + 255) / 256), dim3(256), 0, s, W, count);
+}
+
+// ---------------------------------------------------------------- Exp commit phase (exp.ts:144-149) and comS1
+// item j < sec of proof p:  T = alpha_j * R,  A = T + r_j * h_NIST     (draws 3+4j, 3+4j+1, both mod n)
+// item j = sec          :  comS1 = s1 * R + r0 * h_NIST                 (zkpAttestList.ts:138, draw 0)
+__global__ void __launch_bounds__(256) k_exp_commit(DevParams P, Workspace W, uint32_t count) {
+    uint32_t t = gtid();
+    uint32_t per = W.sec + 1;
+    if (t >= count * per) return;
+    uint32_t p = t / per, j = t % per;
+    uint32_t aw[8], bw[8];
+    if (j < W.sec) {
+        Fe<ModN, 1> a = rng_draw<ModN>(W.rng, p, 3 + 4 * j), b = rng_draw<ModN>(W.rng, p, 3 + 4 * j + 1);
+        words_from_limbs<8>(aw, a.l);
+        words_from_limbs<8>(bw, b.l);
+    } else {
+        Fe<ModN, 1> a = soa_ld<ModN, 1>(W.s1, p), b = rng_draw<ModN>(W.rng, p, 0);
+        words_from_limbs<8>(aw, a.l);
+        words_from_limbs<8>(bw, b.l);
+    }
+    P256Pt T = p256_rtab_mul(W.rtab + (size_t)p * RTAB_WORDS, aw);
+    P256Pt U = p256_fixed_mul(P.pfix_H, bw);
+    P256Pt A = p256_add(T, U);
+    st_proj(W.Tproj, t, T);
+    st_proj(W.Aproj, t, A);
+}
+void launch_exp_commit(hipStream_t s, const DevParams& P, const Workspace& W, uint32_t count) {
+    uint32_t n = count * (W.sec + 1);
+    hipLaunchKernelGGL(k_exp_commit, dim3((n + 255) / 256), dim3(256), 0, s, P, W, count);
+}
+
+// ---------------------------------------------------------------- batch normalisation (weier.ts:231-243)
+// Z = 0 (identity) sets st[owner] = err_code (if no earlier error) and yields (0, 0).
+__global__ void __launch_bounds__(256) k_p256_normalize(Soa3 proj, uint32_t count, uint32_t nthreads, uint32_t per, Soa ox, Soa oy,
+                                                        int32_t* st, uint32_t per_proof, int32_t err_code, const uint32_t* owner) {
+    uint32_t t = gtid();
+    if (t >= nthreads) return;
+    Fq2 acc = fe_one_mont<ModQ>().as<2>();
+    for (uint32_t j = 0; j < per; j++) {
+        uint32_t e = t + j * nthreads;
+        if (e >= count) break;
+        Fq2 z = fe_reduce(soa_ld<ModQ, 8>(proj.z, e));
+        bool zero = fe_is_zero(z);
+        if (zero) {
+            uint32_t o = owner ? owner[e] : e / per_proof;
+            if (err_code) atomicCAS(&st[o], ZK_OK, err_code);
+            z = fe_one_mont<ModQ>().as<2>();
+        }
+        soa_st(ox, e, acc);
+        soa_st(oy, e, z);  // sanitised z
+        acc = acc * z;
+    }
+    Fq2 inv = fe_inv<ModQ>(acc);
+    for (int j = (int)per - 1; j >= 0; j--) {
+        uint32_t e = t + (uint32_t)j * nthreads;
+        if (e >= count) continue;
+        Fq2 z = soa_ld<ModQ, 2>(oy, e);
+        Fq2 zi = inv * soa_ld<ModQ, 2>(ox, e);
+        inv = inv * z;
+        Fq2 x = soa_ld<ModQ, 8>(proj.x, e) * zi;
+        Fq2 y = soa_ld<ModQ, 8>(proj.y, e) * zi;
+        soa_st(ox, e, fe_from_mont(x));
+        soa_st(oy, e, fe_from_mont(y));
+    }
+}
+void launch_p256_normalize(hipStream_t s, const Soa3& proj, uint32_t count, const Soa& ox, const Soa& oy, int32_t* st, uint32_t per_proof,
+                           int32_t err_code, const uint32_t* owner) {
+    if (!count) return;
+    uint32_t per = count / (256 * 4 * 64 * 2);
+    if (per < 4) per = 4;
+    if (per > 64) per = 64;
+    uint32_t nthreads = (count + per - 1) / per;
+    hipLaunchKernelGGL(k_p256_normalize, dim3((nthreads + 255) / 256), dim3(256), 0, s, proj, count, nthreads, per, ox, oy, st, per_proof, err_code, owner);
+}
+
+// ---------------------------------------------------------------- T1 = (alpha_i - s1) * R + Q  (exp.ts:186-191)
+__global__ void __launch_bounds__(256) k_t1(Workspace W, uint32_t items) {
+    uint32_t it = gtid();
+    if (it >= items) return;
+    uint32_t p = W.item_proof[it], i = W.item_rep[it];
+    Fe<ModN, 1> alpha = rng_draw<ModN>(W.rng, p, 3 + 4 * i);
+    Fe<ModN, 1> z = fe_sub_mod(alpha, soa_ld<ModN, 1>(W.s1, p));
+    uint32_t zw[8];
+    words_from_limbs<8>(zw, z.l);
+    P256Pt T1 = p256_rtab_mul(W.rtab + (size_t)p * RTAB_WORDS, zw);
+    T1 = p256_add(T1, ld_proj(W.Q, p));
+    st_proj(W.T1proj, it, T1);
+}
+void launch_t1(hipStream_t s, const Workspace& W, uint32_t items) {
+    if (!items) return;
+    hipLaunchKernelGGL(k_t1, dim3((items + 255) / 256), dim3(256), 0, s, W, items);
+}
+
+// ---------------------------------------------------------------- unit-test hook: k*G / k*h_NIST
+__global__ void k_test_pfix(const uint32_t* tab, uint64_t count, const uint8_t* k_be, uint8_t* out) {
+    uint32_t t = gtid();
+    if (t >= count) return;
+    uint32_t kw[8];
+    load_be32(k_be + 32 * (size_t)t, kw);
+    Fe<ModN, 1> k = fe_from_words256_reduce<ModN>(kw);
+    words_from_limbs<8>(kw, k.l);
+    P256Pt r = p256_fixed_mul(tab, kw);
+    Fq2 z = fe_reduce(r.z);
+    Fq2 zi = fe_inv<ModQ>(z);
+    uint32_t xw[8], yw[8];
+    words_from_limbs<8>(xw, fe_from_mont(r.x * zi).l);
+    words_from_limbs<8>(yw, fe_from_mont(r.y * zi).l);
+    if (fe_is_zero(z)) {
+        for (int i = 0; i < 8; i++) xw[i] = 0, yw[i] = 0;
+    }
+    store_be<8>(out + 64 * (size_t)t, xw);
+    store_be<8>(out + 64 * (size_t)t + 32, yw);
+}
+void launch_test_pfix(hipStream_t s, const uint32_t* tab, uint64_t count, const uint8_t* k_be, uint8_t* out) {
+    hipLaunchKernelGGL(k_test_pfix, dim3((count + 63) / 64), dim3(64), 0, s, tab, count, k_be, out);
+}

@@ -1,0 +1,512 @@
+// Scalar-side kernels of the prover: commitment openings (v, r) for every Pedersen commitment, Sigma-protocol
+// responses, the Groth-Kohlweiss polynomial (fold form), stream compaction of the zero-bit reps and ZKA1 output.
+//
+// Draw indices follow the reference's consumption order of crypto.getRandomValues inside ONE proveSignatureList
+// call:
+//   0 comS1.r (mod n) | 1 pkX.r | 2 pkY.r | 3+4i.. alpha_i, r_i (mod n), Tx_i.r, Ty_i.r |
+//   then for the rho-th zero challenge bit, d0 = 3 + 4 sec + 40 rho:
+//     d0+0 T1x.r, +1 T1y.r, +2 C8.r, +3 C10.r, +4 C11.r, +5 C13.r,
+//     pi8: +6 kx, +7 ky, +8 kz, +9 sx, +10 sy, +11 sz, +12 s4 | pi10: +13.. | pi11: +20.. |
+//     pix: +27 k, +28 s1, +29 s2 | pi13: +30.. | piy: +37 k, +38 s1, +39 s2
+//   then g0 = 3 + 4 sec + 40 z:  g0+5i.. r_i, a_i, s_i, t_i, rho_i   (gk.ts:117-123)
+#include "engine.h"
+
+typedef Fe<ModQ, 1> Sq;  // canonical plain scalar mod q
+typedef Fe<ModN, 1> Sn;
+
+ZK_DEV Sq drawq(const Workspace& W, uint32_t p, uint32_t k) { return rng_draw<ModQ>(W.rng, p, k); }
+ZK_DEV Sn drawn(const Workspace& W, uint32_t p, uint32_t k) { return rng_draw<ModN>(W.rng, p, k); }
+ZK_DEV void put_vr(const TomList& L, uint32_t slot, const Sq& v, const Sq& r) {
+    soa_st(L.v, slot, v);
+    soa_st(L.r, slot, r);
+}
+ZK_DEV Sq chal_scalar(const uint32_t* c3) {
+    uint32_t w[8] = {c3[0], c3[1], c3[2], 0, 0, 0, 0, 0};
+    Sq r;
+    limbs_from_words<8>(r.l, w);
+    return r;
+}
+
+// ---------------------------------------------------------------- list A openings (zkpAttestList.ts:139-140, exp.ts:154-155)
+__global__ void __launch_bounds__(256) k_lista_scalars(Workspace W, uint32_t count) {
+    uint32_t t = gtid();
+    uint32_t per = 2 + 2 * W.sec;
+    if (t >= count * per) return;
+    uint32_t p = t / per, k = t % per;
+    Sq v, r;
+    if (k == 0) v = soa_ld<ModQ, 1>(W.pkx, p), r = drawq(W, p, 1);
+    else if (k == 1) v = soa_ld<ModQ, 1>(W.pky, p), r = drawq(W, p, 2);
+    else {
+        uint32_t i = (k - 2) >> 1, e = p * (W.sec + 1) + i;
+        if ((k & 1) == 0) v = soa_ld<ModQ, 1>(W.Tx, e), r = drawq(W, p, 3 + 4 * i + 2);
+        else v = soa_ld<ModQ, 1>(W.Ty, e), r = drawq(W, p, 3 + 4 * i + 3);
+    }
+    put_vr(W.la, t, v, r);
+}
+void launch_lista_scalars(hipStream_t s, const Workspace& W, uint32_t count) {
+    uint32_t n = count * (2 + 2 * W.sec);
+    hipLaunchKernelGGL(k_lista_scalars, dim3((n + 255) / 256), dim3(256), 0, s, W, count);
+}
+
+// ---------------------------------------------------------------- compaction: sizes, offsets, item list
+ZK_DEV uint32_t count_zero_bits(const uint32_t* chal, uint32_t sec) { return zeros_below(chal, sec); }
+ZK_DEV uint64_t proof_size(uint32_t sec, uint32_t n, uint32_t z) {
+    return (uint64_t)ZK_FIXED + (uint64_t)ZK_REP_HEAD * sec + (uint64_t)ZK_PADD_SZ * z + (uint64_t)n * (4 * 72 + 3 * 32) + 32;
+}
+// single workgroup of 1024 threads
+__global__ void __launch_bounds__(1024) k_scan(Workspace W, uint32_t count, uint64_t cur_in, uint64_t out_cap, uint64_t* out_off, int32_t* status_out,
+                                               uint32_t* totals /* [0] items, [1] overflow flag, [2..3] bytes */, uint64_t first_proof) {
+    __shared__ uint64_t sb[1024];
+    __shared__ uint32_t si[1024];
+    __shared__ uint64_t s_cur;
+    uint32_t t = threadIdx.x;
+    uint32_t per = (count + 1023) / 1024;
+    uint32_t lo = t * per, hi = lo + per < count ? lo + per : count;
+    uint64_t bytes = 0;
+    uint32_t items = 0;
+    for (uint32_t p = lo; p < hi; p++) {
+        int32_t st = W.st[p];
+        uint32_t z = count_zero_bits(W.chal + 4 * p, W.sec);
+        if (st == ZK_OK) {
+            uint32_t need = 3 + 4 * W.sec + 40 * z + 5 * W.n + W.rng.exc_cnt[p];
+            if (W.rng.exc_cnt[p] > RNG_MAX_EXC || (W.rng.mode == 1 && need > W.rng.stride_blocks)) st = ZK_E_RNG_EXHAUSTED, W.st[p] = st;
+        }
+        if (st != ZK_OK) z = 0;
+        W.zcnt[p] = z;
+        items += z;
+        bytes += st == ZK_OK ? proof_size(W.sec, W.n, z) : 0;
+    }
+    sb[t] = bytes, si[t] = items;
+    __syncthreads();
+    if (t == 0) {
+        uint64_t b = 0;
+        uint32_t it = 0;
+        for (int i = 0; i < 1024; i++) {
+            uint64_t nb = sb[i];
+            uint32_t ni = si[i];
+            sb[i] = b, si[i] = it;
+            b += nb, it += ni;
+        }
+        uint64_t cur = cur_in;
+        totals[0] = it;
+        totals[1] = (cur + b > out_cap) ? 1u : 0u;
+        totals[2] = (uint32_t)b, totals[3] = (uint32_t)(b >> 32);
+        W.item_base[count] = it;
+        W.out_base[count] = b;
+        out_off[first_proof + count] = cur + b;
+        s_cur = cur;
+    }
+    __syncthreads();
+    uint64_t b = sb[t];
+    uint32_t it = si[t];
+    uint64_t base = s_cur;
+    for (uint32_t p = lo; p < hi; p++) {
+        W.item_base[p] = it;
+        W.out_base[p] = b;
+        out_off[first_proof + p] = base + b;
+        status_out[first_proof + p] = W.st[p];
+        it += W.zcnt[p];
+        b += W.st[p] == ZK_OK ? proof_size(W.sec, W.n, W.zcnt[p]) : 0;
+    }
+}
+void launch_scan(hipStream_t s, const Workspace& W, uint32_t count, uint64_t cursor, uint64_t out_cap, uint64_t* d_out_off, int32_t* d_status_out,
+                 uint32_t* d_totals, uint64_t first_proof) {
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, W, count, cursor, out_cap, d_out_off, d_status_out, d_totals, first_proof);
+}
+__global__ void __launch_bounds__(256) k_items(Workspace W, uint32_t count) {
+    uint32_t t = gtid();
+    if (t >= count * W.sec) return;
+    uint32_t p = t / W.sec, i = t % W.sec;
+    if (W.st[p] != ZK_OK) return;
+    const uint32_t* c = W.chal + 4 * p;
+    if ((c[i >> 5] >> (i & 31)) & 1) return;
+    uint32_t rank = zeros_below(c, i);
+    uint32_t it = W.item_base[p] + rank;
+    W.item_proof[it] = p, W.item_rep[it] = i, W.item_rank[it] = rank;
+}
+void launch_items(hipStream_t s, const Workspace& W, uint32_t count) {
+    uint32_t n = count * W.sec;
+    hipLaunchKernelGGL(k_items, dim3((n + 255) / 256), dim3(256), 0, s, W, count);
+}
+// copy the chunk's final per-proof status (late, cryptographically negligible errors included)
+__global__ void k_status_out(Workspace W, uint32_t count, int32_t* status_out, uint64_t first_proof) {
+    uint32_t p = gtid();
+    if (p < count) status_out[first_proof + p] = W.st[p];
+}
+void launch_status_out(hipStream_t s, const Workspace& W, uint32_t count, int32_t* d_status_out, uint64_t first_proof) {
+    hipLaunchKernelGGL(k_status_out, dim3((count + 255) / 256), dim3(256), 0, s, W, count, d_status_out, first_proof);
+}
+
+// ---------------------------------------------------------------- PointAdd witness (pointAdd.ts:107-136)
+struct PaddWit {
+    Sq i7, i8, i9, i10, i11, i12, i13;
+    Sq r1, r2, r3, r4, r5, r6, r8, r10, r11, r13;  // blinders of C1..C6, C8, C10, C11, C13
+};
+ZK_DEV void padd_blinders(const Workspace& W, uint32_t p, uint32_t i, uint32_t d0, PaddWit& w) {
+    w.r1 = drawq(W, p, d0 + 0), w.r4 = drawq(W, p, d0 + 1), w.r8 = drawq(W, p, d0 + 2);
+    w.r10 = drawq(W, p, d0 + 3), w.r11 = drawq(W, p, d0 + 4), w.r13 = drawq(W, p, d0 + 5);
+    w.r2 = drawq(W, p, 1), w.r5 = drawq(W, p, 2);
+    w.r3 = drawq(W, p, 3 + 4 * i + 2), w.r6 = drawq(W, p, 3 + 4 * i + 3);
+}
+// openings of one proveMult instance (mult.ts:102-114): 6 commitments starting at `slot`
+ZK_DEV void mult_openings(const Workspace& W, uint32_t p, uint32_t dm, uint32_t slot, const Sq& x, const Sq& y, const Sq& ry) {
+    Sq kx = drawq(W, p, dm), ky = drawq(W, p, dm + 1), kz = drawq(W, p, dm + 2);
+    Sq sx = drawq(W, p, dm + 3), sy = drawq(W, p, dm + 4), sz = drawq(W, p, dm + 5), s4 = drawq(W, p, dm + 6);
+    auto xm = fe_to_mont(x), kxm = fe_to_mont(kx);
+    put_vr(W.lb, slot + 0, fe_canon(xm * y), fe_canon(xm * ry));    // C4 = x * Cy
+    put_vr(W.lb, slot + 1, kx, sx);                                 // Ax
+    put_vr(W.lb, slot + 2, ky, sy);                                 // Ay
+    put_vr(W.lb, slot + 3, kz, sz);                                 // Az
+    put_vr(W.lb, slot + 4, kz, s4);                                 // A4_1
+    put_vr(W.lb, slot + 5, fe_canon(kxm * y), fe_canon(kxm * ry));  // A4_2 = kx * Cy
+}
+__global__ void __launch_bounds__(256) k_padd_scalars(Workspace W, uint32_t items) {
+    uint32_t it = gtid();
+    if (it >= items) return;
+    uint32_t p = W.item_proof[it], i = W.item_rep[it];
+    uint32_t d0 = 3 + 4 * W.sec + 40 * W.item_rank[it];
+    uint32_t lb = it * LB_SLOTS;
+    Sq x1 = soa_ld<ModQ, 1>(W.T1x, it), y1 = soa_ld<ModQ, 1>(W.T1y, it);
+    Sq x2 = soa_ld<ModQ, 1>(W.pkx, p), y2 = soa_ld<ModQ, 1>(W.pky, p);
+    Sq x3 = soa_ld<ModQ, 1>(W.Tx, p * (W.sec + 1) + i);
+    PaddWit w;
+    padd_blinders(W, p, i, d0, w);
+    w.i7 = fe_sub_mod(x2, x1);
+    w.i8 = fe_from_mont(fe_inv<ModQ>(fe_to_mont(w.i7)));
+    w.i9 = fe_sub_mod(y2, y1);
+    w.i10 = fe_mul_mod(w.i8, w.i9);
+    w.i11 = fe_mul_mod(w.i10, w.i10);
+    w.i12 = fe_sub_mod(x1, x3);
+    w.i13 = fe_mul_mod(w.i10, w.i12);
+    put_vr(W.lb, lb + 0, x1, w.r1);       // T1x   (exp.ts:196)
+    put_vr(W.lb, lb + 1, y1, w.r4);       // T1y
+    put_vr(W.lb, lb + 2, w.i8, w.r8);     // C8    (pointAdd.ts:138-143)
+    put_vr(W.lb, lb + 3, w.i10, w.r10);   // C10
+    put_vr(W.lb, lb + 4, w.i11, w.r11);   // C11
+    put_vr(W.lb, lb + 5, w.i13, w.r13);   // C13
+    mult_openings(W, p, d0 + 6, lb + 6, w.i7, w.i8, w.r8);                          // pi8 : Cy = C8
+    mult_openings(W, p, d0 + 13, lb + 12, w.i8, w.i9, fe_sub_mod(w.r5, w.r4));     // pi10: Cy = C9 = C5 - C4
+    mult_openings(W, p, d0 + 20, lb + 18, w.i10, w.i10, w.r10);                    // pi11: Cy = C10
+    mult_openings(W, p, d0 + 30, lb + 24, w.i10, w.i12, fe_sub_mod(w.r1, w.r3));   // pi13: Cy = C12 = C1 - C3
+    {
+        Sq k = drawq(W, p, d0 + 27);                                               // pix (equality.ts:66-68)
+        put_vr(W.lb, lb + 30, k, drawq(W, p, d0 + 28));
+        put_vr(W.lb, lb + 31, k, drawq(W, p, d0 + 29));
+        k = drawq(W, p, d0 + 37);                                                  // piy
+        put_vr(W.lb, lb + 32, k, drawq(W, p, d0 + 38));
+        put_vr(W.lb, lb + 33, k, drawq(W, p, d0 + 39));
+    }
+}
+void launch_padd_scalars(hipStream_t s, const DevParams&, const Workspace& W, uint32_t items) {
+    if (!items) return;
+    hipLaunchKernelGGL(k_padd_scalars, dim3((items + 255) / 256), dim3(256), 0, s, W, items);
+}
+
+// ---------------------------------------------------------------- PointAdd responses (mult.ts:122-130, equality.ts:73-77)
+ZK_DEV void mult_respond(const Workspace& W, uint32_t p, uint32_t dm, const uint32_t* c3, uint8_t* o, const Sq& x, const Sq& y, const Sq& z,
+                         const Sq& rx, const Sq& ry, const Sq& rz) {
+    auto cm = fe_to_mont(chal_scalar(c3));
+    Sq kx = drawq(W, p, dm), ky = drawq(W, p, dm + 1), kz = drawq(W, p, dm + 2);
+    Sq sx = drawq(W, p, dm + 3), sy = drawq(W, p, dm + 4), sz = drawq(W, p, dm + 5), s4 = drawq(W, p, dm + 6);
+    Sq r4 = fe_mul_mod(x, ry);
+    store_scalar_be(o + 0, fe_sub_mod(kx, fe_canon(cm * x)));
+    store_scalar_be(o + 32, fe_sub_mod(ky, fe_canon(cm * y)));
+    store_scalar_be(o + 64, fe_sub_mod(kz, fe_canon(cm * z)));
+    store_scalar_be(o + 96, fe_sub_mod(sx, fe_canon(cm * rx)));
+    store_scalar_be(o + 128, fe_sub_mod(sy, fe_canon(cm * ry)));
+    store_scalar_be(o + 160, fe_sub_mod(sz, fe_canon(cm * rz)));
+    store_scalar_be(o + 192, fe_sub_mod(s4, fe_canon(cm * r4)));
+}
+ZK_DEV void eq_respond(const Workspace& W, uint32_t p, uint32_t de, const uint32_t* c3, uint8_t* o, const Sq& x, const Sq& rc1, const Sq& rc2) {
+    auto cm = fe_to_mont(chal_scalar(c3));
+    Sq k = drawq(W, p, de), s1 = drawq(W, p, de + 1), s2 = drawq(W, p, de + 2);
+    store_scalar_be(o + 0, fe_sub_mod(k, fe_canon(cm * x)));
+    store_scalar_be(o + 32, fe_sub_mod(s1, fe_canon(cm * rc1)));
+    store_scalar_be(o + 64, fe_sub_mod(s2, fe_canon(cm * rc2)));
+}
+__global__ void __launch_bounds__(256) k_padd_respond(Workspace W, uint32_t items, uint8_t* out) {
+    uint32_t it = gtid();
+    if (it >= items) return;
+    uint32_t p = W.item_proof[it], i = W.item_rep[it];
+    uint32_t d0 = 3 + 4 * W.sec + 40 * W.item_rank[it];
+    uint32_t lb = it * LB_SLOTS;
+    uint8_t* rep = out + W.out_base[p] + rep_offset(W.chal + 4 * p, i);
+    // rep-level response for a zero bit (exp.ts:186,221-225): z = alpha - s, z2 = r_i - Cs.r, r1 = T1x.r, r2 = T1y.r
+    {
+        Sn alpha = drawn(W, p, 3 + 4 * i), ri = drawn(W, p, 3 + 4 * i + 1), r0 = drawn(W, p, 0);
+        store_scalar_be(rep + 208, fe_sub_mod(alpha, soa_ld<ModN, 1>(W.s1, p)));
+        store_scalar_be(rep + 240, fe_sub_mod(ri, r0));
+    }
+    PaddWit w;
+    padd_blinders(W, p, i, d0, w);
+    store_scalar_be(rep + 272, w.r1);
+    store_scalar_be(rep + 304, w.r4);
+    Sq x1 = soa_ld<ModQ, 1>(W.lb.v, lb + 0), y1 = soa_ld<ModQ, 1>(W.lb.v, lb + 1);
+    w.i8 = soa_ld<ModQ, 1>(W.lb.v, lb + 2), w.i10 = soa_ld<ModQ, 1>(W.lb.v, lb + 3);
+    w.i11 = soa_ld<ModQ, 1>(W.lb.v, lb + 4), w.i13 = soa_ld<ModQ, 1>(W.lb.v, lb + 5);
+    w.i7 = fe_sub_mod(soa_ld<ModQ, 1>(W.pkx, p), x1);
+    w.i9 = fe_sub_mod(soa_ld<ModQ, 1>(W.pky, p), y1);
+    w.i12 = fe_sub_mod(x1, soa_ld<ModQ, 1>(W.Tx, p * (W.sec + 1) + i));
+    uint8_t* pa = rep + ZK_REP_HEAD;
+    const uint32_t* c = W.padd_c + (size_t)it * 18;
+    Sq one = fe_zero<ModQ>(), zero = fe_zero<ModQ>();
+    one.l[0] = 1;
+    const uint32_t MS = 288 + 432;  // scalars of MultProof m start at 288 + 656 m + 432
+    mult_respond(W, p, d0 + 6, c + 0, pa + MS, w.i7, w.i8, one, fe_sub_mod(w.r2, w.r1), w.r8, zero);                 // pi8 (C14 = g, blinder 0)
+    mult_respond(W, p, d0 + 13, c + 3, pa + MS + 656, w.i8, w.i9, w.i10, w.r8, fe_sub_mod(w.r5, w.r4), w.r10);     // pi10
+    mult_respond(W, p, d0 + 20, c + 6, pa + MS + 2 * 656, w.i10, w.i10, w.i11, w.r10, w.r10, w.r11);               // pi11
+    mult_respond(W, p, d0 + 30, c + 9, pa + MS + 3 * 656, w.i10, w.i12, w.i13, w.r10, fe_sub_mod(w.r1, w.r3), w.r13);  // pi13
+    eq_respond(W, p, d0 + 27, c + 12, pa + 2912 + 144, w.i11, w.r11, fe_add_mod(fe_add_mod(w.r3, w.r1), w.r2));   // pix: Cint = C3+C1+C2
+    eq_respond(W, p, d0 + 37, c + 15, pa + 3152 + 144, w.i13, w.r13, fe_add_mod(w.r6, w.r4));                      // piy: Cint = C6+C4
+}
+void launch_padd_respond(hipStream_t s, const Workspace& W, uint32_t items, uint8_t* out) {
+    if (!items) return;
+    hipLaunchKernelGGL(k_padd_respond, dim3((items + 255) / 256), dim3(256), 0, s, W, items, out);
+}
+
+// ---------------------------------------------------------------- ZKA1 fixed part and rep heads
+ZK_DEV void put_tom_point(uint8_t* o, const TomList& L, uint32_t slot) {
+    store_tomcoord_be(o, soa_ld<ModT, 1>(L.ax, slot));
+    store_tomcoord_be(o + 36, soa_ld<ModT, 1>(L.ay, slot));
+}
+ZK_DEV void put_p256_point(uint8_t* o, const Soa& ax, const Soa& ay, uint32_t e) {
+    store_scalar_be(o, soa_ld<ModQ, 1>(ax, e));
+    store_scalar_be(o + 32, soa_ld<ModQ, 1>(ay, e));
+}
+__global__ void __launch_bounds__(256) k_write_fixed(Workspace W, uint32_t count, uint8_t* out) {
+    uint32_t t = gtid();
+    uint32_t per = W.sec + 1;
+    if (t >= count * per) return;
+    uint32_t p = t / per, j = t % per;
+    if (W.st[p] != ZK_OK) return;
+    uint8_t* base = out + W.out_base[p];
+    const uint32_t* c = W.chal + 4 * p;
+    uint32_t la = p * (2 + 2 * W.sec), ea = p * per;
+    if (j == W.sec) {
+        uint32_t total = (uint32_t)(W.out_base[p + 1] - W.out_base[p]);
+        uint32_t* h = (uint32_t*)base;
+        h[0] = 0x31414b5au;  // "ZKA1"
+        h[1] = bswap32(total), h[2] = bswap32(W.sec), h[3] = bswap32(W.n);
+        uint32_t bits[4] = {c[0], c[1], c[2], 0};
+        for (uint32_t b = W.sec; b < 128; b++) bits[b >> 5] &= ~(1u << (b & 31));
+        store_be<4>(base + 16, bits);
+        put_p256_point(base + 32, W.Rx, W.Ry, p);
+        put_p256_point(base + 96, W.Ax, W.Ay, ea + W.sec);  // comS1
+        put_tom_point(base + 160, W.la, la + 0);
+        put_tom_point(base + 232, W.la, la + 1);
+        return;
+    }
+    uint8_t* rep = base + rep_offset(c, j);
+    put_p256_point(rep, W.Ax, W.Ay, ea + j);
+    put_tom_point(rep + 64, W.la, la + 2 + 2 * j);
+    put_tom_point(rep + 136, W.la, la + 3 + 2 * j);
+    if ((c[j >> 5] >> (j & 31)) & 1) {  // exp.ts:170-184: alpha, r, Tx.r, Ty.r
+        store_scalar_be(rep + 208, drawn(W, p, 3 + 4 * j));
+        store_scalar_be(rep + 240, drawn(W, p, 3 + 4 * j + 1));
+        store_scalar_be(rep + 272, drawq(W, p, 3 + 4 * j + 2));
+        store_scalar_be(rep + 304, drawq(W, p, 3 + 4 * j + 3));
+    }
+}
+void launch_write_fixed(hipStream_t s, const Workspace& W, uint32_t count, uint8_t* out) {
+    uint32_t n = count * (W.sec + 1);
+    hipLaunchKernelGGL(k_write_fixed, dim3((n + 255) / 256), dim3(256), 0, s, W, count, out);
+}
+__global__ void __launch_bounds__(256) k_write_padd_points(Workspace W, uint32_t items, uint8_t* out) {
+    uint32_t t = gtid();
+    if (t >= items * 32) return;
+    uint32_t it = t / 32, k = 2 + t % 32;  // slots 2..33
+    uint32_t p = W.item_proof[it], i = W.item_rep[it];
+    uint8_t* pa = out + W.out_base[p] + rep_offset(W.chal + 4 * p, i) + ZK_REP_HEAD;
+    uint32_t off;
+    if (k < 6) off = 72 * (k - 2);
+    else if (k < 30) off = 288 + 656 * ((k - 6) / 6) + 72 * ((k - 6) % 6);
+    else if (k < 32) off = 2912 + 72 * (k - 30);
+    else off = 3152 + 72 * (k - 32);
+    put_tom_point(pa + off, W.lb, it * LB_SLOTS + k);
+}
+void launch_write_padd_points(hipStream_t s, const Workspace& W, uint32_t items, uint8_t* out) {
+    if (!items) return;
+    hipLaunchKernelGGL(k_write_padd_points, dim3((items * 32 + 255) / 256), dim3(256), 0, s, W, items, out);
+}
+
+// ---------------------------------------------------------------- Groth-Kohlweiss (gk.ts:94-195)
+// Polynomial: the reference evaluates d(w) = sum_i (v_l - v_i) p_i(w) at w = 0..n-1 (2 N n modmuls) and
+// interpolates (interpolate.ts).  Since sum_i p_i(w) = w^n, d(w) = v_l w^n - P(w) with P(w) = sum_i v_i p_i(w), and
+// P is obtained EXACTLY (same coefficients, deg d <= n-1) by folding the ring along the index bits with
+// polynomial-valued entries:  new = w * (l_j ? odd : even) + a_j * (odd - even)   -- (j+1) modmuls per output,
+// 2N in total.  The self-check of interpolate.ts:63-67 holds by construction.
+ZK_DEV uint32_t gk_g0(const Workspace& W, uint32_t p) { return 3 + 4 * W.sec + 40 * W.zcnt[p]; }
+__global__ void __launch_bounds__(256) k_gk_scalars(Workspace W, ChunkIn in, Soa am) {
+    uint32_t t = gtid();
+    if (t >= in.count * W.n) return;
+    uint32_t p = t / W.n, j = t % W.n;
+    uint32_t g0 = gk_g0(W, p) + 5 * j;
+    uint32_t l = (in.which[p] >> j) & 1;
+    Sq r = drawq(W, p, g0), a = drawq(W, p, g0 + 1), s = drawq(W, p, g0 + 2), tt = drawq(W, p, g0 + 3);
+    Sq lv = fe_zero<ModQ>();
+    lv.l[0] = l;
+    uint32_t base = p * 4 * W.n;
+    put_vr(W.lc, base + j, lv, r);                               // cl_j = Com(l_j; r_j)
+    put_vr(W.lc, base + W.n + j, a, s);                          // ca_j = Com(a_j; s_j)
+    put_vr(W.lc, base + 2 * W.n + j, l ? a : fe_zero<ModQ>(), tt);  // cb_j = Com(l_j a_j; t_j)
+    soa_st(am, j * W.C + p, fe_to_mont(a));
+}
+// one fold level for a group of proofs.  in/out element index: (k * G + g) * npoly + m
+__global__ void __launch_bounds__(256) k_gk_level(Workspace W, ChunkIn in, Soa am, uint32_t first, uint32_t G, uint32_t j, Soa src, Soa dst, uint32_t npoly_out) {
+    uint32_t t = gtid();
+    if (t >= G * npoly_out) return;
+    uint32_t g = t / npoly_out, m = t % npoly_out, p = first + g;
+    uint32_t npoly_in = 2 * npoly_out;
+    bool l = (in.which[p] >> j) & 1;
+    Fe<ModQ, 2> a = soa_ld<ModQ, 2>(am, j * W.C + p);
+    Sq prev_sel = fe_zero<ModQ>();
+    bool last = npoly_out == 1;
+    for (uint32_t k = 0; k <= j; k++) {
+        Sq ev, od;
+        if (j == 0) ev = soa_ld<ModQ, 1>(W.ring, 2 * m), od = soa_ld<ModQ, 1>(W.ring, 2 * m + 1);
+        else {
+            uint32_t e = (k * G + g) * npoly_in + 2 * m;
+            ev = soa_ld<ModQ, 1>(src, e), od = soa_ld<ModQ, 1>(src, e + 1);
+        }
+        Sq prod = fe_canon(a * fe_sub_mod(od, ev));
+        Sq c = fe_add_mod(prod, prev_sel);
+        prev_sel = l ? od : ev;
+        if (last) soa_st(W.gk_coef, k * W.C + p, c);
+        else soa_st(dst, (k * G + g) * npoly_out + m, c);
+    }
+    if (last) soa_st(W.gk_coef, (j + 1) * W.C + p, prev_sel);
+    else soa_st(dst, ((j + 1) * G + g) * npoly_out + m, prev_sel);
+}
+__global__ void __launch_bounds__(256) k_gk_cd_scalars(Workspace W, uint32_t count) {
+    uint32_t t = gtid();
+    if (t >= count * W.n) return;
+    uint32_t p = t / W.n, k = t % W.n;
+    Sq c = soa_ld<ModQ, 1>(W.gk_coef, k * W.C + p);
+    Sq d = fe_sub_mod(fe_zero<ModQ>(), c);                       // d_k = -P_k
+    put_vr(W.lc, p * 4 * W.n + 3 * W.n + k, d, drawq(W, p, gk_g0(W, p) + 5 * k + 4));  // cd_k = Com(d_k; rho_k)
+}
+void launch_gk_cd_scalars(hipStream_t s, const Workspace& W, uint32_t count) {
+    uint32_t n = count * W.n;
+    hipLaunchKernelGGL(k_gk_cd_scalars, dim3((n + 255) / 256), dim3(256), 0, s, W, count);
+}
+// responses (gk.ts:181-194) and the GK section of the proof
+__global__ void __launch_bounds__(64) k_gk_respond(Workspace W, ChunkIn in, uint8_t* out) {
+    uint32_t p = gtid();
+    if (p >= in.count || W.st[p] != ZK_OK) return;
+    uint32_t n = W.n, g0 = gk_g0(W, p);
+    uint8_t* gk = out + W.out_base[p] + ZK_FIXED + (uint64_t)ZK_REP_HEAD * W.sec + (uint64_t)ZK_PADD_SZ * W.zcnt[p];
+    uint8_t* sc = gk + 4 * 72 * n;
+    Sq x = chal_scalar(W.gk_x + 3 * p);
+    auto xm = fe_to_mont(x);
+    Sq rcom = drawq(W, p, 1);                                    // blinder of keyXcom
+    Fe<ModQ, 2> xpow = fe_one_mont<ModQ>().as<2>();              // x^i (Montgomery)
+    Sq acc = fe_zero<ModQ>();                                    // sum rho_i x^i
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t l = (in.which[p] >> i) & 1;
+        Sq r = drawq(W, p, g0 + 5 * i), a = drawq(W, p, g0 + 5 * i + 1), s = drawq(W, p, g0 + 5 * i + 2);
+        Sq tt = drawq(W, p, g0 + 5 * i + 3), rho = drawq(W, p, g0 + 5 * i + 4);
+        Sq f = l ? fe_add_mod(x, a) : a;                         // f_i = l_i x + a_i
+        Sq za = fe_add_mod(fe_canon(xm * r), s);                 // za_i = r_i x + s_i
+        Sq zb = fe_add_mod(fe_mul_mod(r, fe_sub_mod(x, f)), tt); // zb_i = r_i (x - f_i) + t_i
+        store_scalar_be(sc + 32 * i, f);
+        store_scalar_be(sc + 32 * (n + i), za);
+        store_scalar_be(sc + 32 * (2 * n + i), zb);
+        acc = fe_add_mod(acc, fe_canon(xpow * rho));
+        xpow = xpow * xm;
+    }
+    Sq zd = fe_sub_mod(fe_canon(xpow * rcom), acc);              // zd = r x^n - sum rho_i x^i
+    store_scalar_be(sc + 32 * 3 * n, zd);
+}
+__global__ void __launch_bounds__(256) k_write_gk_points(Workspace W, uint32_t count, uint8_t* out) {
+    uint32_t t = gtid();
+    if (t >= count * 4 * W.n) return;
+    uint32_t p = t / (4 * W.n), k = t % (4 * W.n);
+    if (W.st[p] != ZK_OK) return;
+    uint8_t* gk = out + W.out_base[p] + ZK_FIXED + (uint64_t)ZK_REP_HEAD * W.sec + (uint64_t)ZK_PADD_SZ * W.zcnt[p];
+    put_tom_point(gk + 72 * k, W.lc, t);
+}
+void launch_gk_respond(hipStream_t s, const Workspace& W, const ChunkIn& in, uint8_t* out) {
+    hipLaunchKernelGGL(k_gk_respond, dim3((in.count + 63) / 64), dim3(64), 0, s, W, in, out);
+    uint32_t n = in.count * 4 * W.n;
+    hipLaunchKernelGGL(k_write_gk_points, dim3((n + 255) / 256), dim3(256), 0, s, W, in.count, out);
+}
+// host-side driver of the fold: a_j scratch lives at the tail of gk_bufB's owner (passed in by api as `am`)
+void launch_gk_scalars_fold(hipStream_t s, const Workspace& W, const ChunkIn& in, const Soa& am) {
+    uint32_t nt = in.count * W.n;
+    hipLaunchKernelGGL(k_gk_scalars, dim3((nt + 255) / 256), dim3(256), 0, s, W, in, am);
+    uint32_t cap = W.gk_group * W.N;  // elements per ping-pong buffer
+    Soa A = {W.gk_bufA, cap}, B = {W.gk_bufB, cap};
+    for (uint32_t first = 0; first < in.count; first += W.gk_group) {
+        uint32_t G = in.count - first < W.gk_group ? in.count - first : W.gk_group;
+        Soa src = A, dst = B;
+        for (uint32_t j = 0; j < W.n; j++) {
+            uint32_t npoly_out = W.N >> (j + 1);
+            uint32_t threads = G * npoly_out;
+            hipLaunchKernelGGL(k_gk_level, dim3((threads + 255) / 256), dim3(256), 0, s, W, in, am, first, G, j, src, dst, npoly_out);
+            Soa tmp = src;
+            src = dst, dst = tmp;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- misc conversions
+__global__ void k_ring_load(const uint8_t* keys, uint64_t nkeys, uint64_t N, Soa ring) {
+    uint64_t i = gtid();
+    if (i >= N) return;
+    uint32_t w[8];
+    load_be32(keys + 32 * (i < nkeys ? i : 0), w);  // gk.ts:80-83 pads with element 0
+    soa_st(ring, (uint32_t)i, fe_from_words256_reduce<ModQ>(w));
+}
+void launch_ring_load(hipStream_t s, const uint8_t* d_keys, uint64_t nkeys, uint64_t N, const Soa& ring) {
+    hipLaunchKernelGGL(k_ring_load, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, s, d_keys, nkeys, N, ring);
+}
+__global__ void k_bytes_to_scalars(const uint8_t* be, uint64_t count, Soa out) {
+    uint64_t i = gtid();
+    if (i >= count) return;
+    uint32_t w[8];
+    load_be32(be + 32 * i, w);
+    soa_st(out, (uint32_t)i, fe_from_words256_reduce<ModQ>(w));
+}
+void launch_bytes_to_scalars(hipStream_t s, const uint8_t* d_be32, uint64_t count, const Soa& out) {
+    hipLaunchKernelGGL(k_bytes_to_scalars, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, s, d_be32, count, out);
+}
+__global__ void k_affine_to_bytes(Soa ax, Soa ay, uint64_t count, int tom, uint8_t* out) {
+    uint64_t i = gtid();
+    if (i >= count) return;
+    if (tom) {
+        store_tomcoord_be(out + 72 * i, soa_ld<ModT, 1>(ax, (uint32_t)i));
+        store_tomcoord_be(out + 72 * i + 36, soa_ld<ModT, 1>(ay, (uint32_t)i));
+    } else {
+        store_scalar_be(out + 64 * i, soa_ld<ModQ, 1>(ax, (uint32_t)i));
+        store_scalar_be(out + 64 * i + 32, soa_ld<ModQ, 1>(ay, (uint32_t)i));
+    }
+}
+void launch_affine_to_bytes(hipStream_t s, const Soa& ax, const Soa& ay, uint64_t count, int tom, uint8_t* d_out) {
+    hipLaunchKernelGGL(k_affine_to_bytes, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, s, ax, ay, count, tom, d_out);
+}
+
+// ---------------------------------------------------------------- unit-test hook: field ops on 40-byte big-endian operands
+template <class M>
+ZK_DEV void test_field_one(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    uint32_t aw[10], bw[10];
+    for (int i = 0; i < 10; i++) aw[i] = bswap32(((const uint32_t*)a)[9 - i]), bw[i] = bswap32(((const uint32_t*)b)[9 - i]);
+    Fe<M, 1> x = fe_from_words<M, 9>(aw), y = fe_from_words<M, 9>(bw), r;
+    if (op == 0) r = fe_mul_mod(x, y);
+    else if (op == 1) r = fe_add_mod(x, y);
+    else if (op == 2) r = fe_sub_mod(x, y);
+    else r = fe_from_mont(fe_inv<M>(fe_to_mont(x)));
+    uint32_t rw[10];
+    words_from_limbs<9>(rw, r.l);
+    rw[9] = 0;
+    for (int i = 0; i < 10; i++) ((uint32_t*)out)[i] = bswap32(rw[9 - i]);
+}
+__global__ void k_test_field(int which, int op, uint64_t count, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    uint64_t i = gtid();
+    if (i >= count) return;
+    if (which == 0) test_field_one<ModQ>(op, a + 40 * i, b + 40 * i, out + 40 * i);
+    else if (which == 1) test_field_one<ModN>(op, a + 40 * i, b + 40 * i, out + 40 * i);
+    else test_field_one<ModT>(op, a + 40 * i, b + 40 * i, out + 40 * i);
+}
+void launch_test_field(hipStream_t s, int which, int op, uint64_t count, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    hipLaunchKernelGGL(k_test_field, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, s, which, op, count, a, b, out);
+}

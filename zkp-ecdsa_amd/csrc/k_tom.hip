@@ -1,0 +1,141 @@
+// Tom-256 kernels: Pedersen commitments by fixed-base comb, batch normalisation to affine, and the few point
+// additions the PointAdd sub-protocol needs.
+//
+// Reference: PedersenParams.commit (src/commit/pedersen.ts:53-58) = h.dblmul(r, g, v), i.e. the Straus/Shamir
+// window-4 double-and-add of src/curves/group.ts:97-132 (256 dbl + 160 add = 4064 modmuls).  Only the AFFINE
+// result is observable (hash input / proof bytes), so the engine evaluates v*g + r*h as 64 additions of
+// precomputed multiples (8 modmuls each, no doublings): 512 modmuls.
+//
+// proveMult's variable-base products C4 = x*Cy and A4_2 = kx*Cy (src/commit/mult.ts:103,114) are also commitments
+// with KNOWN openings (x*y, x*ry), so they go through the same kernel (see k_scalar.hip).
+#include "engine.h"
+
+ZK_DEV TomNiels ld_niels(const uint32_t* e) {
+    const uint4* q = (const uint4*)e;
+    uint32_t w[28];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        uint4 v = q[i];
+        w[4 * i] = v.x, w[4 * i + 1] = v.y, w[4 * i + 2] = v.z, w[4 * i + 3] = v.w;
+    }
+    TomNiels n;
+#pragma unroll
+    for (int l = 0; l < 9; l++) n.x.l[l] = w[l], n.y.l[l] = w[9 + l], n.dt.l[l] = w[18 + l];
+    return n;
+}
+
+__global__ void __launch_bounds__(256) k_tom_commit(const uint32_t* __restrict__ tab_g, const uint32_t* __restrict__ tab_h, TomList L,
+                                                    uint32_t count, uint32_t per_group, uint32_t slots_per_group) {
+    uint32_t c = gtid();
+    if (c >= count) return;
+    uint32_t slot = (c / per_group) * slots_per_group + (c % per_group);
+    uint32_t vw[8], rw[8];
+    {
+        Fe<ModQ, 1> v = soa_ld<ModQ, 1>(L.v, slot), r = soa_ld<ModQ, 1>(L.r, slot);
+        words_from_limbs<8>(vw, v.l);
+        words_from_limbs<8>(rw, r.l);
+    }
+    TomPt acc = tom_identity();
+#pragma unroll 1
+    for (int w = 0; w < TOM_NWIN; w++) {
+        uint32_t dv = vw[0] & 255, dr = rw[0] & 255;
+        TomNiels ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * (w * 256 + dv));
+        TomNiels nh = ld_niels(tab_h + (size_t)TOM_ENTRY_WORDS * (w * 256 + dr));
+        shr256<8>(vw);
+        shr256<8>(rw);
+        acc = tom_add_niels(acc, ng);
+        acc = tom_add_niels(acc, nh);
+    }
+    soa_st(L.proj.x, slot, acc.x);
+    soa_st(L.proj.y, slot, acc.y);
+    soa_st(L.proj.z, slot, acc.z);
+}
+void launch_tom_commit(hipStream_t s, const DevParams& P, const TomList& L, uint32_t count, uint32_t per_group, uint32_t slots_per_group) {
+    if (!count) return;
+    hipLaunchKernelGGL(k_tom_commit, dim3((count + 255) / 256), dim3(256), 0, s, P.tom_tab_g, P.tom_tab_h, L, count, per_group, slots_per_group);
+}
+
+// Batch normalisation: (X:Y:Z) on the a=1 image -> affine (x, y) of the ORIGINAL curve, plain canonical limbs
+// (edwards.ts:184-193 toAffine).  Montgomery's trick: each thread owns `per` elements (strided by the thread
+// count), so one Fermat inversion serves `per` points.  Prefix products are parked in the ax output array.
+// Element c of the pass maps to list slot (c / per_group) * slots_per_group + first + c % per_group.
+__global__ void __launch_bounds__(256) k_tom_normalize(TomList L, uint32_t count, uint32_t nthreads, uint32_t per, uint32_t first,
+                                                       uint32_t per_group, uint32_t slots_per_group) {
+    uint32_t t = gtid();
+    if (t >= nthreads) return;
+    Ft2 acc = fe_one_mont<ModT>().as<2>();
+    for (uint32_t j = 0; j < per; j++) {
+        uint32_t c = t + j * nthreads;
+        if (c >= count) break;
+        uint32_t e = (c / per_group) * slots_per_group + first + c % per_group;
+        soa_st(L.ax, e, acc);  // prefix product before element e
+        acc = acc * soa_ld<ModT, 2>(L.proj.z, e);
+    }
+    Ft2 inv = fe_inv<ModT>(acc);
+    const auto sinv = fe_const<ModT, 1>(TOM_SINV_M);
+    for (int j = (int)per - 1; j >= 0; j--) {
+        uint32_t c = t + (uint32_t)j * nthreads;
+        if (c >= count) continue;
+        uint32_t e = (c / per_group) * slots_per_group + first + c % per_group;
+        Ft2 z = soa_ld<ModT, 2>(L.proj.z, e);
+        Ft2 zi = inv * soa_ld<ModT, 2>(L.ax, e);
+        inv = inv * z;
+        Ft2 x = (soa_ld<ModT, 2>(L.proj.x, e) * zi) * sinv;
+        Ft2 y = soa_ld<ModT, 2>(L.proj.y, e) * zi;
+        soa_st(L.ax, e, fe_from_mont(x));
+        soa_st(L.ay, e, fe_from_mont(y));
+    }
+}
+void launch_tom_normalize(hipStream_t s, const TomList& L, uint32_t count, uint32_t first, uint32_t per_group, uint32_t slots_per_group) {
+    if (!count) return;
+    uint32_t per = count / (256 * 4 * 64 * 2);
+    if (per < 4) per = 4;
+    if (per > 64) per = 64;
+    uint32_t nthreads = (count + per - 1) / per;
+    hipLaunchKernelGGL(k_tom_normalize, dim3((nthreads + 255) / 256), dim3(256), 0, s, L, count, nthreads, per, first, per_group, slots_per_group);
+}
+
+// original-curve affine plain -> a=1 image extended Montgomery (no validation: engine-produced points)
+ZK_DEV TomPt tom_from_affine_plain(const Fe<ModT, 1>& xp, const Fe<ModT, 1>& yp) {
+    TomPt r;
+    Ft2 x = fe_to_mont(xp);
+    r.y = fe_to_mont(yp);
+    r.x = x * fe_const<ModT, 1>(TOM_S_M);
+    r.t = r.x * r.y;
+    r.z = fe_one_mont<ModT>().as<2>();
+    return r;
+}
+ZK_DEV TomPt ld_aff(const TomList& L, uint32_t slot) { return tom_from_affine_plain(soa_ld<ModT, 1>(L.ax, slot), soa_ld<ModT, 1>(L.ay, slot)); }
+
+// The five derived commitments of provePointAdd whose affine encodings enter Fiat-Shamir hashes
+// (src/exp/pointAdd.ts:137-160): C7 = C2 - C1, C9 = C5 - C4, C12 = C1 - C3, Cint_x = C3 + C1 + C2, Cint_y = C6 + C4
+// with C1 = T1x, C2 = pkX, C3 = Tx_i, C4 = T1y, C5 = pkY, C6 = Ty_i.  Inputs are affine (lists A and B);
+// outputs go to slots 34..38 of list B (projective) and are normalised with the rest of the list.
+__global__ void __launch_bounds__(256) k_padd_derived(Workspace W, uint32_t items) {
+    uint32_t t = gtid();
+    if (t >= items * 5) return;
+    uint32_t item = t / 5, k = t % 5;
+    uint32_t proof = W.item_proof[item], rep = W.item_rep[item];
+    uint32_t la = proof * (2 + 2 * W.sec);
+    uint32_t lb = item * LB_SLOTS;
+    TomPt r;
+    if (k == 0) {        // C7 = pkX - T1x
+        r = tom_add(ld_aff(W.la, la + 0), tom_neg(ld_aff(W.lb, lb + 0)));
+    } else if (k == 1) { // C9 = pkY - T1y
+        r = tom_add(ld_aff(W.la, la + 1), tom_neg(ld_aff(W.lb, lb + 1)));
+    } else if (k == 2) { // C12 = T1x - Tx_i
+        r = tom_add(ld_aff(W.lb, lb + 0), tom_neg(ld_aff(W.la, la + 2 + 2 * rep)));
+    } else if (k == 3) { // Cint_x = Tx_i + T1x + pkX
+        r = tom_add(tom_add(ld_aff(W.la, la + 2 + 2 * rep), ld_aff(W.lb, lb + 0)), ld_aff(W.la, la + 0));
+    } else {             // Cint_y = Ty_i + T1y
+        r = tom_add(ld_aff(W.la, la + 3 + 2 * rep), ld_aff(W.lb, lb + 1));
+    }
+    uint32_t slot = lb + LB_COMMITS + k;
+    soa_st(W.lb.proj.x, slot, r.x);
+    soa_st(W.lb.proj.y, slot, r.y);
+    soa_st(W.lb.proj.z, slot, r.z);
+}
+void launch_padd_derived(hipStream_t s, const Workspace& W, uint32_t items) {
+    if (!items) return;
+    hipLaunchKernelGGL(k_padd_derived, dim3((items * 5 + 255) / 256), dim3(256), 0, s, W, items);
+}
