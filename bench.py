@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- proveSignatureList throughput of the MI355X engine (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is one zk_prove_batch_device call over one batch of B synthetic proofs (default B = 65536, ring = 2^16:
+BASELINE.json configs[2]) with every input already resident in HBM and the proofs left in HBM.  Multi-GPU is weak
+scaling: proofs are independent given (params, ring), so every rank proves its own B proofs; the only collective is
+the RCCL broadcast of the key ring at set-up (outside the timed region), as the north star prescribes.
+
+The JSON line carries `roofline` for the dominant kernel (k_tom_commit: integer VALU bound)
+and `cpu_baseline` (the C restatement in oracle/, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# measured on MI355X with tools/valu_peak.hip (profiles/r01_valu_peak_microbench.txt): v_mad_u64_u32 chip-wide issue rate
+# at 16 independent accumulators x 8 waves/SIMD (4.3 cycles per wave-instruction; 39.3 T/s would be 16 lanes/clk at 2.4 GHz)
+VALU_MAD_PEAK_TOPS = 36.66
+HBM_PEAK_GBPS = 8000.0
+# multiplier-pipe instructions (v_mad_u64_u32 + v_mul_lo_u32) the compiler emits per Tom-field Montgomery product:
+# 2526 per k_tom_commit loop iteration of 16 products (ISA histogram; nominal 171, the zero / power-of-two limbs of
+# the modulus are strength-reduced)
+MACS_PER_MODMUL = 158
+TOM_COMMIT_MODMULS = 64 * 8    # executed: 2 x 32 table additions, 8 modmuls each
+TOM_COMMIT_NOMINAL = 4064      # reference: 256 dbl + 160 add (src/curves/group.ts:97-132)
+TOM_COMMIT_BYTES = 2 * 36 + 3 * 36  # algorithmic HBM bytes per commitment: read (v, r), write (X, Y, Z)
+
+
+def rank_seeds(base_seeds: bytes, rank: int) -> bytes:
+    """Per-rank RNG seeds: rank 0 keeps the synthetic seeds, rank r > 0 re-keys them (distinct proofs, same statements)."""
+    if rank == 0:
+        return base_seeds
+    out = bytearray()
+    tag = b'rank' + rank.to_bytes(4, 'big')
+    for i in range(0, len(base_seeds), 32):
+        out += hashlib.sha256(tag + base_seeds[i:i + 32]).digest()
+    return bytes(out)
+
+
+def nominal_modmuls(n_log2, z=40):
+    """Reference-algorithm modular multiplications per proof (SURVEY.md section 8(d) / BASELINE.md section 2)."""
+    wt = (162 + 26 * z + 4 * n_log2) * 4064 + 8 * z * 3184
+    wq = (163 + z) * 4448 + 5568
+    ring = 2 * (1 << n_log2) * n_log2
+    return wt, wq, ring
+
+
+def host_cores():
+    """CPUs this process may actually use: min(affinity, cgroup v2 cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        pass
+    return max(1, min(n, 256))
+
+
+def cpu_baseline(nh, tg, th, ring, nkeys, msg, sig, pk, which, seeds, sec, budget_proofs):
+    """Oracle (C restatement, reference-faithful algorithms) on this box's host cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import coracle as CO
+    nthreads = host_cores()
+    n = min(len(which), budget_proofs)
+    octx = CO.OracleCtx(nh, tg, th, sec)
+    octx.set_ring(ring, nkeys)
+    t0 = time.time()
+    proofs, st = octx.prove_batch(msg[:32 * n], sig[:64 * n], pk[:64 * n], which[:n], seeds=seeds[:32 * n], nthreads=nthreads)
+    dt = time.time() - t0
+    assert all(s == 0 for s in st)
+    return {'value': n / dt, 'unit': 'proofs/s', 'cores': nthreads, 'kind': 'port',
+            'sample': '%d proofs of the same workload (ring=%d keys, secLevel %d), %d threads, %.1f s wall' % (n, nkeys, sec, nthreads, dt)}, proofs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=65536, help='proofs per GPU per step')
+    ap.add_argument('--ring', type=int, default=65536, help='number of keys in the ring')
+    ap.add_argument('--chunk', type=int, default=16384, help='proofs per pipeline pass')
+    ap.add_argument('--seed', type=int, default=2024)
+    ap.add_argument('--sec', type=int, default=80)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=0, help='proofs in the CPU baseline sample (default 2 x cores)')
+    ap.add_argument('--check', type=int, default=8, help='proofs of step 1 diffed against the oracle on rank 0')
+    args = ap.parse_args()
+
+    import torch
+    import zkp_ecdsa_amd as Z
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    B, nkeys, sec = args.batch, args.ring, args.sec
+    eng = Z.Engine(local_rank)
+    nh, tg, th = eng.synth_params(args.seed)
+    eng.set_params(nh, tg, th, sec)
+    eng.set_chunk(min(args.chunk, B))
+    ring, msg, sig, pk, which, seeds = eng.synth_workload(args.seed, nkeys, B)
+
+    # the key ring travels rank 0 -> all ranks over RCCL (xGMI); everything else is generated locally from the seed
+    d_ring = torch.frombuffer(bytearray(ring), dtype=torch.uint8).to(dev)
+    if world > 1:
+        if rank != 0:
+            d_ring.zero_()
+        dist.broadcast(d_ring, src=0)
+    torch.cuda.synchronize()
+    eng.set_ring_device(d_ring.data_ptr(), nkeys)
+
+    my_seeds = rank_seeds(seeds, rank)
+    tb = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d_msg, d_sig, d_pk, d_seeds = tb(msg), tb(sig), tb(pk), tb(my_seeds)
+    d_which = torch.tensor(which, dtype=torch.int32, device=dev)
+    cap = eng.proof_max_size() * B
+    # expected size is ~(sec/2) long reps per proof; keep the worst-case bound only when it is small
+    exp_cap = int(B * (304 + 336 * sec + 3392 * (sec // 2 + 4) + (4 * 72 + 96) * 20 + 32) + (64 << 20))
+    cap = min(cap, max(exp_cap, 1 << 20))
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_off = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    d_st = torch.empty(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        eng.prove_batch_device(B, d_msg.data_ptr(), d_sig.data_ptr(), d_pk.data_ptr(), d_which.data_ptr(), d_seeds.data_ptr(),
+                               d_out.data_ptr(), cap, d_off.data_ptr(), d_st.data_ptr())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.time()
+    fam = {}
+    gpu_ms = 0.0
+    for _ in range(args.steps):
+        step()
+        tot, f = eng.last_timing()
+        gpu_ms += tot
+        for k, v in f.items():
+            fam[k] = fam.get(k, 0.0) + v
+    barrier()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    st = d_st.cpu()
+    nbad = int((st != 0).sum().item())
+    off = d_off.cpu()
+    total_bytes = int(off[B].item())
+
+    if rank == 0:
+        n_log2 = max(1, (nkeys - 1).bit_length())
+        # --- roofline of the dominant kernel, from HIP events recorded on the engine's stream around every launch
+        off_l = off.tolist()
+        zeros_total = sum(((off_l[i + 1] - off_l[i]) - (304 + 336 * sec + (4 * 72 + 96) * n_log2 + 32)) // 3392 for i in range(B) if off_l[i + 1] > off_l[i])
+        commits_per_step = B * (2 + 2 * sec) + zeros_total * 34 + B * 4 * n_log2
+        tom_ms = fam.get('tom_commit', 0.0) / args.steps
+        launches_per_step = 3 * ((B + eng_chunk(args, B) - 1) // eng_chunk(args, B))
+        macs = commits_per_step * TOM_COMMIT_MODMULS * MACS_PER_MODMUL
+        achieved_tmacs = macs / (tom_ms * 1e-3) / 1e12 if tom_ms > 0 else 0.0
+        hbm_gbps = commits_per_step * TOM_COMMIT_BYTES / (tom_ms * 1e-3) / 1e9 if tom_ms > 0 else 0.0
+        wt, wq, wring = nominal_modmuls(n_log2)
+        roofline = {
+            'bound': 'valu_int32',
+            'kernel': 'k_tom_commit',
+            'achieved': round(achieved_tmacs, 3), 'peak': VALU_MAD_PEAK_TOPS, 'unit': 'T multiplier-instr/s (v_mad_u64_u32 + v_mul_lo_u32 lane-ops, peak measured by tools/valu_peak.hip)',
+            'frac': round(achieved_tmacs / VALU_MAD_PEAK_TOPS, 4),
+            'traffic': None,
+            'avg_launch_ms': round(tom_ms / max(1, launches_per_step), 3),
+            'launches_per_step': launches_per_step,
+            'units_per_step': commits_per_step,
+            'executed_modmuls_per_unit': TOM_COMMIT_MODMULS, 'nominal_modmuls_per_unit': TOM_COMMIT_NOMINAL,
+            'hbm': {'achieved': round(hbm_gbps, 2), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(hbm_gbps / HBM_PEAK_GBPS, 5),
+                    'algorithmic_bytes_per_unit': TOM_COMMIT_BYTES},
+            'share_of_gpu_time': round(fam.get('tom_commit', 0.0) / gpu_ms, 3) if gpu_ms else None,
+            'nominal_modmuls_per_proof': {'F_t': wt, 'F_q_ec': wq, 'F_q_ring': wring},
+        }
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            sample = args.cpu_sample or 2 * host_cores()
+            cpu, oproofs = cpu_baseline(nh, tg, th, ring, nkeys, msg, sig, pk, which, seeds, sec, min(sample, B))
+            # spot-check: the first proofs of the last step against the oracle, byte for byte
+            ncheck = min(args.check, len(oproofs))
+            raw = d_out[:int(off[ncheck].item())].cpu().numpy().tobytes()
+            for b in range(ncheck):
+                assert raw[int(off[b]):int(off[b + 1])] == oproofs[b], 'GPU proof %d differs from the oracle' % b
+            cpu['checked_bit_exact'] = ncheck
+        ms_per_step = dt * 1e3 / args.steps
+        line = {
+            'metric': 'proveSignatureList proofs/sec', 'value': round(world * B * args.steps / dt, 2), 'unit': 'proofs/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 2),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32 (9x30-bit limbs, 256/258-bit modular integers)',
+            'data': 'synthetic',
+            'config': {'workload': 'batch=%d proofs per GPU per step, ring=%d keys (n=%d), secLevel=%d, P-256 + Tom-256, chunk=%d'
+                                   % (B, nkeys, n_log2, sec, eng_chunk(args, B)),
+                       'parallelism': 'proofs sharded per GPU; ring broadcast over RCCL at set-up' if world > 1 else 'single GPU'},
+            'proof_bytes_per_step': total_bytes, 'failed_proofs': nbad,
+            'gpu_ms_by_family_per_step': {k: round(v / args.steps, 2) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
+            'roofline': roofline, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+def eng_chunk(args, B):
+    return min(args.chunk, B)
+
+
+if __name__ == '__main__':
+    main()
