@@ -42,3 +42,50 @@ def test_prove_ring_1024_sample():
     assert st == est == [0] * 64
     assert [hashlib.sha256(g).hexdigest() for g in got] == [hashlib.sha256(e).hexdigest() for e in exp]
     eng.close()
+
+
+@pytest.mark.parametrize('name', ['small_full', 'ring6_sec80', 'ring37_sec80', 'rejection_stream'])
+def test_engine_matches_golden(name):
+    """The committed fixtures (tests/golden/golden.json, made by the Python restatement) through the C ABI: seed mode,
+    and stream mode with planted rejected fills (the rnd() retry path, big.ts:171-181, at whole-proof level)."""
+    import json
+    import os
+    import zkp_ecdsa_amd as Z
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'golden.json')))
+    case = gold[name]
+    eng = Z.Engine(0)
+    eng.set_params(bytes.fromhex(case['nist_h']), bytes.fromhex(case['tom_g']), bytes.fromhex(case['tom_h']), case['sec'])
+    eng.set_ring(b''.join(int(v, 16).to_bytes(32, 'big') for v in case['ring']), case['nkeys'])
+    for rec in case['proofs']:
+        args = (bytes.fromhex(rec['msg']), bytes.fromhex(rec['sig']), bytes.fromhex(rec['pk']), [rec['which']])
+        if 'seed' in rec:
+            proofs, st = eng.prove_batch(*args, seeds=bytes.fromhex(rec['seed']))
+        else:
+            seed = bytes.fromhex(rec['stream_seed'])
+            blocks = [hashlib.sha256(seed + k.to_bytes(8, 'big')).digest() for k in range(rec['stream_blocks'])]
+            for idx, val in rec['plant']:
+                blocks[idx] = int(val, 16).to_bytes(32, 'big')
+            proofs, st = eng.prove_batch(*args, streams=b''.join(blocks), stream_blocks=len(blocks))
+        assert st == [0]
+        assert len(proofs[0]) == rec['len'] and hashlib.sha256(proofs[0]).hexdigest() == rec['sha256']
+        if 'proof' in rec:
+            assert proofs[0].hex() == rec['proof']
+    eng.close()
+
+
+def test_error_statuses():
+    """Per-proof statuses mirror the reference's thrown errors; a bad proof does not disturb its neighbours."""
+    eng, octx, (msg, sig, pk, which, seeds) = _setup(31, 8, 4)
+    msg, sig, pk = bytearray(msg), bytearray(sig), bytearray(pk)
+    pk[64 * 1 + 63] ^= 1                       # proof 1: public key off the curve
+    sig[64 * 2 + 32:64 * 2 + 64] = bytes(32)   # proof 2: s = 0 -> R at infinity
+    which = list(which)
+    got, st = eng.prove_batch(bytes(msg), bytes(sig), bytes(pk), which, seeds=seeds)
+    exp, est = octx.prove_batch(bytes(msg), bytes(sig), bytes(pk), which, seeds=seeds, nthreads=4)
+    assert st == est == [0, 1, 3, 0]
+    assert got[0] == exp[0] and got[3] == exp[3] and got[1] is None and got[2] is None
+    # stream too short -> randomness exhausted, not garbage
+    blocks = bytes(32 * 100)
+    _, st = eng.prove_batch(bytes(msg[:32]), bytes(sig[:64]), bytes(pk[:64]), which[:1], streams=blocks, stream_blocks=100)
+    assert st == [11]
+    eng.close()

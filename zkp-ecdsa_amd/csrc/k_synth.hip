@@ -1,5 +1,5 @@
 // Seeded synthetic workload, generated on the GPU with the engine's own P-256 code so that
-// bench.py needs nothing from oracle/.  Byte-for-byte mirror of oracle/zkattest_ref.py synth_*:
+// bench.py needs nothing from the test oracle.  The byte layout is specified here (tests compare it with the restatement):
 //   tag(t, S, i) = SHA-256(t || be64(S) || be64(i))
 //   ring[i] = tag("ring") mod q;  d_b = tag("sk") mod (n-1) + 1;  msg_b = tag("msg");  k_b = tag("nonce") mod (n-1) + 1
 //   pk_b = d_b G;  sig_b = ECDSA(d_b, msg_b, nonce k_b);  seed_b = tag("rng");  which_b = b mod n_keys;  ring[which_b] = pk_b.x
