@@ -1011,6 +1011,7 @@ static void *prove_worker(void *arg) {
         rng_t g = {j->rng_mode, j->rng_mode == 0 ? j->rng_data + 32 * b : j->rng_data + 32 * j->rng_stride_blocks * b, j->rng_stride_blocks, 0, 0};
         wr_t w = {j->out + j->slot * b, j->slot, 0, 0};
         int rc = prove_one(j->c, j->msg + 32 * b, j->sig + 64 * b, j->pk + 64 * b, j->which[b], &g, &w, scratch);
+        if (g.err) rc = ZK_E_RNG_EXHAUSTED; /* a short stream is a caller error, whatever it broke downstream */
         j->status[b] = rc;
         j->sizes[b] = rc ? 0 : w.off;
     }

@@ -85,7 +85,8 @@ def test_error_statuses():
     assert st == est == [0, 1, 3, 0]
     assert got[0] == exp[0] and got[3] == exp[3] and got[1] is None and got[2] is None
     # stream too short -> randomness exhausted, not garbage
-    blocks = bytes(32 * 100)
+    blocks = b''.join(hashlib.sha256(b'blk%d' % k).digest() for k in range(100))
     _, st = eng.prove_batch(bytes(msg[:32]), bytes(sig[:64]), bytes(pk[:64]), which[:1], streams=blocks, stream_blocks=100)
-    assert st == [11]
+    _, est = octx.prove_batch(bytes(msg[:32]), bytes(sig[:64]), bytes(pk[:64]), which[:1], streams=blocks, stream_blocks=100)
+    assert st == est == [11]
     eng.close()

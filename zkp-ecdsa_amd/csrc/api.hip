@@ -366,7 +366,7 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
         }
         {
             Scope t(c, "p256_normalize");
-            launch_p256_normalize(s, W.Tproj, cnt * (W.sec + 1), W.Tx, W.Ty, W.st, W.sec + 1, ZK_E_T_INF, nullptr);
+            launch_p256_normalize(s, W.Tproj, cnt * (W.sec + 1), W.Tx, W.Ty, W.st, W.sec + 1, ZK_ST_T_INF_LATE, nullptr);
             launch_p256_normalize(s, W.Aproj, cnt * (W.sec + 1), W.Ax, W.Ay, W.st, W.sec + 1, 0, nullptr);
         }
         uint32_t na = cnt * (2 + 2 * W.sec);

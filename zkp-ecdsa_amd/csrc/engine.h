@@ -52,6 +52,7 @@ ZK_DEV void soa_st(const Soa& a, uint32_t e, const Fe<M, K>& v) {
 #define ZK_MULT_SZ (6 * 72 + 7 * 32)            // 656
 #define ZK_EQ_SZ (2 * 72 + 3 * 32)              // 240
 #define ZK_PADD_SZ (4 * 72 + 4 * ZK_MULT_SZ + 2 * ZK_EQ_SZ)  // 3392
+#define ZK_ST_T_INF_LATE 103  // internal: T_i = identity found by normalisation (resolved to a public status in k_scan)
 #define ZK_MAXSEC 128
 #define ZK_MAXN 32
 

@@ -67,9 +67,12 @@ __global__ void __launch_bounds__(1024) k_scan(Workspace W, uint32_t count, uint
     for (uint32_t p = lo; p < hi; p++) {
         int32_t st = W.st[p];
         uint32_t z = count_zero_bits(W.chal + 4 * p, W.sec);
-        if (st == ZK_OK) {
-            uint32_t need = 3 + 4 * W.sec + 40 * z + 5 * W.n + W.rng.exc_cnt[p];
-            if (W.rng.exc_cnt[p] > RNG_MAX_EXC || (W.rng.mode == 1 && need > W.rng.stride_blocks)) st = ZK_E_RNG_EXHAUSTED, W.st[p] = st;
+        if (st == ZK_OK || st == ZK_ST_T_INF_LATE) {
+            // a stream that is too short reads as zero fills, which can surface as T[i] = identity first: the caller error wins
+            uint32_t need = 3 + 4 * W.sec + 40 * (st == ZK_OK ? z : 0) + 5 * W.n + W.rng.exc_cnt[p];
+            if (W.rng.exc_cnt[p] > RNG_MAX_EXC || (W.rng.mode == 1 && need > W.rng.stride_blocks)) st = ZK_E_RNG_EXHAUSTED;
+            else if (st == ZK_ST_T_INF_LATE) st = ZK_E_T_INF;
+            W.st[p] = st;
         }
         if (st != ZK_OK) z = 0;
         W.zcnt[p] = z;
