@@ -295,9 +295,13 @@ static size_t carve(zk_ctx* c, uint8_t* base, uint32_t C, uint32_t sec, uint32_t
     W.gk_x = (uint32_t*)k.take(12 * (size_t)C);
     W.gk_coef = k.soa((size_t)(n + 1) * C);
     c->gk_am = k.soa((size_t)n * C);
-    uint64_t g = std::max<uint64_t>(1, std::min<uint64_t>(C, ((uint64_t)1 << 24) / N));
+    // fused fold (n >= 3): gk_bufA holds the tile polynomials, (T+1) coefs x N/2^T tiles per proof; the per-level
+    // fallback for tiny rings ping-pongs G*N elements between gk_bufA and gk_bufB
+    uint64_t g = std::max<uint64_t>(1, std::min<uint64_t>(C, ((uint64_t)1 << 16) / N));
     W.gk_group = (uint32_t)g;
-    W.gk_bufA = (uint32_t*)k.take(36 * g * N);
+    uint32_t T = std::min<uint32_t>(n, 11);
+    uint64_t tile_elems = (uint64_t)(T + 1) * C * (N >> T);
+    W.gk_bufA = (uint32_t*)k.take(36 * std::max<uint64_t>(g * N, tile_elems));
     W.gk_bufB = (uint32_t*)k.take(36 * g * N);
     W.rng.exc_idx = (uint32_t*)k.take(4 * RNG_MAX_EXC * (size_t)C);
     W.rng.exc_flags = (uint32_t*)k.take(4 * RNG_MAX_EXC * (size_t)C);

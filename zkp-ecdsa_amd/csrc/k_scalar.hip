@@ -433,11 +433,142 @@ void launch_gk_respond(hipStream_t s, const Workspace& W, const ChunkIn& in, uin
     uint32_t n = in.count * 4 * W.n;
     hipLaunchKernelGGL(k_write_gk_points, dim3((n + 255) / 256), dim3(256), 0, s, W, in.count, out);
 }
-// host-side driver of the fold: a_j scratch lives at the tail of gk_bufB's owner (passed in by api as `am`)
+// ---- fused fold: a tile of 2^T ring elements per workgroup.  Levels 0..2 run in registers (8 elements per lane),
+// levels 3..T-1 run coefficient-parallel through LDS (one output coefficient = one modmul per lane), so a whole
+// tile costs ~20 modmul latencies instead of one kernel launch per level.  LDS planes are limb-major (conflict-free).
+#define GK_TMAX 11
+#define GK_LDS_A (1u << (GK_TMAX - 1))            // elements: 2^(T-3) polys x 4 coefs
+#define GK_LDS_B ((1u << (GK_TMAX - 4)) * 5)      // 2^(T-4) polys x 5 coefs
+struct LdsPlane {
+    uint32_t* p;
+    uint32_t stride;
+};
+typedef Fe<ModQ, 64> Sq64;  // lazily reduced fold coefficient: after level j the value is < 2(j+1) M (induction: c = prod(<2M) + sel)
+ZK_DEV Sq64 lds_ld(const LdsPlane& a, uint32_t e) {
+    Sq64 r;
+#pragma unroll
+    for (int l = 0; l < NLIMB; l++) r.l[l] = a.p[l * a.stride + e];
+    return r;
+}
+template <int K>
+ZK_DEV void lds_st(const LdsPlane& a, uint32_t e, const Fe<ModQ, K>& v) {
+#pragma unroll
+    for (int l = 0; l < NLIMB; l++) a.p[l * a.stride + e] = v.l[l];
+}
+template <int K>
+ZK_DEV Sq64 as64(const Fe<ModQ, K>& v) {  // bound bookkeeping only (see Sq64)
+    Sq64 r;
+#pragma unroll
+    for (int l = 0; l < NLIMB; l++) r.l[l] = v.l[l];
+    return r;
+}
+// one level on register-resident polynomials: out = w*sel + a*(od - ev)
+template <int J>
+ZK_DEV void gk_combine(Sq (&out)[J + 2], const Sq (&ev)[J + 1], const Sq (&od)[J + 1], const Fe<ModQ, 2>& a, bool l) {
+    Sq prev = fe_zero<ModQ>();
+#pragma unroll
+    for (int k = 0; k <= J; k++) {
+        Sq prod = fe_canon(a * fe_sub_mod(od[k], ev[k]));
+        out[k] = fe_add_mod(prod, prev);
+        prev = l ? od[k] : ev[k];
+    }
+    out[J + 1] = prev;
+}
+// levels j0..j1-1 of `npoly` polynomials (j0+1 coefs each) held in LDS plane A (element (k*npoly + m)); result left in
+// the plane returned by reference (ping-pong with B).  All threads of the workgroup must call this.
+ZK_DEV void gk_lds_levels(LdsPlane& A, LdsPlane& B, uint32_t npoly, uint32_t j0, uint32_t j1, const Workspace& W, const Soa& am, uint32_t p, uint32_t which) {
+    for (uint32_t j = j0; j < j1; j++) {
+        uint32_t nout = npoly >> 1;
+        Fe<ModQ, 2> a = soa_ld<ModQ, 2>(am, j * W.C + p);
+        bool l = (which >> j) & 1;
+        uint32_t items = nout * (j + 2);
+        for (uint32_t it = threadIdx.x; it < items; it += blockDim.x) {
+            uint32_t k = it / nout, m = it % nout;
+            Sq64 c;
+            if (k <= j) {
+                Sq64 ev = lds_ld(A, k * npoly + 2 * m), od = lds_ld(A, k * npoly + 2 * m + 1);
+                Fe<ModQ, 2> prod = a * (od - ev);
+                if (k > 0) c = as64(prod + lds_ld(A, (k - 1) * npoly + 2 * m + (l ? 1 : 0)));
+                else c = as64(prod);
+            } else {
+                c = lds_ld(A, j * npoly + 2 * m + (l ? 1 : 0));
+            }
+            lds_st(B, k * nout + m, c);
+        }
+        __syncthreads();
+        LdsPlane t = A;
+        A = B, B = t;
+        npoly = nout;
+    }
+}
+// grid = count * ntiles workgroups of 256 lanes; T >= 3.  Output: tile polynomial (T+1 coefs) at res[(k*C + p)*ntiles + tile],
+// or straight into gk_coef when the tile is the whole ring.
+__global__ void __launch_bounds__(256) k_gk_tile(Workspace W, ChunkIn in, Soa am, uint32_t T, uint32_t ntiles, Soa res) {
+    __shared__ uint32_t ldsA[NLIMB * GK_LDS_A];
+    __shared__ uint32_t ldsB[NLIMB * GK_LDS_B];
+    uint32_t p = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
+    uint32_t which = in.which[p];
+    uint32_t lanes = 1u << (T - 3);  // active lanes in the register phase
+    uint32_t t = threadIdx.x;
+    LdsPlane A = {ldsA, GK_LDS_A}, B = {ldsB, GK_LDS_B};
+    if (t < lanes) {
+        uint32_t base = (tile << T) + 8 * t;
+        Sq v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = soa_ld<ModQ, 1>(W.ring, base + i);
+        Fe<ModQ, 2> a0 = soa_ld<ModQ, 2>(am, 0 * W.C + p), a1 = soa_ld<ModQ, 2>(am, 1 * W.C + p), a2 = soa_ld<ModQ, 2>(am, 2 * W.C + p);
+        Sq p1[4][2], p2[2][3], p3[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            Sq ev[1] = {v[2 * i]}, od[1] = {v[2 * i + 1]};
+            gk_combine<0>(p1[i], ev, od, a0, which & 1);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) gk_combine<1>(p2[i], p1[2 * i], p1[2 * i + 1], a1, (which >> 1) & 1);
+        gk_combine<2>(p3, p2[0], p2[1], a2, (which >> 2) & 1);
+#pragma unroll
+        for (int k = 0; k < 4; k++) lds_st(A, k * lanes + t, p3[k]);
+    }
+    __syncthreads();
+    gk_lds_levels(A, B, lanes, 3, T, W, am, p, which);
+    // result: one polynomial with T+1 coefficients at A[k]
+    bool whole = ntiles == 1;
+    for (uint32_t k = t; k <= T; k += blockDim.x) {
+        Sq c = fe_canon(fe_reduce(lds_ld(A, k)));
+        if (whole) soa_st(W.gk_coef, k * W.C + p, c);
+        else soa_st(res, (k * W.C + p) * ntiles + tile, c);
+    }
+}
+// finish: one workgroup per proof folds the ntiles tile polynomials (T+1 coefs) through levels T..n-1
+__global__ void __launch_bounds__(256) k_gk_finish(Workspace W, ChunkIn in, Soa am, uint32_t T, uint32_t ntiles, Soa res) {
+    __shared__ uint32_t ldsA[NLIMB * GK_LDS_A];
+    __shared__ uint32_t ldsB[NLIMB * GK_LDS_A];
+    uint32_t p = blockIdx.x;
+    uint32_t which = in.which[p];
+    LdsPlane A = {ldsA, GK_LDS_A}, B = {ldsB, GK_LDS_A};
+    for (uint32_t it = threadIdx.x; it < ntiles * (T + 1); it += blockDim.x) {
+        uint32_t k = it / ntiles, m = it % ntiles;
+        lds_st(A, k * ntiles + m, soa_ld<ModQ, 1>(res, (k * W.C + p) * ntiles + m));  // canonical (< M) on entry
+    }
+    __syncthreads();
+    gk_lds_levels(A, B, ntiles, T, W.n, W, am, p, which);
+    for (uint32_t k = threadIdx.x; k <= W.n; k += blockDim.x) soa_st(W.gk_coef, k * W.C + p, fe_canon(fe_reduce(lds_ld(A, k))));
+}
+// host-side driver of the fold
 void launch_gk_scalars_fold(hipStream_t s, const Workspace& W, const ChunkIn& in, const Soa& am) {
     uint32_t nt = in.count * W.n;
     hipLaunchKernelGGL(k_gk_scalars, dim3((nt + 255) / 256), dim3(256), 0, s, W, in, am);
-    uint32_t cap = W.gk_group * W.N;  // elements per ping-pong buffer
+    if (W.n >= 3) {
+        uint32_t T = W.n < GK_TMAX ? W.n : GK_TMAX;
+        uint32_t ntiles = W.N >> T;
+        // tile results: (T+1) coefs x ntiles per proof, kept in gk_bufA (capacity checked by the workspace carver)
+        Soa res = {W.gk_bufA, (uint32_t)((T + 1) * W.C * ntiles)};
+        hipLaunchKernelGGL(k_gk_tile, dim3(in.count * ntiles), dim3(256), 0, s, W, in, am, T, ntiles, res);
+        if (ntiles > 1) hipLaunchKernelGGL(k_gk_finish, dim3(in.count), dim3(256), 0, s, W, in, am, T, ntiles, res);
+        return;
+    }
+    // tiny rings (N < 8): one kernel per level through ping-pong buffers
+    uint32_t cap = W.gk_group * W.N;
     Soa A = {W.gk_bufA, cap}, B = {W.gk_bufB, cap};
     for (uint32_t first = 0; first < in.count; first += W.gk_group) {
         uint32_t G = in.count - first < W.gk_group ? in.count - first : W.gk_group;
