@@ -103,11 +103,20 @@ zk_status zk_prove_batch_device(zk_ctx *ctx, uint64_t B, const void *d_msg_hash,
                                 void *d_out_off /*u64[B+1]*/, void *d_per_proof_status /*i32[B]*/);
 
 /* Replaces B calls of verifySignatureList(params, msgHash, keys, proof) (src/zkpAttestList.ts:147-184):
- * ok[b] = 1 iff the reference verifier would return true.  Host pointers. */
+ * ok[b] = 1 iff the reference verifier returns true; per_proof_status[b] != 0 mirrors a thrown error
+ * ('params not found', 'T is at infinity', deserialisation failures ...), in which case ok[b] = 0.
+ * The reference verifier is randomised: it checks a random 20-subset of the secLevel reps (src/exp/exp.ts:95-109,
+ * 261-264).  verifier_seeds (B x 32 bytes, may be NULL) fixes that choice under the same contract as the prover's
+ * RNG: verifier fill k = SHA-256(seed_b || be64(k)), randomScalar() consumes a 32-byte fill, rnd(small) the first
+ * byte of a fill; fills are consumed in the reference's order (2n+1 randomScalar draws of verifyMembership, then
+ * generateIndices).  The random multipliers of Relation.drain (src/curves/multimult.ts:168-173) do not influence the
+ * boolean; the engine draws its own 128-bit ones.  NULL seeds: derived from (b, msgHash_b).
+ * proofs must be packed back to back (proof_off[0] = 0, 4-byte aligned).  Host pointers. */
 zk_status zk_verify_batch(zk_ctx *ctx, uint64_t B, const uint8_t *msg_hash /*Bx32*/, const uint8_t *proofs,
-                          const uint64_t *proof_off /*B+1*/, uint8_t *ok /*B*/, int32_t *per_proof_status /*B*/);
+                          const uint64_t *proof_off /*B+1*/, const uint8_t *verifier_seeds /*Bx32 or NULL*/,
+                          uint8_t *ok /*B*/, int32_t *per_proof_status /*B*/);
 zk_status zk_verify_batch_device(zk_ctx *ctx, uint64_t B, const void *d_msg_hash, const void *d_proofs,
-                                 const void *d_proof_off, void *d_ok, void *d_per_proof_status);
+                                 const void *d_proof_off, const void *d_verifier_seeds, void *d_ok, void *d_per_proof_status);
 
 /* Seeded synthetic workload generator: fills device or host buffers with a ring of
  * n_keys uniform scalars, and B valid ECDSA P-256 signatures whose public keys' x-coordinates are planted at

@@ -34,7 +34,7 @@ def lib():
         L.zko_max_proof_size.restype = C.c_uint64
         L.zko_prove_batch.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_int,
                                       C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
-        L.zko_verify_batch.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.zko_verify_batch.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int]
         L.zko_p256_mul.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
         L.zko_tom_mul.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
         L.zko_tom_commit.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]
@@ -76,7 +76,7 @@ class OracleCtx:
         proofs = [raw[slot * b: slot * b + sizes[b]] if status[b] == 0 else None for b in range(B)]
         return proofs, list(status)
 
-    def verify_batch(self, msg, proofs, nthreads=1):
+    def verify_batch(self, msg, proofs, nthreads=1, vseeds=None):
         B = len(proofs)
         off = (C.c_uint64 * (B + 1))()
         o = 0
@@ -86,7 +86,7 @@ class OracleCtx:
         off[B] = o
         ok = (C.c_uint8 * B)()
         status = (C.c_int32 * B)()
-        rc = self.L.zko_verify_batch(self.h, B, bytes(msg), b''.join(proofs), off, ok, status, nthreads)
+        rc = self.L.zko_verify_batch(self.h, B, bytes(msg), b''.join(proofs), off, bytes(vseeds) if vseeds is not None else None, ok, status, nthreads)
         if rc:
             raise ValueError('zko_verify_batch status %d' % rc)
         return list(ok), list(status)

@@ -1447,7 +1447,7 @@ static int verify_one(const zko_ctx *c, const uint8_t *msg_hash, const uint8_t *
 typedef struct {
     const zko_ctx *c;
     u64 lo, hi;
-    const uint8_t *msg, *proofs;
+    const uint8_t *msg, *proofs, *vseeds;
     const u64 *off;
     uint8_t *ok;
     int32_t *status;
@@ -1456,15 +1456,18 @@ static void *verify_worker(void *arg) {
     vjob_t *j = (vjob_t *)arg;
     for (u64 b = j->lo; b < j->hi; b++) {
         uint8_t seed[32];
-        uint8_t tag[16] = "zko-verifier";
-        memcpy(tag + 12, &b, 4);
-        zko_sha256(tag, 16, seed);
-        rng_t vr = {0, seed, 0, 0, 0};
+        if (j->vseeds) memcpy(seed, j->vseeds + 32 * b, 32);
+        else {
+            uint8_t tag[16] = "zko-verifier";
+            memcpy(tag + 12, &b, 4);
+            zko_sha256(tag, 16, seed);
+        }
+        rng_t vr = {0, seed, 0, 0, 0}; /* verifier-RNG contract: fill k = SHA-256(seed || be64(k)) */
         j->status[b] = verify_one(j->c, j->msg + 32 * b, j->proofs + j->off[b], j->off[b + 1] - j->off[b], &vr, &j->ok[b]);
     }
     return NULL;
 }
-int zko_verify_batch(const zko_ctx *c, u64 B, const uint8_t *msg, const uint8_t *proofs, const u64 *off, uint8_t *ok, int32_t *status, int nthreads) {
+int zko_verify_batch(const zko_ctx *c, u64 B, const uint8_t *msg, const uint8_t *proofs, const u64 *off, const uint8_t *vseeds, uint8_t *ok, int32_t *status, int nthreads) {
     if (!c->ring || !c->sec) return ZK_E_BUFFER;
     if (nthreads < 1) nthreads = 1;
     if ((u64)nthreads > B) nthreads = (int)(B ? B : 1);
@@ -1472,7 +1475,7 @@ int zko_verify_batch(const zko_ctx *c, u64 B, const uint8_t *msg, const uint8_t 
     pthread_t th[256];
     vjob_t jobs[256];
     for (int t = 0; t < nthreads; t++) {
-        vjob_t j = {c, B * t / nthreads, B * (t + 1) / nthreads, msg, proofs, off, ok, status};
+        vjob_t j = {c, B * t / nthreads, B * (t + 1) / nthreads, msg, proofs, vseeds, off, ok, status};
         jobs[t] = j;
         if (nthreads == 1) verify_worker(&jobs[t]);
         else pthread_create(&th[t], NULL, verify_worker, &jobs[t]);

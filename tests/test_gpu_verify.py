@@ -1,0 +1,121 @@
+"""-m gpu: verifySignatureList on the HIP engine vs the oracle's verifier (same verdict and status for the same
+verifier seed), on honest, tampered, partially tampered and malformed proofs."""
+import hashlib
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(S, nkeys, B, sec=80):
+    import coracle as CO
+    import zkp_ecdsa_amd as Z
+    eng = Z.Engine(0)
+    nh, tg, th = eng.synth_params(S)
+    eng.set_params(nh, tg, th, sec)
+    ring, msg, sig, pk, which, seeds = eng.synth_workload(S, nkeys, B)
+    eng.set_ring(ring, nkeys)
+    octx = CO.OracleCtx(nh, tg, th, sec)
+    octx.set_ring(ring, nkeys)
+    proofs, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert st == [0] * B
+    return eng, octx, msg, proofs
+
+
+def _vseeds(n, tag=b'v'):
+    return b''.join(hashlib.sha256(tag + bytes([i & 255, i >> 8])).digest() for i in range(n))
+
+
+def _both(eng, octx, msg, proofs, vseeds):
+    g = eng.verify_batch(msg, proofs, vseeds=vseeds)
+    o = octx.verify_batch(msg, proofs, nthreads=16, vseeds=vseeds)
+    return g, o
+
+
+@pytest.mark.parametrize('nkeys,B,sec', [(8, 4, 80), (37, 3, 80), (2, 2, 80), (5, 2, 20), (1024, 6, 80)])
+def test_honest_proofs_verify(nkeys, B, sec):
+    eng, octx, msg, proofs = _setup(500 + nkeys, nkeys, B, sec)
+    vs = _vseeds(B)
+    g, o = _both(eng, octx, msg, proofs, vs)
+    assert g == o == ([1] * B, [0] * B)
+    g2 = eng.verify_batch(msg, proofs)  # default seeds
+    assert g2 == ([1] * B, [0] * B)
+    eng.close()
+
+
+def test_tampered_proofs_rejected_like_the_oracle():
+    eng, octx, msg, proofs = _setup(77, 8, 1)
+    base = proofs[0]
+    n, sec = 3, 80
+    gk_off = len(base) - (n * (4 * 72 + 96) + 32)
+    cases = {}
+
+    def flip(name, pos, bit=1):
+        b = bytearray(base)
+        b[pos] ^= bit
+        cases[name] = bytes(b)
+    flip('zd', len(base) - 1)
+    flip('gk_f0', gk_off + 4 * 72 * n + 31)
+    flip('gk_za1', gk_off + 4 * 72 * n + 32 * (n + 1) + 31)
+    flip('comS1_offcurve', 96 + 5)
+    flip('R_offcurve', 32 + 40)
+    flip('keyX_offcurve', 160 + 60)
+    flip('header_len', 7)
+    flip('header_bits', 31)
+    flip('rep0_scalar', 304 + 208 + 31)
+    # swap two valid Tom points (cl_0 <-> ca_0): still on the curve, wrong statement
+    b = bytearray(base)
+    b[gk_off:gk_off + 72], b[gk_off + 72 * n:gk_off + 72 * n + 72] = b[gk_off + 72 * n:gk_off + 72 * n + 72], b[gk_off:gk_off + 72]
+    cases['swap_cl_ca'] = bytes(b)
+    # keyXcom <-> keyYcom
+    b = bytearray(base)
+    b[160:232], b[232:304] = b[232:304], b[160:232]
+    cases['swap_kx_ky'] = bytes(b)
+    cases['truncated'] = base[:-4]
+    names = sorted(cases)
+    plist = [cases[k] for k in names]
+    msgs = msg[:32] * len(plist)
+    # 'truncated' is not a multiple-of-4 problem (still aligned), keep it last so that packing stays aligned
+    plist.append(plist.pop(names.index('truncated')))
+    names.append(names.pop(names.index('truncated')))
+    for tag in (b'a', b'b', b'c'):
+        vs = _vseeds(len(plist), tag)
+        g, o = _both(eng, octx, msgs, plist, vs)
+        assert g[0] == o[0], dict(zip(names, zip(g[0], o[0])))
+        # statuses: both flag malformed input; the engine validates every point up front (like readJson) so codes agree
+        assert [s != 0 for s in g[1]] == [s != 0 for s in o[1]], dict(zip(names, zip(g[1], o[1])))
+        assert sum(g[0]) <= 1  # only a flipped scalar in an unchecked rep may still pass
+    # wrong message
+    g, o = _both(eng, octx, bytes(32), [base], _vseeds(1))
+    assert g == o == ([0], [0])
+    eng.close()
+
+
+def test_partial_tampering_follows_the_sampled_subset():
+    """One bad rep out of 80: the reference accepts iff that rep is not among the 20 sampled ones (exp.ts:95-109).
+    Engine and oracle must agree for every verifier seed."""
+    eng, octx, msg, proofs = _setup(99, 6, 1)
+    base = bytearray(proofs[0])
+    # corrupt the first response scalar of rep 5 (offset found by walking the header bits)
+    bits = int.from_bytes(base[16:32], 'big')
+    off = 304
+    for i in range(5):
+        off += 336 + (0 if (bits >> i) & 1 else 3392)
+    base[off + 208 + 31] ^= 1
+    bad = bytes(base)
+    nseeds = 24
+    vs = _vseeds(nseeds, b'sub')
+    g, o = _both(eng, octx, msg[:32] * nseeds, [bad] * nseeds, vs)
+    assert g == o
+    assert 0 < sum(g[0]) < nseeds  # some seeds sample rep 5, some do not
+    eng.close()
+
+
+def test_gk_length_mismatch_is_false_not_an_error():
+    eng8, octx8, msg, proofs8 = _setup(123, 8, 1)     # n = 3
+    eng16, octx16, msg16, proofs16 = _setup(123, 16, 1)  # n = 4
+    g = eng16.verify_batch(msg, proofs8, vseeds=_vseeds(1))
+    o = octx16.verify_batch(msg, proofs8, vseeds=_vseeds(1))
+    assert g == o == ([0], [0])  # gk.ts:208-218 returns false
+    eng8.close()
+    eng16.close()

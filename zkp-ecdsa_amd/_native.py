@@ -60,8 +60,8 @@ def lib():
         L.zk_proof_max_size.restype = u64
         L.zk_prove_batch.argtypes = [vp, u64, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(ZkRng), vp, u64, vp, vp]
         L.zk_prove_batch_device.argtypes = [vp, u64, vp, vp, vp, vp, C.POINTER(ZkRng), vp, u64, vp, vp]
-        L.zk_verify_batch.argtypes = [vp, u64, C.c_char_p, C.c_char_p, vp, vp, vp]
-        L.zk_verify_batch_device.argtypes = [vp, u64, vp, vp, vp, vp, vp]
+        L.zk_verify_batch.argtypes = [vp, u64, C.c_char_p, C.c_char_p, vp, C.c_char_p, vp, vp]
+        L.zk_verify_batch_device.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]
         L.zk_synth_workload.argtypes = [vp, u64, u64, u64, vp, vp, vp, vp, vp, vp]
         L.zk_synth_params.argtypes = [vp, u64, vp, vp, vp]
         L.zk_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.POINTER(C.c_float), u32]
@@ -151,7 +151,7 @@ class Engine:
         rng = ZkRng(mode, d_seeds, stride_blocks)
         self._chk(self.L.zk_prove_batch_device(self.h, B, d_msg, d_sig, d_pk, d_which, C.byref(rng), d_out, out_cap, d_off, d_status))
 
-    def verify_batch(self, msg, proofs):
+    def verify_batch(self, msg, proofs, vseeds=None):
         B = len(proofs)
         off = (C.c_uint64 * (B + 1))()
         o = 0
@@ -161,8 +161,11 @@ class Engine:
         off[B] = o
         ok = (C.c_uint8 * B)()
         st = (C.c_int32 * B)()
-        self._chk(self.L.zk_verify_batch(self.h, B, bytes(msg), b''.join(proofs), off, ok, st))
+        self._chk(self.L.zk_verify_batch(self.h, B, bytes(msg), b''.join(proofs), off, bytes(vseeds) if vseeds is not None else None, ok, st))
         return list(ok), list(st)
+
+    def verify_batch_device(self, B, d_msg, d_proofs, d_off, d_vseeds, d_ok, d_status):
+        self._chk(self.L.zk_verify_batch_device(self.h, B, d_msg, d_proofs, d_off, d_vseeds, d_ok, d_status))
 
     def synth_params(self, seed):
         a, b, c = C.create_string_buffer(64), C.create_string_buffer(72), C.create_string_buffer(72)

@@ -13,85 +13,7 @@ void launch_synth(hipStream_t s, const uint32_t* pfix_G, uint64_t seed, uint64_t
                   uint32_t* which, uint8_t* seeds);
 void launch_synth_param_scalars(hipStream_t s, uint64_t seed, uint8_t* kn_be, uint8_t* kt_be);
 
-struct TimerRec {
-    const char* name;
-    hipEvent_t e0, e1;
-};
-struct zk_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-    // params
-    DevParams P{};
-    bool params_set = false;
-    uint32_t* tom_tab_gen = nullptr;  // generator table (synthetic params)
-    uint32_t* tab_scratch = nullptr;
-    int32_t* d_flag = nullptr;
-    // ring
-    uint32_t* ring_mem = nullptr;
-    uint64_t N = 0, nkeys = 0;
-    uint32_t n = 0;
-    // workspace
-    uint32_t chunk = 4096;
-    void* arena = nullptr;
-    size_t arena_bytes = 0;
-    uint32_t ws_C = 0, ws_sec = 0, ws_n = 0;
-    Workspace W{};
-    Soa gk_am{};
-    uint32_t* d_totals = nullptr;
-    // timing
-    std::vector<TimerRec> trecs;
-    std::vector<hipEvent_t> epool;
-    size_t eused = 0;
-    std::vector<std::pair<const char*, float>> last_timing;
-    float last_total_ms = 0;
-};
-
-#define HIPCHK(ctx, x)                                                                                      \
-    do {                                                                                                    \
-        hipError_t e_ = (x);                                                                                \
-        if (e_ != hipSuccess) {                                                                             \
-            char buf_[256];                                                                                 \
-            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
-            (ctx)->err = buf_;                                                                              \
-            return ZK_E_DEVICE;                                                                             \
-        }                                                                                                   \
-    } while (0)
-
-static hipEvent_t get_event(zk_ctx* c) {
-    if (c->eused == c->epool.size()) {
-        hipEvent_t e;
-        hipEventCreate(&e);
-        c->epool.push_back(e);
-    }
-    return c->epool[c->eused++];
-}
-struct Scope {
-    zk_ctx* c;
-    TimerRec r;
-    Scope(zk_ctx* c_, const char* name) : c(c_) {
-        r.name = name, r.e0 = get_event(c), r.e1 = get_event(c);
-        hipEventRecord(r.e0, c->stream);
-    }
-    ~Scope() {
-        hipEventRecord(r.e1, c->stream);
-        c->trecs.push_back(r);
-    }
-};
-static void timing_begin(zk_ctx* c) { c->trecs.clear(), c->eused = 0; }
-static void timing_end(zk_ctx* c) {
-    c->last_timing.clear();
-    c->last_total_ms = 0;
-    for (auto& r : c->trecs) {
-        float ms = 0;
-        hipEventElapsedTime(&ms, r.e0, r.e1);
-        bool found = false;
-        for (auto& p : c->last_timing)
-            if (p.first == r.name) p.second += ms, found = true;
-        if (!found) c->last_timing.push_back({r.name, ms});
-        c->last_total_ms += ms;
-    }
-}
+#include "ctx.h"
 
 extern "C" const char* zk_strerror(zk_status s) {
     switch (s) {
@@ -151,7 +73,7 @@ extern "C" void zk_ctx_destroy(zk_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto e : c->epool) hipEventDestroy(e);
     hipFree(c->P.tom_tab_g), hipFree(c->P.tom_tab_h), hipFree(c->tom_tab_gen), hipFree(c->P.pfix_G), hipFree(c->P.pfix_H);
-    hipFree(c->tab_scratch), hipFree(c->d_flag), hipFree(c->d_totals), hipFree(c->ring_mem), hipFree(c->arena);
+    hipFree(c->tab_scratch), hipFree(c->d_flag), hipFree(c->d_totals), hipFree(c->ring_mem), hipFree(c->arena), hipFree(c->varena);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -249,24 +171,6 @@ extern "C" uint64_t zk_proof_max_size(const zk_ctx* c) {
 }
 
 // ------------------------------------------------------------------ workspace arena
-struct Carver {
-    uint8_t* base;
-    size_t off = 0;
-    explicit Carver(uint8_t* b) : base(b) {}
-    void* take(size_t bytes) {
-        off = (off + 255) & ~(size_t)255;
-        void* p = base ? base + off : nullptr;
-        off += bytes;
-        return p;
-    }
-    Soa soa(size_t elems) { return Soa{(uint32_t*)take(elems * 36), (uint32_t)elems}; }
-    Soa3 soa3(size_t elems) { return Soa3{soa(elems), soa(elems), soa(elems)}; }
-    TomList list(size_t cap) {
-        TomList L;
-        L.v = soa(cap), L.r = soa(cap), L.proj = soa3(cap), L.ax = soa(cap), L.ay = soa(cap), L.cap = (uint32_t)cap;
-        return L;
-    }
-};
 static size_t carve(zk_ctx* c, uint8_t* base, uint32_t C, uint32_t sec, uint32_t n, uint64_t N) {
     Carver k(base);
     Workspace& W = c->W;
@@ -309,7 +213,7 @@ static size_t carve(zk_ctx* c, uint8_t* base, uint32_t C, uint32_t sec, uint32_t
     W.ring = Soa{c->ring_mem, (uint32_t)N};
     return k.off + 256;
 }
-static zk_status ensure_workspace(zk_ctx* c, uint32_t C) {
+zk_status ensure_workspace(zk_ctx* c, uint32_t C) {
     uint32_t sec = c->P.sec, n = c->n;
     if (c->arena && c->ws_C == C && c->ws_sec == sec && c->ws_n == n) {
         c->W.ring = Soa{c->ring_mem, (uint32_t)c->N};
@@ -520,15 +424,6 @@ extern "C" zk_status zk_prove_batch(zk_ctx* c, uint64_t B, const uint8_t* msg, c
     }
     hipFree(d_msg), hipFree(d_sig), hipFree(d_pk), hipFree(d_which), hipFree(d_rng), hipFree(d_out), hipFree(d_off), hipFree(d_st);
     return zs;
-}
-
-extern "C" zk_status zk_verify_batch_device(zk_ctx* c, uint64_t, const void*, const void*, const void*, void*, void*) {
-    if (!c) return ZK_E_ARG;
-    c->err = "verifySignatureList is not on the GPU yet in this build (round 1 ships the prover); use the oracle to check proofs";
-    return ZK_E_DEVICE;
-}
-extern "C" zk_status zk_verify_batch(zk_ctx* c, uint64_t, const uint8_t*, const uint8_t*, const uint64_t*, uint8_t*, int32_t*) {
-    return zk_verify_batch_device(c, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 extern "C" uint32_t zk_last_timing(const zk_ctx* c, float* total_ms, const char** names, float* ms, uint32_t cap) {

@@ -1,0 +1,190 @@
+// zk_verify_batch / zk_verify_batch_device: host-side phase pipeline of the verifier (kernels in k_verify.hip).
+#include "ctx.h"
+
+static size_t vcarve(zk_ctx* c, uint8_t* base, uint32_t C, uint32_t sec, uint32_t n, uint64_t N) {
+    Carver k(base);
+    VWork& V = c->V;
+    V.C = C, V.sec = sec, V.n = n;
+    V.st = (int32_t*)k.take(4 * (size_t)C);
+    V.exp_st = (int32_t*)k.take(4 * (size_t)C);
+    V.okflags = (uint32_t*)k.take(4 * (size_t)C);
+    V.zcnt = (uint32_t*)k.take(4 * (size_t)C);
+    V.hbits = (uint32_t*)k.take(16 * (size_t)C);
+    V.chal = (uint32_t*)k.take(16 * (size_t)C);
+    V.gkx = (uint32_t*)k.take(12 * (size_t)C);
+    size_t ns = (size_t)C * VK;
+    V.idx = (uint32_t*)k.take(4 * ns);
+    V.vc = (uint32_t*)k.take(4 * 18 * ns);
+    V.vd = k.list(ns * 5);
+    V.gk_f = k.soa((size_t)n * C), V.gk_g = k.soa((size_t)n * C);
+    V.gk_total = k.soa(C);
+    auto terms = [&](size_t cnt) { return VTerms{k.soa(cnt), k.soa(cnt), k.soa(cnt), k.soa(cnt)}; };
+    auto soa4 = [&](size_t cnt) { return Soa4{k.soa(cnt), k.soa(cnt), k.soa(cnt), k.soa(cnt)}; };
+    size_t nq = (n + 1) / 2;
+    V.slot_terms = terms(ns * V_SLOT_TERMS);
+    V.gk_terms = terms((size_t)C * nq * 8);
+    V.misc_terms = terms((size_t)C * 3);
+    V.slot_acc = soa4(ns), V.gk_acc = soa4((size_t)C * nq), V.misc_acc = soa4((size_t)C * 3);
+    V.sSg = k.soa(ns), V.sSh = k.soa(ns), V.sSkx = k.soa(ns), V.sSky = k.soa(ns), V.sSR = k.soa(ns), V.sSH = k.soa(ns), V.sSL = k.soa(ns);
+    V.pSR = k.soa(C), V.pSH = k.soa(C), V.pSL = k.soa(C);
+    V.pa_x = k.soa(ns), V.pa_y = k.soa(ns), V.pa_sc = k.soa(ns);
+    V.pacc = k.soa3((size_t)C * 4);
+    V.clx = k.soa(C), V.cly = k.soa(C);
+    uint32_t T = std::min<uint32_t>(n, 11);
+    c->v_res = k.soa((size_t)C * (N >> T));
+    return k.off + 256;
+}
+static zk_status ensure_vworkspace(zk_ctx* c, uint32_t C) {
+    uint32_t sec = c->P.sec, n = c->n;
+    if (c->varena && c->vs_C == C && c->vs_sec == sec && c->vs_n == n) return ZK_OK;
+    size_t need = vcarve(c, nullptr, C, sec, n, c->N);
+    if (need > c->varena_bytes) {
+        if (c->varena) HIPCHK(c, hipFree(c->varena));
+        c->varena = nullptr, c->varena_bytes = 0;
+        HIPCHK(c, hipMalloc(&c->varena, need));
+        c->varena_bytes = need;
+    }
+    vcarve(c, (uint8_t*)c->varena, C, sec, n, c->N);
+    c->vs_C = C, c->vs_sec = sec, c->vs_n = n;
+    return ZK_OK;
+}
+
+__global__ void k_default_vseeds(uint64_t B, const uint8_t* msg, uint8_t* out) {
+    // default verifier seeds when the caller supplies none: SHA-256("zkv" || be64(b) || msgHash_b)
+    uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t m[16], h[8];
+    m[0] = 0x7a6b7600u | 0x01, m[1] = (uint32_t)(b >> 32), m[2] = (uint32_t)b;
+    const uint32_t* q = (const uint32_t*)(msg + 32 * b);
+    for (int i = 0; i < 8; i++) m[3 + i] = bswap32(q[i]);
+    m[11] = 0x80000000u, m[12] = 0, m[13] = 0, m[14] = 0, m[15] = 44 * 8;
+    sha256_iv(h);
+    sha256_compress(h, m);
+    for (int i = 0; i < 8; i++) ((uint32_t*)out)[8 * b + i] = bswap32(h[i]);
+}
+
+static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const uint8_t* d_proofs, const uint64_t* d_off, const uint8_t* d_vseeds, uint8_t* d_ok,
+                               int32_t* d_status) {
+    if (!c->params_set || !c->N) return ZK_E_BUFFER;
+    if (c->P.sec < VK) return ZK_E_SECLEVEL;
+    if (B == 0) return ZK_OK;
+    uint32_t C = (uint32_t)std::min<uint64_t>(c->chunk, B);
+    zk_status zs = ensure_workspace(c, C);
+    if (zs) return zs;
+    zs = ensure_vworkspace(c, C);
+    if (zs) return zs;
+    Workspace& W = c->W;
+    VWork& V = c->V;
+    const DevParams& P = c->P;
+    hipStream_t s = c->stream;
+    timing_begin(c);
+    uint8_t* own_seeds = nullptr;
+    if (!d_vseeds) {
+        HIPCHK(c, hipMalloc(&own_seeds, 32 * B));
+        hipLaunchKernelGGL(k_default_vseeds, dim3((uint32_t)((B + 255) / 256)), dim3(256), 0, s, B, d_msg, own_seeds);
+        d_vseeds = own_seeds;
+    }
+    uint32_t nq = (W.n + 1) / 2;
+    for (uint64_t first = 0; first < B; first += C) {
+        uint32_t cnt = (uint32_t)std::min<uint64_t>(C, B - first);
+        {
+            Scope t(c, "v_parse_validate");
+            launch_v_header_validate(s, V, cnt, d_proofs, d_off, first);
+        }
+        {
+            Scope t(c, "v_p256_front_rtab");
+            launch_v_front(s, P, W, V, cnt, d_proofs, d_off, d_msg, first);
+            launch_rtab(s, W, cnt);
+        }
+        {
+            Scope t(c, "v_hash");
+            launch_v_challenges_sample(s, V, cnt, d_proofs, d_off, d_vseeds, first);
+        }
+        {
+            Scope t(c, "v_p256_exp_points");
+            launch_v_exp_points(s, W, V, cnt, d_proofs, d_off, first);
+            launch_p256_normalize(s, W.Tproj, cnt * VK, W.Tx, W.Ty, W.st, VK, ZK_E_T_INF, nullptr);
+        }
+        {
+            Scope t(c, "v_tom_fixed");
+            launch_v_t1_scalars(s, W, V, cnt, d_proofs, d_off, first);
+            launch_tom_commit(s, P, W.la, cnt * 2 * VK, 2 * VK, 2 + 2 * W.sec);
+            launch_tom_normalize(s, W.la, cnt * 2 * VK, 0, 2 * VK, 2 + 2 * W.sec);
+            launch_v_derived(s, W, V, cnt, d_proofs, d_off, first);
+            launch_tom_normalize(s, V.vd, cnt * VK * 5, 0, 1, 1);
+        }
+        {
+            Scope t(c, "v_hash");
+            launch_v_padd_hash(s, P, W, V, cnt, d_proofs, d_off, first);
+        }
+        {
+            Scope t(c, "v_gk_total");
+            launch_v_gk_total(s, V, W.ring, cnt, W.N, d_proofs, d_off, first, c->v_res);
+        }
+        {
+            Scope t(c, "v_terms");
+            launch_v_terms(s, W, V, cnt, d_proofs, d_off, d_vseeds, first);
+        }
+        {
+            Scope t(c, "v_straus_tom");
+            launch_v_straus(s, V.slot_terms, cnt * VK, V.C * VK, 10, 26, V.slot_acc);
+            launch_v_straus(s, V.gk_terms, cnt * nq, V.C * nq, 4, 4, V.gk_acc);
+            launch_v_straus(s, V.misc_terms, 3 * V.C, 3 * V.C, 1, 0, V.misc_acc);
+        }
+        {
+            Scope t(c, "v_tom_fixed");
+            launch_tom_commit(s, P, W.lc, cnt * 2, 2, 4 * W.n);
+        }
+        {
+            Scope t(c, "v_straus_p256");
+            launch_v_p256_straus(s, V, cnt);
+        }
+        {
+            Scope t(c, "v_final");
+            launch_v_final(s, P, W, V, cnt, d_ok, d_status, first);
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipGetLastError());
+    timing_end(c);
+    if (own_seeds) hipFree(own_seeds);
+    return ZK_OK;
+}
+
+extern "C" zk_status zk_verify_batch_device(zk_ctx* c, uint64_t B, const void* d_msg, const void* d_proofs, const void* d_off, const void* d_vseeds, void* d_ok,
+                                            void* d_status) {
+    if (!c || (B && (!d_msg || !d_proofs || !d_off || !d_ok || !d_status))) return ZK_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    return verify_device(c, B, (const uint8_t*)d_msg, (const uint8_t*)d_proofs, (const uint64_t*)d_off, (const uint8_t*)d_vseeds, (uint8_t*)d_ok, (int32_t*)d_status);
+}
+extern "C" zk_status zk_verify_batch(zk_ctx* c, uint64_t B, const uint8_t* msg, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint8_t* ok,
+                                     int32_t* status) {
+    if (!c || (B && (!msg || !proofs || !off || !ok || !status))) return ZK_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->params_set || !c->N) return ZK_E_BUFFER;
+    if (B == 0) return ZK_OK;
+    if (off[0] != 0) return ZK_E_ARG;
+    uint64_t total = off[B];
+    uint8_t *d_msg = nullptr, *d_proofs = nullptr, *d_seeds = nullptr, *d_ok = nullptr;
+    uint64_t* d_off = nullptr;
+    int32_t* d_st = nullptr;
+    HIPCHK(c, hipMalloc(&d_msg, 32 * B));
+    HIPCHK(c, hipMalloc(&d_proofs, total + 64));
+    HIPCHK(c, hipMalloc(&d_off, 8 * (B + 1)));
+    HIPCHK(c, hipMalloc(&d_ok, B));
+    HIPCHK(c, hipMalloc(&d_st, 4 * B));
+    HIPCHK(c, hipMemcpy(d_msg, msg, 32 * B, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d_proofs, proofs, total, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d_off, off, 8 * (B + 1), hipMemcpyHostToDevice));
+    if (vseeds) {
+        HIPCHK(c, hipMalloc(&d_seeds, 32 * B));
+        HIPCHK(c, hipMemcpy(d_seeds, vseeds, 32 * B, hipMemcpyHostToDevice));
+    }
+    zk_status zs = verify_device(c, B, d_msg, d_proofs, d_off, d_seeds, d_ok, d_st);
+    if (zs == ZK_OK) {
+        HIPCHK(c, hipMemcpy(ok, d_ok, B, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(status, d_st, 4 * B, hipMemcpyDeviceToHost));
+    }
+    hipFree(d_msg), hipFree(d_proofs), hipFree(d_off), hipFree(d_ok), hipFree(d_st), hipFree(d_seeds);
+    return zs;
+}

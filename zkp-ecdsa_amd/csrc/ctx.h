@@ -1,0 +1,116 @@
+// Shared host-side context of libzkattest_hip.so (api.hip: prover pipeline; api_verify.hip: verifier pipeline).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "engine.h"
+
+struct TimerRec {
+    const char* name;
+    hipEvent_t e0, e1;
+};
+struct zk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // params
+    DevParams P{};
+    bool params_set = false;
+    uint32_t* tom_tab_gen = nullptr;  // generator table (synthetic params)
+    uint32_t* tab_scratch = nullptr;
+    int32_t* d_flag = nullptr;
+    // ring
+    uint32_t* ring_mem = nullptr;
+    uint64_t N = 0, nkeys = 0;
+    uint32_t n = 0;
+    // workspace
+    uint32_t chunk = 4096;
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    uint32_t ws_C = 0, ws_sec = 0, ws_n = 0;
+    Workspace W{};
+    Soa gk_am{};
+    uint32_t* d_totals = nullptr;
+    // verifier workspace
+    VWork V{};
+    void* varena = nullptr;
+    size_t varena_bytes = 0;
+    uint32_t vs_C = 0, vs_sec = 0, vs_n = 0;
+    Soa v_res{};
+    // timing
+    std::vector<TimerRec> trecs;
+    std::vector<hipEvent_t> epool;
+    size_t eused = 0;
+    std::vector<std::pair<const char*, float>> last_timing;
+    float last_total_ms = 0;
+};
+
+#define HIPCHK(ctx, x)                                                                                      \
+    do {                                                                                                    \
+        hipError_t e_ = (x);                                                                                \
+        if (e_ != hipSuccess) {                                                                             \
+            char buf_[256];                                                                                 \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (ctx)->err = buf_;                                                                              \
+            return ZK_E_DEVICE;                                                                             \
+        }                                                                                                   \
+    } while (0)
+
+static inline hipEvent_t get_event(zk_ctx* c) {
+    if (c->eused == c->epool.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        c->epool.push_back(e);
+    }
+    return c->epool[c->eused++];
+}
+struct Scope {
+    zk_ctx* c;
+    TimerRec r;
+    Scope(zk_ctx* c_, const char* name) : c(c_) {
+        r.name = name, r.e0 = get_event(c), r.e1 = get_event(c);
+        hipEventRecord(r.e0, c->stream);
+    }
+    ~Scope() {
+        hipEventRecord(r.e1, c->stream);
+        c->trecs.push_back(r);
+    }
+};
+static inline void timing_begin(zk_ctx* c) { c->trecs.clear(), c->eused = 0; }
+static inline void timing_end(zk_ctx* c) {
+    c->last_timing.clear();
+    c->last_total_ms = 0;
+    for (auto& r : c->trecs) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, r.e0, r.e1);
+        bool found = false;
+        for (auto& p : c->last_timing)
+            if (p.first == r.name) p.second += ms, found = true;
+        if (!found) c->last_timing.push_back({r.name, ms});
+        c->last_total_ms += ms;
+    }
+}
+
+zk_status ensure_workspace(zk_ctx* c, uint32_t C);
+
+struct Carver {
+    uint8_t* base;
+    size_t off = 0;
+    explicit Carver(uint8_t* b) : base(b) {}
+    void* take(size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        return p;
+    }
+    Soa soa(size_t elems) { return Soa{(uint32_t*)take(elems * 36), (uint32_t)elems}; }
+    Soa3 soa3(size_t elems) { return Soa3{soa(elems), soa(elems), soa(elems)}; }
+    TomList list(size_t cap) {
+        TomList L;
+        L.v = soa(cap), L.r = soa(cap), L.proj = soa3(cap), L.ax = soa(cap), L.ay = soa(cap), L.cap = (uint32_t)cap;
+        return L;
+    }
+};

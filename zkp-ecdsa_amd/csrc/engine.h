@@ -116,6 +116,50 @@ struct Workspace {
     RngCtx rng;
 };
 
+// ------------------------------------------------------------------ verifier workspace
+#define VK 20             // reps checked by verifySignatureList (zkpAttestList.ts:177)
+#define V_SLOT_TERMS 36   // 10 x 256-bit + 26 x 128-bit terms per checked rep
+struct Soa4 {
+    Soa x, y, z, t;
+};
+struct VTerms {           // terms of the "sum s_i P_i = identity" checks: niels point on the a=1 image + plain scalar
+    Soa nx, ny, ndt, sc;
+};
+struct VWork {
+    uint32_t C, sec, n;
+    int32_t* st;          // [C] structural status (deserialisation)
+    int32_t* exp_st;      // [C] exceptions of verifyExp
+    uint32_t* okflags;    // [C] bit 3: GKProof length mismatch (verifyMembership returns false)
+    uint32_t* zcnt;       // [C]
+    uint32_t* hbits;      // [C][4] challenge bits of the header (layout)
+    uint32_t* chal;       // [C][4] recomputed Exp challenge
+    uint32_t* gkx;        // [C][3]
+    uint32_t* idx;        // [C][VK] checked rep index | bit << 8
+    uint32_t* vc;         // [C*VK][6][3] sub-proof challenges
+    TomList vd;           // [C*VK*5] derived commitments (proj + affine)
+    Soa gk_f, gk_g;       // [n*C] f_j, x - f_j (Montgomery)
+    Soa gk_total;         // [C]
+    VTerms slot_terms, gk_terms, misc_terms;
+    Soa4 slot_acc, gk_acc, misc_acc;
+    Soa sSg, sSh, sSkx, sSky, sSR, sSH, sSL;   // per slot partial sums
+    Soa pSR, pSH, pSL;                         // per proof (mod n)
+    Soa pa_x, pa_y, pa_sc;                     // P-256 A terms [C*VK]
+    Soa3 pacc;                                 // [C*4]
+    Soa clx, cly;                              // Clambda (Montgomery affine)
+};
+void launch_v_header_validate(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
+void launch_v_front(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* msg, uint64_t first);
+void launch_v_challenges_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first);
+void launch_v_exp_points(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
+void launch_v_t1_scalars(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
+void launch_v_derived(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
+void launch_v_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
+void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, uint32_t count, uint32_t N, const uint8_t* proofs, const uint64_t* off, uint64_t first, const Soa& res);
+void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first);
+void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out);
+void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count);
+void launch_v_final(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first);
+
 // chunk inputs (device pointers, already offset to the chunk's first proof)
 struct ChunkIn {
     const uint8_t* msg;

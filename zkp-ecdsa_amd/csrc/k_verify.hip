@@ -1,0 +1,917 @@
+// verifySignatureList on the GPU (src/zkpAttestList.ts:147-184): verifyMembership (src/proofGK/gk.ts:197-262) and
+// verifyExp with secparam 20 (src/exp/exp.ts:233-349) including aggregatePointAdd / aggregateMult /
+// aggregateEquality (src/exp/pointAdd.ts:199-259, src/commit/mult.ts:148-175, src/commit/equality.ts:94-116).
+//
+// The reference batches every verification equation into "sum of scalar*point = identity" checks with fresh random
+// scalars (Relation.drain, src/curves/multimult.ts:168-173) and evaluates them with Bos-Coster (multimult.ts:61-89).
+// Only the boolean is observable, so the engine uses its own 128-bit randomisers and evaluates the same three sums
+// (membership, Exp over Tom-256, Exp over P-256) as interleaved (Straus) double-and-add, one group of <= 36 terms per
+// lane with shared doublings; fixed-base parts (g, h, G, h_NIST, R) go through the comb tables.  Which 20 of the sec
+// reps are checked follows the reference's generateIndices (exp.ts:95-109) under the verifier-RNG contract
+// (fill k = SHA-256(vseed || be64(k)); randomScalar takes 32 bytes, rnd(small) takes 1 byte), so a proof with
+// SOME bad reps gets the same verdict as the reference/oracle for the same verifier seed.
+#include "engine.h"
+
+typedef Fe<ModQ, 1> Sq;
+typedef Fe<ModN, 1> Sn;
+typedef Fe<ModT, 1> St;
+
+// ------------------------------------------------------------------ byte parsing
+ZK_DEV void ld_words_be(const uint8_t* p, int nw, uint32_t* w) {
+    const uint32_t* q = (const uint32_t*)p;
+    for (int i = 0; i < nw; i++) w[i] = bswap32(q[nw - 1 - i]);
+}
+ZK_DEV Sq ld_scalar_q(const uint8_t* p) {
+    uint32_t w[8];
+    load_be32(p, w);
+    return fe_from_words256_reduce<ModQ>(w);  // Scalar ctor reduces (group.ts:164-167)
+}
+ZK_DEV Sn ld_scalar_n(const uint8_t* p) {
+    uint32_t w[8];
+    load_be32(p, w);
+    return fe_from_words256_reduce<ModN>(w);
+}
+// 72-byte Tom point -> plain limbs; false if a coordinate is >= t (edwards.ts:74-77)
+ZK_DEV bool ld_tom_bytes(const uint8_t* p, St& x, St& y) {
+    uint32_t xw[9], yw[9];
+    ld_words_be(p, 9, xw);
+    ld_words_be(p + 36, 9, yw);
+    bool ok = !words_geq<9>(xw, ModT::mod32) && !words_geq<9>(yw, ModT::mod32);
+    limbs_from_words<9>(x.l, xw);
+    limbs_from_words<9>(y.l, yw);
+    return ok;
+}
+ZK_DEV bool tom_bytes_valid(const uint8_t* p) {  // edwards.ts:204-209 afterJson: range + curve equation
+    uint32_t xw[9], yw[9];
+    ld_words_be(p, 9, xw);
+    ld_words_be(p + 36, 9, yw);
+    TomPt t;
+    return tom_from_affine_words(t, xw, yw);
+}
+ZK_DEV bool p256_bytes_valid(const uint8_t* p) {  // weier.ts:256-260
+    uint32_t xw[8], yw[8];
+    load_be32(p, xw);
+    load_be32(p + 32, yw);
+    P256Aff a;
+    a.x = fe_to_mont(fe_from_words256_reduce<ModQ>(xw));
+    a.y = fe_to_mont(fe_from_words256_reduce<ModQ>(yw));
+    return p256_on_curve(a);
+}
+ZK_DEV uint64_t v_proof_size(uint32_t sec, uint32_t n, uint32_t z) {
+    return (uint64_t)ZK_FIXED + (uint64_t)ZK_REP_HEAD * sec + (uint64_t)ZK_PADD_SZ * z + (uint64_t)n * (4 * 72 + 3 * 32) + 32;
+}
+ZK_DEV const uint8_t* v_gk_base(const VWork& V, const uint8_t* pr, uint32_t p) {
+    return pr + ZK_FIXED + (uint64_t)ZK_REP_HEAD * V.sec + (uint64_t)ZK_PADD_SZ * V.zcnt[p];
+}
+
+// ------------------------------------------------------------------ header + structural validation
+__global__ void __launch_bounds__(256) k_v_header(VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    uint32_t p = gtid();
+    if (p >= count) return;
+    uint64_t o0 = off[first + p], o1 = off[first + p + 1];
+    const uint8_t* pr = proofs + o0;
+    int32_t st = ZK_OK;
+    uint32_t bits[4] = {0, 0, 0, 0};
+    uint32_t z = 0;
+    V.okflags[p] = 0;
+    if (o1 < o0 + ZK_HDR || (o0 & 3)) st = ZK_E_BAD_ENCODING;
+    else {
+        const uint32_t* h = (const uint32_t*)pr;
+        uint32_t total = bswap32(h[1]), sec = bswap32(h[2]), n = bswap32(h[3]);
+        bits[0] = bswap32(h[7]), bits[1] = bswap32(h[6]), bits[2] = bswap32(h[5]), bits[3] = bswap32(h[4]);
+        if (h[0] != 0x31414b5au || total != o1 - o0) st = ZK_E_BAD_ENCODING;
+        else if (sec != V.sec) st = sec < VK ? ZK_E_SECLEVEL : ZK_E_BAD_ENCODING;  // exp.ts:243-245 / params mismatch
+        else {
+            for (uint32_t b = V.sec; b < 128; b++)
+                if ((bits[b >> 5] >> (b & 31)) & 1) st = ZK_E_BAD_ENCODING;
+            z = zeros_below(bits, V.sec);
+            // a GKProof of the wrong length is "return false" in the reference (gk.ts:208-218), not an exception
+            if (n != V.n) V.okflags[p] |= 8;
+            else if (total != v_proof_size(V.sec, V.n, z)) st = ZK_E_BAD_ENCODING;
+        }
+    }
+    V.st[p] = st;
+    V.zcnt[p] = z;
+#pragma unroll
+    for (int i = 0; i < 4; i++) V.hbits[4 * p + i] = bits[i];
+}
+// every point of the proof must deserialise (on curve, coordinates in range): thread (proof, rep) and one extra for
+// the fixed part + GK section
+__global__ void __launch_bounds__(256) k_v_validate(VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    uint32_t t = gtid(), per = V.sec + 1;
+    if (t >= count * per) return;
+    uint32_t p = t / per, j = t % per;
+    if (V.st[p] != ZK_OK || (V.okflags[p] & 8)) return;
+    const uint8_t* pr = proofs + off[first + p];
+    const uint32_t* hb = V.hbits + 4 * p;
+    bool ok = true;
+    if (j == V.sec) {
+        ok = p256_bytes_valid(pr + 32) && p256_bytes_valid(pr + 96) && tom_bytes_valid(pr + 160) && tom_bytes_valid(pr + 232);
+        const uint8_t* gk = v_gk_base(V, pr, p);
+        for (uint32_t k = 0; k < 4 * V.n; k++) ok = ok && tom_bytes_valid(gk + 72 * k);
+    } else {
+        const uint8_t* rep = pr + rep_offset(hb, j);
+        ok = p256_bytes_valid(rep) && tom_bytes_valid(rep + 64) && tom_bytes_valid(rep + 136);
+        if (!((hb[j >> 5] >> (j & 31)) & 1)) {
+            const uint8_t* pa = rep + ZK_REP_HEAD;
+            for (uint32_t k = 0; k < 4; k++) ok = ok && tom_bytes_valid(pa + 72 * k);
+            for (uint32_t m = 0; m < 4; m++)
+                for (uint32_t k = 0; k < 6; k++) ok = ok && tom_bytes_valid(pa + 288 + 656 * m + 72 * k);
+            for (uint32_t k = 0; k < 2; k++) ok = ok && tom_bytes_valid(pa + 2912 + 72 * k) && tom_bytes_valid(pa + 3152 + 72 * k);
+        }
+    }
+    if (!ok) atomicCAS(&V.st[p], ZK_OK, ZK_E_BAD_ENCODING);
+}
+
+// ------------------------------------------------------------------ front: R, Q (zkpAttestList.ts:153-164), kx, ky
+__global__ void __launch_bounds__(64) k_v_front(DevParams P, Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* msg, uint64_t first) {
+    uint32_t p = gtid();
+    if (p >= count) return;
+    W.st[p] = V.st[p];
+    if (V.st[p] != ZK_OK || (V.okflags[p] & 8)) {
+        // keep later kernels on defined data: R = G
+        soa_st(W.Rxm, p, fe_const<ModQ, 2>(P256_GX_M)), soa_st(W.Rym, p, fe_const<ModQ, 2>(P256_GY_M));
+        P256Pt id = p256_identity();
+        soa_st(W.Q.x, p, id.x), soa_st(W.Q.y, p, id.y), soa_st(W.Q.z, p, id.z);
+        return;
+    }
+    const uint8_t* pr = proofs + off[first + p];
+    uint32_t xw[8], yw[8], zw[8];
+    load_be32(pr + 32, xw);
+    load_be32(pr + 64, yw);
+    load_be32(msg + 32 * (first + p), zw);
+    Sq rx = fe_from_words256_reduce<ModQ>(xw), ry = fe_from_words256_reduce<ModQ>(yw);
+    soa_st(W.Rxm, p, fe_to_mont(rx)), soa_st(W.Rym, p, fe_to_mont(ry));
+    // rinv = invMod(R.x, n); z1 = rinv * z; Q = G * z1
+    uint32_t rxw[8];
+    words_from_limbs<8>(rxw, rx.l);
+    Fn2 rxn = fe_to_mont(fe_from_words256_reduce<ModN>(rxw));
+    Fn2 z = fe_to_mont(fe_from_words256_reduce<ModN>(zw));
+    Sn z1 = fe_from_mont(fe_inv<ModN>(rxn) * z);
+    uint32_t kw[8];
+    words_from_limbs<8>(kw, z1.l);
+    P256Pt acc = p256_identity();
+#pragma unroll 1
+    for (int w = 0; w < PFIX_NWIN; w++) {
+        uint32_t d = kw[0] & 255;
+        shr256<8>(kw);
+        const uint32_t* e = P.pfix_G + (size_t)PFIX_ENTRY_WORDS * (w * 256 + d);
+        P256Aff a;
+        for (int l = 0; l < 9; l++) a.x.l[l] = e[l], a.y.l[l] = e[9 + l];
+        P256Pt s = p256_add_mixed(acc, a);
+        acc = p256_select(d != 0, s, acc);
+    }
+    soa_st(W.Q.x, p, acc.x), soa_st(W.Q.y, p, acc.y), soa_st(W.Q.z, p, acc.z);
+}
+
+// ------------------------------------------------------------------ hashing from proof bytes
+ZK_DEV void absorb_tom_bytes(ShaStream& s, const uint8_t* p72) {
+    s.put_byte(4);
+    for (int i = 3; i < 36; i++) s.put_byte(p72[i]);
+    for (int i = 39; i < 72; i++) s.put_byte(p72[i]);
+}
+ZK_DEV void absorb_p256_bytes(ShaStream& s, const uint8_t* p64) {
+    s.put_byte(4);
+    for (int i = 0; i < 64; i++) s.put_byte(p64[i]);
+}
+ZK_DEV void absorb_tom_soa(ShaStream& s, const Soa& ax, const Soa& ay, uint32_t e) {
+    uint32_t w[9];
+    s.put_byte(4);
+    words_from_limbs<9>(w, soa_ld<ModT, 1>(ax, e).l);
+    s.put_be<33>(w);
+    words_from_limbs<9>(w, soa_ld<ModT, 1>(ay, e).l);
+    s.put_be<33>(w);
+}
+ZK_DEV void v_challenge_words(const uint32_t h[8], uint32_t c[4]) {
+    c[0] = (h[1] << 16) | (h[2] >> 16), c[1] = (h[0] << 16) | (h[1] >> 16), c[2] = h[0] >> 16, c[3] = 0;
+}
+// Exp challenge over ALL reps (exp.ts:253-260) and the GK challenge x (gk.ts:220-221)
+__global__ void __launch_bounds__(64) k_v_challenges(VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    __shared__ uint32_t lds[16 * 64];
+    uint32_t p = gtid();
+    bool live = p < count;
+    if (!live) p = count - 1;
+    const uint8_t* pr = proofs + off[first + p];
+    bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8);
+    ShaStream s;
+    uint32_t h[8], c[4];
+    s.init(lds, threadIdx.x, 64);
+    if (good) {
+        const uint32_t* hb = V.hbits + 4 * p;
+        absorb_tom_bytes(s, pr + 160);
+        absorb_tom_bytes(s, pr + 232);
+        for (uint32_t i = 0; i < V.sec; i++) {
+            const uint8_t* rep = pr + rep_offset(hb, i);
+            absorb_p256_bytes(s, rep);
+            absorb_tom_bytes(s, rep + 64);
+            absorb_tom_bytes(s, rep + 136);
+        }
+    }
+    s.finish(h);
+    v_challenge_words(h, c);
+    if (live)
+        for (int i = 0; i < 4; i++) V.chal[4 * p + i] = c[i];
+    s.init(lds, threadIdx.x, 64);
+    if (good) {
+        const uint8_t* gk = v_gk_base(V, pr, p);
+        for (uint32_t k = 0; k < 4 * V.n; k++) absorb_tom_bytes(s, gk + 72 * k);
+    }
+    s.finish(h);
+    v_challenge_words(h, c);
+    if (live) V.gkx[3 * p] = c[0], V.gkx[3 * p + 1] = c[1], V.gkx[3 * p + 2] = c[2];
+}
+
+// ------------------------------------------------------------------ verifier randomness
+ZK_DEV void v_fill(const uint8_t* vseeds, uint64_t gp, uint32_t k, uint32_t w[8]) {  // fill k of the contract, as LE words
+    const uint32_t* sd = (const uint32_t*)(vseeds + 32 * gp);
+    uint32_t m[16], h[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) m[i] = bswap32(sd[i]);
+    m[8] = 0, m[9] = k, m[10] = 0x80000000u, m[11] = 0, m[12] = 0, m[13] = 0, m[14] = 0, m[15] = 320;
+    sha256_iv(h);
+    sha256_compress(h, m);
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = h[7 - i];
+}
+// engine-private 128-bit randomisers: two per SHA-256(vseed || be64(2^32 + idx))
+ZK_DEV void v_rho_pair(const uint8_t* vseeds, uint64_t gp, uint32_t idx, Sq& a, Sq& b) {
+    const uint32_t* sd = (const uint32_t*)(vseeds + 32 * gp);
+    uint32_t m[16], h[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) m[i] = bswap32(sd[i]);
+    m[8] = 1, m[9] = idx, m[10] = 0x80000000u, m[11] = 0, m[12] = 0, m[13] = 0, m[14] = 0, m[15] = 320;
+    sha256_iv(h);
+    sha256_compress(h, m);
+    uint32_t wa[8] = {h[0], h[1], h[2], h[3], 0, 0, 0, 0}, wb[8] = {h[4], h[5], h[6], h[7], 0, 0, 0, 0};
+    limbs_from_words<8>(a.l, wa);
+    limbs_from_words<8>(b.l, wb);
+}
+// generateIndices (exp.ts:95-109): runs after verifyMembership's 2n+1 randomScalar draws (gk.ts:223-259)
+__global__ void __launch_bounds__(64) k_v_sample(VWork V, uint32_t count, const uint8_t* vseeds, uint64_t first) {
+    uint32_t p = gtid();
+    if (p >= count) return;
+    uint64_t gp = first + p;
+    uint32_t k = 0, w[8];
+    for (uint32_t i = 0; i < 2 * V.n + 1; i++) {  // randomScalar(): retry while >= q
+        do {
+            v_fill(vseeds, gp, k++, w);
+        } while (words_geq<8>(w, ModQ::mod32));
+    }
+    uint8_t perm[ZK_MAXSEC];
+    for (uint32_t i = 0; i < V.sec; i++) perm[i] = (uint8_t)i;
+    for (uint32_t i = 0; i + 2 < V.sec; i++) {
+        uint32_t range = V.sec - i, v;
+        do {
+            v_fill(vseeds, gp, k++, w);
+            v = w[7] >> 24;  // first byte of the fill
+        } while (v >= range);
+        uint8_t t = perm[i];
+        perm[i] = perm[i + v], perm[i + v] = t;
+    }
+    const uint32_t* c = V.chal + 4 * p;
+    const uint32_t* hb = V.hbits + 4 * p;
+    int32_t st = ZK_OK;
+    for (uint32_t j = 0; j < VK; j++) {
+        uint32_t i = perm[j];
+        uint32_t bit = (c[i >> 5] >> (i & 31)) & 1, hbit = (hb[i >> 5] >> (i & 31)) & 1;
+        V.idx[p * VK + j] = i | (bit << 8);
+        if (bit != hbit && st == ZK_OK) st = ZK_E_PARAMS_NOT_FOUND;  // exp.ts:269-271,301-303
+    }
+    if (st != ZK_OK) V.exp_st[p] = st;
+    else V.exp_st[p] = ZK_OK;
+}
+
+// ------------------------------------------------------------------ Exp: T = alpha*R or T1 = z*R + Q per checked rep (exp.ts:267,299,311)
+ZK_DEV P256Pt v_ld_rtab(const uint32_t* e) {
+    P256Pt a;
+    for (int l = 0; l < 9; l++) a.x.l[l] = e[l], a.y.l[l] = e[9 + l], a.z.l[l] = e[18 + l];
+    return a;
+}
+__global__ void __launch_bounds__(256) k_v_exp_points(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    uint32_t t = gtid();
+    if (t >= count * VK) return;
+    uint32_t p = t / VK;
+    uint32_t iv = V.idx[t], i = iv & 255, bit = iv >> 8;
+    const uint8_t* pr = proofs + off[first + p];
+    P256Pt acc = p256_identity();
+    bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8) && V.exp_st[p] == ZK_OK;
+    if (good) {
+        const uint8_t* rep = pr + rep_offset(V.hbits + 4 * p, i);
+        Sn s = ld_scalar_n(rep + 208);
+        uint32_t kw[8];
+        words_from_limbs<8>(kw, s.l);
+        const uint32_t* rtab = W.rtab + (size_t)p * RTAB_WORDS;
+#pragma unroll 1
+        for (int w = 0; w < RTAB_NWIN; w++) {
+            uint32_t d = kw[0] & 15;
+            shr256<4>(kw);
+            acc = p256_add(acc, v_ld_rtab(rtab + (size_t)RTAB_ENTRY_WORDS * (w * 16 + d)));
+        }
+        if (!bit) {
+            P256Pt q;
+            q.x = soa_ld<ModQ, 8>(W.Q.x, p), q.y = soa_ld<ModQ, 8>(W.Q.y, p), q.z = soa_ld<ModQ, 8>(W.Q.z, p);
+            acc = p256_add(acc, q);
+        }
+    } else {
+        acc.x = fe_const<ModQ, 8>(P256_GX_M), acc.y = fe_const<ModQ, 8>(P256_GY_M), acc.z = fe_one_mont<ModQ>().as<8>();
+    }
+    uint32_t e = t;  // compact: p * VK + j
+    soa_st(W.Tproj.x, e, acc.x), soa_st(W.Tproj.y, e, acc.y), soa_st(W.Tproj.z, e, acc.z);
+}
+// T1x = sx*g + r1*h, T1y = sy*g + r2*h for zero-bit slots (exp.ts:329-330); (0, 0) otherwise
+__global__ void __launch_bounds__(256) k_v_t1_scalars(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    uint32_t t = gtid();
+    if (t >= count * VK) return;
+    uint32_t p = t / VK, j = t % VK;
+    uint32_t iv = V.idx[t], i = iv & 255, bit = iv >> 8;
+    uint32_t e = t, slot = p * (2 + 2 * W.sec) + 2 * j;
+    Sq zero = fe_zero<ModQ>();
+    bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8) && V.exp_st[p] == ZK_OK;
+    if (good && !bit) {
+        const uint8_t* rep = proofs + off[first + p] + rep_offset(V.hbits + 4 * p, i);
+        soa_st(W.la.v, slot, soa_ld<ModQ, 1>(W.Tx, e)), soa_st(W.la.r, slot, ld_scalar_q(rep + 272));
+        soa_st(W.la.v, slot + 1, soa_ld<ModQ, 1>(W.Ty, e)), soa_st(W.la.r, slot + 1, ld_scalar_q(rep + 304));
+    } else {
+        soa_st(W.la.v, slot, zero), soa_st(W.la.r, slot, zero);
+        soa_st(W.la.v, slot + 1, zero), soa_st(W.la.r, slot + 1, zero);
+    }
+}
+// derived commitments needed as hash inputs (pointAdd.ts:210-213,237,250): vd slot (p*VK+j)*5 + {C7, C9, C12, CintX, CintY}
+ZK_DEV TomPt v_tom_from_plain(const St& xp, const St& yp) {
+    TomPt r;
+    Ft2 x = fe_to_mont(xp);
+    r.y = fe_to_mont(yp);
+    r.x = x * fe_const<ModT, 1>(TOM_S_M);
+    r.t = r.x * r.y;
+    r.z = fe_one_mont<ModT>().as<2>();
+    return r;
+}
+ZK_DEV TomPt v_tom_from_bytes(const uint8_t* p72) {
+    St x, y;
+    ld_tom_bytes(p72, x, y);
+    return v_tom_from_plain(x, y);
+}
+__global__ void __launch_bounds__(256) k_v_derived(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    uint32_t t = gtid();
+    if (t >= count * VK * 5) return;
+    uint32_t sl = t / 5, k = t % 5, p = sl / VK, j = sl % VK;
+    uint32_t iv = V.idx[sl], i = iv & 255, bit = iv >> 8;
+    TomPt r = tom_identity();
+    bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8) && V.exp_st[p] == ZK_OK;
+    if (good && !bit) {
+        const uint8_t* pr = proofs + off[first + p];
+        const uint8_t* rep = pr + rep_offset(V.hbits + 4 * p, i);
+        uint32_t la = p * (2 + 2 * W.sec) + 2 * j;
+        TomPt t1x = v_tom_from_plain(soa_ld<ModT, 1>(W.la.ax, la), soa_ld<ModT, 1>(W.la.ay, la));
+        TomPt t1y = v_tom_from_plain(soa_ld<ModT, 1>(W.la.ax, la + 1), soa_ld<ModT, 1>(W.la.ay, la + 1));
+        if (k == 0) r = tom_add(v_tom_from_bytes(pr + 160), tom_neg(t1x));                     // C7 = Px - T1x
+        else if (k == 1) r = tom_add(v_tom_from_bytes(pr + 232), tom_neg(t1y));                // C9 = Py - T1y
+        else if (k == 2) r = tom_add(t1x, tom_neg(v_tom_from_bytes(rep + 64)));                // C12 = T1x - Tx
+        else if (k == 3) r = tom_add(tom_add(v_tom_from_bytes(rep + 64), t1x), v_tom_from_bytes(pr + 160));  // Tx + T1x + Px
+        else r = tom_add(t1y, v_tom_from_bytes(rep + 136));                                    // C4 + C6 = T1y + Ty
+    }
+    soa_st(V.vd.proj.x, t, r.x), soa_st(V.vd.proj.y, t, r.y), soa_st(V.vd.proj.z, t, r.z);
+}
+// the six sub-proof challenges of a zero-bit slot (mult.ts:156, equality.ts:101); thread = h * nslots + slot
+__global__ void __launch_bounds__(256) k_v_padd_hash(DevParams P, Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    __shared__ uint32_t lds[16 * 256];
+    uint32_t t = gtid(), nsl = count * VK;
+    bool live = t < nsl * 6;
+    if (!live) t = nsl * 6 - 1;
+    uint32_t h = t / nsl, sl = t % nsl, p = sl / VK;
+    uint32_t iv = V.idx[sl], i = iv & 255, bit = iv >> 8;
+    bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8) && V.exp_st[p] == ZK_OK && !bit;
+    ShaStream s;
+    s.init(lds, threadIdx.x, 256);
+    if (good) {
+        const uint8_t* pa = proofs + off[first + p] + rep_offset(V.hbits + 4 * p, i) + ZK_REP_HEAD;
+        const uint8_t *c8 = pa, *c10 = pa + 72, *c11 = pa + 144, *c13 = pa + 216;
+        uint32_t d = sl * 5;
+        if (h < 4) {
+            const uint8_t* pts = pa + 288 + 656 * h;
+            if (h == 0) {
+                absorb_tom_soa(s, V.vd.ax, V.vd.ay, d + 0), absorb_tom_bytes(s, c8);
+                uint32_t w[9];
+                s.put_byte(4);
+                words_from_limbs<9>(w, P.tom_g_aff);
+                s.put_be<33>(w);
+                words_from_limbs<9>(w, P.tom_g_aff + 9);
+                s.put_be<33>(w);
+            } else if (h == 1) absorb_tom_bytes(s, c8), absorb_tom_soa(s, V.vd.ax, V.vd.ay, d + 1), absorb_tom_bytes(s, c10);
+            else if (h == 2) absorb_tom_bytes(s, c10), absorb_tom_bytes(s, c10), absorb_tom_bytes(s, c11);
+            else absorb_tom_bytes(s, c10), absorb_tom_soa(s, V.vd.ax, V.vd.ay, d + 2), absorb_tom_bytes(s, c13);
+            for (uint32_t k = 0; k < 6; k++) absorb_tom_bytes(s, pts + 72 * k);
+        } else {
+            const uint8_t* e = pa + (h == 4 ? 2912 : 3152);
+            absorb_tom_bytes(s, h == 4 ? c11 : c13);
+            absorb_tom_soa(s, V.vd.ax, V.vd.ay, d + (h == 4 ? 3 : 4));
+            absorb_tom_bytes(s, e), absorb_tom_bytes(s, e + 72);
+        }
+    }
+    uint32_t dg[8], c[4];
+    s.finish(dg);
+    v_challenge_words(dg, c);
+    if (live) {
+        uint32_t* o = V.vc + ((size_t)sl * 6 + h) * 3;
+        o[0] = c[0], o[1] = c[1], o[2] = c[2];
+    }
+}
+
+// ------------------------------------------------------------------ GK total (gk.ts:239-250), fold form:
+// layer' [i] = (x - f_j) * layer[2i] + f_j * layer[2i+1]; tile of 2^T ring elements per workgroup, levels through LDS
+#define VGK_T 11
+__global__ void __launch_bounds__(256) k_v_gk_fg(VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    uint32_t t = gtid();
+    if (t >= count * V.n) return;
+    uint32_t p = t / V.n, j = t % V.n;
+    Sq f = fe_zero<ModQ>(), g = fe_zero<ModQ>();
+    if (V.st[p] == ZK_OK && !(V.okflags[p] & 8)) {
+        const uint8_t* sc = v_gk_base(V, proofs + off[first + p], p) + 4 * 72 * V.n;
+        f = ld_scalar_q(sc + 32 * j);
+        uint32_t xw[8] = {V.gkx[3 * p], V.gkx[3 * p + 1], V.gkx[3 * p + 2], 0, 0, 0, 0, 0};
+        Sq x;
+        limbs_from_words<8>(x.l, xw);
+        g = fe_sub_mod(x, f);
+    }
+    soa_st(V.gk_f, j * V.C + p, fe_to_mont(f));
+    soa_st(V.gk_g, j * V.C + p, fe_to_mont(g));
+}
+ZK_DEV void v_gk_lds_levels(uint32_t*& A, uint32_t*& B, uint32_t cnt, uint32_t j0, uint32_t j1, const VWork& V, uint32_t p, uint32_t stride) {
+    for (uint32_t j = j0; j < j1; j++) {
+        uint32_t nout = cnt >> 1;
+        Fe<ModQ, 2> f = soa_ld<ModQ, 2>(V.gk_f, j * V.C + p), g = soa_ld<ModQ, 2>(V.gk_g, j * V.C + p);
+        for (uint32_t m = threadIdx.x; m < nout; m += blockDim.x) {
+            Fe<ModQ, 4> ev, od;
+            for (int l = 0; l < NLIMB; l++) ev.l[l] = A[l * stride + 2 * m], od.l[l] = A[l * stride + 2 * m + 1];
+            auto r = g * ev + f * od;  // < 4M, normalised
+            for (int l = 0; l < NLIMB; l++) B[l * stride + m] = r.l[l];
+        }
+        __syncthreads();
+        uint32_t* tmp = A;
+        A = B, B = tmp;
+        cnt = nout;
+    }
+}
+__global__ void __launch_bounds__(256) k_v_gk_tile(VWork V, Soa ring, uint32_t T, uint32_t ntiles, Soa res) {
+    __shared__ uint32_t bufA[NLIMB * (1u << (VGK_T - 3))];
+    __shared__ uint32_t bufB[NLIMB * (1u << (VGK_T - 3))];
+    uint32_t p = blockIdx.x / ntiles, tile = blockIdx.x % ntiles, t = threadIdx.x;
+    uint32_t lanes = 1u << (T - 3), stride = 1u << (VGK_T - 3);
+    if (t < lanes) {
+        uint32_t base = (tile << T) + 8 * t;
+        Fe<ModQ, 4> v[8];
+        for (int i = 0; i < 8; i++) v[i] = soa_ld<ModQ, 1>(ring, base + i).as<4>();
+#pragma unroll
+        for (int lev = 0; lev < 3; lev++) {
+            Fe<ModQ, 2> f = soa_ld<ModQ, 2>(V.gk_f, lev * V.C + p), g = soa_ld<ModQ, 2>(V.gk_g, lev * V.C + p);
+#pragma unroll
+            for (int i = 0; i < (4 >> lev); i++) v[i] = g * v[2 * i] + f * v[2 * i + 1];
+        }
+        for (int l = 0; l < NLIMB; l++) bufA[l * stride + t] = v[0].l[l];
+    }
+    __syncthreads();
+    uint32_t *A = bufA, *B = bufB;
+    v_gk_lds_levels(A, B, lanes, 3, T, V, p, stride);
+    if (t == 0) {
+        Fe<ModQ, 4> r;
+        for (int l = 0; l < NLIMB; l++) r.l[l] = A[l * stride];
+        Sq c = fe_canon(r);
+        if (ntiles == 1) soa_st(V.gk_total, p, c);
+        else soa_st(res, p * ntiles + tile, c);
+    }
+}
+__global__ void __launch_bounds__(256) k_v_gk_finish(VWork V, uint32_t T, uint32_t ntiles, Soa res) {
+    __shared__ uint32_t bufA[NLIMB * (1u << (VGK_T - 3))];
+    __shared__ uint32_t bufB[NLIMB * (1u << (VGK_T - 3))];
+    uint32_t p = blockIdx.x, stride = 1u << (VGK_T - 3);
+    for (uint32_t m = threadIdx.x; m < ntiles; m += blockDim.x) {
+        Sq c = soa_ld<ModQ, 1>(res, p * ntiles + m);
+        for (int l = 0; l < NLIMB; l++) bufA[l * stride + m] = c.l[l];
+    }
+    __syncthreads();
+    uint32_t *A = bufA, *B = bufB;
+    v_gk_lds_levels(A, B, ntiles, T, V.n, V, p, stride);
+    if (threadIdx.x == 0) {
+        Fe<ModQ, 4> r;
+        for (int l = 0; l < NLIMB; l++) r.l[l] = A[l * stride];
+        soa_st(V.gk_total, p, fe_canon(r));
+    }
+}
+// tiny rings (n < 3): one thread per proof
+__global__ void k_v_gk_small(VWork V, Soa ring, uint32_t count) {
+    uint32_t p = gtid();
+    if (p >= count) return;
+    Fe<ModQ, 4> v[4];
+    uint32_t N = 1u << V.n;
+    for (uint32_t i = 0; i < 4; i++) v[i] = soa_ld<ModQ, 1>(ring, i < N ? i : 0).as<4>();
+    for (uint32_t j = 0; j < V.n; j++) {
+        Fe<ModQ, 2> f = soa_ld<ModQ, 2>(V.gk_f, j * V.C + p), g = soa_ld<ModQ, 2>(V.gk_g, j * V.C + p);
+        for (uint32_t i = 0; i < (N >> (j + 1)); i++) v[i] = g * v[2 * i] + f * v[2 * i + 1];
+    }
+    soa_st(V.gk_total, p, fe_canon(v[0]));
+}
+void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, uint32_t count, uint32_t N, const uint8_t* proofs, const uint64_t* off, uint64_t first, const Soa& res) {
+    uint32_t nt = count * V.n;
+    hipLaunchKernelGGL(k_v_gk_fg, dim3((nt + 255) / 256), dim3(256), 0, s, V, count, proofs, off, first);
+    if (V.n < 3) {
+        hipLaunchKernelGGL(k_v_gk_small, dim3((count + 63) / 64), dim3(64), 0, s, V, ring, count);
+        return;
+    }
+    uint32_t T = V.n < VGK_T ? V.n : VGK_T, ntiles = N >> T;
+    hipLaunchKernelGGL(k_v_gk_tile, dim3(count * ntiles), dim3(256), 0, s, V, ring, T, ntiles, res);
+    if (ntiles > 1) hipLaunchKernelGGL(k_v_gk_finish, dim3(count), dim3(256), 0, s, V, T, ntiles, res);
+}
+
+// ------------------------------------------------------------------ term construction
+// A Tom term = niels form of the point on the a=1 image (x', y, d'x'y, Montgomery) + a plain scalar.  Group gidx owns
+// terms [k * ngroups + gidx]; the first n256 terms of a group have 256-bit scalars, the rest 128-bit.
+ZK_DEV void put_term(const VTerms& L, uint32_t idx, const St& xp, const St& yp, bool negate, const Sq& sc) {
+    Ft2 x = fe_to_mont(xp) * fe_const<ModT, 1>(TOM_S_M);
+    Ft2 y = fe_to_mont(yp);
+    if (negate) x = fe_reduce(fe_neg(x));
+    Ft2 dt = (x * y) * fe_const<ModT, 1>(TOM_D1_M);
+    soa_st(L.nx, idx, x), soa_st(L.ny, idx, y), soa_st(L.ndt, idx, dt), soa_st(L.sc, idx, sc);
+}
+ZK_DEV void put_term_bytes(const VTerms& L, uint32_t idx, const uint8_t* p72, bool negate, const Sq& sc) {
+    St x, y;
+    ld_tom_bytes(p72, x, y);
+    put_term(L, idx, x, y, negate, sc);
+}
+ZK_DEV void put_term_null(const VTerms& L, uint32_t idx) {  // identity with scalar 0
+    soa_st(L.nx, idx, fe_zero<ModT>().as<2>()), soa_st(L.ny, idx, fe_one_mont<ModT>().as<2>());
+    soa_st(L.ndt, idx, fe_zero<ModT>().as<2>()), soa_st(L.sc, idx, fe_zero<ModQ>());
+}
+ZK_DEV Sq mulq(const Sq& a, const Sq& b) { return fe_mul_mod(a, b); }
+ZK_DEV Sq addq(const Sq& a, const Sq& b) { return fe_add_mod(a, b); }
+ZK_DEV Sq chalq(const uint32_t* c3) {
+    uint32_t w[8] = {c3[0], c3[1], c3[2], 0, 0, 0, 0, 0};
+    Sq r;
+    limbs_from_words<8>(r.l, w);
+    return r;
+}
+struct SlotAcc {  // coefficients accumulated for shared points of one slot
+    Sq g, h, c8, c10, c11, c13, w7, w9, w12, wX, wY;
+};
+// aggregateMult (mult.ts:158-173) with randomisers r[0..4]; point coefficients returned through references.
+// pts: C4, Ax, Ay, Az, A41, A42 then 7 scalars.  Term slots: 256-bit C4 at i256, 128-bit A's at i128..i128+4
+ZK_DEV void v_mult(const VTerms& L, uint32_t gidx, uint32_t ng, uint32_t i256, uint32_t i128, const uint8_t* pi, const Sq& c, const Sq* r,
+                   Sq& wCx, Sq& wCy, Sq& wCz, Sq& g, Sq& h) {
+    const uint8_t* sc = pi + 432;
+    Sq tx = ld_scalar_q(sc), ty = ld_scalar_q(sc + 32), tz = ld_scalar_q(sc + 64), trx = ld_scalar_q(sc + 96), try_ = ld_scalar_q(sc + 128),
+       trz = ld_scalar_q(sc + 160), tr4 = ld_scalar_q(sc + 192);
+    wCx = addq(wCx, mulq(r[0], c));
+    wCy = addq(wCy, addq(mulq(r[1], c), mulq(r[4], tx)));
+    wCz = addq(wCz, mulq(r[2], c));
+    g = addq(g, addq(addq(mulq(r[0], tx), mulq(r[1], ty)), mulq(addq(r[2], r[3]), tz)));
+    h = addq(h, addq(addq(mulq(r[0], trx), mulq(r[1], try_)), addq(mulq(r[2], trz), mulq(r[3], tr4))));
+    put_term_bytes(L, i256 * ng + gidx, pi, false, mulq(addq(r[3], r[4]), c));  // C4: (r4 + r5) c
+    for (int k = 0; k < 5; k++) put_term_bytes(L, (i128 + k) * ng + gidx, pi + 72 * (k + 1), true, r[k]);  // -r_k * A
+}
+ZK_DEV void v_eq(const VTerms& L, uint32_t gidx, uint32_t ng, uint32_t i128, const uint8_t* pi, const Sq& c, const Sq* r, Sq& wC1, Sq& wC2, Sq& g, Sq& h) {
+    const uint8_t* sc = pi + 144;
+    Sq tx = ld_scalar_q(sc), tr1 = ld_scalar_q(sc + 32), tr2 = ld_scalar_q(sc + 64);
+    wC1 = addq(wC1, mulq(r[0], c));
+    wC2 = addq(wC2, mulq(r[1], c));
+    g = addq(g, mulq(addq(r[0], r[1]), tx));
+    h = addq(h, addq(mulq(r[0], tr1), mulq(r[1], tr2)));
+    put_term_bytes(L, i128 * ng + gidx, pi, true, r[0]);
+    put_term_bytes(L, (i128 + 1) * ng + gidx, pi + 72, true, r[1]);
+}
+// one thread per checked slot: all Tom terms of the slot (group gidx = slot), partial sums for shared points, and the
+// slot's P-256 contribution.  Layout of a slot group: 256-bit terms 0..9 = C8, C10, C11, C13, Tx, Ty, C4 x4;
+// 128-bit terms 10..35 = 4 x (Ax, Ay, Az, A41, A42), pix A1, A2, piy A1, A2, then Tx, Ty of a bit-1 slot.
+__global__ void __launch_bounds__(64) k_v_slot_terms(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
+    uint32_t sl = gtid(), ng = V.C * VK;
+    if (sl >= count * VK) return;
+    uint32_t p = sl / VK, j = sl % VK;
+    uint32_t iv = V.idx[sl], i = iv & 255, bit = iv >> 8;
+    const VTerms& L = V.slot_terms;
+    bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8) && V.exp_st[p] == ZK_OK;
+    Sq zero = fe_zero<ModQ>();
+    Sq Sg = zero, Sh = zero, Skx = zero, Sky = zero;
+    Sn SR = fe_zero<ModN>(), SH = fe_zero<ModN>(), SL = fe_zero<ModN>();
+    for (uint32_t k = 0; k < V_SLOT_TERMS; k++) put_term_null(L, k * ng + sl);
+    uint32_t pa_idx = p * VK + j;  // P-256 A-term index
+    if (!good) {
+        soa_st(V.pa_x, pa_idx, fe_const<ModQ, 2>(P256_GX_M)), soa_st(V.pa_y, pa_idx, fe_const<ModQ, 2>(P256_GY_M)), soa_st(V.pa_sc, pa_idx, fe_zero<ModN>());
+    } else {
+        const uint8_t* pr = proofs + off[first + p];
+        const uint8_t* rep = pr + rep_offset(V.hbits + 4 * p, i);
+        uint64_t gp = first + p;
+        uint32_t e = sl;
+        Sq sx = soa_ld<ModQ, 1>(W.Tx, e), sy = soa_ld<ModQ, 1>(W.Ty, e);  // affine T (bit 1) or T1 + Q (bit 0)
+        Sq r[26];
+        for (uint32_t k = 0; k < 13; k++) v_rho_pair(vseeds, gp, (j << 8) | k, r[2 * k], r[2 * k + 1]);
+        // ---- P-256 relation (exp.ts:270-276 / 305-317) with randomiser r[24] (mod n): the T term is (rho * s) * R
+        {
+            Sn rn;
+            for (int l = 0; l < NLIMB; l++) rn.l[l] = r[24].l[l];
+            Sn s0 = ld_scalar_n(rep + 208), s1 = ld_scalar_n(rep + 240);
+            SR = fe_mul_mod(rn, s0);
+            SH = fe_mul_mod(rn, s1);
+            if (!bit) SL = rn;
+            // -rho * A  ==  rho * (-A)
+            uint32_t xw[8], yw[8];
+            load_be32(rep, xw);
+            load_be32(rep + 32, yw);
+            Fq2 ax = fe_to_mont(fe_from_words256_reduce<ModQ>(xw));
+            Fq2 ay = fe_reduce(fe_neg(fe_to_mont(fe_from_words256_reduce<ModQ>(yw))));
+            soa_st(V.pa_x, pa_idx, ax), soa_st(V.pa_y, pa_idx, ay), soa_st(V.pa_sc, pa_idx, rn);
+        }
+        if (bit) {
+            // relTx, relTy (exp.ts:287-297): r0 (sx g + beta2 h - Tx), r1 (sy g + beta3 h - Ty)
+            Sq b2 = ld_scalar_q(rep + 272), b3 = ld_scalar_q(rep + 304);
+            Sg = addq(mulq(r[0], sx), mulq(r[1], sy));
+            Sh = addq(mulq(r[0], b2), mulq(r[1], b3));
+            put_term_bytes(L, 34 * ng + sl, rep + 64, true, r[0]);
+            put_term_bytes(L, 35 * ng + sl, rep + 136, true, r[1]);
+        } else {
+            const uint8_t* pa = rep + ZK_REP_HEAD;
+            const uint32_t* cw = V.vc + (size_t)sl * 18;
+            Sq c8 = chalq(cw), c10 = chalq(cw + 3), c11 = chalq(cw + 6), c13 = chalq(cw + 9), cx = chalq(cw + 12), cy = chalq(cw + 15);
+            Sq w7 = zero, w8 = zero, w9 = zero, w10 = zero, w11 = zero, w12 = zero, w13 = zero, w14 = zero, wX = zero, wY = zero;
+            // pointAdd.ts:215-255
+            v_mult(L, sl, ng, 6, 10, pa + 288, c8, r + 0, w7, w8, w14, Sg, Sh);                  // pi8 : (C7, C8, C14 = g)
+            v_mult(L, sl, ng, 7, 15, pa + 288 + 656, c10, r + 5, w8, w9, w10, Sg, Sh);           // pi10: (C8, C9, C10)
+            {                                                                                      // pi11: (C10, C10, C11)
+                Sq wa = zero, wb = zero;
+                v_mult(L, sl, ng, 8, 20, pa + 288 + 2 * 656, c11, r + 10, wa, wb, w11, Sg, Sh);
+                w10 = addq(w10, addq(wa, wb));
+            }
+            v_eq(L, sl, ng, 30, pa + 2912, cx, r + 15, w11, wX, Sg, Sh);                          // pix : (C11, C3 + C1 + C2)
+            v_mult(L, sl, ng, 9, 25, pa + 288 + 3 * 656, c13, r + 17, w10, w12, w13, Sg, Sh);    // pi13: (C10, C12, C13)
+            v_eq(L, sl, ng, 32, pa + 3152, cy, r + 22, w13, wY, Sg, Sh);                          // piy : (C13, C4 + C6)
+            // redistribute the derived commitments: C7 = Px - T1x, C9 = Py - T1y, C12 = T1x - Tx, CintX = Tx + T1x + Px,
+            // CintY = T1y + Ty, C14 = g, T1x = sx g + r1 h, T1y = sy g + r2 h
+            Sq r1 = ld_scalar_q(rep + 272), r2 = ld_scalar_q(rep + 304);
+            Sq u1 = addq(fe_sub_mod(w12, w7), wX), u2 = fe_sub_mod(wY, w9);
+            Sg = addq(Sg, addq(w14, addq(mulq(u1, sx), mulq(u2, sy))));
+            Sh = addq(Sh, addq(mulq(u1, r1), mulq(u2, r2)));
+            Skx = addq(w7, wX), Sky = w9;
+            put_term_bytes(L, 0 * ng + sl, pa, false, w8);
+            put_term_bytes(L, 1 * ng + sl, pa + 72, false, w10);
+            put_term_bytes(L, 2 * ng + sl, pa + 144, false, w11);
+            put_term_bytes(L, 3 * ng + sl, pa + 216, false, w13);
+            put_term_bytes(L, 4 * ng + sl, rep + 64, false, fe_sub_mod(wX, w12));  // Tx
+            put_term_bytes(L, 5 * ng + sl, rep + 136, false, wY);                 // Ty
+        }
+    }
+    soa_st(V.sSg, sl, Sg), soa_st(V.sSh, sl, Sh), soa_st(V.sSkx, sl, Skx), soa_st(V.sSky, sl, Sky);
+    soa_st(V.sSR, sl, SR), soa_st(V.sSH, sl, SH), soa_st(V.sSL, sl, SL);
+}
+// one thread per proof: GK relations (gk.ts:223-259) -> groups of the gk list (4 per pair of bit positions: cl, cd 256-bit;
+// ca, cb 128-bit) and the per-proof totals for the shared points.
+// gk group q (q < ceil(n/2)) holds i = 2q, 2q+1: 256-bit terms {cl_i, cd_i} x2 = 0..3, 128-bit {ca_i, cb_i} x2 = 4..7.
+// misc group (index = p): 256-bit terms: 0 = Px (membership coefficient), 1 = Px (Exp), 2 = Py (Exp).
+__global__ void __launch_bounds__(64) k_v_proof_terms(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
+    uint32_t p = gtid();
+    if (p >= count) return;
+    uint32_t n = V.n, nq = (n + 1) / 2, ngk = V.C * nq, nm = V.C;
+    bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8);
+    Sq zero = fe_zero<ModQ>();
+    for (uint32_t q = 0; q < nq; q++)
+        for (uint32_t k = 0; k < 8; k++) put_term_null(V.gk_terms, k * ngk + p * nq + q);
+    for (uint32_t k = 0; k < 3; k++) put_term_null(V.misc_terms, k * nm + p);
+    Sq mg = zero, mh = zero;    // membership g, h coefficients
+    Sq eg = zero, eh = zero, ekx = zero, eky = zero;
+    Sn SR = fe_zero<ModN>(), SH = fe_zero<ModN>(), SL = fe_zero<ModN>();
+    for (uint32_t j = 0; j < VK; j++) {
+        uint32_t sl = p * VK + j;
+        eg = addq(eg, soa_ld<ModQ, 1>(V.sSg, sl)), eh = addq(eh, soa_ld<ModQ, 1>(V.sSh, sl));
+        ekx = addq(ekx, soa_ld<ModQ, 1>(V.sSkx, sl)), eky = addq(eky, soa_ld<ModQ, 1>(V.sSky, sl));
+        SR = fe_add_mod(SR, soa_ld<ModN, 1>(V.sSR, sl)), SH = fe_add_mod(SH, soa_ld<ModN, 1>(V.sSH, sl)), SL = fe_add_mod(SL, soa_ld<ModN, 1>(V.sSL, sl));
+    }
+    if (good) {
+        const uint8_t* pr = proofs + off[first + p];
+        const uint8_t* gk = v_gk_base(V, pr, p);
+        const uint8_t* sc = gk + 4 * 72 * n;
+        uint64_t gp = first + p;
+        Sq x = chalq(V.gkx + 3 * p);
+        Sq rF, dummy;
+        v_rho_pair(vseeds, gp, 0x10000u, rF, dummy);
+        Sq xp = fe_zero<ModQ>();
+        xp.l[0] = 1;  // x^i
+        for (uint32_t i = 0; i < n; i++) {
+            Sq r0, r1;
+            v_rho_pair(vseeds, gp, 0x10001u + i, r0, r1);
+            Sq f = ld_scalar_q(sc + 32 * i), za = ld_scalar_q(sc + 32 * (n + i)), zb = ld_scalar_q(sc + 32 * (2 * n + i));
+            uint32_t grp = p * nq + (i >> 1), o = (i & 1) * 2;
+            // rel0: x cl + ca - f g - za h ; rel1: (x - f) cl + cb - zb h
+            put_term_bytes(V.gk_terms, (o + 0) * ngk + grp, gk + 72 * i, false, addq(mulq(r0, x), mulq(r1, fe_sub_mod(x, f))));
+            put_term_bytes(V.gk_terms, (4 + o) * ngk + grp, gk + 72 * (n + i), false, r0);
+            put_term_bytes(V.gk_terms, (5 + o) * ngk + grp, gk + 72 * (2 * n + i), false, r1);
+            // relFinal: -x^i cd_i
+            put_term_bytes(V.gk_terms, (o + 1) * ngk + grp, gk + 72 * (3 * n + i), true, mulq(rF, xp));
+            mg = addq(mg, mulq(r0, f));
+            mh = addq(mh, addq(mulq(r0, za), mulq(r1, zb)));
+            xp = mulq(xp, x);
+        }
+        Sq zd = ld_scalar_q(sc + 32 * 3 * n);
+        mg = addq(mg, mulq(rF, soa_ld<ModQ, 1>(V.gk_total, p)));
+        mh = addq(mh, mulq(rF, zd));
+        mg = fe_sub_mod(zero, mg), mh = fe_sub_mod(zero, mh);
+        put_term_bytes(V.misc_terms, 0 * nm + p, pr + 160, false, mulq(rF, xp));  // x^n com
+        if (V.exp_st[p] == ZK_OK) {
+            put_term_bytes(V.misc_terms, 1 * nm + p, pr + 160, false, ekx);
+            put_term_bytes(V.misc_terms, 2 * nm + p, pr + 232, false, eky);
+        }
+    }
+    // fixed-base parts: list C slots p*4n + {0: membership, 1: Exp}
+    uint32_t lc = p * 4 * n;
+    soa_st(W.lc.v, lc, mg), soa_st(W.lc.r, lc, mh);
+    soa_st(W.lc.v, lc + 1, eg), soa_st(W.lc.r, lc + 1, eh);
+    soa_st(V.pSR, p, SR), soa_st(V.pSH, p, SH), soa_st(V.pSL, p, SL);
+}
+
+// ------------------------------------------------------------------ Straus double-and-add over a group of terms
+ZK_DEV TomNiels ld_term_niels(const VTerms& L, uint32_t idx) {
+    TomNiels n;
+    n.x = soa_ld<ModT, 2>(L.nx, idx), n.y = soa_ld<ModT, 2>(L.ny, idx), n.dt = soa_ld<ModT, 2>(L.ndt, idx);
+    return n;
+}
+__global__ void __launch_bounds__(256) k_v_straus(VTerms L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, Soa4 out) {
+    uint32_t g = gtid();
+    if (g >= ngroups) return;
+    TomPt acc = tom_identity();
+    uint32_t nt = n256 + n128;
+#pragma unroll 1
+    for (int b = 255; b >= 0; b--) {
+        acc = tom_dbl(acc);
+        uint32_t kmax = b >= 128 ? n256 : nt;
+#pragma unroll 1
+        for (uint32_t k = 0; k < kmax; k++) {
+            uint32_t idx = k * ng_stride + g;
+            // bit b of the plain scalar (30-bit limbs)
+            uint32_t limb = L.sc.p[(size_t)(b / 30) * L.sc.stride + idx];
+            bool bit = (limb >> (b % 30)) & 1;
+            TomPt s = tom_add_niels(acc, ld_term_niels(L, idx));
+            acc.x = fe_select(bit, s.x, acc.x), acc.y = fe_select(bit, s.y, acc.y);
+            acc.t = fe_select(bit, s.t, acc.t), acc.z = fe_select(bit, s.z, acc.z);
+        }
+    }
+    soa_st(out.x, g, acc.x), soa_st(out.y, g, acc.y), soa_st(out.z, g, acc.z), soa_st(out.t, g, acc.t);
+}
+void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out) {
+    if (!ngroups) return;
+    hipLaunchKernelGGL(k_v_straus, dim3((ngroups + 255) / 256), dim3(256), 0, s, L, ngroups, ng_stride, n256, n128, out);
+}
+// P-256: 5 A-terms per thread (128-bit randomisers), complete formulas
+__global__ void __launch_bounds__(256) k_v_p256_straus(VWork V, uint32_t count) {
+    uint32_t t = gtid();
+    if (t >= count * 4) return;
+    uint32_t p = t / 4, q = t % 4;
+    P256Pt acc = p256_identity();
+#pragma unroll 1
+    for (int b = 127; b >= 0; b--) {
+        acc = p256_dbl(acc);
+#pragma unroll 1
+        for (uint32_t k = 0; k < 5; k++) {
+            uint32_t idx = p * VK + q * 5 + k;
+            uint32_t limb = V.pa_sc.p[(size_t)(b / 30) * V.pa_sc.stride + idx];
+            bool bit = (limb >> (b % 30)) & 1;
+            P256Aff a;
+            a.x = soa_ld<ModQ, 2>(V.pa_x, idx), a.y = soa_ld<ModQ, 2>(V.pa_y, idx);
+            P256Pt s = p256_add_mixed(acc, a);
+            acc = p256_select(bit, s, acc);
+        }
+    }
+    soa_st(V.pacc.x, t, acc.x), soa_st(V.pacc.y, t, acc.y), soa_st(V.pacc.z, t, acc.z);
+}
+
+// ------------------------------------------------------------------ final sums and verdict
+ZK_DEV TomPt ld_tom4(const Soa4& a, uint32_t e) {
+    TomPt r;
+    r.x = soa_ld<ModT, 2>(a.x, e), r.y = soa_ld<ModT, 2>(a.y, e), r.z = soa_ld<ModT, 2>(a.z, e), r.t = soa_ld<ModT, 2>(a.t, e);
+    return r;
+}
+ZK_DEV TomPt ld_tom_proj3(const Soa3& a, uint32_t e) {  // (X:Y:Z) without T -> (XZ : YZ : XY : Z^2)
+    Ft2 x = soa_ld<ModT, 2>(a.x, e), y = soa_ld<ModT, 2>(a.y, e), z = soa_ld<ModT, 2>(a.z, e);
+    TomPt r;
+    r.x = x * z, r.y = y * z, r.t = x * y, r.z = z * z;
+    return r;
+}
+ZK_DEV bool tom_is_identity(const TomPt& a) {  // edwards.ts:117-125 on the a=1 image
+    return fe_is_zero(a.x) && fe_eq(a.y, a.z) && !fe_is_zero(a.z);
+}
+__global__ void __launch_bounds__(64) k_v_final(DevParams P, Workspace W, VWork V, uint32_t count, uint8_t* ok_out, int32_t* status_out, uint64_t first) {
+    uint32_t p = gtid();
+    if (p >= count) return;
+    int32_t st = V.st[p];  // structural errors; W.st additionally carries a late "T is at infinity"
+    uint8_t ok = 0;
+    if (V.st[p] == ZK_OK && !(V.okflags[p] & 8)) {
+        uint32_t n = V.n, nq = (n + 1) / 2;
+        // membership (gk.ts:261)
+        TomPt m = ld_tom_proj3(W.lc.proj, p * 4 * n);
+        for (uint32_t q = 0; q < nq; q++) m = tom_add(m, ld_tom4(V.gk_acc, p * nq + q));
+        m = tom_add(m, ld_tom4(V.misc_acc, 0 * V.C + p));
+        bool memb = tom_is_identity(m);
+        if (memb) {
+            // exceptions of verifyExp only surface when membership passed (zkpAttestList.ts:165-183)
+            int32_t est = V.exp_st[p];
+            if (est == ZK_OK && W.st[p] != ZK_OK) est = W.st[p];
+            if (est != ZK_OK) st = est;
+            else {
+                TomPt e = ld_tom_proj3(W.lc.proj, p * 4 * n + 1);
+                for (uint32_t j = 0; j < VK; j++) e = tom_add(e, ld_tom4(V.slot_acc, p * VK + j));
+                e = tom_add(e, ld_tom4(V.misc_acc, 1 * V.C + p));
+                e = tom_add(e, ld_tom4(V.misc_acc, 2 * V.C + p));
+                bool okW = tom_is_identity(e);
+                // P-256: SR * R + SH * h_NIST + SL * Clambda + sum(-rho A)
+                P256Pt acc = p256_identity();
+                {
+                    uint32_t kw[8];
+                    words_from_limbs<8>(kw, soa_ld<ModN, 1>(V.pSR, p).l);
+                    const uint32_t* rtab = W.rtab + (size_t)p * RTAB_WORDS;
+#pragma unroll 1
+                    for (int w = 0; w < RTAB_NWIN; w++) {
+                        uint32_t d = kw[0] & 15;
+                        shr256<4>(kw);
+                        acc = p256_add(acc, v_ld_rtab(rtab + (size_t)RTAB_ENTRY_WORDS * (w * 16 + d)));
+                    }
+                    words_from_limbs<8>(kw, soa_ld<ModN, 1>(V.pSH, p).l);
+#pragma unroll 1
+                    for (int w = 0; w < PFIX_NWIN; w++) {
+                        uint32_t d = kw[0] & 255;
+                        shr256<8>(kw);
+                        const uint32_t* en = P.pfix_H + (size_t)PFIX_ENTRY_WORDS * (w * 256 + d);
+                        P256Aff a;
+                        for (int l = 0; l < 9; l++) a.x.l[l] = en[l], a.y.l[l] = en[9 + l];
+                        P256Pt s = p256_add_mixed(acc, a);
+                        acc = p256_select(d != 0, s, acc);
+                    }
+                    // SL * Clambda (SL < 2^133): double-and-add
+                    P256Aff cl;
+                    cl.x = soa_ld<ModQ, 2>(V.clx, p), cl.y = soa_ld<ModQ, 2>(V.cly, p);
+                    Sn sl = soa_ld<ModN, 1>(V.pSL, p);
+                    P256Pt c2 = p256_identity();
+#pragma unroll 1
+                    for (int b = 135; b >= 0; b--) {
+                        c2 = p256_dbl(c2);
+                        bool bit = (sl.l[b / 30] >> (b % 30)) & 1;
+                        P256Pt s = p256_add_mixed(c2, cl);
+                        c2 = p256_select(bit, s, c2);
+                    }
+                    acc = p256_add(acc, c2);
+                    for (uint32_t q = 0; q < 4; q++) {
+                        P256Pt a;
+                        a.x = soa_ld<ModQ, 8>(V.pacc.x, p * 4 + q), a.y = soa_ld<ModQ, 8>(V.pacc.y, p * 4 + q), a.z = soa_ld<ModQ, 8>(V.pacc.z, p * 4 + q);
+                        acc = p256_add(acc, a);
+                    }
+                }
+                bool okN = fe_is_zero(fe_reduce(acc.x)) && fe_is_zero(fe_reduce(acc.z)) && !fe_is_zero(fe_reduce(acc.y));  // weier.ts:117-119
+                ok = (okW && okN) ? 1 : 0;
+            }
+        }
+    }
+    ok_out[first + p] = ok;
+    status_out[first + p] = st;
+}
+// Clambda = comS1 from the proof (Montgomery affine), for k_v_final
+__global__ void k_v_clambda(VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    uint32_t p = gtid();
+    if (p >= count) return;
+    Fq2 x = fe_const<ModQ, 2>(P256_GX_M), y = fe_const<ModQ, 2>(P256_GY_M);
+    if (V.st[p] == ZK_OK && !(V.okflags[p] & 8)) {
+        const uint8_t* pr = proofs + off[first + p];
+        uint32_t xw[8], yw[8];
+        load_be32(pr + 96, xw);
+        load_be32(pr + 128, yw);
+        x = fe_to_mont(fe_from_words256_reduce<ModQ>(xw)), y = fe_to_mont(fe_from_words256_reduce<ModQ>(yw));
+    }
+    soa_st(V.clx, p, x), soa_st(V.cly, p, y);
+}
+
+// ------------------------------------------------------------------ launch wrappers
+#define L1(kern, n, bs, ...) hipLaunchKernelGGL(kern, dim3(((n) + (bs)-1) / (bs)), dim3(bs), 0, s, __VA_ARGS__)
+void launch_v_header_validate(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    L1(k_v_header, count, 256, V, count, proofs, off, first);
+    L1(k_v_validate, count * (V.sec + 1), 256, V, count, proofs, off, first);
+}
+void launch_v_front(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* msg, uint64_t first) {
+    L1(k_v_front, count, 64, P, W, V, count, proofs, off, msg, first);
+    L1(k_v_clambda, count, 64, V, count, proofs, off, first);
+}
+void launch_v_challenges_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
+    L1(k_v_challenges, count, 64, V, count, proofs, off, first);
+    L1(k_v_sample, count, 64, V, count, vseeds, first);
+}
+void launch_v_exp_points(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    L1(k_v_exp_points, count * VK, 256, W, V, count, proofs, off, first);
+}
+void launch_v_t1_scalars(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    L1(k_v_t1_scalars, count * VK, 256, W, V, count, proofs, off, first);
+}
+void launch_v_derived(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    L1(k_v_derived, count * VK * 5, 256, W, V, count, proofs, off, first);
+}
+void launch_v_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    L1(k_v_padd_hash, count * VK * 6, 256, P, W, V, count, proofs, off, first);
+}
+void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
+    L1(k_v_slot_terms, count * VK, 64, W, V, count, proofs, off, vseeds, first);
+    L1(k_v_proof_terms, count, 64, W, V, count, proofs, off, vseeds, first);
+}
+void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count) { L1(k_v_p256_straus, count * 4, 256, V, count); }
+void launch_v_final(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first) {
+    L1(k_v_final, count, 64, P, W, V, count, ok, status, first);
+}
