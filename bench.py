@@ -95,6 +95,7 @@ def main():
     ap.add_argument('--sec', type=int, default=80)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=0, help='proofs in the CPU baseline sample (default 2 x cores)')
+    ap.add_argument('--verify-steps', type=int, default=1, help='timed verifySignatureList passes over the produced proofs (0 = skip)')
     ap.add_argument('--check', type=int, default=8, help='proofs of step 1 diffed against the oracle on rank 0')
     args = ap.parse_args()
 
@@ -175,6 +176,35 @@ def main():
     off = d_off.cpu()
     total_bytes = int(off[B].item())
 
+    # ---- verifySignatureList over the proofs just produced (the "+ verify/sec" half of the metric); proofs stay in HBM
+    verify = None
+    if args.verify_steps > 0:
+        d_ok = torch.empty(B, dtype=torch.uint8, device=dev)
+        d_vst = torch.empty(B, dtype=torch.int32, device=dev)
+        d_vseeds = tb(rank_seeds(seeds, rank + 1000))
+
+        def vstep():
+            eng.verify_batch_device(B, d_msg.data_ptr(), d_out.data_ptr(), d_off.data_ptr(), d_vseeds.data_ptr(), d_ok.data_ptr(), d_vst.data_ptr())
+        vstep()  # warm-up (allocates the verifier workspace)
+        barrier()
+        tv0 = time.time()
+        vfam = {}
+        for _ in range(args.verify_steps):
+            vstep()
+            _, f = eng.last_timing()
+            for k, v in f.items():
+                vfam[k] = vfam.get(k, 0.0) + v
+        barrier()
+        vdt = time.time() - tv0
+        if world > 1:
+            t = torch.tensor([vdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            vdt = float(t.item())
+        n_ok = int(d_ok.sum().item())
+        verify = {'value': round(world * B * args.verify_steps / vdt, 2), 'unit': 'verifies/s', 'steps': args.verify_steps,
+                  'ms_per_step': round(vdt * 1e3 / args.verify_steps, 2), 'accepted': n_ok, 'of': B,
+                  'gpu_ms_by_family_per_step': {k: round(v / args.verify_steps, 2) for k, v in sorted(vfam.items(), key=lambda kv: -kv[1])}}
+
     if rank == 0:
         n_log2 = max(1, (nkeys - 1).bit_length())
         # --- roofline of the dominant kernel, from HIP events recorded on the engine's stream around every launch
@@ -223,7 +253,7 @@ def main():
                        'parallelism': 'proofs sharded per GPU; ring broadcast over RCCL at set-up' if world > 1 else 'single GPU'},
             'proof_bytes_per_step': total_bytes, 'failed_proofs': nbad,
             'gpu_ms_by_family_per_step': {k: round(v / args.steps, 2) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'roofline': roofline, 'cpu_baseline': cpu, 'verify': verify,
         }
         print(json.dumps(line))
     if world > 1:
