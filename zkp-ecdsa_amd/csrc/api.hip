@@ -330,16 +330,16 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
         }
         {
             Scope t(c, "tom_commit");
-            launch_tom_commit(s, P, W.lb, items * LB_COMMITS, LB_COMMITS, LB_SLOTS);
+            launch_tom_commit(s, P, W.lb, items * LB_COMMITS, items, 0, W.items_cap);
         }
         {
             Scope t(c, "tom_normalize");
-            launch_tom_normalize(s, W.lb, items * LB_COMMITS, 0, LB_COMMITS, LB_SLOTS);
+            launch_tom_normalize(s, W.lb, items * LB_COMMITS, 0, items, 0, W.items_cap);
         }
         {
             Scope t(c, "tom_derived");
             launch_padd_derived(s, W, items);
-            launch_tom_normalize(s, W.lb, items * 5, LB_COMMITS, 5, LB_SLOTS);
+            launch_tom_normalize(s, W.lb, items * 5, LB_COMMITS, items, 0, W.items_cap);
         }
         {
             Scope t(c, "hash");

@@ -30,10 +30,13 @@ ZK_DEV void soa_st(const Soa& a, uint32_t e, const Fe<M, K>& v) {
 
 // ------------------------------------------------------------------ fixed-base tables
 // Tom: 8-bit windows, 32 windows x 256 digits, entry = niels (x, y, d'*x*y) Montgomery limbs, 28 words (112 B).
+#ifndef TOM_WIN_BITS
 #define TOM_WIN_BITS 8
-#define TOM_NWIN 32
+#endif
+#define TOM_NWIN ((256 + TOM_WIN_BITS - 1) / TOM_WIN_BITS)
+#define TOM_WIN_SIZE (1u << TOM_WIN_BITS)
 #define TOM_ENTRY_WORDS 28
-#define TOM_TAB_WORDS (TOM_NWIN * 256 * TOM_ENTRY_WORDS)
+#define TOM_TAB_WORDS ((size_t)TOM_NWIN * TOM_WIN_SIZE * TOM_ENTRY_WORDS)
 // P-256 fixed bases (G, h_NIST): 8-bit windows, entry = affine (x, y) Montgomery limbs, 20 words (80 B); digit 0 unused.
 #define PFIX_NWIN 32
 #define PFIX_ENTRY_WORDS 20
@@ -175,8 +178,8 @@ void launch_build_tom_table(hipStream_t s, const uint32_t* aff_xy_words /*18 wor
 void launch_build_pfix_table(hipStream_t s, const uint32_t* aff_xy_words /*16 words on device, or nullptr for G*/, uint32_t* tab, uint32_t* scratch, int32_t* ok);
 size_t table_scratch_words();
 // k_tom.hip
-void launch_tom_commit(hipStream_t s, const DevParams& P, const TomList& L, uint32_t count, uint32_t per_group, uint32_t slots_per_group);
-void launch_tom_normalize(hipStream_t s, const TomList& L, uint32_t count, uint32_t first, uint32_t per_group, uint32_t slots_per_group);
+void launch_tom_commit(hipStream_t s, const DevParams& P, const TomList& L, uint32_t count, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride = 0);
+void launch_tom_normalize(hipStream_t s, const TomList& L, uint32_t count, uint32_t first, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride = 0);
 void launch_padd_derived(hipStream_t s, const Workspace& W, uint32_t items);
 // k_p256.hip
 void launch_front(hipStream_t s, const DevParams& P, const Workspace& W, const ChunkIn& in);
@@ -209,6 +212,9 @@ void launch_test_field(hipStream_t s, int which, int op, uint64_t count, const u
 void launch_ring_load(hipStream_t s, const uint8_t* d_keys_be32, uint64_t nkeys, uint64_t N, const Soa& ring);
 void launch_bytes_to_scalars(hipStream_t s, const uint8_t* d_be32, uint64_t count, const Soa& out);
 void launch_affine_to_bytes(hipStream_t s, const Soa& ax, const Soa& ay, uint64_t count, int tom, uint8_t* d_out);
+
+// list B is item-fastest: slot k of item i lives at k * items_cap + i (coalesced for every per-item kernel)
+ZK_DEV uint32_t lbi(const Workspace& W, uint32_t item, uint32_t k) { return k * W.items_cap + item; }
 
 // ------------------------------------------------------------------ small device helpers shared by TUs
 ZK_DEV uint32_t gtid() { return blockIdx.x * blockDim.x + threadIdx.x; }

@@ -95,7 +95,6 @@ __global__ void __launch_bounds__(256) k_padd_hash(DevParams P, Workspace W, uin
     bool live = t < items * 6;
     if (!live) t = items * 6 - 1;
     uint32_t h = t / items, item = t % items;
-    uint32_t lb = item * LB_SLOTS;
     ShaStream s;
     s.init(lds, threadIdx.x, 256);
     const Soa &ax = W.lb.ax, &ay = W.lb.ay;
@@ -105,17 +104,17 @@ __global__ void __launch_bounds__(256) k_padd_hash(DevParams P, Workspace W, uin
         else if (h == 1) cx = 2, cy = 35, cz = 3, first = 12;           // C8, C9, C10
         else if (h == 2) cx = 3, cy = 3, cz = 4, first = 18;            // C10, C10, C11
         else cx = 3, cy = 36, cz = 5, first = 24;                       // C10, C12, C13
-        absorb_tom(s, ax, ay, lb + cx);
-        absorb_tom(s, ax, ay, lb + cy);
+        absorb_tom(s, ax, ay, lbi(W, item, cx));
+        absorb_tom(s, ax, ay, lbi(W, item, cy));
         if (cz == 0xffffffffu) absorb_tom_limbs(s, P.tom_g_aff);
-        else absorb_tom(s, ax, ay, lb + cz);
-        for (uint32_t k = 0; k < 6; k++) absorb_tom(s, ax, ay, lb + first + k);
+        else absorb_tom(s, ax, ay, lbi(W, item, cz));
+        for (uint32_t k = 0; k < 6; k++) absorb_tom(s, ax, ay, lbi(W, item, first + k));
     } else {
         uint32_t c1 = h == 4 ? 4 : 5, c2 = h == 4 ? 37 : 38, a1 = h == 4 ? 30 : 32;
-        absorb_tom(s, ax, ay, lb + c1);
-        absorb_tom(s, ax, ay, lb + c2);
-        absorb_tom(s, ax, ay, lb + a1);
-        absorb_tom(s, ax, ay, lb + a1 + 1);
+        absorb_tom(s, ax, ay, lbi(W, item, c1));
+        absorb_tom(s, ax, ay, lbi(W, item, c2));
+        absorb_tom(s, ax, ay, lbi(W, item, a1));
+        absorb_tom(s, ax, ay, lbi(W, item, a1 + 1));
     }
     uint32_t dg[8], c[4];
     s.finish(dg);

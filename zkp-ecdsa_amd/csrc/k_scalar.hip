@@ -152,23 +152,22 @@ ZK_DEV void padd_blinders(const Workspace& W, uint32_t p, uint32_t i, uint32_t d
     w.r3 = drawq(W, p, 3 + 4 * i + 2), w.r6 = drawq(W, p, 3 + 4 * i + 3);
 }
 // openings of one proveMult instance (mult.ts:102-114): 6 commitments starting at `slot`
-ZK_DEV void mult_openings(const Workspace& W, uint32_t p, uint32_t dm, uint32_t slot, const Sq& x, const Sq& y, const Sq& ry) {
+ZK_DEV void mult_openings(const Workspace& W, uint32_t p, uint32_t dm, uint32_t it, uint32_t k0, const Sq& x, const Sq& y, const Sq& ry) {
     Sq kx = drawq(W, p, dm), ky = drawq(W, p, dm + 1), kz = drawq(W, p, dm + 2);
     Sq sx = drawq(W, p, dm + 3), sy = drawq(W, p, dm + 4), sz = drawq(W, p, dm + 5), s4 = drawq(W, p, dm + 6);
     auto xm = fe_to_mont(x), kxm = fe_to_mont(kx);
-    put_vr(W.lb, slot + 0, fe_canon(xm * y), fe_canon(xm * ry));    // C4 = x * Cy
-    put_vr(W.lb, slot + 1, kx, sx);                                 // Ax
-    put_vr(W.lb, slot + 2, ky, sy);                                 // Ay
-    put_vr(W.lb, slot + 3, kz, sz);                                 // Az
-    put_vr(W.lb, slot + 4, kz, s4);                                 // A4_1
-    put_vr(W.lb, slot + 5, fe_canon(kxm * y), fe_canon(kxm * ry));  // A4_2 = kx * Cy
+    put_vr(W.lb, lbi(W, it, k0 + 0), fe_canon(xm * y), fe_canon(xm * ry));    // C4 = x * Cy
+    put_vr(W.lb, lbi(W, it, k0 + 1), kx, sx);                                 // Ax
+    put_vr(W.lb, lbi(W, it, k0 + 2), ky, sy);                                 // Ay
+    put_vr(W.lb, lbi(W, it, k0 + 3), kz, sz);                                 // Az
+    put_vr(W.lb, lbi(W, it, k0 + 4), kz, s4);                                 // A4_1
+    put_vr(W.lb, lbi(W, it, k0 + 5), fe_canon(kxm * y), fe_canon(kxm * ry));  // A4_2 = kx * Cy
 }
 __global__ void __launch_bounds__(256) k_padd_scalars(Workspace W, uint32_t items) {
     uint32_t it = gtid();
     if (it >= items) return;
     uint32_t p = W.item_proof[it], i = W.item_rep[it];
     uint32_t d0 = 3 + 4 * W.sec + 40 * W.item_rank[it];
-    uint32_t lb = it * LB_SLOTS;
     Sq x1 = soa_ld<ModQ, 1>(W.T1x, it), y1 = soa_ld<ModQ, 1>(W.T1y, it);
     Sq x2 = soa_ld<ModQ, 1>(W.pkx, p), y2 = soa_ld<ModQ, 1>(W.pky, p);
     Sq x3 = soa_ld<ModQ, 1>(W.Tx, p * (W.sec + 1) + i);
@@ -181,23 +180,23 @@ __global__ void __launch_bounds__(256) k_padd_scalars(Workspace W, uint32_t item
     w.i11 = fe_mul_mod(w.i10, w.i10);
     w.i12 = fe_sub_mod(x1, x3);
     w.i13 = fe_mul_mod(w.i10, w.i12);
-    put_vr(W.lb, lb + 0, x1, w.r1);       // T1x   (exp.ts:196)
-    put_vr(W.lb, lb + 1, y1, w.r4);       // T1y
-    put_vr(W.lb, lb + 2, w.i8, w.r8);     // C8    (pointAdd.ts:138-143)
-    put_vr(W.lb, lb + 3, w.i10, w.r10);   // C10
-    put_vr(W.lb, lb + 4, w.i11, w.r11);   // C11
-    put_vr(W.lb, lb + 5, w.i13, w.r13);   // C13
-    mult_openings(W, p, d0 + 6, lb + 6, w.i7, w.i8, w.r8);                          // pi8 : Cy = C8
-    mult_openings(W, p, d0 + 13, lb + 12, w.i8, w.i9, fe_sub_mod(w.r5, w.r4));     // pi10: Cy = C9 = C5 - C4
-    mult_openings(W, p, d0 + 20, lb + 18, w.i10, w.i10, w.r10);                    // pi11: Cy = C10
-    mult_openings(W, p, d0 + 30, lb + 24, w.i10, w.i12, fe_sub_mod(w.r1, w.r3));   // pi13: Cy = C12 = C1 - C3
+    put_vr(W.lb, lbi(W, it, 0), x1, w.r1);       // T1x   (exp.ts:196)
+    put_vr(W.lb, lbi(W, it, 1), y1, w.r4);       // T1y
+    put_vr(W.lb, lbi(W, it, 2), w.i8, w.r8);     // C8    (pointAdd.ts:138-143)
+    put_vr(W.lb, lbi(W, it, 3), w.i10, w.r10);   // C10
+    put_vr(W.lb, lbi(W, it, 4), w.i11, w.r11);   // C11
+    put_vr(W.lb, lbi(W, it, 5), w.i13, w.r13);   // C13
+    mult_openings(W, p, d0 + 6, it, 6, w.i7, w.i8, w.r8);                          // pi8 : Cy = C8
+    mult_openings(W, p, d0 + 13, it, 12, w.i8, w.i9, fe_sub_mod(w.r5, w.r4));     // pi10: Cy = C9 = C5 - C4
+    mult_openings(W, p, d0 + 20, it, 18, w.i10, w.i10, w.r10);                    // pi11: Cy = C10
+    mult_openings(W, p, d0 + 30, it, 24, w.i10, w.i12, fe_sub_mod(w.r1, w.r3));   // pi13: Cy = C12 = C1 - C3
     {
         Sq k = drawq(W, p, d0 + 27);                                               // pix (equality.ts:66-68)
-        put_vr(W.lb, lb + 30, k, drawq(W, p, d0 + 28));
-        put_vr(W.lb, lb + 31, k, drawq(W, p, d0 + 29));
+        put_vr(W.lb, lbi(W, it, 30), k, drawq(W, p, d0 + 28));
+        put_vr(W.lb, lbi(W, it, 31), k, drawq(W, p, d0 + 29));
         k = drawq(W, p, d0 + 37);                                                  // piy
-        put_vr(W.lb, lb + 32, k, drawq(W, p, d0 + 38));
-        put_vr(W.lb, lb + 33, k, drawq(W, p, d0 + 39));
+        put_vr(W.lb, lbi(W, it, 32), k, drawq(W, p, d0 + 38));
+        put_vr(W.lb, lbi(W, it, 33), k, drawq(W, p, d0 + 39));
     }
 }
 void launch_padd_scalars(hipStream_t s, const DevParams&, const Workspace& W, uint32_t items) {
@@ -232,7 +231,6 @@ __global__ void __launch_bounds__(256) k_padd_respond(Workspace W, uint32_t item
     if (it >= items) return;
     uint32_t p = W.item_proof[it], i = W.item_rep[it];
     uint32_t d0 = 3 + 4 * W.sec + 40 * W.item_rank[it];
-    uint32_t lb = it * LB_SLOTS;
     uint8_t* rep = out + W.out_base[p] + rep_offset(W.chal + 4 * p, i);
     // rep-level response for a zero bit (exp.ts:186,221-225): z = alpha - s, z2 = r_i - Cs.r, r1 = T1x.r, r2 = T1y.r
     {
@@ -244,9 +242,9 @@ __global__ void __launch_bounds__(256) k_padd_respond(Workspace W, uint32_t item
     padd_blinders(W, p, i, d0, w);
     store_scalar_be(rep + 272, w.r1);
     store_scalar_be(rep + 304, w.r4);
-    Sq x1 = soa_ld<ModQ, 1>(W.lb.v, lb + 0), y1 = soa_ld<ModQ, 1>(W.lb.v, lb + 1);
-    w.i8 = soa_ld<ModQ, 1>(W.lb.v, lb + 2), w.i10 = soa_ld<ModQ, 1>(W.lb.v, lb + 3);
-    w.i11 = soa_ld<ModQ, 1>(W.lb.v, lb + 4), w.i13 = soa_ld<ModQ, 1>(W.lb.v, lb + 5);
+    Sq x1 = soa_ld<ModQ, 1>(W.lb.v, lbi(W, it, 0)), y1 = soa_ld<ModQ, 1>(W.lb.v, lbi(W, it, 1));
+    w.i8 = soa_ld<ModQ, 1>(W.lb.v, lbi(W, it, 2)), w.i10 = soa_ld<ModQ, 1>(W.lb.v, lbi(W, it, 3));
+    w.i11 = soa_ld<ModQ, 1>(W.lb.v, lbi(W, it, 4)), w.i13 = soa_ld<ModQ, 1>(W.lb.v, lbi(W, it, 5));
     w.i7 = fe_sub_mod(soa_ld<ModQ, 1>(W.pkx, p), x1);
     w.i9 = fe_sub_mod(soa_ld<ModQ, 1>(W.pky, p), y1);
     w.i12 = fe_sub_mod(x1, soa_ld<ModQ, 1>(W.Tx, p * (W.sec + 1) + i));
@@ -317,7 +315,7 @@ void launch_write_fixed(hipStream_t s, const Workspace& W, uint32_t count, uint8
 __global__ void __launch_bounds__(256) k_write_padd_points(Workspace W, uint32_t items, uint8_t* out) {
     uint32_t t = gtid();
     if (t >= items * 32) return;
-    uint32_t it = t / 32, k = 2 + t % 32;  // slots 2..33
+    uint32_t it = t % items, k = 2 + t / items;  // slots 2..33, item-fastest
     uint32_t p = W.item_proof[it], i = W.item_rep[it];
     uint8_t* pa = out + W.out_base[p] + rep_offset(W.chal + 4 * p, i) + ZK_REP_HEAD;
     uint32_t off;
@@ -325,7 +323,7 @@ __global__ void __launch_bounds__(256) k_write_padd_points(Workspace W, uint32_t
     else if (k < 30) off = 288 + 656 * ((k - 6) / 6) + 72 * ((k - 6) % 6);
     else if (k < 32) off = 2912 + 72 * (k - 30);
     else off = 3152 + 72 * (k - 32);
-    put_tom_point(pa + off, W.lb, it * LB_SLOTS + k);
+    put_tom_point(pa + off, W.lb, lbi(W, it, k));
 }
 void launch_write_padd_points(hipStream_t s, const Workspace& W, uint32_t items, uint8_t* out) {
     if (!items) return;

@@ -5,7 +5,7 @@
 #include "engine.h"
 
 // scratch layout (words): bases [32][36] extended/projective, entries [32*256][36]
-size_t table_scratch_words() { return 32 * 36 + 32 * 256 * 36; }
+size_t table_scratch_words() { return (size_t)TOM_NWIN * 36 + (size_t)TOM_NWIN * TOM_WIN_SIZE * 36 + 32 * 36 + 32 * 256 * 36; }
 
 ZK_DEV void st_tompt(uint32_t* p, const TomPt& a) {
 #pragma unroll
@@ -24,30 +24,30 @@ __global__ void k_tomtab_bases(const uint32_t* xy, uint32_t* scratch, int32_t* o
     TomPt p;
     bool good = tom_from_affine_words(p, xw, yw);
     if (!good) *ok = 0;
-    for (int w = 0; w < 32; w++) {
+    for (int w = 0; w < TOM_NWIN; w++) {
         st_tompt(scratch + 36 * w, p);
-        for (int i = 0; i < 8; i++) p = tom_dbl(p);
+        for (int i = 0; i < TOM_WIN_BITS; i++) p = tom_dbl(p);
     }
 }
 __global__ void k_tomtab_fill(uint32_t* scratch) {
     uint32_t t = gtid();
-    if (t >= 32 * 256) return;
-    uint32_t w = t >> 8, d = t & 255;
+    if (t >= TOM_NWIN * TOM_WIN_SIZE) return;
+    uint32_t w = t >> TOM_WIN_BITS, d = t & (TOM_WIN_SIZE - 1);
     TomPt base = ld_tompt(scratch + 36 * w);
     TomPt acc = tom_identity();
-    for (int b = 7; b >= 0; b--) {
+    for (int b = TOM_WIN_BITS - 1; b >= 0; b--) {
         acc = tom_dbl(acc);
         TomPt s = tom_add(acc, base);
         bool bit = (d >> b) & 1;
         acc.x = fe_select(bit, s.x, acc.x), acc.y = fe_select(bit, s.y, acc.y);
         acc.t = fe_select(bit, s.t, acc.t), acc.z = fe_select(bit, s.z, acc.z);
     }
-    st_tompt(scratch + 32 * 36 + 36 * t, acc);
+    st_tompt(scratch + TOM_NWIN * 36 + (size_t)36 * t, acc);
 }
 __global__ void k_tomtab_affine(const uint32_t* scratch, uint32_t* tab) {
     uint32_t t = gtid();
-    if (t >= 32 * 256) return;
-    TomPt a = ld_tompt(scratch + 32 * 36 + 36 * t);
+    if (t >= TOM_NWIN * TOM_WIN_SIZE) return;
+    TomPt a = ld_tompt(scratch + TOM_NWIN * 36 + (size_t)36 * t);
     Ft2 zi = fe_inv<ModT>(a.z);
     Ft2 x = a.x * zi, y = a.y * zi;
     Ft2 dt = (x * y) * fe_const<ModT, 1>(TOM_D1_M);
@@ -58,8 +58,8 @@ __global__ void k_tomtab_affine(const uint32_t* scratch, uint32_t* tab) {
 }
 void launch_build_tom_table(hipStream_t s, const uint32_t* xy, uint32_t* tab, uint32_t* scratch, int32_t* ok) {
     hipLaunchKernelGGL(k_tomtab_bases, dim3(1), dim3(64), 0, s, xy, scratch, ok);
-    hipLaunchKernelGGL(k_tomtab_fill, dim3(32 * 256 / 64), dim3(64), 0, s, scratch);
-    hipLaunchKernelGGL(k_tomtab_affine, dim3(32 * 256 / 64), dim3(64), 0, s, scratch, tab);
+    hipLaunchKernelGGL(k_tomtab_fill, dim3((TOM_NWIN * TOM_WIN_SIZE + 63) / 64), dim3(64), 0, s, scratch);
+    hipLaunchKernelGGL(k_tomtab_affine, dim3((TOM_NWIN * TOM_WIN_SIZE + 63) / 64), dim3(64), 0, s, scratch, tab);
 }
 
 // ---------------------------------------------------------------- P-256 fixed bases

@@ -8,6 +8,7 @@
 //
 // proveMult's variable-base products C4 = x*Cy and A4_2 = kx*Cy (src/commit/mult.ts:103,114) are also commitments
 // with KNOWN openings (x*y, x*ry), so they go through the same kernel (see k_scalar.hip).
+#include <cstdlib>
 #include "engine.h"
 
 ZK_DEV TomNiels ld_niels(const uint32_t* e) {
@@ -24,11 +25,13 @@ ZK_DEV TomNiels ld_niels(const uint32_t* e) {
     return n;
 }
 
-__global__ void __launch_bounds__(256) k_tom_commit(const uint32_t* __restrict__ tab_g, const uint32_t* __restrict__ tab_h, TomList L,
-                                                    uint32_t count, uint32_t per_group, uint32_t slots_per_group) {
+template <int OCC>
+__global__ void __launch_bounds__(256, OCC) k_tom_commit(const uint32_t* __restrict__ tab_g, const uint32_t* __restrict__ tab_h, TomList L,
+                                                         uint32_t count, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride) {
     uint32_t c = gtid();
     if (c >= count) return;
-    uint32_t slot = (c / per_group) * slots_per_group + (c % per_group);
+    // kstride == 0: slot = group * slots_per_group + member;  kstride != 0 (list B): per_group = items, slot = k * kstride + item
+    uint32_t slot = kstride ? (c / per_group) * kstride + (c % per_group) : (c / per_group) * slots_per_group + (c % per_group);
     uint32_t vw[8], rw[8];
     {
         Fe<ModQ, 1> v = soa_ld<ModQ, 1>(L.v, slot), r = soa_ld<ModQ, 1>(L.r, slot);
@@ -38,11 +41,11 @@ __global__ void __launch_bounds__(256) k_tom_commit(const uint32_t* __restrict__
     TomPt acc = tom_identity();
 #pragma unroll 1
     for (int w = 0; w < TOM_NWIN; w++) {
-        uint32_t dv = vw[0] & 255, dr = rw[0] & 255;
-        TomNiels ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * (w * 256 + dv));
-        TomNiels nh = ld_niels(tab_h + (size_t)TOM_ENTRY_WORDS * (w * 256 + dr));
-        shr256<8>(vw);
-        shr256<8>(rw);
+        uint32_t dv = vw[0] & (TOM_WIN_SIZE - 1), dr = rw[0] & (TOM_WIN_SIZE - 1);
+        TomNiels ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * (w * TOM_WIN_SIZE + dv));
+        TomNiels nh = ld_niels(tab_h + (size_t)TOM_ENTRY_WORDS * (w * TOM_WIN_SIZE + dr));
+        shr256<TOM_WIN_BITS>(vw);
+        shr256<TOM_WIN_BITS>(rw);
         acc = tom_add_niels(acc, ng);
         acc = tom_add_niels(acc, nh);
     }
@@ -50,24 +53,31 @@ __global__ void __launch_bounds__(256) k_tom_commit(const uint32_t* __restrict__
     soa_st(L.proj.y, slot, acc.y);
     soa_st(L.proj.z, slot, acc.z);
 }
-void launch_tom_commit(hipStream_t s, const DevParams& P, const TomList& L, uint32_t count, uint32_t per_group, uint32_t slots_per_group) {
+void launch_tom_commit(hipStream_t s, const DevParams& P, const TomList& L, uint32_t count, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride) {
     if (!count) return;
-    hipLaunchKernelGGL(k_tom_commit, dim3((count + 255) / 256), dim3(256), 0, s, P.tom_tab_g, P.tom_tab_h, L, count, per_group, slots_per_group);
+    static int occ = getenv("ZK_TOM_OCC") ? atoi(getenv("ZK_TOM_OCC")) : 2;
+    dim3 g((count + 255) / 256), b(256);
+    if (occ == 4) hipLaunchKernelGGL(k_tom_commit<4>, g, b, 0, s, P.tom_tab_g, P.tom_tab_h, L, count, per_group, slots_per_group, kstride);
+    else if (occ == 3) hipLaunchKernelGGL(k_tom_commit<3>, g, b, 0, s, P.tom_tab_g, P.tom_tab_h, L, count, per_group, slots_per_group, kstride);
+    else hipLaunchKernelGGL(k_tom_commit<2>, g, b, 0, s, P.tom_tab_g, P.tom_tab_h, L, count, per_group, slots_per_group, kstride);
 }
 
 // Batch normalisation: (X:Y:Z) on the a=1 image -> affine (x, y) of the ORIGINAL curve, plain canonical limbs
 // (edwards.ts:184-193 toAffine).  Montgomery's trick: each thread owns `per` elements (strided by the thread
 // count), so one Fermat inversion serves `per` points.  Prefix products are parked in the ax output array.
 // Element c of the pass maps to list slot (c / per_group) * slots_per_group + first + c % per_group.
+ZK_DEV uint32_t norm_slot(uint32_t c, uint32_t first, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride) {
+    return kstride ? (first + c / per_group) * kstride + (c % per_group) : (c / per_group) * slots_per_group + first + c % per_group;
+}
 __global__ void __launch_bounds__(256) k_tom_normalize(TomList L, uint32_t count, uint32_t nthreads, uint32_t per, uint32_t first,
-                                                       uint32_t per_group, uint32_t slots_per_group) {
+                                                       uint32_t per_group, uint32_t slots_per_group, uint32_t kstride) {
     uint32_t t = gtid();
     if (t >= nthreads) return;
     Ft2 acc = fe_one_mont<ModT>().as<2>();
     for (uint32_t j = 0; j < per; j++) {
         uint32_t c = t + j * nthreads;
         if (c >= count) break;
-        uint32_t e = (c / per_group) * slots_per_group + first + c % per_group;
+        uint32_t e = norm_slot(c, first, per_group, slots_per_group, kstride);
         soa_st(L.ax, e, acc);  // prefix product before element e
         acc = acc * soa_ld<ModT, 2>(L.proj.z, e);
     }
@@ -76,7 +86,7 @@ __global__ void __launch_bounds__(256) k_tom_normalize(TomList L, uint32_t count
     for (int j = (int)per - 1; j >= 0; j--) {
         uint32_t c = t + (uint32_t)j * nthreads;
         if (c >= count) continue;
-        uint32_t e = (c / per_group) * slots_per_group + first + c % per_group;
+        uint32_t e = norm_slot(c, first, per_group, slots_per_group, kstride);
         Ft2 z = soa_ld<ModT, 2>(L.proj.z, e);
         Ft2 zi = inv * soa_ld<ModT, 2>(L.ax, e);
         inv = inv * z;
@@ -86,13 +96,13 @@ __global__ void __launch_bounds__(256) k_tom_normalize(TomList L, uint32_t count
         soa_st(L.ay, e, fe_from_mont(y));
     }
 }
-void launch_tom_normalize(hipStream_t s, const TomList& L, uint32_t count, uint32_t first, uint32_t per_group, uint32_t slots_per_group) {
+void launch_tom_normalize(hipStream_t s, const TomList& L, uint32_t count, uint32_t first, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride) {
     if (!count) return;
     uint32_t per = count / (256 * 4 * 64 * 2);
     if (per < 4) per = 4;
     if (per > 64) per = 64;
     uint32_t nthreads = (count + per - 1) / per;
-    hipLaunchKernelGGL(k_tom_normalize, dim3((nthreads + 255) / 256), dim3(256), 0, s, L, count, nthreads, per, first, per_group, slots_per_group);
+    hipLaunchKernelGGL(k_tom_normalize, dim3((nthreads + 255) / 256), dim3(256), 0, s, L, count, nthreads, per, first, per_group, slots_per_group, kstride);
 }
 
 // original-curve affine plain -> a=1 image extended Montgomery (no validation: engine-produced points)
@@ -114,23 +124,23 @@ ZK_DEV TomPt ld_aff(const TomList& L, uint32_t slot) { return tom_from_affine_pl
 __global__ void __launch_bounds__(256) k_padd_derived(Workspace W, uint32_t items) {
     uint32_t t = gtid();
     if (t >= items * 5) return;
-    uint32_t item = t / 5, k = t % 5;
+    uint32_t item = t % items, k = t / items;
     uint32_t proof = W.item_proof[item], rep = W.item_rep[item];
     uint32_t la = proof * (2 + 2 * W.sec);
-    uint32_t lb = item * LB_SLOTS;
+    uint32_t lb0 = lbi(W, item, 0), lb1 = lbi(W, item, 1);
     TomPt r;
     if (k == 0) {        // C7 = pkX - T1x
-        r = tom_add(ld_aff(W.la, la + 0), tom_neg(ld_aff(W.lb, lb + 0)));
+        r = tom_add(ld_aff(W.la, la + 0), tom_neg(ld_aff(W.lb, lb0)));
     } else if (k == 1) { // C9 = pkY - T1y
-        r = tom_add(ld_aff(W.la, la + 1), tom_neg(ld_aff(W.lb, lb + 1)));
+        r = tom_add(ld_aff(W.la, la + 1), tom_neg(ld_aff(W.lb, lb1)));
     } else if (k == 2) { // C12 = T1x - Tx_i
-        r = tom_add(ld_aff(W.lb, lb + 0), tom_neg(ld_aff(W.la, la + 2 + 2 * rep)));
+        r = tom_add(ld_aff(W.lb, lb0), tom_neg(ld_aff(W.la, la + 2 + 2 * rep)));
     } else if (k == 3) { // Cint_x = Tx_i + T1x + pkX
-        r = tom_add(tom_add(ld_aff(W.la, la + 2 + 2 * rep), ld_aff(W.lb, lb + 0)), ld_aff(W.la, la + 0));
+        r = tom_add(tom_add(ld_aff(W.la, la + 2 + 2 * rep), ld_aff(W.lb, lb0)), ld_aff(W.la, la + 0));
     } else {             // Cint_y = Ty_i + T1y
-        r = tom_add(ld_aff(W.la, la + 3 + 2 * rep), ld_aff(W.lb, lb + 1));
+        r = tom_add(ld_aff(W.la, la + 3 + 2 * rep), ld_aff(W.lb, lb1));
     }
-    uint32_t slot = lb + LB_COMMITS + k;
+    uint32_t slot = lbi(W, item, LB_COMMITS + k);
     soa_st(W.lb.proj.x, slot, r.x);
     soa_st(W.lb.proj.y, slot, r.y);
     soa_st(W.lb.proj.z, slot, r.z);
