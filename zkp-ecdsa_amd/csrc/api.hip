@@ -203,10 +203,10 @@ static size_t carve(zk_ctx* c, uint8_t* base, uint32_t C, uint32_t sec, uint32_t
     // fallback for tiny rings ping-pongs G*N elements between gk_bufA and gk_bufB
     uint64_t g = std::max<uint64_t>(1, std::min<uint64_t>(C, ((uint64_t)1 << 16) / N));
     W.gk_group = (uint32_t)g;
-    uint32_t T = std::min<uint32_t>(n, 11);
+    uint32_t T = std::min<uint32_t>(n, 12);
     uint64_t tile_elems = (uint64_t)(T + 1) * C * (N >> T);
     W.gk_bufA = (uint32_t*)k.take(36 * std::max<uint64_t>(g * N, tile_elems));
-    W.gk_bufB = (uint32_t*)k.take(36 * g * N);
+    W.gk_bufB = (uint32_t*)k.take(36 * std::max<uint64_t>(g * N, (uint64_t)(n + 1) * C * std::max<uint64_t>(1, (N >> T) / 64)));
     W.rng.exc_idx = (uint32_t*)k.take(4 * RNG_MAX_EXC * (size_t)C);
     W.rng.exc_flags = (uint32_t*)k.take(4 * RNG_MAX_EXC * (size_t)C);
     W.rng.exc_cnt = (uint32_t*)k.take(4 * (size_t)C);

@@ -434,9 +434,8 @@ void launch_gk_respond(hipStream_t s, const Workspace& W, const ChunkIn& in, uin
 // ---- fused fold: a tile of 2^T ring elements per workgroup.  Levels 0..2 run in registers (8 elements per lane),
 // levels 3..T-1 run coefficient-parallel through LDS (one output coefficient = one modmul per lane), so a whole
 // tile costs ~20 modmul latencies instead of one kernel launch per level.  LDS planes are limb-major (conflict-free).
-#define GK_TMAX 11
-#define GK_LDS_A (1u << (GK_TMAX - 1))            // elements: 2^(T-3) polys x 4 coefs
-#define GK_LDS_B ((1u << (GK_TMAX - 4)) * 5)      // 2^(T-4) polys x 5 coefs
+#define GK_TMAX 12   // 256 lanes x 16 elements
+#define GK_LDS_A 1280u   // finish kernel: up to N/2^T tile polynomials x (T+1) coefs (N <= 2^28 is not reachable: see carve)
 struct LdsPlane {
     uint32_t* p;
     uint32_t stride;
@@ -460,18 +459,31 @@ ZK_DEV Sq64 as64(const Fe<ModQ, K>& v) {  // bound bookkeeping only (see Sq64)
     for (int l = 0; l < NLIMB; l++) r.l[l] = v.l[l];
     return r;
 }
-// one level on register-resident polynomials: out = w*sel + a*(od - ev)
-template <int J>
-ZK_DEV void gk_combine(Sq (&out)[J + 2], const Sq (&ev)[J + 1], const Sq (&od)[J + 1], const Fe<ModQ, 2>& a, bool l) {
-    Sq prev = fe_zero<ModQ>();
+// Depth-first register fold of 2^LEV consecutive ring elements: polynomial with LEV+1 coefficients, lazily reduced
+// (coefficient bound K(LEV) = 2 LEV + 1 multiples of q: c = a*(od - ev) [< 2q] + sel [< K(LEV-1) q]).
+template <int LEV>
+struct GkFold {
+    static constexpr int K = 2 * LEV + 1;
+    static ZK_DEV void run(const Soa& ring, const Soa& am, uint32_t C, uint32_t p, uint32_t which, uint32_t base, Fe<ModQ, K> (&out)[LEV + 1]) {
+        Fe<ModQ, GkFold<LEV - 1>::K> ev[LEV], od[LEV];
+        GkFold<LEV - 1>::run(ring, am, C, p, which, base, ev);
+        GkFold<LEV - 1>::run(ring, am, C, p, which, base + (1u << (LEV - 1)), od);
+        Fe<ModQ, 2> a = soa_ld<ModQ, 2>(am, (LEV - 1) * C + p);
+        bool l = (which >> (LEV - 1)) & 1;
 #pragma unroll
-    for (int k = 0; k <= J; k++) {
-        Sq prod = fe_canon(a * fe_sub_mod(od[k], ev[k]));
-        out[k] = fe_add_mod(prod, prev);
-        prev = l ? od[k] : ev[k];
+        for (int k = 0; k < LEV; k++) {
+            Fe<ModQ, 2> prod = a * (od[k] - ev[k]);
+            if (k == 0) out[0] = prod.template as<K>();
+            else out[k] = (prod + fe_select(l, od[k - 1], ev[k - 1])).template as<K>();
+        }
+        out[LEV] = fe_select(l, od[LEV - 1], ev[LEV - 1]).template as<K>();
     }
-    out[J + 1] = prev;
-}
+};
+template <>
+struct GkFold<0> {
+    static constexpr int K = 1;
+    static ZK_DEV void run(const Soa& ring, const Soa&, uint32_t, uint32_t, uint32_t, uint32_t base, Fe<ModQ, 1> (&out)[1]) { out[0] = soa_ld<ModQ, 1>(ring, base); }
+};
 // levels j0..j1-1 of `npoly` polynomials (j0+1 coefs each) held in LDS plane A (element (k*npoly + m)); result left in
 // the plane returned by reference (ping-pong with B).  All threads of the workgroup must call this.
 ZK_DEV void gk_lds_levels(LdsPlane& A, LdsPlane& B, uint32_t npoly, uint32_t j0, uint32_t j1, const Workspace& W, const Soa& am, uint32_t p, uint32_t which) {
@@ -499,37 +511,26 @@ ZK_DEV void gk_lds_levels(LdsPlane& A, LdsPlane& B, uint32_t npoly, uint32_t j0,
         npoly = nout;
     }
 }
-// grid = count * ntiles workgroups of 256 lanes; T >= 3.  Output: tile polynomial (T+1 coefs) at res[(k*C + p)*ntiles + tile],
-// or straight into gk_coef when the tile is the whole ring.
+// grid = count * ntiles workgroups of 256 lanes; RL register levels (2^RL elements per lane), T >= RL levels per tile.
+// Output: tile polynomial (T+1 coefs) at res[(k*C + p)*ntiles + tile], or straight into gk_coef when the tile is the ring.
+template <int RL>
 __global__ void __launch_bounds__(256) k_gk_tile(Workspace W, ChunkIn in, Soa am, uint32_t T, uint32_t ntiles, Soa res) {
-    __shared__ uint32_t ldsA[NLIMB * GK_LDS_A];
-    __shared__ uint32_t ldsB[NLIMB * GK_LDS_B];
+    constexpr uint32_t A_EL = 256u * (RL + 1), B_EL = 128u * (RL + 2);
+    __shared__ uint32_t ldsA[NLIMB * A_EL];
+    __shared__ uint32_t ldsB[NLIMB * B_EL];
     uint32_t p = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
     uint32_t which = in.which[p];
-    uint32_t lanes = 1u << (T - 3);  // active lanes in the register phase
+    uint32_t lanes = 1u << (T - RL);  // active lanes in the register phase (<= 256)
     uint32_t t = threadIdx.x;
-    LdsPlane A = {ldsA, GK_LDS_A}, B = {ldsB, GK_LDS_B};
+    LdsPlane A = {ldsA, A_EL}, B = {ldsB, B_EL};
     if (t < lanes) {
-        uint32_t base = (tile << T) + 8 * t;
-        Sq v[8];
+        Fe<ModQ, GkFold<RL>::K> poly[RL + 1];
+        GkFold<RL>::run(W.ring, am, W.C, p, which, (tile << T) + (t << RL), poly);
 #pragma unroll
-        for (int i = 0; i < 8; i++) v[i] = soa_ld<ModQ, 1>(W.ring, base + i);
-        Fe<ModQ, 2> a0 = soa_ld<ModQ, 2>(am, 0 * W.C + p), a1 = soa_ld<ModQ, 2>(am, 1 * W.C + p), a2 = soa_ld<ModQ, 2>(am, 2 * W.C + p);
-        Sq p1[4][2], p2[2][3], p3[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            Sq ev[1] = {v[2 * i]}, od[1] = {v[2 * i + 1]};
-            gk_combine<0>(p1[i], ev, od, a0, which & 1);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; i++) gk_combine<1>(p2[i], p1[2 * i], p1[2 * i + 1], a1, (which >> 1) & 1);
-        gk_combine<2>(p3, p2[0], p2[1], a2, (which >> 2) & 1);
-#pragma unroll
-        for (int k = 0; k < 4; k++) lds_st(A, k * lanes + t, p3[k]);
+        for (int k = 0; k <= RL; k++) lds_st(A, k * lanes + t, poly[k]);
     }
     __syncthreads();
-    gk_lds_levels(A, B, lanes, 3, T, W, am, p, which);
-    // result: one polynomial with T+1 coefficients at A[k]
+    gk_lds_levels(A, B, lanes, RL, T, W, am, p, which);
     bool whole = ntiles == 1;
     for (uint32_t k = t; k <= T; k += blockDim.x) {
         Sq c = fe_canon(fe_reduce(lds_ld(A, k)));
@@ -537,32 +538,53 @@ __global__ void __launch_bounds__(256) k_gk_tile(Workspace W, ChunkIn in, Soa am
         else soa_st(res, (k * W.C + p) * ntiles + tile, c);
     }
 }
-// finish: one workgroup per proof folds the ntiles tile polynomials (T+1 coefs) through levels T..n-1
-__global__ void __launch_bounds__(256) k_gk_finish(Workspace W, ChunkIn in, Soa am, uint32_t T, uint32_t ntiles, Soa res) {
+// finish pass: workgroup (proof, group) folds `gsz` consecutive polynomials (Tin+1 coefs each, canonical) through
+// log2(gsz) levels; the result goes to gk_coef when it is the whole ring, else to dst[(k*C + p)*ngroups + g].
+__global__ void __launch_bounds__(256) k_gk_finish(Workspace W, ChunkIn in, Soa am, uint32_t Tin, uint32_t npoly, uint32_t gsz, Soa src, Soa dst) {
     __shared__ uint32_t ldsA[NLIMB * GK_LDS_A];
     __shared__ uint32_t ldsB[NLIMB * GK_LDS_A];
-    uint32_t p = blockIdx.x;
+    uint32_t ngroups = npoly / gsz;
+    uint32_t p = blockIdx.x / ngroups, g = blockIdx.x % ngroups;
     uint32_t which = in.which[p];
     LdsPlane A = {ldsA, GK_LDS_A}, B = {ldsB, GK_LDS_A};
-    for (uint32_t it = threadIdx.x; it < ntiles * (T + 1); it += blockDim.x) {
-        uint32_t k = it / ntiles, m = it % ntiles;
-        lds_st(A, k * ntiles + m, soa_ld<ModQ, 1>(res, (k * W.C + p) * ntiles + m));  // canonical (< M) on entry
+    for (uint32_t it = threadIdx.x; it < gsz * (Tin + 1); it += blockDim.x) {
+        uint32_t k = it / gsz, m = it % gsz;
+        lds_st(A, k * gsz + m, soa_ld<ModQ, 1>(src, (k * W.C + p) * npoly + g * gsz + m));
     }
     __syncthreads();
-    gk_lds_levels(A, B, ntiles, T, W.n, W, am, p, which);
-    for (uint32_t k = threadIdx.x; k <= W.n; k += blockDim.x) soa_st(W.gk_coef, k * W.C + p, fe_canon(fe_reduce(lds_ld(A, k))));
+    uint32_t lv = 0;
+    while ((1u << lv) < gsz) lv++;
+    gk_lds_levels(A, B, gsz, Tin, Tin + lv, W, am, p, which);
+    for (uint32_t k = threadIdx.x; k <= Tin + lv; k += blockDim.x) {
+        Sq c = fe_canon(fe_reduce(lds_ld(A, k)));
+        if (ngroups == 1) soa_st(W.gk_coef, k * W.C + p, c);
+        else soa_st(dst, (k * W.C + p) * ngroups + g, c);
+    }
 }
 // host-side driver of the fold
 void launch_gk_scalars_fold(hipStream_t s, const Workspace& W, const ChunkIn& in, const Soa& am) {
     uint32_t nt = in.count * W.n;
     hipLaunchKernelGGL(k_gk_scalars, dim3((nt + 255) / 256), dim3(256), 0, s, W, in, am);
     if (W.n >= 3) {
+        const uint32_t RL = W.n >= 4 ? 4 : 3;
         uint32_t T = W.n < GK_TMAX ? W.n : GK_TMAX;
         uint32_t ntiles = W.N >> T;
         // tile results: (T+1) coefs x ntiles per proof, kept in gk_bufA (capacity checked by the workspace carver)
         Soa res = {W.gk_bufA, (uint32_t)((T + 1) * W.C * ntiles)};
-        hipLaunchKernelGGL(k_gk_tile, dim3(in.count * ntiles), dim3(256), 0, s, W, in, am, T, ntiles, res);
-        if (ntiles > 1) hipLaunchKernelGGL(k_gk_finish, dim3(in.count), dim3(256), 0, s, W, in, am, T, ntiles, res);
+        if (RL == 4) hipLaunchKernelGGL(k_gk_tile<4>, dim3(in.count * ntiles), dim3(256), 0, s, W, in, am, T, ntiles, res);
+        else hipLaunchKernelGGL(k_gk_tile<3>, dim3(in.count * ntiles), dim3(256), 0, s, W, in, am, T, ntiles, res);
+        // finish passes: groups of <= 64 polynomials per workgroup (64 x (n+1) <= GK_LDS_A elements), ping-pong bufA/bufB
+        Soa src = res;
+        uint32_t* other = W.gk_bufB;
+        while (ntiles > 1) {
+            uint32_t gsz = ntiles < 64 ? ntiles : 64, ngroups = ntiles / gsz;
+            uint32_t lv = 0;
+            while ((1u << lv) < gsz) lv++;
+            Soa dst = {other, (uint32_t)((T + lv + 1) * W.C * ngroups)};
+            hipLaunchKernelGGL(k_gk_finish, dim3(in.count * ngroups), dim3(256), 0, s, W, in, am, T, ntiles, gsz, src, dst);
+            other = src.p;
+            src = dst, T += lv, ntiles = ngroups;
+        }
         return;
     }
     // tiny rings (N < 8): one kernel per level through ping-pong buffers
