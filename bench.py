@@ -90,7 +90,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=65536, help='proofs per GPU per step')
     ap.add_argument('--ring', type=int, default=65536, help='number of keys in the ring')
-    ap.add_argument('--chunk', type=int, default=16384, help='proofs per pipeline pass')
+    ap.add_argument('--chunk', type=int, default=32768, help='proofs per pipeline pass')
     ap.add_argument('--seed', type=int, default=2024)
     ap.add_argument('--sec', type=int, default=80)
     ap.add_argument('--no-cpu-baseline', action='store_true')
