@@ -18,7 +18,10 @@ static size_t vcarve(zk_ctx* c, uint8_t* base, uint32_t C, uint32_t sec, uint32_
     V.vd = k.list(ns * 5);
     V.gk_f = k.soa((size_t)n * C), V.gk_g = k.soa((size_t)n * C);
     V.gk_total = k.soa(C);
-    auto terms = [&](size_t cnt) { return VTerms{k.soa(cnt), k.soa(cnt), k.soa(cnt), k.soa(cnt)}; };
+    auto terms = [&](size_t cnt) {
+        VTerms t{k.soa(cnt), k.soa(cnt), k.soa(cnt), k.soa(cnt), (uint32_t*)k.take(cnt * 7 * 36 * 4)};
+        return t;
+    };
     auto soa4 = [&](size_t cnt) { return Soa4{k.soa(cnt), k.soa(cnt), k.soa(cnt), k.soa(cnt)}; };
     size_t nq = (n + 1) / 2;
     V.slot_terms = terms(ns * V_SLOT_TERMS);
@@ -127,9 +130,9 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
         }
         {
             Scope t(c, "v_straus_tom");
-            launch_v_straus(s, V.slot_terms, cnt * VK, V.C * VK, 10, 26, V.slot_acc);
-            launch_v_straus(s, V.gk_terms, cnt * nq, V.C * nq, 4, 4, V.gk_acc);
-            launch_v_straus(s, V.misc_terms, 3 * V.C, 3 * V.C, 1, 0, V.misc_acc);
+            launch_v_straus(s, V.slot_terms, V.C * VK * V_SLOT_TERMS, cnt * VK, V.C * VK, 10, 26, V.slot_acc);
+            launch_v_straus(s, V.gk_terms, V.C * nq * 8, cnt * nq, V.C * nq, 4, 4, V.gk_acc);
+            launch_v_straus(s, V.misc_terms, 3 * V.C, 3 * V.C, 3 * V.C, 1, 0, V.misc_acc);
         }
         {
             Scope t(c, "v_tom_fixed");

@@ -127,6 +127,7 @@ struct Soa4 {
 };
 struct VTerms {           // terms of the "sum s_i P_i = identity" checks: niels point on the a=1 image + plain scalar
     Soa nx, ny, ndt, sc;
+    uint32_t* tab;        // window tables, AoS: multiples 1..7 of term idx, 36 words (X, Y, d'T, Z) each, at tab[(idx*7 + e)*36]
 };
 struct VWork {
     uint32_t C, sec, n;
@@ -159,7 +160,7 @@ void launch_v_derived(hipStream_t s, const Workspace& W, const VWork& V, uint32_
 void launch_v_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, uint32_t count, uint32_t N, const uint8_t* proofs, const uint64_t* off, uint64_t first, const Soa& res);
 void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first);
-void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out);
+void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t nterms, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out);
 void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count);
 void launch_v_final(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first);
 

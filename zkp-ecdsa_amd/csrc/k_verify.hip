@@ -723,11 +723,50 @@ __global__ void __launch_bounds__(64) k_v_proof_terms(Workspace W, VWork V, uint
     soa_st(V.pSR, p, SR), soa_st(V.pSH, p, SH), soa_st(V.pSL, p, SL);
 }
 
-// ------------------------------------------------------------------ Straus double-and-add over a group of terms
-ZK_DEV TomNiels ld_term_niels(const VTerms& L, uint32_t idx) {
-    TomNiels n;
-    n.x = soa_ld<ModT, 2>(L.nx, idx), n.y = soa_ld<ModT, 2>(L.ny, idx), n.dt = soa_ld<ModT, 2>(L.ndt, idx);
-    return n;
+// ------------------------------------------------------------------ windowed Straus over a group of terms
+// Per term a table {1P..7P} (extended coordinates with d'*T premultiplied) is built once; the group's lane then runs
+// 86 windows of 3 bits: 3 shared doublings + one table addition per term (9 modmuls), 43 windows for 128-bit terms.
+// Digits never straddle limbs (30 = 10 x 3).
+#define VW_BITS 3
+#define VW_ENT 7
+// table storage is AoS: entry e of term idx = 36 contiguous words (X, Y, d'T, Z) at tab[(idx*7 + e)*36], so that a lane's
+// digit-dependent lookup is one contiguous 144-byte read
+ZK_DEV void st_tab(const VTerms& L, uint32_t e, uint32_t idx, const TomPt& a) {
+    uint4* q = (uint4*)(L.tab + ((size_t)idx * VW_ENT + e) * 36);
+    Ft2 dt = a.t * fe_const<ModT, 1>(TOM_D1_M);
+    uint32_t w[36];
+#pragma unroll
+    for (int l = 0; l < 9; l++) w[l] = a.x.l[l], w[9 + l] = a.y.l[l], w[18 + l] = dt.l[l], w[27 + l] = a.z.l[l];
+#pragma unroll
+    for (int i = 0; i < 9; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+__global__ void __launch_bounds__(256) k_v_term_tables(VTerms L, uint32_t nterms) {
+    uint32_t idx = gtid();
+    if (idx >= nterms) return;
+    TomPt p;
+    p.x = soa_ld<ModT, 2>(L.nx, idx), p.y = soa_ld<ModT, 2>(L.ny, idx);
+    p.t = p.x * p.y, p.z = fe_one_mont<ModT>().as<2>();
+    TomPt m = p;
+    st_tab(L, 0, idx, m);
+#pragma unroll 1
+    for (uint32_t e = 1; e < VW_ENT; e++) {
+        m = e == 1 ? tom_dbl(p) : tom_add(m, p);
+        st_tab(L, e, idx, m);
+    }
+}
+// addition with a table entry (X2, Y2, d'T2, Z2): 9 modmuls
+ZK_DEV TomPt tom_add_tab(const TomPt& p, const Ft2& x2, const Ft2& y2, const Ft2& dt2, const Ft2& z2) {
+    auto A = p.x * x2;
+    auto B = p.y * y2;
+    auto C = p.t * dt2;
+    auto D = p.z * z2;
+    auto E = ((p.x + p.y) * (x2 + y2) - A) - B;
+    auto F = D - C;
+    auto G = D + C;
+    auto H = B - A;
+    TomPt r;
+    r.x = E * F, r.y = G * H, r.t = E * H, r.z = F * G;
+    return r;
 }
 __global__ void __launch_bounds__(256) k_v_straus(VTerms L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, Soa4 out) {
     uint32_t g = gtid();
@@ -735,24 +774,36 @@ __global__ void __launch_bounds__(256) k_v_straus(VTerms L, uint32_t ngroups, ui
     TomPt acc = tom_identity();
     uint32_t nt = n256 + n128;
 #pragma unroll 1
-    for (int b = 255; b >= 0; b--) {
-        acc = tom_dbl(acc);
-        uint32_t kmax = b >= 128 ? n256 : nt;
+    for (int w = 85; w >= 0; w--) {
+        acc = tom_dbl(tom_dbl(tom_dbl(acc)));
+        uint32_t kmax = w >= 43 ? n256 : nt;
+        uint32_t limb_i = (uint32_t)w / 10, sh = 3 * ((uint32_t)w % 10);
 #pragma unroll 1
         for (uint32_t k = 0; k < kmax; k++) {
             uint32_t idx = k * ng_stride + g;
-            // bit b of the plain scalar (30-bit limbs)
-            uint32_t limb = L.sc.p[(size_t)(b / 30) * L.sc.stride + idx];
-            bool bit = (limb >> (b % 30)) & 1;
-            TomPt s = tom_add_niels(acc, ld_term_niels(L, idx));
-            acc.x = fe_select(bit, s.x, acc.x), acc.y = fe_select(bit, s.y, acc.y);
-            acc.t = fe_select(bit, s.t, acc.t), acc.z = fe_select(bit, s.z, acc.z);
+            uint32_t limb = L.sc.p[(size_t)limb_i * L.sc.stride + idx];
+            uint32_t d = (limb >> sh) & 7;
+            const uint4* q = (const uint4*)(L.tab + ((size_t)idx * VW_ENT + (d ? d - 1 : 0)) * 36);
+            uint32_t tw[36];
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                uint4 v = q[i];
+                tw[4 * i] = v.x, tw[4 * i + 1] = v.y, tw[4 * i + 2] = v.z, tw[4 * i + 3] = v.w;
+            }
+            Ft2 x2, y2, dt2, z2;
+#pragma unroll
+            for (int l = 0; l < 9; l++) x2.l[l] = tw[l], y2.l[l] = tw[9 + l], dt2.l[l] = tw[18 + l], z2.l[l] = tw[27 + l];
+            TomPt s = tom_add_tab(acc, x2, y2, dt2, z2);
+            bool on = d != 0;
+            acc.x = fe_select(on, s.x, acc.x), acc.y = fe_select(on, s.y, acc.y);
+            acc.t = fe_select(on, s.t, acc.t), acc.z = fe_select(on, s.z, acc.z);
         }
     }
     soa_st(out.x, g, acc.x), soa_st(out.y, g, acc.y), soa_st(out.z, g, acc.z), soa_st(out.t, g, acc.t);
 }
-void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out) {
+void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t nterms, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out) {
     if (!ngroups) return;
+    hipLaunchKernelGGL(k_v_term_tables, dim3((nterms + 255) / 256), dim3(256), 0, s, L, nterms);
     hipLaunchKernelGGL(k_v_straus, dim3((ngroups + 255) / 256), dim3(256), 0, s, L, ngroups, ng_stride, n256, n128, out);
 }
 // P-256: 5 A-terms per thread (128-bit randomisers), complete formulas
