@@ -31,9 +31,17 @@ HBM_PEAK_GBPS = 8000.0
 # 2526 per k_tom_commit loop iteration of 16 products (ISA histogram; nominal 171, the zero / power-of-two limbs of
 # the modulus are strength-reduced)
 MACS_PER_MODMUL = 158
-TOM_COMMIT_MODMULS = 64 * 8    # executed: 2 x 32 table additions, 8 modmuls each
+TOM_COMMIT_MODMULS = 32 * 8    # executed: 2 x 16 table additions (16-bit comb windows), 8 modmuls each
 TOM_COMMIT_NOMINAL = 4064      # reference: 256 dbl + 160 add (src/curves/group.ts:97-132)
 TOM_COMMIT_BYTES = 2 * 36 + 3 * 36  # algorithmic HBM bytes per commitment: read (v, r), write (X, Y, Z)
+# PMC pass (profiles/r01_pmc_summary.txt, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, batch 16384):
+# k_tom_commit moved 3238 B (FETCH_SIZE, raw KiB x 1024) + 111 B (WRITE_SIZE) per commitment through the L2's
+# memory-side port: the 32 gathers of 112-byte table entries (235 MB of tables live in Infinity Cache / HBM) dominate.
+# FETCH_SIZE is uncalibrated for 16-byte-per-lane gathers on gfx950 (MI355X_MICROARCH.md section HBM); reported raw.
+TOM_COMMIT_PMC_BYTES = 3238 + 111
+# same pass, SQ counters: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = 0.525 per wave at 2 waves per SIMD (VALU pipe ~saturated),
+# SQ_WAIT_INST_ANY 0.395, SQ_WAIT_ANY (memory) 0.077
+TOM_COMMIT_VALU_ACTIVE_PER_WAVE = 0.525
 
 
 def rank_seeds(base_seeds: bytes, rank: int) -> bytes:
@@ -222,7 +230,10 @@ def main():
             'kernel': 'k_tom_commit',
             'achieved': round(achieved_tmacs, 3), 'peak': VALU_MAD_PEAK_TOPS, 'unit': 'T multiplier-instr/s (v_mad_u64_u32 + v_mul_lo_u32 lane-ops, peak measured by tools/valu_peak.hip)',
             'frac': round(achieved_tmacs / VALU_MAD_PEAK_TOPS, 4),
-            'traffic': None,
+            'traffic': int(commits_per_step / max(1, launches_per_step) * TOM_COMMIT_PMC_BYTES),
+            'traffic_note': 'bytes per launch = units per launch x %d B (FETCH_SIZE + WRITE_SIZE per commitment, separate rocprofv3 --pmc passes, '
+                            'profiles/r01_pmc_summary.txt); table gathers, not the 180 algorithmic bytes, dominate' % TOM_COMMIT_PMC_BYTES,
+            'valu_active_per_wave': TOM_COMMIT_VALU_ACTIVE_PER_WAVE,
             'avg_launch_ms': round(tom_ms / max(1, launches_per_step), 3),
             'launches_per_step': launches_per_step,
             'units_per_step': commits_per_step,

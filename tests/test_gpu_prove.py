@@ -90,3 +90,34 @@ def test_error_statuses():
     _, est = octx.prove_batch(bytes(msg[:32]), bytes(sig[:64]), bytes(pk[:64]), which[:1], streams=blocks, stream_blocks=100)
     assert st == est == [11]
     eng.close()
+
+
+def test_baseline_config2_batch1024_ring1024_all_diffed():
+    """BASELINE.json configs[1]: batch = 1024 proofs, ring = 2^10, every proof compared with the oracle (SHA-256 of the
+    ZKA1 bytes), then every proof verified on the GPU."""
+    eng, octx, (msg, sig, pk, which, seeds) = _setup(2024, 1024, 1024)
+    eng.set_chunk(300)  # ragged chunks
+    got, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    exp, est = octx.prove_batch(msg, sig, pk, which, seeds=seeds, nthreads=64)
+    assert st == est == [0] * 1024
+    bad = [b for b in range(1024) if got[b] != exp[b]]
+    assert not bad, bad[:10]
+    ok, vst = eng.verify_batch(msg, got)
+    assert ok == [1] * 1024 and vst == [0] * 1024
+    eng.close()
+
+
+def test_ring_2_20_prove_and_verify():
+    """Largest ring of BASELINE.json (2^20 keys, n = 20): the multi-pass finish of the GK fold and the verifier's ring fold."""
+    eng, octx, (msg, sig, pk, which, seeds) = _setup(5, 1 << 20, 3)
+    got, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    exp, est = octx.prove_batch(msg, sig, pk, which, seeds=seeds, nthreads=3)
+    assert st == est == [0] * 3
+    assert got == exp
+    vs = b''.join(hashlib.sha256(b'vs%d' % i).digest() for i in range(3))
+    assert eng.verify_batch(msg, got, vseeds=vs) == octx.verify_batch(msg, got, nthreads=3, vseeds=vs) == ([1] * 3, [0] * 3)
+    bad = bytearray(got[1])
+    bad[-40] ^= 4   # zb_{n-1}
+    proofs = [got[0], bytes(bad), got[2]]
+    assert eng.verify_batch(msg, proofs, vseeds=vs) == octx.verify_batch(msg, proofs, nthreads=3, vseeds=vs) == ([1, 0, 1], [0] * 3)
+    eng.close()

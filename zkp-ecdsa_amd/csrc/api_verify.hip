@@ -35,6 +35,7 @@ static size_t vcarve(zk_ctx* c, uint8_t* base, uint32_t C, uint32_t sec, uint32_
     V.clx = k.soa(C), V.cly = k.soa(C);
     uint32_t T = std::min<uint32_t>(n, 11);
     c->v_res = k.soa((size_t)C * (N >> T));
+    c->v_res2 = k.soa((size_t)C * std::max<uint64_t>(1, (N >> T) / 1024));
     return k.off + 256;
 }
 static zk_status ensure_vworkspace(zk_ctx* c, uint32_t C) {
@@ -122,7 +123,7 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
         }
         {
             Scope t(c, "v_gk_total");
-            launch_v_gk_total(s, V, W.ring, cnt, W.N, d_proofs, d_off, first, c->v_res);
+            launch_v_gk_total(s, V, W.ring, cnt, W.N, d_proofs, d_off, first, c->v_res, c->v_res2);
         }
         {
             Scope t(c, "v_terms");

@@ -39,7 +39,7 @@ struct zk_ctx {
     void* varena = nullptr;
     size_t varena_bytes = 0;
     uint32_t vs_C = 0, vs_sec = 0, vs_n = 0;
-    Soa v_res{};
+    Soa v_res{}, v_res2{};
     // timing
     std::vector<TimerRec> trecs;
     std::vector<hipEvent_t> epool;

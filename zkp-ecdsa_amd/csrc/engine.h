@@ -158,7 +158,7 @@ void launch_v_exp_points(hipStream_t s, const Workspace& W, const VWork& V, uint
 void launch_v_t1_scalars(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_derived(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
-void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, uint32_t count, uint32_t N, const uint8_t* proofs, const uint64_t* off, uint64_t first, const Soa& res);
+void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, uint32_t count, uint32_t N, const uint8_t* proofs, const uint64_t* off, uint64_t first, const Soa& res, const Soa& res2);
 void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first);
 void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t nterms, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out);
 void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count);

@@ -480,21 +480,27 @@ __global__ void __launch_bounds__(256) k_v_gk_tile(VWork V, Soa ring, uint32_t T
         else soa_st(res, p * ntiles + tile, c);
     }
 }
-__global__ void __launch_bounds__(256) k_v_gk_finish(VWork V, uint32_t T, uint32_t ntiles, Soa res) {
-    __shared__ uint32_t bufA[NLIMB * (1u << (VGK_T - 3))];
-    __shared__ uint32_t bufB[NLIMB * (1u << (VGK_T - 3))];
-    uint32_t p = blockIdx.x, stride = 1u << (VGK_T - 3);
-    for (uint32_t m = threadIdx.x; m < ntiles; m += blockDim.x) {
-        Sq c = soa_ld<ModQ, 1>(res, p * ntiles + m);
+// finish pass: workgroup (proof, group) folds gsz <= 1024 consecutive tile values through log2(gsz) levels
+#define VGK_FIN 1024u
+__global__ void __launch_bounds__(256) k_v_gk_finish(VWork V, uint32_t Tin, uint32_t npoly, uint32_t gsz, Soa src, Soa dst) {
+    __shared__ uint32_t bufA[NLIMB * VGK_FIN];
+    __shared__ uint32_t bufB[NLIMB * VGK_FIN];
+    uint32_t ngroups = npoly / gsz;
+    uint32_t p = blockIdx.x / ngroups, g = blockIdx.x % ngroups, stride = VGK_FIN;
+    for (uint32_t m = threadIdx.x; m < gsz; m += blockDim.x) {
+        Sq c = soa_ld<ModQ, 1>(src, p * npoly + g * gsz + m);
         for (int l = 0; l < NLIMB; l++) bufA[l * stride + m] = c.l[l];
     }
     __syncthreads();
+    uint32_t lv = 0;
+    while ((1u << lv) < gsz) lv++;
     uint32_t *A = bufA, *B = bufB;
-    v_gk_lds_levels(A, B, ntiles, T, V.n, V, p, stride);
+    v_gk_lds_levels(A, B, gsz, Tin, Tin + lv, V, p, stride);
     if (threadIdx.x == 0) {
         Fe<ModQ, 4> r;
         for (int l = 0; l < NLIMB; l++) r.l[l] = A[l * stride];
-        soa_st(V.gk_total, p, fe_canon(r));
+        if (ngroups == 1) soa_st(V.gk_total, p, fe_canon(r));
+        else soa_st(dst, p * ngroups + g, fe_canon(r));
     }
 }
 // tiny rings (n < 3): one thread per proof
@@ -510,7 +516,7 @@ __global__ void k_v_gk_small(VWork V, Soa ring, uint32_t count) {
     }
     soa_st(V.gk_total, p, fe_canon(v[0]));
 }
-void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, uint32_t count, uint32_t N, const uint8_t* proofs, const uint64_t* off, uint64_t first, const Soa& res) {
+void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, uint32_t count, uint32_t N, const uint8_t* proofs, const uint64_t* off, uint64_t first, const Soa& res, const Soa& res2) {
     uint32_t nt = count * V.n;
     hipLaunchKernelGGL(k_v_gk_fg, dim3((nt + 255) / 256), dim3(256), 0, s, V, count, proofs, off, first);
     if (V.n < 3) {
@@ -519,7 +525,14 @@ void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, uint32_t 
     }
     uint32_t T = V.n < VGK_T ? V.n : VGK_T, ntiles = N >> T;
     hipLaunchKernelGGL(k_v_gk_tile, dim3(count * ntiles), dim3(256), 0, s, V, ring, T, ntiles, res);
-    if (ntiles > 1) hipLaunchKernelGGL(k_v_gk_finish, dim3(count), dim3(256), 0, s, V, T, ntiles, res);
+    Soa src = res, dst = res2;
+    while (ntiles > 1) {
+        uint32_t gsz = ntiles < VGK_FIN ? ntiles : VGK_FIN, ngroups = ntiles / gsz, lv = 0;
+        while ((1u << lv) < gsz) lv++;
+        hipLaunchKernelGGL(k_v_gk_finish, dim3(count * ngroups), dim3(256), 0, s, V, T, ntiles, gsz, src, dst);
+        Soa tmp = src;
+        src = dst, dst = tmp, T += lv, ntiles = ngroups;
+    }
 }
 
 // ------------------------------------------------------------------ term construction
