@@ -18,6 +18,7 @@ static size_t vcarve(zk_ctx* c, uint8_t* base, uint32_t C, uint32_t sec, uint32_
     V.vd = k.list(ns * 5);
     V.gk_f = k.soa((size_t)n * C), V.gk_g = k.soa((size_t)n * C);
     V.gk_total = k.soa(C);
+    V.gk_swap = (uint32_t*)k.take(4 * (size_t)n * C);
     auto terms = [&](size_t cnt) {
         VTerms t{k.soa(cnt), k.soa(cnt), k.soa(cnt), k.soa(cnt), (uint32_t*)k.take(cnt * 7 * 36 * 4)};
         return t;
@@ -33,7 +34,7 @@ static size_t vcarve(zk_ctx* c, uint8_t* base, uint32_t C, uint32_t sec, uint32_
     V.pa_x = k.soa(ns), V.pa_y = k.soa(ns), V.pa_sc = k.soa(ns);
     V.pacc = k.soa3((size_t)C * 4);
     V.clx = k.soa(C), V.cly = k.soa(C);
-    uint32_t T = std::min<uint32_t>(n, 11);
+    uint32_t T = std::min<uint32_t>(n, 13);
     c->v_res = k.soa((size_t)C * (N >> T));
     c->v_res2 = k.soa((size_t)C * std::max<uint64_t>(1, (N >> T) / 1024));
     return k.off + 256;

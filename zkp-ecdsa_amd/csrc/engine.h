@@ -141,7 +141,8 @@ struct VWork {
     uint32_t* idx;        // [C][VK] checked rep index | bit << 8
     uint32_t* vc;         // [C*VK][6][3] sub-proof challenges
     TomList vd;           // [C*VK*5] derived commitments (proj + affine)
-    Soa gk_f, gk_g;       // [n*C] f_j, x - f_j (Montgomery)
+    Soa gk_f, gk_g;       // [n*C] rho_j = f_j/g_j and the level's scale factor g_j (Montgomery); see k_v_gk_fg
+    uint32_t* gk_swap;    // [n*C] 1 where g_j = 0 (x = f_j): the level keeps the odd branch, scale f_j
     Soa gk_total;         // [C]
     VTerms slot_terms, gk_terms, misc_terms;
     Soa4 slot_acc, gk_acc, misc_acc;

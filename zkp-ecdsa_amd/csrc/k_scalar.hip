@@ -461,15 +461,20 @@ ZK_DEV Sq64 as64(const Fe<ModQ, K>& v) {  // bound bookkeeping only (see Sq64)
 }
 // Depth-first register fold of 2^LEV consecutive ring elements: polynomial with LEV+1 coefficients, lazily reduced
 // (coefficient bound K(LEV) = 2 LEV + 1 multiples of q: c = a*(od - ev) [< 2q] + sel [< K(LEV-1) q]).
+// The index bits can be folded in any order (the p_i are products of per-bit linear factors): a lane's 2^LEV elements
+// are `stride` apart, so lanes read consecutive ring elements (coalesced) and the register phase folds index bits
+// bit0 .. bit0+LEV-1; the number of coefficients only depends on how many bits have been folded.
 template <int LEV>
 struct GkFold {
     static constexpr int K = 2 * LEV + 1;
-    static ZK_DEV void run(const Soa& ring, const Soa& am, uint32_t C, uint32_t p, uint32_t which, uint32_t base, Fe<ModQ, K> (&out)[LEV + 1]) {
+    static ZK_DEV void run(const Soa& ring, const Soa& am, uint32_t C, uint32_t p, uint32_t which, uint32_t base, uint32_t stride, uint32_t bit0,
+                           Fe<ModQ, K> (&out)[LEV + 1]) {
         Fe<ModQ, GkFold<LEV - 1>::K> ev[LEV], od[LEV];
-        GkFold<LEV - 1>::run(ring, am, C, p, which, base, ev);
-        GkFold<LEV - 1>::run(ring, am, C, p, which, base + (1u << (LEV - 1)), od);
-        Fe<ModQ, 2> a = soa_ld<ModQ, 2>(am, (LEV - 1) * C + p);
-        bool l = (which >> (LEV - 1)) & 1;
+        GkFold<LEV - 1>::run(ring, am, C, p, which, base, stride, bit0, ev);
+        GkFold<LEV - 1>::run(ring, am, C, p, which, base + (stride << (LEV - 1)), stride, bit0, od);
+        uint32_t jb = bit0 + LEV - 1;
+        Fe<ModQ, 2> a = soa_ld<ModQ, 2>(am, jb * C + p);
+        bool l = (which >> jb) & 1;
 #pragma unroll
         for (int k = 0; k < LEV; k++) {
             Fe<ModQ, 2> prod = a * (od[k] - ev[k]);
@@ -482,15 +487,19 @@ struct GkFold {
 template <>
 struct GkFold<0> {
     static constexpr int K = 1;
-    static ZK_DEV void run(const Soa& ring, const Soa&, uint32_t, uint32_t, uint32_t, uint32_t base, Fe<ModQ, 1> (&out)[1]) { out[0] = soa_ld<ModQ, 1>(ring, base); }
+    static ZK_DEV void run(const Soa& ring, const Soa&, uint32_t, uint32_t, uint32_t, uint32_t base, uint32_t, uint32_t, Fe<ModQ, 1> (&out)[1]) {
+        out[0] = soa_ld<ModQ, 1>(ring, base);
+    }
 };
 // levels j0..j1-1 of `npoly` polynomials (j0+1 coefs each) held in LDS plane A (element (k*npoly + m)); result left in
 // the plane returned by reference (ping-pong with B).  All threads of the workgroup must call this.
-ZK_DEV void gk_lds_levels(LdsPlane& A, LdsPlane& B, uint32_t npoly, uint32_t j0, uint32_t j1, const Workspace& W, const Soa& am, uint32_t p, uint32_t which) {
-    for (uint32_t j = j0; j < j1; j++) {
+// `deg0` = index bits already folded (polynomials have deg0+1 coefficients), the steps fold index bits bit0, bit0+1, ...
+ZK_DEV void gk_lds_levels(LdsPlane& A, LdsPlane& B, uint32_t npoly, uint32_t deg0, uint32_t nsteps, uint32_t bit0, const Workspace& W, const Soa& am, uint32_t p, uint32_t which) {
+    for (uint32_t st = 0; st < nsteps; st++) {
+        uint32_t j = deg0 + st, jb = bit0 + st;
         uint32_t nout = npoly >> 1;
-        Fe<ModQ, 2> a = soa_ld<ModQ, 2>(am, j * W.C + p);
-        bool l = (which >> j) & 1;
+        Fe<ModQ, 2> a = soa_ld<ModQ, 2>(am, jb * W.C + p);
+        bool l = (which >> jb) & 1;
         uint32_t items = nout * (j + 2);
         for (uint32_t it = threadIdx.x; it < items; it += blockDim.x) {
             uint32_t k = it / nout, m = it % nout;
@@ -525,12 +534,12 @@ __global__ void __launch_bounds__(256) k_gk_tile(Workspace W, ChunkIn in, Soa am
     LdsPlane A = {ldsA, A_EL}, B = {ldsB, B_EL};
     if (t < lanes) {
         Fe<ModQ, GkFold<RL>::K> poly[RL + 1];
-        GkFold<RL>::run(W.ring, am, W.C, p, which, (tile << T) + (t << RL), poly);
+        GkFold<RL>::run(W.ring, am, W.C, p, which, (tile << T) + t, lanes, T - RL, poly);
 #pragma unroll
         for (int k = 0; k <= RL; k++) lds_st(A, k * lanes + t, poly[k]);
     }
     __syncthreads();
-    gk_lds_levels(A, B, lanes, RL, T, W, am, p, which);
+    gk_lds_levels(A, B, lanes, RL, T - RL, 0, W, am, p, which);  // adjacent lanes differ in index bit 0, then 1, ...
     bool whole = ntiles == 1;
     for (uint32_t k = t; k <= T; k += blockDim.x) {
         Sq c = fe_canon(fe_reduce(lds_ld(A, k)));
@@ -554,7 +563,7 @@ __global__ void __launch_bounds__(256) k_gk_finish(Workspace W, ChunkIn in, Soa 
     __syncthreads();
     uint32_t lv = 0;
     while ((1u << lv) < gsz) lv++;
-    gk_lds_levels(A, B, gsz, Tin, Tin + lv, W, am, p, which);
+    gk_lds_levels(A, B, gsz, Tin, lv, Tin, W, am, p, which);
     for (uint32_t k = threadIdx.x; k <= Tin + lv; k += blockDim.x) {
         Sq c = fe_canon(fe_reduce(lds_ld(A, k)));
         if (ngroups == 1) soa_st(W.gk_coef, k * W.C + p, c);

@@ -165,14 +165,21 @@ __global__ void __launch_bounds__(64) k_v_front(DevParams P, Workspace W, VWork 
 }
 
 // ------------------------------------------------------------------ hashing from proof bytes
-ZK_DEV void absorb_tom_bytes(ShaStream& s, const uint8_t* p72) {
+ZK_DEV void absorb_tom_bytes(ShaStream& s, const uint8_t* p72) {  // 36-byte padded coordinates -> 33-byte encodings
+    uint32_t w[9];
     s.put_byte(4);
-    for (int i = 3; i < 36; i++) s.put_byte(p72[i]);
-    for (int i = 39; i < 72; i++) s.put_byte(p72[i]);
+    ld_words_be(p72, 9, w);
+    s.put_be<33>(w);
+    ld_words_be(p72 + 36, 9, w);
+    s.put_be<33>(w);
 }
 ZK_DEV void absorb_p256_bytes(ShaStream& s, const uint8_t* p64) {
+    uint32_t w[8];
     s.put_byte(4);
-    for (int i = 0; i < 64; i++) s.put_byte(p64[i]);
+    load_be32(p64, w);
+    s.put_be<32>(w);
+    load_be32(p64 + 32, w);
+    s.put_be<32>(w);
 }
 ZK_DEV void absorb_tom_soa(ShaStream& s, const Soa& ax, const Soa& ay, uint32_t e) {
     uint32_t w[9];
@@ -419,7 +426,7 @@ __global__ void __launch_bounds__(256) k_v_padd_hash(DevParams P, Workspace W, V
 
 // ------------------------------------------------------------------ GK total (gk.ts:239-250), fold form:
 // layer' [i] = (x - f_j) * layer[2i] + f_j * layer[2i+1]; tile of 2^T ring elements per workgroup, levels through LDS
-#define VGK_T 11
+#define VGK_T 13   // 256 lanes x 32 elements per tile
 __global__ void __launch_bounds__(256) k_v_gk_fg(VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
     uint32_t t = gtid();
     if (t >= count * V.n) return;
@@ -433,17 +440,40 @@ __global__ void __launch_bounds__(256) k_v_gk_fg(VWork V, uint32_t count, const 
         limbs_from_words<8>(x.l, xw);
         g = fe_sub_mod(x, f);
     }
-    soa_st(V.gk_f, j * V.C + p, fe_to_mont(f));
-    soa_st(V.gk_g, j * V.C + p, fe_to_mont(g));
+    // gk_f <- rho_j = f_j / g_j (Montgomery), gk_g <- scale factor g_j; if g_j = 0 (x = f_j): rho_j = 0 with the roles of
+    // even/odd swapped (flag in limb 8 bit 29 of gk_g is not needed: rho = 0 and scale = f_j, see v_gk_pair)
+    bool gz = fe_is_zero(g);
+    Fe<ModQ, 2> gm = fe_to_mont(gz ? f : g), fm = fe_to_mont(f);
+    Fe<ModQ, 2> rho = gz ? fe_zero<ModQ>().as<2>() : fm * fe_inv<ModQ>(gm);
+    soa_st(V.gk_f, j * V.C + p, rho);
+    soa_st(V.gk_g, j * V.C + p, gm);
+    V.gk_swap[j * V.C + p] = gz ? 1u : 0u;
+}
+// one pair: (x - f) ev + f od = g (ev + rho od); the common factor g_j of every level is applied once at the end.
+// Values stay lazily reduced: each level adds < 2q, so after n <= 28 levels the bound is < 64 q.
+ZK_DEV Fe<ModQ, 64> v_gk_pair(const Fe<ModQ, 64>& ev, const Fe<ModQ, 64>& od, const Fe<ModQ, 2>& rho, bool swap) {
+    Fe<ModQ, 64> r;
+    if (swap) return od;  // g_j = 0: the even branch vanishes, scale = f_j
+    auto t = rho * od + ev;  // < 66q by type, < 2 (j+1) q by induction
+#pragma unroll
+    for (int l = 0; l < NLIMB; l++) r.l[l] = t.l[l];
+    return r;
+}
+// total = (prod_j scale_j) * folded value   (scale_j = g_j, or f_j where g_j = 0)
+ZK_DEV Sq v_gk_scale(const VWork& V, uint32_t p, const Fe<ModQ, 64>& r) {
+    Fe<ModQ, 2> acc = fe_reduce(r);  // plain value, < 2q
+    for (uint32_t j = 0; j < V.n; j++) acc = acc * soa_ld<ModQ, 2>(V.gk_g, j * V.C + p);  // Montgomery factor: stays plain
+    return fe_canon(acc);
 }
 ZK_DEV void v_gk_lds_levels(uint32_t*& A, uint32_t*& B, uint32_t cnt, uint32_t j0, uint32_t j1, const VWork& V, uint32_t p, uint32_t stride) {
     for (uint32_t j = j0; j < j1; j++) {
         uint32_t nout = cnt >> 1;
-        Fe<ModQ, 2> f = soa_ld<ModQ, 2>(V.gk_f, j * V.C + p), g = soa_ld<ModQ, 2>(V.gk_g, j * V.C + p);
+        Fe<ModQ, 2> rho = soa_ld<ModQ, 2>(V.gk_f, j * V.C + p);
+        bool swap = V.gk_swap[j * V.C + p] != 0;
         for (uint32_t m = threadIdx.x; m < nout; m += blockDim.x) {
-            Fe<ModQ, 4> ev, od;
+            Fe<ModQ, 64> ev, od;
             for (int l = 0; l < NLIMB; l++) ev.l[l] = A[l * stride + 2 * m], od.l[l] = A[l * stride + 2 * m + 1];
-            auto r = g * ev + f * od;  // < 4M, normalised
+            auto r = v_gk_pair(ev, od, rho, swap);
             for (int l = 0; l < NLIMB; l++) B[l * stride + m] = r.l[l];
         }
         __syncthreads();
@@ -452,32 +482,40 @@ ZK_DEV void v_gk_lds_levels(uint32_t*& A, uint32_t*& B, uint32_t cnt, uint32_t j
         cnt = nout;
     }
 }
+// depth-first register fold of 2^LEV consecutive ring elements (one modmul per pair)
+// The contraction sum_i v_i prod_j w_{j, bit_j(i)} can fold the index bits in any order.  A lane's 2^LEV elements are
+// `stride` apart (lanes read consecutive elements: coalesced), so the register phase folds index bits bit0 .. bit0+LEV-1.
+template <int LEV>
+struct VFold {
+    static ZK_DEV Fe<ModQ, 64> run(const VWork& V, const Soa& ring, uint32_t p, uint32_t base, uint32_t stride, uint32_t bit0) {
+        Fe<ModQ, 64> ev = VFold<LEV - 1>::run(V, ring, p, base, stride, bit0);
+        Fe<ModQ, 64> od = VFold<LEV - 1>::run(V, ring, p, base + (stride << (LEV - 1)), stride, bit0);
+        uint32_t j = bit0 + LEV - 1;
+        return v_gk_pair(ev, od, soa_ld<ModQ, 2>(V.gk_f, j * V.C + p), V.gk_swap[j * V.C + p] != 0);
+    }
+};
+template <>
+struct VFold<0> {
+    static ZK_DEV Fe<ModQ, 64> run(const VWork&, const Soa& ring, uint32_t, uint32_t base, uint32_t, uint32_t) { return soa_ld<ModQ, 1>(ring, base).as<64>(); }
+};
+template <int RL>
 __global__ void __launch_bounds__(256) k_v_gk_tile(VWork V, Soa ring, uint32_t T, uint32_t ntiles, Soa res) {
-    __shared__ uint32_t bufA[NLIMB * (1u << (VGK_T - 3))];
-    __shared__ uint32_t bufB[NLIMB * (1u << (VGK_T - 3))];
+    __shared__ uint32_t bufA[NLIMB * 256];
+    __shared__ uint32_t bufB[NLIMB * 256];
     uint32_t p = blockIdx.x / ntiles, tile = blockIdx.x % ntiles, t = threadIdx.x;
-    uint32_t lanes = 1u << (T - 3), stride = 1u << (VGK_T - 3);
+    uint32_t lanes = 1u << (T - RL), stride = 256;
     if (t < lanes) {
-        uint32_t base = (tile << T) + 8 * t;
-        Fe<ModQ, 4> v[8];
-        for (int i = 0; i < 8; i++) v[i] = soa_ld<ModQ, 1>(ring, base + i).as<4>();
-#pragma unroll
-        for (int lev = 0; lev < 3; lev++) {
-            Fe<ModQ, 2> f = soa_ld<ModQ, 2>(V.gk_f, lev * V.C + p), g = soa_ld<ModQ, 2>(V.gk_g, lev * V.C + p);
-#pragma unroll
-            for (int i = 0; i < (4 >> lev); i++) v[i] = g * v[2 * i] + f * v[2 * i + 1];
-        }
-        for (int l = 0; l < NLIMB; l++) bufA[l * stride + t] = v[0].l[l];
+        Fe<ModQ, 64> v = VFold<RL>::run(V, ring, p, (tile << T) + t, lanes, T - RL);
+        for (int l = 0; l < NLIMB; l++) bufA[l * stride + t] = v.l[l];
     }
     __syncthreads();
     uint32_t *A = bufA, *B = bufB;
-    v_gk_lds_levels(A, B, lanes, 3, T, V, p, stride);
+    v_gk_lds_levels(A, B, lanes, 0, T - RL, V, p, stride);  // adjacent lanes differ in index bit 0, then 1, ...
     if (t == 0) {
-        Fe<ModQ, 4> r;
+        Fe<ModQ, 64> r;
         for (int l = 0; l < NLIMB; l++) r.l[l] = A[l * stride];
-        Sq c = fe_canon(r);
-        if (ntiles == 1) soa_st(V.gk_total, p, c);
-        else soa_st(res, p * ntiles + tile, c);
+        if (ntiles == 1) soa_st(V.gk_total, p, v_gk_scale(V, p, r));
+        else soa_st(res, p * ntiles + tile, fe_canon(fe_reduce(r)));
     }
 }
 // finish pass: workgroup (proof, group) folds gsz <= 1024 consecutive tile values through log2(gsz) levels
@@ -497,24 +535,25 @@ __global__ void __launch_bounds__(256) k_v_gk_finish(VWork V, uint32_t Tin, uint
     uint32_t *A = bufA, *B = bufB;
     v_gk_lds_levels(A, B, gsz, Tin, Tin + lv, V, p, stride);
     if (threadIdx.x == 0) {
-        Fe<ModQ, 4> r;
+        Fe<ModQ, 64> r;
         for (int l = 0; l < NLIMB; l++) r.l[l] = A[l * stride];
-        if (ngroups == 1) soa_st(V.gk_total, p, fe_canon(r));
-        else soa_st(dst, p * ngroups + g, fe_canon(r));
+        if (ngroups == 1) soa_st(V.gk_total, p, v_gk_scale(V, p, r));
+        else soa_st(dst, p * ngroups + g, fe_canon(fe_reduce(r)));
     }
 }
 // tiny rings (n < 3): one thread per proof
 __global__ void k_v_gk_small(VWork V, Soa ring, uint32_t count) {
     uint32_t p = gtid();
     if (p >= count) return;
-    Fe<ModQ, 4> v[4];
+    Fe<ModQ, 64> v[4];
     uint32_t N = 1u << V.n;
-    for (uint32_t i = 0; i < 4; i++) v[i] = soa_ld<ModQ, 1>(ring, i < N ? i : 0).as<4>();
+    for (uint32_t i = 0; i < 4; i++) v[i] = soa_ld<ModQ, 1>(ring, i < N ? i : 0).as<64>();
     for (uint32_t j = 0; j < V.n; j++) {
-        Fe<ModQ, 2> f = soa_ld<ModQ, 2>(V.gk_f, j * V.C + p), g = soa_ld<ModQ, 2>(V.gk_g, j * V.C + p);
-        for (uint32_t i = 0; i < (N >> (j + 1)); i++) v[i] = g * v[2 * i] + f * v[2 * i + 1];
+        Fe<ModQ, 2> rho = soa_ld<ModQ, 2>(V.gk_f, j * V.C + p);
+        bool swap = V.gk_swap[j * V.C + p] != 0;
+        for (uint32_t i = 0; i < (N >> (j + 1)); i++) v[i] = v_gk_pair(v[2 * i], v[2 * i + 1], rho, swap);
     }
-    soa_st(V.gk_total, p, fe_canon(v[0]));
+    soa_st(V.gk_total, p, v_gk_scale(V, p, v[0]));
 }
 void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, uint32_t count, uint32_t N, const uint8_t* proofs, const uint64_t* off, uint64_t first, const Soa& res, const Soa& res2) {
     uint32_t nt = count * V.n;
@@ -524,7 +563,8 @@ void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, uint32_t 
         return;
     }
     uint32_t T = V.n < VGK_T ? V.n : VGK_T, ntiles = N >> T;
-    hipLaunchKernelGGL(k_v_gk_tile, dim3(count * ntiles), dim3(256), 0, s, V, ring, T, ntiles, res);
+    if (V.n >= 5) hipLaunchKernelGGL(k_v_gk_tile<5>, dim3(count * ntiles), dim3(256), 0, s, V, ring, T, ntiles, res);
+    else hipLaunchKernelGGL(k_v_gk_tile<3>, dim3(count * ntiles), dim3(256), 0, s, V, ring, T, ntiles, res);
     Soa src = res, dst = res2;
     while (ntiles > 1) {
         uint32_t gsz = ntiles < VGK_FIN ? ntiles : VGK_FIN, ngroups = ntiles / gsz, lv = 0;
