@@ -38,9 +38,13 @@ ZK_DEV void soa_st(const Soa& a, uint32_t e, const Fe<M, K>& v) {
 #define TOM_ENTRY_WORDS 28
 #define TOM_TAB_WORDS ((size_t)TOM_NWIN * TOM_WIN_SIZE * TOM_ENTRY_WORDS)
 // P-256 fixed bases (G, h_NIST): 8-bit windows, entry = affine (x, y) Montgomery limbs, 20 words (80 B); digit 0 unused.
-#define PFIX_NWIN 32
+#ifndef PFIX_WIN_BITS
+#define PFIX_WIN_BITS 16
+#endif
+#define PFIX_NWIN ((256 + PFIX_WIN_BITS - 1) / PFIX_WIN_BITS)
+#define PFIX_WIN_SIZE (1u << PFIX_WIN_BITS)
 #define PFIX_ENTRY_WORDS 20
-#define PFIX_TAB_WORDS (PFIX_NWIN * 256 * PFIX_ENTRY_WORDS)
+#define PFIX_TAB_WORDS ((size_t)PFIX_NWIN * PFIX_WIN_SIZE * PFIX_ENTRY_WORDS)
 // per-proof table of R: 4-bit windows, 64 windows x 16 digits, entry = projective (X, Y, Z), 28 words.
 #define RTAB_NWIN 64
 #define RTAB_ENTRY_WORDS 28

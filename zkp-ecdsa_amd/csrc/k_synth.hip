@@ -56,9 +56,9 @@ ZK_DEV void fixed_mul_affine(const uint32_t* __restrict__ tab, const Fe<ModN, 1>
     P256Pt acc = p256_identity();
 #pragma unroll 1
     for (int w = 0; w < PFIX_NWIN; w++) {
-        uint32_t d = kw[0] & 255;
-        shr256<8>(kw);
-        P256Aff e = ld_pfix_s(tab + (size_t)PFIX_ENTRY_WORDS * (w * 256 + d));
+        uint32_t d = kw[0] & (PFIX_WIN_SIZE - 1);
+        shr256<PFIX_WIN_BITS>(kw);
+        P256Aff e = ld_pfix_s(tab + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + d));
         P256Pt s = p256_add_mixed(acc, e);
         acc = p256_select(d != 0, s, acc);
     }

@@ -5,7 +5,7 @@
 #include "engine.h"
 
 // scratch layout (words): bases [32][36] extended/projective, entries [32*256][36]
-size_t table_scratch_words() { return (size_t)TOM_NWIN * 36 + (size_t)TOM_NWIN * TOM_WIN_SIZE * 36 + 32 * 36 + 32 * 256 * 36; }
+size_t table_scratch_words() { return (size_t)TOM_NWIN * 36 + (size_t)TOM_NWIN * TOM_WIN_SIZE * 36 + (size_t)PFIX_NWIN * 36 + (size_t)PFIX_NWIN * PFIX_WIN_SIZE * 36; }
 
 ZK_DEV void st_tompt(uint32_t* p, const TomPt& a) {
 #pragma unroll
@@ -87,28 +87,28 @@ __global__ void k_pfix_bases(const uint32_t* xy, uint32_t* scratch, int32_t* ok)
         a.y = fe_const<ModQ, 2>(P256_GY_M);
     }
     P256Pt p = p256_from_affine(a);
-    for (int w = 0; w < 32; w++) {
+    for (int w = 0; w < PFIX_NWIN; w++) {
         st_ppt(scratch + 36 * w, p);
-        for (int i = 0; i < 8; i++) p = p256_dbl(p);
+        for (int i = 0; i < PFIX_WIN_BITS; i++) p = p256_dbl(p);
     }
 }
 __global__ void k_pfix_fill(uint32_t* scratch) {
     uint32_t t = gtid();
-    if (t >= 32 * 256) return;
-    uint32_t w = t >> 8, d = t & 255;
+    if (t >= PFIX_NWIN * PFIX_WIN_SIZE) return;
+    uint32_t w = t >> PFIX_WIN_BITS, d = t & (PFIX_WIN_SIZE - 1);
     P256Pt base = ld_ppt(scratch + 36 * w);
     P256Pt acc = p256_identity();
-    for (int b = 7; b >= 0; b--) {
+    for (int b = PFIX_WIN_BITS - 1; b >= 0; b--) {
         acc = p256_dbl(acc);
         P256Pt s = p256_add(acc, base);
         acc = p256_select((d >> b) & 1, s, acc);
     }
-    st_ppt(scratch + 32 * 36 + 36 * t, acc);
+    st_ppt(scratch + PFIX_NWIN * 36 + (size_t)36 * t, acc);
 }
 __global__ void k_pfix_affine(const uint32_t* scratch, uint32_t* tab) {
     uint32_t t = gtid();
-    if (t >= 32 * 256) return;
-    P256Pt a = ld_ppt(scratch + 32 * 36 + 36 * t);
+    if (t >= PFIX_NWIN * PFIX_WIN_SIZE) return;
+    P256Pt a = ld_ppt(scratch + PFIX_NWIN * 36 + (size_t)36 * t);
     Fq2 zi = fe_inv<ModQ>(fe_reduce(a.z));  // identity (digit 0) gives 0 -> entry (0,0), never used
     Fq2 x = a.x * zi, y = a.y * zi;
     uint32_t* e = tab + (size_t)PFIX_ENTRY_WORDS * t;
@@ -118,6 +118,6 @@ __global__ void k_pfix_affine(const uint32_t* scratch, uint32_t* tab) {
 }
 void launch_build_pfix_table(hipStream_t s, const uint32_t* xy, uint32_t* tab, uint32_t* scratch, int32_t* ok) {
     hipLaunchKernelGGL(k_pfix_bases, dim3(1), dim3(64), 0, s, xy, scratch, ok);
-    hipLaunchKernelGGL(k_pfix_fill, dim3(32 * 256 / 64), dim3(64), 0, s, scratch);
-    hipLaunchKernelGGL(k_pfix_affine, dim3(32 * 256 / 64), dim3(64), 0, s, scratch, tab);
+    hipLaunchKernelGGL(k_pfix_fill, dim3((PFIX_NWIN * PFIX_WIN_SIZE + 63) / 64), dim3(64), 0, s, scratch);
+    hipLaunchKernelGGL(k_pfix_affine, dim3((PFIX_NWIN * PFIX_WIN_SIZE + 63) / 64), dim3(64), 0, s, scratch, tab);
 }

@@ -153,9 +153,9 @@ __global__ void __launch_bounds__(64) k_v_front(DevParams P, Workspace W, VWork 
     P256Pt acc = p256_identity();
 #pragma unroll 1
     for (int w = 0; w < PFIX_NWIN; w++) {
-        uint32_t d = kw[0] & 255;
-        shr256<8>(kw);
-        const uint32_t* e = P.pfix_G + (size_t)PFIX_ENTRY_WORDS * (w * 256 + d);
+        uint32_t d = kw[0] & (PFIX_WIN_SIZE - 1);
+        shr256<PFIX_WIN_BITS>(kw);
+        const uint32_t* e = P.pfix_G + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + d);
         P256Aff a;
         for (int l = 0; l < 9; l++) a.x.l[l] = e[l], a.y.l[l] = e[9 + l];
         P256Pt s = p256_add_mixed(acc, a);
@@ -935,9 +935,9 @@ __global__ void __launch_bounds__(64) k_v_final(DevParams P, Workspace W, VWork 
                     words_from_limbs<8>(kw, soa_ld<ModN, 1>(V.pSH, p).l);
 #pragma unroll 1
                     for (int w = 0; w < PFIX_NWIN; w++) {
-                        uint32_t d = kw[0] & 255;
-                        shr256<8>(kw);
-                        const uint32_t* en = P.pfix_H + (size_t)PFIX_ENTRY_WORDS * (w * 256 + d);
+                        uint32_t d = kw[0] & (PFIX_WIN_SIZE - 1);
+                        shr256<PFIX_WIN_BITS>(kw);
+                        const uint32_t* en = P.pfix_H + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + d);
                         P256Aff a;
                         for (int l = 0; l < 9; l++) a.x.l[l] = en[l], a.y.l[l] = en[9 + l];
                         P256Pt s = p256_add_mixed(acc, a);
