@@ -39,15 +39,24 @@ __global__ void __launch_bounds__(256, OCC) k_tom_commit(const uint32_t* __restr
         words_from_limbs<8>(rw, r.l);
     }
     TomPt acc = tom_identity();
+    // software pipeline: the gathers of window w+1 are issued before the two additions of window w
+    uint32_t dv = vw[0] & (TOM_WIN_SIZE - 1), dr = rw[0] & (TOM_WIN_SIZE - 1);
+    shr256<TOM_WIN_BITS>(vw);
+    shr256<TOM_WIN_BITS>(rw);
+    TomNiels ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * dv);
+    TomNiels nh = ld_niels(tab_h + (size_t)TOM_ENTRY_WORDS * dr);
 #pragma unroll 1
     for (int w = 0; w < TOM_NWIN; w++) {
-        uint32_t dv = vw[0] & (TOM_WIN_SIZE - 1), dr = rw[0] & (TOM_WIN_SIZE - 1);
-        TomNiels ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * (w * TOM_WIN_SIZE + dv));
-        TomNiels nh = ld_niels(tab_h + (size_t)TOM_ENTRY_WORDS * (w * TOM_WIN_SIZE + dr));
-        shr256<TOM_WIN_BITS>(vw);
-        shr256<TOM_WIN_BITS>(rw);
-        acc = tom_add_niels(acc, ng);
-        acc = tom_add_niels(acc, nh);
+        TomNiels cg = ng, ch = nh;
+        if (w + 1 < TOM_NWIN) {
+            dv = vw[0] & (TOM_WIN_SIZE - 1), dr = rw[0] & (TOM_WIN_SIZE - 1);
+            shr256<TOM_WIN_BITS>(vw);
+            shr256<TOM_WIN_BITS>(rw);
+            ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * ((size_t)(w + 1) * TOM_WIN_SIZE + dv));
+            nh = ld_niels(tab_h + (size_t)TOM_ENTRY_WORDS * ((size_t)(w + 1) * TOM_WIN_SIZE + dr));
+        }
+        acc = tom_add_niels(acc, cg);
+        acc = tom_add_niels(acc, ch);
     }
     soa_st(L.proj.x, slot, acc.x);
     soa_st(L.proj.y, slot, acc.y);
