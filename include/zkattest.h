@@ -86,6 +86,11 @@ zk_status zk_ctx_set_ring_device(zk_ctx *ctx, const void *d_keys_be32, uint64_t 
 /* Proofs processed per pipeline pass (workspace grows linearly with it).  Default 4096. */
 zk_status zk_ctx_set_chunk(zk_ctx *ctx, uint32_t proofs_per_chunk);
 
+/* Pipeline lanes of the prover: with 2 (default) alternate chunks run on their own HIP stream and workspace, so the
+ * low-occupancy per-proof kernels of one chunk overlap the heavy kernels of the other; 1 = strictly serial kernels
+ * (what bench.py uses for its per-kernel roofline pass). */
+zk_status zk_ctx_set_lanes(zk_ctx *ctx, uint32_t lanes);
+
 /* Upper bound of one proof's ZKA1 size for the current params/ring. */
 uint64_t zk_proof_max_size(const zk_ctx *ctx);
 

@@ -11,7 +11,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 # every symbol include/zkattest.h declares
 SYMBOLS = [
     'zk_ctx_create', 'zk_ctx_destroy', 'zk_strerror', 'zk_last_error', 'zk_ctx_set_params', 'zk_ctx_set_ring',
-    'zk_ctx_set_ring_device', 'zk_ctx_set_chunk', 'zk_proof_max_size', 'zk_prove_batch', 'zk_prove_batch_device',
+    'zk_ctx_set_ring_device', 'zk_ctx_set_chunk', 'zk_ctx_set_lanes', 'zk_proof_max_size', 'zk_prove_batch', 'zk_prove_batch_device',
     'zk_verify_batch', 'zk_verify_batch_device', 'zk_synth_workload', 'zk_synth_params', 'zk_last_timing',
     'zk_test_field_op', 'zk_test_tom_commit', 'zk_test_p256_fixed_mul', 'zk_test_sha256', 'zk_test_rng_draws',
 ]
@@ -56,6 +56,7 @@ def lib():
         L.zk_ctx_set_ring.argtypes = [vp, C.c_char_p, u64]
         L.zk_ctx_set_ring_device.argtypes = [vp, vp, u64]
         L.zk_ctx_set_chunk.argtypes = [vp, u32]
+        L.zk_ctx_set_lanes.argtypes = [vp, u32]
         L.zk_proof_max_size.argtypes = [vp]
         L.zk_proof_max_size.restype = u64
         L.zk_prove_batch.argtypes = [vp, u64, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(ZkRng), vp, u64, vp, vp]
@@ -124,6 +125,9 @@ class Engine:
 
     def set_chunk(self, chunk):
         self._chk(self.L.zk_ctx_set_chunk(self.h, chunk))
+
+    def set_lanes(self, lanes):
+        self._chk(self.L.zk_ctx_set_lanes(self.h, lanes))
 
     def proof_max_size(self):
         return self.L.zk_proof_max_size(self.h)

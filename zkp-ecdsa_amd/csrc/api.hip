@@ -13,6 +13,7 @@ void launch_synth(hipStream_t s, const uint32_t* pfix_G, uint64_t seed, uint64_t
                   uint32_t* which, uint8_t* seeds);
 void launch_synth_param_scalars(hipStream_t s, uint64_t seed, uint8_t* kn_be, uint8_t* kt_be);
 
+#include <cstdlib>
 #include "ctx.h"
 
 extern "C" const char* zk_strerror(zk_status s) {
@@ -73,7 +74,8 @@ extern "C" void zk_ctx_destroy(zk_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto e : c->epool) hipEventDestroy(e);
     hipFree(c->P.tom_tab_g), hipFree(c->P.tom_tab_h), hipFree(c->tom_tab_gen), hipFree(c->P.pfix_G), hipFree(c->P.pfix_H);
-    hipFree(c->tab_scratch), hipFree(c->d_flag), hipFree(c->d_totals), hipFree(c->ring_mem), hipFree(c->arena), hipFree(c->varena);
+    hipFree(c->tab_scratch), hipFree(c->d_flag), hipFree(c->d_totals), hipFree(c->ring_mem), hipFree(c->arena), hipFree(c->varena), hipFree(c->arena2), hipFree(c->d_totals2);
+    if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -158,8 +160,13 @@ extern "C" zk_status zk_ctx_set_ring(zk_ctx* c, const uint8_t* keys, uint64_t nk
     return s;
 }
 extern "C" zk_status zk_ctx_set_chunk(zk_ctx* c, uint32_t chunk) {
-    if (!c || chunk == 0 || chunk > (1u << 20)) return ZK_E_ARG;
+    if (!c || chunk == 0 || chunk > (1u << 18)) return ZK_E_ARG;
     c->chunk = chunk;
+    return ZK_OK;
+}
+extern "C" zk_status zk_ctx_set_lanes(zk_ctx* c, uint32_t lanes) {
+    if (!c || lanes < 1 || lanes > 2) return ZK_E_ARG;
+    c->lanes = lanes;
     return ZK_OK;
 }
 static uint64_t proof_size_host(uint32_t sec, uint32_t n, uint32_t z) {
@@ -171,9 +178,8 @@ extern "C" uint64_t zk_proof_max_size(const zk_ctx* c) {
 }
 
 // ------------------------------------------------------------------ workspace arena
-static size_t carve(zk_ctx* c, uint8_t* base, uint32_t C, uint32_t sec, uint32_t n, uint64_t N) {
+static size_t carve(zk_ctx* c, Workspace& W, Soa& gk_am, uint8_t* base, uint32_t C, uint32_t sec, uint32_t n, uint64_t N) {
     Carver k(base);
-    Workspace& W = c->W;
     uint64_t cs = (uint64_t)C * sec;
     uint64_t items_cap = std::min<uint64_t>(cs, cs / 2 + (uint64_t)(4.0 * std::sqrt((double)cs)) + 64);
     W.C = C, W.sec = sec, W.n = n, W.N = (uint32_t)N, W.items_cap = (uint32_t)items_cap;
@@ -198,7 +204,7 @@ static size_t carve(zk_ctx* c, uint8_t* base, uint32_t C, uint32_t sec, uint32_t
     W.lc = k.list((size_t)C * 4 * n);
     W.gk_x = (uint32_t*)k.take(12 * (size_t)C);
     W.gk_coef = k.soa((size_t)(n + 1) * C);
-    c->gk_am = k.soa((size_t)n * C);
+    gk_am = k.soa((size_t)n * C);
     // fused fold (n >= 3): gk_bufA holds the tile polynomials, (T+1) coefs x N/2^T tiles per proof; the per-level
     // fallback for tiny rings ping-pongs G*N elements between gk_bufA and gk_bufB
     uint64_t g = std::max<uint64_t>(1, std::min<uint64_t>(C, ((uint64_t)1 << 16) / N));
@@ -213,21 +219,36 @@ static size_t carve(zk_ctx* c, uint8_t* base, uint32_t C, uint32_t sec, uint32_t
     W.ring = Soa{c->ring_mem, (uint32_t)N};
     return k.off + 256;
 }
-zk_status ensure_workspace(zk_ctx* c, uint32_t C) {
+zk_status ensure_workspace(zk_ctx* c, uint32_t C, bool second_lane) {
     uint32_t sec = c->P.sec, n = c->n;
-    if (c->arena && c->ws_C == C && c->ws_sec == sec && c->ws_n == n) {
-        c->W.ring = Soa{c->ring_mem, (uint32_t)c->N};
-        return ZK_OK;
+    bool same = c->arena && c->ws_C == C && c->ws_sec == sec && c->ws_n == n;
+    if (!same) {
+        size_t need = carve(c, c->W, c->gk_am, nullptr, C, sec, n, c->N);
+        if (need > c->arena_bytes) {
+            if (c->arena) HIPCHK(c, hipFree(c->arena));
+            c->arena = nullptr, c->arena_bytes = 0;
+            HIPCHK(c, hipMalloc(&c->arena, need));
+            c->arena_bytes = need;
+        }
+        carve(c, c->W, c->gk_am, (uint8_t*)c->arena, C, sec, n, c->N);
+        c->ws_C = C, c->ws_sec = sec, c->ws_n = n;
+        c->lane2_ready = false;
     }
-    size_t need = carve(c, nullptr, C, sec, n, c->N);
-    if (need > c->arena_bytes) {
-        if (c->arena) HIPCHK(c, hipFree(c->arena));
-        c->arena = nullptr, c->arena_bytes = 0;
-        HIPCHK(c, hipMalloc(&c->arena, need));
-        c->arena_bytes = need;
+    c->W.ring = Soa{c->ring_mem, (uint32_t)c->N};
+    if (second_lane && !c->lane2_ready) {
+        size_t need = carve(c, c->W2, c->gk_am2, nullptr, C, sec, n, c->N);
+        if (need > c->arena2_bytes) {
+            if (c->arena2) HIPCHK(c, hipFree(c->arena2));
+            c->arena2 = nullptr, c->arena2_bytes = 0;
+            HIPCHK(c, hipMalloc(&c->arena2, need));
+            c->arena2_bytes = need;
+        }
+        carve(c, c->W2, c->gk_am2, (uint8_t*)c->arena2, C, sec, n, c->N);
+        if (!c->stream2) HIPCHK(c, hipStreamCreate(&c->stream2));
+        if (!c->d_totals2) HIPCHK(c, hipMalloc(&c->d_totals2, 64));
+        c->lane2_ready = true;
     }
-    carve(c, (uint8_t*)c->arena, C, sec, n, c->N);
-    c->ws_C = C, c->ws_sec = sec, c->ws_n = n;
+    if (c->lane2_ready) c->W2.ring = c->W.ring;
     return ZK_OK;
 }
 
@@ -238,144 +259,154 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
     if (!c->params_set || !c->N) return ZK_E_BUFFER;
     if (rng_mode != ZK_RNG_SEED && rng_mode != ZK_RNG_STREAM) return ZK_E_ARG;
     uint32_t C = (uint32_t)std::min<uint64_t>(c->chunk, B ? B : 1);
-    zk_status zs = ensure_workspace(c, C);
+    const bool dual = c->lanes >= 2 && B > C;  // two or more chunks: alternate them over two streams / workspaces
+    zk_status zs = ensure_workspace(c, C, dual);
     if (zs) return zs;
-    Workspace& W = c->W;
     const DevParams& P = c->P;
-    hipStream_t s = c->stream;
     timing_begin(c);
     uint64_t cursor = 0;
     if (B == 0) {
-        HIPCHK(c, hipMemsetAsync(d_out_off, 0, 8, s));
-        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, hipMemsetAsync(d_out_off, 0, 8, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         return ZK_OK;
     }
-    for (uint64_t first = 0; first < B; first += C) {
+    uint32_t chunk_no = 0;
+    for (uint64_t first = 0; first < B; first += C, chunk_no++) {
+        const bool lane2 = dual && (chunk_no & 1);
+        Workspace& W = lane2 ? c->W2 : c->W;
+        hipStream_t s = lane2 ? c->stream2 : c->stream;
+        const Soa& gk_am = lane2 ? c->gk_am2 : c->gk_am;
+        uint32_t* d_totals = lane2 ? c->d_totals2 : c->d_totals;
         uint32_t cnt = (uint32_t)std::min<uint64_t>(C, B - first);
         ChunkIn in{d_msg + 32 * first, d_sig + 64 * first, d_pk + 64 * first, d_which + first, cnt};
         W.rng.seeds = d_rng, W.rng.stream = d_rng, W.rng.stride_blocks = stride, W.rng.mode = rng_mode, W.rng.sec = (int)W.sec;
         W.rng.proof_base = (uint32_t)first;
         uint32_t nblk = 3 + 44 * W.sec + 5 * W.n + RNG_MAX_EXC;
         {
-            Scope t(c, "rng_prepass");
+            Scope t(c, "rng_prepass", s);
             launch_rng_prepass(s, W, cnt, nblk);
         }
         {
-            Scope t(c, "p256_front");
+            Scope t(c, "p256_front", s);
             launch_front(s, P, W, in);
         }
         {
-            Scope t(c, "p256_rtab");
+            Scope t(c, "p256_rtab", s);
             launch_rtab(s, W, cnt);
         }
         {
-            Scope t(c, "p256_exp_commit");
+            Scope t(c, "p256_exp_commit", s);
             launch_exp_commit(s, P, W, cnt);
         }
         {
-            Scope t(c, "p256_normalize");
+            Scope t(c, "p256_normalize", s);
             launch_p256_normalize(s, W.Tproj, cnt * (W.sec + 1), W.Tx, W.Ty, W.st, W.sec + 1, ZK_ST_T_INF_LATE, nullptr);
             launch_p256_normalize(s, W.Aproj, cnt * (W.sec + 1), W.Ax, W.Ay, W.st, W.sec + 1, 0, nullptr);
         }
         uint32_t na = cnt * (2 + 2 * W.sec);
         {
-            Scope t(c, "scalars");
+            Scope t(c, "scalars", s);
             launch_lista_scalars(s, W, cnt);
         }
         {
-            Scope t(c, "tom_commit");
+            Scope t(c, "tom_commit", s);
             launch_tom_commit(s, P, W.la, na, 1, 1);
         }
         {
-            Scope t(c, "tom_normalize");
+            Scope t(c, "tom_normalize", s);
             launch_tom_normalize(s, W.la, na, 0, 1, 1);
         }
         {
-            Scope t(c, "hash");
+            Scope t(c, "hash", s);
             launch_exp_challenge(s, W, cnt);
         }
         uint32_t totals[4];
         {
-            Scope t(c, "scan");
-            launch_scan(s, W, cnt, cursor, out_cap, d_out_off, d_status, c->d_totals, first);
+            Scope t(c, "scan", s);
+            launch_scan(s, W, cnt, cursor, out_cap, d_out_off, d_status, d_totals, first);
         }
-        HIPCHK(c, hipMemcpyAsync(totals, c->d_totals, 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(totals, d_totals, 16, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         if (totals[1]) {
             c->err = "output buffer too small";
+            hipStreamSynchronize(c->stream);
+            if (dual) hipStreamSynchronize(c->stream2);
             return ZK_E_BUFFER;
         }
         uint32_t items = totals[0];
         if (items > W.items_cap) {
             // cannot happen for hash-derived challenges (cap = mean + 8 sigma) unless chunk*sec is tiny, where cap = chunk*sec
             c->err = "zero-bit rep count exceeds workspace capacity";
+            hipStreamSynchronize(c->stream);
+            if (dual) hipStreamSynchronize(c->stream2);
             return ZK_E_BUFFER;
         }
         uint8_t* out = d_out + cursor;
         {
-            Scope t(c, "scan");
+            Scope t(c, "scan", s);
             launch_items(s, W, cnt);
         }
         {
-            Scope t(c, "p256_t1");
+            Scope t(c, "p256_t1", s);
             launch_t1(s, W, items);
         }
         {
-            Scope t(c, "p256_normalize");
+            Scope t(c, "p256_normalize", s);
             launch_p256_normalize(s, W.T1proj, items, W.T1x, W.T1y, W.st, 1, ZK_E_T1_INF, W.item_proof);
         }
         {
-            Scope t(c, "scalars");
+            Scope t(c, "scalars", s);
             launch_padd_scalars(s, P, W, items);
         }
         {
-            Scope t(c, "tom_commit");
+            Scope t(c, "tom_commit", s);
             launch_tom_commit(s, P, W.lb, items * LB_COMMITS, items, 0, W.items_cap);
         }
         {
-            Scope t(c, "tom_normalize");
+            Scope t(c, "tom_normalize", s);
             launch_tom_normalize(s, W.lb, items * LB_COMMITS, 0, items, 0, W.items_cap);
         }
         {
-            Scope t(c, "tom_derived");
+            Scope t(c, "tom_derived", s);
             launch_padd_derived(s, W, items);
             launch_tom_normalize(s, W.lb, items * 5, LB_COMMITS, items, 0, W.items_cap);
         }
         {
-            Scope t(c, "hash");
+            Scope t(c, "hash", s);
             launch_padd_hash(s, P, W, items);
         }
         {
-            Scope t(c, "respond_write");
+            Scope t(c, "respond_write", s);
             launch_padd_respond(s, W, items, out);
             launch_write_padd_points(s, W, items, out);
             launch_write_fixed(s, W, cnt, out);
         }
         {
-            Scope t(c, "gk_fold");
-            launch_gk_scalars_fold(s, W, in, c->gk_am);
+            Scope t(c, "gk_fold", s);
+            launch_gk_scalars_fold(s, W, in, gk_am);
             launch_gk_cd_scalars(s, W, cnt);
         }
         {
-            Scope t(c, "tom_commit");
+            Scope t(c, "tom_commit", s);
             launch_tom_commit(s, P, W.lc, cnt * 4 * W.n, 1, 1);
         }
         {
-            Scope t(c, "tom_normalize");
+            Scope t(c, "tom_normalize", s);
             launch_tom_normalize(s, W.lc, cnt * 4 * W.n, 0, 1, 1);
         }
         {
-            Scope t(c, "hash");
+            Scope t(c, "hash", s);
             launch_gk_hash(s, W, cnt);
         }
         {
-            Scope t(c, "respond_write");
+            Scope t(c, "respond_write", s);
             launch_gk_respond(s, W, in, out);
             launch_status_out(s, W, cnt, d_status, first);
         }
         cursor += (uint64_t)totals[2] | ((uint64_t)totals[3] << 32);
     }
-    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (dual) HIPCHK(c, hipStreamSynchronize(c->stream2));
     HIPCHK(c, hipGetLastError());
     timing_end(c);
     return ZK_OK;

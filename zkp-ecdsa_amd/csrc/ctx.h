@@ -34,6 +34,16 @@ struct zk_ctx {
     Workspace W{};
     Soa gk_am{};
     uint32_t* d_totals = nullptr;
+    // second pipeline lane (alternate chunks run on their own stream + workspace so that the low-occupancy front-end
+    // kernels of chunk k+1 overlap the heavy phases of chunk k)
+    hipStream_t stream2 = nullptr;
+    Workspace W2{};
+    Soa gk_am2{};
+    uint32_t* d_totals2 = nullptr;
+    void* arena2 = nullptr;
+    size_t arena2_bytes = 0;
+    bool lane2_ready = false;
+    uint32_t lanes = 2;
     // verifier workspace
     VWork V{};
     void* varena = nullptr;
@@ -70,12 +80,13 @@ static inline hipEvent_t get_event(zk_ctx* c) {
 struct Scope {
     zk_ctx* c;
     TimerRec r;
-    Scope(zk_ctx* c_, const char* name) : c(c_) {
+    hipStream_t st;
+    Scope(zk_ctx* c_, const char* name, hipStream_t s_ = nullptr) : c(c_), st(s_ ? s_ : c_->stream) {
         r.name = name, r.e0 = get_event(c), r.e1 = get_event(c);
-        hipEventRecord(r.e0, c->stream);
+        hipEventRecord(r.e0, st);
     }
     ~Scope() {
-        hipEventRecord(r.e1, c->stream);
+        hipEventRecord(r.e1, st);
         c->trecs.push_back(r);
     }
 };
@@ -94,7 +105,7 @@ static inline void timing_end(zk_ctx* c) {
     }
 }
 
-zk_status ensure_workspace(zk_ctx* c, uint32_t C);
+zk_status ensure_workspace(zk_ctx* c, uint32_t C, bool second_lane = false);
 
 struct Carver {
     uint8_t* base;
