@@ -74,7 +74,7 @@ extern "C" void zk_ctx_destroy(zk_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto e : c->epool) hipEventDestroy(e);
     hipFree(c->P.tom_tab_g), hipFree(c->P.tom_tab_h), hipFree(c->tom_tab_gen), hipFree(c->P.pfix_G), hipFree(c->P.pfix_H);
-    hipFree(c->tab_scratch), hipFree(c->d_flag), hipFree(c->d_totals), hipFree(c->ring_mem), hipFree(c->arena), hipFree(c->varena), hipFree(c->arena2), hipFree(c->d_totals2);
+    hipFree(c->tab_scratch), hipFree(c->d_flag), hipFree(c->d_totals), hipFree(c->ring_mem), hipFree(c->arena), hipFree(c->varena), hipFree(c->arena2), hipFree(c->d_totals2), hipFree(c->varena2);
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;

@@ -1,9 +1,8 @@
 // zk_verify_batch / zk_verify_batch_device: host-side phase pipeline of the verifier (kernels in k_verify.hip).
 #include "ctx.h"
 
-static size_t vcarve(zk_ctx* c, uint8_t* base, uint32_t C, uint32_t sec, uint32_t n, uint64_t N) {
+static size_t vcarve(VWork& V, Soa& res, Soa& res2, uint8_t* base, uint32_t C, uint32_t sec, uint32_t n, uint64_t N) {
     Carver k(base);
-    VWork& V = c->V;
     V.C = C, V.sec = sec, V.n = n;
     V.st = (int32_t*)k.take(4 * (size_t)C);
     V.exp_st = (int32_t*)k.take(4 * (size_t)C);
@@ -35,22 +34,35 @@ static size_t vcarve(zk_ctx* c, uint8_t* base, uint32_t C, uint32_t sec, uint32_
     V.pacc = k.soa3((size_t)C * 4);
     V.clx = k.soa(C), V.cly = k.soa(C);
     uint32_t T = std::min<uint32_t>(n, 13);
-    c->v_res = k.soa((size_t)C * (N >> T));
-    c->v_res2 = k.soa((size_t)C * std::max<uint64_t>(1, (N >> T) / 1024));
+    res = k.soa((size_t)C * (N >> T));
+    res2 = k.soa((size_t)C * std::max<uint64_t>(1, (N >> T) / 1024));
     return k.off + 256;
 }
-static zk_status ensure_vworkspace(zk_ctx* c, uint32_t C) {
+static zk_status ensure_vworkspace(zk_ctx* c, uint32_t C, bool second_lane) {
     uint32_t sec = c->P.sec, n = c->n;
-    if (c->varena && c->vs_C == C && c->vs_sec == sec && c->vs_n == n) return ZK_OK;
-    size_t need = vcarve(c, nullptr, C, sec, n, c->N);
-    if (need > c->varena_bytes) {
-        if (c->varena) HIPCHK(c, hipFree(c->varena));
-        c->varena = nullptr, c->varena_bytes = 0;
-        HIPCHK(c, hipMalloc(&c->varena, need));
-        c->varena_bytes = need;
+    if (!(c->varena && c->vs_C == C && c->vs_sec == sec && c->vs_n == n)) {
+        size_t need = vcarve(c->V, c->v_res, c->v_res2, nullptr, C, sec, n, c->N);
+        if (need > c->varena_bytes) {
+            if (c->varena) HIPCHK(c, hipFree(c->varena));
+            c->varena = nullptr, c->varena_bytes = 0;
+            HIPCHK(c, hipMalloc(&c->varena, need));
+            c->varena_bytes = need;
+        }
+        vcarve(c->V, c->v_res, c->v_res2, (uint8_t*)c->varena, C, sec, n, c->N);
+        c->vs_C = C, c->vs_sec = sec, c->vs_n = n;
+        c->vlane2_ready = false;
     }
-    vcarve(c, (uint8_t*)c->varena, C, sec, n, c->N);
-    c->vs_C = C, c->vs_sec = sec, c->vs_n = n;
+    if (second_lane && !c->vlane2_ready) {
+        size_t need = vcarve(c->V2, c->v2_res, c->v2_res2, nullptr, C, sec, n, c->N);
+        if (need > c->varena2_bytes) {
+            if (c->varena2) HIPCHK(c, hipFree(c->varena2));
+            c->varena2 = nullptr, c->varena2_bytes = 0;
+            HIPCHK(c, hipMalloc(&c->varena2, need));
+            c->varena2_bytes = need;
+        }
+        vcarve(c->V2, c->v2_res, c->v2_res2, (uint8_t*)c->varena2, C, sec, n, c->N);
+        c->vlane2_ready = true;
+    }
     return ZK_OK;
 }
 
@@ -74,44 +86,49 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
     if (c->P.sec < VK) return ZK_E_SECLEVEL;
     if (B == 0) return ZK_OK;
     uint32_t C = (uint32_t)std::min<uint64_t>(c->chunk, B);
-    zk_status zs = ensure_workspace(c, C);
+    const bool dual = c->lanes >= 2 && B > C;
+    zk_status zs = ensure_workspace(c, C, dual);
     if (zs) return zs;
-    zs = ensure_vworkspace(c, C);
+    zs = ensure_vworkspace(c, C, dual);
     if (zs) return zs;
-    Workspace& W = c->W;
-    VWork& V = c->V;
     const DevParams& P = c->P;
-    hipStream_t s = c->stream;
     timing_begin(c);
     uint8_t* own_seeds = nullptr;
     if (!d_vseeds) {
         HIPCHK(c, hipMalloc(&own_seeds, 32 * B));
-        hipLaunchKernelGGL(k_default_vseeds, dim3((uint32_t)((B + 255) / 256)), dim3(256), 0, s, B, d_msg, own_seeds);
+        hipLaunchKernelGGL(k_default_vseeds, dim3((uint32_t)((B + 255) / 256)), dim3(256), 0, c->stream, B, d_msg, own_seeds);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         d_vseeds = own_seeds;
     }
-    uint32_t nq = (W.n + 1) / 2;
-    for (uint64_t first = 0; first < B; first += C) {
+    uint32_t nq = (c->n + 1) / 2, chunk_no = 0;
+    for (uint64_t first = 0; first < B; first += C, chunk_no++) {
+        const bool lane2 = dual && (chunk_no & 1);
+        Workspace& W = lane2 ? c->W2 : c->W;
+        VWork& V = lane2 ? c->V2 : c->V;
+        hipStream_t s = lane2 ? c->stream2 : c->stream;
+        const Soa& vres = lane2 ? c->v2_res : c->v_res;
+        const Soa& vres2 = lane2 ? c->v2_res2 : c->v_res2;
         uint32_t cnt = (uint32_t)std::min<uint64_t>(C, B - first);
         {
-            Scope t(c, "v_parse_validate");
+            Scope t(c, "v_parse_validate", s);
             launch_v_header_validate(s, V, cnt, d_proofs, d_off, first);
         }
         {
-            Scope t(c, "v_p256_front_rtab");
+            Scope t(c, "v_p256_front_rtab", s);
             launch_v_front(s, P, W, V, cnt, d_proofs, d_off, d_msg, first);
             launch_rtab(s, W, cnt);
         }
         {
-            Scope t(c, "v_hash");
+            Scope t(c, "v_hash", s);
             launch_v_challenges_sample(s, V, cnt, d_proofs, d_off, d_vseeds, first);
         }
         {
-            Scope t(c, "v_p256_exp_points");
+            Scope t(c, "v_p256_exp_points", s);
             launch_v_exp_points(s, W, V, cnt, d_proofs, d_off, first);
             launch_p256_normalize(s, W.Tproj, cnt * VK, W.Tx, W.Ty, W.st, VK, ZK_E_T_INF, nullptr);
         }
         {
-            Scope t(c, "v_tom_fixed");
+            Scope t(c, "v_tom_fixed", s);
             launch_v_t1_scalars(s, W, V, cnt, d_proofs, d_off, first);
             launch_tom_commit(s, P, W.la, cnt * 2 * VK, 2 * VK, 2 + 2 * W.sec);
             launch_tom_normalize(s, W.la, cnt * 2 * VK, 0, 2 * VK, 2 + 2 * W.sec);
@@ -119,37 +136,38 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
             launch_tom_normalize(s, V.vd, cnt * VK * 5, 0, 1, 1);
         }
         {
-            Scope t(c, "v_hash");
+            Scope t(c, "v_hash", s);
             launch_v_padd_hash(s, P, W, V, cnt, d_proofs, d_off, first);
         }
         {
-            Scope t(c, "v_gk_total");
-            launch_v_gk_total(s, V, W.ring, cnt, W.N, d_proofs, d_off, first, c->v_res, c->v_res2);
+            Scope t(c, "v_gk_total", s);
+            launch_v_gk_total(s, V, W.ring, cnt, W.N, d_proofs, d_off, first, vres, vres2);
         }
         {
-            Scope t(c, "v_terms");
+            Scope t(c, "v_terms", s);
             launch_v_terms(s, W, V, cnt, d_proofs, d_off, d_vseeds, first);
         }
         {
-            Scope t(c, "v_straus_tom");
+            Scope t(c, "v_straus_tom", s);
             launch_v_straus(s, V.slot_terms, V.C * VK * V_SLOT_TERMS, cnt * VK, V.C * VK, 10, 26, V.slot_acc);
             launch_v_straus(s, V.gk_terms, V.C * nq * 8, cnt * nq, V.C * nq, 4, 4, V.gk_acc);
             launch_v_straus(s, V.misc_terms, 3 * V.C, 3 * V.C, 3 * V.C, 1, 0, V.misc_acc);
         }
         {
-            Scope t(c, "v_tom_fixed");
+            Scope t(c, "v_tom_fixed", s);
             launch_tom_commit(s, P, W.lc, cnt * 2, 2, 4 * W.n);
         }
         {
-            Scope t(c, "v_straus_p256");
+            Scope t(c, "v_straus_p256", s);
             launch_v_p256_straus(s, V, cnt);
         }
         {
-            Scope t(c, "v_final");
+            Scope t(c, "v_final", s);
             launch_v_final(s, P, W, V, cnt, d_ok, d_status, first);
         }
     }
-    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (dual) HIPCHK(c, hipStreamSynchronize(c->stream2));
     HIPCHK(c, hipGetLastError());
     timing_end(c);
     if (own_seeds) hipFree(own_seeds);

@@ -50,6 +50,11 @@ struct zk_ctx {
     size_t varena_bytes = 0;
     uint32_t vs_C = 0, vs_sec = 0, vs_n = 0;
     Soa v_res{}, v_res2{};
+    VWork V2{};               // second verifier lane
+    void* varena2 = nullptr;
+    size_t varena2_bytes = 0;
+    Soa v2_res{}, v2_res2{};
+    bool vlane2_ready = false;
     // timing
     std::vector<TimerRec> trecs;
     std::vector<hipEvent_t> epool;
