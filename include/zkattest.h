@@ -83,7 +83,8 @@ zk_status zk_ctx_set_params(zk_ctx *ctx, const uint8_t nist_h[64], const uint8_t
 zk_status zk_ctx_set_ring(zk_ctx *ctx, const uint8_t *keys_be32, uint64_t n_keys);
 zk_status zk_ctx_set_ring_device(zk_ctx *ctx, const void *d_keys_be32, uint64_t n_keys);
 
-/* Proofs processed per pipeline pass (workspace grows linearly with it).  Default 4096. */
+/* Proofs processed per pipeline pass (workspace grows linearly with it: about 0.9 MB per proof at secLevel 80).
+ * Default 4096, maximum 2^18. */
 zk_status zk_ctx_set_chunk(zk_ctx *ctx, uint32_t proofs_per_chunk);
 
 /* Pipeline lanes of the prover: with 2 (default) alternate chunks run on their own HIP stream and workspace, so the

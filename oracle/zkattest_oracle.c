@@ -747,17 +747,6 @@ static int interpolate_q(int n, const fe *y, fe *coeff) {
     }
     return ZK_OK;
 }
-int zko_interpolate_u64(int n, const u64 *x_unused, const u64 *y, u64 m_unused, u64 *out) {
-    /* KAT hook is provided by the Python restatement; this export checks the q-field path on small inputs */
-    (void)x_unused; (void)m_unused;
-    ensure_init();
-    fe yy[64], cc[64];
-    for (int i = 0; i < n; i++) fe_set_u64(&yy[i], y[i]);
-    int rc = interpolate_q(n, yy, cc);
-    for (int i = 0; i < n; i++) memcpy(out + 4 * i, cc[i].v, 32);
-    return rc;
-}
-
 /* ------------------------------------------------------------------ gk.ts:94-195 */
 static void fe_pow_small(fe *r, const fe *x, int e) { /* expMod(x, e, q), big.ts:44-59 */
     fe acc, b = *x;

@@ -121,3 +121,22 @@ def test_ring_2_20_prove_and_verify():
     proofs = [got[0], bytes(bad), got[2]]
     assert eng.verify_batch(msg, proofs, vseeds=vs) == octx.verify_batch(msg, proofs, nthreads=3, vseeds=vs) == ([1, 0, 1], [0] * 3)
     eng.close()
+
+
+def test_lanes_and_chunking_do_not_change_the_bytes():
+    """One lane / two lanes / different chunk sizes: identical proofs (every proof only depends on its own inputs)."""
+    eng, octx, (msg, sig, pk, which, seeds) = _setup(321, 48, 40)  # ring >= batch: every proof's key is in the ring
+    ref = None
+    for lanes, chunk in ((1, 40), (1, 7), (2, 7), (2, 13), (2, 20)):
+        eng.set_lanes(lanes)
+        eng.set_chunk(chunk)
+        got, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+        assert st == [0] * 40
+        digest = hashlib.sha256(b''.join(got)).hexdigest()
+        ref = ref or digest
+        assert digest == ref, (lanes, chunk)
+        ok, vst = eng.verify_batch(msg, got)
+        assert ok == [1] * 40 and vst == [0] * 40
+    exp, _ = octx.prove_batch(msg, sig, pk, which, seeds=seeds, nthreads=16)
+    assert hashlib.sha256(b''.join(exp)).hexdigest() == ref
+    eng.close()

@@ -6,8 +6,6 @@
 // (the reference's own test builds its inputs with WebCrypto: test/zkpAttestList.test.ts:28-40)
 #include "engine.h"
 
-ZK_DEV P256Pt p256_fixed_mul_g(const uint32_t* __restrict__ tab, uint32_t kw[8]);
-
 template <int TL>
 ZK_DEV void tag_hash(const char (&tag)[TL], uint64_t S, uint64_t i, uint32_t w[8]) {
     constexpr int taglen = TL - 1;

@@ -1,10 +1,10 @@
 // Fixed-base table construction (one-time, at zk_ctx_set_params).  The reference rebuilds a 16-entry window table
 // inside every mul/dblmul call (src/curves/group.ts:105-112,139-143); bases g, h (Tom-256) and G, h_NIST (P-256)
-// are fixed for a whole batch, so the engine precomputes d * 2^(8w) * P for every window w and
-// digit d once and every commitment becomes 2*32 table additions with no doublings.
+// are fixed for a whole batch, so the engine precomputes d * 2^(W w) * P for every W-bit window w
+// and digit d once (W = 16 by default) and every commitment becomes 2 * 256/W table additions with no doublings.
 #include "engine.h"
 
-// scratch layout (words): bases [32][36] extended/projective, entries [32*256][36]
+// scratch layout (words): window bases [NWIN][36] extended/projective, then entries [NWIN * 2^W][36]
 size_t table_scratch_words() { return (size_t)TOM_NWIN * 36 + (size_t)TOM_NWIN * TOM_WIN_SIZE * 36 + (size_t)PFIX_NWIN * 36 + (size_t)PFIX_NWIN * PFIX_WIN_SIZE * 36; }
 
 ZK_DEV void st_tompt(uint32_t* p, const TomPt& a) {
