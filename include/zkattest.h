@@ -132,6 +132,16 @@ zk_status zk_synth_workload(zk_ctx *ctx, uint64_t seed, uint64_t n_keys, uint64_
 /* Derives the synthetic SystemParametersList of seed S (h = k*g with k = SHA-256 tags). */
 zk_status zk_synth_params(zk_ctx *ctx, uint64_t seed, uint8_t nist_h[64], uint8_t tom_g[72], uint8_t tom_h[72]);
 
+/* JSON wire format of SignatureProofList (writeJson/readJson, src/serde.ts:21-36, over the typedjson decorators of
+ * src/zkpAttestList.ts:27-35, exp/exp.ts:26-40, exp/pointAdd.ts:28-38, commit/mult.ts:26-40, commit/equality.ts:27-33,
+ * proofGK/gk.ts:31-40, curves/{weier.ts:92-101, edwards.ts:89-98, group.ts:155-161}, bignum/big.ts:230-248).
+ * Host-only conversions between one ZKA1 proof and its JSON text; no context and no GPU needed.  *out_len is always
+ * set to the required size; ZK_E_BUFFER if out_cap is too small (call once with out = NULL to size).  from_json is
+ * order-tolerant and ignores "__type"/unknown members; it checks structure, group names and hex syntax/width --
+ * curve membership is checked where the reference checks it semantically, in zk_verify_batch's validation. */
+zk_status zk_proof_to_json(const uint8_t *proof, uint64_t proof_len, char *out, uint64_t out_cap, uint64_t *out_len);
+zk_status zk_proof_from_json(const char *json, uint64_t json_len, uint8_t *out, uint64_t out_cap, uint64_t *out_len);
+
 /* Timing of the last prove/verify call: total GPU milliseconds between the first and last kernel (HIP events
  * on the engine's stream) and, per kernel family, the accumulated milliseconds.  names[i] are static strings. */
 uint32_t zk_last_timing(const zk_ctx *ctx, float *total_ms, const char **names, float *ms, uint32_t cap);

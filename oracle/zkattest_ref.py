@@ -1345,6 +1345,119 @@ def proof_from_bytes(b):
 
 
 # --------------------------------------------------------------------------------------
+# JSON wire format (writeJson/readJson, src/serde.ts:21-36, over the typedjson decorators).
+# typedjson 1.8.0 is not vendored in the reference, so the exact text is UNPINNED; this follows
+# its documented behaviour: members in declaration order, undefined optionals omitted, and a
+# "__type" hint where the runtime class differs from the declared constructor.
+# --------------------------------------------------------------------------------------
+def _jhex(v):  # serdeBigInt.serializer, big.ts:230-239
+    return ('-0x%x' % -v) if v < 0 else ('0x%x' % v)
+
+
+def _jgroup(g):
+    return {'name': g.name, '__type': 'WeierstrassGroup' if isinstance(g, WeierstrassGroup) else 'TEdwards'}
+
+
+def _jpoint(pt):  # weier.ts:92-101 / edwards.ts:89-98 (beforeSerialization: toAffine)
+    x, y = pt.toAffine()
+    w = isinstance(pt.group, WeierstrassGroup)
+    return {'group': _jgroup(pt.group), 'x': _jhex(x), 'y': _jhex(y), '__type': 'WeierstrassPoint' if w else 'TEdwardsPoint'}
+
+
+def _jscalar(s):  # group.ts:155-161 (beforeSerialization: reduce)
+    return {'group': _jgroup(s.group), 'k': _jhex(s.k % s.group.order)}
+
+
+def _jmult(m):
+    d = {f: _jpoint(getattr(m, f)) for f in MultProof.FIELDS_P}
+    d.update({f: _jscalar(getattr(m, f)) for f in MultProof.FIELDS_S})
+    return d
+
+
+def _jeq(e):
+    return {'A_1': _jpoint(e.A_1), 'A_2': _jpoint(e.A_2), 't_x': _jscalar(e.t_x), 't_r1': _jscalar(e.t_r1), 't_r2': _jscalar(e.t_r2)}
+
+
+def proof_to_json(proof):
+    """SignatureProofList -> JSON text (writeJson(SignatureProofList, proof))."""
+    import json
+    reps = []
+    for e in proof.expProof:
+        d = {'A': _jpoint(e.A), 'Tx': _jpoint(e.Tx), 'Ty': _jpoint(e.Ty)}
+        if e.alpha is not None:
+            d.update(alpha=_jscalar(e.alpha), beta1=_jscalar(e.beta1), beta2=_jscalar(e.beta2), beta3=_jscalar(e.beta3))
+        else:
+            p = e.proof
+            pa = {k: _jpoint(getattr(p, k)) for k in ('C_8', 'C_10', 'C_11', 'C_13')}
+            pa.update({k: _jmult(getattr(p, k)) for k in ('pi_8', 'pi_10', 'pi_11', 'pi_13')})
+            pa.update(pi_x=_jeq(p.pi_x), pi_y=_jeq(p.pi_y))
+            d.update(z=_jscalar(e.z), z2=_jscalar(e.z2), proof=pa, r1=_jscalar(e.r1), r2=_jscalar(e.r2))
+        reps.append(d)
+    g = proof.membershipProof
+    gk = {k: [_jpoint(p) for p in getattr(g, k)] for k in ('cl', 'ca', 'cb', 'cd')}
+    gk.update({k: [_jscalar(s) for s in getattr(g, k)] for k in ('f', 'za', 'zb')})
+    gk['zd'] = _jscalar(g.zd)
+    top = {'R': _jpoint(proof.R), 'comS1': _jpoint(proof.comS1), 'keyXcom': _jpoint(proof.keyXcom),
+           'keyYcom': _jpoint(proof.keyYcom), 'expProof': reps, 'membershipProof': gk}
+    return json.dumps(top, separators=(',', ':'))
+
+
+def proof_from_json(text):
+    """JSON text -> SignatureProofList (readJson(SignatureProofList, text)); group names as instances.ts:58-78."""
+    import json
+    W, Nn = tomEdwards256, p256
+
+    def big(v):  # serdeBigInt.deserializer, big.ts:240-248
+        if not v:
+            raise ValueError('required field')
+        return -int(v[1:], 16) if v[0] == '-' else int(v, 16)
+
+    def grp(d):
+        n = d['group']['name']
+        if n == p256.name:
+            return p256
+        if n == tomEdwards256.name:
+            return tomEdwards256
+        raise ValueError('invalid group name: %s' % n)
+
+    def pt(d):
+        g = grp(d)
+        x, y = big(d['x']), big(d['y'])
+        if g is p256:
+            p = WeierstrassPoint(p256, x, y)
+        else:
+            p = TEdwardsPoint(g, x, y, posMod(x * y, g.p), 1)
+        if not g.isOnGroup(p):  # afterJson
+            raise ValueError('point not on group')
+        return p
+
+    def sc(d):
+        return grp(d).newScalar(big(d['k']))
+
+    def mult(d):
+        return MultProof(*[pt(d[f]) for f in MultProof.FIELDS_P], *[sc(d[f]) for f in MultProof.FIELDS_S])
+
+    def eq(d):
+        return EqualityProof(pt(d['A_1']), pt(d['A_2']), sc(d['t_x']), sc(d['t_r1']), sc(d['t_r2']))
+
+    top = json.loads(text)
+    reps = []
+    for d in top['expProof']:
+        A, Tx, Ty = pt(d['A']), pt(d['Tx']), pt(d['Ty'])
+        if 'alpha' in d:
+            reps.append(ExpProof(A, Tx, Ty, sc(d['alpha']), sc(d['beta1']), sc(d['beta2']), sc(d['beta3'])))
+        else:
+            p = d['proof']
+            pa = PointAddProof(pt(p['C_8']), pt(p['C_10']), pt(p['C_11']), pt(p['C_13']), mult(p['pi_8']), mult(p['pi_10']),
+                               mult(p['pi_11']), mult(p['pi_13']), eq(p['pi_x']), eq(p['pi_y']))
+            reps.append(ExpProof(A, Tx, Ty, None, None, None, None, sc(d['z']), sc(d['z2']), pa, sc(d['r1']), sc(d['r2'])))
+    g = top['membershipProof']
+    gk = GKProof([pt(p) for p in g['cl']], [pt(p) for p in g['ca']], [pt(p) for p in g['cb']], [pt(p) for p in g['cd']],
+                 [sc(s) for s in g['f']], [sc(s) for s in g['za']], [sc(s) for s in g['zb']], sc(g['zd']))
+    return SignatureProofList(pt(top['R']), pt(top['comS1']), pt(top['keyXcom']), pt(top['keyYcom']), reps, gk)
+
+
+# --------------------------------------------------------------------------------------
 # ECDSA P-256 helpers for building inputs (not part of the reference; WebCrypto does this
 # in the reference's tests).  Deterministic nonces per RFC 6979 (HMAC-SHA-256).
 # --------------------------------------------------------------------------------------

@@ -44,6 +44,8 @@ def case(S, nkeys, B, sec, full=False, stream_plant=None):
                     'fills_consumed': rng.k})
         if full:
             rec['proof'] = raw.hex()
+            text = R.proof_to_json(proof)   # writeJson(SignatureProofList, proof), src/serde.ts:34-36
+            rec['json_len'], rec['json_sha256'] = len(text), hashlib.sha256(text.encode()).hexdigest()
         out['proofs'].append(rec)
     return out
 

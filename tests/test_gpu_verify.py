@@ -119,3 +119,27 @@ def test_gk_length_mismatch_is_false_not_an_error():
     assert g == o == ([0], [0])  # gk.ts:208-218 returns false
     eng8.close()
     eng16.close()
+
+
+def test_json_wire_round_trip_then_verify():
+    """test/zkpAttestList.test.ts:55-60: prove -> writeJson -> readJson -> verify (here through the C-ABI converters)."""
+    import json
+    import zkattest_ref as R
+    import zkp_ecdsa_amd as Z
+    eng, octx, msg, proofs = _setup(4242, 6, 3)
+    texts = [Z.write_json(p) for p in proofs]
+    assert texts[0] == R.proof_to_json(R.proof_from_bytes(proofs[0]))
+    back = [Z.read_json(t) for t in texts]
+    assert back == proofs
+    assert eng.verify_batch(msg, back, vseeds=_vseeds(3)) == ([1] * 3, [0] * 3)
+    # a proof edited on the wire parses but does not verify; an off-curve point parses and is refused at validation
+    t = json.loads(texts[1])
+    t['membershipProof']['zd']['k'] = hex(int(t['membershipProof']['zd']['k'], 16) ^ 1)
+    forged = Z.read_json(json.dumps(t))
+    t = json.loads(texts[2])
+    t['R']['x'] = hex(int(t['R']['x'], 16) ^ 2)
+    offcurve = Z.read_json(json.dumps(t))
+    g, o = _both(eng, octx, msg, [back[0], forged, offcurve], _vseeds(3))
+    assert g == o
+    assert g[0] == [1, 0, 0] and g[1][1] == 0 and g[1][2] != 0
+    eng.close()

@@ -13,6 +13,7 @@ SYMBOLS = [
     'zk_ctx_create', 'zk_ctx_destroy', 'zk_strerror', 'zk_last_error', 'zk_ctx_set_params', 'zk_ctx_set_ring',
     'zk_ctx_set_ring_device', 'zk_ctx_set_chunk', 'zk_ctx_set_lanes', 'zk_proof_max_size', 'zk_prove_batch', 'zk_prove_batch_device',
     'zk_verify_batch', 'zk_verify_batch_device', 'zk_synth_workload', 'zk_synth_params', 'zk_last_timing',
+    'zk_proof_to_json', 'zk_proof_from_json',
     'zk_test_field_op', 'zk_test_tom_commit', 'zk_test_p256_fixed_mul', 'zk_test_sha256', 'zk_test_rng_draws',
 ]
 
@@ -67,6 +68,8 @@ def lib():
         L.zk_synth_params.argtypes = [vp, u64, vp, vp, vp]
         L.zk_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.POINTER(C.c_float), u32]
         L.zk_last_timing.restype = u32
+        L.zk_proof_to_json.argtypes = [C.c_char_p, u64, vp, u64, C.POINTER(u64)]
+        L.zk_proof_from_json.argtypes = [C.c_char_p, u64, vp, u64, C.POINTER(u64)]
         L.zk_test_field_op.argtypes = [vp, i32, i32, u64, C.c_char_p, C.c_char_p, vp]
         L.zk_test_tom_commit.argtypes = [vp, u64, C.c_char_p, C.c_char_p, vp]
         L.zk_test_p256_fixed_mul.argtypes = [vp, i32, u64, C.c_char_p, vp]
@@ -80,6 +83,35 @@ class ZkError(RuntimeError):
     def __init__(self, status, detail=''):
         self.status = status
         super().__init__('%s (status %d)%s' % (STATUS_TEXT.get(status, '?'), status, (': ' + detail) if detail else ''))
+
+
+def write_json(proof_bytes):
+    """ZKA1 proof -> JSON text; the writeJson(SignatureProofList, proof) of src/serde.ts:34-36."""
+    L = lib()
+    n = C.c_uint64()
+    rc = L.zk_proof_to_json(bytes(proof_bytes), len(proof_bytes), None, 0, C.byref(n))
+    if rc not in (0, 12):
+        raise ZkError(rc)
+    buf = C.create_string_buffer(n.value)
+    rc = L.zk_proof_to_json(bytes(proof_bytes), len(proof_bytes), buf, n.value, C.byref(n))
+    if rc:
+        raise ZkError(rc)
+    return buf.raw[:n.value].decode()
+
+
+def read_json(text):
+    """JSON text -> ZKA1 proof; the readJson(SignatureProofList, text) of src/serde.ts:21-32 (throws on bad input)."""
+    L = lib()
+    raw = text.encode() if isinstance(text, str) else bytes(text)
+    n = C.c_uint64()
+    rc = L.zk_proof_from_json(raw, len(raw), None, 0, C.byref(n))
+    if rc not in (0, 12):
+        raise ZkError(rc)
+    buf = C.create_string_buffer(n.value)
+    rc = L.zk_proof_from_json(raw, len(raw), buf, n.value, C.byref(n))
+    if rc:
+        raise ZkError(rc)
+    return buf.raw[:n.value]
 
 
 class Engine:

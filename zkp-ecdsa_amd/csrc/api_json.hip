@@ -1,0 +1,350 @@
+// ZKA1 <-> JSON wire format of SignatureProofList (host-only code, no kernels).
+//
+// Reference: writeJson/readJson (src/serde.ts:21-36) run typedjson 1.8.0 over the decorated classes.  The decorators
+// pin the member names and order and the scalar/coordinate encoding:
+//   SignatureProofList {R, comS1, keyXcom, keyYcom, expProof[], membershipProof}      src/zkpAttestList.ts:27-34
+//   ExpProof {A, Tx, Ty, [alpha, beta1, beta2, beta3] | [z, z2, proof, r1, r2]}         src/exp/exp.ts:26-40 (optional members)
+//   PointAddProof {C_8, C_10, C_11, C_13, pi_8, pi_10, pi_11, pi_13, pi_x, pi_y}        src/exp/pointAdd.ts:28-38
+//   MultProof {C_4, A_x, A_y, A_z, A_4_1, A_4_2, t_x, t_y, t_z, t_rx, t_ry, t_rz, t_r4} src/commit/mult.ts:26-40
+//   EqualityProof {A_1, A_2, t_x, t_r1, t_r2}                                           src/commit/equality.ts:27-33
+//   GKProof {cl[], ca[], cb[], cd[], f[], za[], zb[], zd}                               src/proofGK/gk.ts:31-40
+//   point  {group: {name}, x, y}  (toAffine before serialisation)   src/curves/weier.ts:92-101, edwards.ts:89-98, group.ts:21
+//   scalar {group: {name}, k}     (reduce before serialisation)     src/curves/group.ts:155-161
+//   bigint "0x" + lowercase hex without leading zeros               src/bignum/big.ts:230-239
+// typedjson itself is not in /root/reference (package.json:64-66), so the byte-level JSON shape is UNPINNED
+// (SURVEY.md section 8c): the emitter follows typedjson's documented behaviour -- members in declaration order,
+// undefined optional members omitted, and a trailing "__type" hint on values whose runtime class differs from the
+// declared one (Group -> WeierstrassGroup / TEdwards, Group.Point -> WeierstrassPoint / TEdwardsPoint).  The parser is
+// deliberately tolerant: member order is free, "__type" and unknown members are ignored, so real typedjson output
+// parses whatever the hint policy of the installed version is.
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/zkattest.h"
+
+namespace {
+const char* G_P = "{\"name\":\"p256\",\"__type\":\"WeierstrassGroup\"}";
+const char* G_T = "{\"name\":\"tomEdwards256\",\"__type\":\"TEdwards\"}";
+
+void hex_of(const uint8_t* be, int n, std::string& o) {
+    static const char* d = "0123456789abcdef";
+    o += "\"0x";
+    int i = 0;
+    while (i < n && be[i] == 0) i++;
+    if (i == n) o += '0';
+    else {
+        if (be[i] >> 4) o += d[be[i] >> 4];
+        o += d[be[i] & 15];
+        for (i++; i < n; i++) o += d[be[i] >> 4], o += d[be[i] & 15];
+    }
+    o += '"';
+}
+struct Rd {
+    const uint8_t* p;
+    uint64_t len, off;
+    bool ok;
+    const uint8_t* take(uint64_t n) {
+        static const uint8_t z[128] = {0};
+        if (off + n > len) {
+            ok = false;
+            return z;
+        }
+        const uint8_t* r = p + off;
+        off += n;
+        return r;
+    }
+};
+void pt_p(Rd& r, std::string& o) {
+    const uint8_t* b = r.take(64);
+    o += "{\"group\":", o += G_P, o += ",\"x\":", hex_of(b, 32, o), o += ",\"y\":", hex_of(b + 32, 32, o), o += ",\"__type\":\"WeierstrassPoint\"}";
+}
+void pt_t(Rd& r, std::string& o) {
+    const uint8_t* b = r.take(72);
+    o += "{\"group\":", o += G_T, o += ",\"x\":", hex_of(b, 36, o), o += ",\"y\":", hex_of(b + 36, 36, o), o += ",\"__type\":\"TEdwardsPoint\"}";
+}
+void sc(Rd& r, bool tom, std::string& o) {
+    const uint8_t* b = r.take(32);
+    o += "{\"group\":", o += tom ? G_T : G_P, o += ",\"k\":", hex_of(b, 32, o), o += "}";
+}
+void key(std::string& o, const char* k, bool first = false) {
+    if (!first) o += ',';
+    o += '"', o += k, o += "\":";
+}
+void mult(Rd& r, std::string& o) {
+    static const char* P[6] = {"C_4", "A_x", "A_y", "A_z", "A_4_1", "A_4_2"};
+    static const char* S[7] = {"t_x", "t_y", "t_z", "t_rx", "t_ry", "t_rz", "t_r4"};
+    o += '{';
+    for (int i = 0; i < 6; i++) key(o, P[i], i == 0), pt_t(r, o);
+    for (int i = 0; i < 7; i++) key(o, S[i]), sc(r, true, o);
+    o += '}';
+}
+void eq(Rd& r, std::string& o) {
+    o += '{';
+    key(o, "A_1", true), pt_t(r, o), key(o, "A_2"), pt_t(r, o);
+    key(o, "t_x"), sc(r, true, o), key(o, "t_r1"), sc(r, true, o), key(o, "t_r2"), sc(r, true, o);
+    o += '}';
+}
+
+// ---------------------------------------------------------------- tolerant JSON reader
+struct Val {
+    enum { NUL, STR, OBJ, ARR, OTHER } t = NUL;
+    std::string s;
+    std::vector<std::pair<std::string, Val>> o;
+    std::vector<Val> a;
+    const Val* get(const char* k) const {
+        for (auto& kv : o)
+            if (kv.first == k) return &kv.second;
+        return nullptr;
+    }
+};
+struct Parser {
+    const char* p;
+    const char* e;
+    bool ok = true;
+    void ws() {
+        while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++;
+    }
+    bool str(std::string& out) {
+        if (p >= e || *p != '"') return ok = false;
+        p++;
+        while (p < e && *p != '"') {
+            if (*p == '\\') {
+                if (++p >= e) return ok = false;
+            }
+            out += *p++;
+        }
+        if (p >= e) return ok = false;
+        p++;
+        return true;
+    }
+    bool val(Val& v, int depth = 0) {
+        if (depth > 16) return ok = false;
+        ws();
+        if (p >= e) return ok = false;
+        if (*p == '"') {
+            v.t = Val::STR;
+            return str(v.s);
+        }
+        if (*p == '{') {
+            v.t = Val::OBJ;
+            p++, ws();
+            if (p < e && *p == '}') return p++, true;
+            for (;;) {
+                ws();
+                std::string k;
+                if (!str(k)) return false;
+                ws();
+                if (p >= e || *p != ':') return ok = false;
+                p++;
+                v.o.emplace_back(k, Val());
+                if (!val(v.o.back().second, depth + 1)) return false;
+                ws();
+                if (p < e && *p == ',') {
+                    p++;
+                    continue;
+                }
+                if (p < e && *p == '}') return p++, true;
+                return ok = false;
+            }
+        }
+        if (*p == '[') {
+            v.t = Val::ARR;
+            p++, ws();
+            if (p < e && *p == ']') return p++, true;
+            for (;;) {
+                v.a.emplace_back();
+                if (!val(v.a.back(), depth + 1)) return false;
+                ws();
+                if (p < e && *p == ',') {
+                    p++;
+                    continue;
+                }
+                if (p < e && *p == ']') return p++, true;
+                return ok = false;
+            }
+        }
+        v.t = Val::OTHER;  // numbers, true/false/null: skipped
+        while (p < e && *p != ',' && *p != '}' && *p != ']') p++;
+        return true;
+    }
+};
+struct Wr {
+    std::vector<uint8_t> b;
+    bool ok = true;
+    // "0x.." -> nbytes big-endian (serdeBigInt.deserializer, big.ts:240-248; negative values are not valid here)
+    void hex(const Val* v, int nbytes) {
+        size_t at = b.size();
+        b.resize(at + nbytes, 0);
+        if (!v || v->t != Val::STR || v->s.size() < 3 || v->s[0] != '0' || (v->s[1] != 'x' && v->s[1] != 'X')) {
+            ok = false;
+            return;
+        }
+        const std::string& s = v->s;
+        size_t nd = s.size() - 2, lead = 2;
+        while (nd > 1 && s[lead] == '0') lead++, nd--;  // BigInt('0x000a') is valid
+        if (nd > (size_t)2 * nbytes) {
+            ok = false;
+            return;
+        }
+        for (size_t i = 0; i < nd; i++) {
+            char c = s[s.size() - 1 - i];
+            int d = c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1;
+            if (d < 0) {
+                ok = false;
+                return;
+            }
+            b[at + nbytes - 1 - i / 2] |= (uint8_t)(d << (4 * (i & 1)));
+        }
+    }
+    bool group_is(const Val* v, const char* name) {
+        const Val* g = v ? v->get("group") : nullptr;
+        const Val* n = g ? g->get("name") : nullptr;
+        return n && n->t == Val::STR && n->s == name;  // instances.ts:58-78: unknown group names are rejected
+    }
+    void pt(const Val* v, bool tom) {
+        if (!v || v->t != Val::OBJ || !group_is(v, tom ? "tomEdwards256" : "p256")) ok = false;
+        hex(v ? v->get("x") : nullptr, tom ? 36 : 32);
+        hex(v ? v->get("y") : nullptr, tom ? 36 : 32);
+    }
+    void sc(const Val* v, bool tom) {
+        if (!v || v->t != Val::OBJ || !group_is(v, tom ? "tomEdwards256" : "p256")) ok = false;
+        hex(v ? v->get("k") : nullptr, 32);
+    }
+    void mult(const Val* v) {
+        static const char* P[6] = {"C_4", "A_x", "A_y", "A_z", "A_4_1", "A_4_2"};
+        static const char* S[7] = {"t_x", "t_y", "t_z", "t_rx", "t_ry", "t_rz", "t_r4"};
+        if (!v || v->t != Val::OBJ) ok = false;
+        for (auto k : P) pt(v ? v->get(k) : nullptr, true);
+        for (auto k : S) sc(v ? v->get(k) : nullptr, true);
+    }
+    void eq(const Val* v) {
+        if (!v || v->t != Val::OBJ) ok = false;
+        pt(v ? v->get("A_1") : nullptr, true), pt(v ? v->get("A_2") : nullptr, true);
+        sc(v ? v->get("t_x") : nullptr, true), sc(v ? v->get("t_r1") : nullptr, true), sc(v ? v->get("t_r2") : nullptr, true);
+    }
+};
+}  // namespace
+
+extern "C" zk_status zk_proof_to_json(const uint8_t* proof, uint64_t len, char* out, uint64_t cap, uint64_t* out_len) {
+    if (!proof || !out_len || len < 32 || memcmp(proof, "ZKA1", 4)) return ZK_E_BAD_ENCODING;
+    uint32_t total = (uint32_t)proof[4] << 24 | proof[5] << 16 | proof[6] << 8 | proof[7];
+    uint32_t sec = (uint32_t)proof[8] << 24 | proof[9] << 16 | proof[10] << 8 | proof[11];
+    uint32_t n = (uint32_t)proof[12] << 24 | proof[13] << 16 | proof[14] << 8 | proof[15];
+    if (total != len || sec > 128 || n > 64) return ZK_E_BAD_ENCODING;
+    Rd r{proof, len, 32, true};
+    std::string o;
+    o.reserve(800000);
+    o += '{';
+    key(o, "R", true), pt_p(r, o), key(o, "comS1"), pt_p(r, o), key(o, "keyXcom"), pt_t(r, o), key(o, "keyYcom"), pt_t(r, o);
+    key(o, "expProof"), o += '[';
+    for (uint32_t i = 0; i < sec; i++) {
+        int bi = 16 + 15 - (int)(i >> 3);
+        bool bit = (proof[bi] >> (i & 7)) & 1;
+        if (i) o += ',';
+        o += '{';
+        key(o, "A", true), pt_p(r, o), key(o, "Tx"), pt_t(r, o), key(o, "Ty"), pt_t(r, o);
+        if (bit) {
+            key(o, "alpha"), sc(r, false, o), key(o, "beta1"), sc(r, false, o), key(o, "beta2"), sc(r, true, o), key(o, "beta3"), sc(r, true, o);
+        } else {
+            std::string z, z2, r1, r2;
+            sc(r, false, z), sc(r, false, z2), sc(r, true, r1), sc(r, true, r2);
+            key(o, "z"), o += z, key(o, "z2"), o += z2;
+            key(o, "proof"), o += '{';
+            static const char* C[4] = {"C_8", "C_10", "C_11", "C_13"};
+            for (int k = 0; k < 4; k++) key(o, C[k], k == 0), pt_t(r, o);
+            static const char* M[4] = {"pi_8", "pi_10", "pi_11", "pi_13"};
+            for (int k = 0; k < 4; k++) key(o, M[k]), mult(r, o);
+            key(o, "pi_x"), eq(r, o), key(o, "pi_y"), eq(r, o);
+            o += '}';
+            key(o, "r1"), o += r1, key(o, "r2"), o += r2;
+        }
+        o += '}';
+    }
+    o += ']';
+    key(o, "membershipProof"), o += '{';
+    static const char* PA[4] = {"cl", "ca", "cb", "cd"};
+    for (int k = 0; k < 4; k++) {
+        key(o, PA[k], k == 0), o += '[';
+        for (uint32_t i = 0; i < n; i++) {
+            if (i) o += ',';
+            pt_t(r, o);
+        }
+        o += ']';
+    }
+    static const char* SA[3] = {"f", "za", "zb"};
+    for (int k = 0; k < 3; k++) {
+        key(o, SA[k]), o += '[';
+        for (uint32_t i = 0; i < n; i++) {
+            if (i) o += ',';
+            sc(r, true, o);
+        }
+        o += ']';
+    }
+    key(o, "zd"), sc(r, true, o);
+    o += "}}";
+    if (!r.ok || r.off != len) return ZK_E_BAD_ENCODING;
+    *out_len = o.size();
+    if (!out || cap < o.size()) return ZK_E_BUFFER;
+    memcpy(out, o.data(), o.size());
+    return ZK_OK;
+}
+
+extern "C" zk_status zk_proof_from_json(const char* json, uint64_t len, uint8_t* out, uint64_t cap, uint64_t* out_len) {
+    if (!json || !out_len) return ZK_E_ARG;
+    Parser ps{json, json + len};
+    Val root;
+    if (!ps.val(root) || root.t != Val::OBJ) return ZK_E_BAD_ENCODING;
+    ps.ws();
+    if (ps.p != ps.e) return ZK_E_BAD_ENCODING;
+    const Val* ex = root.get("expProof");
+    const Val* gk = root.get("membershipProof");
+    if (!ex || ex->t != Val::ARR || !gk || gk->t != Val::OBJ || ex->a.size() > 128) return ZK_E_BAD_ENCODING;
+    Wr w;
+    w.b.resize(32, 0);
+    w.pt(root.get("R"), false), w.pt(root.get("comS1"), false), w.pt(root.get("keyXcom"), true), w.pt(root.get("keyYcom"), true);
+    uint32_t sec = (uint32_t)ex->a.size();
+    uint8_t bits[16] = {0};
+    for (uint32_t i = 0; i < sec; i++) {
+        const Val& e = ex->a[i];
+        if (e.t != Val::OBJ) return ZK_E_BAD_ENCODING;
+        w.pt(e.get("A"), false), w.pt(e.get("Tx"), true), w.pt(e.get("Ty"), true);
+        const Val* alpha = e.get("alpha");
+        if (alpha) {  // response1 (exp.ts:30-34)
+            bits[15 - (i >> 3)] |= (uint8_t)(1u << (i & 7));
+            w.sc(alpha, false), w.sc(e.get("beta1"), false), w.sc(e.get("beta2"), true), w.sc(e.get("beta3"), true);
+        } else {      // response0 (exp.ts:35-40)
+            w.sc(e.get("z"), false), w.sc(e.get("z2"), false), w.sc(e.get("r1"), true), w.sc(e.get("r2"), true);
+            const Val* pa = e.get("proof");
+            if (!pa || pa->t != Val::OBJ) return ZK_E_BAD_ENCODING;
+            for (auto k : {"C_8", "C_10", "C_11", "C_13"}) w.pt(pa->get(k), true);
+            for (auto k : {"pi_8", "pi_10", "pi_11", "pi_13"}) w.mult(pa->get(k));
+            w.eq(pa->get("pi_x")), w.eq(pa->get("pi_y"));
+        }
+    }
+    const Val* cl = gk->get("cl");
+    if (!cl || cl->t != Val::ARR || cl->a.size() > 64) return ZK_E_BAD_ENCODING;
+    uint32_t n = (uint32_t)cl->a.size();
+    for (auto k : {"cl", "ca", "cb", "cd"}) {
+        const Val* a = gk->get(k);
+        if (!a || a->t != Val::ARR || a->a.size() != n) return ZK_E_BAD_ENCODING;
+        for (auto& v : a->a) w.pt(&v, true);
+    }
+    for (auto k : {"f", "za", "zb"}) {
+        const Val* a = gk->get(k);
+        if (!a || a->t != Val::ARR || a->a.size() != n) return ZK_E_BAD_ENCODING;
+        for (auto& v : a->a) w.sc(&v, true);
+    }
+    w.sc(gk->get("zd"), true);
+    if (!w.ok) return ZK_E_BAD_ENCODING;
+    uint32_t total = (uint32_t)w.b.size();
+    memcpy(w.b.data(), "ZKA1", 4);
+    uint32_t hv[3] = {total, sec, n};
+    for (int k = 0; k < 3; k++)
+        for (int j = 0; j < 4; j++) w.b[4 + 4 * k + j] = (uint8_t)(hv[k] >> (24 - 8 * j));
+    memcpy(w.b.data() + 16, bits, 16);
+    *out_len = total;
+    if (!out || cap < total) return ZK_E_BUFFER;
+    memcpy(out, w.b.data(), total);
+    return ZK_OK;
+}
