@@ -103,6 +103,7 @@ def main():
     ap.add_argument('--sec', type=int, default=80)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=0, help='proofs in the CPU baseline sample (default 2 x cores)')
+    ap.add_argument('--lanes', type=int, default=2, help='chunks in flight on separate streams during the timed steps (1 = serial)')
     ap.add_argument('--roofline-steps', type=int, default=1, help='extra single-lane passes used only for per-kernel timings')
     ap.add_argument('--verify-steps', type=int, default=1, help='timed verifySignatureList passes over the produced proofs (0 = skip)')
     ap.add_argument('--check', type=int, default=8, help='proofs of step 1 diffed against the oracle on rank 0')
@@ -128,6 +129,7 @@ def main():
     nh, tg, th = eng.synth_params(args.seed)
     eng.set_params(nh, tg, th, sec)
     eng.set_chunk(min(args.chunk, B))
+    eng.set_lanes(args.lanes)
     ring, msg, sig, pk, which, seeds = eng.synth_workload(args.seed, nkeys, B)
 
     # the key ring travels rank 0 -> all ranks over RCCL (xGMI); everything else is generated locally from the seed
@@ -181,7 +183,7 @@ def main():
         gpu_ms += tot
         for k, v in f.items():
             fam[k] = fam.get(k, 0.0) + v
-    eng.set_lanes(2)
+    eng.set_lanes(args.lanes)
     torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
