@@ -31,17 +31,24 @@ HBM_PEAK_GBPS = 8000.0
 # 2526 per k_tom_commit loop iteration of 16 products (ISA histogram; nominal 171, the zero / power-of-two limbs of
 # the modulus are strength-reduced)
 MACS_PER_MODMUL = 158
-TOM_COMMIT_MODMULS = 32 * 8    # executed: 2 x 16 table additions (16-bit comb windows), 8 modmuls each
+
+
+def tom_commit_modmuls(comb_bits):
+    """executed per commitment: 2 x ceil(256/W) table additions of a W-bit comb, 8 modmuls each"""
+    return 2 * ((256 + comb_bits - 1) // comb_bits) * 8
+
+
 TOM_COMMIT_NOMINAL = 4064      # reference: 256 dbl + 160 add (src/curves/group.ts:97-132, SURVEY.md P7)
 TOM_COMMIT_BYTES = 2 * 36 + 3 * 36  # algorithmic HBM bytes per commitment: read (v, r), write (X, Y, Z)
 # PMC pass (profiles/r01_pmc_summary.txt, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, batch 16384):
 # k_tom_commit moved 3238 B (FETCH_SIZE, raw KiB x 1024) + 111 B (WRITE_SIZE) per commitment through the L2's
 # memory-side port: the 32 gathers of 112-byte table entries (235 MB of tables live in Infinity Cache / HBM) dominate.
 # FETCH_SIZE is uncalibrated for 16-byte-per-lane gathers on gfx950 (MI355X_MICROARCH.md section HBM); reported raw.
-TOM_COMMIT_PMC_BYTES = 3238 + 111
+TOM_COMMIT_PMC_BYTES = {}   # comb width -> bytes per commitment (filled from profiles/r01_pmc_summary.txt)
 # same pass, SQ counters: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = 0.525 per wave at 2 waves per SIMD (VALU pipe ~saturated),
 # SQ_WAIT_INST_ANY 0.395, SQ_WAIT_ANY (memory) 0.077
-TOM_COMMIT_VALU_ACTIVE_PER_WAVE = 0.525
+TOM_COMMIT_VALU_ACTIVE_PER_WAVE = {}
+DEFAULT_COMB_BITS = 24
 
 
 def rank_seeds(base_seeds: bytes, rank: int) -> bytes:
@@ -103,6 +110,7 @@ def main():
     ap.add_argument('--sec', type=int, default=80)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=0, help='proofs in the CPU baseline sample (default 2 x cores)')
+    ap.add_argument('--comb-bits', type=int, default=DEFAULT_COMB_BITS, help='width of the Tom-256 fixed-base comb tables (8..24); 24 = 47 GB of tables')
     ap.add_argument('--lanes', type=int, default=2, help='chunks in flight on separate streams during the timed steps (1 = serial)')
     ap.add_argument('--roofline-steps', type=int, default=1, help='extra single-lane passes used only for per-kernel timings')
     ap.add_argument('--verify-steps', type=int, default=1, help='timed verifySignatureList passes over the produced proofs (0 = skip)')
@@ -127,7 +135,10 @@ def main():
     B, nkeys, sec = args.batch, args.ring, args.sec
     eng = Z.Engine(local_rank)
     nh, tg, th = eng.synth_params(args.seed)
-    eng.set_params(nh, tg, th, sec)
+    eng.set_comb_bits(args.comb_bits)
+    t_tab = time.time()
+    eng.set_params(nh, tg, th, sec)       # builds the fixed-base tables (one-time, not part of a step)
+    t_tab = time.time() - t_tab
     eng.set_chunk(min(args.chunk, B))
     eng.set_lanes(args.lanes)
     ring, msg, sig, pk, which, seeds = eng.synth_workload(args.seed, nkeys, B)
@@ -232,7 +243,9 @@ def main():
         commits_per_step = B * (2 + 2 * sec) + zeros_total * 34 + B * 4 * n_log2
         tom_ms = fam.get('tom_commit', 0.0) / max(1, args.roofline_steps)
         launches_per_step = 3 * ((B + eng_chunk(args, B) - 1) // eng_chunk(args, B))
-        macs = commits_per_step * TOM_COMMIT_MODMULS * MACS_PER_MODMUL
+        modmuls_per_commit = tom_commit_modmuls(args.comb_bits)
+        pmc_bytes = TOM_COMMIT_PMC_BYTES.get(args.comb_bits)
+        macs = commits_per_step * modmuls_per_commit * MACS_PER_MODMUL
         achieved_tmacs = macs / (tom_ms * 1e-3) / 1e12 if tom_ms > 0 else 0.0
         hbm_gbps = commits_per_step * TOM_COMMIT_BYTES / (tom_ms * 1e-3) / 1e9 if tom_ms > 0 else 0.0
         wt, wq, wring = nominal_modmuls(n_log2)
@@ -241,14 +254,16 @@ def main():
             'kernel': 'k_tom_commit',
             'achieved': round(achieved_tmacs, 3), 'peak': VALU_MAD_PEAK_TOPS, 'unit': 'T multiplier-instr/s (v_mad_u64_u32 + v_mul_lo_u32 lane-ops, peak measured by tools/valu_peak.hip)',
             'frac': round(achieved_tmacs / VALU_MAD_PEAK_TOPS, 4),
-            'traffic': int(commits_per_step / max(1, launches_per_step) * TOM_COMMIT_PMC_BYTES),
-            'traffic_note': 'bytes per launch = units per launch x %d B (FETCH_SIZE + WRITE_SIZE per commitment, separate rocprofv3 --pmc passes, '
-                            'profiles/r01_pmc_summary.txt); table gathers, not the 180 algorithmic bytes, dominate' % TOM_COMMIT_PMC_BYTES,
-            'valu_active_per_wave': TOM_COMMIT_VALU_ACTIVE_PER_WAVE,
+            'traffic': int(commits_per_step / max(1, launches_per_step) * pmc_bytes) if pmc_bytes else None,
+            'traffic_note': ('bytes per launch = units per launch x %d B (FETCH_SIZE + WRITE_SIZE per commitment, separate rocprofv3 --pmc passes, '
+                             'profiles/r01_pmc_summary.txt); table gathers, not the 180 algorithmic bytes, dominate' % pmc_bytes) if pmc_bytes
+                            else 'no PMC pass recorded for this comb width',
+            'valu_active_per_wave': TOM_COMMIT_VALU_ACTIVE_PER_WAVE.get(args.comb_bits),
+            'comb_bits': args.comb_bits,
             'avg_launch_ms': round(tom_ms / max(1, launches_per_step), 3),
             'launches_per_step': launches_per_step,
             'units_per_step': commits_per_step,
-            'executed_modmuls_per_unit': TOM_COMMIT_MODMULS, 'nominal_modmuls_per_unit': TOM_COMMIT_NOMINAL,
+            'executed_modmuls_per_unit': modmuls_per_commit, 'nominal_modmuls_per_unit': TOM_COMMIT_NOMINAL,
             'hbm': {'achieved': round(hbm_gbps, 2), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(hbm_gbps / HBM_PEAK_GBPS, 5),
                     'algorithmic_bytes_per_unit': TOM_COMMIT_BYTES},
             'share_of_gpu_time': round(fam.get('tom_commit', 0.0) / gpu_ms, 3) if gpu_ms else None,
@@ -270,9 +285,10 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32 (9x30-bit limbs, 256/258-bit modular integers)',
             'data': 'synthetic',
-            'config': {'workload': 'batch=%d proofs per GPU per step, ring=%d keys (n=%d), secLevel=%d, P-256 + Tom-256, chunk=%d'
-                                   % (B, nkeys, n_log2, sec, eng_chunk(args, B)),
+            'config': {'workload': 'batch=%d proofs per GPU per step, ring=%d keys (n=%d), secLevel=%d, P-256 + Tom-256, chunk=%d, comb=%d bits'
+                                   % (B, nkeys, n_log2, sec, eng_chunk(args, B), args.comb_bits),
                        'parallelism': 'proofs sharded per GPU; ring broadcast over RCCL at set-up' if world > 1 else 'single GPU'},
+            'set_params_s': round(t_tab, 3),
             'proof_bytes_per_step': total_bytes, 'failed_proofs': nbad,
             'gpu_ms_by_family_per_step': {k: round(v / max(1, args.roofline_steps), 2) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
             'gpu_ms_note': 'serial single-lane pass (sum = %.1f ms); the timed steps overlap two chunks on two streams' % (gpu_ms / max(1, args.roofline_steps)),

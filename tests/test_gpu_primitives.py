@@ -132,3 +132,31 @@ def test_synth_matches_python(eng):
     assert th == x.to_bytes(36, 'big') + y.to_bytes(36, 'big')
     x, y = pp.ProofGroup.g.toAffine()
     assert tg == x.to_bytes(36, 'big') + y.to_bytes(36, 'big')
+
+
+@pytest.mark.parametrize('bits', [8, 11, 13, 17, 20, 24])
+def test_tom_commit_every_comb_width(bits):
+    """zk_ctx_set_comb_bits: the composed tables (k_tables.hip) and the run-time-width comb give the oracle's
+    commitments for every width, including widths that do not divide 256 and the 47 GB 24-bit tables."""
+    import coracle as CO
+    import zkattest_ref as R
+    import zkp_ecdsa_amd as Z
+    e = Z.Engine(0)
+    raw = e.synth_params(77)
+    e.set_comb_bits(bits)
+    with pytest.raises(Z.ZkError):       # the tables belong to the previous width: set_params must follow
+        e.test_tom_commit([1], [1])
+    e.set_params(*raw, 80)
+    octx = CO.OracleCtx(*raw, 80)
+    rnd = random.Random(bits)
+    q = R.tomEdwards256.order
+    top = (1 << 256) - 1
+    vs = [rnd.randrange(q) for _ in range(60)] + [0, 0, 1, q - 1, 5, top % q, 1 << (bits - 1), (1 << bits) - 1, 1 << bits]
+    rs = [rnd.randrange(q) for _ in range(60)] + [0, 1, 0, q - 1, 0, q - 2, (1 << 255) % q, 1 << (255 - 255 % bits), 3]
+    got = e.test_tom_commit(vs, rs)
+    for v, r, g in zip(vs, rs, got):
+        assert g == octx.tom_commit(v, r), (bits, v, r)
+    for bad in (7, 25, 0):
+        with pytest.raises(Z.ZkError):
+            e.set_comb_bits(bad)
+    e.close()

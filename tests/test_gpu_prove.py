@@ -139,4 +139,12 @@ def test_lanes_and_chunking_do_not_change_the_bytes():
         assert ok == [1] * 40 and vst == [0] * 40
     exp, _ = octx.prove_batch(msg, sig, pk, which, seeds=seeds, nthreads=16)
     assert hashlib.sha256(b''.join(exp)).hexdigest() == ref
+    # the comb width of the Tom-256 tables is a pure performance knob as well
+    raw = eng.synth_params(321)
+    for bits in (10, 20):
+        eng.set_comb_bits(bits)
+        eng.set_params(*raw, 80)
+        got, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+        assert st == [0] * 40 and hashlib.sha256(b''.join(got)).hexdigest() == ref, bits
+        assert eng.verify_batch(msg, got) == ([1] * 40, [0] * 40)
     eng.close()

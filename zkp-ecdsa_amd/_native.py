@@ -5,13 +5,14 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libzkattest_hip.so')
+# ZKATTEST_LIB selects another build of the same library (e.g. a different comb width, csrc/Makefile TOM_WIN_BITS)
+LIB_PATH = os.environ.get('ZKATTEST_LIB') or os.path.join(_HERE, 'lib', 'libzkattest_hip.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
 # every symbol include/zkattest.h declares
 SYMBOLS = [
     'zk_ctx_create', 'zk_ctx_destroy', 'zk_strerror', 'zk_last_error', 'zk_ctx_set_params', 'zk_ctx_set_ring',
-    'zk_ctx_set_ring_device', 'zk_ctx_set_chunk', 'zk_ctx_set_lanes', 'zk_proof_max_size', 'zk_prove_batch', 'zk_prove_batch_device',
+    'zk_ctx_set_ring_device', 'zk_ctx_set_chunk', 'zk_ctx_set_lanes', 'zk_ctx_set_comb_bits', 'zk_proof_max_size', 'zk_prove_batch', 'zk_prove_batch_device',
     'zk_verify_batch', 'zk_verify_batch_device', 'zk_synth_workload', 'zk_synth_params', 'zk_last_timing',
     'zk_proof_to_json', 'zk_proof_from_json',
     'zk_test_field_op', 'zk_test_tom_commit', 'zk_test_p256_fixed_mul', 'zk_test_sha256', 'zk_test_rng_draws',
@@ -58,6 +59,7 @@ def lib():
         L.zk_ctx_set_ring_device.argtypes = [vp, vp, u64]
         L.zk_ctx_set_chunk.argtypes = [vp, u32]
         L.zk_ctx_set_lanes.argtypes = [vp, u32]
+        L.zk_ctx_set_comb_bits.argtypes = [vp, u32]
         L.zk_proof_max_size.argtypes = [vp]
         L.zk_proof_max_size.restype = u64
         L.zk_prove_batch.argtypes = [vp, u64, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(ZkRng), vp, u64, vp, vp]
@@ -160,6 +162,10 @@ class Engine:
 
     def set_lanes(self, lanes):
         self._chk(self.L.zk_ctx_set_lanes(self.h, lanes))
+
+    def set_comb_bits(self, bits):
+        """Comb width of the Tom-256 fixed-base tables (8..24); call before set_params."""
+        self._chk(self.L.zk_ctx_set_comb_bits(self.h, bits))
 
     def proof_max_size(self):
         return self.L.zk_proof_max_size(self.h)

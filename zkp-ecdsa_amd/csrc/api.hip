@@ -46,26 +46,35 @@ extern "C" zk_status zk_ctx_create(int device_id, zk_ctx** out) {
     *out = c;
     HIPCHK(c, hipSetDevice(device_id));
     HIPCHK(c, hipStreamCreate(&c->stream));
-    HIPCHK(c, hipMalloc(&c->P.tom_tab_g, sizeof(uint32_t) * TOM_TAB_WORDS));
-    HIPCHK(c, hipMalloc(&c->P.tom_tab_h, sizeof(uint32_t) * TOM_TAB_WORDS));
-    HIPCHK(c, hipMalloc(&c->tom_tab_gen, sizeof(uint32_t) * TOM_TAB_WORDS));
+    if (const char* e = getenv("ZKATTEST_COMB_BITS")) {
+        int b = atoi(e);
+        if (b >= 8 && b <= TOM_MAX_BITS) c->tom_bits = (uint32_t)b;
+    }
+    HIPCHK(c, hipMalloc(&c->tom_tab_gen, sizeof(uint32_t) * tom_tab_words(8)));
     HIPCHK(c, hipMalloc(&c->P.pfix_G, sizeof(uint32_t) * PFIX_TAB_WORDS));
     HIPCHK(c, hipMalloc(&c->P.pfix_H, sizeof(uint32_t) * PFIX_TAB_WORDS));
-    HIPCHK(c, hipMalloc(&c->tab_scratch, sizeof(uint32_t) * table_scratch_words()));
+    c->scratch_words = std::max(pfix_table_scratch_words(), tom_table_scratch_words(TOM_MAX_BITS));
+    HIPCHK(c, hipMalloc(&c->tab_scratch, sizeof(uint32_t) * c->scratch_words));
     HIPCHK(c, hipMalloc(&c->d_flag, 64));
     HIPCHK(c, hipMalloc(&c->d_totals, 64));
     int32_t one = 1;
     HIPCHK(c, hipMemcpyAsync(c->d_flag, &one, 4, hipMemcpyHostToDevice, c->stream));
-    // tables that do not depend on the parameters: P-256 generator, Tom generator
+    // tables that do not depend on the parameters: P-256 generator, Tom generator (8-bit comb: only zk_synth_params uses it)
     launch_build_pfix_table(c->stream, nullptr, c->P.pfix_G, c->tab_scratch, c->d_flag);
     uint32_t genw[18];
     memcpy(genw, TOM_GX_W, 36), memcpy(genw + 9, TOM_GY_W, 36);
     uint32_t* d_xy;
     HIPCHK(c, hipMalloc(&d_xy, 18 * 4));
     HIPCHK(c, hipMemcpyAsync(d_xy, genw, 72, hipMemcpyHostToDevice, c->stream));
-    launch_build_tom_table(c->stream, d_xy, c->tom_tab_gen, c->tab_scratch, c->d_flag);
+    launch_build_tom_table(c->stream, d_xy, 8, c->tom_tab_gen, c->tab_scratch, c->d_flag);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipFree(d_xy));
+    return ZK_OK;
+}
+extern "C" zk_status zk_ctx_set_comb_bits(zk_ctx* c, uint32_t bits) {
+    if (!c || bits < 8 || bits > TOM_MAX_BITS) return ZK_E_ARG;
+    if (bits != c->tom_bits) c->params_set = false;  // the tables are rebuilt by the next zk_ctx_set_params
+    c->tom_bits = bits;
     return ZK_OK;
 }
 extern "C" void zk_ctx_destroy(zk_ctx* c) {
@@ -113,9 +122,17 @@ extern "C" zk_status zk_ctx_set_params(zk_ctx* c, const uint8_t nist_h[64], cons
     HIPCHK(c, hipMemcpyAsync(d + 34, hw2, 72, hipMemcpyHostToDevice, c->stream));
     int32_t one = 1;
     HIPCHK(c, hipMemcpyAsync(c->d_flag, &one, 4, hipMemcpyHostToDevice, c->stream));
+    if (c->tab_bits_alloc != c->tom_bits) {
+        if (c->P.tom_tab_g) HIPCHK(c, hipFree(c->P.tom_tab_g));
+        if (c->P.tom_tab_h) HIPCHK(c, hipFree(c->P.tom_tab_h));
+        c->P.tom_tab_g = c->P.tom_tab_h = nullptr, c->tab_bits_alloc = 0;
+        HIPCHK(c, hipMalloc(&c->P.tom_tab_g, sizeof(uint32_t) * tom_tab_words(c->tom_bits)));
+        HIPCHK(c, hipMalloc(&c->P.tom_tab_h, sizeof(uint32_t) * tom_tab_words(c->tom_bits)));
+        c->tab_bits_alloc = c->P.tom_bits = c->tom_bits;
+    }
     launch_build_pfix_table(c->stream, d, c->P.pfix_H, c->tab_scratch, c->d_flag);
-    launch_build_tom_table(c->stream, d + 16, c->P.tom_tab_g, c->tab_scratch, c->d_flag);
-    launch_build_tom_table(c->stream, d + 34, c->P.tom_tab_h, c->tab_scratch, c->d_flag);
+    launch_build_tom_table(c->stream, d + 16, c->tom_bits, c->P.tom_tab_g, c->tab_scratch, c->d_flag);
+    launch_build_tom_table(c->stream, d + 34, c->tom_bits, c->P.tom_tab_h, c->tab_scratch, c->d_flag);
     int32_t ok = 0;
     HIPCHK(c, hipMemcpyAsync(&ok, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -496,7 +513,7 @@ extern "C" zk_status zk_synth_workload(zk_ctx* c, uint64_t seed, uint64_t nkeys,
     return ZK_OK;
 }
 
-static zk_status tom_commit_generic(zk_ctx* c, const uint32_t* tab_g, const uint32_t* tab_h, uint64_t count, const uint8_t* d_v, const uint8_t* d_r, uint8_t* d_out) {
+static zk_status tom_commit_generic(zk_ctx* c, const uint32_t* tab_g, const uint32_t* tab_h, uint32_t bits, uint64_t count, const uint8_t* d_v, const uint8_t* d_r, uint8_t* d_out) {
     // temporary list
     TomList L;
     void* mem;
@@ -507,7 +524,7 @@ static zk_status tom_commit_generic(zk_ctx* c, const uint32_t* tab_g, const uint
     launch_bytes_to_scalars(c->stream, d_v, count, L.v);
     launch_bytes_to_scalars(c->stream, d_r, count, L.r);
     DevParams P = c->P;
-    P.tom_tab_g = (uint32_t*)tab_g, P.tom_tab_h = (uint32_t*)tab_h;
+    P.tom_tab_g = (uint32_t*)tab_g, P.tom_tab_h = (uint32_t*)tab_h, P.tom_bits = bits;
     launch_tom_commit(c->stream, P, L, (uint32_t)count, 1, 1);
     launch_tom_normalize(c->stream, L, (uint32_t)count, 0, 1, 1);
     launch_affine_to_bytes(c->stream, L.ax, L.ay, count, 1, d_out);
@@ -523,7 +540,7 @@ extern "C" zk_status zk_synth_params(zk_ctx* c, uint64_t seed, uint8_t nist_h[64
     HIPCHK(c, hipMemsetAsync(d, 0, 512, c->stream));
     launch_synth_param_scalars(c->stream, seed, d, d + 32);  // kn, kt (big-endian); d+64: zero scalar
     launch_test_pfix(c->stream, c->P.pfix_G, 1, d, d + 128);
-    zk_status zs = tom_commit_generic(c, c->tom_tab_gen, c->tom_tab_gen, 1, d + 32, d + 64, d + 256);
+    zk_status zs = tom_commit_generic(c, c->tom_tab_gen, c->tom_tab_gen, 8, 1, d + 32, d + 64, d + 256);
     if (zs) return zs;
     HIPCHK(c, hipMemcpy(nist_h, d + 128, 64, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(tom_h, d + 256, 72, hipMemcpyDeviceToHost));
@@ -560,7 +577,7 @@ extern "C" zk_status zk_test_tom_commit(zk_ctx* c, uint64_t count, const uint8_t
     HIPCHK(c, hipMalloc(&dv.p, 32 * count)); HIPCHK(c, hipMalloc(&dr.p, 32 * count)); HIPCHK(c, hipMalloc(&dout.p, 72 * count));
     HIPCHK(c, hipMemcpy(dv.p, v, 32 * count, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(dr.p, r, 32 * count, hipMemcpyHostToDevice));
-    zk_status zs = tom_commit_generic(c, c->P.tom_tab_g, c->P.tom_tab_h, count, (uint8_t*)dv.p, (uint8_t*)dr.p, (uint8_t*)dout.p);
+    zk_status zs = tom_commit_generic(c, c->P.tom_tab_g, c->P.tom_tab_h, c->P.tom_bits, count, (uint8_t*)dv.p, (uint8_t*)dr.p, (uint8_t*)dout.p);
     if (zs) return zs;
     HIPCHK(c, hipMemcpy(out, dout.p, 72 * count, hipMemcpyDeviceToHost));
     return ZK_OK;

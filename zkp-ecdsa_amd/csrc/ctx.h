@@ -19,7 +19,10 @@ struct zk_ctx {
     // params
     DevParams P{};
     bool params_set = false;
-    uint32_t* tom_tab_gen = nullptr;  // generator table (synthetic params)
+    uint32_t* tom_tab_gen = nullptr;  // 8-bit comb table of the Tom generator (synthetic params only)
+    uint32_t tom_bits = TOM_DEFAULT_BITS;  // comb width requested for g, h (zk_ctx_set_comb_bits)
+    uint32_t tab_bits_alloc = 0;      // width the allocated P.tom_tab_g/h were sized for (0 = not allocated)
+    size_t scratch_words = 0;
     uint32_t* tab_scratch = nullptr;
     int32_t* d_flag = nullptr;
     // ring

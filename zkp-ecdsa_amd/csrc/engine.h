@@ -29,15 +29,15 @@ ZK_DEV void soa_st(const Soa& a, uint32_t e, const Fe<M, K>& v) {
 }
 
 // ------------------------------------------------------------------ fixed-base tables
-// Tom: TOM_WIN_BITS-bit comb windows (default 16: 16 windows x 65536 digits, 117 MB per base), entry = niels
-// (x, y, d'*x*y) Montgomery limbs, 28 words (112 B).  Measured 8/11/13/16 bits: 361/278/232/201 ms per 104 M commitments.
-#ifndef TOM_WIN_BITS
-#define TOM_WIN_BITS 8
-#endif
-#define TOM_NWIN ((256 + TOM_WIN_BITS - 1) / TOM_WIN_BITS)
-#define TOM_WIN_SIZE (1u << TOM_WIN_BITS)
-#define TOM_ENTRY_WORDS 28
-#define TOM_TAB_WORDS ((size_t)TOM_NWIN * TOM_WIN_SIZE * TOM_ENTRY_WORDS)
+// Tom: W-bit comb windows, W chosen at run time (zk_ctx_set_comb_bits, 8..24): ceil(256/W) windows x 2^W digits,
+// entry = niels (x, y, d'*x*y) Montgomery limbs in a 128-byte line (27 words used), so one gather touches exactly
+// one L2/HBM line.  Measured per 104 M commitments (MI355X): W = 8/11/13/16 with 112-byte entries 361/278/232/201 ms;
+// with 128-byte entries W = 16/20/22/24: 194/170/157/147 ms (tables 0.27/3.5/12.9/47 GB for the two bases).
+#define TOM_ENTRY_WORDS 32
+#define TOM_DEFAULT_BITS 16
+#define TOM_MAX_BITS 24
+static inline uint32_t tom_nwin(uint32_t bits) { return (256 + bits - 1) / bits; }
+static inline size_t tom_tab_words(uint32_t bits) { return (size_t)tom_nwin(bits) * ((size_t)1 << bits) * TOM_ENTRY_WORDS; }
 // P-256 fixed bases (G, h_NIST): PFIX_WIN_BITS-bit comb windows (default 16), entry = affine (x, y) Montgomery limbs,
 // 20 words (80 B); digit 0 unused.
 #ifndef PFIX_WIN_BITS
@@ -77,8 +77,9 @@ struct TomList {   // a list of Pedersen commitments to compute: (v, r) -> proje
 };
 
 struct DevParams {            // device-resident, built by zk_ctx_set_params
-    uint32_t* tom_tab_g;      // TOM_TAB_WORDS
+    uint32_t* tom_tab_g;      // tom_tab_words(tom_bits)
     uint32_t* tom_tab_h;
+    uint32_t tom_bits;        // comb width of the two tables
     uint32_t* pfix_G;         // PFIX_TAB_WORDS
     uint32_t* pfix_H;
     uint32_t tom_g_aff[18];   // original-curve affine plain limbs of g (x, y) -- C_14 in pointAdd.ts:144
@@ -182,9 +183,10 @@ struct ChunkIn {
 
 // ------------------------------------------------------------------ launch wrappers (one per kernel family)
 // k_tables.hip
-void launch_build_tom_table(hipStream_t s, const uint32_t* aff_xy_words /*18 words on device*/, uint32_t* tab, uint32_t* scratch, int32_t* ok);
+void launch_build_tom_table(hipStream_t s, const uint32_t* aff_xy_words /*18 words on device*/, uint32_t bits, uint32_t* tab, uint32_t* scratch, int32_t* ok);
+size_t tom_table_scratch_words(uint32_t bits);
 void launch_build_pfix_table(hipStream_t s, const uint32_t* aff_xy_words /*16 words on device, or nullptr for G*/, uint32_t* tab, uint32_t* scratch, int32_t* ok);
-size_t table_scratch_words();
+size_t pfix_table_scratch_words();
 // k_tom.hip
 void launch_tom_commit(hipStream_t s, const DevParams& P, const TomList& L, uint32_t count, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride = 0);
 void launch_tom_normalize(hipStream_t s, const TomList& L, uint32_t count, uint32_t first, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride = 0);

@@ -3,12 +3,12 @@
 //
 // Reference: PedersenParams.commit (src/commit/pedersen.ts:53-58) = h.dblmul(r, g, v), i.e. the Straus/Shamir
 // window-4 double-and-add of src/curves/group.ts:97-132 (256 dbl + 160 add = 4064 modmuls).  Only the AFFINE
-// result is observable (hash input / proof bytes), so the engine evaluates v*g + r*h as 64 additions of
-// precomputed multiples (8 modmuls each, no doublings): 512 modmuls.
+// result is observable (hash input / proof bytes), so the engine evaluates v*g + r*h as additions of
+// precomputed multiples (8 modmuls each, no doublings): 2 * ceil(256/W) additions for a W-bit comb (256 modmuls at W = 16,
+// 176 at W = 24).
 //
 // proveMult's variable-base products C4 = x*Cy and A4_2 = kx*Cy (src/commit/mult.ts:103,114) are also commitments
 // with KNOWN openings (x*y, x*ry), so they go through the same kernel (see k_scalar.hip).
-#include <cstdlib>
 #include "engine.h"
 
 ZK_DEV TomNiels ld_niels(const uint32_t* e) {
@@ -25,9 +25,16 @@ ZK_DEV TomNiels ld_niels(const uint32_t* e) {
     return n;
 }
 
+// 256-bit right shift by a run-time amount < 32 (v_alignbit_b32 per word)
+ZK_DEV void shr256_rt(uint32_t* w, uint32_t sh) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) w[i] = __funnelshift_r(w[i], w[i + 1], sh);
+    w[7] >>= sh;
+}
 template <int OCC>
 __global__ void __launch_bounds__(256, OCC) k_tom_commit(const uint32_t* __restrict__ tab_g, const uint32_t* __restrict__ tab_h, TomList L,
-                                                         uint32_t count, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride) {
+                                                         uint32_t count, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride,
+                                                         uint32_t bits, uint32_t nwin) {
     uint32_t c = gtid();
     if (c >= count) return;
     // kstride == 0: slot = group * slots_per_group + member;  kstride != 0 (list B): per_group = items, slot = k * kstride + item
@@ -38,22 +45,24 @@ __global__ void __launch_bounds__(256, OCC) k_tom_commit(const uint32_t* __restr
         words_from_limbs<8>(vw, v.l);
         words_from_limbs<8>(rw, r.l);
     }
+    const uint32_t mask = (1u << bits) - 1;
     TomPt acc = tom_identity();
     // software pipeline: the gathers of window w+1 are issued before the two additions of window w
-    uint32_t dv = vw[0] & (TOM_WIN_SIZE - 1), dr = rw[0] & (TOM_WIN_SIZE - 1);
-    shr256<TOM_WIN_BITS>(vw);
-    shr256<TOM_WIN_BITS>(rw);
+    uint32_t dv = vw[0] & mask, dr = rw[0] & mask;
+    shr256_rt(vw, bits);
+    shr256_rt(rw, bits);
     TomNiels ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * dv);
     TomNiels nh = ld_niels(tab_h + (size_t)TOM_ENTRY_WORDS * dr);
 #pragma unroll 1
-    for (int w = 0; w < TOM_NWIN; w++) {
+    for (uint32_t w = 0; w < nwin; w++) {
         TomNiels cg = ng, ch = nh;
-        if (w + 1 < TOM_NWIN) {
-            dv = vw[0] & (TOM_WIN_SIZE - 1), dr = rw[0] & (TOM_WIN_SIZE - 1);
-            shr256<TOM_WIN_BITS>(vw);
-            shr256<TOM_WIN_BITS>(rw);
-            ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * ((size_t)(w + 1) * TOM_WIN_SIZE + dv));
-            nh = ld_niels(tab_h + (size_t)TOM_ENTRY_WORDS * ((size_t)(w + 1) * TOM_WIN_SIZE + dr));
+        if (w + 1 < nwin) {
+            dv = vw[0] & mask, dr = rw[0] & mask;
+            shr256_rt(vw, bits);
+            shr256_rt(rw, bits);
+            size_t base = (size_t)(w + 1) << bits;
+            ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * (base + dv));
+            nh = ld_niels(tab_h + (size_t)TOM_ENTRY_WORDS * (base + dr));
         }
         acc = tom_add_niels(acc, cg);
         acc = tom_add_niels(acc, ch);
@@ -64,11 +73,8 @@ __global__ void __launch_bounds__(256, OCC) k_tom_commit(const uint32_t* __restr
 }
 void launch_tom_commit(hipStream_t s, const DevParams& P, const TomList& L, uint32_t count, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride) {
     if (!count) return;
-    static int occ = getenv("ZK_TOM_OCC") ? atoi(getenv("ZK_TOM_OCC")) : 2;
     dim3 g((count + 255) / 256), b(256);
-    if (occ == 4) hipLaunchKernelGGL(k_tom_commit<4>, g, b, 0, s, P.tom_tab_g, P.tom_tab_h, L, count, per_group, slots_per_group, kstride);
-    else if (occ == 3) hipLaunchKernelGGL(k_tom_commit<3>, g, b, 0, s, P.tom_tab_g, P.tom_tab_h, L, count, per_group, slots_per_group, kstride);
-    else hipLaunchKernelGGL(k_tom_commit<2>, g, b, 0, s, P.tom_tab_g, P.tom_tab_h, L, count, per_group, slots_per_group, kstride);
+    hipLaunchKernelGGL(k_tom_commit<2>, g, b, 0, s, P.tom_tab_g, P.tom_tab_h, L, count, per_group, slots_per_group, kstride, P.tom_bits, tom_nwin(P.tom_bits));
 }
 
 // Batch normalisation: (X:Y:Z) on the a=1 image -> affine (x, y) of the ORIGINAL curve, plain canonical limbs
