@@ -148,3 +148,30 @@ def test_lanes_and_chunking_do_not_change_the_bytes():
         assert st == [0] * 40 and hashlib.sha256(b''.join(got)).hexdigest() == ref, bits
         assert eng.verify_batch(msg, got) == ([1] * 40, [0] * 40)
     eng.close()
+
+
+@pytest.mark.parametrize('nkeys,B,chunk', [(512, 300, 128), (700, 64, 64), (8192, 40, 40), (65536, 24, 16)])
+def test_gk_table_path_equals_plain_fold_and_oracle(nkeys, B, chunk, monkeypatch):
+    """The per-ring table path of the ring polynomial (k_gk.hip: 8 low index bits as one multilinear step, proofs
+    sorted by l_low, XCD-segmented work list) against the plain fold (ZKATTEST_GK_TABLE=0) on every proof and against
+    the oracle's 2*N*n loop + interpolation (gk.ts:141-171) on the first ones; rings on both sides of the
+    one-proof-per-workgroup threshold (n = 9, 10 padded, 13, 16), several l_low groups per chunk, ragged chunks."""
+    eng, octx, (msg, sig, pk, which, seeds) = _setup(900 + nkeys, nkeys, B)
+    eng.set_chunk(chunk)
+    got, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert st == [0] * B
+    monkeypatch.setenv('ZKATTEST_GK_TABLE', '0')
+    import zkp_ecdsa_amd as Z
+    plain = Z.Engine(0)
+    plain.set_params(*eng.synth_params(900 + nkeys), 80)
+    ring = eng.synth_workload(900 + nkeys, nkeys, B)[0]
+    plain.set_ring(ring, nkeys)
+    plain.set_chunk(chunk)
+    ref, st2 = plain.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert st2 == [0] * B
+    assert [hashlib.sha256(g).hexdigest() for g in got] == [hashlib.sha256(r).hexdigest() for r in ref]
+    k = 4
+    exp, est = octx.prove_batch(msg[:32 * k], sig[:64 * k], pk[:64 * k], which[:k], seeds=seeds[:32 * k], nthreads=k)
+    assert est == [0] * k and got[:k] == exp
+    assert eng.verify_batch(msg, got) == ([1] * B, [0] * B)
+    eng.close(), plain.close()

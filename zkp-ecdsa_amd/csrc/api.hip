@@ -50,6 +50,7 @@ extern "C" zk_status zk_ctx_create(int device_id, zk_ctx** out) {
         int b = atoi(e);
         if (b >= 8 && b <= TOM_MAX_BITS) c->tom_bits = (uint32_t)b;
     }
+    if (const char* e = getenv("ZKATTEST_GK_TABLE")) c->gk_table = atoi(e) != 0;
     HIPCHK(c, hipMalloc(&c->tom_tab_gen, sizeof(uint32_t) * tom_tab_words(8)));
     HIPCHK(c, hipMalloc(&c->P.pfix_G, sizeof(uint32_t) * PFIX_TAB_WORDS));
     HIPCHK(c, hipMalloc(&c->P.pfix_H, sizeof(uint32_t) * PFIX_TAB_WORDS));
@@ -83,7 +84,7 @@ extern "C" void zk_ctx_destroy(zk_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto e : c->epool) hipEventDestroy(e);
     hipFree(c->P.tom_tab_g), hipFree(c->P.tom_tab_h), hipFree(c->tom_tab_gen), hipFree(c->P.pfix_G), hipFree(c->P.pfix_H);
-    hipFree(c->tab_scratch), hipFree(c->d_flag), hipFree(c->d_totals), hipFree(c->ring_mem), hipFree(c->arena), hipFree(c->varena), hipFree(c->arena2), hipFree(c->d_totals2), hipFree(c->varena2);
+    hipFree(c->tab_scratch), hipFree(c->gk_etab), hipFree(c->d_flag), hipFree(c->d_totals), hipFree(c->ring_mem), hipFree(c->arena), hipFree(c->varena), hipFree(c->arena2), hipFree(c->d_totals2), hipFree(c->varena2);
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -157,8 +158,15 @@ static zk_status set_ring_common(zk_ctx* c, const uint8_t* d_keys, uint64_t nkey
     HIPCHK(c, hipMalloc(&c->ring_mem, sizeof(uint32_t) * 9 * N));
     Soa ring = {c->ring_mem, (uint32_t)N};
     launch_ring_load(c->stream, d_keys, nkeys, N, ring);
+    if (c->gk_etab) HIPCHK(c, hipFree(c->gk_etab));
+    c->gk_etab = nullptr;
+    if (c->gk_table && n >= GK_ETAB_MINN && n <= GK_ETAB_MAXN) {  // per-ring table of the 8 low fold levels (k_gk.hip)
+        HIPCHK(c, hipMalloc(&c->gk_etab, sizeof(uint32_t) * gk_etab_words(N)));
+        launch_gk_etab(c->stream, ring, (uint32_t)(N >> 8), c->gk_etab);
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->N = N, c->n = n, c->nkeys = nkeys;
+    c->ws_C = 0, c->lane2_ready = false;  // the workspace layout depends on the ring
     return ZK_OK;
 }
 extern "C" zk_status zk_ctx_set_ring_device(zk_ctx* c, const void* d_keys, uint64_t nkeys) {
@@ -226,8 +234,12 @@ static size_t carve(zk_ctx* c, Workspace& W, Soa& gk_am, uint8_t* base, uint32_t
     // fallback for tiny rings ping-pongs G*N elements between gk_bufA and gk_bufB
     uint64_t g = std::max<uint64_t>(1, std::min<uint64_t>(C, ((uint64_t)1 << 16) / N));
     W.gk_group = (uint32_t)g;
-    uint32_t T = std::min<uint32_t>(n, 12);
+    uint32_t T = c->gk_etab ? 8 : std::min<uint32_t>(n, 12);
     uint64_t tile_elems = (uint64_t)(T + 1) * C * (N >> T);
+    W.gk_etab = c->gk_etab;
+    W.gk_asub = c->gk_etab ? (uint32_t*)k.take(36 * 256 * (size_t)C) : nullptr;
+    W.gk_order = (uint32_t*)k.take(4 * (size_t)C);
+    W.gk_goff = (uint32_t*)k.take(4 * 264);
     W.gk_bufA = (uint32_t*)k.take(36 * std::max<uint64_t>(g * N, tile_elems));
     W.gk_bufB = (uint32_t*)k.take(36 * std::max<uint64_t>(g * N, (uint64_t)(n + 1) * C * std::max<uint64_t>(1, (N >> T) / 64)));
     W.rng.exc_idx = (uint32_t*)k.take(4 * RNG_MAX_EXC * (size_t)C);

@@ -27,6 +27,8 @@ struct zk_ctx {
     int32_t* d_flag = nullptr;
     // ring
     uint32_t* ring_mem = nullptr;
+    uint32_t* gk_etab = nullptr;   // per-ring table of the GK block transform (k_gk.hip); nullptr for small / huge rings
+    bool gk_table = true;          // ZKATTEST_GK_TABLE=0 disables it (plain fold for every ring)
     uint64_t N = 0, nkeys = 0;
     uint32_t n = 0;
     // workspace

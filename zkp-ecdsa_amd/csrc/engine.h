@@ -121,6 +121,11 @@ struct Workspace {
     uint32_t gk_group;           // proofs per fold pass
     uint32_t* gk_bufA;           // ping-pong level buffers
     uint32_t* gk_bufB;
+    // block-transform path of the ring fold (k_gk.hip), used when the ring has a table E (9 <= n <= GK_ETAB_MAXN)
+    const uint32_t* gk_etab;     // per-ring table, owned by the context (nullptr: plain fold)
+    uint32_t* gk_asub;           // [C][256][9] products of the a_j over the subsets of the 8 low bits
+    uint32_t* gk_order;          // [C] proofs sorted by the 8 low bits of their ring index
+    uint32_t* gk_goff;           // [257] group offsets of that order
     Soa ring;                    // [N] plain canonical limbs (shared, owned by ctx)
     uint32_t N;
     RngCtx rng;
@@ -182,6 +187,12 @@ struct ChunkIn {
 };
 
 // ------------------------------------------------------------------ launch wrappers (one per kernel family)
+// k_gk.hip
+#define GK_ETAB_MINN 9
+#define GK_ETAB_MAXN 20
+size_t gk_etab_words(uint64_t N);
+void launch_gk_etab(hipStream_t s, const Soa& ring, uint32_t nblocks, uint32_t* E);
+void launch_gk_block_stage(hipStream_t s, const Workspace& W, const ChunkIn& in, const Soa& am, const Soa& res);
 // k_tables.hip
 void launch_build_tom_table(hipStream_t s, const uint32_t* aff_xy_words /*18 words on device*/, uint32_t bits, uint32_t* tab, uint32_t* scratch, int32_t* ok);
 size_t tom_table_scratch_words(uint32_t bits);

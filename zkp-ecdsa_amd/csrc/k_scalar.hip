@@ -576,11 +576,12 @@ void launch_gk_scalars_fold(hipStream_t s, const Workspace& W, const ChunkIn& in
     hipLaunchKernelGGL(k_gk_scalars, dim3((nt + 255) / 256), dim3(256), 0, s, W, in, am);
     if (W.n >= 3) {
         const uint32_t RL = W.n >= 4 ? 4 : 3;
-        uint32_t T = W.n < GK_TMAX ? W.n : GK_TMAX;
+        uint32_t T = W.gk_etab ? 8 : W.n < GK_TMAX ? W.n : GK_TMAX;
         uint32_t ntiles = W.N >> T;
         // tile results: (T+1) coefs x ntiles per proof, kept in gk_bufA (capacity checked by the workspace carver)
         Soa res = {W.gk_bufA, (uint32_t)((T + 1) * W.C * ntiles)};
-        if (RL == 4) hipLaunchKernelGGL(k_gk_tile<4>, dim3(in.count * ntiles), dim3(256), 0, s, W, in, am, T, ntiles, res);
+        if (W.gk_etab) launch_gk_block_stage(s, W, in, am, res);  // 8 low index bits through the per-ring table (k_gk.hip)
+        else if (RL == 4) hipLaunchKernelGGL(k_gk_tile<4>, dim3(in.count * ntiles), dim3(256), 0, s, W, in, am, T, ntiles, res);
         else hipLaunchKernelGGL(k_gk_tile<3>, dim3(in.count * ntiles), dim3(256), 0, s, W, in, am, T, ntiles, res);
         // finish passes: groups of <= 64 polynomials per workgroup (64 x (n+1) <= GK_LDS_A elements), ping-pong bufA/bufB
         Soa src = res;
