@@ -241,7 +241,7 @@ static size_t carve(zk_ctx* c, Workspace& W, Soa& gk_am, uint8_t* base, uint32_t
     W.gk_order = (uint32_t*)k.take(4 * (size_t)C);
     W.gk_goff = (uint32_t*)k.take(4 * 264);
     W.gk_bufA = (uint32_t*)k.take(36 * std::max<uint64_t>(g * N, tile_elems));
-    W.gk_bufB = (uint32_t*)k.take(36 * std::max<uint64_t>(g * N, (uint64_t)(n + 1) * C * std::max<uint64_t>(1, (N >> T) / 64)));
+    W.gk_bufB = (uint32_t*)k.take(36 * std::max<uint64_t>(g * N, (uint64_t)(n + 1) * C * std::max<uint64_t>(1, (N >> T) / gk_finish_gsz(T, (uint32_t)(N >> T)))));
     W.rng.exc_idx = (uint32_t*)k.take(4 * RNG_MAX_EXC * (size_t)C);
     W.rng.exc_flags = (uint32_t*)k.take(4 * RNG_MAX_EXC * (size_t)C);
     W.rng.exc_cnt = (uint32_t*)k.take(4 * (size_t)C);

@@ -187,6 +187,13 @@ struct ChunkIn {
 };
 
 // ------------------------------------------------------------------ launch wrappers (one per kernel family)
+// group size of one k_gk_finish pass over `ntiles` polynomials of T+1 coefficients: <= 64, dynamic LDS below 60 KB
+static inline size_t gk_finish_lds(uint32_t T, uint32_t g) { return sizeof(uint32_t) * 9 * ((size_t)g * (T + 1) + (size_t)(g / 2) * (T + 2)); }
+static inline uint32_t gk_finish_gsz(uint32_t T, uint32_t ntiles) {
+    uint32_t g = ntiles < 64 ? ntiles : 64;
+    while (g > 2 && gk_finish_lds(T, g) > 60 * 1024) g >>= 1;
+    return g;
+}
 // k_gk.hip
 #define GK_ETAB_MINN 9
 #define GK_ETAB_MAXN 20

@@ -435,7 +435,6 @@ void launch_gk_respond(hipStream_t s, const Workspace& W, const ChunkIn& in, uin
 // levels 3..T-1 run coefficient-parallel through LDS (one output coefficient = one modmul per lane), so a whole
 // tile costs ~20 modmul latencies instead of one kernel launch per level.  LDS planes are limb-major (conflict-free).
 #define GK_TMAX 12   // 256 lanes x 16 elements
-#define GK_LDS_A 1280u   // finish kernel: up to N/2^T tile polynomials x (T+1) coefs (N <= 2^28 is not reachable: see carve)
 struct LdsPlane {
     uint32_t* p;
     uint32_t stride;
@@ -550,12 +549,15 @@ __global__ void __launch_bounds__(256) k_gk_tile(Workspace W, ChunkIn in, Soa am
 // finish pass: workgroup (proof, group) folds `gsz` consecutive polynomials (Tin+1 coefs each, canonical) through
 // log2(gsz) levels; the result goes to gk_coef when it is the whole ring, else to dst[(k*C + p)*ngroups + g].
 __global__ void __launch_bounds__(256) k_gk_finish(Workspace W, ChunkIn in, Soa am, uint32_t Tin, uint32_t npoly, uint32_t gsz, Soa src, Soa dst) {
-    __shared__ uint32_t ldsA[NLIMB * GK_LDS_A];
-    __shared__ uint32_t ldsB[NLIMB * GK_LDS_A];
+    // dynamic LDS: plane A holds gsz x (Tin+1) elements, plane B gsz/2 x (Tin+2); later levels need less
+    extern __shared__ uint32_t lds_dyn[];
+    const uint32_t a_el = gsz * (Tin + 1), b_el = (gsz / 2) * (Tin + 2);
+    uint32_t* ldsA = lds_dyn;
+    uint32_t* ldsB = lds_dyn + NLIMB * a_el;
     uint32_t ngroups = npoly / gsz;
     uint32_t p = blockIdx.x / ngroups, g = blockIdx.x % ngroups;
     uint32_t which = in.which[p];
-    LdsPlane A = {ldsA, GK_LDS_A}, B = {ldsB, GK_LDS_A};
+    LdsPlane A = {ldsA, a_el}, B = {ldsB, b_el};
     for (uint32_t it = threadIdx.x; it < gsz * (Tin + 1); it += blockDim.x) {
         uint32_t k = it / gsz, m = it % gsz;
         lds_st(A, k * gsz + m, soa_ld<ModQ, 1>(src, (k * W.C + p) * npoly + g * gsz + m));
@@ -583,15 +585,16 @@ void launch_gk_scalars_fold(hipStream_t s, const Workspace& W, const ChunkIn& in
         if (W.gk_etab) launch_gk_block_stage(s, W, in, am, res);  // 8 low index bits through the per-ring table (k_gk.hip)
         else if (RL == 4) hipLaunchKernelGGL(k_gk_tile<4>, dim3(in.count * ntiles), dim3(256), 0, s, W, in, am, T, ntiles, res);
         else hipLaunchKernelGGL(k_gk_tile<3>, dim3(in.count * ntiles), dim3(256), 0, s, W, in, am, T, ntiles, res);
-        // finish passes: groups of <= 64 polynomials per workgroup (64 x (n+1) <= GK_LDS_A elements), ping-pong bufA/bufB
+        // finish passes: groups of <= 64 polynomials per workgroup (dynamic LDS sized to the group), ping-pong bufA/bufB
         Soa src = res;
         uint32_t* other = W.gk_bufB;
         while (ntiles > 1) {
-            uint32_t gsz = ntiles < 64 ? ntiles : 64, ngroups = ntiles / gsz;
+            uint32_t gsz = gk_finish_gsz(T, ntiles), ngroups = ntiles / gsz;
             uint32_t lv = 0;
             while ((1u << lv) < gsz) lv++;
             Soa dst = {other, (uint32_t)((T + lv + 1) * W.C * ngroups)};
-            hipLaunchKernelGGL(k_gk_finish, dim3(in.count * ngroups), dim3(256), 0, s, W, in, am, T, ntiles, gsz, src, dst);
+            size_t lds = gk_finish_lds(T, gsz);
+            hipLaunchKernelGGL(k_gk_finish, dim3(in.count * ngroups), dim3(256), lds, s, W, in, am, T, ntiles, gsz, src, dst);
             other = src.p;
             src = dst, T += lv, ntiles = ngroups;
         }
