@@ -242,10 +242,13 @@ def main():
         zeros_total = sum(((off_l[i + 1] - off_l[i]) - (304 + 336 * sec + (4 * 72 + 96) * n_log2 + 32)) // 3392 for i in range(B) if off_l[i + 1] > off_l[i])
         commits_per_step = B * (2 + 2 * sec) + zeros_total * 34 + B * 4 * n_log2
         tom_ms = fam.get('tom_commit', 0.0) / max(1, args.roofline_steps)
-        launches_per_step = 3 * ((B + eng_chunk(args, B) - 1) // eng_chunk(args, B))
-        modmuls_per_commit = tom_commit_modmuls(args.comb_bits)
+        launches_per_step = 4 * ((B + eng_chunk(args, B) - 1) // eng_chunk(args, B))   # lists A, B (unpaired + paired slots), C
+        # executed additions: 2 * nwin per commitment, except the 6 pairs per PointAdd item that share v*g (3 * nwin per pair)
+        nwin = (256 + args.comb_bits - 1) // args.comb_bits
+        adds = (commits_per_step - 34 * zeros_total) * 2 * nwin + zeros_total * (22 * 2 + 6 * 3) * nwin
+        modmuls_per_commit = round(adds * 8 / commits_per_step, 2)
         pmc_bytes = TOM_COMMIT_PMC_BYTES.get(args.comb_bits)
-        macs = commits_per_step * modmuls_per_commit * MACS_PER_MODMUL
+        macs = adds * 8 * MACS_PER_MODMUL
         achieved_tmacs = macs / (tom_ms * 1e-3) / 1e12 if tom_ms > 0 else 0.0
         hbm_gbps = commits_per_step * TOM_COMMIT_BYTES / (tom_ms * 1e-3) / 1e9 if tom_ms > 0 else 0.0
         wt, wq, wring = nominal_modmuls(n_log2)

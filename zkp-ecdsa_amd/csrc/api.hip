@@ -389,7 +389,7 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
         }
         {
             Scope t(c, "tom_commit", s);
-            launch_tom_commit(s, P, W.lb, items * LB_COMMITS, items, 0, W.items_cap);
+            launch_tom_commit_listb(s, P, W.lb, items, W.items_cap);
         }
         {
             Scope t(c, "tom_normalize", s);

@@ -207,6 +207,7 @@ void launch_build_pfix_table(hipStream_t s, const uint32_t* aff_xy_words /*16 wo
 size_t pfix_table_scratch_words();
 // k_tom.hip
 void launch_tom_commit(hipStream_t s, const DevParams& P, const TomList& L, uint32_t count, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride = 0);
+void launch_tom_commit_listb(hipStream_t s, const DevParams& P, const TomList& L, uint32_t items, uint32_t kstride);  // the 34 commitments of every PointAdd item
 void launch_tom_normalize(hipStream_t s, const TomList& L, uint32_t count, uint32_t first, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride = 0);
 void launch_padd_derived(hipStream_t s, const Workspace& W, uint32_t items);
 // k_p256.hip

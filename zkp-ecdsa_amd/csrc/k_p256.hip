@@ -242,17 +242,18 @@ void launch_p256_normalize(hipStream_t s, const Soa3& proj, uint32_t count, cons
 }
 
 // ---------------------------------------------------------------- T1 = (alpha_i - s1) * R + Q  (exp.ts:186-191)
+// alpha_i * R is T_i, already in Tproj (k_exp_commit), and s1 * R = Q + pk identically (s1 = s/r, R = (z/s) G + (r/s) pk,
+// Q = (z/r) G: the relation the whole proof is about), so T1 = T_i - pk: one mixed addition instead of a second
+// 256-bit scalar multiplication per zero-bit repetition.  Same group element, hence the same affine bytes; T1 = identity
+// (T_i = pk) is still caught by the normaliser ('T1 is at infinity', exp.ts:193).
 __global__ void __launch_bounds__(256) k_t1(Workspace W, uint32_t items) {
     uint32_t it = gtid();
     if (it >= items) return;
     uint32_t p = W.item_proof[it], i = W.item_rep[it];
-    Fe<ModN, 1> alpha = rng_draw<ModN>(W.rng, p, 3 + 4 * i);
-    Fe<ModN, 1> z = fe_sub_mod(alpha, soa_ld<ModN, 1>(W.s1, p));
-    uint32_t zw[8];
-    words_from_limbs<8>(zw, z.l);
-    P256Pt T1 = p256_rtab_mul(W.rtab + (size_t)p * RTAB_WORDS, zw);
-    T1 = p256_add(T1, ld_proj(W.Q, p));
-    st_proj(W.T1proj, it, T1);
+    P256Aff npk;
+    npk.x = soa_ld<ModQ, 2>(W.pkxm, p);
+    npk.y = fe_reduce(fe_neg(soa_ld<ModQ, 2>(W.pkym, p)));
+    st_proj(W.T1proj, it, p256_add_mixed(ld_proj(W.Tproj, p * (W.sec + 1) + i), npk));
 }
 void launch_t1(hipStream_t s, const Workspace& W, uint32_t items) {
     if (!items) return;
