@@ -94,19 +94,36 @@ ZK_DEV Fe<M, 2 * Ka> fe_dbl(const Fe<M, Ka>& a) {
     return a + a;
 }
 
+// Modulus limb i as an SGPR operand the optimiser cannot see through: left to itself the compiler strength-reduces
+// m * (2^a - 2^b) into 64-bit shift/add/sub sequences that cost more VALU issue slots than the one v_mad_u64_u32
+// they replace (ZK_LAUNDER_MOD=0 keeps the compiler's choice).  Zero limbs stay compile-time zeros (no instruction).
+#ifndef ZK_LAUNDER_MOD
+#define ZK_LAUNDER_MOD 1
+#endif
+template <class M>
+ZK_DEV void mod_limbs(uint32_t md[NLIMB]) {
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) {
+        md[i] = M::mod[i];
+#if ZK_LAUNDER_MOD
+        if (M::mod[i] != 0) asm("" : "+s"(md[i]));
+#endif
+    }
+}
 // Montgomery product, product-scanning with a single 64-bit accumulator (no carry flags).
 template <class M>
 ZK_DEV void limbs_mont_mul(uint32_t out[NLIMB], const uint32_t a[NLIMB], const uint32_t b[NLIMB]) {
     uint64_t acc = 0;
-    uint32_t m[NLIMB];
+    uint32_t m[NLIMB], md[NLIMB];
+    mod_limbs<M>(md);
 #pragma unroll
     for (int k = 0; k < NLIMB; k++) {
 #pragma unroll
         for (int i = 0; i <= k; i++) acc = mad64(a[i], b[k - i], acc);
 #pragma unroll
-        for (int i = 0; i < k; i++) acc = mad64(m[i], M::mod[k - i], acc);
+        for (int i = 0; i < k; i++) acc = mad64(m[i], md[k - i], acc);
         m[k] = ((uint32_t)acc * M::n0) & LIMB_MASK;
-        acc = mad64(m[k], M::mod[0], acc);
+        acc = mad64(m[k], md[0], acc);
         acc >>= LIMB_BITS;
     }
 #pragma unroll
@@ -114,7 +131,7 @@ ZK_DEV void limbs_mont_mul(uint32_t out[NLIMB], const uint32_t a[NLIMB], const u
 #pragma unroll
         for (int i = k - (NLIMB - 1); i < NLIMB; i++) acc = mad64(a[i], b[k - i], acc);
 #pragma unroll
-        for (int i = k - (NLIMB - 1); i < NLIMB; i++) acc = mad64(m[i], M::mod[k - i], acc);
+        for (int i = k - (NLIMB - 1); i < NLIMB; i++) acc = mad64(m[i], md[k - i], acc);
         out[k - NLIMB] = (uint32_t)acc & LIMB_MASK;
         acc >>= LIMB_BITS;
     }
