@@ -212,8 +212,8 @@ static size_t carve(zk_ctx* c, Workspace& W, Soa& gk_am, uint8_t* base, uint32_t
     W.pkx = k.soa(C), W.pky = k.soa(C), W.pkxm = k.soa(C), W.pkym = k.soa(C);
     W.Rxm = k.soa(C), W.Rym = k.soa(C), W.Rx = k.soa(C), W.Ry = k.soa(C);
     W.Q = k.soa3(C), W.s1 = k.soa(C);
-    W.rtab = (uint32_t*)k.take(sizeof(uint32_t) * (size_t)RTAB_WORDS * C);
-    W.rbase = k.soa3((size_t)C * RTAB_NWIN);
+    W.rtab = (uint32_t*)k.take(sizeof(uint32_t) * (size_t)std::max(rtab_words(RTAB_PROVE_BITS), rtab_words(RTAB_VERIFY_BITS)) * C);
+    W.rbase = k.soa3((size_t)C * RTAB_MAX_NWIN);
     W.chal = (uint32_t*)k.take(16 * (size_t)C);
     W.zcnt = (uint32_t*)k.take(4 * (size_t)C);
     W.item_base = (uint32_t*)k.take(4 * ((size_t)C + 1));
@@ -321,7 +321,7 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
         }
         {
             Scope t(c, "p256_rtab", s);
-            launch_rtab(s, W, cnt);
+            launch_rtab(s, W, cnt, RTAB_PROVE_BITS);
         }
         {
             Scope t(c, "p256_exp_commit", s);

@@ -116,7 +116,7 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
         {
             Scope t(c, "v_p256_front_rtab", s);
             launch_v_front(s, P, W, V, cnt, d_proofs, d_off, d_msg, first);
-            launch_rtab(s, W, cnt);
+            launch_rtab(s, W, cnt, RTAB_VERIFY_BITS);
         }
         {
             Scope t(c, "v_hash", s);

@@ -47,10 +47,14 @@ static inline size_t tom_tab_words(uint32_t bits) { return (size_t)tom_nwin(bits
 #define PFIX_WIN_SIZE (1u << PFIX_WIN_BITS)
 #define PFIX_ENTRY_WORDS 20
 #define PFIX_TAB_WORDS ((size_t)PFIX_NWIN * PFIX_WIN_SIZE * PFIX_ENTRY_WORDS)
-// per-proof table of R: 4-bit windows, 64 windows x 16 digits, entry = projective (X, Y, Z), 28 words.
-#define RTAB_NWIN 64
+// per-proof table of R (rtab.h): signed `bits`-bit comb, ceil(257/bits) windows x (2^(bits-1) + 1) entries of 28 words
 #define RTAB_ENTRY_WORDS 28
-#define RTAB_WORDS (RTAB_NWIN * 16 * RTAB_ENTRY_WORDS)
+#define RTAB_PROVE_BITS 6
+#define RTAB_VERIFY_BITS 4
+#define RTAB_MAX_NWIN 65
+__host__ __device__ static inline uint32_t rtab_nwin(uint32_t bits) { return (257 + bits - 1) / bits; }
+__host__ __device__ static inline uint32_t rtab_entries(uint32_t bits) { return (1u << (bits - 1)) + 1; }
+__host__ __device__ static inline uint32_t rtab_words(uint32_t bits) { return rtab_nwin(bits) * rtab_entries(bits) * RTAB_ENTRY_WORDS; }
 
 // ------------------------------------------------------------------ ZKA1 layout constants (bytes)
 #define ZK_PB 32
@@ -98,8 +102,8 @@ struct Workspace {
     Soa Rx, Ry;                  // R affine plain
     Soa3 Q;                      // projective Montgomery
     Soa s1;                      // plain mod n
-    uint32_t* rtab;              // [C][RTAB_WORDS]
-    Soa3 rbase;                  // [C*64] 2^(4w) R, projective
+    uint32_t* rtab;              // [C][rtab_words(bits)], sized for RTAB_PROVE_BITS
+    Soa3 rbase;                  // [C*RTAB_MAX_NWIN] window bases 2^(bits w) R, projective
     uint32_t* chal;              // [C][4] challenge words (80 bits in words 0..2)
     uint32_t* zcnt;              // [C]
     uint32_t* item_base;         // [C+1]
@@ -212,7 +216,7 @@ void launch_tom_normalize(hipStream_t s, const TomList& L, uint32_t count, uint3
 void launch_padd_derived(hipStream_t s, const Workspace& W, uint32_t items);
 // k_p256.hip
 void launch_front(hipStream_t s, const DevParams& P, const Workspace& W, const ChunkIn& in);
-void launch_rtab(hipStream_t s, const Workspace& W, uint32_t count);
+void launch_rtab(hipStream_t s, const Workspace& W, uint32_t count, uint32_t bits);
 void launch_exp_commit(hipStream_t s, const DevParams& P, const Workspace& W, uint32_t count);
 void launch_p256_normalize(hipStream_t s, const Soa3& proj, uint32_t count, const Soa& ox, const Soa& oy, int32_t* st, uint32_t per_proof, int32_t err_code, const uint32_t* owner /*nullable: item->proof*/);
 void launch_t1(hipStream_t s, const Workspace& W, uint32_t items);

@@ -5,7 +5,7 @@
 // observable, so the engine uses: fixed-base combs for G and h_NIST (32 mixed complete additions), and a
 // per-proof 4-bit comb table of R = paramsSigExp.g, shared by the 2*sec+1 multiplications by R of one proof
 // (64 complete additions each).  All additions are the complete RCB formulas the reference uses.
-#include "engine.h"
+#include "rtab.h"
 
 ZK_DEV P256Aff ld_pfix(const uint32_t* e) {
     const uint4* q = (const uint4*)e;
@@ -30,36 +30,6 @@ ZK_DEV P256Pt p256_fixed_mul(const uint32_t* __restrict__ tab, uint32_t kw[8]) {
         P256Aff e = ld_pfix(tab + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + d));
         P256Pt s = p256_add_mixed(acc, e);
         acc = p256_select(d != 0, s, acc);
-    }
-    return acc;
-}
-ZK_DEV P256Pt ld_rtab(const uint32_t* e) {
-    const uint4* q = (const uint4*)e;
-    uint32_t w[28];
-#pragma unroll
-    for (int i = 0; i < 7; i++) {
-        uint4 v = q[i];
-        w[4 * i] = v.x, w[4 * i + 1] = v.y, w[4 * i + 2] = v.z, w[4 * i + 3] = v.w;
-    }
-    P256Pt a;
-#pragma unroll
-    for (int l = 0; l < 9; l++) a.x.l[l] = w[l], a.y.l[l] = w[9 + l], a.z.l[l] = w[18 + l];
-    return a;
-}
-ZK_DEV void st_rtab(uint32_t* e, const P256Pt& a) {
-#pragma unroll
-    for (int l = 0; l < 9; l++) e[l] = a.x.l[l], e[9 + l] = a.y.l[l], e[18 + l] = a.z.l[l];
-    e[27] = 0;
-}
-// k * R with the proof's 4-bit comb table (entry 0 of every window is the identity: complete addition absorbs it)
-ZK_DEV P256Pt p256_rtab_mul(const uint32_t* __restrict__ rtab, uint32_t kw[8]) {
-    P256Pt acc = p256_identity();
-#pragma unroll 1
-    for (int w = 0; w < RTAB_NWIN; w++) {
-        uint32_t d = kw[0] & 15;
-        shr256<4>(kw);
-        P256Pt e = ld_rtab(rtab + (size_t)RTAB_ENTRY_WORDS * (w * 16 + d));
-        acc = p256_add(acc, e);
     }
     return acc;
 }
@@ -136,36 +106,40 @@ void launch_front(hipStream_t s, const DevParams& P, const Workspace& W, const C
     hipLaunchKernelGGL(k_front, dim3((in.count + 63) / 64), dim3(64), 0, s, P, W, in);
 }
 
-// ---------------------------------------------------------------- per-proof table of R
-__global__ void __launch_bounds__(64) k_rtab_base(Workspace W, uint32_t count) {
+// ---------------------------------------------------------------- per-proof table of R (layout and use: rtab.h)
+__global__ void __launch_bounds__(64) k_rtab_base(Workspace W, uint32_t count, uint32_t bits) {
     uint32_t p = gtid();
     if (p >= count) return;
     P256Aff r;
     r.x = soa_ld<ModQ, 2>(W.Rxm, p), r.y = soa_ld<ModQ, 2>(W.Rym, p);
     P256Pt b = p256_from_affine(r);
     if (W.st[p] == ZK_E_T_INF) b = p256_identity();
+    const uint32_t nwin = rtab_nwin(bits);
 #pragma unroll 1
-    for (int w = 0; w < RTAB_NWIN; w++) {
-        st_proj(W.rbase, p * RTAB_NWIN + w, b);
-        b = p256_dbl(p256_dbl(p256_dbl(p256_dbl(b))));
+    for (uint32_t w = 0; w < nwin; w++) {
+        st_proj(W.rbase, p * nwin + w, b);
+#pragma unroll 1
+        for (uint32_t i = 0; i < bits; i++) b = p256_dbl(b);
     }
 }
-__global__ void __launch_bounds__(256) k_rtab_fill(Workspace W, uint32_t count) {
+__global__ void __launch_bounds__(256) k_rtab_fill(Workspace W, uint32_t count, uint32_t bits) {
     uint32_t t = gtid();
-    if (t >= count * RTAB_NWIN) return;
+    const uint32_t nwin = rtab_nwin(bits), ent = rtab_entries(bits);
+    if (t >= count * nwin) return;
     P256Pt b = ld_proj(W.rbase, t);
-    uint32_t* e = W.rtab + (size_t)t * 16 * RTAB_ENTRY_WORDS;
-    P256Pt acc = p256_identity();
-    st_rtab(e, acc);
+    uint32_t* e = W.rtab + (size_t)(t / nwin) * rtab_words(bits) + (size_t)(t % nwin) * ent * RTAB_ENTRY_WORDS;
+    st_rtab(e, p256_identity());
+    st_rtab(e + RTAB_ENTRY_WORDS, b);
+    P256Pt acc = b;
 #pragma unroll 1
-    for (int d = 1; d < 16; d++) {
+    for (uint32_t d = 2; d < ent; d++) {
         acc = p256_add(acc, b);
         st_rtab(e + d * RTAB_ENTRY_WORDS, acc);
     }
 }
-void launch_rtab(hipStream_t s, const Workspace& W, uint32_t count) {
-    hipLaunchKernelGGL(k_rtab_base, dim3((count + 63) / 64), dim3(64), 0, s, W, count);
-    hipLaunchKernelGGL(k_rtab_fill, dim3((count * RTAB_NWIN + 255) / 256), dim3(256), 0, s, W, count);
+void launch_rtab(hipStream_t s, const Workspace& W, uint32_t count, uint32_t bits) {
+    hipLaunchKernelGGL(k_rtab_base, dim3((count + 63) / 64), dim3(64), 0, s, W, count, bits);
+    hipLaunchKernelGGL(k_rtab_fill, dim3((count * rtab_nwin(bits) + 255) / 256), dim3(256), 0, s, W, count, bits);
 }
 
 // ---------------------------------------------------------------- Exp commit phase (exp.ts:144-149) and comS1
@@ -186,7 +160,7 @@ __global__ void __launch_bounds__(256) k_exp_commit(DevParams P, Workspace W, ui
         words_from_limbs<8>(aw, a.l);
         words_from_limbs<8>(bw, b.l);
     }
-    P256Pt T = p256_rtab_mul(W.rtab + (size_t)p * RTAB_WORDS, aw);
+    P256Pt T = p256_rtab_mul(W.rtab + (size_t)p * rtab_words(RTAB_PROVE_BITS), aw, RTAB_PROVE_BITS);
     P256Pt U = p256_fixed_mul(P.pfix_H, bw);
     P256Pt A = p256_add(T, U);
     st_proj(W.Tproj, t, T);

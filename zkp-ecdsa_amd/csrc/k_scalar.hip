@@ -163,6 +163,37 @@ ZK_DEV void mult_openings(const Workspace& W, uint32_t p, uint32_t dm, uint32_t 
     put_vr(W.lb, lbi(W, it, k0 + 4), kz, s4);                                 // A4_1
     put_vr(W.lb, lbi(W, it, k0 + 5), fe_canon(kxm * y), fe_canon(kxm * ry));  // A4_2 = kx * Cy
 }
+// i8 = 1 / (x2 - x1) (pointAdd.ts:131, invMod) for all items of the chunk with Montgomery's trick: k_padd_i7 parks
+// x2 - x1 (Montgomery form) in T1proj.x -- free once T1 is normalised --, k_padd_inv runs one Fermat inversion per
+// `per` items (prefix products in T1proj.z) and leaves the inverses in T1proj.y.  x2 = x1 gives 0 like fe_inv(0).
+__global__ void __launch_bounds__(256) k_padd_i7(Workspace W, uint32_t items) {
+    uint32_t it = gtid();
+    if (it >= items) return;
+    Sq d = fe_sub_mod(soa_ld<ModQ, 1>(W.pkx, W.item_proof[it]), soa_ld<ModQ, 1>(W.T1x, it));
+    soa_st(W.T1proj.x, it, fe_to_mont(d));
+}
+__global__ void __launch_bounds__(256) k_padd_inv(Workspace W, uint32_t items, uint32_t nthreads, uint32_t per) {
+    uint32_t t = gtid();
+    if (t >= nthreads) return;
+    Fq2 acc = fe_one_mont<ModQ>().as<2>();
+    for (uint32_t j = 0; j < per; j++) {
+        uint32_t e = t + j * nthreads;
+        if (e >= items) break;
+        Fq2 v = soa_ld<ModQ, 2>(W.T1proj.x, e);
+        soa_st(W.T1proj.z, e, acc);
+        if (!fe_is_zero(v)) acc = acc * v;
+    }
+    Fq2 inv = fe_inv<ModQ>(acc);
+    for (int j = (int)per - 1; j >= 0; j--) {
+        uint32_t e = t + (uint32_t)j * nthreads;
+        if (e >= items) continue;
+        Fq2 v = soa_ld<ModQ, 2>(W.T1proj.x, e);
+        bool zero = fe_is_zero(v);
+        Fq2 r = inv * soa_ld<ModQ, 2>(W.T1proj.z, e);
+        if (!zero) inv = inv * v;
+        soa_st(W.T1proj.y, e, zero ? fe_zero<ModQ>().as<2>() : r);
+    }
+}
 __global__ void __launch_bounds__(256) k_padd_scalars(Workspace W, uint32_t items) {
     uint32_t it = gtid();
     if (it >= items) return;
@@ -174,7 +205,7 @@ __global__ void __launch_bounds__(256) k_padd_scalars(Workspace W, uint32_t item
     PaddWit w;
     padd_blinders(W, p, i, d0, w);
     w.i7 = fe_sub_mod(x2, x1);
-    w.i8 = fe_from_mont(fe_inv<ModQ>(fe_to_mont(w.i7)));
+    w.i8 = fe_from_mont(soa_ld<ModQ, 2>(W.T1proj.y, it));
     w.i9 = fe_sub_mod(y2, y1);
     w.i10 = fe_mul_mod(w.i8, w.i9);
     w.i11 = fe_mul_mod(w.i10, w.i10);
@@ -201,6 +232,9 @@ __global__ void __launch_bounds__(256) k_padd_scalars(Workspace W, uint32_t item
 }
 void launch_padd_scalars(hipStream_t s, const DevParams&, const Workspace& W, uint32_t items) {
     if (!items) return;
+    hipLaunchKernelGGL(k_padd_i7, dim3((items + 255) / 256), dim3(256), 0, s, W, items);
+    uint32_t per = 16, nthreads = (items + per - 1) / per;
+    hipLaunchKernelGGL(k_padd_inv, dim3((nthreads + 255) / 256), dim3(256), 0, s, W, items, nthreads, per);
     hipLaunchKernelGGL(k_padd_scalars, dim3((items + 255) / 256), dim3(256), 0, s, W, items);
 }
 

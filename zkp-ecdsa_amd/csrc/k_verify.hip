@@ -10,7 +10,7 @@
 // reps are checked follows the reference's generateIndices (exp.ts:95-109) under the verifier-RNG contract
 // (fill k = SHA-256(vseed || be64(k)); randomScalar takes 32 bytes, rnd(small) takes 1 byte), so a proof with
 // SOME bad reps gets the same verdict as the reference/oracle for the same verifier seed.
-#include "engine.h"
+#include "rtab.h"
 
 typedef Fe<ModQ, 1> Sq;
 typedef Fe<ModN, 1> Sn;
@@ -289,11 +289,6 @@ __global__ void __launch_bounds__(64) k_v_sample(VWork V, uint32_t count, const 
 }
 
 // ------------------------------------------------------------------ Exp: T = alpha*R or T1 = z*R + Q per checked rep (exp.ts:267,299,311)
-ZK_DEV P256Pt v_ld_rtab(const uint32_t* e) {
-    P256Pt a;
-    for (int l = 0; l < 9; l++) a.x.l[l] = e[l], a.y.l[l] = e[9 + l], a.z.l[l] = e[18 + l];
-    return a;
-}
 __global__ void __launch_bounds__(256) k_v_exp_points(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
     uint32_t t = gtid();
     if (t >= count * VK) return;
@@ -307,13 +302,7 @@ __global__ void __launch_bounds__(256) k_v_exp_points(Workspace W, VWork V, uint
         Sn s = ld_scalar_n(rep + 208);
         uint32_t kw[8];
         words_from_limbs<8>(kw, s.l);
-        const uint32_t* rtab = W.rtab + (size_t)p * RTAB_WORDS;
-#pragma unroll 1
-        for (int w = 0; w < RTAB_NWIN; w++) {
-            uint32_t d = kw[0] & 15;
-            shr256<4>(kw);
-            acc = p256_add(acc, v_ld_rtab(rtab + (size_t)RTAB_ENTRY_WORDS * (w * 16 + d)));
-        }
+        acc = p256_rtab_mul(W.rtab + (size_t)p * rtab_words(RTAB_VERIFY_BITS), kw, RTAB_VERIFY_BITS);
         if (!bit) {
             P256Pt q;
             q.x = soa_ld<ModQ, 8>(W.Q.x, p), q.y = soa_ld<ModQ, 8>(W.Q.y, p), q.z = soa_ld<ModQ, 8>(W.Q.z, p);
@@ -925,13 +914,7 @@ __global__ void __launch_bounds__(64) k_v_final(DevParams P, Workspace W, VWork 
                 {
                     uint32_t kw[8];
                     words_from_limbs<8>(kw, soa_ld<ModN, 1>(V.pSR, p).l);
-                    const uint32_t* rtab = W.rtab + (size_t)p * RTAB_WORDS;
-#pragma unroll 1
-                    for (int w = 0; w < RTAB_NWIN; w++) {
-                        uint32_t d = kw[0] & 15;
-                        shr256<4>(kw);
-                        acc = p256_add(acc, v_ld_rtab(rtab + (size_t)RTAB_ENTRY_WORDS * (w * 16 + d)));
-                    }
+                    acc = p256_rtab_mul(W.rtab + (size_t)p * rtab_words(RTAB_VERIFY_BITS), kw, RTAB_VERIFY_BITS);
                     words_from_limbs<8>(kw, soa_ld<ModN, 1>(V.pSH, p).l);
 #pragma unroll 1
                     for (int w = 0; w < PFIX_NWIN; w++) {
