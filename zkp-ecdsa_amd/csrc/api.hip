@@ -245,6 +245,7 @@ static size_t carve(zk_ctx* c, Workspace& W, Soa& gk_am, uint8_t* base, uint32_t
     W.rng.exc_idx = (uint32_t*)k.take(4 * RNG_MAX_EXC * (size_t)C);
     W.rng.exc_flags = (uint32_t*)k.take(4 * RNG_MAX_EXC * (size_t)C);
     W.rng.exc_cnt = (uint32_t*)k.take(4 * (size_t)C);
+    W.rng_fill = (uint32_t*)k.take(32 * (size_t)(3 + 44 * sec + 5 * n + RNG_MAX_EXC) * C);
     W.ring = Soa{c->ring_mem, (uint32_t)N};
     return k.off + 256;
 }
@@ -313,7 +314,9 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
         uint32_t nblk = 3 + 44 * W.sec + 5 * W.n + RNG_MAX_EXC;
         {
             Scope t(c, "rng_prepass", s);
-            launch_rng_prepass(s, W, cnt, nblk);
+            launch_rng_prepass(s, W, cnt, nblk, rng_mode == 0 ? W.rng_fill : nullptr);
+            if (rng_mode == 0)  // from here on the chunk reads the fills the prepass wrote
+                W.rng.mode = 1, W.rng.stream = (const uint8_t*)W.rng_fill, W.rng.stride_blocks = nblk, W.rng.proof_base = 0;
         }
         {
             Scope t(c, "p256_front", s);
@@ -630,7 +633,7 @@ extern "C" zk_status zk_test_rng_draws(zk_ctx* c, uint64_t B, const zk_rng* rng,
     W.rng.seeds = (uint8_t*)dr.p, W.rng.stream = (uint8_t*)dr.p, W.rng.stride_blocks = rng->stride_blocks, W.rng.mode = rng->mode, W.rng.sec = (int)sec;
     W.rng.exc_idx = (uint32_t*)dexc.p, W.rng.exc_flags = W.rng.exc_idx + RNG_MAX_EXC * B, W.rng.exc_cnt = W.rng.exc_flags + RNG_MAX_EXC * B;
     W.rng.proof_base = 0;
-    launch_rng_prepass(c->stream, W, (uint32_t)B, first_k + n_k + RNG_MAX_EXC);
+    launch_rng_prepass(c->stream, W, (uint32_t)B, first_k + n_k + RNG_MAX_EXC, nullptr);
     launch_test_rng(c->stream, W.rng, B, first_k, n_k, (uint8_t*)dout.p);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, dout.p, 32 * B * n_k, hipMemcpyDeviceToHost));

@@ -123,6 +123,7 @@ struct Workspace {
     uint32_t* gk_x;              // [C][3]
     Soa gk_coef;                 // [(n+1)*C] final polynomial coefficients, index k*C + proof
     uint32_t gk_group;           // proofs per fold pass
+    uint32_t* rng_fill;          // [C][nblk][8] the chunk's RNG fills as a stream (seed mode), see k_rng_prepass
     uint32_t* gk_bufA;           // ping-pong level buffers
     uint32_t* gk_bufB;
     // block-transform path of the ring fold (k_gk.hip), used when the ring has a table E (9 <= n <= GK_ETAB_MAXN)
@@ -222,7 +223,7 @@ void launch_p256_normalize(hipStream_t s, const Soa3& proj, uint32_t count, cons
 void launch_t1(hipStream_t s, const Workspace& W, uint32_t items);
 void launch_test_pfix(hipStream_t s, const uint32_t* tab, uint64_t count, const uint8_t* k_be, uint8_t* out);
 // k_hash.hip
-void launch_rng_prepass(hipStream_t s, const Workspace& W, uint32_t count, uint32_t nblk);
+void launch_rng_prepass(hipStream_t s, const Workspace& W, uint32_t count, uint32_t nblk, uint32_t* fill);
 void launch_exp_challenge(hipStream_t s, const Workspace& W, uint32_t count);
 void launch_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, uint32_t items);
 void launch_gk_hash(hipStream_t s, const Workspace& W, uint32_t count);

@@ -37,12 +37,19 @@ ZK_DEV void challenge_words(const uint32_t h[8], uint32_t c[4]) {
 }
 
 // ---------------------------------------------------------------- RNG prepass
-__global__ void __launch_bounds__(256) k_rng_prepass(Workspace W, uint32_t count, uint32_t nblk) {
+// `fill` (seed mode only): the fills are also written out as an explicit stream, [proof][block][32 bytes], and every
+// later kernel of the chunk reads its draws from there (mode 1) instead of hashing seed || k again.
+__global__ void __launch_bounds__(256) k_rng_prepass(Workspace W, uint32_t count, uint32_t nblk, uint32_t* fill) {
     uint32_t t = gtid();
     if (t >= count * nblk) return;
     uint32_t p = t / nblk, blk = t % nblk;
     uint32_t w[8];
     rng_block(W.rng, p, blk, w);
+    if (fill) {
+        uint4* o = (uint4*)(fill + (size_t)t * 8);
+        o[0] = make_uint4(bswap32(w[7]), bswap32(w[6]), bswap32(w[5]), bswap32(w[4]));
+        o[1] = make_uint4(bswap32(w[3]), bswap32(w[2]), bswap32(w[1]), bswap32(w[0]));
+    }
     if (w[7] != 0xffffffffu) return;
     uint32_t fl = (words_geq<8>(w, ModN::mod32) ? 1u : 0u) | (words_geq<8>(w, ModQ::mod32) ? 2u : 0u);
     if (!fl) return;
@@ -52,10 +59,10 @@ __global__ void __launch_bounds__(256) k_rng_prepass(Workspace W, uint32_t count
         W.rng.exc_flags[p * RNG_MAX_EXC + i] = fl;
     }
 }
-void launch_rng_prepass(hipStream_t s, const Workspace& W, uint32_t count, uint32_t nblk) {
+void launch_rng_prepass(hipStream_t s, const Workspace& W, uint32_t count, uint32_t nblk, uint32_t* fill) {
     hipMemsetAsync(W.rng.exc_cnt, 0, sizeof(uint32_t) * count, s);
     uint64_t n = (uint64_t)count * nblk;
-    hipLaunchKernelGGL(k_rng_prepass, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, W, count, nblk);
+    hipLaunchKernelGGL(k_rng_prepass, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, W, count, nblk, fill);
 }
 
 // ---------------------------------------------------------------- Exp challenge (exp.ts:158-165)
