@@ -314,10 +314,11 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
         uint32_t nblk = 3 + 44 * W.sec + 5 * W.n + RNG_MAX_EXC;
         {
             Scope t(c, "rng_prepass", s);
-            launch_rng_prepass(s, W, cnt, nblk, rng_mode == 0 ? W.rng_fill : nullptr);
-            if (rng_mode == 0)  // from here on the chunk reads the fills the prepass wrote
-                W.rng.mode = 1, W.rng.stream = (const uint8_t*)W.rng_fill, W.rng.stride_blocks = nblk, W.rng.proof_base = 0;
+            launch_rng_prepass(s, W, cnt, 0, 3 + 4 * W.sec + RNG_MAX_EXC, nblk, rng_mode == 0 ? W.rng_fill : nullptr, false);  // + margin: rejected fills shift later draws
         }
+        Workspace Wgen = W;  // RNG view of the generator (seed mode) for the second prepass stage
+        if (rng_mode == 0)   // from here on the chunk reads the fills the prepass wrote
+            W.rng.mode = 1, W.rng.stream = (const uint8_t*)W.rng_fill, W.rng.stride_blocks = nblk, W.rng.proof_base = 0;
         {
             Scope t(c, "p256_front", s);
             launch_front(s, P, W, in);
@@ -377,6 +378,10 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
         {
             Scope t(c, "scan", s);
             launch_items(s, W, cnt);
+        }
+        {
+            Scope t(c, "rng_prepass", s);  // second stage: only the blocks a proof with z zero bits can reach
+            launch_rng_prepass(s, Wgen, cnt, 3 + 4 * W.sec + RNG_MAX_EXC, nblk, nblk, rng_mode == 0 ? W.rng_fill : nullptr, true);
         }
         {
             Scope t(c, "p256_t1", s);
@@ -633,7 +638,7 @@ extern "C" zk_status zk_test_rng_draws(zk_ctx* c, uint64_t B, const zk_rng* rng,
     W.rng.seeds = (uint8_t*)dr.p, W.rng.stream = (uint8_t*)dr.p, W.rng.stride_blocks = rng->stride_blocks, W.rng.mode = rng->mode, W.rng.sec = (int)sec;
     W.rng.exc_idx = (uint32_t*)dexc.p, W.rng.exc_flags = W.rng.exc_idx + RNG_MAX_EXC * B, W.rng.exc_cnt = W.rng.exc_flags + RNG_MAX_EXC * B;
     W.rng.proof_base = 0;
-    launch_rng_prepass(c->stream, W, (uint32_t)B, first_k + n_k + RNG_MAX_EXC, nullptr);
+    launch_rng_prepass(c->stream, W, (uint32_t)B, 0, first_k + n_k + RNG_MAX_EXC, 0, nullptr, false);
     launch_test_rng(c->stream, W.rng, B, first_k, n_k, (uint8_t*)dout.p);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, dout.p, 32 * B * n_k, hipMemcpyDeviceToHost));

@@ -223,7 +223,7 @@ void launch_p256_normalize(hipStream_t s, const Soa3& proj, uint32_t count, cons
 void launch_t1(hipStream_t s, const Workspace& W, uint32_t items);
 void launch_test_pfix(hipStream_t s, const uint32_t* tab, uint64_t count, const uint8_t* k_be, uint8_t* out);
 // k_hash.hip
-void launch_rng_prepass(hipStream_t s, const Workspace& W, uint32_t count, uint32_t nblk, uint32_t* fill);
+void launch_rng_prepass(hipStream_t s, const Workspace& W, uint32_t count, uint32_t blk0, uint32_t blk1, uint32_t stride, uint32_t* fill, bool by_zcnt);
 void launch_exp_challenge(hipStream_t s, const Workspace& W, uint32_t count);
 void launch_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, uint32_t items);
 void launch_gk_hash(hipStream_t s, const Workspace& W, uint32_t count);

@@ -39,14 +39,17 @@ ZK_DEV void challenge_words(const uint32_t h[8], uint32_t c[4]) {
 // ---------------------------------------------------------------- RNG prepass
 // `fill` (seed mode only): the fills are also written out as an explicit stream, [proof][block][32 bytes], and every
 // later kernel of the chunk reads its draws from there (mode 1) instead of hashing seed || k again.
-__global__ void __launch_bounds__(256) k_rng_prepass(Workspace W, uint32_t count, uint32_t nblk, uint32_t* fill) {
+// The scan runs in two stages: blocks [0, 3 + 4 sec) before the Exp commit phase, and -- once the challenge has fixed the
+// number z of zero bits -- the blocks the rest of the proof can reach, [3 + 4 sec, 3 + 4 sec + 40 z + 5 n + RNG_MAX_EXC).
+__global__ void __launch_bounds__(256) k_rng_prepass(Workspace W, uint32_t count, uint32_t blk0, uint32_t span, uint32_t stride, uint32_t* fill, int by_zcnt) {
     uint32_t t = gtid();
-    if (t >= count * nblk) return;
-    uint32_t p = t / nblk, blk = t % nblk;
+    if (t >= count * span) return;
+    uint32_t p = t / span, blk = blk0 + t % span;
+    if (by_zcnt && blk >= 3 + 4 * W.sec + 40 * W.zcnt[p] + 5 * W.n + RNG_MAX_EXC) return;
     uint32_t w[8];
     rng_block(W.rng, p, blk, w);
     if (fill) {
-        uint4* o = (uint4*)(fill + (size_t)t * 8);
+        uint4* o = (uint4*)(fill + ((size_t)p * stride + blk) * 8);
         o[0] = make_uint4(bswap32(w[7]), bswap32(w[6]), bswap32(w[5]), bswap32(w[4]));
         o[1] = make_uint4(bswap32(w[3]), bswap32(w[2]), bswap32(w[1]), bswap32(w[0]));
     }
@@ -59,10 +62,11 @@ __global__ void __launch_bounds__(256) k_rng_prepass(Workspace W, uint32_t count
         W.rng.exc_flags[p * RNG_MAX_EXC + i] = fl;
     }
 }
-void launch_rng_prepass(hipStream_t s, const Workspace& W, uint32_t count, uint32_t nblk, uint32_t* fill) {
-    hipMemsetAsync(W.rng.exc_cnt, 0, sizeof(uint32_t) * count, s);
-    uint64_t n = (uint64_t)count * nblk;
-    hipLaunchKernelGGL(k_rng_prepass, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, W, count, nblk, fill);
+void launch_rng_prepass(hipStream_t s, const Workspace& W, uint32_t count, uint32_t blk0, uint32_t blk1, uint32_t stride, uint32_t* fill, bool by_zcnt) {
+    if (blk0 == 0) hipMemsetAsync(W.rng.exc_cnt, 0, sizeof(uint32_t) * count, s);
+    uint64_t n = (uint64_t)count * (blk1 - blk0);
+    if (!n) return;
+    hipLaunchKernelGGL(k_rng_prepass, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, W, count, blk0, blk1 - blk0, stride, fill, by_zcnt ? 1 : 0);
 }
 
 // ---------------------------------------------------------------- Exp challenge (exp.ts:158-165)
