@@ -300,13 +300,22 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return ZK_OK;
     }
-    uint32_t chunk_no = 0;
-    for (uint64_t first = 0; first < B; first += C, chunk_no++) {
+    // Every chunk has two stages.  Stage 1 (front end .. Exp challenge) needs nothing from other chunks; stage 2 starts with
+    // the scan, which needs the output cursor, i.e. the byte count of all earlier chunks, and the host has to read the
+    // item count back before it can size the PointAdd launches.  With two lanes, stage 1 of chunk k+1 is enqueued on the
+    // other stream BEFORE the host blocks on chunk k's scan, so neither stream runs dry while the host waits.
+    struct Pending {
+        bool lane2;
+        uint32_t cnt;
+        uint64_t first;
+        ChunkIn in;
+        Workspace Wgen;  // RNG view of the generator (seed mode) for the second prepass stage
+        uint32_t nblk;
+    };
+    auto stage1 = [&](uint64_t first, uint32_t chunk_no, Pending& pd) -> zk_status {
         const bool lane2 = dual && (chunk_no & 1);
         Workspace& W = lane2 ? c->W2 : c->W;
         hipStream_t s = lane2 ? c->stream2 : c->stream;
-        const Soa& gk_am = lane2 ? c->gk_am2 : c->gk_am;
-        uint32_t* d_totals = lane2 ? c->d_totals2 : c->d_totals;
         uint32_t cnt = (uint32_t)std::min<uint64_t>(C, B - first);
         ChunkIn in{d_msg + 32 * first, d_sig + 64 * first, d_pk + 64 * first, d_which + first, cnt};
         W.rng.seeds = d_rng, W.rng.stream = d_rng, W.rng.stride_blocks = stride, W.rng.mode = rng_mode, W.rng.sec = (int)W.sec;
@@ -353,6 +362,19 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
             Scope t(c, "hash", s);
             launch_exp_challenge(s, W, cnt);
         }
+        pd.lane2 = lane2, pd.cnt = cnt, pd.first = first, pd.in = in, pd.Wgen = Wgen, pd.nblk = nblk;
+        return ZK_OK;
+    };
+    auto stage2 = [&](Pending& pd) -> zk_status {
+        const bool lane2 = pd.lane2;
+        Workspace& W = lane2 ? c->W2 : c->W;
+        hipStream_t s = lane2 ? c->stream2 : c->stream;
+        const Soa& gk_am = lane2 ? c->gk_am2 : c->gk_am;
+        uint32_t* d_totals = lane2 ? c->d_totals2 : c->d_totals;
+        const uint32_t cnt = pd.cnt, nblk = pd.nblk;
+        const uint64_t first = pd.first;
+        const ChunkIn& in = pd.in;
+        const Workspace& Wgen = pd.Wgen;
         uint32_t totals[4];
         {
             Scope t(c, "scan", s);
@@ -441,6 +463,22 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
             launch_status_out(s, W, cnt, d_status, first);
         }
         cursor += (uint64_t)totals[2] | ((uint64_t)totals[3] << 32);
+    
+        return ZK_OK;
+    };
+    const uint64_t nchunks = (B + C - 1) / C;
+    Pending pend[2];
+    for (uint64_t k = 0; k < nchunks; k++) {
+        if (k == 0 || !dual) {
+            zs = stage1(k * C, (uint32_t)k, pend[k & 1]);
+            if (zs) return zs;
+        }
+        if (dual && k + 1 < nchunks) {
+            zs = stage1((k + 1) * C, (uint32_t)(k + 1), pend[(k + 1) & 1]);
+            if (zs) return zs;
+        }
+        zs = stage2(pend[k & 1]);
+        if (zs) return zs;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (dual) HIPCHK(c, hipStreamSynchronize(c->stream2));
