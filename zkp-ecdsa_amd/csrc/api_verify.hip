@@ -25,6 +25,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, uint8_t* base, uint32_t C, u
     auto soa4 = [&](size_t cnt) { return Soa4{k.soa(cnt), k.soa(cnt), k.soa(cnt), k.soa(cnt)}; };
     size_t nq = (n + 1) / 2;
     V.slot_terms = terms(ns * V_SLOT_TERMS);
+    V.slot_perm = (uint32_t*)k.take(4 * ns), V.slot_cnt = (uint32_t*)k.take(64);
     V.gk_terms = terms((size_t)C * nq * 8);
     V.misc_terms = terms((size_t)C * 3);
     V.slot_acc = soa4(ns), V.gk_acc = soa4((size_t)C * nq), V.misc_acc = soa4((size_t)C * 3);
@@ -149,9 +150,9 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
         }
         {
             Scope t(c, "v_straus_tom", s);
-            launch_v_straus(s, V.slot_terms, V.C * VK * V_SLOT_TERMS, cnt * VK, V.C * VK, 10, 26, V.slot_acc);
-            launch_v_straus(s, V.gk_terms, V.C * nq * 8, cnt * nq, V.C * nq, 4, 4, V.gk_acc);
-            launch_v_straus(s, V.misc_terms, 3 * V.C, 3 * V.C, 3 * V.C, 1, 0, V.misc_acc);
+            launch_v_straus(s, V.slot_terms, V.C * VK * V_SLOT_TERMS, cnt * VK, V.C * VK, 10, 26, V.slot_acc, V.slot_perm, V.slot_cnt);
+            launch_v_straus(s, V.gk_terms, V.C * nq * 8, cnt * nq, V.C * nq, 4, 4, V.gk_acc, nullptr, nullptr);
+            launch_v_straus(s, V.misc_terms, 3 * V.C, 3 * V.C, 3 * V.C, 1, 0, V.misc_acc, nullptr, nullptr);
         }
         {
             Scope t(c, "v_tom_fixed", s);

@@ -162,6 +162,8 @@ struct VWork {
     uint32_t* gk_swap;    // [n*C] 1 where g_j = 0 (x = f_j): the level keeps the odd branch, scale f_j
     Soa gk_total;         // [C]
     VTerms slot_terms, gk_terms, misc_terms;
+    uint32_t* slot_perm;  // [C*VK] slot ids, zero-bit slots (36 live terms) from the front, the others (2 live terms) from the back
+    uint32_t* slot_cnt;   // [2] how many of each
     Soa4 slot_acc, gk_acc, misc_acc;
     Soa sSg, sSh, sSkx, sSky, sSR, sSH, sSL;   // per slot partial sums
     Soa pSR, pSH, pSL;                         // per proof (mod n)
@@ -178,7 +180,8 @@ void launch_v_derived(hipStream_t s, const Workspace& W, const VWork& V, uint32_
 void launch_v_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, uint32_t count, uint32_t N, const uint8_t* proofs, const uint64_t* off, uint64_t first, const Soa& res, const Soa& res2);
 void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first);
-void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t nterms, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out);
+void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t nterms, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out,
+                     const uint32_t* perm, const uint32_t* cnt);
 void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count);
 void launch_v_final(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first);
 

@@ -700,6 +700,9 @@ __global__ void __launch_bounds__(64) k_v_slot_terms(Workspace W, VWork V, uint3
     }
     soa_st(V.sSg, sl, Sg), soa_st(V.sSh, sl, Sh), soa_st(V.sSkx, sl, Skx), soa_st(V.sSky, sl, Sky);
     soa_st(V.sSR, sl, SR), soa_st(V.sSH, sl, SH), soa_st(V.sSL, sl, SL);
+    // slot classes for k_v_straus: a zero-bit rep has 36 live terms, every other slot only terms 34, 35 (128-bit)
+    if (good && !bit) V.slot_perm[atomicAdd(&V.slot_cnt[0], 1u)] = sl;
+    else V.slot_perm[count * VK - 1 - atomicAdd(&V.slot_cnt[1], 1u)] = sl;
 }
 // one thread per proof: GK relations (gk.ts:223-259) -> groups of the gk list (4 per pair of bit positions: cl, cd 256-bit;
 // ca, cb 128-bit) and the per-proof totals for the shared points.
@@ -785,6 +788,7 @@ ZK_DEV void st_tab(const VTerms& L, uint32_t e, uint32_t idx, const TomPt& a) {
 __global__ void __launch_bounds__(256) k_v_term_tables(VTerms L, uint32_t nterms) {
     uint32_t idx = gtid();
     if (idx >= nterms) return;
+    if (fe_is_zero(soa_ld<ModQ, 1>(L.sc, idx))) return;  // null term: every digit is 0 and its table is never used
     TomPt p;
     p.x = soa_ld<ModT, 2>(L.nx, idx), p.y = soa_ld<ModT, 2>(L.ny, idx);
     p.t = p.x * p.y, p.z = fe_one_mont<ModT>().as<2>();
@@ -810,18 +814,26 @@ ZK_DEV TomPt tom_add_tab(const TomPt& p, const Ft2& x2, const Ft2& y2, const Ft2
     r.x = E * F, r.y = G * H, r.t = E * H, r.z = F * G;
     return r;
 }
-__global__ void __launch_bounds__(256) k_v_straus(VTerms L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, Soa4 out) {
-    uint32_t g = gtid();
-    if (g >= ngroups) return;
+// Lane i works on group perm[i] (identity without perm).  Lanes below cnt[0] are full groups: terms [0, n256) have 256-bit
+// scalars (windows 85..0), terms [n256, n256 + n128) 128-bit scalars (windows 42..0).  The remaining lanes (slots of
+// one-bit repetitions or of rejected proofs) only own the last two 128-bit terms, so they start at window 42 and add
+// two entries per window; sorting the slots keeps waves homogeneous.
+__global__ void __launch_bounds__(256) k_v_straus(VTerms L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, Soa4 out,
+                                                  const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cnt) {
+    uint32_t lane = gtid();
+    if (lane >= ngroups) return;
+    const uint32_t g = perm ? perm[lane] : lane;
+    const bool full = !perm || lane < cnt[0];
     TomPt acc = tom_identity();
-    uint32_t nt = n256 + n128;
+    const uint32_t nt = n256 + n128;
+    const uint32_t klo = full ? 0 : nt - 2;
 #pragma unroll 1
-    for (int w = 85; w >= 0; w--) {
+    for (int w = full && n256 ? 85 : 42; w >= 0; w--) {
         acc = tom_dbl(tom_dbl(tom_dbl(acc)));
         uint32_t kmax = w >= 43 ? n256 : nt;
         uint32_t limb_i = (uint32_t)w / 10, sh = 3 * ((uint32_t)w % 10);
 #pragma unroll 1
-        for (uint32_t k = 0; k < kmax; k++) {
+        for (uint32_t k = klo; k < kmax; k++) {
             uint32_t idx = k * ng_stride + g;
             uint32_t limb = L.sc.p[(size_t)limb_i * L.sc.stride + idx];
             uint32_t d = (limb >> sh) & 7;
@@ -843,10 +855,11 @@ __global__ void __launch_bounds__(256) k_v_straus(VTerms L, uint32_t ngroups, ui
     }
     soa_st(out.x, g, acc.x), soa_st(out.y, g, acc.y), soa_st(out.z, g, acc.z), soa_st(out.t, g, acc.t);
 }
-void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t nterms, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out) {
+void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t nterms, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out,
+                     const uint32_t* perm, const uint32_t* cnt) {
     if (!ngroups) return;
     hipLaunchKernelGGL(k_v_term_tables, dim3((nterms + 255) / 256), dim3(256), 0, s, L, nterms);
-    hipLaunchKernelGGL(k_v_straus, dim3((ngroups + 255) / 256), dim3(256), 0, s, L, ngroups, ng_stride, n256, n128, out);
+    hipLaunchKernelGGL(k_v_straus, dim3((ngroups + 255) / 256), dim3(256), 0, s, L, ngroups, ng_stride, n256, n128, out, perm, cnt);
 }
 // P-256: 5 A-terms per thread (128-bit randomisers), complete formulas
 __global__ void __launch_bounds__(256) k_v_p256_straus(VWork V, uint32_t count) {
@@ -995,6 +1008,7 @@ void launch_v_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, c
     L1(k_v_padd_hash, count * VK * 6, 256, P, W, V, count, proofs, off, first);
 }
 void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
+    hipMemsetAsync(V.slot_cnt, 0, 8, s);
     L1(k_v_slot_terms, count * VK, 64, W, V, count, proofs, off, vseeds, first);
     L1(k_v_proof_terms, count, 64, W, V, count, proofs, off, vseeds, first);
 }
