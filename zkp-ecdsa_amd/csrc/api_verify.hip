@@ -17,6 +17,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, uint8_t* base, uint32_t C, u
     V.vd = k.list(ns * 5);
     V.gk_f = k.soa((size_t)n * C), V.gk_g = k.soa((size_t)n * C);
     V.gk_total = k.soa(C);
+    V.gk_csub = (uint32_t*)k.take(n >= GK_ETAB_MINN && n <= GK_ETAB_MAXN ? 36 * 256 * (size_t)C : 16);
     V.gk_swap = (uint32_t*)k.take(4 * (size_t)n * C);
     auto terms = [&](size_t cnt) {
         VTerms t{k.soa(cnt), k.soa(cnt), k.soa(cnt), k.soa(cnt), (uint32_t*)k.take(cnt * 7 * 36 * 4)};
@@ -34,7 +35,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, uint8_t* base, uint32_t C, u
     V.pa_x = k.soa(ns), V.pa_y = k.soa(ns), V.pa_sc = k.soa(ns);
     V.pacc = k.soa3((size_t)C * 4);
     V.clx = k.soa(C), V.cly = k.soa(C);
-    uint32_t T = std::min<uint32_t>(n, 13);
+    uint32_t T = n >= GK_ETAB_MINN && n <= GK_ETAB_MAXN ? 8 : std::min<uint32_t>(n, 13);  // block path: one value per 256 keys
     res = k.soa((size_t)C * (N >> T));
     res2 = k.soa((size_t)C * std::max<uint64_t>(1, (N >> T) / 1024));
     return k.off + 256;
@@ -142,7 +143,7 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
         }
         {
             Scope t(c, "v_gk_total", s);
-            launch_v_gk_total(s, V, W.ring, cnt, W.N, d_proofs, d_off, first, vres, vres2);
+            launch_v_gk_total(s, V, W.ring, W.gk_etab, cnt, W.N, d_proofs, d_off, first, vres, vres2);
         }
         {
             Scope t(c, "v_terms", s);

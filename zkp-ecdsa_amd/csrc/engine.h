@@ -161,6 +161,7 @@ struct VWork {
     Soa gk_f, gk_g;       // [n*C] rho_j = f_j/g_j and the level's scale factor g_j (Montgomery); see k_v_gk_fg
     uint32_t* gk_swap;    // [n*C] 1 where g_j = 0 (x = f_j): the level keeps the odd branch, scale f_j
     Soa gk_total;         // [C]
+    uint32_t* gk_csub;    // [C][256][9] coefficients of the 8 low index bits (k_gk.hip, used when the ring has table E)
     VTerms slot_terms, gk_terms, misc_terms;
     uint32_t* slot_perm;  // [C*VK] slot ids, zero-bit slots (36 live terms) from the front, the others (2 live terms) from the back
     uint32_t* slot_cnt;   // [2] how many of each
@@ -178,7 +179,7 @@ void launch_v_exp_points(hipStream_t s, const Workspace& W, const VWork& V, uint
 void launch_v_t1_scalars(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_derived(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
-void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, uint32_t count, uint32_t N, const uint8_t* proofs, const uint64_t* off, uint64_t first, const Soa& res, const Soa& res2);
+void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, const uint32_t* etab, uint32_t count, uint32_t N, const uint8_t* proofs, const uint64_t* off, uint64_t first, const Soa& res, const Soa& res2);
 void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first);
 void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t nterms, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out,
                      const uint32_t* perm, const uint32_t* cnt);
@@ -208,6 +209,8 @@ static inline uint32_t gk_finish_gsz(uint32_t T, uint32_t ntiles) {
 size_t gk_etab_words(uint64_t N);
 void launch_gk_etab(hipStream_t s, const Soa& ring, uint32_t nblocks, uint32_t* E);
 void launch_gk_block_stage(hipStream_t s, const Workspace& W, const ChunkIn& in, const Soa& am, const Soa& res);
+struct VWork;
+void launch_v_gk_block_stage(hipStream_t s, const VWork& V, const uint32_t* E, uint32_t nblocks, uint32_t count, uint32_t* csub, const Soa& res);
 // k_tables.hip
 void launch_build_tom_table(hipStream_t s, const uint32_t* aff_xy_words /*18 words on device*/, uint32_t bits, uint32_t* tab, uint32_t* scratch, int32_t* ok);
 size_t tom_table_scratch_words(uint32_t bits);

@@ -264,3 +264,68 @@ void launch_gk_block_stage(hipStream_t s, const Workspace& W, const ChunkIn& in,
     if (uni) hipLaunchKernelGGL(k_gk_block<true>, dim3(grid), dim3(256), 0, s, W, in, W.gk_etab, W.gk_asub, W.gk_order, W.gk_goff, nblocks, nwg, res);
     else hipLaunchKernelGGL(k_gk_block<false>, dim3(grid), dim3(256), 0, s, W, in, W.gk_etab, W.gk_asub, W.gk_order, W.gk_goff, nblocks, nwg, res);
 }
+
+// ---------------------------------------------------------------- verifier: total = sum_i key_i prod_j f_{j,i_j}(x)  (gk.ts:239-250)
+// In the ratio form of k_verify.hip -- (x - f_j) ev + f_j od = g_j (ev + rho_j od), the g_j applied once at the end --
+// the 8 low index bits of a block contribute  sum_{i < 256} c_i key_{block,i},  c_i = prod_{j < 8, bit j of i set} rho_j
+// (a level with g_j = 0 keeps only its odd branch: factor 1 for a set bit, 0 for a clear one).  The coefficients are the
+// same for every block of a proof, and the keys of one index i across blocks are the rank-255 (S = {}) row of slice
+// l_low = i of table E, i.e. the ring transposed to [i][limb][block]: 256 multiply-accumulates and ONE reduction per
+// block instead of 255 modular multiplications, coalesced across lanes, coefficients in SGPRs.
+__global__ void __launch_bounds__(256) k_v_gk_csub(VWork V, uint32_t count, uint32_t* csub) {
+    uint32_t t = gtid();
+    if (t >= count * GKB_SIZE) return;
+    uint32_t p = t >> 8, i = t & 255;
+    Fe<ModQ, 2> acc = fe_one_mont<ModQ>().as<2>();
+    bool zero = false;
+    for (uint32_t j = 0; j < GKB_BITS; j++) {
+        bool swap = V.gk_swap[j * V.C + p] != 0, set = (i >> j) & 1;
+        if (swap) zero = zero || !set;
+        else if (set) acc = acc * soa_ld<ModQ, 2>(V.gk_f, j * V.C + p);
+    }
+    Fe<ModQ, 1> c = zero ? fe_zero<ModQ>() : fe_canon(acc);
+    uint32_t o[9];
+    limbs_repack<30, 29, 9, 9>(o, c.l);
+#pragma unroll
+    for (int l = 0; l < 9; l++) csub[(size_t)t * 9 + l] = o[l];
+}
+template <bool UNI>
+__global__ void __launch_bounds__(256) k_v_gk_block(uint32_t count, const uint32_t* __restrict__ E, const uint32_t* __restrict__ csub, uint32_t nblocks, Soa res) {
+    uint32_t p, block;
+    if (UNI) {
+        uint32_t nbg = nblocks >> 8;
+        p = blockIdx.x / nbg;
+        block = (blockIdx.x % nbg) * 256 + threadIdx.x;
+    } else {
+        uint32_t slot = blockIdx.x * 256 + threadIdx.x;
+        if (slot >= count * nblocks) return;
+        p = slot / nblocks, block = slot % nblocks;
+    }
+    const uint32_t* a = csub + (size_t)p * GKB_SIZE * 9;
+    const uint32_t* e = E + ((size_t)255 * 9) * nblocks + block;  // rank 255 = S {} of slice i: key[block * 256 + i]
+    const size_t slice = (size_t)GKB_SIZE * 9 * nblocks;
+    GkCols acc;
+    gkc_zero(acc);
+#pragma unroll 1
+    for (uint32_t ib = 0; ib < GKB_SIZE; ib += 7) {
+        uint32_t ie = ib + 7 < GKB_SIZE ? ib + 7 : GKB_SIZE;
+#pragma unroll 1
+        for (uint32_t i = ib; i < ie; i++) {
+            uint32_t x[9], y[9];
+#pragma unroll
+            for (int l = 0; l < 9; l++) x[l] = a[i * 9 + l], y[l] = e[i * slice + (size_t)l * nblocks];
+            gkc_mac(acc, x, y);
+        }
+        gkc_carry(acc);
+    }
+    uint32_t t29[18], t30[18];
+#pragma unroll
+    for (int i = 0; i < 18; i++) t29[i] = (uint32_t)acc.c[i];
+    limbs_repack<29, 30, 18, 18>(t30, t29);
+    soa_st(res, p * nblocks + block, fe_canon(redc_wide(t30)));
+}
+void launch_v_gk_block_stage(hipStream_t s, const VWork& V, const uint32_t* E, uint32_t nblocks, uint32_t count, uint32_t* csub, const Soa& res) {
+    hipLaunchKernelGGL(k_v_gk_csub, dim3(count), dim3(256), 0, s, V, count, csub);
+    if ((nblocks & 255) == 0) hipLaunchKernelGGL(k_v_gk_block<true>, dim3(count * (nblocks >> 8)), dim3(256), 0, s, count, E, csub, nblocks, res);
+    else hipLaunchKernelGGL(k_v_gk_block<false>, dim3((uint32_t)(((uint64_t)count * nblocks + 255) / 256)), dim3(256), 0, s, count, E, csub, nblocks, res);
+}
