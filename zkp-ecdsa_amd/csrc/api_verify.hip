@@ -20,7 +20,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, uint8_t* base, uint32_t C, u
     V.gk_csub = (uint32_t*)k.take(n >= GK_ETAB_MINN && n <= GK_ETAB_MAXN ? 36 * 256 * (size_t)C : 16);
     V.gk_swap = (uint32_t*)k.take(4 * (size_t)n * C);
     auto terms = [&](size_t cnt) {
-        VTerms t{k.soa(cnt), k.soa(cnt), k.soa(cnt), k.soa(cnt), (uint32_t*)k.take(cnt * 7 * 36 * 4)};
+        VTerms t{k.soa(cnt), k.soa(cnt), k.soa(cnt), k.soa(cnt), (uint32_t*)k.take(cnt * 8 * 36 * 4), (uint8_t*)k.take(cnt * 65), (uint32_t)cnt};
         return t;
     };
     auto soa4 = [&](size_t cnt) { return Soa4{k.soa(cnt), k.soa(cnt), k.soa(cnt), k.soa(cnt)}; };

@@ -144,7 +144,9 @@ struct Soa4 {
 };
 struct VTerms {           // terms of the "sum s_i P_i = identity" checks: niels point on the a=1 image + plain scalar
     Soa nx, ny, ndt, sc;
-    uint32_t* tab;        // window tables, AoS: multiples 1..7 of term idx, 36 words (X, Y, d'T, Z) each, at tab[(idx*7 + e)*36]
+    uint32_t* tab;        // window tables, AoS: multiples 1..8 of term idx, 36 words (X, Y, d'T, Z) each, at tab[(idx*8 + e)*36]
+    uint8_t* dig;         // signed 4-bit digits of the scalars: dig[w * cap + idx] = |d| (0..8) | sign << 7, w = 0..64
+    uint32_t cap;         // terms the arrays were carved for
 };
 struct VWork {
     uint32_t C, sec, n;

@@ -770,12 +770,14 @@ __global__ void __launch_bounds__(64) k_v_proof_terms(Workspace W, VWork V, uint
 }
 
 // ------------------------------------------------------------------ windowed Straus over a group of terms
-// Per term a table {1P..7P} (extended coordinates with d'*T premultiplied) is built once; the group's lane then runs
-// 86 windows of 3 bits: 3 shared doublings + one table addition per term (9 modmuls), 43 windows for 128-bit terms.
-// Digits never straddle limbs (30 = 10 x 3).
-#define VW_BITS 3
-#define VW_ENT 7
-// table storage is AoS: entry e of term idx = 36 contiguous words (X, Y, d'T, Z) at tab[(idx*7 + e)*36], so that a lane's
+// Scalars are recoded into SIGNED 4-bit digits (65 windows for a 256-bit scalar, 33 for a 128-bit one, digits in
+// [-7, 8]); per term a table {1P..8P} (extended coordinates with d'*T premultiplied) is built once.  The group's lane
+// then runs the windows top down: 4 shared doublings + one table addition per term (9 modmuls); a negative digit
+// negates X and d'T of the entry on load.  (Unsigned 3-bit windows needed 86 / 43 additions per term.)
+#define VW_ENT 8
+#define VW_NW256 65
+#define VW_NW128 33
+// table storage is AoS: entry e of term idx = 36 contiguous words (X, Y, d'T, Z) at tab[(idx*8 + e)*36], so that a lane's
 // digit-dependent lookup is one contiguous 144-byte read
 ZK_DEV void st_tab(const VTerms& L, uint32_t e, uint32_t idx, const TomPt& a) {
     uint4* q = (uint4*)(L.tab + ((size_t)idx * VW_ENT + e) * 36);
@@ -789,7 +791,20 @@ ZK_DEV void st_tab(const VTerms& L, uint32_t e, uint32_t idx, const TomPt& a) {
 __global__ void __launch_bounds__(256) k_v_term_tables(VTerms L, uint32_t nterms) {
     uint32_t idx = gtid();
     if (idx >= nterms) return;
-    if (fe_is_zero(soa_ld<ModQ, 1>(L.sc, idx))) return;  // null term: every digit is 0 and its table is never used
+    Sq sc = soa_ld<ModQ, 1>(L.sc, idx);
+    uint32_t kw[8];
+    words_from_limbs<8>(kw, sc.l);
+    uint32_t carry = 0;
+#pragma unroll 1
+    for (uint32_t w = 0; w < VW_NW256; w++) {  // signed recoding: d in [-7, 8]
+        uint32_t d = (kw[0] & 15) + carry;
+        shr256<4>(kw);
+        bool neg = d > 8;
+        carry = neg ? 1 : 0;
+        if (neg) d = 16 - d;
+        L.dig[(size_t)w * L.cap + idx] = (uint8_t)(d | (neg ? 0x80u : 0u));
+    }
+    if (fe_is_zero(sc)) return;  // null term: every digit is 0 and its table is never used
     TomPt p;
     p.x = soa_ld<ModT, 2>(L.nx, idx), p.y = soa_ld<ModT, 2>(L.ny, idx);
     p.t = p.x * p.y, p.z = fe_one_mont<ModT>().as<2>();
@@ -802,7 +817,8 @@ __global__ void __launch_bounds__(256) k_v_term_tables(VTerms L, uint32_t nterms
     }
 }
 // addition with a table entry (X2, Y2, d'T2, Z2): 9 modmuls
-ZK_DEV TomPt tom_add_tab(const TomPt& p, const Ft2& x2, const Ft2& y2, const Ft2& dt2, const Ft2& z2) {
+template <int KX>
+ZK_DEV TomPt tom_add_tab(const TomPt& p, const Fe<ModT, KX>& x2, const Ft2& y2, const Fe<ModT, KX>& dt2, const Ft2& z2) {
     auto A = p.x * x2;
     auto B = p.y * y2;
     auto C = p.t * dt2;
@@ -815,9 +831,17 @@ ZK_DEV TomPt tom_add_tab(const TomPt& p, const Ft2& x2, const Ft2& y2, const Ft2
     r.x = E * F, r.y = G * H, r.t = E * H, r.z = F * G;
     return r;
 }
+// -v for a coordinate < 2t: 4t - v < 4t ... kept below 4t, which the products of tom_add_tab accept (2 * 4 <= kmax)
+ZK_DEV Fe<ModT, 4> ft_neg_sel(const Ft2& v, bool neg) {
+    Fe<ModT, 4> r;
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) r.l[i] = neg ? ModT::sub4[i] - v.l[i] : v.l[i];
+    limbs_normalize(r.l);
+    return r;
+}
 // Lane i works on group perm[i] (identity without perm).  Lanes below cnt[0] are full groups: terms [0, n256) have 256-bit
-// scalars (windows 85..0), terms [n256, n256 + n128) 128-bit scalars (windows 42..0).  The remaining lanes (slots of
-// one-bit repetitions or of rejected proofs) only own the last two 128-bit terms, so they start at window 42 and add
+// scalars (windows 64..0), terms [n256, n256 + n128) 128-bit scalars (windows 32..0).  The remaining lanes (slots of
+// one-bit repetitions or of rejected proofs) only own the last two 128-bit terms, so they start at window 32 and add
 // two entries per window; sorting the slots keeps waves homogeneous.
 __global__ void __launch_bounds__(256) k_v_straus(VTerms L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, Soa4 out,
                                                   const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cnt) {
@@ -829,15 +853,15 @@ __global__ void __launch_bounds__(256) k_v_straus(VTerms L, uint32_t ngroups, ui
     const uint32_t nt = n256 + n128;
     const uint32_t klo = full ? 0 : nt - 2;
 #pragma unroll 1
-    for (int w = full && n256 ? 85 : 42; w >= 0; w--) {
-        acc = tom_dbl(tom_dbl(tom_dbl(acc)));
-        uint32_t kmax = w >= 43 ? n256 : nt;
-        uint32_t limb_i = (uint32_t)w / 10, sh = 3 * ((uint32_t)w % 10);
+    for (int w = full && n256 ? VW_NW256 - 1 : VW_NW128 - 1; w >= 0; w--) {
+        acc = tom_dbl(tom_dbl(tom_dbl(tom_dbl(acc))));
+        uint32_t kmax = w >= VW_NW128 ? n256 : nt;
 #pragma unroll 1
         for (uint32_t k = klo; k < kmax; k++) {
             uint32_t idx = k * ng_stride + g;
-            uint32_t limb = L.sc.p[(size_t)limb_i * L.sc.stride + idx];
-            uint32_t d = (limb >> sh) & 7;
+            uint32_t db = L.dig[(size_t)w * L.cap + idx];
+            uint32_t d = db & 15;
+            bool neg = (db & 0x80u) != 0;
             const uint4* q = (const uint4*)(L.tab + ((size_t)idx * VW_ENT + (d ? d - 1 : 0)) * 36);
             uint32_t tw[36];
 #pragma unroll
@@ -848,7 +872,7 @@ __global__ void __launch_bounds__(256) k_v_straus(VTerms L, uint32_t ngroups, ui
             Ft2 x2, y2, dt2, z2;
 #pragma unroll
             for (int l = 0; l < 9; l++) x2.l[l] = tw[l], y2.l[l] = tw[9 + l], dt2.l[l] = tw[18 + l], z2.l[l] = tw[27 + l];
-            TomPt s = tom_add_tab(acc, x2, y2, dt2, z2);
+            TomPt s = tom_add_tab(acc, ft_neg_sel(x2, neg), y2, ft_neg_sel(dt2, neg), z2);
             bool on = d != 0;
             acc.x = fe_select(on, s.x, acc.x), acc.y = fe_select(on, s.y, acc.y);
             acc.t = fe_select(on, s.t, acc.t), acc.z = fe_select(on, s.z, acc.z);
