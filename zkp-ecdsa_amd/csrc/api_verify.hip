@@ -13,6 +13,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, uint8_t* base, uint32_t C, u
     V.gkx = (uint32_t*)k.take(12 * (size_t)C);
     size_t ns = (size_t)C * VK;
     V.idx = (uint32_t*)k.take(4 * ns);
+    V.vbytes = (uint8_t*)k.take(1536 * (size_t)C);
     V.vc = (uint32_t*)k.take(4 * 18 * ns);
     V.vd = k.list(ns * 5);
     V.gk_f = k.soa((size_t)n * C), V.gk_g = k.soa((size_t)n * C);
@@ -33,6 +34,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, uint8_t* base, uint32_t C, u
     V.sSg = k.soa(ns), V.sSh = k.soa(ns), V.sSkx = k.soa(ns), V.sSky = k.soa(ns), V.sSR = k.soa(ns), V.sSH = k.soa(ns), V.sSL = k.soa(ns);
     V.pSR = k.soa(C), V.pSH = k.soa(C), V.pSL = k.soa(C);
     V.pa_x = k.soa(ns), V.pa_y = k.soa(ns), V.pa_sc = k.soa(ns);
+    V.pa_tab = (uint32_t*)k.take(ns * 8 * RTAB_ENTRY_WORDS * 4), V.pa_dig = (uint8_t*)k.take(ns * 33);
     V.pacc = k.soa3((size_t)C * 4);
     V.clx = k.soa(C), V.cly = k.soa(C);
     uint32_t T = n >= GK_ETAB_MINN && n <= GK_ETAB_MAXN ? 8 : std::min<uint32_t>(n, 13);  // block path: one value per 256 keys

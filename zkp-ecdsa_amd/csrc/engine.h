@@ -158,6 +158,7 @@ struct VWork {
     uint32_t* chal;       // [C][4] recomputed Exp challenge
     uint32_t* gkx;        // [C][3]
     uint32_t* idx;        // [C][VK] checked rep index | bit << 8
+    uint8_t* vbytes;      // [1536][C] first byte of the verifier-RNG fills (k_v_sample_fills)
     uint32_t* vc;         // [C*VK][6][3] sub-proof challenges
     TomList vd;           // [C*VK*5] derived commitments (proj + affine)
     Soa gk_f, gk_g;       // [n*C] rho_j = f_j/g_j and the level's scale factor g_j (Montgomery); see k_v_gk_fg
@@ -171,6 +172,8 @@ struct VWork {
     Soa sSg, sSh, sSkx, sSky, sSR, sSH, sSL;   // per slot partial sums
     Soa pSR, pSH, pSL;                         // per proof (mod n)
     Soa pa_x, pa_y, pa_sc;                     // P-256 A terms [C*VK]
+    uint32_t* pa_tab;                          // [C*VK][8][28] multiples 1..8 of every A term (k_v_p256_straus)
+    uint8_t* pa_dig;                           // [33][C*VK] signed 4-bit digits of the randomisers
     Soa3 pacc;                                 // [C*4]
     Soa clx, cly;                              // Clambda (Montgomery affine)
 };

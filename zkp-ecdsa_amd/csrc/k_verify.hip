@@ -95,31 +95,40 @@ __global__ void __launch_bounds__(256) k_v_header(VWork V, uint32_t count, const
 #pragma unroll
     for (int i = 0; i < 4; i++) V.hbits[4 * p + i] = bits[i];
 }
-// every point of the proof must deserialise (on curve, coordinates in range): thread (proof, rep) and one extra for
-// the fixed part + GK section
+// every point of the proof must deserialise (on curve, coordinates in range).  One thread per POINT SLOT, P-256 slots
+// first (R, comS1, A_i), then the Tom-256 slots (keyXcom, keyYcom, 4n GK points and per repetition Tx, Ty + the 32
+// PointAdd points, which exist only for zero bits): consecutive lanes check consecutive strings of one kind, every lane
+// does the same amount of work and the branchy part only selects an ADDRESS (one copy of each curve check per wave).
+#define V_REP_TOM_SLOTS 34
 __global__ void __launch_bounds__(256) k_v_validate(VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
-    uint32_t t = gtid(), per = V.sec + 1;
-    if (t >= count * per) return;
-    uint32_t p = t / per, j = t % per;
+    const uint32_t np = 2 + V.sec, nt = 2 + 4 * V.n + V_REP_TOM_SLOTS * V.sec, per = np + nt;
+    uint32_t blocks_per_proof = (per + 255) / 256;           // a workgroup never straddles two proofs
+    uint32_t p = blockIdx.x / blocks_per_proof, m = (blockIdx.x % blocks_per_proof) * 256 + threadIdx.x;
+    if (p >= count || m >= per) return;
     if (V.st[p] != ZK_OK || (V.okflags[p] & 8)) return;
     const uint8_t* pr = proofs + off[first + p];
     const uint32_t* hb = V.hbits + 4 * p;
-    bool ok = true;
-    if (j == V.sec) {
-        ok = p256_bytes_valid(pr + 32) && p256_bytes_valid(pr + 96) && tom_bytes_valid(pr + 160) && tom_bytes_valid(pr + 232);
-        const uint8_t* gk = v_gk_base(V, pr, p);
-        for (uint32_t k = 0; k < 4 * V.n; k++) ok = ok && tom_bytes_valid(gk + 72 * k);
+    const uint8_t* ptr;
+    const bool is_p = m < np;
+    if (is_p) {
+        ptr = m < 2 ? pr + 32 + 64 * m : pr + rep_offset(hb, m - 2);
     } else {
-        const uint8_t* rep = pr + rep_offset(hb, j);
-        ok = p256_bytes_valid(rep) && tom_bytes_valid(rep + 64) && tom_bytes_valid(rep + 136);
-        if (!((hb[j >> 5] >> (j & 31)) & 1)) {
-            const uint8_t* pa = rep + ZK_REP_HEAD;
-            for (uint32_t k = 0; k < 4; k++) ok = ok && tom_bytes_valid(pa + 72 * k);
-            for (uint32_t m = 0; m < 4; m++)
-                for (uint32_t k = 0; k < 6; k++) ok = ok && tom_bytes_valid(pa + 288 + 656 * m + 72 * k);
-            for (uint32_t k = 0; k < 2; k++) ok = ok && tom_bytes_valid(pa + 2912 + 72 * k) && tom_bytes_valid(pa + 3152 + 72 * k);
+        uint32_t u = m - np;
+        if (u < 2) ptr = pr + 160 + 72 * u;
+        else if (u < 2 + 4 * V.n) ptr = v_gk_base(V, pr, p) + 72 * (u - 2);
+        else {
+            uint32_t r = u - (2 + 4 * V.n), j = r / V_REP_TOM_SLOTS, k = r % V_REP_TOM_SLOTS;
+            bool one = (hb[j >> 5] >> (j & 31)) & 1;
+            if (k >= 2 && one) return;  // response1 has no PointAdd proof
+            const uint8_t* rep = pr + rep_offset(hb, j);
+            uint32_t q = k - 2;  // 0..3 C8..C13, 4..27 the six points of the four MultProofs, 28..31 A_1, A_2 of pi_x, pi_y
+            if (k < 2) ptr = rep + 64 + 72 * k;
+            else if (q < 4) ptr = rep + ZK_REP_HEAD + 72 * q;
+            else if (q < 28) ptr = rep + ZK_REP_HEAD + 288 + 656 * ((q - 4) / 6) + 72 * ((q - 4) % 6);
+            else ptr = rep + ZK_REP_HEAD + (q < 30 ? 2912 : 3152) + 72 * (q & 1);
         }
     }
+    bool ok = is_p ? p256_bytes_valid(ptr) : tom_bytes_valid(ptr);
     if (!ok) atomicCAS(&V.st[p], ZK_OK, ZK_E_BAD_ENCODING);
 }
 
@@ -253,6 +262,19 @@ ZK_DEV void v_rho_pair(const uint8_t* vseeds, uint64_t gp, uint32_t idx, Sq& a, 
     limbs_from_words<8>(a.l, wa);
     limbs_from_words<8>(b.l, wb);
 }
+// generateIndices draws one byte per attempt and keeps it only if it is below the shrinking range (rndRange with rejection,
+// big.ts:171-181): about 256 * (H_80 - H_2) = 890 fills per proof, i.e. 890 SHA-256 blocks in sequence if computed on demand.
+// They do not depend on each other, so the first VS_KMAX fills of every proof are hashed in parallel here and k_v_sample
+// only walks the stored bytes (falling back to hashing on demand past VS_KMAX).
+#define VS_KMAX 1536
+__global__ void __launch_bounds__(256) k_v_sample_fills(VWork V, uint32_t count, const uint8_t* vseeds, uint64_t first) {
+    uint32_t t = gtid();
+    if (t >= count * VS_KMAX) return;
+    uint32_t k = t / count, p = t % count;
+    uint32_t w[8];
+    v_fill(vseeds, first + p, k, w);
+    V.vbytes[(size_t)k * V.C + p] = (uint8_t)(w[7] >> 24);
+}
 // generateIndices (exp.ts:95-109): runs after verifyMembership's 2n+1 randomScalar draws (gk.ts:223-259)
 __global__ void __launch_bounds__(64) k_v_sample(VWork V, uint32_t count, const uint8_t* vseeds, uint64_t first) {
     uint32_t p = gtid();
@@ -269,8 +291,12 @@ __global__ void __launch_bounds__(64) k_v_sample(VWork V, uint32_t count, const 
     for (uint32_t i = 0; i + 2 < V.sec; i++) {
         uint32_t range = V.sec - i, v;
         do {
-            v_fill(vseeds, gp, k++, w);
-            v = w[7] >> 24;  // first byte of the fill
+            if (k < VS_KMAX) v = V.vbytes[(size_t)k * V.C + p];
+            else {
+                v_fill(vseeds, gp, k, w);
+                v = w[7] >> 24;  // first byte of the fill
+            }
+            k++;
         } while (v >= range);
         uint8_t t = perm[i];
         perm[i] = perm[i + v], perm[i + v] = t;
@@ -886,24 +912,54 @@ void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t nterms, uint32_t n
     hipLaunchKernelGGL(k_v_term_tables, dim3((nterms + 255) / 256), dim3(256), 0, s, L, nterms);
     hipLaunchKernelGGL(k_v_straus, dim3((ngroups + 255) / 256), dim3(256), 0, s, L, ngroups, ng_stride, n256, n128, out, perm, cnt);
 }
-// P-256: 5 A-terms per thread (128-bit randomisers), complete formulas
+// P-256: sum of rho_j * (-A_j) over the 20 checked repetitions, 5 terms per thread, 128-bit randomisers.  Signed 4-bit
+// windows like the Tom side: every thread first recodes its scalars (33 digits in [-7, 8]) and builds {1A..8A} for its
+// terms in global memory (projective, rtab.h entry format), then runs 33 windows of 4 doublings + 5 complete additions
+// (the bit-serial version computed 128 doublings + 640 additions per thread).
+#define VP_NW 33
 __global__ void __launch_bounds__(256) k_v_p256_straus(VWork V, uint32_t count) {
     uint32_t t = gtid();
     if (t >= count * 4) return;
     uint32_t p = t / 4, q = t % 4;
+    const uint32_t cap = V.C * VK;
+#pragma unroll 1
+    for (uint32_t k = 0; k < 5; k++) {
+        uint32_t idx = p * VK + q * 5 + k;
+        uint32_t kw[8];
+        words_from_limbs<8>(kw, soa_ld<ModN, 1>(V.pa_sc, idx).l);
+        uint32_t carry = 0;
+#pragma unroll 1
+        for (uint32_t w = 0; w < VP_NW; w++) {
+            uint32_t d = (kw[0] & 15) + carry;
+            shr256<4>(kw);
+            bool neg = d > 8;
+            carry = neg ? 1 : 0;
+            if (neg) d = 16 - d;
+            V.pa_dig[(size_t)w * cap + idx] = (uint8_t)(d | (neg ? 0x80u : 0u));
+        }
+        P256Aff a;
+        a.x = soa_ld<ModQ, 2>(V.pa_x, idx), a.y = soa_ld<ModQ, 2>(V.pa_y, idx);
+        P256Pt b = p256_from_affine(a), m = b;
+        uint32_t* e = V.pa_tab + (size_t)idx * 8 * RTAB_ENTRY_WORDS;
+        st_rtab(e, m);
+#pragma unroll 1
+        for (uint32_t d = 1; d < 8; d++) {
+            m = d == 1 ? p256_dbl(b) : p256_add(m, b);
+            st_rtab(e + d * RTAB_ENTRY_WORDS, m);
+        }
+    }
     P256Pt acc = p256_identity();
 #pragma unroll 1
-    for (int b = 127; b >= 0; b--) {
-        acc = p256_dbl(acc);
+    for (int w = VP_NW - 1; w >= 0; w--) {
+        acc = p256_dbl(p256_dbl(p256_dbl(p256_dbl(acc))));
 #pragma unroll 1
         for (uint32_t k = 0; k < 5; k++) {
             uint32_t idx = p * VK + q * 5 + k;
-            uint32_t limb = V.pa_sc.p[(size_t)(b / 30) * V.pa_sc.stride + idx];
-            bool bit = (limb >> (b % 30)) & 1;
-            P256Aff a;
-            a.x = soa_ld<ModQ, 2>(V.pa_x, idx), a.y = soa_ld<ModQ, 2>(V.pa_y, idx);
-            P256Pt s = p256_add_mixed(acc, a);
-            acc = p256_select(bit, s, acc);
+            uint32_t db = V.pa_dig[(size_t)w * cap + idx], d = db & 15;
+            P256Pt e = ld_rtab(V.pa_tab + ((size_t)idx * 8 + (d ? d - 1 : 0)) * RTAB_ENTRY_WORDS);
+            e.y = fe_select((db & 0x80u) != 0, fq8_neg(e.y), e.y);
+            P256Pt s = p256_add(acc, e);
+            acc = p256_select(d != 0, s, acc);
         }
     }
     soa_st(V.pacc.x, t, acc.x), soa_st(V.pacc.y, t, acc.y), soa_st(V.pacc.z, t, acc.z);
@@ -1010,7 +1066,10 @@ __global__ void k_v_clambda(VWork V, uint32_t count, const uint8_t* proofs, cons
 #define L1(kern, n, bs, ...) hipLaunchKernelGGL(kern, dim3(((n) + (bs)-1) / (bs)), dim3(bs), 0, s, __VA_ARGS__)
 void launch_v_header_validate(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
     L1(k_v_header, count, 256, V, count, proofs, off, first);
-    L1(k_v_validate, count * (V.sec + 1), 256, V, count, proofs, off, first);
+    {
+        uint32_t per = 2 + V.sec + 2 + 4 * V.n + V_REP_TOM_SLOTS * V.sec;
+        hipLaunchKernelGGL(k_v_validate, dim3(count * ((per + 255) / 256)), dim3(256), 0, s, V, count, proofs, off, first);
+    }
 }
 void launch_v_front(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* msg, uint64_t first) {
     L1(k_v_front, count, 64, P, W, V, count, proofs, off, msg, first);
@@ -1018,6 +1077,7 @@ void launch_v_front(hipStream_t s, const DevParams& P, const Workspace& W, const
 }
 void launch_v_challenges_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
     L1(k_v_challenges, count, 64, V, count, proofs, off, first);
+    L1(k_v_sample_fills, count * VS_KMAX, 256, V, count, vseeds, first);
     L1(k_v_sample, count, 64, V, count, vseeds, first);
 }
 void launch_v_exp_points(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
