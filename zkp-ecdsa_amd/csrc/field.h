@@ -2,9 +2,10 @@
 //
 // Representation: 9 limbs of 30 bits in 32-bit VGPRs ("radix 2^30"), Montgomery domain with R = 2^270, for all
 // three moduli on the hot path (Tom-256 field t [258 bit], P-256 field q = Tom scalar field, P-256 order n).
-// Why 30-bit limbs: measured on MI355X (profiles/r01_valu_peak_microbench.txt) v_mad_u64_u32 issues in ~10
-// cycles/wave and a carry-chained v_add_co/v_addc pair in ~8.7; with 30-bit limbs every column of the product
-// (<= 18 partial products < 2^60) fits ONE 64-bit accumulator, so a Montgomery multiplication is 162
+// Why 30-bit limbs: measured on MI355X (profiles/r01_valu_peak_microbench.txt) v_mad_u64_u32 issues every 4.3 cycles per
+// wave at full ILP (15.5 cycles dependent latency), the same slot a 64-bit shift or add costs, and a carry out of the
+// 64-bit accumulator would cost a second instruction per product; with 30-bit limbs every column of the product
+// (<= 18 partial products < 2^60) fits ONE 64-bit accumulator, so a Montgomery multiplication is at most 162
 // v_mad_u64_u32 + 9 v_mul_lo_u32 with no carry flags at all, and additions are plain limb-wise v_add_u32.
 //
 // Magnitudes are tracked in the TYPE: Fe<M, K> holds a normalised value (every limb < 2^30) that is < K*M.

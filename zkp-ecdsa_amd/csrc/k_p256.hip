@@ -2,9 +2,9 @@
 //
 // Reference call sites (src/zkpAttestList.ts:104-145, src/exp/exp.ts:144-156,186-193): every scalar multiplication
 // there is the window-4 Point.mul of src/curves/group.ts:133-152 (4448 modmuls).  Only affine results are
-// observable, so the engine uses: fixed-base combs for G and h_NIST (32 mixed complete additions), and a
-// per-proof 4-bit comb table of R = paramsSigExp.g, shared by the 2*sec+1 multiplications by R of one proof
-// (64 complete additions each).  All additions are the complete RCB formulas the reference uses.
+// observable, so the engine uses: 16-bit fixed-base combs for G and h_NIST (16 mixed complete additions), and a
+// per-proof signed-digit comb table of R = paramsSigExp.g (rtab.h), shared by the sec+1 multiplications by R of one
+// proof (43 complete additions each).  All additions are the complete RCB formulas the reference uses.
 #include "rtab.h"
 
 ZK_DEV P256Aff ld_pfix(const uint32_t* e) {

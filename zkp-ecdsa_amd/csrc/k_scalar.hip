@@ -465,8 +465,8 @@ void launch_gk_respond(hipStream_t s, const Workspace& W, const ChunkIn& in, uin
     uint32_t n = in.count * 4 * W.n;
     hipLaunchKernelGGL(k_write_gk_points, dim3((n + 255) / 256), dim3(256), 0, s, W, in.count, out);
 }
-// ---- fused fold: a tile of 2^T ring elements per workgroup.  Levels 0..2 run in registers (8 elements per lane),
-// levels 3..T-1 run coefficient-parallel through LDS (one output coefficient = one modmul per lane), so a whole
+// ---- plain fold (rings without table E, see k_gk.hip for the table path): a tile of 2^T ring elements per workgroup.
+// RL levels run depth-first in registers (2^RL elements per lane), the others coefficient-parallel through LDS (one output coefficient = one modmul per lane), so a whole
 // tile costs ~20 modmul latencies instead of one kernel launch per level.  LDS planes are limb-major (conflict-free).
 #define GK_TMAX 12   // 256 lanes x 16 elements
 struct LdsPlane {
