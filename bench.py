@@ -248,9 +248,11 @@ def main():
         # executed additions: 2 * nwin per commitment, except the 6 pairs per PointAdd item that share v*g (3 * nwin per pair)
         nwin = (256 + args.comb_bits - 1) // args.comb_bits
         adds = (commits_per_step - 34 * zeros_total) * 2 * nwin + zeros_total * (22 * 2 + 6 * 3) * nwin
-        modmuls_per_commit = round(adds * 8 / commits_per_step, 2)
+        # 8 modmuls per addition; the first one of a comb is 1 (identity + entry), the last one 7 (no T coordinate)
+        modmuls = adds * 8 - (commits_per_step - 34 * zeros_total) * 8 - zeros_total * (22 * 8 + 6 * 9)
+        modmuls_per_commit = round(modmuls / commits_per_step, 2)
         pmc_bytes = TOM_COMMIT_PMC_BYTES.get(args.comb_bits)
-        macs = adds * 8 * MACS_PER_MODMUL
+        macs = modmuls * MACS_PER_MODMUL
         achieved_tmacs = macs / (tom_ms * 1e-3) / 1e12 if tom_ms > 0 else 0.0
         hbm_gbps = commits_per_step * TOM_COMMIT_BYTES / (tom_ms * 1e-3) / 1e9 if tom_ms > 0 else 0.0
         wt, wq, wring = nominal_modmuls(n_log2)

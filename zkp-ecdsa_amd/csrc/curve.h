@@ -178,6 +178,30 @@ ZK_DEV TomPt tom_add_niels(const TomPt& p, const TomNiels& q) {
     r.z = F * G;
     return r;
 }
+// the same addition when the result only has to be ADDED TO NOTHING ELSE (last step of a comb): no T3, 7M
+ZK_DEV TomPt tom_add_niels_last(const TomPt& p, const TomNiels& q) {
+    auto A = p.x * q.x;
+    auto B = p.y * q.y;
+    auto C = p.t * q.dt;
+    auto E = ((p.x + p.y) * (q.x + q.y) - A) - B;
+    auto F = p.z - C;
+    auto G = p.z + C;
+    auto H = B - A;
+    TomPt r;
+    r.x = E * F;
+    r.y = G * H;
+    r.t = fe_zero<ModT>().as<2>();
+    r.z = F * G;
+    return r;
+}
+// identity + q: the niels entry as an extended point (X, Y, T = XY, Z = 1), 1M instead of the 8M of an addition
+ZK_DEV TomPt tom_from_niels(const TomNiels& q) {
+    TomPt r;
+    r.x = q.x, r.y = q.y;
+    r.t = q.x * q.y;
+    r.z = fe_one_mont<ModT>().as<2>();
+    return r;
+}
 // general unified addition (both extended): 9M + 1 mult-by-d'
 ZK_DEV TomPt tom_add(const TomPt& p, const TomPt& q) {
     const auto d1 = fe_const<ModT, 1>(TOM_D1_M);

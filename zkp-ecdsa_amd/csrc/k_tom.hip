@@ -70,8 +70,8 @@ __global__ void __launch_bounds__(256, OCC) k_tom_commit(const uint32_t* __restr
             ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * (base + dv));
             nh = ld_niels(tab_h + (size_t)TOM_ENTRY_WORDS * (base + dr));
         }
-        acc = tom_add_niels(acc, cg);
-        acc = tom_add_niels(acc, ch);
+        acc = w == 0 ? tom_from_niels(cg) : tom_add_niels(acc, cg);                    // first step: identity + entry
+        acc = w + 1 == nwin ? tom_add_niels_last(acc, ch) : tom_add_niels(acc, ch);    // last step: nobody reads T
     }
     soa_st(L.proj.x, slot, acc.x);
     soa_st(L.proj.y, slot, acc.y);
@@ -83,7 +83,9 @@ __global__ void __launch_bounds__(256, OCC) k_tom_commit(const uint32_t* __restr
 // 3 * nwin additions instead of 4 * nwin (-8.8 % additions over the list).  Units 0..21 are the unpaired slots.
 #define LB_UNITS_SINGLE 22
 #define LB_UNITS_PAIR 6
-// acc += sum_w tab[w][digit_w(words)], gathers pipelined one window ahead
+// acc += sum_w tab[w][digit_w(words)], gathers pipelined one window ahead.  FIRST: acc is the identity (the first entry is
+// taken as is); LAST: the result is final (no T coordinate).
+template <bool FIRST, bool LAST>
 ZK_DEV TomPt tom_comb_acc(TomPt acc, const uint32_t* __restrict__ tab, uint32_t* words, uint32_t bits, uint32_t nwin) {
     const uint32_t mask = (1u << bits) - 1;
     uint32_t d = words[0] & mask;
@@ -97,7 +99,9 @@ ZK_DEV TomPt tom_comb_acc(TomPt acc, const uint32_t* __restrict__ tab, uint32_t*
             shr256_rt(words, bits);
             nx = ld_niels(tab + (size_t)TOM_ENTRY_WORDS * (((size_t)(w + 1) << bits) + d));
         }
-        acc = tom_add_niels(acc, cur);
+        if (FIRST && w == 0) acc = tom_from_niels(cur);
+        else if (LAST && w + 1 == nwin) acc = tom_add_niels_last(acc, cur);
+        else acc = tom_add_niels(acc, cur);
     }
     return acc;
 }
@@ -108,12 +112,12 @@ __global__ void __launch_bounds__(256, 2) k_tom_commit_pairs(const uint32_t* __r
     uint32_t slot0 = LB_PAIR_K[c / items] * kstride + c % items, slot1 = slot0 + kstride;
     uint32_t w8[8];
     words_from_limbs<8>(w8, soa_ld<ModQ, 1>(L.v, slot0).l);
-    TomPt G = tom_comb_acc(tom_identity(), tab_g, w8, bits, nwin);
+    TomPt G = tom_comb_acc<true, false>(tom_identity(), tab_g, w8, bits, nwin);
     words_from_limbs<8>(w8, soa_ld<ModQ, 1>(L.r, slot0).l);
-    TomPt A = tom_comb_acc(G, tab_h, w8, bits, nwin);
+    TomPt A = tom_comb_acc<false, true>(G, tab_h, w8, bits, nwin);
     soa_st(L.proj.x, slot0, A.x), soa_st(L.proj.y, slot0, A.y), soa_st(L.proj.z, slot0, A.z);
     words_from_limbs<8>(w8, soa_ld<ModQ, 1>(L.r, slot1).l);
-    A = tom_comb_acc(G, tab_h, w8, bits, nwin);
+    A = tom_comb_acc<false, true>(G, tab_h, w8, bits, nwin);
     soa_st(L.proj.x, slot1, A.x), soa_st(L.proj.y, slot1, A.y), soa_st(L.proj.z, slot1, A.z);
 }
 void launch_tom_commit_listb(hipStream_t s, const DevParams& P, const TomList& L, uint32_t items, uint32_t kstride) {
