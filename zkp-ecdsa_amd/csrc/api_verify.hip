@@ -39,7 +39,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, uint8_t* base, uint32_t C, u
     V.clx = k.soa(C), V.cly = k.soa(C);
     uint32_t T = n >= GK_ETAB_MINN && n <= GK_ETAB_MAXN ? 8 : std::min<uint32_t>(n, 13);  // block path: one value per 256 keys
     res = k.soa((size_t)C * (N >> T));
-    res2 = k.soa((size_t)C * std::max<uint64_t>(1, (N >> T) / 1024));
+    res2 = k.soa((size_t)C * std::max<uint64_t>(1, (N >> T) / 512));
     return k.off + 256;
 }
 static zk_status ensure_vworkspace(zk_ctx* c, uint32_t C, bool second_lane) {

@@ -533,13 +533,14 @@ __global__ void __launch_bounds__(256) k_v_gk_tile(VWork V, Soa ring, uint32_t T
         else soa_st(res, p * ntiles + tile, fe_canon(fe_reduce(r)));
     }
 }
-// finish pass: workgroup (proof, group) folds gsz <= 1024 consecutive tile values through log2(gsz) levels
-#define VGK_FIN 1024u
+// finish pass: workgroup (proof, group) folds gsz <= 512 consecutive tile values through log2(gsz) levels (dynamic LDS)
+#define VGK_FIN 512u
 __global__ void __launch_bounds__(256) k_v_gk_finish(VWork V, uint32_t Tin, uint32_t npoly, uint32_t gsz, Soa src, Soa dst) {
-    __shared__ uint32_t bufA[NLIMB * VGK_FIN];
-    __shared__ uint32_t bufB[NLIMB * VGK_FIN];
+    extern __shared__ uint32_t v_lds_dyn[];  // two planes of gsz elements (9 limbs each): sized by the launch
+    uint32_t* bufA = v_lds_dyn;
+    uint32_t* bufB = v_lds_dyn + NLIMB * gsz;
     uint32_t ngroups = npoly / gsz;
-    uint32_t p = blockIdx.x / ngroups, g = blockIdx.x % ngroups, stride = VGK_FIN;
+    uint32_t p = blockIdx.x / ngroups, g = blockIdx.x % ngroups, stride = gsz;
     for (uint32_t m = threadIdx.x; m < gsz; m += blockDim.x) {
         Sq c = soa_ld<ModQ, 1>(src, p * npoly + g * gsz + m);
         for (int l = 0; l < NLIMB; l++) bufA[l * stride + m] = c.l[l];
@@ -585,7 +586,7 @@ void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, const uin
     while (ntiles > 1) {
         uint32_t gsz = ntiles < VGK_FIN ? ntiles : VGK_FIN, ngroups = ntiles / gsz, lv = 0;
         while ((1u << lv) < gsz) lv++;
-        hipLaunchKernelGGL(k_v_gk_finish, dim3(count * ngroups), dim3(256), 0, s, V, T, ntiles, gsz, src, dst);
+        hipLaunchKernelGGL(k_v_gk_finish, dim3(count * ngroups), dim3(256), sizeof(uint32_t) * 2 * NLIMB * gsz, s, V, T, ntiles, gsz, src, dst);
         Soa tmp = src;
         src = dst, dst = tmp, T += lv, ntiles = ngroups;
     }
