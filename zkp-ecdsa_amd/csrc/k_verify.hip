@@ -815,7 +815,7 @@ ZK_DEV void st_tab(const VTerms& L, uint32_t e, uint32_t idx, const TomPt& a) {
 #pragma unroll
     for (int i = 0; i < 9; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
-__global__ void __launch_bounds__(256) k_v_term_tables(VTerms L, uint32_t nterms) {
+__global__ void __launch_bounds__(256, 2) k_v_term_tables(VTerms L, uint32_t nterms) {
     uint32_t idx = gtid();
     if (idx >= nterms) return;
     Sq sc = soa_ld<ModQ, 1>(L.sc, idx);
@@ -918,7 +918,7 @@ void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t nterms, uint32_t n
 // terms in global memory (projective, rtab.h entry format), then runs 33 windows of 4 doublings + 5 complete additions
 // (the bit-serial version computed 128 doublings + 640 additions per thread).
 #define VP_NW 33
-__global__ void __launch_bounds__(256) k_v_p256_straus(VWork V, uint32_t count) {
+__global__ void __launch_bounds__(256, 2) k_v_p256_straus(VWork V, uint32_t count) {
     uint32_t t = gtid();
     if (t >= count * 4) return;
     uint32_t p = t / 4, q = t % 4;
