@@ -175,3 +175,26 @@ def test_gk_table_path_equals_plain_fold_and_oracle(nkeys, B, chunk, monkeypatch
     assert est == [0] * k and got[:k] == exp
     assert eng.verify_batch(msg, got) == ([1] * B, [0] * B)
     eng.close(), plain.close()
+
+
+@pytest.mark.parametrize('sec,nkeys,B', [(1, 4, 3), (7, 5, 4), (33, 12, 3), (128, 9, 2), (96, 300, 2)])
+def test_security_levels_other_than_80(sec, nkeys, B):
+    """secLevel is a run-time parameter of the reference (SystemParametersList.SecLevel): repetition counts that are not a
+    multiple of 32, the maximum the 128-bit challenge allows, and a ring on the table path with a non-default level."""
+    eng, octx, (msg, sig, pk, which, seeds) = _setup(7000 + sec, nkeys, B, sec)
+    got, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    exp, est = octx.prove_batch(msg, sig, pk, which, seeds=seeds, nthreads=4)
+    assert st == est == [0] * B
+    assert got == exp
+    if sec >= 20:   # verifyExp needs secLevel >= 20 (zkpAttestList.ts:177); below that the reference throws
+        assert eng.verify_batch(msg, got) == octx.verify_batch(msg, got, nthreads=4)[:2] == ([1] * B, [0] * B)
+    else:
+        # 'security level not achieved' (exp.ts:244): the reference throws it per call once membership has passed; the
+        # engine refuses the whole batch up front (the level is a property of the context, not of a proof)
+        import zkp_ecdsa_amd as Z
+        with pytest.raises(Z.ZkError) as e:
+            eng.verify_batch(msg, got)
+        assert e.value.status == 9
+        ook, ovst = octx.verify_batch(msg, got, nthreads=4)[:2]
+        assert ook == [0] * B and ovst == [9] * B
+    eng.close()
