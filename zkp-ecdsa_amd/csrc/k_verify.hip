@@ -262,6 +262,18 @@ ZK_DEV void v_rho_pair(const uint8_t* vseeds, uint64_t gp, uint32_t idx, Sq& a, 
     limbs_from_words<8>(a.l, wa);
     limbs_from_words<8>(b.l, wb);
 }
+// randomisers r[FIRST .. FIRST + N) of slot `tag` (r[2k], r[2k+1] come from pair k): generated where they are used so
+// that only a handful are live at a time (all 26 at once cost 234 VGPRs and spilled)
+template <int FIRST, int N>
+ZK_DEV void v_rho_range(const uint8_t* vseeds, uint64_t gp, uint32_t tag, Sq* out) {
+#pragma unroll
+    for (int k = FIRST / 2; 2 * k < FIRST + N; k++) {
+        Sq a, b;
+        v_rho_pair(vseeds, gp, tag | (uint32_t)k, a, b);
+        if (2 * k >= FIRST) out[2 * k - FIRST] = a;
+        if (2 * k + 1 >= FIRST && 2 * k + 1 < FIRST + N) out[2 * k + 1 - FIRST] = b;
+    }
+}
 // generateIndices draws one byte per attempt and keeps it only if it is below the shrinking range (rndRange with rejection,
 // big.ts:171-181): about 256 * (H_80 - H_2) = 890 fills per proof, i.e. 890 SHA-256 blocks in sequence if computed on demand.
 // They do not depend on each other, so the first VS_KMAX fills of every proof are hashed in parallel here and k_v_sample
@@ -650,7 +662,7 @@ ZK_DEV void v_eq(const VTerms& L, uint32_t gidx, uint32_t ng, uint32_t i128, con
 // one thread per checked slot: all Tom terms of the slot (group gidx = slot), partial sums for shared points, and the
 // slot's P-256 contribution.  Layout of a slot group: 256-bit terms 0..9 = C8, C10, C11, C13, Tx, Ty, C4 x4;
 // 128-bit terms 10..35 = 4 x (Ax, Ay, Az, A41, A42), pix A1, A2, piy A1, A2, then Tx, Ty of a bit-1 slot.
-__global__ void __launch_bounds__(64) k_v_slot_terms(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
+__global__ void __launch_bounds__(64, 2) k_v_slot_terms(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
     uint32_t sl = gtid(), ng = V.C * VK;
     if (sl >= count * VK) return;
     uint32_t p = sl / VK, j = sl % VK;
@@ -670,12 +682,13 @@ __global__ void __launch_bounds__(64) k_v_slot_terms(Workspace W, VWork V, uint3
         uint64_t gp = first + p;
         uint32_t e = sl;
         Sq sx = soa_ld<ModQ, 1>(W.Tx, e), sy = soa_ld<ModQ, 1>(W.Ty, e);  // affine T (bit 1) or T1 + Q (bit 0)
-        Sq r[26];
-        for (uint32_t k = 0; k < 13; k++) v_rho_pair(vseeds, gp, (j << 8) | k, r[2 * k], r[2 * k + 1]);
+        const uint32_t tag = j << 8;
         // ---- P-256 relation (exp.ts:270-276 / 305-317) with randomiser r[24] (mod n): the T term is (rho * s) * R
         {
+            Sq r24[1];
+            v_rho_range<24, 1>(vseeds, gp, tag, r24);
             Sn rn;
-            for (int l = 0; l < NLIMB; l++) rn.l[l] = r[24].l[l];
+            for (int l = 0; l < NLIMB; l++) rn.l[l] = r24[0].l[l];
             Sn s0 = ld_scalar_n(rep + 208), s1 = ld_scalar_n(rep + 240);
             SR = fe_mul_mod(rn, s0);
             SH = fe_mul_mod(rn, s1);
@@ -691,6 +704,8 @@ __global__ void __launch_bounds__(64) k_v_slot_terms(Workspace W, VWork V, uint3
         if (bit) {
             // relTx, relTy (exp.ts:287-297): r0 (sx g + beta2 h - Tx), r1 (sy g + beta3 h - Ty)
             Sq b2 = ld_scalar_q(rep + 272), b3 = ld_scalar_q(rep + 304);
+            Sq r[2];
+            v_rho_range<0, 2>(vseeds, gp, tag, r);
             Sg = addq(mulq(r[0], sx), mulq(r[1], sy));
             Sh = addq(mulq(r[0], b2), mulq(r[1], b3));
             put_term_bytes(L, 34 * ng + sl, rep + 64, true, r[0]);
@@ -701,16 +716,23 @@ __global__ void __launch_bounds__(64) k_v_slot_terms(Workspace W, VWork V, uint3
             Sq c8 = chalq(cw), c10 = chalq(cw + 3), c11 = chalq(cw + 6), c13 = chalq(cw + 9), cx = chalq(cw + 12), cy = chalq(cw + 15);
             Sq w7 = zero, w8 = zero, w9 = zero, w10 = zero, w11 = zero, w12 = zero, w13 = zero, w14 = zero, wX = zero, wY = zero;
             // pointAdd.ts:215-255
-            v_mult(L, sl, ng, 6, 10, pa + 288, c8, r + 0, w7, w8, w14, Sg, Sh);                  // pi8 : (C7, C8, C14 = g)
-            v_mult(L, sl, ng, 7, 15, pa + 288 + 656, c10, r + 5, w8, w9, w10, Sg, Sh);           // pi10: (C8, C9, C10)
+            Sq r[5];
+            v_rho_range<0, 5>(vseeds, gp, tag, r);
+            v_mult(L, sl, ng, 6, 10, pa + 288, c8, r, w7, w8, w14, Sg, Sh);                      // pi8 : (C7, C8, C14 = g)
+            v_rho_range<5, 5>(vseeds, gp, tag, r);
+            v_mult(L, sl, ng, 7, 15, pa + 288 + 656, c10, r, w8, w9, w10, Sg, Sh);               // pi10: (C8, C9, C10)
             {                                                                                      // pi11: (C10, C10, C11)
                 Sq wa = zero, wb = zero;
-                v_mult(L, sl, ng, 8, 20, pa + 288 + 2 * 656, c11, r + 10, wa, wb, w11, Sg, Sh);
+                v_rho_range<10, 5>(vseeds, gp, tag, r);
+                v_mult(L, sl, ng, 8, 20, pa + 288 + 2 * 656, c11, r, wa, wb, w11, Sg, Sh);
                 w10 = addq(w10, addq(wa, wb));
             }
-            v_eq(L, sl, ng, 30, pa + 2912, cx, r + 15, w11, wX, Sg, Sh);                          // pix : (C11, C3 + C1 + C2)
-            v_mult(L, sl, ng, 9, 25, pa + 288 + 3 * 656, c13, r + 17, w10, w12, w13, Sg, Sh);    // pi13: (C10, C12, C13)
-            v_eq(L, sl, ng, 32, pa + 3152, cy, r + 22, w13, wY, Sg, Sh);                          // piy : (C13, C4 + C6)
+            v_rho_range<15, 2>(vseeds, gp, tag, r);
+            v_eq(L, sl, ng, 30, pa + 2912, cx, r, w11, wX, Sg, Sh);                               // pix : (C11, C3 + C1 + C2)
+            v_rho_range<17, 5>(vseeds, gp, tag, r);
+            v_mult(L, sl, ng, 9, 25, pa + 288 + 3 * 656, c13, r, w10, w12, w13, Sg, Sh);         // pi13: (C10, C12, C13)
+            v_rho_range<22, 2>(vseeds, gp, tag, r);
+            v_eq(L, sl, ng, 32, pa + 3152, cy, r, w13, wY, Sg, Sh);                               // piy : (C13, C4 + C6)
             // redistribute the derived commitments: C7 = Px - T1x, C9 = Py - T1y, C12 = T1x - Tx, CintX = Tx + T1x + Px,
             // CintY = T1y + Ty, C14 = g, T1x = sx g + r1 h, T1y = sy g + r2 h
             Sq r1 = ld_scalar_q(rep + 272), r2 = ld_scalar_q(rep + 304);
@@ -736,7 +758,7 @@ __global__ void __launch_bounds__(64) k_v_slot_terms(Workspace W, VWork V, uint3
 // ca, cb 128-bit) and the per-proof totals for the shared points.
 // gk group q (q < ceil(n/2)) holds i = 2q, 2q+1: 256-bit terms {cl_i, cd_i} x2 = 0..3, 128-bit {ca_i, cb_i} x2 = 4..7.
 // misc group (index = p): 256-bit terms: 0 = Px (membership coefficient), 1 = Px (Exp), 2 = Py (Exp).
-__global__ void __launch_bounds__(64) k_v_proof_terms(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
+__global__ void __launch_bounds__(64, 2) k_v_proof_terms(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
     uint32_t p = gtid();
     if (p >= count) return;
     uint32_t n = V.n, nq = (n + 1) / 2, ngk = V.C * nq, nm = V.C;
@@ -981,7 +1003,7 @@ ZK_DEV TomPt ld_tom_proj3(const Soa3& a, uint32_t e) {  // (X:Y:Z) without T -> 
 ZK_DEV bool tom_is_identity(const TomPt& a) {  // edwards.ts:117-125 on the a=1 image
     return fe_is_zero(a.x) && fe_eq(a.y, a.z) && !fe_is_zero(a.z);
 }
-__global__ void __launch_bounds__(64) k_v_final(DevParams P, Workspace W, VWork V, uint32_t count, uint8_t* ok_out, int32_t* status_out, uint64_t first) {
+__global__ void __launch_bounds__(64, 2) k_v_final(DevParams P, Workspace W, VWork V, uint32_t count, uint8_t* ok_out, int32_t* status_out, uint64_t first) {
     uint32_t p = gtid();
     if (p >= count) return;
     int32_t st = V.st[p];  // structural errors; W.st additionally carries a late "T is at infinity"
