@@ -83,6 +83,13 @@ zk_status zk_ctx_set_params(zk_ctx *ctx, const uint8_t nist_h[64], const uint8_t
 zk_status zk_ctx_set_ring(zk_ctx *ctx, const uint8_t *keys_be32, uint64_t n_keys);
 zk_status zk_ctx_set_ring_device(zk_ctx *ctx, const void *d_keys_be32, uint64_t n_keys);
 
+/* keyToInt (src/zkpAttestList.ts:94-102) for a whole key set: n_keys public keys as 64-byte affine (x, y) big-endian
+ * (the WebCrypto 'raw' export without its 0x04 prefix) -> n_keys 32-byte big-endian ring entries (the x coordinate,
+ * reduced mod p like toAffine does).  per_key_status[i] = ZK_E_POINT_NOT_IN_GROUP where deserializePoint would throw
+ * (src/curves/weier.ts:74-89: curve equation mod p, coordinates not range-checked); such entries are written as zero.
+ * Host pointers; the return value is ZK_OK even if some keys are bad (check the statuses). */
+zk_status zk_keys_to_ints(zk_ctx *ctx, uint64_t n_keys, const uint8_t *pk_xy64, uint8_t *keys_be32, int32_t *per_key_status);
+
 /* Proofs processed per pipeline pass (workspace grows linearly with it: about 0.9 MB per proof at secLevel 80).
  * Default 4096, maximum 2^18. */
 zk_status zk_ctx_set_chunk(zk_ctx *ctx, uint32_t proofs_per_chunk);

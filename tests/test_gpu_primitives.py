@@ -160,3 +160,31 @@ def test_tom_commit_every_comb_width(bits):
         with pytest.raises(Z.ZkError):
             e.set_comb_bits(bad)
     e.close()
+
+
+def test_keys_to_ints_is_keytoint(eng):
+    """keyToInt (zkpAttestList.ts:94-102) over a key set: x of every valid key, 'point not in group' for the others,
+    coordinates not range-checked (x + p deserialises like x, weier.ts:74-89)."""
+    import zkattest_ref as R
+    rnd = random.Random(99)
+    p = R.p256.p
+    keys, exp_x, exp_st = [], [], []
+    for i in range(40):
+        d = rnd.randrange(1, R.p256.order)
+        x, y = R.p256.generator().mul(R.p256.newScalar(d)).toAffine()
+        kind = i % 5
+        if kind == 1:
+            y ^= 1                                   # off the curve
+        if kind == 2 and x + p < (1 << 256):
+            x += p                                   # same residue, not range-checked
+        raw = x.to_bytes(32, 'big') + y.to_bytes(32, 'big')
+        keys.append(raw)
+        try:
+            exp_x.append(R.keyToInt(b'\x04' + raw))
+            exp_st.append(0)
+        except ValueError:
+            exp_x.append(0)
+            exp_st.append(1)
+    out, st = eng.keys_to_ints(b''.join(keys))
+    assert st == exp_st and 1 in st and 0 in st
+    assert [int.from_bytes(out[32 * i:32 * i + 32], 'big') for i in range(40)] == exp_x

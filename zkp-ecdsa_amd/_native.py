@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 # every symbol include/zkattest.h declares
 SYMBOLS = [
     'zk_ctx_create', 'zk_ctx_destroy', 'zk_strerror', 'zk_last_error', 'zk_ctx_set_params', 'zk_ctx_set_ring',
-    'zk_ctx_set_ring_device', 'zk_ctx_set_chunk', 'zk_ctx_set_lanes', 'zk_ctx_set_comb_bits', 'zk_proof_max_size', 'zk_prove_batch', 'zk_prove_batch_device',
+    'zk_ctx_set_ring_device', 'zk_keys_to_ints', 'zk_ctx_set_chunk', 'zk_ctx_set_lanes', 'zk_ctx_set_comb_bits', 'zk_proof_max_size', 'zk_prove_batch', 'zk_prove_batch_device',
     'zk_verify_batch', 'zk_verify_batch_device', 'zk_synth_workload', 'zk_synth_params', 'zk_last_timing',
     'zk_proof_to_json', 'zk_proof_from_json',
     'zk_test_field_op', 'zk_test_tom_commit', 'zk_test_p256_fixed_mul', 'zk_test_sha256', 'zk_test_rng_draws',
@@ -57,6 +57,7 @@ def lib():
         L.zk_ctx_set_params.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, u32]
         L.zk_ctx_set_ring.argtypes = [vp, C.c_char_p, u64]
         L.zk_ctx_set_ring_device.argtypes = [vp, vp, u64]
+        L.zk_keys_to_ints.argtypes = [vp, u64, C.c_char_p, vp, vp]
         L.zk_ctx_set_chunk.argtypes = [vp, u32]
         L.zk_ctx_set_lanes.argtypes = [vp, u32]
         L.zk_ctx_set_comb_bits.argtypes = [vp, u32]
@@ -153,6 +154,15 @@ class Engine:
         if nkeys is None:
             nkeys = len(keys_be32) // 32
         self._chk(self.L.zk_ctx_set_ring(self.h, keys_be32, nkeys))
+
+    def keys_to_ints(self, pk_xy64):
+        """keyToInt for n keys (64-byte affine each): (n x 32-byte big-endian ring entries, list of statuses)."""
+        pk_xy64 = bytes(pk_xy64)
+        n = len(pk_xy64) // 64
+        out = C.create_string_buffer(32 * n)
+        st = (C.c_int32 * n)()
+        self._chk(self.L.zk_keys_to_ints(self.h, n, pk_xy64, out, st))
+        return out.raw, list(st)
 
     def set_ring_device(self, dev_ptr, nkeys):
         self._chk(self.L.zk_ctx_set_ring_device(self.h, dev_ptr, nkeys))

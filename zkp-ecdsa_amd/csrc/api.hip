@@ -184,6 +184,22 @@ extern "C" zk_status zk_ctx_set_ring(zk_ctx* c, const uint8_t* keys, uint64_t nk
     hipFree(d);
     return s;
 }
+extern "C" zk_status zk_keys_to_ints(zk_ctx* c, uint64_t n, const uint8_t* pk, uint8_t* out, int32_t* st) {
+    if (!c || !pk || !out || !st || !n) return ZK_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint8_t *d_pk = nullptr, *d_out = nullptr;
+    int32_t* d_st = nullptr;
+    HIPCHK(c, hipMalloc(&d_pk, 64 * n));
+    HIPCHK(c, hipMalloc(&d_out, 32 * n));
+    HIPCHK(c, hipMalloc(&d_st, 4 * n));
+    HIPCHK(c, hipMemcpyAsync(d_pk, pk, 64 * n, hipMemcpyHostToDevice, c->stream));
+    launch_keys_to_ints(c->stream, d_pk, n, d_out, d_st);
+    HIPCHK(c, hipMemcpyAsync(out, d_out, 32 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(st, d_st, 4 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(d_pk), hipFree(d_out), hipFree(d_st);
+    return ZK_OK;
+}
 extern "C" zk_status zk_ctx_set_chunk(zk_ctx* c, uint32_t chunk) {
     if (!c || chunk == 0 || chunk > (1u << 18)) return ZK_E_ARG;
     c->chunk = chunk;

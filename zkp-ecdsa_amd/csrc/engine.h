@@ -255,6 +255,7 @@ void launch_gk_cd_scalars(hipStream_t s, const Workspace& W, uint32_t count);
 void launch_gk_respond(hipStream_t s, const Workspace& W, const ChunkIn& in, uint8_t* out);
 void launch_test_field(hipStream_t s, int which, int op, uint64_t count, const uint8_t* a, const uint8_t* b, uint8_t* out);
 void launch_ring_load(hipStream_t s, const uint8_t* d_keys_be32, uint64_t nkeys, uint64_t N, const Soa& ring);
+void launch_keys_to_ints(hipStream_t s, const uint8_t* d_pk, uint64_t count, uint8_t* d_out, int32_t* d_st);
 void launch_bytes_to_scalars(hipStream_t s, const uint8_t* d_be32, uint64_t count, const Soa& out);
 void launch_affine_to_bytes(hipStream_t s, const Soa& ax, const Soa& ay, uint64_t count, int tom, uint8_t* d_out);
 

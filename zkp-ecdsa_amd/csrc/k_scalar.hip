@@ -661,6 +661,24 @@ __global__ void k_ring_load(const uint8_t* keys, uint64_t nkeys, uint64_t N, Soa
 void launch_ring_load(hipStream_t s, const uint8_t* d_keys, uint64_t nkeys, uint64_t N, const Soa& ring) {
     hipLaunchKernelGGL(k_ring_load, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, s, d_keys, nkeys, N, ring);
 }
+// keyToInt (zkpAttestList.ts:94-102): deserializePoint's curve check (weier.ts:74-89, mod p, no range check) + affine x
+__global__ void k_keys_to_ints(const uint8_t* pk, uint64_t count, uint8_t* out, int32_t* st) {
+    uint64_t i = gtid();
+    if (i >= count) return;
+    uint32_t xw[8], yw[8];
+    load_be32(pk + 64 * i, xw);
+    load_be32(pk + 64 * i + 32, yw);
+    Sq x = fe_from_words256_reduce<ModQ>(xw);
+    P256Aff a;
+    a.x = fe_to_mont(x);
+    a.y = fe_to_mont(fe_from_words256_reduce<ModQ>(yw));
+    bool ok = p256_on_curve(a);
+    st[i] = ok ? ZK_OK : ZK_E_POINT_NOT_IN_GROUP;
+    store_scalar_be(out + 32 * i, ok ? x : fe_zero<ModQ>());
+}
+void launch_keys_to_ints(hipStream_t s, const uint8_t* d_pk, uint64_t count, uint8_t* d_out, int32_t* d_st) {
+    hipLaunchKernelGGL(k_keys_to_ints, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, s, d_pk, count, d_out, d_st);
+}
 __global__ void k_bytes_to_scalars(const uint8_t* be, uint64_t count, Soa out) {
     uint64_t i = gtid();
     if (i >= count) return;
