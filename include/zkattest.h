@@ -105,6 +105,12 @@ zk_status zk_ctx_set_lanes(zk_ctx *ctx, uint32_t lanes);
  * ZKATTEST_COMB_BITS sets the default of new contexts. */
 zk_status zk_ctx_set_comb_bits(zk_ctx *ctx, uint32_t bits);
 
+/* Verifier strategy for the Tom-256 relations (default on): the relations of ALL proofs of a chunk are checked with one
+ * bucket-method multi-scalar sum (independent 128-bit multipliers per relation and per proof); only when that sum is not
+ * the identity -- some proof of the chunk is bad -- the per-proof sums run to tell which.  ok[] and the statuses are the same
+ * either way; a chunk containing a bad proof costs about twice as much.  0 = always per proof.  (ZKATTEST_VERIFY_BATCH) */
+zk_status zk_ctx_set_batch_verify(zk_ctx *ctx, int on);
+
 /* Upper bound of one proof's ZKA1 size for the current params/ring. */
 uint64_t zk_proof_max_size(const zk_ctx *ctx);
 
@@ -129,7 +135,9 @@ zk_status zk_prove_batch_device(zk_ctx *ctx, uint64_t B, const void *d_msg_hash,
  * RNG: verifier fill k = SHA-256(seed_b || be64(k)), randomScalar() consumes a 32-byte fill, rnd(small) the first
  * byte of a fill; fills are consumed in the reference's order (2n+1 randomScalar draws of verifyMembership, then
  * generateIndices).  The random multipliers of Relation.drain (src/curves/multimult.ts:168-173) do not influence the
- * boolean; the engine draws its own 128-bit ones.  NULL seeds: derived from (b, msgHash_b).
+ * boolean; the engine draws its own 128-bit ones (from the same seed).  The seeds must be unpredictable to whoever made
+ * the proofs and independent across proofs.  NULL: the engine draws fresh OS randomness for the call (what the
+ * reference does with crypto.getRandomValues); pass seeds only to reproduce a run.
  * proofs must be packed back to back (proof_off[0] = 0, 4-byte aligned).  Host pointers. */
 zk_status zk_verify_batch(zk_ctx *ctx, uint64_t B, const uint8_t *msg_hash /*Bx32*/, const uint8_t *proofs,
                           const uint64_t *proof_off /*B+1*/, const uint8_t *verifier_seeds /*Bx32 or NULL*/,

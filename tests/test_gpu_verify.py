@@ -143,3 +143,30 @@ def test_json_wire_round_trip_then_verify():
     assert g == o
     assert g[0] == [1, 0, 0] and g[1][1] == 0 and g[1][2] != 0
     eng.close()
+
+
+def test_batched_and_per_proof_verification_agree():
+    """zk_ctx_set_batch_verify: the chunk-wide bucket-method check (k_msm.hip) and the per-proof sums give the same verdicts and
+    statuses -- all-honest chunks (fast path), chunks with a forged proof (fallback), ragged chunks, one and two lanes."""
+    eng, octx, msg, proofs = _setup(606, 12, 10)
+    vs = _vseeds(10)
+    bad = bytearray(proofs[7])
+    bad[-1] ^= 1                                  # zd
+    forged = proofs[:7] + [bytes(bad)] + proofs[8:]
+    exp_ok = {True: ([1] * 10, [0] * 10), False: ([1] * 7 + [0] + [1] * 2, [0] * 10)}
+    for chunk in (10, 4):
+        eng.set_chunk(chunk)
+        for lanes in (1, 2):
+            eng.set_lanes(lanes)
+            for on in (True, False):
+                eng.set_batch_verify(on)
+                assert eng.verify_batch(msg, proofs, vseeds=vs) == exp_ok[True], (chunk, lanes, on)
+                fam = eng.last_timing()[1]
+                # an all-honest batch must be settled by the chunk-wide sum alone (no silent fallback)
+                assert ('v_msm_tom' in fam) == on and ('v_straus_tom' in fam) == (not on), (fam, on)
+                assert eng.verify_batch(msg, forged, vseeds=vs) == exp_ok[False], (chunk, lanes, on)
+                fam = eng.last_timing()[1]
+                assert 'v_straus_tom' in fam
+                assert eng.verify_batch(msg, proofs) == exp_ok[True]       # OS-random seeds
+    assert octx.verify_batch(msg, forged, nthreads=8, vseeds=vs) == exp_ok[False]
+    eng.close()

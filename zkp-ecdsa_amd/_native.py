@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 # every symbol include/zkattest.h declares
 SYMBOLS = [
     'zk_ctx_create', 'zk_ctx_destroy', 'zk_strerror', 'zk_last_error', 'zk_ctx_set_params', 'zk_ctx_set_ring',
-    'zk_ctx_set_ring_device', 'zk_keys_to_ints', 'zk_ctx_set_chunk', 'zk_ctx_set_lanes', 'zk_ctx_set_comb_bits', 'zk_proof_max_size', 'zk_prove_batch', 'zk_prove_batch_device',
+    'zk_ctx_set_ring_device', 'zk_keys_to_ints', 'zk_ctx_set_chunk', 'zk_ctx_set_lanes', 'zk_ctx_set_comb_bits', 'zk_ctx_set_batch_verify', 'zk_proof_max_size', 'zk_prove_batch', 'zk_prove_batch_device',
     'zk_verify_batch', 'zk_verify_batch_device', 'zk_synth_workload', 'zk_synth_params', 'zk_last_timing',
     'zk_proof_to_json', 'zk_proof_from_json',
     'zk_test_field_op', 'zk_test_tom_commit', 'zk_test_p256_fixed_mul', 'zk_test_sha256', 'zk_test_rng_draws',
@@ -61,6 +61,7 @@ def lib():
         L.zk_ctx_set_chunk.argtypes = [vp, u32]
         L.zk_ctx_set_lanes.argtypes = [vp, u32]
         L.zk_ctx_set_comb_bits.argtypes = [vp, u32]
+        L.zk_ctx_set_batch_verify.argtypes = [vp, i32]
         L.zk_proof_max_size.argtypes = [vp]
         L.zk_proof_max_size.restype = u64
         L.zk_prove_batch.argtypes = [vp, u64, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(ZkRng), vp, u64, vp, vp]
@@ -176,6 +177,10 @@ class Engine:
     def set_comb_bits(self, bits):
         """Comb width of the Tom-256 fixed-base tables (8..24); call before set_params."""
         self._chk(self.L.zk_ctx_set_comb_bits(self.h, bits))
+
+    def set_batch_verify(self, on):
+        """Chunk-wide bucket-method check of the Tom-256 relations first (default), per-proof sums only on failure."""
+        self._chk(self.L.zk_ctx_set_batch_verify(self.h, 1 if on else 0))
 
     def proof_max_size(self):
         return self.L.zk_proof_max_size(self.h)

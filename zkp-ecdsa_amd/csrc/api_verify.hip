@@ -1,7 +1,7 @@
 // zk_verify_batch / zk_verify_batch_device: host-side phase pipeline of the verifier (kernels in k_verify.hip).
 #include "ctx.h"
 
-static size_t vcarve(VWork& V, Soa& res, Soa& res2, uint8_t* base, uint32_t C, uint32_t sec, uint32_t n, uint64_t N) {
+static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, uint32_t C, uint32_t sec, uint32_t n, uint64_t N) {
     Carver k(base);
     V.C = C, V.sec = sec, V.n = n;
     V.st = (int32_t*)k.take(4 * (size_t)C);
@@ -37,6 +37,22 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, uint8_t* base, uint32_t C, u
     V.pa_tab = (uint32_t*)k.take(ns * 8 * RTAB_ENTRY_WORDS * 4), V.pa_dig = (uint8_t*)k.take(ns * 33);
     V.pacc = k.soa3((size_t)C * 4);
     V.clx = k.soa(C), V.cly = k.soa(C);
+    {   // batched Tom check (k_msm.hip)
+        size_t cap = ns * V_SLOT_TERMS + (size_t)C * nq * 8 + (size_t)C * 3;
+        M.cap = (uint32_t)cap;
+        M.aos = (uint32_t*)k.take(cap * 128);
+        M.keys_all = (uint32_t*)k.take(cap * 4 * 16), M.vals_in = (uint32_t*)k.take(cap * 4), M.keys_out = (uint32_t*)k.take(cap * 4);
+        M.vals_out = (uint32_t*)k.take(cap * 4 * 16);
+        M.start = (uint32_t*)k.take(4 * 16 * 65536), M.end = (uint32_t*)k.take(4 * 16 * 65536);
+        M.counters = (uint32_t*)k.take(256), M.flag = (uint32_t*)k.take(256), M.big_list = (uint32_t*)k.take(4 * 4096);
+        M.buckets = (uint32_t*)k.take((size_t)16 * 65536 * 144);
+        M.F1 = (uint32_t*)k.take((size_t)16 * 1024 * 144), M.G1 = (uint32_t*)k.take((size_t)16 * 1024 * 144);
+        M.F2 = (uint32_t*)k.take(16 * 32 * 144), M.G2 = (uint32_t*)k.take(16 * 32 * 144), M.H2 = (uint32_t*)k.take(16 * 32 * 144);
+        M.Tw = (uint32_t*)k.take(16 * 144);
+        M.sort_tmp_bytes = msm_workspace_bytes((uint32_t)cap);
+        M.sort_tmp = k.take(M.sort_tmp_bytes);
+        M.one = k.list(1);
+    }
     uint32_t T = n >= GK_ETAB_MINN && n <= GK_ETAB_MAXN ? 8 : std::min<uint32_t>(n, 13);  // block path: one value per 256 keys
     res = k.soa((size_t)C * (N >> T));
     res2 = k.soa((size_t)C * std::max<uint64_t>(1, (N >> T) / 512));
@@ -45,38 +61,47 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, uint8_t* base, uint32_t C, u
 static zk_status ensure_vworkspace(zk_ctx* c, uint32_t C, bool second_lane) {
     uint32_t sec = c->P.sec, n = c->n;
     if (!(c->varena && c->vs_C == C && c->vs_sec == sec && c->vs_n == n)) {
-        size_t need = vcarve(c->V, c->v_res, c->v_res2, nullptr, C, sec, n, c->N);
+        size_t need = vcarve(c->V, c->v_res, c->v_res2, c->M, nullptr, C, sec, n, c->N);
         if (need > c->varena_bytes) {
             if (c->varena) HIPCHK(c, hipFree(c->varena));
             c->varena = nullptr, c->varena_bytes = 0;
             HIPCHK(c, hipMalloc(&c->varena, need));
             c->varena_bytes = need;
         }
-        vcarve(c->V, c->v_res, c->v_res2, (uint8_t*)c->varena, C, sec, n, c->N);
+        vcarve(c->V, c->v_res, c->v_res2, c->M, (uint8_t*)c->varena, C, sec, n, c->N);
         c->vs_C = C, c->vs_sec = sec, c->vs_n = n;
         c->vlane2_ready = false;
     }
     if (second_lane && !c->vlane2_ready) {
-        size_t need = vcarve(c->V2, c->v2_res, c->v2_res2, nullptr, C, sec, n, c->N);
+        size_t need = vcarve(c->V2, c->v2_res, c->v2_res2, c->M2, nullptr, C, sec, n, c->N);
         if (need > c->varena2_bytes) {
             if (c->varena2) HIPCHK(c, hipFree(c->varena2));
             c->varena2 = nullptr, c->varena2_bytes = 0;
             HIPCHK(c, hipMalloc(&c->varena2, need));
             c->varena2_bytes = need;
         }
-        vcarve(c->V2, c->v2_res, c->v2_res2, (uint8_t*)c->varena2, C, sec, n, c->N);
+        vcarve(c->V2, c->v2_res, c->v2_res2, c->M2, (uint8_t*)c->varena2, C, sec, n, c->N);
         c->vlane2_ready = true;
     }
     return ZK_OK;
 }
 
-__global__ void k_default_vseeds(uint64_t B, const uint8_t* msg, uint8_t* out) {
-    // default verifier seeds when the caller supplies none: SHA-256("zkv" || be64(b) || msgHash_b)
+static bool os_random(uint8_t* out, size_t n) {
+    FILE* f = fopen("/dev/urandom", "rb");
+    if (!f) return false;
+    size_t got = fread(out, 1, n, f);
+    fclose(f);
+    return got == n;
+}
+__global__ void k_default_vseeds(uint64_t B, const uint8_t* master, uint8_t* out) {
+    // verifier seeds when the caller supplies none: SHA-256("zkv\x01" || be64(b) || master), master = 32 bytes of OS
+    // randomness drawn for this call (the reference's verifier draws from crypto.getRandomValues: the checked subset and the
+    // multipliers must not be predictable from public data)
     uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (b >= B) return;
     uint32_t m[16], h[8];
     m[0] = 0x7a6b7600u | 0x01, m[1] = (uint32_t)(b >> 32), m[2] = (uint32_t)b;
-    const uint32_t* q = (const uint32_t*)(msg + 32 * b);
+    const uint32_t* q = (const uint32_t*)master;
     for (int i = 0; i < 8; i++) m[3 + i] = bswap32(q[i]);
     m[11] = 0x80000000u, m[12] = 0, m[13] = 0, m[14] = 0, m[15] = 44 * 8;
     sha256_iv(h);
@@ -99,13 +124,21 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
     timing_begin(c);
     uint8_t* own_seeds = nullptr;
     if (!d_vseeds) {
-        HIPCHK(c, hipMalloc(&own_seeds, 32 * B));
-        hipLaunchKernelGGL(k_default_vseeds, dim3((uint32_t)((B + 255) / 256)), dim3(256), 0, c->stream, B, d_msg, own_seeds);
+        uint8_t master[32];
+        if (!os_random(master, sizeof master)) {
+            c->err = "no OS randomness for the verifier (getrandom / /dev/urandom failed)";
+            return ZK_E_DEVICE;
+        }
+        HIPCHK(c, hipMalloc(&own_seeds, 32 * B + 32));
+        HIPCHK(c, hipMemcpyAsync(own_seeds + 32 * B, master, 32, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_default_vseeds, dim3((uint32_t)((B + 255) / 256)), dim3(256), 0, c->stream, B, own_seeds + 32 * B, own_seeds);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         d_vseeds = own_seeds;
     }
-    uint32_t nq = (c->n + 1) / 2, chunk_no = 0;
-    for (uint64_t first = 0; first < B; first += C, chunk_no++) {
+    const uint32_t nq = (c->n + 1) / 2;
+    // Stage 1 (everything up to the term lists) of chunk k+1 is enqueued on the other stream before the host blocks on the
+    // batched Tom check of chunk k (k_msm.hip reads counters and the verdict back), so neither stream runs dry.
+    auto stage1 = [&](uint64_t first, uint32_t chunk_no) -> zk_status {
         const bool lane2 = dual && (chunk_no & 1);
         Workspace& W = lane2 ? c->W2 : c->W;
         VWork& V = lane2 ? c->V2 : c->V;
@@ -152,23 +185,58 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
             launch_v_terms(s, W, V, cnt, d_proofs, d_off, d_vseeds, first);
         }
         {
-            Scope t(c, "v_straus_tom", s);
-            launch_v_straus(s, V.slot_terms, V.C * VK * V_SLOT_TERMS, cnt * VK, V.C * VK, 10, 26, V.slot_acc, V.slot_perm, V.slot_cnt);
-            launch_v_straus(s, V.gk_terms, V.C * nq * 8, cnt * nq, V.C * nq, 4, 4, V.gk_acc, nullptr, nullptr);
-            launch_v_straus(s, V.misc_terms, 3 * V.C, 3 * V.C, 3 * V.C, 1, 0, V.misc_acc, nullptr, nullptr);
-        }
-        {
-            Scope t(c, "v_tom_fixed", s);
-            launch_tom_commit(s, P, W.lc, cnt * 2, 2, 4 * W.n);
-        }
-        {
             Scope t(c, "v_straus_p256", s);
             launch_v_p256_straus(s, V, cnt);
         }
+        return ZK_OK;
+    };
+    auto stage2 = [&](uint64_t first, uint32_t chunk_no) -> zk_status {
+        const bool lane2 = dual && (chunk_no & 1);
+        Workspace& W = lane2 ? c->W2 : c->W;
+        VWork& V = lane2 ? c->V2 : c->V;
+        hipStream_t s = lane2 ? c->stream2 : c->stream;
+        uint32_t cnt = (uint32_t)std::min<uint64_t>(C, B - first);
+        // Tom-256 relations: one bucket-method sum over the whole chunk; only if that is not the identity (some proof is
+        // bad) the per-proof windowed sums run to find out which
+        uint32_t all_ok = 0;
+        if (c->verify_batched) {
+            Scope t(c, "v_msm_tom", s);
+            hipError_t e = run_msm(s, P, W, V, cnt, nq, lane2 ? c->M2 : c->M, &all_ok);
+            if (e != hipSuccess) {
+                c->err = std::string("batched verification failed: ") + hipGetErrorString(e);
+                return ZK_E_DEVICE;
+            }
+        }
+        if (!all_ok) {
+            {
+                Scope t(c, "v_straus_tom", s);
+                launch_v_straus(s, V.slot_terms, V.C * VK * V_SLOT_TERMS, cnt * VK, V.C * VK, 10, 26, V.slot_acc, V.slot_perm, V.slot_cnt);
+                launch_v_straus(s, V.gk_terms, V.C * nq * 8, cnt * nq, V.C * nq, 4, 4, V.gk_acc, nullptr, nullptr);
+                launch_v_straus(s, V.misc_terms, 3 * V.C, 3 * V.C, 3 * V.C, 1, 0, V.misc_acc, nullptr, nullptr);
+            }
+            {
+                Scope t(c, "v_tom_fixed", s);
+                launch_tom_commit(s, P, W.lc, cnt * 2, 2, 4 * W.n);
+            }
+        }
         {
             Scope t(c, "v_final", s);
-            launch_v_final(s, P, W, V, cnt, d_ok, d_status, first);
+            launch_v_final(s, P, W, V, cnt, d_ok, d_status, first, all_ok != 0);
         }
+        return ZK_OK;
+    };
+    const uint64_t nchunks = (B + C - 1) / C;
+    for (uint64_t k = 0; k < nchunks; k++) {
+        if (k == 0 || !dual) {
+            zs = stage1(k * C, (uint32_t)k);
+            if (zs) return zs;
+        }
+        if (dual && k + 1 < nchunks) {
+            zs = stage1((k + 1) * C, (uint32_t)(k + 1));
+            if (zs) return zs;
+        }
+        zs = stage2(k * C, (uint32_t)k);
+        if (zs) return zs;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (dual) HIPCHK(c, hipStreamSynchronize(c->stream2));

@@ -55,6 +55,8 @@ struct zk_ctx {
     size_t varena_bytes = 0;
     uint32_t vs_C = 0, vs_sec = 0, vs_n = 0;
     Soa v_res{}, v_res2{};
+    MsmBuf M{}, M2{};         // batched Tom check buffers (k_msm.hip), carved with V / V2
+    bool verify_batched = true;   // zk_ctx_set_batch_verify / ZKATTEST_VERIFY_BATCH=0: per-proof sums only
     VWork V2{};               // second verifier lane
     void* varena2 = nullptr;
     size_t varena2_bytes = 0;

@@ -189,7 +189,7 @@ void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t 
 void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t nterms, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out,
                      const uint32_t* perm, const uint32_t* cnt);
 void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count);
-void launch_v_final(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first);
+void launch_v_final(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first, bool tom_all_ok);
 
 // chunk inputs (device pointers, already offset to the chunk's first proof)
 struct ChunkIn {
@@ -200,7 +200,26 @@ struct ChunkIn {
     uint32_t count;   // proofs in this chunk
 };
 
+// buffers of the batched Tom-256 check (k_msm.hip), one set per verifier lane
+struct MsmBuf {
+    uint32_t cap;          // term ids
+    uint32_t* aos;         // [cap][32] niels entries of the live terms
+    uint32_t* keys_all;    // [16][cap] digit of every live term in every window
+    uint32_t *vals_in, *keys_out;             // live term ids; sorted keys of the window being processed
+    uint32_t* vals_out;    // [16][cap] term ids sorted by digit
+    uint32_t *start, *end; // [16][65536] segment of every digit value
+    uint32_t *counters, *flag;   // counters[0..15]: pairs per window, counters[32]: oversized buckets
+    uint32_t* big_list;    // [4096] window * 65536 + digit of the oversized buckets
+    uint32_t* buckets;     // [16][65536][36]
+    uint32_t *F1, *G1, *F2, *G2, *H2, *Tw;
+    void* sort_tmp;
+    size_t sort_tmp_bytes;
+    TomList one;           // the chunk's single fixed-base commitment
+};
 // ------------------------------------------------------------------ launch wrappers (one per kernel family)
+// k_msm.hip
+size_t msm_workspace_bytes(uint32_t cap);
+hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t* host_flag);
 // group size of one k_gk_finish pass over `ntiles` polynomials of T+1 coefficients: <= 64, dynamic LDS below 60 KB
 static inline size_t gk_finish_lds(uint32_t T, uint32_t g) { return sizeof(uint32_t) * 9 * ((size_t)g * (T + 1) + (size_t)(g / 2) * (T + 2)); }
 static inline uint32_t gk_finish_gsz(uint32_t T, uint32_t ntiles) {

@@ -249,13 +249,14 @@ ZK_DEV void v_fill(const uint8_t* vseeds, uint64_t gp, uint32_t k, uint32_t w[8]
 #pragma unroll
     for (int i = 0; i < 8; i++) w[i] = h[7 - i];
 }
-// engine-private 128-bit randomisers: two per SHA-256(vseed || be64(2^32 + idx))
+// engine-private 128-bit randomisers: two per SHA-256(vseed || be64(2^32 + idx) || be64(proof index)); the proof index keeps
+// the multipliers of different proofs independent even if a caller reuses a seed (the batched check sums over proofs)
 ZK_DEV void v_rho_pair(const uint8_t* vseeds, uint64_t gp, uint32_t idx, Sq& a, Sq& b) {
     const uint32_t* sd = (const uint32_t*)(vseeds + 32 * gp);
     uint32_t m[16], h[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) m[i] = bswap32(sd[i]);
-    m[8] = 1, m[9] = idx, m[10] = 0x80000000u, m[11] = 0, m[12] = 0, m[13] = 0, m[14] = 0, m[15] = 320;
+    m[8] = 1, m[9] = idx, m[10] = (uint32_t)(gp >> 32), m[11] = (uint32_t)gp, m[12] = 0x80000000u, m[13] = 0, m[14] = 0, m[15] = 384;
     sha256_iv(h);
     sha256_compress(h, m);
     uint32_t wa[8] = {h[0], h[1], h[2], h[3], 0, 0, 0, 0}, wb[8] = {h[4], h[5], h[6], h[7], 0, 0, 0, 0};
@@ -1003,7 +1004,9 @@ ZK_DEV TomPt ld_tom_proj3(const Soa3& a, uint32_t e) {  // (X:Y:Z) without T -> 
 ZK_DEV bool tom_is_identity(const TomPt& a) {  // edwards.ts:117-125 on the a=1 image
     return fe_is_zero(a.x) && fe_eq(a.y, a.z) && !fe_is_zero(a.z);
 }
-__global__ void __launch_bounds__(64, 2) k_v_final(DevParams P, Workspace W, VWork V, uint32_t count, uint8_t* ok_out, int32_t* status_out, uint64_t first) {
+// tom_all_ok: the batched check (k_msm.hip) found the chunk's Tom-256 total to be the identity, i.e. every proof's
+// membership and Exp/Tom sums are (the per-proof accumulators were not computed)
+__global__ void __launch_bounds__(64, 2) k_v_final(DevParams P, Workspace W, VWork V, uint32_t count, uint8_t* ok_out, int32_t* status_out, uint64_t first, bool tom_all_ok) {
     uint32_t p = gtid();
     if (p >= count) return;
     int32_t st = V.st[p];  // structural errors; W.st additionally carries a late "T is at infinity"
@@ -1011,21 +1014,27 @@ __global__ void __launch_bounds__(64, 2) k_v_final(DevParams P, Workspace W, VWo
     if (V.st[p] == ZK_OK && !(V.okflags[p] & 8)) {
         uint32_t n = V.n, nq = (n + 1) / 2;
         // membership (gk.ts:261)
-        TomPt m = ld_tom_proj3(W.lc.proj, p * 4 * n);
-        for (uint32_t q = 0; q < nq; q++) m = tom_add(m, ld_tom4(V.gk_acc, p * nq + q));
-        m = tom_add(m, ld_tom4(V.misc_acc, 0 * V.C + p));
-        bool memb = tom_is_identity(m);
+        bool memb = true;
+        if (!tom_all_ok) {
+            TomPt m = ld_tom_proj3(W.lc.proj, p * 4 * n);
+            for (uint32_t q = 0; q < nq; q++) m = tom_add(m, ld_tom4(V.gk_acc, p * nq + q));
+            m = tom_add(m, ld_tom4(V.misc_acc, 0 * V.C + p));
+            memb = tom_is_identity(m);
+        }
         if (memb) {
             // exceptions of verifyExp only surface when membership passed (zkpAttestList.ts:165-183)
             int32_t est = V.exp_st[p];
             if (est == ZK_OK && W.st[p] != ZK_OK) est = W.st[p];
             if (est != ZK_OK) st = est;
             else {
-                TomPt e = ld_tom_proj3(W.lc.proj, p * 4 * n + 1);
-                for (uint32_t j = 0; j < VK; j++) e = tom_add(e, ld_tom4(V.slot_acc, p * VK + j));
-                e = tom_add(e, ld_tom4(V.misc_acc, 1 * V.C + p));
-                e = tom_add(e, ld_tom4(V.misc_acc, 2 * V.C + p));
-                bool okW = tom_is_identity(e);
+                bool okW = true;
+                if (!tom_all_ok) {
+                    TomPt e = ld_tom_proj3(W.lc.proj, p * 4 * n + 1);
+                    for (uint32_t j = 0; j < VK; j++) e = tom_add(e, ld_tom4(V.slot_acc, p * VK + j));
+                    e = tom_add(e, ld_tom4(V.misc_acc, 1 * V.C + p));
+                    e = tom_add(e, ld_tom4(V.misc_acc, 2 * V.C + p));
+                    okW = tom_is_identity(e);
+                }
                 // P-256: SR * R + SH * h_NIST + SL * Clambda + sum(-rho A)
                 P256Pt acc = p256_identity();
                 {
@@ -1121,6 +1130,6 @@ void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t 
     L1(k_v_proof_terms, count, 64, W, V, count, proofs, off, vseeds, first);
 }
 void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count) { L1(k_v_p256_straus, count * 4, 256, V, count); }
-void launch_v_final(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first) {
-    L1(k_v_final, count, 64, P, W, V, count, ok, status, first);
+void launch_v_final(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first, bool tom_all_ok) {
+    L1(k_v_final, count, 64, P, W, V, count, ok, status, first, tom_all_ok);
 }
