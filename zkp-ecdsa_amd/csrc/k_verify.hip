@@ -294,10 +294,16 @@ __global__ void __launch_bounds__(64) k_v_sample(VWork V, uint32_t count, const 
     if (p >= count) return;
     uint64_t gp = first + p;
     uint32_t k = 0, w[8];
-    for (uint32_t i = 0; i < 2 * V.n + 1; i++) {  // randomScalar(): retry while >= q
-        do {
+    for (uint32_t i = 0; i < 2 * V.n + 1; i++) {  // randomScalar(): retry while >= q (possible only if the fill starts with 0xff)
+        for (;;) {
+            bool maybe = k >= VS_KMAX || V.vbytes[(size_t)k * V.C + p] == 0xff;
+            if (!maybe) {
+                k++;
+                break;
+            }
             v_fill(vseeds, gp, k++, w);
-        } while (words_geq<8>(w, ModQ::mod32));
+            if (!words_geq<8>(w, ModQ::mod32)) break;
+        }
     }
     uint8_t perm[ZK_MAXSEC];
     for (uint32_t i = 0; i < V.sec; i++) perm[i] = (uint8_t)i;
