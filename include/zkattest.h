@@ -105,11 +105,12 @@ zk_status zk_ctx_set_lanes(zk_ctx *ctx, uint32_t lanes);
  * ZKATTEST_COMB_BITS sets the default of new contexts. */
 zk_status zk_ctx_set_comb_bits(zk_ctx *ctx, uint32_t bits);
 
-/* Verifier strategy for the Tom-256 relations (default on): the relations of ALL proofs of a chunk are checked with one
- * bucket-method multi-scalar sum (independent 128-bit multipliers per relation and per proof); only when that sum is not
- * the identity -- some proof of the chunk is bad -- the per-proof sums run to tell which.  ok[] and the statuses are the same
- * either way; a chunk containing a bad proof costs about twice as much.  0 = always per proof.  (ZKATTEST_VERIFY_BATCH) */
-zk_status zk_ctx_set_batch_verify(zk_ctx *ctx, int on);
+/* Verifier strategy for the Tom-256 relations: in a chunk of at least min_chunk proofs (default 256) the relations of ALL
+ * proofs are checked with one bucket-method multi-scalar sum (independent 128-bit multipliers per relation and per proof);
+ * only when that sum is not the identity -- some proof of the chunk is bad -- the per-proof sums run to tell which.  ok[] and
+ * the statuses are the same either way; a chunk containing a bad proof costs about twice as much, and the chunk-wide sum has
+ * a fixed cost of a few milliseconds, hence the threshold.  0 = never, 1 = always.  (ZKATTEST_VERIFY_BATCH) */
+zk_status zk_ctx_set_batch_verify(zk_ctx *ctx, uint32_t min_chunk);
 
 /* Upper bound of one proof's ZKA1 size for the current params/ring. */
 uint64_t zk_proof_max_size(const zk_ctx *ctx);

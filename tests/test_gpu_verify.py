@@ -159,7 +159,7 @@ def test_batched_and_per_proof_verification_agree():
         for lanes in (1, 2):
             eng.set_lanes(lanes)
             for on in (True, False):
-                eng.set_batch_verify(on)
+                eng.set_batch_verify(1 if on else 0)
                 assert eng.verify_batch(msg, proofs, vseeds=vs) == exp_ok[True], (chunk, lanes, on)
                 fam = eng.last_timing()[1]
                 # an all-honest batch must be settled by the chunk-wide sum alone (no silent fallback)

@@ -61,7 +61,7 @@ def lib():
         L.zk_ctx_set_chunk.argtypes = [vp, u32]
         L.zk_ctx_set_lanes.argtypes = [vp, u32]
         L.zk_ctx_set_comb_bits.argtypes = [vp, u32]
-        L.zk_ctx_set_batch_verify.argtypes = [vp, i32]
+        L.zk_ctx_set_batch_verify.argtypes = [vp, u32]
         L.zk_proof_max_size.argtypes = [vp]
         L.zk_proof_max_size.restype = u64
         L.zk_prove_batch.argtypes = [vp, u64, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(ZkRng), vp, u64, vp, vp]
@@ -178,9 +178,10 @@ class Engine:
         """Comb width of the Tom-256 fixed-base tables (8..24); call before set_params."""
         self._chk(self.L.zk_ctx_set_comb_bits(self.h, bits))
 
-    def set_batch_verify(self, on):
-        """Chunk-wide bucket-method check of the Tom-256 relations first (default), per-proof sums only on failure."""
-        self._chk(self.L.zk_ctx_set_batch_verify(self.h, 1 if on else 0))
+    def set_batch_verify(self, min_chunk):
+        """Chunks of >= min_chunk proofs (default 256; 0 never, 1 always) get the chunk-wide bucket-method check of the
+        Tom-256 relations first; the per-proof sums only run when it fails."""
+        self._chk(self.L.zk_ctx_set_batch_verify(self.h, int(min_chunk)))
 
     def proof_max_size(self):
         return self.L.zk_proof_max_size(self.h)

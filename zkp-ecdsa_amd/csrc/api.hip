@@ -51,7 +51,7 @@ extern "C" zk_status zk_ctx_create(int device_id, zk_ctx** out) {
         if (b >= 8 && b <= TOM_MAX_BITS) c->tom_bits = (uint32_t)b;
     }
     if (const char* e = getenv("ZKATTEST_GK_TABLE")) c->gk_table = atoi(e) != 0;
-    if (const char* e = getenv("ZKATTEST_VERIFY_BATCH")) c->verify_batched = atoi(e) != 0;
+    if (const char* e = getenv("ZKATTEST_VERIFY_BATCH")) c->verify_batch_min = (uint32_t)atoi(e);
     HIPCHK(c, hipMalloc(&c->tom_tab_gen, sizeof(uint32_t) * tom_tab_words(8)));
     HIPCHK(c, hipMalloc(&c->P.pfix_G, sizeof(uint32_t) * PFIX_TAB_WORDS));
     HIPCHK(c, hipMalloc(&c->P.pfix_H, sizeof(uint32_t) * PFIX_TAB_WORDS));
@@ -206,9 +206,9 @@ extern "C" zk_status zk_ctx_set_chunk(zk_ctx* c, uint32_t chunk) {
     c->chunk = chunk;
     return ZK_OK;
 }
-extern "C" zk_status zk_ctx_set_batch_verify(zk_ctx* c, int on) {
+extern "C" zk_status zk_ctx_set_batch_verify(zk_ctx* c, uint32_t min_chunk) {
     if (!c) return ZK_E_ARG;
-    c->verify_batched = on != 0;
+    c->verify_batch_min = min_chunk;
     return ZK_OK;
 }
 extern "C" zk_status zk_ctx_set_lanes(zk_ctx* c, uint32_t lanes) {

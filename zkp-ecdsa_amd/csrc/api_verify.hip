@@ -199,7 +199,7 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
         // Tom-256 relations: one bucket-method sum over the whole chunk; only if that is not the identity (some proof is
         // bad) the per-proof windowed sums run to find out which
         uint32_t all_ok = 0;
-        if (c->verify_batched) {
+        if (c->verify_batch_min && cnt >= c->verify_batch_min) {
             Scope t(c, "v_msm_tom", s);
             hipError_t e = run_msm(s, P, W, V, cnt, nq, lane2 ? c->M2 : c->M, &all_ok);
             if (e != hipSuccess) {

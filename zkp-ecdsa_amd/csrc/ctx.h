@@ -56,7 +56,7 @@ struct zk_ctx {
     uint32_t vs_C = 0, vs_sec = 0, vs_n = 0;
     Soa v_res{}, v_res2{};
     MsmBuf M{}, M2{};         // batched Tom check buffers (k_msm.hip), carved with V / V2
-    bool verify_batched = true;   // zk_ctx_set_batch_verify / ZKATTEST_VERIFY_BATCH=0: per-proof sums only
+    uint32_t verify_batch_min = 256;   // zk_ctx_set_batch_verify: chunks of at least this many proofs get the batched check (0 = never)
     VWork V2{};               // second verifier lane
     void* varena2 = nullptr;
     size_t varena2_bytes = 0;
