@@ -210,6 +210,7 @@ struct MsmBuf {
     uint32_t *start, *end; // [16][65536] segment of every digit value
     uint32_t *counters, *flag;   // counters[0..15]: pairs per window, counters[32]: oversized buckets
     uint32_t* big_list;    // [4096] window * 65536 + digit of the oversized buckets
+    uint32_t* big_part;    // [4096][128][36] partial sums of their slices
     uint32_t* buckets;     // [16][65536][36]
     uint32_t *F1, *G1, *F2, *G2, *H2, *Tw;
     void* sort_tmp;

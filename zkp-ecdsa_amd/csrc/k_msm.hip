@@ -155,31 +155,53 @@ __global__ void __launch_bounds__(256) k_msm_bucket(const uint32_t* __restrict__
     }
     msm_st(buckets + ((size_t)w * MSM_NB + d) * 36, acc);
 }
+// Oversized buckets (sums of a few 208-bit products put ~6 terms per proof into digits 1..3 of window 13): block (j, b)
+// sums slice j (MSM_SLICE terms, strided over the grid's x extent) of big bucket b into part[b * MSM_NSLICE + j];
+// k_msm_bucket_big2 adds a bucket's partial sums.
+#define MSM_SLICE 2048u
+#define MSM_NSLICE 128u
+ZK_DEV TomPt msm_block_sum(TomPt acc, uint32_t* sh) {  // all 256 lanes: tree over the block, result valid in lane 0
+    uint32_t t = threadIdx.x;
+    for (uint32_t o = 128; o >= 1; o >>= 1) {
+        __syncthreads();
+        if (t >= o && t < 2 * o) msm_st(sh + (size_t)(t - o) * 36, acc);
+        __syncthreads();
+        if (t < o) acc = tom_add(acc, msm_ldp(sh + (size_t)t * 36));
+    }
+    __syncthreads();
+    return acc;
+}
 __global__ void __launch_bounds__(256) k_msm_bucket_big(const uint32_t* __restrict__ aos, const uint32_t* __restrict__ vals, uint32_t cap,
-                                                        const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t* buckets,
-                                                        const uint32_t* __restrict__ big_cnt, const uint32_t* __restrict__ big_list) {
+                                                        const uint32_t* __restrict__ start, const uint32_t* __restrict__ end,
+                                                        const uint32_t* __restrict__ big_cnt, const uint32_t* __restrict__ big_list, uint32_t* part) {
     __shared__ uint32_t sh[128 * 36];
     uint32_t n = *big_cnt < MSM_BIG_MAX ? *big_cnt : MSM_BIG_MAX;
-    for (uint32_t b = blockIdx.x; b < n; b += gridDim.x) {
+    for (uint32_t b = blockIdx.y; b < n; b += gridDim.y) {
         uint32_t wd = big_list[b], w = wd / MSM_NB;
         uint32_t s = start[wd], e = end[wd], t = threadIdx.x;
         const uint32_t* v = vals + (size_t)w * cap;
         TomPt acc = tom_identity();
         bool first = true;
+        for (uint32_t base = s + blockIdx.x * MSM_SLICE; base < e; base += MSM_NSLICE * MSM_SLICE) {
+            uint32_t lim = base + MSM_SLICE < e ? base + MSM_SLICE : e;
 #pragma unroll 1
-        for (uint32_t i = s + t; i < e; i += 256) {
-            TomNiels nx = msm_ld(aos + (size_t)v[i] * MSM_ENTRY_WORDS);
-            acc = first ? tom_from_niels(nx) : tom_add_niels(acc, nx);
-            first = false;
+            for (uint32_t i = base + t; i < lim; i += 256) {
+                TomNiels nx = msm_ld(aos + (size_t)v[i] * MSM_ENTRY_WORDS);
+                acc = first ? tom_from_niels(nx) : tom_add_niels(acc, nx);
+                first = false;
+            }
         }
-        for (uint32_t o = 128; o >= 1; o >>= 1) {  // tree over the 256 partial sums
-            __syncthreads();
-            if (t >= o && t < 2 * o) msm_st(sh + (size_t)(t - o) * 36, acc);
-            __syncthreads();
-            if (t < o) acc = tom_add(acc, msm_ldp(sh + (size_t)t * 36));
-        }
-        if (t == 0) msm_st(buckets + (size_t)wd * 36, acc);
-        __syncthreads();
+        acc = msm_block_sum(acc, sh);
+        if (t == 0) msm_st(part + ((size_t)b * MSM_NSLICE + blockIdx.x) * 36, acc);
+    }
+}
+__global__ void __launch_bounds__(256) k_msm_bucket_big2(const uint32_t* __restrict__ big_cnt, const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ part, uint32_t* buckets) {
+    __shared__ uint32_t sh[128 * 36];
+    uint32_t n = *big_cnt < MSM_BIG_MAX ? *big_cnt : MSM_BIG_MAX;
+    for (uint32_t b = blockIdx.x; b < n; b += gridDim.x) {
+        TomPt acc = threadIdx.x < MSM_NSLICE ? msm_ldp(part + ((size_t)b * MSM_NSLICE + threadIdx.x) * 36) : tom_identity();
+        acc = msm_block_sum(acc, sh);
+        if (threadIdx.x == 0) msm_st(buckets + (size_t)big_list[b] * 36, acc);
     }
 }
 // level 1: 64 buckets per thread.  F1 = sum_j j * B_{64 r + j}, G1 = sum_j B_{64 r + j}
@@ -313,7 +335,8 @@ hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const 
     }
     hipMemsetAsync(M.counters + 32, 0, 4, s);
     hipLaunchKernelGGL(k_msm_bucket, dim3(MSM_NB / 256, MSM_NW), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.buckets, M.counters + 32, M.big_list, 8 * ((nmax + MSM_NB - 1) / MSM_NB) + 64);
-    hipLaunchKernelGGL(k_msm_bucket_big, dim3(512), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.buckets, M.counters + 32, M.big_list);
+    hipLaunchKernelGGL(k_msm_bucket_big, dim3(MSM_NSLICE, 32), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.counters + 32, M.big_list, M.big_part);
+    hipLaunchKernelGGL(k_msm_bucket_big2, dim3(64), dim3(256), 0, s, M.counters + 32, M.big_list, M.big_part, M.buckets);
     hipLaunchKernelGGL(k_msm_reduce1, dim3(1024 / 256, MSM_NW), dim3(256), 0, s, M.buckets, M.F1, M.G1);
     hipLaunchKernelGGL(k_msm_reduce2, dim3((MSM_NW * 32 + 63) / 64), dim3(64), 0, s, M.F1, M.G1, M.F2, M.G2, M.H2);
     hipLaunchKernelGGL(k_msm_reduce3, dim3(1), dim3(64), 0, s, M.F2, M.G2, M.H2, M.Tw);
