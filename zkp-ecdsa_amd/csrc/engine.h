@@ -158,7 +158,7 @@ struct VWork {
     uint32_t* chal;       // [C][4] recomputed Exp challenge
     uint32_t* gkx;        // [C][3]
     uint32_t* idx;        // [C][VK] checked rep index | bit << 8
-    uint8_t* vbytes;      // [1536][C] first byte of the verifier-RNG fills (k_v_sample_fills)
+    uint8_t* vbytes;      // [C][1536] first byte of the verifier-RNG fills (k_v_sample_fills)
     uint32_t* vc;         // [C*VK][6][3] sub-proof challenges
     TomList vd;           // [C*VK*5] derived commitments (proj + affine)
     Soa gk_f, gk_g;       // [n*C] rho_j = f_j/g_j and the level's scale factor g_j (Montgomery); see k_v_gk_fg

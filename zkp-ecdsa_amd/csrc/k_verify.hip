@@ -283,20 +283,33 @@ ZK_DEV void v_rho_range(const uint8_t* vseeds, uint64_t gp, uint32_t tag, Sq* ou
 __global__ void __launch_bounds__(256) k_v_sample_fills(VWork V, uint32_t count, const uint8_t* vseeds, uint64_t first) {
     uint32_t t = gtid();
     if (t >= count * VS_KMAX) return;
-    uint32_t k = t / count, p = t % count;
+    uint32_t p = t / VS_KMAX, k = t % VS_KMAX;  // a proof's bytes are contiguous: k_v_sample reads them 16 at a time
     uint32_t w[8];
     v_fill(vseeds, first + p, k, w);
-    V.vbytes[(size_t)k * V.C + p] = (uint8_t)(w[7] >> 24);
+    V.vbytes[(size_t)p * VS_KMAX + k] = (uint8_t)(w[7] >> 24);
 }
+struct VByteRow {  // sequential reader of one proof's stored first bytes
+    const uint4* row;
+    uint4 cur;
+    uint32_t blk;
+    ZK_DEV uint32_t get(uint32_t k) {
+        if ((k >> 4) != blk) blk = k >> 4, cur = row[blk];
+        uint32_t sel = (k >> 2) & 3;
+        uint32_t wd = sel == 0 ? cur.x : sel == 1 ? cur.y : sel == 2 ? cur.z : cur.w;
+        return (wd >> (8 * (k & 3))) & 0xffu;
+    }
+};
 // generateIndices (exp.ts:95-109): runs after verifyMembership's 2n+1 randomScalar draws (gk.ts:223-259)
 __global__ void __launch_bounds__(64) k_v_sample(VWork V, uint32_t count, const uint8_t* vseeds, uint64_t first) {
     uint32_t p = gtid();
     if (p >= count) return;
     uint64_t gp = first + p;
     uint32_t k = 0, w[8];
+    VByteRow vb;
+    vb.row = (const uint4*)(V.vbytes + (size_t)p * VS_KMAX), vb.blk = 0xffffffffu;
     for (uint32_t i = 0; i < 2 * V.n + 1; i++) {  // randomScalar(): retry while >= q (possible only if the fill starts with 0xff)
         for (;;) {
-            bool maybe = k >= VS_KMAX || V.vbytes[(size_t)k * V.C + p] == 0xff;
+            bool maybe = k >= VS_KMAX || vb.get(k) == 0xff;
             if (!maybe) {
                 k++;
                 break;
@@ -305,26 +318,36 @@ __global__ void __launch_bounds__(64) k_v_sample(VWork V, uint32_t count, const 
             if (!words_geq<8>(w, ModQ::mod32)) break;
         }
     }
-    uint8_t perm[ZK_MAXSEC];
-    for (uint32_t i = 0; i < V.sec; i++) perm[i] = (uint8_t)i;
-    for (uint32_t i = 0; i + 2 < V.sec; i++) {
-        uint32_t range = V.sec - i, v;
-        do {
-            if (k < VS_KMAX) v = V.vbytes[(size_t)k * V.C + p];
-            else {
-                v_fill(vseeds, gp, k, w);
-                v = w[7] >> 24;  // first byte of the fill
-            }
-            k++;
-        } while (v >= range);
-        uint8_t t = perm[i];
-        perm[i] = perm[i + v], perm[i + v] = t;
+    // the permutation lives in LDS (entry i of lane l at i * 64 + l): indexed by data, it would otherwise sit in scratch memory
+    __shared__ uint8_t perm_lds[ZK_MAXSEC * 64];
+    uint8_t* perm = perm_lds + (threadIdx.x & 63);
+#define PERM(i) perm[(i) * 64]
+    for (uint32_t i = 0; i < V.sec; i++) PERM(i) = (uint8_t)i;
+    // one byte per loop iteration for every lane (a nested retry loop would make each step wait for the unluckiest lane);
+    // the stored bytes first, hashing on demand only past VS_KMAX (kept out of the hot loop)
+    uint32_t i = 0;
+    while (i + 2 < V.sec && k < VS_KMAX) {
+        uint32_t range = V.sec - i, v = vb.get(k++);
+        if (v < range) {
+            uint8_t t = PERM(i);
+            PERM(i) = PERM(i + v), PERM(i + v) = t;
+            i++;
+        }
+    }
+    while (i + 2 < V.sec) {
+        v_fill(vseeds, gp, k++, w);
+        uint32_t range = V.sec - i, v = w[7] >> 24;  // first byte of the fill
+        if (v < range) {
+            uint8_t t = PERM(i);
+            PERM(i) = PERM(i + v), PERM(i + v) = t;
+            i++;
+        }
     }
     const uint32_t* c = V.chal + 4 * p;
     const uint32_t* hb = V.hbits + 4 * p;
     int32_t st = ZK_OK;
     for (uint32_t j = 0; j < VK; j++) {
-        uint32_t i = perm[j];
+        uint32_t i = PERM(j);
         uint32_t bit = (c[i >> 5] >> (i & 31)) & 1, hbit = (hb[i >> 5] >> (i & 31)) & 1;
         V.idx[p * VK + j] = i | (bit << 8);
         if (bit != hbit && st == ZK_OK) st = ZK_E_PARAMS_NOT_FOUND;  // exp.ts:269-271,301-303
@@ -332,6 +355,7 @@ __global__ void __launch_bounds__(64) k_v_sample(VWork V, uint32_t count, const 
     if (st != ZK_OK) V.exp_st[p] = st;
     else V.exp_st[p] = ZK_OK;
 }
+#undef PERM
 
 // ------------------------------------------------------------------ Exp: T = alpha*R or T1 = z*R + Q per checked rep (exp.ts:267,299,311)
 __global__ void __launch_bounds__(256) k_v_exp_points(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
