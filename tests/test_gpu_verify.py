@@ -170,3 +170,44 @@ def test_batched_and_per_proof_verification_agree():
                 assert eng.verify_batch(msg, proofs) == exp_ok[True]       # OS-random seeds
     assert octx.verify_batch(msg, forged, nthreads=8, vseeds=vs) == exp_ok[False]
     eng.close()
+
+
+def test_batched_check_with_every_kind_of_bad_proof_in_the_chunk():
+    """A chunk mixing honest proofs with malformed, forged, partially tampered and wrong-statement ones: the chunk-wide sum
+    (forced on: min_chunk = 1) must end in exactly the verdicts and statuses of the per-proof sums, for several verifier
+    seeds, and of the oracle; then the same chunk with the bad proofs replaced (all honest) goes through the fast path."""
+    eng, octx, msg, proofs = _setup(4711, 16, 12)   # ring >= batch: every proof's key is in the ring
+    n = 4
+    mixed = list(proofs)
+
+    def tamper(i, pos, bit=1):
+        b = bytearray(proofs[i])
+        b[pos] ^= bit
+        mixed[i] = bytes(b)
+    gk_off = lambda p: len(p) - (n * (4 * 72 + 96) + 32)
+    tamper(1, len(proofs[1]) - 1)                         # zd: membership relation fails
+    tamper(3, 32 + 40)                                    # R off the curve: status 10
+    tamper(4, gk_off(proofs[4]) + 4 * 72 * n + 31)        # f_0
+    tamper(6, 304 + 208 + 31)                             # a response scalar of rep 0: depends on the sampled subset
+    tamper(8, 31)                                         # header bits: layout / 'params not found'
+    mixed[10] = proofs[9]                                 # valid proof for another message
+    for tag in (b'x', b'y', b'z', b'w'):
+        vs = _vseeds(12, tag)
+        eng.set_batch_verify(0)
+        ref = eng.verify_batch(msg, mixed, vseeds=vs)
+        eng.set_batch_verify(1)
+        got = eng.verify_batch(msg, mixed, vseeds=vs)
+        assert got == ref, (tag, got, ref)
+        o = octx.verify_batch(msg, mixed, nthreads=8, vseeds=vs)
+        assert got[0] == o[0] and [s != 0 for s in got[1]] == [s != 0 for s in o[1]]
+        assert got[0][0] == 1 and got[0][1] == 0 and got[0][3] == 0 and got[0][4] == 0 and got[0][10] == 0
+    # bad proofs whose terms never reach the sums (malformed ones) must not spoil the fast path for the others
+    only_malformed = list(proofs)
+    b = bytearray(proofs[3])
+    b[32 + 40] ^= 1
+    only_malformed[3] = bytes(b)
+    got = eng.verify_batch(msg, only_malformed, vseeds=_vseeds(12))
+    assert got[0] == [1, 1, 1, 0] + [1] * 8 and got[1][3] == 10
+    fam = eng.last_timing()[1]
+    assert 'v_msm_tom' in fam and 'v_straus_tom' not in fam
+    eng.close()
