@@ -237,6 +237,8 @@ def main():
                   'gpu_ms_by_family_per_step': {k: round(v, 2) for k, v in sorted(vfam.items(), key=lambda kv: -kv[1])},
                   'gpu_ms_note': 'serial single-lane pass; the timed passes overlap two chunks on two streams'}
 
+    free_b, total_b = torch.cuda.mem_get_info()
+    hbm_used = total_b - free_b
     if rank == 0:
         n_log2 = max(1, (nkeys - 1).bit_length())
         # --- roofline of the dominant kernel, from HIP events recorded on the engine's stream around every launch
@@ -296,6 +298,7 @@ def main():
                                    % (B, nkeys, n_log2, sec, eng_chunk(args, B), args.comb_bits),
                        'parallelism': 'proofs sharded per GPU; ring broadcast over RCCL at set-up' if world > 1 else 'single GPU'},
             'set_params_s': round(t_tab, 3),
+            'hbm_used_gb': round(hbm_used / 2**30, 1),   # tables + both lanes' prover and verifier workspaces + this step's proofs
             'proof_bytes_per_step': total_bytes, 'failed_proofs': nbad,
             'gpu_ms_by_family_per_step': {k: round(v / max(1, args.roofline_steps), 2) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
             'gpu_ms_note': 'serial single-lane pass (sum = %.1f ms); the timed steps overlap two chunks on two streams' % (gpu_ms / max(1, args.roofline_steps)),
