@@ -110,7 +110,7 @@ def main():
     ap.add_argument('--sec', type=int, default=80)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=0, help='proofs in the CPU baseline sample (default 2 x cores)')
-    ap.add_argument('--comb-bits', type=int, default=DEFAULT_COMB_BITS, help='width of the Tom-256 fixed-base comb tables (8..24); 24 = 47 GB of tables')
+    ap.add_argument('--comb-bits', type=int, default=DEFAULT_COMB_BITS, help='width of the Tom-256 fixed-base comb tables (8..24; 25, 26 = signed digits); 24 = 47 GB of tables')
     ap.add_argument('--lanes', type=int, default=2, help='chunks in flight on separate streams during the timed steps (1 = serial)')
     ap.add_argument('--roofline-steps', type=int, default=1, help='extra single-lane passes used only for per-kernel timings')
     ap.add_argument('--verify-steps', type=int, default=1, help='timed verifySignatureList passes over the produced proofs (0 = skip)')

@@ -98,9 +98,10 @@ zk_status zk_ctx_set_chunk(zk_ctx *ctx, uint32_t proofs_per_chunk);
  * low-occupancy per-proof kernels of one chunk overlap the heavy kernels of the other; 1 = strictly serial kernels
  * (what bench.py uses for its per-kernel roofline pass). */
 zk_status zk_ctx_set_lanes(zk_ctx *ctx, uint32_t lanes);
-/* Width W (8..24 bits, default 16) of the fixed-base comb tables of the Tom-256 bases g and h: a commitment
+/* Width W (8..26 bits, default 16) of the fixed-base comb tables of the Tom-256 bases g and h: a commitment
  * v*g + r*h (PedersenParams.commit, src/commit/pedersen.ts:53-58) costs 2*ceil(256/W) table additions, the tables
- * take 2 * ceil(256/W) * 2^W * 128 bytes of HBM (0.27 GB at 16, 3.5 GB at 20, 47 GB at 24) and are rebuilt by the
+ * take 2 * ceil(256/W) * 2^W * 128 bytes of HBM (0.27 GB at 16, 3.5 GB at 20, 47 GB at 24); 25 and 26 select SIGNED
+ * digits (half the entries per window): 25 = the 22 additions of 24 bits in 23.6 GB, 26 = 20 additions in 86 GB.  They are rebuilt by the
  * next zk_ctx_set_params, which must follow.  The proof bytes do not depend on W.  The environment variable
  * ZKATTEST_COMB_BITS sets the default of new contexts. */
 zk_status zk_ctx_set_comb_bits(zk_ctx *ctx, uint32_t bits);

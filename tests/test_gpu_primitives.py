@@ -134,10 +134,11 @@ def test_synth_matches_python(eng):
     assert tg == x.to_bytes(36, 'big') + y.to_bytes(36, 'big')
 
 
-@pytest.mark.parametrize('bits', [8, 11, 13, 17, 20, 24])
+@pytest.mark.parametrize('bits', [8, 11, 13, 17, 20, 24, 25, 26])
 def test_tom_commit_every_comb_width(bits):
     """zk_ctx_set_comb_bits: the composed tables (k_tables.hip) and the run-time-width comb give the oracle's
-    commitments for every width, including widths that do not divide 256 and the 47 GB 24-bit tables."""
+    commitments for every width, including widths that do not divide 256, the 47 GB 24-bit tables and the signed-digit
+    widths 25 (23.6 GB) and 26 (86 GB)."""
     import coracle as CO
     import zkattest_ref as R
     import zkp_ecdsa_amd as Z
@@ -156,7 +157,7 @@ def test_tom_commit_every_comb_width(bits):
     got = e.test_tom_commit(vs, rs)
     for v, r, g in zip(vs, rs, got):
         assert g == octx.tom_commit(v, r), (bits, v, r)
-    for bad in (7, 25, 0):
+    for bad in (7, 27, 0):
         with pytest.raises(Z.ZkError):
             e.set_comb_bits(bad)
     e.close()

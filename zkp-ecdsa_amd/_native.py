@@ -175,7 +175,7 @@ class Engine:
         self._chk(self.L.zk_ctx_set_lanes(self.h, lanes))
 
     def set_comb_bits(self, bits):
-        """Comb width of the Tom-256 fixed-base tables (8..24); call before set_params."""
+        """Comb width of the Tom-256 fixed-base tables (8..24 unsigned, 25/26 signed digits); call before set_params."""
         self._chk(self.L.zk_ctx_set_comb_bits(self.h, bits))
 
     def set_batch_verify(self, min_chunk):

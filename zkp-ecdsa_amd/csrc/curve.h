@@ -151,9 +151,26 @@ ZK_DEV bool p256_on_curve(const P256Aff& a) {
 struct TomPt {  // extended (X:Y:T:Z), Montgomery
     Ft2 x, y, t, z;
 };
-struct TomNiels {  // affine precomputed: x, y, (d/a)*x*y
-    Ft2 x, y, dt;
+template <int KX>
+struct TomNielsT {  // affine precomputed: x, y, (d/a)*x*y; x and dt may carry a looser bound (negated entries)
+    Fe<ModT, KX> x;
+    Ft2 y;
+    Fe<ModT, KX> dt;
 };
+typedef TomNielsT<2> TomNiels;
+// -P of a table entry when neg (signed comb digits): (-x, y, -dt) with -v = 4t - v < 4t
+ZK_DEV TomNielsT<4> tom_niels_neg_sel(const TomNiels& q, bool neg) {
+    TomNielsT<4> r;
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) {
+        r.x.l[i] = neg ? ModT::sub4[i] - q.x.l[i] : q.x.l[i];
+        r.dt.l[i] = neg ? ModT::sub4[i] - q.dt.l[i] : q.dt.l[i];
+    }
+    limbs_normalize(r.x.l);
+    limbs_normalize(r.dt.l);
+    r.y = q.y;
+    return r;
+}
 ZK_DEV TomPt tom_identity() {  // edwards.ts:46-48
     TomPt r;
     r.x = fe_zero<ModT>().as<2>();
@@ -163,7 +180,8 @@ ZK_DEV TomPt tom_identity() {  // edwards.ts:46-48
     return r;
 }
 // edwards.ts:161-183 with a = 1 and Z2 = 1, d*T2 precomputed: 8M
-ZK_DEV TomPt tom_add_niels(const TomPt& p, const TomNiels& q) {
+template <int KX>
+ZK_DEV TomPt tom_add_niels(const TomPt& p, const TomNielsT<KX>& q) {
     auto A = p.x * q.x;
     auto B = p.y * q.y;
     auto C = p.t * q.dt;
@@ -179,7 +197,8 @@ ZK_DEV TomPt tom_add_niels(const TomPt& p, const TomNiels& q) {
     return r;
 }
 // the same addition when the result only has to be ADDED TO NOTHING ELSE (last step of a comb): no T3, 7M
-ZK_DEV TomPt tom_add_niels_last(const TomPt& p, const TomNiels& q) {
+template <int KX>
+ZK_DEV TomPt tom_add_niels_last(const TomPt& p, const TomNielsT<KX>& q) {
     auto A = p.x * q.x;
     auto B = p.y * q.y;
     auto C = p.t * q.dt;
@@ -195,9 +214,12 @@ ZK_DEV TomPt tom_add_niels_last(const TomPt& p, const TomNiels& q) {
     return r;
 }
 // identity + q: the niels entry as an extended point (X, Y, T = XY, Z = 1), 1M instead of the 8M of an addition
-ZK_DEV TomPt tom_from_niels(const TomNiels& q) {
+template <int KX>
+ZK_DEV TomPt tom_from_niels(const TomNielsT<KX>& q) {
     TomPt r;
-    r.x = q.x, r.y = q.y;
+    if constexpr (KX == 2) r.x = q.x;
+    else r.x = fe_reduce(q.x);  // a (possibly negated) entry with the looser bound: one extra product
+    r.y = q.y;
     r.t = q.x * q.y;
     r.z = fe_one_mont<ModT>().as<2>();
     return r;

@@ -35,9 +35,13 @@ ZK_DEV void soa_st(const Soa& a, uint32_t e, const Fe<M, K>& v) {
 // with 128-byte entries W = 16/20/22/24: 194/170/157/147 ms (tables 0.27/3.5/12.9/47 GB for the two bases).
 #define TOM_ENTRY_WORDS 32
 #define TOM_DEFAULT_BITS 16
-#define TOM_MAX_BITS 24
-static inline uint32_t tom_nwin(uint32_t bits) { return (256 + bits - 1) / bits; }
-static inline size_t tom_tab_words(uint32_t bits) { return (size_t)tom_nwin(bits) * ((size_t)1 << bits) * TOM_ENTRY_WORDS; }
+#define TOM_MAX_BITS 26
+// widths above 24 use SIGNED digits in (-2^(W-1), 2^(W-1)]: half the entries per window (a negative digit negates the
+// entry on load) at the price of one spare bit: 25 = the 11 windows of 24 bits in 23.6 GB, 26 = 10 windows in 86 GB
+__host__ __device__ static inline bool tom_signed(uint32_t bits) { return bits > 24; }
+__host__ __device__ static inline uint32_t tom_nwin(uint32_t bits) { return ((tom_signed(bits) ? 257 : 256) + bits - 1) / bits; }
+__host__ __device__ static inline uint32_t tom_win_entries(uint32_t bits) { return tom_signed(bits) ? (1u << (bits - 1)) + 1 : 1u << bits; }
+static inline size_t tom_tab_words(uint32_t bits) { return (size_t)tom_nwin(bits) * tom_win_entries(bits) * TOM_ENTRY_WORDS; }
 // P-256 fixed bases (G, h_NIST): PFIX_WIN_BITS-bit comb windows (default 16), entry = affine (x, y) Montgomery limbs,
 // 20 words (80 B); digit 0 unused.
 #ifndef PFIX_WIN_BITS

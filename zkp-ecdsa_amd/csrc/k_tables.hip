@@ -14,10 +14,11 @@
 //                       Montgomery's trick over 8 entries per thread (prefix products parked in the entries
 //                       themselves, the sums recomputed on the way back: 2 x 9 + 3 + 4 modmuls + 1/8 inversion per entry).
 // scratch layout (words): window bases [nwin][36], then per window Lo [2^lo][36] and Hi [2^hi][36]
-static inline uint32_t tom_lo_bits(uint32_t bits) { return (bits + 1) / 2; }
+// digits run over [0, E), E = tom_win_entries(bits) (2^bits, or 2^(bits-1) + 1 for the signed widths): split d = i + j * 2^lo
+static inline uint32_t tom_lo_bits(uint32_t bits) { return ((tom_signed(bits) ? bits - 1 : bits) + 1) / 2; }
+static inline uint32_t tom_n_hi(uint32_t bits) { return ((tom_win_entries(bits) - 1) >> tom_lo_bits(bits)) + 1; }
 size_t tom_table_scratch_words(uint32_t bits) {
-    uint32_t lo = tom_lo_bits(bits), hi = bits - lo;
-    return (size_t)tom_nwin(bits) * 36 * (1 + ((size_t)1 << lo) + ((size_t)1 << hi));
+    return (size_t)tom_nwin(bits) * 36 * (1 + ((size_t)1 << tom_lo_bits(bits)) + tom_n_hi(bits));
 }
 size_t pfix_table_scratch_words() { return (size_t)PFIX_NWIN * 36 + (size_t)PFIX_NWIN * PFIX_WIN_SIZE * 36; }
 
@@ -43,9 +44,10 @@ __global__ void k_tomtab_bases(const uint32_t* xy, uint32_t* scratch, int32_t* o
         for (uint32_t i = 0; i < bits; i++) p = tom_dbl(p);
     }
 }
-__global__ void k_tomtab_sub(uint32_t* scratch, uint32_t nwin, uint32_t lo, uint32_t hi) {
+__global__ void k_tomtab_sub(uint32_t* scratch, uint32_t nwin, uint32_t lo, uint32_t n_hi) {
     uint32_t t = gtid();
-    uint32_t per_win = (1u << lo) + (1u << hi);
+    uint32_t per_win = (1u << lo) + n_hi;
+    uint32_t hi = 32 - __clz(n_hi > 1 ? n_hi - 1 : 1);  // bits of the largest Hi index
     if (t >= nwin * per_win) return;
     uint32_t w = t / per_win, i = t % per_win;
     bool is_hi = i >= (1u << lo);
@@ -64,14 +66,14 @@ __global__ void k_tomtab_sub(uint32_t* scratch, uint32_t nwin, uint32_t lo, uint
     st_tompt(scratch + (size_t)36 * nwin + (size_t)36 * t, acc);
 }
 #define TOMTAB_PER 8
-__global__ void __launch_bounds__(256) k_tomtab_compose(const uint32_t* scratch, uint32_t* tab, uint32_t bits, uint32_t nwin, uint32_t lo, uint32_t nthreads) {
+__global__ void __launch_bounds__(256) k_tomtab_compose(const uint32_t* scratch, uint32_t* tab, uint32_t ent, uint32_t nwin, uint32_t lo, uint32_t n_hi, uint32_t nthreads) {
     uint32_t t = gtid();
     if (t >= nthreads) return;
-    const uint32_t per_win = (1u << lo) + (1u << (bits - lo));
+    const uint32_t per_win = (1u << lo) + n_hi;
     const uint32_t* sub = scratch + (size_t)36 * nwin;
-    const uint64_t total = (uint64_t)nwin << bits;
+    const uint64_t total = (uint64_t)nwin * ent;
     auto entry_sum = [&](uint64_t e) {
-        uint32_t w = (uint32_t)(e >> bits), d = (uint32_t)e & ((1u << bits) - 1);
+        uint32_t w = (uint32_t)(e / ent), d = (uint32_t)(e % ent);
         const uint32_t* sw = sub + (size_t)36 * per_win * w;
         return tom_add(ld_tompt(sw + (size_t)36 * (d & ((1u << lo) - 1))), ld_tompt(sw + (size_t)36 * ((1u << lo) + (d >> lo))));
     };
@@ -107,13 +109,13 @@ __global__ void __launch_bounds__(256) k_tomtab_compose(const uint32_t* scratch,
     }
 }
 void launch_build_tom_table(hipStream_t s, const uint32_t* xy, uint32_t bits, uint32_t* tab, uint32_t* scratch, int32_t* ok) {
-    uint32_t nwin = tom_nwin(bits), lo = tom_lo_bits(bits), hi = bits - lo;
+    uint32_t nwin = tom_nwin(bits), lo = tom_lo_bits(bits), n_hi = tom_n_hi(bits), ent = tom_win_entries(bits);
     hipLaunchKernelGGL(k_tomtab_bases, dim3(1), dim3(64), 0, s, xy, scratch, ok, bits, nwin);
-    uint32_t nsub = nwin * ((1u << lo) + (1u << hi));
-    hipLaunchKernelGGL(k_tomtab_sub, dim3((nsub + 63) / 64), dim3(64), 0, s, scratch, nwin, lo, hi);
-    uint64_t total = (uint64_t)nwin << bits;
+    uint32_t nsub = nwin * ((1u << lo) + n_hi);
+    hipLaunchKernelGGL(k_tomtab_sub, dim3((nsub + 63) / 64), dim3(64), 0, s, scratch, nwin, lo, n_hi);
+    uint64_t total = (uint64_t)nwin * ent;
     uint32_t nthreads = (uint32_t)((total + TOMTAB_PER - 1) / TOMTAB_PER);
-    hipLaunchKernelGGL(k_tomtab_compose, dim3((nthreads + 255) / 256), dim3(256), 0, s, scratch, tab, bits, nwin, lo, nthreads);
+    hipLaunchKernelGGL(k_tomtab_compose, dim3((nthreads + 255) / 256), dim3(256), 0, s, scratch, tab, ent, nwin, lo, n_hi, nthreads);
 }
 
 // ---------------------------------------------------------------- P-256 fixed bases

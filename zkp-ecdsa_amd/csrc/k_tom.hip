@@ -34,7 +34,33 @@ ZK_DEV void shr256_rt(uint32_t* w, uint32_t sh) {
     for (int i = 0; i < 7; i++) w[i] = __funnelshift_r(w[i], w[i + 1], sh);
     w[7] >>= sh;
 }
-template <int OCC>
+// successive comb digits of a 256-bit scalar, lowest window first: table index and sign (always + for unsigned widths)
+struct CombDigits {
+    uint32_t w[8];
+    uint32_t bits, mask, half, carry;
+    bool sgn;
+    ZK_DEV void init(uint32_t b) { bits = b, mask = (1u << b) - 1, half = 1u << (b - 1), carry = 0, sgn = tom_signed(b); }
+    ZK_DEV void next(uint32_t& idx, bool& neg) {
+        uint32_t d = (w[0] & mask) + carry;
+        shr256_rt(w, bits);
+        neg = sgn && d > half;
+        carry = neg ? 1u : 0u;
+        idx = neg ? (mask + 1) - d : d;
+    }
+};
+template <bool SGN>
+struct NielsSel;  // table entry as used by the addition: as loaded (unsigned combs) or conditionally negated (signed combs)
+template <>
+struct NielsSel<false> {
+    typedef TomNiels T;
+    static ZK_DEV T sel(const TomNiels& q, bool) { return q; }
+};
+template <>
+struct NielsSel<true> {
+    typedef TomNielsT<4> T;
+    static ZK_DEV T sel(const TomNiels& q, bool neg) { return tom_niels_neg_sel(q, neg); }
+};
+template <int OCC, bool SGN>
 __global__ void __launch_bounds__(256, OCC) k_tom_commit(const uint32_t* __restrict__ tab_g, const uint32_t* __restrict__ tab_h, TomList L,
                                                          uint32_t count, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride,
                                                          uint32_t bits, uint32_t nwin, uint32_t lb_singles) {
@@ -45,31 +71,31 @@ __global__ void __launch_bounds__(256, OCC) k_tom_commit(const uint32_t* __restr
     uint32_t kk = c / per_group;
     if (lb_singles) kk = LB_SINGLE_K[kk];
     uint32_t slot = kstride ? kk * kstride + (c % per_group) : kk * slots_per_group + (c % per_group);
-    uint32_t vw[8], rw[8];
+    CombDigits dgv, dgr;
+    dgv.init(bits), dgr.init(bits);
     {
         Fe<ModQ, 1> v = soa_ld<ModQ, 1>(L.v, slot), r = soa_ld<ModQ, 1>(L.r, slot);
-        words_from_limbs<8>(vw, v.l);
-        words_from_limbs<8>(rw, r.l);
+        words_from_limbs<8>(dgv.w, v.l);
+        words_from_limbs<8>(dgr.w, r.l);
     }
-    const uint32_t mask = (1u << bits) - 1;
+    const uint32_t ent = tom_win_entries(bits);
     TomPt acc = tom_identity();
     // software pipeline: the gathers of window w+1 are issued before the two additions of window w
-    uint32_t dv = vw[0] & mask, dr = rw[0] & mask;
-    shr256_rt(vw, bits);
-    shr256_rt(rw, bits);
+    uint32_t dv, dr;
+    bool sv, sr, nsv = false, nsr = false;
+    dgv.next(dv, sv), dgr.next(dr, sr);
     TomNiels ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * dv);
     TomNiels nh = ld_niels(tab_h + (size_t)TOM_ENTRY_WORDS * dr);
 #pragma unroll 1
     for (uint32_t w = 0; w < nwin; w++) {
-        TomNiels cg = ng, ch = nh;
+        typename NielsSel<SGN>::T cg = NielsSel<SGN>::sel(ng, sv), ch = NielsSel<SGN>::sel(nh, sr);
         if (w + 1 < nwin) {
-            dv = vw[0] & mask, dr = rw[0] & mask;
-            shr256_rt(vw, bits);
-            shr256_rt(rw, bits);
-            size_t base = (size_t)(w + 1) << bits;
+            dgv.next(dv, nsv), dgr.next(dr, nsr);
+            size_t base = (size_t)(w + 1) * ent;
             ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * (base + dv));
             nh = ld_niels(tab_h + (size_t)TOM_ENTRY_WORDS * (base + dr));
         }
+        sv = nsv, sr = nsr;
         acc = w == 0 ? tom_from_niels(cg) : tom_add_niels(acc, cg);                    // first step: identity + entry
         acc = w + 1 == nwin ? tom_add_niels_last(acc, ch) : tom_add_niels(acc, ch);    // last step: nobody reads T
     }
@@ -85,26 +111,32 @@ __global__ void __launch_bounds__(256, OCC) k_tom_commit(const uint32_t* __restr
 #define LB_UNITS_PAIR 6
 // acc += sum_w tab[w][digit_w(words)], gathers pipelined one window ahead.  FIRST: acc is the identity (the first entry is
 // taken as is); LAST: the result is final (no T coordinate).
-template <bool FIRST, bool LAST>
+template <bool FIRST, bool LAST, bool SGN>
 ZK_DEV TomPt tom_comb_acc(TomPt acc, const uint32_t* __restrict__ tab, uint32_t* words, uint32_t bits, uint32_t nwin) {
-    const uint32_t mask = (1u << bits) - 1;
-    uint32_t d = words[0] & mask;
-    shr256_rt(words, bits);
+    CombDigits dg;
+    dg.init(bits);
+#pragma unroll
+    for (int i = 0; i < 8; i++) dg.w[i] = words[i];
+    const uint32_t ent = tom_win_entries(bits);
+    uint32_t d;
+    bool sg, nsg = false;
+    dg.next(d, sg);
     TomNiels nx = ld_niels(tab + (size_t)TOM_ENTRY_WORDS * d);
 #pragma unroll 1
     for (uint32_t w = 0; w < nwin; w++) {
-        TomNiels cur = nx;
+        typename NielsSel<SGN>::T cur = NielsSel<SGN>::sel(nx, sg);
         if (w + 1 < nwin) {
-            d = words[0] & mask;
-            shr256_rt(words, bits);
-            nx = ld_niels(tab + (size_t)TOM_ENTRY_WORDS * (((size_t)(w + 1) << bits) + d));
+            dg.next(d, nsg);
+            nx = ld_niels(tab + (size_t)TOM_ENTRY_WORDS * ((size_t)(w + 1) * ent + d));
         }
+        sg = nsg;
         if (FIRST && w == 0) acc = tom_from_niels(cur);
         else if (LAST && w + 1 == nwin) acc = tom_add_niels_last(acc, cur);
         else acc = tom_add_niels(acc, cur);
     }
     return acc;
 }
+template <bool SGN>
 __global__ void __launch_bounds__(256, 2) k_tom_commit_pairs(const uint32_t* __restrict__ tab_g, const uint32_t* __restrict__ tab_h, TomList L,
                                                              uint32_t items, uint32_t kstride, uint32_t bits, uint32_t nwin) {
     uint32_t c = gtid();
@@ -112,25 +144,31 @@ __global__ void __launch_bounds__(256, 2) k_tom_commit_pairs(const uint32_t* __r
     uint32_t slot0 = LB_PAIR_K[c / items] * kstride + c % items, slot1 = slot0 + kstride;
     uint32_t w8[8];
     words_from_limbs<8>(w8, soa_ld<ModQ, 1>(L.v, slot0).l);
-    TomPt G = tom_comb_acc<true, false>(tom_identity(), tab_g, w8, bits, nwin);
+    TomPt G = tom_comb_acc<true, false, SGN>(tom_identity(), tab_g, w8, bits, nwin);
     words_from_limbs<8>(w8, soa_ld<ModQ, 1>(L.r, slot0).l);
-    TomPt A = tom_comb_acc<false, true>(G, tab_h, w8, bits, nwin);
+    TomPt A = tom_comb_acc<false, true, SGN>(G, tab_h, w8, bits, nwin);
     soa_st(L.proj.x, slot0, A.x), soa_st(L.proj.y, slot0, A.y), soa_st(L.proj.z, slot0, A.z);
     words_from_limbs<8>(w8, soa_ld<ModQ, 1>(L.r, slot1).l);
-    A = tom_comb_acc<false, true>(G, tab_h, w8, bits, nwin);
+    A = tom_comb_acc<false, true, SGN>(G, tab_h, w8, bits, nwin);
     soa_st(L.proj.x, slot1, A.x), soa_st(L.proj.y, slot1, A.y), soa_st(L.proj.z, slot1, A.z);
 }
 void launch_tom_commit_listb(hipStream_t s, const DevParams& P, const TomList& L, uint32_t items, uint32_t kstride) {
     if (!items) return;
     uint32_t nwin = tom_nwin(P.tom_bits);
     uint32_t n1 = items * LB_UNITS_SINGLE, n2 = items * LB_UNITS_PAIR;
-    hipLaunchKernelGGL(k_tom_commit<2>, dim3((n1 + 255) / 256), dim3(256), 0, s, P.tom_tab_g, P.tom_tab_h, L, n1, items, 0u, kstride, P.tom_bits, nwin, 1u);
-    hipLaunchKernelGGL(k_tom_commit_pairs, dim3((n2 + 255) / 256), dim3(256), 0, s, P.tom_tab_g, P.tom_tab_h, L, items, kstride, P.tom_bits, nwin);
+    if (tom_signed(P.tom_bits)) {
+        hipLaunchKernelGGL((k_tom_commit<2, true>), dim3((n1 + 255) / 256), dim3(256), 0, s, P.tom_tab_g, P.tom_tab_h, L, n1, items, 0u, kstride, P.tom_bits, nwin, 1u);
+        hipLaunchKernelGGL(k_tom_commit_pairs<true>, dim3((n2 + 255) / 256), dim3(256), 0, s, P.tom_tab_g, P.tom_tab_h, L, items, kstride, P.tom_bits, nwin);
+    } else {
+        hipLaunchKernelGGL((k_tom_commit<2, false>), dim3((n1 + 255) / 256), dim3(256), 0, s, P.tom_tab_g, P.tom_tab_h, L, n1, items, 0u, kstride, P.tom_bits, nwin, 1u);
+        hipLaunchKernelGGL(k_tom_commit_pairs<false>, dim3((n2 + 255) / 256), dim3(256), 0, s, P.tom_tab_g, P.tom_tab_h, L, items, kstride, P.tom_bits, nwin);
+    }
 }
 void launch_tom_commit(hipStream_t s, const DevParams& P, const TomList& L, uint32_t count, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride) {
     if (!count) return;
     dim3 g((count + 255) / 256), b(256);
-    hipLaunchKernelGGL(k_tom_commit<2>, g, b, 0, s, P.tom_tab_g, P.tom_tab_h, L, count, per_group, slots_per_group, kstride, P.tom_bits, tom_nwin(P.tom_bits), 0u);
+    if (tom_signed(P.tom_bits)) hipLaunchKernelGGL((k_tom_commit<2, true>), g, b, 0, s, P.tom_tab_g, P.tom_tab_h, L, count, per_group, slots_per_group, kstride, P.tom_bits, tom_nwin(P.tom_bits), 0u);
+    else hipLaunchKernelGGL((k_tom_commit<2, false>), g, b, 0, s, P.tom_tab_g, P.tom_tab_h, L, count, per_group, slots_per_group, kstride, P.tom_bits, tom_nwin(P.tom_bits), 0u);
 }
 
 // Batch normalisation: (X:Y:Z) on the a=1 image -> affine (x, y) of the ORIGINAL curve, plain canonical limbs
