@@ -3,6 +3,7 @@ host-side helpers of bench.py behave."""
 import ctypes
 import os
 import re
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -41,3 +42,19 @@ def test_bench_helpers():
     wt, wq, ring = bench.nominal_modmuls(16)
     assert (wt, wq, ring) == ((162 + 26 * 40 + 64) * 4064 + 320 * 3184, (163 + 40) * 4448 + 5568, 2 * 65536 * 16)
     assert bench.host_cores() >= 1
+
+
+def test_c_program_compiles_and_links_against_the_abi(tmp_path):
+    """include/zkattest.h is plain C and the shared library is all a C host needs (examples/c_abi_demo.c)."""
+    import shutil
+    import subprocess
+    import zkp_ecdsa_amd as Z
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which('gcc'):
+        pytest.skip('no gcc')
+    out = tmp_path / 'zk_demo'
+    libdir = os.path.dirname(Z.LIB_PATH)
+    subprocess.check_call(['gcc', '-std=c99', '-O1', '-Wall', '-Werror', '-I' + os.path.join(root, 'include'),
+                           os.path.join(root, 'examples', 'c_abi_demo.c'), '-o', str(out), '-L' + libdir, '-lzkattest_hip',
+                           '-Wl,-rpath,' + libdir])
+    assert out.exists()

@@ -198,3 +198,18 @@ def test_security_levels_other_than_80(sec, nkeys, B):
         ook, ovst = octx.verify_batch(msg, got, nthreads=4)[:2]
         assert ook == [0] * B and ovst == [9] * B
     eng.close()
+
+
+def test_c_abi_demo_program_runs(tmp_path):
+    """examples/c_abi_demo.c: prove, JSON round trip, verify and reject a forged proof from a plain C host."""
+    import os
+    import subprocess
+    import zkp_ecdsa_amd as Z
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / 'zk_demo'
+    libdir = os.path.dirname(Z.LIB_PATH)
+    subprocess.check_call(['gcc', '-std=c99', '-O1', '-I' + os.path.join(root, 'include'), os.path.join(root, 'examples', 'c_abi_demo.c'),
+                           '-o', str(out), '-L' + libdir, '-lzkattest_hip', '-Wl,-rpath,' + libdir])
+    res = subprocess.run([str(out), '5', '16'], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert 'round trip identical' in res.stdout and 'verified 5 of 5' in res.stdout and 'ok[0] = 0' in res.stdout
