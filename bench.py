@@ -109,12 +109,12 @@ def main():
     ap.add_argument('--seed', type=int, default=2024)
     ap.add_argument('--sec', type=int, default=80)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=0, help='proofs in the CPU baseline sample (default 2 x cores)')
+    ap.add_argument('--cpu-sample', type=int, default=0, help='proofs in the CPU baseline sample (default 4 x cores, all of them diffed against the GPU output)')
     ap.add_argument('--comb-bits', type=int, default=DEFAULT_COMB_BITS, help='width of the Tom-256 fixed-base comb tables (8..24; 25, 26 = signed digits); 24 = 47 GB of tables')
     ap.add_argument('--lanes', type=int, default=2, help='chunks in flight on separate streams during the timed steps (1 = serial)')
     ap.add_argument('--roofline-steps', type=int, default=1, help='extra single-lane passes used only for per-kernel timings')
     ap.add_argument('--verify-steps', type=int, default=1, help='timed verifySignatureList passes over the produced proofs (0 = skip)')
-    ap.add_argument('--check', type=int, default=8, help='proofs of step 1 diffed against the oracle on rank 0')
+    ap.add_argument('--check', type=int, default=1 << 30, help='proofs of the last step diffed against the oracle on rank 0 (at most the CPU sample)')
     args = ap.parse_args()
 
     import torch
@@ -280,7 +280,7 @@ def main():
         }
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            sample = args.cpu_sample or 2 * host_cores()
+            sample = args.cpu_sample or 4 * host_cores()
             cpu, oproofs = cpu_baseline(nh, tg, th, ring, nkeys, msg, sig, pk, which, seeds, sec, min(sample, B))
             # spot-check: the first proofs of the last step against the oracle, byte for byte
             ncheck = min(args.check, len(oproofs))
