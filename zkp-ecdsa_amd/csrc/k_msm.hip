@@ -10,14 +10,14 @@
 // falls back to the per-proof sums to find out which ones failed -- the verdicts are the same either way, only the cost
 // of a chunk that contains a bad proof doubles.
 //
-// Pipeline per chunk (one HIP stream):
+// Pipeline per chunk (one HIP stream, two host round trips: the live count and the verdict):
 //   k_msm_pack      live terms -> 128-byte AoS niels entries (the bucket sums gather them)
-//   per 16-bit window w: k_msm_emit (digit, term id) pairs with digit != 0, wave-aggregated append
-//                        rocprim::radix_sort_pairs on the digit
-//                        k_msm_bounds  first / last position of every digit value
-//   k_msm_bucket    thread (window, digit): sum of its terms (8 modmuls per term)
+//   k_msm_compact   ids of the live terms + their sixteen 16-bit digits, one atomic per workgroup
+//   per window w:   rocprim::radix_sort_pairs (digit -> term id), k_msm_bounds first / last position of every digit
+//   k_msm_bucket    thread (window, digit): sum of its terms (8 modmuls per term); buckets far above the average
+//                   (k_msm_bucket_big / _big2) are summed by slices over many workgroups
 //   k_msm_reduce1/2/3  sum_d d * B_d per window by two levels of running sums, times 2^(16 w)
-//   k_msm_final     windows + the fixed-base part (one commitment for the whole chunk) == identity ?
+//   k_msm_coef, one fixed-base commitment, k_msm_final: windows + fixed-base part == identity ?
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -308,7 +308,7 @@ hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const 
     D.n0 = D.g0 * V_SLOT_TERMS, D.n1 = D.g1 * 8, D.n2 = D.g2 * 3;
     D.l0 = count * VK, D.l1 = count * nq, D.l2 = count;
     const uint32_t total = D.n0 + D.n1 + D.n2;
-    const bool dbg = getenv("ZK_MSM_DEBUG") != nullptr;
+    const bool dbg = getenv("ZK_MSM_DEBUG") != nullptr;  // phase timings on stderr (adds stream synchronisations)
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
     hipLaunchKernelGGL(k_msm_pack, dim3((total + 255) / 256), dim3(256), 0, s, V, D, M.aos);
