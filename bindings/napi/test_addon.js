@@ -1,0 +1,52 @@
+// node test_addon.js json <golden.json>      CPU-only: JSON wire format through the addon against the committed digest
+// node test_addon.js gpu                       on an MI355X: synthetic workload -> prove -> writeJson/readJson -> verify
+'use strict'
+const assert = require('assert')
+const crypto = require('crypto')
+const fs = require('fs')
+const zk = require('./zkattest.js')
+
+async function main() {
+    const mode = process.argv[2]
+    if (mode === 'json') {
+        const gold = JSON.parse(fs.readFileSync(process.argv[3], 'utf8'))
+        const rec = gold.small_full.proofs[0]
+        const proof = Buffer.from(rec.proof, 'hex')
+        const text = zk.writeJson(proof)
+        assert.strictEqual(text.length, rec.json_len)
+        assert.strictEqual(crypto.createHash('sha256').update(text).digest('hex'), rec.json_sha256)
+        assert.ok(zk.readJson(text).equals(proof))
+        const obj = JSON.parse(text)
+        assert.deepStrictEqual(Object.keys(obj), ['R', 'comS1', 'keyXcom', 'keyYcom', 'expProof', 'membershipProof'])
+        assert.throws(() => zk.readJson(text.slice(0, -1)), /error deserializing/)
+        console.log('json ok', text.length)
+        return
+    }
+    const eng = new zk.Engine(0)
+    const params = eng.synthParams(7)
+    eng.setParams(params)
+    const B = 6, nKeys = 16
+    const wl = eng.synthWorkload(7, nKeys, B)
+    eng.setRing(wl.ring)
+    const proofs = eng.proveBatch(wl.msg, wl.sig, wl.pk, wl.which, wl.seeds)
+    assert.strictEqual(proofs.length, B)
+    const again = eng.proveBatch(wl.msg, wl.sig, wl.pk, wl.which, wl.seeds)             // deterministic under the RNG contract
+    assert.ok(again.every((p, i) => p.equals(proofs[i])))
+    const viaJson = proofs.map((p) => zk.readJson(zk.writeJson(p)))                      // test/zkpAttestList.test.ts:55-60
+    assert.deepStrictEqual(eng.verifyBatch(wl.msg, viaJson), Array(B).fill(true))
+    const forged = Buffer.from(proofs[2])
+    forged[forged.length - 1] ^= 1
+    const mixed = proofs.slice()
+    mixed[2] = forged
+    assert.deepStrictEqual(eng.verifyBatch(wl.msg, mixed), [true, true, false, true, true, true])
+    const one = await zk.proveSignatureList(eng, wl.msg.slice(0, 32), wl.sig.slice(0, 64), Buffer.concat([Buffer.from([4]), wl.pk.slice(0, 64)]), 0)
+    assert.strictEqual(await zk.verifySignatureList(eng, wl.msg.slice(0, 32), one), true)
+    const bad = Buffer.from(wl.pk.slice(0, 64))
+    bad[63] ^= 1
+    assert.throws(() => eng.proveBatch(wl.msg.slice(0, 32), wl.sig.slice(0, 64), bad, [0], wl.seeds.slice(0, 32)), /point not in group/)
+    const k = eng.keysToInts(wl.pk)
+    assert.ok(k.keys.slice(0, 32).equals(wl.pk.slice(0, 32)))
+    eng.close()
+    console.log('gpu ok', proofs[0].length)
+}
+main().catch((e) => { console.error(e); process.exit(1) })
