@@ -44,6 +44,11 @@ async function main() {
     const bad = Buffer.from(wl.pk.slice(0, 64))
     bad[63] ^= 1
     assert.throws(() => eng.proveBatch(wl.msg.slice(0, 32), wl.sig.slice(0, 64), bad, [0], wl.seeds.slice(0, 32)), /point not in group/)
+    // Promise-based calls: two batches queued back to back on one engine, results in order
+    const [pa, pb] = await Promise.all([eng.proveBatchAsync(wl.msg, wl.sig, wl.pk, wl.which, wl.seeds), eng.proveBatchAsync(wl.msg.slice(0, 64), wl.sig.slice(0, 128), wl.pk.slice(0, 128), [0, 1], wl.seeds.slice(0, 64))])
+    assert.ok(pa.every((p, i) => p.equals(proofs[i])) && pb.length === 2 && pb[1].equals(proofs[1]))
+    assert.deepStrictEqual(await eng.verifyBatchAsync(wl.msg, mixed), [true, true, false, true, true, true])
+    await assert.rejects(eng.proveBatchAsync(wl.msg.slice(0, 32), wl.sig.slice(0, 64), bad, [0], wl.seeds.slice(0, 32)), /point not in group/)
     const k = eng.keysToInts(wl.pk)
     assert.ok(k.keys.slice(0, 32).equals(wl.pk.slice(0, 32)))
     eng.close()

@@ -53,12 +53,42 @@ class Engine {
     }
 }
 
+// Promise-returning batch calls (the batch runs on a libuv worker thread); jobs of one engine are chained because a
+// context runs one batch at a time
+Engine.prototype.proveBatchAsync = function (msg, sig, pk, which, seeds) {
+    const B = msg.length / 32
+    seeds = seeds || crypto.randomBytes(32 * B)
+    const w = Buffer.isBuffer(which) ? which : Buffer.from(Uint32Array.from(which).buffer)
+    const run = () => native.proveBatchAsync(this.ctx, msg, sig, pk, w, seeds).then((r) => {
+        const st = i32(r.status), off = u64(r.offsets), out = []
+        for (let b = 0; b < B; b++) {
+            if (st[b] !== 0) throw new Error(STATUS_TEXT[st[b]] || ('status ' + st[b]))
+            out.push(r.proofs.slice(Number(off[b]), Number(off[b + 1])))
+        }
+        return out
+    })
+    this.tail = (this.tail || Promise.resolve()).then(run, run)
+    return this.tail
+}
+Engine.prototype.verifyBatchAsync = function (msg, proofs, seeds) {
+    const B = proofs.length
+    const off = new BigUint64Array(B + 1)
+    for (let b = 0; b < B; b++) off[b + 1] = off[b] + BigInt(proofs[b].length)
+    const run = () => native.verifyBatchAsync(this.ctx, msg, Buffer.concat(proofs), Buffer.from(off.buffer), seeds || null).then((r) => {
+        const st = i32(r.status)
+        for (let b = 0; b < B; b++) if (st[b] !== 0) throw new Error(STATUS_TEXT[st[b]] || ('status ' + st[b]))
+        return Array.from(r.ok).map((v) => v === 1)
+    })
+    this.tail = (this.tail || Promise.resolve()).then(run, run)
+    return this.tail
+}
+
 // ---- the reference's single-proof API on top (zkpAttestList.ts:104-184); `engine` carries params and ring
 async function proveSignatureList(engine, msgHash, sigBytes, publicKeyRaw, which) {
     const pk = publicKeyRaw.length === 65 ? publicKeyRaw.slice(1) : publicKeyRaw        // WebCrypto 'raw' export: 04 || X || Y
-    return engine.proveBatch(msgHash, sigBytes, pk, [which])[0]
+    return (await engine.proveBatchAsync(msgHash, sigBytes, pk, [which]))[0]
 }
-async function verifySignatureList(engine, msgHash, proof) { return engine.verifyBatch(msgHash, [proof])[0] }
+async function verifySignatureList(engine, msgHash, proof) { return (await engine.verifyBatchAsync(msgHash, [proof]))[0] }
 const writeJson = (proof) => native.proofToJson(proof)       // src/serde.ts:34-36
 const readJson = (text) => native.proofFromJson(text)        // src/serde.ts:21-32
 

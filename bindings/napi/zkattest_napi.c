@@ -218,6 +218,115 @@ static napi_value VerifyBatch(napi_env env, napi_callback_info info) {
     free(off), free(ok), free(status);
     return st == ZK_OK ? o : throw_status(env, ctx, st);
 }
+/* ---- asynchronous variants: the batch runs on a libuv worker thread, the caller gets a Promise (what keeps the reference's
+ * `async function proveSignatureList(...)` signature without blocking the event loop).  One job at a time per context. */
+typedef struct {
+    int verify;
+    zk_ctx *ctx;
+    size_t B;
+    uint8_t *msg, *sig, *pk, *seeds, *proofs_in;
+    uint32_t *which;
+    uint8_t *out;
+    uint64_t cap, *off;
+    int32_t *status;
+    uint8_t *ok;
+    zk_status rc;
+    char err[256];
+    napi_deferred deferred;
+    napi_async_work work;
+} Job;
+static uint8_t *dup_bytes(const uint8_t *p, size_t n) {
+    uint8_t *q = malloc(n ? n : 1);
+    if (p && n) memcpy(q, p, n);
+    return q;
+}
+static void job_free(Job *j) {
+    free(j->msg), free(j->sig), free(j->pk), free(j->seeds), free(j->proofs_in), free(j->which), free(j->out), free(j->off), free(j->status), free(j->ok);
+    free(j);
+}
+static void job_execute(napi_env env, void *data) { /* worker thread: no N-API calls here */
+    Job *j = data;
+    if (j->verify) j->rc = zk_verify_batch(j->ctx, j->B, j->msg, j->proofs_in, j->off, j->seeds, j->ok, j->status);
+    else {
+        zk_rng rng = {ZK_RNG_SEED, j->seeds, 0};
+        j->rc = zk_prove_batch(j->ctx, j->B, j->msg, j->sig, j->pk, j->which, &rng, j->out, j->cap, j->off, j->status);
+    }
+    if (j->rc != ZK_OK) snprintf(j->err, sizeof j->err, "%s: %s", zk_strerror(j->rc), zk_last_error(j->ctx));
+}
+static void job_complete(napi_env env, napi_status status, void *data) { /* main thread */
+    Job *j = data;
+    napi_value v;
+    if (status == napi_ok && j->rc == ZK_OK && napi_create_object(env, &v) == napi_ok) {
+        if (j->verify) set_prop(env, v, "ok", new_buffer(env, j->ok, j->B));
+        else set_prop(env, v, "proofs", new_buffer(env, j->out, (size_t)j->off[j->B])), set_prop(env, v, "offsets", new_buffer(env, j->off, 8 * (j->B + 1)));
+        set_prop(env, v, "status", new_buffer(env, j->status, 4 * j->B));
+        napi_resolve_deferred(env, j->deferred, v);
+    } else {
+        napi_value msg, e;
+        napi_create_string_utf8(env, j->rc != ZK_OK ? j->err : "async work failed", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &e);
+        napi_reject_deferred(env, j->deferred, e);
+    }
+    napi_delete_async_work(env, j->work);
+    job_free(j);
+}
+static napi_value job_start(napi_env env, Job *j, const char *name) {
+    napi_value promise, rn;
+    if (napi_create_promise(env, &j->deferred, &promise) != napi_ok || napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &rn) != napi_ok ||
+        napi_create_async_work(env, NULL, rn, job_execute, job_complete, j, &j->work) != napi_ok || napi_queue_async_work(env, j->work) != napi_ok) {
+        job_free(j);
+        napi_throw_error(env, NULL, "could not queue the batch");
+        return NULL;
+    }
+    return promise;
+}
+static napi_value ProveBatchAsync(napi_env env, napi_callback_info info) { /* same arguments as proveBatch -> Promise of the same object */
+    napi_value argv[6];
+    if (!get_args(env, info, 6, argv)) return NULL;
+    zk_ctx *ctx = get_ctx(env, argv[0]);
+    uint8_t *msg, *sig, *pk, *which, *seeds;
+    size_t lm, ls, lp, lw, lse;
+    if (!ctx || !get_bytes(env, argv[1], &msg, &lm) || !get_bytes(env, argv[2], &sig, &ls) || !get_bytes(env, argv[3], &pk, &lp) ||
+        !get_bytes(env, argv[4], &which, &lw) || !get_bytes(env, argv[5], &seeds, &lse))
+        return NULL;
+    size_t B = lm / 32;
+    if (lm != 32 * B || ls != 64 * B || lp != 64 * B || lw != 4 * B || lse != 32 * B) {
+        napi_throw_range_error(env, NULL, "proveBatchAsync: per proof 32-byte msgHash, 64-byte signature, 64-byte public key, u32 index, 32-byte seed");
+        return NULL;
+    }
+    Job *j = calloc(1, sizeof *j);
+    j->ctx = ctx, j->B = B;
+    j->msg = dup_bytes(msg, lm), j->sig = dup_bytes(sig, ls), j->pk = dup_bytes(pk, lp), j->seeds = dup_bytes(seeds, lse);
+    j->which = (uint32_t *)dup_bytes(which, lw);
+    j->cap = zk_proof_max_size(ctx) * (B ? B : 1);
+    j->out = malloc(j->cap ? j->cap : 1), j->off = malloc(8 * (B + 1)), j->status = malloc(4 * (B + 1));
+    return job_start(env, j, "zkattest.proveBatch");
+}
+static napi_value VerifyBatchAsync(napi_env env, napi_callback_info info) { /* same arguments as verifyBatch -> Promise */
+    napi_value argv[5];
+    if (!get_args(env, info, 5, argv)) return NULL;
+    zk_ctx *ctx = get_ctx(env, argv[0]);
+    uint8_t *msg, *proofs, *offs, *seeds;
+    size_t lm, lp, lo, ls;
+    if (!ctx || !get_bytes(env, argv[1], &msg, &lm) || !get_bytes(env, argv[2], &proofs, &lp) || !get_bytes(env, argv[3], &offs, &lo) || !get_bytes(env, argv[4], &seeds, &ls))
+        return NULL;
+    size_t B = lm / 32;
+    if (lo != 8 * (B + 1) || (seeds && ls != 32 * B)) {
+        napi_throw_range_error(env, NULL, "verifyBatchAsync: B message hashes, B + 1 offsets, B seeds or null");
+        return NULL;
+    }
+    Job *j = calloc(1, sizeof *j);
+    j->verify = 1, j->ctx = ctx, j->B = B;
+    j->msg = dup_bytes(msg, lm), j->proofs_in = dup_bytes(proofs, lp), j->off = (uint64_t *)dup_bytes(offs, lo);
+    j->seeds = seeds ? dup_bytes(seeds, ls) : NULL;
+    j->ok = malloc(B + 1), j->status = malloc(4 * (B + 1));
+    if (j->off[B] > lp) {
+        job_free(j);
+        napi_throw_range_error(env, NULL, "verifyBatchAsync: offsets beyond the proof buffer");
+        return NULL;
+    }
+    return job_start(env, j, "zkattest.verifyBatch");
+}
 static napi_value ProofToJson(napi_env env, napi_callback_info info) { /* (proof: Buffer) -> string   (writeJson, src/serde.ts:34-36) */
     napi_value argv[1];
     if (!get_args(env, info, 1, argv)) return NULL;
@@ -276,7 +385,7 @@ static napi_value Init(napi_env env, napi_value exports) {
         napi_callback fn;
     } fns[] = {{"createContext", CreateContext}, {"destroyContext", DestroyContext}, {"setParams", SetParams}, {"setRing", SetRing},
                {"synthParams", SynthParams},     {"synthWorkload", SynthWorkload},   {"proveBatch", ProveBatch}, {"verifyBatch", VerifyBatch},
-               {"proofToJson", ProofToJson},     {"proofFromJson", ProofFromJson},   {"keysToInts", KeysToInts}};
+               {"proveBatchAsync", ProveBatchAsync}, {"verifyBatchAsync", VerifyBatchAsync}, {"proofToJson", ProofToJson},     {"proofFromJson", ProofFromJson},   {"keysToInts", KeysToInts}};
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;
         if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;
