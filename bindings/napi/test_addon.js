@@ -5,6 +5,7 @@ const assert = require('assert')
 const crypto = require('crypto')
 const fs = require('fs')
 const zk = require('./zkattest.js')
+const i32 = (buf) => new Int32Array(buf.buffer, buf.byteOffset, buf.length / 4)
 
 async function main() {
     const mode = process.argv[2]
@@ -49,6 +50,27 @@ async function main() {
     assert.ok(pa.every((p, i) => p.equals(proofs[i])) && pb.length === 2 && pb[1].equals(proofs[1]))
     assert.deepStrictEqual(await eng.verifyBatchAsync(wl.msg, mixed), [true, true, false, true, true, true])
     await assert.rejects(eng.proveBatchAsync(wl.msg.slice(0, 32), wl.sig.slice(0, 64), bad, [0], wl.seeds.slice(0, 32)), /point not in group/)
+    // the reference's own test flow (test/zkpAttestList.test.ts:25-63) with REAL keys and signatures made by Node's OpenSSL:
+    // ECDSA P-256 / SHA-256 key pairs, ring = keyToInt of every public key, prove for one of them, JSON round trip, verify
+    {
+        const n = 5, mine = 3, message = Buffer.from('ZKAttest: the signer is one of the ring, nobody learns which one')
+        const pairs = Array.from({ length: n }, () => crypto.generateKeyPairSync('ec', { namedCurve: 'P-256' }))
+        const raw = pairs.map((kp) => kp.publicKey.export({ type: 'spki', format: 'der' }).slice(-65))   // 04 || X || Y
+        const ring = eng.keysToInts(Buffer.concat(raw.map((r) => r.slice(1))))
+        assert.ok(i32(ring.status).every((v) => v === 0))
+        eng.setRing(ring.keys)
+        const sig = crypto.sign('sha256', message, { key: pairs[mine].privateKey, dsaEncoding: 'ieee-p1363' })   // r || s
+        const msgHash = crypto.createHash('sha256').update(message).digest()
+        const proof = await zk.proveSignatureList(eng, msgHash, sig, raw[mine], mine)
+        assert.strictEqual(await zk.verifySignatureList(eng, msgHash, zk.readJson(zk.writeJson(proof))), true)
+        const otherHash = crypto.createHash('sha256').update('another message').digest()
+        assert.strictEqual(await zk.verifySignatureList(eng, otherHash, proof), false)
+        const stranger = crypto.generateKeyPairSync('ec', { namedCurve: 'P-256' })                       // not in the ring
+        const sig2 = crypto.sign('sha256', message, { key: stranger.privateKey, dsaEncoding: 'ieee-p1363' })
+        const p2 = await zk.proveSignatureList(eng, msgHash, sig2, stranger.publicKey.export({ type: 'spki', format: 'der' }).slice(-65), mine)
+        assert.strictEqual(await zk.verifySignatureList(eng, msgHash, p2), false)
+        eng.setRing(wl.ring)
+    }
     const k = eng.keysToInts(wl.pk)
     assert.ok(k.keys.slice(0, 32).equals(wl.pk.slice(0, 32)))
     eng.close()
