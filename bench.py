@@ -24,12 +24,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # measured on MI355X with tools/valu_peak.hip (profiles/r01_valu_peak_microbench.txt): v_mad_u64_u32 chip-wide issue rate
-# at 16 independent accumulators x 8 waves/SIMD (4.3 cycles per wave-instruction; 39.3 T/s would be 16 lanes/clk at 2.4 GHz)
-VALU_MAD_PEAK_TOPS = 36.66
+# at 16 independent accumulators x 8 waves/SIMD (4.2 cycles per wave-instruction; 39.3 T/s would be 16 lanes/clk at 2.4 GHz);
+# 36.66 and 37.11 T/s were measured on two boxes of the pool, the larger one is the denominator
+VALU_MAD_PEAK_TOPS = 37.11
 HBM_PEAK_GBPS = 8000.0
 # multiplier-pipe instructions (v_mad_u64_u32 + v_mul_lo_u32) per Tom-field Montgomery product: 2521 + 147 per
 # k_tom_commit loop iteration of 16 products (ISA histogram; nominal 171 = 81 + 81 + 9, the modulus limb that is zero
-# costs nothing); PMC: 45 086 VALU wave-instructions per commitment of 176 products = 256 instructions per product
+# costs nothing); PMC: 43 188 VALU wave-instructions per commitment of 168 products = 257 instructions per product
 MACS_PER_MODMUL = 167
 
 
@@ -42,12 +43,12 @@ TOM_COMMIT_NOMINAL = 4064      # reference: 256 dbl + 160 add (src/curves/group.
 TOM_COMMIT_BYTES = 2 * 36 + 3 * 36  # algorithmic HBM bytes per commitment: read (v, r), write (X, Y, Z)
 # PMC passes (profiles/r01_pmc_summary.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate runs, batch 16384),
 # bytes per commitment through the L2's memory-side port, keyed by comb width.  24 bits (128-byte table entries, 47 GB of
-# tables): 2 x 1303 B fetched (gfx950 tallies 16-byte-per-lane loads at half their bytes, MI355X_MICROARCH.md section HBM;
-# 22 gathers x 128 B = 2816 B expected) + 115 B written.  16 bits (112-byte entries, 235 MB): 3238 B (raw) + 111 B.
-TOM_COMMIT_PMC_BYTES = {24: 2607 + 115, 16: 3238 + 111}
+# tables): 2 x 1306 B fetched (gfx950 tallies 16-byte-per-lane loads at half their bytes, MI355X_MICROARCH.md section HBM;
+# 22 gathers x 128 B = 2816 B expected) + 113 B written.  16 bits (112-byte entries, 235 MB): 3238 B (raw) + 111 B.
+TOM_COMMIT_PMC_BYTES = {24: 2612 + 113, 16: 3238 + 111}
 # same passes, SQ counters: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave at 2 waves per SIMD (VALU pipe saturated);
-# at 24 bits SQ_WAIT_INST_ANY 0.417, SQ_WAIT_ANY (memory) 0.065
-TOM_COMMIT_VALU_ACTIVE_PER_WAVE = {24: 0.511, 16: 0.525}
+# at 24 bits SQ_WAIT_INST_ANY 0.400, SQ_WAIT_ANY (memory) 0.089
+TOM_COMMIT_VALU_ACTIVE_PER_WAVE = {24: 0.502, 16: 0.525}
 DEFAULT_COMB_BITS = 24
 
 
