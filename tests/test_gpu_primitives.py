@@ -39,6 +39,7 @@ def test_field_ops(eng):
         assert eng.test_field_op(which, 0, a, b) == [x * y % m for x, y in zip(a, b)]
         assert eng.test_field_op(which, 1, a, b) == [(x + y) % m for x, y in zip(a, b)]
         assert eng.test_field_op(which, 2, a, b) == [(x - y) % m for x, y in zip(a, b)]
+        assert eng.test_field_op(which, 4, a, b) == [(x * y - x - y) % m for x, y in zip(a, b)]  # fe_sub2
         inv = eng.test_field_op(which, 3, a, b)
         assert inv == [pow(x, -1, m) if x else 0 for x in a]  # invMod(0) = 0 (big.ts:113-119)
 

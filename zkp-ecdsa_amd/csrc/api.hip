@@ -638,7 +638,7 @@ struct DevBuf {
     ~DevBuf() { hipFree(p); }
 };
 extern "C" zk_status zk_test_field_op(zk_ctx* c, int which, int op, uint64_t count, const uint8_t* a, const uint8_t* b, uint8_t* out) {
-    if (!c || !a || !b || !out || which < 0 || which > 2 || op < 0 || op > 3) return ZK_E_ARG;
+    if (!c || !a || !b || !out || which < 0 || which > 2 || op < 0 || op > 4) return ZK_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     DevBuf da, db, dout;
     HIPCHK(c, hipMalloc(&da.p, 40 * count)); HIPCHK(c, hipMalloc(&db.p, 40 * count)); HIPCHK(c, hipMalloc(&dout.p, 40 * count));

@@ -42,11 +42,11 @@ ZK_DEV P256Pt p256_add(const P256Pt& p, const P256Pt& q) {
     auto t1 = p.y * q.y;
     auto t2 = p.z * q.z;
     auto t3 = (p.x + p.y) * (q.x + q.y);
-    auto t3b = t3 - (t0 + t1);
+    auto t3b = fe_sub2(t3, t0, t1);
     auto t4 = (p.y + p.z) * (q.y + q.z);
-    auto t4b = t4 - (t1 + t2);
+    auto t4b = fe_sub2(t4, t1, t2);
     auto x3 = (p.x + p.z) * (q.x + q.z);
-    auto y3 = x3 - (t0 + t2);
+    auto y3 = fe_sub2(x3, t0, t2);
     auto z3 = b * t2;
     auto x3b = y3 - z3;
     auto x3c = x3b + (x3b + x3b);
@@ -54,7 +54,7 @@ ZK_DEV P256Pt p256_add(const P256Pt& p, const P256Pt& q) {
     auto x3d = t1 + x3c;
     auto y3b = b * y3;
     auto t2b = t2 + t2 + t2;
-    auto y3c = (y3b - t2b) - t0;
+    auto y3c = fe_sub2(y3b, t2b, t0);
     auto y3d = y3c + (y3c + y3c);
     auto t0b = (t0 + t0 + t0) - t2b;
     auto t1b = t4b * y3d;
@@ -74,7 +74,7 @@ ZK_DEV P256Pt p256_add_mixed(const P256Pt& p, const P256Aff& q) {
     auto t0 = p.x * q.x;
     auto t1 = p.y * q.y;
     auto t3 = (p.x + p.y) * (q.x + q.y);
-    auto t3b = t3 - (t0 + t1);
+    auto t3b = fe_sub2(t3, t0, t1);
     auto t4b = q.y * p.z + p.y;   // (y1+z1)(y2+1) - t1 - z1
     auto y3 = q.x * p.z + p.x;    // (x1+z1)(x2+1) - t0 - z1
     auto z3 = b * p.z;
@@ -84,7 +84,7 @@ ZK_DEV P256Pt p256_add_mixed(const P256Pt& p, const P256Aff& q) {
     auto x3d = t1 + x3c;
     auto y3b = b * y3;
     auto t2b = p.z + p.z + p.z;
-    auto y3c = (y3b - t2b) - t0;
+    auto y3c = fe_sub2(y3b, t2b, t0);
     auto y3d = y3c + (y3c + y3c);
     auto t0b = (t0 + t0 + t0) - t2b;
     auto t1b = t4b * y3d;
@@ -115,7 +115,7 @@ ZK_DEV P256Pt p256_dbl(const P256Pt& p) {
     auto y3d = x3 * y3c;
     auto x3b = x3 * t3b;
     auto t2b = t2 + t2 + t2;
-    auto z3c = (b * z3b - t2b) - t0;
+    auto z3c = fe_sub2(b * z3b, t2b, t0);
     auto z3d = z3c + (z3c + z3c);
     auto t0b = (t0 + t0 + t0) - t2b;
     auto y3e = y3d + t0b * z3d;
@@ -185,7 +185,7 @@ ZK_DEV TomPt tom_add_niels(const TomPt& p, const TomNielsT<KX>& q) {
     auto A = p.x * q.x;
     auto B = p.y * q.y;
     auto C = p.t * q.dt;
-    auto E = ((p.x + p.y) * (q.x + q.y) - A) - B;
+    auto E = fe_sub2((p.x + p.y) * (q.x + q.y), A, B);
     auto F = p.z - C;
     auto G = p.z + C;
     auto H = B - A;
@@ -202,7 +202,7 @@ ZK_DEV TomPt tom_add_niels_last(const TomPt& p, const TomNielsT<KX>& q) {
     auto A = p.x * q.x;
     auto B = p.y * q.y;
     auto C = p.t * q.dt;
-    auto E = ((p.x + p.y) * (q.x + q.y) - A) - B;
+    auto E = fe_sub2((p.x + p.y) * (q.x + q.y), A, B);
     auto F = p.z - C;
     auto G = p.z + C;
     auto H = B - A;
@@ -231,7 +231,7 @@ ZK_DEV TomPt tom_add(const TomPt& p, const TomPt& q) {
     auto B = p.y * q.y;
     auto C = (p.t * q.t) * d1;
     auto D = p.z * q.z;
-    auto E = ((p.x + p.y) * (q.x + q.y) - A) - B;
+    auto E = fe_sub2((p.x + p.y) * (q.x + q.y), A, B);
     auto F = D - C;
     auto G = D + C;
     auto H = B - A;
@@ -249,7 +249,7 @@ ZK_DEV TomPt tom_dbl(const TomPt& p) {
     auto Cz = p.z * p.z;
     auto C = Cz + Cz;
     auto xy = p.x + p.y;
-    auto E = (xy * xy - A) - B;
+    auto E = fe_sub2(xy * xy, A, B);
     auto G = A + B;
     auto F = G - C;
     auto H = A - B;

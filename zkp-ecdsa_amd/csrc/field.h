@@ -82,6 +82,30 @@ ZK_DEV Fe<M, Ka + SubC<Kb>::value> operator-(const Fe<M, Ka>& a, const Fe<M, Kb>
     limbs_normalize(r.l);
     return r;
 }
+// a - b - c with one carry pass: a + C*M - b - c, C the smallest power of two > Kb + Kc.  The redundant form of C*M used
+// by operator- has limbs >= 2^30 - 1 (one subtrahend limb); lending once more along the chain (+2^30, +2^30 - 1, ..., -1:
+// the value is unchanged) makes them >= 2^31 - 2, enough for two subtrahend limbs, and keeps a + s below 2^32.
+template <class M, int Ka, int Kb, int Kc>
+ZK_DEV Fe<M, Ka + SubC<Kb + Kc>::value> fe_sub2(const Fe<M, Ka>& a, const Fe<M, Kb>& b, const Fe<M, Kc>& c) {
+    constexpr int C = SubC<Kb + Kc>::value;
+    static_assert(Ka + C <= KCAP, "magnitude overflow");
+    Fe<M, Ka + C> r;
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) {
+        uint32_t s;
+        if constexpr (C == 4) s = M::sub4[i];
+        else if constexpr (C == 8) s = M::sub8[i];
+        else if constexpr (C == 16) s = M::sub16[i];
+        else if constexpr (C == 32) s = M::sub32[i];
+        else if constexpr (C == 64) s = M::sub64[i];
+        else if constexpr (C == 128) s = M::sub128[i];
+        else s = M::sub256[i];
+        s += i == 0 ? (1u << LIMB_BITS) : i < NLIMB - 1 ? LIMB_MASK : 0xffffffffu;
+        r.l[i] = a.l[i] + s - b.l[i] - c.l[i];
+    }
+    limbs_normalize(r.l);
+    return r;
+}
 template <class M, int Ka>
 ZK_DEV Fe<M, SubC<Ka>::value> fe_neg(const Fe<M, Ka>& a) {
     Fe<M, 0> z;
@@ -111,6 +135,9 @@ ZK_DEV void mod_limbs(uint32_t md[NLIMB]) {
 #endif
     }
 }
+#ifndef ZK_PIN_LIMBS32
+#define ZK_PIN_LIMBS32 1
+#endif
 // Montgomery product, product-scanning with a single 64-bit accumulator (no carry flags).
 template <class M>
 ZK_DEV void limbs_mont_mul(uint32_t out[NLIMB], const uint32_t a[NLIMB], const uint32_t b[NLIMB]) {
@@ -137,6 +164,14 @@ ZK_DEV void limbs_mont_mul(uint32_t out[NLIMB], const uint32_t a[NLIMB], const u
         acc >>= LIMB_BITS;
     }
     out[NLIMB - 1] = (uint32_t)acc;
+#if ZK_PIN_LIMBS32
+    // Keep every result limb a 32-bit VGPR value (empty asm, no instruction).  Without this the optimiser carries some
+    // products across basic blocks as the 64-bit (acc & mask) they were truncated from; instruction selection works per
+    // block, cannot prove the high halves zero there, and multiplies them as 64 x 32 bits: +72 v_mad_u64_u32 and
+    // +144 v_mov_b32 per table addition in k_tom_commit's loop (ISA inspection; ZK_PIN_LIMBS32=0 shows the old code).
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) asm("" : "+v"(out[i]));
+#endif
 }
 template <class M, int Ka, int Kb>
 ZK_DEV Fe<M, 2> operator*(const Fe<M, Ka>& a, const Fe<M, Kb>& b) {

@@ -713,7 +713,10 @@ ZK_DEV void test_field_one(int op, const uint8_t* a, const uint8_t* b, uint8_t* 
     if (op == 0) r = fe_mul_mod(x, y);
     else if (op == 1) r = fe_add_mod(x, y);
     else if (op == 2) r = fe_sub_mod(x, y);
-    else r = fe_from_mont(fe_inv<M>(fe_to_mont(x)));
+    else if (op == 4) {  // x*y - x - y through the fused double subtraction (the E term of the Edwards addition)
+        auto xm = fe_to_mont(x), ym = fe_to_mont(y);
+        r = fe_from_mont(fe_sub2(xm * ym, xm, ym));
+    } else r = fe_from_mont(fe_inv<M>(fe_to_mont(x)));
     uint32_t rw[10];
     words_from_limbs<9>(rw, r.l);
     rw[9] = 0;

@@ -25,6 +25,16 @@ ZK_DEV TomNiels ld_niels(const uint32_t* e) {
     return n;
 }
 
+// An entry is loaded one window ahead and crosses the loop back edge.  At its point of USE its limbs are pinned as 32-bit
+// values (see limbs_mont_mul: otherwise some reach the multiplier as 64-bit pieces of the dwordx4 loads).  Not at the load:
+// the asm operand would make the wave wait for the gather it has just issued.
+ZK_DEV void niels_pin(TomNiels& n) {
+#if ZK_PIN_LIMBS32
+#pragma unroll
+    for (int l = 0; l < 9; l++) asm("" : "+v"(n.x.l[l]), "+v"(n.y.l[l]), "+v"(n.dt.l[l]));
+#endif
+}
+
 // unpaired / paired commitment slots of list B (see k_tom_commit_pairs)
 __device__ const uint8_t LB_SINGLE_K[22] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 17, 18, 19, 20, 23, 24, 25, 26, 29};
 __device__ const uint8_t LB_PAIR_K[6] = {9, 15, 21, 27, 30, 32};
@@ -46,6 +56,9 @@ struct CombDigits {
         neg = sgn && d > half;
         carry = neg ? 1u : 0u;
         idx = neg ? (mask + 1) - d : d;
+#ifdef ZK_DEBUG_IDX_MASK  // timing experiments only (wrong results): confine the gathers to the first entries of each window
+        idx &= ZK_DEBUG_IDX_MASK;
+#endif
     }
 };
 template <bool SGN>
@@ -80,24 +93,31 @@ __global__ void __launch_bounds__(256, OCC) k_tom_commit(const uint32_t* __restr
     }
     const uint32_t ent = tom_win_entries(bits);
     TomPt acc = tom_identity();
-    // software pipeline: the gathers of window w+1 are issued before the two additions of window w
+    // software pipeline, one addition deep: the h-entry of window w is gathered during the g-addition of window w, the
+    // g-entry of window w+1 during the h-addition (one entry in flight, one in use: 54 VGPRs instead of 108)
     uint32_t dv, dr;
-    bool sv, sr, nsv = false, nsr = false;
-    dgv.next(dv, sv), dgr.next(dr, sr);
-    TomNiels ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * dv);
-    TomNiels nh = ld_niels(tab_h + (size_t)TOM_ENTRY_WORDS * dr);
+    bool sv, sr;
+    dgv.next(dv, sv);
+    TomNiels ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * dv), nh;
 #pragma unroll 1
     for (uint32_t w = 0; w < nwin; w++) {
-        typename NielsSel<SGN>::T cg = NielsSel<SGN>::sel(ng, sv), ch = NielsSel<SGN>::sel(nh, sr);
-        if (w + 1 < nwin) {
-            dgv.next(dv, nsv), dgr.next(dr, nsr);
-            size_t base = (size_t)(w + 1) * ent;
-            ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * (base + dv));
-            nh = ld_niels(tab_h + (size_t)TOM_ENTRY_WORDS * (base + dr));
+        size_t base = (size_t)w * ent;
+        dgr.next(dr, sr);
+        nh = ld_niels(tab_h + (size_t)TOM_ENTRY_WORDS * (base + dr));
+        niels_pin(ng);
+        {
+            typename NielsSel<SGN>::T cg = NielsSel<SGN>::sel(ng, sv);
+            acc = w == 0 ? tom_from_niels(cg) : tom_add_niels(acc, cg);                  // first step: identity + entry
         }
-        sv = nsv, sr = nsr;
-        acc = w == 0 ? tom_from_niels(cg) : tom_add_niels(acc, cg);                    // first step: identity + entry
-        acc = w + 1 == nwin ? tom_add_niels_last(acc, ch) : tom_add_niels(acc, ch);    // last step: nobody reads T
+        if (w + 1 < nwin) {
+            dgv.next(dv, sv);
+            ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * (base + ent + dv));
+        }
+        niels_pin(nh);
+        {
+            typename NielsSel<SGN>::T ch = NielsSel<SGN>::sel(nh, sr);
+            acc = w + 1 == nwin ? tom_add_niels_last(acc, ch) : tom_add_niels(acc, ch);  // last step: nobody reads T
+        }
     }
     soa_st(L.proj.x, slot, acc.x);
     soa_st(L.proj.y, slot, acc.y);
@@ -124,6 +144,7 @@ ZK_DEV TomPt tom_comb_acc(TomPt acc, const uint32_t* __restrict__ tab, uint32_t*
     TomNiels nx = ld_niels(tab + (size_t)TOM_ENTRY_WORDS * d);
 #pragma unroll 1
     for (uint32_t w = 0; w < nwin; w++) {
+        niels_pin(nx);
         typename NielsSel<SGN>::T cur = NielsSel<SGN>::sel(nx, sg);
         if (w + 1 < nwin) {
             dg.next(d, nsg);
