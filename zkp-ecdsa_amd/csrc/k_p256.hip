@@ -192,7 +192,10 @@ __global__ void __launch_bounds__(256) k_p256_normalize(Soa3 proj, uint32_t coun
         soa_st(oy, e, z);  // sanitised z
         acc = acc * z;
     }
-    Fq2 inv = fe_inv<ModQ>(acc);
+    // running inverse in the plain domain (see k_tom_normalize): x and y come out plain, no from-Montgomery products
+    Fe<ModQ, 1> one = fe_zero<ModQ>();
+    one.l[0] = 1;
+    Fq2 inv = fe_inv<ModQ>(acc) * one;
     for (int j = (int)per - 1; j >= 0; j--) {
         uint32_t e = t + (uint32_t)j * nthreads;
         if (e >= count) continue;
@@ -201,8 +204,8 @@ __global__ void __launch_bounds__(256) k_p256_normalize(Soa3 proj, uint32_t coun
         inv = inv * z;
         Fq2 x = soa_ld<ModQ, 8>(proj.x, e) * zi;
         Fq2 y = soa_ld<ModQ, 8>(proj.y, e) * zi;
-        soa_st(ox, e, fe_from_mont(x));
-        soa_st(oy, e, fe_from_mont(y));
+        soa_st(ox, e, fe_canon(x));
+        soa_st(oy, e, fe_canon(y));
     }
 }
 void launch_p256_normalize(hipStream_t s, const Soa3& proj, uint32_t count, const Soa& ox, const Soa& oy, int32_t* st, uint32_t per_proof,
