@@ -30,7 +30,7 @@ VALU_MAD_PEAK_TOPS = 37.11
 HBM_PEAK_GBPS = 8000.0
 # multiplier-pipe instructions (v_mad_u64_u32 + v_mul_lo_u32) per Tom-field Montgomery product: 1224 + 1218 + 72 + 71 per
 # k_tom_commit loop iteration of 16 products (tools/isa_blocks.py; nominal 171 = 81 + 81 + 9, the modulus limb that is zero
-# costs nothing); PMC: 41 274 VALU wave-instructions per commitment of 168 products = 246 instructions per product
+# costs nothing); PMC: 40 112 VALU wave-instructions per commitment of 168 products = 239 instructions per product
 MACS_PER_MODMUL = 162
 
 
@@ -43,12 +43,12 @@ TOM_COMMIT_NOMINAL = 4064      # reference: 256 dbl + 160 add (src/curves/group.
 TOM_COMMIT_BYTES = 2 * 36 + 3 * 36  # algorithmic HBM bytes per commitment: read (v, r), write (X, Y, Z)
 # PMC passes (profiles/r01_pmc_summary.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate runs, batch 16384),
 # bytes per commitment through the L2's memory-side port, keyed by comb width.  24 bits (128-byte table entries, 47 GB of
-# tables): 2 x 1306 B fetched (gfx950 tallies 16-byte-per-lane loads at half their bytes, MI355X_MICROARCH.md section HBM;
-# 22 gathers x 128 B = 2816 B expected) + 113 B written.  16 bits (112-byte entries, 235 MB): 3238 B (raw) + 111 B.
-TOM_COMMIT_PMC_BYTES = {24: 2612 + 113, 16: 3238 + 111}
+# tables): 2 x 1305 B fetched (gfx950 tallies 16-byte-per-lane loads at half their bytes, MI355X_MICROARCH.md section HBM;
+# 22 gathers x 128 B = 2816 B expected) + 111 B written.  16 bits (112-byte entries, 235 MB): 3238 B (raw) + 111 B.
+TOM_COMMIT_PMC_BYTES = {24: 2610 + 111, 16: 3238 + 111}
 # same passes, SQ counters at 24 bits: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave at 2 waves per SIMD (VALU pipe busy
-# 96 % of the time), SQ_WAIT_INST_ANY 0.365, SQ_WAIT_ANY (memory) 0.145
-TOM_COMMIT_VALU_ACTIVE_PER_WAVE = {24: 0.482}
+# 98 % of the time), SQ_WAIT_INST_ANY 0.400, SQ_WAIT_ANY (memory) 0.101
+TOM_COMMIT_VALU_ACTIVE_PER_WAVE = {24: 0.491}
 DEFAULT_COMB_BITS = 24
 
 
