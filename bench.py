@@ -115,6 +115,8 @@ def main():
     ap.add_argument('--lanes', type=int, default=2, help='chunks in flight on separate streams during the timed steps (1 = serial)')
     ap.add_argument('--roofline-steps', type=int, default=1, help='extra single-lane passes used only for per-kernel timings')
     ap.add_argument('--verify-steps', type=int, default=1, help='timed verifySignatureList passes over the produced proofs (0 = skip)')
+    ap.add_argument('--host-io', type=int, default=8192, help='proofs of one extra zk_prove_batch call on HOST buffers (PCIe-inclusive rate, reported apart; 0 = skip)')
+    ap.add_argument('--host-io-chunk', type=int, default=4096, help='proofs per pipeline pass during the --host-io calls')
     ap.add_argument('--check', type=int, default=1 << 30, help='proofs of the last step diffed against the oracle on rank 0 (at most the CPU sample)')
     args = ap.parse_args()
 
@@ -289,6 +291,29 @@ def main():
             for b in range(ncheck):
                 assert raw[int(off[b]):int(off[b + 1])] == oproofs[b], 'GPU proof %d differs from the oracle' % b
             cpu['checked_bit_exact'] = ncheck
+        host_io = None
+        if args.host_io > 0 and world == 1:
+            # the same work through HOST buffers (zk_prove_batch / zk_verify_batch): H2D of the inputs, proving, D2H of the proofs,
+            # and back in for the verifier; with pageable memory and with page-locked buffers from zk_host_alloc.  Never `value`.
+            nb = min(args.host_io, B)
+            hm, hs, hp, hw, hseed = msg[:32 * nb], sig[:64 * nb], pk[:64 * nb], which[:nb], seeds[:32 * nb]
+            eng.prove_batch_host_raw(hm[:32 * 256], hs[:64 * 256], hp[:64 * 256], hw[:256], hseed[:32 * 256])   # warm-up
+            host_io = {'proofs': nb, 'note': 'PCIe-inclusive rates of the host-pointer entry points, not the headline value'}
+            t_pin = time.time()
+            pin = Z.PinnedBuffer(int(nb * (304 + 336 * sec + 3392 * (sec // 2 + 4) + (4 * 72 + 96) * 20 + 32) + (64 << 20)))
+            host_io['zk_host_alloc'] = {'bytes': pin.nbytes, 'seconds': round(time.time() - t_pin, 4)}
+            eng.set_chunk(min(args.host_io_chunk, nb))   # smaller chunks: more of the transfer hides under the other chunks' kernels
+            for name, buf in (('pageable', None), ('pinned', pin)):
+                for _ in range(2):  # the second call: the engine's device staging buffer is allocated once and kept
+                    hdt, hout, hoff, hst = eng.prove_batch_host_raw(hm, hs, hp, hw, hseed, out=buf)
+                    vdt, vok, vst = eng.verify_batch_host_raw(hm, hout, hoff, nb)
+                host_io[name] = {'prove_s': round(hdt, 4), 'proofs_per_s': round(nb / hdt, 1), 'verify_s': round(vdt, 4),
+                                 'verifies_per_s': round(nb / vdt, 1), 'out_bytes': int(hoff[nb]),
+                                 'failed_proofs': sum(1 for x in hst if x != 0), 'accepted': sum(1 for x in vok if x == 1)}
+                del hout
+            pin.free()
+            host_io['chunk'] = min(args.host_io_chunk, nb)
+            eng.set_chunk(min(args.chunk, B))
         ms_per_step = dt * 1e3 / args.steps
         line = {
             'metric': 'proveSignatureList proofs/sec', 'value': round(world * B * args.steps / dt, 2), 'unit': 'proofs/s',
@@ -303,7 +328,7 @@ def main():
             'proof_bytes_per_step': total_bytes, 'failed_proofs': nbad,
             'gpu_ms_by_family_per_step': {k: round(v / max(1, args.roofline_steps), 2) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
             'gpu_ms_note': 'serial single-lane pass (sum = %.1f ms); the timed steps overlap two chunks on two streams' % (gpu_ms / max(1, args.roofline_steps)),
-            'roofline': roofline, 'cpu_baseline': cpu, 'verify': verify,
+            'roofline': roofline, 'cpu_baseline': cpu, 'verify': verify, 'host_io': host_io,
         }
         print(json.dumps(line))
     if world > 1:

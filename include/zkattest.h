@@ -32,6 +32,7 @@
  */
 #ifndef ZKATTEST_H
 #define ZKATTEST_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -116,10 +117,18 @@ zk_status zk_ctx_set_batch_verify(zk_ctx *ctx, uint32_t min_chunk);
 /* Upper bound of one proof's ZKA1 size for the current params/ring. */
 uint64_t zk_proof_max_size(const zk_ctx *ctx);
 
+/* Page-locked host memory for the big buffers of the host-pointer entry points (`out` of zk_prove_batch, `proofs` of
+ * zk_verify_batch: ~169 KB per proof at secLevel 80).  With such a buffer the proof bytes move by DMA chunk by chunk while
+ * the neighbouring chunks are being proved / verified; with ordinary (pageable) memory the runtime stages one blocking copy
+ * through its own bounce buffers (measured 8.6 GB/s, several times the proving time).  Memory that the caller page-locked
+ * itself (hipHostMalloc, hipHostRegister) is recognised too.  NULL when the allocation fails. */
+void *zk_host_alloc(size_t bytes);
+void zk_host_free(void *p);
+
 /* Replaces B calls of proveSignatureList(params, msgHash, sigBytes, publicKey, which, keys)
  * (src/zkpAttestList.ts:104-145).  pk_xy is the WebCrypto 'raw' export without its 0x04 prefix.
  * out receives the proofs back to back; out_off[b]..out_off[b+1] delimits proof b (empty when
- * per_proof_status[b] != 0).  Host pointers. */
+ * per_proof_status[b] != 0).  Host pointers; `out` from zk_host_alloc is filled by overlapped DMA. */
 zk_status zk_prove_batch(zk_ctx *ctx, uint64_t B, const uint8_t *msg_hash /*Bx32*/, const uint8_t *sig /*Bx64*/,
                          const uint8_t *pk_xy /*Bx64*/, const uint32_t *which /*B*/, const zk_rng *rng,
                          uint8_t *out, uint64_t out_cap, uint64_t *out_off /*B+1*/, int32_t *per_proof_status /*B*/);
@@ -140,7 +149,8 @@ zk_status zk_prove_batch_device(zk_ctx *ctx, uint64_t B, const void *d_msg_hash,
  * boolean; the engine draws its own 128-bit ones (from the same seed).  The seeds must be unpredictable to whoever made
  * the proofs and independent across proofs.  NULL: the engine draws fresh OS randomness for the call (what the
  * reference does with crypto.getRandomValues); pass seeds only to reproduce a run.
- * proofs must be packed back to back (proof_off[0] = 0, 4-byte aligned).  Host pointers. */
+ * proofs must be packed back to back (proof_off[0] = 0, 4-byte aligned).  Host pointers; `proofs` from zk_host_alloc is
+ * read by overlapped DMA. */
 zk_status zk_verify_batch(zk_ctx *ctx, uint64_t B, const uint8_t *msg_hash /*Bx32*/, const uint8_t *proofs,
                           const uint64_t *proof_off /*B+1*/, const uint8_t *verifier_seeds /*Bx32 or NULL*/,
                           uint8_t *ok /*B*/, int32_t *per_proof_status /*B*/);

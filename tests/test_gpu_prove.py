@@ -213,3 +213,41 @@ def test_c_abi_demo_program_runs(tmp_path):
     res = subprocess.run([str(out), '5', '16'], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert 'round trip identical' in res.stdout and 'verified 5 of 5' in res.stdout and 'ok[0] = 0' in res.stdout
+
+
+def test_page_locked_host_buffers_give_the_same_bytes_and_verdicts():
+    """zk_host_alloc: `out` of zk_prove_batch is filled by per-chunk DMA behind the kernels, `proofs` of zk_verify_batch is read
+    the same way; bytes, offsets, statuses and verdicts must equal those of pageable buffers (several ragged chunks, both lanes)."""
+    import ctypes as C
+    import zkp_ecdsa_amd as Z
+    eng, octx, (msg, sig, pk, which, seeds) = _setup(31337, 64, 23)
+    ref, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert st == [0] * 23
+    pin = Z.PinnedBuffer(eng.proof_max_size() * 23)
+    for chunk, lanes in ((5, 2), (23, 1), (8, 1), (4, 2)):
+        eng.set_chunk(chunk), eng.set_lanes(lanes)
+        C.memset(pin.ptr, 0xA5, pin.nbytes)
+        _, out, off, pst = eng.prove_batch_host_raw(msg, sig, pk, which, seeds, out=pin)
+        assert list(pst) == [0] * 23 and off[0] == 0
+        raw = bytes(pin.view[:off[23]])
+        assert [raw[off[b]:off[b + 1]] for b in range(23)] == ref, (chunk, lanes)
+        vs = b''.join(hashlib.sha256(b'pl' + bytes([i])).digest() for i in range(23))
+        _, ok, vst = eng.verify_batch_host_raw(msg, pin, off, 23, vseeds=vs)
+        assert list(ok) == [1] * 23 and list(vst) == [0] * 23
+        # a forged proof inside the page-locked buffer is found, the others still pass
+        pos = off[7 + 1] - 1
+        pin.view[pos] ^= 1
+        _, ok, vst = eng.verify_batch_host_raw(msg, pin, off, 23, vseeds=vs)
+        assert list(ok) == [1] * 7 + [0] + [1] * 15
+        pin.view[pos] ^= 1
+        # the same packed bytes from pageable memory
+        page = (C.c_uint8 * off[23]).from_buffer_copy(raw)
+        _, ok2, vst2 = eng.verify_batch_host_raw(msg, page, off, 23, vseeds=vs)
+        assert list(ok2) == [1] * 23 and list(vst2) == [0] * 23
+    # an `out` that is too small is reported, not overrun
+    small = Z.PinnedBuffer(len(ref[0]) * 3)
+    with pytest.raises(Z.ZkError):
+        eng.prove_batch_host_raw(msg, sig, pk, which, seeds, out=small)
+    small.free()
+    pin.free()
+    eng.close()

@@ -14,7 +14,7 @@ SYMBOLS = [
     'zk_ctx_create', 'zk_ctx_destroy', 'zk_strerror', 'zk_last_error', 'zk_ctx_set_params', 'zk_ctx_set_ring',
     'zk_ctx_set_ring_device', 'zk_keys_to_ints', 'zk_ctx_set_chunk', 'zk_ctx_set_lanes', 'zk_ctx_set_comb_bits', 'zk_ctx_set_batch_verify', 'zk_proof_max_size', 'zk_prove_batch', 'zk_prove_batch_device',
     'zk_verify_batch', 'zk_verify_batch_device', 'zk_synth_workload', 'zk_synth_params', 'zk_last_timing',
-    'zk_proof_to_json', 'zk_proof_from_json',
+    'zk_proof_to_json', 'zk_proof_from_json', 'zk_host_alloc', 'zk_host_free',
     'zk_test_field_op', 'zk_test_tom_commit', 'zk_test_p256_fixed_mul', 'zk_test_sha256', 'zk_test_rng_draws',
 ]
 
@@ -66,7 +66,11 @@ def lib():
         L.zk_proof_max_size.restype = u64
         L.zk_prove_batch.argtypes = [vp, u64, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(ZkRng), vp, u64, vp, vp]
         L.zk_prove_batch_device.argtypes = [vp, u64, vp, vp, vp, vp, C.POINTER(ZkRng), vp, u64, vp, vp]
-        L.zk_verify_batch.argtypes = [vp, u64, C.c_char_p, C.c_char_p, vp, C.c_char_p, vp, vp]
+        L.zk_verify_batch.argtypes = [vp, u64, C.c_char_p, vp, vp, C.c_char_p, vp, vp]
+        L.zk_host_alloc.argtypes = [C.c_size_t]
+        L.zk_host_alloc.restype = vp
+        L.zk_host_free.argtypes = [vp]
+        L.zk_host_free.restype = None
         L.zk_verify_batch_device.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]
         L.zk_synth_workload.argtypes = [vp, u64, u64, u64, vp, vp, vp, vp, vp, vp]
         L.zk_synth_params.argtypes = [vp, u64, vp, vp, vp]
@@ -81,6 +85,29 @@ def lib():
         L.zk_test_rng_draws.argtypes = [vp, u64, C.POINTER(ZkRng), u32, u32, vp]
         _lib = L
     return _lib
+
+
+class PinnedBuffer:
+    """Page-locked host memory from zk_host_alloc (include/zkattest.h): .ptr for the C ABI, .view as a ctypes byte array."""
+
+    def __init__(self, nbytes):
+        self.nbytes = nbytes
+        self.ptr = lib().zk_host_alloc(nbytes)
+        if not self.ptr:
+            raise MemoryError('zk_host_alloc(%d) failed' % nbytes)
+        self.view = (C.c_uint8 * nbytes).from_address(self.ptr)
+
+    def free(self):
+        if self.ptr:
+            self.view = None
+            lib().zk_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class ZkError(RuntimeError):
@@ -204,6 +231,39 @@ class Engine:
         raw = out.raw
         proofs = [raw[off[b]:off[b + 1]] if st[b] == 0 else None for b in range(B)]
         return proofs, list(st)
+
+    def prove_batch_host_raw(self, msg, sig, pk, which, seeds, out=None):
+        """zk_prove_batch on host buffers without slicing the output.  out: a PinnedBuffer (overlapped DMA) or None (a pageable
+        buffer is allocated).  Returns (wall seconds of the C call, out buffer, offsets, statuses)."""
+        import time
+        B = len(which)
+        cap = self.proof_max_size() * max(B, 1)
+        if out is None:
+            out = (C.c_uint8 * cap)()
+            optr = C.addressof(out)
+        else:
+            cap = min(cap, out.nbytes)
+            optr = out.ptr
+        off = (C.c_uint64 * (B + 1))()
+        st = (C.c_int32 * B)()
+        w = (C.c_uint32 * B)(*which)
+        data = C.create_string_buffer(bytes(seeds), 32 * B)
+        rng = ZkRng(0, C.cast(data, C.c_void_p), 0)
+        msg, sig, pk = bytes(msg), bytes(sig), bytes(pk)
+        t0 = time.time()
+        self._chk(self.L.zk_prove_batch(self.h, B, msg, sig, pk, w, C.byref(rng), optr, cap, off, st))
+        return time.time() - t0, out, off, st
+
+    def verify_batch_host_raw(self, msg, proofs, off, B, vseeds=None):
+        """zk_verify_batch on a packed host buffer (PinnedBuffer or ctypes array) with offsets `off`.  Returns (seconds, ok, status)."""
+        import time
+        ok = (C.c_uint8 * B)()
+        st = (C.c_int32 * B)()
+        ptr = proofs.ptr if isinstance(proofs, PinnedBuffer) else C.addressof(proofs)
+        msg = bytes(msg)
+        t0 = time.time()
+        self._chk(self.L.zk_verify_batch(self.h, B, msg, ptr, off, bytes(vseeds) if vseeds is not None else None, ok, st))
+        return time.time() - t0, ok, st
 
     def prove_batch_device(self, B, d_msg, d_sig, d_pk, d_which, d_seeds, d_out, out_cap, d_off, d_status, mode=0, stride_blocks=0):
         rng = ZkRng(mode, d_seeds, stride_blocks)

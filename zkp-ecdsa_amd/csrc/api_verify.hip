@@ -109,8 +109,10 @@ __global__ void k_default_vseeds(uint64_t B, const uint8_t* master, uint8_t* out
     for (int i = 0; i < 8; i++) ((uint32_t*)out)[8 * b + i] = bswap32(h[i]);
 }
 
+// host_src / host_off: page-locked source of the proof bytes and the host copy of the offsets (or nullptr): the bytes of chunk k
+// travel on c->copy_stream while earlier chunks are being verified; the chunk's lane waits for its own copy only.
 static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const uint8_t* d_proofs, const uint64_t* d_off, const uint8_t* d_vseeds, uint8_t* d_ok,
-                               int32_t* d_status) {
+                               int32_t* d_status, const uint8_t* host_src = nullptr, const uint64_t* host_off = nullptr) {
     if (!c->params_set || !c->N) return ZK_E_BUFFER;
     if (c->P.sec < VK) return ZK_E_SECLEVEL;
     if (B == 0) return ZK_OK;
@@ -226,23 +228,43 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
         return ZK_OK;
     };
     const uint64_t nchunks = (B + C - 1) / C;
-    for (uint64_t k = 0; k < nchunks; k++) {
-        if (k == 0 || !dual) {
-            zs = stage1(k * C, (uint32_t)k);
-            if (zs) return zs;
+    std::vector<hipEvent_t> arrived;  // host_src: one event per chunk, recorded on the copy stream behind the chunk's bytes
+    auto release = [&] {
+        for (auto e : arrived) hipEventDestroy(e);
+        if (own_seeds) hipFree(own_seeds);
+    };
+    if (host_src) {
+        arrived.resize(nchunks, nullptr);
+        for (uint64_t k = 0; k < nchunks; k++) {
+            uint64_t b0 = host_off[k * C], b1 = host_off[std::min<uint64_t>(B, (k + 1) * C)];
+            if (hipEventCreateWithFlags(&arrived[k], hipEventDisableTiming) != hipSuccess ||
+                (b1 > b0 && hipMemcpyAsync((uint8_t*)d_proofs + b0, host_src + b0, b1 - b0, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess) ||
+                hipEventRecord(arrived[k], c->copy_stream) != hipSuccess) {
+                c->err = "host-to-device copy of the proofs failed";
+                hipStreamSynchronize(c->copy_stream);
+                release();
+                return ZK_E_DEVICE;
+            }
         }
-        if (dual && k + 1 < nchunks) {
-            zs = stage1((k + 1) * C, (uint32_t)(k + 1));
-            if (zs) return zs;
-        }
-        zs = stage2(k * C, (uint32_t)k);
-        if (zs) return zs;
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (dual) HIPCHK(c, hipStreamSynchronize(c->stream2));
+    auto stage1w = [&](uint64_t k) -> zk_status {
+        if (host_src) HIPCHK(c, hipStreamWaitEvent((dual && (k & 1)) ? c->stream2 : c->stream, arrived[k], 0));
+        return stage1(k * C, (uint32_t)k);
+    };
+    for (uint64_t k = 0; k < nchunks && !zs; k++) {
+        if (k == 0 || !dual) zs = stage1w(k);
+        if (!zs && dual && k + 1 < nchunks) zs = stage1w(k + 1);
+        if (!zs) zs = stage2(k * C, (uint32_t)k);
+    }
+    hipError_t e1 = hipStreamSynchronize(c->stream), e2 = dual ? hipStreamSynchronize(c->stream2) : hipSuccess;
+    hipError_t e3 = host_src ? hipStreamSynchronize(c->copy_stream) : hipSuccess;
+    release();
+    if (zs) return zs;
+    HIPCHK(c, e1);
+    HIPCHK(c, e2);
+    HIPCHK(c, e3);
     HIPCHK(c, hipGetLastError());
     timing_end(c);
-    if (own_seeds) hipFree(own_seeds);
     return ZK_OK;
 }
 
@@ -264,22 +286,35 @@ extern "C" zk_status zk_verify_batch(zk_ctx* c, uint64_t B, const uint8_t* msg, 
     uint64_t* d_off = nullptr;
     int32_t* d_st = nullptr;
     HIPCHK(c, hipMalloc(&d_msg, 32 * B));
-    HIPCHK(c, hipMalloc(&d_proofs, total + 64));
+    {
+        zk_status ze = ensure_io_buf(c, total + 64);
+        if (ze) return ze;
+        d_proofs = (uint8_t*)c->io_buf;
+    }
     HIPCHK(c, hipMalloc(&d_off, 8 * (B + 1)));
     HIPCHK(c, hipMalloc(&d_ok, B));
     HIPCHK(c, hipMalloc(&d_st, 4 * B));
     HIPCHK(c, hipMemcpy(d_msg, msg, 32 * B, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(d_proofs, proofs, total, hipMemcpyHostToDevice));
+    // page-locked `proofs` (zk_host_alloc): chunk-wise DMA under the kernels of the earlier chunks; pageable: one blocking copy
+    const bool pinned = host_ptr_is_pinned(proofs);
+    if (pinned) {
+        for (uint64_t b = 0; b < B; b++)
+            if (off[b + 1] < off[b]) return ZK_E_ARG;
+        zk_status ze = ensure_copy_stream(c);
+        if (ze) return ze;
+    } else {
+        HIPCHK(c, hipMemcpy(d_proofs, proofs, total, hipMemcpyHostToDevice));
+    }
     HIPCHK(c, hipMemcpy(d_off, off, 8 * (B + 1), hipMemcpyHostToDevice));
     if (vseeds) {
         HIPCHK(c, hipMalloc(&d_seeds, 32 * B));
         HIPCHK(c, hipMemcpy(d_seeds, vseeds, 32 * B, hipMemcpyHostToDevice));
     }
-    zk_status zs = verify_device(c, B, d_msg, d_proofs, d_off, d_seeds, d_ok, d_st);
+    zk_status zs = verify_device(c, B, d_msg, d_proofs, d_off, d_seeds, d_ok, d_st, pinned ? proofs : nullptr, pinned ? off : nullptr);
     if (zs == ZK_OK) {
         HIPCHK(c, hipMemcpy(ok, d_ok, B, hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(status, d_st, 4 * B, hipMemcpyDeviceToHost));
     }
-    hipFree(d_msg), hipFree(d_proofs), hipFree(d_off), hipFree(d_ok), hipFree(d_st), hipFree(d_seeds);
+    hipFree(d_msg), hipFree(d_off), hipFree(d_ok), hipFree(d_st), hipFree(d_seeds);
     return zs;
 }

@@ -62,6 +62,11 @@ struct zk_ctx {
     size_t varena2_bytes = 0;
     Soa v2_res{}, v2_res2{};
     bool vlane2_ready = false;
+    // host-buffer entry points: DMA stream for page-locked caller buffers (zk_host_alloc), one event per lane
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_ev[2] = {nullptr, nullptr};
+    void* io_buf = nullptr;        // device staging of the proof bytes for the host-pointer entry points (grow-only: a
+    size_t io_bytes = 0;           // multi-GB hipMalloc/hipFree per call costs as much as the transfer itself)
     // timing
     std::vector<TimerRec> trecs;
     std::vector<hipEvent_t> epool;
@@ -118,6 +123,9 @@ static inline void timing_end(zk_ctx* c) {
 }
 
 zk_status ensure_workspace(zk_ctx* c, uint32_t C, bool second_lane = false);
+zk_status ensure_io_buf(zk_ctx* c, size_t bytes);  // api.hip: c->io_buf of at least `bytes`
+bool host_ptr_is_pinned(const void* p);     // api.hip: page-locked (zk_host_alloc / hipHostMalloc / hipHostRegister) host memory?
+zk_status ensure_copy_stream(zk_ctx* c);    // api.hip: c->copy_stream and c->copy_ev
 
 struct Carver {
     uint8_t* base;
