@@ -211,3 +211,19 @@ def test_batched_check_with_every_kind_of_bad_proof_in_the_chunk():
     fam = eng.last_timing()[1]
     assert 'v_msm_tom' in fam and 'v_straus_tom' not in fam
     eng.close()
+
+
+def test_offsets_that_run_backwards_are_an_argument_error():
+    import zkp_ecdsa_amd as Z
+    eng, octx, msg, proofs = _setup(5150, 4, 3)
+    import ctypes as C
+    raw = b''.join(proofs)
+    buf = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+    off = (C.c_uint64 * 4)(0, len(proofs[0]), len(proofs[0]) - 4, len(raw))
+    with pytest.raises(Z.ZkError) as e:
+        eng.verify_batch_host_raw(msg, buf, off, 3)
+    assert e.value.status == 14
+    off = (C.c_uint64 * 4)(0, len(proofs[0]), len(proofs[0]) + len(proofs[1]), len(raw))
+    _, ok, st = eng.verify_batch_host_raw(msg, buf, off, 3)
+    assert list(ok) == [1, 1, 1] and list(st) == [0, 0, 0]
+    eng.close()

@@ -3,6 +3,6 @@ mkdir -p gpurun_out/ab
 for v in "$@"; do
   lib=$PWD/zkp-ecdsa_amd/lib_exp/lib_$v.so
   [ "$v" = base ] && lib=$PWD/zkp-ecdsa_amd/lib/libzkattest_hip.so
-  ZKATTEST_LIB=$lib timeout 300 python bench.py --no-cpu-baseline --verify-steps 0 --steps 1 --warmup 1 > gpurun_out/ab/$v.json 2> gpurun_out/ab/$v.err
+  ZKATTEST_LIB=$lib timeout 300 python bench.py --no-cpu-baseline --steps 1 --warmup 1 > gpurun_out/ab/$v.json 2> gpurun_out/ab/$v.err
   echo "$v rc=$?"
 done

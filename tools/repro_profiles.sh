@@ -6,13 +6,13 @@ python bench.py > gpurun_out/b_default.log 2> gpurun_out/b_default.err
 grep '"metric"' gpurun_out/b_default.log > gpurun_out/r01_bench_line.json
 ROOT=$PWD
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_default -o r -- python $ROOT/bench.py > $ROOT/gpurun_out/b_prof.log 2>&1
-rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_lanes1 -o r -- python $ROOT/bench.py --lanes 1 > $ROOT/gpurun_out/b_prof1.log 2>&1
+rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_default -o r -- python $ROOT/bench.py --host-io 0 > $ROOT/gpurun_out/b_prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_lanes1 -o r -- python $ROOT/bench.py --lanes 1 --host-io 0 > $ROOT/gpurun_out/b_prof1.log 2>&1
 # counters: one group per run, never together with tracing domains other than --kernel-trace
 for c in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM"; do
     n=$(echo $c | cut -d" " -f1)
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $ROOT/gpurun_out/pmc_$n -- python $ROOT/bench.py --batch 16384 --chunk 16384 --steps 1 --warmup 0 \
-        --no-cpu-baseline --verify-steps 0 --roofline-steps 0 > $ROOT/gpurun_out/pmc_$n.log 2>&1
+        --no-cpu-baseline --verify-steps 0 --roofline-steps 0 --host-io 0 > $ROOT/gpurun_out/pmc_$n.log 2>&1
 done
 cd $ROOT
 python tools/rocpd_stats.py gpurun_out/prof_default/r_results.db > gpurun_out/r01_rocprofv3_kernel_stats.csv

@@ -233,17 +233,17 @@ class Engine:
         return proofs, list(st)
 
     def prove_batch_host_raw(self, msg, sig, pk, which, seeds, out=None):
-        """zk_prove_batch on host buffers without slicing the output.  out: a PinnedBuffer (overlapped DMA) or None (a pageable
-        buffer is allocated).  Returns (wall seconds of the C call, out buffer, offsets, statuses)."""
+        """zk_prove_batch on host buffers without slicing the output.  out: a PinnedBuffer (overlapped DMA), a ctypes byte array
+        (pageable) or None (a pageable array is allocated).  Returns (wall seconds of the C call, out buffer, offsets, statuses)."""
         import time
         B = len(which)
         cap = self.proof_max_size() * max(B, 1)
         if out is None:
             out = (C.c_uint8 * cap)()
-            optr = C.addressof(out)
+        if isinstance(out, PinnedBuffer):
+            cap, optr = min(cap, out.nbytes), out.ptr
         else:
-            cap = min(cap, out.nbytes)
-            optr = out.ptr
+            cap, optr = min(cap, C.sizeof(out)), C.addressof(out)
         off = (C.c_uint64 * (B + 1))()
         st = (C.c_int32 * B)()
         w = (C.c_uint32 * B)(*which)

@@ -573,45 +573,39 @@ extern "C" zk_status zk_prove_batch(zk_ctx* c, uint64_t B, const uint8_t* msg, c
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->params_set || !c->N) return ZK_E_BUFFER;
     size_t rng_bytes = rng->mode == ZK_RNG_SEED ? 32 * B : 32 * B * rng->stride_blocks;
-    uint8_t *d_msg = nullptr, *d_sig = nullptr, *d_pk = nullptr, *d_rng = nullptr, *d_out = nullptr;
-    uint32_t* d_which = nullptr;
-    uint64_t* d_off = nullptr;
-    int32_t* d_st = nullptr;
+    DevBuf d_msg, d_sig, d_pk, d_which, d_rng, d_off, d_st;
     size_t bb = B ? B : 1;
     uint64_t cap_dev = std::min<uint64_t>(out_cap, zk_proof_max_size(c) * bb);
-    HIPCHK(c, hipMalloc(&d_msg, 32 * bb));
-    HIPCHK(c, hipMalloc(&d_sig, 64 * bb));
-    HIPCHK(c, hipMalloc(&d_pk, 64 * bb));
-    HIPCHK(c, hipMalloc(&d_which, 4 * bb));
-    HIPCHK(c, hipMalloc(&d_rng, rng_bytes ? rng_bytes : 32));
-    {
-        zk_status ze = ensure_io_buf(c, cap_dev ? cap_dev : 32);
-        if (ze) return ze;
-        d_out = (uint8_t*)c->io_buf;
-    }
-    HIPCHK(c, hipMalloc(&d_off, 8 * (bb + 1)));
-    HIPCHK(c, hipMalloc(&d_st, 4 * bb));
+    HIPCHK(c, hipMalloc(&d_msg.p, 32 * bb));
+    HIPCHK(c, hipMalloc(&d_sig.p, 64 * bb));
+    HIPCHK(c, hipMalloc(&d_pk.p, 64 * bb));
+    HIPCHK(c, hipMalloc(&d_which.p, 4 * bb));
+    HIPCHK(c, hipMalloc(&d_rng.p, rng_bytes ? rng_bytes : 32));
+    HIPCHK(c, hipMalloc(&d_off.p, 8 * (bb + 1)));
+    HIPCHK(c, hipMalloc(&d_st.p, 4 * bb));
+    zk_status zs = ensure_io_buf(c, cap_dev ? cap_dev : 32);  // proof bytes: the context's grow-only staging buffer
+    if (zs) return zs;
+    uint8_t* d_out = (uint8_t*)c->io_buf;
     if (B) {
-        HIPCHK(c, hipMemcpy(d_msg, msg, 32 * B, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(d_sig, sig, 64 * B, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(d_pk, pk, 64 * B, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(d_which, which, 4 * B, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(d_rng, rng->data, rng_bytes, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(d_msg.p, msg, 32 * B, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(d_sig.p, sig, 64 * B, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(d_pk.p, pk, 64 * B, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(d_which.p, which, 4 * B, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(d_rng.p, rng->data, rng_bytes, hipMemcpyHostToDevice));
     }
     // a page-locked `out` (zk_host_alloc) receives each chunk by DMA while the next chunks are proved
     uint8_t* sink = B && host_ptr_is_pinned(out) ? out : nullptr;
     if (sink) {
-        zk_status ze = ensure_copy_stream(c);
-        if (ze) return ze;
+        zs = ensure_copy_stream(c);
+        if (zs) return zs;
     }
-    zk_status zs = prove_device(c, B, d_msg, d_sig, d_pk, d_which, rng->mode, d_rng, rng->stride_blocks, d_out, cap_dev, d_off, d_st, sink);
-    if (zs == ZK_OK) {
-        HIPCHK(c, hipMemcpy(out_off, d_off, 8 * (B + 1), hipMemcpyDeviceToHost));
-        if (B) HIPCHK(c, hipMemcpy(status, d_st, 4 * B, hipMemcpyDeviceToHost));
-        if (!sink && out_off[B]) HIPCHK(c, hipMemcpy(out, d_out, out_off[B], hipMemcpyDeviceToHost));
-    }
-    hipFree(d_msg), hipFree(d_sig), hipFree(d_pk), hipFree(d_which), hipFree(d_rng), hipFree(d_off), hipFree(d_st);
-    return zs;
+    zs = prove_device(c, B, d_msg.as<uint8_t>(), d_sig.as<uint8_t>(), d_pk.as<uint8_t>(), d_which.as<uint32_t>(), rng->mode, d_rng.as<uint8_t>(),
+                      rng->stride_blocks, d_out, cap_dev, d_off.as<uint64_t>(), d_st.as<int32_t>(), sink);
+    if (zs) return zs;
+    HIPCHK(c, hipMemcpy(out_off, d_off.p, 8 * (B + 1), hipMemcpyDeviceToHost));
+    if (B) HIPCHK(c, hipMemcpy(status, d_st.p, 4 * B, hipMemcpyDeviceToHost));
+    if (!sink && out_off[B]) HIPCHK(c, hipMemcpy(out, d_out, out_off[B], hipMemcpyDeviceToHost));
+    return ZK_OK;
 }
 
 extern "C" uint32_t zk_last_timing(const zk_ctx* c, float* total_ms, const char** names, float* ms, uint32_t cap) {
@@ -693,10 +687,6 @@ extern "C" zk_status zk_synth_params(zk_ctx* c, uint64_t seed, uint8_t nist_h[64
 }
 
 // ------------------------------------------------------------------ unit-test hooks
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { hipFree(p); }
-};
 extern "C" zk_status zk_test_field_op(zk_ctx* c, int which, int op, uint64_t count, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     if (!c || !a || !b || !out || which < 0 || which > 2 || op < 0 || op > 4) return ZK_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));

@@ -281,40 +281,35 @@ extern "C" zk_status zk_verify_batch(zk_ctx* c, uint64_t B, const uint8_t* msg, 
     if (!c->params_set || !c->N) return ZK_E_BUFFER;
     if (B == 0) return ZK_OK;
     if (off[0] != 0) return ZK_E_ARG;
+    for (uint64_t b = 0; b < B; b++)
+        if (off[b + 1] < off[b]) return ZK_E_ARG;  // every proof lies inside [0, off[B])
     uint64_t total = off[B];
-    uint8_t *d_msg = nullptr, *d_proofs = nullptr, *d_seeds = nullptr, *d_ok = nullptr;
-    uint64_t* d_off = nullptr;
-    int32_t* d_st = nullptr;
-    HIPCHK(c, hipMalloc(&d_msg, 32 * B));
-    {
-        zk_status ze = ensure_io_buf(c, total + 64);
-        if (ze) return ze;
-        d_proofs = (uint8_t*)c->io_buf;
-    }
-    HIPCHK(c, hipMalloc(&d_off, 8 * (B + 1)));
-    HIPCHK(c, hipMalloc(&d_ok, B));
-    HIPCHK(c, hipMalloc(&d_st, 4 * B));
-    HIPCHK(c, hipMemcpy(d_msg, msg, 32 * B, hipMemcpyHostToDevice));
+    DevBuf d_msg, d_off, d_ok, d_st, d_seeds;
+    HIPCHK(c, hipMalloc(&d_msg.p, 32 * B));
+    HIPCHK(c, hipMalloc(&d_off.p, 8 * (B + 1)));
+    HIPCHK(c, hipMalloc(&d_ok.p, B));
+    HIPCHK(c, hipMalloc(&d_st.p, 4 * B));
+    zk_status zs = ensure_io_buf(c, total + 64);  // proof bytes: the context's grow-only staging buffer
+    if (zs) return zs;
+    uint8_t* d_proofs = (uint8_t*)c->io_buf;
+    HIPCHK(c, hipMemcpy(d_msg.p, msg, 32 * B, hipMemcpyHostToDevice));
     // page-locked `proofs` (zk_host_alloc): chunk-wise DMA under the kernels of the earlier chunks; pageable: one blocking copy
     const bool pinned = host_ptr_is_pinned(proofs);
     if (pinned) {
-        for (uint64_t b = 0; b < B; b++)
-            if (off[b + 1] < off[b]) return ZK_E_ARG;
-        zk_status ze = ensure_copy_stream(c);
-        if (ze) return ze;
+        zs = ensure_copy_stream(c);
+        if (zs) return zs;
     } else {
         HIPCHK(c, hipMemcpy(d_proofs, proofs, total, hipMemcpyHostToDevice));
     }
-    HIPCHK(c, hipMemcpy(d_off, off, 8 * (B + 1), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d_off.p, off, 8 * (B + 1), hipMemcpyHostToDevice));
     if (vseeds) {
-        HIPCHK(c, hipMalloc(&d_seeds, 32 * B));
-        HIPCHK(c, hipMemcpy(d_seeds, vseeds, 32 * B, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc(&d_seeds.p, 32 * B));
+        HIPCHK(c, hipMemcpy(d_seeds.p, vseeds, 32 * B, hipMemcpyHostToDevice));
     }
-    zk_status zs = verify_device(c, B, d_msg, d_proofs, d_off, d_seeds, d_ok, d_st, pinned ? proofs : nullptr, pinned ? off : nullptr);
-    if (zs == ZK_OK) {
-        HIPCHK(c, hipMemcpy(ok, d_ok, B, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(status, d_st, 4 * B, hipMemcpyDeviceToHost));
-    }
-    hipFree(d_msg), hipFree(d_off), hipFree(d_ok), hipFree(d_st), hipFree(d_seeds);
-    return zs;
+    zs = verify_device(c, B, d_msg.as<uint8_t>(), d_proofs, d_off.as<uint64_t>(), d_seeds.as<uint8_t>(), d_ok.as<uint8_t>(), d_st.as<int32_t>(),
+                       pinned ? proofs : nullptr, pinned ? off : nullptr);
+    if (zs) return zs;
+    HIPCHK(c, hipMemcpy(ok, d_ok.p, B, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(status, d_st.p, 4 * B, hipMemcpyDeviceToHost));
+    return ZK_OK;
 }

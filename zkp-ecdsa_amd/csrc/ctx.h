@@ -122,6 +122,16 @@ static inline void timing_end(zk_ctx* c) {
     }
 }
 
+// device allocation released on every exit path of an entry point
+struct DevBuf {
+    void* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { hipFree(p); }
+    template <class T>
+    T* as() const { return (T*)p; }
+};
 zk_status ensure_workspace(zk_ctx* c, uint32_t C, bool second_lane = false);
 zk_status ensure_io_buf(zk_ctx* c, size_t bytes);  // api.hip: c->io_buf of at least `bytes`
 bool host_ptr_is_pinned(const void* p);     // api.hip: page-locked (zk_host_alloc / hipHostMalloc / hipHostRegister) host memory?

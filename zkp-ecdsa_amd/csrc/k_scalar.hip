@@ -194,7 +194,8 @@ __global__ void __launch_bounds__(256) k_padd_inv(Workspace W, uint32_t items, u
         soa_st(W.T1proj.y, e, zero ? fe_zero<ModQ>().as<2>() : r);
     }
 }
-__global__ void __launch_bounds__(256, 2) k_padd_scalars(Workspace W, uint32_t items) {
+// 1 wave per SIMD (AGPRs instead of scratch for the values beyond 256 VGPRs, see k_v_slot_terms)
+__global__ void __launch_bounds__(256, 1) k_padd_scalars(Workspace W, uint32_t items) {
     uint32_t it = gtid();
     if (it >= items) return;
     uint32_t p = W.item_proof[it], i = W.item_rep[it];
@@ -260,7 +261,7 @@ ZK_DEV void eq_respond(const Workspace& W, uint32_t p, uint32_t de, const uint32
     store_scalar_be(o + 32, fe_sub_mod(s1, fe_canon(cm * rc1)));
     store_scalar_be(o + 64, fe_sub_mod(s2, fe_canon(cm * rc2)));
 }
-__global__ void __launch_bounds__(256, 2) k_padd_respond(Workspace W, uint32_t items, uint8_t* out) {
+__global__ void __launch_bounds__(256, 1) k_padd_respond(Workspace W, uint32_t items, uint8_t* out) {
     uint32_t it = gtid();
     if (it >= items) return;
     uint32_t p = W.item_proof[it], i = W.item_rep[it];

@@ -693,7 +693,9 @@ ZK_DEV void v_eq(const VTerms& L, uint32_t gidx, uint32_t ng, uint32_t i128, con
 // one thread per checked slot: all Tom terms of the slot (group gidx = slot), partial sums for shared points, and the
 // slot's P-256 contribution.  Layout of a slot group: 256-bit terms 0..9 = C8, C10, C11, C13, Tx, Ty, C4 x4;
 // 128-bit terms 10..35 = 4 x (Ax, Ay, Az, A41, A42), pix A1, A2, piy A1, A2, then Tx, Ty of a bit-1 slot.
-__global__ void __launch_bounds__(64, 2) k_v_slot_terms(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
+// 1 wave per SIMD: the ~180 values that do not fit 256 VGPRs live in AGPRs instead of scratch memory (slower by 15 % on most boxes of
+// the pool, but scratch-backed spills made this kernel 2x slower on some of them; the two-lane pipeline hides the difference)
+__global__ void __launch_bounds__(64, 1) k_v_slot_terms(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
     uint32_t sl = gtid(), ng = V.C * VK;
     if (sl >= count * VK) return;
     uint32_t p = sl / VK, j = sl % VK;
@@ -789,7 +791,7 @@ __global__ void __launch_bounds__(64, 2) k_v_slot_terms(Workspace W, VWork V, ui
 // ca, cb 128-bit) and the per-proof totals for the shared points.
 // gk group q (q < ceil(n/2)) holds i = 2q, 2q+1: 256-bit terms {cl_i, cd_i} x2 = 0..3, 128-bit {ca_i, cb_i} x2 = 4..7.
 // misc group (index = p): 256-bit terms: 0 = Px (membership coefficient), 1 = Px (Exp), 2 = Py (Exp).
-__global__ void __launch_bounds__(64, 2) k_v_proof_terms(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
+__global__ void __launch_bounds__(64, 1) k_v_proof_terms(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
     uint32_t p = gtid();
     if (p >= count) return;
     uint32_t n = V.n, nq = (n + 1) / 2, ngk = V.C * nq, nm = V.C;
@@ -971,7 +973,7 @@ void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t nterms, uint32_t n
 // terms in global memory (projective, rtab.h entry format), then runs 33 windows of 4 doublings + 5 complete additions
 // (the bit-serial version computed 128 doublings + 640 additions per thread).
 #define VP_NW 33
-__global__ void __launch_bounds__(256, 2) k_v_p256_straus(VWork V, uint32_t count) {
+__global__ void __launch_bounds__(256, 1) k_v_p256_straus(VWork V, uint32_t count) {
     uint32_t t = gtid();
     if (t >= count * 4) return;
     uint32_t p = t / 4, q = t % 4;
