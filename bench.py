@@ -99,6 +99,26 @@ def cpu_baseline(nh, tg, th, ring, nkeys, msg, sig, pk, which, seeds, sec, budge
             'sample': '%d proofs of the same workload (ring=%d keys, secLevel %d), %d threads, %.1f s wall' % (n, nkeys, sec, nthreads, dt)}, proofs
 
 
+def v8_bigint_indicator():
+    """Optional: the plain-JS BigInt restatement oracle/js/zkattest_ref.js proves and verifies
+    one golden proof at ring = 6 keys padded to 8, secLevel 80 (the shape of BASELINE configs[0] and of the reference's own
+    test) on whatever `node` the box has -- an approximation of `npm run bench`, which needs Node >= 24 and cannot run here."""
+    import shutil
+    import subprocess
+    if shutil.which('node') is None:
+        return None
+    try:
+        p = subprocess.run(['node', os.path.join(ROOT, 'oracle', 'js', 'zkattest_ref.js'), 'bench', os.path.join(ROOT, 'tests', 'golden', 'golden.json'),
+                            'ring6_sec80'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        rec = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:  # the indicator must never break the bench line
+        return {'error': repr(e)[:200]}
+    return {'prove_s': rec['prove_ms'] / 1e3, 'verify_s': rec['verify_ms'] / 1e3, 'proofs_per_s': round(1e3 / max(rec['prove_ms'], 1), 3),
+            'node': rec['node'], 'bytes_match_golden': bool(rec['sha256_ok']), 'verified': bool(rec['verified']), 'threads': 1,
+            'workload': 'one proof, ring = 6 keys padded to 8, secLevel 80 (tests/golden/golden.json: ring6_sec80)',
+            'note': 'approximation of `npm run bench` (V8 BigInt, this build\'s JS restatement); not the cpu_baseline value'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -291,6 +311,7 @@ def main():
             for b in range(ncheck):
                 assert raw[int(off[b]):int(off[b + 1])] == oproofs[b], 'GPU proof %d differs from the oracle' % b
             cpu['checked_bit_exact'] = ncheck
+            cpu['v8_bigint'] = v8_bigint_indicator()
         host_io = None
         if args.host_io > 0 and world == 1:
             # the same work through HOST buffers (zk_prove_batch / zk_verify_batch): H2D of the inputs, proving, D2H of the proofs,

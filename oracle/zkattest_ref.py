@@ -19,7 +19,8 @@ reference cannot be executed here and its own tests hold no golden proof vectors
     prove->verify round trips of test/*;
   * public vectors: FIPS 180-4 SHA-256, RFC 6979 A.2.5 ECDSA P-256.
 Proof-level bit-exactness is defined under the deterministic RNG contract below and is
-established by this restatement and the C restatement agreeing byte for byte.
+established by this restatement, the C restatement and the JavaScript restatement
+(oracle/js/zkattest_ref.js, V8 BigInt) agreeing byte for byte.
 
 RNG contract (replaces crypto.getRandomValues, src/bignum/big.ts:171-181): the k-th
 32-byte fill (k counts every fill, including rejected ones) of a proof with 32-byte
