@@ -45,7 +45,6 @@ constexpr GkRankTab gk_make_rank_tab() {
     return t;
 }
 __device__ const GkRankTab GK_RT = gk_make_rank_tab();
-static const GkRankTab GK_RT_HOST = gk_make_rank_tab();
 
 // bit repacking between limb widths (all indices and shifts are compile-time constants after unrolling)
 template <int IN_BITS, int OUT_BITS, int NIN, int NOUT>
