@@ -1,0 +1,179 @@
+// TEST HARNESS (not product code): compiles the engine's own arithmetic headers (zkp-ecdsa_amd/csrc/field.h, curve.h) for the
+// host CPU with g++ -DZK_HOST_BUILD, so that `pytest -m "not gpu"` checks the very templates the HIP kernels instantiate --
+// Montgomery product, magnitude-typed add/sub, fused double subtraction, inversion, the P-256 complete formulas and the Tom-256
+// (a = 1 image) extended / niels formulas -- against the oracle.  Built and driven by tests/test_host_arith.py.
+#define ZK_HOST_BUILD 1
+#include <cstring>
+#include "curve.h"
+
+static uint32_t bswap32h(uint32_t v) { return __builtin_bswap32(v); }
+// 40-byte big-endian operand -> 10 little-endian 32-bit words
+static void be40_to_words(const uint8_t* p, uint32_t w[10]) {
+    for (int i = 0; i < 10; i++) {
+        uint32_t v;
+        memcpy(&v, p + 4 * (9 - i), 4);
+        w[i] = bswap32h(v);
+    }
+}
+static void words_to_be(const uint32_t* w, int nw, uint8_t* out) {  // nw words -> 4*nw bytes big-endian
+    for (int i = 0; i < nw; i++) {
+        uint32_t v = bswap32h(w[nw - 1 - i]);
+        memcpy(out + 4 * i, &v, 4);
+    }
+}
+static void be_to_words(const uint8_t* p, int nbytes, uint32_t* w, int nw) {
+    for (int i = 0; i < nw; i++) w[i] = 0;
+    for (int i = 0; i < nbytes; i++) {
+        int bi = nbytes - 1 - i;
+        w[bi / 4] |= (uint32_t)p[i] << (8 * (bi % 4));
+    }
+}
+
+template <class M>
+static void field_one(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    uint32_t aw[10], bw[10];
+    be40_to_words(a, aw), be40_to_words(b, bw);
+    Fe<M, 1> x = fe_from_words<M, 9>(aw), y = fe_from_words<M, 9>(bw), r;
+    if (op == 0) r = fe_mul_mod(x, y);
+    else if (op == 1) r = fe_add_mod(x, y);
+    else if (op == 2) r = fe_sub_mod(x, y);
+    else if (op == 3) r = fe_from_mont(fe_inv<M>(fe_to_mont(x)));
+    else if (op == 4) {  // x*y - x - y through fe_sub2
+        auto xm = fe_to_mont(x), ym = fe_to_mont(y);
+        r = fe_from_mont(fe_sub2(xm * ym, xm, ym));
+    } else {  // op 5: a lazy chain at large magnitudes: ((x + y) + (x + y)) * (x - y) - (y * y + x) , all in Montgomery form
+        auto xm = fe_to_mont(x), ym = fe_to_mont(y);
+        auto s = (xm + ym) + (xm + ym);          // K = 8
+        auto d = xm - ym;                        // K = 2 + 4
+        auto t = s * d - (ym * ym + xm);         // product of K 8 x 6, subtrahend K 4
+        r = fe_from_mont(t);
+    }
+    uint32_t rw[10];
+    words_from_limbs<9>(rw, r.l);
+    rw[9] = 0;
+    words_to_be(rw, 10, out);
+}
+extern "C" int ha_field_op(int which, int op, uint64_t count, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    for (uint64_t i = 0; i < count; i++) {
+        if (which == 0) field_one<ModQ>(op, a + 40 * i, b + 40 * i, out + 40 * i);
+        else if (which == 1) field_one<ModN>(op, a + 40 * i, b + 40 * i, out + 40 * i);
+        else field_one<ModT>(op, a + 40 * i, b + 40 * i, out + 40 * i);
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- Tom-256
+static bool tom_load(TomPt& r, const uint8_t* xy72) {
+    uint32_t xw[9], yw[9];
+    be_to_words(xy72, 36, xw, 9), be_to_words(xy72 + 36, 36, yw, 9);
+    return tom_from_affine_words(r, xw, yw);
+}
+static TomNiels tom_niels_of(const TomPt& p) {  // affine image point (Z = 1) -> table-entry form (x, y, (d/a) x y)
+    TomNiels n;
+    n.x = p.x, n.y = p.y;
+    n.dt = p.t * fe_const<ModT, 1>(TOM_D1_M);
+    return n;
+}
+static void tom_store(const TomPt& p, uint8_t* out72) {  // image extended -> original-curve affine bytes
+    Ft2 zi = fe_inv<ModT>(p.z);
+    auto x = fe_from_mont((p.x * zi) * fe_const<ModT, 1>(TOM_SINV_M));
+    auto y = fe_from_mont(p.y * zi);
+    uint32_t w[9];
+    words_from_limbs<9>(w, x.l);
+    words_to_be(w, 9, out72);
+    words_from_limbs<9>(w, y.l);
+    words_to_be(w, 9, out72 + 36);
+}
+// k*P by double-and-add: tom_dbl + (odd elements: general tom_add, even elements: tom_add_niels with the precomputed entry)
+extern "C" int ha_tom_mul(uint64_t count, const uint8_t* xy72, const uint8_t* k32, uint8_t* out72) {
+    int bad = 0;
+    for (uint64_t i = 0; i < count; i++) {
+        TomPt P;
+        if (!tom_load(P, xy72 + 72 * i)) {
+            bad++;
+            memset(out72 + 72 * i, 0xff, 72);
+            continue;
+        }
+        TomNiels N = tom_niels_of(P);
+        TomPt acc = tom_identity();
+        for (int bit = 255; bit >= 0; bit--) {
+            acc = tom_dbl(acc);
+            if ((k32[32 * i + 31 - bit / 8] >> (bit % 8)) & 1) acc = (i & 1) ? tom_add(acc, P) : tom_add_niels(acc, N);
+        }
+        tom_store(acc, out72 + 72 * i);
+    }
+    return bad;
+}
+// P + Q - R through the comb's entry forms: from_niels (first step), add_niels, negated entry + add_niels_last (last step)
+extern "C" int ha_tom_combo(uint64_t count, const uint8_t* p72, const uint8_t* q72, const uint8_t* r72, uint8_t* out72) {
+    int bad = 0;
+    for (uint64_t i = 0; i < count; i++) {
+        TomPt P, Q, R;
+        if (!tom_load(P, p72 + 72 * i) || !tom_load(Q, q72 + 72 * i) || !tom_load(R, r72 + 72 * i)) {
+            bad++;
+            continue;
+        }
+        TomPt acc = tom_from_niels(tom_niels_of(P));
+        acc = tom_add_niels(acc, tom_niels_of(Q));
+        acc = tom_add_niels_last(acc, tom_niels_neg_sel(tom_niels_of(R), true));
+        tom_store(acc, out72 + 72 * i);
+    }
+    return bad;
+}
+
+// ---------------------------------------------------------------- P-256
+static bool p256_load(P256Aff& a, const uint8_t* xy64) {
+    uint32_t xw[8], yw[8];
+    be_to_words(xy64, 32, xw, 8), be_to_words(xy64 + 32, 32, yw, 8);
+    a.x = fe_to_mont(fe_from_words<ModQ, 8>(xw));
+    a.y = fe_to_mont(fe_from_words<ModQ, 8>(yw));
+    return p256_on_curve(a);
+}
+static void p256_store(const P256Pt& p, uint8_t* out64) {  // identity -> 64 zero bytes
+    Fq2 z = fe_reduce(p.z);
+    if (fe_is_zero(z)) {
+        memset(out64, 0, 64);
+        return;
+    }
+    Fq2 zi = fe_inv<ModQ>(z);
+    uint32_t w[9];
+    words_from_limbs<9>(w, fe_from_mont(p.x * zi).l);
+    words_to_be(w, 8, out64);
+    words_from_limbs<9>(w, fe_from_mont(p.y * zi).l);
+    words_to_be(w, 8, out64 + 32);
+}
+extern "C" int ha_p256_mul(uint64_t count, const uint8_t* xy64, const uint8_t* k32, uint8_t* out64) {
+    int bad = 0;
+    for (uint64_t i = 0; i < count; i++) {
+        P256Aff A;
+        if (!p256_load(A, xy64 + 64 * i)) {
+            bad++;
+            memset(out64 + 64 * i, 0xff, 64);
+            continue;
+        }
+        P256Pt P = p256_from_affine(A), acc = p256_identity();
+        for (int bit = 255; bit >= 0; bit--) {
+            acc = p256_dbl(acc);
+            if ((k32[32 * i + 31 - bit / 8] >> (bit % 8)) & 1) {
+                // the mixed formula needs a non-identity accumulator only for correctness of Z2 = 1, not of the law; use it when acc != O
+                if ((i & 1) && !fe_is_zero(fe_reduce(acc.z))) acc = p256_add_mixed(acc, A);
+                else acc = p256_add(acc, P);
+            }
+        }
+        p256_store(acc, out64 + 64 * i);
+    }
+    return bad;
+}
+// complete addition on arbitrary pairs (P = Q, P = -Q included)
+extern "C" int ha_p256_add(uint64_t count, const uint8_t* p64, const uint8_t* q64, uint8_t* out64) {
+    int bad = 0;
+    for (uint64_t i = 0; i < count; i++) {
+        P256Aff A, B;
+        if (!p256_load(A, p64 + 64 * i) || !p256_load(B, q64 + 64 * i)) {
+            bad++;
+            continue;
+        }
+        p256_store(p256_add(p256_from_affine(A), p256_from_affine(B)), out64 + 64 * i);
+    }
+    return bad;
+}

@@ -1,0 +1,119 @@
+"""not-gpu: the engine's arithmetic headers (zkp-ecdsa_amd/csrc/field.h, curve.h) compiled for the host CPU (g++ -DZK_HOST_BUILD,
+tests/host_arith/host_arith.cpp) against the oracle.  These are the templates the HIP kernels instantiate -- radix-2^30
+Montgomery product, magnitude-typed lazy add/sub, fused double subtraction, Fermat inversion, the P-256 complete formulas
+(weier.ts:133-230) and the Tom-256 extended / niels formulas on the a = 1 image (edwards.ts:141-183) -- so the CPU tier fails
+when that source breaks, not only when the GPU tier runs."""
+import ctypes as C
+import os
+import random
+import shutil
+import subprocess
+
+import pytest
+
+import zkattest_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.skipif(shutil.which('g++') is None, reason='no g++')
+
+
+@pytest.fixture(scope='module')
+def ha(tmp_path_factory):
+    out = tmp_path_factory.mktemp('host_arith') / 'libhost_arith.so'
+    subprocess.check_call(['g++', '-O1', '-std=c++17', '-shared', '-fPIC', '-Wall', '-Werror', '-Wno-unknown-pragmas',
+                           '-I' + os.path.join(ROOT, 'zkp-ecdsa_amd', 'csrc'), os.path.join(ROOT, 'tests', 'host_arith', 'host_arith.cpp'), '-o', str(out)])
+    return C.CDLL(str(out))
+
+
+def _field(ha, which, op, a, b):
+    n = len(a)
+    ab = b''.join(x.to_bytes(40, 'big') for x in a)
+    bb = b''.join(x.to_bytes(40, 'big') for x in b)
+    out = C.create_string_buffer(40 * n)
+    assert ha.ha_field_op(which, op, C.c_uint64(n), ab, bb, out) == 0
+    return [int.from_bytes(out.raw[40 * i:40 * i + 40], 'big') for i in range(n)]
+
+
+def test_field_templates_on_the_host(ha):
+    rnd = random.Random(11)
+    for which, m in enumerate([R.p256.p, R.p256.order, R.tomEdwards256.p]):
+        a = [rnd.randrange(m) for _ in range(400)] + [0, 1, m - 1, m - 1, 0, 2, m - 2, (1 << 255) % m]
+        b = [rnd.randrange(m) for _ in range(400)] + [0, m - 1, m - 1, 1, m - 1, m - 2, 2, m - 1]
+        assert _field(ha, which, 0, a, b) == [x * y % m for x, y in zip(a, b)]
+        assert _field(ha, which, 1, a, b) == [(x + y) % m for x, y in zip(a, b)]
+        assert _field(ha, which, 2, a, b) == [(x - y) % m for x, y in zip(a, b)]
+        assert _field(ha, which, 3, a[:40] + a[-8:], b[:48]) == [pow(x, -1, m) if x else 0 for x in a[:40] + a[-8:]]
+        assert _field(ha, which, 4, a, b) == [(x * y - x - y) % m for x, y in zip(a, b)]                       # fe_sub2
+        assert _field(ha, which, 5, a, b) == [(2 * (x + y) * (x - y) - (y * y + x)) % m for x, y in zip(a, b)]  # lazy chain, K up to 10
+
+
+def _tom_xy(pt):
+    x, y = pt.toAffine()
+    return x.to_bytes(36, 'big') + y.to_bytes(36, 'big')
+
+
+def test_tom256_formulas_on_the_host(ha):
+    rnd = random.Random(5)
+    g, q = R.tomEdwards256, R.tomEdwards256.order
+    bases = [g.generator().mul(g.newScalar(rnd.randrange(1, q))) for _ in range(6)]
+    ks = [rnd.randrange(1 << 256) for _ in range(8)] + [0, 1, 2, q - 1, q, q + 1, (1 << 256) - 1, 1 << 255]
+    pts, kk = [], []
+    for i, k in enumerate(ks):
+        pts.append(bases[i % len(bases)])
+        kk.append(k)
+    n = len(pts)
+    out = C.create_string_buffer(72 * n)
+    assert ha.ha_tom_mul(C.c_uint64(n), b''.join(_tom_xy(p) for p in pts), b''.join(k.to_bytes(32, 'big') for k in kk), out) == 0
+    for i in range(n):
+        exp = pts[i].mul(g.newScalar(kk[i]))
+        assert out.raw[72 * i:72 * i + 72] == _tom_xy(exp), (i, hex(kk[i]))
+    # comb entry forms: P + Q - R via from_niels / add_niels / negated entry + add_niels_last, incl. P = Q, R = P + Q (-> identity)
+    P = [bases[0], bases[1], bases[2], bases[3], bases[0]]
+    Q = [bases[1], bases[1], bases[3], bases[4], bases[5]]
+    Rr = [bases[2], bases[5], bases[2].add(bases[3]), bases[3], bases[5]]
+    m = len(P)
+    out = C.create_string_buffer(72 * m)
+    assert ha.ha_tom_combo(C.c_uint64(m), b''.join(map(_tom_xy, P)), b''.join(map(_tom_xy, Q)), b''.join(map(_tom_xy, Rr)), out) == 0
+    for i in range(m):
+        assert out.raw[72 * i:72 * i + 72] == _tom_xy(P[i].add(Q[i]).sub(Rr[i])), i
+    # a point off the curve and a coordinate >= t are refused by tom_from_affine_words (edwards.ts:52-65, 74-77)
+    bad = bytearray(_tom_xy(bases[0]))
+    bad[40] ^= 1
+    big = (g.p + 1).to_bytes(36, 'big') + (5).to_bytes(36, 'big')
+    out = C.create_string_buffer(144)
+    assert ha.ha_tom_mul(C.c_uint64(2), bytes(bad) + big, (3).to_bytes(32, 'big') * 2, out) == 2
+
+
+def _p_xy(pt):
+    c = pt.toAffine()
+    return bytes(64) if not c else c[0].to_bytes(32, 'big') + c[1].to_bytes(32, 'big')
+
+
+def test_p256_complete_formulas_on_the_host(ha):
+    rnd = random.Random(8)
+    g, n = R.p256, R.p256.order
+    bases = [g.generator().mul(g.newScalar(rnd.randrange(1, n))) for _ in range(5)] + [g.generator()]
+    ks = [rnd.randrange(1 << 256) for _ in range(8)] + [0, 1, 2, n - 1, n, n + 1, (1 << 256) - 1]
+    pts = [bases[i % len(bases)] for i in range(len(ks))]
+    cnt = len(ks)
+    out = C.create_string_buffer(64 * cnt)
+    assert ha.ha_p256_mul(C.c_uint64(cnt), b''.join(_p_xy(p) for p in pts), b''.join(k.to_bytes(32, 'big') for k in ks), out) == 0
+    for i in range(cnt):
+        assert out.raw[64 * i:64 * i + 64] == _p_xy(pts[i].mul(g.newScalar(ks[i]))), (i, hex(ks[i]))
+    # RFC 6979 A.2.5 public key = x * G for the published private key: a public vector through the host build
+    d = 0xC9AFA9D845BA75166B5C215767B1D6934E50C3DB36E89B127B8A622B120F6721
+    out = C.create_string_buffer(64)
+    assert ha.ha_p256_mul(C.c_uint64(1), _p_xy(g.generator()), d.to_bytes(32, 'big'), out) == 0
+    assert out.raw.hex().upper() == ('60FED4BA255A9D31C961EB74C6356D68C049B8923B61FA6CE669622E60F29FB6'
+                                     '7903FE1008B8BC99A41AE9E95628BC64F2F1B20C2D7E9F5177A3C294D4462299')
+    # complete addition: generic, doubling (P = Q) and inverse (P = -Q -> identity = 64 zero bytes)
+    A = [bases[0], bases[1], bases[2], bases[3]]
+    B = [bases[1], bases[1], bases[2].neg(), bases[5]]
+    out = C.create_string_buffer(64 * 4)
+    assert ha.ha_p256_add(C.c_uint64(4), b''.join(map(_p_xy, A)), b''.join(map(_p_xy, B)), out) == 0
+    for i in range(4):
+        assert out.raw[64 * i:64 * i + 64] == _p_xy(A[i].add(B[i])), i
+    bad = bytearray(_p_xy(bases[0]))
+    bad[5] ^= 4
+    assert ha.ha_p256_mul(C.c_uint64(1), bytes(bad), (7).to_bytes(32, 'big'), C.create_string_buffer(64)) == 1

@@ -14,11 +14,21 @@
 // so every lazy add/sub chain is bounds-checked at compile time.  These replace every BigInt `%` of the
 // reference (src/bignum/big.ts:36-42 posMod; the `% p` lines of src/curves/weier.ts and edwards.ts).
 #pragma once
-#include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifdef ZK_HOST_BUILD
+// tests/host_arith only: the same templates compiled by g++ for the host CPU, so that the CPU test tier exercises THIS source
+// (not a restatement) against the oracle.  No product code defines ZK_HOST_BUILD; the opaque-operand asm statements are off.
+#define ZK_DEV inline
+#define ZK_DEV_NOINLINE
+#define ZK_LAUNDER_MOD 0
+#define ZK_PIN_LIMBS32 0
+#else
+#include <hip/hip_runtime.h>
+#define ZK_DEV __device__ __forceinline__
+#define ZK_DEV_NOINLINE __device__ __noinline__
+#endif
 #include "consts_gen.h"
 
-#define ZK_DEV __device__ __forceinline__
 #define LIMB_BITS 30
 #define LIMB_MASK 0x3fffffffu
 #define NLIMB 9
@@ -311,7 +321,7 @@ ZK_DEV Fe<M, K> fe_select(bool c, const Fe<M, K>& a, const Fe<M, K>& b) {  // c 
 
 // Montgomery-domain inverse by Fermat (a^(M-2)); inv(0) = 0 like the reference's invMod (big.ts:113-119).
 template <class M>
-__device__ __noinline__ Fe<M, 2> fe_inv(const Fe<M, 2>& a) {
+ZK_DEV_NOINLINE Fe<M, 2> fe_inv(const Fe<M, 2>& a) {
     Fe<M, 2> acc = fe_one_mont<M>().template as<2>(), base = a;
     for (int w = 0; w < NLIMB; w++) {
         uint32_t e = M::exp_m2[w];
