@@ -1,10 +1,11 @@
 // TEST HARNESS (not product code): compiles the engine's own arithmetic headers (zkp-ecdsa_amd/csrc/field.h, curve.h) for the
 // host CPU with g++ -DZK_HOST_BUILD, so that `pytest -m "not gpu"` checks the very templates the HIP kernels instantiate --
-// Montgomery product, magnitude-typed add/sub, fused double subtraction, inversion, the P-256 complete formulas and the Tom-256
-// (a = 1 image) extended / niels formulas -- against the oracle.  Built and driven by tests/test_host_arith.py.
+// Montgomery product, magnitude-typed add/sub, fused double subtraction, inversion, the P-256 complete formulas, the Tom-256
+// (a = 1 image) extended / niels formulas, SHA-256 with its byte absorber, and the RNG draw mapping -- against the oracle.  Built and driven by tests/test_host_arith.py.
 #define ZK_HOST_BUILD 1
 #include <cstring>
 #include "curve.h"
+#include "rng.h"
 
 static uint32_t bswap32h(uint32_t v) { return __builtin_bswap32(v); }
 // 40-byte big-endian operand -> 10 little-endian 32-bit words
@@ -176,4 +177,37 @@ extern "C" int ha_p256_add(uint64_t count, const uint8_t* p64, const uint8_t* q6
         p256_store(p256_add(p256_from_affine(A), p256_from_affine(B)), out64 + 64 * i);
     }
     return bad;
+}
+
+// ---------------------------------------------------------------- SHA-256 byte absorber (sha256.h) and the RNG contract (rng.h)
+extern "C" int ha_sha256(uint64_t count, uint64_t len, const uint8_t* msgs, uint8_t* out32) {
+    for (uint64_t t = 0; t < count; t++) {
+        uint32_t col[16];  // one lane's column of the LDS block buffer, stride 1
+        ShaStream s;
+        s.init(col, 0, 1);
+        for (uint64_t i = 0; i < len; i++) s.put_byte(msgs[t * len + i]);
+        uint32_t h[8];
+        s.finish(h);
+        for (int i = 0; i < 8; i++) {  // digest = h[0] .. h[7], each big-endian
+            uint32_t v = bswap32h(h[i]);
+            memcpy(out32 + 32 * t + 4 * i, &v, 4);
+        }
+    }
+    return 0;
+}
+// logical draws first_k .. first_k + n_k - 1 of every proof, 32 bytes big-endian each; exc_* as k_rng_prepass would leave them
+extern "C" int ha_rng_draws(int mode, int sec, uint64_t B, const uint8_t* data, uint64_t stride_blocks, uint32_t* exc_idx, uint32_t* exc_flags,
+                            uint32_t* exc_cnt, uint32_t first_k, uint32_t n_k, uint8_t* out) {
+    RngCtx g;
+    g.seeds = mode == 0 ? data : nullptr;
+    g.stream = mode == 1 ? data : nullptr;
+    g.stride_blocks = stride_blocks, g.mode = mode, g.sec = sec;
+    g.exc_idx = exc_idx, g.exc_flags = exc_flags, g.exc_cnt = exc_cnt, g.proof_base = 0;
+    for (uint64_t p = 0; p < B; p++)
+        for (uint32_t k = 0; k < n_k; k++) {
+            uint32_t w[8];
+            rng_draw_words(g, (uint32_t)p, first_k + k, w);
+            words_to_be(w, 8, out + 32 * (p * n_k + k));
+        }
+    return 0;
 }

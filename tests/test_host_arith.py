@@ -117,3 +117,73 @@ def test_p256_complete_formulas_on_the_host(ha):
     bad = bytearray(_p_xy(bases[0]))
     bad[5] ^= 4
     assert ha.ha_p256_mul(C.c_uint64(1), bytes(bad), (7).to_bytes(32, 'big'), C.create_string_buffer(64)) == 1
+
+
+def test_sha256_byte_absorber_on_the_host(ha):
+    import hashlib
+    for ln in (0, 1, 3, 55, 56, 57, 63, 64, 65, 119, 120, 127, 128, 268, 603, 1000):
+        msgs = [bytes((i * 7 + j * 13 + ln) & 255 for j in range(ln)) for i in range(9)]
+        out = C.create_string_buffer(32 * len(msgs))
+        assert ha.ha_sha256(C.c_uint64(len(msgs)), C.c_uint64(ln), b''.join(msgs), out) == 0
+        assert [out.raw[32 * i:32 * i + 32] for i in range(len(msgs))] == [hashlib.sha256(m).digest() for m in msgs], ln
+    out = C.create_string_buffer(32)
+    ha.ha_sha256(C.c_uint64(1), C.c_uint64(3), b'abc', out)    # FIPS 180-4 B.1
+    assert out.raw.hex() == 'ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad'
+
+
+def _reference_draws(fills, sec, ndraws):
+    """rnd() of big.ts:171-181 over the fill sequence: draw j uses modulus n or q and consumes
+    fills until one is below it.  Returns the accepted 32-byte fills."""
+    n, q = R.p256.order, R.p256.p
+    out, f = [], 0
+    for j in range(ndraws):
+        is_n = j == 0 or (3 <= j < 3 + 4 * sec and ((j - 3) & 3) < 2)
+        m = n if is_n else q
+        while int.from_bytes(fills[f], 'big') >= m:
+            f += 1
+        out.append(fills[f])
+        f += 1
+    return out
+
+
+def test_rng_draw_mapping_on_the_host(ha):
+    """rng_map: logical draw k -> fill index, given the per-proof list of suspicious fills (first word 0xffffffff) the prepass
+    leaves; explicit streams with planted values >= n, in [n, q) and >= q at n-draws and q-draws; seed mode against SHA-256."""
+    import hashlib
+    rnd = random.Random(3)
+    n, q = R.p256.order, R.p256.p
+    sec, nblk, ndraws, B = 20, 140, 120, 6
+    streams, excs = [], []
+    for p in range(B):
+        fills = [bytes([rnd.randrange(255)]) + bytes(rnd.randrange(256) for _ in range(31)) for _ in range(nblk)]   # first byte < 0xff: accepted
+        plant = {0: [], 1: [(0, n + 5)], 2: [(2, q + 1), (3, (1 << 256) - 1)], 3: [(7, n + 99), (8, n + 7), (11, q + 3)],
+                 4: [(1, n + 1), (5, (1 << 256) - 2), (6, n + 2), (40, q + 9), (41, n + 10)], 5: [(3, n + 12345), (4, n + 1), (90, q)]}[p]
+        for idx, val in plant:
+            fills[idx] = val.to_bytes(32, 'big')
+        streams.append(fills)
+        e = [(i, (1 if int.from_bytes(f, 'big') >= n else 0) | (2 if int.from_bytes(f, 'big') >= q else 0))
+             for i, f in enumerate(fills) if f[:4] == b'\xff\xff\xff\xff']
+        rnd.shuffle(e)                      # the prepass appends in arbitrary order
+        excs.append(e)
+    idx = (C.c_uint32 * (8 * B))()
+    fl = (C.c_uint32 * (8 * B))()
+    cnt = (C.c_uint32 * B)()
+    for p, e in enumerate(excs):
+        cnt[p] = len(e)
+        for i, (a, b) in enumerate(e):
+            idx[8 * p + i], fl[8 * p + i] = a, b
+    data = b''.join(b''.join(s) for s in streams)
+    out = C.create_string_buffer(32 * B * ndraws)
+    assert ha.ha_rng_draws(1, sec, C.c_uint64(B), data, C.c_uint64(nblk), idx, fl, cnt, 0, ndraws, out) == 0
+    for p in range(B):
+        exp = _reference_draws(streams[p], sec, ndraws)
+        got = [out.raw[32 * (p * ndraws + k):32 * (p * ndraws + k) + 32] for k in range(ndraws)]
+        assert got == exp, p
+    # seed mode: fill k = SHA-256(seed || be64(k)); no suspicious fills for these seeds
+    seeds = [hashlib.sha256(b'seed%d' % i).digest() for i in range(4)]
+    zero = (C.c_uint32 * 4)()
+    out = C.create_string_buffer(32 * 4 * 10)
+    assert ha.ha_rng_draws(0, sec, C.c_uint64(4), b''.join(seeds), C.c_uint64(0), idx, fl, zero, 5, 10, out) == 0
+    for p in range(4):
+        for k in range(10):
+            assert out.raw[32 * (p * 10 + k):32 * (p * 10 + k) + 32] == hashlib.sha256(seeds[p] + (5 + k).to_bytes(8, 'big')).digest()

@@ -14,19 +14,7 @@
 // so every lazy add/sub chain is bounds-checked at compile time.  These replace every BigInt `%` of the
 // reference (src/bignum/big.ts:36-42 posMod; the `% p` lines of src/curves/weier.ts and edwards.ts).
 #pragma once
-#include <stdint.h>
-#ifdef ZK_HOST_BUILD
-// tests/host_arith only: the same templates compiled by g++ for the host CPU, so that the CPU test tier exercises THIS source
-// (not a restatement) against the oracle.  No product code defines ZK_HOST_BUILD; the opaque-operand asm statements are off.
-#define ZK_DEV inline
-#define ZK_DEV_NOINLINE
-#define ZK_LAUNDER_MOD 0
-#define ZK_PIN_LIMBS32 0
-#else
-#include <hip/hip_runtime.h>
-#define ZK_DEV __device__ __forceinline__
-#define ZK_DEV_NOINLINE __device__ __noinline__
-#endif
+#include "zkdev.h"
 #include "consts_gen.h"
 
 #define LIMB_BITS 30

@@ -1,13 +1,9 @@
 // SHA-256 (FIPS 180-4) device code, one message per lane.  Replaces crypto.subtle.digest('SHA-256', ..) of
 // src/curves/group.ts:221-233 (hashPoints) and implements the counter-mode RNG block of the RNG contract.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#ifndef ZK_DEV
-#define ZK_DEV __device__ __forceinline__
-#endif
+#include "zkdev.h"
 
-__constant__ uint32_t SHA_K[64] = {
+ZK_CONSTANT uint32_t SHA_K[64] = {
     0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
     0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
     0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
@@ -16,7 +12,7 @@ __constant__ uint32_t SHA_K[64] = {
     0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
     0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
 
-ZK_DEV uint32_t rotr32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+ZK_DEV uint32_t rotr32(uint32_t x, int n) { return zk_rotr32(x, n); }
 ZK_DEV uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
 
 ZK_DEV void sha256_iv(uint32_t h[8]) {
@@ -50,7 +46,7 @@ ZK_DEV void sha256_compress(uint32_t h[8], uint32_t w[16]) {
 struct ShaState {
     uint32_t v[8];
 };
-__device__ __noinline__ ShaState sha256_compress_lds(ShaState st, const uint32_t* buf, uint32_t stride) {
+ZK_DEV_NOINLINE ShaState sha256_compress_lds(ShaState st, const uint32_t* buf, uint32_t stride) {
     uint32_t w[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) w[j] = buf[j * stride];

@@ -1,0 +1,20 @@
+// Function qualifiers of the per-lane device code.  The product compiles these headers with hipcc for gfx950 only.
+// tests/host_arith defines ZK_HOST_BUILD and compiles the SAME headers (field.h, curve.h, sha256.h, rng.h) with g++ for the host
+// CPU, so that the CPU test tier exercises this source against the oracle; the opaque-operand asm statements of field.h and the
+// AMDGPU builtins are switched off / replaced by their portable definitions there.  No product code defines ZK_HOST_BUILD.
+#pragma once
+#include <stdint.h>
+#ifdef ZK_HOST_BUILD
+#define ZK_DEV inline
+#define ZK_DEV_NOINLINE
+#define ZK_CONSTANT static const
+#define ZK_LAUNDER_MOD 0
+#define ZK_PIN_LIMBS32 0
+ZK_DEV uint32_t zk_rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+#else
+#include <hip/hip_runtime.h>
+#define ZK_DEV __device__ __forceinline__
+#define ZK_DEV_NOINLINE __device__ __noinline__
+#define ZK_CONSTANT __constant__
+ZK_DEV uint32_t zk_rotr32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+#endif
