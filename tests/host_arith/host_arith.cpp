@@ -6,6 +6,7 @@
 #include <cstring>
 #include "curve.h"
 #include "rng.h"
+#include "comb_digits.h"
 
 static uint32_t bswap32h(uint32_t v) { return __builtin_bswap32(v); }
 // 40-byte big-endian operand -> 10 little-endian 32-bit words
@@ -210,4 +211,21 @@ extern "C" int ha_rng_draws(int mode, int sec, uint64_t B, const uint8_t* data, 
             words_to_be(w, 8, out + 32 * (p * n_k + k));
         }
     return 0;
+}
+
+// ---------------------------------------------------------------- comb digit recoding (comb_digits.h)
+// digits of the 256-bit scalar k (big-endian) for a `bits`-wide comb: idx[i], neg[i] for i < nwin; returns the carry left over
+// plus whatever is left of the scalar (must be 0 when nwin windows cover it)
+extern "C" uint32_t ha_comb_digits(uint32_t bits, uint32_t nwin, const uint8_t* k32, uint32_t* idx, uint8_t* neg) {
+    CombDigits d;
+    d.init(bits);
+    be_to_words(k32, 32, d.w, 8);
+    for (uint32_t i = 0; i < nwin; i++) {
+        bool ng;
+        d.next(idx[i], ng);
+        neg[i] = ng ? 1 : 0;
+    }
+    uint32_t rest = d.carry;
+    for (int i = 0; i < 8; i++) rest |= d.w[i];
+    return rest;
 }

@@ -187,3 +187,23 @@ def test_rng_draw_mapping_on_the_host(ha):
     for p in range(4):
         for k in range(10):
             assert out.raw[32 * (p * 10 + k):32 * (p * 10 + k) + 32] == hashlib.sha256(seeds[p] + (5 + k).to_bytes(8, 'big')).digest()
+
+
+def test_comb_digit_recoding_reproduces_the_scalar(ha):
+    """comb_digits.h: for every supported table width (8..24 unsigned, 25 and 26 signed) the digits (index, sign) of a 256-bit
+    scalar sum back to it, indices stay inside the table (2^W entries, or 2^(W-1) + 1 for signed digits) and nothing is left over."""
+    rnd = random.Random(17)
+    ha.ha_comb_digits.restype = C.c_uint32
+    specials = [0, 1, (1 << 256) - 1, 1 << 255, (1 << 255) - 1, R.p256.p - 1, int('55' * 32, 16), int('aa' * 32, 16)]
+    for bits in range(8, 27):
+        signed = bits > 24
+        nwin = ((257 if signed else 256) + bits - 1) // bits          # engine.h: tom_nwin
+        entries = (1 << (bits - 1)) + 1 if signed else 1 << bits         # engine.h: tom_win_entries
+        for k in specials + [rnd.randrange(1 << 256) for _ in range(40)] + [((1 << bits) - 1) << (bits * j) & ((1 << 256) - 1) for j in range(3)]:
+            idx = (C.c_uint32 * nwin)()
+            neg = (C.c_uint8 * nwin)()
+            rest = ha.ha_comb_digits(bits, nwin, k.to_bytes(32, 'big'), idx, neg)
+            assert rest == 0, (bits, hex(k))
+            assert all(i < entries for i in idx), (bits, hex(k))
+            assert signed or not any(neg)
+            assert sum((-int(i) if s else int(i)) << (bits * j) for j, (i, s) in enumerate(zip(idx, neg))) == k, (bits, hex(k))

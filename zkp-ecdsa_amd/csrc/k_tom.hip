@@ -10,6 +10,7 @@
 // proveMult's variable-base products C4 = x*Cy and A4_2 = kx*Cy (src/commit/mult.ts:103,114) are also commitments
 // with KNOWN openings (x*y, x*ry), so they go through the same kernel (see k_scalar.hip).
 #include "engine.h"
+#include "comb_digits.h"
 
 ZK_DEV TomNiels ld_niels(const uint32_t* e) {
     const uint4* q = (const uint4*)e;
@@ -38,29 +39,6 @@ ZK_DEV void niels_pin(TomNiels& n) {
 // unpaired / paired commitment slots of list B (see k_tom_commit_pairs)
 __device__ const uint8_t LB_SINGLE_K[22] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 17, 18, 19, 20, 23, 24, 25, 26, 29};
 __device__ const uint8_t LB_PAIR_K[6] = {9, 15, 21, 27, 30, 32};
-// 256-bit right shift by a run-time amount < 32 (v_alignbit_b32 per word)
-ZK_DEV void shr256_rt(uint32_t* w, uint32_t sh) {
-#pragma unroll
-    for (int i = 0; i < 7; i++) w[i] = __funnelshift_r(w[i], w[i + 1], sh);
-    w[7] >>= sh;
-}
-// successive comb digits of a 256-bit scalar, lowest window first: table index and sign (always + for unsigned widths)
-struct CombDigits {
-    uint32_t w[8];
-    uint32_t bits, mask, half, carry;
-    bool sgn;
-    ZK_DEV void init(uint32_t b) { bits = b, mask = (1u << b) - 1, half = 1u << (b - 1), carry = 0, sgn = tom_signed(b); }
-    ZK_DEV void next(uint32_t& idx, bool& neg) {
-        uint32_t d = (w[0] & mask) + carry;
-        shr256_rt(w, bits);
-        neg = sgn && d > half;
-        carry = neg ? 1u : 0u;
-        idx = neg ? (mask + 1) - d : d;
-#ifdef ZK_DEBUG_IDX_MASK  // timing experiments only (wrong results): confine the gathers to the first entries of each window
-        idx &= ZK_DEBUG_IDX_MASK;
-#endif
-    }
-};
 template <bool SGN>
 struct NielsSel;  // table entry as used by the addition: as loaded (unsigned combs) or conditionally negated (signed combs)
 template <>

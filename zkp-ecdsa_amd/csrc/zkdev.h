@@ -11,10 +11,12 @@
 #define ZK_LAUNDER_MOD 0
 #define ZK_PIN_LIMBS32 0
 ZK_DEV uint32_t zk_rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+ZK_DEV uint32_t zk_funnelshift_r(uint32_t lo, uint32_t hi, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31)); }
 #else
 #include <hip/hip_runtime.h>
 #define ZK_DEV __device__ __forceinline__
 #define ZK_DEV_NOINLINE __device__ __noinline__
 #define ZK_CONSTANT __constant__
 ZK_DEV uint32_t zk_rotr32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+ZK_DEV uint32_t zk_funnelshift_r(uint32_t lo, uint32_t hi, uint32_t sh) { return __funnelshift_r(lo, hi, sh); }
 #endif
