@@ -324,8 +324,7 @@ def main():
             pin = Z.PinnedBuffer(int(nb * (304 + 336 * sec + 3392 * (sec // 2 + 4) + (4 * 72 + 96) * 20 + 32) + (64 << 20)))
             host_io['zk_host_alloc'] = {'bytes': pin.nbytes, 'seconds': round(time.time() - t_pin, 4)}
             eng.set_chunk(min(args.host_io_chunk, nb))   # smaller chunks: more of the transfer hides under the other chunks' kernels
-            import ctypes
-            page = (ctypes.c_uint8 * pin.nbytes)()
+            page = (C.c_uint8 * pin.nbytes)()
             for name, buf in (('pageable', page), ('pinned', pin)):
                 for _ in range(2):  # the second call: the engine's device staging buffer is allocated once and kept
                     hdt, hout, hoff, hst = eng.prove_batch_host_raw(hm, hs, hp, hw, hseed, out=buf)

@@ -5,7 +5,6 @@ import hashlib
 import os
 import socket
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

@@ -5,7 +5,6 @@ import json
 import os
 import random
 
-import pytest
 
 import zkp_ecdsa_amd as Z
 
