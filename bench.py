@@ -57,7 +57,7 @@ def rank_seeds(base_seeds: bytes, rank: int) -> bytes:
     if rank == 0:
         return base_seeds
     out = bytearray()
-    tag = b'rank' + rank.to_bytes(4, 'big')
+    tag = b'rank' + (rank.to_bytes(4, 'big') if rank < (1 << 32) else rank.to_bytes(12, 'big'))
     for i in range(0, len(base_seeds), 32):
         out += hashlib.sha256(tag + base_seeds[i:i + 32]).digest()
     return bytes(out)
@@ -119,30 +119,184 @@ def v8_bigint_indicator():
             'note': 'approximation of `npm run bench` (V8 BigInt, this build\'s JS restatement); not the cpu_baseline value'}
 
 
-def host_io_rates(Z, eng, args, B, sec, msg, sig, pk, which, seeds):
-    """The same work through HOST buffers (zk_prove_batch / zk_verify_batch): H2D of the inputs, proving, D2H of the proofs, and
-    back in for the verifier; with pageable memory and with page-locked buffers from zk_host_alloc.  Never `value`."""
+def pcie_bandwidth(dev, nbytes=2 << 30):
+    """Plain page-locked copies of `nbytes` in each direction on this box (GB/s): the roofline of the host-pointer calls."""
+    import torch
+    d = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    h = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    out = {}
+    for name, dst, src in (('d2h_gbps', h, d), ('h2d_gbps', d, h)):
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        out[name] = round(nbytes / (time.time() - t0) / 1e9, 2)
+    del d, h
+    return out
+
+
+def host_io_rates(Z, eng, args, B, sec, msg, sig, pk, which, seeds, dev, device_rate, device_vrate):
+    """The SURVEY.md section 8(d) form of the metric: one zk_prove_batch / zk_verify_batch call on HOST buffers -- H2D of the
+    inputs, proving, D2H of the binary proofs, and back in for the verifier -- with page-locked buffers from zk_host_alloc
+    (per-chunk DMA under the kernels, tapered chunk plan) and, optionally, pageable ones.  ~169 KB per proof cross PCIe, so
+    the roofline of these calls is the link: `pcie_frac` = achieved GB/s / this box's measured page-locked copy rate."""
     nb = min(args.host_io, B)
     hm, hs, hp, hw, hseed = msg[:32 * nb], sig[:64 * nb], pk[:64 * nb], which[:nb], seeds[:32 * nb]
+    chunk = min(args.host_io_chunk, nb)
+    eng.set_chunk(chunk)
     eng.prove_batch_host_raw(hm[:32 * 256], hs[:64 * 256], hp[:64 * 256], hw[:256], hseed[:32 * 256])   # warm-up
-    host_io = {'proofs': nb, 'note': 'PCIe-inclusive rates of the host-pointer entry points, not the headline value'}
+    host_io = {'proofs': nb, 'chunk': chunk, 'plan': 'tapered' if not args.host_io_uniform else 'uniform',
+               'note': 'PCIe-inclusive: one zk_prove_batch / zk_verify_batch call on host buffers (SURVEY.md 8(d)); `value` is the device-resident rate'}
+    eng.set_host_taper(0 if args.host_io_uniform else 1)
+    host_io['pcie'] = pcie_bandwidth(dev)
     t_pin = time.time()
     pin = Z.PinnedBuffer(int(nb * (304 + 336 * sec + 3392 * (sec // 2 + 4) + (4 * 72 + 96) * 20 + 32) + (64 << 20)))
     host_io['zk_host_alloc'] = {'bytes': pin.nbytes, 'seconds': round(time.time() - t_pin, 4)}
-    eng.set_chunk(min(args.host_io_chunk, nb))   # smaller chunks: more of the transfer hides under the other chunks' kernels
-    page = (C.c_uint8 * pin.nbytes)()
-    for name, buf in (('pageable', page), ('pinned', pin)):
-        for _ in range(2):  # the second call: the engine's device staging buffer is allocated once and kept
+    bufs = [('pinned', pin)]
+    if args.host_io_pageable:
+        bufs.append(('pageable', (C.c_uint8 * pin.nbytes)()))
+    for name, buf in bufs:
+        best_p, best_v = None, None
+        for _ in range(args.host_io_reps + 1):  # the first call allocates the engine's staging buffers (kept afterwards)
             hdt, hout, hoff, hst = eng.prove_batch_host_raw(hm, hs, hp, hw, hseed, out=buf)
             vdt, vok, vst = eng.verify_batch_host_raw(hm, hout, hoff, nb)
-        host_io[name] = {'prove_s': round(hdt, 4), 'proofs_per_s': round(nb / hdt, 1), 'verify_s': round(vdt, 4),
-                         'verifies_per_s': round(nb / vdt, 1), 'out_bytes': int(hoff[nb]),
-                         'failed_proofs': sum(1 for x in hst if x != 0), 'accepted': sum(1 for x in vok if x == 1)}
-    del page, hout
+            if _ > 0:
+                best_p = hdt if best_p is None else min(best_p, hdt)
+                best_v = vdt if best_v is None else min(best_v, vdt)
+        nbytes = int(hoff[nb])
+        rec = {'prove_s': round(best_p, 4), 'proofs_per_s': round(nb / best_p, 1), 'verify_s': round(best_v, 4),
+               'verifies_per_s': round(nb / best_v, 1), 'out_bytes': nbytes,
+               'd2h_gbps': round(nbytes / best_p / 1e9, 2), 'h2d_gbps': round(nbytes / best_v / 1e9, 2),
+               'failed_proofs': sum(1 for x in hst if x != 0), 'accepted': sum(1 for x in vok if x == 1)}
+        if name == 'pinned':
+            rec['prove_frac_of_device_resident'] = round(nb / best_p / device_rate, 3) if device_rate else None
+            rec['verify_frac_of_device_resident'] = round(nb / best_v / device_vrate, 3) if device_vrate else None
+            rec['prove_pcie_frac'] = round(rec['d2h_gbps'] / host_io['pcie']['d2h_gbps'], 3)
+            rec['verify_pcie_frac'] = round(rec['h2d_gbps'] / host_io['pcie']['h2d_gbps'], 3)
+        host_io[name] = rec
+    del hout
     pin.free()
-    host_io['chunk'] = min(args.host_io_chunk, nb)
     eng.set_chunk(min(args.chunk, B))
     return host_io
+
+
+def run_verify_mode(args, torch, Z, world, rank, local_rank, dev):
+    """BASELINE.json configs[4]: verifySignatureList over `--batch` proofs IN TOTAL and a ring of `--ring` keys, sharded over the
+    ranks (batch / world proofs each, no data-path collective).  2^20 proofs are ~177 GB and do not fit next to the tables, so
+    a rank streams its shard in slabs: prove `--slab` proofs into HBM (untimed: the workload generator of this mode), verify
+    them (timed, every call bracketed by synchronize), next slab.  All slabs prove the same `--slab` statements under fresh
+    per-slab randomness -- distinct proofs, identical verifier work.  A step = one pass over the rank's shard."""
+    import torch.distributed as dist
+    total, nkeys, sec = args.batch, args.ring, args.sec
+    assert total % world == 0, '--batch must be a multiple of the number of ranks'
+    shard = total // world
+    slab = min(args.slab, shard)
+    nslabs = (shard + slab - 1) // slab
+    eng = Z.Engine(local_rank)
+    nh, tg, th = eng.synth_params(args.seed)
+    eng.set_comb_bits(args.comb_bits)
+    eng.set_params(nh, tg, th, sec)
+    eng.set_chunk(min(args.chunk, slab))
+    eng.set_lanes(args.lanes)
+    ring, msg, sig, pk, which, seeds = eng.synth_workload(args.seed, nkeys, slab)
+    d_ring = torch.frombuffer(bytearray(ring), dtype=torch.uint8).to(dev)
+    if world > 1:
+        if rank != 0:
+            d_ring.zero_()
+        dist.broadcast(d_ring, src=0)
+    torch.cuda.synchronize()
+    t_ring = time.time()
+    eng.set_ring_device(d_ring.data_ptr(), nkeys)
+    t_ring = time.time() - t_ring
+    tb = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d_msg, d_sig, d_pk = tb(msg), tb(sig), tb(pk)
+    d_which = torch.tensor(which, dtype=torch.int32, device=dev)
+    n_log2 = max(1, (nkeys - 1).bit_length())
+    cap = int(slab * (304 + 336 * sec + 3392 * (sec // 2 + 4) + (4 * 72 + 96) * n_log2 + 32) + (64 << 20))
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_off = torch.empty(slab + 1, dtype=torch.int64, device=dev)
+    d_st = torch.empty(slab, dtype=torch.int32, device=dev)
+    d_ok = torch.empty(slab, dtype=torch.uint8, device=dev)
+    d_vst = torch.empty(slab, dtype=torch.int32, device=dev)
+
+    def one_pass(pass_no, timed):
+        t_v, acc, t_p, nbytes = 0.0, 0, 0.0, 0
+        for sl in range(nslabs):
+            cnt = min(slab, shard - sl * slab)
+            key = (rank * 1000003 + pass_no) * 4099 + sl + 1
+            d_seeds = tb(rank_seeds(seeds[:32 * cnt], key))
+            d_vseeds = tb(rank_seeds(seeds[:32 * cnt], key + (1 << 40)))
+            t0 = time.time()
+            eng.prove_batch_device(cnt, d_msg.data_ptr(), d_sig.data_ptr(), d_pk.data_ptr(), d_which.data_ptr(), d_seeds.data_ptr(),
+                                   d_out.data_ptr(), cap, d_off.data_ptr(), d_st.data_ptr())
+            torch.cuda.synchronize()
+            t_p += time.time() - t0
+            forged = []
+            if timed and pass_no == 0 and sl == 0 and cnt >= 64:   # planted forgeries in the first timed slab
+                off = d_off[:cnt + 1].cpu().tolist()
+                forged = [3, cnt // 2, cnt - 1]
+                for b in forged:
+                    d_out[off[b + 1] - 9] ^= 1   # a byte of the GK response zd: always caught
+            torch.cuda.synchronize()
+            t0 = time.time()
+            eng.verify_batch_device(cnt, d_msg.data_ptr(), d_out.data_ptr(), d_off.data_ptr(), d_vseeds.data_ptr(), d_ok.data_ptr(), d_vst.data_ptr())
+            torch.cuda.synchronize()
+            t_v += time.time() - t0
+            okc = d_ok[:cnt].cpu()
+            if forged:
+                assert [b for b in range(cnt) if not okc[b]] == forged, 'planted forgeries not (exactly) rejected'
+                okc[forged] = 1
+            assert int((d_st[:cnt] != 0).sum().item()) == 0
+            acc += int(okc.sum().item())
+            nbytes += int(d_off[cnt].item())
+        return t_v, t_p, acc, nbytes
+
+    for w in range(args.warmup):
+        one_pass(-1 - w, False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    tv = tp = 0.0
+    accepted = nbytes = 0
+    for k in range(args.steps):
+        a, b, c, d = one_pass(k, True)
+        tv, tp, accepted, nbytes = tv + a, tp + b, accepted + c, nbytes + d
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.set_lanes(1)
+    eng.verify_batch_device(slab, d_msg.data_ptr(), d_out.data_ptr(), d_off.data_ptr(), None, d_ok.data_ptr(), d_vst.data_ptr())
+    _, vfam = eng.last_timing()
+    if world > 1:
+        t = torch.tensor([tv], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tv = float(t.item())
+        t = torch.tensor([accepted], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        accepted = int(t.item())
+    free_b, total_b = torch.cuda.mem_get_info()
+    if rank == 0:
+        ring_modmuls = nkeys * (n_log2 + 1)
+        line = {
+            'metric': 'verifySignatureList verifies/sec', 'value': round(total * args.steps / tv, 2), 'unit': 'verifies/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(tv * 1e3 / args.steps, 2),
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'u32 (9x30-bit limbs, 256/258-bit modular integers)',
+            'data': 'synthetic',
+            'config': {'workload': 'verifySignatureList batch=%d proofs in total, ring=%d keys (n=%d), secLevel=%d, %d proofs per rank streamed in %d slabs of %d, chunk=%d'
+                                   % (total, nkeys, n_log2, sec, shard, nslabs, slab, min(args.chunk, slab)),
+                       'parallelism': 'proofs sharded per GPU; ring broadcast over RCCL at set-up' if world > 1 else 'single GPU'},
+            'accepted': accepted, 'of': total * args.steps, 'planted_forgeries_rejected': 3 if slab >= 64 else 0,
+            'timed_region': 'the zk_verify_batch_device calls only (proofs resident in HBM); generating the slabs took %.2f s per pass on rank 0' % (tp / max(1, args.steps)),
+            'proof_bytes_per_pass': nbytes // max(1, args.steps), 'set_ring_s': round(t_ring, 3), 'hbm_used_gb': round((total_b - free_b) / 2**30, 1),
+            'gpu_ms_by_family_per_slab': {k: round(v, 2) for k, v in sorted(vfam.items(), key=lambda kv: -kv[1])},
+            'ring_fold': {'reference_modmuls_per_proof': ring_modmuls, 'note': 'gk.ts:239-250 does N*(n+1) modular multiplications per proof; the engine folds the ring in ratio form over table E (DESIGN.md section 4)'},
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
 
 
 def main():
@@ -161,8 +315,14 @@ def main():
     ap.add_argument('--lanes', type=int, default=2, help='chunks in flight on separate streams during the timed steps (1 = serial)')
     ap.add_argument('--roofline-steps', type=int, default=1, help='extra single-lane passes used only for per-kernel timings')
     ap.add_argument('--verify-steps', type=int, default=1, help='timed verifySignatureList passes over the produced proofs (0 = skip)')
-    ap.add_argument('--host-io', type=int, default=8192, help='proofs of one extra zk_prove_batch call on HOST buffers (PCIe-inclusive rate, reported apart; 0 = skip)')
-    ap.add_argument('--host-io-chunk', type=int, default=4096, help='proofs per pipeline pass during the --host-io calls')
+    ap.add_argument('--host-io', type=int, default=1 << 30, help='proofs of the zk_prove_batch / zk_verify_batch calls on HOST buffers (PCIe-inclusive rates; default: the whole batch; 0 = skip)')
+    ap.add_argument('--host-io-chunk', type=int, default=4096, help='largest chunk of the (tapered) plan during the --host-io calls')
+    ap.add_argument('--host-io-reps', type=int, default=2, help='timed repetitions of the host-buffer calls (best is reported)')
+    ap.add_argument('--host-io-uniform', action='store_true', help='uniform chunks instead of the tapered plan')
+    ap.add_argument('--host-io-pageable', action='store_true', help='also measure ordinary (pageable) host buffers')
+    ap.add_argument('--mode', choices=['prove', 'verify'], default='prove',
+                    help="verify: BASELINE configs[4] -- --batch proofs IN TOTAL over --ring keys, sharded over the ranks, generated and verified in streamed slabs")
+    ap.add_argument('--slab', type=int, default=8192, help='--mode verify: proofs generated and verified per slab')
     ap.add_argument('--check', type=int, default=1 << 30, help='proofs of the last step diffed against the oracle on rank 0 (at most the CPU sample)')
     args = ap.parse_args()
 
@@ -181,6 +341,8 @@ def main():
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 
+    if args.mode == 'verify':
+        return run_verify_mode(args, torch, Z, world, rank, local_rank, dev)
     B, nkeys, sec = args.batch, args.ring, args.sec
     eng = Z.Engine(local_rank)
     nh, tg, th = eng.synth_params(args.seed)
@@ -328,7 +490,7 @@ def main():
             'nominal_modmuls_per_proof': {'F_t': wt, 'F_q_ec': wq, 'F_q_ring': wring},
         }
         cpu = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:   # rank 0, at every N (the other ranks wait at the final barrier)
             sample = args.cpu_sample or 4 * host_cores()
             cpu, oproofs = cpu_baseline(nh, tg, th, ring, nkeys, msg, sig, pk, which, seeds, sec, min(sample, B))
             # spot-check: the first proofs of the last step against the oracle, byte for byte
@@ -341,7 +503,8 @@ def main():
         host_io = None
         if args.host_io > 0 and world == 1:
             try:
-                host_io = host_io_rates(Z, eng, args, B, sec, msg, sig, pk, which, seeds)
+                host_io = host_io_rates(Z, eng, args, B, sec, msg, sig, pk, which, seeds, dev, B * args.steps / dt,
+                                        verify['value'] / world if verify else None)
             except Exception as e:  # an auxiliary measurement must never cost the bench line
                 host_io = {'error': repr(e)[:300]}
             eng.set_chunk(min(args.chunk, B))
@@ -361,6 +524,11 @@ def main():
             'gpu_ms_note': 'serial single-lane pass (sum = %.1f ms); the timed steps overlap two chunks on two streams' % (gpu_ms / max(1, args.roofline_steps)),
             'roofline': roofline, 'cpu_baseline': cpu, 'verify': verify, 'host_io': host_io,
         }
+        if host_io and 'pinned' in host_io:   # the SURVEY.md 8(d) form of the metric, next to the device-resident `value`
+            line['value_pcie_inclusive'] = host_io['pinned']['proofs_per_s']
+            line['verify_pcie_inclusive'] = host_io['pinned']['verifies_per_s']
+            line['value_note'] = ('value: inputs and proofs resident in HBM (bench contract); value_pcie_inclusive: one zk_prove_batch call on '
+                                  'page-locked host buffers incl. H2D of the inputs and D2H of %.2f GB of proofs' % (host_io['pinned']['out_bytes'] / 1e9))
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

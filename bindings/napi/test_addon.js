@@ -1,79 +1,168 @@
-// node test_addon.js json <golden.json>      CPU-only: JSON wire format through the addon against the committed digest
-// node test_addon.js gpu                       on an MI355X: synthetic workload -> prove -> writeJson/readJson -> verify
+// node test_addon.js cpu <golden.json>   CPU-only: params / keys / serde of the façade, JSON wire format against the committed digest
+// node test_addon.js gpu                  on an MI355X: the reference's own tests restated against the façade + the batch calls
 'use strict'
 const assert = require('assert')
 const crypto = require('crypto')
 const fs = require('fs')
 const zk = require('./zkattest.js')
-const i32 = (buf) => new Int32Array(buf.buffer, buf.byteOffset, buf.length / 4)
+const { generateParamsList, keyToInt, proveSignatureList, verifySignatureList, writeJson, readJson, SignatureProofList, SystemParametersList } = zk
+const i32 = (buf) => new Int32Array(buf.buffer.slice(buf.byteOffset, buf.byteOffset + buf.length))
 
-async function main() {
-    const mode = process.argv[2]
-    if (mode === 'json') {
-        const gold = JSON.parse(fs.readFileSync(process.argv[3], 'utf8'))
-        const rec = gold.small_full.proofs[0]
-        const proof = Buffer.from(rec.proof, 'hex')
-        const text = zk.writeJson(proof)
-        assert.strictEqual(text.length, rec.json_len)
-        assert.strictEqual(crypto.createHash('sha256').update(text).digest('hex'), rec.json_sha256)
-        assert.ok(zk.readJson(text).equals(proof))
-        const obj = JSON.parse(text)
-        assert.deepStrictEqual(Object.keys(obj), ['R', 'comS1', 'keyXcom', 'keyYcom', 'expProof', 'membershipProof'])
-        assert.throws(() => zk.readJson(text.slice(0, -1)), /error deserializing/)
-        console.log('json ok', text.length)
-        return
+// test/serde.test.ts:21-32
+function serdeTest(type, object) {
+    const json = writeJson(type, object), object2 = readJson(type, json)
+    return object.eq(object2)
+}
+// what crypto.subtle.generateKey / sign / digest give the reference's test, from Node's OpenSSL (Node 12 has no WebCrypto)
+function keyAndSignature(text) {
+    const keyPair = crypto.generateKeyPairSync('ec', { namedCurve: 'P-256' }), msg = Buffer.from(text)
+    return { keyPair, msgHash: crypto.createHash('sha256').update(msg).digest(),
+        signature: crypto.sign('sha256', msg, { key: keyPair.privateKey, dsaEncoding: 'ieee-p1363' }) }   // r || s, like WebCrypto ECDSA
+}
+
+async function cpu(goldenPath) {
+    // generateParamsList (zkpAttestList.ts:88-92): h = g * rnd on both groups, default secLevel 80; serde round trip with eq()
+    const params = generateParamsList()
+    assert.strictEqual(params.SecLevel, 80)
+    assert.ok(params.NistGroup.c.eq(zk.p256) && params.ProofGroup.c.eq(zk.tomEdwards256))
+    assert.ok(params.NistGroup.g.eq(zk.p256.generator()) && zk.p256.isOnGroup(params.NistGroup.h) && zk.tomEdwards256.isOnGroup(params.ProofGroup.h))
+    assert.ok(!generateParamsList(40).eq(params) && generateParamsList(40).SecLevel === 40)
+    assert.ok(serdeTest(SystemParametersList, params))
+    const obj = JSON.parse(writeJson(SystemParametersList, params))
+    assert.deepStrictEqual(Object.keys(obj), ['NistGroup', 'ProofGroup', 'SecLevel'])
+    assert.deepStrictEqual(Object.keys(obj.NistGroup), ['c', 'g', 'h'])
+    assert.strictEqual(obj.ProofGroup.c.name, 'tomEdwards256')
+    assert.ok(/^0x[0-9a-f]+$/.test(obj.ProofGroup.h.x))
+    const tampered = JSON.parse(JSON.stringify(obj))
+    tampered.ProofGroup.h.x = '0x5'
+    assert.throws(() => readJson(SystemParametersList, JSON.stringify(tampered)), /point not in group/)
+    tampered.ProofGroup.h.group.name = 'war256'
+    assert.throws(() => readJson(SystemParametersList, JSON.stringify(tampered)), /invalid group name/)
+    const ep = params.engineParams()
+    assert.ok(ep.nistH.length === 64 && ep.tomG.length === 72 && ep.tomH.length === 72 && ep.secLevel === 80)
+    // group sanity (test/curves/ec.test.ts:21-40): order * G = identity, P + (order - 1) P = identity
+    for (const g of zk.ALL_GROUPS) {
+        const G = g.generator()
+        assert.ok(G.mul(g.order).isIdentity() && G.add(G.mul(g.order - 1n)).isIdentity() && g.isOnGroup(G.mul(12345678901234567890n)))
     }
+    // keyToInt (zkpAttestList.ts:94-102): x coordinate of a KeyObject / raw export; off-curve keys are refused
+    const { keyPair } = keyAndSignature('x')
+    const raw = keyPair.publicKey.export({ type: 'spki', format: 'der' }).slice(-65)
+    assert.strictEqual(await keyToInt(keyPair.publicKey), BigInt('0x' + raw.slice(1, 33).toString('hex')))
+    assert.strictEqual(await keyToInt(raw), await keyToInt(keyPair.publicKey))
+    const off = Buffer.from(raw)
+    off[64] ^= 1
+    await assert.rejects(keyToInt(off), /point not in group/)
+    // JSON wire format of a proof against the committed digest; object model with eq()
+    const gold = JSON.parse(fs.readFileSync(goldenPath, 'utf8'))
+    const rec = gold.small_full.proofs[0]
+    const proof = new SignatureProofList(Buffer.from(rec.proof, 'hex'))
+    const text = writeJson(SignatureProofList, proof)
+    assert.strictEqual(text.length, rec.json_len)
+    assert.strictEqual(crypto.createHash('sha256').update(text).digest('hex'), rec.json_sha256)
+    assert.ok(serdeTest(SignatureProofList, proof))
+    assert.deepStrictEqual(Object.keys(JSON.parse(text)), ['R', 'comS1', 'keyXcom', 'keyYcom', 'expProof', 'membershipProof'])
+    assert.ok(proof.R.group.eq(zk.p256) && zk.p256.isOnGroup(proof.R) && proof.keyXcom.group.eq(zk.tomEdwards256) && zk.tomEdwards256.isOnGroup(proof.keyXcom))
+    assert.strictEqual(proof.expProof.length, gold.small_full.sec)
+    assert.ok(proof.expProof.every((e) => ('alpha' in e) !== ('proof' in e)) && proof.membershipProof.zd.group.eq(zk.tomEdwards256))
+    const other = Buffer.from(proof.bytes)
+    other[other.length - 1] ^= 1
+    assert.ok(!proof.eq(new SignatureProofList(other)))
+    assert.throws(() => readJson(SignatureProofList, text.slice(0, -1)), /error deserializing/)
+    console.log('cpu ok', text.length)
+}
+
+async function gpu() {
+    // ---- test/zkpAttestList.test.ts:28-54, argument for argument
+    {
+        const { keyPair, msgHash, signature } = keyAndSignature('kilroy was here'),
+            testKey = await keyToInt(keyPair.publicKey),
+            testArray = [testKey, BigInt(4), BigInt(5), BigInt(6), BigInt(7), BigInt(8)],
+            params = generateParamsList(),
+            proof = await proveSignatureList(params, msgHash, signature, keyPair.publicKey, 0, testArray),
+            res = await verifySignatureList(params, msgHash, testArray, proof)
+        assert.strictEqual(res, true)
+        assert.ok(serdeTest(SignatureProofList, proof))
+        assert.ok(serdeTest(SystemParametersList, params))
+        // example/usage.ts:43-57: JSON out, verify
+        const proofJSON = writeJson(SignatureProofList, proof)
+        assert.ok(proofJSON.length > 100000)
+        assert.strictEqual(await verifySignatureList(params, msgHash, testArray, readJson(SignatureProofList, proofJSON)), true)
+        // negative cases the reference has no test for: another message, another ring, a signer outside the ring
+        assert.strictEqual(await verifySignatureList(params, crypto.createHash('sha256').update('x').digest(), testArray, proof), false)
+        const otherRing = testArray.slice()
+        otherRing[0] = BigInt(9)
+        assert.strictEqual(await verifySignatureList(params, msgHash, otherRing, proof), false)
+        assert.strictEqual(await verifySignatureList(params, msgHash, testArray, proof), true)   // and back: the ring cache follows the argument
+        const stranger = keyAndSignature('kilroy was here')
+        const p2 = await proveSignatureList(params, msgHash, stranger.signature, stranger.keyPair.publicKey, 0, testArray)
+        assert.strictEqual(await verifySignatureList(params, msgHash, testArray, p2), false)
+        // params are cached by identity: a second SystemParametersList with the same content reuses the engine
+        const again = readJson(SystemParametersList, writeJson(SystemParametersList, params))
+        const t0 = Date.now()
+        assert.strictEqual(await verifySignatureList(again, msgHash, testArray, proof), true)
+        assert.ok(Date.now() - t0 < 2000)
+        // interleaved callers with different rings on one engine
+        const [a, b] = await Promise.all([verifySignatureList(params, msgHash, testArray, proof), verifySignatureList(params, msgHash, otherRing, proof)])
+        assert.deepStrictEqual([a, b], [true, false])
+        const badKey = keyPair.publicKey.export({ type: 'spki', format: 'der' }).slice(-65)
+        badKey[64] ^= 1
+        await assert.rejects(proveSignatureList(params, msgHash, signature, badKey, 0, testArray), /point not in group/)
+        // the batch form over the same ring
+        const B = 5, ks = Array.from({ length: B }, (_, i) => keyAndSignature('message ' + i))
+        const ring = await Promise.all(ks.map((k) => keyToInt(k.keyPair.publicKey)))
+        const proofs = await zk.proveSignatureListBatch(params, ks.map((k) => k.msgHash), ks.map((k) => k.signature), ks.map((k) => k.keyPair.publicKey), [0, 1, 2, 3, 4], ring)
+        const swapped = [proofs[1], proofs[0], proofs[2], proofs[3], proofs[4]]
+        assert.deepStrictEqual(await zk.verifySignatureListBatch(params, ks.map((k) => k.msgHash), ring, proofs), Array(B).fill(true))
+        assert.deepStrictEqual(await zk.verifySignatureListBatch(params, ks.map((k) => k.msgHash), ring, swapped), [false, false, true, true, true])
+        zk.shutdown()
+    }
+    // ---- the low-level engine: synthetic workload, determinism under the RNG contract, misuse of handles
     const eng = new zk.Engine(0)
     const params = eng.synthParams(7)
     eng.setParams(params)
     const B = 6, nKeys = 16
     const wl = eng.synthWorkload(7, nKeys, B)
-    eng.setRing(wl.ring)
+    assert.strictEqual(eng.setRing(wl.ring), 'single')
     const proofs = eng.proveBatch(wl.msg, wl.sig, wl.pk, wl.which, wl.seeds)
     assert.strictEqual(proofs.length, B)
     const again = eng.proveBatch(wl.msg, wl.sig, wl.pk, wl.which, wl.seeds)             // deterministic under the RNG contract
     assert.ok(again.every((p, i) => p.equals(proofs[i])))
-    const viaJson = proofs.map((p) => zk.readJson(zk.writeJson(p)))                      // test/zkpAttestList.test.ts:55-60
+    const viaJson = proofs.map((p) => readJson(SignatureProofList, writeJson(SignatureProofList, p)).bytes)
     assert.deepStrictEqual(eng.verifyBatch(wl.msg, viaJson), Array(B).fill(true))
     const forged = Buffer.from(proofs[2])
     forged[forged.length - 1] ^= 1
     const mixed = proofs.slice()
     mixed[2] = forged
     assert.deepStrictEqual(eng.verifyBatch(wl.msg, mixed), [true, true, false, true, true, true])
-    const one = await zk.proveSignatureList(eng, wl.msg.slice(0, 32), wl.sig.slice(0, 64), Buffer.concat([Buffer.from([4]), wl.pk.slice(0, 64)]), 0)
-    assert.strictEqual(await zk.verifySignatureList(eng, wl.msg.slice(0, 32), one), true)
     const bad = Buffer.from(wl.pk.slice(0, 64))
     bad[63] ^= 1
     assert.throws(() => eng.proveBatch(wl.msg.slice(0, 32), wl.sig.slice(0, 64), bad, [0], wl.seeds.slice(0, 32)), /point not in group/)
-    // Promise-based calls: two batches queued back to back on one engine, results in order
     const [pa, pb] = await Promise.all([eng.proveBatchAsync(wl.msg, wl.sig, wl.pk, wl.which, wl.seeds), eng.proveBatchAsync(wl.msg.slice(0, 64), wl.sig.slice(0, 128), wl.pk.slice(0, 128), [0, 1], wl.seeds.slice(0, 64))])
     assert.ok(pa.every((p, i) => p.equals(proofs[i])) && pb.length === 2 && pb[1].equals(proofs[1]))
     assert.deepStrictEqual(await eng.verifyBatchAsync(wl.msg, mixed), [true, true, false, true, true, true])
     await assert.rejects(eng.proveBatchAsync(wl.msg.slice(0, 32), wl.sig.slice(0, 64), bad, [0], wl.seeds.slice(0, 32)), /point not in group/)
-    // the reference's own test flow (test/zkpAttestList.test.ts:25-63) with REAL keys and signatures made by Node's OpenSSL:
-    // ECDSA P-256 / SHA-256 key pairs, ring = keyToInt of every public key, prove for one of them, JSON round trip, verify
-    {
-        const n = 5, mine = 3, message = Buffer.from('ZKAttest: the signer is one of the ring, nobody learns which one')
-        const pairs = Array.from({ length: n }, () => crypto.generateKeyPairSync('ec', { namedCurve: 'P-256' }))
-        const raw = pairs.map((kp) => kp.publicKey.export({ type: 'spki', format: 'der' }).slice(-65))   // 04 || X || Y
-        const ring = eng.keysToInts(Buffer.concat(raw.map((r) => r.slice(1))))
-        assert.ok(i32(ring.status).every((v) => v === 0))
-        eng.setRing(ring.keys)
-        const sig = crypto.sign('sha256', message, { key: pairs[mine].privateKey, dsaEncoding: 'ieee-p1363' })   // r || s
-        const msgHash = crypto.createHash('sha256').update(message).digest()
-        const proof = await zk.proveSignatureList(eng, msgHash, sig, raw[mine], mine)
-        assert.strictEqual(await zk.verifySignatureList(eng, msgHash, zk.readJson(zk.writeJson(proof))), true)
-        const otherHash = crypto.createHash('sha256').update('another message').digest()
-        assert.strictEqual(await zk.verifySignatureList(eng, otherHash, proof), false)
-        const stranger = crypto.generateKeyPairSync('ec', { namedCurve: 'P-256' })                       // not in the ring
-        const sig2 = crypto.sign('sha256', message, { key: stranger.privateKey, dsaEncoding: 'ieee-p1363' })
-        const p2 = await zk.proveSignatureList(eng, msgHash, sig2, stranger.publicKey.export({ type: 'spki', format: 'der' }).slice(-65), mine)
-        assert.strictEqual(await zk.verifySignatureList(eng, msgHash, p2), false)
-        eng.setRing(wl.ring)
-    }
+    // a handle is busy while an asynchronous batch runs: direct calls and destroy are refused instead of racing the worker thread
+    const running = zk.native.proveBatchAsync(eng.h, wl.msg, wl.sig, wl.pk, wl.which, wl.seeds)
+    assert.throws(() => zk.native.setRing(eng.h, wl.ring), /busy/)
+    assert.throws(() => zk.native.destroyPool(eng.h), /while an asynchronous batch/)
+    await running
+    // two contexts on this GPU behind one handle: sharded batch, same bytes; the ring went device to device
+    const duo = new zk.Engine([0, 0])
+    duo.setParams(params)
+    assert.strictEqual(duo.setRing(wl.ring), 'peer-copy')
+    assert.strictEqual(duo.info().devices, 2)
+    const sharded = await duo.proveBatchAsync(wl.msg, wl.sig, wl.pk, wl.which, wl.seeds)
+    assert.ok(sharded.every((p, i) => p.equals(proofs[i])))
+    assert.deepStrictEqual(await duo.verifyBatchAsync(wl.msg, mixed), [true, true, false, true, true, true])
+    duo.close()
     const k = eng.keysToInts(wl.pk)
-    assert.ok(k.keys.slice(0, 32).equals(wl.pk.slice(0, 32)))
+    assert.ok(i32(k.status).every((v) => v === 0) && k.keys.slice(0, 32).equals(wl.pk.slice(0, 32)))
+    const h = eng.h
     eng.close()
+    eng.close()                                                                          // idempotent
+    assert.throws(() => zk.native.setRing(h, wl.ring), /destroyed/)
     console.log('gpu ok', proofs[0].length)
 }
-main().catch((e) => { console.error(e); process.exit(1) })
+const mode = process.argv[2]
+;(mode === 'cpu' || mode === 'json' ? cpu(process.argv[3]) : gpu()).catch((e) => { console.error(e); process.exit(1) })

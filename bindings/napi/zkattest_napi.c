@@ -4,10 +4,14 @@
  *   gcc -shared -fPIC -O2 -I/usr/include/node -I../../include zkattest_napi.c -o zkattest.node \
  *       -L../../zkp-ecdsa_amd/lib -lzkattest_hip -Wl,-rpath,<abs path of zkp-ecdsa_amd/lib>
  *
- * Calls are synchronous here; a production façade would wrap proveBatch / verifyBatch in napi_create_async_work so
- * that the TypeScript signatures stay Promise-returning without blocking the event loop (the context is not re-entrant:
- * one batch in flight per context).  All buffers are caller-visible Node Buffers / typed arrays; the engine copies. */
+ * One handle = one zk_pool = the listed GPUs of this node (one GPU: a pool of one).  A handle runs one batch at a time: the
+ * synchronous calls finish before they return, the *Async calls run on a libuv worker thread and mark the handle busy
+ * until their Promise settles; a second call on a busy handle, any call on a destroyed one, and destroying a busy one
+ * throw instead of touching freed memory.  The garbage collector destroys a handle nobody closed.
+ * Large proof buffers are page-locked (zk_host_alloc) and handed to JavaScript as external Buffers, so the engine moves
+ * the proof bytes by DMA under its kernels and nothing is copied on the way out. */
 #define NAPI_VERSION 3
+#include <math.h>
 #include <node_api.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -15,21 +19,28 @@
 #include <string.h>
 #include "zkattest.h"
 
-#define NAPI_OK(call)                                          \
-    do {                                                       \
-        if ((call) != napi_ok) {                               \
+#define NAPI_OK(call)                                                 \
+    do {                                                              \
+        if ((call) != napi_ok) {                                      \
             napi_throw_error(env, NULL, "N-API call failed: " #call); \
-            return NULL;                                       \
-        }                                                      \
+            return NULL;                                              \
+        }                                                             \
     } while (0)
+#define PINNED_MIN ((size_t)32 << 20) /* proof buffers from this size on are page-locked */
 
-static napi_value throw_status(napi_env env, zk_ctx *ctx, zk_status st) {
-    char msg[512];
-    const char *detail = ctx ? zk_last_error(ctx) : "";
+typedef struct {
+    zk_pool *pool;
+    int busy, closed;
+    uint32_t sec;
+} Handle;
+
+static napi_value throw_text(napi_env env, zk_status st, const char *detail) {
+    char msg[640];
     snprintf(msg, sizeof msg, "%s%s%s", zk_strerror(st), detail && detail[0] ? ": " : "", detail ? detail : "");
     napi_throw_error(env, NULL, msg); /* the reference's error texts: 'point not in group', 'T[i] is at infinity', ... */
     return NULL;
 }
+static napi_value throw_status(napi_env env, Handle *h, zk_status st) { return throw_text(env, st, h && h->pool ? zk_pool_last_error(h->pool) : ""); }
 static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv) {
     size_t argc = want;
     if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < want) {
@@ -38,13 +49,28 @@ static int get_args(napi_env env, napi_callback_info info, size_t want, napi_val
     }
     return 1;
 }
-static zk_ctx *get_ctx(napi_env env, napi_value v) {
+/* the handle behind an external; refuses destroyed and (unless allow_busy) busy ones */
+static Handle *get_handle(napi_env env, napi_value v, int allow_busy) {
     void *p = NULL;
     if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
-        napi_throw_type_error(env, NULL, "expected a context");
+        napi_throw_type_error(env, NULL, "expected an engine handle");
         return NULL;
     }
-    return (zk_ctx *)p;
+    Handle *h = p;
+    if (h->closed || !h->pool) {
+        napi_throw_error(env, NULL, "the engine has been destroyed");
+        return NULL;
+    }
+    if (h->busy && !allow_busy) {
+        napi_throw_error(env, NULL, "the engine is busy with an asynchronous batch (one batch at a time per engine)");
+        return NULL;
+    }
+    return h;
+}
+static void handle_finalize(napi_env env, void *data, void *hint) {
+    Handle *h = data;
+    if (h->pool && !h->busy) zk_pool_destroy(h->pool);
+    free(h);
 }
 /* Buffer or typed array -> pointer + byte length (NULL for null/undefined) */
 static int get_bytes(napi_env env, napi_value v, uint8_t **p, size_t *len) {
@@ -76,256 +102,404 @@ static napi_value new_buffer(napi_env env, const void *src, size_t len) {
     if (napi_create_buffer_copy(env, len, len ? src : "", &dst, &b) != napi_ok) return NULL;
     return b;
 }
-static void set_prop(napi_env env, napi_value obj, const char *name, napi_value v) { napi_set_named_property(env, obj, name, v); }
+static void set_prop(napi_env env, napi_value obj, const char *name, napi_value v) {
+    if (v) napi_set_named_property(env, obj, name, v);
+}
+static void *xmalloc(napi_env env, size_t n) {
+    void *p = malloc(n ? n : 1);
+    if (!p && env) napi_throw_error(env, NULL, "out of memory");
+    return p;
+}
+/* proof buffers: page-locked from PINNED_MIN on */
+typedef struct {
+    uint8_t *p;
+    size_t cap;
+    int pinned;
+} Slab;
+static int slab_alloc(Slab *s, size_t cap) {
+    s->cap = cap ? cap : 1, s->pinned = 0, s->p = NULL;
+    if (s->cap >= PINNED_MIN) {
+        s->p = zk_host_alloc(s->cap);
+        s->pinned = s->p != NULL;
+    }
+    if (!s->p) s->p = malloc(s->cap);
+    return s->p != NULL;
+}
+static void slab_free(Slab *s) {
+    if (s->p) {
+        if (s->pinned) zk_host_free(s->p);
+        else free(s->p);
+    }
+    s->p = NULL;
+}
+static void slab_finalize(napi_env env, void *data, void *hint) {
+    if (hint) zk_host_free(data);
+    else free(data);
+}
+/* hands the slab to JavaScript as a Buffer of `len` bytes (ownership moves to the Buffer) */
+static napi_value slab_to_buffer(napi_env env, Slab *s, size_t len) {
+    napi_value b = NULL;
+    if (napi_create_external_buffer(env, len, s->p, slab_finalize, s->pinned ? (void *)1 : NULL, &b) != napi_ok) {
+        slab_free(s);
+        return NULL;
+    }
+    s->p = NULL;
+    return b;
+}
 
-static napi_value CreateContext(napi_env env, napi_callback_info info) {
+static napi_value CreatePool(napi_env env, napi_callback_info info) { /* (deviceIds: Int32Array | Buffer of i32) -> handle */
     napi_value argv[1];
     if (!get_args(env, info, 1, argv)) return NULL;
-    int32_t dev = 0;
-    NAPI_OK(napi_get_value_int32(env, argv[0], &dev));
-    zk_ctx *ctx = NULL;
-    zk_status st = zk_ctx_create(dev, &ctx);
+    uint8_t *ids;
+    size_t li;
+    if (!get_bytes(env, argv[0], &ids, &li)) return NULL;
+    if (!ids || li < 4 || li % 4) {
+        napi_throw_type_error(env, NULL, "createPool: an Int32Array of device ids");
+        return NULL;
+    }
+    Handle *h = calloc(1, sizeof *h);
+    if (!h) return throw_text(env, ZK_E_BUFFER, "out of memory");
+    h->sec = 80;
+    zk_status st = zk_pool_create((const int *)ids, (int)(li / 4), &h->pool);
     if (st != ZK_OK) {
-        napi_value r = throw_status(env, ctx, st);
-        if (ctx) zk_ctx_destroy(ctx);
+        napi_value r = throw_status(env, h, st);
+        if (h->pool) zk_pool_destroy(h->pool);
+        free(h);
         return r;
     }
     napi_value ext;
-    NAPI_OK(napi_create_external(env, ctx, NULL, NULL, &ext));
+    if (napi_create_external(env, h, handle_finalize, NULL, &ext) != napi_ok) {
+        zk_pool_destroy(h->pool), free(h);
+        napi_throw_error(env, NULL, "could not create the handle");
+        return NULL;
+    }
     return ext;
 }
-static napi_value DestroyContext(napi_env env, napi_callback_info info) {
+static napi_value DestroyPool(napi_env env, napi_callback_info info) { /* idempotent; throws while an async batch is running */
     napi_value argv[1];
     if (!get_args(env, info, 1, argv)) return NULL;
-    zk_ctx *ctx = get_ctx(env, argv[0]);
-    if (ctx) zk_ctx_destroy(ctx);
+    void *p = NULL;
+    if (napi_get_value_external(env, argv[0], &p) != napi_ok || !p) return NULL;
+    Handle *h = p;
+    if (h->closed) return NULL;
+    if (h->busy) {
+        napi_throw_error(env, NULL, "cannot destroy an engine while an asynchronous batch is running on it");
+        return NULL;
+    }
+    h->closed = 1;
+    zk_pool_destroy(h->pool);
+    h->pool = NULL;
     return NULL;
 }
-static napi_value SetParams(napi_env env, napi_callback_info info) { /* (ctx, nistH 64, tomG 72, tomH 72, secLevel) */
+static napi_value PoolInfo(napi_env env, napi_callback_info info) { /* (h) -> {devices, ringTransport, proofMaxSize} */
+    napi_value argv[1], o, v;
+    if (!get_args(env, info, 1, argv)) return NULL;
+    Handle *h = get_handle(env, argv[0], 1);
+    if (!h) return NULL;
+    NAPI_OK(napi_create_object(env, &o));
+    NAPI_OK(napi_create_int32(env, zk_pool_size(h->pool), &v));
+    set_prop(env, o, "devices", v);
+    NAPI_OK(napi_create_string_utf8(env, zk_pool_ring_transport(h->pool), NAPI_AUTO_LENGTH, &v));
+    set_prop(env, o, "ringTransport", v);
+    NAPI_OK(napi_create_double(env, (double)zk_proof_max_size(zk_pool_ctx(h->pool, 0)), &v));
+    set_prop(env, o, "proofMaxSize", v);
+    return o;
+}
+/* (h, name, value): per-device settings applied to every device of the pool */
+static napi_value SetOption(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return NULL;
+    Handle *h = get_handle(env, argv[0], 0);
+    if (!h) return NULL;
+    char name[32];
+    size_t ln;
+    uint32_t val;
+    NAPI_OK(napi_get_value_string_utf8(env, argv[1], name, sizeof name, &ln));
+    NAPI_OK(napi_get_value_uint32(env, argv[2], &val));
+    for (int i = 0; i < zk_pool_size(h->pool); i++) {
+        zk_ctx *c = zk_pool_ctx(h->pool, i);
+        zk_status st = !strcmp(name, "chunk")         ? zk_ctx_set_chunk(c, val)
+                       : !strcmp(name, "lanes")       ? zk_ctx_set_lanes(c, val)
+                       : !strcmp(name, "combBits")    ? zk_ctx_set_comb_bits(c, val)
+                       : !strcmp(name, "hostTaper")   ? zk_ctx_set_host_taper(c, val)
+                       : !strcmp(name, "batchVerify") ? zk_ctx_set_batch_verify(c, val)
+                                                      : ZK_E_ARG;
+        if (st != ZK_OK) return throw_text(env, st, name);
+    }
+    return NULL;
+}
+static napi_value SetParams(napi_env env, napi_callback_info info) { /* (h, nistH 64, tomG 72, tomH 72, secLevel) */
     napi_value argv[5];
     if (!get_args(env, info, 5, argv)) return NULL;
-    zk_ctx *ctx = get_ctx(env, argv[0]);
+    Handle *h = get_handle(env, argv[0], 0);
     uint8_t *a, *b, *c;
     size_t la, lb, lc;
     uint32_t sec;
-    if (!ctx || !get_bytes(env, argv[1], &a, &la) || !get_bytes(env, argv[2], &b, &lb) || !get_bytes(env, argv[3], &c, &lc)) return NULL;
+    if (!h || !get_bytes(env, argv[1], &a, &la) || !get_bytes(env, argv[2], &b, &lb) || !get_bytes(env, argv[3], &c, &lc)) return NULL;
     NAPI_OK(napi_get_value_uint32(env, argv[4], &sec));
     if (la != 64 || lb != 72 || lc != 72) {
         napi_throw_range_error(env, NULL, "params: h_NIST is 64 bytes, g and h of Tom-256 are 72 bytes (affine, big-endian)");
         return NULL;
     }
-    zk_status st = zk_ctx_set_params(ctx, a, b, c, sec);
-    return st == ZK_OK ? NULL : throw_status(env, ctx, st);
+    zk_status st = zk_pool_set_params(h->pool, a, b, c, sec);
+    if (st == ZK_OK) h->sec = sec;
+    return st == ZK_OK ? NULL : throw_status(env, h, st);
 }
-static napi_value SetRing(napi_env env, napi_callback_info info) { /* (ctx, keys: n x 32 bytes) */
+static napi_value SetRing(napi_env env, napi_callback_info info) { /* (h, keys: n x 32 bytes) -> transport */
     napi_value argv[2];
     if (!get_args(env, info, 2, argv)) return NULL;
-    zk_ctx *ctx = get_ctx(env, argv[0]);
+    Handle *h = get_handle(env, argv[0], 0);
     uint8_t *k;
     size_t lk;
-    if (!ctx || !get_bytes(env, argv[1], &k, &lk)) return NULL;
-    zk_status st = zk_ctx_set_ring(ctx, k, lk / 32);
-    return st == ZK_OK ? NULL : throw_status(env, ctx, st);
+    if (!h || !get_bytes(env, argv[1], &k, &lk)) return NULL;
+    zk_status st = zk_pool_set_ring(h->pool, k, lk / 32);
+    if (st != ZK_OK) return throw_status(env, h, st);
+    napi_value v;
+    NAPI_OK(napi_create_string_utf8(env, zk_pool_ring_transport(h->pool), NAPI_AUTO_LENGTH, &v));
+    return v;
 }
-static napi_value SynthParams(napi_env env, napi_callback_info info) { /* (ctx, seed) -> {nistH, tomG, tomH} */
+static napi_value SynthParams(napi_env env, napi_callback_info info) { /* (h, seed) -> {nistH, tomG, tomH} */
     napi_value argv[2];
     if (!get_args(env, info, 2, argv)) return NULL;
-    zk_ctx *ctx = get_ctx(env, argv[0]);
+    Handle *h = get_handle(env, argv[0], 0);
     uint32_t seed;
-    if (!ctx) return NULL;
+    if (!h) return NULL;
     NAPI_OK(napi_get_value_uint32(env, argv[1], &seed));
     uint8_t a[64], b[72], c[72];
+    zk_ctx *ctx = zk_pool_ctx(h->pool, 0);
     zk_status st = zk_synth_params(ctx, seed, a, b, c);
-    if (st != ZK_OK) return throw_status(env, ctx, st);
+    if (st != ZK_OK) return throw_text(env, st, zk_last_error(ctx));
     napi_value o;
     NAPI_OK(napi_create_object(env, &o));
     set_prop(env, o, "nistH", new_buffer(env, a, 64)), set_prop(env, o, "tomG", new_buffer(env, b, 72)), set_prop(env, o, "tomH", new_buffer(env, c, 72));
     return o;
 }
-static napi_value SynthWorkload(napi_env env, napi_callback_info info) { /* (ctx, seed, nKeys, B) -> {ring, msg, sig, pk, which, seeds} */
+static napi_value SynthWorkload(napi_env env, napi_callback_info info) { /* (h, seed, nKeys, B) -> {ring, msg, sig, pk, which, seeds} */
     napi_value argv[4];
     if (!get_args(env, info, 4, argv)) return NULL;
-    zk_ctx *ctx = get_ctx(env, argv[0]);
+    Handle *h = get_handle(env, argv[0], 0);
     uint32_t seed, nk, B;
-    if (!ctx) return NULL;
+    if (!h) return NULL;
     NAPI_OK(napi_get_value_uint32(env, argv[1], &seed));
     NAPI_OK(napi_get_value_uint32(env, argv[2], &nk));
     NAPI_OK(napi_get_value_uint32(env, argv[3], &B));
-    uint8_t *ring = malloc(32 * (size_t)nk), *msg = malloc(32 * (size_t)B + 1), *sig = malloc(64 * (size_t)B + 1), *pk = malloc(64 * (size_t)B + 1), *seeds = malloc(32 * (size_t)B + 1);
+    uint8_t *ring = malloc(32 * (size_t)nk + 1), *msg = malloc(32 * (size_t)B + 1), *sig = malloc(64 * (size_t)B + 1), *pk = malloc(64 * (size_t)B + 1),
+            *seeds = malloc(32 * (size_t)B + 1);
     uint32_t *which = malloc(4 * (size_t)B + 4);
-    zk_status st = zk_synth_workload(ctx, seed, nk, B, ring, msg, sig, pk, which, seeds);
     napi_value o = NULL;
+    zk_ctx *ctx = zk_pool_ctx(h->pool, 0);
+    zk_status st = ring && msg && sig && pk && seeds && which ? zk_synth_workload(ctx, seed, nk, B, ring, msg, sig, pk, which, seeds) : ZK_E_BUFFER;
     if (st == ZK_OK && napi_create_object(env, &o) == napi_ok) {
         set_prop(env, o, "ring", new_buffer(env, ring, 32 * (size_t)nk)), set_prop(env, o, "msg", new_buffer(env, msg, 32 * (size_t)B));
         set_prop(env, o, "sig", new_buffer(env, sig, 64 * (size_t)B)), set_prop(env, o, "pk", new_buffer(env, pk, 64 * (size_t)B));
         set_prop(env, o, "which", new_buffer(env, which, 4 * (size_t)B)), set_prop(env, o, "seeds", new_buffer(env, seeds, 32 * (size_t)B));
     }
     free(ring), free(msg), free(sig), free(pk), free(seeds), free(which);
-    return st == ZK_OK ? o : throw_status(env, ctx, st);
+    return st == ZK_OK ? o : throw_text(env, st, zk_last_error(ctx));
 }
-/* (ctx, msg Bx32, sig Bx64, pk Bx64, which Bx4 (u32 LE), seeds Bx32) -> {proofs: Buffer, offsets: Buffer of B+1 u64 LE, status: Buffer of B i32} */
-static napi_value ProveBatch(napi_env env, napi_callback_info info) {
-    napi_value argv[6];
-    if (!get_args(env, info, 6, argv)) return NULL;
-    zk_ctx *ctx = get_ctx(env, argv[0]);
-    uint8_t *msg, *sig, *pk, *which, *seeds;
-    size_t lm, ls, lp, lw, lse;
-    if (!ctx || !get_bytes(env, argv[1], &msg, &lm) || !get_bytes(env, argv[2], &sig, &ls) || !get_bytes(env, argv[3], &pk, &lp) ||
-        !get_bytes(env, argv[4], &which, &lw) || !get_bytes(env, argv[5], &seeds, &lse))
-        return NULL;
-    size_t B = lm / 32;
-    if (lm != 32 * B || ls != 64 * B || lp != 64 * B || lw != 4 * B || lse != 32 * B) {
-        napi_throw_range_error(env, NULL, "proveBatch: per proof 32-byte msgHash, 64-byte signature, 64-byte public key, u32 index, 32-byte seed");
-        return NULL;
-    }
-    uint64_t cap = zk_proof_max_size(ctx) * (B ? B : 1);
-    uint8_t *out = malloc(cap ? cap : 1);
-    uint64_t *off = malloc(8 * (B + 1));
-    int32_t *status = malloc(4 * (B + 1));
-    uint32_t *w32 = malloc(4 * (B + 1));
-    memcpy(w32, which, 4 * B);
-    zk_rng rng = {ZK_RNG_SEED, seeds, 0};
-    zk_status st = zk_prove_batch(ctx, B, msg, sig, pk, w32, &rng, out, cap, off, status);
-    napi_value o = NULL;
-    if (st == ZK_OK && napi_create_object(env, &o) == napi_ok) {
-        set_prop(env, o, "proofs", new_buffer(env, out, (size_t)off[B])), set_prop(env, o, "offsets", new_buffer(env, off, 8 * (B + 1)));
-        set_prop(env, o, "status", new_buffer(env, status, 4 * B));
-    }
-    free(out), free(off), free(status), free(w32);
-    return st == ZK_OK ? o : throw_status(env, ctx, st);
-}
-/* (ctx, msg Bx32, proofs, offsets (B+1 u64 LE), seeds Bx32 | null) -> {ok: Buffer of B bytes, status: Buffer of B i32} */
-static napi_value VerifyBatch(napi_env env, napi_callback_info info) {
-    napi_value argv[5];
-    if (!get_args(env, info, 5, argv)) return NULL;
-    zk_ctx *ctx = get_ctx(env, argv[0]);
-    uint8_t *msg, *proofs, *offs, *seeds;
-    size_t lm, lp, lo, ls;
-    if (!ctx || !get_bytes(env, argv[1], &msg, &lm) || !get_bytes(env, argv[2], &proofs, &lp) || !get_bytes(env, argv[3], &offs, &lo) || !get_bytes(env, argv[4], &seeds, &ls))
-        return NULL;
-    size_t B = lm / 32;
-    if (lo != 8 * (B + 1) || (seeds && ls != 32 * B)) {
-        napi_throw_range_error(env, NULL, "verifyBatch: B message hashes, B + 1 offsets, B seeds or null");
-        return NULL;
-    }
-    uint64_t *off = malloc(8 * (B + 1));
-    memcpy(off, offs, 8 * (B + 1));
-    uint8_t *ok = malloc(B + 1);
-    int32_t *status = malloc(4 * (B + 1));
-    zk_status st = off[B] <= lp ? zk_verify_batch(ctx, B, msg, proofs, off, seeds, ok, status) : ZK_E_ARG;
-    napi_value o = NULL;
-    if (st == ZK_OK && napi_create_object(env, &o) == napi_ok) set_prop(env, o, "ok", new_buffer(env, ok, B)), set_prop(env, o, "status", new_buffer(env, status, 4 * B));
-    free(off), free(ok), free(status);
-    return st == ZK_OK ? o : throw_status(env, ctx, st);
-}
-/* ---- asynchronous variants: the batch runs on a libuv worker thread, the caller gets a Promise (what keeps the reference's
- * `async function proveSignatureList(...)` signature without blocking the event loop).  One job at a time per context. */
+
+/* ---- batches.  A Job owns copies of the small inputs; the (large) proof input of a verification is referenced, not copied. */
 typedef struct {
-    int verify;
-    zk_ctx *ctx;
+    int verify, async;
+    Handle *h;
     size_t B;
-    uint8_t *msg, *sig, *pk, *seeds, *proofs_in;
+    uint8_t *msg, *sig, *pk, *seeds;
+    const uint8_t *proofs_in;
+    napi_ref proofs_ref, h_ref; /* an asynchronous job keeps the proof bytes and the handle alive */
     uint32_t *which;
-    uint8_t *out;
-    uint64_t cap, *off;
+    Slab out;
+    uint64_t worst_cap, *off, *len;
     int32_t *status;
     uint8_t *ok;
     zk_status rc;
-    char err[256];
+    char err[384];
     napi_deferred deferred;
     napi_async_work work;
 } Job;
 static uint8_t *dup_bytes(const uint8_t *p, size_t n) {
     uint8_t *q = malloc(n ? n : 1);
-    if (p && n) memcpy(q, p, n);
+    if (q && p && n) memcpy(q, p, n);
     return q;
 }
-static void job_free(Job *j) {
-    free(j->msg), free(j->sig), free(j->pk), free(j->seeds), free(j->proofs_in), free(j->which), free(j->out), free(j->off), free(j->status), free(j->ok);
+static void job_free(napi_env env, Job *j) {
+    if (j->proofs_ref && env) napi_delete_reference(env, j->proofs_ref);
+    if (j->h_ref && env) napi_delete_reference(env, j->h_ref);
+    slab_free(&j->out);
+    free(j->msg), free(j->sig), free(j->pk), free(j->seeds), free(j->which), free(j->off), free(j->len), free(j->status), free(j->ok);
     free(j);
 }
-static void job_execute(napi_env env, void *data) { /* worker thread: no N-API calls here */
+/* output capacity for B proofs over G devices: mean + 8 sigma of the zero-bit repetitions per shard, at most the worst case */
+static void prove_caps(Handle *h, size_t B, uint64_t *cap, uint64_t *worst) {
+    uint64_t G = (uint64_t)zk_pool_size(h->pool), m = (B + G - 1) / G;
+    uint64_t mx = zk_proof_max_size(zk_pool_ctx(h->pool, 0));
+    uint64_t w = ((mx * (m ? m : 1) + 511) & ~(uint64_t)255) * G;
+    double mean = (double)m * ((double)mx - 3392.0 * h->sec / 2.0), dev = 8.0 * 3392.0 * sqrt((double)m * h->sec / 4.0);
+    uint64_t c = (((uint64_t)(mean + dev) + mx + 511) & ~(uint64_t)255) * G;
+    *worst = w, *cap = c < w ? c : w;
+}
+static void job_execute(napi_env env, void *data) { /* worker thread (or inline for the synchronous calls): no N-API calls here */
     Job *j = data;
-    if (j->verify) j->rc = zk_verify_batch(j->ctx, j->B, j->msg, j->proofs_in, j->off, j->seeds, j->ok, j->status);
-    else {
+    zk_pool *p = j->h->pool;
+    if (j->verify) {
+        j->rc = zk_pool_verify_batch(p, j->B, j->msg, j->proofs_in, j->off, j->len, j->seeds, j->ok, j->status);
+    } else {
         zk_rng rng = {ZK_RNG_SEED, j->seeds, 0};
-        j->rc = zk_prove_batch(j->ctx, j->B, j->msg, j->sig, j->pk, j->which, &rng, j->out, j->cap, j->off, j->status);
+        j->rc = zk_pool_prove_batch(p, j->B, j->msg, j->sig, j->pk, j->which, &rng, j->out.p, j->out.cap, j->off, j->len, j->status);
+        if (j->rc == ZK_E_BUFFER && j->out.cap < j->worst_cap) { /* 8 sigma were not enough: worst-case buffer */
+            slab_free(&j->out);
+            if (slab_alloc(&j->out, j->worst_cap))
+                j->rc = zk_pool_prove_batch(p, j->B, j->msg, j->sig, j->pk, j->which, &rng, j->out.p, j->out.cap, j->off, j->len, j->status);
+        }
     }
-    if (j->rc != ZK_OK) snprintf(j->err, sizeof j->err, "%s: %s", zk_strerror(j->rc), zk_last_error(j->ctx));
+    if (j->rc != ZK_OK) snprintf(j->err, sizeof j->err, "%s: %s", zk_strerror(j->rc), zk_pool_last_error(p));
+}
+static napi_value job_result(napi_env env, Job *j) {
+    napi_value v;
+    if (napi_create_object(env, &v) != napi_ok) return NULL;
+    if (j->verify) {
+        set_prop(env, v, "ok", new_buffer(env, j->ok, j->B));
+    } else {
+        uint64_t end = 0;
+        for (size_t b = 0; b < j->B; b++)
+            if (j->off[b] + j->len[b] > end) end = j->off[b] + j->len[b];
+        set_prop(env, v, "proofs", slab_to_buffer(env, &j->out, (size_t)end));
+        set_prop(env, v, "offsets", new_buffer(env, j->off, 8 * j->B)), set_prop(env, v, "lengths", new_buffer(env, j->len, 8 * j->B));
+    }
+    set_prop(env, v, "status", new_buffer(env, j->status, 4 * j->B));
+    return v;
 }
 static void job_complete(napi_env env, napi_status status, void *data) { /* main thread */
     Job *j = data;
-    napi_value v;
-    if (status == napi_ok && j->rc == ZK_OK && napi_create_object(env, &v) == napi_ok) {
-        if (j->verify) set_prop(env, v, "ok", new_buffer(env, j->ok, j->B));
-        else set_prop(env, v, "proofs", new_buffer(env, j->out, (size_t)j->off[j->B])), set_prop(env, v, "offsets", new_buffer(env, j->off, 8 * (j->B + 1)));
-        set_prop(env, v, "status", new_buffer(env, j->status, 4 * j->B));
+    j->h->busy = 0;
+    napi_value v = status == napi_ok && j->rc == ZK_OK ? job_result(env, j) : NULL;
+    if (v) {
         napi_resolve_deferred(env, j->deferred, v);
     } else {
         napi_value msg, e;
-        napi_create_string_utf8(env, j->rc != ZK_OK ? j->err : "async work failed", NAPI_AUTO_LENGTH, &msg);
+        napi_create_string_utf8(env, j->rc != ZK_OK ? j->err : "asynchronous batch failed", NAPI_AUTO_LENGTH, &msg);
         napi_create_error(env, NULL, msg, &e);
         napi_reject_deferred(env, j->deferred, e);
     }
     napi_delete_async_work(env, j->work);
-    job_free(j);
+    job_free(env, j);
 }
-static napi_value job_start(napi_env env, Job *j, const char *name) {
+static napi_value job_run(napi_env env, Job *j, const char *name) {
+    if (!j->async) {
+        job_execute(env, j);
+        napi_value v = j->rc == ZK_OK ? job_result(env, j) : NULL;
+        if (!v) {
+            if (j->rc != ZK_OK) napi_throw_error(env, NULL, j->err);
+            else napi_throw_error(env, NULL, "could not build the result");
+        }
+        job_free(env, j);
+        return v;
+    }
     napi_value promise, rn;
     if (napi_create_promise(env, &j->deferred, &promise) != napi_ok || napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &rn) != napi_ok ||
-        napi_create_async_work(env, NULL, rn, job_execute, job_complete, j, &j->work) != napi_ok || napi_queue_async_work(env, j->work) != napi_ok) {
-        job_free(j);
+        napi_create_async_work(env, NULL, rn, job_execute, job_complete, j, &j->work) != napi_ok) {
+        job_free(env, j);
+        napi_throw_error(env, NULL, "could not queue the batch");
+        return NULL;
+    }
+    j->h->busy = 1;
+    if (napi_queue_async_work(env, j->work) != napi_ok) {
+        j->h->busy = 0;
+        napi_delete_async_work(env, j->work);
+        job_free(env, j);
         napi_throw_error(env, NULL, "could not queue the batch");
         return NULL;
     }
     return promise;
 }
-static napi_value ProveBatchAsync(napi_env env, napi_callback_info info) { /* same arguments as proveBatch -> Promise of the same object */
+/* (h, msg Bx32, sig Bx64, pk Bx64, which Bx4 (u32 LE), seeds Bx32)
+ *   -> {proofs: Buffer, offsets: B u64 LE, lengths: B u64 LE, status: B i32}   proof b = proofs[offsets[b] .. offsets[b] + lengths[b]) */
+static napi_value prove_common(napi_env env, napi_callback_info info, int async) {
     napi_value argv[6];
     if (!get_args(env, info, 6, argv)) return NULL;
-    zk_ctx *ctx = get_ctx(env, argv[0]);
+    Handle *h = get_handle(env, argv[0], 0);
     uint8_t *msg, *sig, *pk, *which, *seeds;
     size_t lm, ls, lp, lw, lse;
-    if (!ctx || !get_bytes(env, argv[1], &msg, &lm) || !get_bytes(env, argv[2], &sig, &ls) || !get_bytes(env, argv[3], &pk, &lp) ||
+    if (!h || !get_bytes(env, argv[1], &msg, &lm) || !get_bytes(env, argv[2], &sig, &ls) || !get_bytes(env, argv[3], &pk, &lp) ||
         !get_bytes(env, argv[4], &which, &lw) || !get_bytes(env, argv[5], &seeds, &lse))
         return NULL;
     size_t B = lm / 32;
-    if (lm != 32 * B || ls != 64 * B || lp != 64 * B || lw != 4 * B || lse != 32 * B) {
-        napi_throw_range_error(env, NULL, "proveBatchAsync: per proof 32-byte msgHash, 64-byte signature, 64-byte public key, u32 index, 32-byte seed");
+    if (!B || lm != 32 * B || ls != 64 * B || lp != 64 * B || lw != 4 * B || lse != 32 * B) {
+        napi_throw_range_error(env, NULL, "proveBatch: per proof 32-byte msgHash, 64-byte signature, 64-byte public key, u32 index, 32-byte seed");
         return NULL;
     }
     Job *j = calloc(1, sizeof *j);
-    j->ctx = ctx, j->B = B;
+    if (!j) return throw_text(env, ZK_E_BUFFER, "out of memory");
+    j->h = h, j->B = B, j->async = async;
     j->msg = dup_bytes(msg, lm), j->sig = dup_bytes(sig, ls), j->pk = dup_bytes(pk, lp), j->seeds = dup_bytes(seeds, lse);
     j->which = (uint32_t *)dup_bytes(which, lw);
-    j->cap = zk_proof_max_size(ctx) * (B ? B : 1);
-    j->out = malloc(j->cap ? j->cap : 1), j->off = malloc(8 * (B + 1)), j->status = malloc(4 * (B + 1));
-    return job_start(env, j, "zkattest.proveBatch");
+    uint64_t cap;
+    prove_caps(h, B, &cap, &j->worst_cap);
+    j->off = malloc(8 * B), j->len = malloc(8 * B), j->status = malloc(4 * B);
+    if (!j->msg || !j->sig || !j->pk || !j->seeds || !j->which || !j->off || !j->len || !j->status || !slab_alloc(&j->out, cap)) {
+        job_free(env, j);
+        return throw_text(env, ZK_E_BUFFER, "out of memory");
+    }
+    if (async && napi_create_reference(env, argv[0], 1, &j->h_ref) != napi_ok) {
+        job_free(env, j);
+        return throw_text(env, ZK_E_BUFFER, "could not reference the handle");
+    }
+    return job_run(env, j, "zkattest.proveBatch");
 }
-static napi_value VerifyBatchAsync(napi_env env, napi_callback_info info) { /* same arguments as verifyBatch -> Promise */
-    napi_value argv[5];
-    if (!get_args(env, info, 5, argv)) return NULL;
-    zk_ctx *ctx = get_ctx(env, argv[0]);
-    uint8_t *msg, *proofs, *offs, *seeds;
-    size_t lm, lp, lo, ls;
-    if (!ctx || !get_bytes(env, argv[1], &msg, &lm) || !get_bytes(env, argv[2], &proofs, &lp) || !get_bytes(env, argv[3], &offs, &lo) || !get_bytes(env, argv[4], &seeds, &ls))
+static napi_value ProveBatch(napi_env env, napi_callback_info info) { return prove_common(env, info, 0); }
+static napi_value ProveBatchAsync(napi_env env, napi_callback_info info) { return prove_common(env, info, 1); }
+/* (h, msg Bx32, proofs, offsets (B u64 LE), lengths (B u64 LE), seeds Bx32 | null) -> {ok: B bytes, status: B i32} */
+static napi_value verify_common(napi_env env, napi_callback_info info, int async) {
+    napi_value argv[6];
+    if (!get_args(env, info, 6, argv)) return NULL;
+    Handle *h = get_handle(env, argv[0], 0);
+    uint8_t *msg, *proofs, *offs, *lens, *seeds;
+    size_t lm, lp, lo, ll, ls;
+    if (!h || !get_bytes(env, argv[1], &msg, &lm) || !get_bytes(env, argv[2], &proofs, &lp) || !get_bytes(env, argv[3], &offs, &lo) ||
+        !get_bytes(env, argv[4], &lens, &ll) || !get_bytes(env, argv[5], &seeds, &ls))
         return NULL;
     size_t B = lm / 32;
-    if (lo != 8 * (B + 1) || (seeds && ls != 32 * B)) {
-        napi_throw_range_error(env, NULL, "verifyBatchAsync: B message hashes, B + 1 offsets, B seeds or null");
+    if (!B || lm != 32 * B || lo != 8 * B || ll != 8 * B || (seeds && ls != 32 * B) || !proofs) {
+        napi_throw_range_error(env, NULL, "verifyBatch: B message hashes, B offsets, B lengths, B seeds or null");
         return NULL;
     }
     Job *j = calloc(1, sizeof *j);
-    j->verify = 1, j->ctx = ctx, j->B = B;
-    j->msg = dup_bytes(msg, lm), j->proofs_in = dup_bytes(proofs, lp), j->off = (uint64_t *)dup_bytes(offs, lo);
+    if (!j) return throw_text(env, ZK_E_BUFFER, "out of memory");
+    j->verify = 1, j->h = h, j->B = B, j->async = async;
+    j->msg = dup_bytes(msg, lm), j->off = (uint64_t *)dup_bytes(offs, lo), j->len = (uint64_t *)dup_bytes(lens, ll);
     j->seeds = seeds ? dup_bytes(seeds, ls) : NULL;
-    j->ok = malloc(B + 1), j->status = malloc(4 * (B + 1));
-    if (j->off[B] > lp) {
-        job_free(j);
-        napi_throw_range_error(env, NULL, "verifyBatchAsync: offsets beyond the proof buffer");
+    j->ok = malloc(B), j->status = malloc(4 * B);
+    j->proofs_in = proofs;
+    int okk = j->msg && j->off && j->len && j->ok && j->status && (!seeds || j->seeds);
+    for (size_t b = 0; okk && b < B; b++) okk = j->off[b] <= lp && j->len[b] <= lp - j->off[b];
+    if (okk && async) okk = napi_create_reference(env, argv[2], 1, &j->proofs_ref) == napi_ok && napi_create_reference(env, argv[0], 1, &j->h_ref) == napi_ok;
+    if (!okk) {
+        job_free(env, j);
+        napi_throw_range_error(env, NULL, "verifyBatch: out of memory, or offsets / lengths beyond the proof buffer");
         return NULL;
     }
-    return job_start(env, j, "zkattest.verifyBatch");
+    return job_run(env, j, "zkattest.verifyBatch");
+}
+static napi_value VerifyBatch(napi_env env, napi_callback_info info) { return verify_common(env, info, 0); }
+static napi_value VerifyBatchAsync(napi_env env, napi_callback_info info) { return verify_common(env, info, 1); }
+
+static napi_value HostAlloc(napi_env env, napi_callback_info info) { /* (bytes) -> page-locked Buffer (zk_host_alloc) */
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    double n;
+    NAPI_OK(napi_get_value_double(env, argv[0], &n));
+    if (!(n >= 1) || n > 1e12) {
+        napi_throw_range_error(env, NULL, "hostAlloc: size in bytes");
+        return NULL;
+    }
+    void *p = zk_host_alloc((size_t)n);
+    if (!p) return throw_text(env, ZK_E_BUFFER, "zk_host_alloc failed");
+    napi_value b;
+    if (napi_create_external_buffer(env, (size_t)n, p, slab_finalize, (void *)1, &b) != napi_ok) {
+        zk_host_free(p);
+        napi_throw_error(env, NULL, "could not wrap the page-locked buffer");
+        return NULL;
+    }
+    return b;
 }
 static napi_value ProofToJson(napi_env env, napi_callback_info info) { /* (proof: Buffer) -> string   (writeJson, src/serde.ts:34-36) */
     napi_value argv[1];
@@ -335,57 +509,67 @@ static napi_value ProofToJson(napi_env env, napi_callback_info info) { /* (proof
     if (!get_bytes(env, argv[0], &p, &lp)) return NULL;
     uint64_t n = 0;
     zk_status st = zk_proof_to_json(p, lp, NULL, 0, &n);
-    if (st != ZK_OK && st != ZK_E_BUFFER) return throw_status(env, NULL, st);
-    char *s = malloc(n + 1);
+    if (st != ZK_OK && st != ZK_E_BUFFER) return throw_text(env, st, "");
+    char *s = xmalloc(env, n + 1);
+    if (!s) return NULL;
     st = zk_proof_to_json(p, lp, s, n, &n);
     napi_value r = NULL;
     if (st == ZK_OK) napi_create_string_utf8(env, s, n, &r);
     free(s);
-    return st == ZK_OK ? r : throw_status(env, NULL, st);
+    return st == ZK_OK ? r : throw_text(env, st, "");
 }
 static napi_value ProofFromJson(napi_env env, napi_callback_info info) { /* (text: string) -> Buffer   (readJson, src/serde.ts:21-32) */
     napi_value argv[1];
     if (!get_args(env, info, 1, argv)) return NULL;
     size_t len = 0;
     NAPI_OK(napi_get_value_string_utf8(env, argv[0], NULL, 0, &len));
-    char *s = malloc(len + 1);
-    NAPI_OK(napi_get_value_string_utf8(env, argv[0], s, len + 1, &len));
+    if (len > ((size_t)64 << 20)) return throw_text(env, ZK_E_BAD_ENCODING, "JSON text too long");
+    char *s = xmalloc(env, len + 1);
+    if (!s) return NULL;
+    if (napi_get_value_string_utf8(env, argv[0], s, len + 1, &len) != napi_ok) {
+        free(s);
+        napi_throw_type_error(env, NULL, "expected a string");
+        return NULL;
+    }
     uint64_t n = 0;
     zk_status st = zk_proof_from_json(s, len, NULL, 0, &n);
     napi_value r = NULL;
     if (st == ZK_OK || st == ZK_E_BUFFER) {
         uint8_t *b = malloc(n + 1);
-        st = zk_proof_from_json(s, len, b, n, &n);
+        st = b ? zk_proof_from_json(s, len, b, n, &n) : ZK_E_BUFFER;
         if (st == ZK_OK) r = new_buffer(env, b, n);
         free(b);
     }
     free(s);
-    return st == ZK_OK ? r : throw_status(env, NULL, st);
+    return st == ZK_OK && r ? r : throw_text(env, st ? st : ZK_E_BUFFER, "");
 }
-static napi_value KeysToInts(napi_env env, napi_callback_info info) { /* (ctx, pk: n x 64 bytes) -> {keys: n x 32, status}  (keyToInt) */
+static napi_value KeysToInts(napi_env env, napi_callback_info info) { /* (h, pk: n x 64 bytes) -> {keys: n x 32, status}  (keyToInt) */
     napi_value argv[2];
     if (!get_args(env, info, 2, argv)) return NULL;
-    zk_ctx *ctx = get_ctx(env, argv[0]);
+    Handle *h = get_handle(env, argv[0], 0);
     uint8_t *pk;
     size_t lp;
-    if (!ctx || !get_bytes(env, argv[1], &pk, &lp)) return NULL;
+    if (!h || !get_bytes(env, argv[1], &pk, &lp)) return NULL;
     size_t n = lp / 64;
     uint8_t *keys = malloc(32 * n + 1);
     int32_t *status = malloc(4 * n + 4);
-    zk_status st = zk_keys_to_ints(ctx, n, pk, keys, status);
+    zk_ctx *ctx = zk_pool_ctx(h->pool, 0);
+    zk_status st = keys && status ? zk_keys_to_ints(ctx, n, pk, keys, status) : ZK_E_BUFFER;
     napi_value o = NULL;
     if (st == ZK_OK && napi_create_object(env, &o) == napi_ok) set_prop(env, o, "keys", new_buffer(env, keys, 32 * n)), set_prop(env, o, "status", new_buffer(env, status, 4 * n));
     free(keys), free(status);
-    return st == ZK_OK ? o : throw_status(env, ctx, st);
+    return st == ZK_OK ? o : throw_text(env, st, zk_last_error(ctx));
 }
 
 static napi_value Init(napi_env env, napi_value exports) {
     static const struct {
         const char *name;
         napi_callback fn;
-    } fns[] = {{"createContext", CreateContext}, {"destroyContext", DestroyContext}, {"setParams", SetParams}, {"setRing", SetRing},
-               {"synthParams", SynthParams},     {"synthWorkload", SynthWorkload},   {"proveBatch", ProveBatch}, {"verifyBatch", VerifyBatch},
-               {"proveBatchAsync", ProveBatchAsync}, {"verifyBatchAsync", VerifyBatchAsync}, {"proofToJson", ProofToJson},     {"proofFromJson", ProofFromJson},   {"keysToInts", KeysToInts}};
+    } fns[] = {{"createPool", CreatePool},       {"destroyPool", DestroyPool},       {"poolInfo", PoolInfo},       {"setOption", SetOption},
+               {"setParams", SetParams},         {"setRing", SetRing},               {"synthParams", SynthParams}, {"synthWorkload", SynthWorkload},
+               {"proveBatch", ProveBatch},       {"verifyBatch", VerifyBatch},       {"proveBatchAsync", ProveBatchAsync},
+               {"verifyBatchAsync", VerifyBatchAsync}, {"proofToJson", ProofToJson}, {"proofFromJson", ProofFromJson},
+               {"keysToInts", KeysToInts},       {"hostAlloc", HostAlloc}};
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;
         if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;

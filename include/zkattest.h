@@ -68,7 +68,8 @@ typedef struct {
     uint64_t stride_blocks; /* ZK_RNG_STREAM only */
 } zk_rng;
 
-/* Creates an engine bound to one GPU.  Owns the HIP stream, the fixed-base tables and the workspace. */
+/* Creates an engine bound to one GPU.  Owns the HIP streams, the fixed-base tables and the workspace.  (SURVEY.md section 8(b)
+ * sketched zk_ctx_create(device_ids, n_dev); here one zk_ctx is one GPU and zk_pool_create below takes the device list.) */
 zk_status zk_ctx_create(int device_id, zk_ctx **out);
 void zk_ctx_destroy(zk_ctx *ctx);
 const char *zk_strerror(zk_status s);
@@ -106,6 +107,12 @@ zk_status zk_ctx_set_lanes(zk_ctx *ctx, uint32_t lanes);
  * next zk_ctx_set_params, which must follow.  The proof bytes do not depend on W.  The environment variable
  * ZKATTEST_COMB_BITS sets the default of new contexts. */
 zk_status zk_ctx_set_comb_bits(zk_ctx *ctx, uint32_t bits);
+
+/* Host-pointer calls on page-locked buffers (zk_prove_batch, zk_verify_batch): 1 (default) = tapered chunk plan -- a half-sized
+ * first chunk, chunks of at most zk_ctx_set_chunk proofs, then chunks of a sixth of what is left down to 2048 proofs, so that
+ * the PCIe transfer of the last chunks, the only one no kernel hides, stays small; 0 = uniform chunks.  The proof bytes do not
+ * depend on it. */
+zk_status zk_ctx_set_host_taper(zk_ctx *ctx, uint32_t on);
 
 /* Verifier strategy for the Tom-256 relations: in a chunk of at least min_chunk proofs (default 256) the relations of ALL
  * proofs are checked with one bucket-method multi-scalar sum (independent 128-bit multipliers per relation and per proof);
@@ -156,6 +163,36 @@ zk_status zk_verify_batch(zk_ctx *ctx, uint64_t B, const uint8_t *msg_hash /*Bx3
                           uint8_t *ok /*B*/, int32_t *per_proof_status /*B*/);
 zk_status zk_verify_batch_device(zk_ctx *ctx, uint64_t B, const void *d_msg_hash, const void *d_proofs,
                                  const void *d_proof_off, const void *d_verifier_seeds, void *d_ok, void *d_per_proof_status);
+
+/* ---- several GPUs of one node behind one handle (the reference is single-threaded,
+ * src/zkpAttestList.ts:104-145 proves one signature per call).  Proofs are independent given (params, ring): a batch is split
+ * into contiguous shards, shard i = proofs [i*B/G, (i+1)*B/G) on device_ids[i], one host thread per device, no exchange while
+ * proving or verifying.  zk_pool_set_ring uploads the ring once and broadcasts it device-to-device (RCCL ncclBroadcast over
+ * xGMI; hipMemcpyPeer when RCCL is not usable -- zk_pool_ring_transport tells which: "rccl", "peer-copy", "single");
+ * fixed-base tables and the per-ring table are rebuilt locally on every device, concurrently.  zk_pool_ctx(i) gives the
+ * per-device context for the settings above (chunk, lanes, comb width: before zk_pool_set_params) and for zk_last_error.
+ * A pool call is not re-entrant; the listed devices may repeat (several contexts on one GPU). */
+typedef struct zk_pool zk_pool;
+zk_status zk_pool_create(const int *device_ids, int n_dev, zk_pool **out);
+void zk_pool_destroy(zk_pool *pool);
+int zk_pool_size(const zk_pool *pool);
+zk_ctx *zk_pool_ctx(zk_pool *pool, int i);
+const char *zk_pool_last_error(const zk_pool *pool);
+const char *zk_pool_ring_transport(const zk_pool *pool);
+void zk_pool_shard(const zk_pool *pool, uint64_t B, int i, uint64_t *first, uint64_t *count);
+zk_status zk_pool_set_params(zk_pool *pool, const uint8_t nist_h[64], const uint8_t tom_g[72], const uint8_t tom_h[72], uint32_t sec_level);
+zk_status zk_pool_set_ring(zk_pool *pool, const uint8_t *keys_be32, uint64_t n_keys);
+/* zk_prove_batch over all devices.  Shard i writes its proofs back to back from out + i * ((out_cap / G) & ~255): proof b lies
+ * at out_off[b] .. out_off[b] + out_len[b] (its ZKA1 header carries the same length); there are gaps between shards, none
+ * inside one.  ZK_E_BUFFER when a shard does not fit its region.  `out` from zk_host_alloc is filled by overlapped DMA. */
+zk_status zk_pool_prove_batch(zk_pool *pool, uint64_t B, const uint8_t *msg_hash, const uint8_t *sig, const uint8_t *pk_xy, const uint32_t *which,
+                              const zk_rng *rng, uint8_t *out, uint64_t out_cap, uint64_t *out_off /*B*/, uint64_t *out_len /*B*/,
+                              int32_t *per_proof_status /*B*/);
+/* zk_verify_batch over all devices.  Inside every shard the proofs must lie back to back in index order (true for the output
+ * of zk_pool_prove_batch and for any fully packed buffer), every shard starting 4-byte aligned; ZK_E_ARG otherwise. */
+zk_status zk_pool_verify_batch(zk_pool *pool, uint64_t B, const uint8_t *msg_hash, const uint8_t *proofs, const uint64_t *proof_off /*B*/,
+                               const uint64_t *proof_len /*B*/, const uint8_t *verifier_seeds /*Bx32 or NULL*/, uint8_t *ok /*B*/,
+                               int32_t *per_proof_status /*B*/);
 
 /* Seeded synthetic workload generator: fills device or host buffers with a ring of
  * n_keys uniform scalars, and B valid ECDSA P-256 signatures whose public keys' x-coordinates are planted at

@@ -22,9 +22,9 @@ def _build(tmp_path):
 def test_addon_builds_and_serves_the_json_wire_format(tmp_path):
     out = _build(tmp_path)
     env = dict(os.environ, ZKATTEST_NODE=out)
-    res = subprocess.run(['node', 'test_addon.js', 'json', os.path.join(ROOT, 'tests', 'golden', 'golden.json')], cwd=NAPI, env=env,
+    res = subprocess.run(['node', 'test_addon.js', 'cpu', os.path.join(ROOT, 'tests', 'golden', 'golden.json')], cwd=NAPI, env=env,
                          capture_output=True, text=True, timeout=120)
-    assert res.returncode == 0 and 'json ok' in res.stdout, res.stdout + res.stderr
+    assert res.returncode == 0 and 'cpu ok' in res.stdout, res.stdout + res.stderr
 
 
 @pytest.mark.gpu

@@ -14,7 +14,9 @@ SYMBOLS = [
     'zk_ctx_create', 'zk_ctx_destroy', 'zk_strerror', 'zk_last_error', 'zk_ctx_set_params', 'zk_ctx_set_ring',
     'zk_ctx_set_ring_device', 'zk_keys_to_ints', 'zk_ctx_set_chunk', 'zk_ctx_set_lanes', 'zk_ctx_set_comb_bits', 'zk_ctx_set_batch_verify', 'zk_proof_max_size', 'zk_prove_batch', 'zk_prove_batch_device',
     'zk_verify_batch', 'zk_verify_batch_device', 'zk_synth_workload', 'zk_synth_params', 'zk_last_timing',
-    'zk_proof_to_json', 'zk_proof_from_json', 'zk_host_alloc', 'zk_host_free',
+    'zk_proof_to_json', 'zk_proof_from_json', 'zk_host_alloc', 'zk_host_free', 'zk_ctx_set_host_taper',
+    'zk_pool_create', 'zk_pool_destroy', 'zk_pool_size', 'zk_pool_ctx', 'zk_pool_last_error', 'zk_pool_ring_transport', 'zk_pool_shard',
+    'zk_pool_set_params', 'zk_pool_set_ring', 'zk_pool_prove_batch', 'zk_pool_verify_batch',
     'zk_test_field_op', 'zk_test_tom_commit', 'zk_test_p256_fixed_mul', 'zk_test_sha256', 'zk_test_rng_draws',
 ]
 
@@ -78,6 +80,23 @@ def lib():
         L.zk_last_timing.restype = u32
         L.zk_proof_to_json.argtypes = [C.c_char_p, u64, vp, u64, C.POINTER(u64)]
         L.zk_proof_from_json.argtypes = [C.c_char_p, u64, vp, u64, C.POINTER(u64)]
+        L.zk_ctx_set_host_taper.argtypes = [vp, u32]
+        L.zk_pool_create.argtypes = [C.POINTER(C.c_int), i32, C.POINTER(vp)]
+        L.zk_pool_destroy.argtypes = [vp]
+        L.zk_pool_destroy.restype = None
+        L.zk_pool_size.argtypes = [vp]
+        L.zk_pool_ctx.argtypes = [vp, i32]
+        L.zk_pool_ctx.restype = vp
+        L.zk_pool_last_error.argtypes = [vp]
+        L.zk_pool_last_error.restype = C.c_char_p
+        L.zk_pool_ring_transport.argtypes = [vp]
+        L.zk_pool_ring_transport.restype = C.c_char_p
+        L.zk_pool_shard.argtypes = [vp, u64, i32, C.POINTER(u64), C.POINTER(u64)]
+        L.zk_pool_shard.restype = None
+        L.zk_pool_set_params.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, u32]
+        L.zk_pool_set_ring.argtypes = [vp, C.c_char_p, u64]
+        L.zk_pool_prove_batch.argtypes = [vp, u64, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(ZkRng), vp, u64, vp, vp, vp]
+        L.zk_pool_verify_batch.argtypes = [vp, u64, C.c_char_p, vp, vp, vp, C.c_char_p, vp, vp]
         L.zk_test_field_op.argtypes = [vp, i32, i32, u64, C.c_char_p, C.c_char_p, vp]
         L.zk_test_tom_commit.argtypes = [vp, u64, C.c_char_p, C.c_char_p, vp]
         L.zk_test_p256_fixed_mul.argtypes = [vp, i32, u64, C.c_char_p, vp]
@@ -148,14 +167,18 @@ def read_json(text):
 class Engine:
     """One engine = one GPU (zk_ctx)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed=None):
         self.L = lib()
+        self.sec = None
+        self._keep = []
+        self._owned = _borrowed is None
+        if _borrowed is not None:   # a context owned by a Pool
+            self.h = C.c_void_p(_borrowed)
+            return
         h = C.c_void_p()
         rc = self.L.zk_ctx_create(device, C.byref(h))
         self.h = h
         self._chk(rc)
-        self.sec = None
-        self._keep = []
 
     def _chk(self, rc):
         if rc:
@@ -164,7 +187,8 @@ class Engine:
 
     def close(self):
         if getattr(self, 'h', None):
-            self.L.zk_ctx_destroy(self.h)
+            if self._owned:
+                self.L.zk_ctx_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -201,6 +225,10 @@ class Engine:
     def set_lanes(self, lanes):
         self._chk(self.L.zk_ctx_set_lanes(self.h, lanes))
 
+    def set_host_taper(self, on):
+        """Tapered chunk plan of the host-pointer calls on page-locked buffers (default on)."""
+        self._chk(self.L.zk_ctx_set_host_taper(self.h, 1 if on else 0))
+
     def set_comb_bits(self, bits):
         """Comb width of the Tom-256 fixed-base tables (8..24 unsigned, 25/26 signed digits); call before set_params."""
         self._chk(self.L.zk_ctx_set_comb_bits(self.h, bits))
@@ -214,8 +242,14 @@ class Engine:
         return self.L.zk_proof_max_size(self.h)
 
     def prove_batch(self, msg, sig, pk, which, seeds=None, streams=None, stream_blocks=0):
-        """Host-buffer entry point.  Returns (list of proof bytes or None, list of status)."""
+        """Host-buffer entry point.  Returns (list of proof bytes or None, list of status).
+        seeds: B x 32 bytes, FRESH, SECRET and distinct per proof (every blinding factor of proof b derives from seed b: a
+        reused or guessable seed reveals the witness).  With neither seeds nor streams the seeds come from os.urandom."""
         B = len(which)
+        if seeds is None and streams is None:
+            seeds = os.urandom(32 * B)
+        if streams is None and len(seeds) != 32 * B:
+            raise ValueError('seeds must hold 32 bytes per proof')
         cap = self.proof_max_size() * max(B, 1)
         out = C.create_string_buffer(cap)
         off = (C.c_uint64 * (B + 1))()
@@ -344,3 +378,94 @@ class Engine:
         out = C.create_string_buffer(32 * B * n_k)
         self._chk(self.L.zk_test_rng_draws(self.h, B, C.byref(rng), first_k, n_k, out))
         return [[out.raw[32 * (b * n_k + j):32 * (b * n_k + j) + 32] for j in range(n_k)] for b in range(B)]
+
+
+class Pool:
+    """Several GPUs of one node behind one handle (zk_pool, include/zkattest.h): the batch is split into contiguous shards, the
+    ring is uploaded once and broadcast device-to-device (RCCL over xGMI, peer copies as fallback)."""
+
+    def __init__(self, device_ids):
+        self.L = lib()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        h = C.c_void_p()
+        rc = self.L.zk_pool_create(ids, len(device_ids), C.byref(h))
+        self.h = h
+        self._chk(rc)
+        self.n = len(device_ids)
+
+    def _chk(self, rc):
+        if rc:
+            raise ZkError(rc, self.L.zk_pool_last_error(self.h).decode() if self.h else '')
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.zk_pool_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def engine(self, i):
+        """Per-device context (settings only: chunk, lanes, comb width, host taper); owned by the pool."""
+        return Engine(_borrowed=self.L.zk_pool_ctx(self.h, i))
+
+    def shard(self, B, i):
+        f, c = C.c_uint64(), C.c_uint64()
+        self.L.zk_pool_shard(self.h, B, i, C.byref(f), C.byref(c))
+        return f.value, c.value
+
+    def set_params(self, nist_h64, tom_g72, tom_h72, sec_level=80):
+        self._chk(self.L.zk_pool_set_params(self.h, bytes(nist_h64), bytes(tom_g72), bytes(tom_h72), sec_level))
+
+    def set_ring(self, keys_be32, nkeys=None):
+        keys_be32 = bytes(keys_be32)
+        self._chk(self.L.zk_pool_set_ring(self.h, keys_be32, nkeys if nkeys is not None else len(keys_be32) // 32))
+        return self.L.zk_pool_ring_transport(self.h).decode()
+
+    def prove_batch_raw(self, msg, sig, pk, which, seeds, out, cap):
+        """zk_pool_prove_batch into `out` (PinnedBuffer or ctypes array).  Returns (seconds, off, len, status)."""
+        import time
+        B = len(which)
+        off, ln, st = (C.c_uint64 * B)(), (C.c_uint64 * B)(), (C.c_int32 * B)()
+        w = (C.c_uint32 * B)(*which)
+        data = C.create_string_buffer(bytes(seeds), 32 * B)
+        rng = ZkRng(0, C.cast(data, C.c_void_p), 0)
+        optr = out.ptr if isinstance(out, PinnedBuffer) else C.addressof(out)
+        msg, sig, pk = bytes(msg), bytes(sig), bytes(pk)
+        t0 = time.time()
+        self._chk(self.L.zk_pool_prove_batch(self.h, B, msg, sig, pk, w, C.byref(rng), optr, cap, off, ln, st))
+        return time.time() - t0, off, ln, st
+
+    def prove_batch(self, msg, sig, pk, which, seeds=None):
+        B = len(which)
+        if seeds is None:
+            seeds = os.urandom(32 * B)
+        e = self.engine(0)
+        cap = (e.proof_max_size() * (B // self.n + 1) + 256) * self.n
+        out = (C.c_uint8 * cap)()
+        _, off, ln, st = self.prove_batch_raw(msg, sig, pk, which, seeds, out, cap)
+        raw = bytes(out)
+        return [raw[off[b]:off[b] + ln[b]] if st[b] == 0 else None for b in range(B)], list(st)
+
+    def verify_batch_raw(self, msg, proofs, off, ln, B, vseeds=None):
+        import time
+        ok, st = (C.c_uint8 * B)(), (C.c_int32 * B)()
+        ptr = proofs.ptr if isinstance(proofs, PinnedBuffer) else C.addressof(proofs)
+        msg = bytes(msg)
+        t0 = time.time()
+        self._chk(self.L.zk_pool_verify_batch(self.h, B, msg, ptr, off, ln, bytes(vseeds) if vseeds is not None else None, ok, st))
+        return time.time() - t0, ok, st
+
+    def verify_batch(self, msg, proofs, vseeds=None):
+        B = len(proofs)
+        off, ln = (C.c_uint64 * B)(), (C.c_uint64 * B)()
+        o = 0
+        for b, p in enumerate(proofs):
+            off[b], ln[b] = o, len(p)
+            o += len(p)
+        blob = (C.c_uint8 * max(o, 1)).from_buffer_copy(b''.join(proofs) or b'\0')
+        _, ok, st = self.verify_batch_raw(msg, blob, off, ln, B, vseeds)
+        return list(ok), list(st)

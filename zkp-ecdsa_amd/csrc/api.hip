@@ -87,7 +87,7 @@ extern "C" void zk_ctx_destroy(zk_ctx* c) {
     hipFree(c->P.tom_tab_g), hipFree(c->P.tom_tab_h), hipFree(c->tom_tab_gen), hipFree(c->P.pfix_G), hipFree(c->P.pfix_H);
     hipFree(c->tab_scratch), hipFree(c->gk_etab), hipFree(c->d_flag), hipFree(c->d_totals), hipFree(c->ring_mem), hipFree(c->arena), hipFree(c->varena), hipFree(c->arena2), hipFree(c->d_totals2), hipFree(c->varena2);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
-    hipFree(c->io_buf);
+    hipFree(c->io_buf), hipFree(c->in_buf);
     for (auto e : c->copy_ev)
         if (e) hipEventDestroy(e);
     if (c->stream2) hipStreamDestroy(c->stream2);
@@ -215,6 +215,11 @@ extern "C" zk_status zk_ctx_set_batch_verify(zk_ctx* c, uint32_t min_chunk) {
     c->verify_batch_min = min_chunk;
     return ZK_OK;
 }
+extern "C" zk_status zk_ctx_set_host_taper(zk_ctx* c, uint32_t on) {
+    if (!c) return ZK_E_ARG;
+    c->host_taper = on ? 1 : 0;
+    return ZK_OK;
+}
 extern "C" zk_status zk_ctx_set_lanes(zk_ctx* c, uint32_t lanes) {
     if (!c || lanes < 1 || lanes > 2) return ZK_E_ARG;
     c->lanes = lanes;
@@ -339,6 +344,15 @@ zk_status ensure_io_buf(zk_ctx* c, size_t bytes) {
     c->io_bytes = bytes;
     return ZK_OK;
 }
+zk_status ensure_in_buf(zk_ctx* c, size_t bytes) {
+    if (bytes <= c->in_bytes) return ZK_OK;
+    if (c->in_buf) hipFree(c->in_buf);
+    c->in_buf = nullptr, c->in_bytes = 0;
+    bytes += bytes / 4 + 4096;
+    HIPCHK(c, hipMalloc(&c->in_buf, bytes));
+    c->in_bytes = bytes;
+    return ZK_OK;
+}
 zk_status ensure_copy_stream(zk_ctx* c) {
     if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (auto& e : c->copy_ev)
@@ -355,7 +369,8 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
     if (!c->params_set || !c->N) return ZK_E_BUFFER;
     if (rng_mode != ZK_RNG_SEED && rng_mode != ZK_RNG_STREAM) return ZK_E_ARG;
     uint32_t C = (uint32_t)std::min<uint64_t>(c->chunk, B ? B : 1);
-    const bool dual = c->lanes >= 2 && B > C;  // two or more chunks: alternate them over two streams / workspaces
+    const std::vector<ChunkPlan> plan = make_chunk_plan(B, C, host_sink != nullptr && c->host_taper);
+    const bool dual = c->lanes >= 2 && plan.size() > 1;  // two or more chunks: alternate them over two streams / workspaces
     zk_status zs = ensure_workspace(c, C, dual);
     if (zs) return zs;
     const DevParams& P = c->P;
@@ -378,11 +393,12 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
         Workspace Wgen;  // RNG view of the generator (seed mode) for the second prepass stage
         uint32_t nblk;
     };
-    auto stage1 = [&](uint64_t first, uint32_t chunk_no, Pending& pd) -> zk_status {
+    auto stage1 = [&](const ChunkPlan& cp, uint32_t chunk_no, Pending& pd) -> zk_status {
         const bool lane2 = dual && (chunk_no & 1);
         Workspace& W = lane2 ? c->W2 : c->W;
         hipStream_t s = lane2 ? c->stream2 : c->stream;
-        uint32_t cnt = (uint32_t)std::min<uint64_t>(C, B - first);
+        const uint64_t first = cp.first;
+        const uint32_t cnt = cp.cnt;
         ChunkIn in{d_msg + 32 * first, d_sig + 64 * first, d_pk + 64 * first, d_which + first, cnt};
         W.rng.seeds = d_rng, W.rng.stream = d_rng, W.rng.stride_blocks = stride, W.rng.mode = rng_mode, W.rng.sec = (int)W.sec;
         W.rng.proof_base = (uint32_t)first;
@@ -538,11 +554,11 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
         cursor += chunk_bytes;
         return ZK_OK;
     };
-    const uint64_t nchunks = (B + C - 1) / C;
+    const uint64_t nchunks = plan.size();
     Pending pend[2];
     for (uint64_t k = 0; k < nchunks && !zs; k++) {
-        if (k == 0 || !dual) zs = stage1(k * C, (uint32_t)k, pend[k & 1]);
-        if (!zs && dual && k + 1 < nchunks) zs = stage1((k + 1) * C, (uint32_t)(k + 1), pend[(k + 1) & 1]);
+        if (k == 0 || !dual) zs = stage1(plan[k], (uint32_t)k, pend[k & 1]);
+        if (!zs && dual && k + 1 < nchunks) zs = stage1(plan[k + 1], (uint32_t)(k + 1), pend[(k + 1) & 1]);
         if (!zs) zs = stage2(pend[k & 1]);
     }
     if (zs) {  // nothing of this call may still be running (or writing into the caller's buffer) when it returns
@@ -573,25 +589,33 @@ extern "C" zk_status zk_prove_batch(zk_ctx* c, uint64_t B, const uint8_t* msg, c
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->params_set || !c->N) return ZK_E_BUFFER;
     size_t rng_bytes = rng->mode == ZK_RNG_SEED ? 32 * B : 32 * B * rng->stride_blocks;
-    DevBuf d_msg, d_sig, d_pk, d_which, d_rng, d_off, d_st;
     size_t bb = B ? B : 1;
     uint64_t cap_dev = std::min<uint64_t>(out_cap, zk_proof_max_size(c) * bb);
-    HIPCHK(c, hipMalloc(&d_msg.p, 32 * bb));
-    HIPCHK(c, hipMalloc(&d_sig.p, 64 * bb));
-    HIPCHK(c, hipMalloc(&d_pk.p, 64 * bb));
-    HIPCHK(c, hipMalloc(&d_which.p, 4 * bb));
-    HIPCHK(c, hipMalloc(&d_rng.p, rng_bytes ? rng_bytes : 32));
-    HIPCHK(c, hipMalloc(&d_off.p, 8 * (bb + 1)));
-    HIPCHK(c, hipMalloc(&d_st.p, 4 * bb));
-    zk_status zs = ensure_io_buf(c, cap_dev ? cap_dev : 32);  // proof bytes: the context's grow-only staging buffer
+    // the small per-proof arrays live in the context's grow-only input buffer (no hipMalloc / hipFree per call)
+    Carver k(nullptr);
+    auto carve_in = [&](Carver& kk, uint8_t*& m, uint8_t*& sg, uint8_t*& p, uint32_t*& w, uint8_t*& r, uint64_t*& o, int32_t*& st_) {
+        m = (uint8_t*)kk.take(32 * bb), sg = (uint8_t*)kk.take(64 * bb), p = (uint8_t*)kk.take(64 * bb), w = (uint32_t*)kk.take(4 * bb);
+        r = (uint8_t*)kk.take(rng_bytes ? rng_bytes : 32), o = (uint64_t*)kk.take(8 * (bb + 1)), st_ = (int32_t*)kk.take(4 * bb);
+    };
+    uint8_t *d_msg, *d_sig, *d_pk, *d_rng;
+    uint32_t* d_which;
+    uint64_t* d_off;
+    int32_t* d_st;
+    carve_in(k, d_msg, d_sig, d_pk, d_which, d_rng, d_off, d_st);
+    zk_status zs = ensure_in_buf(c, k.off + 256);
+    if (zs) return zs;
+    Carver k2((uint8_t*)c->in_buf);
+    carve_in(k2, d_msg, d_sig, d_pk, d_which, d_rng, d_off, d_st);
+    zs = ensure_io_buf(c, cap_dev ? cap_dev : 32);  // proof bytes: the context's grow-only staging buffer
     if (zs) return zs;
     uint8_t* d_out = (uint8_t*)c->io_buf;
     if (B) {
-        HIPCHK(c, hipMemcpy(d_msg.p, msg, 32 * B, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(d_sig.p, sig, 64 * B, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(d_pk.p, pk, 64 * B, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(d_which.p, which, 4 * B, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(d_rng.p, rng->data, rng_bytes, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpyAsync(d_msg, msg, 32 * B, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_sig, sig, 64 * B, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_pk, pk, 64 * B, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_which, which, 4 * B, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_rng, rng->data, rng_bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // both lanes read these arrays
     }
     // a page-locked `out` (zk_host_alloc) receives each chunk by DMA while the next chunks are proved
     uint8_t* sink = B && host_ptr_is_pinned(out) ? out : nullptr;
@@ -599,11 +623,10 @@ extern "C" zk_status zk_prove_batch(zk_ctx* c, uint64_t B, const uint8_t* msg, c
         zs = ensure_copy_stream(c);
         if (zs) return zs;
     }
-    zs = prove_device(c, B, d_msg.as<uint8_t>(), d_sig.as<uint8_t>(), d_pk.as<uint8_t>(), d_which.as<uint32_t>(), rng->mode, d_rng.as<uint8_t>(),
-                      rng->stride_blocks, d_out, cap_dev, d_off.as<uint64_t>(), d_st.as<int32_t>(), sink);
+    zs = prove_device(c, B, d_msg, d_sig, d_pk, d_which, rng->mode, d_rng, rng->stride_blocks, d_out, cap_dev, d_off, d_st, sink);
     if (zs) return zs;
-    HIPCHK(c, hipMemcpy(out_off, d_off.p, 8 * (B + 1), hipMemcpyDeviceToHost));
-    if (B) HIPCHK(c, hipMemcpy(status, d_st.p, 4 * B, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out_off, d_off, 8 * (B + 1), hipMemcpyDeviceToHost));
+    if (B) HIPCHK(c, hipMemcpy(status, d_st, 4 * B, hipMemcpyDeviceToHost));
     if (!sink && out_off[B]) HIPCHK(c, hipMemcpy(out, d_out, out_off[B], hipMemcpyDeviceToHost));
     return ZK_OK;
 }

@@ -226,7 +226,9 @@ struct Wr {
 };
 }  // namespace
 
-extern "C" zk_status zk_proof_to_json(const uint8_t* proof, uint64_t len, char* out, uint64_t cap, uint64_t* out_len) {
+// No C++ exception may cross the C ABI: an allocation failure on a hostile input is reported as ZK_E_BUFFER.
+#define ZK_JSON_MAX_TEXT ((uint64_t)64 << 20)   // a SignatureProofList at secLevel 128, n = 64 is below 4 MB of JSON
+static zk_status proof_to_json_impl(const uint8_t* proof, uint64_t len, char* out, uint64_t cap, uint64_t* out_len) {
     if (!proof || !out_len || len < 32 || memcmp(proof, "ZKA1", 4)) return ZK_E_BAD_ENCODING;
     uint32_t total = (uint32_t)proof[4] << 24 | proof[5] << 16 | proof[6] << 8 | proof[7];
     uint32_t sec = (uint32_t)proof[8] << 24 | proof[9] << 16 | proof[10] << 8 | proof[11];
@@ -290,8 +292,17 @@ extern "C" zk_status zk_proof_to_json(const uint8_t* proof, uint64_t len, char* 
     return ZK_OK;
 }
 
-extern "C" zk_status zk_proof_from_json(const char* json, uint64_t len, uint8_t* out, uint64_t cap, uint64_t* out_len) {
+extern "C" zk_status zk_proof_to_json(const uint8_t* proof, uint64_t len, char* out, uint64_t cap, uint64_t* out_len) {
+    try {
+        return proof_to_json_impl(proof, len, out, cap, out_len);
+    } catch (...) {
+        return ZK_E_BUFFER;
+    }
+}
+
+static zk_status proof_from_json_impl(const char* json, uint64_t len, uint8_t* out, uint64_t cap, uint64_t* out_len) {
     if (!json || !out_len) return ZK_E_ARG;
+    if (len > ZK_JSON_MAX_TEXT) return ZK_E_BAD_ENCODING;
     Parser ps{json, json + len};
     Val root;
     if (!ps.val(root) || root.t != Val::OBJ) return ZK_E_BAD_ENCODING;
@@ -347,4 +358,11 @@ extern "C" zk_status zk_proof_from_json(const char* json, uint64_t len, uint8_t*
     if (!out || cap < total) return ZK_E_BUFFER;
     memcpy(out, w.b.data(), total);
     return ZK_OK;
+}
+extern "C" zk_status zk_proof_from_json(const char* json, uint64_t len, uint8_t* out, uint64_t cap, uint64_t* out_len) {
+    try {
+        return proof_from_json_impl(json, len, out, cap, out_len);
+    } catch (...) {
+        return ZK_E_BUFFER;
+    }
 }

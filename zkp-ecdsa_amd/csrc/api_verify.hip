@@ -117,21 +117,23 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
     if (c->P.sec < VK) return ZK_E_SECLEVEL;
     if (B == 0) return ZK_OK;
     uint32_t C = (uint32_t)std::min<uint64_t>(c->chunk, B);
-    const bool dual = c->lanes >= 2 && B > C;
+    const std::vector<ChunkPlan> plan = make_chunk_plan(B, C, host_src != nullptr && c->host_taper);
+    const bool dual = c->lanes >= 2 && plan.size() > 1;
     zk_status zs = ensure_workspace(c, C, dual);
     if (zs) return zs;
     zs = ensure_vworkspace(c, C, dual);
     if (zs) return zs;
     const DevParams& P = c->P;
     timing_begin(c);
-    uint8_t* own_seeds = nullptr;
+    DevBuf own_seeds_buf;   // released on every exit path
     if (!d_vseeds) {
         uint8_t master[32];
         if (!os_random(master, sizeof master)) {
             c->err = "no OS randomness for the verifier (getrandom / /dev/urandom failed)";
             return ZK_E_DEVICE;
         }
-        HIPCHK(c, hipMalloc(&own_seeds, 32 * B + 32));
+        HIPCHK(c, hipMalloc(&own_seeds_buf.p, 32 * B + 32));
+        uint8_t* own_seeds = own_seeds_buf.as<uint8_t>();
         HIPCHK(c, hipMemcpyAsync(own_seeds + 32 * B, master, 32, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_default_vseeds, dim3((uint32_t)((B + 255) / 256)), dim3(256), 0, c->stream, B, own_seeds + 32 * B, own_seeds);
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -140,14 +142,13 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
     const uint32_t nq = (c->n + 1) / 2;
     // Stage 1 (everything up to the term lists) of chunk k+1 is enqueued on the other stream before the host blocks on the
     // batched Tom check of chunk k (k_msm.hip reads counters and the verdict back), so neither stream runs dry.
-    auto stage1 = [&](uint64_t first, uint32_t chunk_no) -> zk_status {
+    auto stage1 = [&](uint64_t first, uint32_t cnt, uint32_t chunk_no) -> zk_status {
         const bool lane2 = dual && (chunk_no & 1);
         Workspace& W = lane2 ? c->W2 : c->W;
         VWork& V = lane2 ? c->V2 : c->V;
         hipStream_t s = lane2 ? c->stream2 : c->stream;
         const Soa& vres = lane2 ? c->v2_res : c->v_res;
         const Soa& vres2 = lane2 ? c->v2_res2 : c->v_res2;
-        uint32_t cnt = (uint32_t)std::min<uint64_t>(C, B - first);
         {
             Scope t(c, "v_parse_validate", s);
             launch_v_header_validate(s, V, cnt, d_proofs, d_off, first);
@@ -192,12 +193,11 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
         }
         return ZK_OK;
     };
-    auto stage2 = [&](uint64_t first, uint32_t chunk_no) -> zk_status {
+    auto stage2 = [&](uint64_t first, uint32_t cnt, uint32_t chunk_no) -> zk_status {
         const bool lane2 = dual && (chunk_no & 1);
         Workspace& W = lane2 ? c->W2 : c->W;
         VWork& V = lane2 ? c->V2 : c->V;
         hipStream_t s = lane2 ? c->stream2 : c->stream;
-        uint32_t cnt = (uint32_t)std::min<uint64_t>(C, B - first);
         // Tom-256 relations: one bucket-method sum over the whole chunk; only if that is not the identity (some proof is
         // bad) the per-proof windowed sums run to find out which
         uint32_t all_ok = 0;
@@ -227,38 +227,46 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
         }
         return ZK_OK;
     };
-    const uint64_t nchunks = (B + C - 1) / C;
-    std::vector<hipEvent_t> arrived;  // host_src: one event per chunk, recorded on the copy stream behind the chunk's bytes
-    auto release = [&] {
-        for (auto e : arrived) hipEventDestroy(e);
-        if (own_seeds) hipFree(own_seeds);
+    const uint64_t nchunks = plan.size();
+    struct Events {   // host_src: one event per chunk, recorded on the copy stream behind the chunk's bytes
+        std::vector<hipEvent_t> ev;
+        ~Events() {
+            for (auto e : ev)
+                if (e) hipEventDestroy(e);
+        }
+    } arrived;
+    auto drain = [&] {   // nothing of this call may still be running when it returns
+        hipStreamSynchronize(c->stream);
+        if (dual) hipStreamSynchronize(c->stream2);
+        if (host_src) hipStreamSynchronize(c->copy_stream);
     };
     if (host_src) {
-        arrived.resize(nchunks, nullptr);
+        arrived.ev.resize(nchunks, nullptr);
         for (uint64_t k = 0; k < nchunks; k++) {
-            uint64_t b0 = host_off[k * C], b1 = host_off[std::min<uint64_t>(B, (k + 1) * C)];
-            if (hipEventCreateWithFlags(&arrived[k], hipEventDisableTiming) != hipSuccess ||
+            uint64_t b0 = host_off[plan[k].first], b1 = host_off[plan[k].first + plan[k].cnt];
+            if (hipEventCreateWithFlags(&arrived.ev[k], hipEventDisableTiming) != hipSuccess ||
                 (b1 > b0 && hipMemcpyAsync((uint8_t*)d_proofs + b0, host_src + b0, b1 - b0, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess) ||
-                hipEventRecord(arrived[k], c->copy_stream) != hipSuccess) {
+                hipEventRecord(arrived.ev[k], c->copy_stream) != hipSuccess) {
                 c->err = "host-to-device copy of the proofs failed";
-                hipStreamSynchronize(c->copy_stream);
-                release();
+                drain();
                 return ZK_E_DEVICE;
             }
         }
     }
     auto stage1w = [&](uint64_t k) -> zk_status {
-        if (host_src) HIPCHK(c, hipStreamWaitEvent((dual && (k & 1)) ? c->stream2 : c->stream, arrived[k], 0));
-        return stage1(k * C, (uint32_t)k);
+        if (host_src && hipStreamWaitEvent((dual && (k & 1)) ? c->stream2 : c->stream, arrived.ev[k], 0) != hipSuccess) {
+            c->err = "hipStreamWaitEvent failed";
+            return ZK_E_DEVICE;
+        }
+        return stage1(plan[k].first, plan[k].cnt, (uint32_t)k);
     };
     for (uint64_t k = 0; k < nchunks && !zs; k++) {
         if (k == 0 || !dual) zs = stage1w(k);
         if (!zs && dual && k + 1 < nchunks) zs = stage1w(k + 1);
-        if (!zs) zs = stage2(k * C, (uint32_t)k);
+        if (!zs) zs = stage2(plan[k].first, plan[k].cnt, (uint32_t)k);
     }
     hipError_t e1 = hipStreamSynchronize(c->stream), e2 = dual ? hipStreamSynchronize(c->stream2) : hipSuccess;
     hipError_t e3 = host_src ? hipStreamSynchronize(c->copy_stream) : hipSuccess;
-    release();
     if (zs) return zs;
     HIPCHK(c, e1);
     HIPCHK(c, e2);
@@ -284,15 +292,23 @@ extern "C" zk_status zk_verify_batch(zk_ctx* c, uint64_t B, const uint8_t* msg, 
     for (uint64_t b = 0; b < B; b++)
         if (off[b + 1] < off[b]) return ZK_E_ARG;  // every proof lies inside [0, off[B])
     uint64_t total = off[B];
-    DevBuf d_msg, d_off, d_ok, d_st, d_seeds;
-    HIPCHK(c, hipMalloc(&d_msg.p, 32 * B));
-    HIPCHK(c, hipMalloc(&d_off.p, 8 * (B + 1)));
-    HIPCHK(c, hipMalloc(&d_ok.p, B));
-    HIPCHK(c, hipMalloc(&d_st.p, 4 * B));
-    zk_status zs = ensure_io_buf(c, total + 64);  // proof bytes: the context's grow-only staging buffer
+    // the small per-proof arrays live in the context's grow-only input buffer (no hipMalloc / hipFree per call)
+    Carver k0(nullptr);
+    auto carve_in = [&](Carver& kk, uint8_t*& m, uint64_t*& o, uint8_t*& okp, int32_t*& st_, uint8_t*& sd) {
+        m = (uint8_t*)kk.take(32 * B), o = (uint64_t*)kk.take(8 * (B + 1)), okp = (uint8_t*)kk.take(B), st_ = (int32_t*)kk.take(4 * B);
+        sd = (uint8_t*)kk.take(vseeds ? 32 * B : 32);
+    };
+    uint8_t *d_msg, *d_ok, *d_seeds;
+    uint64_t* d_off;
+    int32_t* d_st;
+    carve_in(k0, d_msg, d_off, d_ok, d_st, d_seeds);
+    zk_status zs = ensure_in_buf(c, k0.off + 256);
+    if (zs) return zs;
+    Carver k1((uint8_t*)c->in_buf);
+    carve_in(k1, d_msg, d_off, d_ok, d_st, d_seeds);
+    zs = ensure_io_buf(c, total + 64);  // proof bytes: the context's grow-only staging buffer
     if (zs) return zs;
     uint8_t* d_proofs = (uint8_t*)c->io_buf;
-    HIPCHK(c, hipMemcpy(d_msg.p, msg, 32 * B, hipMemcpyHostToDevice));
     // page-locked `proofs` (zk_host_alloc): chunk-wise DMA under the kernels of the earlier chunks; pageable: one blocking copy
     const bool pinned = host_ptr_is_pinned(proofs);
     if (pinned) {
@@ -301,15 +317,13 @@ extern "C" zk_status zk_verify_batch(zk_ctx* c, uint64_t B, const uint8_t* msg, 
     } else {
         HIPCHK(c, hipMemcpy(d_proofs, proofs, total, hipMemcpyHostToDevice));
     }
-    HIPCHK(c, hipMemcpy(d_off.p, off, 8 * (B + 1), hipMemcpyHostToDevice));
-    if (vseeds) {
-        HIPCHK(c, hipMalloc(&d_seeds.p, 32 * B));
-        HIPCHK(c, hipMemcpy(d_seeds.p, vseeds, 32 * B, hipMemcpyHostToDevice));
-    }
-    zs = verify_device(c, B, d_msg.as<uint8_t>(), d_proofs, d_off.as<uint64_t>(), d_seeds.as<uint8_t>(), d_ok.as<uint8_t>(), d_st.as<int32_t>(),
-                       pinned ? proofs : nullptr, pinned ? off : nullptr);
+    HIPCHK(c, hipMemcpyAsync(d_msg, msg, 32 * B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_off, off, 8 * (B + 1), hipMemcpyHostToDevice, c->stream));
+    if (vseeds) HIPCHK(c, hipMemcpyAsync(d_seeds, vseeds, 32 * B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // both lanes read these arrays
+    zs = verify_device(c, B, d_msg, d_proofs, d_off, vseeds ? d_seeds : nullptr, d_ok, d_st, pinned ? proofs : nullptr, pinned ? off : nullptr);
     if (zs) return zs;
-    HIPCHK(c, hipMemcpy(ok, d_ok.p, B, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(status, d_st.p, 4 * B, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ok, d_ok, B, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(status, d_st, 4 * B, hipMemcpyDeviceToHost));
     return ZK_OK;
 }

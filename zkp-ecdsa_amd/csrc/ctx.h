@@ -67,6 +67,9 @@ struct zk_ctx {
     hipEvent_t copy_ev[2] = {nullptr, nullptr};
     void* io_buf = nullptr;        // device staging of the proof bytes for the host-pointer entry points (grow-only: a
     size_t io_bytes = 0;           // multi-GB hipMalloc/hipFree per call costs as much as the transfer itself)
+    void* in_buf = nullptr;        // device copies of the small per-proof arrays of the host-pointer entry points (inputs,
+    size_t in_bytes = 0;           // offsets, statuses, verdicts), grow-only for the same reason
+    uint32_t host_taper = 1;       // host-pointer calls on page-locked buffers: tapered chunk plan (zk_ctx_set_host_taper)
     // timing
     std::vector<TimerRec> trecs;
     std::vector<hipEvent_t> epool;
@@ -133,6 +136,39 @@ struct DevBuf {
     T* as() const { return (T*)p; }
 };
 zk_status ensure_workspace(zk_ctx* c, uint32_t C, bool second_lane = false);
+zk_status ensure_in_buf(zk_ctx* c, size_t bytes);  // api.hip: c->in_buf of at least `bytes`
+
+// One pipeline pass = one chunk of consecutive proofs.  Device-pointer calls use uniform chunks of C proofs.  Host-pointer
+// calls on page-locked buffers move ~169 KB per proof across PCIe on a copy stream under the kernels of the neighbouring
+// chunks, and the transfer of a step takes almost as long as its kernels (11 GB at ~55 GB/s against ~250 ms).  A prove call
+// then ends at  max_k ( kernels of chunks 0..k  +  transfers of chunks k..last ),  so a chunk of c proofs with R proofs
+// behind it costs about 0.9 c - 0.1 R proof-times of exposed transfer: big chunks are only harmless early, and with two lanes
+// two chunks finish together.  The tapered plan: a half-sized first chunk (staggers the two lanes), chunks of at most C while
+// plenty of work remains, then chunks of a sixth of what is left down to ZK_TAPER_MIN proofs.  The verifier's mirror image
+// (kernels of the last chunks after the last H2D) is served by the same plan.  The bytes of a proof do not depend on the plan
+// (tests/test_gpu_prove.py::test_lanes_and_chunking_do_not_change_the_bytes).
+struct ChunkPlan {
+    uint64_t first;
+    uint32_t cnt;
+};
+#define ZK_TAPER_MIN 2048u
+static inline std::vector<ChunkPlan> make_chunk_plan(uint64_t B, uint32_t C, bool taper) {
+    std::vector<ChunkPlan> plan;
+    uint64_t f = 0;
+    bool first = true;
+    while (f < B) {
+        uint64_t left = B - f, c = C;
+        if (taper && C > ZK_TAPER_MIN) {
+            c = std::min<uint64_t>(C, std::max<uint64_t>(ZK_TAPER_MIN, (left / 6) & ~(uint64_t)255));
+            if (first) c = std::max<uint64_t>(ZK_TAPER_MIN, c / 2);
+        }
+        first = false;
+        c = std::min(c, left);
+        plan.push_back({f, (uint32_t)c});
+        f += c;
+    }
+    return plan;
+}
 zk_status ensure_io_buf(zk_ctx* c, size_t bytes);  // api.hip: c->io_buf of at least `bytes`
 bool host_ptr_is_pinned(const void* p);     // api.hip: page-locked (zk_host_alloc / hipHostMalloc / hipHostRegister) host memory?
 zk_status ensure_copy_stream(zk_ctx* c);    // api.hip: c->copy_stream and c->copy_ev
