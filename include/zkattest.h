@@ -96,9 +96,10 @@ zk_status zk_keys_to_ints(zk_ctx *ctx, uint64_t n_keys, const uint8_t *pk_xy64, 
  * Default 4096, maximum 2^18. */
 zk_status zk_ctx_set_chunk(zk_ctx *ctx, uint32_t proofs_per_chunk);
 
-/* Pipeline lanes of the prover: with 2 (default) alternate chunks run on their own HIP stream and workspace, so the
- * low-occupancy per-proof kernels of one chunk overlap the heavy kernels of the other; 1 = strictly serial kernels
- * (what bench.py uses for its per-kernel roofline pass). */
+/* Pipeline lanes (1..4, default 2; ZKATTEST_LANES): consecutive chunks rotate over that many HIP streams and workspaces, so the
+ * low-occupancy per-proof kernels, the host's waits and (host-pointer calls) the output phases of one chunk overlap the heavy
+ * kernels of the others; 1 = strictly serial kernels (what bench.py uses for its per-kernel roofline pass).  Every lane holds
+ * a workspace of `chunk` proofs. */
 zk_status zk_ctx_set_lanes(zk_ctx *ctx, uint32_t lanes);
 /* Width W (8..26 bits, default 16) of the fixed-base comb tables of the Tom-256 bases g and h: a commitment
  * v*g + r*h (PedersenParams.commit, src/commit/pedersen.ts:53-58) costs 2*ceil(256/W) table additions, the tables
@@ -108,11 +109,14 @@ zk_status zk_ctx_set_lanes(zk_ctx *ctx, uint32_t lanes);
  * ZKATTEST_COMB_BITS sets the default of new contexts. */
 zk_status zk_ctx_set_comb_bits(zk_ctx *ctx, uint32_t bits);
 
-/* Host-pointer calls on page-locked buffers (zk_prove_batch, zk_verify_batch): 1 (default) = tapered chunk plan -- a half-sized
- * first chunk, chunks of at most zk_ctx_set_chunk proofs, then chunks of a sixth of what is left down to 2048 proofs, so that
- * the PCIe transfer of the last chunks, the only one no kernel hides, stays small; 0 = uniform chunks.  The proof bytes do not
+/* zk_prove_batch on a page-locked `out`: 1 (default) = the first chunks of the L lanes hold chunk/L, 2*chunk/L, ... proofs, so
+ * the lanes run out of phase and their output phases (PCIe transfers) interleave; 0 = uniform chunks.  The proof bytes do not
  * depend on it. */
 zk_status zk_ctx_set_host_taper(zk_ctx *ctx, uint32_t on);
+/* The prover runs a chunk's PointAdd phase (src/exp/pointAdd.ts:92-163: 80 % of the proof bytes) in slices of `proofs`
+ * consecutive proofs; with a page-locked `out` every slice is followed by the DMA of the proofs it completed.  0 (default) =
+ * 4096 for page-locked output, no slicing otherwise; at least 64.  The proof bytes do not depend on it. */
+zk_status zk_ctx_set_slice(zk_ctx *ctx, uint32_t proofs);
 
 /* Verifier strategy for the Tom-256 relations: in a chunk of at least min_chunk proofs (default 256) the relations of ALL
  * proofs are checked with one bucket-method multi-scalar sum (independent 128-bit multipliers per relation and per proof);

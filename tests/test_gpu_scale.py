@@ -157,7 +157,7 @@ def test_tapered_chunk_plan_of_the_host_pointer_calls_keeps_the_bytes():
     """Page-locked buffers switch the host-pointer calls to the tapered plan (half-sized first chunk, shrinking tail); uniform
     chunks, pageable buffers and the device-pointer call must give the same bytes and verdicts."""
     import zkp_ecdsa_amd as Z
-    B, nkeys, sec = 9000, 64, 20
+    B, nkeys, sec = 9000, 16384, 20   # ring >= batch: every proof's key is in the ring
     eng, params, (ring, msg, sig, pk, which, seeds) = _engine(99, nkeys, B, sec=sec)
     cap = eng.proof_max_size() * B
     pin = Z.PinnedBuffer(cap)

@@ -31,6 +31,37 @@ template <int KIND, int NACC> __global__ void __launch_bounds__(256) k(uint64_t*
     for (int i = 0; i < NACC; i++) r += acc[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
+// SUSTAINED rate: the same kernel back to back for ~`ms_target` milliseconds (the figures above come from bursts of a few
+// milliseconds, i.e. at boost clock; the engine's kernels run for 10-60 ms each, hundreds of ms per step)
+template <int KIND, int NACC> int run_sustained(const char* name, uint64_t* out, int blocks_per_cu, float ms_target) {
+    int blocks = 256 * blocks_per_cu;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k<KIND, NACC>), dim3(blocks), dim3(256), 0, 0, out, 12345u);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k<KIND, NACC>), dim3(blocks), dim3(256), 0, 0, out, 1u);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float one; CHECK(hipEventElapsedTime(&one, e0, e1));
+    int reps = (int)(ms_target / one) + 1;
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL((k<KIND, NACC>), dim3(blocks), dim3(256), 0, 0, out, 12345u + r);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    // the last tenth alone: the clock has settled by then
+    int tail = reps / 10 + 1;
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < tail; r++) hipLaunchKernelGGL((k<KIND, NACC>), dim3(blocks), dim3(256), 0, 0, out, 777u + r);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms2; CHECK(hipEventElapsedTime(&ms2, e0, e1));
+    double per = (double)blocks * 256 * (double)ITER * 4 * NACC;
+    printf("%-22s NACC=%2d waves/SIMD=%d  SUSTAINED %7.1f ms (%d launches)  %8.2f T lane-ops/s; next %d launches %8.2f T lane-ops/s\n", name, NACC, blocks_per_cu,
+           ms, reps, per * reps / (ms * 1e-3) / 1e12, tail, per * tail / (ms2 * 1e-3) / 1e12);
+    return 0;
+}
 template <int KIND, int NACC> int run(const char* name, uint64_t* out, int blocks_per_cu) {
     int blocks = 256 * blocks_per_cu;
     hipEvent_t e0, e1;
@@ -59,5 +90,9 @@ int main() {
     run<1, 8>("v_mul_lo_u32", out, 8);
     run<2, 8>("shr64+add64", out, 8);
     run<3, 8>("v_add_u32", out, 8);
+    run_sustained<0, 16>("v_mad_u64_u32", out, 8, 300.f);
+    run_sustained<0, 16>("v_mad_u64_u32", out, 8, 2000.f);
+    run_sustained<0, 8>("v_mad_u64_u32", out, 2, 1000.f);
+    run<0, 16>("v_mad_u64_u32", out, 8);
     return 0;
 }

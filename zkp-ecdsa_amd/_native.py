@@ -14,7 +14,7 @@ SYMBOLS = [
     'zk_ctx_create', 'zk_ctx_destroy', 'zk_strerror', 'zk_last_error', 'zk_ctx_set_params', 'zk_ctx_set_ring',
     'zk_ctx_set_ring_device', 'zk_keys_to_ints', 'zk_ctx_set_chunk', 'zk_ctx_set_lanes', 'zk_ctx_set_comb_bits', 'zk_ctx_set_batch_verify', 'zk_proof_max_size', 'zk_prove_batch', 'zk_prove_batch_device',
     'zk_verify_batch', 'zk_verify_batch_device', 'zk_synth_workload', 'zk_synth_params', 'zk_last_timing',
-    'zk_proof_to_json', 'zk_proof_from_json', 'zk_host_alloc', 'zk_host_free', 'zk_ctx_set_host_taper',
+    'zk_proof_to_json', 'zk_proof_from_json', 'zk_host_alloc', 'zk_host_free', 'zk_ctx_set_host_taper', 'zk_ctx_set_slice',
     'zk_pool_create', 'zk_pool_destroy', 'zk_pool_size', 'zk_pool_ctx', 'zk_pool_last_error', 'zk_pool_ring_transport', 'zk_pool_shard',
     'zk_pool_set_params', 'zk_pool_set_ring', 'zk_pool_prove_batch', 'zk_pool_verify_batch',
     'zk_test_field_op', 'zk_test_tom_commit', 'zk_test_p256_fixed_mul', 'zk_test_sha256', 'zk_test_rng_draws',
@@ -81,6 +81,7 @@ def lib():
         L.zk_proof_to_json.argtypes = [C.c_char_p, u64, vp, u64, C.POINTER(u64)]
         L.zk_proof_from_json.argtypes = [C.c_char_p, u64, vp, u64, C.POINTER(u64)]
         L.zk_ctx_set_host_taper.argtypes = [vp, u32]
+        L.zk_ctx_set_slice.argtypes = [vp, u32]
         L.zk_pool_create.argtypes = [C.POINTER(C.c_int), i32, C.POINTER(vp)]
         L.zk_pool_destroy.argtypes = [vp]
         L.zk_pool_destroy.restype = None
@@ -224,6 +225,10 @@ class Engine:
 
     def set_lanes(self, lanes):
         self._chk(self.L.zk_ctx_set_lanes(self.h, lanes))
+
+    def set_slice(self, proofs):
+        """Proofs per PointAdd slice of the prover (0 = automatic: 4096 with page-locked output, none otherwise)."""
+        self._chk(self.L.zk_ctx_set_slice(self.h, int(proofs)))
 
     def set_host_taper(self, on):
         """Tapered chunk plan of the host-pointer calls on page-locked buffers (default on)."""

@@ -46,19 +46,24 @@ extern "C" zk_status zk_ctx_create(int device_id, zk_ctx** out) {
     *out = c;
     HIPCHK(c, hipSetDevice(device_id));
     HIPCHK(c, hipStreamCreate(&c->stream));
+    c->pl[0].stream = c->stream;
     if (const char* e = getenv("ZKATTEST_COMB_BITS")) {
         int b = atoi(e);
         if (b >= 8 && b <= TOM_MAX_BITS) c->tom_bits = (uint32_t)b;
     }
     if (const char* e = getenv("ZKATTEST_GK_TABLE")) c->gk_table = atoi(e) != 0;
     if (const char* e = getenv("ZKATTEST_VERIFY_BATCH")) c->verify_batch_min = (uint32_t)atoi(e);
+    if (const char* e = getenv("ZKATTEST_LANES")) {
+        int l = atoi(e);
+        if (l >= 1 && l <= ZK_MAX_LANES) c->lanes = (uint32_t)l;
+    }
     HIPCHK(c, hipMalloc(&c->tom_tab_gen, sizeof(uint32_t) * tom_tab_words(8)));
     HIPCHK(c, hipMalloc(&c->P.pfix_G, sizeof(uint32_t) * PFIX_TAB_WORDS));
     HIPCHK(c, hipMalloc(&c->P.pfix_H, sizeof(uint32_t) * PFIX_TAB_WORDS));
     c->scratch_words = std::max(pfix_table_scratch_words(), tom_table_scratch_words(TOM_MAX_BITS));
     HIPCHK(c, hipMalloc(&c->tab_scratch, sizeof(uint32_t) * c->scratch_words));
     HIPCHK(c, hipMalloc(&c->d_flag, 64));
-    HIPCHK(c, hipMalloc(&c->d_totals, 64));
+    HIPCHK(c, hipMalloc(&c->pl[0].d_totals, 64));
     int32_t one = 1;
     HIPCHK(c, hipMemcpyAsync(c->d_flag, &one, 4, hipMemcpyHostToDevice, c->stream));
     // tables that do not depend on the parameters: P-256 generator, Tom generator (8-bit comb: only zk_synth_params uses it)
@@ -85,12 +90,14 @@ extern "C" void zk_ctx_destroy(zk_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto e : c->epool) hipEventDestroy(e);
     hipFree(c->P.tom_tab_g), hipFree(c->P.tom_tab_h), hipFree(c->tom_tab_gen), hipFree(c->P.pfix_G), hipFree(c->P.pfix_H);
-    hipFree(c->tab_scratch), hipFree(c->gk_etab), hipFree(c->d_flag), hipFree(c->d_totals), hipFree(c->ring_mem), hipFree(c->arena), hipFree(c->varena), hipFree(c->arena2), hipFree(c->d_totals2), hipFree(c->varena2);
+    hipFree(c->tab_scratch), hipFree(c->gk_etab), hipFree(c->d_flag), hipFree(c->ring_mem);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     hipFree(c->io_buf), hipFree(c->in_buf);
-    for (auto e : c->copy_ev)
-        if (e) hipEventDestroy(e);
-    if (c->stream2) hipStreamDestroy(c->stream2);
+    for (int l = 0; l < ZK_MAX_LANES; l++) {
+        hipFree(c->pl[l].arena), hipFree(c->pl[l].d_totals), hipFree(c->vl[l].arena);
+        if (c->pl[l].copy_ev) hipEventDestroy(c->pl[l].copy_ev);
+        if (l && c->pl[l].stream) hipStreamDestroy(c->pl[l].stream);
+    }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -171,7 +178,7 @@ static zk_status set_ring_common(zk_ctx* c, const uint8_t* d_keys, uint64_t nkey
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->N = N, c->n = n, c->nkeys = nkeys;
-    c->ws_C = 0, c->lane2_ready = false;  // the workspace layout depends on the ring
+    c->ws_C = 0;  // the workspace layout depends on the ring
     return ZK_OK;
 }
 extern "C" zk_status zk_ctx_set_ring_device(zk_ctx* c, const void* d_keys, uint64_t nkeys) {
@@ -215,13 +222,18 @@ extern "C" zk_status zk_ctx_set_batch_verify(zk_ctx* c, uint32_t min_chunk) {
     c->verify_batch_min = min_chunk;
     return ZK_OK;
 }
+extern "C" zk_status zk_ctx_set_slice(zk_ctx* c, uint32_t proofs) {
+    if (!c || (proofs && proofs < 64)) return ZK_E_ARG;
+    c->slice = proofs;
+    return ZK_OK;
+}
 extern "C" zk_status zk_ctx_set_host_taper(zk_ctx* c, uint32_t on) {
     if (!c) return ZK_E_ARG;
     c->host_taper = on ? 1 : 0;
     return ZK_OK;
 }
 extern "C" zk_status zk_ctx_set_lanes(zk_ctx* c, uint32_t lanes) {
-    if (!c || lanes < 1 || lanes > 2) return ZK_E_ARG;
+    if (!c || lanes < 1 || lanes > ZK_MAX_LANES) return ZK_E_ARG;
     c->lanes = lanes;
     return ZK_OK;
 }
@@ -280,36 +292,29 @@ static size_t carve(zk_ctx* c, Workspace& W, Soa& gk_am, uint8_t* base, uint32_t
     W.ring = Soa{c->ring_mem, (uint32_t)N};
     return k.off + 256;
 }
-zk_status ensure_workspace(zk_ctx* c, uint32_t C, bool second_lane) {
+zk_status ensure_workspace(zk_ctx* c, uint32_t C, uint32_t nlanes) {
     uint32_t sec = c->P.sec, n = c->n;
-    bool same = c->arena && c->ws_C == C && c->ws_sec == sec && c->ws_n == n;
-    if (!same) {
-        size_t need = carve(c, c->W, c->gk_am, nullptr, C, sec, n, c->N);
-        if (need > c->arena_bytes) {
-            if (c->arena) HIPCHK(c, hipFree(c->arena));
-            c->arena = nullptr, c->arena_bytes = 0;
-            HIPCHK(c, hipMalloc(&c->arena, need));
-            c->arena_bytes = need;
-        }
-        carve(c, c->W, c->gk_am, (uint8_t*)c->arena, C, sec, n, c->N);
+    if (!(c->ws_C == C && c->ws_sec == sec && c->ws_n == n)) {
+        for (auto& L : c->pl) L.ready = false;
         c->ws_C = C, c->ws_sec = sec, c->ws_n = n;
-        c->lane2_ready = false;
     }
-    c->W.ring = Soa{c->ring_mem, (uint32_t)c->N};
-    if (second_lane && !c->lane2_ready) {
-        size_t need = carve(c, c->W2, c->gk_am2, nullptr, C, sec, n, c->N);
-        if (need > c->arena2_bytes) {
-            if (c->arena2) HIPCHK(c, hipFree(c->arena2));
-            c->arena2 = nullptr, c->arena2_bytes = 0;
-            HIPCHK(c, hipMalloc(&c->arena2, need));
-            c->arena2_bytes = need;
+    for (uint32_t l = 0; l < nlanes && l < ZK_MAX_LANES; l++) {
+        auto& L = c->pl[l];
+        if (!L.ready) {
+            size_t need = carve(c, L.W, L.gk_am, nullptr, C, sec, n, c->N);
+            if (need > L.arena_bytes) {
+                if (L.arena) HIPCHK(c, hipFree(L.arena));
+                L.arena = nullptr, L.arena_bytes = 0;
+                HIPCHK(c, hipMalloc(&L.arena, need));
+                L.arena_bytes = need;
+            }
+            carve(c, L.W, L.gk_am, (uint8_t*)L.arena, C, sec, n, c->N);
+            if (!L.stream) HIPCHK(c, hipStreamCreate(&L.stream));
+            if (!L.d_totals) HIPCHK(c, hipMalloc(&L.d_totals, 64));
+            L.ready = true;
         }
-        carve(c, c->W2, c->gk_am2, (uint8_t*)c->arena2, C, sec, n, c->N);
-        if (!c->stream2) HIPCHK(c, hipStreamCreate(&c->stream2));
-        if (!c->d_totals2) HIPCHK(c, hipMalloc(&c->d_totals2, 64));
-        c->lane2_ready = true;
+        L.W.ring = Soa{c->ring_mem, (uint32_t)c->N};
     }
-    if (c->lane2_ready) c->W2.ring = c->W.ring;
     return ZK_OK;
 }
 
@@ -355,8 +360,8 @@ zk_status ensure_in_buf(zk_ctx* c, size_t bytes) {
 }
 zk_status ensure_copy_stream(zk_ctx* c) {
     if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    for (auto& e : c->copy_ev)
-        if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& L : c->pl)
+        if (!L.copy_ev) HIPCHK(c, hipEventCreateWithFlags(&L.copy_ev, hipEventDisableTiming));
     return ZK_OK;
 }
 
@@ -369,9 +374,9 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
     if (!c->params_set || !c->N) return ZK_E_BUFFER;
     if (rng_mode != ZK_RNG_SEED && rng_mode != ZK_RNG_STREAM) return ZK_E_ARG;
     uint32_t C = (uint32_t)std::min<uint64_t>(c->chunk, B ? B : 1);
-    const std::vector<ChunkPlan> plan = make_chunk_plan(B, C, host_sink != nullptr && c->host_taper);
-    const bool dual = c->lanes >= 2 && plan.size() > 1;  // two or more chunks: alternate them over two streams / workspaces
-    zk_status zs = ensure_workspace(c, C, dual);
+    const std::vector<ChunkPlan> plan = make_chunk_plan(B, C, host_sink != nullptr && c->host_taper ? c->lanes : 1, false);
+    const uint32_t NL = (uint32_t)std::min<size_t>(c->lanes, plan.size() ? plan.size() : 1);  // chunks rotate over NL streams / workspaces
+    zk_status zs = ensure_workspace(c, C, NL);
     if (zs) return zs;
     const DevParams& P = c->P;
     timing_begin(c);
@@ -385,8 +390,16 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
     // the scan, which needs the output cursor, i.e. the byte count of all earlier chunks, and the host has to read the
     // item count back before it can size the PointAdd launches.  With two lanes, stage 1 of chunk k+1 is enqueued on the
     // other stream BEFORE the host blocks on chunk k's scan, so neither stream runs dry while the host waits.
+    auto sync_lanes = [&]() -> hipError_t {
+        hipError_t r = hipSuccess;
+        for (uint32_t l = 0; l < NL; l++) {
+            hipError_t e = hipStreamSynchronize(c->pl[l].stream);
+            if (r == hipSuccess) r = e;
+        }
+        return r;
+    };
     struct Pending {
-        bool lane2;
+        uint32_t lane;
         uint32_t cnt;
         uint64_t first;
         ChunkIn in;
@@ -394,9 +407,9 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
         uint32_t nblk;
     };
     auto stage1 = [&](const ChunkPlan& cp, uint32_t chunk_no, Pending& pd) -> zk_status {
-        const bool lane2 = dual && (chunk_no & 1);
-        Workspace& W = lane2 ? c->W2 : c->W;
-        hipStream_t s = lane2 ? c->stream2 : c->stream;
+        const uint32_t lane = chunk_no % NL;
+        Workspace& W = c->pl[lane].W;
+        hipStream_t s = c->pl[lane].stream;
         const uint64_t first = cp.first;
         const uint32_t cnt = cp.cnt;
         ChunkIn in{d_msg + 32 * first, d_sig + 64 * first, d_pk + 64 * first, d_which + first, cnt};
@@ -444,15 +457,19 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
             Scope t(c, "hash", s);
             launch_exp_challenge(s, W, cnt);
         }
-        pd.lane2 = lane2, pd.cnt = cnt, pd.first = first, pd.in = in, pd.Wgen = Wgen, pd.nblk = nblk;
+        pd.lane = lane, pd.cnt = cnt, pd.first = first, pd.in = in, pd.Wgen = Wgen, pd.nblk = nblk;
         return ZK_OK;
     };
+    // Stage 2.  Order: scan -> fixed part and rep heads -> the whole Groth-Kohlweiss phase -> the PointAdd phase (80 % of the
+    // bytes) in proof-aligned slices.  None of the three depends on another (they share the chunk's RNG fills and the list-A
+    // results), and with this order every byte of a proof is final as soon as the slice holding its PointAdd items is done: a
+    // page-locked sink then receives the slice's proofs by DMA while the next slice is being computed.  A slice runs the
+    // unchanged per-item kernels on a view of the workspace whose item-indexed arrays start at the slice's first item.
     auto stage2 = [&](Pending& pd) -> zk_status {
-        const bool lane2 = pd.lane2;
-        Workspace& W = lane2 ? c->W2 : c->W;
-        hipStream_t s = lane2 ? c->stream2 : c->stream;
-        const Soa& gk_am = lane2 ? c->gk_am2 : c->gk_am;
-        uint32_t* d_totals = lane2 ? c->d_totals2 : c->d_totals;
+        Workspace& W = c->pl[pd.lane].W;
+        hipStream_t s = c->pl[pd.lane].stream;
+        const Soa& gk_am = c->pl[pd.lane].gk_am;
+        uint32_t* d_totals = c->pl[pd.lane].d_totals;
         const uint32_t cnt = pd.cnt, nblk = pd.nblk;
         const uint64_t first = pd.first;
         const ChunkIn& in = pd.in;
@@ -462,23 +479,29 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
             Scope t(c, "scan", s);
             launch_scan(s, W, cnt, cursor, out_cap, d_out_off, d_status, d_totals, first);
         }
+        const uint32_t S = c->slice ? c->slice : (host_sink ? 4096u : 0u);
+        const bool sliced = S && cnt > S;
         HIPCHK(c, hipMemcpyAsync(totals, d_totals, 16, hipMemcpyDeviceToHost, s));
+        if (sliced) {   // slice boundaries: the chunk's item and byte prefix sums
+            c->h_item_base.resize((size_t)cnt + 1), c->h_out_base.resize((size_t)cnt + 1);
+            HIPCHK(c, hipMemcpyAsync(c->h_item_base.data(), W.item_base, 4 * ((size_t)cnt + 1), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(c->h_out_base.data(), W.out_base, 8 * ((size_t)cnt + 1), hipMemcpyDeviceToHost, s));
+        }
         HIPCHK(c, hipStreamSynchronize(s));
         if (totals[1]) {
             c->err = "output buffer too small";
-            hipStreamSynchronize(c->stream);
-            if (dual) hipStreamSynchronize(c->stream2);
+            sync_lanes();
             return ZK_E_BUFFER;
         }
-        uint32_t items = totals[0];
-        if (items > W.items_cap) {
+        const uint32_t items_all = totals[0];
+        if (items_all > W.items_cap) {
             // cannot happen for hash-derived challenges (cap = mean + 8 sigma) unless chunk*sec is tiny, where cap = chunk*sec
             c->err = "zero-bit rep count exceeds workspace capacity";
-            hipStreamSynchronize(c->stream);
-            if (dual) hipStreamSynchronize(c->stream2);
+            sync_lanes();
             return ZK_E_BUFFER;
         }
         uint8_t* out = d_out + cursor;
+        const uint64_t chunk_bytes = (uint64_t)totals[2] | ((uint64_t)totals[3] << 32);
         {
             Scope t(c, "scan", s);
             launch_items(s, W, cnt);
@@ -488,38 +511,7 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
             launch_rng_prepass(s, Wgen, cnt, 3 + 4 * W.sec + RNG_MAX_EXC, nblk, nblk, rng_mode == 0 ? W.rng_fill : nullptr, true);
         }
         {
-            Scope t(c, "p256_t1", s);
-            launch_t1(s, W, items);
-        }
-        {
-            Scope t(c, "p256_normalize", s);
-            launch_p256_normalize(s, W.T1proj, items, W.T1x, W.T1y, W.st, 1, ZK_E_T1_INF, W.item_proof);
-        }
-        {
-            Scope t(c, "scalars", s);
-            launch_padd_scalars(s, P, W, items);
-        }
-        {
-            Scope t(c, "tom_commit", s);
-            launch_tom_commit_listb(s, P, W.lb, items, W.items_cap);
-        }
-        {
-            Scope t(c, "tom_normalize", s);
-            launch_tom_normalize(s, W.lb, items * LB_COMMITS, 0, items, 0, W.items_cap);
-        }
-        {
-            Scope t(c, "tom_derived", s);
-            launch_padd_derived(s, W, items);
-            launch_tom_normalize(s, W.lb, items * 5, LB_COMMITS, items, 0, W.items_cap);
-        }
-        {
-            Scope t(c, "hash", s);
-            launch_padd_hash(s, P, W, items);
-        }
-        {
             Scope t(c, "respond_write", s);
-            launch_padd_respond(s, W, items, out);
-            launch_write_padd_points(s, W, items, out);
             launch_write_fixed(s, W, cnt, out);
         }
         {
@@ -542,34 +534,90 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
         {
             Scope t(c, "respond_write", s);
             launch_gk_respond(s, W, in, out);
-            launch_status_out(s, W, cnt, d_status, first);
         }
-        const uint64_t chunk_bytes = (uint64_t)totals[2] | ((uint64_t)totals[3] << 32);
-        if (host_sink && chunk_bytes) {
-            hipEvent_t ev = c->copy_ev[lane2 ? 1 : 0];
-            HIPCHK(c, hipEventRecord(ev, s));
-            HIPCHK(c, hipStreamWaitEvent(c->copy_stream, ev, 0));
-            HIPCHK(c, hipMemcpyAsync(host_sink + cursor, d_out + cursor, chunk_bytes, hipMemcpyDeviceToHost, c->copy_stream));
+        std::vector<ChunkPlan> slices;
+        if (sliced) slices = make_chunk_plan(cnt, S, 1, host_sink != nullptr, ZK_SLICE_MIN);
+        else slices.push_back({0, cnt});
+        for (const ChunkPlan& sl : slices) {
+            const uint32_t p0 = (uint32_t)sl.first, p1 = p0 + sl.cnt;
+            const uint32_t i0 = sliced ? c->h_item_base[p0] : 0, i1 = sliced ? c->h_item_base[p1] : items_all;
+            const uint32_t items = i1 - i0;
+            if (items) {
+                Workspace Ws = W;   // the slice's view: item-indexed arrays start at item i0
+                Ws.item_proof += i0, Ws.item_rep += i0, Ws.item_rank += i0, Ws.padd_c += (size_t)18 * i0;
+                for (Soa* a : {&Ws.T1proj.x, &Ws.T1proj.y, &Ws.T1proj.z, &Ws.T1x, &Ws.T1y, &Ws.lb.v, &Ws.lb.r, &Ws.lb.proj.x, &Ws.lb.proj.y, &Ws.lb.proj.z,
+                               &Ws.lb.ax, &Ws.lb.ay})
+                    a->p += i0;
+                {
+                    Scope t(c, "p256_t1", s);
+                    launch_t1(s, Ws, items);
+                }
+                {
+                    Scope t(c, "p256_normalize", s);
+                    launch_p256_normalize(s, Ws.T1proj, items, Ws.T1x, Ws.T1y, Ws.st, 1, ZK_E_T1_INF, Ws.item_proof);
+                }
+                {
+                    Scope t(c, "scalars", s);
+                    launch_padd_scalars(s, P, Ws, items);
+                }
+                {
+                    Scope t(c, "tom_commit", s);
+                    launch_tom_commit_listb(s, P, Ws.lb, items, Ws.items_cap);
+                }
+                {
+                    Scope t(c, "tom_normalize", s);
+                    launch_tom_normalize(s, Ws.lb, items * LB_COMMITS, 0, items, 0, Ws.items_cap);
+                }
+                {
+                    Scope t(c, "tom_derived", s);
+                    launch_padd_derived(s, Ws, items);
+                    launch_tom_normalize(s, Ws.lb, items * 5, LB_COMMITS, items, 0, Ws.items_cap);
+                }
+                {
+                    Scope t(c, "hash", s);
+                    launch_padd_hash(s, P, Ws, items);
+                }
+                {
+                    Scope t(c, "respond_write", s);
+                    launch_padd_respond(s, Ws, items, out);
+                    launch_write_padd_points(s, Ws, items, out);
+                }
+            }
+            if (host_sink) {   // every byte of proofs [p0, p1) is final: DMA them out behind the next slice's kernels
+                const uint64_t b0 = sliced ? c->h_out_base[p0] : 0, b1 = sliced ? c->h_out_base[p1] : chunk_bytes;
+                if (b1 > b0) {
+                    hipEvent_t ev = c->pl[pd.lane].copy_ev;
+                    HIPCHK(c, hipEventRecord(ev, s));
+                    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, ev, 0));
+                    HIPCHK(c, hipMemcpyAsync(host_sink + cursor + b0, out + b0, b1 - b0, hipMemcpyDeviceToHost, c->copy_stream));
+                }
+            }
+        }
+        {
+            Scope t(c, "respond_write", s);
+            launch_status_out(s, W, cnt, d_status, first);   // late (cryptographically negligible) errors included: after the last slice
         }
         cursor += chunk_bytes;
         return ZK_OK;
     };
     const uint64_t nchunks = plan.size();
-    Pending pend[2];
+    Pending pend[ZK_MAX_LANES];
+    // stage 1 of the next NL - 1 chunks is enqueued on the other lanes before the host blocks on this chunk's scan
+    uint64_t next_s1 = 0;
     for (uint64_t k = 0; k < nchunks && !zs; k++) {
-        if (k == 0 || !dual) zs = stage1(plan[k], (uint32_t)k, pend[k & 1]);
-        if (!zs && dual && k + 1 < nchunks) zs = stage1(plan[k + 1], (uint32_t)(k + 1), pend[(k + 1) & 1]);
-        if (!zs) zs = stage2(pend[k & 1]);
+        while (!zs && next_s1 < nchunks && next_s1 < k + NL) {
+            zs = stage1(plan[next_s1], (uint32_t)next_s1, pend[next_s1 % NL]);
+            next_s1++;
+        }
+        if (!zs) zs = stage2(pend[k % NL]);
     }
-    if (zs) {  // nothing of this call may still be running (or writing into the caller's buffer) when it returns
-        hipStreamSynchronize(c->stream);
-        if (dual) hipStreamSynchronize(c->stream2);
-        if (host_sink) hipStreamSynchronize(c->copy_stream);
-        return zs;
+    hipError_t e_sync = sync_lanes();   // nothing of this call may still be running (or writing into the caller's buffer) when it returns
+    if (host_sink) {
+        hipError_t e2 = hipStreamSynchronize(c->copy_stream);
+        if (e_sync == hipSuccess) e_sync = e2;
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (dual) HIPCHK(c, hipStreamSynchronize(c->stream2));
-    if (host_sink) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    if (zs) return zs;
+    HIPCHK(c, e_sync);
     HIPCHK(c, hipGetLastError());
     timing_end(c);
     return ZK_OK;

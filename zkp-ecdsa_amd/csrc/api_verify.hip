@@ -58,30 +58,24 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
     res2 = k.soa((size_t)C * std::max<uint64_t>(1, (N >> T) / 512));
     return k.off + 256;
 }
-static zk_status ensure_vworkspace(zk_ctx* c, uint32_t C, bool second_lane) {
+static zk_status ensure_vworkspace(zk_ctx* c, uint32_t C, uint32_t nlanes) {
     uint32_t sec = c->P.sec, n = c->n;
-    if (!(c->varena && c->vs_C == C && c->vs_sec == sec && c->vs_n == n)) {
-        size_t need = vcarve(c->V, c->v_res, c->v_res2, c->M, nullptr, C, sec, n, c->N);
-        if (need > c->varena_bytes) {
-            if (c->varena) HIPCHK(c, hipFree(c->varena));
-            c->varena = nullptr, c->varena_bytes = 0;
-            HIPCHK(c, hipMalloc(&c->varena, need));
-            c->varena_bytes = need;
-        }
-        vcarve(c->V, c->v_res, c->v_res2, c->M, (uint8_t*)c->varena, C, sec, n, c->N);
+    if (!(c->vs_C == C && c->vs_sec == sec && c->vs_n == n)) {
+        for (auto& L : c->vl) L.ready = false;
         c->vs_C = C, c->vs_sec = sec, c->vs_n = n;
-        c->vlane2_ready = false;
     }
-    if (second_lane && !c->vlane2_ready) {
-        size_t need = vcarve(c->V2, c->v2_res, c->v2_res2, c->M2, nullptr, C, sec, n, c->N);
-        if (need > c->varena2_bytes) {
-            if (c->varena2) HIPCHK(c, hipFree(c->varena2));
-            c->varena2 = nullptr, c->varena2_bytes = 0;
-            HIPCHK(c, hipMalloc(&c->varena2, need));
-            c->varena2_bytes = need;
+    for (uint32_t l = 0; l < nlanes && l < ZK_MAX_LANES; l++) {
+        auto& L = c->vl[l];
+        if (L.ready) continue;
+        size_t need = vcarve(L.V, L.res, L.res2, L.M, nullptr, C, sec, n, c->N);
+        if (need > L.arena_bytes) {
+            if (L.arena) HIPCHK(c, hipFree(L.arena));
+            L.arena = nullptr, L.arena_bytes = 0;
+            HIPCHK(c, hipMalloc(&L.arena, need));
+            L.arena_bytes = need;
         }
-        vcarve(c->V2, c->v2_res, c->v2_res2, c->M2, (uint8_t*)c->varena2, C, sec, n, c->N);
-        c->vlane2_ready = true;
+        vcarve(L.V, L.res, L.res2, L.M, (uint8_t*)L.arena, C, sec, n, c->N);
+        L.ready = true;
     }
     return ZK_OK;
 }
@@ -117,11 +111,11 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
     if (c->P.sec < VK) return ZK_E_SECLEVEL;
     if (B == 0) return ZK_OK;
     uint32_t C = (uint32_t)std::min<uint64_t>(c->chunk, B);
-    const std::vector<ChunkPlan> plan = make_chunk_plan(B, C, host_src != nullptr && c->host_taper);
-    const bool dual = c->lanes >= 2 && plan.size() > 1;
-    zk_status zs = ensure_workspace(c, C, dual);
+    const std::vector<ChunkPlan> plan = make_chunk_plan(B, C, 1, false);   // uniform: see ctx.h
+    const uint32_t NL = (uint32_t)std::min<size_t>(c->lanes, plan.size());   // chunks rotate over NL streams / workspaces
+    zk_status zs = ensure_workspace(c, C, NL);
     if (zs) return zs;
-    zs = ensure_vworkspace(c, C, dual);
+    zs = ensure_vworkspace(c, C, NL);
     if (zs) return zs;
     const DevParams& P = c->P;
     timing_begin(c);
@@ -143,12 +137,12 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
     // Stage 1 (everything up to the term lists) of chunk k+1 is enqueued on the other stream before the host blocks on the
     // batched Tom check of chunk k (k_msm.hip reads counters and the verdict back), so neither stream runs dry.
     auto stage1 = [&](uint64_t first, uint32_t cnt, uint32_t chunk_no) -> zk_status {
-        const bool lane2 = dual && (chunk_no & 1);
-        Workspace& W = lane2 ? c->W2 : c->W;
-        VWork& V = lane2 ? c->V2 : c->V;
-        hipStream_t s = lane2 ? c->stream2 : c->stream;
-        const Soa& vres = lane2 ? c->v2_res : c->v_res;
-        const Soa& vres2 = lane2 ? c->v2_res2 : c->v_res2;
+        const uint32_t lane = chunk_no % NL;
+        Workspace& W = c->pl[lane].W;
+        VWork& V = c->vl[lane].V;
+        hipStream_t s = c->pl[lane].stream;
+        const Soa& vres = c->vl[lane].res;
+        const Soa& vres2 = c->vl[lane].res2;
         {
             Scope t(c, "v_parse_validate", s);
             launch_v_header_validate(s, V, cnt, d_proofs, d_off, first);
@@ -194,16 +188,16 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
         return ZK_OK;
     };
     auto stage2 = [&](uint64_t first, uint32_t cnt, uint32_t chunk_no) -> zk_status {
-        const bool lane2 = dual && (chunk_no & 1);
-        Workspace& W = lane2 ? c->W2 : c->W;
-        VWork& V = lane2 ? c->V2 : c->V;
-        hipStream_t s = lane2 ? c->stream2 : c->stream;
+        const uint32_t lane = chunk_no % NL;
+        Workspace& W = c->pl[lane].W;
+        VWork& V = c->vl[lane].V;
+        hipStream_t s = c->pl[lane].stream;
         // Tom-256 relations: one bucket-method sum over the whole chunk; only if that is not the identity (some proof is
         // bad) the per-proof windowed sums run to find out which
         uint32_t all_ok = 0;
         if (c->verify_batch_min && cnt >= c->verify_batch_min) {
             Scope t(c, "v_msm_tom", s);
-            hipError_t e = run_msm(s, P, W, V, cnt, nq, lane2 ? c->M2 : c->M, &all_ok);
+            hipError_t e = run_msm(s, P, W, V, cnt, nq, c->vl[lane].M, &all_ok);
             if (e != hipSuccess) {
                 c->err = std::string("batched verification failed: ") + hipGetErrorString(e);
                 return ZK_E_DEVICE;
@@ -236,8 +230,7 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
         }
     } arrived;
     auto drain = [&] {   // nothing of this call may still be running when it returns
-        hipStreamSynchronize(c->stream);
-        if (dual) hipStreamSynchronize(c->stream2);
+        for (uint32_t l = 0; l < NL; l++) hipStreamSynchronize(c->pl[l].stream);
         if (host_src) hipStreamSynchronize(c->copy_stream);
     };
     if (host_src) {
@@ -254,22 +247,26 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
         }
     }
     auto stage1w = [&](uint64_t k) -> zk_status {
-        if (host_src && hipStreamWaitEvent((dual && (k & 1)) ? c->stream2 : c->stream, arrived.ev[k], 0) != hipSuccess) {
+        if (host_src && hipStreamWaitEvent(c->pl[k % NL].stream, arrived.ev[k], 0) != hipSuccess) {
             c->err = "hipStreamWaitEvent failed";
             return ZK_E_DEVICE;
         }
         return stage1(plan[k].first, plan[k].cnt, (uint32_t)k);
     };
+    // stage 1 of the next NL - 1 chunks is enqueued on the other lanes before the host blocks on this chunk's batched check
+    uint64_t next_s1 = 0;
     for (uint64_t k = 0; k < nchunks && !zs; k++) {
-        if (k == 0 || !dual) zs = stage1w(k);
-        if (!zs && dual && k + 1 < nchunks) zs = stage1w(k + 1);
+        while (!zs && next_s1 < nchunks && next_s1 < k + NL) zs = stage1w(next_s1++);
         if (!zs) zs = stage2(plan[k].first, plan[k].cnt, (uint32_t)k);
     }
-    hipError_t e1 = hipStreamSynchronize(c->stream), e2 = dual ? hipStreamSynchronize(c->stream2) : hipSuccess;
+    hipError_t e1 = hipSuccess;
+    for (uint32_t l = 0; l < NL; l++) {
+        hipError_t e = hipStreamSynchronize(c->pl[l].stream);
+        if (e1 == hipSuccess) e1 = e;
+    }
     hipError_t e3 = host_src ? hipStreamSynchronize(c->copy_stream) : hipSuccess;
     if (zs) return zs;
     HIPCHK(c, e1);
-    HIPCHK(c, e2);
     HIPCHK(c, e3);
     HIPCHK(c, hipGetLastError());
     timing_end(c);

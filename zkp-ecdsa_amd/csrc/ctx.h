@@ -12,6 +12,7 @@ struct TimerRec {
     const char* name;
     hipEvent_t e0, e1;
 };
+#define ZK_MAX_LANES 4
 struct zk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -31,45 +32,43 @@ struct zk_ctx {
     bool gk_table = true;          // ZKATTEST_GK_TABLE=0 disables it (plain fold for every ring)
     uint64_t N = 0, nkeys = 0;
     uint32_t n = 0;
-    // workspace
+    // workspace: up to ZK_MAX_LANES pipeline lanes, each with its own HIP stream and prover / verifier workspace; consecutive
+    // chunks go to consecutive lanes, so the low-occupancy per-proof kernels, the scans the host waits for and (host-pointer
+    // calls) the output phases of different chunks fall into each other's heavy phases.  Lane 0 runs on `stream`.
     uint32_t chunk = 4096;
-    void* arena = nullptr;
-    size_t arena_bytes = 0;
     uint32_t ws_C = 0, ws_sec = 0, ws_n = 0;
-    Workspace W{};
-    Soa gk_am{};
-    uint32_t* d_totals = nullptr;
-    // second pipeline lane (alternate chunks run on their own stream + workspace so that the low-occupancy front-end
-    // kernels of chunk k+1 overlap the heavy phases of chunk k)
-    hipStream_t stream2 = nullptr;
-    Workspace W2{};
-    Soa gk_am2{};
-    uint32_t* d_totals2 = nullptr;
-    void* arena2 = nullptr;
-    size_t arena2_bytes = 0;
-    bool lane2_ready = false;
+    struct ProveLane {
+        hipStream_t stream = nullptr;
+        Workspace W{};
+        Soa gk_am{};
+        uint32_t* d_totals = nullptr;
+        void* arena = nullptr;
+        size_t arena_bytes = 0;
+        bool ready = false;
+        hipEvent_t copy_ev = nullptr;   // host-buffer entry points: "this lane's bytes are final" for the copy stream
+    } pl[ZK_MAX_LANES];
     uint32_t lanes = 2;
     // verifier workspace
-    VWork V{};
-    void* varena = nullptr;
-    size_t varena_bytes = 0;
+    struct VerifyLane {
+        VWork V{};
+        void* arena = nullptr;
+        size_t arena_bytes = 0;
+        Soa res{}, res2{};
+        MsmBuf M{};               // batched Tom check buffers (k_msm.hip), carved with V
+        bool ready = false;
+    } vl[ZK_MAX_LANES];
     uint32_t vs_C = 0, vs_sec = 0, vs_n = 0;
-    Soa v_res{}, v_res2{};
-    MsmBuf M{}, M2{};         // batched Tom check buffers (k_msm.hip), carved with V / V2
     uint32_t verify_batch_min = 256;   // zk_ctx_set_batch_verify: chunks of at least this many proofs get the batched check (0 = never)
-    VWork V2{};               // second verifier lane
-    void* varena2 = nullptr;
-    size_t varena2_bytes = 0;
-    Soa v2_res{}, v2_res2{};
-    bool vlane2_ready = false;
     // host-buffer entry points: DMA stream for page-locked caller buffers (zk_host_alloc), one event per lane
     hipStream_t copy_stream = nullptr;
-    hipEvent_t copy_ev[2] = {nullptr, nullptr};
     void* io_buf = nullptr;        // device staging of the proof bytes for the host-pointer entry points (grow-only: a
     size_t io_bytes = 0;           // multi-GB hipMalloc/hipFree per call costs as much as the transfer itself)
     void* in_buf = nullptr;        // device copies of the small per-proof arrays of the host-pointer entry points (inputs,
     size_t in_bytes = 0;           // offsets, statuses, verdicts), grow-only for the same reason
     uint32_t host_taper = 1;       // host-pointer calls on page-locked buffers: tapered chunk plan (zk_ctx_set_host_taper)
+    uint32_t slice = 0;            // proofs per PointAdd slice of the prover (zk_ctx_set_slice): 0 = 4096 with a page-locked sink, else none
+    std::vector<uint32_t> h_item_base;   // host copies of a chunk's item / byte prefix sums (slice boundaries)
+    std::vector<uint64_t> h_out_base;
     // timing
     std::vector<TimerRec> trecs;
     std::vector<hipEvent_t> epool;
@@ -135,43 +134,56 @@ struct DevBuf {
     template <class T>
     T* as() const { return (T*)p; }
 };
-zk_status ensure_workspace(zk_ctx* c, uint32_t C, bool second_lane = false);
+zk_status ensure_workspace(zk_ctx* c, uint32_t C, uint32_t nlanes = 1);   // api.hip: prover workspaces of lanes 0..nlanes-1
 zk_status ensure_in_buf(zk_ctx* c, size_t bytes);  // api.hip: c->in_buf of at least `bytes`
 
 // One pipeline pass = one chunk of consecutive proofs.  Device-pointer calls use uniform chunks of C proofs.  Host-pointer
 // calls on page-locked buffers move ~169 KB per proof across PCIe on a copy stream under the kernels of the neighbouring
-// chunks, and the transfer of a step takes almost as long as its kernels (11 GB at ~55 GB/s against ~250 ms).  A prove call
-// then ends at  max_k ( kernels of chunks 0..k  +  transfers of chunks k..last ),  so a chunk of c proofs with R proofs
-// behind it costs about 0.9 c - 0.1 R proof-times of exposed transfer: big chunks are only harmless early, and with two lanes
-// two chunks finish together.  The tapered plan: a half-sized first chunk (staggers the two lanes), chunks of at most C while
-// plenty of work remains, then chunks of a sixth of what is left down to ZK_TAPER_MIN proofs.  The verifier's mirror image
-// (kernels of the last chunks after the last H2D) is served by the same plan.  The bytes of a proof do not depend on the plan
-// (tests/test_gpu_prove.py::test_lanes_and_chunking_do_not_change_the_bytes).
+// chunks, and the transfer of a step takes almost as long as its kernels (11 GB at ~57 GB/s = 194 ms against ~250 ms), so the
+// copy stream has to be fed early and evenly and whatever is still in flight at the end stays exposed:
+//   * prove: a chunk's PointAdd phase -- 80 % of its bytes -- runs in proof-aligned SLICES (api.hip), each followed by the
+//     D2H of the proofs it completed; what stays exposed is the last slice of each lane, so a chunk's slices taper;
+//   * verify: the H2D of all chunks is enqueued up front and the lanes wait per chunk; what stays exposed is the kernels of
+//     the last chunks.  Small chunks are inefficient (fixed cost of the chunk-wide bucket sum: 351 k verifies/s at 8 192
+//     proofs per chunk, 250 k at 4 096), so a tapered tail was measured to LOSE (263 k against 287 k verifies/s): uniform chunks;
+//   * prove: the first chunks of the lanes grow C/L, 2C/L, ... so that the lanes run out of phase and one lane's output
+//     phase falls into the others' compute-only phases.
+// The bytes of a proof do not depend on the plan (tests/test_gpu_scale.py::test_tapered_chunk_plan_...).
 struct ChunkPlan {
     uint64_t first;
     uint32_t cnt;
 };
 #define ZK_TAPER_MIN 2048u
-static inline std::vector<ChunkPlan> make_chunk_plan(uint64_t B, uint32_t C, bool taper) {
+#define ZK_SLICE_MIN 1024u
+// sizes summing to B: the first `stagger` chunks grow C/stagger, 2C/stagger, ... (the lanes then finish out of phase), then
+// chunks of C, then (tail) halving chunks C/2, C/4, ... >= lo with the last size twice
+static inline std::vector<ChunkPlan> make_chunk_plan(uint64_t B, uint32_t C, uint32_t stagger, bool tail, uint32_t lo = ZK_TAPER_MIN) {
+    std::vector<uint32_t> sizes, tl;
+    uint64_t left = B;
+    if (tail && C >= 2 * lo && B >= 3ull * C) {
+        for (uint32_t s = C / 2; s >= lo; s /= 2) tl.push_back(s);
+        tl.push_back(tl.back());
+        for (uint32_t s : tl) left -= s;
+    }
+    if (stagger > 1 && C >= stagger * lo && left > (uint64_t)C * (stagger + 1) / 2) {
+        for (uint32_t l = 1; l < stagger; l++) {
+            uint32_t s = (uint32_t)(((uint64_t)C * l / stagger) & ~255ull);
+            sizes.push_back(s), left -= s;
+        }
+    }
+    while (left) {
+        uint32_t c = (uint32_t)std::min<uint64_t>(C, left);
+        sizes.push_back(c), left -= c;
+    }
+    for (uint32_t s : tl) sizes.push_back(s);
     std::vector<ChunkPlan> plan;
     uint64_t f = 0;
-    bool first = true;
-    while (f < B) {
-        uint64_t left = B - f, c = C;
-        if (taper && C > ZK_TAPER_MIN) {
-            c = std::min<uint64_t>(C, std::max<uint64_t>(ZK_TAPER_MIN, (left / 6) & ~(uint64_t)255));
-            if (first) c = std::max<uint64_t>(ZK_TAPER_MIN, c / 2);
-        }
-        first = false;
-        c = std::min(c, left);
-        plan.push_back({f, (uint32_t)c});
-        f += c;
-    }
+    for (uint32_t s : sizes) plan.push_back({f, s}), f += s;
     return plan;
 }
 zk_status ensure_io_buf(zk_ctx* c, size_t bytes);  // api.hip: c->io_buf of at least `bytes`
 bool host_ptr_is_pinned(const void* p);     // api.hip: page-locked (zk_host_alloc / hipHostMalloc / hipHostRegister) host memory?
-zk_status ensure_copy_stream(zk_ctx* c);    // api.hip: c->copy_stream and c->copy_ev
+zk_status ensure_copy_stream(zk_ctx* c);    // api.hip: c->copy_stream and the lanes' copy events
 
 struct Carver {
     uint8_t* base;

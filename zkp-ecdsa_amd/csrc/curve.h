@@ -10,6 +10,15 @@
 #pragma once
 #include "field.h"
 
+// Independent products of a point formula in lock-step (field.h: limbs_mont_mul_n) or one after the other; chosen per
+// translation unit and per curve with -DZK_BATCH_TOM=0/1, -DZK_BATCH_P256=0/1 (csrc/Makefile).
+#ifndef ZK_BATCH_TOM
+#define ZK_BATCH_TOM 1
+#endif
+#ifndef ZK_BATCH_P256
+#define ZK_BATCH_P256 1
+#endif
+
 typedef Fe<ModQ, 8> Fq8;  // P-256 coordinate: < 8q
 typedef Fe<ModQ, 2> Fq2;
 typedef Fe<ModT, 2> Ft2;  // Tom coordinate: < 2t
@@ -38,30 +47,28 @@ ZK_DEV P256Pt p256_from_affine(const P256Aff& a) {
 // weier.ts:176-230 (RCB 2016, Algorithm 4, a = -3): 12M + 2 mult-by-b
 ZK_DEV P256Pt p256_add(const P256Pt& p, const P256Pt& q) {
     const auto b = fe_const<ModQ, 1>(P256_B_M);
-    auto t0 = p.x * q.x;
-    auto t1 = p.y * q.y;
-    auto t2 = p.z * q.z;
-    auto t3 = (p.x + p.y) * (q.x + q.y);
+    Fq2 t0, t1, t2, t3, t4, x3;
+    fe_mul3<ZK_BATCH_P256 != 0>(t0, t1, t2, p.x, q.x, p.y, q.y, p.z, q.z);
+    fe_mul3<ZK_BATCH_P256 != 0>(t3, t4, x3, p.x + p.y, q.x + q.y, p.y + p.z, q.y + q.z, p.x + p.z, q.x + q.z);
     auto t3b = fe_sub2(t3, t0, t1);
-    auto t4 = (p.y + p.z) * (q.y + q.z);
     auto t4b = fe_sub2(t4, t1, t2);
-    auto x3 = (p.x + p.z) * (q.x + q.z);
     auto y3 = fe_sub2(x3, t0, t2);
-    auto z3 = b * t2;
+    Fq2 z3, y3b;
+    fe_mul2<ZK_BATCH_P256 != 0>(z3, y3b, b, t2, b, y3);
     auto x3b = y3 - z3;
     auto x3c = x3b + (x3b + x3b);
     auto z3b = t1 - x3c;
     auto x3d = t1 + x3c;
-    auto y3b = b * y3;
     auto t2b = t2 + t2 + t2;
     auto y3c = fe_sub2(y3b, t2b, t0);
     auto y3d = y3c + (y3c + y3c);
     auto t0b = (t0 + t0 + t0) - t2b;
-    auto t1b = t4b * y3d;
-    auto t2c = t0b * y3d;
-    auto y3e = x3d * z3b + t2c;
-    auto x3e = t3b * x3d - t1b;
-    auto z3c = t4b * z3b + t3b * t0b;
+    Fq2 t1b, t2c, m1, m2, m3, m4;
+    fe_mul3<ZK_BATCH_P256 != 0>(t1b, t2c, m1, t4b, y3d, t0b, y3d, x3d, z3b);
+    fe_mul3<ZK_BATCH_P256 != 0>(m2, m3, m4, t3b, x3d, t4b, z3b, t3b, t0b);
+    auto y3e = m1 + t2c;
+    auto x3e = m2 - t1b;
+    auto z3c = m3 + m4;
     P256Pt r;
     r.x = x3e.template as<8>();
     r.y = y3e.template as<8>();
@@ -71,13 +78,12 @@ ZK_DEV P256Pt p256_add(const P256Pt& p, const P256Pt& q) {
 // Same law with q affine (Z2 = 1): RCB Algorithm 5 shape, 11M + 2 mult-by-b.  q must not be the identity.
 ZK_DEV P256Pt p256_add_mixed(const P256Pt& p, const P256Aff& q) {
     const auto b = fe_const<ModQ, 1>(P256_B_M);
-    auto t0 = p.x * q.x;
-    auto t1 = p.y * q.y;
-    auto t3 = (p.x + p.y) * (q.x + q.y);
+    Fq2 t0, t1, t3, m4, m5, z3;
+    fe_mul3<ZK_BATCH_P256 != 0>(t0, t1, t3, p.x, q.x, p.y, q.y, p.x + p.y, q.x + q.y);
+    fe_mul3<ZK_BATCH_P256 != 0>(m4, m5, z3, q.y, p.z, q.x, p.z, b, p.z);
     auto t3b = fe_sub2(t3, t0, t1);
-    auto t4b = q.y * p.z + p.y;   // (y1+z1)(y2+1) - t1 - z1
-    auto y3 = q.x * p.z + p.x;    // (x1+z1)(x2+1) - t0 - z1
-    auto z3 = b * p.z;
+    auto t4b = m4 + p.y;   // (y1+z1)(y2+1) - t1 - z1
+    auto y3 = m5 + p.x;    // (x1+z1)(x2+1) - t0 - z1
     auto x3b = y3 - z3;
     auto x3c = x3b + (x3b + x3b);
     auto z3b = t1 - x3c;
@@ -87,11 +93,12 @@ ZK_DEV P256Pt p256_add_mixed(const P256Pt& p, const P256Aff& q) {
     auto y3c = fe_sub2(y3b, t2b, t0);
     auto y3d = y3c + (y3c + y3c);
     auto t0b = (t0 + t0 + t0) - t2b;
-    auto t1b = t4b * y3d;
-    auto t2c = t0b * y3d;
-    auto y3e = x3d * z3b + t2c;
-    auto x3e = t3b * x3d - t1b;
-    auto z3c = t4b * z3b + t3b * t0b;
+    Fq2 t1b, t2c, m1, m2, m3, m6;
+    fe_mul3<ZK_BATCH_P256 != 0>(t1b, t2c, m1, t4b, y3d, t0b, y3d, x3d, z3b);
+    fe_mul3<ZK_BATCH_P256 != 0>(m2, m3, m6, t3b, x3d, t4b, z3b, t3b, t0b);
+    auto y3e = m1 + t2c;
+    auto x3e = m2 - t1b;
+    auto z3c = m3 + m6;
     P256Pt r;
     r.x = x3e.template as<8>();
     r.y = y3e.template as<8>();
@@ -101,28 +108,27 @@ ZK_DEV P256Pt p256_add_mixed(const P256Pt& p, const P256Aff& q) {
 // weier.ts:133-175 (RCB Algorithm 6, a = -3): 8M + 3S incl. 2 mult-by-b
 ZK_DEV P256Pt p256_dbl(const P256Pt& p) {
     const auto b = fe_const<ModQ, 1>(P256_B_M);
-    auto t0 = p.x * p.x;
-    auto t1 = p.y * p.y;
-    auto t2 = p.z * p.z;
-    auto t3 = p.x * p.y;
+    Fq2 t0, t1, t2, t3, z3, t0c;
+    fe_mul3<ZK_BATCH_P256 != 0>(t0, t1, t2, p.x, p.x, p.y, p.y, p.z, p.z);
+    fe_mul3<ZK_BATCH_P256 != 0>(t3, z3, t0c, p.x, p.y, p.x, p.z, p.y, p.z);
     auto t3b = t3 + t3;
-    auto z3 = p.x * p.z;
     auto z3b = z3 + z3;
-    auto y3 = b * t2 - z3b;
+    Fq2 bt2, bz3;
+    fe_mul2<ZK_BATCH_P256 != 0>(bt2, bz3, b, t2, b, z3b);
+    auto y3 = bt2 - z3b;
     auto y3b = y3 + (y3 + y3);
     auto x3 = t1 - y3b;
     auto y3c = t1 + y3b;
-    auto y3d = x3 * y3c;
-    auto x3b = x3 * t3b;
     auto t2b = t2 + t2 + t2;
-    auto z3c = fe_sub2(b * z3b, t2b, t0);
+    auto z3c = fe_sub2(bz3, t2b, t0);
     auto z3d = z3c + (z3c + z3c);
     auto t0b = (t0 + t0 + t0) - t2b;
-    auto y3e = y3d + t0b * z3d;
-    auto t0c = p.y * p.z;
     auto t0d = t0c + t0c;
-    auto x3c = x3b - t0d * z3d;
-    auto z3e = t0d * t1;
+    Fq2 y3d, x3b, m1, m2, z3e;
+    fe_mul3<ZK_BATCH_P256 != 0>(y3d, x3b, m1, x3, y3c, x3, t3b, t0b, z3d);
+    fe_mul2<ZK_BATCH_P256 != 0>(m2, z3e, t0d, z3d, t0d, t1);
+    auto y3e = y3d + m1;
+    auto x3c = x3b - m2;
     auto z3f = (z3e + z3e) + (z3e + z3e);
     P256Pt r;
     r.x = x3c.template as<8>();
@@ -179,38 +185,31 @@ ZK_DEV TomPt tom_identity() {  // edwards.ts:46-48
     r.z = fe_one_mont<ModT>().as<2>();
     return r;
 }
-// edwards.ts:161-183 with a = 1 and Z2 = 1, d*T2 precomputed: 8M
+// edwards.ts:161-183 with a = 1 and Z2 = 1, d*T2 precomputed: 8M, as two lock-step groups of four independent products
 template <int KX>
 ZK_DEV TomPt tom_add_niels(const TomPt& p, const TomNielsT<KX>& q) {
-    auto A = p.x * q.x;
-    auto B = p.y * q.y;
-    auto C = p.t * q.dt;
-    auto E = fe_sub2((p.x + p.y) * (q.x + q.y), A, B);
+    Ft2 A, B, C, P4;
+    fe_mul4<ZK_BATCH_TOM != 0>(A, B, C, P4, p.x, q.x, p.y, q.y, p.t, q.dt, p.x + p.y, q.x + q.y);
+    auto E = fe_sub2(P4, A, B);
     auto F = p.z - C;
     auto G = p.z + C;
     auto H = B - A;
     TomPt r;
-    r.x = E * F;
-    r.y = G * H;
-    r.t = E * H;
-    r.z = F * G;
+    fe_mul4<ZK_BATCH_TOM != 0>(r.x, r.y, r.t, r.z, E, F, G, H, E, H, F, G);
     return r;
 }
 // the same addition when the result only has to be ADDED TO NOTHING ELSE (last step of a comb): no T3, 7M
 template <int KX>
 ZK_DEV TomPt tom_add_niels_last(const TomPt& p, const TomNielsT<KX>& q) {
-    auto A = p.x * q.x;
-    auto B = p.y * q.y;
-    auto C = p.t * q.dt;
-    auto E = fe_sub2((p.x + p.y) * (q.x + q.y), A, B);
+    Ft2 A, B, C, P4;
+    fe_mul4<ZK_BATCH_TOM != 0>(A, B, C, P4, p.x, q.x, p.y, q.y, p.t, q.dt, p.x + p.y, q.x + q.y);
+    auto E = fe_sub2(P4, A, B);
     auto F = p.z - C;
     auto G = p.z + C;
     auto H = B - A;
     TomPt r;
-    r.x = E * F;
-    r.y = G * H;
+    fe_mul3<ZK_BATCH_TOM != 0>(r.x, r.y, r.z, E, F, G, H, F, G);
     r.t = fe_zero<ModT>().as<2>();
-    r.z = F * G;
     return r;
 }
 // identity + q: the niels entry as an extended point (X, Y, T = XY, Z = 1), 1M instead of the 8M of an addition
@@ -227,37 +226,30 @@ ZK_DEV TomPt tom_from_niels(const TomNielsT<KX>& q) {
 // general unified addition (both extended): 9M + 1 mult-by-d'
 ZK_DEV TomPt tom_add(const TomPt& p, const TomPt& q) {
     const auto d1 = fe_const<ModT, 1>(TOM_D1_M);
-    auto A = p.x * q.x;
-    auto B = p.y * q.y;
-    auto C = (p.t * q.t) * d1;
-    auto D = p.z * q.z;
-    auto E = fe_sub2((p.x + p.y) * (q.x + q.y), A, B);
+    Ft2 A, B, C0, D, P4;
+    fe_mul4<ZK_BATCH_TOM != 0>(A, B, C0, D, p.x, q.x, p.y, q.y, p.t, q.t, p.z, q.z);
+    Ft2 C;
+    fe_mul2<ZK_BATCH_TOM != 0>(C, P4, C0, d1, p.x + p.y, q.x + q.y);
+    auto E = fe_sub2(P4, A, B);
     auto F = D - C;
     auto G = D + C;
     auto H = B - A;
     TomPt r;
-    r.x = E * F;
-    r.y = G * H;
-    r.t = E * H;
-    r.z = F * G;
+    fe_mul4<ZK_BATCH_TOM != 0>(r.x, r.y, r.t, r.z, E, F, G, H, E, H, F, G);
     return r;
 }
 // edwards.ts:141-160 with a = 1: 4S + 4M
 ZK_DEV TomPt tom_dbl(const TomPt& p) {
-    auto A = p.x * p.x;
-    auto B = p.y * p.y;
-    auto Cz = p.z * p.z;
-    auto C = Cz + Cz;
+    Ft2 A, B, Cz, S;
     auto xy = p.x + p.y;
-    auto E = fe_sub2(xy * xy, A, B);
+    fe_mul4<ZK_BATCH_TOM != 0>(A, B, Cz, S, p.x, p.x, p.y, p.y, p.z, p.z, xy, xy);
+    auto C = Cz + Cz;
+    auto E = fe_sub2(S, A, B);
     auto G = A + B;
     auto F = G - C;
     auto H = A - B;
     TomPt r;
-    r.x = E * F;
-    r.y = G * H;
-    r.t = E * H;
-    r.z = F * G;
+    fe_mul4<ZK_BATCH_TOM != 0>(r.x, r.y, r.t, r.z, E, F, G, H, E, H, F, G);
     return r;
 }
 ZK_DEV TomPt tom_neg(const TomPt& p) {  // edwards.ts:136-140

@@ -136,6 +136,23 @@ ZK_DEV void mod_limbs(uint32_t md[NLIMB]) {
 #ifndef ZK_PIN_LIMBS32
 #define ZK_PIN_LIMBS32 1
 #endif
+// A product computed ALONE: the optimiser starts every column in a fresh accumulator while the previous column is being
+// finished (m_k * M_0, shift) and joins the two with a 64-bit add -- it shortens the dependent chain (a dependent
+// v_mad_u64_u32 issues every 15.6 cycles, an independent one every 4.2) at the price of 16 extra VALU instructions per product,
+// each at the issue cost of a multiply-add.  Where a formula has NP INDEPENDENT products (the four of a Tom-256 addition's first
+// and second half, the pairs of the P-256 laws) limbs_mont_mul_n below runs them in lock-step instead: every product is ONE
+// dependent chain (mad64c hides the sums from the reassociation pass), consecutive instructions belong to different products,
+// so the latency is covered by the other chains and the joins disappear: 212 -> 196 VALU instructions per product.
+#ifndef ZK_SINGLE_CHAIN
+#define ZK_SINGLE_CHAIN 1
+#endif
+ZK_DEV uint64_t mad64c(uint32_t a, uint32_t b, uint64_t c) {
+    uint64_t r = (uint64_t)a * b + c;
+#if ZK_SINGLE_CHAIN && !defined(ZK_HOST_BUILD)
+    asm("" : "+v"(r));   // no instruction: the sum is opaque to the reassociation pass
+#endif
+    return r;
+}
 // Montgomery product, product-scanning with a single 64-bit accumulator (no carry flags).
 template <class M>
 ZK_DEV void limbs_mont_mul(uint32_t out[NLIMB], const uint32_t a[NLIMB], const uint32_t b[NLIMB]) {
@@ -171,6 +188,56 @@ ZK_DEV void limbs_mont_mul(uint32_t out[NLIMB], const uint32_t a[NLIMB], const u
     for (int i = 0; i < NLIMB; i++) asm("" : "+v"(out[i]));
 #endif
 }
+// NP independent Montgomery products in lock-step (see the note above mad64c).  Row-interleaved: column k of every product
+// advances by one multiply-add per row, so a product's own chain is touched every NP-th instruction.
+template <class M, int NP>
+ZK_DEV void limbs_mont_mul_n(uint32_t (&out)[NP][NLIMB], const uint32_t (&a)[NP][NLIMB], const uint32_t (&b)[NP][NLIMB]) {
+    uint64_t acc[NP];
+    uint32_t m[NP][NLIMB], md[NLIMB];
+    mod_limbs<M>(md);
+#pragma unroll
+    for (int p = 0; p < NP; p++) acc[p] = 0;
+#pragma unroll
+    for (int k = 0; k < NLIMB; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++)
+#pragma unroll
+            for (int p = 0; p < NP; p++) acc[p] = mad64c(a[p][i], b[p][k - i], acc[p]);
+#pragma unroll
+        for (int i = 0; i < k; i++)
+#pragma unroll
+            for (int p = 0; p < NP; p++) acc[p] = mad64c(m[p][i], md[k - i], acc[p]);
+#pragma unroll
+        for (int p = 0; p < NP; p++) m[p][k] = ((uint32_t)acc[p] * M::n0) & LIMB_MASK;
+#pragma unroll
+        for (int p = 0; p < NP; p++) acc[p] = mad64c(m[p][k], md[0], acc[p]);
+#pragma unroll
+        for (int p = 0; p < NP; p++) acc[p] >>= LIMB_BITS;
+    }
+#pragma unroll
+    for (int k = NLIMB; k < 2 * NLIMB - 1; k++) {
+#pragma unroll
+        for (int i = k - (NLIMB - 1); i < NLIMB; i++)
+#pragma unroll
+            for (int p = 0; p < NP; p++) acc[p] = mad64c(a[p][i], b[p][k - i], acc[p]);
+#pragma unroll
+        for (int i = k - (NLIMB - 1); i < NLIMB; i++)
+#pragma unroll
+            for (int p = 0; p < NP; p++) acc[p] = mad64c(m[p][i], md[k - i], acc[p]);
+#pragma unroll
+        for (int p = 0; p < NP; p++) out[p][k - NLIMB] = (uint32_t)acc[p] & LIMB_MASK;
+#pragma unroll
+        for (int p = 0; p < NP; p++) acc[p] >>= LIMB_BITS;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; p++) out[p][NLIMB - 1] = (uint32_t)acc[p];
+#if ZK_PIN_LIMBS32
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+#pragma unroll
+        for (int i = 0; i < NLIMB; i++) asm("" : "+v"(out[p][i]));
+#endif
+}
 template <class M, int Ka, int Kb>
 ZK_DEV Fe<M, 2> operator*(const Fe<M, Ka>& a, const Fe<M, Kb>& b) {
     static_assert((long)Ka * Kb <= M::kmax, "Montgomery input magnitudes too large");
@@ -184,6 +251,61 @@ ZK_DEV Fe<M, 2> operator*(const Fe<M, Ka>& a, const Fe<M, Kb>& b) {
 template <class M, int Ka>
 ZK_DEV Fe<M, 2> fe_sqr(const Fe<M, Ka>& a) {
     return a * a;
+}
+// r_i = a_i * b_i for independent products: BATCH = true computes them in lock-step (limbs_mont_mul_n: fewer instructions, more
+// live registers), false one after the other.  A translation unit picks per curve (ZK_BATCH_TOM / ZK_BATCH_P256, curve.h): the
+// register-hungry verifier kernels keep the sequential form (k_v_p256_straus would spill 1.2 KB per lane otherwise).
+template <bool BATCH, class M, int K0a, int K0b, int K1a, int K1b>
+ZK_DEV void fe_mul2(Fe<M, 2>& r0, Fe<M, 2>& r1, const Fe<M, K0a>& a0, const Fe<M, K0b>& b0, const Fe<M, K1a>& a1, const Fe<M, K1b>& b1) {
+    static_assert((long)K0a * K0b <= M::kmax && (long)K1a * K1b <= M::kmax, "Montgomery input magnitudes too large");
+#if !defined(ZK_HOST_BUILD)
+    if constexpr (BATCH) {
+    uint32_t a[2][NLIMB], b[2][NLIMB], o[2][NLIMB];
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) a[0][i] = a0.l[i], b[0][i] = b0.l[i], a[1][i] = a1.l[i], b[1][i] = b1.l[i];
+    limbs_mont_mul_n<M, 2>(o, a, b);
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) r0.l[i] = o[0][i], r1.l[i] = o[1][i];
+    return;
+    }
+#endif
+    r0 = a0 * b0, r1 = a1 * b1;
+}
+template <bool BATCH, class M, int K0a, int K0b, int K1a, int K1b, int K2a, int K2b>
+ZK_DEV void fe_mul3(Fe<M, 2>& r0, Fe<M, 2>& r1, Fe<M, 2>& r2, const Fe<M, K0a>& a0, const Fe<M, K0b>& b0, const Fe<M, K1a>& a1, const Fe<M, K1b>& b1,
+                    const Fe<M, K2a>& a2, const Fe<M, K2b>& b2) {
+    static_assert((long)K0a * K0b <= M::kmax && (long)K1a * K1b <= M::kmax && (long)K2a * K2b <= M::kmax, "Montgomery input magnitudes too large");
+#if !defined(ZK_HOST_BUILD)
+    if constexpr (BATCH) {
+    uint32_t a[3][NLIMB], b[3][NLIMB], o[3][NLIMB];
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) a[0][i] = a0.l[i], b[0][i] = b0.l[i], a[1][i] = a1.l[i], b[1][i] = b1.l[i], a[2][i] = a2.l[i], b[2][i] = b2.l[i];
+    limbs_mont_mul_n<M, 3>(o, a, b);
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) r0.l[i] = o[0][i], r1.l[i] = o[1][i], r2.l[i] = o[2][i];
+    return;
+    }
+#endif
+    r0 = a0 * b0, r1 = a1 * b1, r2 = a2 * b2;
+}
+template <bool BATCH, class M, int K0a, int K0b, int K1a, int K1b, int K2a, int K2b, int K3a, int K3b>
+ZK_DEV void fe_mul4(Fe<M, 2>& r0, Fe<M, 2>& r1, Fe<M, 2>& r2, Fe<M, 2>& r3, const Fe<M, K0a>& a0, const Fe<M, K0b>& b0, const Fe<M, K1a>& a1,
+                    const Fe<M, K1b>& b1, const Fe<M, K2a>& a2, const Fe<M, K2b>& b2, const Fe<M, K3a>& a3, const Fe<M, K3b>& b3) {
+    static_assert((long)K0a * K0b <= M::kmax && (long)K1a * K1b <= M::kmax && (long)K2a * K2b <= M::kmax && (long)K3a * K3b <= M::kmax,
+                  "Montgomery input magnitudes too large");
+#if !defined(ZK_HOST_BUILD)
+    if constexpr (BATCH) {
+    uint32_t a[4][NLIMB], b[4][NLIMB], o[4][NLIMB];
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++)
+        a[0][i] = a0.l[i], b[0][i] = b0.l[i], a[1][i] = a1.l[i], b[1][i] = b1.l[i], a[2][i] = a2.l[i], b[2][i] = b2.l[i], a[3][i] = a3.l[i], b[3][i] = b3.l[i];
+    limbs_mont_mul_n<M, 4>(o, a, b);
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) r0.l[i] = o[0][i], r1.l[i] = o[1][i], r2.l[i] = o[2][i], r3.l[i] = o[3][i];
+    return;
+    }
+#endif
+    r0 = a0 * b0, r1 = a1 * b1, r2 = a2 * b2, r3 = a3 * b3;
 }
 template <class M, int K = 1>
 ZK_DEV Fe<M, K> fe_const(const uint32_t c[NLIMB]) {
