@@ -161,7 +161,12 @@ zk_status zk_prove_batch_device(zk_ctx *ctx, uint64_t B, const void *d_msg_hash,
  * the proofs and independent across proofs.  NULL: the engine draws fresh OS randomness for the call (what the
  * reference does with crypto.getRandomValues); pass seeds only to reproduce a run.
  * proofs must be packed back to back (proof_off[0] = 0, 4-byte aligned).  Host pointers; `proofs` from zk_host_alloc is
- * read by overlapped DMA. */
+ * read by overlapped DMA.
+ * Non-canonical encodings: a P-256 coordinate in [p, 2^256) is accepted where deserializePoint accepts it (the curve equation is
+ * checked mod p, src/curves/weier.ts:74-89) and enters the Fiat-Shamir hashes REDUCED, as toBytes -> toAffine does
+ * (src/curves/weier.ts:231-255).  Tom-256 coordinates must be canonical (< the field prime, zero padding bytes): ZKA1 is this
+ * engine's format and is stricter here than the reference's JSON reader, which reduces out-of-range values silently
+ * (src/curves/edwards.ts:204-209); such a proof gets ZK_E_BAD_ENCODING. */
 zk_status zk_verify_batch(zk_ctx *ctx, uint64_t B, const uint8_t *msg_hash /*Bx32*/, const uint8_t *proofs,
                           const uint64_t *proof_off /*B+1*/, const uint8_t *verifier_seeds /*Bx32 or NULL*/,
                           uint8_t *ok /*B*/, int32_t *per_proof_status /*B*/);

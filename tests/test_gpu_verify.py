@@ -172,6 +172,41 @@ def test_batched_and_per_proof_verification_agree():
     eng.close()
 
 
+def test_one_forged_proof_only_sends_its_group_to_the_per_proof_sums():
+    """The chunk-wide check sums MSM_G = 8 contiguous groups of proofs separately: one forged proof must cost about an eighth
+    of the per-proof work of its chunk (not all of it), and the verdicts must not change.  Forgeries at a group boundary, in
+    the first and in the last group exercise the range views of the per-proof path."""
+    import zkp_ecdsa_amd as Z
+    B, nkeys = 2048, 4096
+    eng = Z.Engine(0)
+    params = eng.synth_params(77)
+    eng.set_params(*params, 80)
+    ring, msg, sig, pk, which, seeds = eng.synth_workload(77, nkeys, B)
+    eng.set_ring(ring, nkeys)
+    eng.set_chunk(B)
+    proofs, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert st == [0] * B
+    vs = _vseeds(B)
+    assert eng.verify_batch(msg, proofs, vseeds=vs) == ([1] * B, [0] * B)
+    assert 'v_straus_tom' not in eng.last_timing()[1]
+    eng.set_batch_verify(0)
+    assert eng.verify_batch(msg, proofs, vseeds=vs) == ([1] * B, [0] * B)
+    full = eng.last_timing()[1]['v_straus_tom']
+    eng.set_batch_verify(256)
+    for bad in ([700], [0], [B - 1], [255, 256], [3, 1500]):    # groups of 256 proofs
+        forged = list(proofs)
+        for b in bad:
+            f = bytearray(proofs[b])
+            f[-9] ^= 2                                   # zd
+            forged[b] = bytes(f)
+        ok, vst = eng.verify_batch(msg, forged, vseeds=vs)
+        assert [b for b in range(B) if not ok[b]] == bad and vst == [0] * B
+        part = eng.last_timing()[1]['v_straus_tom']
+        ngroups = len({b // 256 for b in bad})
+        assert part < full * (ngroups / 8 + 0.12), (bad, part, full)
+    eng.close()
+
+
 def test_batched_check_with_every_kind_of_bad_proof_in_the_chunk():
     """A chunk mixing honest proofs with malformed, forged, partially tampered and wrong-statement ones: the chunk-wide sum
     (forced on: min_chunk = 1) must end in exactly the verdicts and statuses of the per-proof sums, for several verifier

@@ -96,6 +96,7 @@ extern "C" void zk_ctx_destroy(zk_ctx* c) {
     for (int l = 0; l < ZK_MAX_LANES; l++) {
         hipFree(c->pl[l].arena), hipFree(c->pl[l].d_totals), hipFree(c->vl[l].arena);
         if (c->pl[l].copy_ev) hipEventDestroy(c->pl[l].copy_ev);
+        if (c->pl[l].copy_stream) hipStreamDestroy(c->pl[l].copy_stream);
         if (l && c->pl[l].stream) hipStreamDestroy(c->pl[l].stream);
     }
     if (c->stream) hipStreamDestroy(c->stream);
@@ -360,8 +361,10 @@ zk_status ensure_in_buf(zk_ctx* c, size_t bytes) {
 }
 zk_status ensure_copy_stream(zk_ctx* c) {
     if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    for (auto& L : c->pl)
+    for (auto& L : c->pl) {
         if (!L.copy_ev) HIPCHK(c, hipEventCreateWithFlags(&L.copy_ev, hipEventDisableTiming));
+        if (!L.copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&L.copy_stream, hipStreamNonBlocking));
+    }
     return ZK_OK;
 }
 
@@ -588,8 +591,8 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
                 if (b1 > b0) {
                     hipEvent_t ev = c->pl[pd.lane].copy_ev;
                     HIPCHK(c, hipEventRecord(ev, s));
-                    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, ev, 0));
-                    HIPCHK(c, hipMemcpyAsync(host_sink + cursor + b0, out + b0, b1 - b0, hipMemcpyDeviceToHost, c->copy_stream));
+                    HIPCHK(c, hipStreamWaitEvent(c->pl[pd.lane].copy_stream, ev, 0));
+                    HIPCHK(c, hipMemcpyAsync(host_sink + cursor + b0, out + b0, b1 - b0, hipMemcpyDeviceToHost, c->pl[pd.lane].copy_stream));
                 }
             }
         }
@@ -612,10 +615,11 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
         if (!zs) zs = stage2(pend[k % NL]);
     }
     hipError_t e_sync = sync_lanes();   // nothing of this call may still be running (or writing into the caller's buffer) when it returns
-    if (host_sink) {
-        hipError_t e2 = hipStreamSynchronize(c->copy_stream);
-        if (e_sync == hipSuccess) e_sync = e2;
-    }
+    if (host_sink)
+        for (uint32_t l = 0; l < NL; l++) {
+            hipError_t e2 = hipStreamSynchronize(c->pl[l].copy_stream);
+            if (e_sync == hipSuccess) e_sync = e2;
+        }
     if (zs) return zs;
     HIPCHK(c, e_sync);
     HIPCHK(c, hipGetLastError());

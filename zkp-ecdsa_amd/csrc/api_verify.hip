@@ -27,7 +27,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
     auto soa4 = [&](size_t cnt) { return Soa4{k.soa(cnt), k.soa(cnt), k.soa(cnt), k.soa(cnt)}; };
     size_t nq = (n + 1) / 2;
     V.slot_terms = terms(ns * V_SLOT_TERMS);
-    V.slot_perm = (uint32_t*)k.take(4 * ns), V.slot_cnt = (uint32_t*)k.take(64);
+    V.slot_class = (uint8_t*)k.take(ns), V.slot_perm = (uint32_t*)k.take(4 * ns), V.slot_cnt = (uint32_t*)k.take(8 * (MSM_G + 1));
     V.gk_terms = terms((size_t)C * nq * 8);
     V.misc_terms = terms((size_t)C * 3);
     V.slot_acc = soa4(ns), V.gk_acc = soa4((size_t)C * nq), V.misc_acc = soa4((size_t)C * 3);
@@ -43,15 +43,15 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
         M.aos = (uint32_t*)k.take(cap * 128);
         M.keys_all = (uint32_t*)k.take(cap * 4 * 16), M.vals_in = (uint32_t*)k.take(cap * 4), M.keys_out = (uint32_t*)k.take(cap * 4);
         M.vals_out = (uint32_t*)k.take(cap * 4 * 16);
-        M.start = (uint32_t*)k.take(4 * 16 * 65536), M.end = (uint32_t*)k.take(4 * 16 * 65536);
+        M.start = (uint32_t*)k.take((size_t)4 * 16 * 65536 * MSM_G), M.end = (uint32_t*)k.take((size_t)4 * 16 * 65536 * MSM_G);
         M.counters = (uint32_t*)k.take(256), M.flag = (uint32_t*)k.take(256), M.big_list = (uint32_t*)k.take(4 * 4096), M.big_part = (uint32_t*)k.take((size_t)4096 * 128 * 144);
-        M.buckets = (uint32_t*)k.take((size_t)16 * 65536 * 144);
-        M.F1 = (uint32_t*)k.take((size_t)16 * 1024 * 144), M.G1 = (uint32_t*)k.take((size_t)16 * 1024 * 144);
-        M.F2 = (uint32_t*)k.take(16 * 32 * 144), M.G2 = (uint32_t*)k.take(16 * 32 * 144), M.H2 = (uint32_t*)k.take(16 * 32 * 144);
-        M.Tw = (uint32_t*)k.take(16 * 144);
+        M.buckets = (uint32_t*)k.take((size_t)16 * 65536 * 144 * MSM_G);
+        M.F1 = (uint32_t*)k.take((size_t)16 * 1024 * 144 * MSM_G), M.G1 = (uint32_t*)k.take((size_t)16 * 1024 * 144 * MSM_G);
+        M.F2 = (uint32_t*)k.take(16 * 32 * 144 * MSM_G), M.G2 = (uint32_t*)k.take(16 * 32 * 144 * MSM_G), M.H2 = (uint32_t*)k.take(16 * 32 * 144 * MSM_G);
+        M.Tw = (uint32_t*)k.take(16 * 144 * MSM_G);
         M.sort_tmp_bytes = msm_workspace_bytes((uint32_t)cap);
         M.sort_tmp = k.take(M.sort_tmp_bytes);
-        M.one = k.list(1);
+        M.one = k.list(MSM_G);
     }
     uint32_t T = n >= GK_ETAB_MINN && n <= GK_ETAB_MAXN ? 8 : std::min<uint32_t>(n, 13);  // block path: one value per 256 keys
     res = k.soa((size_t)C * (N >> T));
@@ -187,37 +187,71 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
         }
         return ZK_OK;
     };
+    // Per-proof sums (windowed Straus + the two fixed-base commitments) of proofs [p0, p1) of a chunk: the unchanged kernels on
+    // views of the term lists / accumulators that start at the range's first slot, gk group and proof.
+    auto per_proof_range = [&](hipStream_t s, const Workspace& W, const VWork& V, uint32_t p0, uint32_t p1, uint32_t range_no) {
+        const uint32_t np = p1 - p0;
+        auto terms_at = [](VTerms t, size_t o) {
+            t.nx.p += o, t.ny.p += o, t.ndt.p += o, t.sc.p += o, t.tab += o * 8 * 36, t.dig += o;
+            return t;
+        };
+        auto acc_at = [](Soa4 a, size_t o) {
+            a.x.p += o, a.y.p += o, a.z.p += o, a.t.p += o;
+            return a;
+        };
+        {
+            Scope t(c, "v_straus_tom", s);
+            const size_t so = (size_t)p0 * VK;
+            uint32_t* perm = V.slot_perm + so;
+            uint32_t* pc = V.slot_cnt + 2 * range_no;
+            launch_v_slot_perm(s, V.slot_class + so, np * VK, perm, pc);
+            launch_v_straus(s, terms_at(V.slot_terms, so), np * VK, V.C * VK, 10, 26, acc_at(V.slot_acc, so), perm, pc);
+            launch_v_straus(s, terms_at(V.gk_terms, (size_t)p0 * nq), np * nq, V.C * nq, 4, 4, acc_at(V.gk_acc, (size_t)p0 * nq), nullptr, nullptr);
+            for (uint32_t k = 0; k < 3; k++)
+                launch_v_straus(s, terms_at(V.misc_terms, (size_t)k * V.C + p0), np, 3 * V.C, 1, 0, acc_at(V.misc_acc, (size_t)k * V.C + p0), nullptr, nullptr);
+        }
+        {
+            Scope t(c, "v_tom_fixed", s);
+            TomList lc = W.lc;
+            const size_t o = (size_t)p0 * 4 * W.n;
+            for (Soa* a : {&lc.v, &lc.r, &lc.proj.x, &lc.proj.y, &lc.proj.z, &lc.ax, &lc.ay}) a->p += o;
+            launch_tom_commit(s, P, lc, np * 2, 2, 4 * W.n);
+        }
+    };
     auto stage2 = [&](uint64_t first, uint32_t cnt, uint32_t chunk_no) -> zk_status {
         const uint32_t lane = chunk_no % NL;
         Workspace& W = c->pl[lane].W;
         VWork& V = c->vl[lane].V;
+        const MsmBuf& M = c->vl[lane].M;
         hipStream_t s = c->pl[lane].stream;
-        // Tom-256 relations: one bucket-method sum over the whole chunk; only if that is not the identity (some proof is
-        // bad) the per-proof windowed sums run to find out which
-        uint32_t all_ok = 0;
+        // Tom-256 relations: one bucket-method sum per group of the chunk's proofs (MSM_G groups, one pass); the per-proof
+        // windowed sums only run for the groups whose total is not the identity -- some proof of theirs is bad -- to tell which
+        uint32_t flags[MSM_G], gsz = cnt;
         if (c->verify_batch_min && cnt >= c->verify_batch_min) {
             Scope t(c, "v_msm_tom", s);
-            hipError_t e = run_msm(s, P, W, V, cnt, nq, c->vl[lane].M, &all_ok);
+            hipError_t e = run_msm(s, P, W, V, cnt, nq, M, flags, &gsz);
             if (e != hipSuccess) {
                 c->err = std::string("batched verification failed: ") + hipGetErrorString(e);
                 return ZK_E_DEVICE;
             }
+        } else {
+            for (auto& f : flags) f = 0;
+            HIPCHK(c, hipMemsetAsync(M.flag, 0, 4 * MSM_G, s));   // every proof goes through the per-proof sums
         }
-        if (!all_ok) {
-            {
-                Scope t(c, "v_straus_tom", s);
-                launch_v_straus(s, V.slot_terms, V.C * VK * V_SLOT_TERMS, cnt * VK, V.C * VK, 10, 26, V.slot_acc, V.slot_perm, V.slot_cnt);
-                launch_v_straus(s, V.gk_terms, V.C * nq * 8, cnt * nq, V.C * nq, 4, 4, V.gk_acc, nullptr, nullptr);
-                launch_v_straus(s, V.misc_terms, 3 * V.C, 3 * V.C, 3 * V.C, 1, 0, V.misc_acc, nullptr, nullptr);
+        uint32_t ranges = 0;
+        for (uint32_t g = 0; g < MSM_G && (uint64_t)g * gsz < cnt;) {   // maximal runs of groups that failed
+            if (flags[g]) {
+                g++;
+                continue;
             }
-            {
-                Scope t(c, "v_tom_fixed", s);
-                launch_tom_commit(s, P, W.lc, cnt * 2, 2, 4 * W.n);
-            }
+            uint32_t g1 = g;
+            while (g1 < MSM_G && (uint64_t)g1 * gsz < cnt && !flags[g1]) g1++;
+            per_proof_range(s, W, V, g * gsz, std::min<uint32_t>(cnt, g1 * gsz), ranges++);
+            g = g1;
         }
         {
             Scope t(c, "v_final", s);
-            launch_v_final(s, P, W, V, cnt, d_ok, d_status, first, all_ok != 0);
+            launch_v_final(s, P, W, V, cnt, d_ok, d_status, first, M.flag, gsz);
         }
         return ZK_OK;
     };

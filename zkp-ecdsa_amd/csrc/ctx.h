@@ -45,7 +45,9 @@ struct zk_ctx {
         void* arena = nullptr;
         size_t arena_bytes = 0;
         bool ready = false;
-        hipEvent_t copy_ev = nullptr;   // host-buffer entry points: "this lane's bytes are final" for the copy stream
+        hipEvent_t copy_ev = nullptr;   // host-buffer entry points: "this lane's bytes are final" for the lane's copy stream
+        hipStream_t copy_stream = nullptr;   // D2H of this lane's finished slices: one stream per lane, so a lane whose slices
+                                             // are ready never queues behind the unfinished slices of another (FIFO per stream)
     } pl[ZK_MAX_LANES];
     uint32_t lanes = 2;
     // verifier workspace

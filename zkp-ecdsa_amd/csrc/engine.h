@@ -170,8 +170,9 @@ struct VWork {
     Soa gk_total;         // [C]
     uint32_t* gk_csub;    // [C][256][9] coefficients of the 8 low index bits (k_gk.hip, used when the ring has table E)
     VTerms slot_terms, gk_terms, misc_terms;
-    uint32_t* slot_perm;  // [C*VK] slot ids, zero-bit slots (36 live terms) from the front, the others (2 live terms) from the back
-    uint32_t* slot_cnt;   // [2] how many of each
+    uint8_t* slot_class;  // [C*VK] 1 = zero-bit slot of a good proof (36 live terms), 0 = only the two 128-bit terms 34, 35
+    uint32_t* slot_perm;  // [C*VK] per re-checked proof range: local slot ids, class-1 slots from the front, the others from the back
+    uint32_t* slot_cnt;   // [2 * (MSM_G + 1)] how many of each, per range
     Soa4 slot_acc, gk_acc, misc_acc;
     Soa sSg, sSh, sSkx, sSky, sSR, sSH, sSL;   // per slot partial sums
     Soa pSR, pSH, pSL;                         // per proof (mod n)
@@ -190,10 +191,12 @@ void launch_v_derived(hipStream_t s, const Workspace& W, const VWork& V, uint32_
 void launch_v_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, const uint32_t* etab, uint32_t count, uint32_t N, const uint8_t* proofs, const uint64_t* off, uint64_t first, const Soa& res, const Soa& res2);
 void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first);
-void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t nterms, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out,
+void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out,
                      const uint32_t* perm, const uint32_t* cnt);
+void launch_v_slot_perm(hipStream_t s, const uint8_t* slot_class, uint32_t nslots, uint32_t* perm, uint32_t* cnt);
 void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count);
-void launch_v_final(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first, bool tom_all_ok);
+void launch_v_final(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first,
+                    const uint32_t* grp_ok, uint32_t gsz);
 
 // chunk inputs (device pointers, already offset to the chunk's first proof)
 struct ChunkIn {
@@ -204,6 +207,9 @@ struct ChunkIn {
     uint32_t count;   // proofs in this chunk
 };
 
+// The batched Tom-256 check sums the relations of MSM_G contiguous groups of a chunk's proofs separately (same pass: the group
+// index rides on top of the 16-bit digit in the sort key): a forged proof only sends ITS group to the per-proof sums.
+#define MSM_G 8
 // buffers of the batched Tom-256 check (k_msm.hip), one set per verifier lane
 struct MsmBuf {
     uint32_t cap;          // term ids
@@ -211,20 +217,22 @@ struct MsmBuf {
     uint32_t* keys_all;    // [16][cap] digit of every live term in every window
     uint32_t *vals_in, *keys_out;             // live term ids; sorted keys of the window being processed
     uint32_t* vals_out;    // [16][cap] term ids sorted by digit
-    uint32_t *start, *end; // [16][65536] segment of every digit value
+    uint32_t *start, *end; // [16][MSM_G * 65536] segment of every (group, digit) value
     uint32_t *counters, *flag;   // counters[0..15]: pairs per window, counters[32]: oversized buckets
     uint32_t* big_list;    // [4096] window * 65536 + digit of the oversized buckets
     uint32_t* big_part;    // [4096][128][36] partial sums of their slices
-    uint32_t* buckets;     // [16][65536][36]
+    uint32_t* buckets;     // [16][MSM_G * 65536][36]
     uint32_t *F1, *G1, *F2, *G2, *H2, *Tw;
     void* sort_tmp;
     size_t sort_tmp_bytes;
-    TomList one;           // the chunk's single fixed-base commitment
+    TomList one;           // [MSM_G] the groups' fixed-base commitments
 };
 // ------------------------------------------------------------------ launch wrappers (one per kernel family)
 // k_msm.hip
 size_t msm_workspace_bytes(uint32_t cap);
-hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t* host_flag);
+// host_flags[g] = 1: the Tom-256 total of group g (proofs [g * gsz, (g + 1) * gsz) of the chunk) is the identity; M.flag holds the same on the device
+hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t* host_flags /*[MSM_G]*/,
+                   uint32_t* gsz);
 // group size of one k_gk_finish pass over `ntiles` polynomials of T+1 coefficients: <= 64, dynamic LDS below 60 KB
 static inline size_t gk_finish_lds(uint32_t T, uint32_t g) { return sizeof(uint32_t) * 9 * ((size_t)g * (T + 1) + (size_t)(g / 2) * (T + 2)); }
 static inline uint32_t gk_finish_gsz(uint32_t T, uint32_t ntiles) {

@@ -28,6 +28,10 @@
 #define MSM_C 16
 #define MSM_NB 65536u
 #define MSM_NW 16
+#define MSM_GBITS 3
+static_assert((1 << MSM_GBITS) == MSM_G, "MSM_G");
+#define MSM_NBG (MSM_G * MSM_NB)     // (group, digit) values per window
+#define MSM_NWG (MSM_NW * MSM_G)     // (window, group) pairs: the reductions treat each as a window of its own
 #define MSM_ENTRY_WORDS 32
 
 // term id space: [0, n0) slot_terms, [n0, n0 + n1) gk_terms, [n0 + n1, n0 + n1 + n2) misc_terms
@@ -35,25 +39,30 @@ struct MsmDims {
     uint32_t n0, n1, n2;        // capacities (ids)
     uint32_t g0, g1, g2;        // group strides (terms k of group g sit at k * stride + g)
     uint32_t l0, l1, l2;        // live groups of this chunk
+    uint32_t nq, gsz;           // gk groups per proof; proofs per MSM group
 };
-ZK_DEV const VTerms& msm_list(const VWork& V, const MsmDims& D, uint32_t id, uint32_t& idx, bool& live) {
+ZK_DEV const VTerms& msm_list(const VWork& V, const MsmDims& D, uint32_t id, uint32_t& idx, bool& live, uint32_t& proof) {
     if (id < D.n0) {
-        idx = id, live = (id % D.g0) < D.l0;
+        uint32_t g = id % D.g0;
+        idx = id, live = g < D.l0, proof = g / VK;
         return V.slot_terms;
     }
     if (id < D.n0 + D.n1) {
-        idx = id - D.n0, live = (idx % D.g1) < D.l1;
+        idx = id - D.n0;
+        uint32_t g = idx % D.g1;
+        live = g < D.l1, proof = g / D.nq;
         return V.gk_terms;
     }
-    idx = id - D.n0 - D.n1, live = (idx % D.g2) < D.l2;
+    idx = id - D.n0 - D.n1;
+    proof = idx % D.g2, live = proof < D.l2;
     return V.misc_terms;
 }
 __global__ void __launch_bounds__(256) k_msm_pack(VWork V, MsmDims D, uint32_t* aos) {
     uint32_t id = gtid();
     if (id >= D.n0 + D.n1 + D.n2) return;
-    uint32_t idx;
+    uint32_t idx, proof;
     bool live;
-    const VTerms& L = msm_list(V, D, id, idx, live);
+    const VTerms& L = msm_list(V, D, id, idx, live, proof);
     if (!live || fe_is_zero(soa_ld<ModQ, 1>(L.sc, idx))) return;
     Ft2 x = soa_ld<ModT, 2>(L.nx, idx), y = soa_ld<ModT, 2>(L.ny, idx), dt = soa_ld<ModT, 2>(L.ndt, idx);
     uint32_t w[28];
@@ -64,17 +73,17 @@ __global__ void __launch_bounds__(256) k_msm_pack(VWork V, MsmDims D, uint32_t* 
 #pragma unroll
     for (int i = 0; i < 7; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
-// Compaction of the live terms (scalar != 0): ids[pos] = term id and, for every window, keys[w * cap + pos] = its 16-bit
-// digit (0 included: digit 0 is simply a bucket nobody sums).  One atomic per workgroup.
+// Compaction of the live terms (scalar != 0): ids[pos] = term id and, for every window, keys[w * cap + pos] = group << 16 | its
+// 16-bit digit (0 included: digit 0 is simply a bucket nobody sums).  One atomic per workgroup.
 __global__ void __launch_bounds__(256) k_msm_compact(VWork V, MsmDims D, uint32_t cap, uint32_t* keys, uint32_t* ids, uint32_t* counter) {
     __shared__ uint32_t wave_cnt[4], block_base;
     uint32_t id = gtid();
-    uint32_t w8[8];
+    uint32_t w8[8], proof = 0;
     bool act = false;
     if (id < D.n0 + D.n1 + D.n2) {
         uint32_t idx;
         bool live;
-        const VTerms& L = msm_list(V, D, id, idx, live);
+        const VTerms& L = msm_list(V, D, id, idx, live, proof);
         if (live) {
             Fe<ModQ, 1> sc = soa_ld<ModQ, 1>(L.sc, idx);
             act = !fe_is_zero(sc);
@@ -95,8 +104,9 @@ __global__ void __launch_bounds__(256) k_msm_compact(VWork V, MsmDims D, uint32_
     uint32_t pos = block_base + below;
     for (uint32_t k = 0; k < wv; k++) pos += wave_cnt[k];
     ids[pos] = id;
+    const uint32_t grp = (proof / D.gsz) << MSM_C;
 #pragma unroll
-    for (int w = 0; w < MSM_NW; w++) keys[(size_t)w * cap + pos] = (w8[w >> 1] >> (16 * (w & 1))) & 0xffffu;
+    for (int w = 0; w < MSM_NW; w++) keys[(size_t)w * cap + pos] = grp | ((w8[w >> 1] >> (16 * (w & 1))) & 0xffffu);
 }
 __global__ void __launch_bounds__(256) k_msm_bounds(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* start, uint32_t* end) {
     uint32_t i = gtid();
@@ -136,14 +146,15 @@ ZK_DEV TomPt msm_ldp(const uint32_t* p) {
 __global__ void __launch_bounds__(256) k_msm_bucket(const uint32_t* __restrict__ aos, const uint32_t* __restrict__ vals, uint32_t cap,
                                                     const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t* buckets,
                                                     uint32_t* big_cnt, uint32_t* big_list, uint32_t big) {
-    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
-    uint32_t s = start[w * MSM_NB + d], e = end[w * MSM_NB + d];
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;   // d = group << 16 | digit
+    uint32_t s = start[w * MSM_NBG + d], e = end[w * MSM_NBG + d];
     TomPt acc = tom_identity();
-    if (d != 0 && e - s > big) {
+    const bool nz = (d & (MSM_NB - 1)) != 0;
+    if (nz && e - s > big) {
         uint32_t pos = atomicAdd(big_cnt, 1u);
-        if (pos < MSM_BIG_MAX) big_list[pos] = w * MSM_NB + d, e = s;  // handled by k_msm_bucket_big (beyond the list: here after all)
+        if (pos < MSM_BIG_MAX) big_list[pos] = w * MSM_NBG + d, e = s;  // handled by k_msm_bucket_big (beyond the list: here after all)
     }
-    if (d != 0 && e > s) {
+    if (nz && e > s) {
         const uint32_t* v = vals + (size_t)w * cap;
         TomNiels nx = msm_ld(aos + (size_t)v[s] * MSM_ENTRY_WORDS);
         acc = tom_from_niels(nx);
@@ -153,7 +164,7 @@ __global__ void __launch_bounds__(256) k_msm_bucket(const uint32_t* __restrict__
             acc = tom_add_niels(acc, nx);
         }
     }
-    msm_st(buckets + ((size_t)w * MSM_NB + d) * 36, acc);
+    msm_st(buckets + ((size_t)w * MSM_NBG + d) * 36, acc);
 }
 // Oversized buckets (sums of a few 208-bit products put ~6 terms per proof into digits 1..3 of window 13): block (j, b)
 // sums slice j (MSM_SLICE terms, strided over the grid's x extent) of big bucket b into part[b * MSM_NSLICE + j];
@@ -177,7 +188,7 @@ __global__ void __launch_bounds__(256) k_msm_bucket_big(const uint32_t* __restri
     __shared__ uint32_t sh[128 * 36];
     uint32_t n = *big_cnt < MSM_BIG_MAX ? *big_cnt : MSM_BIG_MAX;
     for (uint32_t b = blockIdx.y; b < n; b += gridDim.y) {
-        uint32_t wd = big_list[b], w = wd / MSM_NB;
+        uint32_t wd = big_list[b], w = wd / MSM_NBG;
         uint32_t s = start[wd], e = end[wd], t = threadIdx.x;
         const uint32_t* v = vals + (size_t)w * cap;
         TomPt acc = tom_identity();
@@ -206,7 +217,7 @@ __global__ void __launch_bounds__(256) k_msm_bucket_big2(const uint32_t* __restr
 }
 // level 1: 64 buckets per thread.  F1 = sum_j j * B_{64 r + j}, G1 = sum_j B_{64 r + j}
 __global__ void __launch_bounds__(256) k_msm_reduce1(const uint32_t* __restrict__ buckets, uint32_t* F1, uint32_t* G1) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;  // r < 1024
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;  // r < 1024; w = window * MSM_G + group
     const uint32_t* b = buckets + ((size_t)w * MSM_NB + 64 * r) * 36;
     TomPt run = tom_identity(), acc = tom_identity();
 #pragma unroll 1
@@ -221,7 +232,7 @@ __global__ void __launch_bounds__(256) k_msm_reduce1(const uint32_t* __restrict_
 // level 2: 32 level-1 ranges per thread.  F2 = sum_j j * G1_{32 s + j}, G2 = sum_j G1_{32 s + j}, H2 = sum_j F1_{32 s + j}
 __global__ void __launch_bounds__(64) k_msm_reduce2(const uint32_t* __restrict__ F1, const uint32_t* __restrict__ G1, uint32_t* F2, uint32_t* G2, uint32_t* H2) {
     uint32_t t = gtid();
-    if (t >= MSM_NW * 32) return;
+    if (t >= MSM_NWG * 32) return;
     uint32_t w = t / 32, s = t % 32;
     const uint32_t* g = G1 + ((size_t)w * 1024 + 32 * s) * 36;
     const uint32_t* f = F1 + ((size_t)w * 1024 + 32 * s) * 36;
@@ -238,8 +249,8 @@ __global__ void __launch_bounds__(64) k_msm_reduce2(const uint32_t* __restrict__
 }
 // level 3: one thread per window.  sum_d d B_d = H + 64 (GF2 + 32 FG2);  result times 2^(16 w)
 __global__ void __launch_bounds__(64) k_msm_reduce3(const uint32_t* __restrict__ F2, const uint32_t* __restrict__ G2, const uint32_t* __restrict__ H2, uint32_t* Tw) {
-    uint32_t w = gtid();
-    if (w >= MSM_NW) return;
+    uint32_t w = gtid();   // window * MSM_G + group
+    if (w >= MSM_NWG) return;
     TomPt run = tom_identity(), fg = tom_identity(), gf = tom_identity(), gh = tom_identity();
 #pragma unroll 1
     for (int s = 31; s >= 0; s--) {
@@ -256,20 +267,21 @@ __global__ void __launch_bounds__(64) k_msm_reduce3(const uint32_t* __restrict__
     for (int i = 0; i < 6; i++) t = tom_dbl(t);
     t = tom_add(t, gh);
 #pragma unroll 1
-    for (uint32_t i = 0; i < MSM_C * w; i++) t = tom_dbl(t);
+    for (uint32_t i = 0; i < MSM_C * (w / MSM_G); i++) t = tom_dbl(t);
     msm_st(Tw + (size_t)w * 36, t);
 }
-// coefficient sums of the fixed bases over the chunk's proofs: list C slots p * 4n + {0, 1} hold (mg, mh), (eg, eh)
-__global__ void __launch_bounds__(256) k_msm_coef(Workspace W, uint32_t count, TomList one) {
+// coefficient sums of the fixed bases over a group's proofs (block g): list C slots p * 4n + {0, 1} hold (mg, mh), (eg, eh)
+__global__ void __launch_bounds__(256) k_msm_coef(Workspace W, uint32_t count, uint32_t gsz, TomList one) {
     __shared__ uint32_t sh[2][9][256];
-    uint32_t t = threadIdx.x;
-    Fe<ModQ, 1> g = fe_zero<ModQ>(), h = fe_zero<ModQ>();
-    for (uint32_t p = t; p < count; p += 256) {
+    uint32_t t = threadIdx.x, g = blockIdx.x;
+    uint32_t p0 = g * gsz, p1 = p0 + gsz < count ? p0 + gsz : count;
+    Fe<ModQ, 1> gg = fe_zero<ModQ>(), h = fe_zero<ModQ>();
+    for (uint32_t p = p0 + t; p < p1; p += 256) {
         uint32_t lc = p * 4 * W.n;
-        g = fe_add_mod(g, fe_add_mod(soa_ld<ModQ, 1>(W.lc.v, lc), soa_ld<ModQ, 1>(W.lc.v, lc + 1)));
+        gg = fe_add_mod(gg, fe_add_mod(soa_ld<ModQ, 1>(W.lc.v, lc), soa_ld<ModQ, 1>(W.lc.v, lc + 1)));
         h = fe_add_mod(h, fe_add_mod(soa_ld<ModQ, 1>(W.lc.r, lc), soa_ld<ModQ, 1>(W.lc.r, lc + 1)));
     }
-    for (int l = 0; l < 9; l++) sh[0][l][t] = g.l[l], sh[1][l][t] = h.l[l];
+    for (int l = 0; l < 9; l++) sh[0][l][t] = gg.l[l], sh[1][l][t] = h.l[l];
     __syncthreads();
     for (uint32_t o = 128; o >= 1; o >>= 1) {
         if (t < o) {
@@ -283,37 +295,40 @@ __global__ void __launch_bounds__(256) k_msm_coef(Workspace W, uint32_t count, T
     if (t == 0) {
         Fe<ModQ, 1> a, c2;
         for (int l = 0; l < 9; l++) a.l[l] = sh[0][l][0], c2.l[l] = sh[1][l][0];
-        soa_st(one.v, 0, a), soa_st(one.r, 0, c2);
+        soa_st(one.v, g, a), soa_st(one.r, g, c2);
     }
 }
 __global__ void k_msm_final(const uint32_t* __restrict__ Tw, TomList one, uint32_t* flag) {
-    if (gtid() != 0) return;
-    Ft2 x = soa_ld<ModT, 2>(one.proj.x, 0), y = soa_ld<ModT, 2>(one.proj.y, 0), z = soa_ld<ModT, 2>(one.proj.z, 0);
+    uint32_t g = gtid();
+    if (g >= MSM_G) return;
+    Ft2 x = soa_ld<ModT, 2>(one.proj.x, g), y = soa_ld<ModT, 2>(one.proj.y, g), z = soa_ld<ModT, 2>(one.proj.z, g);
     TomPt t;
     t.x = x * z, t.y = y * z, t.t = x * y, t.z = z * z;  // (X : Y : Z) -> extended
-    for (uint32_t w = 0; w < MSM_NW; w++) t = tom_add(t, msm_ldp(Tw + (size_t)w * 36));
+    for (uint32_t w = 0; w < MSM_NW; w++) t = tom_add(t, msm_ldp(Tw + ((size_t)w * MSM_G + g) * 36));
     bool id = fe_is_zero(t.x) && fe_eq(t.y, t.z) && !fe_is_zero(t.z);
-    *flag = id ? 1u : 0u;
+    flag[g] = id ? 1u : 0u;
 }
 
 size_t msm_workspace_bytes(uint32_t cap) {
     size_t tmp = 0;
-    rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, cap, 0, MSM_C);
+    rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, cap, 0, MSM_C + MSM_GBITS);
     return tmp;
 }
-// returns through *host_flag (after a stream synchronisation): 1 = the chunk's Tom total is the identity
-hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t* host_flag) {
+// returns through host_flags[MSM_G] (after a stream synchronisation): 1 = the Tom total of that group of proofs is the identity
+hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t* host_flags, uint32_t* gsz_out) {
     MsmDims D;
     D.g0 = V.C * VK, D.g1 = V.C * nq, D.g2 = V.C;
     D.n0 = D.g0 * V_SLOT_TERMS, D.n1 = D.g1 * 8, D.n2 = D.g2 * 3;
     D.l0 = count * VK, D.l1 = count * nq, D.l2 = count;
+    D.nq = nq, D.gsz = (count + MSM_G - 1) / MSM_G;
+    *gsz_out = D.gsz;
     const uint32_t total = D.n0 + D.n1 + D.n2;
     const bool dbg = getenv("ZK_MSM_DEBUG") != nullptr;  // phase timings on stderr (adds stream synchronisations)
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
     hipLaunchKernelGGL(k_msm_pack, dim3((total + 255) / 256), dim3(256), 0, s, V, D, M.aos);
-    hipMemsetAsync(M.start, 0, sizeof(uint32_t) * MSM_NW * MSM_NB, s);
-    hipMemsetAsync(M.end, 0, sizeof(uint32_t) * MSM_NW * MSM_NB, s);
+    hipMemsetAsync(M.start, 0, sizeof(uint32_t) * MSM_NW * MSM_NBG, s);
+    hipMemsetAsync(M.end, 0, sizeof(uint32_t) * MSM_NW * MSM_NBG, s);
     hipMemsetAsync(M.counters, 0, sizeof(uint32_t) * MSM_NW, s);
     hipLaunchKernelGGL(k_msm_compact, dim3((total + 255) / 256), dim3(256), 0, s, V, D, M.cap, M.keys_all, M.vals_in, M.counters);
     uint32_t n = 0;
@@ -325,25 +340,27 @@ hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const 
     if (dbg) fprintf(stderr, "msm: %u live terms, pack+compact %.2f ms\n", n, now() - t0), t0 = now();
     for (uint32_t w = 0; w < MSM_NW && n; w++) {
         size_t tmp = M.sort_tmp_bytes;
-        hipError_t e = rocprim::radix_sort_pairs(M.sort_tmp, tmp, M.keys_all + (size_t)w * M.cap, M.keys_out, M.vals_in, M.vals_out + (size_t)w * M.cap, n, 0, MSM_C, s);
+        hipError_t e = rocprim::radix_sort_pairs(M.sort_tmp, tmp, M.keys_all + (size_t)w * M.cap, M.keys_out, M.vals_in, M.vals_out + (size_t)w * M.cap, n, 0,
+                                                 MSM_C + MSM_GBITS, s);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_msm_bounds, dim3((n + 255) / 256), dim3(256), 0, s, M.keys_out, n, M.start + (size_t)w * MSM_NB, M.end + (size_t)w * MSM_NB);
+        hipLaunchKernelGGL(k_msm_bounds, dim3((n + 255) / 256), dim3(256), 0, s, M.keys_out, n, M.start + (size_t)w * MSM_NBG, M.end + (size_t)w * MSM_NBG);
     }
     if (dbg) {
         hipStreamSynchronize(s);
         fprintf(stderr, "msm: 16 sorts + bounds %.2f ms\n", now() - t0), t0 = now();
     }
     hipMemsetAsync(M.counters + 32, 0, 4, s);
-    hipLaunchKernelGGL(k_msm_bucket, dim3(MSM_NB / 256, MSM_NW), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.buckets, M.counters + 32, M.big_list, 8 * ((nmax + MSM_NB - 1) / MSM_NB) + 64);
+    hipLaunchKernelGGL(k_msm_bucket, dim3(MSM_NBG / 256, MSM_NW), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.buckets, M.counters + 32, M.big_list,
+                       8 * ((nmax + MSM_NBG - 1) / MSM_NBG) + 64);
     hipLaunchKernelGGL(k_msm_bucket_big, dim3(MSM_NSLICE, 32), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.counters + 32, M.big_list, M.big_part);
     hipLaunchKernelGGL(k_msm_bucket_big2, dim3(64), dim3(256), 0, s, M.counters + 32, M.big_list, M.big_part, M.buckets);
-    hipLaunchKernelGGL(k_msm_reduce1, dim3(1024 / 256, MSM_NW), dim3(256), 0, s, M.buckets, M.F1, M.G1);
-    hipLaunchKernelGGL(k_msm_reduce2, dim3((MSM_NW * 32 + 63) / 64), dim3(64), 0, s, M.F1, M.G1, M.F2, M.G2, M.H2);
-    hipLaunchKernelGGL(k_msm_reduce3, dim3(1), dim3(64), 0, s, M.F2, M.G2, M.H2, M.Tw);
-    hipLaunchKernelGGL(k_msm_coef, dim3(1), dim3(256), 0, s, W, count, M.one);
-    launch_tom_commit(s, P, M.one, 1, 1, 1);
+    hipLaunchKernelGGL(k_msm_reduce1, dim3(1024 / 256, MSM_NWG), dim3(256), 0, s, M.buckets, M.F1, M.G1);
+    hipLaunchKernelGGL(k_msm_reduce2, dim3((MSM_NWG * 32 + 63) / 64), dim3(64), 0, s, M.F1, M.G1, M.F2, M.G2, M.H2);
+    hipLaunchKernelGGL(k_msm_reduce3, dim3((MSM_NWG + 63) / 64), dim3(64), 0, s, M.F2, M.G2, M.H2, M.Tw);
+    hipLaunchKernelGGL(k_msm_coef, dim3(MSM_G), dim3(256), 0, s, W, count, D.gsz, M.one);
+    launch_tom_commit(s, P, M.one, MSM_G, 1, 1);
     hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, s, M.Tw, M.one, M.flag);
-    hipError_t e = hipMemcpyAsync(host_flag, M.flag, 4, hipMemcpyDeviceToHost, s);
+    hipError_t e = hipMemcpyAsync(host_flags, M.flag, 4 * MSM_G, hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) return e;
     e = hipStreamSynchronize(s);
     if (dbg) fprintf(stderr, "msm tail (bucket .. final) %.2f ms\n", now() - t0);

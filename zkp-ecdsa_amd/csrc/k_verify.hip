@@ -182,12 +182,17 @@ ZK_DEV void absorb_tom_bytes(ShaStream& s, const uint8_t* p72) {  // 36-byte pad
     ld_words_be(p72 + 36, 9, w);
     s.put_be<33>(w);
 }
+// hashPoints serialises through toBytes -> toAffine (group.ts:221-233, weier.ts:231-255), which reduces the coordinates mod p;
+// deserializePoint / isOnGroup accept x or y in [p, 2^256) (weier.ts:74-89 works mod p), so a stored coordinate may be
+// non-canonical: the REDUCED value is what the reference hashes.
 ZK_DEV void absorb_p256_bytes(ShaStream& s, const uint8_t* p64) {
     uint32_t w[8];
     s.put_byte(4);
     load_be32(p64, w);
+    words_from_limbs<8>(w, fe_from_words256_reduce<ModQ>(w).l);
     s.put_be<32>(w);
     load_be32(p64 + 32, w);
+    words_from_limbs<8>(w, fe_from_words256_reduce<ModQ>(w).l);
     s.put_be<32>(w);
 }
 ZK_DEV void absorb_tom_soa(ShaStream& s, const Soa& ax, const Soa& ay, uint32_t e) {
@@ -784,8 +789,20 @@ __global__ void __launch_bounds__(64, 1) k_v_slot_terms(Workspace W, VWork V, ui
     soa_st(V.sSg, sl, Sg), soa_st(V.sSh, sl, Sh), soa_st(V.sSkx, sl, Skx), soa_st(V.sSky, sl, Sky);
     soa_st(V.sSR, sl, SR), soa_st(V.sSH, sl, SH), soa_st(V.sSL, sl, SL);
     // slot classes for k_v_straus: a zero-bit rep has 36 live terms, every other slot only terms 34, 35 (128-bit)
-    if (good && !bit) V.slot_perm[atomicAdd(&V.slot_cnt[0], 1u)] = sl;
-    else V.slot_perm[count * VK - 1 - atomicAdd(&V.slot_cnt[1], 1u)] = sl;
+    V.slot_class[sl] = good && !bit ? 1 : 0;
+}
+// Class-sorted slot order of a range of slots that goes to the per-proof sums (k_v_straus): local ids, class 1 from the front,
+// class 0 from the back, so that waves are homogeneous.
+__global__ void __launch_bounds__(256) k_v_slot_perm(const uint8_t* __restrict__ slot_class, uint32_t nslots, uint32_t* perm, uint32_t* cnt) {
+    uint32_t sl = gtid();
+    if (sl >= nslots) return;
+    if (slot_class[sl]) perm[atomicAdd(&cnt[0], 1u)] = sl;
+    else perm[nslots - 1 - atomicAdd(&cnt[1], 1u)] = sl;
+}
+void launch_v_slot_perm(hipStream_t s, const uint8_t* slot_class, uint32_t nslots, uint32_t* perm, uint32_t* cnt) {
+    if (!nslots) return;
+    hipMemsetAsync(cnt, 0, 8, s);
+    hipLaunchKernelGGL(k_v_slot_perm, dim3((nslots + 255) / 256), dim3(256), 0, s, slot_class, nslots, perm, cnt);
 }
 // one thread per proof: GK relations (gk.ts:223-259) -> groups of the gk list (4 per pair of bit positions: cl, cd 256-bit;
 // ca, cb 128-bit) and the per-proof totals for the shared points.
@@ -870,9 +887,11 @@ ZK_DEV void st_tab(const VTerms& L, uint32_t e, uint32_t idx, const TomPt& a) {
 #pragma unroll
     for (int i = 0; i < 9; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
-__global__ void __launch_bounds__(256, 2) k_v_term_tables(VTerms L, uint32_t nterms) {
-    uint32_t idx = gtid();
-    if (idx >= nterms) return;
+// thread t: term k = t / ngroups of group g = t % ngroups, at index k * ng_stride + g
+__global__ void __launch_bounds__(256, 2) k_v_term_tables(VTerms L, uint32_t ngroups, uint32_t ng_stride, uint32_t nt) {
+    uint32_t t = gtid();
+    if (t >= ngroups * nt) return;
+    uint32_t idx = (t / ngroups) * ng_stride + t % ngroups;
     Sq sc = soa_ld<ModQ, 1>(L.sc, idx);
     uint32_t kw[8];
     words_from_limbs<8>(kw, sc.l);
@@ -962,10 +981,11 @@ __global__ void __launch_bounds__(256) k_v_straus(VTerms L, uint32_t ngroups, ui
     }
     soa_st(out.x, g, acc.x), soa_st(out.y, g, acc.y), soa_st(out.z, g, acc.z), soa_st(out.t, g, acc.t);
 }
-void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t nterms, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out,
+void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out,
                      const uint32_t* perm, const uint32_t* cnt) {
     if (!ngroups) return;
-    hipLaunchKernelGGL(k_v_term_tables, dim3((nterms + 255) / 256), dim3(256), 0, s, L, nterms);
+    const uint32_t nterms = ngroups * (n256 + n128);
+    hipLaunchKernelGGL(k_v_term_tables, dim3((nterms + 255) / 256), dim3(256), 0, s, L, ngroups, ng_stride, n256 + n128);
     hipLaunchKernelGGL(k_v_straus, dim3((ngroups + 255) / 256), dim3(256), 0, s, L, ngroups, ng_stride, n256, n128, out, perm, cnt);
 }
 // P-256: sum of rho_j * (-A_j) over the 20 checked repetitions, 5 terms per thread, 128-bit randomisers.  Signed 4-bit
@@ -1036,11 +1056,13 @@ ZK_DEV TomPt ld_tom_proj3(const Soa3& a, uint32_t e) {  // (X:Y:Z) without T -> 
 ZK_DEV bool tom_is_identity(const TomPt& a) {  // edwards.ts:117-125 on the a=1 image
     return fe_is_zero(a.x) && fe_eq(a.y, a.z) && !fe_is_zero(a.z);
 }
-// tom_all_ok: the batched check (k_msm.hip) found the chunk's Tom-256 total to be the identity, i.e. every proof's
-// membership and Exp/Tom sums are (the per-proof accumulators were not computed)
-__global__ void __launch_bounds__(64, 2) k_v_final(DevParams P, Workspace W, VWork V, uint32_t count, uint8_t* ok_out, int32_t* status_out, uint64_t first, bool tom_all_ok) {
+// grp_ok[p / gsz] != 0: the batched check (k_msm.hip) found the Tom-256 total of the proof's group to be the identity, i.e. the
+// membership and Exp/Tom sums of every proof of the group are (their per-proof accumulators were not computed)
+__global__ void __launch_bounds__(64, 2) k_v_final(DevParams P, Workspace W, VWork V, uint32_t count, uint8_t* ok_out, int32_t* status_out, uint64_t first,
+                                                   const uint32_t* __restrict__ grp_ok, uint32_t gsz) {
     uint32_t p = gtid();
     if (p >= count) return;
+    const bool tom_all_ok = grp_ok[p / gsz] != 0;
     int32_t st = V.st[p];  // structural errors; W.st additionally carries a late "T is at infinity"
     uint8_t ok = 0;
     if (V.st[p] == ZK_OK && !(V.okflags[p] & 8)) {
@@ -1157,11 +1179,11 @@ void launch_v_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, c
     L1(k_v_padd_hash, count * VK * 6, 256, P, W, V, count, proofs, off, first);
 }
 void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
-    hipMemsetAsync(V.slot_cnt, 0, 8, s);
     L1(k_v_slot_terms, count * VK, 64, W, V, count, proofs, off, vseeds, first);
     L1(k_v_proof_terms, count, 64, W, V, count, proofs, off, vseeds, first);
 }
 void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count) { L1(k_v_p256_straus, count * 4, 256, V, count); }
-void launch_v_final(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first, bool tom_all_ok) {
-    L1(k_v_final, count, 64, P, W, V, count, ok, status, first, tom_all_ok);
+void launch_v_final(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first,
+                    const uint32_t* grp_ok, uint32_t gsz) {
+    L1(k_v_final, count, 64, P, W, V, count, ok, status, first, grp_ok, gsz);
 }
