@@ -69,6 +69,11 @@ async function cpu(goldenPath) {
     other[other.length - 1] ^= 1
     assert.ok(!proof.eq(new SignatureProofList(other)))
     assert.throws(() => readJson(SignatureProofList, text.slice(0, -1)), /error deserializing/)
+    // hardened parameters: derived, not drawn -- the same every time, on the curves, different per tag
+    const hp = zk.generateParamsListHardened(), hp2 = zk.generateParamsListHardened(80)
+    assert.ok(hp.eq(hp2) && hp.hardened && !hp.eq(zk.generateParamsListHardened(80, Buffer.from('x'))))
+    assert.ok(zk.p256.isOnGroup(hp.NistGroup.h) && zk.tomEdwards256.isOnGroup(hp.ProofGroup.h) && hp.ProofGroup.h.mul(zk.tomEdwards256.order).isIdentity())
+    assert.ok(serdeTest(SystemParametersList, hp))
     console.log('cpu ok', text.length)
 }
 
@@ -115,6 +120,13 @@ async function gpu() {
         const swapped = [proofs[1], proofs[0], proofs[2], proofs[3], proofs[4]]
         assert.deepStrictEqual(await zk.verifySignatureListBatch(params, ks.map((k) => k.msgHash), ring, proofs), Array(B).fill(true))
         assert.deepStrictEqual(await zk.verifySignatureListBatch(params, ks.map((k) => k.msgHash), ring, swapped), [false, false, true, true, true])
+        // hardened mode end to end: proofs of one mode do not verify in the other
+        const hparams = zk.generateParamsListHardened()
+        const hproof = await proveSignatureList(hparams, msgHash, signature, keyPair.publicKey, 0, testArray)
+        assert.strictEqual(await verifySignatureList(hparams, msgHash, testArray, hproof), true)
+        const soft = readJson(SystemParametersList, writeJson(SystemParametersList, hparams))      // same generators, reference mode
+        assert.strictEqual(await verifySignatureList(soft, msgHash, testArray, hproof), false)
+        assert.strictEqual(await verifySignatureList(hparams, msgHash, otherRing, hproof), false)
         zk.shutdown()
     }
     // ---- the low-level engine: synthetic workload, determinism under the RNG contract, misuse of handles

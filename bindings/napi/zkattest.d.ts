@@ -26,6 +26,8 @@ export class SignatureProofList {
 }
 export type PublicKey = Buffer | Uint8Array | import('crypto').KeyObject | CryptoKey
 export function generateParamsList(secLevel?: number): SystemParametersList
+/** hardened mode: NUMS generators + statement-bound membership challenge; not byte-compatible with the reference */
+export function generateParamsListHardened(secLevel?: number, tag?: Uint8Array): SystemParametersList & { hardened: boolean }
 export function keyToInt(publicKey: PublicKey): Promise<bigint>
 export function proveSignatureList(params: SystemParametersList, msgHash: Uint8Array, sigBytes: Uint8Array, publicKey: PublicKey, which: number, keys: bigint[]): Promise<SignatureProofList>
 export function verifySignatureList(params: SystemParametersList, msgHash: Uint8Array, keys: bigint[], proof: SignatureProofList): Promise<boolean>
@@ -41,7 +43,7 @@ export class Engine {
     constructor(devices?: number | number[])
     close(): void
     info(): { devices: number; ringTransport: string; proofMaxSize: number }
-    setOption(name: 'chunk' | 'lanes' | 'combBits' | 'hostTaper' | 'batchVerify', value: number): void
+    setOption(name: 'chunk' | 'lanes' | 'combBits' | 'hostTaper' | 'batchVerify' | 'mode' | 'slice', value: number): void
     setParams(p: EngineParams): void
     setRing(keys: Buffer | bigint[]): string
     keysToInts(pkxy: Buffer): { keys: Buffer; status: Buffer }

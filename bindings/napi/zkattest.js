@@ -150,6 +150,18 @@ class SystemParametersList { // src/zkpAttestList.ts:62-78
 function generateParamsList(secLevel = 80) { // src/zkpAttestList.ts:88-92
     return new SystemParametersList(generatePedersenParams(p256), generatePedersenParams(tomEdwards256), secLevel)
 }
+// Hardened mode (include/zkattest.h; NOT byte-compatible with the reference, both sides must opt in): h of both groups derived
+// from SHA-256 (nobody knows log_g h: the TODO of src/commit/pedersen.ts:62) and the statement hashed into the membership
+// challenge (the TODO of src/proofGK/gk.ts:178).  `params.hardened = true` selects the mode for proveSignatureList /
+// verifySignatureList; the flag is not part of the JSON form (set it again after readJson).
+function generateParamsListHardened(secLevel = 80, tag = Buffer.alloc(0)) {
+    const h = native.hardenedH(Buffer.from(tag))
+    const pt = (g, buf, w) => new Point(g, fromBE(buf.slice(0, w)), fromBE(buf.slice(w)))
+    const params = new SystemParametersList(new PedersenParams(p256, p256.generator(), pt(p256, h.nistH, 32)),
+        new PedersenParams(tomEdwards256, tomEdwards256.generator(), pt(tomEdwards256, h.tomH, 36)), secLevel)
+    params.hardened = true
+    return params
+}
 
 // Proof objects keep the engine's ZKA1 bytes (the binary equivalent of the reference's object graph, include/zkattest.h) and
 // materialise the reference's members (R, comS1, keyXcom, keyYcom, expProof[], membershipProof: Points and Scalars) on demand.
@@ -272,19 +284,21 @@ function ringOf(keys) {
 }
 function engineFor(params, keys) {
     if (!(params instanceof SystemParametersList)) throw new TypeError('params: a SystemParametersList (generateParamsList / readJson)')
-    if (!params._tag) {
+    if (!params._ep) {
         const ep = params.engineParams(), devices = defaultDevices()
         const tag = crypto.createHash('sha256').update(ep.nistH).update(ep.tomG).update(ep.tomH).update(String(ep.secLevel) + '|' + devices.join(',')).digest('hex')
-        Object.defineProperty(params, '_tag', { value: tag })
+        Object.defineProperty(params, '_tag0', { value: tag })
         Object.defineProperty(params, '_ep', { value: ep })
     }
-    let slot = engines.get(params._tag)
+    const key = params._tag0 + (params.hardened ? '|hardened' : '')
+    let slot = engines.get(key)
     if (!slot) {
         const engine = new Engine(defaultDevices())
         if (process.env.ZKATTEST_COMB_BITS) engine.setOption('combBits', parseInt(process.env.ZKATTEST_COMB_BITS, 10))
+        if (params.hardened) engine.setOption('mode', 1)
         engine.setParams(params._ep)           // builds the fixed-base tables: once per SystemParametersList
         slot = { engine, ringTag: null }
-        engines.set(params._tag, slot)
+        engines.set(key, slot)
     }
     const ring = ringOf(keys)
     // one queued unit per call: (re)load the ring if the loaded one differs (table E: once per key ring), then run the batch;
@@ -336,6 +350,6 @@ async function verifySignatureListBatch(params, msgHashes, keys, proofs) {
     return engineFor(params, keys).withRing((engine) => engine._verifyNow(msg, raw))
 }
 
-module.exports = { generateParamsList, keyToInt, proveSignatureList, verifySignatureList, proveSignatureListBatch, verifySignatureListBatch,
+module.exports = { generateParamsList, generateParamsListHardened, keyToInt, proveSignatureList, verifySignatureList, proveSignatureListBatch, verifySignatureListBatch,
     writeJson, readJson, SignatureProofList, SystemParametersList, PedersenParams, generatePedersenParams, p256, tomEdwards256, ALL_GROUPS,
     Group, Point, Scalar, Engine, shutdown, native }

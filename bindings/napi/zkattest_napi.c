@@ -223,6 +223,8 @@ static napi_value SetOption(napi_env env, napi_callback_info info) {
                        : !strcmp(name, "combBits")    ? zk_ctx_set_comb_bits(c, val)
                        : !strcmp(name, "hostTaper")   ? zk_ctx_set_host_taper(c, val)
                        : !strcmp(name, "batchVerify") ? zk_ctx_set_batch_verify(c, val)
+                       : !strcmp(name, "mode")        ? zk_ctx_set_mode(c, val)
+                       : !strcmp(name, "slice")       ? zk_ctx_set_slice(c, val)
                                                       : ZK_E_ARG;
         if (st != ZK_OK) return throw_text(env, st, name);
     }
@@ -501,6 +503,20 @@ static napi_value HostAlloc(napi_env env, napi_callback_info info) { /* (bytes) 
     }
     return b;
 }
+static napi_value HardenedH(napi_env env, napi_callback_info info) { /* (tag: Buffer) -> {nistH, tomH}   zk_hardened_h: host-only */
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    uint8_t *tag;
+    size_t lt;
+    if (!get_bytes(env, argv[0], &tag, &lt)) return NULL;
+    uint8_t a[64], b[72];
+    zk_status st = zk_hardened_h(tag, lt, a, b);
+    if (st != ZK_OK) return throw_text(env, st, "");
+    napi_value o;
+    NAPI_OK(napi_create_object(env, &o));
+    set_prop(env, o, "nistH", new_buffer(env, a, 64)), set_prop(env, o, "tomH", new_buffer(env, b, 72));
+    return o;
+}
 static napi_value ProofToJson(napi_env env, napi_callback_info info) { /* (proof: Buffer) -> string   (writeJson, src/serde.ts:34-36) */
     napi_value argv[1];
     if (!get_args(env, info, 1, argv)) return NULL;
@@ -569,7 +585,7 @@ static napi_value Init(napi_env env, napi_value exports) {
                {"setParams", SetParams},         {"setRing", SetRing},               {"synthParams", SynthParams}, {"synthWorkload", SynthWorkload},
                {"proveBatch", ProveBatch},       {"verifyBatch", VerifyBatch},       {"proveBatchAsync", ProveBatchAsync},
                {"verifyBatchAsync", VerifyBatchAsync}, {"proofToJson", ProofToJson}, {"proofFromJson", ProofFromJson},
-               {"keysToInts", KeysToInts},       {"hostAlloc", HostAlloc}};
+               {"keysToInts", KeysToInts},       {"hostAlloc", HostAlloc},           {"hardenedH", HardenedH}};
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;
         if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;

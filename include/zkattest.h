@@ -203,6 +203,20 @@ zk_status zk_pool_verify_batch(zk_pool *pool, uint64_t B, const uint8_t *msg_has
                                const uint64_t *proof_len /*B*/, const uint8_t *verifier_seeds /*Bx32 or NULL*/, uint8_t *ok /*B*/,
                                int32_t *per_proof_status /*B*/);
 
+/* ---- hardened mode: the two protocol hardenings the reference leaves as TODOs, as an explicit opt-in.  NOT byte-compatible
+ * with the reference: a proof made in one mode only verifies in that mode.  Default: ZK_MODE_REFERENCE (byte parity).
+ *   (1) src/commit/pedersen.ts:62 "we must generate h without using scalar mult": zk_hardened_h derives NistGroup.h and
+ *       ProofGroup.h from SHA-256 by try-and-increment (specification in csrc/h2c_host.cpp), so that nobody knows their
+ *       discrete logarithms; pass them to zk_ctx_set_params like any other parameters.  Host-only, no context.
+ *   (2) src/proofGK/gk.ts:178 "we should hash in the statement": with zk_ctx_set_mode(ctx, ZK_MODE_HARDENED) the challenge of
+ *       the membership proof is SHA-256(cl || ca || cb || cd || "ZKAttest-GK-statement-v1" || ring digest || msgHash || R ||
+ *       keyXcom)[0..10) instead of the hash of the commitments alone; ring digest = zk_ring_digest: SHA-256("ZKAttest-ring-v1" ||
+ *       be64(N) || SHA-256 of every 256 consecutive entries of the padded ring).  Prover and verifier must use the same mode. */
+enum { ZK_MODE_REFERENCE = 0, ZK_MODE_HARDENED = 1 };
+zk_status zk_ctx_set_mode(zk_ctx *ctx, uint32_t mode);
+zk_status zk_ring_digest(zk_ctx *ctx, uint8_t digest[32]);
+zk_status zk_hardened_h(const uint8_t *tag, uint64_t tag_len, uint8_t nist_h[64], uint8_t tom_h[72]);
+
 /* Seeded synthetic workload generator: fills device or host buffers with a ring of
  * n_keys uniform scalars, and B valid ECDSA P-256 signatures whose public keys' x-coordinates are planted at
  * ring[which_b], which_b = b mod n_keys.  Mirrors oracle/zkattest_ref.py synth_* byte for byte.  Host pointers. */

@@ -518,8 +518,8 @@ tomEdwards256 = TEdwards(
      0xbe231cb9f9bf18319c9f081141559b0a33dddccd2221f0464a9cd57081b01a01))
 
 
-def hashPoints(points):  # group.ts:221-233 (SHA-256; first 10 bytes, big-endian)
-    data = b''.join(p.toBytes() for p in points)
+def hashPoints(points, suffix=b''):  # group.ts:221-233 (SHA-256; first 10 bytes, big-endian); suffix: hardened mode only
+    data = b''.join(p.toBytes() for p in points) + suffix
     return fromBytes(hashlib.sha256(data).digest()[:10])
 
 
@@ -1008,7 +1008,7 @@ def gk_commit(params, val, blinder):  # gk.ts:88-92
                            params.c.newScalar(posMod(blinder, order)))
 
 
-def proveMembership(params, com, index, initialValues, rng, dv_override=None):  # gk.ts:94-195
+def proveMembership(params, com, index, initialValues, rng, dv_override=None, statement=b''):  # gk.ts:94-195
     values = pad(initialValues, params.c)
     c = params.c
     n = _ceil_log2(len(values))
@@ -1053,7 +1053,7 @@ def proveMembership(params, com, index, initialValues, rng, dv_override=None):  
     di = interpolate(omegas, dv, c.order)
     for i in range(n):
         cd.append(gk_commit(params, di[i], rho[i]))
-    x = hashPoints(cl + ca + cb + cd)
+    x = hashPoints(cl + ca + cb + cd, statement)
     f, za, zb = [], [], []
     zd = (com.r.k * expMod(x, n, c.order)) % c.order
     for i in range(n):
@@ -1065,7 +1065,7 @@ def proveMembership(params, com, index, initialValues, rng, dv_override=None):  
     return GKProof(cl, ca, cb, cd, f, za, zb, c.newScalar(zd))
 
 
-def verifyMembership(params, com, initVec, proof, vrng):  # gk.ts:197-262
+def verifyMembership(params, com, initVec, proof, vrng, statement=b''):  # gk.ts:197-262
     c = params.c
     multi = MultiMult(c)
     vec = pad(initVec, c)
@@ -1074,7 +1074,7 @@ def verifyMembership(params, com, initVec, proof, vrng):  # gk.ts:197-262
             == len(proof.f) == len(proof.za) == len(proof.zb)):
         return False
     f = proof.f
-    x = hashPoints(proof.cl + proof.ca + proof.cb + proof.cd)
+    x = hashPoints(proof.cl + proof.ca + proof.cb + proof.cd, statement)
     multi.addKnown(params.g)
     multi.addKnown(params.h)
     for i in range(n):
@@ -1151,7 +1151,7 @@ def keyToInt(pkBytes):  # zkpAttestList.ts:94-102 (pkBytes = WebCrypto 'raw' exp
     return pkCoords[0]
 
 
-def proveSignatureList(params, msgHash, sigBytes, pkBytes, which, keys, rng):  # zkpAttestList.ts:104-145
+def proveSignatureList(params, msgHash, sigBytes, pkBytes, which, keys, rng, hardened=False):  # zkpAttestList.ts:104-145
     ec = p256
     pkPoint = p256.deserializePoint(pkBytes)
     pkCoords = pkPoint.toAffine()
@@ -1175,11 +1175,12 @@ def proveSignatureList(params, msgHash, sigBytes, pkBytes, which, keys, rng):  #
     pkX = params.ProofGroup.commit(pkCoords[0], rng)
     pkY = params.ProofGroup.commit(pkCoords[1], rng)
     sigProof = proveExp(paramsSigExp, params.ProofGroup, s1, comS1, pkPoint, pkX, pkY, params.SecLevel, rng, Q)
-    membershipProof = proveMembership(params.ProofGroup, pkX, which, keys, rng)
+    stmt = gk_statement([v.k for v in pad(keys, params.ProofGroup.c)], msgHash, R, pkX.p) if hardened else b''
+    membershipProof = proveMembership(params.ProofGroup, pkX, which, keys, rng, statement=stmt)
     return SignatureProofList(R, comS1.p, pkX.p, pkY.p, sigProof, membershipProof)
 
 
-def verifySignatureList(params, msgHash, keys, proof, vrng=None):  # zkpAttestList.ts:147-184
+def verifySignatureList(params, msgHash, keys, proof, vrng=None, hardened=False):  # zkpAttestList.ts:147-184
     vrng = vrng or OsRng()
     ec = p256
     groupOrder = ec.order
@@ -1192,7 +1193,8 @@ def verifySignatureList(params, msgHash, keys, proof, vrng=None):  # zkpAttestLi
     paramsSigExp = PedersenParams(p256, R, params.NistGroup.h)
     z1 = posMod(rinv * z, groupOrder)
     Q = ec.generator().mul(ec.newScalar(z1))
-    if not verifyMembership(params.ProofGroup, proof.keyXcom, keys, proof.membershipProof, vrng):
+    stmt = gk_statement([v.k for v in pad(keys, params.ProofGroup.c)], msgHash, R, proof.keyXcom) if hardened else b''
+    if not verifyMembership(params.ProofGroup, proof.keyXcom, keys, proof.membershipProof, vrng, statement=stmt):
         return False
     if not verifyExp(paramsSigExp, params.ProofGroup, proof.comS1, proof.keyXcom, proof.keyYcom,
                      proof.expProof, 20, vrng, Q):
@@ -1559,3 +1561,60 @@ def synth_proof_input(S, b, N):
     sig = ecdsa_sign(d, msgHash, k)
     seed = synth_tag(b'rng', S, b)
     return msgHash, sig, pk, b % N, d, seed
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# HARDENED MODE (not in the reference: its two TODOs, src/commit/pedersen.ts:62 and src/proofGK/gk.ts:178).  Restatement of
+# the engine's own specification (include/zkattest.h, csrc/h2c_host.cpp, k_hash.hip) for the parity tests of that mode.
+def _sqrt_3mod4(v, p):
+    y = pow(v, (p + 1) // 4, p)
+    return y if y * y % p == v % p else None
+
+
+def hardened_h(tag=b''):
+    """Nothing-up-my-sleeve second generators: (h_NIST, h_Tom) as affine (x, y) pairs, by try-and-increment over SHA-256."""
+    dom = b'ZKAttest-NUMS-h-v1'
+    p, b = p256.p, p256.b
+    ctr = 0
+    while True:
+        x = int.from_bytes(hashlib.sha256(dom + b'\x01' + tag + ctr.to_bytes(4, 'big')).digest(), 'big') % p
+        y = _sqrt_3mod4((x * x * x - 3 * x + b) % p, p)
+        ctr += 1
+        if y is not None:
+            h_nist = (x, y if y % 2 == 0 else p - y)
+            break
+    t, a, d = tomEdwards256.p, tomEdwards256.a, tomEdwards256.d
+    ctr = 0
+    while True:
+        m = dom + b'\x02' + tag + ctr.to_bytes(4, 'big')
+        ctr += 1
+        x = (int.from_bytes(hashlib.sha256(m + b'\x00').digest(), 'big') << 256 | int.from_bytes(hashlib.sha256(m + b'\x01').digest(), 'big')) % t
+        den = (1 - d * x * x) % t
+        if den == 0:
+            continue
+        y = _sqrt_3mod4((1 - a * x * x) * pow(den, -1, t) % t, t)
+        if y is None:
+            continue
+        y = y if y % 2 == 0 else t - y
+        P = TEdwardsPoint(tomEdwards256, x, y)
+        Q = P.dbl().dbl()
+        qx, qy = Q.toAffine()
+        if qx == 0:
+            continue
+        return h_nist, (qx, qy)
+
+
+GK_STATEMENT_TAG = b'ZKAttest-GK-statement-v1'
+
+
+def ring_digest(values):
+    """SHA-256('ZKAttest-ring-v1' || be64(N) || leaf_0 || leaf_1 ...), leaf_i = SHA-256 of 256 consecutive padded ring entries
+    (32-byte big-endian each; the last leaf may be shorter when N < 256)."""
+    N = len(values)
+    leaves = b''.join(hashlib.sha256(b''.join(int(v).to_bytes(32, 'big') for v in values[i:i + 256])).digest() for i in range(0, N, 256))
+    return hashlib.sha256(b'ZKAttest-ring-v1' + N.to_bytes(8, 'big') + leaves).digest()
+
+
+def gk_statement(padded_values, msgHash, R, keyXcom):
+    """Bytes appended to the Groth-Kohlweiss transcript in hardened mode: the statement the membership proof is about."""
+    return GK_STATEMENT_TAG + ring_digest(padded_values) + bytes(msgHash) + R.toBytes() + keyXcom.toBytes()

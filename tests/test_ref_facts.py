@@ -109,8 +109,8 @@ def test_fiat_shamir_transcripts_of_the_restatements():
     assert re.search(r'arr = \[Px\.p, Py\.p\]\s+for i in range\(secparam\):\s+arr \+= \[A\[i\], Tx\[i\]\.p, Ty\[i\]\.p\]', src)
     assert fills['exp_arr'][4:] == ['Px, Py', 'pi[i as number].A', 'pi[i as number].Tx', 'pi[i as number].Ty']
     assert re.search(r'arr = \[Px, Py\]\s+for e in pi:\s+arr \+= \[e\.A, e\.Tx, e\.Ty\]', src)
-    assert fills['gk_commitments'] == 'cl.concat(ca).concat(cb).concat(cd)' and 'hashPoints(cl + ca + cb + cd)' in src
-    assert 'hashPoints(proof.cl + proof.ca + proof.cb + proof.cd)' in src
+    assert fills['gk_commitments'] == 'cl.concat(ca).concat(cb).concat(cd)' and 'hashPoints(cl + ca + cb + cd, statement)' in src   # statement = b'' outside the hardened mode
+    assert 'hashPoints(proof.cl + proof.ca + proof.cb + proof.cd, statement)' in src
     # challenge width, bit order, repetition counts
     import zkattest_ref as R
     mi = FACTS['misc']

@@ -14,7 +14,7 @@ SYMBOLS = [
     'zk_ctx_create', 'zk_ctx_destroy', 'zk_strerror', 'zk_last_error', 'zk_ctx_set_params', 'zk_ctx_set_ring',
     'zk_ctx_set_ring_device', 'zk_keys_to_ints', 'zk_ctx_set_chunk', 'zk_ctx_set_lanes', 'zk_ctx_set_comb_bits', 'zk_ctx_set_batch_verify', 'zk_proof_max_size', 'zk_prove_batch', 'zk_prove_batch_device',
     'zk_verify_batch', 'zk_verify_batch_device', 'zk_synth_workload', 'zk_synth_params', 'zk_last_timing',
-    'zk_proof_to_json', 'zk_proof_from_json', 'zk_host_alloc', 'zk_host_free', 'zk_ctx_set_host_taper', 'zk_ctx_set_slice',
+    'zk_proof_to_json', 'zk_proof_from_json', 'zk_host_alloc', 'zk_host_free', 'zk_ctx_set_host_taper', 'zk_ctx_set_slice', 'zk_ctx_set_mode', 'zk_ring_digest', 'zk_hardened_h',
     'zk_pool_create', 'zk_pool_destroy', 'zk_pool_size', 'zk_pool_ctx', 'zk_pool_last_error', 'zk_pool_ring_transport', 'zk_pool_shard',
     'zk_pool_set_params', 'zk_pool_set_ring', 'zk_pool_prove_batch', 'zk_pool_verify_batch',
     'zk_test_field_op', 'zk_test_tom_commit', 'zk_test_p256_fixed_mul', 'zk_test_sha256', 'zk_test_rng_draws',
@@ -82,6 +82,9 @@ def lib():
         L.zk_proof_from_json.argtypes = [C.c_char_p, u64, vp, u64, C.POINTER(u64)]
         L.zk_ctx_set_host_taper.argtypes = [vp, u32]
         L.zk_ctx_set_slice.argtypes = [vp, u32]
+        L.zk_ctx_set_mode.argtypes = [vp, u32]
+        L.zk_ring_digest.argtypes = [vp, vp]
+        L.zk_hardened_h.argtypes = [C.c_char_p, u64, vp, vp]
         L.zk_pool_create.argtypes = [C.POINTER(C.c_int), i32, C.POINTER(vp)]
         L.zk_pool_destroy.argtypes = [vp]
         L.zk_pool_destroy.restype = None
@@ -134,6 +137,18 @@ class ZkError(RuntimeError):
     def __init__(self, status, detail=''):
         self.status = status
         super().__init__('%s (status %d)%s' % (STATUS_TEXT.get(status, '?'), status, (': ' + detail) if detail else ''))
+
+
+MODE_REFERENCE, MODE_HARDENED = 0, 1
+
+
+def hardened_h(tag=b''):
+    """Nothing-up-my-sleeve NistGroup.h (64 bytes) and ProofGroup.h (72 bytes) of the hardened mode (zk_hardened_h; host-only)."""
+    a, b = C.create_string_buffer(64), C.create_string_buffer(72)
+    rc = lib().zk_hardened_h(bytes(tag), len(tag), a, b)
+    if rc:
+        raise ZkError(rc)
+    return a.raw, b.raw
 
 
 def write_json(proof_bytes):
@@ -225,6 +240,15 @@ class Engine:
 
     def set_lanes(self, lanes):
         self._chk(self.L.zk_ctx_set_lanes(self.h, lanes))
+
+    def set_mode(self, mode):
+        """MODE_REFERENCE (default, byte parity with the reference) or MODE_HARDENED (statement hashed into the GK challenge)."""
+        self._chk(self.L.zk_ctx_set_mode(self.h, int(mode)))
+
+    def ring_digest(self):
+        d = C.create_string_buffer(32)
+        self._chk(self.L.zk_ring_digest(self.h, d))
+        return d.raw
 
     def set_slice(self, proofs):
         """Proofs per PointAdd slice of the prover (0 = automatic: 4096 with page-locked output, none otherwise)."""

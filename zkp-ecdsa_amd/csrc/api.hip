@@ -90,7 +90,7 @@ extern "C" void zk_ctx_destroy(zk_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto e : c->epool) hipEventDestroy(e);
     hipFree(c->P.tom_tab_g), hipFree(c->P.tom_tab_h), hipFree(c->tom_tab_gen), hipFree(c->P.pfix_G), hipFree(c->P.pfix_H);
-    hipFree(c->tab_scratch), hipFree(c->gk_etab), hipFree(c->d_flag), hipFree(c->ring_mem);
+    hipFree(c->tab_scratch), hipFree(c->gk_etab), hipFree(c->d_flag), hipFree(c->ring_mem), hipFree(c->ring_digest);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     hipFree(c->io_buf), hipFree(c->in_buf);
     for (int l = 0; l < ZK_MAX_LANES; l++) {
@@ -177,6 +177,14 @@ static zk_status set_ring_common(zk_ctx* c, const uint8_t* d_keys, uint64_t nkey
         HIPCHK(c, hipMalloc(&c->gk_etab, sizeof(uint32_t) * gk_etab_words(N)));
         launch_gk_etab(c->stream, ring, (uint32_t)(N >> 8), c->gk_etab);
     }
+    {   // digest of the padded ring: what the hardened mode hashes into the membership challenge
+        if (!c->ring_digest) HIPCHK(c, hipMalloc(&c->ring_digest, 32));
+        uint32_t* leaves = nullptr;
+        HIPCHK(c, hipMalloc(&leaves, 32 * ((N + 255) / 256)));
+        launch_ring_digest(c->stream, ring, N, leaves, c->ring_digest);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(leaves));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->N = N, c->n = n, c->nkeys = nkeys;
     c->ws_C = 0;  // the workspace layout depends on the ring
@@ -221,6 +229,21 @@ extern "C" zk_status zk_ctx_set_chunk(zk_ctx* c, uint32_t chunk) {
 extern "C" zk_status zk_ctx_set_batch_verify(zk_ctx* c, uint32_t min_chunk) {
     if (!c) return ZK_E_ARG;
     c->verify_batch_min = min_chunk;
+    return ZK_OK;
+}
+extern "C" zk_status zk_ctx_set_mode(zk_ctx* c, uint32_t mode) {
+    if (!c || (mode != ZK_MODE_REFERENCE && mode != ZK_MODE_HARDENED)) return ZK_E_ARG;
+    c->mode = mode;
+    return ZK_OK;
+}
+extern "C" zk_status zk_ring_digest(zk_ctx* c, uint8_t digest[32]) {
+    if (!c || !digest) return ZK_E_ARG;
+    if (!c->N || !c->ring_digest) return ZK_E_BUFFER;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t w[8];
+    HIPCHK(c, hipMemcpy(w, c->ring_digest, 32, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 4; j++) digest[4 * i + j] = (uint8_t)(w[i] >> (24 - 8 * j));
     return ZK_OK;
 }
 extern "C" zk_status zk_ctx_set_slice(zk_ctx* c, uint32_t proofs) {
@@ -315,6 +338,7 @@ zk_status ensure_workspace(zk_ctx* c, uint32_t C, uint32_t nlanes) {
             L.ready = true;
         }
         L.W.ring = Soa{c->ring_mem, (uint32_t)c->N};
+        L.W.hardened = c->mode == ZK_MODE_HARDENED, L.W.ring_digest = c->ring_digest;
     }
     return ZK_OK;
 }
@@ -532,7 +556,7 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
         }
         {
             Scope t(c, "hash", s);
-            launch_gk_hash(s, W, cnt);
+            launch_gk_hash(s, W, cnt, in.msg);
         }
         {
             Scope t(c, "respond_write", s);

@@ -30,7 +30,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
     V.slot_class = (uint8_t*)k.take(ns), V.slot_perm = (uint32_t*)k.take(4 * ns), V.slot_cnt = (uint32_t*)k.take(8 * (MSM_G + 1));
     V.gk_terms = terms((size_t)C * nq * 8);
     V.misc_terms = terms((size_t)C * 3);
-    V.slot_acc = soa4(ns), V.gk_acc = soa4((size_t)C * nq), V.misc_acc = soa4((size_t)C * 3);
+    V.slot_acc = soa4(ns * V_SLOT_SPLIT), V.gk_acc = soa4((size_t)C * nq), V.misc_acc = soa4((size_t)C * 3);
     V.sSg = k.soa(ns), V.sSh = k.soa(ns), V.sSkx = k.soa(ns), V.sSky = k.soa(ns), V.sSR = k.soa(ns), V.sSH = k.soa(ns), V.sSL = k.soa(ns);
     V.pSR = k.soa(C), V.pSH = k.soa(C), V.pSL = k.soa(C);
     V.pa_x = k.soa(ns), V.pa_y = k.soa(ns), V.pa_sc = k.soa(ns);
@@ -77,6 +77,7 @@ static zk_status ensure_vworkspace(zk_ctx* c, uint32_t C, uint32_t nlanes) {
         vcarve(L.V, L.res, L.res2, L.M, (uint8_t*)L.arena, C, sec, n, c->N);
         L.ready = true;
     }
+    for (uint32_t l = 0; l < nlanes && l < ZK_MAX_LANES; l++) c->vl[l].V.hardened = c->mode == ZK_MODE_HARDENED, c->vl[l].V.ring_digest = c->ring_digest;
     return ZK_OK;
 }
 
@@ -154,7 +155,7 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
         }
         {
             Scope t(c, "v_hash", s);
-            launch_v_challenges_sample(s, V, cnt, d_proofs, d_off, d_vseeds, first);
+            launch_v_challenges_sample(s, V, cnt, d_proofs, d_off, d_vseeds, d_msg, first);
         }
         {
             Scope t(c, "v_p256_exp_points", s);
@@ -189,7 +190,7 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
     };
     // Per-proof sums (windowed Straus + the two fixed-base commitments) of proofs [p0, p1) of a chunk: the unchanged kernels on
     // views of the term lists / accumulators that start at the range's first slot, gk group and proof.
-    auto per_proof_range = [&](hipStream_t s, const Workspace& W, const VWork& V, uint32_t p0, uint32_t p1, uint32_t range_no) {
+    auto per_proof_range = [&](hipStream_t s, const Workspace& W, const VWork& V, uint32_t p0, uint32_t p1, uint32_t range_no, uint32_t tsplit) {
         const uint32_t np = p1 - p0;
         auto terms_at = [](VTerms t, size_t o) {
             t.nx.p += o, t.ny.p += o, t.ndt.p += o, t.sc.p += o, t.tab += o * 8 * 36, t.dig += o;
@@ -205,7 +206,7 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
             uint32_t* perm = V.slot_perm + so;
             uint32_t* pc = V.slot_cnt + 2 * range_no;
             launch_v_slot_perm(s, V.slot_class + so, np * VK, perm, pc);
-            launch_v_straus(s, terms_at(V.slot_terms, so), np * VK, V.C * VK, 10, 26, acc_at(V.slot_acc, so), perm, pc);
+            launch_v_straus(s, terms_at(V.slot_terms, so), np * VK, V.C * VK, 10, 26, acc_at(V.slot_acc, so * V_SLOT_SPLIT), perm, pc, tsplit, V_SLOT_SPLIT);
             launch_v_straus(s, terms_at(V.gk_terms, (size_t)p0 * nq), np * nq, V.C * nq, 4, 4, acc_at(V.gk_acc, (size_t)p0 * nq), nullptr, nullptr);
             for (uint32_t k = 0; k < 3; k++)
                 launch_v_straus(s, terms_at(V.misc_terms, (size_t)k * V.C + p0), np, 3 * V.C, 1, 0, acc_at(V.misc_acc, (size_t)k * V.C + p0), nullptr, nullptr);
@@ -235,10 +236,11 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
                 return ZK_E_DEVICE;
             }
         } else {
-            for (auto& f : flags) f = 0;
-            HIPCHK(c, hipMemsetAsync(M.flag, 0, 4 * MSM_G, s));   // every proof goes through the per-proof sums
+            for (auto& f : flags) f = 0;   // every proof goes through the per-proof sums
         }
         uint32_t ranges = 0;
+        VGroupFlags gf;
+        for (uint32_t g = 0; g < MSM_G; g++) gf.v[g] = 1;
         for (uint32_t g = 0; g < MSM_G && (uint64_t)g * gsz < cnt;) {   // maximal runs of groups that failed
             if (flags[g]) {
                 g++;
@@ -246,12 +248,16 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
             }
             uint32_t g1 = g;
             while (g1 < MSM_G && (uint64_t)g1 * gsz < cnt && !flags[g1]) g1++;
-            per_proof_range(s, W, V, g * gsz, std::min<uint32_t>(cnt, g1 * gsz), ranges++);
+            const uint32_t p0 = g * gsz, p1 = std::min<uint32_t>(cnt, g1 * gsz);
+            // few slots: a slot's 36 terms over 4 lanes (the chain of one lane is ~12 ms long, the GPU is far from full)
+            const uint32_t tsplit = (uint64_t)(p1 - p0) * VK * V_SLOT_SPLIT <= 131072 ? V_SLOT_SPLIT : 1;
+            per_proof_range(s, W, V, p0, p1, ranges++, tsplit);
+            for (uint32_t k = g; k < g1; k++) gf.v[k] = V_RECHECK | tsplit;
             g = g1;
         }
         {
             Scope t(c, "v_final", s);
-            launch_v_final(s, P, W, V, cnt, d_ok, d_status, first, M.flag, gsz);
+            launch_v_final(s, P, W, V, cnt, d_ok, d_status, first, gf, gsz);
         }
         return ZK_OK;
     };

@@ -32,6 +32,8 @@ struct zk_ctx {
     bool gk_table = true;          // ZKATTEST_GK_TABLE=0 disables it (plain fold for every ring)
     uint64_t N = 0, nkeys = 0;
     uint32_t n = 0;
+    uint32_t* ring_digest = nullptr;   // [8] SHA-256 words of the padded ring (hardened mode), computed by every zk_ctx_set_ring
+    uint32_t mode = 0;                 // zk_ctx_set_mode: ZK_MODE_REFERENCE / ZK_MODE_HARDENED
     // workspace: up to ZK_MAX_LANES pipeline lanes, each with its own HIP stream and prover / verifier workspace; consecutive
     // chunks go to consecutive lanes, so the low-occupancy per-proof kernels, the scans the host waits for and (host-pointer
     // calls) the output phases of different chunks fall into each other's heavy phases.  Lane 0 runs on `stream`.

@@ -137,9 +137,19 @@ struct Workspace {
     uint32_t* gk_goff;           // [257] group offsets of that order
     Soa ring;                    // [N] plain canonical limbs (shared, owned by ctx)
     uint32_t N;
+    uint32_t hardened;           // zk_ctx_set_mode: the GK challenge also hashes the statement (ring digest, msgHash, R, keyXcom)
+    const uint32_t* ring_digest; // [8] SHA-256 words of the padded ring (k_hash.hip: launch_ring_digest), owned by ctx
     RngCtx rng;
 };
 
+// The batched Tom-256 check sums the relations of MSM_G contiguous groups of a chunk's proofs separately (same pass: the group
+// index rides on top of the 16-bit digit in the sort key): a forged proof only sends ITS group to the per-proof sums.
+#define MSM_G 8
+#define V_SLOT_SPLIT 4      // slot accumulators per checked repetition (k_v_straus: a slot's terms over up to 4 lanes)
+#define V_RECHECK 0x100u    // group flag: per-proof sums were computed, low byte = lanes per slot
+struct VGroupFlags {        // per group of a chunk: 1 = passed the batched check, V_RECHECK | tsplit otherwise (kernel argument of k_v_final)
+    uint32_t v[MSM_G];
+};
 // ------------------------------------------------------------------ verifier workspace
 #define VK 20             // reps checked by verifySignatureList (zkpAttestList.ts:177)
 #define V_SLOT_TERMS 36   // 10 x 256-bit + 26 x 128-bit terms per checked rep
@@ -154,6 +164,8 @@ struct VTerms {           // terms of the "sum s_i P_i = identity" checks: niels
 };
 struct VWork {
     uint32_t C, sec, n;
+    uint32_t hardened;           // as in Workspace
+    const uint32_t* ring_digest;
     int32_t* st;          // [C] structural status (deserialisation)
     int32_t* exp_st;      // [C] exceptions of verifyExp
     uint32_t* okflags;    // [C] bit 3: GKProof length mismatch (verifyMembership returns false)
@@ -184,7 +196,7 @@ struct VWork {
 };
 void launch_v_header_validate(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_front(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* msg, uint64_t first);
-void launch_v_challenges_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first);
+void launch_v_challenges_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, const uint8_t* msg, uint64_t first);
 void launch_v_exp_points(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_t1_scalars(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_derived(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
@@ -192,11 +204,11 @@ void launch_v_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, c
 void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, const uint32_t* etab, uint32_t count, uint32_t N, const uint8_t* proofs, const uint64_t* off, uint64_t first, const Soa& res, const Soa& res2);
 void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first);
 void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out,
-                     const uint32_t* perm, const uint32_t* cnt);
+                     const uint32_t* perm, const uint32_t* cnt, uint32_t tsplit = 1, uint32_t ostride = 1);
 void launch_v_slot_perm(hipStream_t s, const uint8_t* slot_class, uint32_t nslots, uint32_t* perm, uint32_t* cnt);
 void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count);
 void launch_v_final(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first,
-                    const uint32_t* grp_ok, uint32_t gsz);
+                    const VGroupFlags& gf, uint32_t gsz);
 
 // chunk inputs (device pointers, already offset to the chunk's first proof)
 struct ChunkIn {
@@ -207,9 +219,6 @@ struct ChunkIn {
     uint32_t count;   // proofs in this chunk
 };
 
-// The batched Tom-256 check sums the relations of MSM_G contiguous groups of a chunk's proofs separately (same pass: the group
-// index rides on top of the 16-bit digit in the sort key): a forged proof only sends ITS group to the per-proof sums.
-#define MSM_G 8
 // buffers of the batched Tom-256 check (k_msm.hip), one set per verifier lane
 struct MsmBuf {
     uint32_t cap;          // term ids
@@ -269,7 +278,8 @@ void launch_test_pfix(hipStream_t s, const uint32_t* tab, uint64_t count, const 
 void launch_rng_prepass(hipStream_t s, const Workspace& W, uint32_t count, uint32_t blk0, uint32_t blk1, uint32_t stride, uint32_t* fill, bool by_zcnt);
 void launch_exp_challenge(hipStream_t s, const Workspace& W, uint32_t count);
 void launch_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, uint32_t items);
-void launch_gk_hash(hipStream_t s, const Workspace& W, uint32_t count);
+void launch_gk_hash(hipStream_t s, const Workspace& W, uint32_t count, const uint8_t* msg);
+void launch_ring_digest(hipStream_t s, const Soa& ring, uint64_t N, uint32_t* leaf_words /*[8 * ceil(N/256)]*/, uint32_t* digest8);
 void launch_test_sha256(hipStream_t s, uint64_t count, uint64_t len, const uint8_t* d_msgs, uint8_t* d_out);
 void launch_test_rng(hipStream_t s, const RngCtx& g, uint64_t B, uint32_t first_k, uint32_t n_k, uint8_t* d_out);
 // k_scalar.hip

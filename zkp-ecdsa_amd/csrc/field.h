@@ -429,20 +429,25 @@ ZK_DEV Fe<M, K> fe_select(bool c, const Fe<M, K>& a, const Fe<M, K>& b) {  // c 
     return r;
 }
 
-// Montgomery-domain inverse by Fermat (a^(M-2)); inv(0) = 0 like the reference's invMod (big.ts:113-119).
+// a^e for a public exponent e given as 9 little-endian 32-bit words (right-to-left binary), Montgomery domain
 template <class M>
-ZK_DEV_NOINLINE Fe<M, 2> fe_inv(const Fe<M, 2>& a) {
+ZK_DEV_NOINLINE Fe<M, 2> fe_pow_words(const Fe<M, 2>& a, const uint32_t e[NLIMB]) {
     Fe<M, 2> acc = fe_one_mont<M>().template as<2>(), base = a;
     for (int w = 0; w < NLIMB; w++) {
-        uint32_t e = M::exp_m2[w];
+        uint32_t ew = e[w];
         int nb = M::bits - 32 * w;
         if (nb > 32) nb = 32;
         for (int b = 0; b < nb; b++) {
-            if ((e >> b) & 1) acc = acc * base;
+            if ((ew >> b) & 1) acc = acc * base;
             base = base * base;
         }
     }
     return acc;
+}
+// Montgomery-domain inverse by Fermat (a^(M-2)); inv(0) = 0 like the reference's invMod (big.ts:113-119).
+template <class M>
+ZK_DEV Fe<M, 2> fe_inv(const Fe<M, 2>& a) {
+    return fe_pow_words<M>(a, M::exp_m2);
 }
 
 // ---- plain 32-bit-word <-> 30-bit-limb conversions ----

@@ -141,7 +141,7 @@ void launch_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, uin
 }
 
 // ---------------------------------------------------------------- GK challenge x = H(cl || ca || cb || cd) (gk.ts:178-180)
-__global__ void __launch_bounds__(64) k_gk_hash(Workspace W, uint32_t count) {
+__global__ void __launch_bounds__(64) k_gk_hash(Workspace W, uint32_t count, const uint8_t* __restrict__ msg) {
     __shared__ uint32_t lds[16 * 64];
     uint32_t p = gtid();
     bool live = p < count;
@@ -149,13 +149,63 @@ __global__ void __launch_bounds__(64) k_gk_hash(Workspace W, uint32_t count) {
     ShaStream s;
     s.init(lds, threadIdx.x, 64);
     for (uint32_t k = 0; k < 4 * W.n; k++) absorb_tom(s, W.lc.ax, W.lc.ay, p * 4 * W.n + k);
+    if (W.hardened) {   // the statement: which ring, which message, which R, which committed key (gk.ts:178 TODO)
+        sha_put_gk_statement_head(s, W.ring_digest, msg + 32 * (size_t)p);
+        absorb_p256(s, W.Rx, W.Ry, p);
+        absorb_tom(s, W.la.ax, W.la.ay, p * (2 + 2 * W.sec));
+    }
     uint32_t h[8], c[4];
     s.finish(h);
     challenge_words(h, c);
     if (live) W.gk_x[3 * p] = c[0], W.gk_x[3 * p + 1] = c[1], W.gk_x[3 * p + 2] = c[2];
 }
-void launch_gk_hash(hipStream_t s, const Workspace& W, uint32_t count) {
-    hipLaunchKernelGGL(k_gk_hash, dim3((count + 63) / 64), dim3(64), 0, s, W, count);
+void launch_gk_hash(hipStream_t s, const Workspace& W, uint32_t count, const uint8_t* msg) {
+    hipLaunchKernelGGL(k_gk_hash, dim3((count + 63) / 64), dim3(64), 0, s, W, count, msg);
+}
+
+// ---------------------------------------------------------------- digest of the padded ring (hardened mode)
+// SHA-256("ZKAttest-ring-v1" || be64(N) || leaf_0 || leaf_1 || ...), leaf_i = SHA-256 of ring entries [256 i, 256 i + 256) as
+// 32-byte big-endian integers: one lane per leaf, then one lane over the leaf digests.
+__global__ void __launch_bounds__(64) k_ring_leaves(Soa ring, uint64_t N, uint32_t nleaves, uint32_t* leaf_words) {
+    __shared__ uint32_t lds[16 * 64];
+    uint32_t t = gtid();
+    bool live = t < nleaves;
+    if (!live) t = nleaves - 1;
+    ShaStream s;
+    s.init(lds, threadIdx.x, 64);
+    uint64_t e0 = (uint64_t)t * 256, e1 = e0 + 256 < N ? e0 + 256 : N;
+    // all lanes of a wave must absorb the same structure: a short last leaf only occurs when it is the only leaf (N < 256)
+    // or N is not a multiple of 256, which a padded ring (power of two) excludes for N >= 256
+    for (uint64_t e = e0; e < e1; e++) {
+        uint32_t w[8];
+        words_from_limbs<8>(w, soa_ld<ModQ, 1>(ring, (uint32_t)e).l);
+        s.put_be<32>(w);
+    }
+    uint32_t h[8];
+    s.finish(h);
+    if (live)
+        for (int i = 0; i < 8; i++) leaf_words[8 * t + i] = h[i];
+}
+__global__ void __launch_bounds__(64) k_ring_root(uint64_t N, uint32_t nleaves, const uint32_t* __restrict__ leaf_words, uint32_t* digest8) {
+    __shared__ uint32_t lds[16 * 64];
+    ShaStream s;
+    s.init(lds, threadIdx.x, 64);
+    if (threadIdx.x) return;
+    const char tag[] = "ZKAttest-ring-v1";
+    for (int i = 0; i < 16; i++) s.put_byte((uint8_t)tag[i]);
+    for (int i = 7; i >= 0; i--) s.put_byte((uint32_t)(N >> (8 * i)));
+    for (uint32_t l = 0; l < nleaves * 8; l++) {
+        uint32_t w = leaf_words[l];
+        s.put_byte(w >> 24), s.put_byte(w >> 16), s.put_byte(w >> 8), s.put_byte(w);
+    }
+    uint32_t h[8];
+    s.finish(h);
+    for (int i = 0; i < 8; i++) digest8[i] = h[i];
+}
+void launch_ring_digest(hipStream_t s, const Soa& ring, uint64_t N, uint32_t* leaf_words, uint32_t* digest8) {
+    uint32_t nleaves = (uint32_t)((N + 255) / 256);
+    hipLaunchKernelGGL(k_ring_leaves, dim3((nleaves + 63) / 64), dim3(64), 0, s, ring, N, nleaves, leaf_words);
+    hipLaunchKernelGGL(k_ring_root, dim3(1), dim3(64), 0, s, N, nleaves, leaf_words, digest8);
 }
 
 // ---------------------------------------------------------------- unit-test hooks

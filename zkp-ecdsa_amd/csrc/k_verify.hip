@@ -207,7 +207,7 @@ ZK_DEV void v_challenge_words(const uint32_t h[8], uint32_t c[4]) {
     c[0] = (h[1] << 16) | (h[2] >> 16), c[1] = (h[0] << 16) | (h[1] >> 16), c[2] = h[0] >> 16, c[3] = 0;
 }
 // Exp challenge over ALL reps (exp.ts:253-260) and the GK challenge x (gk.ts:220-221)
-__global__ void __launch_bounds__(64) k_v_challenges(VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+__global__ void __launch_bounds__(64) k_v_challenges(VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* __restrict__ msg, uint64_t first) {
     __shared__ uint32_t lds[16 * 64];
     uint32_t p = gtid();
     bool live = p < count;
@@ -236,6 +236,11 @@ __global__ void __launch_bounds__(64) k_v_challenges(VWork V, uint32_t count, co
     if (good) {
         const uint8_t* gk = v_gk_base(V, pr, p);
         for (uint32_t k = 0; k < 4 * V.n; k++) absorb_tom_bytes(s, gk + 72 * k);
+        if (V.hardened) {   // the statement binds the challenge (k_hash.hip: k_gk_hash)
+            sha_put_gk_statement_head(s, V.ring_digest, msg + 32 * (first + p));
+            absorb_p256_bytes(s, pr + 32);
+            absorb_tom_bytes(s, pr + 160);
+        }
     }
     s.finish(h);
     v_challenge_words(h, c);
@@ -944,21 +949,26 @@ ZK_DEV Fe<ModT, 4> ft_neg_sel(const Ft2& v, bool neg) {
 // scalars (windows 64..0), terms [n256, n256 + n128) 128-bit scalars (windows 32..0).  The remaining lanes (slots of
 // one-bit repetitions or of rejected proofs) only own the last two 128-bit terms, so they start at window 32 and add
 // two entries per window; sorting the slots keeps waves homogeneous.
+// tsplit > 1: a group's terms are dealt round-robin to tsplit lanes, each with its own accumulator (own doublings), written to
+// out[g * ostride + part]: a lane's chain of 65 windows x 36 additions is ~12 ms long on its own, so when only a few thousand
+// slots are re-checked (one failing group of the batched check) four short chains finish in a third of the time.
 __global__ void __launch_bounds__(256) k_v_straus(VTerms L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, Soa4 out,
-                                                  const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cnt) {
+                                                  const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cnt, uint32_t tsplit, uint32_t ostride) {
     uint32_t lane = gtid();
-    if (lane >= ngroups) return;
-    const uint32_t g = perm ? perm[lane] : lane;
-    const bool full = !perm || lane < cnt[0];
+    if (lane >= ngroups * tsplit) return;
+    const uint32_t gi = lane / tsplit, part = lane % tsplit;
+    const uint32_t g = perm ? perm[gi] : gi;
+    const bool full = !perm || gi < cnt[0];
     TomPt acc = tom_identity();
     const uint32_t nt = n256 + n128;
-    const uint32_t klo = full ? 0 : nt - 2;
+    const uint32_t klo = full ? part : nt - 2, kstep = full ? tsplit : 1;
+    const bool idle = !full && part != 0;   // a light slot's two terms stay with part 0
 #pragma unroll 1
-    for (int w = full && n256 ? VW_NW256 - 1 : VW_NW128 - 1; w >= 0; w--) {
+    for (int w = idle ? -1 : (full && n256 > part ? VW_NW256 - 1 : VW_NW128 - 1); w >= 0; w--) {
         acc = tom_dbl(tom_dbl(tom_dbl(tom_dbl(acc))));
         uint32_t kmax = w >= VW_NW128 ? n256 : nt;
 #pragma unroll 1
-        for (uint32_t k = klo; k < kmax; k++) {
+        for (uint32_t k = klo; k < kmax; k += kstep) {
             uint32_t idx = k * ng_stride + g;
             uint32_t db = L.dig[(size_t)w * L.cap + idx];
             uint32_t d = db & 15;
@@ -979,14 +989,15 @@ __global__ void __launch_bounds__(256) k_v_straus(VTerms L, uint32_t ngroups, ui
             acc.t = fe_select(on, s.t, acc.t), acc.z = fe_select(on, s.z, acc.z);
         }
     }
-    soa_st(out.x, g, acc.x), soa_st(out.y, g, acc.y), soa_st(out.z, g, acc.z), soa_st(out.t, g, acc.t);
+    const uint32_t o = g * ostride + part;
+    soa_st(out.x, o, acc.x), soa_st(out.y, o, acc.y), soa_st(out.z, o, acc.z), soa_st(out.t, o, acc.t);
 }
 void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out,
-                     const uint32_t* perm, const uint32_t* cnt) {
+                     const uint32_t* perm, const uint32_t* cnt, uint32_t tsplit, uint32_t ostride) {
     if (!ngroups) return;
     const uint32_t nterms = ngroups * (n256 + n128);
     hipLaunchKernelGGL(k_v_term_tables, dim3((nterms + 255) / 256), dim3(256), 0, s, L, ngroups, ng_stride, n256 + n128);
-    hipLaunchKernelGGL(k_v_straus, dim3((ngroups + 255) / 256), dim3(256), 0, s, L, ngroups, ng_stride, n256, n128, out, perm, cnt);
+    hipLaunchKernelGGL(k_v_straus, dim3((ngroups * tsplit + 255) / 256), dim3(256), 0, s, L, ngroups, ng_stride, n256, n128, out, perm, cnt, tsplit, ostride);
 }
 // P-256: sum of rho_j * (-A_j) over the 20 checked repetitions, 5 terms per thread, 128-bit randomisers.  Signed 4-bit
 // windows like the Tom side: every thread first recodes its scalars (33 digits in [-7, 8]) and builds {1A..8A} for its
@@ -1059,10 +1070,12 @@ ZK_DEV bool tom_is_identity(const TomPt& a) {  // edwards.ts:117-125 on the a=1 
 // grp_ok[p / gsz] != 0: the batched check (k_msm.hip) found the Tom-256 total of the proof's group to be the identity, i.e. the
 // membership and Exp/Tom sums of every proof of the group are (their per-proof accumulators were not computed)
 __global__ void __launch_bounds__(64, 2) k_v_final(DevParams P, Workspace W, VWork V, uint32_t count, uint8_t* ok_out, int32_t* status_out, uint64_t first,
-                                                   const uint32_t* __restrict__ grp_ok, uint32_t gsz) {
+                                                   VGroupFlags gf, uint32_t gsz) {
     uint32_t p = gtid();
     if (p >= count) return;
-    const bool tom_all_ok = grp_ok[p / gsz] != 0;
+    const uint32_t flag = gf.v[p / gsz];          // 1: the group passed the batched check; else V_RECHECK | tsplit of its slot sums
+    const bool tom_all_ok = flag == 1;
+    const uint32_t tsplit = flag & 0xff;
     int32_t st = V.st[p];  // structural errors; W.st additionally carries a late "T is at infinity"
     uint8_t ok = 0;
     if (V.st[p] == ZK_OK && !(V.okflags[p] & 8)) {
@@ -1084,7 +1097,8 @@ __global__ void __launch_bounds__(64, 2) k_v_final(DevParams P, Workspace W, VWo
                 bool okW = true;
                 if (!tom_all_ok) {
                     TomPt e = ld_tom_proj3(W.lc.proj, p * 4 * n + 1);
-                    for (uint32_t j = 0; j < VK; j++) e = tom_add(e, ld_tom4(V.slot_acc, p * VK + j));
+                    for (uint32_t j = 0; j < VK; j++)
+                        for (uint32_t q = 0; q < tsplit; q++) e = tom_add(e, ld_tom4(V.slot_acc, (p * VK + j) * V_SLOT_SPLIT + q));
                     e = tom_add(e, ld_tom4(V.misc_acc, 1 * V.C + p));
                     e = tom_add(e, ld_tom4(V.misc_acc, 2 * V.C + p));
                     okW = tom_is_identity(e);
@@ -1161,8 +1175,8 @@ void launch_v_front(hipStream_t s, const DevParams& P, const Workspace& W, const
     L1(k_v_front, count, 64, P, W, V, count, proofs, off, msg, first);
     L1(k_v_clambda, count, 64, V, count, proofs, off, first);
 }
-void launch_v_challenges_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
-    L1(k_v_challenges, count, 64, V, count, proofs, off, first);
+void launch_v_challenges_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, const uint8_t* msg, uint64_t first) {
+    L1(k_v_challenges, count, 64, V, count, proofs, off, msg, first);
     L1(k_v_sample_fills, count * VS_KMAX, 256, V, count, vseeds, first);
     L1(k_v_sample, count, 64, V, count, vseeds, first);
 }
@@ -1184,6 +1198,6 @@ void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t 
 }
 void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count) { L1(k_v_p256_straus, count * 4, 256, V, count); }
 void launch_v_final(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first,
-                    const uint32_t* grp_ok, uint32_t gsz) {
-    L1(k_v_final, count, 64, P, W, V, count, ok, status, first, grp_ok, gsz);
+                    const VGroupFlags& gf, uint32_t gsz) {
+    L1(k_v_final, count, 64, P, W, V, count, ok, status, first, gf, gsz);
 }

@@ -96,3 +96,19 @@ struct ShaStream {
         for (int i = 0; i < 8; i++) out[i] = h.v[i];
     }
 };
+
+// Hardened mode (include/zkattest.h, zk_ctx_set_mode): bytes appended to the Groth-Kohlweiss transcript before the points'
+// hash is finished -- tag || ring digest || msgHash; the caller then absorbs R and keyXcom in their hashPoints encodings.
+ZK_DEV void sha_put_gk_statement_head(ShaStream& s, const uint32_t* ring_digest8, const uint8_t* msg32) {
+    const char tag[] = "ZKAttest-GK-statement-v1";
+#pragma unroll 1
+    for (int i = 0; i < 24; i++) s.put_byte((uint8_t)tag[i]);
+#pragma unroll 1
+    for (int i = 0; i < 8; i++) {
+        uint32_t w = ring_digest8[i];
+        s.put_byte(w >> 24), s.put_byte(w >> 16), s.put_byte(w >> 8), s.put_byte(w);
+    }
+#pragma unroll 1
+    for (int i = 0; i < 32; i++) s.put_byte(msg32[i]);
+}
+

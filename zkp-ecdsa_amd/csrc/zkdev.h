@@ -1,7 +1,8 @@
 // Function qualifiers of the per-lane device code.  The product compiles these headers with hipcc for gfx950 only.
 // tests/host_arith defines ZK_HOST_BUILD and compiles the SAME headers (field.h, curve.h, sha256.h, rng.h) with g++ for the host
 // CPU, so that the CPU test tier exercises this source against the oracle; the opaque-operand asm statements of field.h and the
-// AMDGPU builtins are switched off / replaced by their portable definitions there.  No product code defines ZK_HOST_BUILD.
+// AMDGPU builtins are switched off / replaced by their portable definitions there.  One product unit is built that way too: h2c_host.cpp, the
+// one-time host-side derivation of the hardened mode's generators (no kernel involved).
 #pragma once
 #include <stdint.h>
 #ifdef ZK_HOST_BUILD
