@@ -22,6 +22,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP maps its streams onto 4 hardware queues by default; the engine's lanes and copy streams want their own (csrc/api.hip,
+# zk_ctx_create).  Must be in the environment before the first HIP call of the process, i.e. before torch touches the device.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 # measured on MI355X with tools/valu_peak.hip (profiles/r01_valu_peak_microbench.txt): v_mad_u64_u32 chip-wide issue rate
 # at 16 independent accumulators x 8 waves/SIMD (4.2 cycles per wave-instruction; 39.3 T/s would be 16 lanes/clk at 2.4 GHz);
@@ -143,10 +146,10 @@ def host_io_rates(Z, eng, args, B, sec, msg, sig, pk, which, seeds, dev, device_
     the roofline of these calls is the link: `pcie_frac` = achieved GB/s / this box's measured page-locked copy rate."""
     nb = min(args.host_io, B)
     hm, hs, hp, hw, hseed = msg[:32 * nb], sig[:64 * nb], pk[:64 * nb], which[:nb], seeds[:32 * nb]
-    chunk = min(args.host_io_chunk, nb)
+    chunk, vchunk = min(args.host_io_chunk, nb), min(args.host_io_verify_chunk, nb)
     eng.set_chunk(chunk)
     eng.prove_batch_host_raw(hm[:32 * 256], hs[:64 * 256], hp[:64 * 256], hw[:256], hseed[:32 * 256])   # warm-up
-    host_io = {'proofs': nb, 'chunk': chunk, 'plan': 'tapered' if not args.host_io_uniform else 'uniform',
+    host_io = {'proofs': nb, 'chunk': chunk, 'verify_chunk': vchunk, 'plan': 'staggered lanes, sliced PointAdd phase' if not args.host_io_uniform else 'uniform chunks',
                'note': 'PCIe-inclusive: one zk_prove_batch / zk_verify_batch call on host buffers (SURVEY.md 8(d)); `value` is the device-resident rate'}
     eng.set_host_taper(0 if args.host_io_uniform else 1)
     host_io['pcie'] = pcie_bandwidth(dev)
@@ -159,7 +162,9 @@ def host_io_rates(Z, eng, args, B, sec, msg, sig, pk, which, seeds, dev, device_
     for name, buf in bufs:
         best_p, best_v = None, None
         for _ in range(args.host_io_reps + 1):  # the first call allocates the engine's staging buffers (kept afterwards)
+            eng.set_chunk(chunk)
             hdt, hout, hoff, hst = eng.prove_batch_host_raw(hm, hs, hp, hw, hseed, out=buf)
+            eng.set_chunk(vchunk)
             vdt, vok, vst = eng.verify_batch_host_raw(hm, hout, hoff, nb)
             if _ > 0:
                 best_p = hdt if best_p is None else min(best_p, hdt)
@@ -316,7 +321,8 @@ def main():
     ap.add_argument('--roofline-steps', type=int, default=1, help='extra single-lane passes used only for per-kernel timings')
     ap.add_argument('--verify-steps', type=int, default=1, help='timed verifySignatureList passes over the produced proofs (0 = skip)')
     ap.add_argument('--host-io', type=int, default=1 << 30, help='proofs of the zk_prove_batch / zk_verify_batch calls on HOST buffers (PCIe-inclusive rates; default: the whole batch; 0 = skip)')
-    ap.add_argument('--host-io-chunk', type=int, default=4096, help='largest chunk of the (tapered) plan during the --host-io calls')
+    ap.add_argument('--host-io-chunk', type=int, default=16384, help='proofs per chunk of the zk_prove_batch --host-io calls (the PointAdd phase of a chunk runs in slices of 4096 proofs, each followed by its D2H)')
+    ap.add_argument('--host-io-verify-chunk', type=int, default=8192, help='proofs per chunk of the zk_verify_batch --host-io calls (H2D-bound: smaller chunks start earlier and leave less work behind the last transfer)')
     ap.add_argument('--host-io-reps', type=int, default=2, help='timed repetitions of the host-buffer calls (best is reported)')
     ap.add_argument('--host-io-uniform', action='store_true', help='uniform chunks instead of the tapered plan')
     ap.add_argument('--host-io-pageable', action='store_true', help='also measure ordinary (pageable) host buffers')

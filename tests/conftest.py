@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # see zkp-ecdsa_amd/csrc/api.hip: zk_ctx_create
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'oracle')):
     if p not in sys.path:

@@ -59,7 +59,7 @@ def test_hardened_prove_and_verify_match_the_restatement(nkeys, sec):
         R.PedersenParams(R.p256, R.p256.generator(), R.WeierstrassPoint(R.p256, int.from_bytes(nh[:32], 'big'), int.from_bytes(nh[32:], 'big'), 1)),
         R.PedersenParams(R.tomEdwards256, g, R.TEdwardsPoint(R.tomEdwards256, int.from_bytes(th[:36], 'big'), int.from_bytes(th[36:], 'big'))), sec)
     for b in range(B):
-        args = (msg[32 * b:32 * b + 32], sig[64 * b:64 * b + 64], b'\\x04' + pk[64 * b:64 * b + 64], which[b], keys)
+        args = (msg[32 * b:32 * b + 32], sig[64 * b:64 * b + 64], b'\x04' + pk[64 * b:64 * b + 64], which[b], keys)
         want = R.proof_to_bytes(R.proveSignatureList(params, *args, R.SeedRng(seeds[32 * b:32 * b + 32]), hardened=True))
         assert hard[b] == want
         assert ref[b] == R.proof_to_bytes(R.proveSignatureList(params, *args, R.SeedRng(seeds[32 * b:32 * b + 32])))

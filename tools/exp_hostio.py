@@ -6,6 +6,7 @@ import argparse
 import json
 import os
 import sys
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,6 +20,7 @@ def main():
     ap.add_argument('--comb-bits', type=int, default=24)
     ap.add_argument('--chunks', default='8192,16384')
     ap.add_argument('--lanes', default='2,3,4')
+    ap.add_argument('--tapers', default='1')
     args = ap.parse_args()
     import torch
     import zkp_ecdsa_amd as Z
@@ -44,8 +46,8 @@ def main():
     pin = Z.PinnedBuffer(cap)
     for lanes in [int(x) for x in args.lanes.split(',')]:
         eng.set_lanes(lanes)
-        for c in [int(x) for x in args.chunks.split(',')]:
-            eng.set_chunk(min(c, B))
+        for c, taper in [(int(x), int(y)) for x in args.chunks.split(',') for y in args.tapers.split(',')]:
+            eng.set_chunk(min(c, B)), eng.set_host_taper(taper)
             r = {}
             for name, f in (('prove', lambda: eng.prove_batch_device(B, d_msg.data_ptr(), d_sig.data_ptr(), d_pk.data_ptr(), d_which.data_ptr(), d_seeds.data_ptr(),
                                                                     d_out.data_ptr(), cap, d_off.data_ptr(), d_st.data_ptr())),
@@ -66,8 +68,8 @@ def main():
             r.update({'host_prove': round(B / best[0]), 'host_verify': round(B / best[1]), 'd2h_gbps': round(nbytes / best[0] / 1e9, 1), 'h2d_gbps': round(nbytes / best[1] / 1e9, 1),
                       'accepted': int(sum(ok)), 'failed': int(sum(1 for x in st if x)), 'prove_frac': round(B / best[0] / r['prove'], 3),
                       'hbm_gb': round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 2**30, 1)})
-            res['device']['%dx%d' % (lanes, c)] = r
-            print('lanes', lanes, 'chunk', c, r, flush=True)
+            res['device']['%dx%d/%d' % (lanes, c, taper)] = r
+            print('lanes', lanes, 'chunk', c, 'stagger', taper, r, flush=True)
     print(json.dumps(res))
 
 

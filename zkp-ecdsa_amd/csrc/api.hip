@@ -2,6 +2,7 @@
 // One context = one GPU = one HIP stream.  A batch is processed in chunks of `chunk` proofs; every phase of a chunk
 // is one kernel over all proofs (or all zero-bit reps) of the chunk -- see DESIGN.md for the phase list.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -39,14 +40,27 @@ extern "C" const char* zk_strerror(zk_status s) {
 }
 extern "C" const char* zk_last_error(const zk_ctx* c) { return c ? c->err.c_str() : ""; }
 
+// HIP multiplexes its streams onto a few hardware queues, round-robin in creation order (GPU_MAX_HW_QUEUES, default 4; measured
+// with tools/stream_overlap.hip: of eight streams, numbers 3 and 7 queue behind number 0).  Two streams on one hardware queue
+// run strictly one after the other, and a "wait for that event" of a copy stream stalls every compute kernel queued behind it:
+// with carelessly created streams the two lanes of a context executed serially.  So (1) the library asks for 8 hardware queues
+// when it is loaded before the HIP runtime starts (it cannot change a runtime that is already up: a host that initialises HIP
+// first -- bench.py imports torch -- exports GPU_MAX_HW_QUEUES itself), and (2) a context creates all its streams in one go, in
+// an order that gives the first two lanes and their copy streams four different queues even with the default of 4.
+__attribute__((constructor)) static void zk_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 extern "C" zk_status zk_ctx_create(int device_id, zk_ctx** out) {
     if (!out) return ZK_E_ARG;
     zk_ctx* c = new zk_ctx();
     c->device = device_id;
     *out = c;
     HIPCHK(c, hipSetDevice(device_id));
-    HIPCHK(c, hipStreamCreate(&c->stream));
-    c->pl[0].stream = c->stream;
+    for (int base = 0; base < ZK_MAX_LANES; base += 2) {   // compute 0, compute 1, copy 0, copy 1; then the same for lanes 2, 3
+        for (int l = base; l < base + 2; l++) HIPCHK(c, hipStreamCreate(&c->pl[l].stream));
+        for (int l = base; l < base + 2; l++) HIPCHK(c, hipStreamCreateWithFlags(&c->pl[l].copy_stream, hipStreamNonBlocking));
+    }
+    c->stream = c->pl[0].stream;
+    c->copy_stream = c->pl[0].copy_stream;   // H2D of the verifier's proofs
     if (const char* e = getenv("ZKATTEST_COMB_BITS")) {
         int b = atoi(e);
         if (b >= 8 && b <= TOM_MAX_BITS) c->tom_bits = (uint32_t)b;
@@ -63,7 +77,6 @@ extern "C" zk_status zk_ctx_create(int device_id, zk_ctx** out) {
     c->scratch_words = std::max(pfix_table_scratch_words(), tom_table_scratch_words(TOM_MAX_BITS));
     HIPCHK(c, hipMalloc(&c->tab_scratch, sizeof(uint32_t) * c->scratch_words));
     HIPCHK(c, hipMalloc(&c->d_flag, 64));
-    HIPCHK(c, hipMalloc(&c->pl[0].d_totals, 64));
     int32_t one = 1;
     HIPCHK(c, hipMemcpyAsync(c->d_flag, &one, 4, hipMemcpyHostToDevice, c->stream));
     // tables that do not depend on the parameters: P-256 generator, Tom generator (8-bit comb: only zk_synth_params uses it)
@@ -91,15 +104,15 @@ extern "C" void zk_ctx_destroy(zk_ctx* c) {
     for (auto e : c->epool) hipEventDestroy(e);
     hipFree(c->P.tom_tab_g), hipFree(c->P.tom_tab_h), hipFree(c->tom_tab_gen), hipFree(c->P.pfix_G), hipFree(c->P.pfix_H);
     hipFree(c->tab_scratch), hipFree(c->gk_etab), hipFree(c->d_flag), hipFree(c->ring_mem), hipFree(c->ring_digest);
-    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     hipFree(c->io_buf), hipFree(c->in_buf);
     for (int l = 0; l < ZK_MAX_LANES; l++) {
         hipFree(c->pl[l].arena), hipFree(c->pl[l].d_totals), hipFree(c->vl[l].arena);
+        if (c->pl[l].h_scan) hipHostFree(c->pl[l].h_scan);
+        if (c->vl[l].h_msm) hipHostFree(c->vl[l].h_msm);
         if (c->pl[l].copy_ev) hipEventDestroy(c->pl[l].copy_ev);
         if (c->pl[l].copy_stream) hipStreamDestroy(c->pl[l].copy_stream);
-        if (l && c->pl[l].stream) hipStreamDestroy(c->pl[l].stream);
+        if (c->pl[l].stream) hipStreamDestroy(c->pl[l].stream);
     }
-    if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -333,8 +346,14 @@ zk_status ensure_workspace(zk_ctx* c, uint32_t C, uint32_t nlanes) {
                 L.arena_bytes = need;
             }
             carve(c, L.W, L.gk_am, (uint8_t*)L.arena, C, sec, n, c->N);
-            if (!L.stream) HIPCHK(c, hipStreamCreate(&L.stream));
             if (!L.d_totals) HIPCHK(c, hipMalloc(&L.d_totals, 64));
+            const size_t hs = 64 + 16 * ((size_t)C + 2);
+            if (hs > L.h_scan_bytes) {
+                if (L.h_scan) HIPCHK(c, hipHostFree(L.h_scan));
+                L.h_scan = nullptr, L.h_scan_bytes = 0;
+                HIPCHK(c, hipHostMalloc(&L.h_scan, hs, hipHostMallocMapped | hipHostMallocCoherent));
+                L.h_scan_bytes = hs;
+            }
             L.ready = true;
         }
         L.W.ring = Soa{c->ring_mem, (uint32_t)c->N};
@@ -383,12 +402,9 @@ zk_status ensure_in_buf(zk_ctx* c, size_t bytes) {
     c->in_bytes = bytes;
     return ZK_OK;
 }
-zk_status ensure_copy_stream(zk_ctx* c) {
-    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    for (auto& L : c->pl) {
+zk_status ensure_copy_stream(zk_ctx* c) {   // the streams exist since zk_ctx_create; their events are made on first use
+    for (auto& L : c->pl)
         if (!L.copy_ev) HIPCHK(c, hipEventCreateWithFlags(&L.copy_ev, hipEventDisableTiming));
-        if (!L.copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&L.copy_stream, hipStreamNonBlocking));
-    }
     return ZK_OK;
 }
 
@@ -417,6 +433,21 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
     // the scan, which needs the output cursor, i.e. the byte count of all earlier chunks, and the host has to read the
     // item count back before it can size the PointAdd launches.  With two lanes, stage 1 of chunk k+1 is enqueued on the
     // other stream BEFORE the host blocks on chunk k's scan, so neither stream runs dry while the host waits.
+    // ZK_IO_DEBUG=1: timeline of the D2H slices on stderr (ready / copy start / copy end in ms since the call began)
+    struct IoRec {
+        hipEvent_t ready, c0, c1;
+        uint64_t bytes;
+        uint32_t chunk, lane;
+    };
+    std::vector<IoRec> iorecs;
+    hipEvent_t io_t0 = nullptr;
+    const bool io_dbg = host_sink && getenv("ZK_IO_DEBUG");
+    auto host_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double host_t0 = host_ms();
+    if (io_dbg) {
+        hipEventCreate(&io_t0);
+        hipEventRecord(io_t0, c->stream);
+    }
     auto sync_lanes = [&]() -> hipError_t {
         hipError_t r = hipSuccess;
         for (uint32_t l = 0; l < NL; l++) {
@@ -439,12 +470,14 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
         hipStream_t s = c->pl[lane].stream;
         const uint64_t first = cp.first;
         const uint32_t cnt = cp.cnt;
+        if (io_dbg) fprintf(stderr, "host %7.1f ms: stage1 of chunk %u (%u proofs) -> lane %u\n", host_ms() - host_t0, chunk_no, cnt, lane);
         ChunkIn in{d_msg + 32 * first, d_sig + 64 * first, d_pk + 64 * first, d_which + first, cnt};
         W.rng.seeds = d_rng, W.rng.stream = d_rng, W.rng.stride_blocks = stride, W.rng.mode = rng_mode, W.rng.sec = (int)W.sec;
         W.rng.proof_base = (uint32_t)first;
         uint32_t nblk = 3 + 44 * W.sec + 5 * W.n + RNG_MAX_EXC;
         {
             Scope t(c, "rng_prepass", s);
+            if (io_dbg) fprintf(stderr, "host %7.1f ms:   enqueue rng_prepass\n", host_ms() - host_t0);
             launch_rng_prepass(s, W, cnt, 0, 3 + 4 * W.sec + RNG_MAX_EXC, nblk, rng_mode == 0 ? W.rng_fill : nullptr, false);  // + margin: rejected fills shift later draws
         }
         Workspace Wgen = W;  // RNG view of the generator (seed mode) for the second prepass stage
@@ -452,36 +485,44 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
             W.rng.mode = 1, W.rng.stream = (const uint8_t*)W.rng_fill, W.rng.stride_blocks = nblk, W.rng.proof_base = 0;
         {
             Scope t(c, "p256_front", s);
+            if (io_dbg) fprintf(stderr, "host %7.1f ms:   enqueue p256_front\n", host_ms() - host_t0);
             launch_front(s, P, W, in);
         }
         {
             Scope t(c, "p256_rtab", s);
+            if (io_dbg) fprintf(stderr, "host %7.1f ms:   enqueue p256_rtab\n", host_ms() - host_t0);
             launch_rtab(s, W, cnt, RTAB_PROVE_BITS);
         }
         {
             Scope t(c, "p256_exp_commit", s);
+            if (io_dbg) fprintf(stderr, "host %7.1f ms:   enqueue p256_exp_commit\n", host_ms() - host_t0);
             launch_exp_commit(s, P, W, cnt);
         }
         {
             Scope t(c, "p256_normalize", s);
+            if (io_dbg) fprintf(stderr, "host %7.1f ms:   enqueue p256_normalize\n", host_ms() - host_t0);
             launch_p256_normalize(s, W.Tproj, cnt * (W.sec + 1), W.Tx, W.Ty, W.st, W.sec + 1, ZK_ST_T_INF_LATE, nullptr);
             launch_p256_normalize(s, W.Aproj, cnt * (W.sec + 1), W.Ax, W.Ay, W.st, W.sec + 1, 0, nullptr);
         }
         uint32_t na = cnt * (2 + 2 * W.sec);
         {
             Scope t(c, "scalars", s);
+            if (io_dbg) fprintf(stderr, "host %7.1f ms:   enqueue scalars\n", host_ms() - host_t0);
             launch_lista_scalars(s, W, cnt);
         }
         {
             Scope t(c, "tom_commit", s);
+            if (io_dbg) fprintf(stderr, "host %7.1f ms:   enqueue tom_commit\n", host_ms() - host_t0);
             launch_tom_commit(s, P, W.la, na, 1, 1);
         }
         {
             Scope t(c, "tom_normalize", s);
+            if (io_dbg) fprintf(stderr, "host %7.1f ms:   enqueue tom_normalize\n", host_ms() - host_t0);
             launch_tom_normalize(s, W.la, na, 0, 1, 1);
         }
         {
             Scope t(c, "hash", s);
+            if (io_dbg) fprintf(stderr, "host %7.1f ms:   enqueue hash\n", host_ms() - host_t0);
             launch_exp_challenge(s, W, cnt);
         }
         pd.lane = lane, pd.cnt = cnt, pd.first = first, pd.in = in, pd.Wgen = Wgen, pd.nblk = nblk;
@@ -501,20 +542,25 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
         const uint64_t first = pd.first;
         const ChunkIn& in = pd.in;
         const Workspace& Wgen = pd.Wgen;
-        uint32_t totals[4];
+        // page-locked read-back area of the lane: totals, then the prefix sums the slices need
+        uint32_t* totals = (uint32_t*)c->pl[pd.lane].h_scan;
+        uint64_t* h_out_base = (uint64_t*)((uint8_t*)c->pl[pd.lane].h_scan + 64);
+        uint32_t* h_item_base = (uint32_t*)(h_out_base + (size_t)C + 2);
         {
             Scope t(c, "scan", s);
             launch_scan(s, W, cnt, cursor, out_cap, d_out_off, d_status, d_totals, first);
         }
         const uint32_t S = c->slice ? c->slice : (host_sink ? 4096u : 0u);
         const bool sliced = S && cnt > S;
-        HIPCHK(c, hipMemcpyAsync(totals, d_totals, 16, hipMemcpyDeviceToHost, s));
+        const bool last_chunk = first + cnt == B;
+        launch_words_to_host(s, totals, d_totals, 4);
         if (sliced) {   // slice boundaries: the chunk's item and byte prefix sums
-            c->h_item_base.resize((size_t)cnt + 1), c->h_out_base.resize((size_t)cnt + 1);
-            HIPCHK(c, hipMemcpyAsync(c->h_item_base.data(), W.item_base, 4 * ((size_t)cnt + 1), hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipMemcpyAsync(c->h_out_base.data(), W.out_base, 8 * ((size_t)cnt + 1), hipMemcpyDeviceToHost, s));
+            launch_words_to_host(s, h_item_base, W.item_base, (size_t)cnt + 1);
+            launch_words_to_host(s, h_out_base, W.out_base, 2 * ((size_t)cnt + 1));
         }
+        if (io_dbg) fprintf(stderr, "host %7.1f ms: stage2 lane %u waits for its scan\n", host_ms() - host_t0, pd.lane);
         HIPCHK(c, hipStreamSynchronize(s));
+        if (io_dbg) fprintf(stderr, "host %7.1f ms: scan done\n", host_ms() - host_t0);
         if (totals[1]) {
             c->err = "output buffer too small";
             sync_lanes();
@@ -563,11 +609,11 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
             launch_gk_respond(s, W, in, out);
         }
         std::vector<ChunkPlan> slices;
-        if (sliced) slices = make_chunk_plan(cnt, S, 1, host_sink != nullptr, ZK_SLICE_MIN);
+        if (sliced) slices = make_chunk_plan(cnt, S, 1, host_sink != nullptr, last_chunk ? ZK_SLICE_MIN / 2 : ZK_SLICE_MIN);   // the call's very last slices stay exposed
         else slices.push_back({0, cnt});
         for (const ChunkPlan& sl : slices) {
             const uint32_t p0 = (uint32_t)sl.first, p1 = p0 + sl.cnt;
-            const uint32_t i0 = sliced ? c->h_item_base[p0] : 0, i1 = sliced ? c->h_item_base[p1] : items_all;
+            const uint32_t i0 = sliced ? h_item_base[p0] : 0, i1 = sliced ? h_item_base[p1] : items_all;
             const uint32_t items = i1 - i0;
             if (items) {
                 Workspace Ws = W;   // the slice's view: item-indexed arrays start at item i0
@@ -611,12 +657,23 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
                 }
             }
             if (host_sink) {   // every byte of proofs [p0, p1) is final: DMA them out behind the next slice's kernels
-                const uint64_t b0 = sliced ? c->h_out_base[p0] : 0, b1 = sliced ? c->h_out_base[p1] : chunk_bytes;
+                const uint64_t b0 = sliced ? h_out_base[p0] : 0, b1 = sliced ? h_out_base[p1] : chunk_bytes;
                 if (b1 > b0) {
                     hipEvent_t ev = c->pl[pd.lane].copy_ev;
+                    IoRec r{};
+                    if (io_dbg) {
+                        hipEventCreate(&r.ready), hipEventCreate(&r.c0), hipEventCreate(&r.c1);
+                        r.bytes = b1 - b0, r.chunk = (uint32_t)(first / (C ? C : 1)), r.lane = pd.lane;
+                        hipEventRecord(r.ready, s);
+                    }
                     HIPCHK(c, hipEventRecord(ev, s));
                     HIPCHK(c, hipStreamWaitEvent(c->pl[pd.lane].copy_stream, ev, 0));
+                    if (io_dbg) hipEventRecord(r.c0, c->pl[pd.lane].copy_stream);
                     HIPCHK(c, hipMemcpyAsync(host_sink + cursor + b0, out + b0, b1 - b0, hipMemcpyDeviceToHost, c->pl[pd.lane].copy_stream));
+                    if (io_dbg) {
+                        hipEventRecord(r.c1, c->pl[pd.lane].copy_stream);
+                        iorecs.push_back(r);
+                    }
                 }
             }
         }
@@ -625,6 +682,7 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
             launch_status_out(s, W, cnt, d_status, first);   // late (cryptographically negligible) errors included: after the last slice
         }
         cursor += chunk_bytes;
+        if (io_dbg) fprintf(stderr, "host %7.1f ms: stage2 lane %u enqueued\n", host_ms() - host_t0, pd.lane);
         return ZK_OK;
     };
     const uint64_t nchunks = plan.size();
@@ -644,6 +702,21 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
             hipError_t e2 = hipStreamSynchronize(c->pl[l].copy_stream);
             if (e_sync == hipSuccess) e_sync = e2;
         }
+    if (io_dbg) {
+        for (auto& r : iorecs) {
+            float a = 0, b = 0, d = 0;
+            hipEventElapsedTime(&a, io_t0, r.ready), hipEventElapsedTime(&b, io_t0, r.c0), hipEventElapsedTime(&d, io_t0, r.c1);
+            fprintf(stderr, "io: first-proof-block %4u lane %u  %8.1f MB  ready %7.1f  copy %7.1f .. %7.1f ms  (%5.1f GB/s)\n", r.chunk, r.lane, r.bytes / 1e6, a, b, d,
+                    r.bytes / 1e6 / (d - b > 1e-3 ? d - b : 1e-3));
+            hipEventDestroy(r.ready), hipEventDestroy(r.c0), hipEventDestroy(r.c1);
+        }
+        for (auto& r : c->trecs) {   // every timed scope of the call, in enqueue order
+            float a = 0, b = 0;
+            hipEventElapsedTime(&a, io_t0, r.e0), hipEventElapsedTime(&b, io_t0, r.e1);
+            fprintf(stderr, "gpu: %-16s %7.1f .. %7.1f ms\n", r.name, a, b);
+        }
+        hipEventDestroy(io_t0);
+    }
     if (zs) return zs;
     HIPCHK(c, e_sync);
     HIPCHK(c, hipGetLastError());

@@ -47,6 +47,9 @@ struct zk_ctx {
         void* arena = nullptr;
         size_t arena_bytes = 0;
         bool ready = false;
+        void* h_scan = nullptr;         // page-locked: the chunk's totals (4 x u32), item prefix sums (u32[C+1]) and byte prefix sums
+        size_t h_scan_bytes = 0;        // (u64[C+1]) read back after the scan.  Pageable destinations made the runtime wait for
+                                        // EVERY stream of the device (measured: the host sat 50 ms behind the other lane's kernels)
         hipEvent_t copy_ev = nullptr;   // host-buffer entry points: "this lane's bytes are final" for the lane's copy stream
         hipStream_t copy_stream = nullptr;   // D2H of this lane's finished slices: one stream per lane, so a lane whose slices
                                              // are ready never queues behind the unfinished slices of another (FIFO per stream)
@@ -59,6 +62,7 @@ struct zk_ctx {
         size_t arena_bytes = 0;
         Soa res{}, res2{};
         MsmBuf M{};               // batched Tom check buffers (k_msm.hip), carved with V
+        uint32_t* h_msm = nullptr;   // page-locked read-back words of run_msm
         bool ready = false;
     } vl[ZK_MAX_LANES];
     uint32_t vs_C = 0, vs_sec = 0, vs_n = 0;
@@ -71,8 +75,6 @@ struct zk_ctx {
     size_t in_bytes = 0;           // offsets, statuses, verdicts), grow-only for the same reason
     uint32_t host_taper = 1;       // host-pointer calls on page-locked buffers: tapered chunk plan (zk_ctx_set_host_taper)
     uint32_t slice = 0;            // proofs per PointAdd slice of the prover (zk_ctx_set_slice): 0 = 4096 with a page-locked sink, else none
-    std::vector<uint32_t> h_item_base;   // host copies of a chunk's item / byte prefix sums (slice boundaries)
-    std::vector<uint64_t> h_out_base;
     // timing
     std::vector<TimerRec> trecs;
     std::vector<hipEvent_t> epool;
@@ -164,7 +166,7 @@ struct ChunkPlan {
 static inline std::vector<ChunkPlan> make_chunk_plan(uint64_t B, uint32_t C, uint32_t stagger, bool tail, uint32_t lo = ZK_TAPER_MIN) {
     std::vector<uint32_t> sizes, tl;
     uint64_t left = B;
-    if (tail && C >= 2 * lo && B >= 3ull * C) {
+    if (tail && C >= 2 * lo && B >= 2ull * C) {
         for (uint32_t s = C / 2; s >= lo; s /= 2) tl.push_back(s);
         tl.push_back(tl.back());
         for (uint32_t s : tl) left -= s;

@@ -235,6 +235,8 @@ struct MsmBuf {
     void* sort_tmp;
     size_t sort_tmp_bytes;
     TomList one;           // [MSM_G] the groups' fixed-base commitments
+    uint32_t* host;        // page-locked host words (live-term count, group verdicts): a pageable destination makes the runtime
+                           // wait for every stream of the device, i.e. for the other lanes' kernels
 };
 // ------------------------------------------------------------------ launch wrappers (one per kernel family)
 // k_msm.hip
@@ -286,6 +288,7 @@ void launch_test_rng(hipStream_t s, const RngCtx& g, uint64_t B, uint32_t first_
 void launch_lista_scalars(hipStream_t s, const Workspace& W, uint32_t count);
 void launch_scan(hipStream_t s, const Workspace& W, uint32_t count, uint64_t cursor, uint64_t out_cap, uint64_t* d_out_off, int32_t* d_status_out,
                  uint32_t* d_totals /*[4]: items, overflow, bytes lo, bytes hi*/, uint64_t first_proof);
+void launch_words_to_host(hipStream_t s, void* dst_pinned, const void* src_dev, size_t nwords);   // read-back without the DMA engine
 void launch_status_out(hipStream_t s, const Workspace& W, uint32_t count, int32_t* d_status_out, uint64_t first_proof);
 void launch_items(hipStream_t s, const Workspace& W, uint32_t count);
 void launch_padd_scalars(hipStream_t s, const DevParams& P, const Workspace& W, uint32_t items);

@@ -133,8 +133,9 @@ void launch_gk_etab(hipStream_t s, const Soa& ring, uint32_t nblocks, uint32_t* 
 size_t gk_etab_words(uint64_t N) { return (size_t)GKB_SIZE * GKB_SIZE * 9 * (N / GKB_SIZE); }
 
 // ---------------------------------------------------------------- per chunk: sort by l_low, a_S
-// order[pos] = proof, goff[g] = first sorted position of l_low group g (goff[256] = count).  One workgroup.
-__global__ void __launch_bounds__(1024) k_gk_sort(ChunkIn in, uint32_t* order, uint32_t* goff) {
+// order[pos] = proof, goff[g] = first sorted position of l_low group g (goff[256] = count).  One workgroup of 320 threads (a
+// 16-wave workgroup can starve behind the other lane's kernels, see k_scan).
+__global__ void __launch_bounds__(320) k_gk_sort(ChunkIn in, uint32_t* order, uint32_t* goff) {
     __shared__ uint32_t hist[GKB_SIZE], offs[GKB_SIZE + 1];
     uint32_t t = threadIdx.x;
     if (t < GKB_SIZE) hist[t] = 0;
@@ -255,7 +256,7 @@ __global__ void __launch_bounds__(256) k_gk_block(Workspace W, ChunkIn in, const
 }
 void launch_gk_block_stage(hipStream_t s, const Workspace& W, const ChunkIn& in, const Soa& am, const Soa& res) {
     uint32_t nblocks = W.N >> GKB_BITS;
-    hipLaunchKernelGGL(k_gk_sort, dim3(1), dim3(1024), 0, s, in, W.gk_order, W.gk_goff);
+    hipLaunchKernelGGL(k_gk_sort, dim3(1), dim3(320), 0, s, in, W.gk_order, W.gk_goff);
     hipLaunchKernelGGL(k_gk_asub, dim3(in.count), dim3(256), 0, s, W, in.count, am, W.gk_asub);
     bool uni = (nblocks & 255) == 0;
     uint32_t nwg = uni ? in.count * (nblocks >> 8) : (uint32_t)(((uint64_t)in.count * nblocks + 255) / 256);

@@ -331,11 +331,10 @@ hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const 
     hipMemsetAsync(M.end, 0, sizeof(uint32_t) * MSM_NW * MSM_NBG, s);
     hipMemsetAsync(M.counters, 0, sizeof(uint32_t) * MSM_NW, s);
     hipLaunchKernelGGL(k_msm_compact, dim3((total + 255) / 256), dim3(256), 0, s, V, D, M.cap, M.keys_all, M.vals_in, M.counters);
-    uint32_t n = 0;
-    hipError_t e0 = hipMemcpyAsync(&n, M.counters, 4, hipMemcpyDeviceToHost, s);
+    launch_words_to_host(s, M.host, M.counters, 1);
+    hipError_t e0 = hipStreamSynchronize(s);
     if (e0 != hipSuccess) return e0;
-    e0 = hipStreamSynchronize(s);
-    if (e0 != hipSuccess) return e0;
+    const uint32_t n = M.host[0];
     const uint32_t nmax = n;
     if (dbg) fprintf(stderr, "msm: %u live terms, pack+compact %.2f ms\n", n, now() - t0), t0 = now();
     for (uint32_t w = 0; w < MSM_NW && n; w++) {
@@ -360,9 +359,9 @@ hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const 
     hipLaunchKernelGGL(k_msm_coef, dim3(MSM_G), dim3(256), 0, s, W, count, D.gsz, M.one);
     launch_tom_commit(s, P, M.one, MSM_G, 1, 1);
     hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, s, M.Tw, M.one, M.flag);
-    hipError_t e = hipMemcpyAsync(host_flags, M.flag, 4 * MSM_G, hipMemcpyDeviceToHost, s);
-    if (e != hipSuccess) return e;
-    e = hipStreamSynchronize(s);
+    launch_words_to_host(s, M.host + 8, M.flag, MSM_G);
+    hipError_t e = hipStreamSynchronize(s);
+    for (uint32_t g = 0; g < MSM_G; g++) host_flags[g] = M.host[8 + g];
     if (dbg) fprintf(stderr, "msm tail (bucket .. final) %.2f ms\n", now() - t0);
     return e;
 }

@@ -53,14 +53,17 @@ ZK_DEV uint32_t count_zero_bits(const uint32_t* chal, uint32_t sec) { return zer
 ZK_DEV uint64_t proof_size(uint32_t sec, uint32_t n, uint32_t z) {
     return (uint64_t)ZK_FIXED + (uint64_t)ZK_REP_HEAD * sec + (uint64_t)ZK_PADD_SZ * z + (uint64_t)n * (4 * 72 + 3 * 32) + 32;
 }
-// single workgroup of 1024 threads
-__global__ void __launch_bounds__(1024) k_scan(Workspace W, uint32_t count, uint64_t cur_in, uint64_t out_cap, uint64_t* out_off, int32_t* status_out,
+// Single workgroup.  256 threads, not 1024: the host WAITS for this kernel, and a 16-wave workgroup needs sixteen free wave
+// slots on one CU at the same moment -- under the other lane's register-heavy commitment kernels it was seen to starve for
+// 60 ms (tools/exp_io_timeline.py), leaving its lane idle; four waves slip in as soon as any wave retires.
+#define SCAN_T 256
+__global__ void __launch_bounds__(SCAN_T) k_scan(Workspace W, uint32_t count, uint64_t cur_in, uint64_t out_cap, uint64_t* out_off, int32_t* status_out,
                                                uint32_t* totals /* [0] items, [1] overflow flag, [2..3] bytes */, uint64_t first_proof) {
-    __shared__ uint64_t sb[1024];
-    __shared__ uint32_t si[1024];
+    __shared__ uint64_t sb[SCAN_T];
+    __shared__ uint32_t si[SCAN_T];
     __shared__ uint64_t s_cur;
     uint32_t t = threadIdx.x;
-    uint32_t per = (count + 1023) / 1024;
+    uint32_t per = (count + SCAN_T - 1) / SCAN_T;
     uint32_t lo = t * per, hi = lo + per < count ? lo + per : count;
     uint64_t bytes = 0;
     uint32_t items = 0;
@@ -84,7 +87,7 @@ __global__ void __launch_bounds__(1024) k_scan(Workspace W, uint32_t count, uint
     if (t == 0) {
         uint64_t b = 0;
         uint32_t it = 0;
-        for (int i = 0; i < 1024; i++) {
+        for (int i = 0; i < SCAN_T; i++) {
             uint64_t nb = sb[i];
             uint32_t ni = si[i];
             sb[i] = b, si[i] = it;
@@ -112,9 +115,21 @@ __global__ void __launch_bounds__(1024) k_scan(Workspace W, uint32_t count, uint
         b += W.st[p] == ZK_OK ? proof_size(W.sec, W.n, W.zcnt[p]) : 0;
     }
 }
+// Small read-backs the host waits for (chunk totals, slice boundaries, the batched check's verdicts) are WRITTEN by a kernel
+// into page-locked, device-mapped host memory instead of being copied: an asynchronous D2H copy is served by the same DMA
+// engine as the proof bytes of the other lanes and queues behind them -- a 16-byte read-back was seen to wait 60 ms for five
+// 700 MB slices (tools/exp_io_timeline.py).  The host only synchronises with the stream.
+__global__ void k_words_to_host(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint32_t n) {
+    uint32_t i = gtid();
+    if (i < n) dst[i] = src[i];
+}
+void launch_words_to_host(hipStream_t s, void* dst_pinned, const void* src_dev, size_t nwords) {
+    if (!nwords) return;
+    hipLaunchKernelGGL(k_words_to_host, dim3((uint32_t)((nwords + 255) / 256)), dim3(256), 0, s, (uint32_t*)dst_pinned, (const uint32_t*)src_dev, (uint32_t)nwords);
+}
 void launch_scan(hipStream_t s, const Workspace& W, uint32_t count, uint64_t cursor, uint64_t out_cap, uint64_t* d_out_off, int32_t* d_status_out,
                  uint32_t* d_totals, uint64_t first_proof) {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, W, count, cursor, out_cap, d_out_off, d_status_out, d_totals, first_proof);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(SCAN_T), 0, s, W, count, cursor, out_cap, d_out_off, d_status_out, d_totals, first_proof);
 }
 __global__ void __launch_bounds__(256) k_items(Workspace W, uint32_t count) {
     uint32_t t = gtid();
