@@ -329,6 +329,7 @@ def main():
     ap.add_argument('--mode', choices=['prove', 'verify'], default='prove',
                     help="verify: BASELINE configs[4] -- --batch proofs IN TOTAL over --ring keys, sharded over the ranks, generated and verified in streamed slabs")
     ap.add_argument('--slab', type=int, default=8192, help='--mode verify: proofs generated and verified per slab')
+    ap.add_argument('--json-sample', type=int, default=32, help='proofs converted to the JSON wire format and back on one host thread (toJson / fromJson of the reference bench; 0 = skip)')
     ap.add_argument('--check', type=int, default=1 << 30, help='proofs of the last step diffed against the oracle on rank 0 (at most the CPU sample)')
     args = ap.parse_args()
 
@@ -506,6 +507,19 @@ def main():
                 assert raw[int(off[b]):int(off[b + 1])] == oproofs[b], 'GPU proof %d differs from the oracle' % b
             cpu['checked_bit_exact'] = ncheck
             cpu['v8_bigint'] = v8_bigint_indicator()
+        json_rates = None
+        if args.json_sample > 0:   # bench/zkpAttestList.bench.ts:63-68 (toJson / fromJson), host-only converters of the C ABI, one thread
+            nj = min(args.json_sample, B)
+            raw = d_out[:int(off[nj].item())].cpu().numpy().tobytes()
+            ps = [raw[int(off[b]):int(off[b + 1])] for b in range(nj)]
+            t0 = time.time()
+            texts = [Z.write_json(p) for p in ps]
+            t1 = time.time()
+            back = [Z.read_json(t) for t in texts]
+            t2 = time.time()
+            assert back == ps
+            json_rates = {'proofs': nj, 'to_json_per_s': round(nj / (t1 - t0), 1), 'from_json_per_s': round(nj / (t2 - t1), 1),
+                          'json_bytes_per_proof': sum(len(t) for t in texts) // nj, 'threads': 1}
         host_io = None
         if args.host_io > 0 and world == 1:
             try:
@@ -528,7 +542,7 @@ def main():
             'proof_bytes_per_step': total_bytes, 'failed_proofs': nbad,
             'gpu_ms_by_family_per_step': {k: round(v / max(1, args.roofline_steps), 2) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
             'gpu_ms_note': 'serial single-lane pass (sum = %.1f ms); the timed steps overlap two chunks on two streams' % (gpu_ms / max(1, args.roofline_steps)),
-            'roofline': roofline, 'cpu_baseline': cpu, 'verify': verify, 'host_io': host_io,
+            'roofline': roofline, 'cpu_baseline': cpu, 'verify': verify, 'host_io': host_io, 'json': json_rates,
         }
         if host_io and 'pinned' in host_io:   # the SURVEY.md 8(d) form of the metric, next to the device-resident `value`
             line['value_pcie_inclusive'] = host_io['pinned']['proofs_per_s']

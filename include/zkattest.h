@@ -240,7 +240,7 @@ zk_status zk_proof_from_json(const char *json, uint64_t json_len, uint8_t *out, 
 uint32_t zk_last_timing(const zk_ctx *ctx, float *total_ms, const char **names, float *ms, uint32_t cap);
 
 /* Unit-test hooks (tests/ call these through the C ABI to compare single primitives with the oracle).
- * which_field: 0 = F_q (p256.p), 1 = Z_n, 2 = F_t;  op: 0 mul, 1 add, 2 sub, 3 inverse, 4 a*b - a - b (fused double subtraction).  count x 40-byte BE operands. */
+ * which_field: 0 = F_q (p256.p), 1 = Z_n, 2 = F_t;  op: 0 mul, 1 add, 2 sub, 3 inverse, 4 a*b - a - b (fused double subtraction), 5 (a + b)^2 (dedicated squaring).  count x 40-byte BE operands. */
 zk_status zk_test_field_op(zk_ctx *ctx, int which_field, int op, uint64_t count, const uint8_t *a_be40, const uint8_t *b_be40, uint8_t *out_be40);
 /* out[i] = v[i]*g + r[i]*h on Tom-256 (72-byte affine), through the fixed-base comb kernel */
 zk_status zk_test_tom_commit(zk_ctx *ctx, uint64_t count, const uint8_t *v_be32, const uint8_t *r_be32, uint8_t *out_xy72);

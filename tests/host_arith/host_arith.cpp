@@ -43,6 +43,8 @@ static void field_one(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) 
     else if (op == 4) {  // x*y - x - y through fe_sub2
         auto xm = fe_to_mont(x), ym = fe_to_mont(y);
         r = fe_from_mont(fe_sub2(xm * ym, xm, ym));
+    } else if (op == 6) {  // (x + y)^2 through limbs_mont_sqr
+        r = fe_from_mont(fe_sqr(fe_to_mont(x) + fe_to_mont(y)));
     } else {  // op 5: a lazy chain at large magnitudes: ((x + y) + (x + y)) * (x - y) - (y * y + x) , all in Montgomery form
         auto xm = fe_to_mont(x), ym = fe_to_mont(y);
         auto s = (xm + ym) + (xm + ym);          // K = 8

@@ -40,6 +40,7 @@ def test_field_ops(eng):
         assert eng.test_field_op(which, 1, a, b) == [(x + y) % m for x, y in zip(a, b)]
         assert eng.test_field_op(which, 2, a, b) == [(x - y) % m for x, y in zip(a, b)]
         assert eng.test_field_op(which, 4, a, b) == [(x * y - x - y) % m for x, y in zip(a, b)]  # fe_sub2
+        assert eng.test_field_op(which, 5, a, b) == [(x + y) ** 2 % m for x, y in zip(a, b)]       # limbs_mont_sqr
         inv = eng.test_field_op(which, 3, a, b)
         assert inv == [pow(x, -1, m) if x else 0 for x in a]  # invMod(0) = 0 (big.ts:113-119)
 

