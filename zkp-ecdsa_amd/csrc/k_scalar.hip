@@ -156,16 +156,6 @@ void launch_status_out(hipStream_t s, const Workspace& W, uint32_t count, int32_
 }
 
 // ---------------------------------------------------------------- PointAdd witness (pointAdd.ts:107-136)
-struct PaddWit {
-    Sq i7, i8, i9, i10, i11, i12, i13;
-    Sq r1, r2, r3, r4, r5, r6, r8, r10, r11, r13;  // blinders of C1..C6, C8, C10, C11, C13
-};
-ZK_DEV void padd_blinders(const Workspace& W, uint32_t p, uint32_t i, uint32_t d0, PaddWit& w) {
-    w.r1 = drawq(W, p, d0 + 0), w.r4 = drawq(W, p, d0 + 1), w.r8 = drawq(W, p, d0 + 2);
-    w.r10 = drawq(W, p, d0 + 3), w.r11 = drawq(W, p, d0 + 4), w.r13 = drawq(W, p, d0 + 5);
-    w.r2 = drawq(W, p, 1), w.r5 = drawq(W, p, 2);
-    w.r3 = drawq(W, p, 3 + 4 * i + 2), w.r6 = drawq(W, p, 3 + 4 * i + 3);
-}
 // openings of one proveMult instance (mult.ts:102-114): 6 commitments starting at `slot`
 ZK_DEV void mult_openings(const Workspace& W, uint32_t p, uint32_t dm, uint32_t it, uint32_t k0, const Sq& x, const Sq& y, const Sq& ry) {
     Sq kx = drawq(W, p, dm), ky = drawq(W, p, dm + 1), kz = drawq(W, p, dm + 2);
@@ -209,41 +199,62 @@ __global__ void __launch_bounds__(256) k_padd_inv(Workspace W, uint32_t items, u
         soa_st(W.T1proj.y, e, zero ? fe_zero<ModQ>().as<2>() : r);
     }
 }
-// 1 wave per SIMD (AGPRs instead of scratch for the values beyond 256 VGPRs, see k_v_slot_terms)
-__global__ void __launch_bounds__(256, 1) k_padd_scalars(Workspace W, uint32_t items) {
-    uint32_t it = gtid();
-    if (it >= items) return;
-    uint32_t p = W.item_proof[it], i = W.item_rep[it];
-    uint32_t d0 = 3 + 4 * W.sec + 40 * W.item_rank[it];
-    Sq x1 = soa_ld<ModQ, 1>(W.T1x, it), y1 = soa_ld<ModQ, 1>(W.T1y, it);
-    Sq x2 = soa_ld<ModQ, 1>(W.pkx, p), y2 = soa_ld<ModQ, 1>(W.pky, p);
-    Sq x3 = soa_ld<ModQ, 1>(W.Tx, p * (W.sec + 1) + i);
-    PaddWit w;
-    padd_blinders(W, p, i, d0, w);
-    w.i7 = fe_sub_mod(x2, x1);
-    w.i8 = fe_from_mont(soa_ld<ModQ, 2>(W.T1proj.y, it));
-    w.i9 = fe_sub_mod(y2, y1);
-    w.i10 = fe_mul_mod(w.i8, w.i9);
-    w.i11 = fe_mul_mod(w.i10, w.i10);
-    w.i12 = fe_sub_mod(x1, x3);
-    w.i13 = fe_mul_mod(w.i10, w.i12);
-    put_vr(W.lb, lbi(W, it, 0), x1, w.r1);       // T1x   (exp.ts:196)
-    put_vr(W.lb, lbi(W, it, 1), y1, w.r4);       // T1y
-    put_vr(W.lb, lbi(W, it, 2), w.i8, w.r8);     // C8    (pointAdd.ts:138-143)
-    put_vr(W.lb, lbi(W, it, 3), w.i10, w.r10);   // C10
-    put_vr(W.lb, lbi(W, it, 4), w.i11, w.r11);   // C11
-    put_vr(W.lb, lbi(W, it, 5), w.i13, w.r13);   // C13
-    mult_openings(W, p, d0 + 6, it, 6, w.i7, w.i8, w.r8);                          // pi8 : Cy = C8
-    mult_openings(W, p, d0 + 13, it, 12, w.i8, w.i9, fe_sub_mod(w.r5, w.r4));     // pi10: Cy = C9 = C5 - C4
-    mult_openings(W, p, d0 + 20, it, 18, w.i10, w.i10, w.r10);                    // pi11: Cy = C10
-    mult_openings(W, p, d0 + 30, it, 24, w.i10, w.i12, fe_sub_mod(w.r1, w.r3));   // pi13: Cy = C12 = C1 - C3
-    {
-        Sq k = drawq(W, p, d0 + 27);                                               // pix (equality.ts:66-68)
-        put_vr(W.lb, lbi(W, it, 30), k, drawq(W, p, d0 + 28));
-        put_vr(W.lb, lbi(W, it, 31), k, drawq(W, p, d0 + 29));
-        k = drawq(W, p, d0 + 37);                                                  // piy
-        put_vr(W.lb, lbi(W, it, 32), k, drawq(W, p, d0 + 38));
-        put_vr(W.lb, lbi(W, it, 33), k, drawq(W, p, d0 + 39));
+// One thread per (part, item), part-major so that a wave runs one part: 0 = the six commitments T1x, T1y, C8, C10, C11, C13;
+// 1..4 = openings of pi8, pi10, pi11, pi13; 5 = pix, piy.  Each part derives the witness values it needs from x1, y1, x2, y2, x3 and
+// i8 itself (at most two extra products), so no part holds more than a few scalars.
+#define PADD_PARTS 6
+struct PaddIn {
+    uint32_t p, i, d0;
+    Sq x1, y1;
+};
+ZK_DEV PaddIn padd_in(const Workspace& W, uint32_t it) {
+    PaddIn a;
+    a.p = W.item_proof[it], a.i = W.item_rep[it];
+    a.d0 = 3 + 4 * W.sec + 40 * W.item_rank[it];
+    a.x1 = soa_ld<ModQ, 1>(W.T1x, it), a.y1 = soa_ld<ModQ, 1>(W.T1y, it);
+    return a;
+}
+ZK_DEV Sq padd_i9(const Workspace& W, const PaddIn& a) { return fe_sub_mod(soa_ld<ModQ, 1>(W.pky, a.p), a.y1); }
+ZK_DEV Sq padd_i12(const Workspace& W, const PaddIn& a) { return fe_sub_mod(a.x1, soa_ld<ModQ, 1>(W.Tx, a.p * (W.sec + 1) + a.i)); }
+__global__ void __launch_bounds__(256) k_padd_scalars(Workspace W, uint32_t items) {
+    uint32_t t = gtid();
+    if (t >= items * PADD_PARTS) return;
+    uint32_t part = t / items, it = t % items;
+    PaddIn a = padd_in(W, it);
+    uint32_t p = a.p, d0 = a.d0;
+    Sq i8 = fe_from_mont(soa_ld<ModQ, 2>(W.T1proj.y, it));
+    switch (part) {
+        case 0: {
+            put_vr(W.lb, lbi(W, it, 0), a.x1, drawq(W, p, d0 + 0));       // T1x   (exp.ts:196)
+            put_vr(W.lb, lbi(W, it, 1), a.y1, drawq(W, p, d0 + 1));       // T1y
+            put_vr(W.lb, lbi(W, it, 2), i8, drawq(W, p, d0 + 2));         // C8    (pointAdd.ts:138-143)
+            Sq i10 = fe_mul_mod(i8, padd_i9(W, a));
+            put_vr(W.lb, lbi(W, it, 3), i10, drawq(W, p, d0 + 3));        // C10
+            put_vr(W.lb, lbi(W, it, 4), fe_mul_mod(i10, i10), drawq(W, p, d0 + 4));                // C11
+            put_vr(W.lb, lbi(W, it, 5), fe_mul_mod(i10, padd_i12(W, a)), drawq(W, p, d0 + 5));     // C13
+        } break;
+        case 1:  // pi8 : x = i7, Cy = C8
+            mult_openings(W, p, d0 + 6, it, 6, fe_sub_mod(soa_ld<ModQ, 1>(W.pkx, p), a.x1), i8, drawq(W, p, d0 + 2));
+            break;
+        case 2:  // pi10: x = i8, Cy = C9 = C5 - C4
+            mult_openings(W, p, d0 + 13, it, 12, i8, padd_i9(W, a), fe_sub_mod(drawq(W, p, 2), drawq(W, p, d0 + 1)));
+            break;
+        case 3: {  // pi11: x = i10, Cy = C10
+            Sq i10 = fe_mul_mod(i8, padd_i9(W, a));
+            mult_openings(W, p, d0 + 20, it, 18, i10, i10, drawq(W, p, d0 + 3));
+        } break;
+        case 4: {  // pi13: x = i10, Cy = C12 = C1 - C3
+            Sq i10 = fe_mul_mod(i8, padd_i9(W, a));
+            mult_openings(W, p, d0 + 30, it, 24, i10, padd_i12(W, a), fe_sub_mod(drawq(W, p, d0 + 0), drawq(W, p, 3 + 4 * a.i + 2)));
+        } break;
+        default: {
+            Sq k = drawq(W, p, d0 + 27);                                               // pix (equality.ts:66-68)
+            put_vr(W.lb, lbi(W, it, 30), k, drawq(W, p, d0 + 28));
+            put_vr(W.lb, lbi(W, it, 31), k, drawq(W, p, d0 + 29));
+            k = drawq(W, p, d0 + 37);                                                  // piy
+            put_vr(W.lb, lbi(W, it, 32), k, drawq(W, p, d0 + 38));
+            put_vr(W.lb, lbi(W, it, 33), k, drawq(W, p, d0 + 39));
+        }
     }
 }
 void launch_padd_scalars(hipStream_t s, const DevParams&, const Workspace& W, uint32_t items) {
@@ -251,7 +262,7 @@ void launch_padd_scalars(hipStream_t s, const DevParams&, const Workspace& W, ui
     hipLaunchKernelGGL(k_padd_i7, dim3((items + 255) / 256), dim3(256), 0, s, W, items);
     uint32_t per = 16, nthreads = (items + per - 1) / per;
     hipLaunchKernelGGL(k_padd_inv, dim3((nthreads + 255) / 256), dim3(256), 0, s, W, items, nthreads, per);
-    hipLaunchKernelGGL(k_padd_scalars, dim3((items + 255) / 256), dim3(256), 0, s, W, items);
+    hipLaunchKernelGGL(k_padd_scalars, dim3((items * PADD_PARTS + 255) / 256), dim3(256), 0, s, W, items);
 }
 
 // ---------------------------------------------------------------- PointAdd responses (mult.ts:122-130, equality.ts:73-77)
@@ -276,43 +287,57 @@ ZK_DEV void eq_respond(const Workspace& W, uint32_t p, uint32_t de, const uint32
     store_scalar_be(o + 32, fe_sub_mod(s1, fe_canon(cm * rc1)));
     store_scalar_be(o + 64, fe_sub_mod(s2, fe_canon(cm * rc2)));
 }
-__global__ void __launch_bounds__(256, 1) k_padd_respond(Workspace W, uint32_t items, uint8_t* out) {
-    uint32_t it = gtid();
-    if (it >= items) return;
+// Same split as k_padd_scalars: part 0 = the rep-level responses of a zero bit, 1..4 = pi8, pi10, pi11, pi13, 5 = pix, piy.
+__global__ void __launch_bounds__(256) k_padd_respond(Workspace W, uint32_t items, uint8_t* out) {
+    uint32_t t = gtid();
+    if (t >= items * PADD_PARTS) return;
+    uint32_t part = t / items, it = t % items;
     uint32_t p = W.item_proof[it], i = W.item_rep[it];
     uint32_t d0 = 3 + 4 * W.sec + 40 * W.item_rank[it];
     uint8_t* rep = out + W.out_base[p] + rep_offset(W.chal + 4 * p, i);
-    // rep-level response for a zero bit (exp.ts:186,221-225): z = alpha - s, z2 = r_i - Cs.r, r1 = T1x.r, r2 = T1y.r
-    {
-        Sn alpha = drawn(W, p, 3 + 4 * i), ri = drawn(W, p, 3 + 4 * i + 1), r0 = drawn(W, p, 0);
-        store_scalar_be(rep + 208, fe_sub_mod(alpha, soa_ld<ModN, 1>(W.s1, p)));
-        store_scalar_be(rep + 240, fe_sub_mod(ri, r0));
-    }
-    PaddWit w;
-    padd_blinders(W, p, i, d0, w);
-    store_scalar_be(rep + 272, w.r1);
-    store_scalar_be(rep + 304, w.r4);
-    Sq x1 = soa_ld<ModQ, 1>(W.lb.v, lbi(W, it, 0)), y1 = soa_ld<ModQ, 1>(W.lb.v, lbi(W, it, 1));
-    w.i8 = soa_ld<ModQ, 1>(W.lb.v, lbi(W, it, 2)), w.i10 = soa_ld<ModQ, 1>(W.lb.v, lbi(W, it, 3));
-    w.i11 = soa_ld<ModQ, 1>(W.lb.v, lbi(W, it, 4)), w.i13 = soa_ld<ModQ, 1>(W.lb.v, lbi(W, it, 5));
-    w.i7 = fe_sub_mod(soa_ld<ModQ, 1>(W.pkx, p), x1);
-    w.i9 = fe_sub_mod(soa_ld<ModQ, 1>(W.pky, p), y1);
-    w.i12 = fe_sub_mod(x1, soa_ld<ModQ, 1>(W.Tx, p * (W.sec + 1) + i));
     uint8_t* pa = rep + ZK_REP_HEAD;
     const uint32_t* c = W.padd_c + (size_t)it * 18;
-    Sq one = fe_zero<ModQ>(), zero = fe_zero<ModQ>();
-    one.l[0] = 1;
     const uint32_t MS = 288 + 432;  // scalars of MultProof m start at 288 + 656 m + 432
-    mult_respond(W, p, d0 + 6, c + 0, pa + MS, w.i7, w.i8, one, fe_sub_mod(w.r2, w.r1), w.r8, zero);                 // pi8 (C14 = g, blinder 0)
-    mult_respond(W, p, d0 + 13, c + 3, pa + MS + 656, w.i8, w.i9, w.i10, w.r8, fe_sub_mod(w.r5, w.r4), w.r10);     // pi10
-    mult_respond(W, p, d0 + 20, c + 6, pa + MS + 2 * 656, w.i10, w.i10, w.i11, w.r10, w.r10, w.r11);               // pi11
-    mult_respond(W, p, d0 + 30, c + 9, pa + MS + 3 * 656, w.i10, w.i12, w.i13, w.r10, fe_sub_mod(w.r1, w.r3), w.r13);  // pi13
-    eq_respond(W, p, d0 + 27, c + 12, pa + 2912 + 144, w.i11, w.r11, fe_add_mod(fe_add_mod(w.r3, w.r1), w.r2));   // pix: Cint = C3+C1+C2
-    eq_respond(W, p, d0 + 37, c + 15, pa + 3152 + 144, w.i13, w.r13, fe_add_mod(w.r6, w.r4));                      // piy: Cint = C6+C4
+    auto lbv = [&](uint32_t k) { return soa_ld<ModQ, 1>(W.lb.v, lbi(W, it, k)); };  // 0..5 = x1, y1, i8, i10, i11, i13
+    // blinders: r1, r4, r8, r10, r11, r13 = draws d0 + 0..5; r2, r5 = draws 1, 2 (Px, Py); r3, r6 = draws of Tx, Ty of the rep
+    switch (part) {
+        case 0: {
+            // rep-level response for a zero bit (exp.ts:186,221-225): z = alpha - s, z2 = r_i - Cs.r, r1 = T1x.r, r2 = T1y.r
+            Sn alpha = drawn(W, p, 3 + 4 * i), ri = drawn(W, p, 3 + 4 * i + 1), r0 = drawn(W, p, 0);
+            store_scalar_be(rep + 208, fe_sub_mod(alpha, soa_ld<ModN, 1>(W.s1, p)));
+            store_scalar_be(rep + 240, fe_sub_mod(ri, r0));
+            store_scalar_be(rep + 272, drawq(W, p, d0 + 0));
+            store_scalar_be(rep + 304, drawq(W, p, d0 + 1));
+        } break;
+        case 1: {  // pi8: (i7, i8, 1) with blinders (r2 - r1, r8, 0): C14 = g
+            Sq one = fe_zero<ModQ>();
+            one.l[0] = 1;
+            mult_respond(W, p, d0 + 6, c + 0, pa + MS, fe_sub_mod(soa_ld<ModQ, 1>(W.pkx, p), lbv(0)), lbv(2), one,
+                         fe_sub_mod(drawq(W, p, 1), drawq(W, p, d0 + 0)), drawq(W, p, d0 + 2), fe_zero<ModQ>());
+        } break;
+        case 2:  // pi10: (i8, i9, i10)
+            mult_respond(W, p, d0 + 13, c + 3, pa + MS + 656, lbv(2), fe_sub_mod(soa_ld<ModQ, 1>(W.pky, p), lbv(1)), lbv(3), drawq(W, p, d0 + 2),
+                         fe_sub_mod(drawq(W, p, 2), drawq(W, p, d0 + 1)), drawq(W, p, d0 + 3));
+            break;
+        case 3: {  // pi11: (i10, i10, i11)
+            Sq i10 = lbv(3), r10 = drawq(W, p, d0 + 3);
+            mult_respond(W, p, d0 + 20, c + 6, pa + MS + 2 * 656, i10, i10, lbv(4), r10, r10, drawq(W, p, d0 + 4));
+        } break;
+        case 4:  // pi13: (i10, i12, i13)
+            mult_respond(W, p, d0 + 30, c + 9, pa + MS + 3 * 656, lbv(3), fe_sub_mod(lbv(0), soa_ld<ModQ, 1>(W.Tx, p * (W.sec + 1) + i)), lbv(5),
+                         drawq(W, p, d0 + 3), fe_sub_mod(drawq(W, p, d0 + 0), drawq(W, p, 3 + 4 * i + 2)), drawq(W, p, d0 + 5));
+            break;
+        default: {
+            Sq r1 = drawq(W, p, d0 + 0), r4 = drawq(W, p, d0 + 1);
+            // pix: Cint = C3 + C1 + C2; piy: Cint = C6 + C4
+            eq_respond(W, p, d0 + 27, c + 12, pa + 2912 + 144, lbv(4), drawq(W, p, d0 + 4), fe_add_mod(fe_add_mod(drawq(W, p, 3 + 4 * i + 2), r1), drawq(W, p, 1)));
+            eq_respond(W, p, d0 + 37, c + 15, pa + 3152 + 144, lbv(5), drawq(W, p, d0 + 5), fe_add_mod(drawq(W, p, 3 + 4 * i + 3), r4));
+        }
+    }
 }
 void launch_padd_respond(hipStream_t s, const Workspace& W, uint32_t items, uint8_t* out) {
     if (!items) return;
-    hipLaunchKernelGGL(k_padd_respond, dim3((items + 255) / 256), dim3(256), 0, s, W, items, out);
+    hipLaunchKernelGGL(k_padd_respond, dim3((items * PADD_PARTS + 255) / 256), dim3(256), 0, s, W, items, out);
 }
 
 // ---------------------------------------------------------------- ZKA1 fixed part and rep heads

@@ -660,11 +660,40 @@ ZK_DEV void put_term_bytes(const VTerms& L, uint32_t idx, const uint8_t* p72, bo
     ld_tom_bytes(p72, x, y);
     put_term(L, idx, x, y, negate, sc);
 }
+ZK_DEV void put_term_point_null(const VTerms& L, uint32_t idx) {  // identity; the scalar is written by the scalar kernel
+    soa_st(L.nx, idx, fe_zero<ModT>().as<2>()), soa_st(L.ny, idx, fe_one_mont<ModT>().as<2>()), soa_st(L.ndt, idx, fe_zero<ModT>().as<2>());
+}
+// niels form of the 72-byte point at p72 (nullptr: the identity)
+ZK_DEV void term_point(const uint8_t* p72, bool negate, Ft2& x, Ft2& y, Ft2& dt) {
+    if (!p72) {
+        x = fe_zero<ModT>().as<2>(), y = fe_one_mont<ModT>().as<2>(), dt = fe_zero<ModT>().as<2>();
+        return;
+    }
+    St xp, yp;
+    ld_tom_bytes(p72, xp, yp);
+    x = fe_to_mont(xp) * fe_const<ModT, 1>(TOM_S_M);
+    y = fe_to_mont(yp);
+    if (negate) x = fe_reduce(fe_neg(x));
+    dt = (x * y) * fe_const<ModT, 1>(TOM_D1_M);
+}
+ZK_DEV void put_term_point(const VTerms& L, uint32_t idx, const uint8_t* p72, bool negate) {
+    Ft2 x, y, dt;
+    term_point(p72, negate, x, y, dt);
+    soa_st(L.nx, idx, x), soa_st(L.ny, idx, y), soa_st(L.ndt, idx, dt);
+}
 ZK_DEV void put_term_null(const VTerms& L, uint32_t idx) {  // identity with scalar 0
     soa_st(L.nx, idx, fe_zero<ModT>().as<2>()), soa_st(L.ny, idx, fe_one_mont<ModT>().as<2>());
     soa_st(L.ndt, idx, fe_zero<ModT>().as<2>()), soa_st(L.sc, idx, fe_zero<ModQ>());
 }
-ZK_DEV Sq mulq(const Sq& a, const Sq& b) { return fe_mul_mod(a, b); }
+// mod-q product between two scheduling fences: the term kernels are chains of independent products, and without the fences the
+// compiler interleaves them until the live set spills (256 VGPRs + scratch); in order they fit two or more waves per SIMD.
+ZK_DEV Sq mulq(const Sq& a, const Sq& b) {
+    Sq x = a;
+    for (int l = 0; l < NLIMB; l++) asm volatile("" : "+v"(x.l[l]));
+    Sq r = fe_mul_mod(x, b);
+    for (int l = 0; l < NLIMB; l++) asm volatile("" : "+v"(r.l[l]));
+    return r;
+}
 ZK_DEV Sq addq(const Sq& a, const Sq& b) { return fe_add_mod(a, b); }
 ZK_DEV Sq chalq(const uint32_t* c3) {
     uint32_t w[8] = {c3[0], c3[1], c3[2], 0, 0, 0, 0, 0};
@@ -676,36 +705,66 @@ struct SlotAcc {  // coefficients accumulated for shared points of one slot
     Sq g, h, c8, c10, c11, c13, w7, w9, w12, wX, wY;
 };
 // aggregateMult (mult.ts:158-173) with randomisers r[0..4]; point coefficients returned through references.
-// pts: C4, Ax, Ay, Az, A41, A42 then 7 scalars.  Term slots: 256-bit C4 at i256, 128-bit A's at i128..i128+4
+// pts: C4, Ax, Ay, Az, A41, A42 then 7 scalars.  Term slots: 256-bit C4 at i256, 128-bit A's at i128..i128+4.  Scalars only: the
+// points of the same terms are converted by k_v_slot_points.
 ZK_DEV void v_mult(const VTerms& L, uint32_t gidx, uint32_t ng, uint32_t i256, uint32_t i128, const uint8_t* pi, const Sq& c, const Sq* r,
                    Sq& wCx, Sq& wCy, Sq& wCz, Sq& g, Sq& h) {
     const uint8_t* sc = pi + 432;
-    Sq tx = ld_scalar_q(sc), ty = ld_scalar_q(sc + 32), tz = ld_scalar_q(sc + 64), trx = ld_scalar_q(sc + 96), try_ = ld_scalar_q(sc + 128),
-       trz = ld_scalar_q(sc + 160), tr4 = ld_scalar_q(sc + 192);
-    wCx = addq(wCx, mulq(r[0], c));
-    wCy = addq(wCy, addq(mulq(r[1], c), mulq(r[4], tx)));
-    wCz = addq(wCz, mulq(r[2], c));
-    g = addq(g, addq(addq(mulq(r[0], tx), mulq(r[1], ty)), mulq(addq(r[2], r[3]), tz)));
-    h = addq(h, addq(addq(mulq(r[0], trx), mulq(r[1], try_)), addq(mulq(r[2], trz), mulq(r[3], tr4))));
-    put_term_bytes(L, i256 * ng + gidx, pi, false, mulq(addq(r[3], r[4]), c));  // C4: (r4 + r5) c
-    for (int k = 0; k < 5; k++) put_term_bytes(L, (i128 + k) * ng + gidx, pi + 72 * (k + 1), true, r[k]);  // -r_k * A
+    {
+        Sq tx = ld_scalar_q(sc);
+        wCx = addq(wCx, mulq(r[0], c));
+        wCy = addq(wCy, addq(mulq(r[1], c), mulq(r[4], tx)));
+        wCz = addq(wCz, mulq(r[2], c));
+        g = addq(g, mulq(r[0], tx));
+    }
+    g = addq(g, mulq(r[1], ld_scalar_q(sc + 32)));
+    g = addq(g, mulq(addq(r[2], r[3]), ld_scalar_q(sc + 64)));
+    h = addq(h, mulq(r[0], ld_scalar_q(sc + 96)));
+    h = addq(h, mulq(r[1], ld_scalar_q(sc + 128)));
+    h = addq(h, mulq(r[2], ld_scalar_q(sc + 160)));
+    h = addq(h, mulq(r[3], ld_scalar_q(sc + 192)));
+    soa_st(L.sc, i256 * ng + gidx, mulq(addq(r[3], r[4]), c));  // C4: (r4 + r5) c
+    for (int k = 0; k < 5; k++) soa_st(L.sc, (i128 + k) * ng + gidx, r[k]);  // r_k * (-A)
 }
 ZK_DEV void v_eq(const VTerms& L, uint32_t gidx, uint32_t ng, uint32_t i128, const uint8_t* pi, const Sq& c, const Sq* r, Sq& wC1, Sq& wC2, Sq& g, Sq& h) {
     const uint8_t* sc = pi + 144;
-    Sq tx = ld_scalar_q(sc), tr1 = ld_scalar_q(sc + 32), tr2 = ld_scalar_q(sc + 64);
     wC1 = addq(wC1, mulq(r[0], c));
     wC2 = addq(wC2, mulq(r[1], c));
-    g = addq(g, mulq(addq(r[0], r[1]), tx));
-    h = addq(h, addq(mulq(r[0], tr1), mulq(r[1], tr2)));
-    put_term_bytes(L, i128 * ng + gidx, pi, true, r[0]);
-    put_term_bytes(L, (i128 + 1) * ng + gidx, pi + 72, true, r[1]);
+    g = addq(g, mulq(addq(r[0], r[1]), ld_scalar_q(sc)));
+    h = addq(h, mulq(r[0], ld_scalar_q(sc + 32)));
+    h = addq(h, mulq(r[1], ld_scalar_q(sc + 64)));
+    soa_st(L.sc, i128 * ng + gidx, r[0]);
+    soa_st(L.sc, (i128 + 1) * ng + gidx, r[1]);
 }
-// one thread per checked slot: all Tom terms of the slot (group gidx = slot), partial sums for shared points, and the
-// slot's P-256 contribution.  Layout of a slot group: 256-bit terms 0..9 = C8, C10, C11, C13, Tx, Ty, C4 x4;
-// 128-bit terms 10..35 = 4 x (Ax, Ay, Az, A41, A42), pix A1, A2, piy A1, A2, then Tx, Ty of a bit-1 slot.
-// 1 wave per SIMD: the ~180 values that do not fit 256 VGPRs live in AGPRs instead of scratch memory (slower by 15 % on most boxes of
-// the pool, but scratch-backed spills made this kernel 2x slower on some of them; the two-lane pipeline hides the difference)
-__global__ void __launch_bounds__(64, 1) k_v_slot_terms(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
+// Layout of a slot group (group gidx = slot): 256-bit terms 0..9 = C8, C10, C11, C13, Tx, Ty, C4 x4; 128-bit terms 10..35 =
+// 4 x (Ax, Ay, Az, A41, A42), pix A1, A2, piy A1, A2, then Tx, Ty of a bit-1 slot.
+//
+// Points: one thread per (term, slot), term-major so that the stores are coalesced.  Three Tom products per thread.
+__global__ void __launch_bounds__(256) k_v_slot_points(VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    uint32_t t = gtid(), ns = count * VK, ng = V.C * VK;
+    if (t >= ns * V_SLOT_TERMS) return;
+    uint32_t k = t / ns, sl = t % ns, p = sl / VK;
+    uint32_t iv = V.idx[sl], i = iv & 255, bit = iv >> 8;
+    const VTerms& L = V.slot_terms;
+    bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8) && V.exp_st[p] == ZK_OK;
+    const uint8_t* src = nullptr;
+    bool neg = false;
+    if (good) {
+        const uint8_t* rep = proofs + off[first + p] + rep_offset(V.hbits + 4 * p, i);
+        const uint8_t* pa = rep + ZK_REP_HEAD;
+        if (bit) {
+            if (k >= 34) src = rep + (k == 34 ? 64 : 136), neg = true;
+        } else if (k < 4) src = pa + 72 * k;
+        else if (k < 6) src = rep + (k == 4 ? 64 : 136);
+        else if (k < 10) src = pa + 288 + 656 * (k - 6);
+        else if (k < 30) src = pa + 288 + 656 * ((k - 10) / 5) + 72 * ((k - 10) % 5 + 1), neg = true;
+        else if (k < 34) src = pa + (k < 32 ? 2912 : 3152) + 72 * (k & 1), neg = true;
+    }
+    put_term_point(L, k * ng + sl, src, neg);
+}
+// Scalars: one thread per checked slot: the scalars of the slot's terms, partial sums for shared points, and the slot's P-256
+// contribution.  Only mod-q arithmetic here; sums that are complete are stored at once so that few values stay live.
+__global__ void __launch_bounds__(64, 2) k_v_slot_terms(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
     uint32_t sl = gtid(), ng = V.C * VK;
     if (sl >= count * VK) return;
     uint32_t p = sl / VK, j = sl % VK;
@@ -713,88 +772,87 @@ __global__ void __launch_bounds__(64, 1) k_v_slot_terms(Workspace W, VWork V, ui
     const VTerms& L = V.slot_terms;
     bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8) && V.exp_st[p] == ZK_OK;
     Sq zero = fe_zero<ModQ>();
-    Sq Sg = zero, Sh = zero, Skx = zero, Sky = zero;
-    Sn SR = fe_zero<ModN>(), SH = fe_zero<ModN>(), SL = fe_zero<ModN>();
-    for (uint32_t k = 0; k < V_SLOT_TERMS; k++) put_term_null(L, k * ng + sl);
     uint32_t pa_idx = p * VK + j;  // P-256 A-term index
-    if (!good) {
-        soa_st(V.pa_x, pa_idx, fe_const<ModQ, 2>(P256_GX_M)), soa_st(V.pa_y, pa_idx, fe_const<ModQ, 2>(P256_GY_M)), soa_st(V.pa_sc, pa_idx, fe_zero<ModN>());
-    } else {
-        const uint8_t* pr = proofs + off[first + p];
-        const uint8_t* rep = pr + rep_offset(V.hbits + 4 * p, i);
-        uint64_t gp = first + p;
-        uint32_t e = sl;
-        Sq sx = soa_ld<ModQ, 1>(W.Tx, e), sy = soa_ld<ModQ, 1>(W.Ty, e);  // affine T (bit 1) or T1 + Q (bit 0)
-        const uint32_t tag = j << 8;
-        // ---- P-256 relation (exp.ts:270-276 / 305-317) with randomiser r[24] (mod n): the T term is (rho * s) * R
-        {
-            Sq r24[1];
-            v_rho_range<24, 1>(vseeds, gp, tag, r24);
-            Sn rn;
-            for (int l = 0; l < NLIMB; l++) rn.l[l] = r24[0].l[l];
-            Sn s0 = ld_scalar_n(rep + 208), s1 = ld_scalar_n(rep + 240);
-            SR = fe_mul_mod(rn, s0);
-            SH = fe_mul_mod(rn, s1);
-            if (!bit) SL = rn;
-            // -rho * A  ==  rho * (-A)
-            uint32_t xw[8], yw[8];
-            load_be32(rep, xw);
-            load_be32(rep + 32, yw);
-            Fq2 ax = fe_to_mont(fe_from_words256_reduce<ModQ>(xw));
-            Fq2 ay = fe_reduce(fe_neg(fe_to_mont(fe_from_words256_reduce<ModQ>(yw))));
-            soa_st(V.pa_x, pa_idx, ax), soa_st(V.pa_y, pa_idx, ay), soa_st(V.pa_sc, pa_idx, rn);
-        }
-        if (bit) {
-            // relTx, relTy (exp.ts:287-297): r0 (sx g + beta2 h - Tx), r1 (sy g + beta3 h - Ty)
-            Sq b2 = ld_scalar_q(rep + 272), b3 = ld_scalar_q(rep + 304);
-            Sq r[2];
-            v_rho_range<0, 2>(vseeds, gp, tag, r);
-            Sg = addq(mulq(r[0], sx), mulq(r[1], sy));
-            Sh = addq(mulq(r[0], b2), mulq(r[1], b3));
-            put_term_bytes(L, 34 * ng + sl, rep + 64, true, r[0]);
-            put_term_bytes(L, 35 * ng + sl, rep + 136, true, r[1]);
-        } else {
-            const uint8_t* pa = rep + ZK_REP_HEAD;
-            const uint32_t* cw = V.vc + (size_t)sl * 18;
-            Sq c8 = chalq(cw), c10 = chalq(cw + 3), c11 = chalq(cw + 6), c13 = chalq(cw + 9), cx = chalq(cw + 12), cy = chalq(cw + 15);
-            Sq w7 = zero, w8 = zero, w9 = zero, w10 = zero, w11 = zero, w12 = zero, w13 = zero, w14 = zero, wX = zero, wY = zero;
-            // pointAdd.ts:215-255
-            Sq r[5];
-            v_rho_range<0, 5>(vseeds, gp, tag, r);
-            v_mult(L, sl, ng, 6, 10, pa + 288, c8, r, w7, w8, w14, Sg, Sh);                      // pi8 : (C7, C8, C14 = g)
-            v_rho_range<5, 5>(vseeds, gp, tag, r);
-            v_mult(L, sl, ng, 7, 15, pa + 288 + 656, c10, r, w8, w9, w10, Sg, Sh);               // pi10: (C8, C9, C10)
-            {                                                                                      // pi11: (C10, C10, C11)
-                Sq wa = zero, wb = zero;
-                v_rho_range<10, 5>(vseeds, gp, tag, r);
-                v_mult(L, sl, ng, 8, 20, pa + 288 + 2 * 656, c11, r, wa, wb, w11, Sg, Sh);
-                w10 = addq(w10, addq(wa, wb));
-            }
-            v_rho_range<15, 2>(vseeds, gp, tag, r);
-            v_eq(L, sl, ng, 30, pa + 2912, cx, r, w11, wX, Sg, Sh);                               // pix : (C11, C3 + C1 + C2)
-            v_rho_range<17, 5>(vseeds, gp, tag, r);
-            v_mult(L, sl, ng, 9, 25, pa + 288 + 3 * 656, c13, r, w10, w12, w13, Sg, Sh);         // pi13: (C10, C12, C13)
-            v_rho_range<22, 2>(vseeds, gp, tag, r);
-            v_eq(L, sl, ng, 32, pa + 3152, cy, r, w13, wY, Sg, Sh);                               // piy : (C13, C4 + C6)
-            // redistribute the derived commitments: C7 = Px - T1x, C9 = Py - T1y, C12 = T1x - Tx, CintX = Tx + T1x + Px,
-            // CintY = T1y + Ty, C14 = g, T1x = sx g + r1 h, T1y = sy g + r2 h
-            Sq r1 = ld_scalar_q(rep + 272), r2 = ld_scalar_q(rep + 304);
-            Sq u1 = addq(fe_sub_mod(w12, w7), wX), u2 = fe_sub_mod(wY, w9);
-            Sg = addq(Sg, addq(w14, addq(mulq(u1, sx), mulq(u2, sy))));
-            Sh = addq(Sh, addq(mulq(u1, r1), mulq(u2, r2)));
-            Skx = addq(w7, wX), Sky = w9;
-            put_term_bytes(L, 0 * ng + sl, pa, false, w8);
-            put_term_bytes(L, 1 * ng + sl, pa + 72, false, w10);
-            put_term_bytes(L, 2 * ng + sl, pa + 144, false, w11);
-            put_term_bytes(L, 3 * ng + sl, pa + 216, false, w13);
-            put_term_bytes(L, 4 * ng + sl, rep + 64, false, fe_sub_mod(wX, w12));  // Tx
-            put_term_bytes(L, 5 * ng + sl, rep + 136, false, wY);                 // Ty
-        }
-    }
-    soa_st(V.sSg, sl, Sg), soa_st(V.sSh, sl, Sh), soa_st(V.sSkx, sl, Skx), soa_st(V.sSky, sl, Sky);
-    soa_st(V.sSR, sl, SR), soa_st(V.sSH, sl, SH), soa_st(V.sSL, sl, SL);
     // slot classes for k_v_straus: a zero-bit rep has 36 live terms, every other slot only terms 34, 35 (128-bit)
     V.slot_class[sl] = good && !bit ? 1 : 0;
+    if (!good) {
+        soa_st(V.pa_x, pa_idx, fe_const<ModQ, 2>(P256_GX_M)), soa_st(V.pa_y, pa_idx, fe_const<ModQ, 2>(P256_GY_M)), soa_st(V.pa_sc, pa_idx, fe_zero<ModN>());
+        for (uint32_t k = 0; k < V_SLOT_TERMS; k++) soa_st(L.sc, k * ng + sl, zero);
+        soa_st(V.sSg, sl, zero), soa_st(V.sSh, sl, zero), soa_st(V.sSkx, sl, zero), soa_st(V.sSky, sl, zero);
+        soa_st(V.sSR, sl, fe_zero<ModN>()), soa_st(V.sSH, sl, fe_zero<ModN>()), soa_st(V.sSL, sl, fe_zero<ModN>());
+        return;
+    }
+    const uint8_t* pr = proofs + off[first + p];
+    const uint8_t* rep = pr + rep_offset(V.hbits + 4 * p, i);
+    uint64_t gp = first + p;
+    const uint32_t tag = j << 8;
+    // ---- P-256 relation (exp.ts:270-276 / 305-317) with randomiser r[24] (mod n): the T term is (rho * s) * R
+    {
+        Sq r24[1];
+        v_rho_range<24, 1>(vseeds, gp, tag, r24);
+        Sn rn;
+        for (int l = 0; l < NLIMB; l++) rn.l[l] = r24[0].l[l];
+        soa_st(V.sSR, sl, fe_mul_mod(rn, ld_scalar_n(rep + 208)));
+        soa_st(V.sSH, sl, fe_mul_mod(rn, ld_scalar_n(rep + 240)));
+        soa_st(V.sSL, sl, bit ? fe_zero<ModN>() : rn);
+        // -rho * A  ==  rho * (-A)
+        uint32_t xw[8], yw[8];
+        load_be32(rep, xw);
+        load_be32(rep + 32, yw);
+        Fq2 ax = fe_to_mont(fe_from_words256_reduce<ModQ>(xw));
+        Fq2 ay = fe_reduce(fe_neg(fe_to_mont(fe_from_words256_reduce<ModQ>(yw))));
+        soa_st(V.pa_x, pa_idx, ax), soa_st(V.pa_y, pa_idx, ay), soa_st(V.pa_sc, pa_idx, rn);
+    }
+    Sq Sg, Sh;
+    if (bit) {
+        // relTx, relTy (exp.ts:287-297): r0 (sx g + beta2 h - Tx), r1 (sy g + beta3 h - Ty); sx, sy = affine T
+        Sq r[2];
+        v_rho_range<0, 2>(vseeds, gp, tag, r);
+        Sg = addq(mulq(r[0], soa_ld<ModQ, 1>(W.Tx, sl)), mulq(r[1], soa_ld<ModQ, 1>(W.Ty, sl)));
+        Sh = addq(mulq(r[0], ld_scalar_q(rep + 272)), mulq(r[1], ld_scalar_q(rep + 304)));
+        for (uint32_t k = 0; k < 34; k++) soa_st(L.sc, k * ng + sl, zero);
+        soa_st(L.sc, 34 * ng + sl, r[0]);
+        soa_st(L.sc, 35 * ng + sl, r[1]);
+        soa_st(V.sSkx, sl, zero), soa_st(V.sSky, sl, zero);
+    } else {
+        const uint8_t* pa = rep + ZK_REP_HEAD;
+        const uint32_t* cw = V.vc + (size_t)sl * 18;
+        Sq w7 = zero, w8 = zero, w9 = zero, w10 = zero, w11 = zero, w12 = zero, w13 = zero, w14 = zero, wX = zero, wY = zero;
+        Sg = zero, Sh = zero;
+        // pointAdd.ts:215-255
+        Sq r[5];
+        v_rho_range<0, 5>(vseeds, gp, tag, r);
+        v_mult(L, sl, ng, 6, 10, pa + 288, chalq(cw), r, w7, w8, w14, Sg, Sh);                      // pi8 : (C7, C8, C14 = g)
+        Sg = addq(Sg, w14);
+        v_rho_range<5, 5>(vseeds, gp, tag, r);
+        v_mult(L, sl, ng, 7, 15, pa + 288 + 656, chalq(cw + 3), r, w8, w9, w10, Sg, Sh);             // pi10: (C8, C9, C10)
+        soa_st(L.sc, 0 * ng + sl, w8);
+        {                                                                                             // pi11: (C10, C10, C11)
+            Sq wa = zero, wb = zero;
+            v_rho_range<10, 5>(vseeds, gp, tag, r);
+            v_mult(L, sl, ng, 8, 20, pa + 288 + 2 * 656, chalq(cw + 6), r, wa, wb, w11, Sg, Sh);
+            w10 = addq(w10, addq(wa, wb));
+        }
+        v_rho_range<15, 2>(vseeds, gp, tag, r);
+        v_eq(L, sl, ng, 30, pa + 2912, chalq(cw + 12), r, w11, wX, Sg, Sh);                            // pix : (C11, C3 + C1 + C2)
+        soa_st(L.sc, 2 * ng + sl, w11);
+        v_rho_range<17, 5>(vseeds, gp, tag, r);
+        v_mult(L, sl, ng, 9, 25, pa + 288 + 3 * 656, chalq(cw + 9), r, w10, w12, w13, Sg, Sh);         // pi13: (C10, C12, C13)
+        soa_st(L.sc, 1 * ng + sl, w10);
+        v_rho_range<22, 2>(vseeds, gp, tag, r);
+        v_eq(L, sl, ng, 32, pa + 3152, chalq(cw + 15), r, w13, wY, Sg, Sh);                            // piy : (C13, C4 + C6)
+        soa_st(L.sc, 3 * ng + sl, w13);
+        // redistribute the derived commitments: C7 = Px - T1x, C9 = Py - T1y, C12 = T1x - Tx, CintX = Tx + T1x + Px,
+        // CintY = T1y + Ty, C14 = g, T1x = sx g + r1 h, T1y = sy g + r2 h; sx, sy = T1 + Q of the slot
+        soa_st(L.sc, 4 * ng + sl, fe_sub_mod(wX, w12));  // Tx
+        soa_st(L.sc, 5 * ng + sl, wY);                   // Ty
+        soa_st(L.sc, 34 * ng + sl, zero), soa_st(L.sc, 35 * ng + sl, zero);
+        soa_st(V.sSkx, sl, addq(w7, wX)), soa_st(V.sSky, sl, w9);
+        Sq u1 = addq(fe_sub_mod(w12, w7), wX), u2 = fe_sub_mod(wY, w9);
+        Sg = addq(Sg, addq(mulq(u1, soa_ld<ModQ, 1>(W.Tx, sl)), mulq(u2, soa_ld<ModQ, 1>(W.Ty, sl))));
+        Sh = addq(Sh, addq(mulq(u1, ld_scalar_q(rep + 272)), mulq(u2, ld_scalar_q(rep + 304))));
+    }
+    soa_st(V.sSg, sl, Sg), soa_st(V.sSh, sl, Sh);
 }
 // Class-sorted slot order of a range of slots that goes to the per-proof sums (k_v_straus): local ids, class 1 from the front,
 // class 0 from the back, so that waves are homogeneous.
@@ -809,68 +867,103 @@ void launch_v_slot_perm(hipStream_t s, const uint8_t* slot_class, uint32_t nslot
     hipMemsetAsync(cnt, 0, 8, s);
     hipLaunchKernelGGL(k_v_slot_perm, dim3((nslots + 255) / 256), dim3(256), 0, s, slot_class, nslots, perm, cnt);
 }
-// one thread per proof: GK relations (gk.ts:223-259) -> groups of the gk list (4 per pair of bit positions: cl, cd 256-bit;
-// ca, cb 128-bit) and the per-proof totals for the shared points.
+// GK relations (gk.ts:223-259) -> groups of the gk list (4 per pair of bit positions: cl, cd 256-bit; ca, cb 128-bit) and the
+// per-proof totals for the shared points.
 // gk group q (q < ceil(n/2)) holds i = 2q, 2q+1: 256-bit terms {cl_i, cd_i} x2 = 0..3, 128-bit {ca_i, cb_i} x2 = 4..7.
 // misc group (index = p): 256-bit terms: 0 = Px (membership coefficient), 1 = Px (Exp), 2 = Py (Exp).
-__global__ void __launch_bounds__(64, 1) k_v_proof_terms(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
+//
+// Points: one thread per (term, group), term-major.
+__global__ void __launch_bounds__(256) k_v_proof_points(VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    uint32_t t = gtid(), n = V.n, nq = (n + 1) / 2, ngk = V.C * nq, nm = V.C, ngl = count * nq;
+    if (t >= ngl * 8 + count * 3) return;
+    const uint8_t* src = nullptr;
+    bool neg = false;
+    uint32_t idx;
+    if (t < ngl * 8) {
+        uint32_t k = t / ngl, g = t % ngl, p = g / nq, i = 2 * (g % nq) + ((k & 3) >> 1);
+        if (V.st[p] == ZK_OK && !(V.okflags[p] & 8) && i < n) {
+            const uint8_t* gk = v_gk_base(V, proofs + off[first + p], p);
+            // cl_i, -cd_i | ca_i, cb_i
+            src = gk + 72 * ((k < 4 ? (k & 1 ? 3 * n : 0) : (k & 1 ? 2 * n : n)) + i), neg = k < 4 && (k & 1);
+        }
+        idx = k * ngk + g;
+    } else {
+        uint32_t u = t - ngl * 8, k = u / count, p = u % count;
+        bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8);
+        if (good && (k == 0 || V.exp_st[p] == ZK_OK)) src = proofs + off[first + p] + (k == 2 ? 232 : 160);
+        idx = k * nm + p;
+    }
+    Ft2 x, y, dt;
+    term_point(src, neg, x, y, dt);
+    if (t < ngl * 8) soa_st(V.gk_terms.nx, idx, x), soa_st(V.gk_terms.ny, idx, y), soa_st(V.gk_terms.ndt, idx, dt);
+    else soa_st(V.misc_terms.nx, idx, x), soa_st(V.misc_terms.ny, idx, y), soa_st(V.misc_terms.ndt, idx, dt);
+}
+// Scalars: one thread per proof.
+__global__ void __launch_bounds__(64, 2) k_v_proof_terms(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
     uint32_t p = gtid();
     if (p >= count) return;
     uint32_t n = V.n, nq = (n + 1) / 2, ngk = V.C * nq, nm = V.C;
     bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8);
     Sq zero = fe_zero<ModQ>();
-    for (uint32_t q = 0; q < nq; q++)
-        for (uint32_t k = 0; k < 8; k++) put_term_null(V.gk_terms, k * ngk + p * nq + q);
-    for (uint32_t k = 0; k < 3; k++) put_term_null(V.misc_terms, k * nm + p);
-    Sq mg = zero, mh = zero;    // membership g, h coefficients
-    Sq eg = zero, eh = zero, ekx = zero, eky = zero;
-    Sn SR = fe_zero<ModN>(), SH = fe_zero<ModN>(), SL = fe_zero<ModN>();
-    for (uint32_t j = 0; j < VK; j++) {
-        uint32_t sl = p * VK + j;
-        eg = addq(eg, soa_ld<ModQ, 1>(V.sSg, sl)), eh = addq(eh, soa_ld<ModQ, 1>(V.sSh, sl));
-        ekx = addq(ekx, soa_ld<ModQ, 1>(V.sSkx, sl)), eky = addq(eky, soa_ld<ModQ, 1>(V.sSky, sl));
-        SR = fe_add_mod(SR, soa_ld<ModN, 1>(V.sSR, sl)), SH = fe_add_mod(SH, soa_ld<ModN, 1>(V.sSH, sl)), SL = fe_add_mod(SL, soa_ld<ModN, 1>(V.sSL, sl));
+    {
+        Sq eg = zero, eh = zero, ekx = zero, eky = zero;
+        Sn SR = fe_zero<ModN>(), SH = fe_zero<ModN>(), SL = fe_zero<ModN>();
+#pragma unroll 1
+        for (uint32_t j = 0; j < VK; j++) {
+            uint32_t sl = p * VK + j;
+            eg = addq(eg, soa_ld<ModQ, 1>(V.sSg, sl)), eh = addq(eh, soa_ld<ModQ, 1>(V.sSh, sl));
+            ekx = addq(ekx, soa_ld<ModQ, 1>(V.sSkx, sl)), eky = addq(eky, soa_ld<ModQ, 1>(V.sSky, sl));
+            SR = fe_add_mod(SR, soa_ld<ModN, 1>(V.sSR, sl)), SH = fe_add_mod(SH, soa_ld<ModN, 1>(V.sSH, sl)), SL = fe_add_mod(SL, soa_ld<ModN, 1>(V.sSL, sl));
+        }
+        // fixed-base parts: list C slots p*4n + {0: membership, 1: Exp}
+        soa_st(W.lc.v, p * 4 * n + 1, eg), soa_st(W.lc.r, p * 4 * n + 1, eh);
+        soa_st(V.pSR, p, SR), soa_st(V.pSH, p, SH), soa_st(V.pSL, p, SL);
+        bool e = good && V.exp_st[p] == ZK_OK;
+        soa_st(V.misc_terms.sc, 1 * nm + p, e ? ekx : zero);
+        soa_st(V.misc_terms.sc, 2 * nm + p, e ? eky : zero);
     }
+    Sq mg = zero, mh = zero;    // membership g, h coefficients
     if (good) {
         const uint8_t* pr = proofs + off[first + p];
-        const uint8_t* gk = v_gk_base(V, pr, p);
-        const uint8_t* sc = gk + 4 * 72 * n;
+        const uint8_t* sc = v_gk_base(V, pr, p) + 4 * 72 * n;
         uint64_t gp = first + p;
         Sq x = chalq(V.gkx + 3 * p);
         Sq rF, dummy;
         v_rho_pair(vseeds, gp, 0x10000u, rF, dummy);
         Sq xp = fe_zero<ModQ>();
         xp.l[0] = 1;  // x^i
+#pragma unroll 1
         for (uint32_t i = 0; i < n; i++) {
             Sq r0, r1;
             v_rho_pair(vseeds, gp, 0x10001u + i, r0, r1);
-            Sq f = ld_scalar_q(sc + 32 * i), za = ld_scalar_q(sc + 32 * (n + i)), zb = ld_scalar_q(sc + 32 * (2 * n + i));
             uint32_t grp = p * nq + (i >> 1), o = (i & 1) * 2;
             // rel0: x cl + ca - f g - za h ; rel1: (x - f) cl + cb - zb h
-            put_term_bytes(V.gk_terms, (o + 0) * ngk + grp, gk + 72 * i, false, addq(mulq(r0, x), mulq(r1, fe_sub_mod(x, f))));
-            put_term_bytes(V.gk_terms, (4 + o) * ngk + grp, gk + 72 * (n + i), false, r0);
-            put_term_bytes(V.gk_terms, (5 + o) * ngk + grp, gk + 72 * (2 * n + i), false, r1);
+            {
+                Sq f = ld_scalar_q(sc + 32 * i);
+                soa_st(V.gk_terms.sc, (o + 0) * ngk + grp, addq(mulq(r0, x), mulq(r1, fe_sub_mod(x, f))));
+                mg = addq(mg, mulq(r0, f));
+            }
+            soa_st(V.gk_terms.sc, (4 + o) * ngk + grp, r0);
+            soa_st(V.gk_terms.sc, (5 + o) * ngk + grp, r1);
             // relFinal: -x^i cd_i
-            put_term_bytes(V.gk_terms, (o + 1) * ngk + grp, gk + 72 * (3 * n + i), true, mulq(rF, xp));
-            mg = addq(mg, mulq(r0, f));
-            mh = addq(mh, addq(mulq(r0, za), mulq(r1, zb)));
+            soa_st(V.gk_terms.sc, (o + 1) * ngk + grp, mulq(rF, xp));
+            mh = addq(mh, mulq(r0, ld_scalar_q(sc + 32 * (n + i))));
+            mh = addq(mh, mulq(r1, ld_scalar_q(sc + 32 * (2 * n + i))));
             xp = mulq(xp, x);
         }
-        Sq zd = ld_scalar_q(sc + 32 * 3 * n);
+        if (n & 1)
+            for (uint32_t k = 2; k < 8; k++)
+                if (k != 4 && k != 5) soa_st(V.gk_terms.sc, k * ngk + p * nq + nq - 1, zero);
         mg = addq(mg, mulq(rF, soa_ld<ModQ, 1>(V.gk_total, p)));
-        mh = addq(mh, mulq(rF, zd));
+        mh = addq(mh, mulq(rF, ld_scalar_q(sc + 32 * 3 * n)));
         mg = fe_sub_mod(zero, mg), mh = fe_sub_mod(zero, mh);
-        put_term_bytes(V.misc_terms, 0 * nm + p, pr + 160, false, mulq(rF, xp));  // x^n com
-        if (V.exp_st[p] == ZK_OK) {
-            put_term_bytes(V.misc_terms, 1 * nm + p, pr + 160, false, ekx);
-            put_term_bytes(V.misc_terms, 2 * nm + p, pr + 232, false, eky);
-        }
+        soa_st(V.misc_terms.sc, 0 * nm + p, mulq(rF, xp));  // x^n com
+    } else {
+        for (uint32_t q = 0; q < nq; q++)
+            for (uint32_t k = 0; k < 8; k++) soa_st(V.gk_terms.sc, k * ngk + p * nq + q, zero);
+        soa_st(V.misc_terms.sc, 0 * nm + p, zero);
     }
-    // fixed-base parts: list C slots p*4n + {0: membership, 1: Exp}
-    uint32_t lc = p * 4 * n;
-    soa_st(W.lc.v, lc, mg), soa_st(W.lc.r, lc, mh);
-    soa_st(W.lc.v, lc + 1, eg), soa_st(W.lc.r, lc + 1, eh);
-    soa_st(V.pSR, p, SR), soa_st(V.pSH, p, SH), soa_st(V.pSL, p, SL);
+    soa_st(W.lc.v, p * 4 * n, mg), soa_st(W.lc.r, p * 4 * n, mh);
 }
 
 // ------------------------------------------------------------------ windowed Straus over a group of terms
@@ -1004,41 +1097,47 @@ void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t 
 // terms in global memory (projective, rtab.h entry format), then runs 33 windows of 4 doublings + 5 complete additions
 // (the bit-serial version computed 128 doublings + 640 additions per thread).
 #define VP_NW 33
-__global__ void __launch_bounds__(256, 1) k_v_p256_straus(VWork V, uint32_t count) {
+// one thread per term: digits of its randomiser and the multiples {1A..8A}
+__global__ void __launch_bounds__(256, 2) k_v_p256_tables(VWork V, uint32_t count) {
+    uint32_t idx = gtid();
+    if (idx >= count * VK) return;
+    const uint32_t cap = V.C * VK;
+    uint32_t kw[8];
+    words_from_limbs<8>(kw, soa_ld<ModN, 1>(V.pa_sc, idx).l);
+    uint32_t carry = 0;
+#pragma unroll 1
+    for (uint32_t w = 0; w < VP_NW; w++) {
+        uint32_t d = (kw[0] & 15) + carry;
+        shr256<4>(kw);
+        bool neg = d > 8;
+        carry = neg ? 1 : 0;
+        if (neg) d = 16 - d;
+        V.pa_dig[(size_t)w * cap + idx] = (uint8_t)(d | (neg ? 0x80u : 0u));
+    }
+    P256Aff a;
+    a.x = soa_ld<ModQ, 2>(V.pa_x, idx), a.y = soa_ld<ModQ, 2>(V.pa_y, idx);
+    P256Pt b = p256_from_affine(a), m = b;
+    uint32_t* e = V.pa_tab + (size_t)idx * 8 * RTAB_ENTRY_WORDS;
+    st_rtab(e, m);
+    m = p256_dbl(b);
+    st_rtab(e + RTAB_ENTRY_WORDS, m);
+#pragma unroll 1
+    for (uint32_t d = 2; d < 8; d++) {   // doubling and additions in separate regions: one live set at a time
+        m = p256_add(m, b);
+        st_rtab(e + d * RTAB_ENTRY_WORDS, m);
+    }
+}
+// thread (p, q): windowed sum over terms 5q .. 5q+4 of proof p
+__global__ void __launch_bounds__(256) k_v_p256_straus(VWork V, uint32_t count) {
     uint32_t t = gtid();
     if (t >= count * 4) return;
     uint32_t p = t / 4, q = t % 4;
     const uint32_t cap = V.C * VK;
-#pragma unroll 1
-    for (uint32_t k = 0; k < 5; k++) {
-        uint32_t idx = p * VK + q * 5 + k;
-        uint32_t kw[8];
-        words_from_limbs<8>(kw, soa_ld<ModN, 1>(V.pa_sc, idx).l);
-        uint32_t carry = 0;
-#pragma unroll 1
-        for (uint32_t w = 0; w < VP_NW; w++) {
-            uint32_t d = (kw[0] & 15) + carry;
-            shr256<4>(kw);
-            bool neg = d > 8;
-            carry = neg ? 1 : 0;
-            if (neg) d = 16 - d;
-            V.pa_dig[(size_t)w * cap + idx] = (uint8_t)(d | (neg ? 0x80u : 0u));
-        }
-        P256Aff a;
-        a.x = soa_ld<ModQ, 2>(V.pa_x, idx), a.y = soa_ld<ModQ, 2>(V.pa_y, idx);
-        P256Pt b = p256_from_affine(a), m = b;
-        uint32_t* e = V.pa_tab + (size_t)idx * 8 * RTAB_ENTRY_WORDS;
-        st_rtab(e, m);
-#pragma unroll 1
-        for (uint32_t d = 1; d < 8; d++) {
-            m = d == 1 ? p256_dbl(b) : p256_add(m, b);
-            st_rtab(e + d * RTAB_ENTRY_WORDS, m);
-        }
-    }
     P256Pt acc = p256_identity();
 #pragma unroll 1
     for (int w = VP_NW - 1; w >= 0; w--) {
-        acc = p256_dbl(p256_dbl(p256_dbl(p256_dbl(acc))));
+#pragma unroll 1
+        for (int d = 0; d < 4; d++) acc = p256_dbl(acc);
 #pragma unroll 1
         for (uint32_t k = 0; k < 5; k++) {
             uint32_t idx = p * VK + q * 5 + k;
@@ -1193,10 +1292,15 @@ void launch_v_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, c
     L1(k_v_padd_hash, count * VK * 6, 256, P, W, V, count, proofs, off, first);
 }
 void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
+    L1(k_v_slot_points, count * VK * V_SLOT_TERMS, 256, V, count, proofs, off, first);
     L1(k_v_slot_terms, count * VK, 64, W, V, count, proofs, off, vseeds, first);
+    L1(k_v_proof_points, count * ((V.n + 1) / 2 * 8 + 3), 256, V, count, proofs, off, first);
     L1(k_v_proof_terms, count, 64, W, V, count, proofs, off, vseeds, first);
 }
-void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count) { L1(k_v_p256_straus, count * 4, 256, V, count); }
+void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count) {
+    L1(k_v_p256_tables, count * VK, 256, V, count);
+    L1(k_v_p256_straus, count * 4, 256, V, count);
+}
 void launch_v_final(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first,
                     const VGroupFlags& gf, uint32_t gsz) {
     L1(k_v_final, count, 64, P, W, V, count, ok, status, first, gf, gsz);
