@@ -1,0 +1,67 @@
+"""Register / scratch budget of every kernel in the built library, read from the AMDGPU metadata notes of the gfx950 code object
+(tools/kernel_meta.py).  No GPU needed.
+
+Why this is a test: some MI355X boxes of the pool run kernels that lean on AGPR copies or scratch-backed spills 2-3x slower than
+others (profiles/r02_rocprofv3_kernel_stats.csv was taken on one), so the library keeps every kernel at >= 2 waves per SIMD without
+AGPRs and without register spills; the few kernels that own a private-memory frame are listed here with the reason."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, 'zkp-ecdsa_amd', 'lib', 'libzkattest_hip.so')
+
+spec = importlib.util.spec_from_file_location('kernel_meta', os.path.join(ROOT, 'tools', 'kernel_meta.py'))
+kernel_meta = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(kernel_meta)
+
+# kernels that may own a scratch frame: (substring of the mangled name, max bytes, reason)
+SCRATCH_OK = [
+    ('rocprim', 96, 'rocPRIM radix sort of the MSM keys (library code)'),
+    ('k_synth_proofs', 96, 'workload generator of bench/tests, not on the prove/verify path'),
+    ('k_v_gk_small', 192, 'rings of <= 4 keys only: dynamically indexed fold buffer'),
+    # the out-of-line SHA-256 compression saves one callee-saved VGPR in its frame
+    ('k_v_padd_hash', 8, 'sha frame'), ('k_v_challenges', 8, 'sha frame'), ('k_exp_challenge', 8, 'sha frame'),
+    ('k_padd_hash', 8, 'sha frame'), ('k_gk_hash', 8, 'sha frame'), ('k_ring_leaves', 8, 'sha frame'), ('k_ring_root', 8, 'sha frame'),
+    ('k_test_sha256', 8, 'sha frame'),
+]
+# verifier / prover kernels the round-1 review named: they must fit two waves per SIMD in architectural VGPRs alone
+NAMED = ['k_v_slot_terms', 'k_v_slot_points', 'k_v_proof_terms', 'k_v_proof_points', 'k_v_p256_straus', 'k_v_p256_tables', 'k_v_term_tables',
+         'k_v_straus', 'k_v_final', 'k_padd_scalars', 'k_padd_respond', 'k_tom_commit', 'k_exp_commit']
+
+
+@pytest.fixture(scope='module')
+def kernels():
+    if not os.path.exists(LIB):
+        pytest.skip('library not built')
+    ks = kernel_meta.kernels(LIB)
+    assert len(ks) > 100, 'metadata of the gfx950 code object not found'
+    return ks
+
+
+def test_no_kernel_uses_agprs_or_spills_vgprs(kernels):
+    bad = {n: k for n, k in kernels.items() if k['agpr'] or k['vgpr_spill']}
+    assert not bad, bad
+
+
+def test_every_kernel_fits_two_waves_per_simd(kernels):
+    # gfx950: 512 registers per SIMD lane shared by the waves of a SIMD; vgpr_count includes AGPRs
+    bad = {n: k['vgpr'] for n, k in kernels.items() if k['vgpr'] > 256}
+    assert not bad, bad
+
+
+def test_scratch_only_where_listed(kernels):
+    for name, k in kernels.items():
+        if not k['scratch']:
+            continue
+        allowed = [mx for sub, mx, _ in SCRATCH_OK if sub in name]
+        assert allowed and k['scratch'] <= max(allowed), (name, k['scratch'])
+
+
+def test_named_kernels_present_and_clean(kernels):
+    for want in NAMED:
+        hits = [(n, k) for n, k in kernels.items() if want in n]
+        assert hits, want
+        for n, k in hits:
+            assert k['scratch'] == 0 and k['agpr'] == 0 and k['vgpr'] <= 256 and k['waves_per_simd'] >= 2, (n, k)

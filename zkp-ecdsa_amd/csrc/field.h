@@ -474,7 +474,7 @@ ZK_DEV Fe<M, K> fe_select(bool c, const Fe<M, K>& a, const Fe<M, K>& b) {  // c 
 
 // a^e for a public exponent e given as 9 little-endian 32-bit words (right-to-left binary), Montgomery domain
 template <class M>
-ZK_DEV_NOINLINE Fe<M, 2> fe_pow_words(const Fe<M, 2>& a, const uint32_t e[NLIMB]) {
+ZK_DEV_NOINLINE Fe<M, 2> fe_pow_words(Fe<M, 2> a, const uint32_t e[NLIMB]) {
     Fe<M, 2> acc = fe_one_mont<M>().template as<2>(), base = a;
     for (int w = 0; w < NLIMB; w++) {
         uint32_t ew = e[w];
@@ -500,10 +500,10 @@ ZK_DEV void limbs_from_words(uint32_t l[NLIMB], const uint32_t w[NW]) {
 #pragma unroll
     for (int i = 0; i < NLIMB; i++) {
         const int bit = i * LIMB_BITS, wi = bit / 32, sh = bit % 32;
-        uint64_t v = 0;
-        if (wi < NW) v = w[wi];
-        if (wi + 1 < NW) v |= (uint64_t)w[wi + 1] << 32;
-        l[i] = (uint32_t)(v >> sh) & LIMB_MASK;
+        uint32_t v = 0;  // 32-bit shifts only: a 64-bit (w[wi+1]:w[wi]) pair makes the compiler park w[] in scratch to reload it as dwordx2
+        if (wi < NW) v = w[wi] >> sh;
+        if (sh > 32 - LIMB_BITS && wi + 1 < NW) v |= w[wi + 1] << (32 - sh);
+        l[i] = v & LIMB_MASK;
     }
 }
 template <int NW>

@@ -238,7 +238,7 @@ void launch_t1(hipStream_t s, const Workspace& W, uint32_t items) {
 }
 
 // ---------------------------------------------------------------- unit-test hook: k*G / k*h_NIST
-__global__ void k_test_pfix(const uint32_t* tab, uint64_t count, const uint8_t* k_be, uint8_t* out) {
+__global__ void __launch_bounds__(64) k_test_pfix(const uint32_t* tab, uint64_t count, const uint8_t* k_be, uint8_t* out) {
     uint32_t t = gtid();
     if (t >= count) return;
     uint32_t kw[8];

@@ -32,7 +32,7 @@ ZK_DEV TomPt ld_tompt(const uint32_t* p) {
     for (int l = 0; l < 9; l++) a.x.l[l] = p[l], a.y.l[l] = p[9 + l], a.t.l[l] = p[18 + l], a.z.l[l] = p[27 + l];
     return a;
 }
-__global__ void k_tomtab_bases(const uint32_t* xy, uint32_t* scratch, int32_t* ok, uint32_t bits, uint32_t nwin) {
+__global__ void __launch_bounds__(64) k_tomtab_bases(const uint32_t* xy, uint32_t* scratch, int32_t* ok, uint32_t bits, uint32_t nwin) {
     if (gtid() != 0) return;
     uint32_t xw[9], yw[9];
     for (int i = 0; i < 9; i++) xw[i] = xy[i], yw[i] = xy[9 + i];
@@ -44,7 +44,7 @@ __global__ void k_tomtab_bases(const uint32_t* xy, uint32_t* scratch, int32_t* o
         for (uint32_t i = 0; i < bits; i++) p = tom_dbl(p);
     }
 }
-__global__ void k_tomtab_sub(uint32_t* scratch, uint32_t nwin, uint32_t lo, uint32_t n_hi) {
+__global__ void __launch_bounds__(64) k_tomtab_sub(uint32_t* scratch, uint32_t nwin, uint32_t lo, uint32_t n_hi) {
     uint32_t t = gtid();
     uint32_t per_win = (1u << lo) + n_hi;
     uint32_t hi = 32 - __clz(n_hi > 1 ? n_hi - 1 : 1);  // bits of the largest Hi index
@@ -148,7 +148,7 @@ __global__ void k_pfix_bases(const uint32_t* xy, uint32_t* scratch, int32_t* ok)
         for (int i = 0; i < PFIX_WIN_BITS; i++) p = p256_dbl(p);
     }
 }
-__global__ void k_pfix_fill(uint32_t* scratch) {
+__global__ void __launch_bounds__(64) k_pfix_fill(uint32_t* scratch) {
     uint32_t t = gtid();
     if (t >= PFIX_NWIN * PFIX_WIN_SIZE) return;
     uint32_t w = t >> PFIX_WIN_BITS, d = t & (PFIX_WIN_SIZE - 1);

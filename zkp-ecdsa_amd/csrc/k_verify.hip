@@ -17,9 +17,11 @@ typedef Fe<ModN, 1> Sn;
 typedef Fe<ModT, 1> St;
 
 // ------------------------------------------------------------------ byte parsing
-ZK_DEV void ld_words_be(const uint8_t* p, int nw, uint32_t* w) {
+template <int NW>
+ZK_DEV void ld_words_be(const uint8_t* p, uint32_t* w) {
     const uint32_t* q = (const uint32_t*)p;
-    for (int i = 0; i < nw; i++) w[i] = bswap32(q[nw - 1 - i]);
+#pragma unroll
+    for (int i = 0; i < NW; i++) w[i] = bswap32(q[NW - 1 - i]);
 }
 ZK_DEV Sq ld_scalar_q(const uint8_t* p) {
     uint32_t w[8];
@@ -34,8 +36,8 @@ ZK_DEV Sn ld_scalar_n(const uint8_t* p) {
 // 72-byte Tom point -> plain limbs; false if a coordinate is >= t (edwards.ts:74-77)
 ZK_DEV bool ld_tom_bytes(const uint8_t* p, St& x, St& y) {
     uint32_t xw[9], yw[9];
-    ld_words_be(p, 9, xw);
-    ld_words_be(p + 36, 9, yw);
+    ld_words_be<9>(p, xw);
+    ld_words_be<9>(p + 36, yw);
     bool ok = !words_geq<9>(xw, ModT::mod32) && !words_geq<9>(yw, ModT::mod32);
     limbs_from_words<9>(x.l, xw);
     limbs_from_words<9>(y.l, yw);
@@ -43,8 +45,8 @@ ZK_DEV bool ld_tom_bytes(const uint8_t* p, St& x, St& y) {
 }
 ZK_DEV bool tom_bytes_valid(const uint8_t* p) {  // edwards.ts:204-209 afterJson: range + curve equation
     uint32_t xw[9], yw[9];
-    ld_words_be(p, 9, xw);
-    ld_words_be(p + 36, 9, yw);
+    ld_words_be<9>(p, xw);
+    ld_words_be<9>(p + 36, yw);
     TomPt t;
     return tom_from_affine_words(t, xw, yw);
 }
@@ -177,9 +179,9 @@ __global__ void __launch_bounds__(64) k_v_front(DevParams P, Workspace W, VWork 
 ZK_DEV void absorb_tom_bytes(ShaStream& s, const uint8_t* p72) {  // 36-byte padded coordinates -> 33-byte encodings
     uint32_t w[9];
     s.put_byte(4);
-    ld_words_be(p72, 9, w);
+    ld_words_be<9>(p72, w);
     s.put_be<33>(w);
-    ld_words_be(p72 + 36, 9, w);
+    ld_words_be<9>(p72 + 36, w);
     s.put_be<33>(w);
 }
 // hashPoints serialises through toBytes -> toAffine (group.ts:221-233, weier.ts:231-255), which reduces the coordinates mod p;
@@ -437,13 +439,15 @@ __global__ void __launch_bounds__(256) k_v_derived(Workspace W, VWork V, uint32_
         const uint8_t* pr = proofs + off[first + p];
         const uint8_t* rep = pr + rep_offset(V.hbits + 4 * p, i);
         uint32_t la = p * (2 + 2 * W.sec) + 2 * j;
-        TomPt t1x = v_tom_from_plain(soa_ld<ModT, 1>(W.la.ax, la), soa_ld<ModT, 1>(W.la.ay, la));
-        TomPt t1y = v_tom_from_plain(soa_ld<ModT, 1>(W.la.ax, la + 1), soa_ld<ModT, 1>(W.la.ay, la + 1));
-        if (k == 0) r = tom_add(v_tom_from_bytes(pr + 160), tom_neg(t1x));                     // C7 = Px - T1x
-        else if (k == 1) r = tom_add(v_tom_from_bytes(pr + 232), tom_neg(t1y));                // C9 = Py - T1y
-        else if (k == 2) r = tom_add(t1x, tom_neg(v_tom_from_bytes(rep + 64)));                // C12 = T1x - Tx
-        else if (k == 3) r = tom_add(tom_add(v_tom_from_bytes(rep + 64), t1x), v_tom_from_bytes(pr + 160));  // Tx + T1x + Px
-        else r = tom_add(t1y, v_tom_from_bytes(rep + 136));                                    // C4 + C6 = T1y + Ty
+        // C7 = Px - T1x | C9 = Py - T1y | C12 = T1x - Tx | CintX = Tx + T1x + Px | CintY = C4 + C6 = T1y + Ty: one T1 coordinate
+        // commitment and one point of the proof, either of them negated, selected by k so that there is one code path
+        uint32_t lai = la + (k == 1 || k == 4 ? 1 : 0);
+        TomPt a = v_tom_from_plain(soa_ld<ModT, 1>(W.la.ax, lai), soa_ld<ModT, 1>(W.la.ay, lai));
+        TomPt b = v_tom_from_bytes(k == 0 ? pr + 160 : k == 1 ? pr + 232 : k == 4 ? rep + 136 : rep + 64);
+        if (k < 2) a = tom_neg(a);
+        if (k == 2) b = tom_neg(b);
+        r = tom_add(a, b);
+        if (k == 3) r = tom_add(r, v_tom_from_bytes(pr + 160));
     }
     soa_st(V.vd.proj.x, t, r.x), soa_st(V.vd.proj.y, t, r.y), soa_st(V.vd.proj.z, t, r.z);
 }
