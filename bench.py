@@ -148,8 +148,9 @@ def host_io_rates(Z, eng, args, B, sec, msg, sig, pk, which, seeds, dev, device_
     hm, hs, hp, hw, hseed = msg[:32 * nb], sig[:64 * nb], pk[:64 * nb], which[:nb], seeds[:32 * nb]
     chunk, vchunk = min(args.host_io_chunk, nb), min(args.host_io_verify_chunk, nb)
     eng.set_chunk(chunk)
+    eng.set_lanes(args.host_io_lanes)
     eng.prove_batch_host_raw(hm[:32 * 256], hs[:64 * 256], hp[:64 * 256], hw[:256], hseed[:32 * 256])   # warm-up
-    host_io = {'proofs': nb, 'chunk': chunk, 'verify_chunk': vchunk, 'plan': 'staggered lanes, sliced PointAdd phase' if not args.host_io_uniform else 'uniform chunks',
+    host_io = {'proofs': nb, 'chunk': chunk, 'verify_chunk': vchunk, 'lanes': args.host_io_lanes, 'plan': 'staggered lanes, sliced PointAdd phase' if not args.host_io_uniform else 'uniform chunks',
                'note': 'PCIe-inclusive: one zk_prove_batch / zk_verify_batch call on host buffers (SURVEY.md 8(d)); `value` is the device-resident rate'}
     eng.set_host_taper(0 if args.host_io_uniform else 1)
     host_io['pcie'] = pcie_bandwidth(dev)
@@ -183,6 +184,7 @@ def host_io_rates(Z, eng, args, B, sec, msg, sig, pk, which, seeds, dev, device_
     del hout
     pin.free()
     eng.set_chunk(min(args.chunk, B))
+    eng.set_lanes(args.lanes)
     return host_io
 
 
@@ -311,18 +313,21 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=65536, help='proofs per GPU per step')
     ap.add_argument('--ring', type=int, default=65536, help='number of keys in the ring')
-    ap.add_argument('--chunk', type=int, default=32768, help='proofs per pipeline pass')
+    ap.add_argument('--chunk', type=int, default=22016, help='proofs per pipeline pass of the prover (3 chunks of a 65536-proof step, one per lane)')
     ap.add_argument('--seed', type=int, default=2024)
     ap.add_argument('--sec', type=int, default=80)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=0, help='proofs in the CPU baseline sample (default 4 x cores, all of them diffed against the GPU output)')
     ap.add_argument('--comb-bits', type=int, default=DEFAULT_COMB_BITS, help='width of the Tom-256 fixed-base comb tables (8..24; 25, 26 = signed digits); 24 = 47 GB of tables')
-    ap.add_argument('--lanes', type=int, default=2, help='chunks in flight on separate streams during the timed steps (1 = serial)')
+    ap.add_argument('--lanes', type=int, default=3, help='chunks in flight on separate streams during the timed steps (1 = serial)')
+    ap.add_argument('--verify-chunk', type=int, default=32768, help='proofs per pipeline pass of the verify half (0 = --chunk): the cross-proof sums like large chunks')
+    ap.add_argument('--verify-lanes', type=int, default=2, help='chunks in flight of the verify half (0 = --lanes)')
     ap.add_argument('--roofline-steps', type=int, default=1, help='extra single-lane passes used only for per-kernel timings')
     ap.add_argument('--verify-steps', type=int, default=1, help='timed verifySignatureList passes over the produced proofs (0 = skip)')
     ap.add_argument('--host-io', type=int, default=1 << 30, help='proofs of the zk_prove_batch / zk_verify_batch calls on HOST buffers (PCIe-inclusive rates; default: the whole batch; 0 = skip)')
     ap.add_argument('--host-io-chunk', type=int, default=16384, help='proofs per chunk of the zk_prove_batch --host-io calls (the PointAdd phase of a chunk runs in slices of 4096 proofs, each followed by its D2H)')
     ap.add_argument('--host-io-verify-chunk', type=int, default=8192, help='proofs per chunk of the zk_verify_batch --host-io calls (H2D-bound: smaller chunks start earlier and leave less work behind the last transfer)')
+    ap.add_argument('--host-io-lanes', type=int, default=2, help='chunks in flight during the host-buffer calls')
     ap.add_argument('--host-io-reps', type=int, default=2, help='timed repetitions of the host-buffer calls (best is reported)')
     ap.add_argument('--host-io-uniform', action='store_true', help='uniform chunks instead of the tapered plan')
     ap.add_argument('--host-io-pageable', action='store_true', help='also measure ordinary (pageable) host buffers')
@@ -401,7 +406,7 @@ def main():
     barrier()
     dt = time.time() - t0
     # per-kernel timings for the roofline: ONE extra pass with strictly serial kernels (single lane), HIP events on the
-    # engine's stream around every launch.  In the timed steps above two chunks overlap on two streams, which makes a
+    # engine's stream around every launch.  In the timed steps above the chunks of a step overlap on their lanes' streams, which makes a
     # single kernel's duration ill-defined; this pass is not part of `value`.
     fam = {}
     gpu_ms = 0.0
@@ -431,6 +436,10 @@ def main():
         d_vst = torch.empty(B, dtype=torch.int32, device=dev)
         d_vseeds = tb(rank_seeds(seeds, rank + 1000))
 
+        vchunk, vlanes = min(args.verify_chunk or args.chunk, B), args.verify_lanes or args.lanes
+        eng.set_chunk(vchunk)
+        eng.set_lanes(vlanes)
+
         def vstep():
             eng.verify_batch_device(B, d_msg.data_ptr(), d_out.data_ptr(), d_off.data_ptr(), d_vseeds.data_ptr(), d_ok.data_ptr(), d_vst.data_ptr())
         vstep()  # warm-up (allocates the verifier workspace)
@@ -445,15 +454,16 @@ def main():
         vstep()
         _, vfam = eng.last_timing()
         eng.set_lanes(args.lanes)
+        eng.set_chunk(min(args.chunk, B))
         if world > 1:
             t = torch.tensor([vdt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             vdt = float(t.item())
         n_ok = int(d_ok.sum().item())
         verify = {'value': round(world * B * args.verify_steps / vdt, 2), 'unit': 'verifies/s', 'steps': args.verify_steps,
-                  'ms_per_step': round(vdt * 1e3 / args.verify_steps, 2), 'accepted': n_ok, 'of': B,
+                  'ms_per_step': round(vdt * 1e3 / args.verify_steps, 2), 'accepted': n_ok, 'of': B, 'chunk': vchunk, 'lanes': vlanes,
                   'gpu_ms_by_family_per_step': {k: round(v, 2) for k, v in sorted(vfam.items(), key=lambda kv: -kv[1])},
-                  'gpu_ms_note': 'serial single-lane pass; the timed passes overlap two chunks on two streams'}
+                  'gpu_ms_note': 'serial single-lane pass; the timed passes overlap %d chunks on %d streams' % (vlanes, vlanes)}
 
     free_b, total_b = torch.cuda.mem_get_info()
     hbm_used = total_b - free_b
@@ -534,14 +544,14 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32 (9x30-bit limbs, 256/258-bit modular integers)',
             'data': 'synthetic',
-            'config': {'workload': 'batch=%d proofs per GPU per step, ring=%d keys (n=%d), secLevel=%d, P-256 + Tom-256, chunk=%d, comb=%d bits'
-                                   % (B, nkeys, n_log2, sec, eng_chunk(args, B), args.comb_bits),
+            'config': {'workload': 'batch=%d proofs per GPU per step, ring=%d keys (n=%d), secLevel=%d, P-256 + Tom-256, chunk=%d x %d lanes, comb=%d bits'
+                                   % (B, nkeys, n_log2, sec, eng_chunk(args, B), args.lanes, args.comb_bits),
                        'parallelism': 'proofs sharded per GPU; ring broadcast over RCCL at set-up' if world > 1 else 'single GPU'},
             'set_params_s': round(t_tab, 3),
             'hbm_used_gb': round(hbm_used / 2**30, 1),   # tables + both lanes' prover and verifier workspaces + this step's proofs
             'proof_bytes_per_step': total_bytes, 'failed_proofs': nbad,
             'gpu_ms_by_family_per_step': {k: round(v / max(1, args.roofline_steps), 2) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
-            'gpu_ms_note': 'serial single-lane pass (sum = %.1f ms); the timed steps overlap two chunks on two streams' % (gpu_ms / max(1, args.roofline_steps)),
+            'gpu_ms_note': 'serial single-lane pass (sum = %.1f ms); the timed steps overlap %d chunks on %d streams' % (gpu_ms / max(1, args.roofline_steps), args.lanes, args.lanes),
             'roofline': roofline, 'cpu_baseline': cpu, 'verify': verify, 'host_io': host_io, 'json': json_rates,
         }
         if host_io and 'pinned' in host_io:   # the SURVEY.md 8(d) form of the metric, next to the device-resident `value`

@@ -42,10 +42,14 @@ __host__ __device__ static inline bool tom_signed(uint32_t bits) { return bits >
 __host__ __device__ static inline uint32_t tom_nwin(uint32_t bits) { return ((tom_signed(bits) ? 257 : 256) + bits - 1) / bits; }
 __host__ __device__ static inline uint32_t tom_win_entries(uint32_t bits) { return tom_signed(bits) ? (1u << (bits - 1)) + 1 : 1u << bits; }
 static inline size_t tom_tab_words(uint32_t bits) { return (size_t)tom_nwin(bits) * tom_win_entries(bits) * TOM_ENTRY_WORDS; }
-// P-256 fixed bases (G, h_NIST): PFIX_WIN_BITS-bit comb windows (default 16), entry = affine (x, y) Montgomery limbs,
+// P-256 fixed bases (G, h_NIST): PFIX_WIN_BITS-bit comb windows (default 20: 13 windows, 1.1 GB per base), entry = affine (x, y) Montgomery limbs,
 // 20 words (80 B); digit 0 unused.
+// batch normalisers: points per Fermat inversion (one thread walks `per` points strided by the thread count)
+#ifndef ZK_NORM_PER_MAX
+#define ZK_NORM_PER_MAX 256
+#endif
 #ifndef PFIX_WIN_BITS
-#define PFIX_WIN_BITS 16
+#define PFIX_WIN_BITS 20
 #endif
 #define PFIX_NWIN ((256 + PFIX_WIN_BITS - 1) / PFIX_WIN_BITS)
 #define PFIX_WIN_SIZE (1u << PFIX_WIN_BITS)

@@ -20,7 +20,7 @@ ZK_DEV P256Aff ld_pfix(const uint32_t* e) {
     for (int l = 0; l < 9; l++) a.x.l[l] = w[l], a.y.l[l] = w[9 + l];
     return a;
 }
-// k * B for a fixed base with an 8-bit comb table; k given as 8 little-endian words (clobbered)
+// k * B for a fixed base with a PFIX_WIN_BITS-bit comb table; k given as 8 little-endian words (clobbered)
 ZK_DEV P256Pt p256_fixed_mul(const uint32_t* __restrict__ tab, uint32_t kw[8]) {
     P256Pt acc = p256_identity();
 #pragma unroll 1
@@ -213,7 +213,7 @@ void launch_p256_normalize(hipStream_t s, const Soa3& proj, uint32_t count, cons
     if (!count) return;
     uint32_t per = count / (256 * 4 * 64 * 2);
     if (per < 4) per = 4;
-    if (per > 64) per = 64;
+    if (per > ZK_NORM_PER_MAX) per = ZK_NORM_PER_MAX;
     uint32_t nthreads = (count + per - 1) / per;
     hipLaunchKernelGGL(k_p256_normalize, dim3((nthreads + 255) / 256), dim3(256), 0, s, proj, count, nthreads, per, ox, oy, st, per_proof, err_code, owner);
 }

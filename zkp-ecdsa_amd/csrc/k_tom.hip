@@ -213,7 +213,7 @@ void launch_tom_normalize(hipStream_t s, const TomList& L, uint32_t count, uint3
     if (!count) return;
     uint32_t per = count / (256 * 4 * 64 * 2);
     if (per < 4) per = 4;
-    if (per > 64) per = 64;
+    if (per > ZK_NORM_PER_MAX) per = ZK_NORM_PER_MAX;
     uint32_t nthreads = (count + per - 1) / per;
     hipLaunchKernelGGL(k_tom_normalize, dim3((nthreads + 255) / 256), dim3(256), 0, s, L, count, nthreads, per, first, per_group, slots_per_group, kstride);
 }
