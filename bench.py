@@ -227,7 +227,7 @@ def run_verify_mode(args, torch, Z, world, rank, local_rank, dev):
     d_ok = torch.empty(slab, dtype=torch.uint8, device=dev)
     d_vst = torch.empty(slab, dtype=torch.int32, device=dev)
 
-    def one_pass(pass_no, timed):
+    def one_pass(pass_no, plant):   # pass_no >= 0 keys the per-slab seeds; plant: forgeries in the first slab
         t_v, acc, t_p, nbytes = 0.0, 0, 0.0, 0
         for sl in range(nslabs):
             cnt = min(slab, shard - sl * slab)
@@ -240,7 +240,7 @@ def run_verify_mode(args, torch, Z, world, rank, local_rank, dev):
             torch.cuda.synchronize()
             t_p += time.time() - t0
             forged = []
-            if timed and pass_no == 0 and sl == 0 and cnt >= 64:   # planted forgeries in the first timed slab
+            if plant and sl == 0 and cnt >= 64:   # planted forgeries in the first timed slab
                 off = d_off[:cnt + 1].cpu().tolist()
                 forged = [3, cnt // 2, cnt - 1]
                 for b in forged:
@@ -260,14 +260,14 @@ def run_verify_mode(args, torch, Z, world, rank, local_rank, dev):
         return t_v, t_p, acc, nbytes
 
     for w in range(args.warmup):
-        one_pass(-1 - w, False)
+        one_pass(w, False)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     tv = tp = 0.0
     accepted = nbytes = 0
     for k in range(args.steps):
-        a, b, c, d = one_pass(k, True)
+        a, b, c, d = one_pass(args.warmup + k, k == 0)
         tv, tp, accepted, nbytes = tv + a, tp + b, accepted + c, nbytes + d
     if world > 1:
         dist.barrier()
@@ -344,11 +344,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # ZK_BENCH_ONE_DEVICE=1: every rank uses cuda:0 and the process group runs on gloo (RCCL refuses two ranks on one GPU) -- a
+    # smoke test of the N > 1 code path on a one-GPU box (tools/smoke_multirank.sh); never set by the driver
+    one_device = os.environ.get('ZK_BENCH_ONE_DEVICE') == '1'
+    if one_device:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group('gloo' if one_device else 'nccl', rank=rank, world_size=world)
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
