@@ -387,22 +387,50 @@ void launch_write_fixed(hipStream_t s, const Workspace& W, uint32_t count, uint8
     uint32_t n = count * (W.sec + 1);
     hipLaunchKernelGGL(k_write_fixed, dim3((n + 255) / 256), dim3(256), 0, s, W, count, out);
 }
+// The 32 Tom points of a PointAdd block (2 304 of its 3 392 bytes), staged through LDS: list B is item-fastest, the proof bytes are
+// item-major.  A workgroup takes WP_ITEMS consecutive items; phase A reads the limbs coalesced (32 consecutive items per limb row) and
+// parks the 18 big-endian words of each point in LDS, phase B walks an item's words in output order so that consecutive lanes write
+// consecutive dwords of the runs of 4 / 6 / 2 points (round 1 wrote one 72-byte piece per lane, 3.4 KB apart: 1.8 TB/s).
+#ifndef WP_ITEMS
+#define WP_ITEMS 32
+#endif
+#define WP_WORDS (32 * 18)       // point words per item
+#define WP_STRIDE (WP_WORDS + 1)  // LDS item stride: odd, so that the 32 items of a phase-A row fall into 32 banks
+ZK_DEV uint32_t padd_point_off(uint32_t k) {  // byte offset of point k (0..31) inside the PointAdd block (pointAdd.ts:138-191 order)
+    return k < 4 ? 72 * k : k < 28 ? 288 + 656 * ((k - 4) / 6) + 72 * ((k - 4) % 6) : k < 30 ? 2912 + 72 * (k - 28) : 3152 + 72 * (k - 30);
+}
 __global__ void __launch_bounds__(256) k_write_padd_points(Workspace W, uint32_t items, uint8_t* out) {
-    uint32_t t = gtid();
-    if (t >= items * 32) return;
-    uint32_t it = t % items, k = 2 + t / items;  // slots 2..33, item-fastest
-    uint32_t p = W.item_proof[it], i = W.item_rep[it];
-    uint8_t* pa = out + W.out_base[p] + rep_offset(W.chal + 4 * p, i) + ZK_REP_HEAD;
-    uint32_t off;
-    if (k < 6) off = 72 * (k - 2);
-    else if (k < 30) off = 288 + 656 * ((k - 6) / 6) + 72 * ((k - 6) % 6);
-    else if (k < 32) off = 2912 + 72 * (k - 30);
-    else off = 3152 + 72 * (k - 32);
-    put_tom_point(pa + off, W.lb, lbi(W, it, k));
+    __shared__ uint32_t words[WP_ITEMS * WP_STRIDE];
+    __shared__ uint64_t base[WP_ITEMS];
+    const uint32_t t = threadIdx.x, it0 = blockIdx.x * WP_ITEMS;
+    const uint32_t li = t % WP_ITEMS, kk = t / WP_ITEMS, it = it0 + li;
+    if (it < items) {
+        if (kk == 0) {
+            uint32_t p = W.item_proof[it], i = W.item_rep[it];
+            base[li] = W.out_base[p] + rep_offset(W.chal + 4 * p, i) + ZK_REP_HEAD;
+        }
+#pragma unroll 1
+        for (uint32_t k = kk; k < 32; k += 256 / WP_ITEMS) {
+            uint32_t slot = lbi(W, it, 2 + k), w[9];
+            uint32_t* d = words + li * WP_STRIDE + k * 18;
+            words_from_limbs<9>(w, soa_ld<ModT, 1>(W.lb.ax, slot).l);
+#pragma unroll
+            for (int j = 0; j < 9; j++) d[j] = bswap32(w[8 - j]);
+            words_from_limbs<9>(w, soa_ld<ModT, 1>(W.lb.ay, slot).l);
+#pragma unroll
+            for (int j = 0; j < 9; j++) d[9 + j] = bswap32(w[8 - j]);
+        }
+    }
+    __syncthreads();
+    const uint32_t n = (items - it0 < WP_ITEMS ? items - it0 : WP_ITEMS) * WP_WORDS;
+    for (uint32_t e = t; e < n; e += 256) {
+        uint32_t i = e / WP_WORDS, d = e % WP_WORDS, k = d / 18;
+        *(uint32_t*)(out + base[i] + padd_point_off(k) + 4 * (d % 18)) = words[i * WP_STRIDE + d];
+    }
 }
 void launch_write_padd_points(hipStream_t s, const Workspace& W, uint32_t items, uint8_t* out) {
     if (!items) return;
-    hipLaunchKernelGGL(k_write_padd_points, dim3((items * 32 + 255) / 256), dim3(256), 0, s, W, items, out);
+    hipLaunchKernelGGL(k_write_padd_points, dim3((items + WP_ITEMS - 1) / WP_ITEMS), dim3(256), 0, s, W, items, out);
 }
 
 // ---------------------------------------------------------------- Groth-Kohlweiss (gk.ts:94-195)
