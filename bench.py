@@ -26,14 +26,16 @@ sys.path.insert(0, ROOT)
 # zk_ctx_create).  Must be in the environment before the first HIP call of the process, i.e. before torch touches the device.
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
-# measured on MI355X with tools/valu_peak.hip (profiles/r01_valu_peak_microbench.txt): v_mad_u64_u32 chip-wide issue rate
-# at 16 independent accumulators x 8 waves/SIMD (4.2 cycles per wave-instruction; 39.3 T/s would be 16 lanes/clk at 2.4 GHz);
-# 36.66 and 37.11 T/s were measured on two boxes of the pool, the larger one is the denominator
+# measured on MI355X with tools/valu_peak.hip (profiles/r01_valu_peak_microbench.txt, r02_...): v_mad_u64_u32 chip-wide issue
+# rate at 16 independent accumulators x 8 waves/SIMD (4.2 cycles per wave-instruction; 39.3 T/s would be 16 lanes/clk at 2.4 GHz);
+# 36.66 and 37.11 T/s were measured on two boxes of the pool in round 1 (37.28-37.36 T/s sustained over 2 s in round 2); the
+# denominator stays 37.11 so that the fractions of the two rounds compare
 VALU_MAD_PEAK_TOPS = 37.11
 HBM_PEAK_GBPS = 8000.0
-# multiplier-pipe instructions (v_mad_u64_u32 + v_mul_lo_u32) per Tom-field Montgomery product: 1224 + 1218 + 72 + 71 per
-# k_tom_commit loop iteration of 16 products (tools/isa_blocks.py; nominal 171 = 81 + 81 + 9, the modulus limb that is zero
-# costs nothing); PMC: 40 112 VALU wave-instructions per commitment of 168 products = 239 instructions per product
+# multiplier-pipe instructions (v_mad_u64_u32 + v_mul_lo_u32) per Tom-field Montgomery product: 1224 + 72 per table addition
+# of 8 products in k_tom_commit (tools/isa_blocks.py; nominal 171 = 81 + 81 + 9, the modulus limb that is zero costs nothing);
+# PMC (profiles/r02_pmc_summary.txt): 37 458 VALU wave-instructions per commitment of 168 products = 223 instructions per
+# product (round 1: 239)
 MACS_PER_MODMUL = 162
 
 
@@ -44,14 +46,14 @@ def tom_commit_modmuls(comb_bits):
 
 TOM_COMMIT_NOMINAL = 4064      # reference: 256 dbl + 160 add (src/curves/group.ts:97-132)
 TOM_COMMIT_BYTES = 2 * 36 + 3 * 36  # algorithmic HBM bytes per commitment: read (v, r), write (X, Y, Z)
-# PMC passes (profiles/r01_pmc_summary.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate runs, batch 16384),
+# PMC passes (profiles/r02_pmc_summary.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate runs, batch 16384),
 # bytes per commitment through the L2's memory-side port, keyed by comb width.  24 bits (128-byte table entries, 47 GB of
-# tables): 2 x 1305 B fetched (gfx950 tallies 16-byte-per-lane loads at half their bytes, MI355X_MICROARCH.md section HBM;
-# 22 gathers x 128 B = 2816 B expected) + 111 B written.  16 bits (112-byte entries, 235 MB): 3238 B (raw) + 111 B.
-TOM_COMMIT_PMC_BYTES = {24: 2610 + 111, 16: 3238 + 111}
+# tables): 2 x 1304 B fetched (gfx950 tallies 16-byte-per-lane loads at half their bytes, MI355X_MICROARCH.md section HBM;
+# 22 gathers x 128 B = 2816 B expected) + 112 B written.  16 bits (112-byte entries, 235 MB; round-1 pass): 3238 B (raw) + 111 B.
+TOM_COMMIT_PMC_BYTES = {24: 2608 + 112, 16: 3238 + 111}
 # same passes, SQ counters at 24 bits: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave at 2 waves per SIMD (VALU pipe busy
-# 98 % of the time), SQ_WAIT_INST_ANY 0.400, SQ_WAIT_ANY (memory) 0.101
-TOM_COMMIT_VALU_ACTIVE_PER_WAVE = {24: 0.491}
+# 96 % of the time), SQ_WAIT_INST_ANY 0.373, SQ_WAIT_ANY (memory) 0.138
+TOM_COMMIT_VALU_ACTIVE_PER_WAVE = {24: 0.482}
 DEFAULT_COMB_BITS = 24
 
 
@@ -498,7 +500,7 @@ def main():
             'frac': round(achieved_tmacs / VALU_MAD_PEAK_TOPS, 4),
             'traffic': int(commits_per_step / max(1, launches_per_step) * pmc_bytes) if pmc_bytes else None,
             'traffic_note': ('bytes per launch = units per launch x %d B (FETCH_SIZE + WRITE_SIZE per commitment, separate rocprofv3 --pmc passes, '
-                             'profiles/r01_pmc_summary.txt); table gathers, not the 180 algorithmic bytes, dominate' % pmc_bytes) if pmc_bytes
+                             'profiles/r02_pmc_summary.txt); table gathers, not the 180 algorithmic bytes, dominate' % pmc_bytes) if pmc_bytes
                             else 'no PMC pass recorded for this comb width',
             'valu_active_per_wave': TOM_COMMIT_VALU_ACTIVE_PER_WAVE.get(args.comb_bits),
             'comb_bits': args.comb_bits,
