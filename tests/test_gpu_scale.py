@@ -11,11 +11,13 @@
 """
 import ctypes as C
 import hashlib
+import os
 import random
 
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _engine(S, nkeys, B, sec=80, comb_bits=None):
@@ -190,3 +192,23 @@ def test_tapered_chunk_plan_of_the_host_pointer_calls_keeps_the_bytes():
     assert [bytes(page[off2[b]:off2[b + 1]]) for b in pick] == exp
     pin.free()
     eng.close()
+
+
+@pytest.mark.parametrize('mode', ['prove', 'verify'])
+def test_bench_two_ranks_on_one_gpu(mode):
+    """The N > 1 path of bench.py with the ENGINE on the device: two ranks under torch.distributed.run, both on cuda:0 over a gloo
+    group (tools/smoke_multirank.sh; RCCL refuses two ranks on one GPU).  Ring broadcast, per-rank seeds, max-over-ranks timing and
+    the rank-0 JSON line, which must carry cpu_baseline at N > 1."""
+    import json
+    import subprocess
+    r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'smoke_multirank.sh'), mode], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['value'] > 0
+    if mode == 'prove':
+        assert d['scaling'] == 'weak' and d['failed_proofs'] == 0
+        assert d['cpu_baseline'] and d['cpu_baseline']['value'] > 0 and d['cpu_baseline']['checked_bit_exact'] >= 1
+        assert d['verify']['accepted'] == d['verify']['of']
+    else:
+        assert d['scaling'] == 'strong' and d['accepted'] == d['of'] and d['planted_forgeries_rejected'] == 3
