@@ -482,11 +482,13 @@ def main():
         commits_per_step = B * (2 + 2 * sec) + zeros_total * 34 + B * 4 * n_log2
         tom_ms = fam.get('tom_commit', 0.0) / max(1, args.roofline_steps)
         launches_per_step = 4 * ((B + eng_chunk(args, B) - 1) // eng_chunk(args, B))   # lists A, B (unpaired + paired slots), C
-        # executed additions: 2 * nwin per commitment, except the 6 pairs per PointAdd item that share v*g (3 * nwin per pair)
+        # executed additions: 2 * nwin per commitment, except, per PointAdd item, the 9 pairs that share v*g (3 * nwin per pair) and
+        # C4 of pi8, whose value is i7 * i8 = 1: its g-windows above the first are skipped wave-wide on unsigned combs (k_tom.hip)
         nwin = (256 + args.comb_bits - 1) // args.comb_bits
-        adds = (commits_per_step - 34 * zeros_total) * 2 * nwin + zeros_total * (22 * 2 + 6 * 3) * nwin
+        skipped = nwin - 1 if args.comb_bits <= 24 else 0
+        adds = (commits_per_step - 34 * zeros_total) * 2 * nwin + zeros_total * ((16 * 2 + 9 * 3) * nwin - skipped)
         # 8 modmuls per addition; the first one of a comb is 1 (identity + entry), the last one 7 (no T coordinate)
-        modmuls = adds * 8 - (commits_per_step - 34 * zeros_total) * 8 - zeros_total * (22 * 8 + 6 * 9)
+        modmuls = adds * 8 - (commits_per_step - 34 * zeros_total) * 8 - zeros_total * (16 * 8 + 9 * 9)
         modmuls_per_commit = round(modmuls / commits_per_step, 2)
         pmc_bytes = TOM_COMMIT_PMC_BYTES.get(args.comb_bits)
         macs = modmuls * MACS_PER_MODMUL

@@ -37,8 +37,9 @@ ZK_DEV void niels_pin(TomNiels& n) {
 }
 
 // unpaired / paired commitment slots of list B (see k_tom_commit_pairs)
-__device__ const uint8_t LB_SINGLE_K[22] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 17, 18, 19, 20, 23, 24, 25, 26, 29};
-__device__ const uint8_t LB_PAIR_K[6] = {9, 15, 21, 27, 30, 32};
+__device__ const uint8_t LB_SINGLE_K[16] = {0, 1, 2, 6, 7, 8, 11, 13, 14, 17, 19, 20, 23, 25, 26, 29};
+__device__ const uint8_t LB_PAIR_K0[9] = {9, 15, 21, 27, 30, 32, 3, 4, 5};
+__device__ const uint8_t LB_PAIR_K1[9] = {10, 16, 22, 28, 31, 33, 12, 18, 24};
 template <bool SGN>
 struct NielsSel;  // table entry as used by the addition: as loaded (unsigned combs) or conditionally negated (signed combs)
 template <>
@@ -73,8 +74,11 @@ __global__ void __launch_bounds__(256, OCC) k_tom_commit(const uint32_t* __restr
     TomPt acc = tom_identity();
     // software pipeline, one addition deep: the h-entry of window w is gathered during the g-addition of window w, the
     // g-entry of window w+1 during the h-addition (one entry in flight, one in use: 54 VGPRs instead of 108)
+    // A g-window whose digit is 0 in EVERY lane of the wave is skipped (entry 0 is the identity): list B is item-fastest, so a wave
+    // holds one slot of 64 items, and slot 6 -- C4 of pi8, the commitment to i7 * i8 = 1 (mult.ts:103 with x = i7, y = 1/i7) -- has
+    // v in {0, 1} for all of them: 10 of its 11 g-additions go.  Unsigned combs only (a signed zero digit is not entry 0).
     uint32_t dv, dr;
-    bool sv, sr;
+    bool sv, sr, g_live = true;
     dgv.next(dv, sv);
     TomNiels ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * dv), nh;
 #pragma unroll 1
@@ -82,14 +86,15 @@ __global__ void __launch_bounds__(256, OCC) k_tom_commit(const uint32_t* __restr
         size_t base = (size_t)w * ent;
         dgr.next(dr, sr);
         nh = ld_niels(tab_h + (size_t)TOM_ENTRY_WORDS * (base + dr));
-        niels_pin(ng);
-        {
+        if (g_live) {
+            niels_pin(ng);
             typename NielsSel<SGN>::T cg = NielsSel<SGN>::sel(ng, sv);
             acc = w == 0 ? tom_from_niels(cg) : tom_add_niels(acc, cg);                  // first step: identity + entry
         }
         if (w + 1 < nwin) {
             dgv.next(dv, sv);
-            ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * (base + ent + dv));
+            g_live = SGN || __ballot(dv != 0) != 0;   // wave-uniform
+            if (g_live) ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * (base + ent + dv));
         }
         niels_pin(nh);
         {
@@ -101,12 +106,15 @@ __global__ void __launch_bounds__(256, OCC) k_tom_commit(const uint32_t* __restr
     soa_st(L.proj.y, slot, acc.y);
     soa_st(L.proj.z, slot, acc.z);
 }
-// ---- list B of provePointAdd (34 commitments per zero-bit repetition, slot = k * kstride + item).  Six pairs commit
-// to the SAME value under two blinding factors: A_z / A_4_1 of each proveMult (k_z, mult.ts:110-113) and A_1 / A_2 of
-// each proveEquality (k, equality.ts:62-64).  v*g is accumulated once per pair and both h-parts continue from it:
-// 3 * nwin additions instead of 4 * nwin (-8.8 % additions over the list).  Units 0..21 are the unpaired slots.
-#define LB_UNITS_SINGLE 22
-#define LB_UNITS_PAIR 6
+// ---- list B of provePointAdd (34 commitments per zero-bit repetition, slot = k * kstride + item).  Nine pairs commit
+// to the SAME value under two blinding factors: A_z / A_4_1 of each proveMult (k_z, mult.ts:110-113), A_1 / A_2 of each
+// proveEquality (k, equality.ts:62-64), and -- round 2 -- C_z / C_4 of pi10, pi11, pi13: C_4 = x * C_y opens to x * y
+// (mult.ts:103), which is the z the proof is about, i.e. the value of C10, C11, C13 (pointAdd.ts:133-136: i10 = i8 i9,
+// i11 = i10 i10, i13 = i10 i12).  v*g is accumulated once per pair and both h-parts continue from it: 3 * nwin additions
+// instead of 4 * nwin.  With the skipped g-windows of pi8's C4 (k_tom_commit): 639 instead of 748 additions per item.
+// Units 0..15 are the unpaired slots.
+#define LB_UNITS_SINGLE 16
+#define LB_UNITS_PAIR 9
 // acc += sum_w tab[w][digit_w(words)], gathers pipelined one window ahead.  FIRST: acc is the identity (the first entry is
 // taken as is); LAST: the result is final (no T coordinate).
 template <bool FIRST, bool LAST, bool SGN>
@@ -140,7 +148,7 @@ __global__ void __launch_bounds__(256, 2) k_tom_commit_pairs(const uint32_t* __r
                                                              uint32_t items, uint32_t kstride, uint32_t bits, uint32_t nwin) {
     uint32_t c = gtid();
     if (c >= items * LB_UNITS_PAIR) return;
-    uint32_t slot0 = LB_PAIR_K[c / items] * kstride + c % items, slot1 = slot0 + kstride;
+    uint32_t slot0 = LB_PAIR_K0[c / items] * kstride + c % items, slot1 = LB_PAIR_K1[c / items] * kstride + c % items;
     uint32_t w8[8];
     words_from_limbs<8>(w8, soa_ld<ModQ, 1>(L.v, slot0).l);
     TomPt G = tom_comb_acc<true, false, SGN>(tom_identity(), tab_g, w8, bits, nwin);
