@@ -34,8 +34,8 @@ VALU_MAD_PEAK_TOPS = 37.11
 HBM_PEAK_GBPS = 8000.0
 # multiplier-pipe instructions (v_mad_u64_u32 + v_mul_lo_u32) per Tom-field Montgomery product: 1224 + 72 per table addition
 # of 8 products in k_tom_commit (tools/isa_blocks.py; nominal 171 = 81 + 81 + 9, the modulus limb that is zero costs nothing);
-# PMC (profiles/r02_pmc_summary.txt): 37 458 VALU wave-instructions per commitment of 168 products = 223 instructions per
-# product (round 1: 239)
+# PMC (profiles/r02_pmc_summary.txt): 36 674 VALU wave-instructions per unpaired commitment of 163 products on average = 225
+# instructions per product, 230 in the paired kernel (round 1: 239)
 MACS_PER_MODMUL = 162
 
 
@@ -48,12 +48,12 @@ TOM_COMMIT_NOMINAL = 4064      # reference: 256 dbl + 160 add (src/curves/group.
 TOM_COMMIT_BYTES = 2 * 36 + 3 * 36  # algorithmic HBM bytes per commitment: read (v, r), write (X, Y, Z)
 # PMC passes (profiles/r02_pmc_summary.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate runs, batch 16384),
 # bytes per commitment through the L2's memory-side port, keyed by comb width.  24 bits (128-byte table entries, 47 GB of
-# tables): 2 x 1304 B fetched (gfx950 tallies 16-byte-per-lane loads at half their bytes, MI355X_MICROARCH.md section HBM;
-# 22 gathers x 128 B = 2816 B expected) + 112 B written.  16 bits (112-byte entries, 235 MB; round-1 pass): 3238 B (raw) + 111 B.
-TOM_COMMIT_PMC_BYTES = {24: 2608 + 112, 16: 3238 + 111}
+# tables): 2 x 1251 B fetched (gfx950 tallies 16-byte-per-lane loads at half their bytes, MI355X_MICROARCH.md section HBM;
+# 20.3 gathers x 128 B = 2600 B expected) + 112 B written.  16 bits (112-byte entries, 235 MB; round-1 pass): 3238 B (raw) + 111 B.
+TOM_COMMIT_PMC_BYTES = {24: 2501 + 112, 16: 3238 + 111}
 # same passes, SQ counters at 24 bits: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave at 2 waves per SIMD (VALU pipe busy
-# 96 % of the time), SQ_WAIT_INST_ANY 0.373, SQ_WAIT_ANY (memory) 0.138
-TOM_COMMIT_VALU_ACTIVE_PER_WAVE = {24: 0.482}
+# 99 % of the time), SQ_WAIT_INST_ANY 0.378, SQ_WAIT_ANY (memory) 0.117
+TOM_COMMIT_VALU_ACTIVE_PER_WAVE = {24: 0.495}
 DEFAULT_COMB_BITS = 24
 
 
