@@ -44,9 +44,15 @@ __host__ __device__ static inline uint32_t tom_win_entries(uint32_t bits) { retu
 static inline size_t tom_tab_words(uint32_t bits) { return (size_t)tom_nwin(bits) * tom_win_entries(bits) * TOM_ENTRY_WORDS; }
 // P-256 fixed bases (G, h_NIST): PFIX_WIN_BITS-bit comb windows (default 20: 13 windows, 1.1 GB per base), entry = affine (x, y) Montgomery limbs,
 // 20 words (80 B); digit 0 unused.
-// batch normalisers: points per Fermat inversion (one thread walks `per` points strided by the thread count)
+// batch normalisers: a thread walks `per` points strided by the thread count, a workgroup shares one Fermat inversion
+// (block_inverse).  Few fat threads beat many thin ones when other lanes' kernels share the GPU (same-box A/B, proofs/s at
+// per <= 32 / 64 / 128 / 256 with 524288 / 262144 / 131072 / 131072 threads at least: 292 / 297 / 300 / 292 k against 296 k for one
+// inversion per thread of 256 points).
 #ifndef ZK_NORM_PER_MAX
-#define ZK_NORM_PER_MAX 256
+#define ZK_NORM_PER_MAX 128
+#endif
+#ifndef ZK_NORM_MIN_THREADS
+#define ZK_NORM_MIN_THREADS 131072
 #endif
 #ifndef PFIX_WIN_BITS
 #define PFIX_WIN_BITS 20
@@ -307,6 +313,47 @@ void launch_ring_load(hipStream_t s, const uint8_t* d_keys_be32, uint64_t nkeys,
 void launch_keys_to_ints(hipStream_t s, const uint8_t* d_pk, uint64_t count, uint8_t* d_out, int32_t* d_st);
 void launch_bytes_to_scalars(hipStream_t s, const uint8_t* d_be32, uint64_t count, const Soa& out);
 void launch_affine_to_bytes(hipStream_t s, const Soa& ax, const Soa& ay, uint64_t count, int tom, uint8_t* d_out);
+
+// Montgomery's trick across a workgroup of 256 threads: every thread brings `acc`, the product of its own elements (Montgomery
+// domain, non-zero), and receives 1/acc.  Inclusive prefix and suffix products by a doubling scan through LDS (8 rounds, 2 products
+// each), ONE Fermat inversion per workgroup (thread 0), 1/acc_t = (1/total) * prefix_{t-1} * suffix_{t+1}.  The batch normalisers
+// use it so that the number of points per inversion (256 x per) no longer dictates how few threads a launch has.
+// lds: 2 * 256 * NLIMB words, limb-major.  Every thread of the workgroup must call it.
+#if !defined(ZK_HOST_BUILD)
+template <class M>
+__device__ inline Fe<M, 2> block_inverse(const Fe<M, 2>& acc, uint32_t* lds) {
+    const uint32_t lt = threadIdx.x;
+    uint32_t *P = lds, *S = lds + 256 * NLIMB;
+    auto put = [&](uint32_t* a, uint32_t i, const Fe<M, 2>& v) {
+#pragma unroll
+        for (int l = 0; l < NLIMB; l++) a[l * 256 + i] = v.l[l];
+    };
+    auto get = [&](const uint32_t* a, uint32_t i) {
+        Fe<M, 2> v;
+#pragma unroll
+        for (int l = 0; l < NLIMB; l++) v.l[l] = a[l * 256 + i];
+        return v;
+    };
+    Fe<M, 2> pre = acc, suf = acc;
+#pragma unroll 1
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        put(P, lt, pre), put(S, lt, suf);
+        __syncthreads();
+        if (lt >= d) pre = get(P, lt - d) * pre;
+        if (lt + d < 256) suf = get(S, lt + d) * suf;
+        __syncthreads();
+    }
+    put(P, lt, pre), put(S, lt, suf);
+    __syncthreads();
+    Fe<M, 2> total = get(P, 255);
+    Fe<M, 2> left = lt > 0 ? get(P, lt - 1) : fe_one_mont<M>().template as<2>();
+    Fe<M, 2> right = lt < 255 ? get(S, lt + 1) : fe_one_mont<M>().template as<2>();
+    __syncthreads();
+    if (lt == 0) put(P, 0, fe_inv<M>(total));
+    __syncthreads();
+    return (get(P, 0) * left) * right;
+}
+#endif
 
 // list B is item-fastest: slot k of item i lives at k * items_cap + i (coalesced for every per-item kernel)
 ZK_DEV uint32_t lbi(const Workspace& W, uint32_t item, uint32_t k) { return k * W.items_cap + item; }

@@ -175,12 +175,12 @@ void launch_exp_commit(hipStream_t s, const DevParams& P, const Workspace& W, ui
 // Z = 0 (identity) sets st[owner] = err_code (if no earlier error) and yields (0, 0).
 __global__ void __launch_bounds__(256) k_p256_normalize(Soa3 proj, uint32_t count, uint32_t nthreads, uint32_t per, Soa ox, Soa oy,
                                                         int32_t* st, uint32_t per_proof, int32_t err_code, const uint32_t* owner) {
-    uint32_t t = gtid();
-    if (t >= nthreads) return;
+    __shared__ uint32_t lds[2 * 256 * NLIMB];
+    uint32_t t = gtid();   // threads beyond nthreads own no element but take part in the workgroup's inversion
     Fq2 acc = fe_one_mont<ModQ>().as<2>();
     for (uint32_t j = 0; j < per; j++) {
         uint32_t e = t + j * nthreads;
-        if (e >= count) break;
+        if (t >= nthreads || e >= count) break;
         Fq2 z = fe_reduce(soa_ld<ModQ, 8>(proj.z, e));
         bool zero = fe_is_zero(z);
         if (zero) {
@@ -195,7 +195,8 @@ __global__ void __launch_bounds__(256) k_p256_normalize(Soa3 proj, uint32_t coun
     // running inverse in the plain domain (see k_tom_normalize): x and y come out plain, no from-Montgomery products
     Fe<ModQ, 1> one = fe_zero<ModQ>();
     one.l[0] = 1;
-    Fq2 inv = fe_inv<ModQ>(acc) * one;
+    Fq2 inv = block_inverse<ModQ>(acc, lds) * one;
+    if (t >= nthreads) return;
     for (int j = (int)per - 1; j >= 0; j--) {
         uint32_t e = t + (uint32_t)j * nthreads;
         if (e >= count) continue;
@@ -211,7 +212,7 @@ __global__ void __launch_bounds__(256) k_p256_normalize(Soa3 proj, uint32_t coun
 void launch_p256_normalize(hipStream_t s, const Soa3& proj, uint32_t count, const Soa& ox, const Soa& oy, int32_t* st, uint32_t per_proof,
                            int32_t err_code, const uint32_t* owner) {
     if (!count) return;
-    uint32_t per = count / (256 * 4 * 64 * 2);
+    uint32_t per = count / ZK_NORM_MIN_THREADS;
     if (per < 4) per = 4;
     if (per > ZK_NORM_PER_MAX) per = ZK_NORM_PER_MAX;
     uint32_t nthreads = (count + per - 1) / per;

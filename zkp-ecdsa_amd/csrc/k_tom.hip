@@ -180,19 +180,20 @@ void launch_tom_commit(hipStream_t s, const DevParams& P, const TomList& L, uint
 
 // Batch normalisation: (X:Y:Z) on the a=1 image -> affine (x, y) of the ORIGINAL curve, plain canonical limbs
 // (edwards.ts:184-193 toAffine).  Montgomery's trick: each thread owns `per` elements (strided by the thread
-// count), so one Fermat inversion serves `per` points.  Prefix products are parked in the ax output array.
+// count), the 256 threads of a workgroup share ONE Fermat inversion (block_inverse, engine.h).  Prefix products are parked in
+// the ax output array.
 // Element c of the pass maps to list slot (c / per_group) * slots_per_group + first + c % per_group.
 ZK_DEV uint32_t norm_slot(uint32_t c, uint32_t first, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride) {
     return kstride ? (first + c / per_group) * kstride + (c % per_group) : (c / per_group) * slots_per_group + first + c % per_group;
 }
 __global__ void __launch_bounds__(256) k_tom_normalize(TomList L, uint32_t count, uint32_t nthreads, uint32_t per, uint32_t first,
                                                        uint32_t per_group, uint32_t slots_per_group, uint32_t kstride) {
-    uint32_t t = gtid();
-    if (t >= nthreads) return;
+    __shared__ uint32_t lds[2 * 256 * NLIMB];
+    uint32_t t = gtid();   // threads beyond nthreads own no element but take part in the workgroup's inversion
     Ft2 acc = fe_one_mont<ModT>().as<2>();
     for (uint32_t j = 0; j < per; j++) {
         uint32_t c = t + j * nthreads;
-        if (c >= count) break;
+        if (t >= nthreads || c >= count) break;
         uint32_t e = norm_slot(c, first, per_group, slots_per_group, kstride);
         soa_st(L.ax, e, acc);  // prefix product before element e
         acc = acc * soa_ld<ModT, 2>(L.proj.z, e);
@@ -202,7 +203,8 @@ __global__ void __launch_bounds__(256) k_tom_normalize(TomList L, uint32_t count
     // from-Montgomery products per point (5 products per point in this pass instead of 7).
     Fe<ModT, 1> one = fe_zero<ModT>();
     one.l[0] = 1;
-    Ft2 inv = fe_inv<ModT>(acc) * one;
+    Ft2 inv = block_inverse<ModT>(acc, lds) * one;
+    if (t >= nthreads) return;
     const auto sinv = fe_const<ModT, 1>(TOM_SINV_M);
     for (int j = (int)per - 1; j >= 0; j--) {
         uint32_t c = t + (uint32_t)j * nthreads;
@@ -219,7 +221,7 @@ __global__ void __launch_bounds__(256) k_tom_normalize(TomList L, uint32_t count
 }
 void launch_tom_normalize(hipStream_t s, const TomList& L, uint32_t count, uint32_t first, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride) {
     if (!count) return;
-    uint32_t per = count / (256 * 4 * 64 * 2);
+    uint32_t per = count / ZK_NORM_MIN_THREADS;
     if (per < 4) per = 4;
     if (per > ZK_NORM_PER_MAX) per = ZK_NORM_PER_MAX;
     uint32_t nthreads = (count + per - 1) / per;
