@@ -44,6 +44,8 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
         M.keys_all = (uint32_t*)k.take(cap * 4 * 16), M.vals_in = (uint32_t*)k.take(cap * 4), M.keys_out = (uint32_t*)k.take(cap * 4);
         M.vals_out = (uint32_t*)k.take(cap * 4 * 16);
         M.start = (uint32_t*)k.take((size_t)4 * 16 * 65536 * MSM_G), M.end = (uint32_t*)k.take((size_t)4 * 16 * 65536 * MSM_G);
+        M.ord_key = (uint32_t*)k.take((size_t)4 * 16 * 65536 * MSM_G), M.ord_key2 = (uint32_t*)k.take((size_t)4 * 16 * 65536 * MSM_G);
+        M.ord_id = (uint32_t*)k.take((size_t)4 * 16 * 65536 * MSM_G), M.ord_id2 = (uint32_t*)k.take((size_t)4 * 16 * 65536 * MSM_G);
         M.counters = (uint32_t*)k.take(256), M.flag = (uint32_t*)k.take(256), M.big_list = (uint32_t*)k.take(4 * 4096), M.big_part = (uint32_t*)k.take((size_t)4096 * 128 * 144);
         M.buckets = (uint32_t*)k.take((size_t)16 * 65536 * 144 * MSM_G);
         M.F1 = (uint32_t*)k.take((size_t)16 * 1024 * 144 * MSM_G), M.G1 = (uint32_t*)k.take((size_t)16 * 1024 * 144 * MSM_G);

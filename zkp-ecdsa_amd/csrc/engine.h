@@ -237,6 +237,7 @@ struct MsmBuf {
     uint32_t *vals_in, *keys_out;             // live term ids; sorted keys of the window being processed
     uint32_t* vals_out;    // [16][cap] term ids sorted by digit
     uint32_t *start, *end; // [16][MSM_G * 65536] segment of every (group, digit) value
+    uint32_t *ord_key, *ord_key2, *ord_id, *ord_id2;   // [16 * MSM_G * 65536] buckets ordered by size (k_msm_sizes + one radix pass)
     uint32_t *counters, *flag;   // counters[0..15]: pairs per window, counters[32]: oversized buckets
     uint32_t* big_list;    // [4096] window * 65536 + digit of the oversized buckets
     uint32_t* big_part;    // [4096][128][36] partial sums of their slices

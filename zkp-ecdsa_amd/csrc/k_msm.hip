@@ -143,16 +143,25 @@ ZK_DEV TomPt msm_ldp(const uint32_t* p) {
 // than `big` terms (8 x the window's average + 64) is left to k_msm_bucket_big, one workgroup per such bucket, so that no lane
 // walks a long list alone.
 #define MSM_BIG_MAX 4096u
+// A lane sums one bucket, so a wave takes as long as its largest bucket: with Poisson-sized buckets (mean 27 in the low windows, 10
+// in the high ones) a wave of 64 neighbouring digits waits for a bucket 1.5-1.8x the mean.  The buckets of all windows are therefore
+// ordered by size first (k_msm_sizes + ONE 8-bit radix pass over 8.4 M (key, id) pairs), largest first: the lanes of a wave get
+// buckets of the same size, the empty ones end up together at the end.
+__global__ void __launch_bounds__(256) k_msm_sizes(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t* key, uint32_t* id) {
+    uint32_t wd = gtid();   // w * MSM_NBG + (group << 16 | digit)
+    uint32_t n = (wd & (MSM_NB - 1)) != 0 ? end[wd] - start[wd] : 0;
+    key[wd] = 255u - (n < 255u ? n : 255u), id[wd] = wd;
+}
 __global__ void __launch_bounds__(256) k_msm_bucket(const uint32_t* __restrict__ aos, const uint32_t* __restrict__ vals, uint32_t cap,
-                                                    const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t* buckets,
-                                                    uint32_t* big_cnt, uint32_t* big_list, uint32_t big) {
-    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;   // d = group << 16 | digit
-    uint32_t s = start[w * MSM_NBG + d], e = end[w * MSM_NBG + d];
+                                                    const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, const uint32_t* __restrict__ order,
+                                                    uint32_t* buckets, uint32_t* big_cnt, uint32_t* big_list, uint32_t big) {
+    uint32_t wd = order[gtid()], w = wd / MSM_NBG, d = wd % MSM_NBG;   // d = group << 16 | digit
+    uint32_t s = start[wd], e = end[wd];
     TomPt acc = tom_identity();
     const bool nz = (d & (MSM_NB - 1)) != 0;
     if (nz && e - s > big) {
         uint32_t pos = atomicAdd(big_cnt, 1u);
-        if (pos < MSM_BIG_MAX) big_list[pos] = w * MSM_NBG + d, e = s;  // handled by k_msm_bucket_big (beyond the list: here after all)
+        if (pos < MSM_BIG_MAX) big_list[pos] = wd, e = s;  // handled by k_msm_bucket_big (beyond the list: here after all)
     }
     if (nz && e > s) {
         const uint32_t* v = vals + (size_t)w * cap;
@@ -164,7 +173,7 @@ __global__ void __launch_bounds__(256) k_msm_bucket(const uint32_t* __restrict__
             acc = tom_add_niels(acc, nx);
         }
     }
-    msm_st(buckets + ((size_t)w * MSM_NBG + d) * 36, acc);
+    msm_st(buckets + (size_t)wd * 36, acc);
 }
 // Oversized buckets (sums of a few 208-bit products put ~6 terms per proof into digits 1..3 of window 13): block (j, b)
 // sums slice j (MSM_SLICE terms, strided over the grid's x extent) of big bucket b into part[b * MSM_NSLICE + j];
@@ -312,7 +321,9 @@ __global__ void k_msm_final(const uint32_t* __restrict__ Tw, TomList one, uint32
 size_t msm_workspace_bytes(uint32_t cap) {
     size_t tmp = 0;
     rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, cap, 0, MSM_C + MSM_GBITS);
-    return tmp;
+    size_t tmp2 = 0;   // the bucket ordering pass
+    rocprim::radix_sort_pairs(nullptr, tmp2, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, MSM_NW * MSM_NBG, 0, 8);
+    return tmp > tmp2 ? tmp : tmp2;
 }
 // returns through host_flags[MSM_G] (after a stream synchronisation): 1 = the Tom total of that group of proofs is the identity
 hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t* host_flags, uint32_t* gsz_out) {
@@ -349,8 +360,14 @@ hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const 
         fprintf(stderr, "msm: 16 sorts + bounds %.2f ms\n", now() - t0), t0 = now();
     }
     hipMemsetAsync(M.counters + 32, 0, 4, s);
-    hipLaunchKernelGGL(k_msm_bucket, dim3(MSM_NBG / 256, MSM_NW), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.buckets, M.counters + 32, M.big_list,
-                       8 * ((nmax + MSM_NBG - 1) / MSM_NBG) + 64);
+    {
+        hipLaunchKernelGGL(k_msm_sizes, dim3(MSM_NW * MSM_NBG / 256), dim3(256), 0, s, M.start, M.end, M.ord_key, M.ord_id);
+        size_t tmp = M.sort_tmp_bytes;
+        hipError_t e = rocprim::radix_sort_pairs(M.sort_tmp, tmp, M.ord_key, M.ord_key2, M.ord_id, M.ord_id2, MSM_NW * MSM_NBG, 0, 8, s);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_msm_bucket, dim3(MSM_NW * MSM_NBG / 256), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.ord_id2, M.buckets, M.counters + 32,
+                       M.big_list, 8 * ((nmax + MSM_NBG - 1) / MSM_NBG) + 64);
     hipLaunchKernelGGL(k_msm_bucket_big, dim3(MSM_NSLICE, 32), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.counters + 32, M.big_list, M.big_part);
     hipLaunchKernelGGL(k_msm_bucket_big2, dim3(64), dim3(256), 0, s, M.counters + 32, M.big_list, M.big_part, M.buckets);
     hipLaunchKernelGGL(k_msm_reduce1, dim3(1024 / 256, MSM_NWG), dim3(256), 0, s, M.buckets, M.F1, M.G1);
