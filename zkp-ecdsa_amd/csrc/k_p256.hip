@@ -28,7 +28,7 @@ ZK_DEV P256Pt p256_fixed_mul(const uint32_t* __restrict__ tab, uint32_t kw[8]) {
         uint32_t d = kw[0] & (PFIX_WIN_SIZE - 1);
         shr256<PFIX_WIN_BITS>(kw);
         P256Aff e = ld_pfix(tab + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + d));
-        P256Pt s = p256_add_mixed(acc, e);
+        P256Pt s = w == 0 ? p256_from_affine(e) : p256_add_mixed(acc, e);   // first window: identity + entry
         acc = p256_select(d != 0, s, acc);
     }
     return acc;

@@ -42,7 +42,7 @@ ZK_DEV void shr256_var(uint32_t* w, uint32_t sh) {  // sh < 32
 // k * R, k < 2^256 as 8 little-endian words (destroyed)
 ZK_DEV P256Pt p256_rtab_mul(const uint32_t* __restrict__ rtab, uint32_t kw[8], uint32_t bits) {
     const uint32_t nwin = rtab_nwin(bits), ent = rtab_entries(bits), half = 1u << (bits - 1), mask = (1u << bits) - 1;
-    P256Pt acc = p256_identity();
+    P256Pt acc;
     uint32_t carry = 0;
 #pragma unroll 1
     for (uint32_t w = 0; w < nwin; w++) {
@@ -54,7 +54,8 @@ ZK_DEV P256Pt p256_rtab_mul(const uint32_t* __restrict__ rtab, uint32_t kw[8], u
         P256Pt e = ld_rtab(rtab + (size_t)RTAB_ENTRY_WORDS * (w * ent + d));
         Fq8 ny = fq8_neg(e.y);
         e.y = fe_select(neg, ny, e.y);
-        acc = p256_add(acc, e);
+        if (w == 0) acc = e;   // identity + entry (entry 0 is the identity itself)
+        else acc = p256_add(acc, e);
     }
     return acc;
 }
