@@ -110,8 +110,8 @@ zk_status zk_ctx_set_lanes(zk_ctx *ctx, uint32_t lanes);
 zk_status zk_ctx_set_comb_bits(zk_ctx *ctx, uint32_t bits);
 
 /* zk_prove_batch on a page-locked `out`: 1 (default) = the first chunks of the L lanes hold chunk/L, 2*chunk/L, ... proofs, so
- * the lanes run out of phase and their output phases (PCIe transfers) interleave; 0 = uniform chunks.  The proof bytes do not
- * depend on it. */
+ * the lanes run out of phase and their output phases (PCIe transfers) interleave; 0 = uniform chunks; n >= 2 = n rising first
+ * chunks (chunk/n, 2*chunk/n, ...) whatever the number of lanes.  The proof bytes do not depend on it. */
 zk_status zk_ctx_set_host_taper(zk_ctx *ctx, uint32_t on);
 /* The prover runs a chunk's PointAdd phase (src/exp/pointAdd.ts:92-163: 80 % of the proof bytes) in slices of `proofs`
  * consecutive proofs; with a page-locked `out` every slice is followed by the DMA of the proofs it completed.  0 (default) =

@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--chunks', default='8192,16384')
     ap.add_argument('--lanes', default='2,3,4')
     ap.add_argument('--tapers', default='1')
+    ap.add_argument('--slice', type=int, default=0, help='zk_ctx_set_slice (0 = the engine default)')
     args = ap.parse_args()
     import torch
     import zkp_ecdsa_amd as Z
@@ -44,6 +45,8 @@ def main():
     res = {'pcie': bench.pcie_bandwidth(dev), 'device': {}, 'host': {}}
     print(json.dumps(res['pcie']), flush=True)
     pin = Z.PinnedBuffer(cap)
+    if args.slice:
+        eng.set_slice(args.slice)
     for lanes in [int(x) for x in args.lanes.split(',')]:
         eng.set_lanes(lanes)
         for c, taper in [(int(x), int(y)) for x in args.chunks.split(',') for y in args.tapers.split(',')]:

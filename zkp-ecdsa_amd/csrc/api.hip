@@ -266,7 +266,7 @@ extern "C" zk_status zk_ctx_set_slice(zk_ctx* c, uint32_t proofs) {
 }
 extern "C" zk_status zk_ctx_set_host_taper(zk_ctx* c, uint32_t on) {
     if (!c) return ZK_E_ARG;
-    c->host_taper = on ? 1 : 0;
+    c->host_taper = on > 64 ? 64 : on;   // 0 = uniform chunks, 1 = as many rising first chunks as lanes, n >= 2 = n of them
     return ZK_OK;
 }
 extern "C" zk_status zk_ctx_set_lanes(zk_ctx* c, uint32_t lanes) {
@@ -417,7 +417,7 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
     if (!c->params_set || !c->N) return ZK_E_BUFFER;
     if (rng_mode != ZK_RNG_SEED && rng_mode != ZK_RNG_STREAM) return ZK_E_ARG;
     uint32_t C = (uint32_t)std::min<uint64_t>(c->chunk, B ? B : 1);
-    const std::vector<ChunkPlan> plan = make_chunk_plan(B, C, host_sink != nullptr && c->host_taper ? c->lanes : 1, false);
+    const std::vector<ChunkPlan> plan = make_chunk_plan(B, C, host_sink != nullptr && c->host_taper ? (c->host_taper == 1 ? c->lanes : c->host_taper) : 1, false);
     const uint32_t NL = (uint32_t)std::min<size_t>(c->lanes, plan.size() ? plan.size() : 1);  // chunks rotate over NL streams / workspaces
     zk_status zs = ensure_workspace(c, C, NL);
     if (zs) return zs;

@@ -155,7 +155,7 @@ extern "C" zk_status zk_pool_set_ring(zk_pool* p, const uint8_t* keys, uint64_t 
             ncclResult_t r = p->rccl.GroupStart();
             for (int i = 0; i < G && r == 0; i++) {
                 hipSetDevice(p->dev[i]);
-                r = p->rccl.Broadcast(d[0], d[i], bytes, kNcclUint8, 0, p->comms[i], p->ctx[i]->stream);
+                r = p->rccl.Broadcast(d[i], d[i], bytes, kNcclUint8, 0, p->comms[i], p->ctx[i]->stream);   // in place; only the root's buffer is read
             }
             ncclResult_t r2 = p->rccl.GroupEnd();
             if (r == 0 && r2 == 0) {
