@@ -523,12 +523,16 @@ static napi_value ProofToJson(napi_env env, napi_callback_info info) { /* (proof
     uint8_t *p;
     size_t lp;
     if (!get_bytes(env, argv[0], &p, &lp)) return NULL;
-    uint64_t n = 0;
-    zk_status st = zk_proof_to_json(p, lp, NULL, 0, &n);
-    if (st != ZK_OK && st != ZK_E_BUFFER) return throw_text(env, st, "");
-    char *s = xmalloc(env, n + 1);
+    uint64_t n = 0, cap = 5 * (uint64_t)lp + 4096;   /* the text is ~3.5x the binary proof: one conversion in the common case */
+    char *s = xmalloc(env, cap + 1);
     if (!s) return NULL;
-    st = zk_proof_to_json(p, lp, s, n, &n);
+    zk_status st = zk_proof_to_json(p, lp, s, cap, &n);
+    if (st == ZK_E_BUFFER) {
+        free(s);
+        s = xmalloc(env, n + 1);
+        if (!s) return NULL;
+        st = zk_proof_to_json(p, lp, s, n, &n);
+    }
     napi_value r = NULL;
     if (st == ZK_OK) napi_create_string_utf8(env, s, n, &r);
     free(s);
@@ -547,15 +551,17 @@ static napi_value ProofFromJson(napi_env env, napi_callback_info info) { /* (tex
         napi_throw_type_error(env, NULL, "expected a string");
         return NULL;
     }
-    uint64_t n = 0;
-    zk_status st = zk_proof_from_json(s, len, NULL, 0, &n);
+    uint64_t n = 0, cap = len / 2 + 64;   /* at least two hex digits per byte: the binary proof is shorter than half the text */
     napi_value r = NULL;
-    if (st == ZK_OK || st == ZK_E_BUFFER) {
-        uint8_t *b = malloc(n + 1);
-        st = b ? zk_proof_from_json(s, len, b, n, &n) : ZK_E_BUFFER;
-        if (st == ZK_OK) r = new_buffer(env, b, n);
+    uint8_t *b = malloc(cap + 1);
+    zk_status st = b ? zk_proof_from_json(s, len, b, cap, &n) : ZK_E_BUFFER;
+    if (b && st == ZK_E_BUFFER && n > cap) {
         free(b);
+        b = malloc(n + 1);
+        st = b ? zk_proof_from_json(s, len, b, n, &n) : ZK_E_BUFFER;
     }
+    if (st == ZK_OK) r = new_buffer(env, b, n);
+    free(b);
     free(s);
     return st == ZK_OK && r ? r : throw_text(env, st ? st : ZK_E_BUFFER, "");
 }

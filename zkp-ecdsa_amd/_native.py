@@ -154,12 +154,15 @@ def hardened_h(tag=b''):
 def write_json(proof_bytes):
     """ZKA1 proof -> JSON text; the writeJson(SignatureProofList, proof) of src/serde.ts:34-36."""
     L = lib()
+    raw = bytes(proof_bytes)
     n = C.c_uint64()
-    rc = L.zk_proof_to_json(bytes(proof_bytes), len(proof_bytes), None, 0, C.byref(n))
-    if rc not in (0, 12):
-        raise ZkError(rc)
-    buf = C.create_string_buffer(n.value)
-    rc = L.zk_proof_to_json(bytes(proof_bytes), len(proof_bytes), buf, n.value, C.byref(n))
+    cap = 5 * len(raw) + 4096          # the text is ~3.5x the binary proof: one call in the common case
+    for _ in range(2):
+        buf = C.create_string_buffer(cap)
+        rc = L.zk_proof_to_json(raw, len(raw), buf, cap, C.byref(n))
+        if rc != 12:
+            break
+        cap = n.value
     if rc:
         raise ZkError(rc)
     return buf.raw[:n.value].decode()
@@ -170,11 +173,12 @@ def read_json(text):
     L = lib()
     raw = text.encode() if isinstance(text, str) else bytes(text)
     n = C.c_uint64()
-    rc = L.zk_proof_from_json(raw, len(raw), None, 0, C.byref(n))
-    if rc not in (0, 12):
-        raise ZkError(rc)
-    buf = C.create_string_buffer(n.value)
-    rc = L.zk_proof_from_json(raw, len(raw), buf, n.value, C.byref(n))
+    cap = len(raw) // 2 + 64            # two hex digits per byte at least: the binary proof is shorter than half the text
+    buf = C.create_string_buffer(cap)
+    rc = L.zk_proof_from_json(raw, len(raw), buf, cap, C.byref(n))
+    if rc == 12:
+        buf = C.create_string_buffer(n.value)
+        rc = L.zk_proof_from_json(raw, len(raw), buf, n.value, C.byref(n))
     if rc:
         raise ZkError(rc)
     return buf.raw[:n.value]

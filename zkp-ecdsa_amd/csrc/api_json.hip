@@ -87,27 +87,60 @@ void eq(Rd& r, std::string& o) {
 }
 
 // ---------------------------------------------------------------- tolerant JSON reader
-struct Val {
-    enum { NUL, STR, OBJ, ARR, OTHER } t = NUL;
-    std::string s;
-    std::vector<std::pair<std::string, Val>> o;
-    std::vector<Val> a;
-    const Val* get(const char* k) const {
-        for (auto& kv : o)
-            if (kv.first == k) return &kv.second;
+// One pass over the text into a flat node array (no allocation per value: a proof at secLevel 80 is ~36 000 values in 596 KB of text);
+// strings and keys are spans of the input, only strings with escapes -- none in honest output -- are decoded into a side list.
+struct Node {
+    enum { NUL, STR, OBJ, ARR, OTHER };
+    uint8_t t = NUL;
+    uint32_t ks = 0, kl = 0;      // key span (members of an object), or an index into Doc::dec if kesc
+    uint32_t s = 0, l = 0;        // STR: value span, or an index into Doc::dec if sesc
+    bool kesc = false, sesc = false;
+    uint32_t child = 0, next = 0, n = 0;   // first child / next sibling (0 = none; node 0 is the root), number of children
+};
+struct Doc {
+    const char* base = nullptr;
+    std::vector<Node> nd;
+    std::vector<std::string> dec;
+    // key and string accessors
+    bool key_is(const Node& m, const char* k, size_t kl) const {
+        if (m.kesc) return dec[m.ks] == std::string(k, kl);
+        return m.kl == kl && memcmp(base + m.ks, k, kl) == 0;
+    }
+    void str(const Node& v, const char*& p, size_t& l) const {
+        if (v.sesc) p = dec[v.s].data(), l = dec[v.s].size();
+        else p = base + v.s, l = v.l;
+    }
+    const Node* get(const Node* v, const char* k) const {   // first member named k, like the map lookup of a JSON parser
+        if (!v || v->t != Node::OBJ) return nullptr;
+        size_t kl = strlen(k);
+        for (uint32_t c = v->child; c; c = nd[c].next)
+            if (key_is(nd[c], k, kl)) return &nd[c];
         return nullptr;
     }
 };
 struct Parser {
     const char* p;
     const char* e;
+    Doc& d;
     bool ok = true;
     void ws() {
         while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++;
     }
-    bool str(std::string& out) {
+    // a string: span [s, s + l) of the input, or (escapes present) decoded like the earlier reader did: the character after a
+    // backslash is taken literally
+    bool str(uint32_t& s, uint32_t& l, bool& esc) {
         if (p >= e || *p != '"') return ok = false;
         p++;
+        const char* q = (const char*)memchr(p, '"', (size_t)(e - p));   // the common case: no escape before the closing quote
+        if (!q) return ok = false;
+        if (const char* bs = (const char*)memchr(p, '\\', (size_t)(q - p))) q = bs;
+        if (*q == '"') {
+            s = (uint32_t)(p - d.base), l = (uint32_t)(q - p), esc = false;
+            p = q + 1;
+            return true;
+        }
+        std::string out(p, q);
+        p = q;
         while (p < e && *p != '"') {
             if (*p == '\\') {
                 if (++p >= e) return ok = false;
@@ -116,112 +149,123 @@ struct Parser {
         }
         if (p >= e) return ok = false;
         p++;
+        s = (uint32_t)d.dec.size(), l = 0, esc = true;
+        d.dec.push_back(std::move(out));
         return true;
     }
-    bool val(Val& v, int depth = 0) {
+    // parses one value into node `at` (already allocated)
+    bool val(uint32_t at, int depth = 0) {
         if (depth > 16) return ok = false;
         ws();
         if (p >= e) return ok = false;
         if (*p == '"') {
-            v.t = Val::STR;
-            return str(v.s);
+            d.nd[at].t = Node::STR;
+            uint32_t s, l;
+            bool esc;
+            if (!str(s, l, esc)) return false;
+            d.nd[at].s = s, d.nd[at].l = l, d.nd[at].sesc = esc;
+            return true;
         }
-        if (*p == '{') {
-            v.t = Val::OBJ;
+        if (*p == '{' || *p == '[') {
+            const bool obj = *p == '{';
+            d.nd[at].t = obj ? Node::OBJ : Node::ARR;
             p++, ws();
-            if (p < e && *p == '}') return p++, true;
+            if (p < e && *p == (obj ? '}' : ']')) return p++, true;
+            uint32_t last = 0, cnt = 0;
             for (;;) {
-                ws();
-                std::string k;
-                if (!str(k)) return false;
-                ws();
-                if (p >= e || *p != ':') return ok = false;
-                p++;
-                v.o.emplace_back(k, Val());
-                if (!val(v.o.back().second, depth + 1)) return false;
+                uint32_t c = (uint32_t)d.nd.size();
+                d.nd.emplace_back();
+                if (obj) {
+                    ws();
+                    uint32_t s, l;
+                    bool esc;
+                    if (!str(s, l, esc)) return false;
+                    d.nd[c].ks = s, d.nd[c].kl = l, d.nd[c].kesc = esc;
+                    ws();
+                    if (p >= e || *p != ':') return ok = false;
+                    p++;
+                }
+                if (last) d.nd[last].next = c;
+                else d.nd[at].child = c;
+                last = c, cnt++;
+                if (!val(c, depth + 1)) return false;
                 ws();
                 if (p < e && *p == ',') {
                     p++;
                     continue;
                 }
-                if (p < e && *p == '}') return p++, true;
-                return ok = false;
-            }
-        }
-        if (*p == '[') {
-            v.t = Val::ARR;
-            p++, ws();
-            if (p < e && *p == ']') return p++, true;
-            for (;;) {
-                v.a.emplace_back();
-                if (!val(v.a.back(), depth + 1)) return false;
-                ws();
-                if (p < e && *p == ',') {
-                    p++;
-                    continue;
+                if (p < e && *p == (obj ? '}' : ']')) {
+                    d.nd[at].n = cnt;
+                    return p++, true;
                 }
-                if (p < e && *p == ']') return p++, true;
                 return ok = false;
             }
         }
-        v.t = Val::OTHER;  // numbers, true/false/null: skipped
+        d.nd[at].t = Node::OTHER;  // numbers, true/false/null: skipped
         while (p < e && *p != ',' && *p != '}' && *p != ']') p++;
         return true;
     }
 };
 struct Wr {
+    const Doc& d;
     std::vector<uint8_t> b;
     bool ok = true;
+    explicit Wr(const Doc& doc) : d(doc) {}
     // "0x.." -> nbytes big-endian (serdeBigInt.deserializer, big.ts:240-248; negative values are not valid here)
-    void hex(const Val* v, int nbytes) {
+    void hex(const Node* v, int nbytes) {
         size_t at = b.size();
         b.resize(at + nbytes, 0);
-        if (!v || v->t != Val::STR || v->s.size() < 3 || v->s[0] != '0' || (v->s[1] != 'x' && v->s[1] != 'X')) {
+        const char* s = nullptr;
+        size_t sl = 0;
+        if (v && v->t == Node::STR) d.str(*v, s, sl);
+        if (!s || sl < 3 || s[0] != '0' || (s[1] != 'x' && s[1] != 'X')) {
             ok = false;
             return;
         }
-        const std::string& s = v->s;
-        size_t nd = s.size() - 2, lead = 2;
+        size_t nd = sl - 2, lead = 2;
         while (nd > 1 && s[lead] == '0') lead++, nd--;  // BigInt('0x000a') is valid
         if (nd > (size_t)2 * nbytes) {
             ok = false;
             return;
         }
         for (size_t i = 0; i < nd; i++) {
-            char c = s[s.size() - 1 - i];
-            int d = c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1;
-            if (d < 0) {
+            char c = s[sl - 1 - i];
+            int dg = c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1;
+            if (dg < 0) {
                 ok = false;
                 return;
             }
-            b[at + nbytes - 1 - i / 2] |= (uint8_t)(d << (4 * (i & 1)));
+            b[at + nbytes - 1 - i / 2] |= (uint8_t)(dg << (4 * (i & 1)));
         }
     }
-    bool group_is(const Val* v, const char* name) {
-        const Val* g = v ? v->get("group") : nullptr;
-        const Val* n = g ? g->get("name") : nullptr;
-        return n && n->t == Val::STR && n->s == name;  // instances.ts:58-78: unknown group names are rejected
+    bool group_is(const Node* v, const char* name) {
+        const Node* n = d.get(d.get(v, "group"), "name");
+        if (!n || n->t != Node::STR) return false;   // instances.ts:58-78: unknown group names are rejected
+        const char* s;
+        size_t sl;
+        d.str(*n, s, sl);
+        return sl == strlen(name) && memcmp(s, name, sl) == 0;
     }
-    void pt(const Val* v, bool tom) {
-        if (!v || v->t != Val::OBJ || !group_is(v, tom ? "tomEdwards256" : "p256")) ok = false;
-        hex(v ? v->get("x") : nullptr, tom ? 36 : 32);
-        hex(v ? v->get("y") : nullptr, tom ? 36 : 32);
+    void pt(const Node* v, bool tom) {
+        if (!v || v->t != Node::OBJ || !group_is(v, tom ? "tomEdwards256" : "p256")) ok = false;
+        hex(d.get(v, "x"), tom ? 36 : 32);
+        hex(d.get(v, "y"), tom ? 36 : 32);
     }
-    void sc(const Val* v, bool tom) {
-        if (!v || v->t != Val::OBJ || !group_is(v, tom ? "tomEdwards256" : "p256")) ok = false;
-        hex(v ? v->get("k") : nullptr, 32);
+    void sc(const Node* v, bool tom) {
+        if (!v || v->t != Node::OBJ || !group_is(v, tom ? "tomEdwards256" : "p256")) ok = false;
+        hex(d.get(v, "k"), 32);
     }
-    void mult(const Val* v) {
+    void mult(const Node* v) {
         static const char* P[6] = {"C_4", "A_x", "A_y", "A_z", "A_4_1", "A_4_2"};
         static const char* S[7] = {"t_x", "t_y", "t_z", "t_rx", "t_ry", "t_rz", "t_r4"};
-        if (!v || v->t != Val::OBJ) ok = false;
-        for (auto k : P) pt(v ? v->get(k) : nullptr, true);
-        for (auto k : S) sc(v ? v->get(k) : nullptr, true);
+        if (!v || v->t != Node::OBJ) ok = false;
+        for (auto k : P) pt(d.get(v, k), true);
+        for (auto k : S) sc(d.get(v, k), true);
     }
-    void eq(const Val* v) {
-        if (!v || v->t != Val::OBJ) ok = false;
-        pt(v ? v->get("A_1") : nullptr, true), pt(v ? v->get("A_2") : nullptr, true);
-        sc(v ? v->get("t_x") : nullptr, true), sc(v ? v->get("t_r1") : nullptr, true), sc(v ? v->get("t_r2") : nullptr, true);
+    void eq(const Node* v) {
+        if (!v || v->t != Node::OBJ) ok = false;
+        pt(d.get(v, "A_1"), true), pt(d.get(v, "A_2"), true);
+        sc(d.get(v, "t_x"), true), sc(d.get(v, "t_r1"), true), sc(d.get(v, "t_r2"), true);
     }
 };
 }  // namespace
@@ -303,50 +347,56 @@ extern "C" zk_status zk_proof_to_json(const uint8_t* proof, uint64_t len, char* 
 static zk_status proof_from_json_impl(const char* json, uint64_t len, uint8_t* out, uint64_t cap, uint64_t* out_len) {
     if (!json || !out_len) return ZK_E_ARG;
     if (len > ZK_JSON_MAX_TEXT) return ZK_E_BAD_ENCODING;
-    Parser ps{json, json + len};
-    Val root;
-    if (!ps.val(root) || root.t != Val::OBJ) return ZK_E_BAD_ENCODING;
+    Doc d;
+    d.base = json;
+    d.nd.reserve((size_t)(len / 14) + 16);
+    d.nd.emplace_back();
+    Parser ps{json, json + len, d};
+    if (!ps.val(0) || d.nd[0].t != Node::OBJ) return ZK_E_BAD_ENCODING;
     ps.ws();
     if (ps.p != ps.e) return ZK_E_BAD_ENCODING;
-    const Val* ex = root.get("expProof");
-    const Val* gk = root.get("membershipProof");
-    if (!ex || ex->t != Val::ARR || !gk || gk->t != Val::OBJ || ex->a.size() > 128) return ZK_E_BAD_ENCODING;
-    Wr w;
+    const Node* root = &d.nd[0];
+    const Node* ex = d.get(root, "expProof");
+    const Node* gk = d.get(root, "membershipProof");
+    if (!ex || ex->t != Node::ARR || !gk || gk->t != Node::OBJ || ex->n > 128) return ZK_E_BAD_ENCODING;
+    Wr w(d);
+    w.b.reserve((size_t)(len / 3) + 64);
     w.b.resize(32, 0);
-    w.pt(root.get("R"), false), w.pt(root.get("comS1"), false), w.pt(root.get("keyXcom"), true), w.pt(root.get("keyYcom"), true);
-    uint32_t sec = (uint32_t)ex->a.size();
+    w.pt(d.get(root, "R"), false), w.pt(d.get(root, "comS1"), false), w.pt(d.get(root, "keyXcom"), true), w.pt(d.get(root, "keyYcom"), true);
+    uint32_t sec = ex->n;
     uint8_t bits[16] = {0};
-    for (uint32_t i = 0; i < sec; i++) {
-        const Val& e = ex->a[i];
-        if (e.t != Val::OBJ) return ZK_E_BAD_ENCODING;
-        w.pt(e.get("A"), false), w.pt(e.get("Tx"), true), w.pt(e.get("Ty"), true);
-        const Val* alpha = e.get("alpha");
+    uint32_t i = 0;
+    for (uint32_t c = ex->child; c; c = d.nd[c].next, i++) {
+        const Node* e = &d.nd[c];
+        if (e->t != Node::OBJ) return ZK_E_BAD_ENCODING;
+        w.pt(d.get(e, "A"), false), w.pt(d.get(e, "Tx"), true), w.pt(d.get(e, "Ty"), true);
+        const Node* alpha = d.get(e, "alpha");
         if (alpha) {  // response1 (exp.ts:30-34)
             bits[15 - (i >> 3)] |= (uint8_t)(1u << (i & 7));
-            w.sc(alpha, false), w.sc(e.get("beta1"), false), w.sc(e.get("beta2"), true), w.sc(e.get("beta3"), true);
+            w.sc(alpha, false), w.sc(d.get(e, "beta1"), false), w.sc(d.get(e, "beta2"), true), w.sc(d.get(e, "beta3"), true);
         } else {      // response0 (exp.ts:35-40)
-            w.sc(e.get("z"), false), w.sc(e.get("z2"), false), w.sc(e.get("r1"), true), w.sc(e.get("r2"), true);
-            const Val* pa = e.get("proof");
-            if (!pa || pa->t != Val::OBJ) return ZK_E_BAD_ENCODING;
-            for (auto k : {"C_8", "C_10", "C_11", "C_13"}) w.pt(pa->get(k), true);
-            for (auto k : {"pi_8", "pi_10", "pi_11", "pi_13"}) w.mult(pa->get(k));
-            w.eq(pa->get("pi_x")), w.eq(pa->get("pi_y"));
+            w.sc(d.get(e, "z"), false), w.sc(d.get(e, "z2"), false), w.sc(d.get(e, "r1"), true), w.sc(d.get(e, "r2"), true);
+            const Node* pa = d.get(e, "proof");
+            if (!pa || pa->t != Node::OBJ) return ZK_E_BAD_ENCODING;
+            for (auto k : {"C_8", "C_10", "C_11", "C_13"}) w.pt(d.get(pa, k), true);
+            for (auto k : {"pi_8", "pi_10", "pi_11", "pi_13"}) w.mult(d.get(pa, k));
+            w.eq(d.get(pa, "pi_x")), w.eq(d.get(pa, "pi_y"));
         }
     }
-    const Val* cl = gk->get("cl");
-    if (!cl || cl->t != Val::ARR || cl->a.size() > 64) return ZK_E_BAD_ENCODING;
-    uint32_t n = (uint32_t)cl->a.size();
+    const Node* cl = d.get(gk, "cl");
+    if (!cl || cl->t != Node::ARR || cl->n > 64) return ZK_E_BAD_ENCODING;
+    uint32_t n = cl->n;
     for (auto k : {"cl", "ca", "cb", "cd"}) {
-        const Val* a = gk->get(k);
-        if (!a || a->t != Val::ARR || a->a.size() != n) return ZK_E_BAD_ENCODING;
-        for (auto& v : a->a) w.pt(&v, true);
+        const Node* a = d.get(gk, k);
+        if (!a || a->t != Node::ARR || a->n != n) return ZK_E_BAD_ENCODING;
+        for (uint32_t c = a->child; c; c = d.nd[c].next) w.pt(&d.nd[c], true);
     }
     for (auto k : {"f", "za", "zb"}) {
-        const Val* a = gk->get(k);
-        if (!a || a->t != Val::ARR || a->a.size() != n) return ZK_E_BAD_ENCODING;
-        for (auto& v : a->a) w.sc(&v, true);
+        const Node* a = d.get(gk, k);
+        if (!a || a->t != Node::ARR || a->n != n) return ZK_E_BAD_ENCODING;
+        for (uint32_t c = a->child; c; c = d.nd[c].next) w.sc(&d.nd[c], true);
     }
-    w.sc(gk->get("zd"), true);
+    w.sc(d.get(gk, "zd"), true);
     if (!w.ok) return ZK_E_BAD_ENCODING;
     uint32_t total = (uint32_t)w.b.size();
     memcpy(w.b.data(), "ZKA1", 4);
