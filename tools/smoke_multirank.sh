@@ -4,7 +4,7 @@
 mode=${1:-prove}
 export ZK_BENCH_ONE_DEVICE=1
 if [ "$mode" = verify ]; then
-  extra="--mode verify --batch 4096 --ring 65536 --slab 1024 --chunk 1024 --lanes 2 --comb-bits 16"
+  extra="--mode verify --batch 4096 --ring 65536 --slab 1024 --verify-chunk 512 --verify-lanes 2 --comb-bits 16"
 else
   extra="--batch 4096 --chunk 2048 --lanes 2 --verify-chunk 2048 --comb-bits 16 --host-io 1024 --host-io-chunk 512 --host-io-verify-chunk 512 --cpu-sample 4 --json-sample 2"
 fi
