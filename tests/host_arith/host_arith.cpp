@@ -198,6 +198,32 @@ extern "C" int ha_sha256(uint64_t count, uint64_t len, const uint8_t* msgs, uint
     }
     return 0;
 }
+// The word-wise path of the absorber (put_be<N> -> put_word at any byte alignment): `lead` single bytes, then `count` values of
+// `nbytes` (32, 33 or 36) bytes each taken from `vals` (big-endian, nbytes apiece), then `trail` single bytes -- the shape of
+// hashPoints: 0x04 || X || Y per point.  The digest must be that of the same bytes absorbed one by one.
+extern "C" int ha_sha256_values(uint64_t lead, const uint8_t* lead_bytes, uint64_t count, int nbytes, const uint8_t* vals, uint64_t trail,
+                                const uint8_t* trail_bytes, uint8_t* out32) {
+    uint32_t col[16];
+    ShaStream s;
+    s.init(col, 0, 1);
+    for (uint64_t i = 0; i < lead; i++) s.put_byte(lead_bytes[i]);
+    for (uint64_t k = 0; k < count; k++) {
+        uint32_t w[9] = {0};   // little-endian words of the value
+        for (int i = 0; i < nbytes; i++) w[i >> 2] |= (uint32_t)vals[k * nbytes + (nbytes - 1 - i)] << (8 * (i & 3));
+        if (nbytes == 32) s.put_be<32>(w);
+        else if (nbytes == 33) s.put_be<33>(w);
+        else if (nbytes == 36) s.put_be<36>(w);
+        else return 1;
+    }
+    for (uint64_t i = 0; i < trail; i++) s.put_byte(trail_bytes[i]);
+    uint32_t h[8];
+    s.finish(h);
+    for (int i = 0; i < 8; i++) {
+        uint32_t v = bswap32h(h[i]);
+        memcpy(out32 + 4 * i, &v, 4);
+    }
+    return 0;
+}
 // logical draws first_k .. first_k + n_k - 1 of every proof, 32 bytes big-endian each; exc_* as k_rng_prepass would leave them
 extern "C" int ha_rng_draws(int mode, int sec, uint64_t B, const uint8_t* data, uint64_t stride_blocks, uint32_t* exc_idx, uint32_t* exc_flags,
                             uint32_t* exc_cnt, uint32_t first_k, uint32_t n_k, uint8_t* out) {

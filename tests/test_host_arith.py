@@ -132,6 +132,22 @@ def test_sha256_byte_absorber_on_the_host(ha):
     assert out.raw.hex() == 'ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad'
 
 
+def test_sha256_word_path_at_every_alignment_on_the_host(ha):
+    """put_be<32|33|36> -> put_word: whole words into a stream that is not word-aligned (hashPoints: 0x04 || X || Y with 33-byte
+    Tom coordinates), across block boundaries, for every number of leading bytes mod 4."""
+    import hashlib
+    for nbytes in (32, 33, 36):
+        for lead in range(0, 9):
+            for count in (1, 2, 3, 7, 20):
+                for trail in (0, 1, 5):
+                    lb = bytes((3 * i + lead) & 255 for i in range(lead))
+                    vals = bytes((i * 11 + nbytes * 5 + count) & 255 for i in range(nbytes * count))
+                    tb = bytes((7 * i + 1) & 255 for i in range(trail))
+                    out = C.create_string_buffer(32)
+                    assert ha.ha_sha256_values(C.c_uint64(lead), lb, C.c_uint64(count), nbytes, vals, C.c_uint64(trail), tb, out) == 0
+                    assert out.raw == hashlib.sha256(lb + vals + tb).digest(), (nbytes, lead, count, trail)
+
+
 def _reference_draws(fills, sec, ndraws):
     """rnd() of big.ts:171-181 over the fill sequence: draw j uses modulus n or q and consumes
     fills until one is below it.  Returns the accepted 32-byte fills."""
