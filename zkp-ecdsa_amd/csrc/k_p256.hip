@@ -43,7 +43,17 @@ ZK_DEV P256Pt ld_proj(const Soa3& a, uint32_t e) {
 }
 
 // ---------------------------------------------------------------- front end (zkpAttestList.ts:112-136)
-__global__ void __launch_bounds__(64) k_front(DevParams P, Workspace W, ChunkIn in) {
+// Three kernels, one thread per proof each, so that no live set exceeds 256 registers:
+//   k_front          key check, the scalars u1, u2, s1, z1 mod n (two Fermat inversions)
+//   k_front_table    1..8 times pk and the signed 4-bit digits of u2; u1*G and Q = z1*G by the fixed-base comb
+//   k_front_walk     u2*pk by 65 windows of 4 doublings + one addition (260 + 72 point operations instead of the 256 + 256 of a
+//                    bit-serial ladder), R = u1*G + u2*pk, R affine
+// Between the kernels the values live in the proof's R-table area, which k_rtab_* only writes afterwards: entries 0..7 = d * pk,
+// entry 8 = u1*G, words of entry 9: u2's digits (65 bytes), entry 10: u1, z1.
+#define FRONT_NW 65   // signed 4-bit digits of a 256-bit scalar
+ZK_DEV uint32_t* front_area(const Workspace& W, uint32_t p) { return W.rtab + (size_t)p * rtab_words(RTAB_PROVE_BITS); }
+static_assert(FRONT_NW <= 4 * RTAB_ENTRY_WORDS && 2 * NLIMB <= RTAB_ENTRY_WORDS, "front-end scratch inside R-table entries");
+__global__ void __launch_bounds__(64, 2) k_front(DevParams P, Workspace W, ChunkIn in) {
     uint32_t p = gtid();
     if (p >= in.count) return;
     uint32_t xw[8], yw[8], zw[8], rw[8], sw[8];
@@ -69,41 +79,82 @@ __global__ void __launch_bounds__(64) k_front(DevParams P, Workspace W, ChunkIn 
     Fe<ModN, 1> u1 = fe_from_mont(sinv * z), u2 = fe_from_mont(sinv * r);
     Fe<ModN, 1> s1 = fe_from_mont(rinv * s), z1 = fe_from_mont(rinv * z);
     soa_st(W.s1, p, s1);
-    // R = u1*G + u2*pk : comb for G, double-and-add (complete formulas) for the one-off base pk
+    uint32_t* area = front_area(W, p);
+    {
+        uint8_t* dig = (uint8_t*)(area + 9 * RTAB_ENTRY_WORDS);
+        uint32_t u2w[8], carry = 0;
+        words_from_limbs<8>(u2w, u2.l);
+#pragma unroll 1
+        for (uint32_t w = 0; w < FRONT_NW; w++) {
+            uint32_t d = (u2w[0] & 15) + carry;
+            shr256<4>(u2w);
+            bool neg = d > 8;
+            carry = neg ? 1 : 0;
+            if (neg) d = 16 - d;
+            dig[w] = (uint8_t)(d | (neg ? 0x80u : 0u));
+        }
+        uint32_t* sc = area + 10 * RTAB_ENTRY_WORDS;
+#pragma unroll
+        for (int l = 0; l < NLIMB; l++) sc[l] = u1.l[l], sc[NLIMB + l] = z1.l[l];
+    }
+    W.st[p] = status;
+}
+__global__ void __launch_bounds__(64, 2) k_front_table(DevParams P, Workspace W, uint32_t count) {
+    uint32_t p = gtid();
+    if (p >= count) return;
+    uint32_t* area = front_area(W, p);
+    {
+        P256Aff pk;
+        pk.x = soa_ld<ModQ, 2>(W.pkxm, p), pk.y = soa_ld<ModQ, 2>(W.pkym, p);
+        P256Pt base = p256_from_affine(pk), m = base;
+        st_rtab(area, m);
+        m = p256_dbl(base);
+        st_rtab(area + RTAB_ENTRY_WORDS, m);
+#pragma unroll 1
+        for (uint32_t d = 2; d < 8; d++) {
+            m = p256_add(m, base);
+            st_rtab(area + d * RTAB_ENTRY_WORDS, m);
+        }
+    }
+    const uint32_t* sc = area + 10 * RTAB_ENTRY_WORDS;
+    Fe<ModN, 1> u1, z1;
+#pragma unroll
+    for (int l = 0; l < NLIMB; l++) u1.l[l] = sc[l], z1.l[l] = sc[NLIMB + l];
     uint32_t kw[8];
     words_from_limbs<8>(kw, u1.l);
-    P256Pt R = p256_fixed_mul(P.pfix_G, kw);
-    {
-        uint32_t u2w[8];
-        words_from_limbs<8>(u2w, u2.l);
-        P256Pt acc = p256_identity();
-        P256Pt base = p256_from_affine(pk);
-#pragma unroll 1
-        for (int i = 255; i >= 0; i--) {
-            acc = p256_dbl(acc);
-            P256Pt sum = p256_add(acc, base);
-            bool bit = (u2w[7] >> 31) & 1;
-#pragma unroll
-            for (int j = 7; j > 0; j--) u2w[j] = (u2w[j] << 1) | (u2w[j - 1] >> 31);
-            u2w[0] <<= 1;
-            acc = p256_select(bit, sum, acc);
-        }
-        R = p256_add(R, acc);
-    }
+    st_rtab(area + 8 * RTAB_ENTRY_WORDS, p256_fixed_mul(P.pfix_G, kw));
     words_from_limbs<8>(kw, z1.l);
-    P256Pt Q = p256_fixed_mul(P.pfix_G, kw);
-    st_proj(W.Q, p, Q);
+    st_proj(W.Q, p, p256_fixed_mul(P.pfix_G, kw));
+}
+__global__ void __launch_bounds__(64, 2) k_front_walk(Workspace W, uint32_t count) {
+    uint32_t p = gtid();
+    if (p >= count) return;
+    const uint32_t* area = front_area(W, p);
+    const uint8_t* dig = (const uint8_t*)(area + 9 * RTAB_ENTRY_WORDS);
+    P256Pt acc = p256_identity();
+#pragma unroll 1
+    for (int w = FRONT_NW - 1; w >= 0; w--) {
+#pragma unroll 1
+        for (int i = 0; i < 4; i++) acc = p256_dbl(acc);
+        uint32_t db = dig[w], d = db & 15;
+        P256Pt e = ld_rtab(area + (d ? d - 1 : 0) * RTAB_ENTRY_WORDS);
+        e.y = fe_select((db & 0x80u) != 0, fq8_neg(e.y), e.y);
+        P256Pt s = p256_add(acc, e);
+        acc = p256_select(d != 0, s, acc);
+    }
+    P256Pt R = p256_add(ld_rtab(area + 8 * RTAB_ENTRY_WORDS), acc);
     // R affine (output + base of the per-proof table).  R = identity makes every T_i the identity: exp.ts:151.
     Fq2 rz = fe_reduce(R.z);
-    if (fe_is_zero(rz) && status == ZK_OK) status = ZK_E_T_INF;
+    if (fe_is_zero(rz) && W.st[p] == ZK_OK) W.st[p] = ZK_E_T_INF;
     Fq2 zi = fe_inv<ModQ>(rz);
     Fq2 rx = R.x * zi, ry = R.y * zi;
     soa_st(W.Rxm, p, rx), soa_st(W.Rym, p, ry);
     soa_st(W.Rx, p, fe_from_mont(rx)), soa_st(W.Ry, p, fe_from_mont(ry));
-    W.st[p] = status;
 }
 void launch_front(hipStream_t s, const DevParams& P, const Workspace& W, const ChunkIn& in) {
     hipLaunchKernelGGL(k_front, dim3((in.count + 63) / 64), dim3(64), 0, s, P, W, in);
+    hipLaunchKernelGGL(k_front_table, dim3((in.count + 63) / 64), dim3(64), 0, s, P, W, in.count);
+    hipLaunchKernelGGL(k_front_walk, dim3((in.count + 63) / 64), dim3(64), 0, s, W, in.count);
 }
 
 // ---------------------------------------------------------------- per-proof table of R (layout and use: rtab.h)
