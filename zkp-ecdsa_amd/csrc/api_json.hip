@@ -27,18 +27,21 @@ namespace {
 const char* G_P = "{\"name\":\"p256\",\"__type\":\"WeierstrassGroup\"}";
 const char* G_T = "{\"name\":\"tomEdwards256\",\"__type\":\"TEdwards\"}";
 
-void hex_of(const uint8_t* be, int n, std::string& o) {
+void hex_of(const uint8_t* be, int n, std::string& o) {   // n <= 36
     static const char* d = "0123456789abcdef";
-    o += "\"0x";
+    char tmp[2 * 36 + 4];
+    char* q = tmp;
+    *q++ = '"', *q++ = '0', *q++ = 'x';
     int i = 0;
     while (i < n && be[i] == 0) i++;
-    if (i == n) o += '0';
+    if (i == n) *q++ = '0';
     else {
-        if (be[i] >> 4) o += d[be[i] >> 4];
-        o += d[be[i] & 15];
-        for (i++; i < n; i++) o += d[be[i] >> 4], o += d[be[i] & 15];
+        if (be[i] >> 4) *q++ = d[be[i] >> 4];
+        *q++ = d[be[i] & 15];
+        for (i++; i < n; i++) *q++ = d[be[i] >> 4], *q++ = d[be[i] & 15];
     }
-    o += '"';
+    *q++ = '"';
+    o.append(tmp, (size_t)(q - tmp));
 }
 struct Rd {
     const uint8_t* p;
@@ -228,15 +231,31 @@ struct Wr {
             ok = false;
             return;
         }
-        for (size_t i = 0; i < nd; i++) {
-            char c = s[sl - 1 - i];
-            int dg = c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1;
-            if (dg < 0) {
-                ok = false;
-                return;
+        // two digits per byte from the least significant end, through a nibble table (0xff = not a hex digit)
+        static const struct Lut {
+            uint8_t v[256];
+            Lut() {
+                memset(v, 0xff, sizeof v);
+                for (int c = '0'; c <= '9'; c++) v[c] = (uint8_t)(c - '0');
+                for (int c = 'a'; c <= 'f'; c++) v[c] = (uint8_t)(c - 'a' + 10), v[c - 32] = (uint8_t)(c - 'a' + 10);
             }
-            b[at + nbytes - 1 - i / 2] |= (uint8_t)(dg << (4 * (i & 1)));
+        } lut;
+        const uint8_t* q = (const uint8_t*)s + sl;   // one past the last digit
+        uint8_t* o = b.data() + at + nbytes;           // one past the last byte
+        uint8_t bad = 0;
+        size_t i = nd;
+        for (; i >= 2; i -= 2) {
+            uint8_t lo = lut.v[q[-1]], hi = lut.v[q[-2]];
+            q -= 2;
+            bad |= lo | hi;
+            *--o = (uint8_t)(hi << 4 | (lo & 15));
         }
+        if (i) {
+            uint8_t lo = lut.v[q[-1]];
+            bad |= lo;
+            *--o = (uint8_t)(lo & 15);
+        }
+        if (bad & 0x80) ok = false;   // 0xff entries only
     }
     bool group_is(const Node* v, const char* name) {
         const Node* n = d.get(d.get(v, "group"), "name");
