@@ -99,6 +99,14 @@ async function gpu() {
         otherRing[0] = BigInt(9)
         assert.strictEqual(await verifySignatureList(params, msgHash, otherRing, proof), false)
         assert.strictEqual(await verifySignatureList(params, msgHash, testArray, proof), true)   // and back: the ring cache follows the argument
+        // an IN-PLACE change of the caller's array (same identity, same length, an element no sample would look at) is seen too
+        const big = testArray.concat(Array.from({ length: 58 }, (_, i) => BigInt(100 + i)))
+        const pbig = await proveSignatureList(params, msgHash, signature, keyPair.publicKey, 0, big)
+        assert.strictEqual(await verifySignatureList(params, msgHash, big, pbig), true)
+        big[37] = BigInt(3)
+        assert.strictEqual(await verifySignatureList(params, msgHash, big, pbig), false)
+        big[37] = BigInt(137)
+        assert.strictEqual(await verifySignatureList(params, msgHash, Object.freeze(big), pbig), true)
         const stranger = keyAndSignature('kilroy was here')
         const p2 = await proveSignatureList(params, msgHash, stranger.signature, stranger.keyPair.publicKey, 0, testArray)
         assert.strictEqual(await verifySignatureList(params, msgHash, testArray, p2), false)
@@ -147,6 +155,19 @@ async function gpu() {
     const mixed = proofs.slice()
     mixed[2] = forged
     assert.deepStrictEqual(eng.verifyBatch(wl.msg, mixed), [true, true, false, true, true, true])
+    // one malformed proof (truncated: its length no longer matches its header) must not deny the verdicts of the honest ones
+    const broken = proofs.slice()
+    broken[1] = proofs[1].slice(0, proofs[1].length - 5)
+    broken[4] = Buffer.from('not a proof')
+    const bv = eng.verifyBatch(wl.msg, broken)
+    assert.deepStrictEqual(bv, [true, false, true, true, false, true])
+    assert.ok(/deserializ/.test(bv.errors[1].message) && /deserializ/.test(bv.errors[4].message) && bv.errors[0] === null)
+    assert.throws(() => new SignatureProofList(broken[1]), /deserializ/)
+    const otherSec = Buffer.from(proofs[3])
+    otherSec.writeUInt32BE(7, 8)                                                       // header claims secLevel 7 < 20 checked reps
+    const sv = eng.verifyBatch(wl.msg, [proofs[0], otherSec])
+    assert.deepStrictEqual(sv, [true, false])
+    assert.ok(/security level/.test(sv.errors[1].message))
     const bad = Buffer.from(wl.pk.slice(0, 64))
     bad[63] ^= 1
     assert.throws(() => eng.proveBatch(wl.msg.slice(0, 32), wl.sig.slice(0, 64), bad, [0], wl.seeds.slice(0, 32)), /point not in group/)

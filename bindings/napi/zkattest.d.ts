@@ -32,7 +32,9 @@ export function keyToInt(publicKey: PublicKey): Promise<bigint>
 export function proveSignatureList(params: SystemParametersList, msgHash: Uint8Array, sigBytes: Uint8Array, publicKey: PublicKey, which: number, keys: bigint[]): Promise<SignatureProofList>
 export function verifySignatureList(params: SystemParametersList, msgHash: Uint8Array, keys: bigint[], proof: SignatureProofList): Promise<boolean>
 export function proveSignatureListBatch(params: SystemParametersList, msgHashes: Uint8Array[], sigs: Uint8Array[], publicKeys: PublicKey[], whichs: number[], keys: bigint[] | Buffer): Promise<SignatureProofList[]>
-export function verifySignatureListBatch(params: SystemParametersList, msgHashes: Uint8Array[], keys: bigint[] | Buffer, proofs: (SignatureProofList | Buffer)[]): Promise<boolean[]>
+/** booleans per proof; `errors[b]` holds what verifySignatureList would have thrown for proof b (null otherwise) -- a malformed proof never affects its neighbours */
+export type Verdicts = boolean[] & { readonly errors: (Error | null)[] }
+export function verifySignatureListBatch(params: SystemParametersList, msgHashes: Uint8Array[], keys: bigint[] | Buffer, proofs: (SignatureProofList | Buffer)[]): Promise<Verdicts>
 type Newable<T> = new (...args: any[]) => T
 export function writeJson<T>(type: Newable<T>, object: T): string
 export function readJson<T>(type: Newable<T>, text: string): T
@@ -48,7 +50,7 @@ export class Engine {
     setRing(keys: Buffer | bigint[]): string
     keysToInts(pkxy: Buffer): { keys: Buffer; status: Buffer }
     proveBatch(msg: Buffer, sig: Buffer, pk: Buffer, which: number[] | Buffer, seeds?: Buffer): Buffer[]
-    verifyBatch(msg: Buffer, proofs: Buffer[], seeds?: Buffer): boolean[]
+    verifyBatch(msg: Buffer, proofs: Buffer[], seeds?: Buffer): Verdicts
     proveBatchAsync(msg: Buffer, sig: Buffer, pk: Buffer, which: number[] | Buffer, seeds?: Buffer): Promise<Buffer[]>
-    verifyBatchAsync(msg: Buffer, proofs: Buffer[], seeds?: Buffer): Promise<boolean[]>
+    verifyBatchAsync(msg: Buffer, proofs: Buffer[], seeds?: Buffer): Promise<Verdicts>
 }

@@ -165,6 +165,9 @@ function generateParamsListHardened(secLevel = 80, tag = Buffer.alloc(0)) {
 
 // Proof objects keep the engine's ZKA1 bytes (the binary equivalent of the reference's object graph, include/zkattest.h) and
 // materialise the reference's members (R, comS1, keyXcom, keyYcom, expProof[], membershipProof: Points and Scalars) on demand.
+// ZKA1 framing (include/zkattest.h): magic, big-endian total length at byte 4 equal to the buffer's length, 4-byte granular.  Checked
+// before a proof may enter a packed batch: a proof with a wrong length would shift every later proof of the blob.
+function wellFormedProof(b) { return Buffer.isBuffer(b) && b.length >= 32 && b.length % 4 === 0 && b.slice(0, 4).toString('latin1') === 'ZKA1' && b.readUInt32BE(4) === b.length }
 function revive(v) {
     if (Array.isArray(v)) return v.map(revive)
     if (v && typeof v === 'object') {
@@ -177,7 +180,7 @@ function revive(v) {
     return v
 }
 class SignatureProofList { // src/zkpAttestList.ts:27-60
-    constructor(bytes) { if (!Buffer.isBuffer(bytes) || bytes.slice(0, 4).toString() !== 'ZKA1') throw new Error('error deserializing'); this.bytes = bytes }
+    constructor(bytes) { if (!wellFormedProof(bytes)) throw new Error('error deserializing'); this.bytes = bytes }
     eq(o) { return o instanceof SignatureProofList && this.bytes.equals(o.bytes) }   // the encoding is canonical: equal members <=> equal bytes
     toJson() { return native.proofToJson(this.bytes) }
     get members() { if (!this._m) Object.defineProperty(this, '_m', { value: revive(JSON.parse(this.toJson())) }); return this._m }
@@ -213,16 +216,41 @@ function unpackProofs(r, B) {
     }
     return out
 }
+// Only well-formed proofs are packed (back to back, so every one starts 4-byte aligned); a malformed one never reaches the engine
+// and cannot misalign its neighbours -- it is reported on its own as 'error deserializing', like the reference's readJson would.
 function packProofs(proofs) {
-    const B = proofs.length, off = new BigUint64Array(B), len = new BigUint64Array(B)
+    const good = [], slot = new Int32Array(proofs.length).fill(-1)
+    for (let b = 0; b < proofs.length; b++) if (wellFormedProof(proofs[b])) { slot[b] = good.length; good.push(proofs[b]) }
+    const B = good.length, off = new BigUint64Array(B), len = new BigUint64Array(B)
     let o = 0n
-    for (let b = 0; b < B; b++) { off[b] = o; len[b] = BigInt(proofs[b].length); o += len[b] }
-    return { blob: B === 1 ? proofs[0] : Buffer.concat(proofs), off: Buffer.from(off.buffer), len: Buffer.from(len.buffer) }
+    for (let b = 0; b < B; b++) { off[b] = o; len[b] = BigInt(good[b].length); o += len[b] }
+    return { blob: B === 1 ? good[0] : Buffer.concat(good), off: Buffer.from(off.buffer), len: Buffer.from(len.buffer), slot, n: B }
 }
-function verdicts(r, B) {
-    const st = i32(r.status)
-    for (let b = 0; b < B; b++) if (st[b] !== 0) throw new Error(STATUS_TEXT[st[b]] || ('status ' + st[b]))
-    return Array.from(r.ok).map((v) => v === 1)
+// -> booleans, one per submitted proof.  A proof for which the reference's verifier would THROW ('params not found', a point that
+// does not deserialise, ...) is `false` here and its Error sits in the result's non-enumerable `errors[b]` (null otherwise): one bad
+// proof must not deny the verdicts of the others.  verifySignatureList (one proof) rethrows, as the reference does.
+function verdicts(r, slot) {
+    const st = r ? i32(r.status) : null, out = [], errors = []
+    for (let b = 0; b < slot.length; b++) {
+        const k = slot[b]
+        if (k < 0) { out.push(false); errors.push(new Error('error deserializing')); continue }
+        errors.push(st[k] !== 0 ? new Error(STATUS_TEXT[st[k]] || ('status ' + st[k])) : null)
+        out.push(st[k] === 0 && r.ok[k] === 1)
+    }
+    Object.defineProperty(out, 'errors', { value: errors })
+    return out
+}
+function msgOf(msg, pk) {   // the message hashes of the packed proofs only
+    if (pk.n === pk.slot.length) return msg
+    const parts = []
+    for (let b = 0; b < pk.slot.length; b++) if (pk.slot[b] >= 0) parts.push(msg.slice(32 * b, 32 * b + 32))
+    return Buffer.concat(parts)
+}
+function seedsOf(seeds, pk) {
+    if (!seeds || pk.n === pk.slot.length) return seeds || null
+    const parts = []
+    for (let b = 0; b < pk.slot.length; b++) if (pk.slot[b] >= 0) parts.push(seeds.slice(32 * b, 32 * b + 32))
+    return Buffer.concat(parts)
 }
 class Engine {
     constructor(devices = 0) {
@@ -250,8 +278,8 @@ class Engine {
     }
     // -> array of booleans; exceptions of the reference's verifier are thrown for the first proof that has one
     verifyBatch(msg, proofs, seeds) {
-        const { blob, off, len } = packProofs(proofs)
-        return verdicts(native.verifyBatch(this.h, msg, blob, off, len, seeds || null), proofs.length)
+        const pk = packProofs(proofs)
+        return verdicts(pk.n ? native.verifyBatch(this.h, msgOf(msg, pk), pk.blob, pk.off, pk.len, seedsOf(seeds, pk)) : null, pk.slot)
     }
     // Promise-returning variants: the batch runs on a libuv worker thread; jobs of one engine are chained (one batch at a time)
     _chain(run) { this.tail = this.tail.then(run, run); return this.tail }
@@ -260,8 +288,9 @@ class Engine {
         return native.proveBatchAsync(this.h, msg, sig, pk, w, s).then((r) => unpackProofs(r, B))
     }
     _verifyNow(msg, proofs, seeds) {
-        const { blob, off, len } = packProofs(proofs)
-        return native.verifyBatchAsync(this.h, msg, blob, off, len, seeds || null).then((r) => verdicts(r, proofs.length))
+        const pk = packProofs(proofs)
+        if (!pk.n) return Promise.resolve(verdicts(null, pk.slot))
+        return native.verifyBatchAsync(this.h, msgOf(msg, pk), pk.blob, pk.off, pk.len, seedsOf(seeds, pk)).then((r) => verdicts(r, pk.slot))
     }
     proveBatchAsync(msg, sig, pk, which, seeds) { return this._chain(() => this._proveNow(msg, sig, pk, which, seeds)) }
     verifyBatchAsync(msg, proofs, seeds) { return this._chain(() => this._verifyNow(msg, proofs, seeds)) }
@@ -270,15 +299,18 @@ class Engine {
 
 // ---------------------------------------------------------------- context cache: (params) -> engine, (engine, ring) -> loaded
 const engines = new Map()      // sha256(params bytes | secLevel | devices) -> { engine, ringTag }
-const ringCache = new WeakMap() // keys array -> { buf, tag, n, probe } (validated by length and a strided sample on every use)
+const ringCache = new WeakMap() // keys array -> { buf, tag }: valid only while the array is FROZEN (nobody can change it in place)
+// The loaded ring is identified by the SHA-256 of the whole key list (2 MiB at 2^16 keys: a few milliseconds).  A mutable bigint[]
+// is serialised and hashed on EVERY call -- a cached copy validated by a sample would silently prove against a stale ring after an
+// in-place change of an unsampled element; callers that want the serialisation cached pass a Buffer or Object.freeze(keys).
 function ringOf(keys) {
     if (Buffer.isBuffer(keys)) return { buf: keys, tag: crypto.createHash('sha256').update(keys).digest('hex') }
-    const probe = () => { let s = ''; const step = Math.max(1, Math.floor(keys.length / 16)); for (let i = 0; i < keys.length; i += step) s += keys[i].toString(36) + ','; return s + keys[keys.length - 1].toString(36) }
-    let c = ringCache.get(keys)
-    if (!c || c.n !== keys.length || c.probe !== probe()) {
+    const frozen = Object.isFrozen(keys)
+    let c = frozen ? ringCache.get(keys) : undefined
+    if (!c) {
         const buf = Buffer.concat(keys.map(be32))
-        c = { buf, tag: crypto.createHash('sha256').update(buf).digest('hex'), n: keys.length, probe: probe() }
-        ringCache.set(keys, c)
+        c = { buf, tag: crypto.createHash('sha256').update(buf).digest('hex') }
+        if (frozen) ringCache.set(keys, c)
     }
     return c
 }
@@ -335,7 +367,9 @@ async function proveSignatureList(params, msgHash, sigBytes, publicKey, which, k
     return (await proveSignatureListBatch(params, [msgHash], [sigBytes], [publicKey], [which], keys))[0]
 }
 async function verifySignatureList(params, msgHash, keys, proof) {
-    return (await verifySignatureListBatch(params, [msgHash], keys, [proof]))[0]
+    const r = await verifySignatureListBatch(params, [msgHash], keys, [proof])
+    if (r.errors[0]) throw r.errors[0]   // the reference's verifier throws these (src/exp/exp.ts:244,270,302; deserialisation)
+    return r[0]
 }
 // B statements over one ring in one call (what the engine is built for): arrays of the single-proof arguments
 async function proveSignatureListBatch(params, msgHashes, sigs, publicKeys, whichs, keys) {

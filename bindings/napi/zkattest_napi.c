@@ -31,6 +31,7 @@
 typedef struct {
     zk_pool *pool;
     int busy, closed;
+    int orphaned; /* the external was finalized (environment teardown) while a batch was still running: job_complete frees it */
     uint32_t sec;
 } Handle;
 
@@ -40,7 +41,8 @@ static napi_value throw_text(napi_env env, zk_status st, const char *detail) {
     napi_throw_error(env, NULL, msg); /* the reference's error texts: 'point not in group', 'T[i] is at infinity', ... */
     return NULL;
 }
-static napi_value throw_status(napi_env env, Handle *h, zk_status st) { return throw_text(env, st, h && h->pool ? zk_pool_last_error(h->pool) : ""); }
+/* a NULL pool asks the library why the last zk_pool_create of this thread failed */
+static napi_value throw_status(napi_env env, Handle *h, zk_status st) { return throw_text(env, st, zk_pool_last_error(h ? h->pool : NULL)); }
 static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv) {
     size_t argc = want;
     if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < want) {
@@ -67,10 +69,16 @@ static Handle *get_handle(napi_env env, napi_value v, int allow_busy) {
     }
     return h;
 }
+static void handle_release(Handle *h) {
+    if (h->pool) zk_pool_destroy(h->pool);
+    free(h);
+}
+/* The worker thread of a running batch still uses h->pool and job_complete still writes h->busy: a busy handle outlives its
+ * external and is released by job_complete. */
 static void handle_finalize(napi_env env, void *data, void *hint) {
     Handle *h = data;
-    if (h->pool && !h->busy) zk_pool_destroy(h->pool);
-    free(h);
+    if (h->busy) h->orphaned = 1;
+    else handle_release(h);
 }
 /* Buffer or typed array -> pointer + byte length (NULL for null/undefined) */
 static int get_bytes(napi_env env, napi_value v, uint8_t **p, size_t *len) {
@@ -373,6 +381,10 @@ static napi_value job_result(napi_env env, Job *j) {
 static void job_complete(napi_env env, napi_status status, void *data) { /* main thread */
     Job *j = data;
     j->h->busy = 0;
+    if (j->h->orphaned) { /* finalized meanwhile: nobody can reach the handle any more */
+        handle_release(j->h);
+        j->h = NULL;
+    }
     napi_value v = status == napi_ok && j->rc == ZK_OK ? job_result(env, j) : NULL;
     if (v) {
         napi_resolve_deferred(env, j->deferred, v);

@@ -70,10 +70,10 @@ typedef struct {
 
 /* Creates an engine bound to one GPU.  Owns the HIP streams, the fixed-base tables and the workspace.  (SURVEY.md section 8(b)
  * sketched zk_ctx_create(device_ids, n_dev); here one zk_ctx is one GPU and zk_pool_create below takes the device list.) */
-zk_status zk_ctx_create(int device_id, zk_ctx **out);
+zk_status zk_ctx_create(int device_id, zk_ctx **out);   /* *out = NULL on failure (never a half-built context) */
 void zk_ctx_destroy(zk_ctx *ctx);
 const char *zk_strerror(zk_status s);
-const char *zk_last_error(const zk_ctx *ctx);
+const char *zk_last_error(const zk_ctx *ctx);           /* ctx = NULL: why this thread's last zk_ctx_create failed */
 
 /* Replaces SystemParametersList as produced by generateParamsList (src/zkpAttestList.ts:88-92,62-78):
  * NistGroup.h, ProofGroup.g, ProofGroup.h and SecLevel.  Builds the fixed-base tables for g, h, G, h_NIST. */
@@ -120,9 +120,10 @@ zk_status zk_ctx_set_slice(zk_ctx *ctx, uint32_t proofs);
 
 /* Verifier strategy for the Tom-256 relations: in a chunk of at least min_chunk proofs (default 256) the relations of ALL
  * proofs are checked with one bucket-method multi-scalar sum (independent 128-bit multipliers per relation and per proof);
- * only when that sum is not the identity -- some proof of the chunk is bad -- the per-proof sums run to tell which.  ok[] and
- * the statuses are the same either way; a chunk containing a bad proof costs about twice as much, and the chunk-wide sum has
- * a fixed cost of a few milliseconds, hence the threshold.  0 = never, 1 = always.  (ZKATTEST_VERIFY_BATCH) */
+ * a chunk is cut into 8 contiguous groups of proofs whose sums come out of the same pass, and only the groups whose sum is not
+ * the identity -- some proof of theirs is bad -- go through the per-proof sums to tell which.  ok[] and the statuses are the same
+ * either way; a forged proof costs the per-proof sums of its group (an eighth of the chunk), and the chunk-wide sum has a fixed
+ * cost of a few milliseconds, hence the threshold.  0 = never, 1 = always.  (ZKATTEST_VERIFY_BATCH) */
 zk_status zk_ctx_set_batch_verify(zk_ctx *ctx, uint32_t min_chunk);
 
 /* Upper bound of one proof's ZKA1 size for the current params/ring. */
@@ -173,6 +174,25 @@ zk_status zk_verify_batch(zk_ctx *ctx, uint64_t B, const uint8_t *msg_hash /*Bx3
 zk_status zk_verify_batch_device(zk_ctx *ctx, uint64_t B, const void *d_msg_hash, const void *d_proofs,
                                  const void *d_proof_off, const void *d_verifier_seeds, void *d_ok, void *d_per_proof_status);
 
+/* ---- two (or more) batches in flight on one context.  zk_prove_batch / zk_verify_batch are synchronous: each call pays its own head
+ * (no byte of a chunk exists before its stage 1 is over) and its own tail (the copies of the last slices, with nothing left to
+ * hide them).  The submit / wait pair splits a call so that the pipeline keeps running ACROSS calls: submit stages the inputs and
+ * queues the job (the verifier's proof bytes start crossing PCIe at once, right behind the bytes of the job before), wait drives the
+ * job's chunks -- enqueueing stage 1 of the NEXT job's first chunks while this job's last chunks are in their output phase -- and
+ * hands the results back.  Steady state:  submit(0); submit(1); wait(0); submit(2); wait(1); submit(3); wait(2); ...
+ * Rules: one thread per context; waits in submission order; at most 4 jobs queued; jobs of one kind (prove or verify) at a time;
+ * `out` / `proofs` page-locked (zk_host_alloc; ZK_E_ARG otherwise); every pointer of a job -- inputs included -- stays valid and
+ * untouched until its wait returns; chunk, lanes, parameters and ring do not change while jobs are queued; the synchronous calls
+ * return ZK_E_ARG while jobs are queued.  Bytes, statuses and verdicts are those of the synchronous calls.  zk_ctx_destroy abandons
+ * queued jobs.  (The reference proves one signature per call on one thread, src/zkpAttestList.ts:104-145: no counterpart.) */
+typedef struct zk_job zk_job;
+zk_status zk_prove_submit(zk_ctx *ctx, uint64_t B, const uint8_t *msg_hash, const uint8_t *sig, const uint8_t *pk_xy, const uint32_t *which,
+                          const zk_rng *rng, uint8_t *out, uint64_t out_cap, uint64_t *out_off /*B+1*/, int32_t *per_proof_status /*B*/, zk_job **job);
+zk_status zk_prove_wait(zk_ctx *ctx, zk_job *job);   /* the job is released whatever the result */
+zk_status zk_verify_submit(zk_ctx *ctx, uint64_t B, const uint8_t *msg_hash, const uint8_t *proofs, const uint64_t *proof_off /*B+1*/,
+                           const uint8_t *verifier_seeds /*Bx32 or NULL*/, uint8_t *ok /*B*/, int32_t *per_proof_status /*B*/, zk_job **job);
+zk_status zk_verify_wait(zk_ctx *ctx, zk_job *job);
+
 /* ---- several GPUs of one node behind one handle (the reference is single-threaded,
  * src/zkpAttestList.ts:104-145 proves one signature per call).  Proofs are independent given (params, ring): a batch is split
  * into contiguous shards, shard i = proofs [i*B/G, (i+1)*B/G) on device_ids[i], one host thread per device, no exchange while
@@ -182,11 +202,19 @@ zk_status zk_verify_batch_device(zk_ctx *ctx, uint64_t B, const void *d_msg_hash
  * per-device context for the settings above (chunk, lanes, comb width: before zk_pool_set_params) and for zk_last_error.
  * A pool call is not re-entrant; the listed devices may repeat (several contexts on one GPU). */
 typedef struct zk_pool zk_pool;
-zk_status zk_pool_create(const int *device_ids, int n_dev, zk_pool **out);
+zk_status zk_pool_create(const int *device_ids, int n_dev, zk_pool **out);   /* *out = NULL on failure (never a half-built pool) */
 void zk_pool_destroy(zk_pool *pool);
 int zk_pool_size(const zk_pool *pool);
 zk_ctx *zk_pool_ctx(zk_pool *pool, int i);
-const char *zk_pool_last_error(const zk_pool *pool);
+const char *zk_pool_last_error(const zk_pool *pool);                        /* pool = NULL: why this thread's last zk_pool_create failed */
+/* Host side of a shard.  Every shard of a pool call runs on its own host thread, bound to the CPUs next to its device (sysfs
+ * local_cpulist of the device's PCI address; ZKATTEST_POOL_AFFINITY=0 switches the binding off).  zk_pool_host_alloc returns a
+ * page-locked buffer for `out` of zk_pool_prove_batch / `proofs` of zk_pool_verify_batch whose per-shard regions
+ * [i * R, (i+1) * R), R = (bytes / G) & ~255, were first touched on the NUMA node of device i, so that the ~40 GB/s of proof
+ * bytes per device stay on that device's socket.  Free with zk_pool_host_free.  zk_pool_numa_node: -1 = unknown. */
+void *zk_pool_host_alloc(zk_pool *pool, size_t bytes);
+void zk_pool_host_free(void *p);
+int zk_pool_numa_node(const zk_pool *pool, int i);
 const char *zk_pool_ring_transport(const zk_pool *pool);
 void zk_pool_shard(const zk_pool *pool, uint64_t B, int i, uint64_t *first, uint64_t *count);
 zk_status zk_pool_set_params(zk_pool *pool, const uint8_t nist_h[64], const uint8_t tom_g[72], const uint8_t tom_h[72], uint32_t sec_level);
@@ -230,16 +258,32 @@ zk_status zk_synth_params(zk_ctx *ctx, uint64_t seed, uint8_t nist_h[64], uint8_
  * proofGK/gk.ts:31-40, curves/{weier.ts:92-101, edwards.ts:89-98, group.ts:155-161}, bignum/big.ts:230-248).
  * Host-only conversions between one ZKA1 proof and its JSON text; no context and no GPU needed.  *out_len is always
  * set to the required size; ZK_E_BUFFER if out_cap is too small (call once with out = NULL to size).  from_json is
- * order-tolerant and ignores "__type"/unknown members; it checks structure, group names and hex syntax/width --
+ * order-tolerant and ignores "__type"/unknown members; like JSON.parse it keeps the LAST of duplicated members, decodes the string
+ * escapes (\uXXXX included) and rejects text that is not JSON (stray tokens, raw control characters, unknown escapes); it checks
+ * structure, group names and hex syntax/width --
  * curve membership is checked where the reference checks it semantically, in zk_verify_batch's validation. */
 zk_status zk_proof_to_json(const uint8_t *proof, uint64_t proof_len, char *out, uint64_t out_cap, uint64_t *out_len);
 zk_status zk_proof_from_json(const char *json, uint64_t json_len, uint8_t *out, uint64_t out_cap, uint64_t *out_len);
+/* The same for whole batches on `threads` host threads (0 = one per hardware thread; ZKATTEST_JSON_THREADS): the reference's bench
+ * times toJson / fromJson per proof (bench/zkpAttestList.bench.ts:63-68); at ~600 KB of text per proof a batch of the GPU's size
+ * needs every core.  Item i is proofs[proof_off[i] .. proof_off[i+1]) (texts[text_off[i] .. text_off[i+1])); the results lie back
+ * to back in `out`, delimited by the n + 1 offsets written; an item that does not convert gets its status and an empty result.
+ * ZK_E_BUFFER when `out` is too small: the offsets are complete anyway (the last one is the size to come back with). */
+zk_status zk_proofs_to_json_batch(uint64_t n, const uint8_t *proofs, const uint64_t *proof_off /*n+1*/, char *out, uint64_t out_cap,
+                                  uint64_t *text_off /*n+1*/, int32_t *per_proof_status /*n*/, uint32_t threads);
+zk_status zk_proofs_from_json_batch(uint64_t n, const char *texts, const uint64_t *text_off /*n+1*/, uint8_t *out, uint64_t out_cap,
+                                    uint64_t *proof_off /*n+1*/, int32_t *per_proof_status /*n*/, uint32_t threads);
 
 /* Timing of the last prove/verify call: total GPU milliseconds between the first and last kernel (HIP events
  * on the engine's stream) and, per kernel family, the accumulated milliseconds.  names[i] are static strings. */
 uint32_t zk_last_timing(const zk_ctx *ctx, float *total_ms, const char **names, float *ms, uint32_t cap);
 
 /* Unit-test hooks (tests/ call these through the C ABI to compare single primitives with the oracle).
+ * zk_pool_test_locality: NUMA node and local CPUs of a PCI address as the pool reads them from sysfs (ZKATTEST_SYSFS_ROOT). */
+int zk_pool_test_locality(const char *pci_bus_id, int *numa_node, int *cpus, int cap);
+/* work counters since the context was created: 0 = proofs that went through the verifier's per-proof sums (fallback of the batched check) */
+uint64_t zk_test_counter(const zk_ctx *ctx, int which);
+/*
  * which_field: 0 = F_q (p256.p), 1 = Z_n, 2 = F_t;  op: 0 mul, 1 add, 2 sub, 3 inverse, 4 a*b - a - b (fused double subtraction), 5 (a + b)^2 (dedicated squaring).  count x 40-byte BE operands. */
 zk_status zk_test_field_op(zk_ctx *ctx, int which_field, int op, uint64_t count, const uint8_t *a_be40, const uint8_t *b_be40, uint8_t *out_be40);
 /* out[i] = v[i]*g + r[i]*h on Tom-256 (72-byte affine), through the fixed-base comb kernel */

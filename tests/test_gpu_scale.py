@@ -65,16 +65,18 @@ def test_baseline_config3_batch65536_ring65536_verify_all_diff_one_percent():
     forged = sorted(rnd.sample(range(B), 5))
     for b in forged:
         pin.view[off[b + 1] - 9] ^= 0x10
-    dt_forged, ok, vst = eng.verify_batch_host_raw(msg, pin, off, B)
+    before = eng.test_counter(0)
+    _, ok, vst = eng.verify_batch_host_raw(msg, pin, off, B)
     assert [b for b in range(B) if not ok[b]] == forged
-    # five forged proofs in 65 536 (at most five of the 64 groups re-checked per proof): within 25 % of the all-honest time
+    # five forged proofs in 65 536: only the groups holding one (an eighth of a 8192-proof chunk each) went through the per-proof
+    # sums -- asserted on the work counter, not on wall time (the boxes of the pool differ by 2-3x)
+    rechecked = eng.test_counter(0) - before
+    assert 0 < rechecked <= 5 * (8192 // 8), rechecked
     for b in forged:
         pin.view[off[b + 1] - 9] ^= 0x10
-    dt_clean = min(eng.verify_batch_host_raw(msg, pin, off, B)[0] for _ in range(2))
-    for b in forged:
-        pin.view[off[b + 1] - 9] ^= 0x10
-    dt_forged = min(dt_forged, eng.verify_batch_host_raw(msg, pin, off, B)[0])
-    assert dt_forged < 1.25 * dt_clean, (dt_forged, dt_clean)
+    before = eng.test_counter(0)
+    _, ok, vst = eng.verify_batch_host_raw(msg, pin, off, B)
+    assert sum(ok) == B and eng.test_counter(0) == before
     pin.free()
     eng.close()
 

@@ -1,0 +1,144 @@
+"""-m gpu: the streamed host-pointer calls (zk_prove_submit / zk_prove_wait, zk_verify_submit / zk_verify_wait; include/zkattest.h
+"two batches in flight"): several jobs queued on one context, the stage-1 look-ahead crossing job boundaries.  The bytes, statuses
+and verdicts must be those of the synchronous calls, whatever the job sizes, the chunk size and the number of lanes."""
+import ctypes as C
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(S, nkeys, B, chunk, lanes):
+    import zkp_ecdsa_amd as Z
+    eng = Z.Engine(0)
+    params = eng.synth_params(S)
+    eng.set_comb_bits(16)
+    eng.set_params(*params, 80)
+    work = eng.synth_workload(S, nkeys, B)
+    eng.set_ring(work[0], nkeys)
+    eng.set_chunk(chunk)
+    eng.set_lanes(lanes)
+    return Z, eng, work
+
+
+def _cut(work, a, b):
+    ring, msg, sig, pk, which, seeds = work
+    return msg[32 * a:32 * b], sig[64 * a:64 * b], pk[64 * a:64 * b], which[a:b], seeds[32 * a:32 * b]
+
+
+@pytest.mark.parametrize('chunk,lanes,sizes', [(256, 2, (700, 300, 1000, 130)), (512, 3, (512, 1536, 100)), (4096, 2, (900, 900))])
+def test_streamed_prove_and_verify_equal_the_synchronous_calls(chunk, lanes, sizes):
+    B = sum(sizes)
+    Z, eng, work = _setup(77, 64, B, chunk, lanes)
+    cap = eng.proof_max_size()
+    bounds, a = [], 0
+    for n in sizes:
+        bounds.append((a, a + n))
+        a += n
+    # synchronous reference: one zk_prove_batch per job on a page-locked buffer
+    ref = []
+    for (a, b) in bounds:
+        m, s, p, w, sd = _cut(work, a, b)
+        pin = Z.PinnedBuffer(cap * (b - a) // 2 + (8 << 20))
+        _, _, off, st = eng.prove_batch_host_raw(m, s, p, w, sd, out=pin)
+        assert not any(st)
+        ref.append((bytes(pin.view[:off[b - a]]), list(off)))
+        pin.free()
+    # streamed: submit(0); submit(1); wait(0); submit(2); wait(1); ...
+    pins = [Z.PinnedBuffer(cap * (b - a) // 2 + (8 << 20)) for (a, b) in bounds]
+    tickets, got = [], []
+    for k, (a, b) in enumerate(bounds):
+        tickets.append(eng.prove_submit(*_cut(work, a, b), pins[k]))
+        if k >= 1:
+            got.append(eng.prove_wait(tickets[k - 1]))
+    got.append(eng.prove_wait(tickets[-1]))
+    for k, (a, b) in enumerate(bounds):
+        off, st = got[k]
+        assert not any(st)
+        assert list(off) == ref[k][1]
+        assert bytes(pins[k].view[:off[b - a]]) == ref[k][0], 'job %d differs from the synchronous call' % k
+    # ---- verify: a forged proof in job 1, a truncated header claim in job 2; fixed verifier seeds -> the synchronous verdicts
+    vseeds = [os.urandom(32 * (b - a)) for (a, b) in bounds]
+    offs = [got[k][0] for k in range(len(bounds))]
+    if len(bounds) > 1:
+        o = offs[1]
+        pins[1].view[o[5 + 1] - 9] ^= 1          # a response byte of proof 5 of job 1
+    if len(bounds) > 2:
+        o = offs[2]
+        pins[2].view[o[3] + 11] ^= 1             # secLevel field of proof 3 of job 2
+    sync = []
+    for k, (a, b) in enumerate(bounds):
+        _, ok, vst = eng.verify_batch_host_raw(work[1][32 * a:32 * b], pins[k], offs[k], b - a, vseeds[k])
+        sync.append((list(ok), list(vst)))
+    vt, vgot = [], []
+    for k, (a, b) in enumerate(bounds):
+        vt.append(eng.verify_submit(work[1][32 * a:32 * b], pins[k], offs[k], b - a, vseeds[k]))
+        if k >= 1:
+            vgot.append(eng.verify_wait(vt[k - 1]))
+    vgot.append(eng.verify_wait(vt[-1]))
+    for k in range(len(bounds)):
+        assert (list(vgot[k][0]), list(vgot[k][1])) == sync[k], 'verdicts of job %d differ' % k
+    if len(bounds) > 1:
+        assert sync[1][0][5] == 0 and sum(sync[1][0]) == bounds[1][1] - bounds[1][0] - 1
+    assert sum(sync[0][0]) == bounds[0][1] - bounds[0][0]
+    # default verifier seeds (drawn on the device from OS randomness): honest jobs are accepted
+    t = eng.verify_submit(work[1][:32 * sizes[0]], pins[0], offs[0], sizes[0])
+    ok, vst = eng.verify_wait(t)
+    assert sum(ok) == sizes[0] and not any(vst)
+    for p in pins:
+        p.free()
+    eng.close()
+
+
+def test_streamed_calls_enforce_their_rules():
+    B = 600
+    Z, eng, work = _setup(78, 32, B, 256, 2)
+    cap = eng.proof_max_size()
+    pins = [Z.PinnedBuffer(cap * 200 // 2 + (8 << 20)) for _ in range(5)]
+    pageable = (C.c_uint8 * (cap * 10))()
+    args = _cut(work, 0, 200)
+
+    class Fake:   # a pageable buffer dressed up as a PinnedBuffer
+        ptr, nbytes = C.addressof(pageable), C.sizeof(pageable)
+    with pytest.raises(Z.ZkError) as e:
+        eng.prove_submit(*_cut(work, 0, 10), Fake)
+    assert e.value.status == 14 and 'page-locked' in str(e.value)
+    t0 = eng.prove_submit(*args, pins[0])
+    t1 = eng.prove_submit(*_cut(work, 200, 400), pins[1])
+    with pytest.raises(Z.ZkError) as e:   # the synchronous calls are refused while jobs are queued
+        eng.prove_batch_host_raw(*_cut(work, 0, 4))
+    assert e.value.status == 14 and 'streamed' in str(e.value)
+    with pytest.raises(Z.ZkError) as e:   # waits in submission order
+        eng.prove_wait(t1)
+    assert 'submission order' in str(e.value)
+    t2 = eng.prove_submit(*_cut(work, 400, 600), pins[2])
+    t3 = eng.prove_submit(*args, pins[3])
+    with pytest.raises(Z.ZkError) as e:   # at most four jobs
+        eng.prove_submit(*args, pins[4])
+    assert 'too many' in str(e.value)
+    off0, st0 = eng.prove_wait(t0)
+    with pytest.raises(Z.ZkError) as e:   # kinds do not mix
+        eng.verify_submit(work[1][:32 * 200], pins[0], off0, 200)
+    assert 'together' in str(e.value)
+    for t in (t1, t2, t3):
+        off, st = eng.prove_wait(t)
+        assert not any(st)
+    assert bytes(pins[3].view[:off[200]]) == bytes(pins[0].view[:off0[200]])   # the same statements and seeds: the same bytes
+    # an output buffer that is too small fails that job only
+    small = Z.PinnedBuffer(1 << 20)
+    ta = eng.prove_submit(*args, small)
+    tb = eng.prove_submit(*_cut(work, 200, 400), pins[1])
+    with pytest.raises(Z.ZkError) as e:
+        eng.prove_wait(ta)
+    assert e.value.status == 12
+    off, st = eng.prove_wait(tb)
+    assert not any(st)
+    ok, vst = eng.verify_batch_host_raw(work[1][32 * 200:32 * 400], pins[1], off, 200)[1:]
+    assert sum(ok) == 200
+    # a context destroyed with jobs still queued releases them
+    eng.prove_submit(*args, pins[0])
+    eng.prove_submit(*args, pins[2])
+    eng.close()
+    for p in pins + [small]:
+        p.free()

@@ -191,23 +191,25 @@ def test_one_forged_proof_only_sends_its_group_to_the_per_proof_sums():
     assert 'v_straus_tom' not in eng.last_timing()[1]
     eng.set_batch_verify(0)
     assert eng.verify_batch(msg, proofs, vseeds=vs) == ([1] * B, [0] * B)
-    full = eng.last_timing()[1]['v_straus_tom']
+    assert 'v_straus_tom' in eng.last_timing()[1]
     eng.set_batch_verify(256)
-    for bad in ([2700], [0], [B - 1], [1023, 1024], [3, 6000]):    # groups of 1024 proofs
+    groups = {(2700,): 1, (0,): 1, (B - 1,): 1, (1023, 1024): 2, (3, 6000): 2}
+    for bad, ng in groups.items():    # groups of 1024 proofs
+        bad = list(bad)
         forged = list(proofs)
         for b in bad:
             f = bytearray(proofs[b])
             f[-9] ^= 2                                   # zd
             forged[b] = bytes(f)
-        part = None
-        for _ in range(3):   # GPU event timings of one pass: best of three, the boxes of the pool are not equally quiet
-            ok, vst = eng.verify_batch(msg, forged, vseeds=vs)
-            assert [b for b in range(B) if not ok[b]] == bad and vst == [0] * B
-            t = eng.last_timing()[1]['v_straus_tom']
-            part = t if part is None else min(part, t)
-        # one range: 20 480 slots over 4 lanes each instead of 163 840 slots on one lane each; two separate ranges run one after
-        # the other (each is latency-bound: 65 windows of a lane's own doublings and additions)
-        assert part < (0.55 if bad != [3, 6000] else 0.85) * full, (bad, part, full)
+        before = eng.test_counter(0)
+        ok, vst = eng.verify_batch(msg, forged, vseeds=vs)
+        assert [b for b in range(B) if not ok[b]] == bad and vst == [0] * B
+        # WORK, not time (the boxes of the pool differ by 2-3x): exactly the groups holding a forgery went through the per-proof sums
+        assert eng.test_counter(0) - before == ng * (B // 8), (bad, eng.test_counter(0) - before)
+        assert 'v_straus_tom' in eng.last_timing()[1]
+    before = eng.test_counter(0)
+    assert eng.verify_batch(msg, proofs, vseeds=vs) == ([1] * B, [0] * B)
+    assert eng.test_counter(0) == before                 # an all-honest chunk never reaches them
     eng.close()
 
 

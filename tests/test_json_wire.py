@@ -129,3 +129,57 @@ def test_sizing_call_reports_required_length():
     assert n.value == len(Z.write_json(raw))
     small = C.create_string_buffer(16)
     assert L.zk_proof_to_json(raw, len(raw), small, 16, C.byref(n)) == 12
+
+
+def test_reader_follows_json_parse_on_the_corner_cases():
+    """Parser differentials on attacker-controlled text (the same text must not decode to another proof here than under
+    JSON.parse + typedjson): a duplicated member -- the LAST one counts; escapes are decoded, \\uXXXX included; stray tokens, raw
+    control characters and unknown escapes are syntax errors; numbers / literals in unknown members are valid JSON and ignored."""
+    raw = _golden_proofs()[0][1]
+    text = Z.write_json(raw)
+    top = json.loads(text)
+    x = top['R']['x']
+    other = '0x' + format(int(x, 16) ^ 1, 'x')
+    # duplicate key: python's json.loads keeps the last one too
+    dup = text.replace('"x":"%s"' % x, '"x":"%s","x":"%s"' % (other, x), 1)
+    assert json.loads(dup) == top and Z.read_json(dup) == raw
+    dup2 = text.replace('"x":"%s"' % x, '"x":"%s","x":"%s"' % (x, other), 1)
+    assert Z.read_json(dup2) != raw and Z.read_json(dup2) == Z.read_json(json.dumps(json.loads(dup2)))
+    # escapes: "0x..." is "0x...", "name" is "name"
+    esc = text.replace('"x":"0x', '"x":"\\u0030x', 1).replace('"name"', '"na\\u006de"', 1).replace('"R"', '"\\u0052"', 1)
+    assert json.loads(esc) == top and Z.read_json(esc) == raw
+    for bad_text in (text.replace('"x":"0x', '"x":"\\q0x', 1),            # unknown escape
+                     text.replace('"x":"0x', '"x":"\\u00zz', 1),          # bad \u
+                     text.replace('"x":"0x', '"x":"0\tx', 1),             # raw control character inside a string
+                     text.replace('{"R":', '{"extra":tru,"R":', 1),       # not a literal
+                     text.replace('{"R":', '{"extra":01,"R":', 1),        # not a number
+                     text.replace('{"R":', '{"extra":1.,"R":', 1),
+                     text.replace('{"R":', '{"extra":-,"R":', 1)):
+        with pytest.raises(Z.ZkError):
+            Z.read_json(bad_text)
+        with pytest.raises(ValueError):
+            json.loads(bad_text)
+    for fine in ('{"extra":true,"R":', '{"extra":-1.5e+3,"R":', '{"extra":null,"e2":[0,false,{"a":1E2}],"R":'):
+        assert Z.read_json(text.replace('{"R":', fine, 1)) == raw
+
+
+def test_batch_converters_equal_the_single_proof_ones():
+    cases = [raw for _, raw in _golden_proofs()]
+    proofs = (cases * 9)[:40]
+    single = [Z.write_json(p).encode() for p in proofs]
+    for threads in (1, 3, 0):
+        texts, st = Z.write_json_batch(proofs, threads)
+        assert st == [0] * len(proofs) and texts == single
+        back, st = Z.read_json_batch(texts, threads)
+        assert st == [0] * len(proofs) and back == proofs
+    # a bad item gets its status and an empty result; its neighbours are converted
+    broken = list(proofs[:5])
+    broken[2] = broken[2][:-4]
+    texts, st = Z.write_json_batch(broken, 2)
+    assert st == [0, 0, 10, 0, 0] and texts[2] == b'' and texts[3] == single[3]
+    bad_texts = list(single[:5])
+    bad_texts[1] = bad_texts[1][:-1]
+    bad_texts[4] = b'[]'
+    back, st = Z.read_json_batch(bad_texts, 2)
+    assert st == [0, 10, 0, 0, 10] and back[1] == b'' and back[0] == proofs[0] and back[3] == proofs[3]
+    assert Z.write_json_batch([], 0) == ([], []) and Z.read_json_batch([], 0) == ([], [])

@@ -17,6 +17,9 @@ SYMBOLS = [
     'zk_proof_to_json', 'zk_proof_from_json', 'zk_host_alloc', 'zk_host_free', 'zk_ctx_set_host_taper', 'zk_ctx_set_slice', 'zk_ctx_set_mode', 'zk_ring_digest', 'zk_hardened_h',
     'zk_pool_create', 'zk_pool_destroy', 'zk_pool_size', 'zk_pool_ctx', 'zk_pool_last_error', 'zk_pool_ring_transport', 'zk_pool_shard',
     'zk_pool_set_params', 'zk_pool_set_ring', 'zk_pool_prove_batch', 'zk_pool_verify_batch',
+    'zk_pool_host_alloc', 'zk_pool_host_free', 'zk_pool_numa_node', 'zk_pool_test_locality',
+    'zk_prove_submit', 'zk_prove_wait', 'zk_verify_submit', 'zk_verify_wait', 'zk_test_counter',
+    'zk_proofs_to_json_batch', 'zk_proofs_from_json_batch',
     'zk_test_field_op', 'zk_test_tom_commit', 'zk_test_p256_fixed_mul', 'zk_test_sha256', 'zk_test_rng_draws',
 ]
 
@@ -101,6 +104,20 @@ def lib():
         L.zk_pool_set_ring.argtypes = [vp, C.c_char_p, u64]
         L.zk_pool_prove_batch.argtypes = [vp, u64, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(ZkRng), vp, u64, vp, vp, vp]
         L.zk_pool_verify_batch.argtypes = [vp, u64, C.c_char_p, vp, vp, vp, C.c_char_p, vp, vp]
+        L.zk_proofs_to_json_batch.argtypes = [u64, vp, vp, vp, u64, vp, vp, u32]
+        L.zk_proofs_from_json_batch.argtypes = [u64, vp, vp, vp, u64, vp, vp, u32]
+        L.zk_prove_submit.argtypes = [vp, u64, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(ZkRng), vp, u64, vp, vp, C.POINTER(vp)]
+        L.zk_prove_wait.argtypes = [vp, vp]
+        L.zk_verify_submit.argtypes = [vp, u64, C.c_char_p, vp, vp, C.c_char_p, vp, vp, C.POINTER(vp)]
+        L.zk_verify_wait.argtypes = [vp, vp]
+        L.zk_test_counter.argtypes = [vp, i32]
+        L.zk_test_counter.restype = u64
+        L.zk_pool_host_alloc.argtypes = [vp, C.c_size_t]
+        L.zk_pool_host_alloc.restype = vp
+        L.zk_pool_host_free.argtypes = [vp]
+        L.zk_pool_host_free.restype = None
+        L.zk_pool_numa_node.argtypes = [vp, i32]
+        L.zk_pool_test_locality.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), i32]
         L.zk_test_field_op.argtypes = [vp, i32, i32, u64, C.c_char_p, C.c_char_p, vp]
         L.zk_test_tom_commit.argtypes = [vp, u64, C.c_char_p, C.c_char_p, vp]
         L.zk_test_p256_fixed_mul.argtypes = [vp, i32, u64, C.c_char_p, vp]
@@ -111,19 +128,21 @@ def lib():
 
 
 class PinnedBuffer:
-    """Page-locked host memory from zk_host_alloc (include/zkattest.h): .ptr for the C ABI, .view as a ctypes byte array."""
+    """Page-locked host memory from zk_host_alloc (include/zkattest.h): .ptr for the C ABI, .view as a ctypes byte array.
+    With `pool`: zk_pool_host_alloc -- the per-shard regions are placed on the NUMA nodes of the shards' devices."""
 
-    def __init__(self, nbytes):
+    def __init__(self, nbytes, pool=None):
         self.nbytes = nbytes
-        self.ptr = lib().zk_host_alloc(nbytes)
+        self._pooled = pool is not None
+        self.ptr = lib().zk_pool_host_alloc(pool.h, nbytes) if self._pooled else lib().zk_host_alloc(nbytes)
         if not self.ptr:
-            raise MemoryError('zk_host_alloc(%d) failed' % nbytes)
+            raise MemoryError('zk_%shost_alloc(%d) failed' % ('pool_' if self._pooled else '', nbytes))
         self.view = (C.c_uint8 * nbytes).from_address(self.ptr)
 
     def free(self):
         if self.ptr:
             self.view = None
-            lib().zk_host_free(self.ptr)
+            (lib().zk_pool_host_free if self._pooled else lib().zk_host_free)(self.ptr)
             self.ptr = None
 
     def __del__(self):
@@ -184,6 +203,44 @@ def read_json(text):
     return buf.raw[:n.value]
 
 
+def _json_batch(fn, blob, off, n, cap, threads):
+    L = lib()
+    out_off, st = (C.c_uint64 * (n + 1))(), (C.c_int32 * n)()
+    src = (C.c_uint8 * max(len(blob), 1)).from_buffer_copy(blob or b'\0')
+    for _ in range(2):
+        out = (C.c_uint8 * max(cap, 1))()
+        rc = fn(n, src, off, out, cap, out_off, st, threads)
+        if rc != 12:
+            break
+        cap = out_off[n]
+    if rc:
+        raise ZkError(rc)
+    return out, out_off, st
+
+
+def write_json_batch(proofs, threads=0):
+    """n ZKA1 proofs -> n JSON texts on `threads` host threads (0 = all): zk_proofs_to_json_batch.  -> (texts as bytes, statuses)."""
+    n = len(proofs)
+    off = (C.c_uint64 * (n + 1))()
+    for i, p in enumerate(proofs):
+        off[i + 1] = off[i] + len(p)
+    out, toff, st = _json_batch(lib().zk_proofs_to_json_batch, b''.join(proofs), off, n, int(3.7 * off[n]) + 4096 * n, threads)
+    raw = memoryview(out)
+    return [bytes(raw[toff[i]:toff[i + 1]]) for i in range(n)], list(st)
+
+
+def read_json_batch(texts, threads=0):
+    """n JSON texts -> n ZKA1 proofs (b'' where a text does not parse: see the statuses): zk_proofs_from_json_batch."""
+    texts = [t.encode() if isinstance(t, str) else bytes(t) for t in texts]
+    n = len(texts)
+    off = (C.c_uint64 * (n + 1))()
+    for i, t in enumerate(texts):
+        off[i + 1] = off[i] + len(t)
+    out, poff, st = _json_batch(lib().zk_proofs_from_json_batch, b''.join(texts), off, n, off[n] // 3 + 64 * n, threads)
+    raw = memoryview(out)
+    return [bytes(raw[poff[i]:poff[i + 1]]) for i in range(n)], list(st)
+
+
 class Engine:
     """One engine = one GPU (zk_ctx)."""
 
@@ -202,7 +259,7 @@ class Engine:
 
     def _chk(self, rc):
         if rc:
-            detail = self.L.zk_last_error(self.h).decode() if self.h else ''
+            detail = self.L.zk_last_error(self.h).decode()   # NULL handle: why zk_ctx_create failed (thread-local in the library)
             raise ZkError(rc, detail)
 
     def close(self):
@@ -332,6 +389,35 @@ class Engine:
         self._chk(self.L.zk_verify_batch(self.h, B, msg, ptr, off, bytes(vseeds) if vseeds is not None else None, ok, st))
         return time.time() - t0, ok, st
 
+    # ---- streamed calls (zk_prove_submit / zk_prove_wait ...): several batches in flight, waits in submission order
+    def prove_submit(self, msg, sig, pk, which, seeds, out):
+        """Queues one batch; `out` is a PinnedBuffer.  Returns a ticket for prove_wait (it keeps every buffer of the job alive)."""
+        B = len(which)
+        t = {'B': B, 'out': out, 'off': (C.c_uint64 * (B + 1))(), 'st': (C.c_int32 * B)(), 'w': (C.c_uint32 * B)(*which),
+             'data': C.create_string_buffer(bytes(seeds), 32 * B), 'msg': bytes(msg), 'sig': bytes(sig), 'pk': bytes(pk), 'job': C.c_void_p()}
+        t['rng'] = ZkRng(0, C.cast(t['data'], C.c_void_p), 0)
+        cap = min(self.proof_max_size() * max(B, 1), out.nbytes)
+        self._chk(self.L.zk_prove_submit(self.h, B, t['msg'], t['sig'], t['pk'], t['w'], C.byref(t['rng']), out.ptr, cap, t['off'], t['st'], C.byref(t['job'])))
+        return t
+
+    def prove_wait(self, t):
+        """-> (offsets, statuses) of the ticket's batch; the proofs are in the ticket's PinnedBuffer."""
+        self._chk(self.L.zk_prove_wait(self.h, t['job']))
+        return t['off'], t['st']
+
+    def verify_submit(self, msg, proofs, off, B, vseeds=None):
+        t = {'B': B, 'proofs': proofs, 'off': off, 'ok': (C.c_uint8 * B)(), 'st': (C.c_int32 * B)(), 'msg': bytes(msg),
+             'seeds': bytes(vseeds) if vseeds is not None else None, 'job': C.c_void_p()}
+        self._chk(self.L.zk_verify_submit(self.h, B, t['msg'], proofs.ptr, off, t['seeds'], t['ok'], t['st'], C.byref(t['job'])))
+        return t
+
+    def verify_wait(self, t):
+        self._chk(self.L.zk_verify_wait(self.h, t['job']))
+        return t['ok'], t['st']
+
+    def test_counter(self, which=0):
+        return int(self.L.zk_test_counter(self.h, which))
+
     def prove_batch_device(self, B, d_msg, d_sig, d_pk, d_which, d_seeds, d_out, out_cap, d_off, d_status, mode=0, stride_blocks=0):
         rng = ZkRng(mode, d_seeds, stride_blocks)
         self._chk(self.L.zk_prove_batch_device(self.h, B, d_msg, d_sig, d_pk, d_which, C.byref(rng), d_out, out_cap, d_off, d_status))
@@ -428,7 +514,7 @@ class Pool:
 
     def _chk(self, rc):
         if rc:
-            raise ZkError(rc, self.L.zk_pool_last_error(self.h).decode() if self.h else '')
+            raise ZkError(rc, self.L.zk_pool_last_error(self.h).decode())   # NULL handle: why zk_pool_create failed
 
     def close(self):
         if getattr(self, 'h', None):
@@ -444,6 +530,9 @@ class Pool:
     def engine(self, i):
         """Per-device context (settings only: chunk, lanes, comb width, host taper); owned by the pool."""
         return Engine(_borrowed=self.L.zk_pool_ctx(self.h, i))
+
+    def numa_node(self, i):
+        return self.L.zk_pool_numa_node(self.h, i)
 
     def shard(self, B, i):
         f, c = C.c_uint64(), C.c_uint64()

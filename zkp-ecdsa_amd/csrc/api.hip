@@ -16,6 +16,7 @@ void launch_synth_param_scalars(hipStream_t s, uint64_t seed, uint8_t* kn_be, ui
 
 #include <cstdlib>
 #include "ctx.h"
+#include "jobs.h"
 
 extern "C" const char* zk_strerror(zk_status s) {
     switch (s) {
@@ -38,7 +39,8 @@ extern "C" const char* zk_strerror(zk_status s) {
     }
     return "unknown status";
 }
-extern "C" const char* zk_last_error(const zk_ctx* c) { return c ? c->err.c_str() : ""; }
+static thread_local std::string g_ctx_create_err;   // why this thread's last zk_ctx_create failed: zk_last_error(NULL)
+extern "C" const char* zk_last_error(const zk_ctx* c) { return c ? c->err.c_str() : g_ctx_create_err.c_str(); }
 
 // HIP multiplexes its streams onto a few hardware queues, round-robin in creation order (GPU_MAX_HW_QUEUES, default 4; measured
 // with tools/stream_overlap.hip: of eight streams, numbers 3 and 7 queue behind number 0).  Two streams on one hardware queue
@@ -49,11 +51,24 @@ extern "C" const char* zk_last_error(const zk_ctx* c) { return c ? c->err.c_str(
 // an order that gives the first two lanes and their copy streams four different queues even with the default of 4.
 __attribute__((constructor)) static void zk_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
+static zk_status ctx_init(zk_ctx* c, int device_id);
+// *out is either a fully initialised context or NULL (then zk_last_error(NULL) has the reason): a caller never holds a half-built one
 extern "C" zk_status zk_ctx_create(int device_id, zk_ctx** out) {
     if (!out) return ZK_E_ARG;
+    *out = nullptr;
     zk_ctx* c = new zk_ctx();
     c->device = device_id;
+    zk_status zs = ctx_init(c, device_id);
+    if (zs) {
+        g_ctx_create_err = c->err;
+        zk_ctx_destroy(c);
+        (void)hipGetLastError();
+        return zs;
+    }
     *out = c;
+    return ZK_OK;
+}
+static zk_status ctx_init(zk_ctx* c, int device_id) {
     HIPCHK(c, hipSetDevice(device_id));
     for (int base = 0; base < ZK_MAX_LANES; base += 2) {   // compute 0, compute 1, copy 0, copy 1; then the same for lanes 2, 3
         for (int l = base; l < base + 2; l++) HIPCHK(c, hipStreamCreate(&c->pl[l].stream));
@@ -97,10 +112,14 @@ extern "C" zk_status zk_ctx_set_comb_bits(zk_ctx* c, uint32_t bits) {
     c->tom_bits = bits;
     return ZK_OK;
 }
+void stream_release_spares(zk_ctx* c);   // api_stream.hip
+void stream_abandon_jobs(zk_ctx* c);
 extern "C" void zk_ctx_destroy(zk_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    stream_abandon_jobs(c);
+    stream_release_spares(c);
     for (auto e : c->epool) hipEventDestroy(e);
     hipFree(c->P.tom_tab_g), hipFree(c->P.tom_tab_h), hipFree(c->tom_tab_gen), hipFree(c->P.pfix_G), hipFree(c->P.pfix_H);
     hipFree(c->tab_scratch), hipFree(c->gk_etab), hipFree(c->d_flag), hipFree(c->ring_mem), hipFree(c->ring_digest);
@@ -409,313 +428,289 @@ zk_status ensure_copy_stream(zk_ctx* c) {   // the streams exist since zk_ctx_cr
 }
 
 // ------------------------------------------------------------------ the prover pipeline
-// host_sink: page-locked destination of the proof bytes (or nullptr): every chunk is copied out on c->copy_stream as soon as
-// its last kernel has run, while the next chunks are being proved.
+// One call = one ProveJob: the chunk plan of its B proofs and the two stage functions.  The synchronous entry points run one job
+// to completion; the streamed ones (zk_prove_submit / zk_prove_wait below) keep several jobs queued and let the stage-1 look-ahead
+// run across the boundary between consecutive jobs, so the device never drains between calls.
+//
+// Every chunk has two stages.  Stage 1 (front end .. Exp challenge) needs nothing from other chunks; stage 2 starts with
+// the scan, which needs the output cursor, i.e. the byte count of all earlier chunks of the job, and the host has to read the
+// item count back before it can size the PointAdd launches.  Stage 1 of the next NL - 1 chunks is enqueued on the other
+// lanes BEFORE the host blocks on a chunk's scan, so no stream runs dry while the host waits.
+// host_sink: page-locked destination of the proof bytes (or nullptr): every slice is copied out on its lane's copy stream as soon
+// as its last kernel has run, while the next slices / chunks are being proved.
+zk_status ProveJob::stage1(uint64_t chunk_no) {
+    const ChunkPlan& cp = plan[chunk_no];
+    const DevParams& P = c->P;
+    const uint32_t lane = lane_of(chunk_no);
+    Workspace& W = c->pl[lane].W;
+    hipStream_t s = c->pl[lane].stream;
+    const uint64_t first = cp.first;
+    const uint32_t cnt = cp.cnt;
+    if (io_dbg) fprintf(stderr, "host %7.1f ms: stage1 of chunk %u (%u proofs) -> lane %u\n", host_ms() - host_t0, (uint32_t)chunk_no, cnt, lane);
+    if (inputs_ready) HIPCHK(c, hipStreamWaitEvent(s, inputs_ready, 0));
+    ChunkIn in{d_msg + 32 * first, d_sig + 64 * first, d_pk + 64 * first, d_which + first, cnt};
+    W.rng.seeds = d_rng, W.rng.stream = d_rng, W.rng.stride_blocks = stride, W.rng.mode = rng_mode, W.rng.sec = (int)W.sec;
+    W.rng.proof_base = (uint32_t)first;
+    uint32_t nblk = 3 + 44 * W.sec + 5 * W.n + RNG_MAX_EXC;
+    {
+        MaybeScope t(timed, c, "rng_prepass", s);
+        launch_rng_prepass(s, W, cnt, 0, 3 + 4 * W.sec + RNG_MAX_EXC, nblk, rng_mode == 0 ? W.rng_fill : nullptr, false);  // + margin: rejected fills shift later draws
+    }
+    Workspace Wgen = W;  // RNG view of the generator (seed mode) for the second prepass stage
+    if (rng_mode == 0)   // from here on the chunk reads the fills the prepass wrote
+        W.rng.mode = 1, W.rng.stream = (const uint8_t*)W.rng_fill, W.rng.stride_blocks = nblk, W.rng.proof_base = 0;
+    {
+        MaybeScope t(timed, c, "p256_front", s);
+        launch_front(s, P, W, in);
+    }
+    {
+        MaybeScope t(timed, c, "p256_rtab", s);
+        launch_rtab(s, W, cnt, RTAB_PROVE_BITS);
+    }
+    {
+        MaybeScope t(timed, c, "p256_exp_commit", s);
+        launch_exp_commit(s, P, W, cnt);
+    }
+    {
+        MaybeScope t(timed, c, "p256_normalize", s);
+        launch_p256_normalize(s, W.Tproj, cnt * (W.sec + 1), W.Tx, W.Ty, W.st, W.sec + 1, ZK_ST_T_INF_LATE, nullptr);
+        launch_p256_normalize(s, W.Aproj, cnt * (W.sec + 1), W.Ax, W.Ay, W.st, W.sec + 1, 0, nullptr);
+    }
+    uint32_t na = cnt * (2 + 2 * W.sec);
+    {
+        MaybeScope t(timed, c, "scalars", s);
+        launch_lista_scalars(s, W, cnt);
+    }
+    {
+        MaybeScope t(timed, c, "tom_commit", s);
+        launch_tom_commit(s, P, W.la, na, 1, 1);
+    }
+    {
+        MaybeScope t(timed, c, "tom_normalize", s);
+        launch_tom_normalize(s, W.la, na, 0, 1, 1);
+    }
+    {
+        MaybeScope t(timed, c, "hash", s);
+        launch_exp_challenge(s, W, cnt);
+    }
+    Pending& pd = pend[lane];
+    pd.lane = lane, pd.cnt = cnt, pd.first = first, pd.in = in, pd.Wgen = Wgen, pd.nblk = nblk;
+    return ZK_OK;
+}
+// Stage 2.  Order: scan -> fixed part and rep heads -> the whole Groth-Kohlweiss phase -> the PointAdd phase (80 % of the
+// bytes) in proof-aligned slices.  None of the three depends on another (they share the chunk's RNG fills and the list-A
+// results), and with this order every byte of a proof is final as soon as the slice holding its PointAdd items is done: a
+// page-locked sink then receives the slice's proofs by DMA while the next slice is being computed.  A slice runs the
+// unchanged per-item kernels on a view of the workspace whose item-indexed arrays start at the slice's first item.
+zk_status ProveJob::stage2(uint64_t chunk_no) {
+    const DevParams& P = c->P;
+    Pending& pd = pend[lane_of(chunk_no)];
+    Workspace& W = c->pl[pd.lane].W;
+    hipStream_t s = c->pl[pd.lane].stream;
+    const Soa& gk_am = c->pl[pd.lane].gk_am;
+    uint32_t* d_totals = c->pl[pd.lane].d_totals;
+    const uint32_t cnt = pd.cnt, nblk = pd.nblk;
+    const uint64_t first = pd.first;
+    const ChunkIn& in = pd.in;
+    const Workspace& Wgen = pd.Wgen;
+    // page-locked read-back area of the lane: totals, then the prefix sums the slices need
+    uint32_t* totals = (uint32_t*)c->pl[pd.lane].h_scan;
+    uint64_t* h_out_base = (uint64_t*)((uint8_t*)c->pl[pd.lane].h_scan + 64);
+    uint32_t* h_item_base = (uint32_t*)(h_out_base + (size_t)c->ws_C + 2);
+    {
+        MaybeScope t(timed, c, "scan", s);
+        launch_scan(s, W, cnt, cursor, out_cap, d_out_off, d_status, d_totals, first);
+    }
+    const uint32_t S = c->slice ? c->slice : (host_sink ? 4096u : 0u);
+    const bool sliced = S && cnt > S;
+    const bool last_chunk = first + cnt == B && !more_follows;
+    launch_words_to_host(s, totals, d_totals, 4);
+    if (sliced) {   // slice boundaries: the chunk's item and byte prefix sums
+        launch_words_to_host(s, h_item_base, W.item_base, (size_t)cnt + 1);
+        launch_words_to_host(s, h_out_base, W.out_base, 2 * ((size_t)cnt + 1));
+    }
+    if (io_dbg) fprintf(stderr, "host %7.1f ms: stage2 lane %u waits for its scan\n", host_ms() - host_t0, pd.lane);
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (io_dbg) fprintf(stderr, "host %7.1f ms: scan done\n", host_ms() - host_t0);
+    if (totals[1]) {
+        c->err = "output buffer too small";
+        sync_lanes();
+        return ZK_E_BUFFER;
+    }
+    const uint32_t items_all = totals[0];
+    if (items_all > W.items_cap) {
+        // cannot happen for hash-derived challenges (cap = mean + 8 sigma) unless chunk*sec is tiny, where cap = chunk*sec
+        c->err = "zero-bit rep count exceeds workspace capacity";
+        sync_lanes();
+        return ZK_E_BUFFER;
+    }
+    uint8_t* out = d_out + cursor;
+    const uint64_t chunk_bytes = (uint64_t)totals[2] | ((uint64_t)totals[3] << 32);
+    {
+        MaybeScope t(timed, c, "scan", s);
+        launch_items(s, W, cnt);
+    }
+    {
+        MaybeScope t(timed, c, "rng_prepass", s);  // second stage: only the blocks a proof with z zero bits can reach
+        launch_rng_prepass(s, Wgen, cnt, 3 + 4 * W.sec + RNG_MAX_EXC, nblk, nblk, rng_mode == 0 ? W.rng_fill : nullptr, true);
+    }
+    {
+        MaybeScope t(timed, c, "respond_write", s);
+        launch_write_fixed(s, W, cnt, out);
+    }
+    {
+        MaybeScope t(timed, c, "gk_fold", s);
+        launch_gk_scalars_fold(s, W, in, gk_am);
+        launch_gk_cd_scalars(s, W, cnt);
+    }
+    {
+        MaybeScope t(timed, c, "tom_commit", s);
+        launch_tom_commit(s, P, W.lc, cnt * 4 * W.n, 1, 1);
+    }
+    {
+        MaybeScope t(timed, c, "tom_normalize", s);
+        launch_tom_normalize(s, W.lc, cnt * 4 * W.n, 0, 1, 1);
+    }
+    {
+        MaybeScope t(timed, c, "hash", s);
+        launch_gk_hash(s, W, cnt, in.msg);
+    }
+    {
+        MaybeScope t(timed, c, "respond_write", s);
+        launch_gk_respond(s, W, in, out);
+    }
+    std::vector<ChunkPlan> slices;
+    if (sliced) slices = make_chunk_plan(cnt, S, 1, host_sink != nullptr && !more_follows, last_chunk ? ZK_SLICE_MIN / 2 : ZK_SLICE_MIN);   // the call's very last slices stay exposed
+    else slices.push_back({0, cnt});
+    for (const ChunkPlan& sl : slices) {
+        const uint32_t p0 = (uint32_t)sl.first, p1 = p0 + sl.cnt;
+        const uint32_t i0 = sliced ? h_item_base[p0] : 0, i1 = sliced ? h_item_base[p1] : items_all;
+        const uint32_t items = i1 - i0;
+        if (items) {
+            Workspace Ws = W;   // the slice's view: item-indexed arrays start at item i0
+            Ws.item_proof += i0, Ws.item_rep += i0, Ws.item_rank += i0, Ws.padd_c += (size_t)18 * i0;
+            for (Soa* a : {&Ws.T1proj.x, &Ws.T1proj.y, &Ws.T1proj.z, &Ws.T1x, &Ws.T1y, &Ws.lb.v, &Ws.lb.r, &Ws.lb.proj.x, &Ws.lb.proj.y, &Ws.lb.proj.z,
+                           &Ws.lb.ax, &Ws.lb.ay})
+                a->p += i0;
+            {
+                MaybeScope t(timed, c, "p256_t1", s);
+                launch_t1(s, Ws, items);
+            }
+            {
+                MaybeScope t(timed, c, "p256_normalize", s);
+                launch_p256_normalize(s, Ws.T1proj, items, Ws.T1x, Ws.T1y, Ws.st, 1, ZK_E_T1_INF, Ws.item_proof);
+            }
+            {
+                MaybeScope t(timed, c, "scalars", s);
+                launch_padd_scalars(s, P, Ws, items);
+            }
+            {
+                MaybeScope t(timed, c, "tom_commit", s);
+                launch_tom_commit_listb(s, P, Ws.lb, items, Ws.items_cap);
+            }
+            {
+                MaybeScope t(timed, c, "tom_normalize", s);
+                launch_tom_normalize(s, Ws.lb, items * LB_COMMITS, 0, items, 0, Ws.items_cap);
+            }
+            {
+                MaybeScope t(timed, c, "tom_derived", s);
+                launch_padd_derived(s, Ws, items);
+                launch_tom_normalize(s, Ws.lb, items * 5, LB_COMMITS, items, 0, Ws.items_cap);
+            }
+            {
+                MaybeScope t(timed, c, "hash", s);
+                launch_padd_hash(s, P, Ws, items);
+            }
+            {
+                MaybeScope t(timed, c, "respond_write", s);
+                launch_padd_respond(s, Ws, items, out);
+                launch_write_padd_points(s, Ws, items, out);
+            }
+        }
+        if (host_sink) {   // every byte of proofs [p0, p1) is final: DMA them out behind the next slice's kernels
+            const uint64_t b0 = sliced ? h_out_base[p0] : 0, b1 = sliced ? h_out_base[p1] : chunk_bytes;
+            if (b1 > b0) {
+                hipEvent_t ev = c->pl[pd.lane].copy_ev;
+                IoRec r{};
+                if (io_dbg) {
+                    hipEventCreate(&r.ready), hipEventCreate(&r.c0), hipEventCreate(&r.c1);
+                    r.bytes = b1 - b0, r.chunk = (uint32_t)(first / (C ? C : 1)), r.lane = pd.lane;
+                    hipEventRecord(r.ready, s);
+                }
+                HIPCHK(c, hipEventRecord(ev, s));
+                HIPCHK(c, hipStreamWaitEvent(c->pl[pd.lane].copy_stream, ev, 0));
+                if (io_dbg) hipEventRecord(r.c0, c->pl[pd.lane].copy_stream);
+                HIPCHK(c, hipMemcpyAsync(host_sink + cursor + b0, out + b0, b1 - b0, hipMemcpyDeviceToHost, c->pl[pd.lane].copy_stream));
+                if (io_dbg) {
+                    hipEventRecord(r.c1, c->pl[pd.lane].copy_stream);
+                    iorecs.push_back(r);
+                }
+            }
+        }
+    }
+    {
+        MaybeScope t(timed, c, "respond_write", s);
+        launch_status_out(s, W, cnt, d_status, first);   // late (cryptographically negligible) errors included: after the last slice
+    }
+    cursor += chunk_bytes;
+    if (io_dbg) fprintf(stderr, "host %7.1f ms: stage2 lane %u enqueued\n", host_ms() - host_t0, pd.lane);
+    return ZK_OK;
+}
+
 static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const uint8_t* d_sig, const uint8_t* d_pk, const uint32_t* d_which,
                               int rng_mode, const uint8_t* d_rng, uint64_t stride, uint8_t* d_out, uint64_t out_cap, uint64_t* d_out_off,
                               int32_t* d_status, uint8_t* host_sink = nullptr) {
     if (!c->params_set || !c->N) return ZK_E_BUFFER;
     if (rng_mode != ZK_RNG_SEED && rng_mode != ZK_RNG_STREAM) return ZK_E_ARG;
-    uint32_t C = (uint32_t)std::min<uint64_t>(c->chunk, B ? B : 1);
-    const std::vector<ChunkPlan> plan = make_chunk_plan(B, C, host_sink != nullptr && c->host_taper ? (c->host_taper == 1 ? c->lanes : c->host_taper) : 1, false);
-    const uint32_t NL = (uint32_t)std::min<size_t>(c->lanes, plan.size() ? plan.size() : 1);  // chunks rotate over NL streams / workspaces
-    zk_status zs = ensure_workspace(c, C, NL);
+    if (c->stream_busy) {
+        c->err = "streamed jobs are in flight on this context (zk_prove_wait / zk_verify_wait them first)";
+        return ZK_E_ARG;
+    }
+    ProveJob J;
+    J.c = c, J.B = B, J.d_msg = d_msg, J.d_sig = d_sig, J.d_pk = d_pk, J.d_which = d_which, J.rng_mode = rng_mode, J.d_rng = d_rng, J.stride = stride;
+    J.d_out = d_out, J.out_cap = out_cap, J.d_out_off = d_out_off, J.d_status = d_status, J.host_sink = host_sink;
+    J.C = (uint32_t)std::min<uint64_t>(c->chunk, B ? B : 1);
+    J.plan = make_chunk_plan(B, J.C, host_sink != nullptr && c->host_taper ? (c->host_taper == 1 ? c->lanes : c->host_taper) : 1, false);
+    J.NL = (uint32_t)std::min<size_t>(c->lanes, J.plan.size() ? J.plan.size() : 1);  // chunks rotate over NL streams / workspaces
+    zk_status zs = ensure_workspace(c, J.C, J.NL);
     if (zs) return zs;
-    const DevParams& P = c->P;
     timing_begin(c);
-    uint64_t cursor = 0;
     if (B == 0) {
         HIPCHK(c, hipMemsetAsync(d_out_off, 0, 8, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return ZK_OK;
     }
-    // Every chunk has two stages.  Stage 1 (front end .. Exp challenge) needs nothing from other chunks; stage 2 starts with
-    // the scan, which needs the output cursor, i.e. the byte count of all earlier chunks, and the host has to read the
-    // item count back before it can size the PointAdd launches.  With two lanes, stage 1 of chunk k+1 is enqueued on the
-    // other stream BEFORE the host blocks on chunk k's scan, so neither stream runs dry while the host waits.
-    // ZK_IO_DEBUG=1: timeline of the D2H slices on stderr (ready / copy start / copy end in ms since the call began)
-    struct IoRec {
-        hipEvent_t ready, c0, c1;
-        uint64_t bytes;
-        uint32_t chunk, lane;
-    };
-    std::vector<IoRec> iorecs;
-    hipEvent_t io_t0 = nullptr;
-    const bool io_dbg = host_sink && getenv("ZK_IO_DEBUG");
-    auto host_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double host_t0 = host_ms();
-    if (io_dbg) {
-        hipEventCreate(&io_t0);
-        hipEventRecord(io_t0, c->stream);
+    J.io_dbg = host_sink && getenv("ZK_IO_DEBUG");
+    J.host_t0 = ProveJob::host_ms();
+    if (J.io_dbg) {
+        hipEventCreate(&J.io_t0);
+        hipEventRecord(J.io_t0, c->stream);
     }
-    auto sync_lanes = [&]() -> hipError_t {
-        hipError_t r = hipSuccess;
-        for (uint32_t l = 0; l < NL; l++) {
-            hipError_t e = hipStreamSynchronize(c->pl[l].stream);
-            if (r == hipSuccess) r = e;
-        }
-        return r;
-    };
-    struct Pending {
-        uint32_t lane;
-        uint32_t cnt;
-        uint64_t first;
-        ChunkIn in;
-        Workspace Wgen;  // RNG view of the generator (seed mode) for the second prepass stage
-        uint32_t nblk;
-    };
-    auto stage1 = [&](const ChunkPlan& cp, uint32_t chunk_no, Pending& pd) -> zk_status {
-        const uint32_t lane = chunk_no % NL;
-        Workspace& W = c->pl[lane].W;
-        hipStream_t s = c->pl[lane].stream;
-        const uint64_t first = cp.first;
-        const uint32_t cnt = cp.cnt;
-        if (io_dbg) fprintf(stderr, "host %7.1f ms: stage1 of chunk %u (%u proofs) -> lane %u\n", host_ms() - host_t0, chunk_no, cnt, lane);
-        ChunkIn in{d_msg + 32 * first, d_sig + 64 * first, d_pk + 64 * first, d_which + first, cnt};
-        W.rng.seeds = d_rng, W.rng.stream = d_rng, W.rng.stride_blocks = stride, W.rng.mode = rng_mode, W.rng.sec = (int)W.sec;
-        W.rng.proof_base = (uint32_t)first;
-        uint32_t nblk = 3 + 44 * W.sec + 5 * W.n + RNG_MAX_EXC;
-        {
-            Scope t(c, "rng_prepass", s);
-            if (io_dbg) fprintf(stderr, "host %7.1f ms:   enqueue rng_prepass\n", host_ms() - host_t0);
-            launch_rng_prepass(s, W, cnt, 0, 3 + 4 * W.sec + RNG_MAX_EXC, nblk, rng_mode == 0 ? W.rng_fill : nullptr, false);  // + margin: rejected fills shift later draws
-        }
-        Workspace Wgen = W;  // RNG view of the generator (seed mode) for the second prepass stage
-        if (rng_mode == 0)   // from here on the chunk reads the fills the prepass wrote
-            W.rng.mode = 1, W.rng.stream = (const uint8_t*)W.rng_fill, W.rng.stride_blocks = nblk, W.rng.proof_base = 0;
-        {
-            Scope t(c, "p256_front", s);
-            if (io_dbg) fprintf(stderr, "host %7.1f ms:   enqueue p256_front\n", host_ms() - host_t0);
-            launch_front(s, P, W, in);
-        }
-        {
-            Scope t(c, "p256_rtab", s);
-            if (io_dbg) fprintf(stderr, "host %7.1f ms:   enqueue p256_rtab\n", host_ms() - host_t0);
-            launch_rtab(s, W, cnt, RTAB_PROVE_BITS);
-        }
-        {
-            Scope t(c, "p256_exp_commit", s);
-            if (io_dbg) fprintf(stderr, "host %7.1f ms:   enqueue p256_exp_commit\n", host_ms() - host_t0);
-            launch_exp_commit(s, P, W, cnt);
-        }
-        {
-            Scope t(c, "p256_normalize", s);
-            if (io_dbg) fprintf(stderr, "host %7.1f ms:   enqueue p256_normalize\n", host_ms() - host_t0);
-            launch_p256_normalize(s, W.Tproj, cnt * (W.sec + 1), W.Tx, W.Ty, W.st, W.sec + 1, ZK_ST_T_INF_LATE, nullptr);
-            launch_p256_normalize(s, W.Aproj, cnt * (W.sec + 1), W.Ax, W.Ay, W.st, W.sec + 1, 0, nullptr);
-        }
-        uint32_t na = cnt * (2 + 2 * W.sec);
-        {
-            Scope t(c, "scalars", s);
-            if (io_dbg) fprintf(stderr, "host %7.1f ms:   enqueue scalars\n", host_ms() - host_t0);
-            launch_lista_scalars(s, W, cnt);
-        }
-        {
-            Scope t(c, "tom_commit", s);
-            if (io_dbg) fprintf(stderr, "host %7.1f ms:   enqueue tom_commit\n", host_ms() - host_t0);
-            launch_tom_commit(s, P, W.la, na, 1, 1);
-        }
-        {
-            Scope t(c, "tom_normalize", s);
-            if (io_dbg) fprintf(stderr, "host %7.1f ms:   enqueue tom_normalize\n", host_ms() - host_t0);
-            launch_tom_normalize(s, W.la, na, 0, 1, 1);
-        }
-        {
-            Scope t(c, "hash", s);
-            if (io_dbg) fprintf(stderr, "host %7.1f ms:   enqueue hash\n", host_ms() - host_t0);
-            launch_exp_challenge(s, W, cnt);
-        }
-        pd.lane = lane, pd.cnt = cnt, pd.first = first, pd.in = in, pd.Wgen = Wgen, pd.nblk = nblk;
-        return ZK_OK;
-    };
-    // Stage 2.  Order: scan -> fixed part and rep heads -> the whole Groth-Kohlweiss phase -> the PointAdd phase (80 % of the
-    // bytes) in proof-aligned slices.  None of the three depends on another (they share the chunk's RNG fills and the list-A
-    // results), and with this order every byte of a proof is final as soon as the slice holding its PointAdd items is done: a
-    // page-locked sink then receives the slice's proofs by DMA while the next slice is being computed.  A slice runs the
-    // unchanged per-item kernels on a view of the workspace whose item-indexed arrays start at the slice's first item.
-    auto stage2 = [&](Pending& pd) -> zk_status {
-        Workspace& W = c->pl[pd.lane].W;
-        hipStream_t s = c->pl[pd.lane].stream;
-        const Soa& gk_am = c->pl[pd.lane].gk_am;
-        uint32_t* d_totals = c->pl[pd.lane].d_totals;
-        const uint32_t cnt = pd.cnt, nblk = pd.nblk;
-        const uint64_t first = pd.first;
-        const ChunkIn& in = pd.in;
-        const Workspace& Wgen = pd.Wgen;
-        // page-locked read-back area of the lane: totals, then the prefix sums the slices need
-        uint32_t* totals = (uint32_t*)c->pl[pd.lane].h_scan;
-        uint64_t* h_out_base = (uint64_t*)((uint8_t*)c->pl[pd.lane].h_scan + 64);
-        uint32_t* h_item_base = (uint32_t*)(h_out_base + (size_t)C + 2);
-        {
-            Scope t(c, "scan", s);
-            launch_scan(s, W, cnt, cursor, out_cap, d_out_off, d_status, d_totals, first);
-        }
-        const uint32_t S = c->slice ? c->slice : (host_sink ? 4096u : 0u);
-        const bool sliced = S && cnt > S;
-        const bool last_chunk = first + cnt == B;
-        launch_words_to_host(s, totals, d_totals, 4);
-        if (sliced) {   // slice boundaries: the chunk's item and byte prefix sums
-            launch_words_to_host(s, h_item_base, W.item_base, (size_t)cnt + 1);
-            launch_words_to_host(s, h_out_base, W.out_base, 2 * ((size_t)cnt + 1));
-        }
-        if (io_dbg) fprintf(stderr, "host %7.1f ms: stage2 lane %u waits for its scan\n", host_ms() - host_t0, pd.lane);
-        HIPCHK(c, hipStreamSynchronize(s));
-        if (io_dbg) fprintf(stderr, "host %7.1f ms: scan done\n", host_ms() - host_t0);
-        if (totals[1]) {
-            c->err = "output buffer too small";
-            sync_lanes();
-            return ZK_E_BUFFER;
-        }
-        const uint32_t items_all = totals[0];
-        if (items_all > W.items_cap) {
-            // cannot happen for hash-derived challenges (cap = mean + 8 sigma) unless chunk*sec is tiny, where cap = chunk*sec
-            c->err = "zero-bit rep count exceeds workspace capacity";
-            sync_lanes();
-            return ZK_E_BUFFER;
-        }
-        uint8_t* out = d_out + cursor;
-        const uint64_t chunk_bytes = (uint64_t)totals[2] | ((uint64_t)totals[3] << 32);
-        {
-            Scope t(c, "scan", s);
-            launch_items(s, W, cnt);
-        }
-        {
-            Scope t(c, "rng_prepass", s);  // second stage: only the blocks a proof with z zero bits can reach
-            launch_rng_prepass(s, Wgen, cnt, 3 + 4 * W.sec + RNG_MAX_EXC, nblk, nblk, rng_mode == 0 ? W.rng_fill : nullptr, true);
-        }
-        {
-            Scope t(c, "respond_write", s);
-            launch_write_fixed(s, W, cnt, out);
-        }
-        {
-            Scope t(c, "gk_fold", s);
-            launch_gk_scalars_fold(s, W, in, gk_am);
-            launch_gk_cd_scalars(s, W, cnt);
-        }
-        {
-            Scope t(c, "tom_commit", s);
-            launch_tom_commit(s, P, W.lc, cnt * 4 * W.n, 1, 1);
-        }
-        {
-            Scope t(c, "tom_normalize", s);
-            launch_tom_normalize(s, W.lc, cnt * 4 * W.n, 0, 1, 1);
-        }
-        {
-            Scope t(c, "hash", s);
-            launch_gk_hash(s, W, cnt, in.msg);
-        }
-        {
-            Scope t(c, "respond_write", s);
-            launch_gk_respond(s, W, in, out);
-        }
-        std::vector<ChunkPlan> slices;
-        if (sliced) slices = make_chunk_plan(cnt, S, 1, host_sink != nullptr, last_chunk ? ZK_SLICE_MIN / 2 : ZK_SLICE_MIN);   // the call's very last slices stay exposed
-        else slices.push_back({0, cnt});
-        for (const ChunkPlan& sl : slices) {
-            const uint32_t p0 = (uint32_t)sl.first, p1 = p0 + sl.cnt;
-            const uint32_t i0 = sliced ? h_item_base[p0] : 0, i1 = sliced ? h_item_base[p1] : items_all;
-            const uint32_t items = i1 - i0;
-            if (items) {
-                Workspace Ws = W;   // the slice's view: item-indexed arrays start at item i0
-                Ws.item_proof += i0, Ws.item_rep += i0, Ws.item_rank += i0, Ws.padd_c += (size_t)18 * i0;
-                for (Soa* a : {&Ws.T1proj.x, &Ws.T1proj.y, &Ws.T1proj.z, &Ws.T1x, &Ws.T1y, &Ws.lb.v, &Ws.lb.r, &Ws.lb.proj.x, &Ws.lb.proj.y, &Ws.lb.proj.z,
-                               &Ws.lb.ax, &Ws.lb.ay})
-                    a->p += i0;
-                {
-                    Scope t(c, "p256_t1", s);
-                    launch_t1(s, Ws, items);
-                }
-                {
-                    Scope t(c, "p256_normalize", s);
-                    launch_p256_normalize(s, Ws.T1proj, items, Ws.T1x, Ws.T1y, Ws.st, 1, ZK_E_T1_INF, Ws.item_proof);
-                }
-                {
-                    Scope t(c, "scalars", s);
-                    launch_padd_scalars(s, P, Ws, items);
-                }
-                {
-                    Scope t(c, "tom_commit", s);
-                    launch_tom_commit_listb(s, P, Ws.lb, items, Ws.items_cap);
-                }
-                {
-                    Scope t(c, "tom_normalize", s);
-                    launch_tom_normalize(s, Ws.lb, items * LB_COMMITS, 0, items, 0, Ws.items_cap);
-                }
-                {
-                    Scope t(c, "tom_derived", s);
-                    launch_padd_derived(s, Ws, items);
-                    launch_tom_normalize(s, Ws.lb, items * 5, LB_COMMITS, items, 0, Ws.items_cap);
-                }
-                {
-                    Scope t(c, "hash", s);
-                    launch_padd_hash(s, P, Ws, items);
-                }
-                {
-                    Scope t(c, "respond_write", s);
-                    launch_padd_respond(s, Ws, items, out);
-                    launch_write_padd_points(s, Ws, items, out);
-                }
-            }
-            if (host_sink) {   // every byte of proofs [p0, p1) is final: DMA them out behind the next slice's kernels
-                const uint64_t b0 = sliced ? h_out_base[p0] : 0, b1 = sliced ? h_out_base[p1] : chunk_bytes;
-                if (b1 > b0) {
-                    hipEvent_t ev = c->pl[pd.lane].copy_ev;
-                    IoRec r{};
-                    if (io_dbg) {
-                        hipEventCreate(&r.ready), hipEventCreate(&r.c0), hipEventCreate(&r.c1);
-                        r.bytes = b1 - b0, r.chunk = (uint32_t)(first / (C ? C : 1)), r.lane = pd.lane;
-                        hipEventRecord(r.ready, s);
-                    }
-                    HIPCHK(c, hipEventRecord(ev, s));
-                    HIPCHK(c, hipStreamWaitEvent(c->pl[pd.lane].copy_stream, ev, 0));
-                    if (io_dbg) hipEventRecord(r.c0, c->pl[pd.lane].copy_stream);
-                    HIPCHK(c, hipMemcpyAsync(host_sink + cursor + b0, out + b0, b1 - b0, hipMemcpyDeviceToHost, c->pl[pd.lane].copy_stream));
-                    if (io_dbg) {
-                        hipEventRecord(r.c1, c->pl[pd.lane].copy_stream);
-                        iorecs.push_back(r);
-                    }
-                }
-            }
-        }
-        {
-            Scope t(c, "respond_write", s);
-            launch_status_out(s, W, cnt, d_status, first);   // late (cryptographically negligible) errors included: after the last slice
-        }
-        cursor += chunk_bytes;
-        if (io_dbg) fprintf(stderr, "host %7.1f ms: stage2 lane %u enqueued\n", host_ms() - host_t0, pd.lane);
-        return ZK_OK;
-    };
-    const uint64_t nchunks = plan.size();
-    Pending pend[ZK_MAX_LANES];
-    // stage 1 of the next NL - 1 chunks is enqueued on the other lanes before the host blocks on this chunk's scan
-    uint64_t next_s1 = 0;
+    const uint64_t nchunks = J.plan.size();
     for (uint64_t k = 0; k < nchunks && !zs; k++) {
-        while (!zs && next_s1 < nchunks && next_s1 < k + NL) {
-            zs = stage1(plan[next_s1], (uint32_t)next_s1, pend[next_s1 % NL]);
-            next_s1++;
-        }
-        if (!zs) zs = stage2(pend[k % NL]);
+        while (!zs && J.next_s1 < nchunks && J.next_s1 < k + J.NL) zs = J.stage1(J.next_s1++);
+        if (!zs) zs = J.stage2(k);
     }
-    hipError_t e_sync = sync_lanes();   // nothing of this call may still be running (or writing into the caller's buffer) when it returns
+    hipError_t e_sync = J.sync_lanes();   // nothing of this call may still be running (or writing into the caller's buffer) when it returns
     if (host_sink)
-        for (uint32_t l = 0; l < NL; l++) {
+        for (uint32_t l = 0; l < J.NL; l++) {
             hipError_t e2 = hipStreamSynchronize(c->pl[l].copy_stream);
             if (e_sync == hipSuccess) e_sync = e2;
         }
-    if (io_dbg) {
-        for (auto& r : iorecs) {
+    if (J.io_dbg) {
+        for (auto& r : J.iorecs) {
             float a = 0, b = 0, d = 0;
-            hipEventElapsedTime(&a, io_t0, r.ready), hipEventElapsedTime(&b, io_t0, r.c0), hipEventElapsedTime(&d, io_t0, r.c1);
+            hipEventElapsedTime(&a, J.io_t0, r.ready), hipEventElapsedTime(&b, J.io_t0, r.c0), hipEventElapsedTime(&d, J.io_t0, r.c1);
             fprintf(stderr, "io: first-proof-block %4u lane %u  %8.1f MB  ready %7.1f  copy %7.1f .. %7.1f ms  (%5.1f GB/s)\n", r.chunk, r.lane, r.bytes / 1e6, a, b, d,
                     r.bytes / 1e6 / (d - b > 1e-3 ? d - b : 1e-3));
             hipEventDestroy(r.ready), hipEventDestroy(r.c0), hipEventDestroy(r.c1);
         }
         for (auto& r : c->trecs) {   // every timed scope of the call, in enqueue order
             float a = 0, b = 0;
-            hipEventElapsedTime(&a, io_t0, r.e0), hipEventElapsedTime(&b, io_t0, r.e1);
+            hipEventElapsedTime(&a, J.io_t0, r.e0), hipEventElapsedTime(&b, J.io_t0, r.e1);
             fprintf(stderr, "gpu: %-16s %7.1f .. %7.1f ms\n", r.name, a, b);
         }
-        hipEventDestroy(io_t0);
+        hipEventDestroy(J.io_t0);
     }
     if (zs) return zs;
     HIPCHK(c, e_sync);
@@ -737,6 +732,10 @@ extern "C" zk_status zk_prove_batch(zk_ctx* c, uint64_t B, const uint8_t* msg, c
     if (!c || !rng || !out_off || !status || (B && (!msg || !sig || !pk || !which || !rng->data || !out))) return ZK_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->params_set || !c->N) return ZK_E_BUFFER;
+    if (c->stream_busy) {
+        c->err = "streamed jobs are in flight on this context (zk_prove_wait / zk_verify_wait them first)";
+        return ZK_E_ARG;
+    }
     size_t rng_bytes = rng->mode == ZK_RNG_SEED ? 32 * B : 32 * B * rng->stride_blocks;
     size_t bb = B ? B : 1;
     uint64_t cap_dev = std::min<uint64_t>(out_cap, zk_proof_max_size(c) * bb);

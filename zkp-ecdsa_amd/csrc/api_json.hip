@@ -18,31 +18,75 @@
 // deliberately tolerant: member order is free, "__type" and unknown members are ignored, so real typedjson output
 // parses whatever the hint policy of the installed version is.
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 #include "../../include/zkattest.h"
 
 namespace {
-const char* G_P = "{\"name\":\"p256\",\"__type\":\"WeierstrassGroup\"}";
-const char* G_T = "{\"name\":\"tomEdwards256\",\"__type\":\"TEdwards\"}";
-
-void hex_of(const uint8_t* be, int n, std::string& o) {   // n <= 36
-    static const char* d = "0123456789abcdef";
-    char tmp[2 * 36 + 4];
-    char* q = tmp;
-    *q++ = '"', *q++ = '0', *q++ = 'x';
-    int i = 0;
-    while (i < n && be[i] == 0) i++;
-    if (i == n) *q++ = '0';
-    else {
-        if (be[i] >> 4) *q++ = d[be[i] >> 4];
-        *q++ = d[be[i] & 15];
-        for (i++; i < n; i++) *q++ = d[be[i] >> 4], *q++ = d[be[i] & 15];
+// ---------------------------------------------------------------- writer
+// The text is produced by ONE traversal of the ZKA1 bytes, instantiated for two sinks: MaxSink adds up an upper bound of the
+// text length (literals exactly, every hex field at its full width), BufSink writes into a buffer of at least that size without
+// any further check.  Literals carry their length (no strlen per append: a proof is ~10 000 points and scalars), hex digits come
+// out 16 bytes per step through a byte shuffle where the CPU has one.
+#define LIT(s) s, sizeof(s) - 1
+#define G_P_TXT "{\"name\":\"p256\",\"__type\":\"WeierstrassGroup\"}"
+#define G_T_TXT "{\"name\":\"tomEdwards256\",\"__type\":\"TEdwards\"}"
+struct MaxSink {
+    uint64_t n = 0;
+    void lit(const char*, size_t l) { n += l; }
+    void hex(const uint8_t*, int nbytes) { n += 4 + 2 * (size_t)nbytes; }
+};
+struct LenSink {   // the exact length: hex fields without their leading zeros
+    uint64_t n = 0;
+    void lit(const char*, size_t l) { n += l; }
+    void hex(const uint8_t* be, int nbytes) {
+        int i = 0;
+        while (i < nbytes && be[i] == 0) i++;
+        n += 4 + (i == nbytes ? 1 : 2 * (size_t)(nbytes - i) - ((be[i] >> 4) ? 0 : 1));
     }
-    *q++ = '"';
-    o.append(tmp, (size_t)(q - tmp));
+};
+#if defined(__x86_64__)
+__attribute__((target("ssse3"))) static inline void hex16_ssse3(const uint8_t* src, char* dst) {   // 16 bytes -> 32 lowercase digits
+    typedef char v16 __attribute__((vector_size(16)));
+    typedef unsigned char u16v __attribute__((vector_size(16)));
+    u16v in;
+    memcpy(&in, src, 16);
+    const u16v lut = {'0', '1', '2', '3', '4', '5', '6', '7', '8', '9', 'a', 'b', 'c', 'd', 'e', 'f'};
+    u16v hi = (in >> 4) & (unsigned char)15, lo = in & (unsigned char)15;
+    u16v dh = (u16v)__builtin_ia32_pshufb128((v16)lut, (v16)hi), dl = (u16v)__builtin_ia32_pshufb128((v16)lut, (v16)lo);
+    u16v a = __builtin_shufflevector(dh, dl, 0, 16, 1, 17, 2, 18, 3, 19, 4, 20, 5, 21, 6, 22, 7, 23);
+    u16v b = __builtin_shufflevector(dh, dl, 8, 24, 9, 25, 10, 26, 11, 27, 12, 28, 13, 29, 14, 30, 15, 31);
+    memcpy(dst, &a, 16), memcpy(dst + 16, &b, 16);
 }
+static const bool g_have_ssse3 = __builtin_cpu_supports("ssse3");
+#endif
+struct BufSink {
+    char* q;
+    void lit(const char* s, size_t l) {
+        memcpy(q, s, l);
+        q += l;
+    }
+    void hex(const uint8_t* be, int n) {   // "0x" + lowercase hex without leading zeros (big.ts:230-239); n <= 36
+        static const char* d = "0123456789abcdef";
+        *q++ = '"', *q++ = '0', *q++ = 'x';
+        int i = 0;
+        while (i < n && be[i] == 0) i++;
+        if (i == n) *q++ = '0';
+        else {
+            if (be[i] >> 4) *q++ = d[be[i] >> 4];
+            *q++ = d[be[i] & 15];
+            i++;
+#if defined(__x86_64__)
+            if (g_have_ssse3)
+                for (; i + 16 <= n; i += 16) hex16_ssse3(be + i, q), q += 32;
+#endif
+            for (; i < n; i++) *q++ = d[be[i] >> 4], *q++ = d[be[i] & 15];
+        }
+        *q++ = '"';
+    }
+};
 struct Rd {
     const uint8_t* p;
     uint64_t len, off;
@@ -58,35 +102,109 @@ struct Rd {
         return r;
     }
 };
-void pt_p(Rd& r, std::string& o) {
+template <class S>
+void pt_p(Rd& r, S& o) {
     const uint8_t* b = r.take(64);
-    o += "{\"group\":", o += G_P, o += ",\"x\":", hex_of(b, 32, o), o += ",\"y\":", hex_of(b + 32, 32, o), o += ",\"__type\":\"WeierstrassPoint\"}";
+    o.lit(LIT("{\"group\":" G_P_TXT ",\"x\":")), o.hex(b, 32), o.lit(LIT(",\"y\":")), o.hex(b + 32, 32), o.lit(LIT(",\"__type\":\"WeierstrassPoint\"}"));
 }
-void pt_t(Rd& r, std::string& o) {
+template <class S>
+void pt_t(Rd& r, S& o) {
     const uint8_t* b = r.take(72);
-    o += "{\"group\":", o += G_T, o += ",\"x\":", hex_of(b, 36, o), o += ",\"y\":", hex_of(b + 36, 36, o), o += ",\"__type\":\"TEdwardsPoint\"}";
+    o.lit(LIT("{\"group\":" G_T_TXT ",\"x\":")), o.hex(b, 36), o.lit(LIT(",\"y\":")), o.hex(b + 36, 36), o.lit(LIT(",\"__type\":\"TEdwardsPoint\"}"));
 }
-void sc(Rd& r, bool tom, std::string& o) {
+template <class S>
+void sc(Rd& r, bool tom, S& o) {
     const uint8_t* b = r.take(32);
-    o += "{\"group\":", o += tom ? G_T : G_P, o += ",\"k\":", hex_of(b, 32, o), o += "}";
+    if (tom) o.lit(LIT("{\"group\":" G_T_TXT ",\"k\":"));
+    else o.lit(LIT("{\"group\":" G_P_TXT ",\"k\":"));
+    o.hex(b, 32), o.lit(LIT("}"));
 }
-void key(std::string& o, const char* k, bool first = false) {
-    if (!first) o += ',';
-    o += '"', o += k, o += "\":";
+template <class S>
+void key(S& o, const char* k, bool first = false) {
+    if (!first) o.lit(LIT(","));
+    o.lit(LIT("\"")), o.lit(k, strlen(k)), o.lit(LIT("\":"));
 }
-void mult(Rd& r, std::string& o) {
+template <class S>
+void mult(Rd& r, S& o) {
     static const char* P[6] = {"C_4", "A_x", "A_y", "A_z", "A_4_1", "A_4_2"};
-    static const char* S[7] = {"t_x", "t_y", "t_z", "t_rx", "t_ry", "t_rz", "t_r4"};
-    o += '{';
+    static const char* T[7] = {"t_x", "t_y", "t_z", "t_rx", "t_ry", "t_rz", "t_r4"};
+    o.lit(LIT("{"));
     for (int i = 0; i < 6; i++) key(o, P[i], i == 0), pt_t(r, o);
-    for (int i = 0; i < 7; i++) key(o, S[i]), sc(r, true, o);
-    o += '}';
+    for (int i = 0; i < 7; i++) key(o, T[i]), sc(r, true, o);
+    o.lit(LIT("}"));
 }
-void eq(Rd& r, std::string& o) {
-    o += '{';
+template <class S>
+void eq(Rd& r, S& o) {
+    o.lit(LIT("{"));
     key(o, "A_1", true), pt_t(r, o), key(o, "A_2"), pt_t(r, o);
     key(o, "t_x"), sc(r, true, o), key(o, "t_r1"), sc(r, true, o), key(o, "t_r2"), sc(r, true, o);
-    o += '}';
+    o.lit(LIT("}"));
+}
+// the whole SignatureProofList; returns false when the bytes are not a well-formed ZKA1 proof
+template <class S>
+bool proof_text(const uint8_t* proof, uint64_t len, S& o) {
+    if (!proof || len < 32 || memcmp(proof, "ZKA1", 4)) return false;
+    uint32_t total = (uint32_t)proof[4] << 24 | proof[5] << 16 | proof[6] << 8 | proof[7];
+    uint32_t sec = (uint32_t)proof[8] << 24 | proof[9] << 16 | proof[10] << 8 | proof[11];
+    uint32_t n = (uint32_t)proof[12] << 24 | proof[13] << 16 | proof[14] << 8 | proof[15];
+    if (total != len || sec > 128 || n > 64) return false;
+    Rd r{proof, len, 32, true};
+    o.lit(LIT("{"));
+    key(o, "R", true), pt_p(r, o), key(o, "comS1"), pt_p(r, o), key(o, "keyXcom"), pt_t(r, o), key(o, "keyYcom"), pt_t(r, o);
+    key(o, "expProof"), o.lit(LIT("["));
+    for (uint32_t i = 0; i < sec; i++) {
+        int bi = 16 + 15 - (int)(i >> 3);
+        bool bit = (proof[bi] >> (i & 7)) & 1;
+        if (i) o.lit(LIT(","));
+        o.lit(LIT("{"));
+        key(o, "A", true), pt_p(r, o), key(o, "Tx"), pt_t(r, o), key(o, "Ty"), pt_t(r, o);
+        if (bit) {
+            key(o, "alpha"), sc(r, false, o), key(o, "beta1"), sc(r, false, o), key(o, "beta2"), sc(r, true, o), key(o, "beta3"), sc(r, true, o);
+        } else {
+            // ZKA1 stores z, z2, r1, r2 ahead of the PointAddProof; the JSON member order is z, z2, proof, r1, r2 (exp.ts:35-40)
+            key(o, "z"), sc(r, false, o), key(o, "z2"), sc(r, false, o);
+            Rd rr{proof, len, r.off, true};          // r1, r2: emitted after the proof
+            r.take(64);
+            key(o, "proof"), o.lit(LIT("{"));
+            static const char* C[4] = {"C_8", "C_10", "C_11", "C_13"};
+            for (int k = 0; k < 4; k++) key(o, C[k], k == 0), pt_t(r, o);
+            static const char* M[4] = {"pi_8", "pi_10", "pi_11", "pi_13"};
+            for (int k = 0; k < 4; k++) key(o, M[k]), mult(r, o);
+            key(o, "pi_x"), eq(r, o), key(o, "pi_y"), eq(r, o);
+            o.lit(LIT("}"));
+            key(o, "r1"), sc(rr, true, o), key(o, "r2"), sc(rr, true, o);
+            if (!rr.ok) r.ok = false;
+        }
+        o.lit(LIT("}"));
+    }
+    o.lit(LIT("]"));
+    key(o, "membershipProof"), o.lit(LIT("{"));
+    static const char* PA[4] = {"cl", "ca", "cb", "cd"};
+    for (int k = 0; k < 4; k++) {
+        key(o, PA[k], k == 0), o.lit(LIT("["));
+        for (uint32_t i = 0; i < n; i++) {
+            if (i) o.lit(LIT(","));
+            pt_t(r, o);
+        }
+        o.lit(LIT("]"));
+    }
+    static const char* SA[3] = {"f", "za", "zb"};
+    for (int k = 0; k < 3; k++) {
+        key(o, SA[k]), o.lit(LIT("["));
+        for (uint32_t i = 0; i < n; i++) {
+            if (i) o.lit(LIT(","));
+            sc(r, true, o);
+        }
+        o.lit(LIT("]"));
+    }
+    key(o, "zd"), sc(r, true, o);
+    o.lit(LIT("}}"));
+    return r.ok && r.off == len;
+}
+// upper bound of a proof's JSON length from its header alone (every hex field at full width); 0 = malformed
+uint64_t proof_text_bound(const uint8_t* proof, uint64_t len) {
+    MaxSink m;
+    return proof_text(proof, len, m) ? m.n : 0;
 }
 
 // ---------------------------------------------------------------- tolerant JSON reader
@@ -104,6 +222,7 @@ struct Doc {
     const char* base = nullptr;
     std::vector<Node> nd;
     std::vector<std::string> dec;
+    void reset(const char* b) { base = b, nd.clear(), dec.clear(); }   // keeps the capacity: one node array per THREAD, not per proof
     // key and string accessors
     bool key_is(const Node& m, const char* k, size_t kl) const {
         if (m.kesc) return dec[m.ks] == std::string(k, kl);
@@ -113,12 +232,13 @@ struct Doc {
         if (v.sesc) p = dec[v.s].data(), l = dec[v.s].size();
         else p = base + v.s, l = v.l;
     }
-    const Node* get(const Node* v, const char* k) const {   // first member named k, like the map lookup of a JSON parser
+    const Node* get(const Node* v, const char* k) const {   // LAST member named k: what JSON.parse keeps of a duplicated key
         if (!v || v->t != Node::OBJ) return nullptr;
         size_t kl = strlen(k);
+        const Node* hit = nullptr;
         for (uint32_t c = v->child; c; c = nd[c].next)
-            if (key_is(nd[c], k, kl)) return &nd[c];
-        return nullptr;
+            if (key_is(nd[c], k, kl)) hit = &nd[c];
+        return hit;
     }
 };
 struct Parser {
@@ -129,14 +249,42 @@ struct Parser {
     void ws() {
         while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++;
     }
-    // a string: span [s, s + l) of the input, or (escapes present) decoded like the earlier reader did: the character after a
-    // backslash is taken literally
+    // a string: span [s, s + l) of the input, or (escapes present) decoded as JSON.parse decodes it: the eight short escapes and
+    // \uXXXX (UTF-8 out, surrogate pairs joined); anything else after a backslash, and raw control characters, are syntax errors
+    static int hex4(const char* q) {
+        int v = 0;
+        for (int i = 0; i < 4; i++) {
+            char ch = q[i];
+            int d = ch >= '0' && ch <= '9' ? ch - '0' : ch >= 'a' && ch <= 'f' ? ch - 'a' + 10 : ch >= 'A' && ch <= 'F' ? ch - 'A' + 10 : -1;
+            if (d < 0) return -1;
+            v = v << 4 | d;
+        }
+        return v;
+    }
+    static void utf8(std::string& o, uint32_t cp) {
+        if (cp < 0x80) o += (char)cp;
+        else if (cp < 0x800) o += (char)(0xc0 | cp >> 6), o += (char)(0x80 | (cp & 63));
+        else if (cp < 0x10000) o += (char)(0xe0 | cp >> 12), o += (char)(0x80 | (cp >> 6 & 63)), o += (char)(0x80 | (cp & 63));
+        else o += (char)(0xf0 | cp >> 18), o += (char)(0x80 | (cp >> 12 & 63)), o += (char)(0x80 | (cp >> 6 & 63)), o += (char)(0x80 | (cp & 63));
+    }
+    static bool has_ctl(const char* a, const char* b) {   // any byte below 0x20?  eight at a time
+        for (; b - a >= 8; a += 8) {
+            uint64_t v;
+            memcpy(&v, a, 8);
+            // a byte x is < 0x20 iff its top three bits are clear: (x - 0x20) borrows into bit 7 while x's own bit 7 is clear
+            if ((v - 0x2020202020202020ull) & ~v & 0x8080808080808080ull) return true;
+        }
+        for (; a < b; a++)
+            if ((unsigned char)*a < 0x20) return true;
+        return false;
+    }
     bool str(uint32_t& s, uint32_t& l, bool& esc) {
         if (p >= e || *p != '"') return ok = false;
         p++;
         const char* q = (const char*)memchr(p, '"', (size_t)(e - p));   // the common case: no escape before the closing quote
         if (!q) return ok = false;
         if (const char* bs = (const char*)memchr(p, '\\', (size_t)(q - p))) q = bs;
+        if (has_ctl(p, q)) return ok = false;
         if (*q == '"') {
             s = (uint32_t)(p - d.base), l = (uint32_t)(q - p), esc = false;
             p = q + 1;
@@ -145,15 +293,66 @@ struct Parser {
         std::string out(p, q);
         p = q;
         while (p < e && *p != '"') {
-            if (*p == '\\') {
-                if (++p >= e) return ok = false;
+            if ((unsigned char)*p < 0x20) return ok = false;
+            if (*p != '\\') {
+                out += *p++;
+                continue;
             }
-            out += *p++;
+            if (++p >= e) return ok = false;
+            switch (*p++) {
+            case '"': out += '"'; break;
+            case '\\': out += '\\'; break;
+            case '/': out += '/'; break;
+            case 'b': out += '\b'; break;
+            case 'f': out += '\f'; break;
+            case 'n': out += '\n'; break;
+            case 'r': out += '\r'; break;
+            case 't': out += '\t'; break;
+            case 'u': {
+                if (e - p < 4) return ok = false;
+                int hi = hex4(p);
+                if (hi < 0) return ok = false;
+                p += 4;
+                uint32_t cp = (uint32_t)hi;
+                if (hi >= 0xd800 && hi < 0xdc00 && e - p >= 6 && p[0] == '\\' && p[1] == 'u') {   // a surrogate pair
+                    int lo = hex4(p + 2);
+                    if (lo >= 0xdc00 && lo < 0xe000) cp = 0x10000 + (((uint32_t)hi - 0xd800) << 10) + ((uint32_t)lo - 0xdc00), p += 6;
+                }
+                utf8(out, cp);   // a lone surrogate comes out as its own 3-byte form (never equal to an ASCII name or digit)
+                break;
+            }
+            default: return ok = false;
+            }
         }
         if (p >= e) return ok = false;
         p++;
         s = (uint32_t)d.dec.size(), l = 0, esc = true;
         d.dec.push_back(std::move(out));
+        return true;
+    }
+    // true / false / null / a number of the JSON grammar: -?(0|[1-9][0-9]*)(\.[0-9]+)?([eE][+-]?[0-9]+)?
+    bool scalar_token() {
+        auto word = [&](const char* w, size_t n) { return (size_t)(e - p) >= n && memcmp(p, w, n) == 0 ? (p += n, true) : false; };
+        if (word("true", 4) || word("false", 5) || word("null", 4)) return true;
+        const char* q = p;
+        auto digits = [&] {
+            const char* a = q;
+            while (q < e && *q >= '0' && *q <= '9') q++;
+            return q > a;
+        };
+        if (q < e && *q == '-') q++;
+        if (q < e && *q == '0') q++;
+        else if (!digits()) return false;
+        if (q < e && *q == '.') {
+            q++;
+            if (!digits()) return false;
+        }
+        if (q < e && (*q == 'e' || *q == 'E')) {
+            q++;
+            if (q < e && (*q == '+' || *q == '-')) q++;
+            if (!digits()) return false;
+        }
+        p = q;
         return true;
     }
     // parses one value into node `at` (already allocated)
@@ -204,16 +403,16 @@ struct Parser {
                 return ok = false;
             }
         }
-        d.nd[at].t = Node::OTHER;  // numbers, true/false/null: skipped
-        while (p < e && *p != ',' && *p != '}' && *p != ']') p++;
+        d.nd[at].t = Node::OTHER;  // numbers, true / false / null: valid JSON, but never a member this format reads
+        if (!scalar_token()) return ok = false;
         return true;
     }
 };
 struct Wr {
     const Doc& d;
-    std::vector<uint8_t> b;
+    std::vector<uint8_t>& b;
     bool ok = true;
-    explicit Wr(const Doc& doc) : d(doc) {}
+    Wr(const Doc& doc, std::vector<uint8_t>& buf) : d(doc), b(buf) {}
     // "0x.." -> nbytes big-endian (serdeBigInt.deserializer, big.ts:240-248; negative values are not valid here)
     void hex(const Node* v, int nbytes) {
         size_t at = b.size();
@@ -292,66 +491,21 @@ struct Wr {
 // No C++ exception may cross the C ABI: an allocation failure on a hostile input is reported as ZK_E_BUFFER.
 #define ZK_JSON_MAX_TEXT ((uint64_t)64 << 20)   // a SignatureProofList at secLevel 128, n = 64 is below 4 MB of JSON
 static zk_status proof_to_json_impl(const uint8_t* proof, uint64_t len, char* out, uint64_t cap, uint64_t* out_len) {
-    if (!proof || !out_len || len < 32 || memcmp(proof, "ZKA1", 4)) return ZK_E_BAD_ENCODING;
-    uint32_t total = (uint32_t)proof[4] << 24 | proof[5] << 16 | proof[6] << 8 | proof[7];
-    uint32_t sec = (uint32_t)proof[8] << 24 | proof[9] << 16 | proof[10] << 8 | proof[11];
-    uint32_t n = (uint32_t)proof[12] << 24 | proof[13] << 16 | proof[14] << 8 | proof[15];
-    if (total != len || sec > 128 || n > 64) return ZK_E_BAD_ENCODING;
-    Rd r{proof, len, 32, true};
-    std::string o;
-    o.reserve(800000);
-    o += '{';
-    key(o, "R", true), pt_p(r, o), key(o, "comS1"), pt_p(r, o), key(o, "keyXcom"), pt_t(r, o), key(o, "keyYcom"), pt_t(r, o);
-    key(o, "expProof"), o += '[';
-    for (uint32_t i = 0; i < sec; i++) {
-        int bi = 16 + 15 - (int)(i >> 3);
-        bool bit = (proof[bi] >> (i & 7)) & 1;
-        if (i) o += ',';
-        o += '{';
-        key(o, "A", true), pt_p(r, o), key(o, "Tx"), pt_t(r, o), key(o, "Ty"), pt_t(r, o);
-        if (bit) {
-            key(o, "alpha"), sc(r, false, o), key(o, "beta1"), sc(r, false, o), key(o, "beta2"), sc(r, true, o), key(o, "beta3"), sc(r, true, o);
-        } else {
-            std::string z, z2, r1, r2;
-            sc(r, false, z), sc(r, false, z2), sc(r, true, r1), sc(r, true, r2);
-            key(o, "z"), o += z, key(o, "z2"), o += z2;
-            key(o, "proof"), o += '{';
-            static const char* C[4] = {"C_8", "C_10", "C_11", "C_13"};
-            for (int k = 0; k < 4; k++) key(o, C[k], k == 0), pt_t(r, o);
-            static const char* M[4] = {"pi_8", "pi_10", "pi_11", "pi_13"};
-            for (int k = 0; k < 4; k++) key(o, M[k]), mult(r, o);
-            key(o, "pi_x"), eq(r, o), key(o, "pi_y"), eq(r, o);
-            o += '}';
-            key(o, "r1"), o += r1, key(o, "r2"), o += r2;
-        }
-        o += '}';
+    if (!proof || !out_len) return ZK_E_BAD_ENCODING;
+    const uint64_t bound = proof_text_bound(proof, len);
+    if (!bound) return ZK_E_BAD_ENCODING;
+    std::vector<char> tmp;
+    char* dst = out;
+    if (!out || cap < bound) {   // the exact length is only known after the conversion (hex fields drop their leading zeros)
+        tmp.resize(bound);
+        dst = tmp.data();
     }
-    o += ']';
-    key(o, "membershipProof"), o += '{';
-    static const char* PA[4] = {"cl", "ca", "cb", "cd"};
-    for (int k = 0; k < 4; k++) {
-        key(o, PA[k], k == 0), o += '[';
-        for (uint32_t i = 0; i < n; i++) {
-            if (i) o += ',';
-            pt_t(r, o);
-        }
-        o += ']';
-    }
-    static const char* SA[3] = {"f", "za", "zb"};
-    for (int k = 0; k < 3; k++) {
-        key(o, SA[k]), o += '[';
-        for (uint32_t i = 0; i < n; i++) {
-            if (i) o += ',';
-            sc(r, true, o);
-        }
-        o += ']';
-    }
-    key(o, "zd"), sc(r, true, o);
-    o += "}}";
-    if (!r.ok || r.off != len) return ZK_E_BAD_ENCODING;
-    *out_len = o.size();
-    if (!out || cap < o.size()) return ZK_E_BUFFER;
-    memcpy(out, o.data(), o.size());
+    BufSink b{dst};
+    if (!proof_text(proof, len, b)) return ZK_E_BAD_ENCODING;
+    const uint64_t n = (uint64_t)(b.q - dst);
+    *out_len = n;
+    if (!out || cap < n) return ZK_E_BUFFER;
+    if (dst != out) memcpy(out, dst, n);
     return ZK_OK;
 }
 
@@ -366,8 +520,11 @@ extern "C" zk_status zk_proof_to_json(const uint8_t* proof, uint64_t len, char* 
 static zk_status proof_from_json_impl(const char* json, uint64_t len, uint8_t* out, uint64_t cap, uint64_t* out_len) {
     if (!json || !out_len) return ZK_E_ARG;
     if (len > ZK_JSON_MAX_TEXT) return ZK_E_BAD_ENCODING;
-    Doc d;
-    d.base = json;
+    // per-thread scratch, reused from proof to proof: a fresh 1.8 MB node array per proof costs more in page faults (and, across
+    // threads, in contention on the address space) than the parse itself
+    static thread_local Doc d;
+    static thread_local std::vector<uint8_t> wbuf;
+    d.reset(json);
     d.nd.reserve((size_t)(len / 14) + 16);
     d.nd.emplace_back();
     Parser ps{json, json + len, d};
@@ -378,7 +535,8 @@ static zk_status proof_from_json_impl(const char* json, uint64_t len, uint8_t* o
     const Node* ex = d.get(root, "expProof");
     const Node* gk = d.get(root, "membershipProof");
     if (!ex || ex->t != Node::ARR || !gk || gk->t != Node::OBJ || ex->n > 128) return ZK_E_BAD_ENCODING;
-    Wr w(d);
+    Wr w(d, wbuf);
+    w.b.clear();
     w.b.reserve((size_t)(len / 3) + 64);
     w.b.resize(32, 0);
     w.pt(d.get(root, "R"), false), w.pt(d.get(root, "comS1"), false), w.pt(d.get(root, "keyXcom"), true), w.pt(d.get(root, "keyYcom"), true);
@@ -431,6 +589,137 @@ static zk_status proof_from_json_impl(const char* json, uint64_t len, uint8_t* o
 extern "C" zk_status zk_proof_from_json(const char* json, uint64_t len, uint8_t* out, uint64_t cap, uint64_t* out_len) {
     try {
         return proof_from_json_impl(json, len, out, cap, out_len);
+    } catch (...) {
+        return ZK_E_BUFFER;
+    }
+}
+
+// ---------------------------------------------------------------- whole batches, on several host threads
+// bench/zkpAttestList.bench.ts:63-68 times toJson / fromJson per proof; a GPU that makes 300 000 proofs per second needs the
+// converters at batch scale ("so the ~10 GB/batch host conversion is not the bottleneck").  Proofs are
+// converted in blocks: every thread converts whole proofs into its own scratch, a prefix sum places them, the threads copy them out.
+#include <atomic>
+#include <thread>
+static uint32_t json_threads(uint32_t want, uint64_t n) {
+    uint32_t hw = std::thread::hardware_concurrency();
+    if (const char* e = getenv("ZKATTEST_JSON_THREADS")) hw = (uint32_t)atoi(e);
+    uint32_t t = want ? want : (hw ? hw : 1);
+    if (t > 256) t = 256;
+    if (t > n) t = (uint32_t)(n ? n : 1);
+    return t;
+}
+template <class F>
+static void run_threads(uint32_t T, F f) {
+    if (T <= 1) return f(0);
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < T; t++) th.emplace_back(f, t);
+    for (auto& x : th) x.join();
+}
+// `conv(i, scratch)` converts item i into scratch (resized by it) and returns its status; items are placed back to back in out.
+template <class Conv>
+static zk_status batch_convert(uint64_t n, uint8_t* out, uint64_t cap, uint64_t* out_off, int32_t* status, uint32_t threads, Conv conv) {
+    const uint32_t T = json_threads(threads, n);
+    const uint64_t BLOCK = (uint64_t)T * 16;
+    std::vector<std::vector<uint8_t>> tmp(BLOCK);
+    uint64_t cursor = 0;
+    bool overflow = false;
+    out_off[0] = 0;
+    for (uint64_t b0 = 0; b0 < n; b0 += BLOCK) {
+        const uint64_t b1 = b0 + BLOCK < n ? b0 + BLOCK : n;
+        std::atomic<uint64_t> next(b0);
+        run_threads(T, [&](uint32_t) {
+            for (;;) {
+                uint64_t i = next.fetch_add(1);
+                if (i >= b1) break;
+                auto& v = tmp[i - b0];
+                v.clear();
+                int32_t st = ZK_E_BUFFER;
+                try {
+                    st = conv(i, v);
+                } catch (...) {
+                    st = ZK_E_BUFFER;
+                }
+                if (st) v.clear();
+                status[i] = st;
+            }
+        });
+        for (uint64_t i = b0; i < b1; i++) cursor += tmp[i - b0].size(), out_off[i + 1] = cursor;
+        if (cursor > cap || !out) overflow = true;
+        if (!overflow) {
+            next = b0;
+            run_threads(T, [&](uint32_t) {
+                for (;;) {
+                    uint64_t i = next.fetch_add(1);
+                    if (i >= b1) break;
+                    const auto& v = tmp[i - b0];
+                    if (!v.empty()) memcpy(out + out_off[i], v.data(), v.size());
+                }
+            });
+        }
+    }
+    return overflow ? ZK_E_BUFFER : ZK_OK;   // out_off[] is complete either way: out_off[n] is the size to come back with
+}
+// to JSON: the exact length of every text first (a traversal that only counts), a prefix sum, then every thread writes its proofs'
+// texts straight into their final place -- no scratch copies.
+extern "C" zk_status zk_proofs_to_json_batch(uint64_t n, const uint8_t* proofs, const uint64_t* proof_off, char* out, uint64_t out_cap, uint64_t* text_off,
+                                             int32_t* per_proof_status, uint32_t threads) {
+    if (!text_off || !per_proof_status || (n && (!proofs || !proof_off))) return ZK_E_ARG;
+    for (uint64_t i = 0; i < n; i++)
+        if (proof_off[i + 1] < proof_off[i]) return ZK_E_ARG;
+    try {
+        const uint32_t T = json_threads(threads, n);
+        std::atomic<uint64_t> next(0);
+        run_threads(T, [&](uint32_t) {
+            for (;;) {
+                uint64_t i0 = next.fetch_add(8);
+                if (i0 >= n) break;
+                for (uint64_t i = i0; i < i0 + 8 && i < n; i++) {
+                    LenSink m;
+                    const bool good = proof_text(proofs + proof_off[i], proof_off[i + 1] - proof_off[i], m);
+                    per_proof_status[i] = good ? ZK_OK : ZK_E_BAD_ENCODING;
+                    text_off[i + 1] = good ? m.n : 0;   // lengths for now
+                }
+            }
+        });
+        text_off[0] = 0;
+        for (uint64_t i = 0; i < n; i++) text_off[i + 1] += text_off[i];
+        if (!out || text_off[n] > out_cap) return n && text_off[n] ? ZK_E_BUFFER : ZK_OK;
+        next = 0;
+        run_threads(T, [&](uint32_t) {
+            for (;;) {
+                uint64_t i0 = next.fetch_add(8);
+                if (i0 >= n) break;
+                for (uint64_t i = i0; i < i0 + 8 && i < n; i++) {
+                    if (per_proof_status[i]) continue;
+                    BufSink b{out + text_off[i]};
+                    proof_text(proofs + proof_off[i], proof_off[i + 1] - proof_off[i], b);
+                }
+            }
+        });
+        return ZK_OK;
+    } catch (...) {
+        return ZK_E_BUFFER;
+    }
+}
+extern "C" zk_status zk_proofs_from_json_batch(uint64_t n, const char* texts, const uint64_t* text_off, uint8_t* out, uint64_t out_cap, uint64_t* proof_off,
+                                               int32_t* per_proof_status, uint32_t threads) {
+    if (!proof_off || !per_proof_status || (n && (!texts || !text_off))) return ZK_E_ARG;
+    for (uint64_t i = 0; i < n; i++)
+        if (text_off[i + 1] < text_off[i]) return ZK_E_ARG;
+    try {
+        return batch_convert(n, out, out_cap, proof_off, per_proof_status, threads, [&](uint64_t i, std::vector<uint8_t>& v) -> int32_t {
+            const uint64_t len = text_off[i + 1] - text_off[i];
+            v.resize((size_t)(len / 3) + 64);   // every proof byte costs at least two hex digits plus punctuation
+            uint64_t got = 0;
+            zk_status st = proof_from_json_impl(texts + text_off[i], len, v.data(), v.size(), &got);
+            if (st == ZK_E_BUFFER && got > v.size()) {
+                v.resize((size_t)got);
+                st = proof_from_json_impl(texts + text_off[i], len, v.data(), v.size(), &got);
+            }
+            if (st) return st;
+            v.resize((size_t)got);
+            return ZK_OK;
+        });
     } catch (...) {
         return ZK_E_BUFFER;
     }

@@ -10,6 +10,11 @@
 // The fixed-base tables and the per-ring table E are rebuilt locally on every device, concurrently: that is cheaper than
 // moving 47 GB of tables per device across the links.
 #include <dlfcn.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
+#include <map>
+#include <mutex>
 #include <thread>
 #include "ctx.h"
 
@@ -57,9 +62,73 @@ struct zk_pool {
     std::vector<ncclComm_t> comms;     // one per device when RCCL is in use
     bool comms_tried = false;
     const char* transport = "none";    // how the last ring reached the devices: "single", "rccl", "peer-copy"
+    // host side of a shard: the CPUs next to the device's PCIe root (sysfs local_cpulist of its bus address).  The shard's host
+    // thread runs there, and zk_pool_host_alloc has the shard's output region first-touched there, so that a device's 40 GB/s
+    // of proof bytes land in the memory of its own socket instead of crossing the inter-socket link.
+    std::vector<std::vector<int>> cpus;   // empty = unknown (no affinity is set)
+    std::vector<int> numa;                // -1 = unknown
+    bool affinity = true;                 // ZKATTEST_POOL_AFFINITY=0 switches it off
 };
 
-// runs f(i) for every device on its own host thread and returns the first non-zero status
+// "0-15,128-143" -> cpu numbers (the format of sysfs cpulist files)
+static std::vector<int> parse_cpulist(const char* s) {
+    std::vector<int> v;
+    while (*s) {
+        char* e;
+        long a = strtol(s, &e, 10);
+        if (e == s) break;
+        long b = a;
+        if (*e == '-') {
+            const char* q = e + 1;
+            b = strtol(q, &e, 10);
+            if (e == q) break;
+        }
+        for (long c = a; c <= b && c < 4096 && v.size() < 4096; c++) v.push_back((int)c);
+        s = *e == ',' ? e + 1 : e;
+        if (*e != ',') break;
+    }
+    return v;
+}
+static bool read_small_file(const std::string& path, char* buf, size_t cap) {
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    size_t n = fread(buf, 1, cap - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    return n > 0;
+}
+// PCI bus address of a device -> its NUMA node and local CPUs (ZKATTEST_SYSFS_ROOT lets the CPU tests point this at a fake tree)
+static void locality_of_bus(const char* busid, int* numa, std::vector<int>* cpus) {
+    *numa = -1;
+    cpus->clear();
+    const char* root = getenv("ZKATTEST_SYSFS_ROOT");
+    std::string dir = std::string(root ? root : "/sys") + "/bus/pci/devices/";
+    std::string id(busid);
+    for (auto& ch : id) ch = (char)tolower(ch);
+    char buf[4096];
+    if (read_small_file(dir + id + "/numa_node", buf, sizeof buf)) *numa = atoi(buf);
+    if (read_small_file(dir + id + "/local_cpulist", buf, sizeof buf)) *cpus = parse_cpulist(buf);
+}
+// test hook (tests/test_abi_and_host.py): the parsing above without a GPU.  Returns the number of CPUs, fills up to cap of them.
+extern "C" int zk_pool_test_locality(const char* busid, int* numa, int* cpus, int cap) {
+    std::vector<int> v;
+    int nn = -1;
+    locality_of_bus(busid, &nn, &v);
+    if (numa) *numa = nn;
+    for (int i = 0; i < (int)v.size() && i < cap; i++) cpus[i] = v[i];
+    return (int)v.size();
+}
+static void bind_thread_to(const std::vector<int>& cpus) {
+    if (cpus.empty()) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int c : cpus)
+        if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
+    (void)sched_setaffinity(0, sizeof set, &set);   // best effort: a cgroup that does not own these CPUs refuses, and that is fine
+}
+
+// runs f(i) for every device on its own host thread (bound to the device's local CPUs when they are known) and returns the
+// first non-zero status
 template <class F>
 static zk_status pool_each(zk_pool* p, F f) {
     const int G = (int)p->ctx.size();
@@ -68,7 +137,11 @@ static zk_status pool_each(zk_pool* p, F f) {
         st[0] = f(0);
     } else {
         std::vector<std::thread> th;
-        for (int i = 0; i < G; i++) th.emplace_back([&, i] { st[i] = f(i); });
+        for (int i = 0; i < G; i++)
+            th.emplace_back([&, i] {
+                if (p->affinity && i < (int)p->cpus.size()) bind_thread_to(p->cpus[i]);
+                st[i] = f(i);
+            });
         for (auto& t : th) t.join();
     }
     for (int i = 0; i < G; i++)
@@ -81,13 +154,40 @@ static zk_status pool_each(zk_pool* p, F f) {
     return ZK_OK;
 }
 
+static thread_local std::string g_pool_create_err;   // why the last zk_pool_create of this thread failed (zk_pool_last_error(NULL))
 extern "C" zk_status zk_pool_create(const int* device_ids, int n_dev, zk_pool** out) {
-    if (!out || !device_ids || n_dev < 1 || n_dev > 64) return ZK_E_ARG;
+    if (!out) return ZK_E_ARG;
+    *out = nullptr;   // a caller never sees a half-built pool: either every context exists or *out stays NULL
+    if (!device_ids || n_dev < 1 || n_dev > 64) return ZK_E_ARG;
     zk_pool* p = new zk_pool();
-    *out = p;
     p->ctx.assign(n_dev, nullptr);
     p->dev.assign(device_ids, device_ids + n_dev);
-    return pool_each(p, [&](int i) { return zk_ctx_create(p->dev[i], &p->ctx[i]); });   // the generator tables are built concurrently
+    p->cpus.assign(n_dev, {});
+    p->numa.assign(n_dev, -1);
+    if (const char* e = getenv("ZKATTEST_POOL_AFFINITY")) p->affinity = atoi(e) != 0;
+    for (int i = 0; i < n_dev; i++) {
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, sizeof bus, p->dev[i]) == hipSuccess) locality_of_bus(bus, &p->numa[i], &p->cpus[i]);
+        else (void)hipGetLastError();
+    }
+    std::vector<std::string> why(n_dev);   // zk_last_error(NULL) is per thread: read it on the thread that created the context
+    zk_status zs = pool_each(p, [&](int i) {   // the generator tables are built concurrently
+        zk_status s = zk_ctx_create(p->dev[i], &p->ctx[i]);
+        if (s) why[i] = zk_last_error(nullptr);
+        return s;
+    });
+    if (zs) {
+        g_pool_create_err = p->err;
+        for (int i = 0; i < n_dev; i++)
+            if (!why[i].empty()) {
+                g_pool_create_err += why[i];
+                break;
+            }
+        zk_pool_destroy(p);
+        return zs;
+    }
+    *out = p;
+    return ZK_OK;
 }
 extern "C" void zk_pool_destroy(zk_pool* p) {
     if (!p) return;
@@ -98,7 +198,61 @@ extern "C" void zk_pool_destroy(zk_pool* p) {
 }
 extern "C" int zk_pool_size(const zk_pool* p) { return p ? (int)p->ctx.size() : 0; }
 extern "C" zk_ctx* zk_pool_ctx(zk_pool* p, int i) { return p && i >= 0 && i < (int)p->ctx.size() ? p->ctx[i] : nullptr; }
-extern "C" const char* zk_pool_last_error(const zk_pool* p) { return p ? p->err.c_str() : ""; }
+extern "C" const char* zk_pool_last_error(const zk_pool* p) { return p ? p->err.c_str() : g_pool_create_err.c_str(); }
+extern "C" int zk_pool_numa_node(const zk_pool* p, int i) { return p && i >= 0 && i < (int)p->numa.size() ? p->numa[i] : -1; }
+
+// ---- page-locked output buffer of a pool call with per-shard placement.  zk_pool_prove_batch gives shard i the region
+// [i * R, (i + 1) * R), R = (bytes / G) & ~255: the pages of region i are first touched by a thread bound to the CPUs of device
+// i's socket (the kernel's default policy then places them on that node) and the whole range is page-locked afterwards, so
+// every device's DMA writes stay on its own side of the machine.  Falls back to plain zk_host_alloc behaviour when the
+// locality is unknown.  Free with zk_pool_host_free (NOT zk_host_free).
+static std::mutex g_regs_mu;
+static std::map<void*, size_t> g_regs;
+extern "C" void* zk_pool_host_alloc(zk_pool* p, size_t bytes) {
+    if (!p || !bytes) return nullptr;
+    const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+    const size_t len = (bytes + page - 1) / page * page;
+    void* mem = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (mem == MAP_FAILED) return nullptr;
+    (void)madvise(mem, len, MADV_HUGEPAGE);
+    const size_t G = p->ctx.size(), region = (bytes / G) & ~(size_t)255;
+    auto touch = [&](size_t a, size_t b) {   // one write per page of [a, b)
+        volatile uint8_t* q = (volatile uint8_t*)mem;
+        for (size_t o = a / page * page; o < b; o += page) q[o] = 0;
+    };
+    if (G == 1 || !p->affinity) {
+        touch(0, len);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < G; i++)
+            th.emplace_back([&, i] {
+                bind_thread_to(p->cpus[i]);
+                touch(i * region, i + 1 == G ? len : (i + 1) * region);
+            });
+        for (auto& t : th) t.join();
+    }
+    if (hipHostRegister(mem, len, hipHostRegisterPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        munmap(mem, len);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> g(g_regs_mu);
+    g_regs[mem] = len;
+    return mem;
+}
+extern "C" void zk_pool_host_free(void* mem) {
+    if (!mem) return;
+    size_t len = 0;
+    {
+        std::lock_guard<std::mutex> g(g_regs_mu);
+        auto it = g_regs.find(mem);
+        if (it == g_regs.end()) return;
+        len = it->second;
+        g_regs.erase(it);
+    }
+    (void)hipHostUnregister(mem);
+    munmap(mem, len);
+}
 extern "C" const char* zk_pool_ring_transport(const zk_pool* p) { return p ? p->transport : ""; }
 
 extern "C" void zk_pool_shard(const zk_pool* p, uint64_t B, int i, uint64_t* first, uint64_t* count) {
@@ -118,12 +272,15 @@ extern "C" zk_status zk_pool_set_ring(zk_pool* p, const uint8_t* keys, uint64_t 
     const int G = (int)p->ctx.size();
     const size_t bytes = 32 * (size_t)nkeys;
     std::vector<void*> d(G, nullptr);
+    int dev_at_entry = -1;   // the calling thread's current device is restored on every exit path
+    if (hipGetDevice(&dev_at_entry) != hipSuccess) dev_at_entry = -1, (void)hipGetLastError();
     auto release = [&] {
         for (int i = 0; i < G; i++)
             if (d[i]) {
                 hipSetDevice(p->dev[i]);
                 hipFree(d[i]);
             }
+        if (dev_at_entry >= 0) hipSetDevice(dev_at_entry);
     };
     auto fail = [&](const char* what, hipError_t e) {
         p->err = std::string(what) + ": " + hipGetErrorString(e);
@@ -157,7 +314,7 @@ extern "C" zk_status zk_pool_set_ring(zk_pool* p, const uint8_t* keys, uint64_t 
                 hipSetDevice(p->dev[i]);
                 r = p->rccl.Broadcast(d[i], d[i], bytes, kNcclUint8, 0, p->comms[i], p->ctx[i]->stream);   // in place; only the root's buffer is read
             }
-            ncclResult_t r2 = p->rccl.GroupEnd();
+            ncclResult_t r2 = p->rccl.GroupEnd();   // closes the group also when a Broadcast was refused (its status is then an error too)
             if (r == 0 && r2 == 0) {
                 done = true;
                 for (int i = 0; i < G; i++) {
@@ -166,6 +323,12 @@ extern "C" zk_status zk_pool_set_ring(zk_pool* p, const uint8_t* keys, uint64_t 
                 }
             }
             if (done) p->transport = "rccl";
+            else {   // communicators that failed once are not trusted again: this and every later ring go by peer copies
+                (void)hipGetLastError();
+                for (auto cm : p->comms)
+                    if (cm) p->rccl.CommDestroy(cm);
+                p->comms.clear();
+            }
         }
         if (!done) {   // device-to-device copies (xGMI where the devices are peers)
             for (int i = 1; i < G; i++) {

@@ -1,5 +1,6 @@
 // zk_verify_batch / zk_verify_batch_device: host-side phase pipeline of the verifier (kernels in k_verify.hip).
 #include "ctx.h"
+#include "jobs.h"
 
 static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, uint32_t C, uint32_t sec, uint32_t n, uint64_t N) {
     Carver k(base);
@@ -60,7 +61,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
     res2 = k.soa((size_t)C * std::max<uint64_t>(1, (N >> T) / 512));
     return k.off + 256;
 }
-static zk_status ensure_vworkspace(zk_ctx* c, uint32_t C, uint32_t nlanes) {
+zk_status ensure_vworkspace(zk_ctx* c, uint32_t C, uint32_t nlanes) {
     uint32_t sec = c->P.sec, n = c->n;
     if (!(c->vs_C == C && c->vs_sec == sec && c->vs_n == n)) {
         for (auto& L : c->vl) L.ready = false;
@@ -108,203 +109,220 @@ __global__ void k_default_vseeds(uint64_t B, const uint8_t* master, uint8_t* out
     for (int i = 0; i < 8; i++) ((uint32_t*)out)[8 * b + i] = bswap32(h[i]);
 }
 
-// host_src / host_off: page-locked source of the proof bytes and the host copy of the offsets (or nullptr): the bytes of chunk k
-// travel on c->copy_stream while earlier chunks are being verified; the chunk's lane waits for its own copy only.
+zk_status VerifyJob::enqueue_h2d() {
+    if (!host_src) return ZK_OK;
+    const uint64_t nchunks = plan.size();
+    arrived.assign(nchunks, nullptr);
+    for (uint64_t k = 0; k < nchunks; k++) {
+        uint64_t b0 = host_off[plan[k].first], b1 = host_off[plan[k].first + plan[k].cnt];
+        if (hipEventCreateWithFlags(&arrived[k], hipEventDisableTiming) != hipSuccess ||
+            (b1 > b0 && hipMemcpyAsync((uint8_t*)d_proofs + b0, host_src + b0, b1 - b0, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess) ||
+            hipEventRecord(arrived[k], c->copy_stream) != hipSuccess) {
+            c->err = "host-to-device copy of the proofs failed";
+            return ZK_E_DEVICE;
+        }
+    }
+    return ZK_OK;
+}
+// Stage 1 (everything up to the term lists) of chunk k+1 is enqueued on the other stream before the host blocks on the
+// batched Tom check of chunk k (k_msm.hip reads counters and the verdict back), so neither stream runs dry.
+zk_status VerifyJob::stage1(uint64_t chunk_no) {
+    const DevParams& P = c->P;
+    const uint64_t first = plan[chunk_no].first;
+    const uint32_t cnt = plan[chunk_no].cnt;
+    const uint32_t lane = lane_of(chunk_no);
+    Workspace& W = c->pl[lane].W;
+    VWork& V = c->vl[lane].V;
+    hipStream_t s = c->pl[lane].stream;
+    const Soa& vres = c->vl[lane].res;
+    const Soa& vres2 = c->vl[lane].res2;
+    if (inputs_ready) HIPCHK(c, hipStreamWaitEvent(s, inputs_ready, 0));
+    if (host_src && hipStreamWaitEvent(s, arrived[chunk_no], 0) != hipSuccess) {
+        c->err = "hipStreamWaitEvent failed";
+        return ZK_E_DEVICE;
+    }
+    {
+        MaybeScope t(timed, c, "v_parse_validate", s);
+        launch_v_header_validate(s, V, cnt, d_proofs, d_off, first);
+    }
+    {
+        MaybeScope t(timed, c, "v_p256_front_rtab", s);
+        launch_v_front(s, P, W, V, cnt, d_proofs, d_off, d_msg, first);
+        launch_rtab(s, W, cnt, RTAB_VERIFY_BITS);
+    }
+    {
+        MaybeScope t(timed, c, "v_hash", s);
+        launch_v_challenges_sample(s, V, cnt, d_proofs, d_off, d_vseeds, d_msg, first);
+    }
+    {
+        MaybeScope t(timed, c, "v_p256_exp_points", s);
+        launch_v_exp_points(s, W, V, cnt, d_proofs, d_off, first);
+        launch_p256_normalize(s, W.Tproj, cnt * VK, W.Tx, W.Ty, W.st, VK, ZK_E_T_INF, nullptr);
+    }
+    {
+        MaybeScope t(timed, c, "v_tom_fixed", s);
+        launch_v_t1_scalars(s, W, V, cnt, d_proofs, d_off, first);
+        launch_tom_commit(s, P, W.la, cnt * 2 * VK, 2 * VK, 2 + 2 * W.sec);
+        launch_tom_normalize(s, W.la, cnt * 2 * VK, 0, 2 * VK, 2 + 2 * W.sec);
+        launch_v_derived(s, W, V, cnt, d_proofs, d_off, first);
+        launch_tom_normalize(s, V.vd, cnt * VK * 5, 0, 1, 1);
+    }
+    {
+        MaybeScope t(timed, c, "v_hash", s);
+        launch_v_padd_hash(s, P, W, V, cnt, d_proofs, d_off, first);
+    }
+    {
+        MaybeScope t(timed, c, "v_gk_total", s);
+        launch_v_gk_total(s, V, W.ring, W.gk_etab, cnt, W.N, d_proofs, d_off, first, vres, vres2);
+    }
+    {
+        MaybeScope t(timed, c, "v_terms", s);
+        launch_v_terms(s, W, V, cnt, d_proofs, d_off, d_vseeds, first);
+    }
+    {
+        MaybeScope t(timed, c, "v_straus_p256", s);
+        launch_v_p256_straus(s, V, cnt);
+    }
+    return ZK_OK;
+}
+// Per-proof sums (windowed Straus + the two fixed-base commitments) of proofs [p0, p1) of a chunk: the unchanged kernels on
+// views of the term lists / accumulators that start at the range's first slot, gk group and proof.
+static void per_proof_range(zk_ctx* c, bool timed, hipStream_t s, const Workspace& W, const VWork& V, uint32_t p0, uint32_t p1, uint32_t range_no, uint32_t tsplit) {
+    const DevParams& P = c->P;
+    const uint32_t nq = (c->n + 1) / 2;
+    const uint32_t np = p1 - p0;
+    auto terms_at = [](VTerms t, size_t o) {
+        t.nx.p += o, t.ny.p += o, t.ndt.p += o, t.sc.p += o, t.tab += o * 8 * 36, t.dig += o;
+        return t;
+    };
+    auto acc_at = [](Soa4 a, size_t o) {
+        a.x.p += o, a.y.p += o, a.z.p += o, a.t.p += o;
+        return a;
+    };
+    {
+        MaybeScope t(timed, c, "v_straus_tom", s);
+        const size_t so = (size_t)p0 * VK;
+        uint32_t* perm = V.slot_perm + so;
+        uint32_t* pc = V.slot_cnt + 2 * range_no;
+        launch_v_slot_perm(s, V.slot_class + so, np * VK, perm, pc);
+        launch_v_straus(s, terms_at(V.slot_terms, so), np * VK, V.C * VK, 10, 26, acc_at(V.slot_acc, so * V_SLOT_SPLIT), perm, pc, tsplit, V_SLOT_SPLIT);
+        launch_v_straus(s, terms_at(V.gk_terms, (size_t)p0 * nq), np * nq, V.C * nq, 4, 4, acc_at(V.gk_acc, (size_t)p0 * nq), nullptr, nullptr);
+        for (uint32_t k = 0; k < 3; k++)
+            launch_v_straus(s, terms_at(V.misc_terms, (size_t)k * V.C + p0), np, 3 * V.C, 1, 0, acc_at(V.misc_acc, (size_t)k * V.C + p0), nullptr, nullptr);
+    }
+    {
+        MaybeScope t(timed, c, "v_tom_fixed", s);
+        TomList lc = W.lc;
+        const size_t o = (size_t)p0 * 4 * W.n;
+        for (Soa* a : {&lc.v, &lc.r, &lc.proj.x, &lc.proj.y, &lc.proj.z, &lc.ax, &lc.ay}) a->p += o;
+        launch_tom_commit(s, P, lc, np * 2, 2, 4 * W.n);
+    }
+}
+zk_status VerifyJob::stage2(uint64_t chunk_no) {
+    const DevParams& P = c->P;
+    const uint64_t first = plan[chunk_no].first;
+    const uint32_t cnt = plan[chunk_no].cnt;
+    const uint32_t lane = lane_of(chunk_no);
+    const uint32_t nq = (c->n + 1) / 2;
+    Workspace& W = c->pl[lane].W;
+    VWork& V = c->vl[lane].V;
+    const MsmBuf& M = c->vl[lane].M;
+    hipStream_t s = c->pl[lane].stream;
+    // Tom-256 relations: one bucket-method sum per group of the chunk's proofs (MSM_G groups, one pass); the per-proof
+    // windowed sums only run for the groups whose total is not the identity -- some proof of theirs is bad -- to tell which
+    uint32_t flags[MSM_G], gsz = cnt;
+    if (c->verify_batch_min && cnt >= c->verify_batch_min) {
+        MaybeScope t(timed, c, "v_msm_tom", s);
+        hipError_t e = run_msm(s, P, W, V, cnt, nq, M, flags, &gsz);
+        if (e != hipSuccess) {
+            c->err = std::string("batched verification failed: ") + hipGetErrorString(e);
+            return ZK_E_DEVICE;
+        }
+    } else {
+        for (auto& f : flags) f = 0;   // every proof goes through the per-proof sums
+    }
+    uint32_t ranges = 0;
+    VGroupFlags gf;
+    for (uint32_t g = 0; g < MSM_G; g++) gf.v[g] = 1;
+    for (uint32_t g = 0; g < MSM_G && (uint64_t)g * gsz < cnt;) {   // maximal runs of groups that failed
+        if (flags[g]) {
+            g++;
+            continue;
+        }
+        uint32_t g1 = g;
+        while (g1 < MSM_G && (uint64_t)g1 * gsz < cnt && !flags[g1]) g1++;
+        const uint32_t p0 = g * gsz, p1 = std::min<uint32_t>(cnt, g1 * gsz);
+        // few slots: a slot's 36 terms over 4 lanes (the chain of one lane is ~12 ms long, the GPU is far from full)
+        const uint32_t tsplit = (uint64_t)(p1 - p0) * VK * V_SLOT_SPLIT <= 524288 ? V_SLOT_SPLIT : 1;   // up to two residencies of the GPU (4 waves per SIMD, 262 144 lanes)
+        per_proof_range(c, timed, s, W, V, p0, p1, ranges++, tsplit);
+        c->dbg_recheck_proofs += p1 - p0;
+        for (uint32_t k = g; k < g1; k++) gf.v[k] = V_RECHECK | tsplit;
+        g = g1;
+    }
+    {
+        MaybeScope t(timed, c, "v_final", s);
+        launch_v_final(s, P, W, V, cnt, d_ok, d_status, first, gf, gsz);
+    }
+    return ZK_OK;
+}
+
+// verifier seeds when the caller supplies none: derived on the device from 32 bytes of OS randomness drawn for this call
+zk_status make_default_vseeds(zk_ctx* c, uint64_t B, uint8_t* d_seeds /* 32 * B + 32 bytes */, hipStream_t s) {
+    uint8_t master[32];
+    if (!os_random(master, sizeof master)) {
+        c->err = "no OS randomness for the verifier (getrandom / /dev/urandom failed)";
+        return ZK_E_DEVICE;
+    }
+    HIPCHK(c, hipMemcpyAsync(d_seeds + 32 * B, master, 32, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_default_vseeds, dim3((uint32_t)((B + 255) / 256)), dim3(256), 0, s, B, d_seeds + 32 * B, d_seeds);
+    HIPCHK(c, hipStreamSynchronize(s));
+    return ZK_OK;
+}
+
 static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const uint8_t* d_proofs, const uint64_t* d_off, const uint8_t* d_vseeds, uint8_t* d_ok,
                                int32_t* d_status, const uint8_t* host_src = nullptr, const uint64_t* host_off = nullptr) {
     if (!c->params_set || !c->N) return ZK_E_BUFFER;
     if (c->P.sec < VK) return ZK_E_SECLEVEL;
     if (B == 0) return ZK_OK;
-    uint32_t C = (uint32_t)std::min<uint64_t>(c->chunk, B);
-    const std::vector<ChunkPlan> plan = make_chunk_plan(B, C, 1, false);   // uniform: see ctx.h
-    const uint32_t NL = (uint32_t)std::min<size_t>(c->lanes, plan.size());   // chunks rotate over NL streams / workspaces
-    zk_status zs = ensure_workspace(c, C, NL);
+    if (c->stream_busy) {
+        c->err = "streamed jobs are in flight on this context (zk_prove_wait / zk_verify_wait them first)";
+        return ZK_E_ARG;
+    }
+    VerifyJob J;
+    J.c = c, J.B = B, J.d_msg = d_msg, J.d_proofs = d_proofs, J.d_off = d_off, J.d_ok = d_ok, J.d_status = d_status, J.host_src = host_src, J.host_off = host_off;
+    J.C = (uint32_t)std::min<uint64_t>(c->chunk, B);
+    J.plan = make_chunk_plan(B, J.C, 1, false);   // uniform: see ctx.h
+    J.NL = (uint32_t)std::min<size_t>(c->lanes, J.plan.size());   // chunks rotate over NL streams / workspaces
+    zk_status zs = ensure_workspace(c, J.C, J.NL);
     if (zs) return zs;
-    zs = ensure_vworkspace(c, C, NL);
+    zs = ensure_vworkspace(c, J.C, J.NL);
     if (zs) return zs;
-    const DevParams& P = c->P;
     timing_begin(c);
     DevBuf own_seeds_buf;   // released on every exit path
     if (!d_vseeds) {
-        uint8_t master[32];
-        if (!os_random(master, sizeof master)) {
-            c->err = "no OS randomness for the verifier (getrandom / /dev/urandom failed)";
-            return ZK_E_DEVICE;
-        }
         HIPCHK(c, hipMalloc(&own_seeds_buf.p, 32 * B + 32));
-        uint8_t* own_seeds = own_seeds_buf.as<uint8_t>();
-        HIPCHK(c, hipMemcpyAsync(own_seeds + 32 * B, master, 32, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_default_vseeds, dim3((uint32_t)((B + 255) / 256)), dim3(256), 0, c->stream, B, own_seeds + 32 * B, own_seeds);
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        d_vseeds = own_seeds;
+        zs = make_default_vseeds(c, B, own_seeds_buf.as<uint8_t>(), c->stream);
+        if (zs) return zs;
+        d_vseeds = own_seeds_buf.as<uint8_t>();
     }
-    const uint32_t nq = (c->n + 1) / 2;
-    // Stage 1 (everything up to the term lists) of chunk k+1 is enqueued on the other stream before the host blocks on the
-    // batched Tom check of chunk k (k_msm.hip reads counters and the verdict back), so neither stream runs dry.
-    auto stage1 = [&](uint64_t first, uint32_t cnt, uint32_t chunk_no) -> zk_status {
-        const uint32_t lane = chunk_no % NL;
-        Workspace& W = c->pl[lane].W;
-        VWork& V = c->vl[lane].V;
-        hipStream_t s = c->pl[lane].stream;
-        const Soa& vres = c->vl[lane].res;
-        const Soa& vres2 = c->vl[lane].res2;
-        {
-            Scope t(c, "v_parse_validate", s);
-            launch_v_header_validate(s, V, cnt, d_proofs, d_off, first);
-        }
-        {
-            Scope t(c, "v_p256_front_rtab", s);
-            launch_v_front(s, P, W, V, cnt, d_proofs, d_off, d_msg, first);
-            launch_rtab(s, W, cnt, RTAB_VERIFY_BITS);
-        }
-        {
-            Scope t(c, "v_hash", s);
-            launch_v_challenges_sample(s, V, cnt, d_proofs, d_off, d_vseeds, d_msg, first);
-        }
-        {
-            Scope t(c, "v_p256_exp_points", s);
-            launch_v_exp_points(s, W, V, cnt, d_proofs, d_off, first);
-            launch_p256_normalize(s, W.Tproj, cnt * VK, W.Tx, W.Ty, W.st, VK, ZK_E_T_INF, nullptr);
-        }
-        {
-            Scope t(c, "v_tom_fixed", s);
-            launch_v_t1_scalars(s, W, V, cnt, d_proofs, d_off, first);
-            launch_tom_commit(s, P, W.la, cnt * 2 * VK, 2 * VK, 2 + 2 * W.sec);
-            launch_tom_normalize(s, W.la, cnt * 2 * VK, 0, 2 * VK, 2 + 2 * W.sec);
-            launch_v_derived(s, W, V, cnt, d_proofs, d_off, first);
-            launch_tom_normalize(s, V.vd, cnt * VK * 5, 0, 1, 1);
-        }
-        {
-            Scope t(c, "v_hash", s);
-            launch_v_padd_hash(s, P, W, V, cnt, d_proofs, d_off, first);
-        }
-        {
-            Scope t(c, "v_gk_total", s);
-            launch_v_gk_total(s, V, W.ring, W.gk_etab, cnt, W.N, d_proofs, d_off, first, vres, vres2);
-        }
-        {
-            Scope t(c, "v_terms", s);
-            launch_v_terms(s, W, V, cnt, d_proofs, d_off, d_vseeds, first);
-        }
-        {
-            Scope t(c, "v_straus_p256", s);
-            launch_v_p256_straus(s, V, cnt);
-        }
-        return ZK_OK;
-    };
-    // Per-proof sums (windowed Straus + the two fixed-base commitments) of proofs [p0, p1) of a chunk: the unchanged kernels on
-    // views of the term lists / accumulators that start at the range's first slot, gk group and proof.
-    auto per_proof_range = [&](hipStream_t s, const Workspace& W, const VWork& V, uint32_t p0, uint32_t p1, uint32_t range_no, uint32_t tsplit) {
-        const uint32_t np = p1 - p0;
-        auto terms_at = [](VTerms t, size_t o) {
-            t.nx.p += o, t.ny.p += o, t.ndt.p += o, t.sc.p += o, t.tab += o * 8 * 36, t.dig += o;
-            return t;
-        };
-        auto acc_at = [](Soa4 a, size_t o) {
-            a.x.p += o, a.y.p += o, a.z.p += o, a.t.p += o;
-            return a;
-        };
-        {
-            Scope t(c, "v_straus_tom", s);
-            const size_t so = (size_t)p0 * VK;
-            uint32_t* perm = V.slot_perm + so;
-            uint32_t* pc = V.slot_cnt + 2 * range_no;
-            launch_v_slot_perm(s, V.slot_class + so, np * VK, perm, pc);
-            launch_v_straus(s, terms_at(V.slot_terms, so), np * VK, V.C * VK, 10, 26, acc_at(V.slot_acc, so * V_SLOT_SPLIT), perm, pc, tsplit, V_SLOT_SPLIT);
-            launch_v_straus(s, terms_at(V.gk_terms, (size_t)p0 * nq), np * nq, V.C * nq, 4, 4, acc_at(V.gk_acc, (size_t)p0 * nq), nullptr, nullptr);
-            for (uint32_t k = 0; k < 3; k++)
-                launch_v_straus(s, terms_at(V.misc_terms, (size_t)k * V.C + p0), np, 3 * V.C, 1, 0, acc_at(V.misc_acc, (size_t)k * V.C + p0), nullptr, nullptr);
-        }
-        {
-            Scope t(c, "v_tom_fixed", s);
-            TomList lc = W.lc;
-            const size_t o = (size_t)p0 * 4 * W.n;
-            for (Soa* a : {&lc.v, &lc.r, &lc.proj.x, &lc.proj.y, &lc.proj.z, &lc.ax, &lc.ay}) a->p += o;
-            launch_tom_commit(s, P, lc, np * 2, 2, 4 * W.n);
-        }
-    };
-    auto stage2 = [&](uint64_t first, uint32_t cnt, uint32_t chunk_no) -> zk_status {
-        const uint32_t lane = chunk_no % NL;
-        Workspace& W = c->pl[lane].W;
-        VWork& V = c->vl[lane].V;
-        const MsmBuf& M = c->vl[lane].M;
-        hipStream_t s = c->pl[lane].stream;
-        // Tom-256 relations: one bucket-method sum per group of the chunk's proofs (MSM_G groups, one pass); the per-proof
-        // windowed sums only run for the groups whose total is not the identity -- some proof of theirs is bad -- to tell which
-        uint32_t flags[MSM_G], gsz = cnt;
-        if (c->verify_batch_min && cnt >= c->verify_batch_min) {
-            Scope t(c, "v_msm_tom", s);
-            hipError_t e = run_msm(s, P, W, V, cnt, nq, M, flags, &gsz);
-            if (e != hipSuccess) {
-                c->err = std::string("batched verification failed: ") + hipGetErrorString(e);
-                return ZK_E_DEVICE;
-            }
-        } else {
-            for (auto& f : flags) f = 0;   // every proof goes through the per-proof sums
-        }
-        uint32_t ranges = 0;
-        VGroupFlags gf;
-        for (uint32_t g = 0; g < MSM_G; g++) gf.v[g] = 1;
-        for (uint32_t g = 0; g < MSM_G && (uint64_t)g * gsz < cnt;) {   // maximal runs of groups that failed
-            if (flags[g]) {
-                g++;
-                continue;
-            }
-            uint32_t g1 = g;
-            while (g1 < MSM_G && (uint64_t)g1 * gsz < cnt && !flags[g1]) g1++;
-            const uint32_t p0 = g * gsz, p1 = std::min<uint32_t>(cnt, g1 * gsz);
-            // few slots: a slot's 36 terms over 4 lanes (the chain of one lane is ~12 ms long, the GPU is far from full)
-            const uint32_t tsplit = (uint64_t)(p1 - p0) * VK * V_SLOT_SPLIT <= 524288 ? V_SLOT_SPLIT : 1;   // up to two residencies of the GPU (4 waves per SIMD, 262 144 lanes)
-            per_proof_range(s, W, V, p0, p1, ranges++, tsplit);
-            for (uint32_t k = g; k < g1; k++) gf.v[k] = V_RECHECK | tsplit;
-            g = g1;
-        }
-        {
-            Scope t(c, "v_final", s);
-            launch_v_final(s, P, W, V, cnt, d_ok, d_status, first, gf, gsz);
-        }
-        return ZK_OK;
-    };
-    const uint64_t nchunks = plan.size();
-    struct Events {   // host_src: one event per chunk, recorded on the copy stream behind the chunk's bytes
-        std::vector<hipEvent_t> ev;
-        ~Events() {
-            for (auto e : ev)
-                if (e) hipEventDestroy(e);
-        }
-    } arrived;
+    J.d_vseeds = d_vseeds;
     auto drain = [&] {   // nothing of this call may still be running when it returns
-        for (uint32_t l = 0; l < NL; l++) hipStreamSynchronize(c->pl[l].stream);
+        for (uint32_t l = 0; l < J.NL; l++) hipStreamSynchronize(c->pl[l].stream);
         if (host_src) hipStreamSynchronize(c->copy_stream);
     };
-    if (host_src) {
-        arrived.ev.resize(nchunks, nullptr);
-        for (uint64_t k = 0; k < nchunks; k++) {
-            uint64_t b0 = host_off[plan[k].first], b1 = host_off[plan[k].first + plan[k].cnt];
-            if (hipEventCreateWithFlags(&arrived.ev[k], hipEventDisableTiming) != hipSuccess ||
-                (b1 > b0 && hipMemcpyAsync((uint8_t*)d_proofs + b0, host_src + b0, b1 - b0, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess) ||
-                hipEventRecord(arrived.ev[k], c->copy_stream) != hipSuccess) {
-                c->err = "host-to-device copy of the proofs failed";
-                drain();
-                return ZK_E_DEVICE;
-            }
-        }
+    zs = J.enqueue_h2d();
+    if (zs) {
+        drain();
+        return zs;
     }
-    auto stage1w = [&](uint64_t k) -> zk_status {
-        if (host_src && hipStreamWaitEvent(c->pl[k % NL].stream, arrived.ev[k], 0) != hipSuccess) {
-            c->err = "hipStreamWaitEvent failed";
-            return ZK_E_DEVICE;
-        }
-        return stage1(plan[k].first, plan[k].cnt, (uint32_t)k);
-    };
+    const uint64_t nchunks = J.plan.size();
     // stage 1 of the next NL - 1 chunks is enqueued on the other lanes before the host blocks on this chunk's batched check
-    uint64_t next_s1 = 0;
     for (uint64_t k = 0; k < nchunks && !zs; k++) {
-        while (!zs && next_s1 < nchunks && next_s1 < k + NL) zs = stage1w(next_s1++);
-        if (!zs) zs = stage2(plan[k].first, plan[k].cnt, (uint32_t)k);
+        while (!zs && J.next_s1 < nchunks && J.next_s1 < k + J.NL) zs = J.stage1(J.next_s1++);
+        if (!zs) zs = J.stage2(k);
     }
     hipError_t e1 = hipSuccess;
-    for (uint32_t l = 0; l < NL; l++) {
+    for (uint32_t l = 0; l < J.NL; l++) {
         hipError_t e = hipStreamSynchronize(c->pl[l].stream);
         if (e1 == hipSuccess) e1 = e;
     }
@@ -329,6 +347,10 @@ extern "C" zk_status zk_verify_batch(zk_ctx* c, uint64_t B, const uint8_t* msg, 
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->params_set || !c->N) return ZK_E_BUFFER;
     if (B == 0) return ZK_OK;
+    if (c->stream_busy) {
+        c->err = "streamed jobs are in flight on this context (zk_prove_wait / zk_verify_wait them first)";
+        return ZK_E_ARG;
+    }
     if (off[0] != 0) return ZK_E_ARG;
     for (uint64_t b = 0; b < B; b++)
         if (off[b + 1] < off[b]) return ZK_E_ARG;  // every proof lies inside [0, off[B])

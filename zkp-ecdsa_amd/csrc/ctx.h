@@ -75,6 +75,18 @@ struct zk_ctx {
     size_t in_bytes = 0;           // offsets, statuses, verdicts), grow-only for the same reason
     uint32_t host_taper = 1;       // host-pointer calls on page-locked buffers: tapered chunk plan (zk_ctx_set_host_taper)
     uint32_t slice = 0;            // proofs per PointAdd slice of the prover (zk_ctx_set_slice): 0 = 4096 with a page-locked sink, else none
+    // streamed calls (api_stream.hip): jobs submitted and not yet waited for, in submission order
+    bool stream_busy = false;
+    std::vector<struct zk_job*> jobs;
+    uint64_t next_lane_base = 0;       // global chunk number of the next job's first chunk (lanes rotate across jobs)
+    hipStream_t fin_stream = nullptr;  // collects a job's results (offsets, statuses, verdicts) behind its last kernels and copies
+    struct Spare {                     // buffers of finished jobs, reused by the next ones (grow-only, like io_buf)
+        void* p;
+        size_t bytes;
+    };
+    std::vector<Spare> spare_dev, spare_pinned;
+    // unit-test counters (zk_test_counter): work done, so that tests can assert on counts instead of timings
+    uint64_t dbg_recheck_proofs = 0;   // proofs that went through the verifier's per-proof sums since the context was created
     // timing
     std::vector<TimerRec> trecs;
     std::vector<hipEvent_t> epool;
