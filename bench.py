@@ -51,6 +51,7 @@ TOM_COMMIT_BYTES = 2 * 36 + 3 * 36  # algorithmic HBM bytes per commitment: read
 # tables): 2 x 1251 B fetched (gfx950 tallies 16-byte-per-lane loads at half their bytes, MI355X_MICROARCH.md section HBM;
 # 20.3 gathers x 128 B = 2600 B expected) + 112 B written.  16 bits (112-byte entries, 235 MB; round-1 pass): 3238 B (raw) + 111 B.
 TOM_COMMIT_PMC_BYTES = {24: 2501 + 112, 16: 3238 + 111}
+PMC_SOURCE = 'profiles/r02_pmc_summary.txt (separate rocprofv3 --pmc passes at batch 16384; constants of bench.py, NOT measured in this run)'
 # same passes, SQ counters at 24 bits: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave at 2 waves per SIMD (VALU pipe busy
 # 99 % of the time), SQ_WAIT_INST_ANY 0.378, SQ_WAIT_ANY (memory) 0.117
 TOM_COMMIT_VALU_ACTIVE_PER_WAVE = {24: 0.495}
@@ -124,6 +125,37 @@ def v8_bigint_indicator():
             'note': 'approximation of `npm run bench` (V8 BigInt, this build\'s JS restatement); not the cpu_baseline value'}
 
 
+def json_batch_rates(Z, ps):
+    """zk_proofs_to_json_batch / zk_proofs_from_json_batch over the proofs `ps`: one thread, then every core this process may use;
+    round-trip equality on the whole sample."""
+    n = len(ps)
+    off = (C.c_uint64 * (n + 1))()
+    for i, p in enumerate(ps):
+        off[i + 1] = off[i] + len(p)
+    blob = (C.c_uint8 * max(1, off[n])).from_buffer_copy(b''.join(ps))
+    cap = int(3.8 * off[n]) + 4096 * n
+    out, toff, st = (C.c_uint8 * cap)(), (C.c_uint64 * (n + 1))(), (C.c_int32 * n)()
+    back, poff = (C.c_uint8 * max(1, off[n]))(), (C.c_uint64 * (n + 1))()
+    L = Z.lib()
+    rec = {'proofs': n}
+    for name, th in (('one_thread', 1), ('all_threads', host_cores())):
+        best_w = best_r = None
+        for _ in range(2):   # the first pass touches the output pages
+            t0 = time.time()
+            rc = L.zk_proofs_to_json_batch(n, blob, off, out, cap, toff, st, th)
+            t1 = time.time()
+            rc2 = L.zk_proofs_from_json_batch(n, out, toff, back, off[n], poff, st, th)
+            t2 = time.time()
+            assert rc == 0 and rc2 == 0, (rc, rc2)
+            best_w = t1 - t0 if best_w is None else min(best_w, t1 - t0)
+            best_r = t2 - t1 if best_r is None else min(best_r, t2 - t1)
+        assert bytes(back) == bytes(blob) and list(poff) == list(off)
+        rec[name] = {'threads': th, 'to_json_per_s': round(n / best_w, 1), 'from_json_per_s': round(n / best_r, 1)}
+    rec['json_bytes_per_proof'] = int(toff[n]) // max(1, n)
+    rec['to_json_per_s'], rec['from_json_per_s'], rec['threads'] = rec['all_threads']['to_json_per_s'], rec['all_threads']['from_json_per_s'], rec['all_threads']['threads']
+    return rec
+
+
 def pcie_bandwidth(dev, nbytes=2 << 30):
     """Plain page-locked copies of `nbytes` in each direction on this box (GB/s): the roofline of the host-pointer calls."""
     import torch
@@ -184,10 +216,155 @@ def host_io_rates(Z, eng, args, B, sec, msg, sig, pk, which, seeds, dev, device_
             rec['verify_pcie_frac'] = round(rec['h2d_gbps'] / host_io['pcie']['h2d_gbps'], 3)
         host_io[name] = rec
     del hout
+    if args.host_io_stream > 1:
+        try:
+            host_io['stream'] = host_io_stream(Z, eng, args, nb, chunk, vchunk, hm, hs, hp, hw, hseed, pin, device_rate, device_vrate, host_io['pcie'])
+        except Exception as e:  # an auxiliary measurement must never cost the bench line
+            host_io['stream'] = {'error': repr(e)[:300]}
     pin.free()
     eng.set_chunk(min(args.chunk, B))
     eng.set_lanes(args.lanes)
     return host_io
+
+
+def host_io_stream(Z, eng, args, nb, chunk, vchunk, hm, hs, hp, hw, hseed, pin, device_rate, device_vrate, pcie):
+    """Steady state of the host-pointer path: `--host-io-stream` batches of nb proofs back to back through zk_prove_submit /
+    zk_prove_wait (two jobs in flight, two page-locked buffers in turn), then the same batches through zk_verify_submit /
+    zk_verify_wait.  Rates over ALL batches, first submit to last wait (ramp-up and drain included), and over the batches after the
+    first one (wait-to-wait)."""
+    nj = args.host_io_stream
+    pin2 = Z.PinnedBuffer(pin.nbytes)
+    bufs = [pin, pin2]
+    rec = {'batches': nj, 'proofs_per_batch': nb, 'in_flight': 2}
+    eng.set_chunk(chunk)
+    seeds = [hseed] + [rank_seeds(hseed, 7000 + k) for k in range(1, nj)]
+    for _ in range(2):   # the first round allocates the jobs' staging buffers (kept by the context afterwards)
+        t0 = time.time()
+        tk, waits, offs = [], [], [None] * nj
+        for k in range(nj):
+            tk.append(eng.prove_submit(hm, hs, hp, hw, seeds[k], bufs[k % 2]))
+            if k >= 1:
+                offs[k - 1], st = eng.prove_wait(tk[k - 1])
+                waits.append(time.time())
+                assert not any(st)
+        offs[nj - 1], st = eng.prove_wait(tk[nj - 1])
+        waits.append(time.time())
+        assert not any(st)
+    total_bytes = sum(int(o[nb]) for o in offs)
+    rec['prove'] = {'proofs_per_s': round(nj * nb / (waits[-1] - t0), 1), 'steady_proofs_per_s': round((nj - 1) * nb / (waits[-1] - waits[0]), 1),
+                    'd2h_gbps': round(total_bytes / (waits[-1] - t0) / 1e9, 2), 'seconds': round(waits[-1] - t0, 4)}
+    eng.set_chunk(vchunk)
+    for _ in range(2):
+        t0 = time.time()
+        tk, waits, acc = [], [], 0
+        for k in range(nj):   # the last two batches sit in the two buffers: verified alternately
+            j = nj - 2 + (k % 2) if nj >= 2 else 0
+            tk.append(eng.verify_submit(hm, bufs[j % 2], offs[j], nb))
+            if k >= 1:
+                ok, vst = eng.verify_wait(tk[k - 1])
+                waits.append(time.time())
+                acc += sum(ok)
+        ok, vst = eng.verify_wait(tk[nj - 1])
+        waits.append(time.time())
+        acc += sum(ok)
+        assert acc == nj * nb, (acc, nj * nb)
+    vbytes = sum(int(offs[nj - 2 + (k % 2) if nj >= 2 else 0][nb]) for k in range(nj))
+    rec['verify'] = {'verifies_per_s': round(nj * nb / (waits[-1] - t0), 1), 'steady_verifies_per_s': round((nj - 1) * nb / (waits[-1] - waits[0]), 1),
+                     'h2d_gbps': round(vbytes / (waits[-1] - t0) / 1e9, 2), 'seconds': round(waits[-1] - t0, 4)}
+    if device_rate:
+        rec['prove']['frac_of_device_resident'] = round(rec['prove']['proofs_per_s'] / device_rate, 3)
+        rec['prove']['steady_frac_of_device_resident'] = round(rec['prove']['steady_proofs_per_s'] / device_rate, 3)
+    if device_vrate:
+        rec['verify']['frac_of_device_resident'] = round(rec['verify']['verifies_per_s'] / device_vrate, 3)
+    rec['prove']['pcie_frac'] = round(rec['prove']['d2h_gbps'] / pcie['d2h_gbps'], 3)
+    rec['verify']['pcie_frac'] = round(rec['verify']['h2d_gbps'] / pcie['h2d_gbps'], 3)
+    pin2.free()
+    return rec
+
+
+def run_pool_mode(args, Z):
+    """`--pool`: ONE process, the --gpus devices of the node through the library's own zk_pool (csrc/api_pool.hip): zk_pool_set_ring
+    uploads the ring once and broadcasts it device to device (RCCL over xGMI; peer copies when RCCL is unusable), every shard of a
+    zk_pool_prove_batch / zk_pool_verify_batch call runs on its own host thread next to its device, the proofs land in one
+    page-locked buffer whose per-shard regions sit on the shards' NUMA nodes.  Weak scaling: --batch proofs per device.  This
+    is the SURVEY.md section 8(d) form of the metric (host buffers in, host buffers out): the rate is PCIe-inclusive by construction."""
+    devs = [int(x) for x in args.pool_devices.split(',')] if args.pool_devices else list(range(args.gpus))
+    G, Bg, nkeys, sec = len(devs), args.batch, args.ring, args.sec
+    B = Bg * G
+    pool = Z.Pool(devs)
+    for i in range(G):
+        e = pool.engine(i)
+        e.set_comb_bits(args.comb_bits)
+        e.set_chunk(min(args.host_io_chunk, Bg))
+        e.set_lanes(args.host_io_lanes)
+    e0 = pool.engine(0)
+    nh, tg, th = e0.synth_params(args.seed)
+    t0 = time.time()
+    pool.set_params(nh, tg, th, sec)
+    t_tab, tab_ms = time.time() - t0, pool.shard_ms()
+    ring, msg, sig, pk, which, seeds = e0.synth_workload(args.seed, nkeys, Bg)
+    t0 = time.time()
+    transport = pool.set_ring(ring, nkeys)
+    t_ring, ring_ms = time.time() - t0, pool.shard_ms()
+    # every shard proves the same Bg statements under its own randomness (distinct proofs, identical work)
+    msg_a, sig_a, pk_a, which_a = msg * G, sig * G, pk * G, list(which) * G
+    seeds_a = b''.join(rank_seeds(seeds, i) for i in range(G))
+    n_log2 = max(1, (nkeys - 1).bit_length())
+    per_shard = int(Bg * (304 + 336 * sec + 3392 * (sec // 2 + 4) + (4 * 72 + 96) * n_log2 + 32) + (64 << 20))
+    t0 = time.time()
+    pin = Z.PinnedBuffer(per_shard * G, pool=pool)
+    t_pin = time.time() - t0
+    for _ in range(args.warmup):
+        pool.prove_batch_raw(msg_a, sig_a, pk_a, which_a, seeds_a, pin, pin.nbytes)
+    dts, shard = [], []
+    for _ in range(args.steps):
+        dt, off, ln, st = pool.prove_batch_raw(msg_a, sig_a, pk_a, which_a, seeds_a, pin, pin.nbytes)
+        dts.append(dt)
+        shard.append(pool.shard_ms())
+    assert not any(st), [b for b in range(B) if st[b]][:8]
+    nbytes = sum(ln)
+    for i in range(G):
+        pool.engine(i).set_chunk(min(args.host_io_verify_chunk, Bg))
+    pool.verify_batch_raw(msg_a, pin, off, ln, B)   # warm-up (allocates the verifier workspaces)
+    vdt, ok, vst = pool.verify_batch_raw(msg_a, pin, off, ln, B)
+    vshard = pool.shard_ms()
+    accepted = sum(ok)
+    assert accepted == B and not any(vst), (accepted, B)
+    # planted forgeries: one per shard, exactly those are rejected
+    forged = [i * Bg + (i * 7919) % Bg for i in range(G)]
+    for b in forged:
+        pin.view[off[b] + ln[b] - 9] ^= 1
+    _, ok2, _ = pool.verify_batch_raw(msg_a, pin, off, ln, B)
+    assert [b for b in range(B) if not ok2[b]] == forged, 'planted forgeries not (exactly) rejected'
+    for b in forged:
+        pin.view[off[b] + ln[b] - 9] ^= 1
+    cpu = None
+    if not args.no_cpu_baseline:
+        sample = args.cpu_sample or 4 * host_cores()
+        cpu, oproofs = cpu_baseline(nh, tg, th, ring, nkeys, msg, sig, pk, which, seeds, sec, min(sample, Bg))
+        for b in range(min(args.check, len(oproofs))):   # shard 0 proves under the synthetic seeds themselves
+            assert bytes(pin.view[off[b]:off[b] + ln[b]]) == oproofs[b], 'GPU proof %d differs from the oracle' % b
+        cpu['checked_bit_exact'] = min(args.check, len(oproofs))
+    total = sum(dts)
+    rate = B * args.steps / total
+    line = {
+        'metric': 'proveSignatureList proofs/sec (zk_pool: host buffers in, host buffers out)', 'value': round(rate, 2), 'unit': 'proofs/s',
+        'value_is': 'PCIe-inclusive (SURVEY.md 8(d) form); this mode has no device-resident form -- bench.py without --pool reports that one',
+        'value_pcie_inclusive': round(rate, 2), 'verify_pcie_inclusive': round(B / vdt, 2),
+        'n_gpus': G, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(total * 1e3 / args.steps, 2), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32 (9x30-bit limbs, 256/258-bit modular integers)', 'data': 'synthetic',
+        'config': {'workload': 'batch=%d proofs per GPU per step (%d in total), ring=%d keys (n=%d), secLevel=%d, chunk=%d x %d lanes, comb=%d bits'
+                               % (Bg, B, nkeys, n_log2, sec, min(args.host_io_chunk, Bg), args.host_io_lanes, args.comb_bits),
+                   'parallelism': 'zk_pool: one process, devices %s, contiguous shards on host threads, ring %s' % (devs, transport)},
+        'ring_transport': transport, 'set_ring_s': round(t_ring, 3), 'set_ring_shard_ms': ring_ms, 'set_params_s': round(t_tab, 3), 'set_params_shard_ms': tab_ms,
+        'numa_nodes': [pool.numa_node(i) for i in range(G)], 'zk_pool_host_alloc': {'bytes': pin.nbytes, 'seconds': round(t_pin, 3)},
+        'prove_shard_ms_per_step': shard, 'verify_shard_ms': vshard, 'proof_bytes_per_step': int(nbytes), 'failed_proofs': 0,
+        'accepted': int(accepted), 'of': B, 'planted_forgeries_rejected': len(forged),
+        'd2h_gbps_total': round(nbytes * args.steps / total / 1e9, 2), 'h2d_gbps_total': round(nbytes / vdt / 1e9, 2), 'cpu_baseline': cpu,
+    }
+    print(json.dumps(line))
+    pin.free()
+    pool.close()
 
 
 def run_verify_mode(args, torch, Z, world, rank, local_rank, dev):
@@ -334,16 +511,21 @@ def main():
     ap.add_argument('--host-io-lanes', type=int, default=2, help='chunks in flight during the host-buffer calls')
     ap.add_argument('--host-io-reps', type=int, default=2, help='timed repetitions of the host-buffer calls (best is reported)')
     ap.add_argument('--host-io-uniform', action='store_true', help='uniform chunks instead of the tapered plan')
+    ap.add_argument('--host-io-stream', type=int, default=5, help='batches sent back to back through zk_prove_submit / zk_prove_wait (two in flight) for the steady-state PCIe-inclusive rate (0/1 = skip)')
+    ap.add_argument('--pool', action='store_true', help="ONE process, --gpus devices through the library's own zk_pool (RCCL ring broadcast, shards on host threads, page-locked host buffers): python bench.py --pool --gpus N")
+    ap.add_argument('--pool-devices', default='', help='--pool: comma-separated device ids (default 0..gpus-1; a device may repeat: several contexts on one GPU)')
     ap.add_argument('--host-io-pageable', action='store_true', help='also measure ordinary (pageable) host buffers')
     ap.add_argument('--mode', choices=['prove', 'verify'], default='prove',
                     help="verify: BASELINE configs[4] -- --batch proofs IN TOTAL over --ring keys, sharded over the ranks, generated and verified in streamed slabs")
     ap.add_argument('--slab', type=int, default=32768, help='--mode verify: proofs generated and verified per slab (one --verify-chunk by default: 176 k verifies/s at ring 2^20 against 141 k with slabs and chunks of 8192)')
-    ap.add_argument('--json-sample', type=int, default=32, help='proofs converted to the JSON wire format and back on one host thread (toJson / fromJson of the reference bench; 0 = skip)')
+    ap.add_argument('--json-sample', type=int, default=2048, help='proofs converted to the JSON wire format and back by the batch converters, on one host thread and on all of them (toJson / fromJson of the reference bench; 0 = skip)')
     ap.add_argument('--check', type=int, default=1 << 30, help='proofs of the last step diffed against the oracle on rank 0 (at most the CPU sample)')
     args = ap.parse_args()
 
-    import torch
     import zkp_ecdsa_amd as Z
+    if args.pool:
+        return run_pool_mode(args, Z)
+    import torch
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -507,6 +689,7 @@ def main():
                              'profiles/r02_pmc_summary.txt); table gathers, not the 180 algorithmic bytes, dominate' % pmc_bytes) if pmc_bytes
                             else 'no PMC pass recorded for this comb width',
             'valu_active_per_wave': TOM_COMMIT_VALU_ACTIVE_PER_WAVE.get(args.comb_bits),
+            'pmc_source': PMC_SOURCE,
             'comb_bits': args.comb_bits,
             'avg_launch_ms': round(tom_ms / max(1, launches_per_step), 3),
             'launches_per_step': launches_per_step,
@@ -529,18 +712,11 @@ def main():
             cpu['checked_bit_exact'] = ncheck
             cpu['v8_bigint'] = v8_bigint_indicator()
         json_rates = None
-        if args.json_sample > 0:   # bench/zkpAttestList.bench.ts:63-68 (toJson / fromJson), host-only converters of the C ABI, one thread
+        if args.json_sample > 0:   # bench/zkpAttestList.bench.ts:63-68 (toJson / fromJson): the batch converters of the C ABI on every host core
             nj = min(args.json_sample, B)
             raw = d_out[:int(off[nj].item())].cpu().numpy().tobytes()
             ps = [raw[int(off[b]):int(off[b + 1])] for b in range(nj)]
-            t0 = time.time()
-            texts = [Z.write_json(p) for p in ps]
-            t1 = time.time()
-            back = [Z.read_json(t) for t in texts]
-            t2 = time.time()
-            assert back == ps
-            json_rates = {'proofs': nj, 'to_json_per_s': round(nj / (t1 - t0), 1), 'from_json_per_s': round(nj / (t2 - t1), 1),
-                          'json_bytes_per_proof': sum(len(t) for t in texts) // nj, 'threads': 1}
+            json_rates = json_batch_rates(Z, ps)
         host_io = None
         if args.host_io > 0 and world == 1:
             try:
@@ -569,7 +745,12 @@ def main():
             line['value_pcie_inclusive'] = host_io['pinned']['proofs_per_s']
             line['verify_pcie_inclusive'] = host_io['pinned']['verifies_per_s']
             line['value_note'] = ('value: inputs and proofs resident in HBM (bench contract); value_pcie_inclusive: one zk_prove_batch call on '
-                                  'page-locked host buffers incl. H2D of the inputs and D2H of %.2f GB of proofs' % (host_io['pinned']['out_bytes'] / 1e9))
+                                  'page-locked host buffers incl. H2D of the inputs and D2H of %.2f GB of proofs; value_pcie_inclusive_steady: %d such '
+                                  'batches back to back through zk_prove_submit / zk_prove_wait, two in flight (first submit to last wait)'
+                                  % (host_io['pinned']['out_bytes'] / 1e9, args.host_io_stream))
+            if 'prove' in host_io.get('stream', {}):
+                line['value_pcie_inclusive_steady'] = host_io['stream']['prove']['proofs_per_s']
+                line['verify_pcie_inclusive_steady'] = host_io['stream']['verify']['verifies_per_s']
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -215,6 +215,9 @@ const char *zk_pool_last_error(const zk_pool *pool);                        /* p
 void *zk_pool_host_alloc(zk_pool *pool, size_t bytes);
 void zk_pool_host_free(void *p);
 int zk_pool_numa_node(const zk_pool *pool, int i);
+/* wall milliseconds every shard's host thread spent in its part of the last pool call (set_params, set_ring, prove, verify);
+ * returns the number of shards */
+int zk_pool_shard_ms(const zk_pool *pool, float *ms, int cap);
 const char *zk_pool_ring_transport(const zk_pool *pool);
 void zk_pool_shard(const zk_pool *pool, uint64_t B, int i, uint64_t *first, uint64_t *count);
 zk_status zk_pool_set_params(zk_pool *pool, const uint8_t nist_h[64], const uint8_t tom_g[72], const uint8_t tom_h[72], uint32_t sec_level);

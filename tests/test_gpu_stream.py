@@ -30,7 +30,7 @@ def _cut(work, a, b):
 @pytest.mark.parametrize('chunk,lanes,sizes', [(256, 2, (700, 300, 1000, 130)), (512, 3, (512, 1536, 100)), (4096, 2, (900, 900))])
 def test_streamed_prove_and_verify_equal_the_synchronous_calls(chunk, lanes, sizes):
     B = sum(sizes)
-    Z, eng, work = _setup(77, 64, B, chunk, lanes)
+    Z, eng, work = _setup(77, 4096, B, chunk, lanes)   # ring >= batch: every proof's key stays in the ring
     cap = eng.proof_max_size()
     bounds, a = [], 0
     for n in sizes:
@@ -40,13 +40,13 @@ def test_streamed_prove_and_verify_equal_the_synchronous_calls(chunk, lanes, siz
     ref = []
     for (a, b) in bounds:
         m, s, p, w, sd = _cut(work, a, b)
-        pin = Z.PinnedBuffer(cap * (b - a) // 2 + (8 << 20))
+        pin = Z.PinnedBuffer(cap * (b - a) * 7 // 10 + (8 << 20))
         _, _, off, st = eng.prove_batch_host_raw(m, s, p, w, sd, out=pin)
         assert not any(st)
         ref.append((bytes(pin.view[:off[b - a]]), list(off)))
         pin.free()
     # streamed: submit(0); submit(1); wait(0); submit(2); wait(1); ...
-    pins = [Z.PinnedBuffer(cap * (b - a) // 2 + (8 << 20)) for (a, b) in bounds]
+    pins = [Z.PinnedBuffer(cap * (b - a) * 7 // 10 + (8 << 20)) for (a, b) in bounds]
     tickets, got = [], []
     for k, (a, b) in enumerate(bounds):
         tickets.append(eng.prove_submit(*_cut(work, a, b), pins[k]))
@@ -93,9 +93,9 @@ def test_streamed_prove_and_verify_equal_the_synchronous_calls(chunk, lanes, siz
 
 def test_streamed_calls_enforce_their_rules():
     B = 600
-    Z, eng, work = _setup(78, 32, B, 256, 2)
+    Z, eng, work = _setup(78, 1024, B, 256, 2)
     cap = eng.proof_max_size()
-    pins = [Z.PinnedBuffer(cap * 200 // 2 + (8 << 20)) for _ in range(5)]
+    pins = [Z.PinnedBuffer(cap * 200 * 7 // 10 + (8 << 20)) for _ in range(5)]
     pageable = (C.c_uint8 * (cap * 10))()
     args = _cut(work, 0, 200)
 

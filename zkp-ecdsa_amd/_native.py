@@ -17,7 +17,7 @@ SYMBOLS = [
     'zk_proof_to_json', 'zk_proof_from_json', 'zk_host_alloc', 'zk_host_free', 'zk_ctx_set_host_taper', 'zk_ctx_set_slice', 'zk_ctx_set_mode', 'zk_ring_digest', 'zk_hardened_h',
     'zk_pool_create', 'zk_pool_destroy', 'zk_pool_size', 'zk_pool_ctx', 'zk_pool_last_error', 'zk_pool_ring_transport', 'zk_pool_shard',
     'zk_pool_set_params', 'zk_pool_set_ring', 'zk_pool_prove_batch', 'zk_pool_verify_batch',
-    'zk_pool_host_alloc', 'zk_pool_host_free', 'zk_pool_numa_node', 'zk_pool_test_locality',
+    'zk_pool_host_alloc', 'zk_pool_host_free', 'zk_pool_numa_node', 'zk_pool_test_locality', 'zk_pool_shard_ms',
     'zk_prove_submit', 'zk_prove_wait', 'zk_verify_submit', 'zk_verify_wait', 'zk_test_counter',
     'zk_proofs_to_json_batch', 'zk_proofs_from_json_batch',
     'zk_test_field_op', 'zk_test_tom_commit', 'zk_test_p256_fixed_mul', 'zk_test_sha256', 'zk_test_rng_draws',
@@ -117,6 +117,7 @@ def lib():
         L.zk_pool_host_free.argtypes = [vp]
         L.zk_pool_host_free.restype = None
         L.zk_pool_numa_node.argtypes = [vp, i32]
+        L.zk_pool_shard_ms.argtypes = [vp, C.POINTER(C.c_float), i32]
         L.zk_pool_test_locality.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), i32]
         L.zk_test_field_op.argtypes = [vp, i32, i32, u64, C.c_char_p, C.c_char_p, vp]
         L.zk_test_tom_commit.argtypes = [vp, u64, C.c_char_p, C.c_char_p, vp]
@@ -533,6 +534,11 @@ class Pool:
 
     def numa_node(self, i):
         return self.L.zk_pool_numa_node(self.h, i)
+
+    def shard_ms(self):
+        ms = (C.c_float * self.n)()
+        self.L.zk_pool_shard_ms(self.h, ms, self.n)
+        return [round(float(x), 2) for x in ms]
 
     def shard(self, B, i):
         f, c = C.c_uint64(), C.c_uint64()

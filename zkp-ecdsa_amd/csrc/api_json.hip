@@ -488,6 +488,155 @@ struct Wr {
 };
 }  // namespace
 
+// ---------------------------------------------------------------- fast path of the reader
+// Text in exactly the writer's shape (member order of the decorators, "__type" hints, no white space: what writeJson produces here
+// and, per the decorators, in the reference) is matched literal by literal and decoded field by field, without building the node
+// tree -- one pass at hex-decoding speed.  ANY deviation (another member order, white space, missing hints, escapes, duplicated
+// members ...) abandons the attempt and the tolerant reader above decides; the fast path never rejects a text by itself.
+struct Cur {
+    const char* p;
+    const char* e;
+    bool lit(const char* s, size_t l) {
+        if ((size_t)(e - p) < l || memcmp(p, s, l)) return false;
+        p += l;
+        return true;
+    }
+    bool peek(const char* s, size_t l) const { return (size_t)(e - p) >= l && memcmp(p, s, l) == 0; }
+    // "0x<1 .. 2*nbytes hex digits>" -> nbytes big-endian
+    bool hex(uint8_t* dst, int nbytes) {
+        if (e - p < 5 || p[0] != '"' || p[1] != '0' || p[2] != 'x') return false;
+        const char* q = p + 3;
+        const char* end = (const char*)memchr(q, '"', (size_t)(e - q) < 80 ? (size_t)(e - q) : 80);
+        if (!end || end == q || end - q > 2 * nbytes) return false;
+        static const struct Lut {
+            uint8_t v[256];
+            Lut() {
+                memset(v, 0xff, sizeof v);
+                for (int c = '0'; c <= '9'; c++) v[c] = (uint8_t)(c - '0');
+                for (int c = 'a'; c <= 'f'; c++) v[c] = (uint8_t)(c - 'a' + 10), v[c - 32] = (uint8_t)(c - 'a' + 10);
+            }
+        } lut;
+        memset(dst, 0, (size_t)nbytes);
+        const uint8_t* r = (const uint8_t*)end;
+        uint8_t* o = dst + nbytes;
+        uint8_t bad = 0;
+        size_t nd = (size_t)(end - q);
+        for (; nd >= 2; nd -= 2) {
+            uint8_t lo = lut.v[r[-1]], hi = lut.v[r[-2]];
+            r -= 2, bad |= lo | hi;
+            *--o = (uint8_t)(hi << 4 | (lo & 15));
+        }
+        if (nd) {
+            uint8_t lo = lut.v[r[-1]];
+            bad |= lo;
+            *--o = (uint8_t)(lo & 15);
+        }
+        if (bad & 0x80) return false;
+        p = end + 1;
+        return true;
+    }
+};
+struct FastRd {
+    Cur c;
+    std::vector<uint8_t>& b;
+    uint8_t* put(size_t n) {
+        size_t at = b.size();
+        b.resize(at + n);
+        return b.data() + at;
+    }
+    bool pt_p() {
+        uint8_t* d = put(64);
+        return c.lit(LIT("{\"group\":" G_P_TXT ",\"x\":")) && c.hex(d, 32) && c.lit(LIT(",\"y\":")) && c.hex(d + 32, 32) && c.lit(LIT(",\"__type\":\"WeierstrassPoint\"}"));
+    }
+    bool pt_t() {
+        uint8_t* d = put(72);
+        return c.lit(LIT("{\"group\":" G_T_TXT ",\"x\":")) && c.hex(d, 36) && c.lit(LIT(",\"y\":")) && c.hex(d + 36, 36) && c.lit(LIT(",\"__type\":\"TEdwardsPoint\"}"));
+    }
+    bool sc_at(uint8_t* d, bool tom) {
+        return (tom ? c.lit(LIT("{\"group\":" G_T_TXT ",\"k\":")) : c.lit(LIT("{\"group\":" G_P_TXT ",\"k\":"))) && c.hex(d, 32) && c.lit(LIT("}"));
+    }
+    bool sc(bool tom) { return sc_at(put(32), tom); }
+    bool key(const char* k, bool first = false) { return (first || c.lit(LIT(","))) && c.lit(LIT("\"")) && c.lit(k, strlen(k)) && c.lit(LIT("\":")); }
+    bool mult() {
+        static const char* P[6] = {"C_4", "A_x", "A_y", "A_z", "A_4_1", "A_4_2"};
+        static const char* T[7] = {"t_x", "t_y", "t_z", "t_rx", "t_ry", "t_rz", "t_r4"};
+        if (!c.lit(LIT("{"))) return false;
+        for (int i = 0; i < 6; i++)
+            if (!key(P[i], i == 0) || !pt_t()) return false;
+        for (int i = 0; i < 7; i++)
+            if (!key(T[i]) || !sc(true)) return false;
+        return c.lit(LIT("}"));
+    }
+    bool eq() {
+        return c.lit(LIT("{")) && key("A_1", true) && pt_t() && key("A_2") && pt_t() && key("t_x") && sc(true) && key("t_r1") && sc(true) && key("t_r2") && sc(true) &&
+               c.lit(LIT("}"));
+    }
+    bool run() {
+        b.clear();
+        b.resize(32, 0);
+        if (!(c.lit(LIT("{")) && key("R", true) && pt_p() && key("comS1") && pt_p() && key("keyXcom") && pt_t() && key("keyYcom") && pt_t() && key("expProof") &&
+              c.lit(LIT("["))))
+            return false;
+        uint32_t sec = 0;
+        uint8_t bits[16] = {0};
+        if (!c.peek(LIT("]"))) {
+            for (;;) {
+                if (sec >= 128) return false;
+                if (!(c.lit(LIT("{")) && key("A", true) && pt_p() && key("Tx") && pt_t() && key("Ty") && pt_t())) return false;
+                if (c.peek(LIT(",\"alpha\":"))) {
+                    bits[15 - (sec >> 3)] |= (uint8_t)(1u << (sec & 7));
+                    if (!(key("alpha") && sc(false) && key("beta1") && sc(false) && key("beta2") && sc(true) && key("beta3") && sc(true))) return false;
+                } else {
+                    if (!(key("z") && sc(false) && key("z2") && sc(false))) return false;
+                    const size_t r12 = b.size();   // ZKA1 keeps r1, r2 ahead of the PointAddProof; the text has them behind it
+                    put(64);
+                    static const char* C4[4] = {"C_8", "C_10", "C_11", "C_13"};
+                    static const char* M4[4] = {"pi_8", "pi_10", "pi_11", "pi_13"};
+                    if (!(key("proof") && c.lit(LIT("{")))) return false;
+                    for (int k = 0; k < 4; k++)
+                        if (!key(C4[k], k == 0) || !pt_t()) return false;
+                    for (int k = 0; k < 4; k++)
+                        if (!key(M4[k]) || !mult()) return false;
+                    if (!(key("pi_x") && eq() && key("pi_y") && eq() && c.lit(LIT("}")))) return false;
+                    if (!(key("r1") && sc_at(b.data() + r12, true) && key("r2") && sc_at(b.data() + r12 + 32, true))) return false;
+                }
+                if (!c.lit(LIT("}"))) return false;
+                sec++;
+                if (c.lit(LIT(","))) continue;
+                break;
+            }
+        }
+        if (!(c.lit(LIT("]")) && key("membershipProof") && c.lit(LIT("{")))) return false;
+        static const char* PA[4] = {"cl", "ca", "cb", "cd"};
+        static const char* SA[3] = {"f", "za", "zb"};
+        uint32_t n = 0;
+        for (int k = 0; k < 7; k++) {
+            if (!(key(k < 4 ? PA[k] : SA[k - 4], k == 0) && c.lit(LIT("[")))) return false;
+            uint32_t cnt = 0;
+            if (!c.peek(LIT("]"))) {
+                for (;;) {
+                    if (cnt >= 64) return false;
+                    if (!(k < 4 ? pt_t() : sc(true))) return false;
+                    cnt++;
+                    if (c.lit(LIT(","))) continue;
+                    break;
+                }
+            }
+            if (!c.lit(LIT("]"))) return false;
+            if (k == 0) n = cnt;
+            else if (cnt != n) return false;
+        }
+        if (!(key("zd") && sc(true) && c.lit(LIT("}}")) && c.p == c.e)) return false;
+        const uint32_t total = (uint32_t)b.size();
+        memcpy(b.data(), "ZKA1", 4);
+        const uint32_t hv[3] = {total, sec, n};
+        for (int k = 0; k < 3; k++)
+            for (int j = 0; j < 4; j++) b[4 + 4 * k + j] = (uint8_t)(hv[k] >> (24 - 8 * j));
+        memcpy(b.data() + 16, bits, 16);
+        return true;
+    }
+};
+
 // No C++ exception may cross the C ABI: an allocation failure on a hostile input is reported as ZK_E_BUFFER.
 #define ZK_JSON_MAX_TEXT ((uint64_t)64 << 20)   // a SignatureProofList at secLevel 128, n = 64 is below 4 MB of JSON
 static zk_status proof_to_json_impl(const uint8_t* proof, uint64_t len, char* out, uint64_t cap, uint64_t* out_len) {
@@ -524,6 +673,16 @@ static zk_status proof_from_json_impl(const char* json, uint64_t len, uint8_t* o
     // threads, in contention on the address space) than the parse itself
     static thread_local Doc d;
     static thread_local std::vector<uint8_t> wbuf;
+    if (!getenv("ZKATTEST_JSON_NO_FAST")) {   // the writer's own shape: one pass, no tree (falls through on any deviation)
+        wbuf.reserve((size_t)(len / 3) + 64);
+        FastRd f{Cur{json, json + len}, wbuf};
+        if (f.run()) {
+            *out_len = wbuf.size();
+            if (!out || cap < wbuf.size()) return ZK_E_BUFFER;
+            memcpy(out, wbuf.data(), wbuf.size());
+            return ZK_OK;
+        }
+    }
     d.reset(json);
     d.nd.reserve((size_t)(len / 14) + 16);
     d.nd.emplace_back();

@@ -10,6 +10,7 @@
 // The fixed-base tables and the per-ring table E are rebuilt locally on every device, concurrently: that is cheaper than
 // moving 47 GB of tables per device across the links.
 #include <dlfcn.h>
+#include <chrono>
 #include <sched.h>
 #include <sys/mman.h>
 #include <unistd.h>
@@ -68,6 +69,7 @@ struct zk_pool {
     std::vector<std::vector<int>> cpus;   // empty = unknown (no affinity is set)
     std::vector<int> numa;                // -1 = unknown
     bool affinity = true;                 // ZKATTEST_POOL_AFFINITY=0 switches it off
+    std::vector<float> shard_ms;          // wall time of every shard's part of the last pool call (zk_pool_shard_ms)
 };
 
 // "0-15,128-143" -> cpu numbers (the format of sysfs cpulist files)
@@ -133,14 +135,20 @@ template <class F>
 static zk_status pool_each(zk_pool* p, F f) {
     const int G = (int)p->ctx.size();
     std::vector<zk_status> st(G, ZK_OK);
+    p->shard_ms.assign(G, 0.f);
+    auto timed = [&](int i) {
+        auto t0 = std::chrono::steady_clock::now();
+        st[i] = f(i);
+        p->shard_ms[i] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
     if (G == 1) {
-        st[0] = f(0);
+        timed(0);
     } else {
         std::vector<std::thread> th;
         for (int i = 0; i < G; i++)
             th.emplace_back([&, i] {
                 if (p->affinity && i < (int)p->cpus.size()) bind_thread_to(p->cpus[i]);
-                st[i] = f(i);
+                timed(i);
             });
         for (auto& t : th) t.join();
     }
@@ -199,6 +207,11 @@ extern "C" void zk_pool_destroy(zk_pool* p) {
 extern "C" int zk_pool_size(const zk_pool* p) { return p ? (int)p->ctx.size() : 0; }
 extern "C" zk_ctx* zk_pool_ctx(zk_pool* p, int i) { return p && i >= 0 && i < (int)p->ctx.size() ? p->ctx[i] : nullptr; }
 extern "C" const char* zk_pool_last_error(const zk_pool* p) { return p ? p->err.c_str() : g_pool_create_err.c_str(); }
+extern "C" int zk_pool_shard_ms(const zk_pool* p, float* ms, int cap) {
+    if (!p) return 0;
+    for (int i = 0; i < (int)p->shard_ms.size() && i < cap; i++) ms[i] = p->shard_ms[i];
+    return (int)p->shard_ms.size();
+}
 extern "C" int zk_pool_numa_node(const zk_pool* p, int i) { return p && i >= 0 && i < (int)p->numa.size() ? p->numa[i] : -1; }
 
 // ---- page-locked output buffer of a pool call with per-shard placement.  zk_pool_prove_batch gives shard i the region
