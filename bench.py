@@ -231,46 +231,78 @@ def host_io_stream(Z, eng, args, nb, chunk, vchunk, hm, hs, hp, hw, hseed, pin, 
     """Steady state of the host-pointer path: `--host-io-stream` batches of nb proofs back to back through zk_prove_submit /
     zk_prove_wait (two jobs in flight, two page-locked buffers in turn), then the same batches through zk_verify_submit /
     zk_verify_wait.  Rates over ALL batches, first submit to last wait (ramp-up and drain included), and over the batches after the
-    first one (wait-to-wait)."""
-    nj = args.host_io_stream
-    pin2 = Z.PinnedBuffer(pin.nbytes)
-    bufs = [pin, pin2]
-    rec = {'batches': nj, 'proofs_per_batch': nb, 'in_flight': 2}
-    eng.set_chunk(chunk)
+    first one (wait-to-wait).  Between calls nothing has to be hidden inside ONE call any more, so the plan may differ from the
+    single-call one: --host-io-stream-configs / --host-io-stream-vconfigs list chunk:lanes:slice / chunk:lanes settings, the best is
+    reported next to all of them."""
+    nj, F = args.host_io_stream, max(2, args.host_io_stream_inflight)
+    bufs = [pin] + [Z.PinnedBuffer(pin.nbytes) for _ in range(F - 1)]
+    rec = {'batches': nj, 'proofs_per_batch': nb, 'in_flight': F, 'prove_configs': [], 'verify_configs': []}
     seeds = [hseed] + [rank_seeds(hseed, 7000 + k) for k in range(1, nj)]
-    for _ in range(2):   # the first round allocates the jobs' staging buffers (kept by the context afterwards)
-        t0 = time.time()
-        tk, waits, offs = [], [], [None] * nj
-        for k in range(nj):
-            tk.append(eng.prove_submit(hm, hs, hp, hw, seeds[k], bufs[k % 2]))
-            if k >= 1:
-                offs[k - 1], st = eng.prove_wait(tk[k - 1])
+    offs = [None] * nj
+    def guarded(cfg, run):   # one configuration running out of memory (workspaces of more lanes) must not cost the others
+        try:
+            return run()
+        except Exception as e:
+            return {'config': cfg, 'error': repr(e)[:200]}
+
+    def prove_cfg(cfg):
+        c_, l_, s_ = (int(x) for x in cfg.split(':'))
+        eng.set_chunk(min(c_, nb))
+        eng.set_lanes(l_)
+        eng.set_slice(s_)
+        for _ in range(2):   # the first round allocates the jobs' staging buffers (kept by the context afterwards)
+            t0 = time.time()
+            tk, waits = [], []
+            for k in range(min(F, nj)):
+                tk.append(eng.prove_submit(hm, hs, hp, hw, seeds[k], bufs[k % F]))
+            for k in range(nj):
+                offs[k], st = eng.prove_wait(tk[k])
                 waits.append(time.time())
                 assert not any(st)
-        offs[nj - 1], st = eng.prove_wait(tk[nj - 1])
-        waits.append(time.time())
-        assert not any(st)
-    total_bytes = sum(int(o[nb]) for o in offs)
-    rec['prove'] = {'proofs_per_s': round(nj * nb / (waits[-1] - t0), 1), 'steady_proofs_per_s': round((nj - 1) * nb / (waits[-1] - waits[0]), 1),
-                    'd2h_gbps': round(total_bytes / (waits[-1] - t0) / 1e9, 2), 'seconds': round(waits[-1] - t0, 4)}
-    eng.set_chunk(vchunk)
-    for _ in range(2):
-        t0 = time.time()
-        tk, waits, acc = [], [], 0
-        for k in range(nj):   # the last two batches sit in the two buffers: verified alternately
-            j = nj - 2 + (k % 2) if nj >= 2 else 0
-            tk.append(eng.verify_submit(hm, bufs[j % 2], offs[j], nb))
-            if k >= 1:
-                ok, vst = eng.verify_wait(tk[k - 1])
+                if k + F < nj:   # job k's buffer is free again
+                    tk.append(eng.prove_submit(hm, hs, hp, hw, seeds[k + F], bufs[(k + F) % F]))
+        total_bytes = sum(int(o[nb]) for o in offs)
+        return {'chunk': min(c_, nb), 'lanes': l_, 'slice': s_, 'proofs_per_s': round(nj * nb / (waits[-1] - t0), 1),
+                'steady_proofs_per_s': round((nj - 1) * nb / (waits[-1] - waits[0]), 1), 'd2h_gbps': round(total_bytes / (waits[-1] - t0) / 1e9, 2),
+                'seconds': round(waits[-1] - t0, 4)}
+
+    for cfg in args.host_io_stream_configs.split(','):
+        rec['prove_configs'].append(guarded(cfg, lambda: prove_cfg(cfg)))
+    eng.set_slice(0)
+    rec['prove'] = dict(max(rec['prove_configs'], key=lambda r: r.get('proofs_per_s', 0)))
+
+    def verify_cfg(cfg):
+        c_, l_ = (int(x) for x in cfg.split(':'))
+        eng.set_chunk(min(c_, nb))
+        eng.set_lanes(l_)
+        Fv = max(2, min(F, args.host_io_stream_vinflight))
+        src = lambda k: nj - 1 - (k % F) if nj >= F else k % nj   # the last F batches sit in the F buffers: verified in turn
+        for _ in range(2):
+            t0 = time.time()
+            tk, waits, acc = [], [], 0
+            for k in range(min(Fv, nj)):
+                tk.append(eng.verify_submit(hm, bufs[src(k) % F], offs[src(k)], nb))
+            for k in range(nj):
+                ok, vst = eng.verify_wait(tk[k])
                 waits.append(time.time())
                 acc += sum(ok)
-        ok, vst = eng.verify_wait(tk[nj - 1])
-        waits.append(time.time())
-        acc += sum(ok)
-        assert acc == nj * nb, (acc, nj * nb)
-    vbytes = sum(int(offs[nj - 2 + (k % 2) if nj >= 2 else 0][nb]) for k in range(nj))
-    rec['verify'] = {'verifies_per_s': round(nj * nb / (waits[-1] - t0), 1), 'steady_verifies_per_s': round((nj - 1) * nb / (waits[-1] - waits[0]), 1),
-                     'h2d_gbps': round(vbytes / (waits[-1] - t0) / 1e9, 2), 'seconds': round(waits[-1] - t0, 4)}
+                if k + Fv < nj:
+                    tk.append(eng.verify_submit(hm, bufs[src(k + Fv) % F], offs[src(k + Fv)], nb))
+            assert acc == nj * nb, (acc, nj * nb)
+        vbytes = sum(int(offs[src(k)][nb]) for k in range(nj))
+        return {'chunk': min(c_, nb), 'lanes': l_, 'in_flight': Fv, 'verifies_per_s': round(nj * nb / (waits[-1] - t0), 1),
+                'steady_verifies_per_s': round((nj - 1) * nb / (waits[-1] - waits[0]), 1),
+                'h2d_gbps': round(vbytes / (waits[-1] - t0) / 1e9, 2), 'seconds': round(waits[-1] - t0, 4)}
+
+    if offs[nj - 1] is not None:
+        for cfg in args.host_io_stream_vconfigs.split(','):
+            rec['verify_configs'].append(guarded(cfg, lambda: verify_cfg(cfg)))
+    good_v = [r for r in rec['verify_configs'] if 'verifies_per_s' in r]
+    rec['verify'] = dict(max(good_v, key=lambda r: r['verifies_per_s'])) if good_v else {}
+    if 'proofs_per_s' not in rec['prove'] or not rec['verify']:
+        for b_ in bufs[1:]:
+            b_.free()
+        return rec
     if device_rate:
         rec['prove']['frac_of_device_resident'] = round(rec['prove']['proofs_per_s'] / device_rate, 3)
         rec['prove']['steady_frac_of_device_resident'] = round(rec['prove']['steady_proofs_per_s'] / device_rate, 3)
@@ -278,7 +310,8 @@ def host_io_stream(Z, eng, args, nb, chunk, vchunk, hm, hs, hp, hw, hseed, pin, 
         rec['verify']['frac_of_device_resident'] = round(rec['verify']['verifies_per_s'] / device_vrate, 3)
     rec['prove']['pcie_frac'] = round(rec['prove']['d2h_gbps'] / pcie['d2h_gbps'], 3)
     rec['verify']['pcie_frac'] = round(rec['verify']['h2d_gbps'] / pcie['h2d_gbps'], 3)
-    pin2.free()
+    for b_ in bufs[1:]:
+        b_.free()
     return rec
 
 
@@ -511,7 +544,11 @@ def main():
     ap.add_argument('--host-io-lanes', type=int, default=2, help='chunks in flight during the host-buffer calls')
     ap.add_argument('--host-io-reps', type=int, default=2, help='timed repetitions of the host-buffer calls (best is reported)')
     ap.add_argument('--host-io-uniform', action='store_true', help='uniform chunks instead of the tapered plan')
-    ap.add_argument('--host-io-stream', type=int, default=5, help='batches sent back to back through zk_prove_submit / zk_prove_wait (two in flight) for the steady-state PCIe-inclusive rate (0/1 = skip)')
+    ap.add_argument('--host-io-stream', type=int, default=8, help='batches sent back to back through zk_prove_submit / zk_prove_wait (two in flight) for the steady-state PCIe-inclusive rate (0/1 = skip)')
+    ap.add_argument('--host-io-stream-inflight', type=int, default=3, help='jobs kept in flight by the streamed measurement (2..4); 3 lets the stage-1 look-ahead always find a queued job')
+    ap.add_argument('--host-io-stream-vinflight', type=int, default=2, help='jobs in flight of the streamed verify batches (link-bound: two keep the H2D stream full)')
+    ap.add_argument('--host-io-stream-configs', default='22016:3:8192', help='chunk:lanes:slice settings of the streamed prove batches (comma-separated; the best is reported)')
+    ap.add_argument('--host-io-stream-vconfigs', default='32768:2', help='chunk:lanes settings of the streamed verify batches')
     ap.add_argument('--pool', action='store_true', help="ONE process, --gpus devices through the library's own zk_pool (RCCL ring broadcast, shards on host threads, page-locked host buffers): python bench.py --pool --gpus N")
     ap.add_argument('--pool-devices', default='', help='--pool: comma-separated device ids (default 0..gpus-1; a device may repeat: several contexts on one GPU)')
     ap.add_argument('--host-io-pageable', action='store_true', help='also measure ordinary (pageable) host buffers')

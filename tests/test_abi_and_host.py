@@ -58,3 +58,30 @@ def test_c_program_compiles_and_links_against_the_abi(tmp_path):
                            os.path.join(root, 'examples', 'c_abi_demo.c'), '-o', str(out), '-L' + libdir, '-lzkattest_hip',
                            '-Wl,-rpath,' + libdir])
     assert out.exists()
+
+
+def test_pool_reads_device_locality_from_sysfs(tmp_path, monkeypatch):
+    """zk_pool binds every shard's host thread to the CPUs next to its device and places the shard's output region on that NUMA
+    node: both come from /sys/bus/pci/devices/<bus id>/{numa_node, local_cpulist}.  The parser, on a fake tree (no GPU needed)."""
+    import ctypes as C
+    import zkp_ecdsa_amd as Z
+    d = tmp_path / 'bus' / 'pci' / 'devices' / '0000:c1:00.0'
+    d.mkdir(parents=True)
+    (d / 'numa_node').write_text('3\n')
+    (d / 'local_cpulist').write_text('48-63,176-191\n')
+    d2 = tmp_path / 'bus' / 'pci' / 'devices' / '0000:05:00.0'
+    d2.mkdir(parents=True)
+    (d2 / 'numa_node').write_text('-1\n')
+    (d2 / 'local_cpulist').write_text('7\n')
+    monkeypatch.setenv('ZKATTEST_SYSFS_ROOT', str(tmp_path))
+    L = Z.lib()
+    numa, cpus = C.c_int(-5), (C.c_int * 64)()
+    n = L.zk_pool_test_locality(b'0000:C1:00.0', C.byref(numa), cpus, 64)   # HIP prints upper-case hex, sysfs is lower-case
+    assert (n, numa.value, list(cpus[:n])) == (32, 3, list(range(48, 64)) + list(range(176, 192)))
+    n = L.zk_pool_test_locality(b'0000:05:00.0', C.byref(numa), cpus, 64)
+    assert (n, numa.value, cpus[0]) == (1, -1, 7)
+    n = L.zk_pool_test_locality(b'0000:ff:00.0', C.byref(numa), cpus, 64)     # unknown device: no affinity, no placement
+    assert (n, numa.value) == (0, -1)
+    # a failed create leaves NULL behind and says why
+    h = C.c_void_p(1)
+    assert L.zk_pool_create(None, 0, C.byref(h)) == 14 and not h.value

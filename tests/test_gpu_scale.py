@@ -130,6 +130,8 @@ def test_pool_shards_one_call_over_devices_and_matches_single_device():
     assert transport in ('rccl', 'peer-copy'), transport
     if ids[0] == ids[1]:
         assert transport == 'peer-copy'   # RCCL refuses one device twice
+    else:
+        assert transport == 'rccl'        # two distinct devices: the ring must have travelled by ncclBroadcast
     for i in range(2):
         pool.engine(i).set_chunk(7)
     got, pst = pool.prove_batch(msg, sig, pk, which, seeds=seeds)
@@ -151,6 +153,12 @@ def test_pool_shards_one_call_over_devices_and_matches_single_device():
     assert off[18] == cap // 2 and off[17] + ln[17] < off[18]
     _, ok, vst = pool.verify_batch_raw(msg, pin, off, ln, B, vseeds=vs)
     assert list(ok) == [1] * B
+    # the pool's own page-locked buffer (per-shard regions first touched next to their devices) behaves like zk_host_alloc's
+    npin = Z.PinnedBuffer(cap, pool=pool)
+    _, off3, ln3, pst = pool.prove_batch_raw(msg, sig, pk, which, seeds, npin, cap)
+    assert [bytes(npin.view[off3[b]:off3[b] + ln3[b]]) for b in range(B)] == ref and list(off3) == list(off)
+    assert len(pool.shard_ms()) == 2 and all(ms > 0 for ms in pool.shard_ms()) and pool.numa_node(0) >= -1
+    npin.free()
     # a layout with a hole inside a shard is refused, not misread
     off2 = (C.c_uint64 * B)(*off)
     off2[5] += 4
@@ -163,6 +171,58 @@ def test_pool_shards_one_call_over_devices_and_matches_single_device():
     assert solo.set_ring(ring, nkeys) == 'single'
     assert solo.prove_batch(msg, sig, pk, which, seeds=seeds)[0] == ref
     solo.close(), pool.close(), pin.free(), eng.close()
+
+
+def _bench(args, env=None, timeout=900):
+    import json
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env or {})
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stderr[-3000:]
+    return json.loads(res.stdout.strip().splitlines()[-1])
+
+
+def test_baseline_config5_full_per_gpu_shard_131072_proofs_over_ring_2_20():
+    """BASELINE configs[4] (verifySignatureList, batch 2^20, ring 2^20, 8 GPUs) at the scale ONE of its eight GPUs sees: 131 072
+    proofs over a ring of 2^20 keys, streamed through HBM in slabs (bench.py --mode verify, the very command the driver's scaling
+    run executes per rank).  bench.py itself asserts that every honest proof is accepted, that exactly the three planted
+    forgeries of the first slab are rejected and that no proof failed to be made; verdict parity with the oracle at this ring
+    size is test_baseline_config5_shape_ring_2_20_verify_4096."""
+    line = _bench(['--mode', 'verify', '--batch', '131072', '--ring', '1048576', '--steps', '1', '--warmup', '0'])
+    assert line['metric'].startswith('verifySignatureList') and line['n_gpus'] == 1
+    assert line['accepted'] == line['of'] == 131072 and line['planted_forgeries_rejected'] == 3
+    assert '131072 proofs per rank' in line['config']['workload'] and 'ring=1048576' in line['config']['workload']
+    assert line['value'] > 0
+
+
+def test_bench_pool_mode_runs_the_librarys_own_multi_gpu_path():
+    """bench.py --pool: one process, zk_pool over the listed devices (two contexts on device 0 here; the visible devices on a
+    multi-GPU box), page-locked NUMA-placed buffers, ring transport reported, every proof verified, forgeries rejected, shard 0
+    byte for byte against the oracle."""
+    import torch
+    ndev = torch.cuda.device_count()
+    devs = ','.join(str(i) for i in range(min(ndev, 8))) if ndev >= 2 else '0,0'
+    line = _bench(['--pool', '--pool-devices', devs, '--batch', '2048', '--ring', '4096', '--comb-bits', '16', '--host-io-chunk', '1024',
+                   '--host-io-verify-chunk', '1024', '--steps', '1', '--warmup', '1', '--cpu-sample', '4'])
+    G = len(devs.split(','))
+    assert line['n_gpus'] == G and line['accepted'] == line['of'] == 2048 * G and line['planted_forgeries_rejected'] == G
+    assert line['ring_transport'] == ('rccl' if ndev >= 2 else 'peer-copy')
+    assert len(line['prove_shard_ms_per_step'][0]) == G and line['cpu_baseline']['checked_bit_exact'] == 4
+    assert line['value_pcie_inclusive'] == line['value'] > 0
+
+
+def test_bench_eight_ranks_on_one_gpu_dry_run():
+    """The driver's `--gpus 8` launch line, with all eight ranks on this one GPU (gloo group, small tables): rendezvous, ring
+    broadcast, per-rank seeds, max-over-ranks timing and the rank-0 JSON line at world size 8."""
+    import subprocess
+    import json
+    res = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'smoke_multirank.sh'), 'prove8'], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 8 and line['failed_proofs'] == 0 and line['verify']['accepted'] == line['verify']['of']
+    assert line['cpu_baseline']['checked_bit_exact'] >= 1
 
 
 def test_tapered_chunk_plan_of_the_host_pointer_calls_keeps_the_bytes():

@@ -404,10 +404,16 @@ bool host_ptr_is_pinned(const void* p) {
     }
     return a.type == hipMemoryTypeHost;
 }
+void* stream_take_spare_dev(zk_ctx* c, size_t bytes, size_t* got);   // api_stream.hip: staging buffers of finished streamed jobs
 zk_status ensure_io_buf(zk_ctx* c, size_t bytes) {
     if (bytes <= c->io_bytes) return ZK_OK;
     if (c->io_buf) hipFree(c->io_buf);
     c->io_buf = nullptr, c->io_bytes = 0;
+    size_t got = 0;
+    if (void* p = stream_take_spare_dev(c, bytes, &got)) {
+        c->io_buf = p, c->io_bytes = got;
+        return ZK_OK;
+    }
     HIPCHK(c, hipMalloc(&c->io_buf, bytes));
     c->io_bytes = bytes;
     return ZK_OK;
@@ -640,7 +646,14 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
                 HIPCHK(c, hipEventRecord(ev, s));
                 HIPCHK(c, hipStreamWaitEvent(c->pl[pd.lane].copy_stream, ev, 0));
                 if (io_dbg) hipEventRecord(r.c0, c->pl[pd.lane].copy_stream);
-                HIPCHK(c, hipMemcpyAsync(host_sink + cursor + b0, out + b0, b1 - b0, hipMemcpyDeviceToHost, c->pl[pd.lane].copy_stream));
+                // in pieces: ZKATTEST_COPY_PIECE_MB (default 512) bounds one DMA command
+                static const uint64_t piece = [] {
+                    const char* e = getenv("ZKATTEST_COPY_PIECE_MB");
+                    uint64_t mb = e ? strtoull(e, nullptr, 10) : 512;
+                    return (mb ? mb : 512) << 20;
+                }();
+                for (uint64_t o = b0; o < b1; o += piece)
+                    HIPCHK(c, hipMemcpyAsync(host_sink + cursor + o, out + o, std::min<uint64_t>(piece, b1 - o), hipMemcpyDeviceToHost, c->pl[pd.lane].copy_stream));
                 if (io_dbg) {
                     hipEventRecord(r.c1, c->pl[pd.lane].copy_stream);
                     iorecs.push_back(r);

@@ -10,6 +10,8 @@
 //     submit(0); submit(1); wait(0); submit(2); wait(1); submit(3); wait(2); ...
 // The reference has no counterpart (one proof per call on one thread, src/zkpAttestList.ts:104-145); the bytes and verdicts
 // are those of the synchronous calls (tests/test_gpu_stream.py).
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include "jobs.h"
 
@@ -71,12 +73,12 @@ static zk_status get_pinned(zk_ctx* c, size_t bytes, void** p, size_t* got) {
     *got = bytes;
     return ZK_OK;
 }
+void* stream_take_spare_dev(zk_ctx* c, size_t bytes, size_t* got) { return take_spare(c->spare_dev, bytes, got); }   // ensure_io_buf (api.hip)
 void stream_release_spares(zk_ctx* c) {   // zk_ctx_destroy
     for (auto& s : c->spare_dev) hipFree(s.p);
     for (auto& s : c->spare_pinned) hipHostFree(s.p);
     c->spare_dev.clear(), c->spare_pinned.clear();
-    if (c->fin_stream) hipStreamDestroy(c->fin_stream);
-    c->fin_stream = nullptr;
+    c->fin_stream = nullptr;   // borrowed: the last lane's copy stream
 }
 static void job_free(zk_job* j) {
     zk_ctx* c = j->c;
@@ -128,7 +130,14 @@ static zk_status stream_common(zk_ctx* c, int kind) {
         c->err = "chunk / lanes / parameters / ring changed while streamed jobs are in flight";
         return ZK_E_ARG;
     }
-    if (!c->fin_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->fin_stream, hipStreamNonBlocking));
+    // The finisher stream is the LAST lane's copy stream, not a new one: HIP multiplexes streams onto 8 hardware queues in creation
+    // order and the context already owns eight (api.hip, zk_ctx_create) -- a ninth stream would share lane 0's queue, and the
+    // finisher's "wait for every lane" would stall the kernels of the next job queued behind it there.
+    if (!c->fin_stream) c->fin_stream = c->pl[ZK_MAX_LANES - 1].copy_stream;
+    if (c->io_buf) {   // the synchronous calls' staging buffer serves as a job's (it comes back through the pool: ensure_io_buf)
+        c->spare_dev.push_back({c->io_buf, c->io_bytes});
+        c->io_buf = nullptr, c->io_bytes = 0;
+    }
     zk_status zs = ensure_copy_stream(c);
     if (zs) return zs;
     zs = ensure_workspace(c, c->chunk, c->lanes);   // whole-chunk workspaces whatever the job's size: jobs of any size may follow
@@ -188,6 +197,37 @@ static void lookahead(zk_ctx* c, size_t ji, uint64_t horizon) {
         if (Q->next_s1() < Q->nchunks()) break;
     }
 }
+// ZK_STREAM_DEBUG=1: host-side timeline of the queue on stderr (ms since the first submit) plus, per chunk, GPU timestamps of the
+// end of stage 1, the end of stage 2 and the end of its last copy
+struct StreamDbg {
+    bool on = false;
+    double t0 = 0;
+    hipEvent_t g0 = nullptr;
+    struct Rec {
+        uint64_t gchunk;
+        uint32_t lane, cnt;
+        hipEvent_t s1, s2, cp;
+    };
+    std::vector<Rec> recs;
+    static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    double ms() const { return now() - t0; }
+};
+static StreamDbg g_dbg;
+static void dbg_start(zk_ctx* c) {
+    if (g_dbg.g0 || !getenv("ZK_STREAM_DEBUG")) return;
+    g_dbg.on = true, g_dbg.t0 = StreamDbg::now();
+    hipEventCreate(&g_dbg.g0);
+    hipEventRecord(g_dbg.g0, c->pl[0].stream);
+}
+static void dbg_flush() {
+    for (auto& r : g_dbg.recs) {
+        float a = 0, b = 0, d = 0;
+        hipEventElapsedTime(&a, g_dbg.g0, r.s1), hipEventElapsedTime(&b, g_dbg.g0, r.s2), hipEventElapsedTime(&d, g_dbg.g0, r.cp);
+        fprintf(stderr, "gpu: chunk %3llu lane %u %6u proofs  stage1 done %8.1f  stage2 done %8.1f  copies done %8.1f ms\n", (unsigned long long)r.gchunk, r.lane, r.cnt, a, b, d);
+        hipEventDestroy(r.s1), hipEventDestroy(r.s2), hipEventDestroy(r.cp);
+    }
+    g_dbg.recs.clear();
+}
 static void drive(zk_ctx* c, zk_job* upto, uint32_t ahead) {
     const uint32_t NL = c->lanes;
     bool past = false;
@@ -200,8 +240,21 @@ static void drive(zk_ctx* c, zk_job* upto, uint32_t ahead) {
             }
             lookahead(c, ji, J->lane_base() + J->next_s2() + NL);   // global chunks below that may have their stage 1 enqueued
             if (J->all_enqueued) break;
-            zk_status zs = J->stage2(J->next_s2());
+            const uint64_t k2 = J->next_s2();
+            const uint32_t lane2 = (uint32_t)((J->lane_base() + k2) % NL);
+            StreamDbg::Rec rec{J->lane_base() + k2, lane2, J->kind ? J->vj.plan[k2].cnt : J->pj.plan[k2].cnt, nullptr, nullptr, nullptr};
+            if (g_dbg.on) {
+                hipEventCreate(&rec.s1), hipEventCreate(&rec.s2), hipEventCreate(&rec.cp);
+                hipEventRecord(rec.s1, c->pl[lane2].stream);
+                fprintf(stderr, "host %8.1f ms: stage2 of global chunk %llu (lane %u) begins\n", g_dbg.ms(), (unsigned long long)rec.gchunk, lane2);
+            }
+            zk_status zs = J->stage2(k2);
             J->next_s2()++;
+            if (g_dbg.on) {
+                hipEventRecord(rec.s2, c->pl[lane2].stream), hipEventRecord(rec.cp, c->pl[lane2].copy_stream);
+                g_dbg.recs.push_back(rec);
+                fprintf(stderr, "host %8.1f ms: stage2 of global chunk %llu enqueued\n", g_dbg.ms(), (unsigned long long)rec.gchunk);
+            }
             if (zs) job_fail(J, zs);
         }
         if (J->next_s2() >= J->nchunks()) J->all_enqueued = true;
@@ -220,8 +273,17 @@ static zk_status wait_common(zk_ctx* c, zk_job* j) {
         return ZK_E_ARG;
     }
     HIPCHK(c, hipSetDevice(c->device));
+    if (g_dbg.on) fprintf(stderr, "host %8.1f ms: wait begins\n", g_dbg.ms());
     drive(c, j, c->lanes - 1 ? c->lanes - 1 : 0);
+    if (g_dbg.on) fprintf(stderr, "host %8.1f ms: wait blocks on the job's completion\n", g_dbg.ms());
     hipError_t e = j->finisher_enqueued ? hipEventSynchronize(j->done) : hipSuccess;
+    if (g_dbg.on) {
+        fprintf(stderr, "host %8.1f ms: job complete\n", g_dbg.ms());
+        if (c->jobs.size() == 1) {
+            for (uint32_t l = 0; l < c->lanes; l++) hipStreamSynchronize(c->pl[l].stream), hipStreamSynchronize(c->pl[l].copy_stream);
+            dbg_flush();
+        }
+    }
     if (j->result != ZK_OK || e != hipSuccess) {   // leave nothing of this job running: its buffers go back to the pool
         for (uint32_t l = 0; l < c->lanes; l++) hipStreamSynchronize(c->pl[l].stream), hipStreamSynchronize(c->pl[l].copy_stream);
         hipStreamSynchronize(c->fin_stream), hipStreamSynchronize(c->copy_stream);
@@ -254,6 +316,8 @@ extern "C" zk_status zk_prove_submit(zk_ctx* c, uint64_t B, const uint8_t* msg, 
     }
     zk_status zs = stream_common(c, 0);
     if (zs) return zs;
+    dbg_start(c);
+    if (g_dbg.on) fprintf(stderr, "host %8.1f ms: prove submit of %llu proofs\n", g_dbg.ms(), (unsigned long long)B);
     const size_t rng_bytes = rng->mode == ZK_RNG_SEED ? 32 * B : 32 * B * rng->stride_blocks;
     const uint64_t cap_dev = std::min<uint64_t>(out_cap, zk_proof_max_size(c) * B);
     zk_job* j = new zk_job();
