@@ -126,6 +126,12 @@ zk_status zk_ctx_set_slice(zk_ctx *ctx, uint32_t proofs);
  * cost of a few milliseconds, hence the threshold.  0 = never, 1 = always.  (ZKATTEST_VERIFY_BATCH) */
 zk_status zk_ctx_set_batch_verify(zk_ctx *ctx, uint32_t min_chunk);
 
+/* The verifier's ring fold (verifyMembership's total, src/proofGK/gk.ts:239-250): 1 (default) = the 8 low index bits of every
+ * block of 256 keys as int8 matrix products on the matrix cores (v_mfma_i32_16x16x64_i8; rings of at least 4096 keys), 0 = the
+ * 64-bit multiply-add form on the vector ALU.  Exact integer arithmetic either way: same totals, same verdicts.  Takes effect
+ * with the next verify call.  (ZKATTEST_GK_MFMA) */
+zk_status zk_ctx_set_ring_fold(zk_ctx *ctx, uint32_t matrix_pipe);
+
 /* Upper bound of one proof's ZKA1 size for the current params/ring. */
 uint64_t zk_proof_max_size(const zk_ctx *ctx);
 

@@ -268,3 +268,34 @@ def test_offsets_that_run_backwards_are_an_argument_error():
     _, ok, st = eng.verify_batch_host_raw(msg, buf, off, 3)
     assert list(ok) == [1, 1, 1] and list(st) == [0, 0, 0]
     eng.close()
+
+
+@pytest.mark.parametrize('nkeys,B', [(4096, 37), (8192, 300), (65536, 1029)])
+def test_ring_fold_on_the_matrix_pipe_equals_the_vector_form(nkeys, B):
+    """verifyMembership's total (gk.ts:239-250) through v_mfma_i32_16x16x64_i8 (k_gk_mfma.hip: balanced base-256 digits, exact
+    int32 accumulation, the same final reduction) against the 64-bit multiply-add form: identical verdicts and statuses for
+    honest proofs, forged membership responses and a proof made for another ring position; batch sizes that leave ragged tiles."""
+    import zkp_ecdsa_amd as Z
+    eng = Z.Engine(0)
+    eng.set_comb_bits(16)
+    params = eng.synth_params(1212)
+    eng.set_params(*params, 80)
+    ring, msg, sig, pk, which, seeds = eng.synth_workload(1212, nkeys, B)
+    eng.set_ring(ring, nkeys)
+    eng.set_chunk(512)
+    proofs, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert st == [0] * B
+    bad = list(proofs)
+    for b, pos in ((1, -9), (B // 2, -40), (B - 1, -9 - 32 * 3)):     # zd, a zb / za / f response of the GK proof
+        f = bytearray(proofs[b])
+        f[pos] ^= 0x20
+        bad[b] = bytes(f)
+    vs = _vseeds(B)
+    got = {}
+    for pipe in (0, 1):
+        eng.set_ring_fold(pipe)
+        got[pipe] = (eng.verify_batch(msg, proofs, vseeds=vs), eng.verify_batch(msg, bad, vseeds=vs))
+    assert got[0] == got[1]
+    assert got[1][0] == ([1] * B, [0] * B)
+    assert [b for b in range(B) if not got[1][1][0][b]] == sorted({1, B // 2, B - 1})
+    eng.close()

@@ -81,6 +81,7 @@ static zk_status ctx_init(zk_ctx* c, int device_id) {
         if (b >= 8 && b <= TOM_MAX_BITS) c->tom_bits = (uint32_t)b;
     }
     if (const char* e = getenv("ZKATTEST_GK_TABLE")) c->gk_table = atoi(e) != 0;
+    if (const char* e = getenv("ZKATTEST_GK_MFMA")) c->gk_mfma = atoi(e) != 0;
     if (const char* e = getenv("ZKATTEST_VERIFY_BATCH")) c->verify_batch_min = (uint32_t)atoi(e);
     if (const char* e = getenv("ZKATTEST_LANES")) {
         int l = atoi(e);
@@ -122,6 +123,7 @@ extern "C" void zk_ctx_destroy(zk_ctx* c) {
     stream_release_spares(c);
     for (auto e : c->epool) hipEventDestroy(e);
     hipFree(c->P.tom_tab_g), hipFree(c->P.tom_tab_h), hipFree(c->tom_tab_gen), hipFree(c->P.pfix_G), hipFree(c->P.pfix_H);
+    hipFree(c->gk_kdig);
     hipFree(c->tab_scratch), hipFree(c->gk_etab), hipFree(c->d_flag), hipFree(c->ring_mem), hipFree(c->ring_digest);
     hipFree(c->io_buf), hipFree(c->in_buf);
     for (int l = 0; l < ZK_MAX_LANES; l++) {
@@ -209,6 +211,12 @@ static zk_status set_ring_common(zk_ctx* c, const uint8_t* d_keys, uint64_t nkey
         HIPCHK(c, hipMalloc(&c->gk_etab, sizeof(uint32_t) * gk_etab_words(N)));
         launch_gk_etab(c->stream, ring, (uint32_t)(N >> 8), c->gk_etab);
     }
+    if (c->gk_kdig) HIPCHK(c, hipFree(c->gk_kdig));
+    c->gk_kdig = nullptr;
+    if (c->gk_etab && n >= GKM_MINN) {   // 33 bytes per key: the verifier's ring fold on the matrix pipe (k_gk_mfma.hip)
+        HIPCHK(c, hipMalloc(&c->gk_kdig, gkm_ring_frag_bytes(N)));
+        launch_gkm_ring_digits(c->stream, ring, (uint32_t)(N >> 8), c->gk_kdig);
+    }
     {   // digest of the padded ring: what the hardened mode hashes into the membership challenge
         if (!c->ring_digest) HIPCHK(c, hipMalloc(&c->ring_digest, 32));
         uint32_t* leaves = nullptr;
@@ -261,6 +269,11 @@ extern "C" zk_status zk_ctx_set_chunk(zk_ctx* c, uint32_t chunk) {
 extern "C" zk_status zk_ctx_set_batch_verify(zk_ctx* c, uint32_t min_chunk) {
     if (!c) return ZK_E_ARG;
     c->verify_batch_min = min_chunk;
+    return ZK_OK;
+}
+extern "C" zk_status zk_ctx_set_ring_fold(zk_ctx* c, uint32_t matrix_pipe) {
+    if (!c) return ZK_E_ARG;
+    c->gk_mfma = matrix_pipe != 0;
     return ZK_OK;
 }
 extern "C" zk_status zk_ctx_set_mode(zk_ctx* c, uint32_t mode) {
@@ -336,6 +349,7 @@ static size_t carve(zk_ctx* c, Workspace& W, Soa& gk_am, uint8_t* base, uint32_t
     uint32_t T = c->gk_etab ? 8 : std::min<uint32_t>(n, 12);
     uint64_t tile_elems = (uint64_t)(T + 1) * C * (N >> T);
     W.gk_etab = c->gk_etab;
+    W.gk_kdig = c->gk_mfma ? c->gk_kdig : nullptr;
     W.gk_asub = c->gk_etab ? (uint32_t*)k.take(36 * 256 * (size_t)C) : nullptr;
     W.gk_order = (uint32_t*)k.take(4 * (size_t)C);
     W.gk_goff = (uint32_t*)k.take(4 * 264);
@@ -377,6 +391,7 @@ zk_status ensure_workspace(zk_ctx* c, uint32_t C, uint32_t nlanes) {
         }
         L.W.ring = Soa{c->ring_mem, (uint32_t)c->N};
         L.W.hardened = c->mode == ZK_MODE_HARDENED, L.W.ring_digest = c->ring_digest;
+        L.W.gk_kdig = c->gk_mfma ? c->gk_kdig : nullptr;
     }
     return ZK_OK;
 }

@@ -19,7 +19,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
     V.vd = k.list(ns * 5);
     V.gk_f = k.soa((size_t)n * C), V.gk_g = k.soa((size_t)n * C);
     V.gk_total = k.soa(C);
-    V.gk_csub = (uint32_t*)k.take(n >= GK_ETAB_MINN && n <= GK_ETAB_MAXN ? 36 * 256 * (size_t)C : 16);
+    V.gk_csub = (uint32_t*)k.take(n >= GK_ETAB_MINN && n <= GK_ETAB_MAXN ? std::max<size_t>(36 * 256 * (size_t)C, n >= GKM_MINN ? gkm_coef_frag_bytes(C) : 0) : 16);
     V.gk_swap = (uint32_t*)k.take(4 * (size_t)n * C);
     auto terms = [&](size_t cnt) {
         VTerms t{k.soa(cnt), k.soa(cnt), k.soa(cnt), k.soa(cnt), (uint32_t*)k.take(cnt * 8 * 36 * 4), (uint8_t*)k.take(cnt * 65), (uint32_t)cnt};
@@ -173,7 +173,7 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
     }
     {
         MaybeScope t(timed, c, "v_gk_total", s);
-        launch_v_gk_total(s, V, W.ring, W.gk_etab, cnt, W.N, d_proofs, d_off, first, vres, vres2);
+        launch_v_gk_total(s, V, W.ring, W.gk_etab, W.gk_kdig, cnt, W.N, d_proofs, d_off, first, vres, vres2);
     }
     {
         MaybeScope t(timed, c, "v_terms", s);

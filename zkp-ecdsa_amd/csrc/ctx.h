@@ -30,6 +30,8 @@ struct zk_ctx {
     uint32_t* ring_mem = nullptr;
     uint32_t* gk_etab = nullptr;   // per-ring table of the GK block transform (k_gk.hip); nullptr for small / huge rings
     bool gk_table = true;          // ZKATTEST_GK_TABLE=0 disables it (plain fold for every ring)
+    int8_t* gk_kdig = nullptr;     // the ring as int8 digit fragments (k_gk_mfma.hip), built with table E for rings of >= 2^12 keys
+    bool gk_mfma = true;           // verifier's ring fold on the matrix pipe where gk_kdig exists (zk_ctx_set_ring_fold, ZKATTEST_GK_MFMA)
     uint64_t N = 0, nkeys = 0;
     uint32_t n = 0;
     uint32_t* ring_digest = nullptr;   // [8] SHA-256 words of the padded ring (hardened mode), computed by every zk_ctx_set_ring

@@ -142,6 +142,7 @@ struct Workspace {
     uint32_t* gk_bufB;
     // block-transform path of the ring fold (k_gk.hip), used when the ring has a table E (9 <= n <= GK_ETAB_MAXN)
     const uint32_t* gk_etab;     // per-ring table, owned by the context (nullptr: plain fold)
+    const int8_t* gk_kdig;       // the ring as int8 digit fragments for the verifier's matrix-pipe fold (k_gk_mfma.hip; nullptr: VALU fold)
     uint32_t* gk_asub;           // [C][256][9] products of the a_j over the subsets of the 8 low bits
     uint32_t* gk_order;          // [C] proofs sorted by the 8 low bits of their ring index
     uint32_t* gk_goff;           // [257] group offsets of that order
@@ -211,7 +212,13 @@ void launch_v_exp_points(hipStream_t s, const Workspace& W, const VWork& V, uint
 void launch_v_t1_scalars(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_derived(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
-void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, const uint32_t* etab, uint32_t count, uint32_t N, const uint8_t* proofs, const uint64_t* off, uint64_t first, const Soa& res, const Soa& res2);
+void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, const uint32_t* etab, const int8_t* kdig, uint32_t count, uint32_t N, const uint8_t* proofs, const uint64_t* off, uint64_t first, const Soa& res, const Soa& res2);
+// k_gk_mfma.hip: the 8 low index bits of the verifier's ring fold as int8 matrix products (rings of at least 2^12 keys)
+#define GKM_MINN 12
+size_t gkm_ring_frag_bytes(uint64_t N);
+size_t gkm_coef_frag_bytes(uint32_t C);
+void launch_gkm_ring_digits(hipStream_t s, const Soa& ring, uint32_t nblocks, int8_t* frag);
+void launch_v_gk_block_mfma(hipStream_t s, const VWork& V, const int8_t* ring_frag, uint32_t nblocks, uint32_t count, int8_t* coef_frag, const Soa& res);
 void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first);
 void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out,
                      const uint32_t* perm, const uint32_t* cnt, uint32_t tsplit = 1, uint32_t ostride = 1);
@@ -355,6 +362,35 @@ __device__ inline Fe<M, 2> block_inverse(const Fe<M, 2>& acc, uint32_t* lds) {
     return (get(P, 0) * left) * right;
 }
 #endif
+
+// Montgomery reduction of an 18-limb radix-2^30 integer T < q * 2^270: returns T / 2^270 mod q, < 2q.
+ZK_DEV Fe<ModQ, 2> redc_wide(const uint32_t T[2 * NLIMB]) {
+    uint64_t acc = 0;
+    uint32_t m[NLIMB];
+    Fe<ModQ, 2> r;
+#pragma unroll
+    for (int k = 0; k < NLIMB; k++) {
+        acc += T[k];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc = mad64(m[i], ModQ::mod[k - i], acc);
+        m[k] = ((uint32_t)acc * ModQ::n0) & LIMB_MASK;
+        acc = mad64(m[k], ModQ::mod[0], acc);
+        acc >>= LIMB_BITS;
+    }
+#pragma unroll
+    for (int k = NLIMB; k < 2 * NLIMB; k++) {
+        acc += T[k];
+#pragma unroll
+        for (int i = k - (NLIMB - 1); i < NLIMB; i++) acc = mad64(m[i], ModQ::mod[k - i], acc);
+        if (k < 2 * NLIMB - 1) {
+            r.l[k - NLIMB] = (uint32_t)acc & LIMB_MASK;
+            acc >>= LIMB_BITS;
+        } else {
+            r.l[NLIMB - 1] = (uint32_t)acc;
+        }
+    }
+    return r;
+}
 
 // list B is item-fastest: slot k of item i lives at k * items_cap + i (coalesced for every per-item kernel)
 ZK_DEV uint32_t lbi(const Workspace& W, uint32_t item, uint32_t k) { return k * W.items_cap + item; }

@@ -73,35 +73,6 @@ ZK_DEV void limbs_repack(uint32_t* out, const uint32_t* in) {
             buf >>= OUT_BITS;
         }
 }
-// Montgomery reduction of an 18-limb radix-2^30 integer T < q * 2^270: returns T / 2^270 mod q, < 2q.
-ZK_DEV Fe<ModQ, 2> redc_wide(const uint32_t T[2 * NLIMB]) {
-    uint64_t acc = 0;
-    uint32_t m[NLIMB];
-    Fe<ModQ, 2> r;
-#pragma unroll
-    for (int k = 0; k < NLIMB; k++) {
-        acc += T[k];
-#pragma unroll
-        for (int i = 0; i < k; i++) acc = mad64(m[i], ModQ::mod[k - i], acc);
-        m[k] = ((uint32_t)acc * ModQ::n0) & LIMB_MASK;
-        acc = mad64(m[k], ModQ::mod[0], acc);
-        acc >>= LIMB_BITS;
-    }
-#pragma unroll
-    for (int k = NLIMB; k < 2 * NLIMB; k++) {
-        acc += T[k];
-#pragma unroll
-        for (int i = k - (NLIMB - 1); i < NLIMB; i++) acc = mad64(m[i], ModQ::mod[k - i], acc);
-        if (k < 2 * NLIMB - 1) {
-            r.l[k - NLIMB] = (uint32_t)acc & LIMB_MASK;
-            acc >>= LIMB_BITS;
-        } else {
-            r.l[NLIMB - 1] = (uint32_t)acc;
-        }
-    }
-    return r;
-}
-
 // ---------------------------------------------------------------- per-ring table E (zk_ctx_set_ring)
 // E[((l_low * 256 + rank(S)) * 9 + limb) * nblocks + block] = limb of D_S(l_low) for that block, canonical, 29-bit limbs.
 __global__ void __launch_bounds__(256) k_gk_etab(Soa ring, uint32_t nblocks, uint32_t* E) {

@@ -628,7 +628,7 @@ __global__ void k_v_gk_small(VWork V, Soa ring, uint32_t count) {
     }
     soa_st(V.gk_total, p, v_gk_scale(V, p, v[0]));
 }
-void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, const uint32_t* etab, uint32_t count, uint32_t N, const uint8_t* proofs, const uint64_t* off, uint64_t first, const Soa& res, const Soa& res2) {
+void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, const uint32_t* etab, const int8_t* kdig, uint32_t count, uint32_t N, const uint8_t* proofs, const uint64_t* off, uint64_t first, const Soa& res, const Soa& res2) {
     uint32_t nt = count * V.n;
     hipLaunchKernelGGL(k_v_gk_fg, dim3((nt + 255) / 256), dim3(256), 0, s, V, count, proofs, off, first);
     if (V.n < 3) {
@@ -636,7 +636,8 @@ void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, const uin
         return;
     }
     uint32_t T = etab ? 8 : V.n < VGK_T ? V.n : VGK_T, ntiles = N >> T;
-    if (etab) launch_v_gk_block_stage(s, V, etab, ntiles, count, V.gk_csub, res);  // 8 low index bits through table E (k_gk.hip)
+    if (etab && kdig && V.n >= GKM_MINN) launch_v_gk_block_mfma(s, V, kdig, ntiles, count, (int8_t*)V.gk_csub, res);   // the same sums as int8 matrix products (k_gk_mfma.hip)
+    else if (etab) launch_v_gk_block_stage(s, V, etab, ntiles, count, V.gk_csub, res);  // 8 low index bits through table E (k_gk.hip)
     else if (V.n >= 5) hipLaunchKernelGGL(k_v_gk_tile<5>, dim3(count * ntiles), dim3(256), 0, s, V, ring, T, ntiles, res);
     else hipLaunchKernelGGL(k_v_gk_tile<3>, dim3(count * ntiles), dim3(256), 0, s, V, ring, T, ntiles, res);
     Soa src = res, dst = res2;
