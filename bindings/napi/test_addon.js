@@ -69,6 +69,11 @@ async function cpu(goldenPath) {
     other[other.length - 1] ^= 1
     assert.ok(!proof.eq(new SignatureProofList(other)))
     assert.throws(() => readJson(SignatureProofList, text.slice(0, -1)), /error deserializing/)
+    // the batch converters: the same texts, the same proofs, a malformed item does not disturb its neighbours
+    const texts = await zk.writeJsonBatch([proof, proof.bytes.slice(0, -4), proof], 2)
+    assert.deepStrictEqual(texts, [text, null, text])
+    const back = await zk.readJsonBatch([text, text.slice(0, -1), Buffer.from(text)])
+    assert.ok(back[0].eq(proof) && back[1] === null && back[2].eq(proof))
     // hardened parameters: derived, not drawn -- the same every time, on the curves, different per tag
     const hp = zk.generateParamsListHardened(), hp2 = zk.generateParamsListHardened(80)
     assert.ok(hp.eq(hp2) && hp.hardened && !hp.eq(zk.generateParamsListHardened(80, Buffer.from('x'))))

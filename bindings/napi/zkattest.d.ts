@@ -38,6 +38,9 @@ export function verifySignatureListBatch(params: SystemParametersList, msgHashes
 type Newable<T> = new (...args: any[]) => T
 export function writeJson<T>(type: Newable<T>, object: T): string
 export function readJson<T>(type: Newable<T>, text: string): T
+/** whole batches on every host core, off the event loop; null where an item is malformed */
+export function writeJsonBatch(proofs: (SignatureProofList | Buffer)[], threads?: number): Promise<(string | null)[]>
+export function readJsonBatch(texts: (string | Buffer)[], threads?: number): Promise<(SignatureProofList | null)[]>
 /** closes every cached GPU context (they are keyed by SystemParametersList content and device list) */
 export function shutdown(): void
 export interface EngineParams { nistH: Buffer; tomG: Buffer; tomH: Buffer; secLevel?: number }

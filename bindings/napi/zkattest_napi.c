@@ -595,6 +595,92 @@ static napi_value KeysToInts(napi_env env, napi_callback_info info) { /* (h, pk:
     return st == ZK_OK ? o : throw_text(env, st, zk_last_error(ctx));
 }
 
+/* ---- whole batches of proofs <-> JSON texts on every host core (zk_proofs_to_json_batch / zk_proofs_from_json_batch), off the event
+ * loop: (blob: Buffer, offsets: Buffer of n + 1 u64 LE, threads) -> Promise<{ blob, offsets, status }>.  `to` = 1: ZKA1 -> JSON. */
+typedef struct {
+    int to;
+    uint64_t n;
+    uint8_t *in;
+    uint64_t *in_off;
+    uint32_t threads;
+    uint8_t *out;
+    uint64_t out_cap, *out_off;
+    int32_t *status;
+    zk_status rc;
+    napi_ref in_ref, off_ref;
+    napi_deferred deferred;
+    napi_async_work work;
+} JsonJob;
+static void json_job_free(napi_env env, JsonJob *j) {
+    if (j->in_ref) napi_delete_reference(env, j->in_ref);
+    if (j->off_ref) napi_delete_reference(env, j->off_ref);
+    free(j->out), free(j->out_off), free(j->status), free(j);
+}
+static void json_execute(napi_env env, void *data) { /* worker thread: no N-API calls */
+    JsonJob *j = data;
+    for (int pass = 0; pass < 2; pass++) {
+        j->rc = j->to ? zk_proofs_to_json_batch(j->n, j->in, j->in_off, (char *)j->out, j->out_cap, j->out_off, j->status, j->threads)
+                      : zk_proofs_from_json_batch(j->n, (const char *)j->in, j->in_off, j->out, j->out_cap, j->out_off, j->status, j->threads);
+        if (j->rc != ZK_E_BUFFER) break;
+        free(j->out);                       /* the offsets are complete: come back with the exact size */
+        j->out_cap = j->out_off[j->n] + 64;
+        j->out = malloc(j->out_cap);
+        if (!j->out) break;
+    }
+}
+static void json_complete(napi_env env, napi_status status, void *data) { /* main thread */
+    JsonJob *j = data;
+    napi_value v = NULL, b = NULL;
+    if (status == napi_ok && j->rc == ZK_OK && napi_create_object(env, &v) == napi_ok) {
+        uint64_t len = j->out_off[j->n];
+        if (napi_create_external_buffer(env, (size_t)len, j->out, slab_finalize, NULL, &b) == napi_ok) j->out = NULL; /* ownership moved */
+        else b = new_buffer(env, j->out, (size_t)len);
+        set_prop(env, v, "blob", b);
+        set_prop(env, v, "offsets", new_buffer(env, j->out_off, 8 * (j->n + 1)));
+        set_prop(env, v, "status", new_buffer(env, j->status, 4 * j->n));
+        napi_resolve_deferred(env, j->deferred, v);
+    } else {
+        napi_value msg, e;
+        napi_create_string_utf8(env, "batch JSON conversion failed", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &e);
+        napi_reject_deferred(env, j->deferred, e);
+    }
+    napi_delete_async_work(env, j->work);
+    json_job_free(env, j);
+}
+static napi_value json_batch(napi_env env, napi_callback_info info, int to) {
+    napi_value argv[3], promise, rn;
+    if (!get_args(env, info, 3, argv)) return NULL;
+    uint8_t *in, *off;
+    size_t li, lo;
+    uint32_t threads = 0;
+    if (!get_bytes(env, argv[0], &in, &li) || !get_bytes(env, argv[1], &off, &lo) || napi_get_value_uint32(env, argv[2], &threads) != napi_ok || lo < 8 || lo % 8) {
+        napi_throw_type_error(env, NULL, "expected (blob: Buffer, offsets: Buffer of n + 1 u64, threads: number)");
+        return NULL;
+    }
+    JsonJob *j = calloc(1, sizeof *j);
+    if (!j) return throw_text(env, ZK_E_BUFFER, "out of memory");
+    j->to = to, j->n = lo / 8 - 1, j->in = in, j->in_off = (uint64_t *)off, j->threads = threads;
+    if (j->in_off[j->n] > li) {
+        free(j);
+        napi_throw_range_error(env, NULL, "offsets run past the blob");
+        return NULL;
+    }
+    j->out_cap = to ? 4 * (uint64_t)li + 4096 * (j->n + 1) : (uint64_t)li / 3 + 64 * (j->n + 1);
+    j->out = malloc(j->out_cap), j->out_off = malloc(8 * (j->n + 1)), j->status = malloc(4 * (j->n ? j->n : 1));
+    if (!j->out || !j->out_off || !j->status || napi_create_reference(env, argv[0], 1, &j->in_ref) != napi_ok ||
+        napi_create_reference(env, argv[1], 1, &j->off_ref) != napi_ok || napi_create_promise(env, &j->deferred, &promise) != napi_ok ||
+        napi_create_string_utf8(env, to ? "zkattest:toJsonBatch" : "zkattest:fromJsonBatch", NAPI_AUTO_LENGTH, &rn) != napi_ok ||
+        napi_create_async_work(env, NULL, rn, json_execute, json_complete, j, &j->work) != napi_ok || napi_queue_async_work(env, j->work) != napi_ok) {
+        json_job_free(env, j);
+        napi_throw_error(env, NULL, "could not queue the conversion");
+        return NULL;
+    }
+    return promise;
+}
+static napi_value ProofsToJsonBatch(napi_env env, napi_callback_info info) { return json_batch(env, info, 1); }
+static napi_value ProofsFromJsonBatch(napi_env env, napi_callback_info info) { return json_batch(env, info, 0); }
+
 static napi_value Init(napi_env env, napi_value exports) {
     static const struct {
         const char *name;
@@ -603,7 +689,8 @@ static napi_value Init(napi_env env, napi_value exports) {
                {"setParams", SetParams},         {"setRing", SetRing},               {"synthParams", SynthParams}, {"synthWorkload", SynthWorkload},
                {"proveBatch", ProveBatch},       {"verifyBatch", VerifyBatch},       {"proveBatchAsync", ProveBatchAsync},
                {"verifyBatchAsync", VerifyBatchAsync}, {"proofToJson", ProofToJson}, {"proofFromJson", ProofFromJson},
-               {"keysToInts", KeysToInts},       {"hostAlloc", HostAlloc},           {"hardenedH", HardenedH}};
+               {"keysToInts", KeysToInts},       {"hostAlloc", HostAlloc},           {"hardenedH", HardenedH},
+               {"proofsToJsonBatch", ProofsToJsonBatch}, {"proofsFromJsonBatch", ProofsFromJsonBatch}};
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;
         if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;

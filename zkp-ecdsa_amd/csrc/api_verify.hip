@@ -2,7 +2,7 @@
 #include "ctx.h"
 #include "jobs.h"
 
-static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, uint32_t C, uint32_t sec, uint32_t n, uint64_t N) {
+static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, uint32_t C, uint32_t sec, uint32_t n, uint64_t N, bool want_msm) {
     Carver k(base);
     V.C = C, V.sec = sec, V.n = n;
     V.st = (int32_t*)k.take(4 * (size_t)C);
@@ -38,7 +38,8 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
     V.pa_tab = (uint32_t*)k.take(ns * 8 * RTAB_ENTRY_WORDS * 4), V.pa_dig = (uint8_t*)k.take(ns * 33);
     V.pacc = k.soa3((size_t)C * 4);
     V.clx = k.soa(C), V.cly = k.soa(C);
-    {   // batched Tom check (k_msm.hip)
+    M = MsmBuf{};
+    if (want_msm) {   // batched Tom check (k_msm.hip): ~1.5 GB per lane, only where chunks are large enough to use it
         size_t cap = ns * V_SLOT_TERMS + (size_t)C * nq * 8 + (size_t)C * 3;
         M.cap = (uint32_t)cap;
         M.aos = (uint32_t*)k.take(cap * 128);
@@ -63,21 +64,22 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
 }
 zk_status ensure_vworkspace(zk_ctx* c, uint32_t C, uint32_t nlanes) {
     uint32_t sec = c->P.sec, n = c->n;
-    if (!(c->vs_C == C && c->vs_sec == sec && c->vs_n == n)) {
+    const bool want_msm = c->verify_batch_min && C >= c->verify_batch_min;   // the chunk-wide sums never run on smaller chunks
+    if (!(c->vs_C == C && c->vs_sec == sec && c->vs_n == n && c->vs_msm == want_msm)) {
         for (auto& L : c->vl) L.ready = false;
-        c->vs_C = C, c->vs_sec = sec, c->vs_n = n;
+        c->vs_C = C, c->vs_sec = sec, c->vs_n = n, c->vs_msm = want_msm;
     }
     for (uint32_t l = 0; l < nlanes && l < ZK_MAX_LANES; l++) {
         auto& L = c->vl[l];
         if (L.ready) continue;
-        size_t need = vcarve(L.V, L.res, L.res2, L.M, nullptr, C, sec, n, c->N);
+        size_t need = vcarve(L.V, L.res, L.res2, L.M, nullptr, C, sec, n, c->N, want_msm);
         if (need > L.arena_bytes) {
             if (L.arena) HIPCHK(c, hipFree(L.arena));
             L.arena = nullptr, L.arena_bytes = 0;
             HIPCHK(c, hipMalloc(&L.arena, need));
             L.arena_bytes = need;
         }
-        vcarve(L.V, L.res, L.res2, L.M, (uint8_t*)L.arena, C, sec, n, c->N);
+        vcarve(L.V, L.res, L.res2, L.M, (uint8_t*)L.arena, C, sec, n, c->N, want_msm);
         if (!L.h_msm) HIPCHK(c, hipHostMalloc((void**)&L.h_msm, 256, hipHostMallocMapped | hipHostMallocCoherent));
         L.M.host = L.h_msm;
         L.ready = true;
@@ -231,7 +233,7 @@ zk_status VerifyJob::stage2(uint64_t chunk_no) {
     // Tom-256 relations: one bucket-method sum per group of the chunk's proofs (MSM_G groups, one pass); the per-proof
     // windowed sums only run for the groups whose total is not the identity -- some proof of theirs is bad -- to tell which
     uint32_t flags[MSM_G], gsz = cnt;
-    if (c->verify_batch_min && cnt >= c->verify_batch_min) {
+    if (c->verify_batch_min && cnt >= c->verify_batch_min && M.cap) {
         MaybeScope t(timed, c, "v_msm_tom", s);
         hipError_t e = run_msm(s, P, W, V, cnt, nq, M, flags, &gsz);
         if (e != hipSuccess) {

@@ -68,6 +68,7 @@ struct zk_ctx {
         bool ready = false;
     } vl[ZK_MAX_LANES];
     uint32_t vs_C = 0, vs_sec = 0, vs_n = 0;
+    bool vs_msm = false;          // the lanes' workspaces hold the buffers of the batched Tom check
     uint32_t verify_batch_min = 256;   // zk_ctx_set_batch_verify: chunks of at least this many proofs get the batched check (0 = never)
     // host-buffer entry points: DMA stream for page-locked caller buffers (zk_host_alloc), one event per lane
     hipStream_t copy_stream = nullptr;

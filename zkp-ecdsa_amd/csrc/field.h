@@ -38,12 +38,27 @@ struct Fe {
     }
 };
 
+// ZK_PAR_CARRY=1 (experiment, per translation unit): ONE parallel carry step instead of the ripple -- every limb hands its excess
+// to its neighbour at once, so the eight steps do not depend on each other.  The result is "nearly normalised" (limbs <= 2^30 + 2
+// after a difference of three operands): fine as a product operand (the column bound of tools/radix_budget.py moves by 2^-28) and as
+// an operand of another sum, NOT for fe_canon / comparisons -- only translation units that canonicalise product outputs may use it.
+#ifndef ZK_PAR_CARRY
+#define ZK_PAR_CARRY 0
+#endif
 ZK_DEV void limbs_normalize(uint32_t r[NLIMB]) {
+#if ZK_PAR_CARRY
+    uint32_t c[NLIMB - 1];
+#pragma unroll
+    for (int i = 0; i < NLIMB - 1; i++) c[i] = r[i] >> LIMB_BITS, r[i] &= LIMB_MASK;
+#pragma unroll
+    for (int i = 0; i < NLIMB - 1; i++) r[i + 1] += c[i];
+#else
 #pragma unroll
     for (int i = 0; i < NLIMB - 1; i++) {
         r[i + 1] += r[i] >> LIMB_BITS;
         r[i] &= LIMB_MASK;
     }
+#endif
 }
 
 template <class M, int Ka, int Kb>
