@@ -31,6 +31,10 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 # 36.66 and 37.11 T/s were measured on two boxes of the pool in round 1 (37.28-37.36 T/s sustained over 2 s in round 2); the
 # denominator stays 37.11 so that the fractions of the two rounds compare
 VALU_MAD_PEAK_TOPS = 37.11
+# the same instruction at the kernel's OWN parallelism: 4 lock-step chains per wave x 2 waves per SIMD (212 VGPRs) = 8 independent
+# accumulator chains per SIMD issue at 5.7 cycles per wave-instruction (tools/valu_peak.hip "NACC= 4 waves/SIMD=2",
+# profiles/r03_valu_peak_microbench.txt: 27.83 T/s; 16 chains 31.9, 64 chains 36.3, 128 chains 37.2)
+VALU_MAD_8CHAIN_TOPS = 27.83
 HBM_PEAK_GBPS = 8000.0
 # multiplier-pipe instructions (v_mad_u64_u32 + v_mul_lo_u32) per Tom-field Montgomery product: 1224 + 72 per table addition
 # of 8 products in k_tom_commit (tools/isa_blocks.py; nominal 171 = 81 + 81 + 9, the modulus limb that is zero costs nothing);
@@ -721,6 +725,9 @@ def main():
             'kernel': 'k_tom_commit',
             'achieved': round(achieved_tmacs, 3), 'peak': VALU_MAD_PEAK_TOPS, 'unit': 'T multiplier-instr/s (v_mad_u64_u32 + v_mul_lo_u32 lane-ops, peak measured by tools/valu_peak.hip)',
             'frac': round(achieved_tmacs / VALU_MAD_PEAK_TOPS, 4),
+            'frac_of_rate_at_kernel_ilp': round(achieved_tmacs / VALU_MAD_8CHAIN_TOPS, 4),
+            'rate_at_kernel_ilp': {'value': VALU_MAD_8CHAIN_TOPS, 'note': 'v_mad_u64_u32 microbenchmark at 8 independent chains per SIMD (4 per wave x 2 waves: what 212 VGPRs allow); '
+                                   'the kernel issues 1.39 VALU instructions per multiplier instruction on top (profiles/r03_valu_peak_microbench.txt, DESIGN.md section 8)'},
             'traffic': int(commits_per_step / max(1, launches_per_step) * pmc_bytes) if pmc_bytes else None,
             'traffic_note': ('bytes per launch = units per launch x %d B (FETCH_SIZE + WRITE_SIZE per commitment, separate rocprofv3 --pmc passes, '
                              'profiles/r02_pmc_summary.txt); table gathers, not the 180 algorithmic bytes, dominate' % pmc_bytes) if pmc_bytes

@@ -85,6 +85,14 @@ int main() {
     run<0, 1>("v_mad_u64_u32", out, 4);
     run<0, 1>("v_mad_u64_u32", out, 8);
     run<0, 4>("v_mad_u64_u32", out, 2);
+    // independent accumulator chains per SIMD = NACC x waves/SIMD: the dependent-issue behaviour the lock-step products of
+    // k_tom_commit (4 chains per wave, 2 waves per SIMD) run into
+    run<0, 2>("v_mad_u64_u32", out, 2);
+    run<0, 8>("v_mad_u64_u32", out, 2);
+    run<0, 16>("v_mad_u64_u32", out, 2);
+    run<0, 2>("v_mad_u64_u32", out, 4);
+    run<0, 4>("v_mad_u64_u32", out, 4);
+    run<0, 8>("v_mad_u64_u32", out, 4);
     run<0, 8>("v_mad_u64_u32", out, 8);
     run<0, 16>("v_mad_u64_u32", out, 8);
     run<1, 8>("v_mul_lo_u32", out, 8);
