@@ -375,6 +375,33 @@ def run_pool_mode(args, Z):
     assert [b for b in range(B) if not ok2[b]] == forged, 'planted forgeries not (exactly) rejected'
     for b in forged:
         pin.view[off[b] + ln[b] - 9] ^= 1
+    # steady state: --host-io-stream batches back to back through zk_pool_prove_submit / zk_pool_prove_wait, F in flight per device
+    stream = None
+    if args.host_io_stream > 1:
+        try:
+            nj, F = args.host_io_stream, max(2, min(4, args.host_io_stream_inflight))
+            c_, l_, s_ = (int(x) for x in args.host_io_stream_configs.split(',')[0].split(':'))
+            for i in range(G):
+                e = pool.engine(i)
+                e.set_chunk(min(c_, Bg)), e.set_lanes(l_), e.set_slice(s_)
+            bufs = [pin] + [Z.PinnedBuffer(pin.nbytes, pool=pool) for _ in range(F - 1)]
+            for _ in range(2):
+                t0 = time.time()
+                tk = [pool.prove_submit(msg_a, sig_a, pk_a, which_a, seeds_a, bufs[k % F], pin.nbytes) for k in range(min(F, nj))]
+                for k in range(nj):
+                    so, sl, sst = pool.prove_wait(tk[k])
+                    assert not any(sst)
+                    if k + F < nj:
+                        tk.append(pool.prove_submit(msg_a, sig_a, pk_a, which_a, seeds_a, bufs[(k + F) % F], pin.nbytes))
+                dts_ = time.time() - t0
+            stream = {'batches': nj, 'in_flight': F, 'chunk': min(c_, Bg), 'lanes': l_, 'slice': s_, 'proofs_per_s': round(nj * B / dts_, 1), 'seconds': round(dts_, 4)}
+            for b_ in bufs[1:]:
+                b_.free()
+            for i in range(G):
+                e = pool.engine(i)
+                e.set_chunk(min(args.host_io_verify_chunk, Bg)), e.set_lanes(args.host_io_lanes), e.set_slice(0)
+        except Exception as e:
+            stream = {'error': repr(e)[:300]}
     cpu = None
     if not args.no_cpu_baseline:
         sample = args.cpu_sample or 4 * host_cores()
@@ -398,6 +425,7 @@ def run_pool_mode(args, Z):
         'prove_shard_ms_per_step': shard, 'verify_shard_ms': vshard, 'proof_bytes_per_step': int(nbytes), 'failed_proofs': 0,
         'accepted': int(accepted), 'of': B, 'planted_forgeries_rejected': len(forged),
         'd2h_gbps_total': round(nbytes * args.steps / total / 1e9, 2), 'h2d_gbps_total': round(nbytes / vdt / 1e9, 2), 'cpu_baseline': cpu,
+        'stream': stream, 'value_pcie_inclusive_steady': stream.get('proofs_per_s') if stream else None,
     }
     print(json.dumps(line))
     pin.free()

@@ -240,6 +240,17 @@ zk_status zk_pool_verify_batch(zk_pool *pool, uint64_t B, const uint8_t *msg_has
                                const uint64_t *proof_len /*B*/, const uint8_t *verifier_seeds /*Bx32 or NULL*/, uint8_t *ok /*B*/,
                                int32_t *per_proof_status /*B*/);
 
+/* The streamed form of the two pool calls (see "two batches in flight"): every device's shard goes through zk_prove_submit / zk_prove_wait on
+ * its own context, so a node keeps two or three batches in flight per GPU.  Same rules per device (waits in submission order, `out` /
+ * `proofs` page-locked -- zk_pool_host_alloc --, every pointer valid until the wait returns); (out_off, out_len) are filled by the wait. */
+typedef struct zk_pool_job zk_pool_job;
+zk_status zk_pool_prove_submit(zk_pool *pool, uint64_t B, const uint8_t *msg_hash, const uint8_t *sig, const uint8_t *pk_xy, const uint32_t *which, const zk_rng *rng,
+                               uint8_t *out, uint64_t out_cap, uint64_t *out_off /*B*/, uint64_t *out_len /*B*/, int32_t *per_proof_status /*B*/, zk_pool_job **job);
+zk_status zk_pool_prove_wait(zk_pool *pool, zk_pool_job *job);
+zk_status zk_pool_verify_submit(zk_pool *pool, uint64_t B, const uint8_t *msg_hash, const uint8_t *proofs, const uint64_t *proof_off /*B*/, const uint64_t *proof_len /*B*/,
+                                const uint8_t *verifier_seeds /*Bx32 or NULL*/, uint8_t *ok /*B*/, int32_t *per_proof_status /*B*/, zk_pool_job **job);
+zk_status zk_pool_verify_wait(zk_pool *pool, zk_pool_job *job);
+
 /* ---- hardened mode: the two protocol hardenings the reference leaves as TODOs, as an explicit opt-in.  NOT byte-compatible
  * with the reference: a proof made in one mode only verifies in that mode.  Default: ZK_MODE_REFERENCE (byte parity).
  *   (1) src/commit/pedersen.ts:62 "we must generate h without using scalar mult": zk_hardened_h derives NistGroup.h and

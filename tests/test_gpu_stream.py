@@ -142,3 +142,57 @@ def test_streamed_calls_enforce_their_rules():
     eng.close()
     for p in pins + [small]:
         p.free()
+
+
+def test_streamed_pool_calls_equal_the_synchronous_pool_calls():
+    """zk_pool_prove_submit / _wait and the verify pair: every device's shard streamed on its own context (two contexts on device 0
+    here), three jobs, two in flight; bytes, (offset, length) pairs and verdicts are those of zk_pool_prove_batch / zk_pool_verify_batch."""
+    import zkp_ecdsa_amd as Z
+    B, nkeys = 1500, 2048
+    pool = Z.Pool([0, 0])
+    e0 = pool.engine(0)
+    params = e0.synth_params(91)
+    for i in range(2):
+        pool.engine(i).set_comb_bits(16)
+        pool.engine(i).set_chunk(256)
+    pool.set_params(*params, 80)
+    ring, msg, sig, pk, which, seeds = e0.synth_workload(91, nkeys, B)
+    pool.set_ring(ring, nkeys)
+    jobs = [(0, 500), (500, 1100), (1100, 1500)]
+    cap = 2 * ((e0.proof_max_size() * 300 * 7 // 10 + (4 << 20)) & ~255)
+    cut = lambda a, b: (msg[32 * a:32 * b], sig[64 * a:64 * b], pk[64 * a:64 * b], which[a:b], seeds[32 * a:32 * b])
+    ref = []
+    for (a, b) in jobs:
+        pin = Z.PinnedBuffer(cap, pool=pool)
+        _, off, ln, st = pool.prove_batch_raw(*cut(a, b), pin, cap)
+        assert not any(st)
+        ref.append([bytes(pin.view[off[k]:off[k] + ln[k]]) for k in range(b - a)])
+        pin.free()
+    pins = [Z.PinnedBuffer(cap, pool=pool) for _ in jobs]
+    tk, got = [], []
+    for k, (a, b) in enumerate(jobs):
+        tk.append(pool.prove_submit(*cut(a, b), pins[k], cap))
+        if k:
+            got.append(pool.prove_wait(tk[k - 1]))
+    got.append(pool.prove_wait(tk[-1]))
+    for k, (a, b) in enumerate(jobs):
+        off, ln, st = got[k]
+        assert not any(st)
+        assert [bytes(pins[k].view[off[i]:off[i] + ln[i]]) for i in range(b - a)] == ref[k], 'job %d differs' % k
+    # verify, with a forged proof in the second shard of job 1
+    off1, ln1, _ = got[1]
+    pins[1].view[off1[450] + ln1[450] - 9] ^= 1
+    vs = [os.urandom(32 * (b - a)) for (a, b) in jobs]
+    sync = [pool.verify_batch_raw(msg[32 * a:32 * b], pins[k], got[k][0], got[k][1], b - a, vs[k])[1:] for k, (a, b) in enumerate(jobs)]
+    vt, vg = [], []
+    for k, (a, b) in enumerate(jobs):
+        vt.append(pool.verify_submit(msg[32 * a:32 * b], pins[k], got[k][0], got[k][1], b - a, vs[k]))
+        if k:
+            vg.append(pool.verify_wait(vt[k - 1]))
+    vg.append(pool.verify_wait(vt[-1]))
+    for k, (a, b) in enumerate(jobs):
+        assert (list(vg[k][0]), list(vg[k][1])) == (list(sync[k][0]), list(sync[k][1]))
+    assert [i for i in range(600) if not vg[1][0][i]] == [450] and sum(vg[0][0]) == 500 and sum(vg[2][0]) == 400
+    for p_ in pins:
+        p_.free()
+    pool.close()

@@ -20,6 +20,7 @@ SYMBOLS = [
     'zk_pool_host_alloc', 'zk_pool_host_free', 'zk_pool_numa_node', 'zk_pool_test_locality', 'zk_pool_shard_ms',
     'zk_prove_submit', 'zk_prove_wait', 'zk_verify_submit', 'zk_verify_wait', 'zk_test_counter',
     'zk_proofs_to_json_batch', 'zk_proofs_from_json_batch', 'zk_ctx_set_ring_fold',
+    'zk_pool_prove_submit', 'zk_pool_prove_wait', 'zk_pool_verify_submit', 'zk_pool_verify_wait',
     'zk_test_field_op', 'zk_test_tom_commit', 'zk_test_p256_fixed_mul', 'zk_test_sha256', 'zk_test_rng_draws',
 ]
 
@@ -113,6 +114,10 @@ def lib():
         L.zk_ctx_set_ring_fold.argtypes = [vp, u32]
         L.zk_test_counter.argtypes = [vp, i32]
         L.zk_test_counter.restype = u64
+        L.zk_pool_prove_submit.argtypes = [vp, u64, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(ZkRng), vp, u64, vp, vp, vp, C.POINTER(vp)]
+        L.zk_pool_prove_wait.argtypes = [vp, vp]
+        L.zk_pool_verify_submit.argtypes = [vp, u64, C.c_char_p, vp, vp, vp, C.c_char_p, vp, vp, C.POINTER(vp)]
+        L.zk_pool_verify_wait.argtypes = [vp, vp]
         L.zk_pool_host_alloc.argtypes = [vp, C.c_size_t]
         L.zk_pool_host_alloc.restype = vp
         L.zk_pool_host_free.argtypes = [vp]
@@ -570,6 +575,29 @@ class Pool:
         t0 = time.time()
         self._chk(self.L.zk_pool_prove_batch(self.h, B, msg, sig, pk, w, C.byref(rng), optr, cap, off, ln, st))
         return time.time() - t0, off, ln, st
+
+    # ---- streamed pool calls: tickets keep every buffer of the job alive until its wait
+    def prove_submit(self, msg, sig, pk, which, seeds, out, cap):
+        B = len(which)
+        t = {'B': B, 'out': out, 'off': (C.c_uint64 * B)(), 'ln': (C.c_uint64 * B)(), 'st': (C.c_int32 * B)(), 'w': (C.c_uint32 * B)(*which),
+             'data': C.create_string_buffer(bytes(seeds), 32 * B), 'msg': bytes(msg), 'sig': bytes(sig), 'pk': bytes(pk), 'job': C.c_void_p()}
+        t['rng'] = ZkRng(0, C.cast(t['data'], C.c_void_p), 0)
+        self._chk(self.L.zk_pool_prove_submit(self.h, B, t['msg'], t['sig'], t['pk'], t['w'], C.byref(t['rng']), out.ptr, cap, t['off'], t['ln'], t['st'], C.byref(t['job'])))
+        return t
+
+    def prove_wait(self, t):
+        self._chk(self.L.zk_pool_prove_wait(self.h, t['job']))
+        return t['off'], t['ln'], t['st']
+
+    def verify_submit(self, msg, proofs, off, ln, B, vseeds=None):
+        t = {'B': B, 'proofs': proofs, 'off': off, 'ln': ln, 'ok': (C.c_uint8 * B)(), 'st': (C.c_int32 * B)(), 'msg': bytes(msg),
+             'seeds': bytes(vseeds) if vseeds is not None else None, 'job': C.c_void_p()}
+        self._chk(self.L.zk_pool_verify_submit(self.h, B, t['msg'], proofs.ptr, off, ln, t['seeds'], t['ok'], t['st'], C.byref(t['job'])))
+        return t
+
+    def verify_wait(self, t):
+        self._chk(self.L.zk_pool_verify_wait(self.h, t['job']))
+        return t['ok'], t['st']
 
     def prove_batch(self, msg, sig, pk, which, seeds=None):
         B = len(which)

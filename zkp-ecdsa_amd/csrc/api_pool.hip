@@ -396,3 +396,100 @@ extern "C" zk_status zk_pool_verify_batch(zk_pool* p, uint64_t B, const uint8_t*
         return zk_verify_batch(p->ctx[i], cnt, msg + 32 * first, proofs + base, off.data(), vseeds ? vseeds + 32 * first : nullptr, ok + first, status + first);
     });
 }
+
+// ---- streamed pool calls: zk_prove_submit / zk_prove_wait (api_stream.hip) on every device's shard, so that a node keeps two or three
+// batches in flight per GPU.  A pool job is the set of its shards' jobs; submit runs on the caller's thread (staging the inputs is a
+// memcpy and an asynchronous upload per device), wait drives every device's queue on that device's own host thread.
+struct zk_pool_job {
+    int kind = 0;                         // 0 prove, 1 verify
+    uint64_t B = 0;
+    std::vector<zk_job*> shard;           // per device (nullptr: empty shard)
+    std::vector<std::vector<uint64_t>> off;   // per device: the shard's own offsets (prove: filled by wait; verify: input)
+    uint64_t region = 0;
+    uint64_t *out_off = nullptr, *out_len = nullptr;   // prove: where the caller wants (offset, length) per proof
+};
+static void pool_job_abandon(zk_pool* p, zk_pool_job* j) {   // a submit that failed half way: the shards already queued are waited for
+    for (size_t i = 0; i < j->shard.size(); i++)
+        if (j->shard[i]) (void)(j->kind ? zk_verify_wait(p->ctx[i], j->shard[i]) : zk_prove_wait(p->ctx[i], j->shard[i]));
+    delete j;
+}
+extern "C" zk_status zk_pool_prove_submit(zk_pool* p, uint64_t B, const uint8_t* msg, const uint8_t* sig, const uint8_t* pk, const uint32_t* which, const zk_rng* rng,
+                                          uint8_t* out, uint64_t out_cap, uint64_t* out_off, uint64_t* out_len, int32_t* status, zk_pool_job** job) {
+    if (!p || !job || !rng || !out_off || !out_len || !status || !B || !msg || !sig || !pk || !which || !rng->data || !out) return ZK_E_ARG;
+    *job = nullptr;
+    const uint64_t G = p->ctx.size();
+    zk_pool_job* j = new zk_pool_job();
+    j->B = B, j->shard.assign(G, nullptr), j->off.resize(G), j->region = (out_cap / G) & ~(uint64_t)255, j->out_off = out_off, j->out_len = out_len;
+    for (uint64_t i = 0; i < G; i++) {
+        uint64_t first, cnt;
+        zk_pool_shard(p, B, (int)i, &first, &cnt);
+        if (!cnt) continue;
+        zk_rng r = *rng;
+        r.data = rng->data + (rng->mode == ZK_RNG_SEED ? 32 * first : 32 * first * rng->stride_blocks);
+        j->off[i].assign(cnt + 1, 0);
+        zk_status zs = zk_prove_submit(p->ctx[i], cnt, msg + 32 * first, sig + 64 * first, pk + 64 * first, which + first, &r, out + j->region * i, j->region,
+                                       j->off[i].data(), status + first, &j->shard[i]);
+        if (zs) {
+            p->err = std::string("device slot ") + std::to_string(i) + ": " + zk_strerror(zs) + " " + zk_last_error(p->ctx[i]);
+            pool_job_abandon(p, j);
+            return zs;
+        }
+    }
+    *job = j;
+    return ZK_OK;
+}
+extern "C" zk_status zk_pool_prove_wait(zk_pool* p, zk_pool_job* j) {
+    if (!p || !j || j->kind != 0 || j->shard.size() != p->ctx.size()) return ZK_E_ARG;
+    zk_status zs = pool_each(p, [&](int i) -> zk_status {
+        if (!j->shard[i]) return ZK_OK;
+        zk_status s = zk_prove_wait(p->ctx[i], j->shard[i]);
+        j->shard[i] = nullptr;
+        if (s) return s;
+        uint64_t first, cnt;
+        zk_pool_shard(p, j->B, i, &first, &cnt);
+        for (uint64_t k = 0; k < cnt; k++) j->out_off[first + k] = j->region * i + j->off[i][k], j->out_len[first + k] = j->off[i][k + 1] - j->off[i][k];
+        return ZK_OK;
+    });
+    delete j;
+    return zs;
+}
+extern "C" zk_status zk_pool_verify_submit(zk_pool* p, uint64_t B, const uint8_t* msg, const uint8_t* proofs, const uint64_t* proof_off, const uint64_t* proof_len,
+                                           const uint8_t* vseeds, uint8_t* ok, int32_t* status, zk_pool_job** job) {
+    if (!p || !job || !B || !msg || !proofs || !proof_off || !proof_len || !ok || !status) return ZK_E_ARG;
+    *job = nullptr;
+    const uint64_t G = p->ctx.size();
+    zk_pool_job* j = new zk_pool_job();
+    j->kind = 1, j->B = B, j->shard.assign(G, nullptr), j->off.resize(G);
+    for (uint64_t i = 0; i < G; i++) {
+        uint64_t first, cnt;
+        zk_pool_shard(p, B, (int)i, &first, &cnt);
+        if (!cnt) continue;
+        std::vector<uint64_t>& off = j->off[i];   // lives until the job is waited for: the shard's job reads it
+        off.assign(cnt + 1, 0);
+        const uint64_t base = proof_off[first];
+        zk_status zs = base & 3 ? ZK_E_ARG : ZK_OK;
+        for (uint64_t k = 0; k < cnt && !zs; k++) {
+            if (proof_off[first + k] - base != off[k]) zs = ZK_E_ARG;   // a gap or an overlap inside the shard
+            off[k + 1] = off[k] + proof_len[first + k];
+        }
+        if (!zs) zs = zk_verify_submit(p->ctx[i], cnt, msg + 32 * first, proofs + base, off.data(), vseeds ? vseeds + 32 * first : nullptr, ok + first, status + first, &j->shard[i]);
+        if (zs) {
+            p->err = std::string("device slot ") + std::to_string(i) + ": " + zk_strerror(zs) + " " + zk_last_error(p->ctx[i]);
+            pool_job_abandon(p, j);
+            return zs;
+        }
+    }
+    *job = j;
+    return ZK_OK;
+}
+extern "C" zk_status zk_pool_verify_wait(zk_pool* p, zk_pool_job* j) {
+    if (!p || !j || j->kind != 1 || j->shard.size() != p->ctx.size()) return ZK_E_ARG;
+    zk_status zs = pool_each(p, [&](int i) -> zk_status {
+        if (!j->shard[i]) return ZK_OK;
+        zk_status s = zk_verify_wait(p->ctx[i], j->shard[i]);
+        j->shard[i] = nullptr;
+        return s;
+    });
+    delete j;
+    return zs;
+}
