@@ -160,3 +160,47 @@ def test_binary_side_mutations_never_crash_the_writer():
         back = Z.read_json(text)
         assert Z.write_json(back) == text
     assert 0 < ok < 1200
+
+
+def test_fast_path_and_tree_reader_agree_on_every_mutation(monkeypatch):
+    """The reader has a fast path for text in exactly the writer's shape (csrc/api_json.hip: literal-by-literal matching, no node
+    tree) that must never decide on its own: for every mutated text the outcome -- the proof bytes or the status -- with the fast
+    path (default) and without it (ZKATTEST_JSON_NO_FAST=1: the tolerant tree reader alone) is the same."""
+    rnd = random.Random(33)
+    texts = _texts()
+
+    def outcome(s):
+        try:
+            return Z.read_json(s)
+        except Z.ZkError as e:
+            return e.status
+
+    checked = accepted = 0
+    for it in range(600):
+        t = bytearray(rnd.choice(texts).encode())
+        for _ in range(rnd.choice((0, 1, 1, 2, 4))):
+            pos = rnd.randrange(len(t))
+            op = rnd.randrange(5)
+            if op == 0:
+                t[pos] = rnd.choice(b'0123456789abcdefx",:{}[] ')
+            elif op == 1:
+                del t[pos:pos + rnd.choice((1, 2, 64))]
+            elif op == 2:
+                t[pos:pos] = rnd.choice((b' ', b'0', b'00', b'"', b',', b'\n', b'A', b'{"a":1},'))
+            elif op == 3:   # swap two members of the top-level object: only the tree reader takes it, and it must still give the proof
+                s0 = t.decode('latin-1')
+                i = s0.find(',"comS1":')
+                j = s0.find(',"keyXcom":')
+                if 0 < i < j:
+                    t = bytearray((s0[:1] + s0[i + 1:j] + ',' + s0[1:i] + s0[j:]).encode('latin-1'))
+            else:
+                t[pos:pos + 1] = bytes([t[pos]]).upper()
+        s = t.decode('latin-1')
+        monkeypatch.delenv('ZKATTEST_JSON_NO_FAST', raising=False)
+        a = outcome(s)
+        monkeypatch.setenv('ZKATTEST_JSON_NO_FAST', '1')
+        b = outcome(s)
+        assert a == b, (it, a if isinstance(a, int) else len(a), b if isinstance(b, int) else len(b))
+        checked += 1
+        accepted += not isinstance(a, int)
+    assert checked == 600 and 0 < accepted < 600
