@@ -23,7 +23,8 @@ rocprofv3 --pmc SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ
 cd $ROOT
 python tools/rocpd_stats.py gpurun_out/prof_default/r_results.db > gpurun_out/${R}_rocprofv3_kernel_stats.csv
 python tools/rocpd_stats.py gpurun_out/prof_lanes1/r_results.db > gpurun_out/${R}_rocprofv3_kernel_stats_lanes1.csv
-python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_SQ_WAVES gpurun_out/pmc_SQ_WAIT_ANY gpurun_out/pmc_MFMA > gpurun_out/${R}_pmc_summary_body.txt
+python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_SQ_WAVES gpurun_out/pmc_SQ_WAIT_ANY > gpurun_out/${R}_pmc_summary_body.txt
+python tools/pmc_summary.py gpurun_out/pmc_MFMA > gpurun_out/${R}_pmc_mfma_body.txt   # another workload (verify, ring 2^20, 8192 proofs): its own summary
 [ -x tools/valu_peak ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/valu_peak.hip -o tools/valu_peak
 tools/valu_peak > gpurun_out/${R}_valu_peak_microbench.txt
 python tools/exp_stream_timeline.py 22016 3 8192 4 > gpurun_out/${R}_stream_timeline.txt 2>&1 || true

@@ -757,10 +757,32 @@ extern "C" zk_status zk_proof_from_json(const char* json, uint64_t len, uint8_t*
 // bench/zkpAttestList.bench.ts:63-68 times toJson / fromJson per proof; a GPU that makes 300 000 proofs per second needs the
 // converters at batch scale ("so the ~10 GB/batch host conversion is not the bottleneck").  Proofs are
 // converted in blocks: every thread converts whole proofs into its own scratch, a prefix sum places them, the threads copy them out.
+#include <sched.h>
 #include <atomic>
+#include <cstdio>
 #include <thread>
+// CPUs this process may really use: the affinity mask, capped by the cgroup v2 CPU quota (a container with 16 CPUs' worth of quota on a
+// 256-thread host reports hardware_concurrency() = 256; 256 threads on 16 CPUs' worth of time convert more slowly than 16)
+static uint32_t usable_cpus() {
+    uint32_t n = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) {
+        int c = CPU_COUNT(&set);
+        if (c > 0 && (uint32_t)c < n) n = (uint32_t)c;
+    }
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        unsigned long long period = 0;
+        if (fscanf(f, "%63s %llu", q, &period) == 2 && strcmp(q, "max") != 0 && period) {
+            unsigned long long quota = strtoull(q, nullptr, 10), c = quota / period;
+            if (c >= 1 && c < n) n = (uint32_t)c;
+        }
+        fclose(f);
+    }
+    return n ? n : 1;
+}
 static uint32_t json_threads(uint32_t want, uint64_t n) {
-    uint32_t hw = std::thread::hardware_concurrency();
+    uint32_t hw = usable_cpus();
     if (const char* e = getenv("ZKATTEST_JSON_THREADS")) hw = (uint32_t)atoi(e);
     uint32_t t = want ? want : (hw ? hw : 1);
     if (t > 256) t = 256;

@@ -233,9 +233,9 @@ extern "C" void* zk_pool_host_alloc(zk_pool* p, size_t bytes) {
         volatile uint8_t* q = (volatile uint8_t*)mem;
         for (size_t o = a / page * page; o < b; o += page) q[o] = 0;
     };
-    if (G == 1 || !p->affinity) {
+    if (!p->affinity) {
         touch(0, len);
-    } else {
+    } else {   // also for a single device: the pages belong on ITS node, wherever the calling thread happens to run
         std::vector<std::thread> th;
         for (size_t i = 0; i < G; i++)
             th.emplace_back([&, i] {
