@@ -120,11 +120,16 @@ zk_status zk_ctx_set_slice(zk_ctx *ctx, uint32_t proofs);
 
 /* Verifier strategy for the Tom-256 relations: in a chunk of at least min_chunk proofs (default 256) the relations of ALL
  * proofs are checked with one bucket-method multi-scalar sum (independent 128-bit multipliers per relation and per proof);
- * a chunk is cut into 8 contiguous groups of proofs whose sums come out of the same pass, and only the groups whose sum is not
- * the identity -- some proof of theirs is bad -- go through the per-proof sums to tell which.  ok[] and the statuses are the same
- * either way; a forged proof costs the per-proof sums of its group (an eighth of the chunk), and the chunk-wide sum has a fixed
+ * a chunk is cut into 8 (or 64: zk_ctx_set_verify_groups) contiguous groups of proofs whose sums come out of the same pass, and only
+ * the groups whose sum is not the identity -- some proof of theirs is bad -- go through the per-proof sums to tell which.  ok[] and the
+ * statuses are the same either way; a forged proof costs the per-proof sums of its group, and the chunk-wide sum has a fixed
  * cost of a few milliseconds, hence the threshold.  0 = never, 1 = always.  (ZKATTEST_VERIFY_BATCH) */
 zk_status zk_ctx_set_batch_verify(zk_ctx *ctx, uint32_t min_chunk);
+/* Groups per chunk of that check: 8 (default; 16-bit windows) or 64 (13-bit windows: 25 % more bucket additions and four more sorts on
+ * every chunk -- about 8 % of the device-resident verification rate at the headline shape, nothing where the PCIe link is the
+ * bound -- for a forged proof that costs a 64th of its chunk instead of an eighth).  Verdicts and statuses do not depend on it.
+ * (ZKATTEST_VERIFY_GROUPS) */
+zk_status zk_ctx_set_verify_groups(zk_ctx *ctx, uint32_t groups);
 
 /* The verifier's ring fold (verifyMembership's total, src/proofGK/gk.ts:239-250): 1 (default) = the 8 low index bits of every
  * block of 256 keys as int8 matrix products on the matrix cores (v_mfma_i32_16x16x64_i8; rings of at least 4096 keys), 0 = the

@@ -299,3 +299,41 @@ def test_ring_fold_on_the_matrix_pipe_equals_the_vector_form(nkeys, B):
     assert got[1][0] == ([1] * B, [0] * B)
     assert [b for b in range(B) if not got[1][1][0][b]] == sorted({1, B // 2, B - 1})
     eng.close()
+
+
+def test_sixty_four_groups_give_the_same_verdicts_and_a_finer_fallback():
+    """zk_ctx_set_verify_groups(64): the chunk-wide check with 64 groups and 13-bit windows instead of 8 groups and 16-bit windows.
+    Same verdicts and statuses for honest, forged and malformed proofs; a forged proof sends a 64th of its chunk (not an eighth) to
+    the per-proof sums -- counted, not timed."""
+    import zkp_ecdsa_amd as Z
+    B, nkeys = 8192, 8192
+    eng = Z.Engine(0)
+    eng.set_comb_bits(16)
+    params = eng.synth_params(64)
+    eng.set_params(*params, 80)
+    ring, msg, sig, pk, which, seeds = eng.synth_workload(64, nkeys, B)
+    eng.set_ring(ring, nkeys)
+    eng.set_chunk(B)
+    proofs, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert st == [0] * B
+    vs = _vseeds(B)
+    mixed = list(proofs)
+    for b, pos in ((5, -9), (127, -9), (128, 400), (4000, -40), (B - 1, -9)):
+        f = bytearray(proofs[b])
+        f[pos] ^= 4
+        mixed[b] = bytes(f)
+    mixed[700] = proofs[700][:32] + bytes(64) + proofs[700][96:]     # R = (0, 0): not on the curve
+    res = {}
+    for groups in (8, 64):
+        eng.set_verify_groups(groups)
+        before = eng.test_counter(0)
+        honest = eng.verify_batch(msg, proofs, vseeds=vs)
+        assert honest == ([1] * B, [0] * B) and eng.test_counter(0) == before
+        res[groups] = (eng.verify_batch(msg, mixed, vseeds=vs), eng.test_counter(0) - before)
+    assert res[8][0] == res[64][0]
+    ok, vst = res[64][0]
+    bad = [b for b in range(B) if not ok[b]]
+    assert set(bad) >= {5, 127, 4000, B - 1, 700} and vst[700] != 0
+    # forged proofs sit in groups {0} + {0 or 1} + {3} + {7} of 8 (1024 proofs each) and in {0}, {0 or 1}, {31}, {63}, ... of 64 (128 each)
+    assert res[64][1] < res[8][1] and res[64][1] <= 6 * (B // 64) and res[8][1] >= 3 * (B // 8)
+    eng.close()

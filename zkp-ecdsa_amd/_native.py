@@ -20,7 +20,7 @@ SYMBOLS = [
     'zk_pool_host_alloc', 'zk_pool_host_free', 'zk_pool_numa_node', 'zk_pool_test_locality', 'zk_pool_shard_ms',
     'zk_prove_submit', 'zk_prove_wait', 'zk_verify_submit', 'zk_verify_wait', 'zk_test_counter',
     'zk_proofs_to_json_batch', 'zk_proofs_from_json_batch', 'zk_ctx_set_ring_fold',
-    'zk_pool_prove_submit', 'zk_pool_prove_wait', 'zk_pool_verify_submit', 'zk_pool_verify_wait',
+    'zk_pool_prove_submit', 'zk_pool_prove_wait', 'zk_pool_verify_submit', 'zk_pool_verify_wait', 'zk_ctx_set_verify_groups',
     'zk_test_field_op', 'zk_test_tom_commit', 'zk_test_p256_fixed_mul', 'zk_test_sha256', 'zk_test_rng_draws',
 ]
 
@@ -112,6 +112,7 @@ def lib():
         L.zk_verify_submit.argtypes = [vp, u64, C.c_char_p, vp, vp, C.c_char_p, vp, vp, C.POINTER(vp)]
         L.zk_verify_wait.argtypes = [vp, vp]
         L.zk_ctx_set_ring_fold.argtypes = [vp, u32]
+        L.zk_ctx_set_verify_groups.argtypes = [vp, u32]
         L.zk_test_counter.argtypes = [vp, i32]
         L.zk_test_counter.restype = u64
         L.zk_pool_prove_submit.argtypes = [vp, u64, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(ZkRng), vp, u64, vp, vp, vp, C.POINTER(vp)]
@@ -317,6 +318,9 @@ class Engine:
         d = C.create_string_buffer(32)
         self._chk(self.L.zk_ring_digest(self.h, d))
         return d.raw
+
+    def set_verify_groups(self, groups):
+        self._chk(self.L.zk_ctx_set_verify_groups(self.h, groups))
 
     def set_ring_fold(self, matrix_pipe):
         self._chk(self.L.zk_ctx_set_ring_fold(self.h, 1 if matrix_pipe else 0))

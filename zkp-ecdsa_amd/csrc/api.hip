@@ -82,6 +82,7 @@ static zk_status ctx_init(zk_ctx* c, int device_id) {
     }
     if (const char* e = getenv("ZKATTEST_GK_TABLE")) c->gk_table = atoi(e) != 0;
     if (const char* e = getenv("ZKATTEST_GK_MFMA")) c->gk_mfma = atoi(e) != 0;
+    if (const char* e = getenv("ZKATTEST_VERIFY_GROUPS")) c->verify_groups = atoi(e) == 64 ? 64 : 8;
     if (const char* e = getenv("ZKATTEST_VERIFY_BATCH")) c->verify_batch_min = (uint32_t)atoi(e);
     if (const char* e = getenv("ZKATTEST_LANES")) {
         int l = atoi(e);
@@ -269,6 +270,11 @@ extern "C" zk_status zk_ctx_set_chunk(zk_ctx* c, uint32_t chunk) {
 extern "C" zk_status zk_ctx_set_batch_verify(zk_ctx* c, uint32_t min_chunk) {
     if (!c) return ZK_E_ARG;
     c->verify_batch_min = min_chunk;
+    return ZK_OK;
+}
+extern "C" zk_status zk_ctx_set_verify_groups(zk_ctx* c, uint32_t groups) {
+    if (!c || (groups != 8 && groups != 64)) return ZK_E_ARG;
+    c->verify_groups = groups;
     return ZK_OK;
 }
 extern "C" zk_status zk_ctx_set_ring_fold(zk_ctx* c, uint32_t matrix_pipe) {

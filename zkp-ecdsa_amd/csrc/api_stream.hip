@@ -126,7 +126,8 @@ static zk_status stream_common(zk_ctx* c, int kind) {
         c->err = "prove and verify jobs cannot be in flight together on one context";
         return ZK_E_ARG;
     }
-    if (!c->jobs.empty() && (!(c->ws_C == c->chunk && c->ws_sec == c->P.sec && c->ws_n == c->n) || (c->jobs[0]->kind ? c->jobs[0]->vj.NL : c->jobs[0]->pj.NL) != c->lanes)) {
+    if (!c->jobs.empty() && (!(c->ws_C == c->chunk && c->ws_sec == c->P.sec && c->ws_n == c->n) || (c->jobs[0]->kind ? c->jobs[0]->vj.NL : c->jobs[0]->pj.NL) != c->lanes ||
+                              (kind == 1 && c->vs_groups != c->verify_groups))) {
         c->err = "chunk / lanes / parameters / ring changed while streamed jobs are in flight";
         return ZK_E_ARG;
     }

@@ -2,7 +2,7 @@
 #include "ctx.h"
 #include "jobs.h"
 
-static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, uint32_t C, uint32_t sec, uint32_t n, uint64_t N, bool want_msm) {
+static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, uint32_t C, uint32_t sec, uint32_t n, uint64_t N, bool want_msm, uint32_t want_groups) {
     Carver k(base);
     V.C = C, V.sec = sec, V.n = n;
     V.st = (int32_t*)k.take(4 * (size_t)C);
@@ -28,7 +28,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
     auto soa4 = [&](size_t cnt) { return Soa4{k.soa(cnt), k.soa(cnt), k.soa(cnt), k.soa(cnt)}; };
     size_t nq = (n + 1) / 2;
     V.slot_terms = terms(ns * V_SLOT_TERMS);
-    V.slot_class = (uint8_t*)k.take(ns), V.slot_perm = (uint32_t*)k.take(4 * ns), V.slot_cnt = (uint32_t*)k.take(8 * (MSM_G + 1));
+    V.slot_class = (uint8_t*)k.take(ns), V.slot_perm = (uint32_t*)k.take(4 * ns), V.slot_cnt = (uint32_t*)k.take(8 * (MSM_G_MAX + 1));
     V.gk_terms = terms((size_t)C * nq * 8);
     V.misc_terms = terms((size_t)C * 3);
     V.slot_acc = soa4(ns * V_SLOT_SPLIT), V.gk_acc = soa4((size_t)C * nq), V.misc_acc = soa4((size_t)C * 3);
@@ -43,19 +43,22 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
         size_t cap = ns * V_SLOT_TERMS + (size_t)C * nq * 8 + (size_t)C * 3;
         M.cap = (uint32_t)cap;
         M.aos = (uint32_t*)k.take(cap * 128);
-        M.keys_all = (uint32_t*)k.take(cap * 4 * 16), M.vals_in = (uint32_t*)k.take(cap * 4), M.keys_out = (uint32_t*)k.take(cap * 4);
-        M.vals_out = (uint32_t*)k.take(cap * 4 * 16);
-        M.start = (uint32_t*)k.take((size_t)4 * 16 * 65536 * MSM_G), M.end = (uint32_t*)k.take((size_t)4 * 16 * 65536 * MSM_G);
-        M.ord_key = (uint32_t*)k.take((size_t)4 * 16 * 65536 * MSM_G), M.ord_key2 = (uint32_t*)k.take((size_t)4 * 16 * 65536 * MSM_G);
-        M.ord_id = (uint32_t*)k.take((size_t)4 * 16 * 65536 * MSM_G), M.ord_id2 = (uint32_t*)k.take((size_t)4 * 16 * 65536 * MSM_G);
+        // sized for either shape of the pass: 16 windows x (8 groups x 2^16 digits) or 20 windows x (64 groups x 2^13 digits)
+        const size_t NW = want_groups == 64 ? 20 : 16, NBG = (size_t)1 << 19, NWG = NW * want_groups;
+        const size_t L1 = want_groups == 64 ? 128 : 1024, L2 = L1 / 32;
+        M.keys_all = (uint32_t*)k.take(cap * 4 * NW), M.vals_in = (uint32_t*)k.take(cap * 4), M.keys_out = (uint32_t*)k.take(cap * 4);
+        M.vals_out = (uint32_t*)k.take(cap * 4 * NW);
+        M.start = (uint32_t*)k.take(4 * NW * NBG), M.end = (uint32_t*)k.take(4 * NW * NBG);
+        M.ord_key = (uint32_t*)k.take(4 * NW * NBG), M.ord_key2 = (uint32_t*)k.take(4 * NW * NBG);
+        M.ord_id = (uint32_t*)k.take(4 * NW * NBG), M.ord_id2 = (uint32_t*)k.take(4 * NW * NBG);
         M.counters = (uint32_t*)k.take(256), M.flag = (uint32_t*)k.take(256), M.big_list = (uint32_t*)k.take(4 * 4096), M.big_part = (uint32_t*)k.take((size_t)4096 * 128 * 144);
-        M.buckets = (uint32_t*)k.take((size_t)16 * 65536 * 144 * MSM_G);
-        M.F1 = (uint32_t*)k.take((size_t)16 * 1024 * 144 * MSM_G), M.G1 = (uint32_t*)k.take((size_t)16 * 1024 * 144 * MSM_G);
-        M.F2 = (uint32_t*)k.take(16 * 32 * 144 * MSM_G), M.G2 = (uint32_t*)k.take(16 * 32 * 144 * MSM_G), M.H2 = (uint32_t*)k.take(16 * 32 * 144 * MSM_G);
-        M.Tw = (uint32_t*)k.take(16 * 144 * MSM_G);
+        M.buckets = (uint32_t*)k.take(NW * NBG * 144);
+        M.F1 = (uint32_t*)k.take(NWG * L1 * 144), M.G1 = (uint32_t*)k.take(NWG * L1 * 144);
+        M.F2 = (uint32_t*)k.take(NWG * L2 * 144), M.G2 = (uint32_t*)k.take(NWG * L2 * 144), M.H2 = (uint32_t*)k.take(NWG * L2 * 144);
+        M.Tw = (uint32_t*)k.take(NWG * 144);
         M.sort_tmp_bytes = msm_workspace_bytes((uint32_t)cap);
         M.sort_tmp = k.take(M.sort_tmp_bytes);
-        M.one = k.list(MSM_G);
+        M.one = k.list(MSM_G_MAX);
     }
     uint32_t T = n >= GK_ETAB_MINN && n <= GK_ETAB_MAXN ? 8 : std::min<uint32_t>(n, 13);  // block path: one value per 256 keys
     res = k.soa((size_t)C * (N >> T));
@@ -65,22 +68,22 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
 zk_status ensure_vworkspace(zk_ctx* c, uint32_t C, uint32_t nlanes) {
     uint32_t sec = c->P.sec, n = c->n;
     const bool want_msm = c->verify_batch_min && C >= c->verify_batch_min;   // the chunk-wide sums never run on smaller chunks
-    if (!(c->vs_C == C && c->vs_sec == sec && c->vs_n == n && c->vs_msm == want_msm)) {
+    if (!(c->vs_C == C && c->vs_sec == sec && c->vs_n == n && c->vs_msm == want_msm && c->vs_groups == c->verify_groups)) {
         for (auto& L : c->vl) L.ready = false;
-        c->vs_C = C, c->vs_sec = sec, c->vs_n = n, c->vs_msm = want_msm;
+        c->vs_C = C, c->vs_sec = sec, c->vs_n = n, c->vs_msm = want_msm, c->vs_groups = c->verify_groups;
     }
     for (uint32_t l = 0; l < nlanes && l < ZK_MAX_LANES; l++) {
         auto& L = c->vl[l];
         if (L.ready) continue;
-        size_t need = vcarve(L.V, L.res, L.res2, L.M, nullptr, C, sec, n, c->N, want_msm);
+        size_t need = vcarve(L.V, L.res, L.res2, L.M, nullptr, C, sec, n, c->N, want_msm, c->verify_groups);
         if (need > L.arena_bytes) {
             if (L.arena) HIPCHK(c, hipFree(L.arena));
             L.arena = nullptr, L.arena_bytes = 0;
             HIPCHK(c, hipMalloc(&L.arena, need));
             L.arena_bytes = need;
         }
-        vcarve(L.V, L.res, L.res2, L.M, (uint8_t*)L.arena, C, sec, n, c->N, want_msm);
-        if (!L.h_msm) HIPCHK(c, hipHostMalloc((void**)&L.h_msm, 256, hipHostMallocMapped | hipHostMallocCoherent));
+        vcarve(L.V, L.res, L.res2, L.M, (uint8_t*)L.arena, C, sec, n, c->N, want_msm, c->verify_groups);
+        if (!L.h_msm) HIPCHK(c, hipHostMalloc((void**)&L.h_msm, 1024, hipHostMallocMapped | hipHostMallocCoherent));
         L.M.host = L.h_msm;
         L.ready = true;
     }
@@ -230,12 +233,13 @@ zk_status VerifyJob::stage2(uint64_t chunk_no) {
     VWork& V = c->vl[lane].V;
     const MsmBuf& M = c->vl[lane].M;
     hipStream_t s = c->pl[lane].stream;
-    // Tom-256 relations: one bucket-method sum per group of the chunk's proofs (MSM_G groups, one pass); the per-proof
+    // Tom-256 relations: one bucket-method sum per group of the chunk's proofs (8 or 64 groups, one pass); the per-proof
     // windowed sums only run for the groups whose total is not the identity -- some proof of theirs is bad -- to tell which
-    uint32_t flags[MSM_G], gsz = cnt;
+    const uint32_t G = c->vs_groups;   // 8 or 64 groups per chunk (zk_ctx_set_verify_groups)
+    uint32_t flags[MSM_G_MAX], gsz = cnt;
     if (c->verify_batch_min && cnt >= c->verify_batch_min && M.cap) {
         MaybeScope t(timed, c, "v_msm_tom", s);
-        hipError_t e = run_msm(s, P, W, V, cnt, nq, M, flags, &gsz);
+        hipError_t e = run_msm(s, P, W, V, cnt, nq, M, G, flags, &gsz);
         if (e != hipSuccess) {
             c->err = std::string("batched verification failed: ") + hipGetErrorString(e);
             return ZK_E_DEVICE;
@@ -245,14 +249,14 @@ zk_status VerifyJob::stage2(uint64_t chunk_no) {
     }
     uint32_t ranges = 0;
     VGroupFlags gf;
-    for (uint32_t g = 0; g < MSM_G; g++) gf.v[g] = 1;
-    for (uint32_t g = 0; g < MSM_G && (uint64_t)g * gsz < cnt;) {   // maximal runs of groups that failed
+    for (uint32_t g = 0; g < MSM_G_MAX; g++) gf.v[g] = 1;
+    for (uint32_t g = 0; g < G && (uint64_t)g * gsz < cnt;) {   // maximal runs of groups that failed
         if (flags[g]) {
             g++;
             continue;
         }
         uint32_t g1 = g;
-        while (g1 < MSM_G && (uint64_t)g1 * gsz < cnt && !flags[g1]) g1++;
+        while (g1 < G && (uint64_t)g1 * gsz < cnt && !flags[g1]) g1++;
         const uint32_t p0 = g * gsz, p1 = std::min<uint32_t>(cnt, g1 * gsz);
         // few slots: a slot's 36 terms over 4 lanes (the chain of one lane is ~12 ms long, the GPU is far from full)
         const uint32_t tsplit = (uint64_t)(p1 - p0) * VK * V_SLOT_SPLIT <= 524288 ? V_SLOT_SPLIT : 1;   // up to two residencies of the GPU (4 waves per SIMD, 262 144 lanes)

@@ -68,6 +68,8 @@ struct zk_ctx {
         bool ready = false;
     } vl[ZK_MAX_LANES];
     uint32_t vs_C = 0, vs_sec = 0, vs_n = 0;
+    uint32_t verify_groups = 8;   // groups per chunk of the batched Tom check: 8 (16-bit windows) or 64 (13-bit windows); zk_ctx_set_verify_groups
+    uint32_t vs_groups = 8;       // ... the lanes' workspaces were carved for
     bool vs_msm = false;          // the lanes' workspaces hold the buffers of the batched Tom check
     uint32_t verify_batch_min = 256;   // zk_ctx_set_batch_verify: chunks of at least this many proofs get the batched check (0 = never)
     // host-buffer entry points: DMA stream for page-locked caller buffers (zk_host_alloc), one event per lane

@@ -153,13 +153,15 @@ struct Workspace {
     RngCtx rng;
 };
 
-// The batched Tom-256 check sums the relations of MSM_G contiguous groups of a chunk's proofs separately (same pass: the group
-// index rides on top of the 16-bit digit in the sort key): a forged proof only sends ITS group to the per-proof sums.
-#define MSM_G 8
+// The batched Tom-256 check sums the relations of contiguous groups of a chunk's proofs separately (same pass: the group index
+// rides on top of the digit in the 19-bit sort key): a forged proof only sends ITS group to the per-proof sums.  8 groups with
+// 16-bit windows or 64 groups with 13-bit windows (zk_ctx_set_verify_groups; k_msm.hip).
+#define MSM_G_MAX 64
+#define MSM_NW_MAX 20
 #define V_SLOT_SPLIT 4      // slot accumulators per checked repetition (k_v_straus: a slot's terms over up to 4 lanes)
 #define V_RECHECK 0x100u    // group flag: per-proof sums were computed, low byte = lanes per slot
 struct VGroupFlags {        // per group of a chunk: 1 = passed the batched check, V_RECHECK | tsplit otherwise (kernel argument of k_v_final)
-    uint32_t v[MSM_G];
+    uint32_t v[MSM_G_MAX];
 };
 // ------------------------------------------------------------------ verifier workspace
 #define VK 20             // reps checked by verifySignatureList (zkpAttestList.ts:177)
@@ -195,7 +197,7 @@ struct VWork {
     VTerms slot_terms, gk_terms, misc_terms;
     uint8_t* slot_class;  // [C*VK] 1 = zero-bit slot of a good proof (36 live terms), 0 = only the two 128-bit terms 34, 35
     uint32_t* slot_perm;  // [C*VK] per re-checked proof range: local slot ids, class-1 slots from the front, the others from the back
-    uint32_t* slot_cnt;   // [2 * (MSM_G + 1)] how many of each, per range
+    uint32_t* slot_cnt;   // [2 * (MSM_G_MAX + 1)] how many of each, per range
     Soa4 slot_acc, gk_acc, misc_acc;
     Soa sSg, sSh, sSkx, sSky, sSR, sSH, sSL;   // per slot partial sums
     Soa pSR, pSH, pSL;                         // per proof (mod n)
@@ -243,16 +245,16 @@ struct MsmBuf {
     uint32_t* keys_all;    // [16][cap] digit of every live term in every window
     uint32_t *vals_in, *keys_out;             // live term ids; sorted keys of the window being processed
     uint32_t* vals_out;    // [16][cap] term ids sorted by digit
-    uint32_t *start, *end; // [16][MSM_G * 65536] segment of every (group, digit) value
-    uint32_t *ord_key, *ord_key2, *ord_id, *ord_id2;   // [16 * MSM_G * 65536] buckets ordered by size (k_msm_sizes + one radix pass)
+    uint32_t *start, *end; // [windows][2^19] segment of every (group, digit) value
+    uint32_t *ord_key, *ord_key2, *ord_id, *ord_id2;   // [windows * 2^19] buckets ordered by size (k_msm_sizes + one radix pass)
     uint32_t *counters, *flag;   // counters[0..15]: pairs per window, counters[32]: oversized buckets
     uint32_t* big_list;    // [4096] window * 65536 + digit of the oversized buckets
     uint32_t* big_part;    // [4096][128][36] partial sums of their slices
-    uint32_t* buckets;     // [16][MSM_G * 65536][36]
+    uint32_t* buckets;     // [windows][2^19][36]
     uint32_t *F1, *G1, *F2, *G2, *H2, *Tw;
     void* sort_tmp;
     size_t sort_tmp_bytes;
-    TomList one;           // [MSM_G] the groups' fixed-base commitments
+    TomList one;           // [groups] the groups' fixed-base commitments
     uint32_t* host;        // page-locked host words (live-term count, group verdicts): a pageable destination makes the runtime
                            // wait for every stream of the device, i.e. for the other lanes' kernels
 };
@@ -260,8 +262,8 @@ struct MsmBuf {
 // k_msm.hip
 size_t msm_workspace_bytes(uint32_t cap);
 // host_flags[g] = 1: the Tom-256 total of group g (proofs [g * gsz, (g + 1) * gsz) of the chunk) is the identity; M.flag holds the same on the device
-hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t* host_flags /*[MSM_G]*/,
-                   uint32_t* gsz);
+hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t groups /*8 or 64*/,
+                   uint32_t* host_flags /*[groups]*/, uint32_t* gsz);
 // group size of one k_gk_finish pass over `ntiles` polynomials of T+1 coefficients: <= 64, dynamic LDS below 60 KB
 static inline size_t gk_finish_lds(uint32_t T, uint32_t g) { return sizeof(uint32_t) * 9 * ((size_t)g * (T + 1) + (size_t)(g / 2) * (T + 2)); }
 static inline uint32_t gk_finish_gsz(uint32_t T, uint32_t ntiles) {

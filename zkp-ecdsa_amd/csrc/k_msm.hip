@@ -25,14 +25,21 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include "engine.h"
 
-#define MSM_C 16
-#define MSM_NB 65536u
-#define MSM_NW 16
-#define MSM_GBITS 3
-static_assert((1 << MSM_GBITS) == MSM_G, "MSM_G");
-#define MSM_NBG (MSM_G * MSM_NB)     // (group, digit) values per window
-#define MSM_NWG (MSM_NW * MSM_G)     // (window, group) pairs: the reductions treat each as a window of its own
+// Two shapes of the same pass, chosen per context (zk_ctx_set_verify_groups): 8 groups x 16-bit windows (16 windows) or 64 groups x
+// 13-bit windows (20 windows).  Either way a window has 2^19 (group, digit) buckets and the sort keys are 19 bits wide, so every
+// buffer keeps its size; the finer shape costs 25 % more bucket additions and four more sorts on every chunk and makes a forged
+// proof cost a 64th of its chunk instead of an eighth.  C is a template parameter: the digit cuts and loop bounds stay constants.
+#define MSM_KEY_BITS 19
+#define MSM_NBG (1u << MSM_KEY_BITS)   // (group, digit) values per window
 #define MSM_ENTRY_WORDS 32
+template <int C>
+struct MsmShape {
+    static constexpr uint32_t c = C, nb = 1u << C, nw = (256 + C - 1) / C, gbits = MSM_KEY_BITS - C, g = 1u << gbits;
+    static constexpr uint32_t nwg = nw * g;        // (window, group) pairs: the reductions treat each as a window of its own
+    static constexpr uint32_t l1 = nb / 64;        // level-1 ranges of 64 buckets per (window, group)
+    static constexpr uint32_t l2 = l1 / 32;        // level-2 ranges of 32 level-1 ranges
+    static_assert(nw <= MSM_NW_MAX && g <= MSM_G_MAX && l2 >= 1, "shape");
+};
 
 // term id space: [0, n0) slot_terms, [n0, n0 + n1) gk_terms, [n0 + n1, n0 + n1 + n2) misc_terms
 struct MsmDims {
@@ -75,7 +82,9 @@ __global__ void __launch_bounds__(256) k_msm_pack(VWork V, MsmDims D, uint32_t* 
 }
 // Compaction of the live terms (scalar != 0): ids[pos] = term id and, for every window, keys[w * cap + pos] = group << 16 | its
 // 16-bit digit (0 included: digit 0 is simply a bucket nobody sums).  One atomic per workgroup.
+template <int C>
 __global__ void __launch_bounds__(256) k_msm_compact(VWork V, MsmDims D, uint32_t cap, uint32_t* keys, uint32_t* ids, uint32_t* counter) {
+    typedef MsmShape<C> S;
     __shared__ uint32_t wave_cnt[4], block_base;
     uint32_t id = gtid();
     uint32_t w8[8], proof = 0;
@@ -104,9 +113,14 @@ __global__ void __launch_bounds__(256) k_msm_compact(VWork V, MsmDims D, uint32_
     uint32_t pos = block_base + below;
     for (uint32_t k = 0; k < wv; k++) pos += wave_cnt[k];
     ids[pos] = id;
-    const uint32_t grp = (proof / D.gsz) << MSM_C;
+    const uint32_t grp = (proof / D.gsz) << S::c;
 #pragma unroll
-    for (int w = 0; w < MSM_NW; w++) keys[(size_t)w * cap + pos] = grp | ((w8[w >> 1] >> (16 * (w & 1))) & 0xffffu);
+    for (int w = 0; w < (int)S::nw; w++) {   // bits [C w, C (w + 1)) of the 256-bit scalar: word index and shift are constants
+        const int bit = C * w, k = bit >> 5, sh = bit & 31;
+        uint32_t d = w8[k] >> sh;
+        if (sh + C > 32 && k + 1 < 8) d |= w8[k + 1] << (32 - sh);
+        keys[(size_t)w * cap + pos] = grp | (d & (S::nb - 1));
+    }
 }
 __global__ void __launch_bounds__(256) k_msm_bounds(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* start, uint32_t* end) {
     uint32_t i = gtid();
@@ -147,18 +161,20 @@ ZK_DEV TomPt msm_ldp(const uint32_t* p) {
 // in the high ones) a wave of 64 neighbouring digits waits for a bucket 1.5-1.8x the mean.  The buckets of all windows are therefore
 // ordered by size first (k_msm_sizes + ONE 8-bit radix pass over 8.4 M (key, id) pairs), largest first: the lanes of a wave get
 // buckets of the same size, the empty ones end up together at the end.
+template <int C>
 __global__ void __launch_bounds__(256) k_msm_sizes(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t* key, uint32_t* id) {
-    uint32_t wd = gtid();   // w * MSM_NBG + (group << 16 | digit)
-    uint32_t n = (wd & (MSM_NB - 1)) != 0 ? end[wd] - start[wd] : 0;
+    uint32_t wd = gtid();   // w * MSM_NBG + (group << C | digit)
+    uint32_t n = (wd & (MsmShape<C>::nb - 1)) != 0 ? end[wd] - start[wd] : 0;
     key[wd] = 255u - (n < 255u ? n : 255u), id[wd] = wd;
 }
+template <int C>
 __global__ void __launch_bounds__(256) k_msm_bucket(const uint32_t* __restrict__ aos, const uint32_t* __restrict__ vals, uint32_t cap,
                                                     const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, const uint32_t* __restrict__ order,
                                                     uint32_t* buckets, uint32_t* big_cnt, uint32_t* big_list, uint32_t big) {
-    uint32_t wd = order[gtid()], w = wd / MSM_NBG, d = wd % MSM_NBG;   // d = group << 16 | digit
+    uint32_t wd = order[gtid()], w = wd / MSM_NBG, d = wd % MSM_NBG;   // d = group << C | digit
     uint32_t s = start[wd], e = end[wd];
     TomPt acc = tom_identity();
-    const bool nz = (d & (MSM_NB - 1)) != 0;
+    const bool nz = (d & (MsmShape<C>::nb - 1)) != 0;
     if (nz && e - s > big) {
         uint32_t pos = atomicAdd(big_cnt, 1u);
         if (pos < MSM_BIG_MAX) big_list[pos] = wd, e = s;  // handled by k_msm_bucket_big (beyond the list: here after all)
@@ -225,9 +241,12 @@ __global__ void __launch_bounds__(256) k_msm_bucket_big2(const uint32_t* __restr
     }
 }
 // level 1: 64 buckets per thread.  F1 = sum_j j * B_{64 r + j}, G1 = sum_j B_{64 r + j}
+template <int C>
 __global__ void __launch_bounds__(256) k_msm_reduce1(const uint32_t* __restrict__ buckets, uint32_t* F1, uint32_t* G1) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;  // r < 1024; w = window * MSM_G + group
-    const uint32_t* b = buckets + ((size_t)w * MSM_NB + 64 * r) * 36;
+    typedef MsmShape<C> S;
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;  // r < l1; w = window * groups + group
+    if (r >= S::l1) return;
+    const uint32_t* b = buckets + ((size_t)w * S::nb + 64 * r) * 36;
     TomPt run = tom_identity(), acc = tom_identity();
 #pragma unroll 1
     for (int j = 63; j >= 1; j--) {
@@ -235,16 +254,18 @@ __global__ void __launch_bounds__(256) k_msm_reduce1(const uint32_t* __restrict_
         acc = tom_add(acc, run);
     }
     run = tom_add(run, msm_ldp(b));
-    msm_st(F1 + ((size_t)w * 1024 + r) * 36, acc);
-    msm_st(G1 + ((size_t)w * 1024 + r) * 36, run);
+    msm_st(F1 + ((size_t)w * S::l1 + r) * 36, acc);
+    msm_st(G1 + ((size_t)w * S::l1 + r) * 36, run);
 }
 // level 2: 32 level-1 ranges per thread.  F2 = sum_j j * G1_{32 s + j}, G2 = sum_j G1_{32 s + j}, H2 = sum_j F1_{32 s + j}
+template <int C>
 __global__ void __launch_bounds__(64) k_msm_reduce2(const uint32_t* __restrict__ F1, const uint32_t* __restrict__ G1, uint32_t* F2, uint32_t* G2, uint32_t* H2) {
+    typedef MsmShape<C> S;
     uint32_t t = gtid();
-    if (t >= MSM_NWG * 32) return;
-    uint32_t w = t / 32, s = t % 32;
-    const uint32_t* g = G1 + ((size_t)w * 1024 + 32 * s) * 36;
-    const uint32_t* f = F1 + ((size_t)w * 1024 + 32 * s) * 36;
+    if (t >= S::nwg * S::l2) return;
+    uint32_t w = t / S::l2, s = t % S::l2;
+    const uint32_t* g = G1 + ((size_t)w * S::l1 + 32 * s) * 36;
+    const uint32_t* f = F1 + ((size_t)w * S::l1 + 32 * s) * 36;
     TomPt run = tom_identity(), acc = tom_identity(), h = tom_identity();
 #pragma unroll 1
     for (int j = 31; j >= 1; j--) {
@@ -257,13 +278,15 @@ __global__ void __launch_bounds__(64) k_msm_reduce2(const uint32_t* __restrict__
     msm_st(F2 + (size_t)t * 36, acc), msm_st(G2 + (size_t)t * 36, run), msm_st(H2 + (size_t)t * 36, h);
 }
 // level 3: one thread per window.  sum_d d B_d = H + 64 (GF2 + 32 FG2);  result times 2^(16 w)
+template <int C>
 __global__ void __launch_bounds__(64) k_msm_reduce3(const uint32_t* __restrict__ F2, const uint32_t* __restrict__ G2, const uint32_t* __restrict__ H2, uint32_t* Tw) {
-    uint32_t w = gtid();   // window * MSM_G + group
-    if (w >= MSM_NWG) return;
+    typedef MsmShape<C> S;
+    uint32_t w = gtid();   // window * groups + group
+    if (w >= S::nwg) return;
     TomPt run = tom_identity(), fg = tom_identity(), gf = tom_identity(), gh = tom_identity();
 #pragma unroll 1
-    for (int s = 31; s >= 0; s--) {
-        size_t o = ((size_t)w * 32 + s) * 36;
+    for (int s = (int)S::l2 - 1; s >= 0; s--) {
+        size_t o = ((size_t)w * S::l2 + s) * 36;
         if (s >= 1) {
             run = tom_add(run, msm_ldp(G2 + o));
             fg = tom_add(fg, run);
@@ -276,7 +299,7 @@ __global__ void __launch_bounds__(64) k_msm_reduce3(const uint32_t* __restrict__
     for (int i = 0; i < 6; i++) t = tom_dbl(t);
     t = tom_add(t, gh);
 #pragma unroll 1
-    for (uint32_t i = 0; i < MSM_C * (w / MSM_G); i++) t = tom_dbl(t);
+    for (uint32_t i = 0; i < S::c * (w / S::g); i++) t = tom_dbl(t);
     msm_st(Tw + (size_t)w * 36, t);
 }
 // coefficient sums of the fixed bases over a group's proofs (block g): list C slots p * 4n + {0, 1} hold (mg, mh), (eg, eh)
@@ -307,78 +330,87 @@ __global__ void __launch_bounds__(256) k_msm_coef(Workspace W, uint32_t count, u
         soa_st(one.v, g, a), soa_st(one.r, g, c2);
     }
 }
+template <int C>
 __global__ void k_msm_final(const uint32_t* __restrict__ Tw, TomList one, uint32_t* flag) {
+    typedef MsmShape<C> S;
     uint32_t g = gtid();
-    if (g >= MSM_G) return;
+    if (g >= S::g) return;
     Ft2 x = soa_ld<ModT, 2>(one.proj.x, g), y = soa_ld<ModT, 2>(one.proj.y, g), z = soa_ld<ModT, 2>(one.proj.z, g);
     TomPt t;
     t.x = x * z, t.y = y * z, t.t = x * y, t.z = z * z;  // (X : Y : Z) -> extended
-    for (uint32_t w = 0; w < MSM_NW; w++) t = tom_add(t, msm_ldp(Tw + ((size_t)w * MSM_G + g) * 36));
+    for (uint32_t w = 0; w < S::nw; w++) t = tom_add(t, msm_ldp(Tw + ((size_t)w * S::g + g) * 36));
     bool id = fe_is_zero(t.x) && fe_eq(t.y, t.z) && !fe_is_zero(t.z);
     flag[g] = id ? 1u : 0u;
 }
 
 size_t msm_workspace_bytes(uint32_t cap) {
     size_t tmp = 0;
-    rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, cap, 0, MSM_C + MSM_GBITS);
+    rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, cap, 0, MSM_KEY_BITS);
     size_t tmp2 = 0;   // the bucket ordering pass
-    rocprim::radix_sort_pairs(nullptr, tmp2, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, MSM_NW * MSM_NBG, 0, 8);
+    rocprim::radix_sort_pairs(nullptr, tmp2, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, MSM_NW_MAX * MSM_NBG, 0, 8);
     return tmp > tmp2 ? tmp : tmp2;
 }
-// returns through host_flags[MSM_G] (after a stream synchronisation): 1 = the Tom total of that group of proofs is the identity
-hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t* host_flags, uint32_t* gsz_out) {
+// returns through host_flags[groups] (after a stream synchronisation): 1 = the Tom total of that group of proofs is the identity
+template <int C>
+static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t* host_flags, uint32_t* gsz_out) {
+    typedef MsmShape<C> S;
     MsmDims D;
     D.g0 = V.C * VK, D.g1 = V.C * nq, D.g2 = V.C;
     D.n0 = D.g0 * V_SLOT_TERMS, D.n1 = D.g1 * 8, D.n2 = D.g2 * 3;
     D.l0 = count * VK, D.l1 = count * nq, D.l2 = count;
-    D.nq = nq, D.gsz = (count + MSM_G - 1) / MSM_G;
+    D.nq = nq, D.gsz = (count + S::g - 1) / S::g;
     *gsz_out = D.gsz;
     const uint32_t total = D.n0 + D.n1 + D.n2;
     const bool dbg = getenv("ZK_MSM_DEBUG") != nullptr;  // phase timings on stderr (adds stream synchronisations)
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
     hipLaunchKernelGGL(k_msm_pack, dim3((total + 255) / 256), dim3(256), 0, s, V, D, M.aos);
-    hipMemsetAsync(M.start, 0, sizeof(uint32_t) * MSM_NW * MSM_NBG, s);
-    hipMemsetAsync(M.end, 0, sizeof(uint32_t) * MSM_NW * MSM_NBG, s);
-    hipMemsetAsync(M.counters, 0, sizeof(uint32_t) * MSM_NW, s);
-    hipLaunchKernelGGL(k_msm_compact, dim3((total + 255) / 256), dim3(256), 0, s, V, D, M.cap, M.keys_all, M.vals_in, M.counters);
+    hipMemsetAsync(M.start, 0, sizeof(uint32_t) * S::nw * MSM_NBG, s);
+    hipMemsetAsync(M.end, 0, sizeof(uint32_t) * S::nw * MSM_NBG, s);
+    hipMemsetAsync(M.counters, 0, sizeof(uint32_t) * 32, s);
+    hipLaunchKernelGGL(k_msm_compact<C>, dim3((total + 255) / 256), dim3(256), 0, s, V, D, M.cap, M.keys_all, M.vals_in, M.counters);
     launch_words_to_host(s, M.host, M.counters, 1);
     hipError_t e0 = hipStreamSynchronize(s);
     if (e0 != hipSuccess) return e0;
     const uint32_t n = M.host[0];
     const uint32_t nmax = n;
     if (dbg) fprintf(stderr, "msm: %u live terms, pack+compact %.2f ms\n", n, now() - t0), t0 = now();
-    for (uint32_t w = 0; w < MSM_NW && n; w++) {
+    for (uint32_t w = 0; w < S::nw && n; w++) {
         size_t tmp = M.sort_tmp_bytes;
         hipError_t e = rocprim::radix_sort_pairs(M.sort_tmp, tmp, M.keys_all + (size_t)w * M.cap, M.keys_out, M.vals_in, M.vals_out + (size_t)w * M.cap, n, 0,
-                                                 MSM_C + MSM_GBITS, s);
+                                                 MSM_KEY_BITS, s);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_msm_bounds, dim3((n + 255) / 256), dim3(256), 0, s, M.keys_out, n, M.start + (size_t)w * MSM_NBG, M.end + (size_t)w * MSM_NBG);
     }
     if (dbg) {
         hipStreamSynchronize(s);
-        fprintf(stderr, "msm: 16 sorts + bounds %.2f ms\n", now() - t0), t0 = now();
+        fprintf(stderr, "msm: %u sorts + bounds %.2f ms\n", S::nw, now() - t0), t0 = now();
     }
     hipMemsetAsync(M.counters + 32, 0, 4, s);
     {
-        hipLaunchKernelGGL(k_msm_sizes, dim3(MSM_NW * MSM_NBG / 256), dim3(256), 0, s, M.start, M.end, M.ord_key, M.ord_id);
+        hipLaunchKernelGGL(k_msm_sizes<C>, dim3(S::nw * MSM_NBG / 256), dim3(256), 0, s, M.start, M.end, M.ord_key, M.ord_id);
         size_t tmp = M.sort_tmp_bytes;
-        hipError_t e = rocprim::radix_sort_pairs(M.sort_tmp, tmp, M.ord_key, M.ord_key2, M.ord_id, M.ord_id2, MSM_NW * MSM_NBG, 0, 8, s);
+        hipError_t e = rocprim::radix_sort_pairs(M.sort_tmp, tmp, M.ord_key, M.ord_key2, M.ord_id, M.ord_id2, S::nw * MSM_NBG, 0, 8, s);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_msm_bucket, dim3(MSM_NW * MSM_NBG / 256), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.ord_id2, M.buckets, M.counters + 32,
+    hipLaunchKernelGGL(k_msm_bucket<C>, dim3(S::nw * MSM_NBG / 256), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.ord_id2, M.buckets, M.counters + 32,
                        M.big_list, 8 * ((nmax + MSM_NBG - 1) / MSM_NBG) + 64);
     hipLaunchKernelGGL(k_msm_bucket_big, dim3(MSM_NSLICE, 32), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.counters + 32, M.big_list, M.big_part);
     hipLaunchKernelGGL(k_msm_bucket_big2, dim3(64), dim3(256), 0, s, M.counters + 32, M.big_list, M.big_part, M.buckets);
-    hipLaunchKernelGGL(k_msm_reduce1, dim3(1024 / 256, MSM_NWG), dim3(256), 0, s, M.buckets, M.F1, M.G1);
-    hipLaunchKernelGGL(k_msm_reduce2, dim3((MSM_NWG * 32 + 63) / 64), dim3(64), 0, s, M.F1, M.G1, M.F2, M.G2, M.H2);
-    hipLaunchKernelGGL(k_msm_reduce3, dim3((MSM_NWG + 63) / 64), dim3(64), 0, s, M.F2, M.G2, M.H2, M.Tw);
-    hipLaunchKernelGGL(k_msm_coef, dim3(MSM_G), dim3(256), 0, s, W, count, D.gsz, M.one);
-    launch_tom_commit(s, P, M.one, MSM_G, 1, 1);
-    hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, s, M.Tw, M.one, M.flag);
-    launch_words_to_host(s, M.host + 8, M.flag, MSM_G);
+    constexpr uint32_t bt = S::l1 < 256 ? S::l1 : 256;
+    hipLaunchKernelGGL(k_msm_reduce1<C>, dim3(S::l1 / bt, S::nwg), dim3(bt), 0, s, M.buckets, M.F1, M.G1);
+    hipLaunchKernelGGL(k_msm_reduce2<C>, dim3((S::nwg * S::l2 + 63) / 64), dim3(64), 0, s, M.F1, M.G1, M.F2, M.G2, M.H2);
+    hipLaunchKernelGGL(k_msm_reduce3<C>, dim3((S::nwg + 63) / 64), dim3(64), 0, s, M.F2, M.G2, M.H2, M.Tw);
+    hipLaunchKernelGGL(k_msm_coef, dim3(S::g), dim3(256), 0, s, W, count, D.gsz, M.one);
+    launch_tom_commit(s, P, M.one, S::g, 1, 1);
+    hipLaunchKernelGGL(k_msm_final<C>, dim3(1), dim3(64), 0, s, M.Tw, M.one, M.flag);
+    launch_words_to_host(s, M.host + 8, M.flag, S::g);
     hipError_t e = hipStreamSynchronize(s);
-    for (uint32_t g = 0; g < MSM_G; g++) host_flags[g] = M.host[8 + g];
+    for (uint32_t g = 0; g < S::g; g++) host_flags[g] = M.host[8 + g];
     if (dbg) fprintf(stderr, "msm tail (bucket .. final) %.2f ms\n", now() - t0);
     return e;
+}
+hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t groups, uint32_t* host_flags,
+                   uint32_t* gsz_out) {
+    return groups == 64 ? run_msm_t<13>(s, P, W, V, count, nq, M, host_flags, gsz_out) : run_msm_t<16>(s, P, W, V, count, nq, M, host_flags, gsz_out);
 }
