@@ -13,6 +13,7 @@
 #include <chrono>
 #include <sched.h>
 #include <sys/mman.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 #include <map>
 #include <mutex>
@@ -229,6 +230,18 @@ extern "C" void* zk_pool_host_alloc(zk_pool* p, size_t bytes) {
     if (mem == MAP_FAILED) return nullptr;
     (void)madvise(mem, len, MADV_HUGEPAGE);
     const size_t G = p->ctx.size(), region = (bytes / G) & ~(size_t)255;
+    // placement: an explicit memory policy per shard region (mbind, MPOL_PREFERRED: the device's node if it has room) -- first touch
+    // alone depends on where the touching thread happens to run when the cpuset does not grant the device's CPUs -- and the touch
+    // from a thread bound to those CPUs on top of it.  Measured on a two-socket box: D2H into a buffer on the far node runs at 30
+    // instead of 57 GB/s.
+    auto prefer_node = [&](size_t a, size_t b, int node) {
+        if (node < 0 || node >= 1024) return;
+        unsigned long mask[16] = {0};
+        mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
+        const size_t a0 = a / page * page;
+        (void)syscall(SYS_mbind, (char*)mem + a0, b - a0, 1 /* MPOL_PREFERRED */, mask, 1024ul, 0u);
+    };
+    for (size_t i = 0; i < G; i++) prefer_node(i * region, i + 1 == G ? len : (i + 1) * region, p->numa[i]);
     auto touch = [&](size_t a, size_t b) {   // one write per page of [a, b)
         volatile uint8_t* q = (volatile uint8_t*)mem;
         for (size_t o = a / page * page; o < b; o += page) q[o] = 0;
