@@ -131,10 +131,12 @@ zk_status zk_ctx_set_batch_verify(zk_ctx *ctx, uint32_t min_chunk);
  * (ZKATTEST_VERIFY_GROUPS) */
 zk_status zk_ctx_set_verify_groups(zk_ctx *ctx, uint32_t groups);
 
-/* The verifier's ring fold (verifyMembership's total, src/proofGK/gk.ts:239-250): 1 (default) = the 8 low index bits of every
- * block of 256 keys as int8 matrix products on the matrix cores (v_mfma_i32_16x16x64_i8; rings of at least 4096 keys), 0 = the
- * 64-bit multiply-add form on the vector ALU.  Exact integer arithmetic either way: same totals, same verdicts.  Takes effect
- * with the next verify call.  (ZKATTEST_GK_MFMA) */
+/* The ring fold's 8 low index bits on the matrix cores (v_mfma_i32_16x16x64_i8; rings of at least 4096 keys), 1 (default), or as
+ * 64-bit multiply-adds on the vector ALU, 0.  Verifier: verifyMembership's total (src/proofGK/gk.ts:239-250), every block of 256 keys
+ * as int8 matrix products (ZKATTEST_GK_MFMA).  Prover: the table path's coefficient classes 2..6 of proveMembership's polynomial
+ * (gk.ts:141-171), per group of proofs with equal low index bits; its operand table (0.83 GB at 2^16 keys, 13 GB at 2^20) is built
+ * by zk_ctx_set_ring unless ZKATTEST_GK_MFMA_PROVE=0.  Exact integer arithmetic either way: same proofs, totals and verdicts.
+ * Takes effect with the next prove / verify call. */
 zk_status zk_ctx_set_ring_fold(zk_ctx *ctx, uint32_t matrix_pipe);
 
 /* Upper bound of one proof's ZKA1 size for the current params/ring. */

@@ -177,6 +177,43 @@ def test_gk_table_path_equals_plain_fold_and_oracle(nkeys, B, chunk, monkeypatch
     eng.close(), plain.close()
 
 
+@pytest.mark.parametrize('nkeys,B0', [(4096, 4096), (65536, 6144)])
+def test_gk_table_path_on_the_matrix_cores_equals_the_vector_form(nkeys, B0, monkeypatch):
+    """Coefficient classes 2..6 of the table path as int8 matrix products (k_gk_mfma.hip: k_gk_block_mfma, rings of >= 4096 keys)
+    against the all-VALU table path (ZKATTEST_GK_MFMA_PROVE=0) on every proof and against the oracle on the first ones.  The
+    workload is thinned to three l_low groups so that a group fills a 16-proof tile (ring 2^12: exactly one; ring 2^16: one and a
+    partial one), plus one proof that is alone in its group.  (The generator gives proof b the ring slot b mod nkeys: B0 <= nkeys.)"""
+    import coracle as CO
+    import zkp_ecdsa_amd as Z
+    S = 4400 + nkeys
+    eng, vec = Z.Engine(0), None
+    nh, tg, th = eng.synth_params(S)
+    eng.set_params(nh, tg, th, 80)
+    ring, msg, sig, pk, which, seeds = eng.synth_workload(S, nkeys, B0)
+    eng.set_ring(ring, nkeys)
+    groups = sorted({w & 255 for w in which})[:3]
+    sel = [b for b in range(B0) if (which[b] & 255) in groups] + [next(b for b in range(B0) if (which[b] & 255) not in groups)]
+    B = len(sel)
+    assert max(sum(1 for b in sel if (which[b] & 255) == g) for g in groups) >= 16
+    cut = lambda buf, n: b''.join(buf[n * b:n * (b + 1)] for b in sel)
+    msg, sig, pk, seeds, which = cut(msg, 32), cut(sig, 64), cut(pk, 64), cut(seeds, 32), [which[b] for b in sel]
+    got, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert st == [0] * B
+    monkeypatch.setenv('ZKATTEST_GK_MFMA_PROVE', '0')
+    vec = Z.Engine(0)
+    vec.set_params(nh, tg, th, 80)
+    vec.set_ring(ring, nkeys)
+    ref, st2 = vec.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert st2 == [0] * B
+    assert [hashlib.sha256(g).hexdigest() for g in got] == [hashlib.sha256(r).hexdigest() for r in ref]
+    octx = CO.OracleCtx(nh, tg, th, 80)
+    octx.set_ring(ring, nkeys)
+    exp, est = octx.prove_batch(msg[:32 * 2], sig[:64 * 2], pk[:64 * 2], which[:2], seeds=seeds[:32 * 2], nthreads=2)
+    assert est == [0, 0] and got[:2] == exp
+    assert eng.verify_batch(msg, got) == ([1] * B, [0] * B)
+    eng.close(), vec.close()
+
+
 @pytest.mark.parametrize('sec,nkeys,B', [(1, 4, 3), (7, 5, 4), (33, 12, 3), (128, 9, 2), (96, 300, 2)])
 def test_security_levels_other_than_80(sec, nkeys, B):
     """secLevel is a run-time parameter of the reference (SystemParametersList.SecLevel): repetition counts that are not a

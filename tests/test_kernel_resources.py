@@ -40,16 +40,17 @@ def kernels():
     return ks
 
 
-# The one matrix-core kernel (k_gk_mfma.hip): its 65 x 4 int32 accumulators of v_mfma_i32_16x16x64_i8 LIVE in accumulator registers --
-# that is what AGPRs are for, not the VGPR-overflow copies the rule below is about -- and it runs one wave per SIMD by design.
-MATRIX_CORE = ('k_v_gk_block_mfma',)
+# The two matrix-core kernels (k_gk_mfma.hip; verifier's ring fold, prover's table path): their 64 x 4 int32 accumulators of
+# v_mfma_i32_16x16x64_i8 LIVE in accumulator registers -- that is what AGPRs are for, not the VGPR-overflow copies the rule below is
+# about -- and they run one wave per SIMD by design.
+MATRIX_CORE = ('k_v_gk_block_mfma', 'k_gk_block_mfma')
 
 
 def test_no_kernel_uses_agprs_or_spills_vgprs(kernels):
     bad = {n: k for n, k in kernels.items() if (k['agpr'] and not any(m in n for m in MATRIX_CORE)) or k['vgpr_spill']}
     assert not bad, bad
     mm = [k for n, k in kernels.items() if any(m in n for m in MATRIX_CORE)]
-    assert mm and all(k['agpr'] >= 252 and k['scratch'] == 0 and k['vgpr_spill'] == 0 for k in mm), mm
+    assert len(mm) == 2 and all(k['agpr'] >= 252 and k['scratch'] == 0 and k['vgpr_spill'] == 0 for k in mm), mm
 
 
 def test_every_kernel_fits_two_waves_per_simd(kernels):

@@ -82,6 +82,7 @@ static zk_status ctx_init(zk_ctx* c, int device_id) {
     }
     if (const char* e = getenv("ZKATTEST_GK_TABLE")) c->gk_table = atoi(e) != 0;
     if (const char* e = getenv("ZKATTEST_GK_MFMA")) c->gk_mfma = atoi(e) != 0;
+    if (const char* e = getenv("ZKATTEST_GK_MFMA_PROVE")) c->gk_mfma_prove = atoi(e) != 0;
     if (const char* e = getenv("ZKATTEST_VERIFY_GROUPS")) c->verify_groups = atoi(e) == 64 ? 64 : 8;
     if (const char* e = getenv("ZKATTEST_VERIFY_BATCH")) c->verify_batch_min = (uint32_t)atoi(e);
     if (const char* e = getenv("ZKATTEST_LANES")) {
@@ -124,7 +125,7 @@ extern "C" void zk_ctx_destroy(zk_ctx* c) {
     stream_release_spares(c);
     for (auto e : c->epool) hipEventDestroy(e);
     hipFree(c->P.tom_tab_g), hipFree(c->P.tom_tab_h), hipFree(c->tom_tab_gen), hipFree(c->P.pfix_G), hipFree(c->P.pfix_H);
-    hipFree(c->gk_kdig);
+    hipFree(c->gk_kdig), hipFree(c->gk_edig);
     hipFree(c->tab_scratch), hipFree(c->gk_etab), hipFree(c->d_flag), hipFree(c->ring_mem), hipFree(c->ring_digest);
     hipFree(c->io_buf), hipFree(c->in_buf);
     for (int l = 0; l < ZK_MAX_LANES; l++) {
@@ -217,6 +218,12 @@ static zk_status set_ring_common(zk_ctx* c, const uint8_t* d_keys, uint64_t nkey
     if (c->gk_etab && n >= GKM_MINN) {   // 33 bytes per key: the verifier's ring fold on the matrix pipe (k_gk_mfma.hip)
         HIPCHK(c, hipMalloc(&c->gk_kdig, gkm_ring_frag_bytes(N)));
         launch_gkm_ring_digits(c->stream, ring, (uint32_t)(N >> 8), c->gk_kdig);
+    }
+    if (c->gk_edig) HIPCHK(c, hipFree(c->gk_edig));
+    c->gk_edig = nullptr;
+    if (c->gk_etab && n >= GKM_MINN && c->gk_mfma_prove) {   // table E's classes 2..6 as digit fragments: the prover's matrix-pipe path
+        HIPCHK(c, hipMalloc(&c->gk_edig, gkm_etab_frag_bytes(N)));
+        launch_gkm_etab_digits(c->stream, c->gk_etab, (uint32_t)(N >> 8), c->gk_edig);
     }
     {   // digest of the padded ring: what the hardened mode hashes into the membership challenge
         if (!c->ring_digest) HIPCHK(c, hipMalloc(&c->ring_digest, 32));
@@ -356,6 +363,9 @@ static size_t carve(zk_ctx* c, Workspace& W, Soa& gk_am, uint8_t* base, uint32_t
     uint64_t tile_elems = (uint64_t)(T + 1) * C * (N >> T);
     W.gk_etab = c->gk_etab;
     W.gk_kdig = c->gk_mfma ? c->gk_kdig : nullptr;
+    W.gk_edig = c->gk_mfma ? c->gk_edig : nullptr;
+    W.gk_adig = c->gk_edig ? (int8_t*)k.take(gkm_asub_frag_bytes(C)) : nullptr;
+    W.gk_toff = (uint32_t*)k.take(4 * 264);
     W.gk_asub = c->gk_etab ? (uint32_t*)k.take(36 * 256 * (size_t)C) : nullptr;
     W.gk_order = (uint32_t*)k.take(4 * (size_t)C);
     W.gk_goff = (uint32_t*)k.take(4 * 264);
@@ -398,6 +408,7 @@ zk_status ensure_workspace(zk_ctx* c, uint32_t C, uint32_t nlanes) {
         L.W.ring = Soa{c->ring_mem, (uint32_t)c->N};
         L.W.hardened = c->mode == ZK_MODE_HARDENED, L.W.ring_digest = c->ring_digest;
         L.W.gk_kdig = c->gk_mfma ? c->gk_kdig : nullptr;
+        L.W.gk_edig = c->gk_mfma && L.W.gk_adig ? c->gk_edig : nullptr;
     }
     return ZK_OK;
 }

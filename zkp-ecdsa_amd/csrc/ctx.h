@@ -31,6 +31,8 @@ struct zk_ctx {
     uint32_t* gk_etab = nullptr;   // per-ring table of the GK block transform (k_gk.hip); nullptr for small / huge rings
     bool gk_table = true;          // ZKATTEST_GK_TABLE=0 disables it (plain fold for every ring)
     int8_t* gk_kdig = nullptr;     // the ring as int8 digit fragments (k_gk_mfma.hip), built with table E for rings of >= 2^12 keys
+    int8_t* gk_edig = nullptr;     // table E's coefficient classes 2..6 as digit fragments: the prover's matrix-pipe table path (k_gk_mfma.hip)
+    bool gk_mfma_prove = true;     // build gk_edig with the ring (ZKATTEST_GK_MFMA_PROVE; read at zk_ctx_set_ring)
     bool gk_mfma = true;           // verifier's ring fold on the matrix pipe where gk_kdig exists (zk_ctx_set_ring_fold, ZKATTEST_GK_MFMA)
     uint64_t N = 0, nkeys = 0;
     uint32_t n = 0;

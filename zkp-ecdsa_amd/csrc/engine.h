@@ -143,6 +143,9 @@ struct Workspace {
     // block-transform path of the ring fold (k_gk.hip), used when the ring has a table E (9 <= n <= GK_ETAB_MAXN)
     const uint32_t* gk_etab;     // per-ring table, owned by the context (nullptr: plain fold)
     const int8_t* gk_kdig;       // the ring as int8 digit fragments for the verifier's matrix-pipe fold (k_gk_mfma.hip; nullptr: VALU fold)
+    const int8_t* gk_edig;       // table E's coefficient classes 2..6 as int8 digit fragments (prover's matrix-pipe path; nullptr: VALU only)
+    int8_t* gk_adig;             // [tiles][6 chunks][33 digits][1 KB] digit fragments of the chunk's a_S products, proofs sorted by l_low
+    uint32_t* gk_toff;           // [257] first 16-proof tile of every l_low group
     uint32_t* gk_asub;           // [C][256][9] products of the a_j over the subsets of the 8 low bits
     uint32_t* gk_order;          // [C] proofs sorted by the 8 low bits of their ring index
     uint32_t* gk_goff;           // [257] group offsets of that order
@@ -221,6 +224,12 @@ size_t gkm_ring_frag_bytes(uint64_t N);
 size_t gkm_coef_frag_bytes(uint32_t C);
 void launch_gkm_ring_digits(hipStream_t s, const Soa& ring, uint32_t nblocks, int8_t* frag);
 void launch_v_gk_block_mfma(hipStream_t s, const VWork& V, const int8_t* ring_frag, uint32_t nblocks, uint32_t count, int8_t* coef_frag, const Soa& res);
+// prover: coefficients 2..6 of a block's polynomial (238 of its 255 products a_S * D_S) as int8 matrix products
+struct ChunkIn;
+size_t gkm_etab_frag_bytes(uint64_t N);
+size_t gkm_asub_frag_bytes(uint32_t C);
+void launch_gkm_etab_digits(hipStream_t s, const uint32_t* E, uint32_t nblocks, int8_t* edig);
+void launch_gk_block_mfma(hipStream_t s, const Workspace& W, const ChunkIn& in, uint32_t nblocks, const Soa& res);
 void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first);
 void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out,
                      const uint32_t* perm, const uint32_t* cnt, uint32_t tsplit = 1, uint32_t ostride = 1);
@@ -365,6 +374,33 @@ __device__ inline Fe<M, 2> block_inverse(const Fe<M, 2>& acc, uint32_t* lds) {
 }
 #endif
 
+// bit repacking between limb widths (all indices and shifts are compile-time constants after unrolling)
+template <int IN_BITS, int OUT_BITS, int NIN, int NOUT>
+ZK_DEV void limbs_repack(uint32_t* out, const uint32_t* in) {
+    uint64_t buf = 0;
+    int nb = 0, oi = 0;
+#pragma unroll
+    for (int i = 0; i < NIN; i++) {
+        buf |= (uint64_t)in[i] << nb;
+        nb += IN_BITS;
+        if (nb >= OUT_BITS && oi < NOUT) {
+            out[oi++] = (uint32_t)buf & ((1u << OUT_BITS) - 1);
+            buf >>= OUT_BITS;
+            nb -= OUT_BITS;
+        }
+        if (nb >= OUT_BITS && oi < NOUT) {
+            out[oi++] = (uint32_t)buf & ((1u << OUT_BITS) - 1);
+            buf >>= OUT_BITS;
+            nb -= OUT_BITS;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NOUT; k++)
+        if (k >= oi) {
+            out[k] = (uint32_t)buf & ((1u << OUT_BITS) - 1);
+            buf >>= OUT_BITS;
+        }
+}
 // Montgomery reduction of an 18-limb radix-2^30 integer T < q * 2^270: returns T / 2^270 mod q, < 2q.
 ZK_DEV Fe<ModQ, 2> redc_wide(const uint32_t T[2 * NLIMB]) {
     uint64_t acc = 0;

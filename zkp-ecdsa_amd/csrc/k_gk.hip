@@ -46,33 +46,6 @@ constexpr GkRankTab gk_make_rank_tab() {
 }
 __device__ const GkRankTab GK_RT = gk_make_rank_tab();
 
-// bit repacking between limb widths (all indices and shifts are compile-time constants after unrolling)
-template <int IN_BITS, int OUT_BITS, int NIN, int NOUT>
-ZK_DEV void limbs_repack(uint32_t* out, const uint32_t* in) {
-    uint64_t buf = 0;
-    int nb = 0, oi = 0;
-#pragma unroll
-    for (int i = 0; i < NIN; i++) {
-        buf |= (uint64_t)in[i] << nb;
-        nb += IN_BITS;
-        if (nb >= OUT_BITS && oi < NOUT) {
-            out[oi++] = (uint32_t)buf & ((1u << OUT_BITS) - 1);
-            buf >>= OUT_BITS;
-            nb -= OUT_BITS;
-        }
-        if (nb >= OUT_BITS && oi < NOUT) {
-            out[oi++] = (uint32_t)buf & ((1u << OUT_BITS) - 1);
-            buf >>= OUT_BITS;
-            nb -= OUT_BITS;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < NOUT; k++)
-        if (k >= oi) {
-            out[k] = (uint32_t)buf & ((1u << OUT_BITS) - 1);
-            buf >>= OUT_BITS;
-        }
-}
 // ---------------------------------------------------------------- per-ring table E (zk_ctx_set_ring)
 // E[((l_low * 256 + rank(S)) * 9 + limb) * nblocks + block] = limb of D_S(l_low) for that block, canonical, 29-bit limbs.
 __global__ void __launch_bounds__(256) k_gk_etab(Soa ring, uint32_t nblocks, uint32_t* E) {
@@ -106,7 +79,8 @@ size_t gk_etab_words(uint64_t N) { return (size_t)GKB_SIZE * GKB_SIZE * 9 * (N /
 // ---------------------------------------------------------------- per chunk: sort by l_low, a_S
 // order[pos] = proof, goff[g] = first sorted position of l_low group g (goff[256] = count).  One workgroup of 320 threads (a
 // 16-wave workgroup can starve behind the other lane's kernels, see k_scan).
-__global__ void __launch_bounds__(320) k_gk_sort(ChunkIn in, uint32_t* order, uint32_t* goff) {
+// toff (may be nullptr): toff[g] = first 16-proof tile of group g in the matrix-core path (k_gk_mfma.hip), toff[256] = tiles in all
+__global__ void __launch_bounds__(320) k_gk_sort(ChunkIn in, uint32_t* order, uint32_t* goff, uint32_t* toff) {
     __shared__ uint32_t hist[GKB_SIZE], offs[GKB_SIZE + 1];
     uint32_t t = threadIdx.x;
     if (t < GKB_SIZE) hist[t] = 0;
@@ -114,9 +88,13 @@ __global__ void __launch_bounds__(320) k_gk_sort(ChunkIn in, uint32_t* order, ui
     for (uint32_t p = t; p < in.count; p += blockDim.x) atomicAdd(&hist[in.which[p] & 255], 1u);
     __syncthreads();
     if (t == 0) {
-        uint32_t a = 0;
-        for (int g = 0; g < GKB_SIZE; g++) offs[g] = a, a += hist[g];
+        uint32_t a = 0, tl = 0;
+        for (int g = 0; g < GKB_SIZE; g++) {
+            offs[g] = a, a += hist[g];
+            if (toff) toff[g] = tl, tl += (hist[g] + 15) >> 4;
+        }
         offs[GKB_SIZE] = a;
+        if (toff) toff[GKB_SIZE] = tl;
     }
     __syncthreads();
     if (t <= GKB_SIZE) goff[t] = offs[t];
@@ -167,7 +145,8 @@ ZK_DEV void gkc_mac(GkCols& a, const uint32_t x[9], const uint32_t y[9]) {
 }
 template <bool UNI>
 __global__ void __launch_bounds__(256) k_gk_block(Workspace W, ChunkIn in, const uint32_t* __restrict__ E, const uint32_t* __restrict__ asub,
-                                                  const uint32_t* __restrict__ order, const uint32_t* __restrict__ goff, uint32_t nblocks, uint32_t nwg, Soa res) {
+                                                  const uint32_t* __restrict__ order, const uint32_t* __restrict__ goff, uint32_t nblocks, uint32_t nwg, Soa res,
+                                                  uint32_t kmask) {   // bit k set: coefficient k is computed here (the others on the matrix cores)
     // XCD-aware placement: workgroup w runs on XCD w % 8; XCD x takes the x-th contiguous eighth of the sorted work
     uint32_t w = blockIdx.x, seg = (nwg + 7) / 8;
     uint32_t widx = (w & 7) * seg + (w >> 3);
@@ -199,6 +178,7 @@ __global__ void __launch_bounds__(256) k_gk_block(Workspace W, ChunkIn in, const
     const uint32_t* e = E + (size_t)llow * GKB_SIZE * 9 * nblocks + block;
 #pragma unroll 1
     for (uint32_t k = 0; k < 8; k++) {
+        if (!((kmask >> k) & 1)) continue;
         GkCols acc;
         gkc_zero(acc);
         uint32_t r0 = GK_RT.kstart[k], r1 = GK_RT.kstart[k + 1];
@@ -227,13 +207,16 @@ __global__ void __launch_bounds__(256) k_gk_block(Workspace W, ChunkIn in, const
 }
 void launch_gk_block_stage(hipStream_t s, const Workspace& W, const ChunkIn& in, const Soa& am, const Soa& res) {
     uint32_t nblocks = W.N >> GKB_BITS;
-    hipLaunchKernelGGL(k_gk_sort, dim3(1), dim3(320), 0, s, in, W.gk_order, W.gk_goff);
+    const bool mm = W.gk_edig != nullptr && W.n >= GKM_MINN;   // coefficients 2..6 (238 of the 255 products) on the matrix cores
+    hipLaunchKernelGGL(k_gk_sort, dim3(1), dim3(320), 0, s, in, W.gk_order, W.gk_goff, mm ? W.gk_toff : nullptr);
     hipLaunchKernelGGL(k_gk_asub, dim3(in.count), dim3(256), 0, s, W, in.count, am, W.gk_asub);
     bool uni = (nblocks & 255) == 0;
     uint32_t nwg = uni ? in.count * (nblocks >> 8) : (uint32_t)(((uint64_t)in.count * nblocks + 255) / 256);
     uint32_t grid = ((nwg + 7) / 8) * 8;
-    if (uni) hipLaunchKernelGGL(k_gk_block<true>, dim3(grid), dim3(256), 0, s, W, in, W.gk_etab, W.gk_asub, W.gk_order, W.gk_goff, nblocks, nwg, res);
-    else hipLaunchKernelGGL(k_gk_block<false>, dim3(grid), dim3(256), 0, s, W, in, W.gk_etab, W.gk_asub, W.gk_order, W.gk_goff, nblocks, nwg, res);
+    const uint32_t kmask = mm ? 0x83u : 0xffu;   // with the matrix path: coefficients 0, 1, 7 (1 + 8 + 8 products) and x^8 stay here
+    if (uni) hipLaunchKernelGGL(k_gk_block<true>, dim3(grid), dim3(256), 0, s, W, in, W.gk_etab, W.gk_asub, W.gk_order, W.gk_goff, nblocks, nwg, res, kmask);
+    else hipLaunchKernelGGL(k_gk_block<false>, dim3(grid), dim3(256), 0, s, W, in, W.gk_etab, W.gk_asub, W.gk_order, W.gk_goff, nblocks, nwg, res, kmask);
+    if (mm) launch_gk_block_mfma(s, W, in, nblocks, res);
 }
 
 // ---------------------------------------------------------------- verifier: total = sum_i key_i prod_j f_{j,i_j}(x)  (gk.ts:239-250)
