@@ -186,6 +186,32 @@ async function gpu() {
     assert.throws(() => zk.native.setRing(eng.h, wl.ring), /busy/)
     assert.throws(() => zk.native.destroyPool(eng.h), /while an asynchronous batch/)
     await running
+    // streamed form: five batches through three page-locked buffers, three inside the engine at a time; bytes = the synchronous call
+    {
+        const nb = 5, bufs = [0, 1, 2].map(() => zk.Engine.hostAlloc(4 << 20))
+        eng.setOption('inflight', 3)
+        const sub = (k) => eng.proveStream(wl.msg, wl.sig, wl.pk, wl.which, wl.seeds, bufs[k % 3])
+        const pend = [sub(0), sub(1), sub(2)]
+        assert.throws(() => zk.native.setRing(eng.h, wl.ring), /busy/)                   // exclusive calls wait for the stream to drain
+        assert.throws(() => zk.native.destroyPool(eng.h), /while an asynchronous batch/)
+        for (let k = 0; k < nb; k++) {
+            const r = await pend[k]
+            assert.ok(r.status.every((v) => v === 0) && r.proofs.every((p, i) => p.equals(proofs[i])), 'streamed batch ' + k)
+            if (k + 3 < nb) pend.push(sub(k + 3))                                        // its buffer is free again
+        }
+        // verify straight out of a page-locked buffer; a forged proof in the middle batch
+        const packed = zk.Engine.hostAlloc(4 << 20), off = new BigUint64Array(B), len = new BigUint64Array(B)
+        let at = 0n
+        proofs.forEach((p, i) => { p.copy(packed, Number(at)); off[i] = at; len[i] = BigInt(p.length); at += BigInt(p.length) })
+        const forgedPacked = zk.Engine.hostAlloc(4 << 20)
+        packed.copy(forgedPacked)
+        forgedPacked[Number(off[2] + len[2]) - 1] ^= 1
+        const ob = Buffer.from(off.buffer), lb = Buffer.from(len.buffer)
+        const vs = await Promise.all([eng.verifyStream(wl.msg, packed, ob, lb), eng.verifyStream(wl.msg, forgedPacked, ob, lb), eng.verifyStream(wl.msg, packed, ob, lb)])
+        assert.deepStrictEqual(vs.map((v) => v.ok), [Array(B).fill(true), [true, true, false, true, true, true], Array(B).fill(true)])
+        await assert.rejects(eng.proveStream(wl.msg, wl.sig, wl.pk, wl.which, wl.seeds, Buffer.alloc(64)), /buffer|page-locked|argument/i)   // not page-locked, too small
+        assert.strictEqual(eng.setRing(wl.ring), 'single')                               // drained: exclusive calls work again
+    }
     // two contexts on this GPU behind one handle: sharded batch, same bytes; the ring went device to device
     const duo = new zk.Engine([0, 0])
     duo.setParams(params)

@@ -55,5 +55,9 @@ export class Engine {
     proveBatch(msg: Buffer, sig: Buffer, pk: Buffer, which: number[] | Buffer, seeds?: Buffer): Buffer[]
     verifyBatch(msg: Buffer, proofs: Buffer[], seeds?: Buffer): Verdicts
     proveBatchAsync(msg: Buffer, sig: Buffer, pk: Buffer, which: number[] | Buffer, seeds?: Buffer): Promise<Buffer[]>
+    /** Streamed form (zk_pool_prove_submit / _wait): up to `inflight` batches inside the engine; `out` is a page-locked Buffer (Engine.hostAlloc) owned by the job until its Promise settles. */
+    static hostAlloc(bytes: number): Buffer
+    proveStream(msg: Buffer, sig: Buffer, pk: Buffer, which: number[] | Buffer, seeds: Buffer | undefined, out: Buffer): Promise<{ proofs: Buffer[]; status: Int32Array; used: number }>
+    verifyStream(msg: Buffer, blob: Buffer, offsets: Buffer, lengths: Buffer, seeds?: Buffer): Promise<{ ok: boolean[]; status: Int32Array }>
     verifyBatchAsync(msg: Buffer, proofs: Buffer[], seeds?: Buffer): Promise<Verdicts>
 }

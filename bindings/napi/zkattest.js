@@ -319,6 +319,21 @@ class Engine {
     proveBatchAsync(msg, sig, pk, which, seeds) { return this._chain(() => this._proveNow(msg, sig, pk, which, seeds)) }
     verifyBatchAsync(msg, proofs, seeds) { return this._chain(() => this._verifyNow(msg, proofs, seeds)) }
     run(f) { return this._chain(f) }   // any other call on the handle, queued behind the running batches
+    // Streamed form (zk_pool_prove_submit / _wait, DESIGN.md 5c): every call returns its Promise at once and up to `inflight` batches are
+    // inside the engine together (setOption('inflight', n), default 3), so the pipeline does not drain between batches.  `out` /
+    // `blob` are page-locked Buffers (Engine.hostAlloc) owned by the job until its Promise settles -- one per batch in flight.
+    // No other call on this engine until every streamed Promise has settled.
+    static hostAlloc(bytes) { return native.hostAlloc(bytes) }
+    proveStream(msg, sig, pk, which, seeds, out) {   // -> { proofs: Buffer[] (views into out), status: Int32Array }
+        const [B, w, s] = this._proveArgs(msg, which, seeds)
+        return native.proveSubmit(this.h, msg, sig, pk, w, s, out).then((r) => {
+            const off = u64(r.offsets), len = u64(r.lengths)
+            return { proofs: Array.from({ length: B }, (_, b) => r.proofs.slice(Number(off[b]), Number(off[b] + len[b]))), status: i32(r.status), used: r.used }
+        })
+    }
+    verifyStream(msg, blob, offsets, lengths, seeds) {   // packed proofs in a page-locked Buffer -> { ok: boolean[], status: Int32Array }
+        return native.verifySubmit(this.h, msg, blob, offsets, lengths, seeds || null).then((r) => ({ ok: Array.from(r.ok, (v) => v === 1), status: i32(r.status) }))
+    }
 }
 
 // ---------------------------------------------------------------- context cache: (params) -> engine, (engine, ring) -> loaded

@@ -7,7 +7,8 @@
  * One handle = one zk_pool = the listed GPUs of this node (one GPU: a pool of one).  A handle runs one batch at a time: the
  * synchronous calls finish before they return, the *Async calls run on a libuv worker thread and mark the handle busy
  * until their Promise settles; a second call on a busy handle, any call on a destroyed one, and destroying a busy one
- * throw instead of touching freed memory.  The garbage collector destroys a handle nobody closed.
+ * throw instead of touching freed memory.  The garbage collector destroys a handle nobody closed.  proveSubmit / verifySubmit
+ * are the streamed form: several batches of one handle in flight (zk_pool_prove_submit / _wait), one Promise per batch.
  * Large proof buffers are page-locked (zk_host_alloc) and handed to JavaScript as external Buffers, so the engine moves
  * the proof bytes by DMA under its kernels and nothing is copied on the way out. */
 #define NAPI_VERSION 3
@@ -28,11 +29,16 @@
     } while (0)
 #define PINNED_MIN ((size_t)32 << 20) /* proof buffers from this size on are page-locked */
 
+struct Job;
 typedef struct {
     zk_pool *pool;
     int busy, closed;
     int orphaned; /* the external was finalized (environment teardown) while a batch was still running: job_complete frees it */
     uint32_t sec;
+    /* streamed batches (proveSubmit / verifySubmit): jobs in submission order, at most `inflight` of them submitted to the engine */
+    struct Job *sq_head, *sq_tail;
+    int sq_submitted, sq_running;
+    uint32_t inflight;
 } Handle;
 
 static napi_value throw_text(napi_env env, zk_status st, const char *detail) {
@@ -224,6 +230,11 @@ static napi_value SetOption(napi_env env, napi_callback_info info) {
     uint32_t val;
     NAPI_OK(napi_get_value_string_utf8(env, argv[1], name, sizeof name, &ln));
     NAPI_OK(napi_get_value_uint32(env, argv[2], &val));
+    if (!strcmp(name, "inflight")) { /* streamed jobs inside the engine at a time (proveSubmit / verifySubmit); the addon's own knob */
+        if (val < 1 || val > 8) return throw_text(env, ZK_E_ARG, name);
+        h->inflight = val;
+        return NULL;
+    }
     for (int i = 0; i < zk_pool_size(h->pool); i++) {
         zk_ctx *c = zk_pool_ctx(h->pool, i);
         zk_status st = !strcmp(name, "chunk")         ? zk_ctx_set_chunk(c, val)
@@ -233,6 +244,8 @@ static napi_value SetOption(napi_env env, napi_callback_info info) {
                        : !strcmp(name, "batchVerify") ? zk_ctx_set_batch_verify(c, val)
                        : !strcmp(name, "mode")        ? zk_ctx_set_mode(c, val)
                        : !strcmp(name, "slice")       ? zk_ctx_set_slice(c, val)
+                       : !strcmp(name, "ringFold")    ? zk_ctx_set_ring_fold(c, val)
+                       : !strcmp(name, "verifyGroups") ? zk_ctx_set_verify_groups(c, val)
                                                       : ZK_E_ARG;
         if (st != ZK_OK) return throw_text(env, st, name);
     }
@@ -309,7 +322,7 @@ static napi_value SynthWorkload(napi_env env, napi_callback_info info) { /* (h, 
 }
 
 /* ---- batches.  A Job owns copies of the small inputs; the (large) proof input of a verification is referenced, not copied. */
-typedef struct {
+typedef struct Job {
     int verify, async;
     Handle *h;
     size_t B;
@@ -325,6 +338,13 @@ typedef struct {
     char err[384];
     napi_deferred deferred;
     napi_async_work work;
+    /* streamed form */
+    struct Job *next;
+    int stream, submitted, op; /* op of the running step: 0 = submit, 1 = wait */
+    zk_pool_job *pj;
+    napi_ref out_ref; /* the caller's page-locked output Buffer */
+    uint8_t *out_ext;
+    size_t out_ext_cap;
 } Job;
 static uint8_t *dup_bytes(const uint8_t *p, size_t n) {
     uint8_t *q = malloc(n ? n : 1);
@@ -334,6 +354,7 @@ static uint8_t *dup_bytes(const uint8_t *p, size_t n) {
 static void job_free(napi_env env, Job *j) {
     if (j->proofs_ref && env) napi_delete_reference(env, j->proofs_ref);
     if (j->h_ref && env) napi_delete_reference(env, j->h_ref);
+    if (j->out_ref && env) napi_delete_reference(env, j->out_ref);
     slab_free(&j->out);
     free(j->msg), free(j->sig), free(j->pk), free(j->seeds), free(j->which), free(j->off), free(j->len), free(j->status), free(j->ok);
     free(j);
@@ -495,6 +516,198 @@ static napi_value verify_common(napi_env env, napi_callback_info info, int async
 }
 static napi_value VerifyBatch(napi_env env, napi_callback_info info) { return verify_common(env, info, 0); }
 static napi_value VerifyBatchAsync(napi_env env, napi_callback_info info) { return verify_common(env, info, 1); }
+
+/* ---- streamed batches: several jobs of one handle in flight (zk_pool_prove_submit / _wait).
+ * proveSubmit / verifySubmit return a Promise at once and append the job to the handle's queue.  The engine wants one caller at a
+ * time and its waits in submission order, so every engine call of the queue -- a submit or a wait -- is ONE libuv work item, and the
+ * next one is chosen on the main thread when it completes: submit the oldest job not yet submitted while fewer than `inflight`
+ * (setOption 'inflight', default 3) are inside the engine, otherwise wait for the oldest.  With three jobs queued the engine sees
+ * submit(0) submit(1) submit(2) wait(0) submit(3) wait(1) ...  A handle with queued jobs is busy for every other call. */
+static void stream_kick(napi_env env, Handle *h);
+static void stream_execute(napi_env env, void *data) { /* worker thread: no N-API calls */
+    Job *j = data;
+    zk_pool *p = j->h->pool;
+    if (j->op == 0) {
+        if (j->verify) {
+            j->rc = zk_pool_verify_submit(p, j->B, j->msg, j->proofs_in, j->off, j->len, j->seeds, j->ok, j->status, &j->pj);
+        } else {
+            zk_rng rng = {ZK_RNG_SEED, j->seeds, 0};
+            j->rc = zk_pool_prove_submit(p, j->B, j->msg, j->sig, j->pk, j->which, &rng, j->out_ext, j->out_ext_cap, j->off, j->len, j->status, &j->pj);
+        }
+    } else {
+        j->rc = j->verify ? zk_pool_verify_wait(p, j->pj) : zk_pool_prove_wait(p, j->pj);
+    }
+    if (j->rc != ZK_OK) snprintf(j->err, sizeof j->err, "%s: %s", zk_strerror(j->rc), zk_pool_last_error(p));
+}
+static napi_value stream_result(napi_env env, Job *j) {
+    napi_value v, out = NULL;
+    if (napi_create_object(env, &v) != napi_ok) return NULL;
+    if (j->verify) {
+        set_prop(env, v, "ok", new_buffer(env, j->ok, j->B));
+    } else {
+        uint64_t end = 0;
+        for (size_t b = 0; b < j->B; b++)
+            if (j->off[b] + j->len[b] > end) end = j->off[b] + j->len[b];
+        napi_value used;
+        if (napi_get_reference_value(env, j->out_ref, &out) != napi_ok || napi_create_double(env, (double)end, &used) != napi_ok) return NULL;
+        set_prop(env, v, "proofs", out), set_prop(env, v, "used", used);
+        set_prop(env, v, "offsets", new_buffer(env, j->off, 8 * j->B)), set_prop(env, v, "lengths", new_buffer(env, j->len, 8 * j->B));
+    }
+    set_prop(env, v, "status", new_buffer(env, j->status, 4 * j->B));
+    return v;
+}
+static void stream_settle(napi_env env, Job *j, int ok) {
+    napi_value v = ok ? stream_result(env, j) : NULL;
+    if (v) {
+        napi_resolve_deferred(env, j->deferred, v);
+    } else {
+        napi_value msg, e;
+        napi_create_string_utf8(env, j->rc != ZK_OK ? j->err : "streamed batch failed", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &e);
+        napi_reject_deferred(env, j->deferred, e);
+    }
+    job_free(env, j);
+}
+static void stream_unlink(Handle *h, Job *j) {
+    Job **pp = &h->sq_head, *prev = NULL;
+    while (*pp && *pp != j) prev = *pp, pp = &(*pp)->next;
+    if (*pp) *pp = j->next;
+    if (h->sq_tail == j) h->sq_tail = prev;
+}
+static void stream_complete(napi_env env, napi_status status, void *data) { /* main thread */
+    Job *j = data;
+    Handle *h = j->h;
+    h->sq_running = 0;
+    napi_delete_async_work(env, j->work);
+    int ok = status == napi_ok && j->rc == ZK_OK;
+    if (j->op == 0 && ok) {
+        j->submitted = 1, h->sq_submitted++;
+    } else { /* a finished wait, or a submit the engine refused: the job leaves the queue */
+        if (j->op == 1) h->sq_submitted--;
+        stream_unlink(h, j);
+        stream_settle(env, j, ok);
+    }
+    if (!h->sq_head) {
+        h->busy = 0;
+        if (h->orphaned) {
+            handle_release(h);
+            return;
+        }
+    }
+    stream_kick(env, h);
+}
+static void stream_kick(napi_env env, Handle *h) {
+    while (!h->sq_running && h->sq_head) {
+        Job *u = h->sq_head;
+        while (u && u->submitted) u = u->next;
+        Job *j = u && (uint32_t)h->sq_submitted < (h->inflight ? h->inflight : 3) ? u : h->sq_head;
+        j->op = j == u ? 0 : 1;
+        napi_value rn;
+        if (napi_create_string_utf8(env, "zkattest.stream", NAPI_AUTO_LENGTH, &rn) == napi_ok &&
+            napi_create_async_work(env, NULL, rn, stream_execute, stream_complete, j, &j->work) == napi_ok) {
+            if (napi_queue_async_work(env, j->work) == napi_ok) {
+                h->sq_running = 1;
+                return;
+            }
+            napi_delete_async_work(env, j->work);
+        }
+        /* could not queue: a job that is inside the engine has to be waited for here, the others are dropped */
+        if (j->submitted) {
+            j->rc = j->verify ? zk_pool_verify_wait(h->pool, j->pj) : zk_pool_prove_wait(h->pool, j->pj);
+            h->sq_submitted--;
+        }
+        snprintf(j->err, sizeof j->err, "could not queue the streamed batch");
+        j->rc = j->rc == ZK_OK ? ZK_E_BUFFER : j->rc;
+        stream_unlink(h, j);
+        stream_settle(env, j, 0);
+    }
+    if (!h->sq_head) h->busy = 0;
+}
+static napi_value stream_enqueue(napi_env env, Job *j, napi_value hv) {
+    napi_value promise;
+    Handle *h = j->h;
+    if (napi_create_reference(env, hv, 1, &j->h_ref) != napi_ok || napi_create_promise(env, &j->deferred, &promise) != napi_ok) {
+        job_free(env, j);
+        return throw_text(env, ZK_E_BUFFER, "could not queue the streamed batch");
+    }
+    j->stream = 1;
+    if (h->sq_tail) h->sq_tail->next = j;
+    else h->sq_head = j;
+    h->sq_tail = j;
+    h->busy = 1;
+    stream_kick(env, h);
+    return promise;
+}
+/* a handle that is busy with streamed jobs accepts more of them; one that runs an exclusive batch does not */
+static Handle *get_stream_handle(napi_env env, napi_value v) {
+    Handle *h = get_handle(env, v, 1);
+    if (h && h->busy && !h->sq_head) {
+        napi_throw_error(env, NULL, "the engine is busy with an asynchronous batch (one batch at a time per engine)");
+        return NULL;
+    }
+    return h;
+}
+/* (h, msg Bx32, sig Bx64, pk Bx64, which Bx4, seeds Bx32, out: page-locked Buffer from hostAlloc)
+ *   -> Promise<{proofs: out, used: bytes, offsets, lengths, status}>; `out` belongs to the job until its Promise settles */
+static napi_value ProveSubmit(napi_env env, napi_callback_info info) {
+    napi_value argv[7];
+    if (!get_args(env, info, 7, argv)) return NULL;
+    Handle *h = get_stream_handle(env, argv[0]);
+    uint8_t *msg, *sig, *pk, *which, *seeds, *out;
+    size_t lm, ls, lp, lw, lse, lo;
+    if (!h || !get_bytes(env, argv[1], &msg, &lm) || !get_bytes(env, argv[2], &sig, &ls) || !get_bytes(env, argv[3], &pk, &lp) ||
+        !get_bytes(env, argv[4], &which, &lw) || !get_bytes(env, argv[5], &seeds, &lse) || !get_bytes(env, argv[6], &out, &lo))
+        return NULL;
+    size_t B = lm / 32;
+    if (!B || lm != 32 * B || ls != 64 * B || lp != 64 * B || lw != 4 * B || lse != 32 * B || !out) {
+        napi_throw_range_error(env, NULL, "proveSubmit: per proof 32-byte msgHash, 64-byte signature, 64-byte public key, u32 index, 32-byte seed; a page-locked output Buffer");
+        return NULL;
+    }
+    Job *j = calloc(1, sizeof *j);
+    if (!j) return throw_text(env, ZK_E_BUFFER, "out of memory");
+    j->h = h, j->B = B, j->async = 1, j->out_ext = out, j->out_ext_cap = lo;
+    j->msg = dup_bytes(msg, lm), j->sig = dup_bytes(sig, ls), j->pk = dup_bytes(pk, lp), j->seeds = dup_bytes(seeds, lse);
+    j->which = (uint32_t *)dup_bytes(which, lw);
+    j->off = malloc(8 * B), j->len = malloc(8 * B), j->status = malloc(4 * B);
+    if (!j->msg || !j->sig || !j->pk || !j->seeds || !j->which || !j->off || !j->len || !j->status ||
+        napi_create_reference(env, argv[6], 1, &j->out_ref) != napi_ok) {
+        job_free(env, j);
+        return throw_text(env, ZK_E_BUFFER, "out of memory");
+    }
+    return stream_enqueue(env, j, argv[0]);
+}
+/* (h, msg Bx32, proofs: page-locked Buffer, offsets, lengths, seeds | null) -> Promise<{ok, status}> */
+static napi_value VerifySubmit(napi_env env, napi_callback_info info) {
+    napi_value argv[6];
+    if (!get_args(env, info, 6, argv)) return NULL;
+    Handle *h = get_stream_handle(env, argv[0]);
+    uint8_t *msg, *proofs, *offs, *lens, *seeds;
+    size_t lm, lp, lo, ll, ls;
+    if (!h || !get_bytes(env, argv[1], &msg, &lm) || !get_bytes(env, argv[2], &proofs, &lp) || !get_bytes(env, argv[3], &offs, &lo) ||
+        !get_bytes(env, argv[4], &lens, &ll) || !get_bytes(env, argv[5], &seeds, &ls))
+        return NULL;
+    size_t B = lm / 32;
+    if (!B || lm != 32 * B || lo != 8 * B || ll != 8 * B || (seeds && ls != 32 * B) || !proofs) {
+        napi_throw_range_error(env, NULL, "verifySubmit: B message hashes, B offsets, B lengths, B seeds or null");
+        return NULL;
+    }
+    Job *j = calloc(1, sizeof *j);
+    if (!j) return throw_text(env, ZK_E_BUFFER, "out of memory");
+    j->verify = 1, j->h = h, j->B = B, j->async = 1;
+    j->msg = dup_bytes(msg, lm), j->off = (uint64_t *)dup_bytes(offs, lo), j->len = (uint64_t *)dup_bytes(lens, ll);
+    j->seeds = seeds ? dup_bytes(seeds, ls) : NULL;
+    j->ok = malloc(B), j->status = malloc(4 * B);
+    j->proofs_in = proofs;
+    int okk = j->msg && j->off && j->len && j->ok && j->status && (!seeds || j->seeds);
+    for (size_t b = 0; okk && b < B; b++) okk = j->off[b] <= lp && j->len[b] <= lp - j->off[b];
+    if (okk) okk = napi_create_reference(env, argv[2], 1, &j->proofs_ref) == napi_ok;
+    if (!okk) {
+        job_free(env, j);
+        napi_throw_range_error(env, NULL, "verifySubmit: out of memory, or offsets / lengths beyond the proof buffer");
+        return NULL;
+    }
+    return stream_enqueue(env, j, argv[0]);
+}
 
 static napi_value HostAlloc(napi_env env, napi_callback_info info) { /* (bytes) -> page-locked Buffer (zk_host_alloc) */
     napi_value argv[1];
@@ -690,7 +903,8 @@ static napi_value Init(napi_env env, napi_value exports) {
                {"proveBatch", ProveBatch},       {"verifyBatch", VerifyBatch},       {"proveBatchAsync", ProveBatchAsync},
                {"verifyBatchAsync", VerifyBatchAsync}, {"proofToJson", ProofToJson}, {"proofFromJson", ProofFromJson},
                {"keysToInts", KeysToInts},       {"hostAlloc", HostAlloc},           {"hardenedH", HardenedH},
-               {"proofsToJsonBatch", ProofsToJsonBatch}, {"proofsFromJsonBatch", ProofsFromJsonBatch}};
+               {"proofsToJsonBatch", ProofsToJsonBatch}, {"proofsFromJsonBatch", ProofsFromJsonBatch},
+               {"proveSubmit", ProveSubmit},     {"verifySubmit", VerifySubmit}};
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;
         if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;
