@@ -38,7 +38,7 @@ VALU_MAD_8CHAIN_TOPS = 27.83
 HBM_PEAK_GBPS = 8000.0
 # multiplier-pipe instructions (v_mad_u64_u32 + v_mul_lo_u32) per Tom-field Montgomery product: 1224 + 72 per table addition
 # of 8 products in k_tom_commit (tools/isa_blocks.py; nominal 171 = 81 + 81 + 9, the modulus limb that is zero costs nothing);
-# PMC (profiles/r02_pmc_summary.txt): 36 674 VALU wave-instructions per unpaired commitment of 163 products on average = 225
+# PMC (profiles/r03_pmc_summary.txt; r02: 36 674): 36 769 VALU wave-instructions per unpaired commitment of 163 products on average = 225
 # instructions per product, 230 in the paired kernel (round 1: 239)
 MACS_PER_MODMUL = 162
 
@@ -50,12 +50,12 @@ def tom_commit_modmuls(comb_bits):
 
 TOM_COMMIT_NOMINAL = 4064      # reference: 256 dbl + 160 add (src/curves/group.ts:97-132)
 TOM_COMMIT_BYTES = 2 * 36 + 3 * 36  # algorithmic HBM bytes per commitment: read (v, r), write (X, Y, Z)
-# PMC passes (profiles/r02_pmc_summary.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate runs, batch 16384),
+# PMC passes (profiles/r03_pmc_summary.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate runs, batch 16384),
 # bytes per commitment through the L2's memory-side port, keyed by comb width.  24 bits (128-byte table entries, 47 GB of
-# tables): 2 x 1251 B fetched (gfx950 tallies 16-byte-per-lane loads at half their bytes, MI355X_MICROARCH.md section HBM;
+# tables): 2 x 1310 B fetched (round 2: 2 x 1251) (gfx950 tallies 16-byte-per-lane loads at half their bytes, MI355X_MICROARCH.md section HBM;
 # 20.3 gathers x 128 B = 2600 B expected) + 112 B written.  16 bits (112-byte entries, 235 MB; round-1 pass): 3238 B (raw) + 111 B.
-TOM_COMMIT_PMC_BYTES = {24: 2501 + 112, 16: 3238 + 111}
-PMC_SOURCE = 'profiles/r02_pmc_summary.txt (separate rocprofv3 --pmc passes at batch 16384; constants of bench.py, NOT measured in this run)'
+TOM_COMMIT_PMC_BYTES = {24: 2620 + 113, 16: 3238 + 111}
+PMC_SOURCE = 'profiles/r03_pmc_summary.txt (separate rocprofv3 --pmc passes at batch 16384; constants of bench.py, NOT measured in this run)'
 # same passes, SQ counters at 24 bits: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave at 2 waves per SIMD (VALU pipe busy
 # 99 % of the time), SQ_WAIT_INST_ANY 0.378, SQ_WAIT_ANY (memory) 0.117
 TOM_COMMIT_VALU_ACTIVE_PER_WAVE = {24: 0.495}
@@ -758,7 +758,7 @@ def main():
                                    'the kernel issues 1.39 VALU instructions per multiplier instruction on top (profiles/r03_valu_peak_microbench.txt, DESIGN.md section 8)'},
             'traffic': int(commits_per_step / max(1, launches_per_step) * pmc_bytes) if pmc_bytes else None,
             'traffic_note': ('bytes per launch = units per launch x %d B (FETCH_SIZE + WRITE_SIZE per commitment, separate rocprofv3 --pmc passes, '
-                             'profiles/r02_pmc_summary.txt); table gathers, not the 180 algorithmic bytes, dominate' % pmc_bytes) if pmc_bytes
+                             'profiles/r03_pmc_summary.txt); table gathers, not the 180 algorithmic bytes, dominate' % pmc_bytes) if pmc_bytes
                             else 'no PMC pass recorded for this comb width',
             'valu_active_per_wave': TOM_COMMIT_VALU_ACTIVE_PER_WAVE.get(args.comb_bits),
             'pmc_source': PMC_SOURCE,
