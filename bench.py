@@ -581,6 +581,7 @@ def main():
     ap.add_argument('--host-io-stream-vinflight', type=int, default=2, help='jobs in flight of the streamed verify batches (link-bound: two keep the H2D stream full)')
     ap.add_argument('--host-io-stream-configs', default='22016:3:8192', help='chunk:lanes:slice settings of the streamed prove batches (comma-separated; the best is reported)')
     ap.add_argument('--host-io-stream-vconfigs', default='32768:2', help='chunk:lanes settings of the streamed verify batches')
+    ap.add_argument('--device-stream', type=int, default=0, help='also time the steps as jobs kept in flight on the context (zk_prove_submit_device / zk_prove_wait, this many at a time, 2..4; every job its own output buffer): the pipeline does not drain between steps')
     ap.add_argument('--pool', action='store_true', help="ONE process, --gpus devices through the library's own zk_pool (RCCL ring broadcast, shards on host threads, page-locked host buffers): python bench.py --pool --gpus N")
     ap.add_argument('--pool-devices', default='', help='--pool: comma-separated device ids (default 0..gpus-1; a device may repeat: several contexts on one GPU)')
     ap.add_argument('--host-io-pageable', action='store_true', help='also measure ordinary (pageable) host buffers')
@@ -665,6 +666,39 @@ def main():
         step()
     barrier()
     dt = time.time() - t0
+    # the same steps as jobs in flight on the context: submit(0) .. submit(n-1); wait(0); submit(n); wait(1); ...
+    dstream = None
+    if args.device_stream >= 2:
+        nf = min(args.device_stream, 4)
+        outs = [(d_out, d_off, d_st)] + [(torch.empty(cap, dtype=torch.uint8, device=dev), torch.empty(B + 1, dtype=torch.int64, device=dev),
+                                          torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(nf - 1)]
+        ref_sum = int(d_out[:int(d_off[B].item())].to(torch.int64).sum().item())
+        torch.cuda.synchronize()
+
+        def submit(k):
+            o, f, st_ = outs[k % nf]
+            return eng.prove_submit_device(B, d_msg.data_ptr(), d_sig.data_ptr(), d_pk.data_ptr(), d_which.data_ptr(), d_seeds.data_ptr(), o.data_ptr(), cap, f.data_ptr(), st_.data_ptr())
+
+        def run(K):
+            q = [submit(k) for k in range(min(nf, K))]
+            for k in range(K):
+                eng.prove_wait(q[k])
+                if k + nf < K:
+                    q.append(submit(k + nf))
+        run(max(args.warmup, nf))
+        barrier()
+        K = max(args.steps, 2 * nf)
+        ts0 = time.time()
+        run(K)
+        barrier()
+        sdt = time.time() - ts0
+        if world > 1:
+            t = torch.tensor([sdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sdt = float(t.item())
+        same = all(int(o[:int(f[B].item())].to(torch.int64).sum().item()) == ref_sum and int((st_ != 0).sum().item()) == 0 for o, f, st_ in outs)
+        dstream = {'jobs_in_flight': nf, 'steps': K, 'value': round(world * B * K / sdt, 2), 'ms_per_step': round(1000 * sdt / K, 2), 'outputs_equal_sync_call': bool(same)}
+        del outs
     # per-kernel timings for the roofline: ONE extra pass with strictly serial kernels (single lane), HIP events on the
     # engine's stream around every launch.  In the timed steps above the chunks of a step overlap on their lanes' streams, which makes a
     # single kernel's duration ill-defined; this pass is not part of `value`.
@@ -813,6 +847,8 @@ def main():
             'gpu_ms_note': 'serial single-lane pass (sum = %.1f ms); the timed steps overlap %d chunks on %d streams' % (gpu_ms / max(1, args.roofline_steps), args.lanes, args.lanes),
             'roofline': roofline, 'cpu_baseline': cpu, 'verify': verify, 'host_io': host_io, 'json': json_rates,
         }
+        if dstream:
+            line['device_stream'] = dstream
         if host_io and 'pinned' in host_io:   # the SURVEY.md 8(d) form of the metric, next to the device-resident `value`
             line['value_pcie_inclusive'] = host_io['pinned']['proofs_per_s']
             line['verify_pcie_inclusive'] = host_io['pinned']['verifies_per_s']

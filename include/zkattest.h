@@ -201,6 +201,11 @@ zk_status zk_verify_batch_device(zk_ctx *ctx, uint64_t B, const void *d_msg_hash
 typedef struct zk_job zk_job;
 zk_status zk_prove_submit(zk_ctx *ctx, uint64_t B, const uint8_t *msg_hash, const uint8_t *sig, const uint8_t *pk_xy, const uint32_t *which,
                           const zk_rng *rng, uint8_t *out, uint64_t out_cap, uint64_t *out_off /*B+1*/, int32_t *per_proof_status /*B*/, zk_job **job);
+/* the same job with every buffer already in HBM (zk_prove_batch_device's arguments; rng->data is a device pointer): nothing crosses
+ * the link, consecutive batches keep the lanes' pipelines full.  The buffers must be complete when the call is made. */
+zk_status zk_prove_submit_device(zk_ctx *ctx, uint64_t B, const uint8_t *d_msg_hash, const uint8_t *d_sig, const uint8_t *d_pk_xy, const uint32_t *d_which,
+                                 const zk_rng *rng, uint8_t *d_out, uint64_t out_cap, uint64_t *d_out_off /*B+1*/, int32_t *d_per_proof_status /*B*/,
+                                 zk_job **job);
 zk_status zk_prove_wait(zk_ctx *ctx, zk_job *job);   /* the job is released whatever the result */
 zk_status zk_verify_submit(zk_ctx *ctx, uint64_t B, const uint8_t *msg_hash, const uint8_t *proofs, const uint64_t *proof_off /*B+1*/,
                            const uint8_t *verifier_seeds /*Bx32 or NULL*/, uint8_t *ok /*B*/, int32_t *per_proof_status /*B*/, zk_job **job);

@@ -5,6 +5,7 @@ import ctypes as C
 import os
 
 import pytest
+import torch   # before the first engine of the process: the wheel bundles its own HIP runtime, which must be the one that initialises first
 
 pytestmark = pytest.mark.gpu
 
@@ -196,3 +197,37 @@ def test_streamed_pool_calls_equal_the_synchronous_pool_calls():
     for p_ in pins:
         p_.free()
     pool.close()
+
+
+def test_streamed_device_pointer_jobs_equal_the_synchronous_device_call():
+    """zk_prove_submit_device: three jobs of different sizes in flight on buffers that never leave HBM; bytes, offsets and statuses
+    are those of zk_prove_batch_device."""
+    sizes = (600, 1000, 200)
+    B = sum(sizes)
+    Z, eng, work = _setup(78, 4096, B, 256, 3)
+    dev = torch.device('cuda:0')
+    tb = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    cap1 = eng.proof_max_size()
+    jobs, a = [], 0
+    for n in sizes:
+        m, s, p, w, sd = _cut(work, a, a + n)
+        a += n
+        jobs.append({'n': n, 'in': (tb(m), tb(s), tb(p), torch.tensor(list(w), dtype=torch.int32, device=dev), tb(sd)),
+                     'out': [(torch.zeros(cap1 * n, dtype=torch.uint8, device=dev), torch.zeros(n + 1, dtype=torch.int64, device=dev),
+                              torch.ones(n, dtype=torch.int32, device=dev)) for _ in range(2)]})
+    torch.cuda.synchronize()
+    args = lambda j, o: (j['n'],) + tuple(t.data_ptr() for t in j['in']) + (o[0].data_ptr(), cap1 * j['n'], o[1].data_ptr(), o[2].data_ptr())
+    for j in jobs:
+        eng.prove_batch_device(*args(j, j['out'][0]))
+    tickets = [eng.prove_submit_device(*args(j, j['out'][1])) for j in jobs]
+    with pytest.raises(Z.ZkError):   # the synchronous calls are refused while jobs are queued
+        eng.prove_batch_device(*args(jobs[0], jobs[0]['out'][0]))
+    for t in tickets:
+        eng.prove_wait(t)
+    torch.cuda.synchronize()
+    for j in jobs:
+        (o0, f0, s0), (o1, f1, s1) = j['out']
+        end = int(f0[j['n']].item())
+        assert end > 0 and torch.equal(f0, f1) and torch.equal(s0, s1) and int(s0.abs().sum().item()) == 0
+        assert torch.equal(o0[:end], o1[:end])
+    eng.close()

@@ -18,7 +18,7 @@ SYMBOLS = [
     'zk_pool_create', 'zk_pool_destroy', 'zk_pool_size', 'zk_pool_ctx', 'zk_pool_last_error', 'zk_pool_ring_transport', 'zk_pool_shard',
     'zk_pool_set_params', 'zk_pool_set_ring', 'zk_pool_prove_batch', 'zk_pool_verify_batch',
     'zk_pool_host_alloc', 'zk_pool_host_free', 'zk_pool_numa_node', 'zk_pool_test_locality', 'zk_pool_shard_ms',
-    'zk_prove_submit', 'zk_prove_wait', 'zk_verify_submit', 'zk_verify_wait', 'zk_test_counter',
+    'zk_prove_submit', 'zk_prove_submit_device', 'zk_prove_wait', 'zk_verify_submit', 'zk_verify_wait', 'zk_test_counter',
     'zk_proofs_to_json_batch', 'zk_proofs_from_json_batch', 'zk_ctx_set_ring_fold',
     'zk_pool_prove_submit', 'zk_pool_prove_wait', 'zk_pool_verify_submit', 'zk_pool_verify_wait', 'zk_ctx_set_verify_groups',
     'zk_test_field_op', 'zk_test_tom_commit', 'zk_test_p256_fixed_mul', 'zk_test_sha256', 'zk_test_rng_draws',
@@ -108,6 +108,7 @@ def lib():
         L.zk_proofs_to_json_batch.argtypes = [u64, vp, vp, vp, u64, vp, vp, u32]
         L.zk_proofs_from_json_batch.argtypes = [u64, vp, vp, vp, u64, vp, vp, u32]
         L.zk_prove_submit.argtypes = [vp, u64, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(ZkRng), vp, u64, vp, vp, C.POINTER(vp)]
+        L.zk_prove_submit_device.argtypes = [vp, u64, vp, vp, vp, vp, C.POINTER(ZkRng), vp, u64, vp, vp, C.POINTER(vp)]
         L.zk_prove_wait.argtypes = [vp, vp]
         L.zk_verify_submit.argtypes = [vp, u64, C.c_char_p, vp, vp, C.c_char_p, vp, vp, C.POINTER(vp)]
         L.zk_verify_wait.argtypes = [vp, vp]
@@ -431,6 +432,12 @@ class Engine:
 
     def test_counter(self, which=0):
         return int(self.L.zk_test_counter(self.h, which))
+
+    def prove_submit_device(self, B, d_msg, d_sig, d_pk, d_which, d_seeds, d_out, out_cap, d_off, d_status, mode=0, stride_blocks=0):
+        """zk_prove_submit_device: every pointer a device address; returns the ticket for prove_wait."""
+        t = {'rng': ZkRng(mode, d_seeds, stride_blocks), 'job': C.c_void_p(), 'off': None, 'st': None}
+        self._chk(self.L.zk_prove_submit_device(self.h, B, d_msg, d_sig, d_pk, d_which, C.byref(t['rng']), d_out, out_cap, d_off, d_status, C.byref(t['job'])))
+        return t
 
     def prove_batch_device(self, B, d_msg, d_sig, d_pk, d_which, d_seeds, d_out, out_cap, d_off, d_status, mode=0, stride_blocks=0):
         rng = ZkRng(mode, d_seeds, stride_blocks)

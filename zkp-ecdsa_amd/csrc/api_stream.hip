@@ -370,6 +370,50 @@ extern "C" zk_status zk_prove_submit(zk_ctx* c, uint64_t B, const uint8_t* msg, 
     *job = j;
     return ZK_OK;
 }
+// The device-pointer form: inputs and outputs already in HBM (what bench.py's `value` times), same queue, same waits.  Nothing crosses
+// the link; the job only owns its events.  The caller's buffers must be complete when the call is made (the lanes' streams do not know
+// the caller's streams) and stay untouched until the wait returns.
+extern "C" zk_status zk_prove_submit_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const uint8_t* d_sig, const uint8_t* d_pk, const uint32_t* d_which,
+                                            const zk_rng* rng, uint8_t* d_out, uint64_t out_cap, uint64_t* d_out_off, int32_t* d_status, zk_job** job) {
+    if (!c || !job || !rng || !d_out_off || !d_status || !B || !d_msg || !d_sig || !d_pk || !d_which || !rng->data || !d_out) return ZK_E_ARG;
+    *job = nullptr;
+    if (rng->mode != ZK_RNG_SEED && rng->mode != ZK_RNG_STREAM) return ZK_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    zk_status zs = stream_common(c, 0);
+    if (zs) return zs;
+    dbg_start(c);
+    zk_job* j = new zk_job();
+    j->kind = 0, j->c = c;
+    if ((zs = job_events(j))) {
+        job_free(j);
+        return zs;
+    }
+    if (hipEventRecord(j->inputs_ready, c->fin_stream) != hipSuccess) {
+        c->err = "could not record the job's start";
+        job_free(j);
+        return ZK_E_DEVICE;
+    }
+    ProveJob& J = j->pj;
+    J.c = c, J.B = B, J.d_msg = d_msg, J.d_sig = d_sig, J.d_pk = d_pk, J.d_which = d_which, J.rng_mode = rng->mode, J.d_rng = rng->data;
+    J.stride = rng->stride_blocks, J.d_out = d_out, J.out_cap = out_cap, J.d_out_off = d_out_off, J.d_status = d_status;
+    J.host_sink = nullptr, J.timed = false, J.inputs_ready = j->inputs_ready;
+    J.C = (uint32_t)std::min<uint64_t>(c->chunk, B);
+    const bool idle = c->jobs.empty();
+    J.plan = make_chunk_plan(B, J.C, 1, false);
+    J.NL = c->lanes;
+    if (idle) c->next_lane_base = 0;
+    J.lane_base = c->next_lane_base;
+    c->next_lane_base += J.plan.size();
+    if (!idle) {
+        zk_job* prev = c->jobs.back();
+        if (prev->kind == 0) prev->pj.more_follows = true;
+    }
+    c->jobs.push_back(j);
+    c->stream_busy = true;
+    if (idle) lookahead(c, 0, J.lane_base + J.NL);
+    *job = j;
+    return ZK_OK;
+}
 extern "C" zk_status zk_prove_wait(zk_ctx* c, zk_job* job) { return wait_common(c, job); }
 
 extern "C" zk_status zk_verify_submit(zk_ctx* c, uint64_t B, const uint8_t* msg, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint8_t* ok,
