@@ -856,9 +856,11 @@ def main():
                                   'page-locked host buffers incl. H2D of the inputs and D2H of %.2f GB of proofs; value_pcie_inclusive_steady: %d such '
                                   'batches back to back through zk_prove_submit / zk_prove_wait, two in flight (first submit to last wait)'
                                   % (host_io['pinned']['out_bytes'] / 1e9, args.host_io_stream))
-            if 'prove' in host_io.get('stream', {}):
-                line['value_pcie_inclusive_steady'] = host_io['stream']['prove']['proofs_per_s']
-                line['verify_pcie_inclusive_steady'] = host_io['stream']['verify']['verifies_per_s']
+            st = host_io.get('stream') or {}
+            if 'proofs_per_s' in (st.get('prove') or {}):
+                line['value_pcie_inclusive_steady'] = st['prove']['proofs_per_s']
+            if 'verifies_per_s' in (st.get('verify') or {}):
+                line['verify_pcie_inclusive_steady'] = st['verify']['verifies_per_s']
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

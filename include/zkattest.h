@@ -131,6 +131,14 @@ zk_status zk_ctx_set_batch_verify(zk_ctx *ctx, uint32_t min_chunk);
  * (ZKATTEST_VERIFY_GROUPS) */
 zk_status zk_ctx_set_verify_groups(zk_ctx *ctx, uint32_t groups);
 
+/* Per-key tables (default on; rings of up to 65 536 keys): zk_ctx_set_ring stores 128 multiples x 33 byte positions of EVERY ring key
+ * (264 KB per key, 17.7 GB at 2^16 keys, built in ~0.1 s), so that the prover's u2 * publicKey (src/zkpAttestList.ts:129-131) and the
+ * alpha_i * R of proveExp (src/exp/exp.ts:144-149, as (alpha_i u1) * G + (alpha_i u2) * publicKey) are sums of 33 gathered entries instead of
+ * a doubling chain and a per-proof table of R.  A proof whose `which` names a ring value that is not its own key's x-coordinate takes
+ * the per-proof path; the bytes are the same either way.  0 = per-proof tables for every proof.  Call before zk_ctx_set_ring.
+ * (ZKATTEST_KEYTAB) */
+zk_status zk_ctx_set_key_tables(zk_ctx *ctx, uint32_t on);
+
 /* The ring fold's 8 low index bits on the matrix cores (v_mfma_i32_16x16x64_i8; rings of at least 4096 keys), 1 (default), or as
  * 64-bit multiply-adds on the vector ALU, 0.  Verifier: verifyMembership's total (src/proofGK/gk.ts:239-250), every block of 256 keys
  * as int8 matrix products (ZKATTEST_GK_MFMA).  Prover: the table path's coefficient classes 2..6 of proveMembership's polynomial
@@ -313,7 +321,8 @@ uint32_t zk_last_timing(const zk_ctx *ctx, float *total_ms, const char **names, 
 /* Unit-test hooks (tests/ call these through the C ABI to compare single primitives with the oracle).
  * zk_pool_test_locality: NUMA node and local CPUs of a PCI address as the pool reads them from sysfs (ZKATTEST_SYSFS_ROOT). */
 int zk_pool_test_locality(const char *pci_bus_id, int *numa_node, int *cpus, int cap);
-/* work counters since the context was created: 0 = proofs that went through the verifier's per-proof sums (fallback of the batched check) */
+/* work counters: 0 = proofs that went through the verifier's per-proof sums since the context was created (fallback of the batched check);
+ * 1 = proofs of the last chunk on lane 0 whose scalar multiplications by the signer's key went through the per-key tables */
 uint64_t zk_test_counter(const zk_ctx *ctx, int which);
 /*
  * which_field: 0 = F_q (p256.p), 1 = Z_n, 2 = F_t;  op: 0 mul, 1 add, 2 sub, 3 inverse, 4 a*b - a - b (fused double subtraction), 5 (a + b)^2 (dedicated squaring).  count x 40-byte BE operands. */

@@ -288,3 +288,48 @@ def test_page_locked_host_buffers_give_the_same_bytes_and_verdicts():
     small.free()
     pin.free()
     eng.close()
+
+
+def test_key_tables_equal_the_per_proof_tables_and_fall_back_where_they_must(monkeypatch):
+    """Per-key tables (k_ktab.hip; zk_ctx_set_key_tables): u2 * pk and alpha_i * R as sums of gathered multiples of the signer's ring key
+    against the per-proof tables of R (ZKATTEST_KEYTAB=0) and the oracle, byte for byte.  The batch holds honest proofs (both square roots
+    of a ring value occur among the keys), proofs whose `which` names ANOTHER key, and proofs that name ring values which are no
+    x-coordinate at all: the latter two must take the per-proof path and still produce the bytes the reference would."""
+    import coracle as CO
+    import zkp_ecdsa_amd as Z
+    S, nkeys, B = 5150, 300, 96
+    eng = Z.Engine(0)
+    nh, tg, th = eng.synth_params(S)
+    eng.set_params(nh, tg, th, 80)
+    ring, msg, sig, pk, which, seeds = eng.synth_workload(S, nkeys, B)
+    ring = bytearray(ring)
+    for i in range(200, 232):   # 32 ring values that are (mostly) no key: half of all residues have no square root
+        ring[32 * i:32 * i + 32] = hashlib.sha256(b'not a key %d' % i).digest()
+    ring = bytes(ring)
+    which = list(which)
+    for b in range(60, 72):
+        which[b] = (which[b] + 7) % 200        # another signer's slot
+    for b in range(72, 96):
+        which[b] = 200 + (b - 72)              # a slot that holds no x-coordinate of theirs
+    eng.set_ring(ring, nkeys)
+    eng.set_chunk(128)
+    got, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert st == [0] * B
+    assert eng.test_counter(1) == 60           # exactly the honest proofs went through the key tables
+    monkeypatch.setenv('ZKATTEST_KEYTAB', '0')
+    ref = Z.Engine(0)
+    ref.set_params(nh, tg, th, 80)
+    ref.set_ring(ring, nkeys)
+    ref.set_chunk(128)
+    exp, st2 = ref.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert st2 == [0] * B and ref.test_counter(1) == 0
+    assert [hashlib.sha256(g).hexdigest() for g in got] == [hashlib.sha256(e).hexdigest() for e in exp]
+    octx = CO.OracleCtx(nh, tg, th, 80)
+    octx.set_ring(ring, nkeys)
+    pick = [0, 1, 2, 59, 60, 71, 72, 95]
+    cut = lambda buf, n: b''.join(buf[n * b:n * (b + 1)] for b in pick)
+    oexp, est = octx.prove_batch(cut(msg, 32), cut(sig, 64), cut(pk, 64), [which[b] for b in pick], seeds=cut(seeds, 32), nthreads=8)
+    assert est == [0] * len(pick) and [got[b] for b in pick] == oexp
+    ok, vst = eng.verify_batch(msg, got)
+    assert ok[:60] == [1] * 60 and not any(ok[60:]) and vst == [0] * B   # a proof for a slot that is not the signer's does not verify
+    eng.close(), ref.close()

@@ -18,7 +18,7 @@ SYMBOLS = [
     'zk_pool_create', 'zk_pool_destroy', 'zk_pool_size', 'zk_pool_ctx', 'zk_pool_last_error', 'zk_pool_ring_transport', 'zk_pool_shard',
     'zk_pool_set_params', 'zk_pool_set_ring', 'zk_pool_prove_batch', 'zk_pool_verify_batch',
     'zk_pool_host_alloc', 'zk_pool_host_free', 'zk_pool_numa_node', 'zk_pool_test_locality', 'zk_pool_shard_ms',
-    'zk_prove_submit', 'zk_prove_submit_device', 'zk_prove_wait', 'zk_verify_submit', 'zk_verify_wait', 'zk_test_counter',
+    'zk_prove_submit', 'zk_prove_submit_device', 'zk_prove_wait', 'zk_verify_submit', 'zk_verify_wait', 'zk_test_counter', 'zk_ctx_set_key_tables',
     'zk_proofs_to_json_batch', 'zk_proofs_from_json_batch', 'zk_ctx_set_ring_fold',
     'zk_pool_prove_submit', 'zk_pool_prove_wait', 'zk_pool_verify_submit', 'zk_pool_verify_wait', 'zk_ctx_set_verify_groups',
     'zk_test_field_op', 'zk_test_tom_commit', 'zk_test_p256_fixed_mul', 'zk_test_sha256', 'zk_test_rng_draws',
@@ -113,6 +113,7 @@ def lib():
         L.zk_verify_submit.argtypes = [vp, u64, C.c_char_p, vp, vp, C.c_char_p, vp, vp, C.POINTER(vp)]
         L.zk_verify_wait.argtypes = [vp, vp]
         L.zk_ctx_set_ring_fold.argtypes = [vp, u32]
+        L.zk_ctx_set_key_tables.argtypes = [vp, u32]
         L.zk_ctx_set_verify_groups.argtypes = [vp, u32]
         L.zk_test_counter.argtypes = [vp, i32]
         L.zk_test_counter.restype = u64
@@ -432,6 +433,9 @@ class Engine:
 
     def test_counter(self, which=0):
         return int(self.L.zk_test_counter(self.h, which))
+
+    def set_key_tables(self, on):
+        self._chk(self.L.zk_ctx_set_key_tables(self.h, 1 if on else 0))
 
     def prove_submit_device(self, B, d_msg, d_sig, d_pk, d_which, d_seeds, d_out, out_cap, d_off, d_status, mode=0, stride_blocks=0):
         """zk_prove_submit_device: every pointer a device address; returns the ticket for prove_wait."""

@@ -81,6 +81,7 @@ static zk_status ctx_init(zk_ctx* c, int device_id) {
         if (b >= 8 && b <= TOM_MAX_BITS) c->tom_bits = (uint32_t)b;
     }
     if (const char* e = getenv("ZKATTEST_GK_TABLE")) c->gk_table = atoi(e) != 0;
+    if (const char* e = getenv("ZKATTEST_KEYTAB")) c->key_tables = atoi(e) != 0;
     if (const char* e = getenv("ZKATTEST_GK_MFMA")) c->gk_mfma = atoi(e) != 0;
     if (const char* e = getenv("ZKATTEST_GK_MFMA_PROVE")) c->gk_mfma_prove = atoi(e) != 0;
     if (const char* e = getenv("ZKATTEST_VERIFY_GROUPS")) c->verify_groups = atoi(e) == 64 ? 64 : 8;
@@ -125,7 +126,7 @@ extern "C" void zk_ctx_destroy(zk_ctx* c) {
     stream_release_spares(c);
     for (auto e : c->epool) hipEventDestroy(e);
     hipFree(c->P.tom_tab_g), hipFree(c->P.tom_tab_h), hipFree(c->tom_tab_gen), hipFree(c->P.pfix_G), hipFree(c->P.pfix_H);
-    hipFree(c->gk_kdig), hipFree(c->gk_edig);
+    hipFree(c->gk_kdig), hipFree(c->gk_edig), hipFree(c->ktab), hipFree(c->ktab_ok);
     hipFree(c->tab_scratch), hipFree(c->gk_etab), hipFree(c->d_flag), hipFree(c->ring_mem), hipFree(c->ring_digest);
     hipFree(c->io_buf), hipFree(c->in_buf);
     for (int l = 0; l < ZK_MAX_LANES; l++) {
@@ -225,6 +226,19 @@ static zk_status set_ring_common(zk_ctx* c, const uint8_t* d_keys, uint64_t nkey
         HIPCHK(c, hipMalloc(&c->gk_edig, gkm_etab_frag_bytes(N)));
         launch_gkm_etab_digits(c->stream, c->gk_etab, (uint32_t)(N >> 8), c->gk_edig);
     }
+    if (c->ktab) HIPCHK(c, hipFree(c->ktab));
+    if (c->ktab_ok) HIPCHK(c, hipFree(c->ktab_ok));
+    c->ktab = nullptr, c->ktab_ok = nullptr;
+    if (c->key_tables && n <= KTAB_MAXN) {   // multiples of every ring key (k_ktab.hip): the prover's k * pk and alpha * R become table sums
+        const uint32_t slab = (uint32_t)std::min<uint64_t>(N, 4096);
+        void* tmp = nullptr;
+        HIPCHK(c, hipMalloc(&c->ktab, sizeof(uint32_t) * KTAB_KEY_WORDS * N));
+        HIPCHK(c, hipMalloc(&c->ktab_ok, N));
+        HIPCHK(c, hipMalloc(&tmp, ktab_temp_bytes(N, slab)));
+        launch_ktab_build(c->stream, ring, N, c->ktab, c->ktab_ok, tmp, slab);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(tmp));
+    }
     {   // digest of the padded ring: what the hardened mode hashes into the membership challenge
         if (!c->ring_digest) HIPCHK(c, hipMalloc(&c->ring_digest, 32));
         uint32_t* leaves = nullptr;
@@ -284,6 +298,11 @@ extern "C" zk_status zk_ctx_set_verify_groups(zk_ctx* c, uint32_t groups) {
     c->verify_groups = groups;
     return ZK_OK;
 }
+extern "C" zk_status zk_ctx_set_key_tables(zk_ctx* c, uint32_t on) {
+    if (!c) return ZK_E_ARG;
+    c->key_tables = on != 0;
+    return ZK_OK;
+}
 extern "C" zk_status zk_ctx_set_ring_fold(zk_ctx* c, uint32_t matrix_pipe) {
     if (!c) return ZK_E_ARG;
     c->gk_mfma = matrix_pipe != 0;
@@ -337,6 +356,9 @@ static size_t carve(zk_ctx* c, Workspace& W, Soa& gk_am, uint8_t* base, uint32_t
     W.pkx = k.soa(C), W.pky = k.soa(C), W.pkxm = k.soa(C), W.pkym = k.soa(C);
     W.Rxm = k.soa(C), W.Rym = k.soa(C), W.Rx = k.soa(C), W.Ry = k.soa(C);
     W.Q = k.soa3(C), W.s1 = k.soa(C);
+    W.ktab = c->ktab, W.ktab_ok = c->ktab_ok;
+    W.kt_use = (uint8_t*)k.take((size_t)C), W.kt_key = (uint32_t*)k.take(4 * (size_t)C);
+    W.u1m = k.soa(C), W.u2m = k.soa(C);
     W.rtab = (uint32_t*)k.take(sizeof(uint32_t) * (size_t)std::max(rtab_words(RTAB_PROVE_BITS), rtab_words(RTAB_VERIFY_BITS)) * C);
     W.rbase = k.soa3((size_t)C * RTAB_MAX_NWIN);
     W.chal = (uint32_t*)k.take(16 * (size_t)C);
@@ -407,6 +429,7 @@ zk_status ensure_workspace(zk_ctx* c, uint32_t C, uint32_t nlanes) {
         }
         L.W.ring = Soa{c->ring_mem, (uint32_t)c->N};
         L.W.hardened = c->mode == ZK_MODE_HARDENED, L.W.ring_digest = c->ring_digest;
+        L.W.ktab = c->ktab, L.W.ktab_ok = c->ktab_ok;
         L.W.gk_kdig = c->gk_mfma ? c->gk_kdig : nullptr;
         L.W.gk_edig = c->gk_mfma && L.W.gk_adig ? c->gk_edig : nullptr;
     }
@@ -484,6 +507,7 @@ zk_status ProveJob::stage1(uint64_t chunk_no) {
     hipStream_t s = c->pl[lane].stream;
     const uint64_t first = cp.first;
     const uint32_t cnt = cp.cnt;
+    c->pl[lane].last_cnt = cnt;
     if (io_dbg) fprintf(stderr, "host %7.1f ms: stage1 of chunk %u (%u proofs) -> lane %u\n", host_ms() - host_t0, (uint32_t)chunk_no, cnt, lane);
     if (inputs_ready) HIPCHK(c, hipStreamWaitEvent(s, inputs_ready, 0));
     ChunkIn in{d_msg + 32 * first, d_sig + 64 * first, d_pk + 64 * first, d_which + first, cnt};
@@ -503,7 +527,7 @@ zk_status ProveJob::stage1(uint64_t chunk_no) {
     }
     {
         MaybeScope t(timed, c, "p256_rtab", s);
-        launch_rtab(s, W, cnt, RTAB_PROVE_BITS);
+        launch_rtab(s, W, cnt, RTAB_PROVE_BITS, W.ktab ? W.kt_use : nullptr);   // proofs on the key-table path need no table of R
     }
     {
         MaybeScope t(timed, c, "p256_exp_commit", s);

@@ -12,6 +12,7 @@
 // are those of the synchronous calls (tests/test_gpu_stream.py).
 #include <chrono>
 #include <cstdio>
+#include <vector>
 #include <cstdlib>
 #include "jobs.h"
 
@@ -493,5 +494,16 @@ extern "C" zk_status zk_verify_wait(zk_ctx* c, zk_job* job) { return wait_common
 
 extern "C" uint64_t zk_test_counter(const zk_ctx* c, int which) {
     if (!c) return 0;
+    if (which == 1) {   // proofs of lane 0's last chunk that took the key-table path (k_ktab.hip)
+        const auto& L = c->pl[0];
+        if (!L.ready || !L.last_cnt || !L.W.kt_use) return 0;
+        std::vector<uint8_t> u(L.last_cnt);
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(L.stream) != hipSuccess ||
+            hipMemcpy(u.data(), L.W.kt_use, L.last_cnt, hipMemcpyDeviceToHost) != hipSuccess)
+            return ~0ull;
+        uint64_t n = 0;
+        for (uint8_t v : u) n += v != 0;
+        return n;
+    }
     return which == 0 ? c->dbg_recheck_proofs : 0;
 }

@@ -30,6 +30,9 @@ struct zk_ctx {
     uint32_t* ring_mem = nullptr;
     uint32_t* gk_etab = nullptr;   // per-ring table of the GK block transform (k_gk.hip); nullptr for small / huge rings
     bool gk_table = true;          // ZKATTEST_GK_TABLE=0 disables it (plain fold for every ring)
+    uint32_t* ktab = nullptr;      // per-key tables of the ring (k_ktab.hip): 512 KB per key, rings of up to 2^KTAB_MAXN keys
+    uint8_t* ktab_ok = nullptr;    // [N] which ring values are x-coordinates and own a table
+    bool key_tables = true;        // ZKATTEST_KEYTAB=0 / zk_ctx_set_key_tables(ctx, 0): per-proof tables of R for every proof (read at zk_ctx_set_ring)
     int8_t* gk_kdig = nullptr;     // the ring as int8 digit fragments (k_gk_mfma.hip), built with table E for rings of >= 2^12 keys
     int8_t* gk_edig = nullptr;     // table E's coefficient classes 2..6 as digit fragments: the prover's matrix-pipe table path (k_gk_mfma.hip)
     bool gk_mfma_prove = true;     // build gk_edig with the ring (ZKATTEST_GK_MFMA_PROVE; read at zk_ctx_set_ring)
@@ -51,6 +54,7 @@ struct zk_ctx {
         void* arena = nullptr;
         size_t arena_bytes = 0;
         bool ready = false;
+        uint32_t last_cnt = 0;          // proofs of the last chunk this lane started (zk_test_counter)
         void* h_scan = nullptr;         // page-locked: the chunk's totals (4 x u32), item prefix sums (u32[C+1]) and byte prefix sums
         size_t h_scan_bytes = 0;        // (u64[C+1]) read back after the scan.  Pageable destinations made the runtime wait for
                                         // EVERY stream of the device (measured: the host sat 50 ms behind the other lane's kernels)

@@ -61,6 +61,18 @@ static inline size_t tom_tab_words(uint32_t bits) { return (size_t)tom_nwin(bits
 #define PFIX_WIN_SIZE (1u << PFIX_WIN_BITS)
 #define PFIX_ENTRY_WORDS 20
 #define PFIX_TAB_WORDS ((size_t)PFIX_NWIN * PFIX_WIN_SIZE * PFIX_ENTRY_WORDS)
+// per-KEY tables (k_ktab.hip): every ring key P gets d * 2^(8 w) * P, d = 1..128, w = 0..32, affine, 64 bytes per entry (slot d - 1 of
+// window w): 264 KB per key, 17.7 GB for a ring of 2^16 keys.  A scalar is recoded into signed 8-bit digits in [-127, 128] (a negative
+// digit negates the entry on load), so a prover's k * pk is 33 mixed additions of gathered entries, and alpha_i * R of proveExp
+// (exp.ts:144-149) becomes (alpha_i u1) * G + (alpha_i u2) * pk -- no per-proof table of R, no doubling chain in the front end.
+#define KTAB_BITS 8
+#define KTAB_NWIN 33
+#define KTAB_ENT 128
+#define KTAB_ENTRY_WORDS 16
+#define KTAB_MAXN 16
+#define KTAB_KEY_WORDS ((size_t)KTAB_NWIN * KTAB_ENT * KTAB_ENTRY_WORDS)
+size_t ktab_temp_bytes(uint64_t N, uint32_t slab_keys);
+void launch_ktab_build(hipStream_t s, const Soa& ring, uint64_t N, uint32_t* ktab, uint8_t* ok, void* temp, uint32_t slab_keys);
 // per-proof table of R (rtab.h): signed `bits`-bit comb, ceil(257/bits) windows x (2^(bits-1) + 1) entries of 28 words
 #define RTAB_ENTRY_WORDS 28
 #define RTAB_PROVE_BITS 6
@@ -116,6 +128,12 @@ struct Workspace {
     Soa Rx, Ry;                  // R affine plain
     Soa3 Q;                      // projective Montgomery
     Soa s1;                      // plain mod n
+    // per-key tables (k_ktab.hip): multiples of every ring key, owned by the context; nullptr for rings above 2^KTAB_MAXN keys
+    const uint32_t* ktab;        // [N][KTAB_NWIN][KTAB_ENT][16] affine Montgomery (x, y) as 2 x 8 words; slot d - 1 holds d * 2^(8 w) * key
+    const uint8_t* ktab_ok;      // [N] 1: the ring value is the x-coordinate of a curve point and has a table
+    uint32_t* kt_key;            // [C] ring index of the proof's key (in.which)
+    uint8_t* kt_use;             // [C] 0: per-proof table of R (rtab.h); 1 / 2: pk = + / - the key table's base point
+    Soa u1m, u2m;                // u1, u2 mod n in Montgomery form (proofs on the key-table path multiply their nonces into them)
     uint32_t* rtab;              // [C][rtab_words(bits)], sized for RTAB_PROVE_BITS
     Soa3 rbase;                  // [C*RTAB_MAX_NWIN] window bases 2^(bits w) R, projective
     uint32_t* chal;              // [C][4] challenge words (80 bits in words 0..2)
@@ -300,7 +318,7 @@ void launch_tom_normalize(hipStream_t s, const TomList& L, uint32_t count, uint3
 void launch_padd_derived(hipStream_t s, const Workspace& W, uint32_t items);
 // k_p256.hip
 void launch_front(hipStream_t s, const DevParams& P, const Workspace& W, const ChunkIn& in);
-void launch_rtab(hipStream_t s, const Workspace& W, uint32_t count, uint32_t bits);
+void launch_rtab(hipStream_t s, const Workspace& W, uint32_t count, uint32_t bits, const uint8_t* skip = nullptr /*[count] != 0: no table for that proof*/);
 void launch_exp_commit(hipStream_t s, const DevParams& P, const Workspace& W, uint32_t count);
 void launch_p256_normalize(hipStream_t s, const Soa3& proj, uint32_t count, const Soa& ox, const Soa& oy, int32_t* st, uint32_t per_proof, int32_t err_code, const uint32_t* owner /*nullable: item->proof*/);
 void launch_t1(hipStream_t s, const Workspace& W, uint32_t items);

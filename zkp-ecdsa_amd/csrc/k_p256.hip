@@ -5,7 +5,7 @@
 // observable, so the engine uses: 16-bit fixed-base combs for G and h_NIST (16 mixed complete additions), and a
 // per-proof signed-digit comb table of R = paramsSigExp.g (rtab.h), shared by the sec+1 multiplications by R of one
 // proof (43 complete additions each).  All additions are the complete RCB formulas the reference uses.
-#include "rtab.h"
+#include "ktab.h"
 
 ZK_DEV P256Aff ld_pfix(const uint32_t* e) {
     const uint4* q = (const uint4*)e;
@@ -29,6 +29,18 @@ ZK_DEV P256Pt p256_fixed_mul(const uint32_t* __restrict__ tab, uint32_t kw[8]) {
         shr256<PFIX_WIN_BITS>(kw);
         P256Aff e = ld_pfix(tab + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + d));
         P256Pt s = w == 0 ? p256_from_affine(e) : p256_add_mixed(acc, e);   // first window: identity + entry
+        acc = p256_select(d != 0, s, acc);
+    }
+    return acc;
+}
+// acc + k * B: the comb's additions go straight onto a running point (one complete addition less than summing two results)
+ZK_DEV P256Pt p256_fixed_mul_acc(P256Pt acc, const uint32_t* __restrict__ tab, uint32_t kw[8]) {
+#pragma unroll 1
+    for (int w = 0; w < PFIX_NWIN; w++) {
+        uint32_t d = kw[0] & (PFIX_WIN_SIZE - 1);
+        shr256<PFIX_WIN_BITS>(kw);
+        P256Aff e = ld_pfix(tab + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + d));
+        P256Pt s = p256_add_mixed(acc, e);
         acc = p256_select(d != 0, s, acc);
     }
     return acc;
@@ -79,6 +91,20 @@ __global__ void __launch_bounds__(64, 2) k_front(DevParams P, Workspace W, Chunk
     Fe<ModN, 1> u1 = fe_from_mont(sinv * z), u2 = fe_from_mont(sinv * r);
     Fe<ModN, 1> s1 = fe_from_mont(rinv * s), z1 = fe_from_mont(rinv * z);
     soa_st(W.s1, p, s1);
+    // key-table path (k_ktab.hip): the ring value this proof names is its own key's x and that key has a table; + / - by the root
+    uint32_t use = 0;
+    if (W.ktab && status == ZK_OK && W.ktab_ok[in.which[p]]) {
+        Fe<ModQ, 1> rv = soa_ld<ModQ, 1>(W.ring, in.which[p]);
+        bool same = true;
+#pragma unroll
+        for (int l = 0; l < NLIMB; l++) same = same && rv.l[l] == pkx.l[l];
+        if (same) {
+            P256Aff b0 = ld_ktab(W.ktab + (size_t)in.which[p] * KTAB_KEY_WORDS);   // window 0, slot 0: the base point
+            use = fe_eq(pk.y, b0.y) ? 1 : 2;
+        }
+    }
+    W.kt_use[p] = (uint8_t)use, W.kt_key[p] = in.which[p];
+    soa_st(W.u1m, p, fe_canon(sinv * z)), soa_st(W.u2m, p, fe_canon(sinv * r));
     uint32_t* area = front_area(W, p);
     {
         uint8_t* dig = (uint8_t*)(area + 9 * RTAB_ENTRY_WORDS);
@@ -103,7 +129,7 @@ __global__ void __launch_bounds__(64, 2) k_front_table(DevParams P, Workspace W,
     uint32_t p = gtid();
     if (p >= count) return;
     uint32_t* area = front_area(W, p);
-    {
+    if (!W.kt_use[p]) {
         P256Aff pk;
         pk.x = soa_ld<ModQ, 2>(W.pkxm, p), pk.y = soa_ld<ModQ, 2>(W.pkym, p);
         P256Pt base = p256_from_affine(pk), m = base;
@@ -131,18 +157,26 @@ __global__ void __launch_bounds__(64, 2) k_front_walk(Workspace W, uint32_t coun
     if (p >= count) return;
     const uint32_t* area = front_area(W, p);
     const uint8_t* dig = (const uint8_t*)(area + 9 * RTAB_ENTRY_WORDS);
-    P256Pt acc = p256_identity();
+    P256Pt R;
+    const uint32_t use = W.kt_use[p];
+    if (use) {   // u1 * G + u2 * pk with u2 * pk through the key's table: 33 gathered entries instead of the doubling chain
+        uint32_t kw[8];
+        words_from_limbs<8>(kw, fe_from_mont(soa_ld<ModN, 1>(W.u2m, p).as<2>()).l);
+        R = p256_ktab_mul_acc(ld_rtab(area + 8 * RTAB_ENTRY_WORDS), W.ktab + (size_t)W.kt_key[p] * KTAB_KEY_WORDS, kw, use == 2);
+    } else {
+        P256Pt acc = p256_identity();
 #pragma unroll 1
-    for (int w = FRONT_NW - 1; w >= 0; w--) {
+        for (int w = FRONT_NW - 1; w >= 0; w--) {
 #pragma unroll 1
-        for (int i = 0; i < 4; i++) acc = p256_dbl(acc);
-        uint32_t db = dig[w], d = db & 15;
-        P256Pt e = ld_rtab(area + (d ? d - 1 : 0) * RTAB_ENTRY_WORDS);
-        e.y = fe_select((db & 0x80u) != 0, fq8_neg(e.y), e.y);
-        P256Pt s = p256_add(acc, e);
-        acc = p256_select(d != 0, s, acc);
+            for (int i = 0; i < 4; i++) acc = p256_dbl(acc);
+            uint32_t db = dig[w], d = db & 15;
+            P256Pt e = ld_rtab(area + (d ? d - 1 : 0) * RTAB_ENTRY_WORDS);
+            e.y = fe_select((db & 0x80u) != 0, fq8_neg(e.y), e.y);
+            P256Pt s = p256_add(acc, e);
+            acc = p256_select(d != 0, s, acc);
+        }
+        R = p256_add(ld_rtab(area + 8 * RTAB_ENTRY_WORDS), acc);
     }
-    P256Pt R = p256_add(ld_rtab(area + 8 * RTAB_ENTRY_WORDS), acc);
     // R affine (output + base of the per-proof table).  R = identity makes every T_i the identity: exp.ts:151.
     Fq2 rz = fe_reduce(R.z);
     if (fe_is_zero(rz) && W.st[p] == ZK_OK) W.st[p] = ZK_E_T_INF;
@@ -158,9 +192,9 @@ void launch_front(hipStream_t s, const DevParams& P, const Workspace& W, const C
 }
 
 // ---------------------------------------------------------------- per-proof table of R (layout and use: rtab.h)
-__global__ void __launch_bounds__(64) k_rtab_base(Workspace W, uint32_t count, uint32_t bits) {
+__global__ void __launch_bounds__(64) k_rtab_base(Workspace W, uint32_t count, uint32_t bits, const uint8_t* __restrict__ skip) {
     uint32_t p = gtid();
-    if (p >= count) return;
+    if (p >= count || (skip && skip[p])) return;
     P256Aff r;
     r.x = soa_ld<ModQ, 2>(W.Rxm, p), r.y = soa_ld<ModQ, 2>(W.Rym, p);
     P256Pt b = p256_from_affine(r);
@@ -173,10 +207,10 @@ __global__ void __launch_bounds__(64) k_rtab_base(Workspace W, uint32_t count, u
         for (uint32_t i = 0; i < bits; i++) b = p256_dbl(b);
     }
 }
-__global__ void __launch_bounds__(256) k_rtab_fill(Workspace W, uint32_t count, uint32_t bits) {
+__global__ void __launch_bounds__(256) k_rtab_fill(Workspace W, uint32_t count, uint32_t bits, const uint8_t* __restrict__ skip) {
     uint32_t t = gtid();
     const uint32_t nwin = rtab_nwin(bits), ent = rtab_entries(bits);
-    if (t >= count * nwin) return;
+    if (t >= count * nwin || (skip && skip[t / nwin])) return;
     P256Pt b = ld_proj(W.rbase, t);
     uint32_t* e = W.rtab + (size_t)(t / nwin) * rtab_words(bits) + (size_t)(t % nwin) * ent * RTAB_ENTRY_WORDS;
     st_rtab(e, p256_identity());
@@ -188,37 +222,72 @@ __global__ void __launch_bounds__(256) k_rtab_fill(Workspace W, uint32_t count, 
         st_rtab(e + d * RTAB_ENTRY_WORDS, acc);
     }
 }
-void launch_rtab(hipStream_t s, const Workspace& W, uint32_t count, uint32_t bits) {
-    hipLaunchKernelGGL(k_rtab_base, dim3((count + 63) / 64), dim3(64), 0, s, W, count, bits);
-    hipLaunchKernelGGL(k_rtab_fill, dim3((count * rtab_nwin(bits) + 255) / 256), dim3(256), 0, s, W, count, bits);
+void launch_rtab(hipStream_t s, const Workspace& W, uint32_t count, uint32_t bits, const uint8_t* skip) {
+    hipLaunchKernelGGL(k_rtab_base, dim3((count + 63) / 64), dim3(64), 0, s, W, count, bits, skip);
+    hipLaunchKernelGGL(k_rtab_fill, dim3((count * rtab_nwin(bits) + 255) / 256), dim3(256), 0, s, W, count, bits, skip);
 }
 
 // ---------------------------------------------------------------- Exp commit phase (exp.ts:144-149) and comS1
 // item j < sec of proof p:  T = alpha_j * R,  A = T + r_j * h_NIST     (draws 3+4j, 3+4j+1, both mod n)
 // item j = sec          :  comS1 = s1 * R + r0 * h_NIST                 (zkpAttestList.ts:138, draw 0)
+// Proofs with a per-proof table of R: one kernel.  Proofs on the key-table path (W.kt_use != 0): alpha * R = (alpha u1) * G + (alpha u2) * pk
+// with R = u1 G + u2 pk (zkpAttestList.ts:119-131), both through tables, in two kernels (T, then A = T + r * h) so that each stays within
+// the registers of three waves per SIMD.
+ZK_DEV void exp_scalars(const Workspace& W, uint32_t p, uint32_t j, uint32_t aw[8], uint32_t bw[8], bool want_a, bool want_b) {
+    if (want_a) {
+        Fe<ModN, 1> a = j < W.sec ? rng_draw<ModN>(W.rng, p, 3 + 4 * j) : soa_ld<ModN, 1>(W.s1, p);
+        words_from_limbs<8>(aw, a.l);
+    }
+    if (want_b) {
+        Fe<ModN, 1> b = rng_draw<ModN>(W.rng, p, j < W.sec ? 3 + 4 * j + 1 : 0);
+        words_from_limbs<8>(bw, b.l);
+    }
+}
 __global__ void __launch_bounds__(256) k_exp_commit(DevParams P, Workspace W, uint32_t count) {
     uint32_t t = gtid();
     uint32_t per = W.sec + 1;
     if (t >= count * per) return;
     uint32_t p = t / per, j = t % per;
+    if (W.kt_use[p]) return;
     uint32_t aw[8], bw[8];
-    if (j < W.sec) {
-        Fe<ModN, 1> a = rng_draw<ModN>(W.rng, p, 3 + 4 * j), b = rng_draw<ModN>(W.rng, p, 3 + 4 * j + 1);
-        words_from_limbs<8>(aw, a.l);
-        words_from_limbs<8>(bw, b.l);
-    } else {
-        Fe<ModN, 1> a = soa_ld<ModN, 1>(W.s1, p), b = rng_draw<ModN>(W.rng, p, 0);
-        words_from_limbs<8>(aw, a.l);
-        words_from_limbs<8>(bw, b.l);
-    }
+    exp_scalars(W, p, j, aw, bw, true, true);
     P256Pt T = p256_rtab_mul(W.rtab + (size_t)p * rtab_words(RTAB_PROVE_BITS), aw, RTAB_PROVE_BITS);
     P256Pt U = p256_fixed_mul(P.pfix_H, bw);
     P256Pt A = p256_add(T, U);
     st_proj(W.Tproj, t, T);
     st_proj(W.Aproj, t, A);
 }
+__global__ void __launch_bounds__(256) k_exp_commit_kt_T(DevParams P, Workspace W, uint32_t count) {
+    uint32_t t = gtid();
+    uint32_t per = W.sec + 1;
+    if (t >= count * per) return;
+    uint32_t p = t / per, j = t % per;
+    const uint32_t use = W.kt_use[p];
+    if (!use) return;
+    uint32_t aw[8], gw[8], kw[8];
+    exp_scalars(W, p, j, aw, nullptr, true, false);
+    Fe<ModN, 1> al;
+    limbs_from_words<8>(al.l, aw);
+    words_from_limbs<8>(gw, fe_canon(al.as<2>() * soa_ld<ModN, 1>(W.u1m, p).as<2>()).l);   // plain x Montgomery = plain
+    words_from_limbs<8>(kw, fe_canon(al.as<2>() * soa_ld<ModN, 1>(W.u2m, p).as<2>()).l);
+    st_proj(W.Tproj, t, p256_ktab_mul_acc(p256_fixed_mul(P.pfix_G, gw), W.ktab + (size_t)W.kt_key[p] * KTAB_KEY_WORDS, kw, use == 2));
+}
+__global__ void __launch_bounds__(256) k_exp_commit_kt_A(DevParams P, Workspace W, uint32_t count) {
+    uint32_t t = gtid();
+    uint32_t per = W.sec + 1;
+    if (t >= count * per) return;
+    uint32_t p = t / per, j = t % per;
+    if (!W.kt_use[p]) return;
+    uint32_t bw[8];
+    exp_scalars(W, p, j, nullptr, bw, false, true);
+    st_proj(W.Aproj, t, p256_fixed_mul_acc(ld_proj(W.Tproj, t), P.pfix_H, bw));
+}
 void launch_exp_commit(hipStream_t s, const DevParams& P, const Workspace& W, uint32_t count) {
     uint32_t n = count * (W.sec + 1);
+    if (W.ktab) {
+        hipLaunchKernelGGL(k_exp_commit_kt_T, dim3((n + 255) / 256), dim3(256), 0, s, P, W, count);
+        hipLaunchKernelGGL(k_exp_commit_kt_A, dim3((n + 255) / 256), dim3(256), 0, s, P, W, count);
+    }
     hipLaunchKernelGGL(k_exp_commit, dim3((n + 255) / 256), dim3(256), 0, s, P, W, count);
 }
 

@@ -1,0 +1,50 @@
+// Per-key tables of the ring (layout: engine.h, KTAB_*; built by k_ktab.hip at zk_ctx_set_ring) and k * P through them.
+#pragma once
+#include "rtab.h"
+
+ZK_DEV P256Aff ld_ktab(const uint32_t* e, bool neg = false) {   // neg: (x, p - y), on the words (entries are canonical, y != 0 on this curve)
+    const uint4* q = (const uint4*)e;
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint4 v = q[i];
+        w[4 * i] = v.x, w[4 * i + 1] = v.y, w[4 * i + 2] = v.z, w[4 * i + 3] = v.w;
+    }
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t d = (uint64_t)ModQ::mod32[i] - w[8 + i] - br;
+        br = (d >> 32) & 1;
+        w[8 + i] = neg ? (uint32_t)d : w[8 + i];
+    }
+    P256Aff a;
+    limbs_from_words<8>(a.x.l, w);
+    limbs_from_words<8>(a.y.l, w + 8);
+    return a;
+}
+ZK_DEV void st_ktab(uint32_t* e, const Fe<ModQ, 1>& x, const Fe<ModQ, 1>& y) {
+    uint32_t w[16];
+    words_from_limbs<8>(w, x.l);
+    words_from_limbs<8>(w + 8, y.l);
+    uint4* q = (uint4*)e;
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+// acc + k * P for the ring key whose table starts at kt; k < 2^256 as 8 little-endian words (destroyed).  33 gathers of 64 bytes and
+// 33 mixed complete additions (weier.ts:176-230 with Z2 = 1) over signed 8-bit digits; neg: the prover's key is the NEGATIVE of the
+// table's base point (the ring holds x-coordinates only, the table was built for one of the two roots), which flips every digit's sign.
+ZK_DEV P256Pt p256_ktab_mul_acc(P256Pt acc, const uint32_t* __restrict__ kt, uint32_t kw[8], bool neg) {
+    uint32_t carry = 0;
+#pragma unroll 1
+    for (uint32_t w = 0; w < KTAB_NWIN; w++) {
+        uint32_t d = (kw[0] & 255u) + carry;   // the 33rd window sees only the carry
+        shr256<KTAB_BITS>(kw);
+        const bool dn = d > KTAB_ENT;
+        carry = dn ? 1 : 0;
+        if (dn) d = 256 - d;
+        P256Aff e = ld_ktab(kt + ((size_t)w * KTAB_ENT + (d ? d - 1 : 0)) * KTAB_ENTRY_WORDS, neg != dn);   // digit 0: slot 0, result discarded
+        P256Pt s = p256_add_mixed(acc, e);
+        acc = p256_select(d != 0, s, acc);
+    }
+    return acc;
+}
