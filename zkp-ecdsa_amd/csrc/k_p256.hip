@@ -22,14 +22,17 @@ ZK_DEV P256Aff ld_pfix(const uint32_t* e) {
 }
 // k * B for a fixed base with a PFIX_WIN_BITS-bit comb table; k given as 8 little-endian words (clobbered)
 ZK_DEV P256Pt p256_fixed_mul(const uint32_t* __restrict__ tab, uint32_t kw[8]) {
-    P256Pt acc = p256_identity();
-#pragma unroll 1
-    for (int w = 0; w < PFIX_NWIN; w++) {
+    P256Pt acc;
+    {   // first window: identity + entry = the entry
         uint32_t d = kw[0] & (PFIX_WIN_SIZE - 1);
         shr256<PFIX_WIN_BITS>(kw);
-        P256Aff e = ld_pfix(tab + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + d));
-        P256Pt s = w == 0 ? p256_from_affine(e) : p256_add_mixed(acc, e);   // first window: identity + entry
-        acc = p256_select(d != 0, s, acc);
+        acc = p256_select(d != 0, p256_from_affine(ld_pfix(tab + (size_t)PFIX_ENTRY_WORDS * d)), p256_identity());
+    }
+#pragma unroll 1
+    for (int w = 1; w < PFIX_NWIN; w++) {
+        uint32_t d = kw[0] & (PFIX_WIN_SIZE - 1);
+        shr256<PFIX_WIN_BITS>(kw);
+        if (d != 0) acc = p256_add_mixed(acc, ld_pfix(tab + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + d)));   // a zero digit (2^-20) idles its lane
     }
     return acc;
 }
@@ -39,9 +42,7 @@ ZK_DEV P256Pt p256_fixed_mul_acc(P256Pt acc, const uint32_t* __restrict__ tab, u
     for (int w = 0; w < PFIX_NWIN; w++) {
         uint32_t d = kw[0] & (PFIX_WIN_SIZE - 1);
         shr256<PFIX_WIN_BITS>(kw);
-        P256Aff e = ld_pfix(tab + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + d));
-        P256Pt s = p256_add_mixed(acc, e);
-        acc = p256_select(d != 0, s, acc);
+        if (d != 0) acc = p256_add_mixed(acc, ld_pfix(tab + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + d)));   // a zero digit (2^-20) idles its lane
     }
     return acc;
 }
@@ -230,9 +231,9 @@ void launch_rtab(hipStream_t s, const Workspace& W, uint32_t count, uint32_t bit
 // ---------------------------------------------------------------- Exp commit phase (exp.ts:144-149) and comS1
 // item j < sec of proof p:  T = alpha_j * R,  A = T + r_j * h_NIST     (draws 3+4j, 3+4j+1, both mod n)
 // item j = sec          :  comS1 = s1 * R + r0 * h_NIST                 (zkpAttestList.ts:138, draw 0)
-// Proofs with a per-proof table of R: one kernel.  Proofs on the key-table path (W.kt_use != 0): alpha * R = (alpha u1) * G + (alpha u2) * pk
-// with R = u1 G + u2 pk (zkpAttestList.ts:119-131), both through tables, in two kernels (T, then A = T + r * h) so that each stays within
-// the registers of three waves per SIMD.
+// Proofs with a per-proof table of R: k_exp_commit.  Proofs on the key-table path (W.kt_use != 0): k_exp_commit_kt, alpha * R =
+// (alpha u1) * G + (alpha u2) * pk with R = u1 G + u2 pk (zkpAttestList.ts:119-131), both through tables.  Two kernels so that neither
+// carries the other's registers.
 ZK_DEV void exp_scalars(const Workspace& W, uint32_t p, uint32_t j, uint32_t aw[8], uint32_t bw[8], bool want_a, bool want_b) {
     if (want_a) {
         Fe<ModN, 1> a = j < W.sec ? rng_draw<ModN>(W.rng, p, 3 + 4 * j) : soa_ld<ModN, 1>(W.s1, p);
@@ -257,36 +258,27 @@ __global__ void __launch_bounds__(256) k_exp_commit(DevParams P, Workspace W, ui
     st_proj(W.Tproj, t, T);
     st_proj(W.Aproj, t, A);
 }
-__global__ void __launch_bounds__(256) k_exp_commit_kt_T(DevParams P, Workspace W, uint32_t count) {
+__global__ void __launch_bounds__(256) k_exp_commit_kt(DevParams P, Workspace W, uint32_t count) {
     uint32_t t = gtid();
     uint32_t per = W.sec + 1;
     if (t >= count * per) return;
     uint32_t p = t / per, j = t % per;
     const uint32_t use = W.kt_use[p];
     if (!use) return;
-    uint32_t aw[8], gw[8], kw[8];
-    exp_scalars(W, p, j, aw, nullptr, true, false);
+    uint32_t aw[8], bw[8], gw[8], kw[8];
+    exp_scalars(W, p, j, aw, bw, true, true);
     Fe<ModN, 1> al;
     limbs_from_words<8>(al.l, aw);
     words_from_limbs<8>(gw, fe_canon(al.as<2>() * soa_ld<ModN, 1>(W.u1m, p).as<2>()).l);   // plain x Montgomery = plain
     words_from_limbs<8>(kw, fe_canon(al.as<2>() * soa_ld<ModN, 1>(W.u2m, p).as<2>()).l);
-    st_proj(W.Tproj, t, p256_ktab_mul_acc(p256_fixed_mul(P.pfix_G, gw), W.ktab + (size_t)W.kt_key[p] * KTAB_KEY_WORDS, kw, use == 2));
-}
-__global__ void __launch_bounds__(256) k_exp_commit_kt_A(DevParams P, Workspace W, uint32_t count) {
-    uint32_t t = gtid();
-    uint32_t per = W.sec + 1;
-    if (t >= count * per) return;
-    uint32_t p = t / per, j = t % per;
-    if (!W.kt_use[p]) return;
-    uint32_t bw[8];
-    exp_scalars(W, p, j, nullptr, bw, false, true);
-    st_proj(W.Aproj, t, p256_fixed_mul_acc(ld_proj(W.Tproj, t), P.pfix_H, bw));
+    P256Pt T = p256_ktab_mul_acc(p256_fixed_mul(P.pfix_G, gw), W.ktab + (size_t)W.kt_key[p] * KTAB_KEY_WORDS, kw, use == 2);
+    st_proj(W.Tproj, t, T);
+    st_proj(W.Aproj, t, p256_fixed_mul_acc(T, P.pfix_H, bw));   // A = T + r * h, the comb's additions straight onto T
 }
 void launch_exp_commit(hipStream_t s, const DevParams& P, const Workspace& W, uint32_t count) {
     uint32_t n = count * (W.sec + 1);
     if (W.ktab) {
-        hipLaunchKernelGGL(k_exp_commit_kt_T, dim3((n + 255) / 256), dim3(256), 0, s, P, W, count);
-        hipLaunchKernelGGL(k_exp_commit_kt_A, dim3((n + 255) / 256), dim3(256), 0, s, P, W, count);
+        hipLaunchKernelGGL(k_exp_commit_kt, dim3((n + 255) / 256), dim3(256), 0, s, P, W, count);
     }
     hipLaunchKernelGGL(k_exp_commit, dim3((n + 255) / 256), dim3(256), 0, s, P, W, count);
 }

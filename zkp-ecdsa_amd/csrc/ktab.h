@@ -42,9 +42,7 @@ ZK_DEV P256Pt p256_ktab_mul_acc(P256Pt acc, const uint32_t* __restrict__ kt, uin
         const bool dn = d > KTAB_ENT;
         carry = dn ? 1 : 0;
         if (dn) d = 256 - d;
-        P256Aff e = ld_ktab(kt + ((size_t)w * KTAB_ENT + (d ? d - 1 : 0)) * KTAB_ENTRY_WORDS, neg != dn);   // digit 0: slot 0, result discarded
-        P256Pt s = p256_add_mixed(acc, e);
-        acc = p256_select(d != 0, s, acc);
+        if (d != 0) acc = p256_add_mixed(acc, ld_ktab(kt + ((size_t)w * KTAB_ENT + d - 1) * KTAB_ENTRY_WORDS, neg != dn));   // a zero digit (2^-8) idles its lane
     }
     return acc;
 }
