@@ -35,4 +35,5 @@ for m in 1 0; do
 done
 python bench.py --pool --gpus 1 --steps 2 --warmup 1 2>/dev/null | grep '"metric"' > gpurun_out/${R}_bench_line_pool.json
 python tools/json_rate.py 2048 1 0 > gpurun_out/${R}_json_rates.txt
+python tools/exp_set_ring.py 65536 > gpurun_out/${R}_set_ring.txt 2>/dev/null
 rm -rf gpurun_out/prof_default gpurun_out/prof_lanes1 gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_SQ_WAVES gpurun_out/pmc_SQ_WAIT_ANY gpurun_out/pmc_MFMA

@@ -232,12 +232,18 @@ static zk_status set_ring_common(zk_ctx* c, const uint8_t* d_keys, uint64_t nkey
     if (c->key_tables && n <= KTAB_MAXN) {   // multiples of every ring key (k_ktab.hip): the prover's k * pk and alpha * R become table sums
         const uint32_t slab = (uint32_t)std::min<uint64_t>(N, 4096);
         void* tmp = nullptr;
-        HIPCHK(c, hipMalloc(&c->ktab, sizeof(uint32_t) * KTAB_KEY_WORDS * N));
-        HIPCHK(c, hipMalloc(&c->ktab_ok, N));
-        HIPCHK(c, hipMalloc(&tmp, ktab_temp_bytes(N, slab)));
-        launch_ktab_build(c->stream, ring, N, c->ktab, c->ktab_ok, tmp, slab);
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipFree(tmp));
+        // an optimisation, not a requirement: where the HBM is not there (several contexts on one device, a small card) the per-proof
+        // tables of R serve every proof
+        if (hipMalloc(&c->ktab, sizeof(uint32_t) * KTAB_KEY_WORDS * N) == hipSuccess && hipMalloc(&c->ktab_ok, N) == hipSuccess &&
+            hipMalloc(&tmp, ktab_temp_bytes(N, slab)) == hipSuccess) {
+            launch_ktab_build(c->stream, ring, N, c->ktab, c->ktab_ok, tmp, slab);
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        } else {
+            (void)hipGetLastError();
+            hipFree(c->ktab), hipFree(c->ktab_ok);
+            c->ktab = nullptr, c->ktab_ok = nullptr;
+        }
+        if (tmp) HIPCHK(c, hipFree(tmp));
     }
     {   // digest of the padded ring: what the hardened mode hashes into the membership challenge
         if (!c->ring_digest) HIPCHK(c, hipMalloc(&c->ring_digest, 32));
