@@ -257,3 +257,18 @@ extern "C" uint32_t ha_comb_digits(uint32_t bits, uint32_t nwin, const uint8_t* 
     for (int i = 0; i < 8; i++) rest |= d.w[i];
     return rest;
 }
+
+// digits of k for the per-key tables (comb_digits.h, KeyDigits): 33 signed 8-bit digits; returns what is left over (must be 0)
+extern "C" uint32_t ha_key_digits(const uint8_t* k32, uint32_t* dig, uint8_t* neg) {
+    KeyDigits d;
+    d.init();
+    be_to_words(k32, 32, d.w, 8);
+    for (uint32_t i = 0; i < 33; i++) {
+        bool ng;
+        d.next(dig[i], ng);
+        neg[i] = ng ? 1 : 0;
+    }
+    uint32_t rest = d.carry;
+    for (int i = 0; i < 8; i++) rest |= d.w[i];
+    return rest;
+}

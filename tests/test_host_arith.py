@@ -224,3 +224,17 @@ def test_comb_digit_recoding_reproduces_the_scalar(ha):
             assert all(i < entries for i in idx), (bits, hex(k))
             assert signed or not any(neg)
             assert sum((-int(i) if s else int(i)) << (bits * j) for j, (i, s) in enumerate(zip(idx, neg))) == k, (bits, hex(k))
+
+
+def test_key_table_digits_on_the_host(ha):
+    """comb_digits.h, KeyDigits: the signed 8-bit digits the per-key tables are indexed with (ktab.h) sum back to the scalar, stay within
+    the 128 stored multiples, and leave nothing behind after 33 windows -- including the carry into the 33rd."""
+    rnd = random.Random(23)
+    ha.ha_key_digits.restype = C.c_uint32
+    specials = [0, 1, 128, 129, 255, 256, (1 << 256) - 1, 1 << 255, (1 << 255) - 1, R.p256.order - 1, int('81' * 32, 16), int('80' * 32, 16), int('ff' * 31 + '81', 16)]
+    for k in specials + [rnd.randrange(1 << 256) for _ in range(300)]:
+        dig = (C.c_uint32 * 33)()
+        neg = (C.c_uint8 * 33)()
+        assert ha.ha_key_digits(k.to_bytes(32, 'big'), dig, neg) == 0, hex(k)
+        assert all(d <= 128 for d in dig) and dig[32] <= 1 and not neg[32], hex(k)
+        assert sum((-int(d) if s else int(d)) << (8 * j) for j, (d, s) in enumerate(zip(dig, neg))) == k, hex(k)

@@ -28,3 +28,18 @@ struct CombDigits {
 #endif
     }
 };
+
+// Signed 8-bit digits of a 256-bit scalar for the per-key tables (k_ktab.hip, ktab.h): 33 windows, digit in [-127, 128], the table
+// holds the multiples 1..128 of every window base (slot d - 1); the 33rd window only sees the carry out of the 32nd.
+struct KeyDigits {
+    uint32_t w[8];
+    uint32_t carry;
+    ZK_DEV void init() { carry = 0; }
+    ZK_DEV void next(uint32_t& d, bool& neg) {   // d = 0: nothing to add
+        d = (w[0] & 255u) + carry;
+        shr256_rt(w, 8);
+        neg = d > 128u;
+        carry = neg ? 1u : 0u;
+        if (neg) d = 256u - d;
+    }
+};

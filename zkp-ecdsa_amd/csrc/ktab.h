@@ -1,5 +1,6 @@
 // Per-key tables of the ring (layout: engine.h, KTAB_*; built by k_ktab.hip at zk_ctx_set_ring) and k * P through them.
 #pragma once
+#include "comb_digits.h"
 #include "rtab.h"
 
 ZK_DEV P256Aff ld_ktab(const uint32_t* e, bool neg = false) {   // neg: (x, p - y), on the words (entries are canonical, y != 0 on this curve)
@@ -34,14 +35,15 @@ ZK_DEV void st_ktab(uint32_t* e, const Fe<ModQ, 1>& x, const Fe<ModQ, 1>& y) {
 // 33 mixed complete additions (weier.ts:176-230 with Z2 = 1) over signed 8-bit digits; neg: the prover's key is the NEGATIVE of the
 // table's base point (the ring holds x-coordinates only, the table was built for one of the two roots), which flips every digit's sign.
 ZK_DEV P256Pt p256_ktab_mul_acc(P256Pt acc, const uint32_t* __restrict__ kt, uint32_t kw[8], bool neg) {
-    uint32_t carry = 0;
+    KeyDigits kd;   // comb_digits.h (checked on the host by tests/test_host_arith.py)
+    kd.init();
+#pragma unroll
+    for (int i = 0; i < 8; i++) kd.w[i] = kw[i];
 #pragma unroll 1
     for (uint32_t w = 0; w < KTAB_NWIN; w++) {
-        uint32_t d = (kw[0] & 255u) + carry;   // the 33rd window sees only the carry
-        shr256<KTAB_BITS>(kw);
-        const bool dn = d > KTAB_ENT;
-        carry = dn ? 1 : 0;
-        if (dn) d = 256 - d;
+        uint32_t d;
+        bool dn;
+        kd.next(d, dn);
         if (d != 0) acc = p256_add_mixed(acc, ld_ktab(kt + ((size_t)w * KTAB_ENT + d - 1) * KTAB_ENTRY_WORDS, neg != dn));   // a zero digit (2^-8) idles its lane
     }
     return acc;
