@@ -110,6 +110,9 @@ def test_streamed_calls_enforce_their_rules():
     with pytest.raises(Z.ZkError) as e:   # the synchronous calls are refused while jobs are queued
         eng.prove_batch_host_raw(*_cut(work, 0, 4))
     assert e.value.status == 14 and 'streamed' in str(e.value)
+    with pytest.raises(Z.ZkError) as e:   # nor may the ring (table E, key tables) or the parameters be replaced under queued jobs
+        eng.set_ring(work[0], 4096)
+    assert e.value.status == 14 and 'streamed' in str(e.value)
     with pytest.raises(Z.ZkError) as e:   # waits in submission order
         eng.prove_wait(t1)
     assert 'submission order' in str(e.value)

@@ -161,6 +161,10 @@ static void words_to_limbs30(const uint32_t* w, int nw, uint32_t* l) {
 extern "C" zk_status zk_ctx_set_params(zk_ctx* c, const uint8_t nist_h[64], const uint8_t tom_g[72], const uint8_t tom_h[72], uint32_t sec) {
     if (!c || !nist_h || !tom_g || !tom_h) return ZK_E_ARG;
     if (sec == 0 || sec > ZK_MAXSEC) return ZK_E_SECLEVEL;
+    if (c->stream_busy) {
+        c->err = "streamed jobs are in flight on this context (zk_prove_wait / zk_verify_wait them first)";
+        return ZK_E_ARG;
+    }
     HIPCHK(c, hipSetDevice(c->device));
     uint32_t hw[16], gw[18], hw2[18];
     be_to_words(nist_h, 32, hw, 8), be_to_words(nist_h + 32, 32, hw + 8, 8);
@@ -199,6 +203,10 @@ extern "C" zk_status zk_ctx_set_params(zk_ctx* c, const uint8_t nist_h[64], cons
 }
 
 static zk_status set_ring_common(zk_ctx* c, const uint8_t* d_keys, uint64_t nkeys) {
+    if (c->stream_busy) {   // the queued jobs read the ring, table E and the key tables this call would free
+        c->err = "streamed jobs are in flight on this context (zk_prove_wait / zk_verify_wait them first)";
+        return ZK_E_ARG;
+    }
     uint32_t n = 0;
     while (((uint64_t)1 << n) < nkeys) n++;
     if (n < 1 || n > ZK_MAXN - 4) return ZK_E_ARG;  // N = 1 is the reference's degenerate n = 0 case (untested there)
