@@ -1,10 +1,12 @@
-// P-256 kernels of the prover: ECDSA front end, per-proof comb table of R, the Exp commit phase and T1.
+// P-256 kernels of the prover: ECDSA front end, the multiplications by R of the Exp commit phase, T1.
 //
 // Reference call sites (src/zkpAttestList.ts:104-145, src/exp/exp.ts:144-156,186-193): every scalar multiplication
 // there is the window-4 Point.mul of src/curves/group.ts:133-152 (4448 modmuls).  Only affine results are
-// observable, so the engine uses: 16-bit fixed-base combs for G and h_NIST (16 mixed complete additions), and a
-// per-proof signed-digit comb table of R = paramsSigExp.g (rtab.h), shared by the sec+1 multiplications by R of one
-// proof (43 complete additions each).  All additions are the complete RCB formulas the reference uses.
+// observable, so the engine uses: 20-bit fixed-base combs for G and h_NIST (13 mixed complete additions), per-KEY tables of the
+// ring for every multiple of the signer's public key (ktab.h: 33 mixed additions; R = u1 G + u2 pk turns alpha * R into
+// (alpha u1) * G + (alpha u2) * pk), and -- for proofs whose `which` does not name their own key, and for rings above 2^16 keys -- a
+// per-proof signed-digit table of R (rtab.h), shared by the sec + 1 multiplications by R of one proof (43 complete additions each).
+// All additions are the complete RCB formulas the reference uses.
 #include "ktab.h"
 
 ZK_DEV P256Aff ld_pfix(const uint32_t* e) {
