@@ -13,6 +13,8 @@
 #define ZK_PIN_LIMBS32 0
 ZK_DEV uint32_t zk_rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 ZK_DEV uint32_t zk_funnelshift_r(uint32_t lo, uint32_t hi, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31)); }
+ZK_DEV uint32_t zk_xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
+ZK_DEV uint32_t zk_bfi(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }   // bitwise m ? a : b
 #else
 #include <hip/hip_runtime.h>
 #define ZK_DEV __device__ __forceinline__
@@ -20,4 +22,12 @@ ZK_DEV uint32_t zk_funnelshift_r(uint32_t lo, uint32_t hi, uint32_t sh) { return
 #define ZK_CONSTANT __constant__
 ZK_DEV uint32_t zk_rotr32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
 ZK_DEV uint32_t zk_funnelshift_r(uint32_t lo, uint32_t hi, uint32_t sh) { return __funnelshift_r(lo, hi, sh); }
+// v_bfi_b32, which the compiler does not form by itself from the textbook Ch / Maj expressions (gfx950 has no v_xor3_b32: the
+// assembler refuses it)
+ZK_DEV uint32_t zk_xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
+ZK_DEV uint32_t zk_bfi(uint32_t m, uint32_t a, uint32_t b) {   // bitwise m ? a : b
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
 #endif
