@@ -7,6 +7,8 @@
 #include "curve.h"
 #include "rng.h"
 #include "comb_digits.h"
+#include "ktab.h"
+#include <vector>
 
 static uint32_t bswap32h(uint32_t v) { return __builtin_bswap32(v); }
 // 40-byte big-endian operand -> 10 little-endian 32-bit words
@@ -271,4 +273,37 @@ extern "C" uint32_t ha_key_digits(const uint8_t* k32, uint32_t* dig, uint8_t* ne
     uint32_t rest = d.carry;
     for (int i = 0; i < 8; i++) rest |= d.w[i];
     return rest;
+}
+
+// ---------------------------------------------------------------- per-key table (ktab.h): one key's table built here the way k_ktab.hip
+// builds it (window bases by doubling, 128 multiples by complete additions, affine canonical entries), then acc0 + k * (+-P) through
+// p256_ktab_mul_acc for every scalar.  xy64: the table's base point; start64: the accumulator's start (64 zero bytes = identity).
+extern "C" int ha_ktab_mul(const uint8_t* xy64, const uint8_t* start64, uint64_t count, const uint8_t* k32, const uint8_t* negs, uint8_t* out64) {
+    P256Aff A;
+    if (!p256_load(A, xy64)) return -1;
+    std::vector<uint32_t> tab(KTAB_KEY_WORDS);
+    P256Pt base = p256_from_affine(A);
+    for (uint32_t w = 0; w < KTAB_NWIN; w++) {
+        P256Pt acc = base;
+        for (uint32_t d = 1; d <= KTAB_ENT; d++) {
+            if (d > 1) acc = p256_add(acc, base);
+            Fq2 zi = fe_inv<ModQ>(fe_reduce(acc.z));
+            st_ktab(tab.data() + ((size_t)w * KTAB_ENT + d - 1) * KTAB_ENTRY_WORDS, fe_canon(acc.x * zi), fe_canon(acc.y * zi));
+        }
+        for (uint32_t k = 0; k < KTAB_BITS; k++) base = p256_dbl(base);
+    }
+    P256Pt start = p256_identity();
+    bool have_start = false;
+    for (int i = 0; i < 64; i++) have_start = have_start || start64[i] != 0;
+    if (have_start) {
+        P256Aff S;
+        if (!p256_load(S, start64)) return -2;
+        start = p256_from_affine(S);
+    }
+    for (uint64_t i = 0; i < count; i++) {
+        uint32_t kw[8];
+        be_to_words(k32 + 32 * i, 32, kw, 8);
+        p256_store(p256_ktab_mul_acc(start, tab.data(), kw, negs[i] != 0), out64 + 64 * i);
+    }
+    return 0;
 }

@@ -238,3 +238,22 @@ def test_key_table_digits_on_the_host(ha):
         assert ha.ha_key_digits(k.to_bytes(32, 'big'), dig, neg) == 0, hex(k)
         assert all(d <= 128 for d in dig) and dig[32] <= 1 and not neg[32], hex(k)
         assert sum((-int(d) if s else int(d)) << (8 * j) for j, (d, s) in enumerate(zip(dig, neg))) == k, hex(k)
+
+
+def test_key_table_multiplication_on_the_host(ha):
+    """ktab.h: a key's table built like k_ktab.hip builds it and acc + k * (+-P) through p256_ktab_mul_acc (33 gathered entries, signed
+    digits, entries negated on their words when the prover's key is the table's other root) against the oracle's Point.mul."""
+    rnd = random.Random(31)
+    g, n = R.p256, R.p256.order
+    P = g.generator().mul(g.newScalar(rnd.randrange(1, n)))
+    S = g.generator().mul(g.newScalar(rnd.randrange(1, n)))
+    ks = [rnd.randrange(1 << 256) for _ in range(12)] + [0, 1, 127, 128, 129, 255, 256, n - 1, n, (1 << 256) - 1, int('80' * 32, 16), int('81' * 32, 16)]
+    negs = bytes(i & 1 for i in range(len(ks)))
+    for start in (None, S):
+        out = C.create_string_buffer(64 * len(ks))
+        assert ha.ha_ktab_mul(_p_xy(P), bytes(64) if start is None else _p_xy(start), C.c_uint64(len(ks)), b''.join(k.to_bytes(32, 'big') for k in ks), negs, out) == 0
+        for i, k in enumerate(ks):
+            want = (P.neg() if negs[i] else P).mul(g.newScalar(k % n))
+            if start is not None:
+                want = want.add(start)
+            assert out.raw[64 * i:64 * i + 64] == _p_xy(want), (i, hex(k), negs[i])

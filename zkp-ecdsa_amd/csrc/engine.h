@@ -61,16 +61,7 @@ static inline size_t tom_tab_words(uint32_t bits) { return (size_t)tom_nwin(bits
 #define PFIX_WIN_SIZE (1u << PFIX_WIN_BITS)
 #define PFIX_ENTRY_WORDS 20
 #define PFIX_TAB_WORDS ((size_t)PFIX_NWIN * PFIX_WIN_SIZE * PFIX_ENTRY_WORDS)
-// per-KEY tables (k_ktab.hip): every ring key P gets d * 2^(8 w) * P, d = 1..128, w = 0..32, affine, 64 bytes per entry (slot d - 1 of
-// window w): 264 KB per key, 17.7 GB for a ring of 2^16 keys.  A scalar is recoded into signed 8-bit digits in [-127, 128] (a negative
-// digit negates the entry on load), so a prover's k * pk is 33 mixed additions of gathered entries, and alpha_i * R of proveExp
-// (exp.ts:144-149) becomes (alpha_i u1) * G + (alpha_i u2) * pk -- no per-proof table of R, no doubling chain in the front end.
-#define KTAB_BITS 8
-#define KTAB_NWIN 33
-#define KTAB_ENT 128
-#define KTAB_ENTRY_WORDS 16
-#define KTAB_MAXN 16
-#define KTAB_KEY_WORDS ((size_t)KTAB_NWIN * KTAB_ENT * KTAB_ENTRY_WORDS)
+#include "ktab.h"   // layout of the per-key tables of the ring (KTAB_*) and the multiplication through them
 size_t ktab_temp_bytes(uint64_t N, uint32_t slab_keys);
 void launch_ktab_build(hipStream_t s, const Soa& ring, uint64_t N, uint32_t* ktab, uint8_t* ok, void* temp, uint32_t slab_keys);
 // per-proof table of R (rtab.h): signed `bits`-bit comb, ceil(257/bits) windows x (2^(bits-1) + 1) entries of 28 words

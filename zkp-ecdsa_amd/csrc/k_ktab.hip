@@ -10,7 +10,7 @@
 //                 normalised to affine with Montgomery's trick over the thread's own 128 entries (one Fermat inversion per thread)
 // Entries are exact group elements in canonical Montgomery form, so every multiple taken through them equals the reference's
 // Point.mul (group.ts:133-152) as a group element -- only affine coordinates are ever observable.
-#include "ktab.h"
+#include "rtab.h"   // engine.h (and with it ktab.h), the projective table entries of rtab.h
 
 #define KTB_BASE_WORDS 28   // X, Y, Z (9 limbs each) + pad
 #define KTB_TMP_WORDS 36    // X, Y, Z, prefix product of the Z's before this entry

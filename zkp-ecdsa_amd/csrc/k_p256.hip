@@ -7,7 +7,7 @@
 // (alpha u1) * G + (alpha u2) * pk), and -- for proofs whose `which` does not name their own key, and for rings above 2^16 keys -- a
 // per-proof signed-digit table of R (rtab.h), shared by the sec + 1 multiplications by R of one proof (43 complete additions each).
 // All additions are the complete RCB formulas the reference uses.
-#include "ktab.h"
+#include "rtab.h"   // engine.h (and with it ktab.h), the projective table entries of rtab.h
 
 ZK_DEV P256Aff ld_pfix(const uint32_t* e) {
     const uint4* q = (const uint4*)e;

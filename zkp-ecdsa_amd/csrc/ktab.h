@@ -1,16 +1,32 @@
-// Per-key tables of the ring (layout: engine.h, KTAB_*; built by k_ktab.hip at zk_ctx_set_ring) and k * P through them.
+// Per-key tables of the ring (built by k_ktab.hip at zk_ctx_set_ring) and k * P through them.  Depends on the arithmetic headers only, so
+// tests/host_arith compiles it for the host as well (table of one key, every multiplication against the oracle).
 #pragma once
 #include "comb_digits.h"
-#include "rtab.h"
+#include "curve.h"
+
+// per-KEY tables (k_ktab.hip): every ring key P gets d * 2^(8 w) * P, d = 1..128, w = 0..32, affine, 64 bytes per entry (slot d - 1 of
+// window w): 264 KB per key, 17.7 GB for a ring of 2^16 keys.  A scalar is recoded into signed 8-bit digits in [-127, 128] (a negative
+// digit negates the entry on load), so a prover's k * pk is 33 mixed additions of gathered entries, and alpha_i * R of proveExp
+// (exp.ts:144-149) becomes (alpha_i u1) * G + (alpha_i u2) * pk -- no per-proof table of R, no doubling chain in the front end.
+#define KTAB_BITS 8
+#define KTAB_NWIN 33
+#define KTAB_ENT 128
+#define KTAB_ENTRY_WORDS 16
+#define KTAB_MAXN 16
+#define KTAB_KEY_WORDS ((size_t)KTAB_NWIN * KTAB_ENT * KTAB_ENTRY_WORDS)
 
 ZK_DEV P256Aff ld_ktab(const uint32_t* e, bool neg = false) {   // neg: (x, p - y), on the words (entries are canonical, y != 0 on this curve)
-    const uint4* q = (const uint4*)e;
     uint32_t w[16];
+#ifdef ZK_HOST_BUILD
+    for (int i = 0; i < 16; i++) w[i] = e[i];
+#else
+    const uint4* q = (const uint4*)e;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         uint4 v = q[i];
         w[4 * i] = v.x, w[4 * i + 1] = v.y, w[4 * i + 2] = v.z, w[4 * i + 3] = v.w;
     }
+#endif
     uint64_t br = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -27,9 +43,13 @@ ZK_DEV void st_ktab(uint32_t* e, const Fe<ModQ, 1>& x, const Fe<ModQ, 1>& y) {
     uint32_t w[16];
     words_from_limbs<8>(w, x.l);
     words_from_limbs<8>(w + 8, y.l);
+#ifdef ZK_HOST_BUILD
+    for (int i = 0; i < 16; i++) e[i] = w[i];
+#else
     uint4* q = (uint4*)e;
 #pragma unroll
     for (int i = 0; i < 4; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+#endif
 }
 // acc + k * P for the ring key whose table starts at kt; k < 2^256 as 8 little-endian words (destroyed).  33 gathers of 64 bytes and
 // 33 mixed complete additions (weier.ts:176-230 with Z2 = 1) over signed 8-bit digits; neg: the prover's key is the NEGATIVE of the
