@@ -837,8 +837,9 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32 (9x30-bit limbs, 256/258-bit modular integers)',
             'data': 'synthetic',
-            'config': {'workload': 'batch=%d proofs per GPU per step, ring=%d keys (n=%d), secLevel=%d, P-256 + Tom-256, chunk=%d x %d lanes, comb=%d bits'
-                                   % (B, nkeys, n_log2, sec, eng_chunk(args, B), args.lanes, args.comb_bits),
+            'config': {'workload': 'batch=%d proofs per GPU per step, ring=%d keys (n=%d), secLevel=%d, P-256 + Tom-256, chunk=%d x %d lanes, comb=%d bits%s'
+                                   % (B, nkeys, n_log2, sec, eng_chunk(args, B), args.lanes, args.comb_bits,
+                                      ', per-key tables of the ring' if n_log2 <= 16 and os.environ.get('ZKATTEST_KEYTAB', '1') != '0' else ''),
                        'parallelism': 'proofs sharded per GPU; ring broadcast over RCCL at set-up' if world > 1 else 'single GPU'},
             'set_params_s': round(t_tab, 3),
             'hbm_used_gb': round(hbm_used / 2**30, 1),   # tables + both lanes' prover and verifier workspaces + this step's proofs
