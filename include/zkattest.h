@@ -81,7 +81,14 @@ zk_status zk_ctx_set_params(zk_ctx *ctx, const uint8_t nist_h[64], const uint8_t
 
 /* Replaces the `keys: bigint[]` argument (src/zkpAttestList.ts:110,150): n_keys big-endian 32-byte scalars.
  * Pads to the next power of two with copies of keys[0] (src/proofGK/gk.ts:75-86).  The _device variant takes a
- * pointer already resident on this context's GPU (e.g. the target of an RCCL broadcast). */
+ * pointer already resident on this context's GPU (e.g. the target of an RCCL broadcast).
+ * n_keys >= 2.  A ONE-key ring is refused with ZK_E_ARG: the reference cannot prove over it either -- the padded length is 1, n = 0, and
+ * proveMembership's interpolate([], []) evaluates `-x[0] % m` with x[0] undefined (src/proofGK/interpolate.ts:40), a TypeError
+ * ("Cannot mix BigInt and other types") for every `which` -- so no proof over such a ring exists to be verified; the facade throws that
+ * TypeError.  `which` (zk_prove_batch) indexes the PADDED ring: [0, n_keys) are the caller's keys, [n_keys, N) the padding copies of keys[0]
+ * (the owner of keys[0] may name any of them; the index bits enter the proof), and which >= N is per-proof status ZK_E_ARG, the
+ * reference's `values[index].k` on undefined (gk.ts:162; proveMembership runs last, so an invalid key and 'T[i] is at infinity' are
+ * reported in its place when they apply too; 'T1 is at infinity' -- a planted nonce and a bad index in one call -- is not). */
 zk_status zk_ctx_set_ring(zk_ctx *ctx, const uint8_t *keys_be32, uint64_t n_keys);
 zk_status zk_ctx_set_ring_device(zk_ctx *ctx, const void *d_keys_be32, uint64_t n_keys);
 
@@ -144,7 +151,9 @@ zk_status zk_ctx_set_key_tables(zk_ctx *ctx, uint32_t on);
  * as int8 matrix products (ZKATTEST_GK_MFMA).  Prover: the table path's coefficient classes 2..6 of proveMembership's polynomial
  * (gk.ts:141-171), per group of proofs with equal low index bits; its operand table (0.83 GB at 2^16 keys, 13 GB at 2^20) is built
  * by zk_ctx_set_ring unless ZKATTEST_GK_MFMA_PROVE=0.  Exact integer arithmetic either way: same proofs, totals and verdicts.
- * Takes effect with the next prove / verify call. */
+ * Takes effect with the next prove / verify call.
+ * Every zk_ctx_set_* above returns ZK_E_ARG while streamed jobs are queued on the context (zk_prove_submit below): a queued job keeps
+ * the lanes, chunk size, workspaces and mode it was planned with. */
 zk_status zk_ctx_set_ring_fold(zk_ctx *ctx, uint32_t matrix_pipe);
 
 /* Upper bound of one proof's ZKA1 size for the current params/ring. */
@@ -188,7 +197,15 @@ zk_status zk_prove_batch_device(zk_ctx *ctx, uint64_t B, const void *d_msg_hash,
  * checked mod p, src/curves/weier.ts:74-89) and enters the Fiat-Shamir hashes REDUCED, as toBytes -> toAffine does
  * (src/curves/weier.ts:231-255).  Tom-256 coordinates must be canonical (< the field prime, zero padding bytes): ZKA1 is this
  * engine's format and is stricter here than the reference's JSON reader, which reduces out-of-range values silently
- * (src/curves/edwards.ts:204-209); such a proof gets ZK_E_BAD_ENCODING. */
+ * (src/curves/edwards.ts:204-209); such a proof gets ZK_E_BAD_ENCODING.
+ * Status codes are exact (tests/test_gpu_mutants.py: seeded mutants, engine == oracle): ZK_E_BAD_ENCODING for anything that does not
+ * deserialise -- magic, lengths, a header n above 63, challenge bits set above secLevel, any point of the announced structure off its
+ * curve, also inside a GKProof of the wrong length --; ok = 0 with status 0 where the reference returns false (membership, a GKProof
+ * whose length is not the ring's, gk.ts:208-218, a failed relation); otherwise the exception verifyExp throws FIRST when it walks
+ * the 20 sampled repetitions in order (exp.ts:265-346): ZK_E_PARAMS_NOT_FOUND, ZK_E_T_INF or ZK_E_T1_INF.  ZK_E_R_INF cannot occur (R
+ * travels in affine form).  One restriction: a batch is homogeneous in secLevel -- a proof whose header announces another repetition
+ * count than the context's gets ZK_E_BAD_ENCODING, where the reference would verify it with its own count (exp.ts:243-260); a context
+ * with secLevel < 20 refuses the call with ZK_E_SECLEVEL. */
 zk_status zk_verify_batch(zk_ctx *ctx, uint64_t B, const uint8_t *msg_hash /*Bx32*/, const uint8_t *proofs,
                           const uint64_t *proof_off /*B+1*/, const uint8_t *verifier_seeds /*Bx32 or NULL*/,
                           uint8_t *ok /*B*/, int32_t *per_proof_status /*B*/);
@@ -321,6 +338,9 @@ uint32_t zk_last_timing(const zk_ctx *ctx, float *total_ms, const char **names, 
 /* Unit-test hooks (tests/ call these through the C ABI to compare single primitives with the oracle).
  * zk_pool_test_locality: NUMA node and local CPUs of a PCI address as the pool reads them from sysfs (ZKATTEST_SYSFS_ROOT). */
 int zk_pool_test_locality(const char *pci_bus_id, int *numa_node, int *cpus, int cap);
+/* the next zk_pool_prove_submit / zk_pool_verify_submit fails with ZK_E_DEVICE at device slot `slot`, after the earlier slots were
+ * submitted (one shot): the half-submitted job is taken out of the queues again, older jobs stay in flight and waitable */
+void zk_pool_test_fail_submit(zk_pool *pool, int slot);
 /* work counters: 0 = proofs that went through the verifier's per-proof sums since the context was created (fallback of the batched check);
  * 1 = proofs of the last chunk on lane 0 whose scalar multiplications by the signer's key went through the per-key tables */
 uint64_t zk_test_counter(const zk_ctx *ctx, int which);

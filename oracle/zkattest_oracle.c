@@ -40,6 +40,7 @@ enum {
     ZK_E_RNG_EXHAUSTED = 11,
     ZK_E_BUFFER = 12,
     ZK_E_INTERPOLATION = 13,     /* interpolate.ts:65 */
+    ZK_E_ARG = 14,               /* a TypeError of the JavaScript runtime (`which` past the padded ring, gk.ts:162) */
 };
 
 /* ------------------------------------------------------------------ SHA-256 (FIPS 180-4) */
@@ -956,6 +957,10 @@ static int prove_one(const zko_ctx *c, const uint8_t *msg_hash, const uint8_t *s
             if (rc) return rc;
         }
     }
+    /* gk.ts:162 reads values[index].k with index = which: past the padded ring that is `undefined.k`, a TypeError -- thrown by
+     * proveMembership, i.e. after proveExp and its exceptions (zkpAttestList.ts:141-142).  (A one-key ring never gets that far: n = 0 and
+     * interpolate([], []) evaluates -x[0] % m with x[0] undefined, interpolate.ts:40, a TypeError for every `which`.) */
+    if ((u64)which >= c->N) return ZK_E_ARG;
     int rc = prove_membership(&c->tom, g, w, &pkX, which, c->ring_m, c->N, c->n, scratch_p);
     if (rc) return rc;
     if (g->err) return ZK_E_RNG_EXHAUSTED;
@@ -1311,6 +1316,8 @@ static int verify_one(const zko_ctx *c, const uint8_t *msg_hash, const uint8_t *
     if (total != plen || hdr[8] || hdr[9] || hdr[10] || hdr[12] || hdr[13] || hdr[14] || n > 63 || sec > MAXSEC) return ZK_E_BAD_ENCODING;
     fe bits;
     fe_from_be(&bits, hdr + 16, 16);
+    for (int i = sec; i < 128; i++) /* ZKA1 (include/zkattest.h): the challenge-bit field is zero above secLevel */
+        if ((bits.v[i / 64] >> (i % 64)) & 1) return ZK_E_BAD_ENCODING;
     ppt R, comS1, G, Q;
     tpt kx, ky;
     rd_pp(&rd, &R); rd_pp(&rd, &comS1); rd_tp(&rd, &kx); rd_tp(&rd, &ky);

@@ -1311,6 +1311,8 @@ def proof_from_bytes(b):
     bits = fromBytes(rd.take(16))
     if total != len(rd.b):
         raise ValueError('bad length')
+    if bits >> sec:   # ZKA1 (include/zkattest.h): the challenge-bit field is zero above secLevel
+        raise ValueError('challenge bits above secLevel')
     W, Nn = tomEdwards256, p256
     R, comS1, kx, ky = rd.pp(), rd.pp(), rd.tp(), rd.tp()
 

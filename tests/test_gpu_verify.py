@@ -82,8 +82,8 @@ def test_tampered_proofs_rejected_like_the_oracle():
         vs = _vseeds(len(plist), tag)
         g, o = _both(eng, octx, msgs, plist, vs)
         assert g[0] == o[0], dict(zip(names, zip(g[0], o[0])))
-        # statuses: both flag malformed input; the engine validates every point up front (like readJson) so codes agree
-        assert [s != 0 for s in g[1]] == [s != 0 for s in o[1]], dict(zip(names, zip(g[1], o[1])))
+        # statuses: the exact codes (the facade re-throws the reference's error text from them); tests/test_gpu_mutants.py sweeps this
+        assert g[1] == o[1], dict(zip(names, zip(g[1], o[1])))
         assert sum(g[0]) <= 1  # only a flipped scalar in an unchecked rep may still pass
     # wrong message
     g, o = _both(eng, octx, bytes(32), [base], _vseeds(1))
@@ -240,7 +240,7 @@ def test_batched_check_with_every_kind_of_bad_proof_in_the_chunk():
         got = eng.verify_batch(msg, mixed, vseeds=vs)
         assert got == ref, (tag, got, ref)
         o = octx.verify_batch(msg, mixed, nthreads=8, vseeds=vs)
-        assert got[0] == o[0] and [s != 0 for s in got[1]] == [s != 0 for s in o[1]]
+        assert got == o, (tag, got, o)
         assert got[0][0] == 1 and got[0][1] == 0 and got[0][3] == 0 and got[0][4] == 0 and got[0][10] == 0
     # bad proofs whose terms never reach the sums (malformed ones) must not spoil the fast path for the others
     only_malformed = list(proofs)

@@ -17,7 +17,7 @@ SYMBOLS = [
     'zk_proof_to_json', 'zk_proof_from_json', 'zk_host_alloc', 'zk_host_free', 'zk_ctx_set_host_taper', 'zk_ctx_set_slice', 'zk_ctx_set_mode', 'zk_ring_digest', 'zk_hardened_h',
     'zk_pool_create', 'zk_pool_destroy', 'zk_pool_size', 'zk_pool_ctx', 'zk_pool_last_error', 'zk_pool_ring_transport', 'zk_pool_shard',
     'zk_pool_set_params', 'zk_pool_set_ring', 'zk_pool_prove_batch', 'zk_pool_verify_batch',
-    'zk_pool_host_alloc', 'zk_pool_host_free', 'zk_pool_numa_node', 'zk_pool_test_locality', 'zk_pool_shard_ms',
+    'zk_pool_host_alloc', 'zk_pool_host_free', 'zk_pool_numa_node', 'zk_pool_test_locality', 'zk_pool_shard_ms', 'zk_pool_test_fail_submit',
     'zk_prove_submit', 'zk_prove_submit_device', 'zk_prove_wait', 'zk_verify_submit', 'zk_verify_wait', 'zk_test_counter', 'zk_ctx_set_key_tables',
     'zk_proofs_to_json_batch', 'zk_proofs_from_json_batch', 'zk_ctx_set_ring_fold',
     'zk_pool_prove_submit', 'zk_pool_prove_wait', 'zk_pool_verify_submit', 'zk_pool_verify_wait', 'zk_ctx_set_verify_groups',
@@ -121,6 +121,8 @@ def lib():
         L.zk_pool_prove_wait.argtypes = [vp, vp]
         L.zk_pool_verify_submit.argtypes = [vp, u64, C.c_char_p, vp, vp, vp, C.c_char_p, vp, vp, C.POINTER(vp)]
         L.zk_pool_verify_wait.argtypes = [vp, vp]
+        L.zk_pool_test_fail_submit.argtypes = [vp, i32]
+        L.zk_pool_test_fail_submit.restype = None
         L.zk_pool_host_alloc.argtypes = [vp, C.c_size_t]
         L.zk_pool_host_alloc.restype = vp
         L.zk_pool_host_free.argtypes = [vp]
@@ -603,6 +605,10 @@ class Pool:
     def prove_wait(self, t):
         self._chk(self.L.zk_pool_prove_wait(self.h, t['job']))
         return t['off'], t['ln'], t['st']
+
+    def test_fail_submit(self, slot):
+        """unit-test hook: the next streamed submit fails at device slot `slot` after the earlier slots were submitted"""
+        self.L.zk_pool_test_fail_submit(self.h, slot)
 
     def verify_submit(self, msg, proofs, off, ln, B, vseeds=None):
         t = {'B': B, 'proofs': proofs, 'off': off, 'ln': ln, 'ok': (C.c_uint8 * B)(), 'st': (C.c_int32 * B)(), 'msg': bytes(msg),

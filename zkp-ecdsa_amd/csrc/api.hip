@@ -110,8 +110,14 @@ static zk_status ctx_init(zk_ctx* c, int device_id) {
     HIPCHK(c, hipFree(d_xy));
     return ZK_OK;
 }
+// settings a queued streamed job was planned with (its lane rotation, chunk size, workspaces, mode) stay frozen until it is waited for
+static zk_status busy_refusal(zk_ctx* c) {
+    c->err = "streamed jobs are in flight on this context (zk_prove_wait / zk_verify_wait them first)";
+    return ZK_E_ARG;
+}
 extern "C" zk_status zk_ctx_set_comb_bits(zk_ctx* c, uint32_t bits) {
     if (!c || bits < 8 || bits > TOM_MAX_BITS) return ZK_E_ARG;
+    if (c->stream_busy) return busy_refusal(c);
     if (bits != c->tom_bits) c->params_set = false;  // the tables are rebuilt by the next zk_ctx_set_params
     c->tom_bits = bits;
     return ZK_OK;
@@ -224,15 +230,18 @@ static zk_status set_ring_common(zk_ctx* c, const uint8_t* d_keys, uint64_t nkey
     }
     if (c->gk_kdig) HIPCHK(c, hipFree(c->gk_kdig));
     c->gk_kdig = nullptr;
+    // the two digit-fragment tables and the per-key tables below are optimisations, not requirements: where the HBM is not there (several
+    // contexts on one device, a ring of 2^20 keys next to other tenants) the allocation failure is cleared and the vector-ALU fold / the
+    // per-proof tables of R serve every proof -- same bytes, same verdicts
     if (c->gk_etab && n >= GKM_MINN) {   // 33 bytes per key: the verifier's ring fold on the matrix pipe (k_gk_mfma.hip)
-        HIPCHK(c, hipMalloc(&c->gk_kdig, gkm_ring_frag_bytes(N)));
-        launch_gkm_ring_digits(c->stream, ring, (uint32_t)(N >> 8), c->gk_kdig);
+        if (hipMalloc(&c->gk_kdig, gkm_ring_frag_bytes(N)) == hipSuccess) launch_gkm_ring_digits(c->stream, ring, (uint32_t)(N >> 8), c->gk_kdig);
+        else (void)hipGetLastError(), c->gk_kdig = nullptr;
     }
     if (c->gk_edig) HIPCHK(c, hipFree(c->gk_edig));
     c->gk_edig = nullptr;
     if (c->gk_etab && n >= GKM_MINN && c->gk_mfma_prove) {   // table E's classes 2..6 as digit fragments: the prover's matrix-pipe path
-        HIPCHK(c, hipMalloc(&c->gk_edig, gkm_etab_frag_bytes(N)));
-        launch_gkm_etab_digits(c->stream, c->gk_etab, (uint32_t)(N >> 8), c->gk_edig);
+        if (hipMalloc(&c->gk_edig, gkm_etab_frag_bytes(N)) == hipSuccess) launch_gkm_etab_digits(c->stream, c->gk_etab, (uint32_t)(N >> 8), c->gk_edig);
+        else (void)hipGetLastError(), c->gk_edig = nullptr;
     }
     if (c->ktab) HIPCHK(c, hipFree(c->ktab));
     if (c->ktab_ok) HIPCHK(c, hipFree(c->ktab_ok));
@@ -245,7 +254,11 @@ static zk_status set_ring_common(zk_ctx* c, const uint8_t* d_keys, uint64_t nkey
         if (hipMalloc(&c->ktab, sizeof(uint32_t) * KTAB_KEY_WORDS * N) == hipSuccess && hipMalloc(&c->ktab_ok, N) == hipSuccess &&
             hipMalloc(&tmp, ktab_temp_bytes(N, slab)) == hipSuccess) {
             launch_ktab_build(c->stream, ring, N, c->ktab, c->ktab_ok, tmp, slab);
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipError_t e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) {
+                hipFree(tmp);
+                HIPCHK(c, e);
+            }
         } else {
             (void)hipGetLastError();
             hipFree(c->ktab), hipFree(c->ktab_ok);
@@ -299,16 +312,19 @@ extern "C" zk_status zk_keys_to_ints(zk_ctx* c, uint64_t n, const uint8_t* pk, u
 }
 extern "C" zk_status zk_ctx_set_chunk(zk_ctx* c, uint32_t chunk) {
     if (!c || chunk == 0 || chunk > (1u << 18)) return ZK_E_ARG;
+    if (c->stream_busy) return busy_refusal(c);
     c->chunk = chunk;
     return ZK_OK;
 }
 extern "C" zk_status zk_ctx_set_batch_verify(zk_ctx* c, uint32_t min_chunk) {
     if (!c) return ZK_E_ARG;
+    if (c->stream_busy) return busy_refusal(c);
     c->verify_batch_min = min_chunk;
     return ZK_OK;
 }
 extern "C" zk_status zk_ctx_set_verify_groups(zk_ctx* c, uint32_t groups) {
     if (!c || (groups != 8 && groups != 64)) return ZK_E_ARG;
+    if (c->stream_busy) return busy_refusal(c);
     c->verify_groups = groups;
     return ZK_OK;
 }
@@ -319,11 +335,13 @@ extern "C" zk_status zk_ctx_set_key_tables(zk_ctx* c, uint32_t on) {
 }
 extern "C" zk_status zk_ctx_set_ring_fold(zk_ctx* c, uint32_t matrix_pipe) {
     if (!c) return ZK_E_ARG;
+    if (c->stream_busy) return busy_refusal(c);
     c->gk_mfma = matrix_pipe != 0;
     return ZK_OK;
 }
 extern "C" zk_status zk_ctx_set_mode(zk_ctx* c, uint32_t mode) {
     if (!c || (mode != ZK_MODE_REFERENCE && mode != ZK_MODE_HARDENED)) return ZK_E_ARG;
+    if (c->stream_busy) return busy_refusal(c);
     c->mode = mode;
     return ZK_OK;
 }
@@ -339,16 +357,19 @@ extern "C" zk_status zk_ring_digest(zk_ctx* c, uint8_t digest[32]) {
 }
 extern "C" zk_status zk_ctx_set_slice(zk_ctx* c, uint32_t proofs) {
     if (!c || (proofs && proofs < 64)) return ZK_E_ARG;
+    if (c->stream_busy) return busy_refusal(c);
     c->slice = proofs;
     return ZK_OK;
 }
 extern "C" zk_status zk_ctx_set_host_taper(zk_ctx* c, uint32_t on) {
     if (!c) return ZK_E_ARG;
+    if (c->stream_busy) return busy_refusal(c);
     c->host_taper = on > 64 ? 64 : on;   // 0 = uniform chunks, 1 = as many rising first chunks as lanes, n >= 2 = n of them
     return ZK_OK;
 }
 extern "C" zk_status zk_ctx_set_lanes(zk_ctx* c, uint32_t lanes) {
     if (!c || lanes < 1 || lanes > ZK_MAX_LANES) return ZK_E_ARG;
+    if (c->stream_busy) return busy_refusal(c);
     c->lanes = lanes;
     return ZK_OK;
 }

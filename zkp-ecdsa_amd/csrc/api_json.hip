@@ -792,8 +792,17 @@ static uint32_t json_threads(uint32_t want, uint64_t n) {
 template <class F>
 static void run_threads(uint32_t T, F f) {
     if (T <= 1) return f(0);
+    // std::thread's constructor throws std::system_error when the process may not start another thread (pid / cgroup limits): a
+    // joinable thread destroyed by the unwinding would terminate the process before the entry point's catch (...) could answer, so the
+    // threads already running are kept and the parts that got no thread run here
     std::vector<std::thread> th;
-    for (uint32_t t = 0; t < T; t++) th.emplace_back(f, t);
+    th.reserve(T);
+    uint32_t started = 0;
+    try {
+        for (; started < T; started++) th.emplace_back(f, started);
+    } catch (...) {
+    }
+    for (uint32_t t = started; t < T; t++) f(t);
     for (auto& x : th) x.join();
 }
 // `conv(i, scratch)` converts item i into scratch (resized by it) and returns its status; items are placed back to back in out.

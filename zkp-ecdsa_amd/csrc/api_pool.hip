@@ -71,6 +71,7 @@ struct zk_pool {
     std::vector<int> numa;                // -1 = unknown
     bool affinity = true;                 // ZKATTEST_POOL_AFFINITY=0 switches it off
     std::vector<float> shard_ms;          // wall time of every shard's part of the last pool call (zk_pool_shard_ms)
+    int test_fail_slot = -1;              // zk_pool_test_fail_submit: the next streamed submit fails at this device slot (one shot)
 };
 
 // "0-15,128-143" -> cpu numbers (the format of sysfs cpulist files)
@@ -145,12 +146,18 @@ static zk_status pool_each(zk_pool* p, F f) {
     if (G == 1) {
         timed(0);
     } else {
-        std::vector<std::thread> th;
-        for (int i = 0; i < G; i++)
-            th.emplace_back([&, i] {
-                if (p->affinity && i < (int)p->cpus.size()) bind_thread_to(p->cpus[i]);
-                timed(i);
-            });
+        std::vector<std::thread> th;   // a shard that gets no thread (std::system_error: thread limits) runs on the caller's: see run_threads, api_json.hip
+        th.reserve(G);
+        int started = 0;
+        try {
+            for (; started < G; started++)
+                th.emplace_back([&, i = started] {
+                    if (p->affinity && i < (int)p->cpus.size()) bind_thread_to(p->cpus[i]);
+                    timed(i);
+                });
+        } catch (...) {
+        }
+        for (int i = started; i < G; i++) timed(i);
         for (auto& t : th) t.join();
     }
     for (int i = 0; i < G; i++)
@@ -205,6 +212,11 @@ extern "C" void zk_pool_destroy(zk_pool* p) {
     for (auto c : p->ctx) zk_ctx_destroy(c);
     delete p;
 }
+// unit-test hook: the next zk_pool_prove_submit / zk_pool_verify_submit fails at device slot `slot` with ZK_E_DEVICE after the earlier
+// slots were submitted (tests/test_gpu_stream.py: the abandon path with older pool jobs in flight)
+extern "C" void zk_pool_test_fail_submit(zk_pool* p, int slot) {
+    if (p) p->test_fail_slot = slot;
+}
 extern "C" int zk_pool_size(const zk_pool* p) { return p ? (int)p->ctx.size() : 0; }
 extern "C" zk_ctx* zk_pool_ctx(zk_pool* p, int i) { return p && i >= 0 && i < (int)p->ctx.size() ? p->ctx[i] : nullptr; }
 extern "C" const char* zk_pool_last_error(const zk_pool* p) { return p ? p->err.c_str() : g_pool_create_err.c_str(); }
@@ -250,11 +262,17 @@ extern "C" void* zk_pool_host_alloc(zk_pool* p, size_t bytes) {
         touch(0, len);
     } else {   // also for a single device: the pages belong on ITS node, wherever the calling thread happens to run
         std::vector<std::thread> th;
-        for (size_t i = 0; i < G; i++)
-            th.emplace_back([&, i] {
-                bind_thread_to(p->cpus[i]);
-                touch(i * region, i + 1 == G ? len : (i + 1) * region);
-            });
+        th.reserve(G);
+        size_t started = 0;
+        try {
+            for (; started < G; started++)
+                th.emplace_back([&, i = started] {
+                    bind_thread_to(p->cpus[i]);
+                    touch(i * region, i + 1 == G ? len : (i + 1) * region);
+                });
+        } catch (...) {
+        }
+        for (size_t i = started; i < G; i++) touch(i * region, i + 1 == G ? len : (i + 1) * region);   // placement by policy only
         for (auto& t : th) t.join();
     }
     if (hipHostRegister(mem, len, hipHostRegisterPortable) != hipSuccess) {
@@ -421,9 +439,12 @@ struct zk_pool_job {
     uint64_t region = 0;
     uint64_t *out_off = nullptr, *out_len = nullptr;   // prove: where the caller wants (offset, length) per proof
 };
-static void pool_job_abandon(zk_pool* p, zk_pool_job* j) {   // a submit that failed half way: the shards already queued are waited for
+zk_status stream_cancel_job(zk_ctx* c, zk_job* j);   // api_stream.hip
+// a submit that failed half way: the shards already queued are taken out again.  Earlier pool jobs may still be in flight on those
+// contexts, so this is NOT a wait (waits go in submission order; see stream_cancel_job).
+static void pool_job_abandon(zk_pool* p, zk_pool_job* j) {
     for (size_t i = 0; i < j->shard.size(); i++)
-        if (j->shard[i]) (void)(j->kind ? zk_verify_wait(p->ctx[i], j->shard[i]) : zk_prove_wait(p->ctx[i], j->shard[i]));
+        if (j->shard[i]) (void)stream_cancel_job(p->ctx[i], j->shard[i]);
     delete j;
 }
 extern "C" zk_status zk_pool_prove_submit(zk_pool* p, uint64_t B, const uint8_t* msg, const uint8_t* sig, const uint8_t* pk, const uint32_t* which, const zk_rng* rng,
@@ -440,9 +461,11 @@ extern "C" zk_status zk_pool_prove_submit(zk_pool* p, uint64_t B, const uint8_t*
         zk_rng r = *rng;
         r.data = rng->data + (rng->mode == ZK_RNG_SEED ? 32 * first : 32 * first * rng->stride_blocks);
         j->off[i].assign(cnt + 1, 0);
-        zk_status zs = zk_prove_submit(p->ctx[i], cnt, msg + 32 * first, sig + 64 * first, pk + 64 * first, which + first, &r, out + j->region * i, j->region,
-                                       j->off[i].data(), status + first, &j->shard[i]);
+        zk_status zs = (int)i == p->test_fail_slot ? (zk_status)ZK_E_DEVICE
+                                                   : zk_prove_submit(p->ctx[i], cnt, msg + 32 * first, sig + 64 * first, pk + 64 * first, which + first, &r,
+                                                                     out + j->region * i, j->region, j->off[i].data(), status + first, &j->shard[i]);
         if (zs) {
+            if ((int)i == p->test_fail_slot) p->test_fail_slot = -1, p->ctx[i]->err = "(injected by zk_pool_test_fail_submit)";
             p->err = std::string("device slot ") + std::to_string(i) + ": " + zk_strerror(zs) + " " + zk_last_error(p->ctx[i]);
             pool_job_abandon(p, j);
             return zs;
@@ -485,7 +508,8 @@ extern "C" zk_status zk_pool_verify_submit(zk_pool* p, uint64_t B, const uint8_t
             if (proof_off[first + k] - base != off[k]) zs = ZK_E_ARG;   // a gap or an overlap inside the shard
             off[k + 1] = off[k] + proof_len[first + k];
         }
-        if (!zs) zs = zk_verify_submit(p->ctx[i], cnt, msg + 32 * first, proofs + base, off.data(), vseeds ? vseeds + 32 * first : nullptr, ok + first, status + first, &j->shard[i]);
+        if (!zs && (int)i == p->test_fail_slot) zs = ZK_E_DEVICE, p->test_fail_slot = -1, p->ctx[i]->err = "(injected by zk_pool_test_fail_submit)";
+        else if (!zs) zs = zk_verify_submit(p->ctx[i], cnt, msg + 32 * first, proofs + base, off.data(), vseeds ? vseeds + 32 * first : nullptr, ok + first, status + first, &j->shard[i]);
         if (zs) {
             p->err = std::string("device slot ") + std::to_string(i) + ": " + zk_strerror(zs) + " " + zk_last_error(p->ctx[i]);
             pool_job_abandon(p, j);

@@ -33,6 +33,7 @@ struct zk_job {
     // results: where they sit in d_in / h_pin and where the caller wants them
     size_t res_a_off = 0, res_a_bytes = 0, res_b_off = 0, res_b_bytes = 0;
     void *user_a = nullptr, *user_b = nullptr;
+    uint32_t nl = 1;                      // lanes the job was planned over (c->lanes at submit time; frozen while jobs are queued)
     bool all_enqueued = false, finisher_enqueued = false;
     zk_status result = ZK_OK;
     std::string err;
@@ -151,7 +152,8 @@ static zk_status job_events(zk_job* j) {
     zk_ctx* c = j->c;
     HIPCHK(c, hipEventCreateWithFlags(&j->inputs_ready, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&j->done, hipEventDisableTiming));
-    for (uint32_t l = 0; l < c->lanes; l++) {
+    j->nl = c->lanes;
+    for (uint32_t l = 0; l < j->nl; l++) {
         HIPCHK(c, hipEventCreateWithFlags(&j->lane_ev[l], hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&j->copy_ev[l], hipEventDisableTiming));
     }
@@ -161,7 +163,7 @@ static zk_status job_events(zk_job* j) {
 static zk_status enqueue_finisher(zk_job* j) {
     zk_ctx* c = j->c;
     j->finisher_enqueued = true;
-    for (uint32_t l = 0; l < c->lanes; l++) {
+    for (uint32_t l = 0; l < j->nl; l++) {
         HIPCHK(c, hipEventRecord(j->lane_ev[l], c->pl[l].stream));
         HIPCHK(c, hipStreamWaitEvent(c->fin_stream, j->lane_ev[l], 0));
         HIPCHK(c, hipEventRecord(j->copy_ev[l], c->pl[l].copy_stream));
@@ -231,7 +233,7 @@ static void dbg_flush() {
     g_dbg.recs.clear();
 }
 static void drive(zk_ctx* c, zk_job* upto, uint32_t ahead) {
-    const uint32_t NL = c->lanes;
+    const uint32_t NL = upto->nl;   // the lanes the queued jobs were planned over, not whatever c->lanes says now
     bool past = false;
     for (size_t ji = 0; ji < c->jobs.size(); ji++) {
         zk_job* J = c->jobs[ji];
@@ -276,18 +278,18 @@ static zk_status wait_common(zk_ctx* c, zk_job* j) {
     }
     HIPCHK(c, hipSetDevice(c->device));
     if (g_dbg.on) fprintf(stderr, "host %8.1f ms: wait begins\n", g_dbg.ms());
-    drive(c, j, c->lanes - 1 ? c->lanes - 1 : 0);
+    drive(c, j, j->nl - 1);
     if (g_dbg.on) fprintf(stderr, "host %8.1f ms: wait blocks on the job's completion\n", g_dbg.ms());
     hipError_t e = j->finisher_enqueued ? hipEventSynchronize(j->done) : hipSuccess;
     if (g_dbg.on) {
         fprintf(stderr, "host %8.1f ms: job complete\n", g_dbg.ms());
         if (c->jobs.size() == 1) {
-            for (uint32_t l = 0; l < c->lanes; l++) hipStreamSynchronize(c->pl[l].stream), hipStreamSynchronize(c->pl[l].copy_stream);
+            for (uint32_t l = 0; l < j->nl; l++) hipStreamSynchronize(c->pl[l].stream), hipStreamSynchronize(c->pl[l].copy_stream);
             dbg_flush();
         }
     }
     if (j->result != ZK_OK || e != hipSuccess) {   // leave nothing of this job running: its buffers go back to the pool
-        for (uint32_t l = 0; l < c->lanes; l++) hipStreamSynchronize(c->pl[l].stream), hipStreamSynchronize(c->pl[l].copy_stream);
+        for (uint32_t l = 0; l < j->nl; l++) hipStreamSynchronize(c->pl[l].stream), hipStreamSynchronize(c->pl[l].copy_stream);
         hipStreamSynchronize(c->fin_stream), hipStreamSynchronize(c->copy_stream);
     }
     zk_status zs = j->result;
@@ -304,6 +306,33 @@ static zk_status wait_common(zk_ctx* c, zk_job* j) {
     unlink_job(c, j);
     job_free(j);
     return zs;
+}
+
+// A job its submitter gives up without waiting for it (zk_pool_*_submit: a later device's submit failed, the shards already queued must
+// not stay behind).  Two cases cover every caller: the job heads the queue -- stage 1 of its first chunks may already be out, so it simply
+// runs to completion here and its results are dropped --, or it is the LAST job behind older ones that are still in flight: submit only
+// staged its inputs (nothing of its stages is enqueued before the queue reaches it), so it is taken out again once those uploads are
+// through; the older jobs are untouched and stay waitable in their order.  wait_common on it would refuse ("submission order") and leave a
+// zombie whose result pointers dangle.
+zk_status stream_cancel_job(zk_ctx* c, zk_job* j) {
+    if (!c || !j || j->c != c || c->jobs.empty()) return ZK_E_ARG;
+    if (c->jobs[0] == j) {
+        j->res_a_bytes = j->res_b_bytes = 0;   // nobody wants the results
+        (void)wait_common(c, j);
+        return ZK_OK;
+    }
+    if (c->jobs.back() != j || j->next_s1() != 0) {
+        c->err = "only the head or the untouched tail of the queue can be cancelled";
+        return ZK_E_ARG;
+    }
+    (void)hipSetDevice(c->device);
+    if (j->inputs_ready) (void)hipEventSynchronize(j->inputs_ready);           // the pinned staging block goes back to the pool
+    if (j->kind == 1 && j->vj.host_src) (void)hipStreamSynchronize(c->copy_stream);   // the caller's proof bytes are no longer read
+    c->next_lane_base -= j->nchunks();
+    unlink_job(c, j);
+    if (!c->jobs.empty() && c->jobs.back()->kind == 0) c->jobs.back()->pj.more_follows = false;
+    job_free(j);
+    return ZK_OK;
 }
 
 extern "C" zk_status zk_prove_submit(zk_ctx* c, uint64_t B, const uint8_t* msg, const uint8_t* sig, const uint8_t* pk, const uint32_t* which, const zk_rng* rng,

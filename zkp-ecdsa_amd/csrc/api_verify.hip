@@ -162,7 +162,7 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
     {
         MaybeScope t(timed, c, "v_p256_exp_points", s);
         launch_v_exp_points(s, W, V, cnt, d_proofs, d_off, first);
-        launch_p256_normalize(s, W.Tproj, cnt * VK, W.Tx, W.Ty, W.st, VK, ZK_E_T_INF, nullptr);
+        launch_p256_normalize(s, W.Tproj, cnt * VK, W.Tx, W.Ty, W.st, VK, 0, nullptr);   // identities were given their status by k_v_exp_status
     }
     {
         MaybeScope t(timed, c, "v_tom_fixed", s);

@@ -30,7 +30,7 @@ struct zk_ctx {
     uint32_t* ring_mem = nullptr;
     uint32_t* gk_etab = nullptr;   // per-ring table of the GK block transform (k_gk.hip); nullptr for small / huge rings
     bool gk_table = true;          // ZKATTEST_GK_TABLE=0 disables it (plain fold for every ring)
-    uint32_t* ktab = nullptr;      // per-key tables of the ring (k_ktab.hip): 512 KB per key, rings of up to 2^KTAB_MAXN keys
+    uint32_t* ktab = nullptr;      // per-key tables of the ring (k_ktab.hip): 264 KB per key (KTAB_KEY_WORDS), rings of up to 2^KTAB_MAXN keys
     uint8_t* ktab_ok = nullptr;    // [N] which ring values are x-coordinates and own a table
     bool key_tables = true;        // ZKATTEST_KEYTAB=0 / zk_ctx_set_key_tables(ctx, 0): per-proof tables of R for every proof (read at zk_ctx_set_ring)
     int8_t* gk_kdig = nullptr;     // the ring as int8 digit fragments (k_gk_mfma.hip), built with table E for rings of >= 2^12 keys

@@ -78,7 +78,10 @@ __global__ void __launch_bounds__(64, 2) k_front(DevParams P, Workspace W, Chunk
     load_be32(in.sig + 64 * (size_t)p, rw);
     load_be32(in.sig + 64 * (size_t)p + 32, sw);
     int32_t status = ZK_OK;
-    if (in.which[p] >= W.N) status = ZK_E_ARG;  // values[index] must exist (gk.ts:167)
+    // values[index] must exist (gk.ts:162: `undefined.k` is a TypeError).  proveMembership runs last (zkpAttestList.ts:141-142), so an
+    // invalid key (below) and 'T[i] is at infinity' (k_front_walk, the normaliser) replace this status; indices in [n_keys, N) name the
+    // padding, i.e. keys[0] (gk.ts:75-86)
+    if (in.which[p] >= W.N) status = ZK_E_ARG;
     // deserializePoint (weier.ts:74-89): isOnGroup works mod p, coordinates are not range-checked
     Fe<ModQ, 1> pkx = fe_from_words256_reduce<ModQ>(xw), pky = fe_from_words256_reduce<ModQ>(yw);
     P256Aff pk;
@@ -182,7 +185,7 @@ __global__ void __launch_bounds__(64, 2) k_front_walk(Workspace W, uint32_t coun
     }
     // R affine (output + base of the per-proof table).  R = identity makes every T_i the identity: exp.ts:151.
     Fq2 rz = fe_reduce(R.z);
-    if (fe_is_zero(rz) && W.st[p] == ZK_OK) W.st[p] = ZK_E_T_INF;
+    if (fe_is_zero(rz) && (W.st[p] == ZK_OK || W.st[p] == ZK_E_ARG)) W.st[p] = ZK_E_T_INF;
     Fq2 zi = fe_inv<ModQ>(rz);
     Fq2 rx = R.x * zi, ry = R.y * zi;
     soa_st(W.Rxm, p, rx), soa_st(W.Rym, p, ry);
@@ -299,7 +302,7 @@ __global__ void __launch_bounds__(256) k_p256_normalize(Soa3 proj, uint32_t coun
         bool zero = fe_is_zero(z);
         if (zero) {
             uint32_t o = owner ? owner[e] : e / per_proof;
-            if (err_code) atomicCAS(&st[o], ZK_OK, err_code);
+            if (err_code && atomicCAS(&st[o], ZK_OK, err_code) == ZK_E_ARG) atomicCAS(&st[o], ZK_E_ARG, err_code);   // `which` out of range is found last in the reference
             z = fe_one_mont<ModQ>().as<2>();
         }
         soa_st(ox, e, acc);

@@ -74,24 +74,26 @@ __global__ void __launch_bounds__(256) k_v_header(VWork V, uint32_t count, const
     const uint8_t* pr = proofs + o0;
     int32_t st = ZK_OK;
     uint32_t bits[4] = {0, 0, 0, 0};
-    uint32_t z = 0;
-    V.okflags[p] = 0;
+    uint32_t z = 0, flags = 0;
     if (o1 < o0 + ZK_HDR || (o0 & 3)) st = ZK_E_BAD_ENCODING;
     else {
         const uint32_t* h = (const uint32_t*)pr;
         uint32_t total = bswap32(h[1]), sec = bswap32(h[2]), n = bswap32(h[3]);
         bits[0] = bswap32(h[7]), bits[1] = bswap32(h[6]), bits[2] = bswap32(h[5]), bits[3] = bswap32(h[4]);
-        if (h[0] != 0x31414b5au || total != o1 - o0) st = ZK_E_BAD_ENCODING;
-        else if (sec != V.sec) st = sec < VK ? ZK_E_SECLEVEL : ZK_E_BAD_ENCODING;  // exp.ts:243-245 / params mismatch
+        // ZKA1 is this engine's format: a batch is homogeneous in secLevel (the reference would verify a proof of another length with
+        // that proof's own repetition count, exp.ts:243-260; include/zkattest.h documents the restriction)
+        if (h[0] != 0x31414b5au || total != o1 - o0 || sec != V.sec || n > 63) st = ZK_E_BAD_ENCODING;
         else {
             for (uint32_t b = V.sec; b < 128; b++)
-                if ((bits[b >> 5] >> (b & 31)) & 1) st = ZK_E_BAD_ENCODING;
+                if ((bits[b >> 5] >> (b & 31)) & 1) st = ZK_E_BAD_ENCODING;   // unused challenge bits are zero
             z = zeros_below(bits, V.sec);
-            // a GKProof of the wrong length is "return false" in the reference (gk.ts:208-218), not an exception
-            if (n != V.n) V.okflags[p] |= 8;
-            else if (total != v_proof_size(V.sec, V.n, z)) st = ZK_E_BAD_ENCODING;
+            if (total != v_proof_size(V.sec, n, z)) st = ZK_E_BAD_ENCODING;   // the structure the header announces, with ITS n
+            // a GKProof of the wrong length is "return false" in the reference (gk.ts:208-218), not an exception -- but the proof was
+            // deserialised first, so every one of its points, the 4 n' membership commitments included, must still be a point
+            else if (n != V.n) flags = 8 | (n << 16);
         }
     }
+    V.okflags[p] = flags;
     V.st[p] = st;
     V.zcnt[p] = z;
 #pragma unroll
@@ -101,24 +103,35 @@ __global__ void __launch_bounds__(256) k_v_header(VWork V, uint32_t count, const
 // first (R, comS1, A_i), then the Tom-256 slots (keyXcom, keyYcom, 4n GK points and per repetition Tx, Ty + the 32
 // PointAdd points, which exist only for zero bits): consecutive lanes check consecutive strings of one kind, every lane
 // does the same amount of work and the branchy part only selects an ADDRESS (one copy of each curve check per wave).
+// A proof whose GKProof has another length n' than the ring's (okflags bit 3; never produced by an honest prover) keeps its
+// slots for everything else and has its 4 n' membership commitments walked by the thread of its keyXcom slot.
 #define V_REP_TOM_SLOTS 34
 __global__ void __launch_bounds__(256) k_v_validate(VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
     const uint32_t np = 2 + V.sec, nt = 2 + 4 * V.n + V_REP_TOM_SLOTS * V.sec, per = np + nt;
     uint32_t blocks_per_proof = (per + 255) / 256;           // a workgroup never straddles two proofs
     uint32_t p = blockIdx.x / blocks_per_proof, m = (blockIdx.x % blocks_per_proof) * 256 + threadIdx.x;
     if (p >= count || m >= per) return;
-    if (V.st[p] != ZK_OK || (V.okflags[p] & 8)) return;
+    if (V.st[p] != ZK_OK) return;
+    const uint32_t other_n = V.okflags[p] & 8 ? V.okflags[p] >> 16 : 0xffffffffu;
     const uint8_t* pr = proofs + off[first + p];
     const uint32_t* hb = V.hbits + 4 * p;
     const uint8_t* ptr;
     const bool is_p = m < np;
+    bool ok = true;
     if (is_p) {
         ptr = m < 2 ? pr + 32 + 64 * m : pr + rep_offset(hb, m - 2);
     } else {
         uint32_t u = m - np;
-        if (u < 2) ptr = pr + 160 + 72 * u;
-        else if (u < 2 + 4 * V.n) ptr = v_gk_base(V, pr, p) + 72 * (u - 2);
-        else {
+        if (u < 2) {
+            ptr = pr + 160 + 72 * u;
+            if (u == 0 && other_n != 0xffffffffu) {
+                const uint8_t* gk = v_gk_base(V, pr, p);
+                for (uint32_t k = 0; k < 4 * other_n; k++) ok = ok && tom_bytes_valid(gk + 72 * k);
+            }
+        } else if (u < 2 + 4 * V.n) {
+            if (other_n != 0xffffffffu) return;
+            ptr = v_gk_base(V, pr, p) + 72 * (u - 2);
+        } else {
             uint32_t r = u - (2 + 4 * V.n), j = r / V_REP_TOM_SLOTS, k = r % V_REP_TOM_SLOTS;
             bool one = (hb[j >> 5] >> (j & 31)) & 1;
             if (k >= 2 && one) return;  // response1 has no PointAdd proof
@@ -130,7 +143,7 @@ __global__ void __launch_bounds__(256) k_v_validate(VWork V, uint32_t count, con
             else ptr = rep + ZK_REP_HEAD + (q < 30 ? 2912 : 3152) + 72 * (q & 1);
         }
     }
-    bool ok = is_p ? p256_bytes_valid(ptr) : tom_bytes_valid(ptr);
+    ok = ok && (is_p ? p256_bytes_valid(ptr) : tom_bytes_valid(ptr));
     if (!ok) atomicCAS(&V.st[p], ZK_OK, ZK_E_BAD_ENCODING);
 }
 
@@ -357,15 +370,19 @@ __global__ void __launch_bounds__(64) k_v_sample(VWork V, uint32_t count, const 
     }
     const uint32_t* c = V.chal + 4 * p;
     const uint32_t* hb = V.hbits + 4 * p;
-    int32_t st = ZK_OK;
+    // verifyExp walks the sampled repetitions in order and throws at the FIRST one that fails (exp.ts:265-346): 'params not found' where
+    // the response's type does not match the recomputed challenge bit (exp.ts:269-271,301-303), 'T is at infinity' / 'T1 is at infinity'
+    // (exp.ts:274,312) where the point is the identity.  jm = first slot whose type mismatches; the slots before it still get their
+    // point computed, and k_v_exp_status picks the earliest exception.
+    uint32_t jm = VK;
     for (uint32_t j = 0; j < VK; j++) {
         uint32_t i = PERM(j);
         uint32_t bit = (c[i >> 5] >> (i & 31)) & 1, hbit = (hb[i >> 5] >> (i & 31)) & 1;
         V.idx[p * VK + j] = i | (bit << 8);
-        if (bit != hbit && st == ZK_OK) st = ZK_E_PARAMS_NOT_FOUND;  // exp.ts:269-271,301-303
+        if (bit != hbit && jm == VK) jm = j;
     }
-    if (st != ZK_OK) V.exp_st[p] = st;
-    else V.exp_st[p] = ZK_OK;
+    V.exp_st[p] = jm < VK ? ZK_E_PARAMS_NOT_FOUND : ZK_OK;
+    V.okflags[p] = (V.okflags[p] & 0xffff00ffu) | (jm << 8);
 }
 #undef PERM
 
@@ -377,7 +394,8 @@ __global__ void __launch_bounds__(256) k_v_exp_points(Workspace W, VWork V, uint
     uint32_t iv = V.idx[t], i = iv & 255, bit = iv >> 8;
     const uint8_t* pr = proofs + off[first + p];
     P256Pt acc = p256_identity();
-    bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8) && V.exp_st[p] == ZK_OK;
+    // every slot before the first type mismatch (all of them in an honest proof): an identity there is thrown before the mismatch is seen
+    bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8) && t % VK < ((V.okflags[p] >> 8) & 0xffu);
     if (good) {
         const uint8_t* rep = pr + rep_offset(V.hbits + 4 * p, i);
         Sn s = ld_scalar_n(rep + 208);
@@ -394,6 +412,20 @@ __global__ void __launch_bounds__(256) k_v_exp_points(Workspace W, VWork V, uint
     }
     uint32_t e = t;  // compact: p * VK + j
     soa_st(W.Tproj.x, e, acc.x), soa_st(W.Tproj.y, e, acc.y), soa_st(W.Tproj.z, e, acc.z);
+}
+// the exception verifyExp throws, if any: the first sampled slot, in order, with T = identity (bit 1, exp.ts:274), T1 = identity
+// (bit 0, exp.ts:312) or a response of the wrong type.  Runs between k_v_exp_points and the normaliser (which maps Z = 0 to (0, 0)).
+__global__ void __launch_bounds__(64) k_v_exp_status(Workspace W, VWork V, uint32_t count) {
+    uint32_t p = gtid();
+    if (p >= count) return;
+    if (V.st[p] != ZK_OK || (V.okflags[p] & 8)) return;
+    const uint32_t jm = (V.okflags[p] >> 8) & 0xffu;
+    int32_t st = jm < VK ? ZK_E_PARAMS_NOT_FOUND : ZK_OK;
+    for (int j = (int)(jm < VK ? jm : VK) - 1; j >= 0; j--) {
+        const uint32_t e = p * VK + j;
+        if (fe_is_zero(fe_reduce(soa_ld<ModQ, 8>(W.Tproj.z, e)))) st = (V.idx[e] >> 8) ? ZK_E_T_INF : ZK_E_T1_INF;
+    }
+    V.exp_st[p] = st;
 }
 // T1x = sx*g + r1*h, T1y = sy*g + r2*h for zero-bit slots (exp.ts:329-330); (0, 0) otherwise
 __global__ void __launch_bounds__(256) k_v_t1_scalars(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
@@ -1286,6 +1318,7 @@ void launch_v_challenges_sample(hipStream_t s, const VWork& V, uint32_t count, c
 }
 void launch_v_exp_points(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
     L1(k_v_exp_points, count * VK, 256, W, V, count, proofs, off, first);
+    L1(k_v_exp_status, count, 64, W, V, count);
 }
 void launch_v_t1_scalars(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
     L1(k_v_t1_scalars, count * VK, 256, W, V, count, proofs, off, first);
