@@ -170,7 +170,8 @@ void zk_host_free(void *p);
 /* Replaces B calls of proveSignatureList(params, msgHash, sigBytes, publicKey, which, keys)
  * (src/zkpAttestList.ts:104-145).  pk_xy is the WebCrypto 'raw' export without its 0x04 prefix.
  * out receives the proofs back to back; out_off[b]..out_off[b+1] delimits proof b (empty when
- * per_proof_status[b] != 0).  Host pointers; `out` from zk_host_alloc is filled by overlapped DMA. */
+ * per_proof_status[b] != 0).  Host pointers; `out` from zk_host_alloc is filled by overlapped DMA.  `out` may also be memory of
+ * this context's GPU (hipMalloc): the proofs then stay in HBM and only the inputs cross the link. */
 zk_status zk_prove_batch(zk_ctx *ctx, uint64_t B, const uint8_t *msg_hash /*Bx32*/, const uint8_t *sig /*Bx64*/,
                          const uint8_t *pk_xy /*Bx64*/, const uint32_t *which /*B*/, const zk_rng *rng,
                          uint8_t *out, uint64_t out_cap, uint64_t *out_off /*B+1*/, int32_t *per_proof_status /*B*/);
@@ -249,7 +250,8 @@ zk_status zk_pool_create(const int *device_ids, int n_dev, zk_pool **out);   /* 
 void zk_pool_destroy(zk_pool *pool);
 int zk_pool_size(const zk_pool *pool);
 zk_ctx *zk_pool_ctx(zk_pool *pool, int i);
-const char *zk_pool_last_error(const zk_pool *pool);                        /* pool = NULL: why this thread's last zk_pool_create failed */
+const char *zk_pool_last_error(const zk_pool *pool);                        /* pool = NULL: why this thread's last zk_pool_create failed;
+                                                                             * after a zk_pool_set_ring whose transport is not "rccl": why RCCL was not used */
 /* Host side of a shard.  Every shard of a pool call runs on its own host thread, bound to the CPUs next to its device (sysfs
  * local_cpulist of the device's PCI address; ZKATTEST_POOL_AFFINITY=0 switches the binding off).  zk_pool_host_alloc returns a
  * page-locked buffer for `out` of zk_pool_prove_batch / `proofs` of zk_pool_verify_batch whose per-shard regions
@@ -271,6 +273,16 @@ zk_status zk_pool_set_ring(zk_pool *pool, const uint8_t *keys_be32, uint64_t n_k
 zk_status zk_pool_prove_batch(zk_pool *pool, uint64_t B, const uint8_t *msg_hash, const uint8_t *sig, const uint8_t *pk_xy, const uint32_t *which,
                               const zk_rng *rng, uint8_t *out, uint64_t out_cap, uint64_t *out_off /*B*/, uint64_t *out_len /*B*/,
                               int32_t *per_proof_status /*B*/);
+/* The same with the proofs left in HBM: shard i writes its proofs back to back from d_out[i], a buffer of out_cap[i] bytes on
+ * device_ids[i] (zk_pool_device_alloc / zk_pool_device_free); out_off[b] is relative to the proof's own shard buffer.  Only the 160 bytes of
+ * inputs per proof cross PCIe: through this entry point a multi-GPU run measures the GPUs and their host threads without the node's host
+ * memory (eight shards of zk_pool_prove_batch emit ~55 GB/s of page-locked writes each).  zk_prove_batch accepts a
+ * device-resident `out` the same way for one context. */
+zk_status zk_pool_prove_batch_device(zk_pool *pool, uint64_t B, const uint8_t *msg_hash, const uint8_t *sig, const uint8_t *pk_xy, const uint32_t *which,
+                                     const zk_rng *rng, void *const *d_out /*G*/, const uint64_t *out_cap /*G*/, uint64_t *out_off /*B*/, uint64_t *out_len /*B*/,
+                                     int32_t *per_proof_status /*B*/);
+void *zk_pool_device_alloc(zk_pool *pool, int i, size_t bytes);   /* hipMalloc on device_ids[i]; the calling thread's current device is kept */
+void zk_pool_device_free(zk_pool *pool, int i, void *p);
 /* zk_verify_batch over all devices.  Inside every shard the proofs must lie back to back in index order (true for the output
  * of zk_pool_prove_batch and for any fully packed buffer), every shard starting 4-byte aligned; ZK_E_ARG otherwise. */
 zk_status zk_pool_verify_batch(zk_pool *pool, uint64_t B, const uint8_t *msg_hash, const uint8_t *proofs, const uint64_t *proof_off /*B*/,

@@ -197,6 +197,61 @@ def test_baseline_config5_full_per_gpu_shard_131072_proofs_over_ring_2_20():
     assert line['value'] > 0
 
 
+def test_the_references_own_bench_ring_of_100001_keys_runs_on_the_key_tables():
+    """bench/zkpAttestList.bench.ts:38-68 proves over 1 + 100 000 keys (padded to 2^17).  bench.py --ring 100001: the per-key tables cover
+    that ring too (35 GB at 2^17 keys; they stopped at 2^16 until round 4), every proof of the CPU sample is diffed byte for byte against
+    the oracle inside bench.py, every proof verifies, and the line carries the small-batch latency table."""
+    line = _bench(['--ring', '100001', '--batch', '8192', '--chunk', '4096', '--lanes', '2', '--verify-chunk', '4096', '--steps', '1', '--warmup', '1',
+                   '--cpu-sample', '8', '--host-io', '0', '--json-sample', '0'], timeout=1500)
+    assert 'ring=100001 keys (n=17)' in line['config']['workload'] and 'per-key tables' in line['config']['workload']
+    assert line['key_table_proofs_last_chunk'] == 4096          # zk_test_counter(ctx, 1): every proof of the last chunk went through them
+    assert line['failed_proofs'] == 0 and line['cpu_baseline']['checked_bit_exact'] == 8
+    assert line['verify']['accepted'] == line['verify']['of'] == 8192
+    lat = line['latency']['rings']
+    assert set(lat) == {'100001', '1024'} and set(lat['1024']) == {'1', '8', '64', '512', '4096'}
+    assert line['latency_ms_b1'] == lat['100001']['1']['prove_ms'] > 0
+
+
+def test_pool_prove_with_device_resident_output_equals_the_host_buffer_call():
+    """zk_pool_prove_batch_device (and zk_prove_batch with `out` in HBM): the proofs stay on each shard's device; copied back by hand they are
+    the bytes zk_pool_prove_batch delivers."""
+    import torch
+    import zkp_ecdsa_amd as Z
+    B, nkeys = 700, 1024
+    pool = Z.Pool([0, 0])
+    e0 = pool.engine(0)
+    for i in range(2):
+        pool.engine(i).set_comb_bits(16)
+        pool.engine(i).set_chunk(256)
+    pool.set_params(*e0.synth_params(93), 80)
+    ring, msg, sig, pk, which, seeds = e0.synth_workload(93, nkeys, B)
+    pool.set_ring(ring, nkeys)
+    ref, st = pool.prove_batch(msg, sig, pk, which, seeds)
+    assert not any(st)
+    cap = e0.proof_max_size() * 350 * 7 // 10 + (4 << 20)
+    t = [torch.zeros(cap, dtype=torch.uint8, device='cuda:0') for _ in range(2)]
+    torch.cuda.synchronize()
+    _, off, ln, st = pool.prove_batch_device_out(msg, sig, pk, which, seeds, [x.data_ptr() for x in t], [cap, cap])
+    assert not any(st)
+    for i in range(2):
+        first, cnt = pool.shard(B, i)
+        raw = t[i].cpu().numpy().tobytes()
+        assert off[first] == 0                                  # offsets are relative to the shard's own buffer
+        for k in range(first, first + cnt):
+            assert raw[off[k]:off[k] + ln[k]] == ref[k], (i, k)
+    # the pool's own allocator for such buffers
+    d = [pool.device_alloc(i, cap) for i in range(2)]
+    _, off2, ln2, st2 = pool.prove_batch_device_out(msg, sig, pk, which, seeds, d, [cap, cap])
+    assert list(off2) == list(off) and list(ln2) == list(ln) and not any(st2)
+    for i in range(2):
+        pool.device_free(i, d[i])
+    # a buffer that is too small fails that call, not the process
+    with pytest.raises(Z.ZkError) as e:
+        pool.prove_batch_device_out(msg, sig, pk, which, seeds, [x.data_ptr() for x in t], [cap, 4096])
+    assert e.value.status == 12
+    pool.close()
+
+
 def test_bench_pool_mode_runs_the_librarys_own_multi_gpu_path():
     """bench.py --pool: one process, zk_pool over the listed devices (two contexts on device 0 here; the visible devices on a
     multi-GPU box), page-locked NUMA-placed buffers, ring transport reported, every proof verified, forgeries rejected, shard 0

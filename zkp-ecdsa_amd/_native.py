@@ -17,7 +17,7 @@ SYMBOLS = [
     'zk_proof_to_json', 'zk_proof_from_json', 'zk_host_alloc', 'zk_host_free', 'zk_ctx_set_host_taper', 'zk_ctx_set_slice', 'zk_ctx_set_mode', 'zk_ring_digest', 'zk_hardened_h',
     'zk_pool_create', 'zk_pool_destroy', 'zk_pool_size', 'zk_pool_ctx', 'zk_pool_last_error', 'zk_pool_ring_transport', 'zk_pool_shard',
     'zk_pool_set_params', 'zk_pool_set_ring', 'zk_pool_prove_batch', 'zk_pool_verify_batch',
-    'zk_pool_host_alloc', 'zk_pool_host_free', 'zk_pool_numa_node', 'zk_pool_test_locality', 'zk_pool_shard_ms', 'zk_pool_test_fail_submit',
+    'zk_pool_host_alloc', 'zk_pool_host_free', 'zk_pool_numa_node', 'zk_pool_test_locality', 'zk_pool_shard_ms', 'zk_pool_test_fail_submit', 'zk_pool_prove_batch_device', 'zk_pool_device_alloc', 'zk_pool_device_free',
     'zk_prove_submit', 'zk_prove_submit_device', 'zk_prove_wait', 'zk_verify_submit', 'zk_verify_wait', 'zk_test_counter', 'zk_ctx_set_key_tables',
     'zk_proofs_to_json_batch', 'zk_proofs_from_json_batch', 'zk_ctx_set_ring_fold',
     'zk_pool_prove_submit', 'zk_pool_prove_wait', 'zk_pool_verify_submit', 'zk_pool_verify_wait', 'zk_ctx_set_verify_groups',
@@ -121,6 +121,11 @@ def lib():
         L.zk_pool_prove_wait.argtypes = [vp, vp]
         L.zk_pool_verify_submit.argtypes = [vp, u64, C.c_char_p, vp, vp, vp, C.c_char_p, vp, vp, C.POINTER(vp)]
         L.zk_pool_verify_wait.argtypes = [vp, vp]
+        L.zk_pool_prove_batch_device.argtypes = [vp, u64, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(ZkRng), vp, vp, vp, vp, vp]
+        L.zk_pool_device_alloc.argtypes = [vp, i32, C.c_size_t]
+        L.zk_pool_device_alloc.restype = vp
+        L.zk_pool_device_free.argtypes = [vp, i32, vp]
+        L.zk_pool_device_free.restype = None
         L.zk_pool_test_fail_submit.argtypes = [vp, i32]
         L.zk_pool_test_fail_submit.restype = None
         L.zk_pool_host_alloc.argtypes = [vp, C.c_size_t]
@@ -592,6 +597,30 @@ class Pool:
         t0 = time.time()
         self._chk(self.L.zk_pool_prove_batch(self.h, B, msg, sig, pk, w, C.byref(rng), optr, cap, off, ln, st))
         return time.time() - t0, off, ln, st
+
+    def prove_batch_device_out(self, msg, sig, pk, which, seeds, d_out, caps):
+        """zk_pool_prove_batch_device: d_out = per-device buffers from device_alloc.  Returns (seconds, off, len, status)."""
+        import time
+        B = len(which)
+        off, ln, st = (C.c_uint64 * B)(), (C.c_uint64 * B)(), (C.c_int32 * B)()
+        w = (C.c_uint32 * B)(*which)
+        data = C.create_string_buffer(bytes(seeds), 32 * B)
+        rng = ZkRng(0, C.cast(data, C.c_void_p), 0)
+        ptrs = (C.c_void_p * self.n)(*d_out)
+        cp = (C.c_uint64 * self.n)(*caps)
+        msg, sig, pk = bytes(msg), bytes(sig), bytes(pk)
+        t0 = time.time()
+        self._chk(self.L.zk_pool_prove_batch_device(self.h, B, msg, sig, pk, w, C.byref(rng), ptrs, cp, off, ln, st))
+        return time.time() - t0, off, ln, st
+
+    def device_alloc(self, i, nbytes):
+        p = self.L.zk_pool_device_alloc(self.h, i, nbytes)
+        if not p:
+            raise MemoryError('zk_pool_device_alloc(%d, %d) failed' % (i, nbytes))
+        return p
+
+    def device_free(self, i, p):
+        self.L.zk_pool_device_free(self.h, i, p)
 
     # ---- streamed pool calls: tickets keep every buffer of the job alive until its wait
     def prove_submit(self, msg, sig, pk, which, seeds, out, cap):

@@ -49,7 +49,13 @@ extern "C" const char* zk_last_error(const zk_ctx* c) { return c ? c->err.c_str(
 // when it is loaded before the HIP runtime starts (it cannot change a runtime that is already up: a host that initialises HIP
 // first -- bench.py imports torch -- exports GPU_MAX_HW_QUEUES itself), and (2) a context creates all its streams in one go, in
 // an order that gives the first two lanes and their copy streams four different queues even with the default of 4.
-__attribute__((constructor)) static void zk_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// ZKATTEST_NO_ENV=1 (any value but "0") keeps the library from touching the process environment at load: the host then exports
+// GPU_MAX_HW_QUEUES=8 itself, or lives with lanes that share hardware queues.  An existing value is never overwritten.
+__attribute__((constructor)) static void zk_more_hw_queues() {
+    const char* off = getenv("ZKATTEST_NO_ENV");
+    if (off && *off && strcmp(off, "0") != 0) return;
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
 
 static zk_status ctx_init(zk_ctx* c, int device_id);
 // *out is either a fully initialised context or NULL (then zk_last_error(NULL) has the reason): a caller never holds a half-built one
@@ -435,6 +441,19 @@ static size_t carve(zk_ctx* c, Workspace& W, Soa& gk_am, uint8_t* base, uint32_t
     W.ring = Soa{c->ring_mem, (uint32_t)N};
     return k.off + 256;
 }
+// hipMalloc for a workspace that gives up the OPTIONAL per-ring tables before it gives up itself: the per-key tables (35 GB at 2^17 keys)
+// are taken at zk_ctx_set_ring, before anybody knows how large the chunks will be; if a lane's arena no longer fits, the tables go and
+// every proof takes the per-proof tables of R -- slower, same bytes.
+hipError_t malloc_or_shed(zk_ctx* c, void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess || !c->ktab) return e;
+    (void)hipGetLastError();
+    (void)hipDeviceSynchronize();
+    hipFree(c->ktab), hipFree(c->ktab_ok);
+    c->ktab = nullptr, c->ktab_ok = nullptr;
+    for (auto& L : c->pl) L.W.ktab = nullptr, L.W.ktab_ok = nullptr;
+    return hipMalloc(p, bytes);
+}
 zk_status ensure_workspace(zk_ctx* c, uint32_t C, uint32_t nlanes) {
     uint32_t sec = c->P.sec, n = c->n;
     if (!(c->ws_C == C && c->ws_sec == sec && c->ws_n == n)) {
@@ -448,7 +467,7 @@ zk_status ensure_workspace(zk_ctx* c, uint32_t C, uint32_t nlanes) {
             if (need > L.arena_bytes) {
                 if (L.arena) HIPCHK(c, hipFree(L.arena));
                 L.arena = nullptr, L.arena_bytes = 0;
-                HIPCHK(c, hipMalloc(&L.arena, need));
+                HIPCHK(c, malloc_or_shed(c, &L.arena, need));
                 L.arena_bytes = need;
             }
             carve(c, L.W, L.gk_am, (uint8_t*)L.arena, C, sec, n, c->N);
@@ -858,9 +877,21 @@ extern "C" zk_status zk_prove_batch(zk_ctx* c, uint64_t B, const uint8_t* msg, c
     if (zs) return zs;
     Carver k2((uint8_t*)c->in_buf);
     carve_in(k2, d_msg, d_sig, d_pk, d_which, d_rng, d_off, d_st);
-    zs = ensure_io_buf(c, cap_dev ? cap_dev : 32);  // proof bytes: the context's grow-only staging buffer
-    if (zs) return zs;
-    uint8_t* d_out = (uint8_t*)c->io_buf;
+    // `out` may itself lie in this GPU's HBM (hipMalloc'ed by the caller): the proofs are written there and never cross the link --
+    // host inputs, device-resident output (zk_pool_prove_batch_device is this, per shard)
+    bool out_on_device = false;
+    if (B) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, out) == hipSuccess) out_on_device = a.type == hipMemoryTypeDevice;
+        else (void)hipGetLastError();
+        if (out_on_device && a.device != c->device) {
+            c->err = "`out` lies on another device than this context's";
+            return ZK_E_ARG;
+        }
+    }
+    if (out_on_device) cap_dev = out_cap;
+    else if ((zs = ensure_io_buf(c, cap_dev ? cap_dev : 32))) return zs;  // proof bytes: the context's grow-only staging buffer
+    uint8_t* d_out = out_on_device ? out : (uint8_t*)c->io_buf;
     if (B) {
         HIPCHK(c, hipMemcpyAsync(d_msg, msg, 32 * B, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(d_sig, sig, 64 * B, hipMemcpyHostToDevice, c->stream));
@@ -870,7 +901,7 @@ extern "C" zk_status zk_prove_batch(zk_ctx* c, uint64_t B, const uint8_t* msg, c
         HIPCHK(c, hipStreamSynchronize(c->stream));   // both lanes read these arrays
     }
     // a page-locked `out` (zk_host_alloc) receives each chunk by DMA while the next chunks are proved
-    uint8_t* sink = B && host_ptr_is_pinned(out) ? out : nullptr;
+    uint8_t* sink = B && !out_on_device && host_ptr_is_pinned(out) ? out : nullptr;
     if (sink) {
         zs = ensure_copy_stream(c);
         if (zs) return zs;
@@ -879,7 +910,7 @@ extern "C" zk_status zk_prove_batch(zk_ctx* c, uint64_t B, const uint8_t* msg, c
     if (zs) return zs;
     HIPCHK(c, hipMemcpy(out_off, d_off, 8 * (B + 1), hipMemcpyDeviceToHost));
     if (B) HIPCHK(c, hipMemcpy(status, d_st, 4 * B, hipMemcpyDeviceToHost));
-    if (!sink && out_off[B]) HIPCHK(c, hipMemcpy(out, d_out, out_off[B], hipMemcpyDeviceToHost));
+    if (!sink && !out_on_device && out_off[B]) HIPCHK(c, hipMemcpy(out, d_out, out_off[B], hipMemcpyDeviceToHost));
     return ZK_OK;
 }
 

@@ -234,13 +234,42 @@ extern "C" int zk_pool_numa_node(const zk_pool* p, int i) { return p && i >= 0 &
 // locality is unknown.  Free with zk_pool_host_free (NOT zk_host_free).
 static std::mutex g_regs_mu;
 static std::map<void*, size_t> g_regs;
+// ZKATTEST_POOL_ALLOC (tools/exp_pool_first_call.py: the experiment behind DESIGN.md section 9 "first-call anomaly"):
+//   register (default)  mmap + mbind per shard region + first touch + hipHostRegister
+//   nohuge              the same without MADV_HUGEPAGE
+//   hostmalloc          plain hipHostMalloc (the runtime's own pinned allocator: no per-shard placement)
+//   numauser            set_mempolicy(MPOL_PREFERRED, node of device 0) around hipHostMalloc(hipHostMallocNumaUser)
+static int pool_alloc_mode() {
+    const char* e = getenv("ZKATTEST_POOL_ALLOC");
+    if (!e) return 0;
+    return !strcmp(e, "nohuge") ? 1 : !strcmp(e, "hostmalloc") ? 2 : !strcmp(e, "numauser") ? 3 : 0;
+}
 extern "C" void* zk_pool_host_alloc(zk_pool* p, size_t bytes) {
     if (!p || !bytes) return nullptr;
     const size_t page = (size_t)sysconf(_SC_PAGESIZE);
     const size_t len = (bytes + page - 1) / page * page;
+    const int mode = pool_alloc_mode();
+    if (mode >= 2) {
+        void* hp = nullptr;
+        unsigned long mask[16] = {0};
+        const int node = p->numa.empty() ? -1 : p->numa[0];
+        if (mode == 3 && node >= 0 && node < 1024) {
+            mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
+            (void)syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, 1024ul);
+        }
+        hipError_t e = hipHostMalloc(&hp, len, mode == 3 ? hipHostMallocNumaUser : hipHostMallocDefault);
+        if (mode == 3) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        std::lock_guard<std::mutex> g(g_regs_mu);
+        g_regs[hp] = 0;   // length 0: hipHostFree, not munmap
+        return hp;
+    }
     void* mem = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (mem == MAP_FAILED) return nullptr;
-    (void)madvise(mem, len, MADV_HUGEPAGE);
+    if (mode != 1) (void)madvise(mem, len, MADV_HUGEPAGE);
     const size_t G = p->ctx.size(), region = (bytes / G) & ~(size_t)255;
     // placement: an explicit memory policy per shard region (mbind, MPOL_PREFERRED: the device's node if it has room) -- first touch
     // alone depends on where the touching thread happens to run when the cpuset does not grant the device's CPUs -- and the touch
@@ -293,6 +322,10 @@ extern "C" void zk_pool_host_free(void* mem) {
         if (it == g_regs.end()) return;
         len = it->second;
         g_regs.erase(it);
+    }
+    if (!len) {   // came from hipHostMalloc (ZKATTEST_POOL_ALLOC=hostmalloc / numauser)
+        (void)hipHostFree(mem);
+        return;
     }
     (void)hipHostUnregister(mem);
     munmap(mem, len);
@@ -348,7 +381,14 @@ extern "C" zk_status zk_pool_set_ring(zk_pool* p, const uint8_t* keys, uint64_t 
             p->comms_tried = true;
             if (p->rccl.load()) {
                 p->comms.assign(G, nullptr);
-                if (p->rccl.CommInitAll(p->comms.data(), G, p->dev.data()) != 0) p->comms.clear();
+                ncclResult_t r = p->rccl.CommInitAll(p->comms.data(), G, p->dev.data());
+                if (r != 0) {
+                    p->comms.clear();
+                    p->err = std::string("rccl: ncclCommInitAll failed (") + (p->rccl.GetErrorString ? p->rccl.GetErrorString(r) : "?") + "); the ring travels by peer copies";
+                }
+            } else {
+                p->err = getenv("ZKATTEST_NO_RCCL") ? "rccl: switched off by ZKATTEST_NO_RCCL; the ring travels by peer copies"
+                                                   : "rccl: librccl.so not found or incomplete; the ring travels by peer copies";
             }
         }
         bool done = false;
@@ -368,12 +408,16 @@ extern "C" zk_status zk_pool_set_ring(zk_pool* p, const uint8_t* keys, uint64_t 
             }
             if (done) p->transport = "rccl";
             else {   // communicators that failed once are not trusted again: this and every later ring go by peer copies
+                const ncclResult_t bad = r ? r : r2;   // zk_pool_last_error says why, although the call itself succeeds through the fallback
+                p->err = std::string("rccl: ncclBroadcast of the ring failed (") + (bad && p->rccl.GetErrorString ? p->rccl.GetErrorString(bad) : "stream synchronisation") +
+                         "); the ring travels by peer copies from now on";
                 (void)hipGetLastError();
                 for (auto cm : p->comms)
                     if (cm) p->rccl.CommDestroy(cm);
                 p->comms.clear();
             }
         }
+        if (!distinct) p->err = "rccl: a device is listed twice in this pool; the ring travels by peer copies";
         if (!done) {   // device-to-device copies (xGMI where the devices are peers)
             for (int i = 1; i < G; i++) {
                 e = hipMemcpyPeer(d[i], p->dev[i], d[0], p->dev[0], bytes);
@@ -405,6 +449,44 @@ extern "C" zk_status zk_pool_prove_batch(zk_pool* p, uint64_t B, const uint8_t* 
         for (uint64_t j = 0; j < cnt; j++) out_off[first + j] = region * i + off[j], out_len[first + j] = off[j + 1] - off[j];
         return ZK_OK;
     });
+}
+
+// The same with the proofs left in HBM: shard i writes into d_out[i], a buffer of out_cap[i] bytes on device_ids[i] (zk_pool_device_alloc).
+// Nothing but 160 bytes of inputs per proof crosses the link, so a scaling run through this entry point measures the GPUs and their host
+// threads, not the node's host memory (8 shards emit ~55 GB/s of page-locked writes each through zk_pool_prove_batch).
+extern "C" zk_status zk_pool_prove_batch_device(zk_pool* p, uint64_t B, const uint8_t* msg, const uint8_t* sig, const uint8_t* pk, const uint32_t* which,
+                                                const zk_rng* rng, void* const* d_out, const uint64_t* out_cap, uint64_t* out_off, uint64_t* out_len, int32_t* status) {
+    if (!p || !rng || !d_out || !out_cap || !out_off || !out_len || !status || (B && (!msg || !sig || !pk || !which || !rng->data))) return ZK_E_ARG;
+    return pool_each(p, [&](int i) -> zk_status {
+        uint64_t first, cnt;
+        zk_pool_shard(p, B, i, &first, &cnt);
+        if (!cnt) return ZK_OK;
+        if (!d_out[i]) return ZK_E_ARG;
+        zk_rng r = *rng;
+        r.data = rng->data + (rng->mode == ZK_RNG_SEED ? 32 * first : 32 * first * rng->stride_blocks);
+        std::vector<uint64_t> off(cnt + 1);
+        zk_status zs = zk_prove_batch(p->ctx[i], cnt, msg + 32 * first, sig + 64 * first, pk + 64 * first, which + first, &r, (uint8_t*)d_out[i], out_cap[i], off.data(),
+                                      status + first);
+        if (zs) return zs;
+        for (uint64_t j = 0; j < cnt; j++) out_off[first + j] = off[j], out_len[first + j] = off[j + 1] - off[j];   // relative to d_out[i]
+        return ZK_OK;
+    });
+}
+extern "C" void* zk_pool_device_alloc(zk_pool* p, int i, size_t bytes) {
+    if (!p || i < 0 || i >= (int)p->ctx.size()) return nullptr;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) cur = -1, (void)hipGetLastError();
+    void* mem = nullptr;
+    if (hipSetDevice(p->dev[i]) != hipSuccess || hipMalloc(&mem, bytes ? bytes : 1) != hipSuccess) (void)hipGetLastError(), mem = nullptr;
+    if (cur >= 0) (void)hipSetDevice(cur);
+    return mem;
+}
+extern "C" void zk_pool_device_free(zk_pool* p, int i, void* mem) {
+    if (!p || !mem || i < 0 || i >= (int)p->ctx.size()) return;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) cur = -1, (void)hipGetLastError();
+    if (hipSetDevice(p->dev[i]) == hipSuccess) (void)hipFree(mem);
+    if (cur >= 0) (void)hipSetDevice(cur);
 }
 
 extern "C" zk_status zk_pool_verify_batch(zk_pool* p, uint64_t B, const uint8_t* msg, const uint8_t* proofs, const uint64_t* proof_off, const uint64_t* proof_len,

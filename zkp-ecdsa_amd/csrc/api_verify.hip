@@ -79,7 +79,7 @@ zk_status ensure_vworkspace(zk_ctx* c, uint32_t C, uint32_t nlanes) {
         if (need > L.arena_bytes) {
             if (L.arena) HIPCHK(c, hipFree(L.arena));
             L.arena = nullptr, L.arena_bytes = 0;
-            HIPCHK(c, hipMalloc(&L.arena, need));
+            HIPCHK(c, malloc_or_shed(c, &L.arena, need));
             L.arena_bytes = need;
         }
         vcarve(L.V, L.res, L.res2, L.M, (uint8_t*)L.arena, C, sec, n, c->N, want_msm, c->verify_groups);

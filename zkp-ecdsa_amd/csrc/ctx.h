@@ -164,6 +164,7 @@ struct DevBuf {
     T* as() const { return (T*)p; }
 };
 zk_status ensure_workspace(zk_ctx* c, uint32_t C, uint32_t nlanes = 1);   // api.hip: prover workspaces of lanes 0..nlanes-1
+hipError_t malloc_or_shed(zk_ctx* c, void** p, size_t bytes);   // api.hip: a workspace allocation that sheds the optional per-ring tables first
 zk_status ensure_in_buf(zk_ctx* c, size_t bytes);  // api.hip: c->in_buf of at least `bytes`
 
 // One pipeline pass = one chunk of consecutive proofs.  Device-pointer calls use uniform chunks of C proofs.  Host-pointer

@@ -12,7 +12,7 @@
 #define KTAB_NWIN 33
 #define KTAB_ENT 128
 #define KTAB_ENTRY_WORDS 16
-#define KTAB_MAXN 16
+#define KTAB_MAXN 17   // 35 GB at 2^17 keys (the reference's own bench ring, 100 001 keys, pads to that); zk_ctx_set_ring falls back when the HBM is not there
 #define KTAB_KEY_WORDS ((size_t)KTAB_NWIN * KTAB_ENT * KTAB_ENTRY_WORDS)
 
 ZK_DEV P256Aff ld_ktab(const uint32_t* e, bool neg = false) {   // neg: (x, p - y), on the words (entries are canonical, y != 0 on this curve)
