@@ -347,6 +347,13 @@ zk_status zk_proofs_from_json_batch(uint64_t n, const char *texts, const uint64_
  * on the engine's stream) and, per kernel family, the accumulated milliseconds.  names[i] are static strings. */
 uint32_t zk_last_timing(const zk_ctx *ctx, float *total_ms, const char **names, float *ms, uint32_t cap);
 
+/* Diagnostic: the rate (GB/s) a page-locked copy of `bytes` (at least 1 MiB) reaches on the copy stream of pipeline lane `lane` (0..3), device
+ * to host and host to device, measured with HIP events.  ~57 GB/s is what the link carries on MI355X boxes; ~27 GB/s says that the runtime of this
+ * PROCESS serves copies with shader blits instead of an SDMA engine, and every host-pointer call will run at about 0.6 of
+ * its usual rate whatever the buffers are. */
+zk_status zk_ctx_copy_probe(zk_ctx *ctx, uint32_t lane, size_t bytes, int numa_node /* >= 0: the host buffer is bound to that node; -1: wherever
+                            the runtime puts it */, float *d2h_gbps, float *h2d_gbps);
+
 /* Unit-test hooks (tests/ call these through the C ABI to compare single primitives with the oracle).
  * zk_pool_test_locality: NUMA node and local CPUs of a PCI address as the pool reads them from sysfs (ZKATTEST_SYSFS_ROOT). */
 int zk_pool_test_locality(const char *pci_bus_id, int *numa_node, int *cpus, int cap);

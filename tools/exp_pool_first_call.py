@@ -57,6 +57,9 @@ def main():
     ap.add_argument('--sync-calls', type=int, default=3)
     ap.add_argument('--stream', type=int, default=4)
     ap.add_argument('--tag', default='')
+    ap.add_argument('--clean-exit', type=int, default=0, help='1: destroy the pool and free the buffers before exiting (default: os._exit)')
+    ap.add_argument('--probe', type=int, default=1, help='zk_ctx_copy_probe on the four copy streams at start and at the end')
+    ap.add_argument('--hold', type=float, default=0, help='only create the pool, probe, and sleep this many seconds (a process that holds its queues)')
     args = ap.parse_args()
     import zkp_ecdsa_amd as Z
     B, sec = args.batch, 80
@@ -64,6 +67,11 @@ def main():
     pool = Z.Pool([0])
     e0 = pool.engine(0)
     e0.set_comb_bits(args.comb_bits), e0.set_chunk(min(16384, B)), e0.set_lanes(2)
+    probe0 = [e0.copy_probe(l) for l in range(4)] if args.probe else None   # before anything else ran on the device
+    if args.hold:   # holder process: keeps its queues alive while others start
+        print(json.dumps({'tag': args.tag, 'probe_at_start': probe0}), flush=True)
+        time.sleep(args.hold)
+        os._exit(0)
     pool.set_params(*e0.synth_params(2024), sec)
     ring, msg, sig, pk, which, seeds = e0.synth_workload(2024, args.ring, B)
     pool.set_ring(ring, args.ring)
@@ -91,7 +99,15 @@ def main():
         dt = time.time() - t0
         rec['calls'].append({'kind': 'stream x%d' % args.stream, 'proofs_per_s': round(args.stream * B / dt), 'd2h_gbps': round(args.stream * nbytes / dt / 1e9, 1)})
         rec['other_buffers'] = [mapping_info(b.ptr) for b in bufs[1:]]
+    rec['probe_at_start'] = probe0
+    if args.probe:
+        e0.set_slice(0)
+        rec['probe_at_end'] = [e0.copy_probe(l) for l in range(4)]
     print(json.dumps(rec), flush=True)
+    if args.clean_exit:
+        pin.free()
+        pool.close()
+        return
     os._exit(0)   # a fresh process per measurement: no tear-down in the timed path of the loop that starts us
 
 

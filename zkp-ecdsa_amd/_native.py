@@ -17,7 +17,7 @@ SYMBOLS = [
     'zk_proof_to_json', 'zk_proof_from_json', 'zk_host_alloc', 'zk_host_free', 'zk_ctx_set_host_taper', 'zk_ctx_set_slice', 'zk_ctx_set_mode', 'zk_ring_digest', 'zk_hardened_h',
     'zk_pool_create', 'zk_pool_destroy', 'zk_pool_size', 'zk_pool_ctx', 'zk_pool_last_error', 'zk_pool_ring_transport', 'zk_pool_shard',
     'zk_pool_set_params', 'zk_pool_set_ring', 'zk_pool_prove_batch', 'zk_pool_verify_batch',
-    'zk_pool_host_alloc', 'zk_pool_host_free', 'zk_pool_numa_node', 'zk_pool_test_locality', 'zk_pool_shard_ms', 'zk_pool_test_fail_submit', 'zk_pool_prove_batch_device', 'zk_pool_device_alloc', 'zk_pool_device_free',
+    'zk_pool_host_alloc', 'zk_pool_host_free', 'zk_pool_numa_node', 'zk_pool_test_locality', 'zk_pool_shard_ms', 'zk_pool_test_fail_submit', 'zk_ctx_copy_probe', 'zk_pool_prove_batch_device', 'zk_pool_device_alloc', 'zk_pool_device_free',
     'zk_prove_submit', 'zk_prove_submit_device', 'zk_prove_wait', 'zk_verify_submit', 'zk_verify_wait', 'zk_test_counter', 'zk_ctx_set_key_tables',
     'zk_proofs_to_json_batch', 'zk_proofs_from_json_batch', 'zk_ctx_set_ring_fold',
     'zk_pool_prove_submit', 'zk_pool_prove_wait', 'zk_pool_verify_submit', 'zk_pool_verify_wait', 'zk_ctx_set_verify_groups',
@@ -126,6 +126,7 @@ def lib():
         L.zk_pool_device_alloc.restype = vp
         L.zk_pool_device_free.argtypes = [vp, i32, vp]
         L.zk_pool_device_free.restype = None
+        L.zk_ctx_copy_probe.argtypes = [vp, u32, C.c_size_t, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.zk_pool_test_fail_submit.argtypes = [vp, i32]
         L.zk_pool_test_fail_submit.restype = None
         L.zk_pool_host_alloc.argtypes = [vp, C.c_size_t]
@@ -437,6 +438,12 @@ class Engine:
     def verify_wait(self, t):
         self._chk(self.L.zk_verify_wait(self.h, t['job']))
         return t['ok'], t['st']
+
+    def copy_probe(self, lane=0, nbytes=256 << 20, numa_node=-1):
+        """(d2h GB/s, h2d GB/s) of a page-locked copy on that lane's copy stream (zk_ctx_copy_probe); numa_node >= 0 binds the host buffer"""
+        a, b = C.c_float(), C.c_float()
+        self._chk(self.L.zk_ctx_copy_probe(self.h, lane, nbytes, numa_node, C.byref(a), C.byref(b)))
+        return round(a.value, 1), round(b.value, 1)
 
     def test_counter(self, which=0):
         return int(self.L.zk_test_counter(self.h, which))

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 #include "engine.h"
@@ -15,6 +16,8 @@ void launch_synth(hipStream_t s, const uint32_t* pfix_G, uint64_t seed, uint64_t
 void launch_synth_param_scalars(hipStream_t s, uint64_t seed, uint8_t* kn_be, uint8_t* kt_be);
 
 #include <cstdlib>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include "ctx.h"
 #include "jobs.h"
 
@@ -79,6 +82,13 @@ static zk_status ctx_init(zk_ctx* c, int device_id) {
     for (int base = 0; base < ZK_MAX_LANES; base += 2) {   // compute 0, compute 1, copy 0, copy 1; then the same for lanes 2, 3
         for (int l = base; l < base + 2; l++) HIPCHK(c, hipStreamCreate(&c->pl[l].stream));
         for (int l = base; l < base + 2; l++) HIPCHK(c, hipStreamCreateWithFlags(&c->pl[l].copy_stream, hipStreamNonBlocking));
+    }
+    if (const char* e = getenv("ZKATTEST_COPY_STREAMS")) {   // experiment knob (tools/exp_pool_first_call.py): 1 = every lane copies out on lane 0's copy stream
+        if (atoi(e) == 1)
+            for (int l = 1; l < ZK_MAX_LANES; l++) {
+                hipStreamDestroy(c->pl[l].copy_stream);
+                c->pl[l].copy_stream = c->pl[0].copy_stream;
+            }
     }
     c->stream = c->pl[0].stream;
     c->copy_stream = c->pl[0].copy_stream;   // H2D of the verifier's proofs
@@ -146,7 +156,7 @@ extern "C" void zk_ctx_destroy(zk_ctx* c) {
         if (c->pl[l].h_scan) hipHostFree(c->pl[l].h_scan);
         if (c->vl[l].h_msm) hipHostFree(c->vl[l].h_msm);
         if (c->pl[l].copy_ev) hipEventDestroy(c->pl[l].copy_ev);
-        if (c->pl[l].copy_stream) hipStreamDestroy(c->pl[l].copy_stream);
+        if (c->pl[l].copy_stream && (l == 0 || c->pl[l].copy_stream != c->pl[0].copy_stream)) hipStreamDestroy(c->pl[l].copy_stream);
         if (c->pl[l].stream) hipStreamDestroy(c->pl[l].stream);
     }
     delete c;
@@ -494,13 +504,119 @@ zk_status ensure_workspace(zk_ctx* c, uint32_t C, uint32_t nlanes) {
 // zk_prove_batch / zk_verify_batch move ~169 KB per proof across PCIe.  From pageable memory the runtime stages every
 // copy through its own bounce buffers (measured 8.6 GB/s, one blocking copy); from page-locked memory the copies are DMA
 // transfers on their own stream, chunk by chunk, under the kernels of the neighbouring chunks.
-extern "C" void* zk_host_alloc(size_t bytes) {
-    void* p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
+// ---- "slow pages".  Measured on MI355X boxes (tools/exp_link_state.py, tools/exp_pool_first_call.py): a page-locked
+// buffer allocated shortly after another process (or this one) released gigabytes of page-locked memory can come out of the allocator
+// with pages that the device's DMA engines reach at HALF rate -- 30 instead of 57 GB/s, both directions, whatever stream, SDMA or blit,
+// hipHostMalloc or mmap + hipHostRegister, huge pages or not, near or far NUMA node, with unchanged device clocks and link speed --
+// while a buffer allocated next to it at the same moment copies at full rate.  The property sticks to the buffer for as long as it
+// lives.  A process whose output buffer drew such pages ran every host-pointer call at 160 k instead of 262 k proofs/s ("first
+// synchronous pool call anomaly" of round 3).  So the allocators below measure what they hand out and try again -- holding the slow
+// buffer meanwhile, so that the allocator cannot return the same pages -- up to ZK_ALLOC_TRIES times.  ZKATTEST_HOST_ALLOC_PROBE=0
+// switches the check off.
+#define ZK_ALLOC_TRIES 4
+// slowest device-to-host rate (GB/s) over up to three 64 MiB windows of the page-locked range [p, p + bytes); 0 = could not measure
+float pinned_d2h_rate(void* p, size_t bytes) {
+    const size_t win = 64u << 20;
+    if (bytes < (4u << 20)) return 0.f;
+    const size_t w = std::min(win, bytes);
+    void* d = nullptr;
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float worst = 0.f;
+    if (hipMalloc(&d, w) == hipSuccess && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
+        hipEventCreate(&e1) == hipSuccess) {
+        const size_t offs[3] = {0, ((bytes - w) / 2) & ~(size_t)4095, (bytes - w) & ~(size_t)4095};
+        const int nw = bytes >= 3 * w ? 3 : 1;
+        (void)hipMemcpyAsync(p, d, 1u << 20, hipMemcpyDeviceToHost, s);   // the stream's first copy sets its queue up
+        for (int k = 0; k < nw; k++) {
+            float ms = 0.f;
+            if (hipEventRecord(e0, s) != hipSuccess || hipMemcpyAsync((uint8_t*)p + offs[k], d, w, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipEventRecord(e1, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.f) {
+                worst = 0.f;
+                break;
+            }
+            const float r = (float)(w / 1e6 / ms);
+            worst = k == 0 ? r : std::min(worst, r);
+        }
     }
-    return p;
+    (void)hipGetLastError();
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (s) hipStreamDestroy(s);
+    if (d) hipFree(d);
+    return worst;
+}
+bool host_alloc_probe_enabled() {
+    const char* e = getenv("ZKATTEST_HOST_ALLOC_PROBE");
+    return !(e && !strcmp(e, "0"));
+}
+// What a page-locked copy should reach on the current device's PCIe link: 0.89 (the share measured on these boxes: 57 of 64 GB/s) of
+// speed x width from sysfs (current_link_speed "32.0 GT/s PCIe", current_link_width "16"); 0 when sysfs does not say.
+static float link_expected_gbps() {
+    int dev = 0;
+    char bus[64] = {0}, buf[128];
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, sizeof bus, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0.f;
+    }
+    for (char* q = bus; *q; q++) *q = (char)tolower(*q);
+    auto rd = [&](const char* leaf) -> float {
+        std::string path = std::string("/sys/bus/pci/devices/") + bus + "/" + leaf;
+        FILE* f = fopen(path.c_str(), "r");
+        if (!f) return 0.f;
+        float v = fgets(buf, sizeof buf, f) ? (float)atof(buf) : 0.f;
+        fclose(f);
+        return v;
+    };
+    const float gts = rd("current_link_speed"), width = rd("current_link_width");
+    if (gts < 2.f || width < 1.f) return 0.f;
+    return 0.89f * gts * width / 8.f * (gts >= 8.f ? 128.f / 130.f : 0.8f);
+}
+// Allocates with `alloc`, measures, and keeps the fastest of up to ZK_ALLOC_TRIES candidates; the rejected ones are held until the choice is
+// made (so that the allocator cannot hand the same pages out again) and then released with `release`.  A candidate is good when it reaches
+// 0.8 of what the link should carry (sysfs); where sysfs does not say, when it is within 25 % of the best rate this process has measured
+// on any page-locked buffer (the first large allocation then draws a second candidate for comparison).  Slow pages are a transient of
+// the allocator (recently released page-locked memory), so a pause precedes every further attempt.
+static float g_best_pinned_rate = 0.f;
+void* alloc_fast_pinned(size_t bytes, const std::function<void*()>& alloc, const std::function<void(void*)>& release) {
+    const bool probe = host_alloc_probe_enabled() && bytes >= (64u << 20);
+    const float expected = probe ? link_expected_gbps() : 0.f;
+    const bool dbg = getenv("ZK_ALLOC_DEBUG") != nullptr;
+    void *best = nullptr, *held[ZK_ALLOC_TRIES] = {};
+    float best_r = -1.f;
+    int nheld = 0;
+    for (int t = 0; t < ZK_ALLOC_TRIES; t++) {
+        void* p = alloc();
+        if (!p) break;
+        const float r = probe ? pinned_d2h_rate(p, bytes) : 0.f;
+        const bool had_yardstick = g_best_pinned_rate > 0.f;
+        if (dbg) fprintf(stderr, "alloc: candidate %d of %zu MB: %.1f GB/s device-to-host (link should carry %.1f, best seen so far %.1f)\n", t, bytes >> 20, r, expected, g_best_pinned_rate);
+        if (r > g_best_pinned_rate) g_best_pinned_rate = r;
+        if (r > best_r) {
+            if (best) held[nheld++] = best;
+            best = p, best_r = r;
+        } else {
+            held[nheld++] = p;
+        }
+        if (!probe || r == 0.f) break;   // not measuring (or could not)
+        if (expected > 0.f ? best_r >= 0.8f * expected : ((had_yardstick || t > 0) && best_r >= 0.75f * g_best_pinned_rate)) break;
+        if (t + 1 < ZK_ALLOC_TRIES) usleep(300000u * (unsigned)(t + 1));
+    }
+    for (int i = 0; i < nheld; i++) release(held[i]);
+    return best;
+}
+extern "C" void* zk_host_alloc(size_t bytes) {
+    return alloc_fast_pinned(
+        bytes,
+        [&]() -> void* {
+            void* p = nullptr;
+            if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+            return p;
+        },
+        [](void* p) { hipHostFree(p); });
 }
 extern "C" void zk_host_free(void* p) {
     if (p) hipHostFree(p);
@@ -912,6 +1028,62 @@ extern "C" zk_status zk_prove_batch(zk_ctx* c, uint64_t B, const uint8_t* msg, c
     if (B) HIPCHK(c, hipMemcpy(status, d_st, 4 * B, hipMemcpyDeviceToHost));
     if (!sink && !out_on_device && out_off[B]) HIPCHK(c, hipMemcpy(out, d_out, out_off[B], hipMemcpyDeviceToHost));
     return ZK_OK;
+}
+
+// Diagnostic: what a page-locked copy of `bytes` reaches on lane `lane`'s copy stream, in both directions (GB/s), measured with HIP
+// events on that stream.  The link carries ~57 GB/s on these boxes; a stream whose copies the runtime serves with shader blits instead of
+// an SDMA engine -- seen in about half of the processes of some boxes, whatever the allocation of the host buffer: DESIGN.md section 9 --
+// reaches ~27 GB/s, and every host-pointer call of the process then runs at 160 k instead of 262 k proofs/s.
+extern "C" zk_status zk_ctx_copy_probe(zk_ctx* c, uint32_t lane, size_t bytes, int numa_node, float* d2h_gbps, float* h2d_gbps) {
+    if (!c || lane >= ZK_MAX_LANES || bytes < (1u << 20)) return ZK_E_ARG;
+    if (c->stream_busy) return busy_refusal(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->pl[lane].copy_stream;
+    void *d = nullptr, *h = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    zk_status zs = ZK_OK;
+    auto fail = [&](hipError_t e, const char* what) {
+        c->err = std::string(what) + ": " + hipGetErrorString(e);
+        zs = ZK_E_DEVICE;
+    };
+    hipError_t e = hipMalloc(&d, bytes);
+    if (e == hipSuccess) {
+        // numa_node >= 0: the page-locked buffer is bound to that node (the policy is the calling thread's for the duration of the allocation)
+        unsigned long mask[16] = {0};
+        const bool bind = numa_node >= 0 && numa_node < 1024;
+        if (bind) {
+            mask[numa_node / (8 * sizeof(unsigned long))] |= 1ul << (numa_node % (8 * sizeof(unsigned long)));
+            (void)syscall(SYS_set_mempolicy, 2 /* MPOL_BIND */, mask, 1024ul);
+        }
+        e = hipHostMalloc(&h, bytes, bind ? hipHostMallocNumaUser : hipHostMallocDefault);
+        if (e == hipSuccess) memset(h, 1, bytes);
+        if (bind) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
+    }
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e != hipSuccess) fail(e, "copy probe set-up");
+    for (int dir = 0; dir < 2 && !zs; dir++) {
+        void *dst = dir ? d : h, *src = dir ? h : d;
+        hipMemcpyKind kind = dir ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+        e = hipMemcpyAsync(dst, src, 1 << 20, kind, s);   // the stream's first copy of this kind sets its queue up
+        if (e == hipSuccess) e = hipEventRecord(e0, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes, kind, s);
+        if (e == hipSuccess) e = hipEventRecord(e1, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) {
+            fail(e, "copy probe");
+            break;
+        }
+        float* out = dir ? h2d_gbps : d2h_gbps;
+        if (out) *out = ms > 0 ? (float)(bytes / 1e6 / ms) : 0.f;
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (h) hipHostFree(h);
+    if (d) hipFree(d);
+    return zs;
 }
 
 extern "C" uint32_t zk_last_timing(const zk_ctx* c, float* total_ms, const char** names, float* ms, uint32_t cap) {

@@ -244,8 +244,15 @@ static int pool_alloc_mode() {
     if (!e) return 0;
     return !strcmp(e, "nohuge") ? 1 : !strcmp(e, "hostmalloc") ? 2 : !strcmp(e, "numauser") ? 3 : 0;
 }
+static void* pool_host_alloc_once(zk_pool* p, size_t bytes);
+extern "C" void zk_pool_host_free(void* mem);
+// the fastest of up to three candidates: see "slow pages" in api.hip
 extern "C" void* zk_pool_host_alloc(zk_pool* p, size_t bytes) {
     if (!p || !bytes) return nullptr;
+    (void)hipSetDevice(p->dev[0]);
+    return alloc_fast_pinned(bytes, [&]() { return pool_host_alloc_once(p, bytes); }, [](void* m) { zk_pool_host_free(m); });
+}
+static void* pool_host_alloc_once(zk_pool* p, size_t bytes) {
     const size_t page = (size_t)sysconf(_SC_PAGESIZE);
     const size_t len = (bytes + page - 1) / page * page;
     const int mode = pool_alloc_mode();

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 #include "engine.h"
@@ -212,6 +213,8 @@ static inline std::vector<ChunkPlan> make_chunk_plan(uint64_t B, uint32_t C, uin
     return plan;
 }
 zk_status ensure_io_buf(zk_ctx* c, size_t bytes);  // api.hip: c->io_buf of at least `bytes`
+float pinned_d2h_rate(void* p, size_t bytes);   // api.hip: slowest D2H rate over three windows of a page-locked range (the "slow pages" check)
+void* alloc_fast_pinned(size_t bytes, const std::function<void*()>& alloc, const std::function<void(void*)>& release);   // api.hip: the fastest of up to three candidates
 bool host_ptr_is_pinned(const void* p);     // api.hip: page-locked (zk_host_alloc / hipHostMalloc / hipHostRegister) host memory?
 zk_status ensure_copy_stream(zk_ctx* c);    // api.hip: c->copy_stream and the lanes' copy events
 
