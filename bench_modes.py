@@ -204,7 +204,7 @@ def latency_table(Z, eng, args, nh, tg, th, sec, ring, nkeys, msg, sig, pk, whic
     on the bench's ring and on a ring of `small_ring` keys.  Median of a few calls after one untimed call per size (the first call of a new
     chunk size re-carves the workspace)."""
     out = {'unit': 'ms per call (median)', 'path': 'zk_prove_batch / zk_verify_batch on host pointers, page-locked proof buffer', 'rings': {}}
-    pin = Z.PinnedBuffer(int(max(sizes) * (304 + 336 * sec + 3392 * sec + 384 * 20 + 32) // 2 + (8 << 20)))
+    pin = Z.PinnedBuffer(int(max(sizes) * (304 + 336 * sec + 3392 * (sec // 2 + 4) + 384 * 20 + 32) + (64 << 20)))
     rings = [(nkeys, ring, msg, sig, pk, which, seeds)]
     if small_ring and small_ring != nkeys:
         r2, m2, s2, p2, w2, sd2 = eng.synth_workload(args.seed + 1, small_ring, max(sizes))
@@ -216,7 +216,7 @@ def latency_table(Z, eng, args, nh, tg, th, sec, ring, nkeys, msg, sig, pk, whic
             eng.set_ring(rg, nk)
         rows = {}
         for B in sizes:
-            if B > len(w):
+            if B > len(w) or B > nk:   # the synthetic workload plants key b at ring slot b mod n_keys: more proofs than keys would overwrite signers
                 continue
             eng.set_chunk(B)
             a = (m[:32 * B], s_[:64 * B], p[:64 * B], w[:B], sd[:32 * B])

@@ -361,7 +361,8 @@ int zk_pool_test_locality(const char *pci_bus_id, int *numa_node, int *cpus, int
  * submitted (one shot): the half-submitted job is taken out of the queues again, older jobs stay in flight and waitable */
 void zk_pool_test_fail_submit(zk_pool *pool, int slot);
 /* work counters: 0 = proofs that went through the verifier's per-proof sums since the context was created (fallback of the batched check);
- * 1 = proofs of the last chunk on lane 0 whose scalar multiplications by the signer's key went through the per-key tables */
+ * 1 = proofs of the last chunk on lane 0 whose scalar multiplications by the signer's key went through the per-key tables;
+ * 2 = live terms that went through the verifier's batched Tom-256 check (bucket pass) since the context was created */
 uint64_t zk_test_counter(const zk_ctx *ctx, int which);
 /*
  * which_field: 0 = F_q (p256.p), 1 = Z_n, 2 = F_t;  op: 0 mul, 1 add, 2 sub, 3 inverse, 4 a*b - a - b (fused double subtraction), 5 (a + b)^2 (dedicated squaring).  count x 40-byte BE operands. */

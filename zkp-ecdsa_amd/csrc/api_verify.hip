@@ -244,6 +244,7 @@ zk_status VerifyJob::stage2(uint64_t chunk_no) {
             c->err = std::string("batched verification failed: ") + hipGetErrorString(e);
             return ZK_E_DEVICE;
         }
+        c->dbg_msm_terms += M.host[0];   // live terms of this chunk's bucket pass (zk_test_counter 2)
     } else {
         for (auto& f : flags) f = 0;   // every proof goes through the per-proof sums
     }

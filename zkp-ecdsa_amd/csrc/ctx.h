@@ -99,6 +99,7 @@ struct zk_ctx {
     std::vector<Spare> spare_dev, spare_pinned;
     // unit-test counters (zk_test_counter): work done, so that tests can assert on counts instead of timings
     uint64_t dbg_recheck_proofs = 0;   // proofs that went through the verifier's per-proof sums since the context was created
+    uint64_t dbg_msm_terms = 0;        // live terms that went through the batched Tom-256 check (k_msm.hip) since the context was created
     // timing
     std::vector<TimerRec> trecs;
     std::vector<hipEvent_t> epool;

@@ -487,17 +487,67 @@ ZK_DEV Fe<M, K> fe_select(bool c, const Fe<M, K>& a, const Fe<M, K>& b) {  // c 
     return r;
 }
 
+// Montgomery product for the places where ONE thread multiplies while everybody else waits for it (the Fermat inversions: thread 0 of a
+// normaliser workgroup, the front end's one thread per proof): operand-scanning, one 64-bit accumulator PER COLUMN, so the nine
+// multiply-adds of a row are independent of each other and issue back to back (4.2 cycles each) instead of one behind the other
+// (15.8 cycles, profiles/r03_valu_peak_microbench.txt).  The column sums are those of limbs_mont_mul -- the same partial products and
+// carries, added in another order -- so the result limbs are identical.  Eighteen live accumulators: not for kernels short of registers.
+template <class M>
+ZK_DEV void limbs_mont_mul_rows(uint32_t out[NLIMB], const uint32_t a[NLIMB], const uint32_t b[NLIMB]) {
+    uint64_t T[2 * NLIMB];
+    uint32_t md[NLIMB];
+    mod_limbs<M>(md);
+#pragma unroll
+    for (int k = 0; k < 2 * NLIMB; k++) T[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) {
+#pragma unroll
+        for (int j = 0; j < NLIMB; j++) T[i + j] = mad64(a[i], b[j], T[i + j]);
+        if (i > 0) T[i] += T[i - 1] >> LIMB_BITS;   // column i is complete now: every a_r b_(i-r), every m_r M_(i-r) with r < i, the carry
+        const uint32_t m = ((uint32_t)T[i] * M::n0) & LIMB_MASK;
+#pragma unroll
+        for (int j = 0; j < NLIMB; j++) T[i + j] = mad64(m, md[j], T[i + j]);
+    }
+    uint64_t carry = T[NLIMB - 1] >> LIMB_BITS;
+#pragma unroll
+    for (int k = NLIMB; k < 2 * NLIMB - 1; k++) {
+        const uint64_t v = T[k] + carry;
+        out[k - NLIMB] = (uint32_t)v & LIMB_MASK;
+        carry = v >> LIMB_BITS;
+    }
+    out[NLIMB - 1] = (uint32_t)carry;
+}
+// Measured (profiles/r04_ab_variants.txt, same box): no effect -- tom_normalize 10.82 -> 10.96 ms, p256_front 3.16 -> 3.26 ms per step, proofs/s
+// unchanged: the inversions are not what those kernels wait for.  Default off; kept as the record of the experiment.
+#ifndef ZK_POW_ROWS
+#define ZK_POW_ROWS 0
+#endif
+template <class M>
+ZK_DEV Fe<M, 2> fe_mul_rows(const Fe<M, 2>& a, const Fe<M, 2>& b) {
+#if ZK_POW_ROWS
+    Fe<M, 2> r;
+    limbs_mont_mul_rows<M>(r.l, a.l, b.l);
+    return r;
+#else
+    return a * b;
+#endif
+}
 // a^e for a public exponent e given as 9 little-endian 32-bit words (right-to-left binary), Montgomery domain
 template <class M>
 ZK_DEV_NOINLINE Fe<M, 2> fe_pow_words(Fe<M, 2> a, const uint32_t e[NLIMB]) {
+    static_assert(4 <= M::kmax, "Montgomery input magnitudes too large");
     Fe<M, 2> acc = fe_one_mont<M>().template as<2>(), base = a;
     for (int w = 0; w < NLIMB; w++) {
         uint32_t ew = e[w];
         int nb = M::bits - 32 * w;
         if (nb > 32) nb = 32;
         for (int b = 0; b < nb; b++) {
-            if ((ew >> b) & 1) acc = acc * base;
+            if ((ew >> b) & 1) acc = fe_mul_rows(acc, base);
+#if ZK_POW_ROWS
+            base = fe_mul_rows(base, base);
+#else
             base = fe_sqr(base);
+#endif
         }
     }
     return acc;

@@ -290,33 +290,67 @@ void launch_exp_commit(hipStream_t s, const DevParams& P, const Workspace& W, ui
 
 // ---------------------------------------------------------------- batch normalisation (weier.ts:231-243)
 // Z = 0 (identity) sets st[owner] = err_code (if no earlier error) and yields (0, 0).
+#ifndef ZK_NORM_PIPELINE
+#define ZK_NORM_PIPELINE 0   // 1: loads of the next element issued before the products of the current one; measured, no gain: see k_tom_normalize (k_tom.hip)
+#endif
 __global__ void __launch_bounds__(256) k_p256_normalize(Soa3 proj, uint32_t count, uint32_t nthreads, uint32_t per, Soa ox, Soa oy,
                                                         int32_t* st, uint32_t per_proof, int32_t err_code, const uint32_t* owner) {
     __shared__ uint32_t lds[2 * 256 * NLIMB];
     uint32_t t = gtid();   // threads beyond nthreads own no element but take part in the workgroup's inversion
     Fq2 acc = fe_one_mont<ModQ>().as<2>();
-    for (uint32_t j = 0; j < per; j++) {
-        uint32_t e = t + j * nthreads;
-        if (t >= nthreads || e >= count) break;
-        Fq2 z = fe_reduce(soa_ld<ModQ, 8>(proj.z, e));
-        bool zero = fe_is_zero(z);
-        if (zero) {
-            uint32_t o = owner ? owner[e] : e / per_proof;
-            if (err_code && atomicCAS(&st[o], ZK_OK, err_code) == ZK_E_ARG) atomicCAS(&st[o], ZK_E_ARG, err_code);   // `which` out of range is found last in the reference
-            z = fe_one_mont<ModQ>().as<2>();
+    uint32_t mine = 0;
+    if (t < nthreads && t < count) mine = std::min<uint32_t>(per, (count - t + nthreads - 1) / nthreads);
+    {
+#if ZK_NORM_PIPELINE
+        Fe<ModQ, 8> zn = fe_one_mont<ModQ>().as<8>();
+        if (mine) zn = soa_ld<ModQ, 8>(proj.z, t);
+#endif
+        for (uint32_t j = 0; j < mine; j++) {
+            uint32_t e = t + j * nthreads;
+#if ZK_NORM_PIPELINE
+            Fq2 z = fe_reduce(zn);
+            if (j + 1 < mine) zn = soa_ld<ModQ, 8>(proj.z, e + nthreads);
+#else
+            Fq2 z = fe_reduce(soa_ld<ModQ, 8>(proj.z, e));
+#endif
+            bool zero = fe_is_zero(z);
+            if (zero) {
+                uint32_t o = owner ? owner[e] : e / per_proof;
+                if (err_code && atomicCAS(&st[o], ZK_OK, err_code) == ZK_E_ARG) atomicCAS(&st[o], ZK_E_ARG, err_code);   // `which` out of range is found last in the reference
+                z = fe_one_mont<ModQ>().as<2>();
+            }
+            soa_st(ox, e, acc);
+            soa_st(oy, e, z);  // sanitised z
+            acc = acc * z;
         }
-        soa_st(ox, e, acc);
-        soa_st(oy, e, z);  // sanitised z
-        acc = acc * z;
     }
     // running inverse in the plain domain (see k_tom_normalize): x and y come out plain, no from-Montgomery products
     Fe<ModQ, 1> one = fe_zero<ModQ>();
     one.l[0] = 1;
     Fq2 inv = block_inverse<ModQ>(acc, lds) * one;
-    if (t >= nthreads) return;
-    for (int j = (int)per - 1; j >= 0; j--) {
+    if (!mine) return;
+#if ZK_NORM_PIPELINE
+    uint32_t en = t + (mine - 1) * nthreads;
+    Fq2 zn = soa_ld<ModQ, 2>(oy, en), pn = soa_ld<ModQ, 2>(ox, en);
+    Fe<ModQ, 8> xn = soa_ld<ModQ, 8>(proj.x, en), yn = soa_ld<ModQ, 8>(proj.y, en);
+    for (int j = (int)mine - 1; j >= 0; j--) {
+        const uint32_t e = en;
+        const Fq2 z = zn, pre = pn;
+        const Fe<ModQ, 8> px = xn, py = yn;
+        if (j > 0) {
+            en = e - nthreads;
+            zn = soa_ld<ModQ, 2>(oy, en), pn = soa_ld<ModQ, 2>(ox, en), xn = soa_ld<ModQ, 8>(proj.x, en), yn = soa_ld<ModQ, 8>(proj.y, en);
+        }
+        Fq2 zi = inv * pre;
+        inv = inv * z;
+        Fq2 x = px * zi;
+        Fq2 y = py * zi;
+        soa_st(ox, e, fe_canon(x));
+        soa_st(oy, e, fe_canon(y));
+    }
+#else
+    for (int j = (int)mine - 1; j >= 0; j--) {
         uint32_t e = t + (uint32_t)j * nthreads;
-        if (e >= count) continue;
         Fq2 z = soa_ld<ModQ, 2>(oy, e);
         Fq2 zi = inv * soa_ld<ModQ, 2>(ox, e);
         inv = inv * z;
@@ -325,6 +359,7 @@ __global__ void __launch_bounds__(256) k_p256_normalize(Soa3 proj, uint32_t coun
         soa_st(ox, e, fe_canon(x));
         soa_st(oy, e, fe_canon(y));
     }
+#endif
 }
 void launch_p256_normalize(hipStream_t s, const Soa3& proj, uint32_t count, const Soa& ox, const Soa& oy, int32_t* st, uint32_t per_proof,
                            int32_t err_code, const uint32_t* owner) {

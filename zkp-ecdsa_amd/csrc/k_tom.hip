@@ -186,30 +186,73 @@ void launch_tom_commit(hipStream_t s, const DevParams& P, const TomList& L, uint
 ZK_DEV uint32_t norm_slot(uint32_t c, uint32_t first, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride) {
     return kstride ? (first + c / per_group) * kstride + (c % per_group) : (c / per_group) * slots_per_group + first + c % per_group;
 }
+// -DZK_NORM_PIPELINE=1 software-pipelines both passes by hand (the loads of element j + 1 -- j - 1 in the backward pass -- are issued before
+// the products of element j; without it the stores to the output arrays, which may alias the inputs as far as the compiler knows, keep
+// load -> multiply -> store -> load in program order).  Measured, same box (profiles/r04_ab_variants.txt): tom_normalize 10.90 -> 10.68 ms,
+// p256_normalize 3.89 -> 3.77 ms per step, 78 -> 99 VGPRs, no change in proofs/s: the passes are not waiting for those loads.  A thread's
+// products form ONE dependent chain (acc = acc * z), two or three in the backward pass, at two to four waves per SIMD -- the multiplier
+// issues a dependent v_mad_u64_u32 every 8 cycles at two chains per SIMD against 5.7 at eight (profiles/r03_valu_peak_microbench.txt) -- and
+// every workgroup waits once for thread 0's Fermat inversion (~380 dependent products).  More, thinner threads (per <= 32) lose: 12.5 ms,
+// four times as many inversions.  Default off.
+#ifndef ZK_NORM_PIPELINE
+#define ZK_NORM_PIPELINE 0
+#endif
 __global__ void __launch_bounds__(256) k_tom_normalize(TomList L, uint32_t count, uint32_t nthreads, uint32_t per, uint32_t first,
                                                        uint32_t per_group, uint32_t slots_per_group, uint32_t kstride) {
     __shared__ uint32_t lds[2 * 256 * NLIMB];
     uint32_t t = gtid();   // threads beyond nthreads own no element but take part in the workgroup's inversion
     Ft2 acc = fe_one_mont<ModT>().as<2>();
-    for (uint32_t j = 0; j < per; j++) {
-        uint32_t c = t + j * nthreads;
-        if (t >= nthreads || c >= count) break;
-        uint32_t e = norm_slot(c, first, per_group, slots_per_group, kstride);
+    // elements of this thread: c = t + j * nthreads < count, j < per
+    uint32_t mine = 0;
+    if (t < nthreads && t < count) mine = std::min<uint32_t>(per, (count - t + nthreads - 1) / nthreads);
+#if ZK_NORM_PIPELINE
+    {
+        Ft2 zn = fe_one_mont<ModT>().as<2>();
+        uint32_t en = 0;
+        if (mine) en = norm_slot(t, first, per_group, slots_per_group, kstride), zn = soa_ld<ModT, 2>(L.proj.z, en);
+        for (uint32_t j = 0; j < mine; j++) {
+            const uint32_t e = en;
+            const Ft2 z = zn;
+            if (j + 1 < mine) en = norm_slot(t + (j + 1) * nthreads, first, per_group, slots_per_group, kstride), zn = soa_ld<ModT, 2>(L.proj.z, en);
+            soa_st(L.ax, e, acc);  // prefix product before element e
+            acc = acc * z;
+        }
+    }
+#else
+    for (uint32_t j = 0; j < mine; j++) {
+        uint32_t e = norm_slot(t + j * nthreads, first, per_group, slots_per_group, kstride);
         soa_st(L.ax, e, acc);  // prefix product before element e
         acc = acc * soa_ld<ModT, 2>(L.proj.z, e);
     }
+#endif
     // The running inverse is kept in the PLAIN domain (one extra product per thread): a Montgomery product of a plain and a
     // Montgomery operand is plain, so 1/z_e, the next running inverse, x and y come out plain without the two
     // from-Montgomery products per point (5 products per point in this pass instead of 7).
     Fe<ModT, 1> one = fe_zero<ModT>();
     one.l[0] = 1;
     Ft2 inv = block_inverse<ModT>(acc, lds) * one;
-    if (t >= nthreads) return;
+    if (!mine) return;
     const auto sinv = fe_const<ModT, 1>(TOM_SINV_M);
-    for (int j = (int)per - 1; j >= 0; j--) {
-        uint32_t c = t + (uint32_t)j * nthreads;
-        if (c >= count) continue;
-        uint32_t e = norm_slot(c, first, per_group, slots_per_group, kstride);
+#if ZK_NORM_PIPELINE
+    uint32_t en = norm_slot(t + (mine - 1) * nthreads, first, per_group, slots_per_group, kstride);
+    Ft2 zn = soa_ld<ModT, 2>(L.proj.z, en), pn = soa_ld<ModT, 2>(L.ax, en), xn = soa_ld<ModT, 2>(L.proj.x, en), yn = soa_ld<ModT, 2>(L.proj.y, en);
+    for (int j = (int)mine - 1; j >= 0; j--) {
+        const uint32_t e = en;
+        const Ft2 z = zn, pre = pn, px = xn, py = yn;
+        if (j > 0) {
+            en = norm_slot(t + (uint32_t)(j - 1) * nthreads, first, per_group, slots_per_group, kstride);
+            zn = soa_ld<ModT, 2>(L.proj.z, en), pn = soa_ld<ModT, 2>(L.ax, en), xn = soa_ld<ModT, 2>(L.proj.x, en), yn = soa_ld<ModT, 2>(L.proj.y, en);
+        }
+        Ft2 zi = inv * pre;
+        inv = inv * z;
+        Ft2 x = px * (zi * sinv);
+        Ft2 y = py * zi;
+        soa_st(L.ax, e, fe_canon(x));
+        soa_st(L.ay, e, fe_canon(y));
+    }
+#else
+    for (int j = (int)mine - 1; j >= 0; j--) {
+        uint32_t e = norm_slot(t + (uint32_t)j * nthreads, first, per_group, slots_per_group, kstride);
         Ft2 z = soa_ld<ModT, 2>(L.proj.z, e);
         Ft2 zi = inv * soa_ld<ModT, 2>(L.ax, e);
         inv = inv * z;
@@ -218,6 +261,7 @@ __global__ void __launch_bounds__(256) k_tom_normalize(TomList L, uint32_t count
         soa_st(L.ax, e, fe_canon(x));
         soa_st(L.ay, e, fe_canon(y));
     }
+#endif
 }
 void launch_tom_normalize(hipStream_t s, const TomList& L, uint32_t count, uint32_t first, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride) {
     if (!count) return;
