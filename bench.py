@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 # zk_ctx_create).  Must be in the environment before the first HIP call of the process, i.e. before torch touches the device.
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
-from bench_common import (DEFAULT_COMB_BITS, HBM_PEAK_GBPS, MACS_PER_MODMUL, PMC_SOURCE, TOM_COMMIT_BYTES, TOM_COMMIT_NOMINAL, TOM_COMMIT_PMC_BYTES,  # noqa: E402,F401
+from bench_common import (DEFAULT_COMB_BITS, EXP_ADD_MACS, EXP_KT_ADDS, EXP_RTAB_ADDS, HBM_PEAK_GBPS, MACS_PER_MODMUL, PMC_SOURCE, TOM_COMMIT_BYTES, TOM_COMMIT_NOMINAL, TOM_COMMIT_PMC_BYTES,  # noqa: E402,F401
                           TOM_COMMIT_VALU_ACTIVE_PER_WAVE, VALU_MAD_8CHAIN_TOPS, VALU_MAD_PEAK_TOPS, cpu_baseline, host_cores, nominal_modmuls, rank_seeds,
                           tom_commit_modmuls, v8_bigint_indicator)
 from bench_modes import host_io_rates, json_batch_rates, latency_table, run_pool_mode, run_verify_mode  # noqa: E402
@@ -220,11 +220,13 @@ def main():
             eng.verify_batch_device(B, d_msg.data_ptr(), d_out.data_ptr(), d_off.data_ptr(), d_vseeds.data_ptr(), d_ok.data_ptr(), d_vst.data_ptr())
         vstep()  # warm-up (allocates the verifier workspace)
         barrier()
+        terms0 = eng.test_counter(2)
         tv0 = time.time()
         for _ in range(args.verify_steps):
             vstep()
         barrier()
         vdt = time.time() - tv0
+        msm_terms = (eng.test_counter(2) - terms0) // max(1, args.verify_steps)   # live terms of one step's batched Tom-256 check
         # per-kernel-family GPU time from one extra serial (single-lane) pass, like the prover's roofline pass
         eng.set_lanes(1)
         vstep()
@@ -237,7 +239,7 @@ def main():
             vdt = float(t.item())
         n_ok = int(d_ok.sum().item())
         verify = {'value': round(world * B * args.verify_steps / vdt, 2), 'unit': 'verifies/s', 'steps': args.verify_steps,
-                  'ms_per_step': round(vdt * 1e3 / args.verify_steps, 2), 'accepted': n_ok, 'of': B, 'chunk': vchunk, 'lanes': vlanes,
+                  'ms_per_step': round(vdt * 1e3 / args.verify_steps, 2), 'accepted': n_ok, 'of': B, 'chunk': vchunk, 'lanes': vlanes, 'msm_live_terms': int(msm_terms),
                   'gpu_ms_by_family_per_step': {k: round(v, 2) for k, v in sorted(vfam.items(), key=lambda kv: -kv[1])},
                   'gpu_ms_note': 'serial single-lane pass; the timed passes overlap %d chunks on %d streams' % (vlanes, vlanes)}
 
@@ -288,6 +290,34 @@ def main():
             'share_of_gpu_time': round(fam.get('tom_commit', 0.0) / gpu_ms, 3) if gpu_ms else None,
             'nominal_modmuls_per_proof': {'F_t': wt, 'F_q_ec': wq, 'F_q_ring': wring},
         }
+        # ---- the two next-largest arithmetic kernels, priced the same way (multiplier instructions of the shipped ISA / measured peak)
+        others = {}
+        exp_ms = fam.get('p256_exp_commit', 0.0) / max(1, args.roofline_steps)
+        if exp_ms > 0:
+            lanes = B * (sec + 1)
+            adds = EXP_KT_ADDS if kt_count else EXP_RTAB_ADDS
+            ops = lanes * adds * EXP_ADD_MACS
+            others['k_exp_commit_kt' if kt_count else 'k_exp_commit'] = {
+                'units': lanes, 'unit': 'T_i = alpha_i R, A_i = T_i + r_i h (one lane each; exp.ts:144-149)', 'mixed_additions_per_unit': adds,
+                'multiplier_instr_per_addition': EXP_ADD_MACS, 'ms_per_step': round(exp_ms, 2), 'achieved': round(ops / (exp_ms * 1e-3) / 1e12, 3),
+                'peak': VALU_MAD_PEAK_TOPS, 'frac': round(ops / (exp_ms * 1e-3) / 1e12 / VALU_MAD_PEAK_TOPS, 4),
+                'note': 'ISA count of the loop body (tools/isa_blocks.py: 1872 v_mad_u64_u32 + 99 v_mul_lo_u32 per mixed complete addition of 11 products); 13 + 33 + 13 gathered '
+                        'table entries per lane minus the first (no addition)'}
+        if verify and verify.get('msm_live_terms'):
+            bms = verify['gpu_ms_by_family_per_step'].get('+v_msm_bucket', 0.0)
+            terms = verify['msm_live_terms']
+            # a 256-bit term has a digit in all 16 windows, a 128-bit one in 8; per proof 135 of the former and 312 of the latter are expected at n = 16
+            # (10 zero-bit slots x (10 + 26), 10 one-bit slots x 2, 8 membership groups x (4 + 4), 3 per proof); a bucket's first term is a copy
+            nq = (n_log2 + 1) // 2
+            t256, t128 = 10 * 10 + nq * 4 + 3, 10 * 26 + 10 * 2 + nq * 4
+            adds = terms * (16 * t256 + 8 * t128) / (t256 + t128) - 2 * 16 * 8 * 65535 * ((B + vchunk - 1) // vchunk) / 2
+            ops = adds * 8 * MACS_PER_MODMUL
+            if bms > 0:
+                others['k_msm_bucket'] = {'units': int(adds), 'unit': 'niels additions into (window, group, digit) buckets, 8 products each (estimate from the live-term count)',
+                                          'live_terms': terms, 'ms_per_step': round(bms, 2), 'achieved': round(ops / (bms * 1e-3) / 1e12, 3), 'peak': VALU_MAD_PEAK_TOPS,
+                                          'frac': round(ops / (bms * 1e-3) / 1e12 / VALU_MAD_PEAK_TOPS, 4),
+                                          'note': 'one lane per bucket, lanes of a wave walk lists of equal length (buckets ordered by size); gathers of 128-byte entries'}
+        roofline['others'] = others
         cpu = None
         if not args.no_cpu_baseline:   # rank 0, at every N (the other ranks wait at the final barrier)
             sample = args.cpu_sample or 4 * host_cores()
@@ -318,7 +348,8 @@ def main():
             try:
                 latency = latency_table(Z, eng, args, nh, tg, th, sec, ring, nkeys, msg, sig, pk, which, seeds)
             except Exception as e:  # an auxiliary measurement must never cost the bench line
-                latency = {'error': repr(e)[:300]}
+                import traceback
+                latency = {'error': repr(e)[:300], 'where': traceback.format_exc()[-600:]}
             eng.set_chunk(min(args.chunk, B))
         ms_per_step = dt * 1e3 / args.steps
         line = {

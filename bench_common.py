@@ -25,6 +25,14 @@ HBM_PEAK_GBPS = 8000.0
 MACS_PER_MODMUL = 162
 
 
+# k_exp_commit_kt / k_exp_commit (csrc/k_p256.hip): multiplier instructions of ONE mixed complete P-256 addition in the shipped ISA (tools/isa_blocks.py:
+# 1872 v_mad_u64_u32 + 99 v_mul_lo_u32 for its 11 products) and the additions per lane: key-table path 12 (comb of G, first entry loaded) + 33 (key
+# table) + 13 (comb of h); per-proof table of R: 43 complete additions (12 products each, priced like 12/11 mixed ones) + 13
+EXP_ADD_MACS = 1872 + 99
+EXP_KT_ADDS = 12 + 33 + 13
+EXP_RTAB_ADDS = round(43 * 12 / 11) + 13
+
+
 def tom_commit_modmuls(comb_bits):
     """executed per commitment: 2 x ceil(256/W) table additions of a W-bit comb, 8 modmuls each"""
     return 2 * ((256 + comb_bits - 1) // comb_bits) * 8

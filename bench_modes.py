@@ -207,7 +207,7 @@ def latency_table(Z, eng, args, nh, tg, th, sec, ring, nkeys, msg, sig, pk, whic
     pin = Z.PinnedBuffer(int(max(sizes) * (304 + 336 * sec + 3392 * (sec // 2 + 4) + 384 * 20 + 32) + (64 << 20)))
     rings = [(nkeys, ring, msg, sig, pk, which, seeds)]
     if small_ring and small_ring != nkeys:
-        r2, m2, s2, p2, w2, sd2 = eng.synth_workload(args.seed + 1, small_ring, max(sizes))
+        r2, m2, s2, p2, w2, sd2 = eng.synth_workload(args.seed + 1, small_ring, min(max(sizes), small_ring))   # proof b's key sits at ring slot b mod n_keys
         rings.append((small_ring, r2, m2, s2, p2, w2, sd2))
     lanes0 = args.lanes
     eng.set_lanes(1)

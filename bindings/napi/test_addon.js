@@ -127,6 +127,11 @@ async function gpu() {
         const badKey = keyPair.publicKey.export({ type: 'spki', format: 'der' }).slice(-65)
         badKey[64] ^= 1
         await assert.rejects(proveSignatureList(params, msgHash, signature, badKey, 0, testArray), /point not in group/)
+        // where the reference dies with a TypeError of the runtime: `which` past the padded ring (gk.ts:162), a one-key ring (interpolate.ts:40)
+        await assert.rejects(proveSignatureList(params, msgHash, signature, keyPair.publicKey, testArray.length + 2, testArray), TypeError)
+        await assert.rejects(proveSignatureList(params, msgHash, signature, keyPair.publicKey, 0, [testArray[0]]), /Cannot mix BigInt/)
+        const pad = await proveSignatureList(params, msgHash, signature, keyPair.publicKey, testArray.length, testArray)   // 6 keys pad to 8: index 6 is keys[0]
+        assert.strictEqual(await verifySignatureList(params, msgHash, testArray, pad), true)
         // the batch form over the same ring
         const B = 5, ks = Array.from({ length: B }, (_, i) => keyAndSignature('message ' + i))
         const ring = await Promise.all(ks.map((k) => keyToInt(k.keyPair.publicKey)))
@@ -170,10 +175,10 @@ async function gpu() {
     assert.ok(/deserializ/.test(bv.errors[1].message) && /deserializ/.test(bv.errors[4].message) && bv.errors[0] === null)
     assert.throws(() => new SignatureProofList(broken[1]), /deserializ/)
     const otherSec = Buffer.from(proofs[3])
-    otherSec.writeUInt32BE(7, 8)                                                       // header claims secLevel 7 < 20 checked reps
+    otherSec.writeUInt32BE(7, 8)                                                       // header claims another secLevel than its structure holds
     const sv = eng.verifyBatch(Buffer.concat([wl.msg.slice(0, 32), wl.msg.slice(96, 128)]), [proofs[0], otherSec])
     assert.deepStrictEqual(sv, [true, false])
-    assert.ok(/security level/.test(sv.errors[1].message))
+    assert.ok(/deserializ/.test(sv.errors[1].message))                                 // exact codes: include/zkattest.h, tests/test_gpu_mutants.py
     const bad = Buffer.from(wl.pk.slice(0, 64))
     bad[63] ^= 1
     assert.throws(() => eng.proveBatch(wl.msg.slice(0, 32), wl.sig.slice(0, 64), bad, [0], wl.seeds.slice(0, 32)), /point not in group/)

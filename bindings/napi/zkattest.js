@@ -21,6 +21,17 @@ const native = require(process.env.ZKATTEST_NODE || path.join(__dirname, 'zkatte
 
 const STATUS_TEXT = { 1: 'point not in group', 2: 'invalid public key', 3: 'T[i] is at infinity', 4: 'T1 is at infinity', 5: 'P/Q/R is at infinity',
     6: "Points don't add up!", 7: 'R is at infinity', 8: 'params not found', 9: 'security level not achieved', 10: 'error deserializing' }
+// The two places where the reference dies with a TypeError of the JavaScript runtime instead of one of its own errors (include/zkattest.h):
+// `which` past the padded ring reads values[index].k of undefined (src/proofGK/gk.ts:162, engine status 14), and a ring of ONE key pads to
+// length 1, n = 0, where interpolate([], []) evaluates -x[0] % m with x[0] undefined (src/proofGK/interpolate.ts:40).
+function statusError(st) {
+    if (st === 14) return new TypeError("Cannot read properties of undefined (reading 'k')")
+    return new Error(STATUS_TEXT[st] || ('status ' + st))
+}
+function checkRingSize(nKeys, proving) {
+    if (nKeys === 1 && proving) throw new TypeError('Cannot mix BigInt and other types, use explicit conversions')
+    if (nKeys < 2) throw new RangeError('the key ring needs at least two keys (the reference cannot prove over fewer: interpolate.ts:40)')
+}
 
 // ---------------------------------------------------------------- big numbers and the two groups (host side, BigInt)
 const mod = (a, m) => { const r = a % m; return r < 0n ? r + m : r }
@@ -235,7 +246,7 @@ function defaultDevices() { return (process.env.ZKATTEST_DEVICES || '0').split('
 function unpackProofs(r, B) {
     const st = i32(r.status), off = u64(r.offsets), len = u64(r.lengths), out = []
     for (let b = 0; b < B; b++) {
-        if (st[b] !== 0) throw new Error(STATUS_TEXT[st[b]] || ('status ' + st[b]))
+        if (st[b] !== 0) throw statusError(st[b])
         out.push(r.proofs.slice(Number(off[b]), Number(off[b] + len[b])))   // views of one (page-locked) buffer, no copies
     }
     return out
@@ -258,7 +269,7 @@ function verdicts(r, slot) {
     for (let b = 0; b < slot.length; b++) {
         const k = slot[b]
         if (k < 0) { out.push(false); errors.push(new Error('error deserializing')); continue }
-        errors.push(st[k] !== 0 ? new Error(STATUS_TEXT[st[k]] || ('status ' + st[k])) : null)
+        errors.push(st[k] !== 0 ? statusError(st[k]) : null)
         out.push(st[k] === 0 && r.ok[k] === 1)
     }
     Object.defineProperty(out, 'errors', { value: errors })
@@ -415,11 +426,13 @@ async function proveSignatureListBatch(params, msgHashes, sigs, publicKeys, whic
     const raws = await Promise.all(publicKeys.map(rawPublicKey))
     for (const r of raws) if (r.length !== 65 || r[0] !== 4) throw new Error('invalid public key')
     const msg = Buffer.concat(msgHashes.map((m) => Buffer.from(m))), sig = Buffer.concat(sigs.map((s) => Buffer.from(s)))
+    checkRingSize(Buffer.isBuffer(keys) ? keys.length / 32 : keys.length, true)
     const proofs = await engineFor(params, keys).withRing((engine) => engine._proveNow(msg, sig, Buffer.concat(raws.map((r) => r.slice(1))), whichs))
     return proofs.map((b) => new SignatureProofList(b))
 }
 async function verifySignatureListBatch(params, msgHashes, keys, proofs) {
     const msg = Buffer.concat(msgHashes.map((m) => Buffer.from(m))), raw = proofs.map((p) => (p instanceof SignatureProofList ? p.bytes : p))
+    checkRingSize(Buffer.isBuffer(keys) ? keys.length / 32 : keys.length, false)
     return engineFor(params, keys).withRing((engine) => engine._verifyNow(msg, raw))
 }
 

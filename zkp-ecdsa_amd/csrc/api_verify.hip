@@ -239,7 +239,10 @@ zk_status VerifyJob::stage2(uint64_t chunk_no) {
     uint32_t flags[MSM_G_MAX], gsz = cnt;
     if (c->verify_batch_min && cnt >= c->verify_batch_min && M.cap) {
         MaybeScope t(timed, c, "v_msm_tom", s);
-        hipError_t e = run_msm(s, P, W, V, cnt, nq, M, G, flags, &gsz);
+        TimerRec sub{"+v_msm_bucket", nullptr, nullptr};   // a part of v_msm_tom ('+': not added to the total again)
+        if (timed) sub.e0 = get_event(c), sub.e1 = get_event(c);
+        hipError_t e = run_msm(s, P, W, V, cnt, nq, M, G, flags, &gsz, sub.e0, sub.e1);
+        if (timed && e == hipSuccess) c->trecs.push_back(sub);
         if (e != hipSuccess) {
             c->err = std::string("batched verification failed: ") + hipGetErrorString(e);
             return ZK_E_DEVICE;

@@ -151,7 +151,7 @@ static inline void timing_end(zk_ctx* c) {
         for (auto& p : c->last_timing)
             if (p.first == r.name) p.second += ms, found = true;
         if (!found) c->last_timing.push_back({r.name, ms});
-        c->last_total_ms += ms;
+        if (r.name[0] != '+') c->last_total_ms += ms;   // '+name': a part of another scope
     }
 }
 

@@ -352,7 +352,8 @@ size_t msm_workspace_bytes(uint32_t cap) {
 }
 // returns through host_flags[groups] (after a stream synchronisation): 1 = the Tom total of that group of proofs is the identity
 template <int C>
-static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t* host_flags, uint32_t* gsz_out) {
+static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t* host_flags, uint32_t* gsz_out,
+                            hipEvent_t ev0, hipEvent_t ev1) {
     typedef MsmShape<C> S;
     MsmDims D;
     D.g0 = V.C * VK, D.g1 = V.C * nq, D.g2 = V.C;
@@ -393,8 +394,10 @@ static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& 
         hipError_t e = rocprim::radix_sort_pairs(M.sort_tmp, tmp, M.ord_key, M.ord_key2, M.ord_id, M.ord_id2, S::nw * MSM_NBG, 0, 8, s);
         if (e != hipSuccess) return e;
     }
+    if (ev0) hipEventRecord(ev0, s);   // the bucket sums alone (bench.py: roofline.others)
     hipLaunchKernelGGL(k_msm_bucket<C>, dim3(S::nw * MSM_NBG / 256), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.ord_id2, M.buckets, M.counters + 32,
                        M.big_list, 8 * ((nmax + MSM_NBG - 1) / MSM_NBG) + 64);
+    if (ev1) hipEventRecord(ev1, s);
     hipLaunchKernelGGL(k_msm_bucket_big, dim3(MSM_NSLICE, 32), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.counters + 32, M.big_list, M.big_part);
     hipLaunchKernelGGL(k_msm_bucket_big2, dim3(64), dim3(256), 0, s, M.counters + 32, M.big_list, M.big_part, M.buckets);
     constexpr uint32_t bt = S::l1 < 256 ? S::l1 : 256;
@@ -411,6 +414,6 @@ static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& 
     return e;
 }
 hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t groups, uint32_t* host_flags,
-                   uint32_t* gsz_out) {
-    return groups == 64 ? run_msm_t<13>(s, P, W, V, count, nq, M, host_flags, gsz_out) : run_msm_t<16>(s, P, W, V, count, nq, M, host_flags, gsz_out);
+                   uint32_t* gsz_out, hipEvent_t ev0, hipEvent_t ev1) {
+    return groups == 64 ? run_msm_t<13>(s, P, W, V, count, nq, M, host_flags, gsz_out, ev0, ev1) : run_msm_t<16>(s, P, W, V, count, nq, M, host_flags, gsz_out, ev0, ev1);
 }
