@@ -156,7 +156,21 @@ zk_status zk_ctx_set_key_tables(zk_ctx *ctx, uint32_t on);
  * the lanes, chunk size, workspaces and mode it was planned with. */
 zk_status zk_ctx_set_ring_fold(zk_ctx *ctx, uint32_t matrix_pipe);
 
-/* Upper bound of one proof's ZKA1 size for the current params/ring. */
+/* Wire layout of the proofs (default ZK_WIRE_ZKA1).  ZK_WIRE_ZKA1P is ZKA1 with every Tom-256 coordinate in the reference's own 33 bytes
+ * instead of 36 (src/curves/edwards.ts:194-203) and the magic "ZK1P": every run of Tom points in the layout holds an even number of points, so
+ * all other fields stay 4-byte aligned; 5.3 % fewer bytes (160.0 instead of 169.0 KB per proof at secLevel 80, n = 16), which is what the
+ * host-pointer entry points are bound by (PCIe).  The prover's writers emit the chosen layout directly (every entry point, device pointers
+ * included); the verifier expands packed proofs on the device, chunk by chunk, before its unchanged kernels read them (every entry point; a
+ * device-pointer call reads one offset per chunk back first).  Verdicts and statuses are those of the ZKA1 form of the same proofs.
+ * zk_proof_pack / zk_proof_unpack convert single proofs on the host; the JSON converters accept both layouts and write ZKA1. */
+enum { ZK_WIRE_ZKA1 = 0, ZK_WIRE_ZKA1P = 1 };
+zk_status zk_ctx_set_wire(zk_ctx *ctx, uint32_t wire);
+/* host-side conversions of ONE proof; *out_len is always set to the required size, ZK_E_BUFFER when out_cap is too small, ZK_E_BAD_ENCODING
+ * when the input is not a structurally complete proof of its layout (header, length, challenge bits) */
+zk_status zk_proof_pack(const uint8_t *zka1, uint64_t len, uint8_t *out, uint64_t out_cap, uint64_t *out_len);
+zk_status zk_proof_unpack(const uint8_t *zka1p, uint64_t len, uint8_t *out, uint64_t out_cap, uint64_t *out_len);
+
+/* Upper bound of one proof's size, in the context's wire layout, for the current params/ring. */
 uint64_t zk_proof_max_size(const zk_ctx *ctx);
 
 /* Page-locked host memory for the big buffers of the host-pointer entry points (`out` of zk_prove_batch, `proofs` of

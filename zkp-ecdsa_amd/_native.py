@@ -17,7 +17,7 @@ SYMBOLS = [
     'zk_proof_to_json', 'zk_proof_from_json', 'zk_host_alloc', 'zk_host_free', 'zk_ctx_set_host_taper', 'zk_ctx_set_slice', 'zk_ctx_set_mode', 'zk_ring_digest', 'zk_hardened_h',
     'zk_pool_create', 'zk_pool_destroy', 'zk_pool_size', 'zk_pool_ctx', 'zk_pool_last_error', 'zk_pool_ring_transport', 'zk_pool_shard',
     'zk_pool_set_params', 'zk_pool_set_ring', 'zk_pool_prove_batch', 'zk_pool_verify_batch',
-    'zk_pool_host_alloc', 'zk_pool_host_free', 'zk_pool_numa_node', 'zk_pool_test_locality', 'zk_pool_shard_ms', 'zk_pool_test_fail_submit', 'zk_ctx_copy_probe', 'zk_pool_prove_batch_device', 'zk_pool_device_alloc', 'zk_pool_device_free',
+    'zk_pool_host_alloc', 'zk_pool_host_free', 'zk_pool_numa_node', 'zk_pool_test_locality', 'zk_pool_shard_ms', 'zk_pool_test_fail_submit', 'zk_ctx_copy_probe', 'zk_ctx_set_wire', 'zk_proof_pack', 'zk_proof_unpack', 'zk_pool_prove_batch_device', 'zk_pool_device_alloc', 'zk_pool_device_free',
     'zk_prove_submit', 'zk_prove_submit_device', 'zk_prove_wait', 'zk_verify_submit', 'zk_verify_wait', 'zk_test_counter', 'zk_ctx_set_key_tables',
     'zk_proofs_to_json_batch', 'zk_proofs_from_json_batch', 'zk_ctx_set_ring_fold',
     'zk_pool_prove_submit', 'zk_pool_prove_wait', 'zk_pool_verify_submit', 'zk_pool_verify_wait', 'zk_ctx_set_verify_groups',
@@ -126,6 +126,9 @@ def lib():
         L.zk_pool_device_alloc.restype = vp
         L.zk_pool_device_free.argtypes = [vp, i32, vp]
         L.zk_pool_device_free.restype = None
+        L.zk_ctx_set_wire.argtypes = [vp, u32]
+        L.zk_proof_pack.argtypes = [C.c_char_p, u64, vp, u64, C.POINTER(u64)]
+        L.zk_proof_unpack.argtypes = [C.c_char_p, u64, vp, u64, C.POINTER(u64)]
         L.zk_ctx_copy_probe.argtypes = [vp, u32, C.c_size_t, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.zk_pool_test_fail_submit.argtypes = [vp, i32]
         L.zk_pool_test_fail_submit.restype = None
@@ -186,6 +189,29 @@ def hardened_h(tag=b''):
     if rc:
         raise ZkError(rc)
     return a.raw, b.raw
+
+
+def _wire_convert(fn, raw):
+    raw = bytes(raw)
+    n = C.c_uint64()
+    rc = fn(raw, len(raw), None, 0, C.byref(n))
+    if rc not in (0, 12):
+        raise ZkError(rc, 'not a structurally complete proof of that layout')
+    out = C.create_string_buffer(n.value)
+    rc = fn(raw, len(raw), out, n.value, C.byref(n))
+    if rc:
+        raise ZkError(rc, 'not a structurally complete proof of that layout')
+    return out.raw[:n.value]
+
+
+def pack_proof(zka1):
+    """ZKA1 -> ZKA1P (33-byte Tom coordinates): zk_proof_pack"""
+    return _wire_convert(lib().zk_proof_pack, zka1)
+
+
+def unpack_proof(zka1p):
+    """ZKA1P -> ZKA1: zk_proof_unpack"""
+    return _wire_convert(lib().zk_proof_unpack, zka1p)
 
 
 def write_json(proof_bytes):
@@ -334,6 +360,10 @@ class Engine:
 
     def set_ring_fold(self, matrix_pipe):
         self._chk(self.L.zk_ctx_set_ring_fold(self.h, 1 if matrix_pipe else 0))
+
+    def set_wire(self, packed):
+        """zk_ctx_set_wire: False / 0 = ZKA1, True / 1 = ZKA1P (33-byte Tom coordinates) for what the prover emits and the verifier is handed"""
+        self._chk(self.L.zk_ctx_set_wire(self.h, 1 if packed else 0))
 
     def set_slice(self, proofs):
         """Proofs per PointAdd slice of the prover (0 = automatic: 4096 with page-locked output, none otherwise)."""

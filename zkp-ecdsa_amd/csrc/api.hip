@@ -150,7 +150,7 @@ extern "C" void zk_ctx_destroy(zk_ctx* c) {
     hipFree(c->P.tom_tab_g), hipFree(c->P.tom_tab_h), hipFree(c->tom_tab_gen), hipFree(c->P.pfix_G), hipFree(c->P.pfix_H);
     hipFree(c->gk_kdig), hipFree(c->gk_edig), hipFree(c->ktab), hipFree(c->ktab_ok);
     hipFree(c->tab_scratch), hipFree(c->gk_etab), hipFree(c->d_flag), hipFree(c->ring_mem), hipFree(c->ring_digest);
-    hipFree(c->io_buf), hipFree(c->in_buf);
+    hipFree(c->io_buf), hipFree(c->in_buf), hipFree(c->unp_buf), hipFree(c->unp_off);
     for (int l = 0; l < ZK_MAX_LANES; l++) {
         hipFree(c->pl[l].arena), hipFree(c->pl[l].d_totals), hipFree(c->vl[l].arena);
         if (c->pl[l].h_scan) hipHostFree(c->pl[l].h_scan);
@@ -371,6 +371,13 @@ extern "C" zk_status zk_ring_digest(zk_ctx* c, uint8_t digest[32]) {
         for (int j = 0; j < 4; j++) digest[4 * i + j] = (uint8_t)(w[i] >> (24 - 8 * j));
     return ZK_OK;
 }
+extern "C" zk_status zk_ctx_set_wire(zk_ctx* c, uint32_t wire) {
+    if (!c || (wire != ZK_WIRE_ZKA1 && wire != ZK_WIRE_ZKA1P)) return ZK_E_ARG;
+    if (c->stream_busy) return busy_refusal(c);
+    if (wire != c->wire) c->ws_C = 0;   // the lanes' workspaces carry the layout
+    c->wire = wire;
+    return ZK_OK;
+}
 extern "C" zk_status zk_ctx_set_slice(zk_ctx* c, uint32_t proofs) {
     if (!c || (proofs && proofs < 64)) return ZK_E_ARG;
     if (c->stream_busy) return busy_refusal(c);
@@ -389,12 +396,9 @@ extern "C" zk_status zk_ctx_set_lanes(zk_ctx* c, uint32_t lanes) {
     c->lanes = lanes;
     return ZK_OK;
 }
-static uint64_t proof_size_host(uint32_t sec, uint32_t n, uint32_t z) {
-    return (uint64_t)ZK_FIXED + (uint64_t)ZK_REP_HEAD * sec + (uint64_t)ZK_PADD_SZ * z + (uint64_t)n * (4 * 72 + 3 * 32) + 32;
-}
 extern "C" uint64_t zk_proof_max_size(const zk_ctx* c) {
     if (!c || !c->params_set || !c->N) return 0;
-    return proof_size_host(c->P.sec, c->n, c->P.sec);
+    return wire_proof_size(wire_make(c->wire == ZK_WIRE_ZKA1P), c->P.sec, c->n, c->P.sec);
 }
 
 // ------------------------------------------------------------------ workspace arena
@@ -493,6 +497,7 @@ zk_status ensure_workspace(zk_ctx* c, uint32_t C, uint32_t nlanes) {
         }
         L.W.ring = Soa{c->ring_mem, (uint32_t)c->N};
         L.W.hardened = c->mode == ZK_MODE_HARDENED, L.W.ring_digest = c->ring_digest;
+        L.W.wire = wire_make(c->wire == ZK_WIRE_ZKA1P);
         L.W.ktab = c->ktab, L.W.ktab_ok = c->ktab_ok;
         L.W.gk_kdig = c->gk_mfma ? c->gk_kdig : nullptr;
         L.W.gk_edig = c->gk_mfma && L.W.gk_adig ? c->gk_edig : nullptr;

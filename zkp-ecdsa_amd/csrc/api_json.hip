@@ -23,6 +23,7 @@
 #include <string>
 #include <vector>
 #include "../../include/zkattest.h"
+#include "wire.h"
 
 namespace {
 // ---------------------------------------------------------------- writer
@@ -658,8 +659,68 @@ static zk_status proof_to_json_impl(const uint8_t* proof, uint64_t len, char* ou
     return ZK_OK;
 }
 
+// ---- ZKA1 <-> ZKA1P on the host (one proof): the same fields in the same order, Tom-256 coordinates 36 <-> 33 bytes (include/zkattest.h)
+static zk_status convert_wire(const uint8_t* in, uint64_t len, bool to_packed, uint8_t* out, uint64_t cap, uint64_t* out_len) {
+    if (!in || !out_len) return ZK_E_ARG;
+    const Wire src = wire_make(!to_packed), dst = wire_make(to_packed);
+    auto be32 = [](const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; };
+    if (len < ZK_HDR || memcmp(in, to_packed ? "ZKA1" : "ZK1P", 4) != 0) return ZK_E_BAD_ENCODING;
+    const uint32_t total = be32(in + 4), sec = be32(in + 8), n = be32(in + 12);
+    if (total != len || sec > ZK_MAXSEC || n > 63) return ZK_E_BAD_ENCODING;
+    uint32_t z = 0;
+    auto bit = [&](uint32_t i) { return (in[31 - i / 8] >> (i % 8)) & 1u; };
+    for (uint32_t i = 0; i < 128; i++) {
+        if (i >= sec && bit(i)) return ZK_E_BAD_ENCODING;
+        if (i < sec && !bit(i)) z++;
+    }
+    if (len != wire_proof_size(src, sec, n, z)) return ZK_E_BAD_ENCODING;
+    const uint64_t need = wire_proof_size(dst, sec, n, z);
+    *out_len = need;
+    if (!out || cap < need) return ZK_E_BUFFER;
+    const uint8_t* p = in;
+    uint8_t* q = out;
+    bool bad = false;
+    auto plain = [&](size_t nb) { memcpy(q, p, nb), p += nb, q += nb; };
+    auto coords = [&](uint32_t cnt) {
+        for (uint32_t k = 0; k < cnt; k++) {
+            if (to_packed) {
+                bad = bad || p[0] || p[1] || p[2];   // a value of 2^264 or more has no 33-byte form (and is no coordinate)
+                memcpy(q, p + 3, 33), p += 36, q += 33;
+            } else {
+                q[0] = q[1] = q[2] = 0;
+                memcpy(q + 3, p, 33), p += 33, q += 36;
+            }
+        }
+    };
+    plain(ZK_HDR + 128), coords(4);
+    for (uint32_t i = 0; i < sec; i++) {
+        plain(64), coords(4), plain(128);
+        if (!bit(i)) {
+            coords(8);
+            for (int m = 0; m < 4; m++) coords(12), plain(224);
+            for (int e = 0; e < 2; e++) coords(4), plain(96);
+        }
+    }
+    coords(8 * n), plain(32 * (3 * (size_t)n + 1));
+    if (bad || (uint64_t)(p - in) != len || (uint64_t)(q - out) != need) return ZK_E_BAD_ENCODING;
+    memcpy(out, to_packed ? "ZK1P" : "ZKA1", 4);
+    out[4] = (uint8_t)(need >> 24), out[5] = (uint8_t)(need >> 16), out[6] = (uint8_t)(need >> 8), out[7] = (uint8_t)need;
+    return ZK_OK;
+}
+extern "C" zk_status zk_proof_pack(const uint8_t* zka1, uint64_t len, uint8_t* out, uint64_t cap, uint64_t* out_len) { return convert_wire(zka1, len, true, out, cap, out_len); }
+extern "C" zk_status zk_proof_unpack(const uint8_t* zka1p, uint64_t len, uint8_t* out, uint64_t cap, uint64_t* out_len) { return convert_wire(zka1p, len, false, out, cap, out_len); }
+
 extern "C" zk_status zk_proof_to_json(const uint8_t* proof, uint64_t len, char* out, uint64_t cap, uint64_t* out_len) {
     try {
+        if (proof && len >= 4 && memcmp(proof, "ZK1P", 4) == 0) {   // the packed layout: expanded first, the text is the same
+            static thread_local std::vector<uint8_t> tmp;
+            uint64_t need = 0;
+            zk_status zs = convert_wire(proof, len, false, nullptr, 0, &need);
+            if (zs != ZK_E_BUFFER) return zs ? zs : ZK_E_BAD_ENCODING;
+            tmp.resize(need);
+            if ((zs = convert_wire(proof, len, false, tmp.data(), need, &need))) return zs;
+            return proof_to_json_impl(tmp.data(), need, out, cap, out_len);
+        }
         return proof_to_json_impl(proof, len, out, cap, out_len);
     } catch (...) {
         return ZK_E_BUFFER;
@@ -849,6 +910,19 @@ static zk_status batch_convert(uint64_t n, uint8_t* out, uint64_t cap, uint64_t*
     }
     return overflow ? ZK_E_BUFFER : ZK_OK;   // out_off[] is complete either way: out_off[n] is the size to come back with
 }
+// proof_text for either layout: a ZKA1P proof is expanded into a per-thread scratch first (the text does not know the layout)
+template <class Sink>
+static bool proof_text_any(const uint8_t* proof, uint64_t len, Sink& sink) {
+    if (len >= 4 && memcmp(proof, "ZK1P", 4) == 0) {
+        static thread_local std::vector<uint8_t> tmp;
+        uint64_t need = 0;
+        if (convert_wire(proof, len, false, nullptr, 0, &need) != ZK_E_BUFFER) return false;
+        tmp.resize(need);
+        if (convert_wire(proof, len, false, tmp.data(), need, &need) != ZK_OK) return false;
+        return proof_text(tmp.data(), need, sink);
+    }
+    return proof_text(proof, len, sink);
+}
 // to JSON: the exact length of every text first (a traversal that only counts), a prefix sum, then every thread writes its proofs'
 // texts straight into their final place -- no scratch copies.
 extern "C" zk_status zk_proofs_to_json_batch(uint64_t n, const uint8_t* proofs, const uint64_t* proof_off, char* out, uint64_t out_cap, uint64_t* text_off,
@@ -865,7 +939,7 @@ extern "C" zk_status zk_proofs_to_json_batch(uint64_t n, const uint8_t* proofs, 
                 if (i0 >= n) break;
                 for (uint64_t i = i0; i < i0 + 8 && i < n; i++) {
                     LenSink m;
-                    const bool good = proof_text(proofs + proof_off[i], proof_off[i + 1] - proof_off[i], m);
+                    const bool good = proof_text_any(proofs + proof_off[i], proof_off[i + 1] - proof_off[i], m);
                     per_proof_status[i] = good ? ZK_OK : ZK_E_BAD_ENCODING;
                     text_off[i + 1] = good ? m.n : 0;   // lengths for now
                 }
@@ -882,7 +956,7 @@ extern "C" zk_status zk_proofs_to_json_batch(uint64_t n, const uint8_t* proofs, 
                 for (uint64_t i = i0; i < i0 + 8 && i < n; i++) {
                     if (per_proof_status[i]) continue;
                     BufSink b{out + text_off[i]};
-                    proof_text(proofs + proof_off[i], proof_off[i + 1] - proof_off[i], b);
+                    proof_text_any(proofs + proof_off[i], proof_off[i + 1] - proof_off[i], b);
                 }
             }
         });

@@ -26,7 +26,8 @@ struct zk_job {
     ProveJob pj;
     VerifyJob vj;
     void *d_in = nullptr, *d_stage = nullptr, *h_pin = nullptr;   // device inputs / results, device proof bytes, pinned staging
-    size_t d_in_bytes = 0, d_stage_bytes = 0, h_pin_bytes = 0;
+    void* d_unp = nullptr;                // verify jobs on ZKA1P input: the expanded proofs (d_stage receives the packed bytes)
+    size_t d_in_bytes = 0, d_stage_bytes = 0, h_pin_bytes = 0, d_unp_bytes = 0;
     size_t in_bytes = 0;                  // the input block at the head of d_in / h_pin
     hipEvent_t inputs_ready = nullptr, done = nullptr;
     hipEvent_t lane_ev[ZK_MAX_LANES] = {}, copy_ev[ZK_MAX_LANES] = {};
@@ -86,6 +87,7 @@ static void job_free(zk_job* j) {
     zk_ctx* c = j->c;
     if (j->d_in) c->spare_dev.push_back({j->d_in, j->d_in_bytes});
     if (j->d_stage) c->spare_dev.push_back({j->d_stage, j->d_stage_bytes});
+    if (j->d_unp) c->spare_dev.push_back({j->d_unp, j->d_unp_bytes});
     if (j->h_pin) c->spare_pinned.push_back({j->h_pin, j->h_pin_bytes});
     if (j->inputs_ready) hipEventDestroy(j->inputs_ready);
     if (j->done) hipEventDestroy(j->done);
@@ -472,11 +474,15 @@ extern "C" zk_status zk_verify_submit(zk_ctx* c, uint64_t B, const uint8_t* msg,
     };
     const size_t o_msg = take(32 * B), o_off = take(8 * (B + 1)), o_seed = take(32 * B + 32);
     j->in_bytes = vseeds ? top : o_seed;   // without caller seeds the seed area is filled on the device
+    const bool packed = c->wire == ZK_WIRE_ZKA1P;
+    const uint32_t Cj = (uint32_t)std::min<uint64_t>(c->chunk, B);
+    const size_t o_uoff = packed ? take(8 * unpack_off_entries(B, Cj)) : 0;
     j->res_a_off = take(B), j->res_a_bytes = B, j->user_a = ok;
     j->res_b_off = take(4 * B), j->res_b_bytes = 4 * B, j->user_b = status;
     const size_t blk = top + 256;
     if ((zs = get_dev(c, blk, &j->d_in, &j->d_in_bytes)) || (zs = get_pinned(c, blk, &j->h_pin, &j->h_pin_bytes)) ||
-        (zs = get_dev(c, total + 64, &j->d_stage, &j->d_stage_bytes)) || (zs = job_events(j))) {
+        (zs = get_dev(c, total + 64, &j->d_stage, &j->d_stage_bytes)) || (packed && (zs = get_dev(c, unpack_stage_bytes(B, total, Cj), &j->d_unp, &j->d_unp_bytes))) ||
+        (zs = job_events(j))) {
         job_free(j);
         return zs;
     }
@@ -500,9 +506,16 @@ extern "C" zk_status zk_verify_submit(zk_ctx* c, uint64_t B, const uint8_t* msg,
     VerifyJob& J = j->vj;
     J.c = c, J.B = B, J.d_msg = d + o_msg, J.d_proofs = (const uint8_t*)j->d_stage, J.d_off = (const uint64_t*)(d + o_off), J.d_vseeds = d + o_seed;
     J.d_ok = d + j->res_a_off, J.d_status = (int32_t*)(d + j->res_b_off), J.host_src = proofs, J.host_off = off, J.timed = false, J.inputs_ready = j->inputs_ready;
-    J.C = (uint32_t)std::min<uint64_t>(c->chunk, B);
+    J.C = Cj;
     J.plan = make_chunk_plan(B, J.C, 1, false);
     J.NL = c->lanes;
+    if (packed) {   // d_stage receives the packed bytes, every chunk is expanded into d_unp before the kernels read it
+        J.d_packed = (const uint8_t*)j->d_stage, J.d_poff = (const uint64_t*)(d + o_off), J.d_proofs = (const uint8_t*)j->d_unp, J.d_uoff = (uint64_t*)(d + o_uoff);
+        if ((zs = J.plan_unpack())) {
+            job_free(j);
+            return zs;
+        }
+    }
     const bool idle = c->jobs.empty();
     if (idle) c->next_lane_base = 0;
     J.lane_base = c->next_lane_base;

@@ -114,14 +114,28 @@ __global__ void k_default_vseeds(uint64_t B, const uint8_t* master, uint8_t* out
     for (int i = 0; i < 8; i++) ((uint32_t*)out)[8 * b + i] = bswap32(h[i]);
 }
 
+zk_status VerifyJob::plan_unpack() {
+    if (!d_packed) return ZK_OK;
+    const uint64_t nchunks = plan.size();
+    std::vector<uint64_t> pfirst(nchunks);
+    for (uint64_t k = 0; k < nchunks; k++) {
+        if (host_off) pfirst[k] = host_off[plan[k].first];
+        else HIPCHK(c, hipMemcpy(&pfirst[k], d_poff + plan[k].first, 8, hipMemcpyDeviceToHost));   // device-pointer call: one word per chunk
+    }
+    ubase.resize(nchunks);
+    for (uint64_t k = 0; k < nchunks; k++)   // expansion is at most 36 / 33 per proof, and 32 bytes for a proof that is shorter than its header
+        ubase[k] = (((pfirst[k] * 12 + 10) / 11 + 32 * plan[k].first + 256 * k) + 255) & ~(uint64_t)255;
+    return ZK_OK;
+}
 zk_status VerifyJob::enqueue_h2d() {
     if (!host_src) return ZK_OK;
+    uint8_t* dst = d_packed ? (uint8_t*)d_packed : (uint8_t*)d_proofs;
     const uint64_t nchunks = plan.size();
     arrived.assign(nchunks, nullptr);
     for (uint64_t k = 0; k < nchunks; k++) {
         uint64_t b0 = host_off[plan[k].first], b1 = host_off[plan[k].first + plan[k].cnt];
         if (hipEventCreateWithFlags(&arrived[k], hipEventDisableTiming) != hipSuccess ||
-            (b1 > b0 && hipMemcpyAsync((uint8_t*)d_proofs + b0, host_src + b0, b1 - b0, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess) ||
+            (b1 > b0 && hipMemcpyAsync(dst + b0, host_src + b0, b1 - b0, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess) ||
             hipEventRecord(arrived[k], c->copy_stream) != hipSuccess) {
             c->err = "host-to-device copy of the proofs failed";
             return ZK_E_DEVICE;
@@ -146,8 +160,10 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
         c->err = "hipStreamWaitEvent failed";
         return ZK_E_DEVICE;
     }
+    const uint64_t* d_off = off_of(chunk_no);   // shadows the member: the chunk's own offsets when the input is packed
     {
         MaybeScope t(timed, c, "v_parse_validate", s);
+        if (d_packed) launch_v_unpack(s, V.sec, cnt, d_packed, d_poff, first, ubase[chunk_no], (uint8_t*)d_proofs, d_uoff + first + chunk_no);
         launch_v_header_validate(s, V, cnt, d_proofs, d_off, first);
     }
     {
@@ -303,6 +319,27 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
     J.C = (uint32_t)std::min<uint64_t>(c->chunk, B);
     J.plan = make_chunk_plan(B, J.C, 1, false);   // uniform: see ctx.h
     J.NL = (uint32_t)std::min<size_t>(c->lanes, J.plan.size());   // chunks rotate over NL streams / workspaces
+    if (c->wire == ZK_WIRE_ZKA1P) {   // the proofs handed in are packed: every chunk is expanded into the context's staging first
+        uint64_t total = 0;
+        if (host_off) total = host_off[B];
+        else HIPCHK(c, hipMemcpy(&total, d_off + B, 8, hipMemcpyDeviceToHost));
+        const size_t need = unpack_stage_bytes(B, total, J.C), ents = unpack_off_entries(B, J.C);
+        if (need > c->unp_bytes) {
+            if (c->unp_buf) HIPCHK(c, hipFree(c->unp_buf));
+            c->unp_buf = nullptr, c->unp_bytes = 0;
+            HIPCHK(c, hipMalloc(&c->unp_buf, need));
+            c->unp_bytes = need;
+        }
+        if (ents > c->unp_off_entries) {
+            if (c->unp_off) HIPCHK(c, hipFree(c->unp_off));
+            c->unp_off = nullptr, c->unp_off_entries = 0;
+            HIPCHK(c, hipMalloc((void**)&c->unp_off, 8 * ents));
+            c->unp_off_entries = ents;
+        }
+        J.d_packed = d_proofs, J.d_poff = d_off, J.d_proofs = (const uint8_t*)c->unp_buf, J.d_uoff = c->unp_off;
+        zk_status zp = J.plan_unpack();
+        if (zp) return zp;
+    }
     zk_status zs = ensure_workspace(c, J.C, J.NL);
     if (zs) return zs;
     zs = ensure_vworkspace(c, J.C, J.NL);

@@ -85,6 +85,11 @@ struct zk_ctx {
     size_t io_bytes = 0;           // multi-GB hipMalloc/hipFree per call costs as much as the transfer itself)
     void* in_buf = nullptr;        // device copies of the small per-proof arrays of the host-pointer entry points (inputs,
     size_t in_bytes = 0;           // offsets, statuses, verdicts), grow-only for the same reason
+    uint32_t wire = 0;             // zk_ctx_set_wire: 0 = ZKA1 (36-byte Tom coordinates), 1 = ZKA1P (33-byte): what the prover emits and the verifier is handed
+    void* unp_buf = nullptr;       // ZKA1P input of the synchronous verify calls: staging of the expanded proofs and their per-chunk offsets (grow-only)
+    size_t unp_bytes = 0;
+    uint64_t* unp_off = nullptr;
+    size_t unp_off_entries = 0;
     uint32_t host_taper = 1;       // host-pointer calls on page-locked buffers: tapered chunk plan (zk_ctx_set_host_taper)
     uint32_t slice = 0;            // proofs per PointAdd slice of the prover (zk_ctx_set_slice): 0 = 4096 with a page-locked sink, else none
     // streamed calls (api_stream.hip): jobs submitted and not yet waited for, in submission order

@@ -76,14 +76,13 @@ __host__ __device__ static inline uint32_t rtab_words(uint32_t bits) { return rt
 // ------------------------------------------------------------------ ZKA1 layout constants (bytes)
 #define ZK_PB 32
 #define ZK_TB 36
-#define ZK_HDR 32
 #define ZK_FIXED (ZK_HDR + 2 * 64 + 2 * 72)  // header, R, comS1, keyXcom, keyYcom = 304
 #define ZK_REP_HEAD (64 + 72 + 72 + 4 * 32)    // 336
 #define ZK_MULT_SZ (6 * 72 + 7 * 32)            // 656
 #define ZK_EQ_SZ (2 * 72 + 3 * 32)              // 240
 #define ZK_PADD_SZ (4 * 72 + 4 * ZK_MULT_SZ + 2 * ZK_EQ_SZ)  // 3392
+#include "wire.h"   // struct Wire: the two byte layouts of a proof (ZKA1 / ZKA1P)
 #define ZK_ST_T_INF_LATE 103  // internal: T_i = identity found by normalisation (resolved to a public status in k_scan)
-#define ZK_MAXSEC 128
 #define ZK_MAXN 32
 
 // list A: per proof 2 + 2*sec Tom commitments (pkX, pkY, Tx_i, Ty_i);  list B: per zero-bit rep 39 points
@@ -162,6 +161,7 @@ struct Workspace {
     uint32_t N;
     uint32_t hardened;           // zk_ctx_set_mode: the GK challenge also hashes the statement (ring digest, msgHash, R, keyXcom)
     const uint32_t* ring_digest; // [8] SHA-256 words of the padded ring (k_hash.hip: launch_ring_digest), owned by ctx
+    Wire wire;                   // layout the prover's writers emit (zk_ctx_set_wire)
     RngCtx rng;
 };
 
@@ -219,6 +219,8 @@ struct VWork {
     Soa3 pacc;                                 // [C*4]
     Soa clx, cly;                              // Clambda (Montgomery affine)
 };
+// ZKA1P -> ZKA1 for `count` proofs from proof `first` on: uoff[0 .. count] = their offsets in `out`, starting at `base` (k_verify.hip)
+void launch_v_unpack(hipStream_t s, uint32_t sec, uint32_t count, const uint8_t* packed, const uint64_t* poff, uint64_t first, uint64_t base, uint8_t* out, uint64_t* uoff);
 void launch_v_header_validate(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_front(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* msg, uint64_t first);
 void launch_v_challenges_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, const uint8_t* msg, uint64_t first);
@@ -490,3 +492,22 @@ ZK_DEV uint32_t zeros_below(const uint32_t* chal, uint32_t i) {  // number of 0 
     return i - ones;
 }
 ZK_DEV uint64_t rep_offset(const uint32_t* chal, uint32_t i) { return ZK_FIXED + (uint64_t)ZK_REP_HEAD * i + (uint64_t)ZK_PADD_SZ * zeros_below(chal, i); }
+ZK_DEV uint64_t rep_offset_w(const Wire& w, const uint32_t* chal, uint32_t i) { return w.fixed + (uint64_t)w.rep_head * i + (uint64_t)w.padd * zeros_below(chal, i); }
+// Two Tom points (x0, y0, x1, y1: canonical plain) as 4 x 33 big-endian bytes = 33 dwords at a 4-byte aligned address (ZKA1P).  Byte k of a
+// coordinate's string: k = 0 the top byte (bits 256..263), then the eight words big-endian; all shifts are constants after unrolling.
+ZK_DEV uint32_t tomc_byte(const uint32_t w[9], int k) { return k == 0 ? (w[8] & 0xffu) : ((w[8 - ((k - 1) / 4 + 1)] >> (8 * (3 - (k - 1) % 4))) & 0xffu); }
+ZK_DEV void store_tom_pair_packed(uint8_t* p4, const Fe<ModT, 1>& x0, const Fe<ModT, 1>& y0, const Fe<ModT, 1>& x1, const Fe<ModT, 1>& y1) {
+    uint32_t w[4][9];
+    words_from_limbs<9>(w[0], x0.l), words_from_limbs<9>(w[1], y0.l), words_from_limbs<9>(w[2], x1.l), words_from_limbs<9>(w[3], y1.l);
+    uint32_t* q = (uint32_t*)p4;
+#pragma unroll
+    for (int d = 0; d < 33; d++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int pos = 4 * d + b;
+            v |= tomc_byte(w[pos / 33], pos % 33) << (8 * b);
+        }
+        q[d] = v;
+    }
+}

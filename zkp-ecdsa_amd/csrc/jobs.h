@@ -81,6 +81,12 @@ struct VerifyJob {
     const uint8_t* d_vseeds = nullptr;
     uint8_t* d_ok = nullptr;
     int32_t* d_status = nullptr;
+    // ZKA1P input (zk_ctx_set_wire): the caller's bytes / offsets are the PACKED ones; every chunk is expanded into d_proofs (staging owned by
+    // the caller of the job) by launch_v_unpack and the kernels read the chunk's own offset array d_uoff + first + k (k = chunk number)
+    const uint8_t* d_packed = nullptr;
+    const uint64_t* d_poff = nullptr;
+    uint64_t* d_uoff = nullptr;          // [B + chunks + 1]
+    std::vector<uint64_t> ubase;         // per chunk: where its expanded proofs start in d_proofs
     const uint8_t* host_src = nullptr;   // page-locked source of the proof bytes (or nullptr) and the host copy of the offsets:
     const uint64_t* host_off = nullptr;  // the bytes of chunk k travel on c->copy_stream while earlier chunks are being verified
     uint32_t C = 0, NL = 1;
@@ -95,8 +101,13 @@ struct VerifyJob {
             if (e) hipEventDestroy(e);
     }
     uint32_t lane_of(uint64_t k) const { return (uint32_t)((lane_base + k) % NL); }
+    const uint64_t* off_of(uint64_t k) const { return d_packed ? d_uoff + k : d_off; }   // what the kernels index with [first + p]
+    zk_status plan_unpack();             // ubase from the packed offsets of the chunks' first proofs (host copy, or read back from d_poff)
     zk_status enqueue_h2d();             // all chunks' bytes up front, one event per chunk
     zk_status stage1(uint64_t chunk_no);
     zk_status stage2(uint64_t chunk_no);
 };
 zk_status ensure_vworkspace(zk_ctx* c, uint32_t C, uint32_t nlanes);   // api_verify.hip
+// bytes of the expansion staging and entries of the offset array for a ZKA1P batch of B proofs, `total` packed bytes, chunks of C proofs
+static inline size_t unpack_stage_bytes(uint64_t B, uint64_t total, uint32_t C) { return (size_t)((total * 12 + 10) / 11 + 32 * B + 256 * (B / (C ? C : 1) + 2) + 64); }
+static inline size_t unpack_off_entries(uint64_t B, uint32_t C) { return (size_t)(B + B / (C ? C : 1) + 4); }

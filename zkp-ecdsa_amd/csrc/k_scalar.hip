@@ -50,9 +50,7 @@ void launch_lista_scalars(hipStream_t s, const Workspace& W, uint32_t count) {
 
 // ---------------------------------------------------------------- compaction: sizes, offsets, item list
 ZK_DEV uint32_t count_zero_bits(const uint32_t* chal, uint32_t sec) { return zeros_below(chal, sec); }
-ZK_DEV uint64_t proof_size(uint32_t sec, uint32_t n, uint32_t z) {
-    return (uint64_t)ZK_FIXED + (uint64_t)ZK_REP_HEAD * sec + (uint64_t)ZK_PADD_SZ * z + (uint64_t)n * (4 * 72 + 3 * 32) + 32;
-}
+
 // Single workgroup.  256 threads, not 1024: the host WAITS for this kernel, and a 16-wave workgroup needs sixteen free wave
 // slots on one CU at the same moment -- under the other lane's register-heavy commitment kernels it was seen to starve for
 // 60 ms (tools/exp_io_timeline.py), leaving its lane idle; four waves slip in as soon as any wave retires.
@@ -80,7 +78,7 @@ __global__ void __launch_bounds__(SCAN_T) k_scan(Workspace W, uint32_t count, ui
         if (st != ZK_OK) z = 0;
         W.zcnt[p] = z;
         items += z;
-        bytes += st == ZK_OK ? proof_size(W.sec, W.n, z) : 0;
+        bytes += st == ZK_OK ? wire_proof_size(W.wire, W.sec, W.n, z) : 0;
     }
     sb[t] = bytes, si[t] = items;
     __syncthreads();
@@ -112,7 +110,7 @@ __global__ void __launch_bounds__(SCAN_T) k_scan(Workspace W, uint32_t count, ui
         out_off[first_proof + p] = base + b;
         status_out[first_proof + p] = W.st[p];
         it += W.zcnt[p];
-        b += W.st[p] == ZK_OK ? proof_size(W.sec, W.n, W.zcnt[p]) : 0;
+        b += W.st[p] == ZK_OK ? wire_proof_size(W.wire, W.sec, W.n, W.zcnt[p]) : 0;
     }
 }
 // Small read-backs the host waits for (chunk totals, slice boundaries, the batched check's verdicts) are WRITTEN by a kernel
@@ -294,20 +292,23 @@ __global__ void __launch_bounds__(256) k_padd_respond(Workspace W, uint32_t item
     uint32_t part = t / items, it = t % items;
     uint32_t p = W.item_proof[it], i = W.item_rep[it];
     uint32_t d0 = 3 + 4 * W.sec + 40 * W.item_rank[it];
-    uint8_t* rep = out + W.out_base[p] + rep_offset(W.chal + 4 * p, i);
-    uint8_t* pa = rep + ZK_REP_HEAD;
+    const Wire& wr = W.wire;
+    uint8_t* rep = out + W.out_base[p] + rep_offset_w(wr, W.chal + 4 * p, i);
+    uint8_t* pa = rep + wr.rep_head;
+    uint8_t* rsc = rep + 64 + 4 * wr.tc;   // the repetition's four response scalars (ZKA1: rep + 208)
     const uint32_t* c = W.padd_c + (size_t)it * 18;
-    const uint32_t MS = 288 + 432;  // scalars of MultProof m start at 288 + 656 m + 432
+    const uint32_t MS = 8 * wr.tc + 12 * wr.tc;  // scalars of MultProof m start behind C8..C13 (8 coordinates), m MultProofs and its own 6 points
+    const uint32_t ES = 8 * wr.tc + 4 * wr.mult + 4 * wr.tc;   // scalars of EqualityProof e: + eq * e
     auto lbv = [&](uint32_t k) { return soa_ld<ModQ, 1>(W.lb.v, lbi(W, it, k)); };  // 0..5 = x1, y1, i8, i10, i11, i13
     // blinders: r1, r4, r8, r10, r11, r13 = draws d0 + 0..5; r2, r5 = draws 1, 2 (Px, Py); r3, r6 = draws of Tx, Ty of the rep
     switch (part) {
         case 0: {
             // rep-level response for a zero bit (exp.ts:186,221-225): z = alpha - s, z2 = r_i - Cs.r, r1 = T1x.r, r2 = T1y.r
             Sn alpha = drawn(W, p, 3 + 4 * i), ri = drawn(W, p, 3 + 4 * i + 1), r0 = drawn(W, p, 0);
-            store_scalar_be(rep + 208, fe_sub_mod(alpha, soa_ld<ModN, 1>(W.s1, p)));
-            store_scalar_be(rep + 240, fe_sub_mod(ri, r0));
-            store_scalar_be(rep + 272, drawq(W, p, d0 + 0));
-            store_scalar_be(rep + 304, drawq(W, p, d0 + 1));
+            store_scalar_be(rsc, fe_sub_mod(alpha, soa_ld<ModN, 1>(W.s1, p)));
+            store_scalar_be(rsc + 32, fe_sub_mod(ri, r0));
+            store_scalar_be(rsc + 64, drawq(W, p, d0 + 0));
+            store_scalar_be(rsc + 96, drawq(W, p, d0 + 1));
         } break;
         case 1: {  // pi8: (i7, i8, 1) with blinders (r2 - r1, r8, 0): C14 = g
             Sq one = fe_zero<ModQ>();
@@ -316,22 +317,22 @@ __global__ void __launch_bounds__(256) k_padd_respond(Workspace W, uint32_t item
                          fe_sub_mod(drawq(W, p, 1), drawq(W, p, d0 + 0)), drawq(W, p, d0 + 2), fe_zero<ModQ>());
         } break;
         case 2:  // pi10: (i8, i9, i10)
-            mult_respond(W, p, d0 + 13, c + 3, pa + MS + 656, lbv(2), fe_sub_mod(soa_ld<ModQ, 1>(W.pky, p), lbv(1)), lbv(3), drawq(W, p, d0 + 2),
+            mult_respond(W, p, d0 + 13, c + 3, pa + MS + wr.mult, lbv(2), fe_sub_mod(soa_ld<ModQ, 1>(W.pky, p), lbv(1)), lbv(3), drawq(W, p, d0 + 2),
                          fe_sub_mod(drawq(W, p, 2), drawq(W, p, d0 + 1)), drawq(W, p, d0 + 3));
             break;
         case 3: {  // pi11: (i10, i10, i11)
             Sq i10 = lbv(3), r10 = drawq(W, p, d0 + 3);
-            mult_respond(W, p, d0 + 20, c + 6, pa + MS + 2 * 656, i10, i10, lbv(4), r10, r10, drawq(W, p, d0 + 4));
+            mult_respond(W, p, d0 + 20, c + 6, pa + MS + 2 * wr.mult, i10, i10, lbv(4), r10, r10, drawq(W, p, d0 + 4));
         } break;
         case 4:  // pi13: (i10, i12, i13)
-            mult_respond(W, p, d0 + 30, c + 9, pa + MS + 3 * 656, lbv(3), fe_sub_mod(lbv(0), soa_ld<ModQ, 1>(W.Tx, p * (W.sec + 1) + i)), lbv(5),
+            mult_respond(W, p, d0 + 30, c + 9, pa + MS + 3 * wr.mult, lbv(3), fe_sub_mod(lbv(0), soa_ld<ModQ, 1>(W.Tx, p * (W.sec + 1) + i)), lbv(5),
                          drawq(W, p, d0 + 3), fe_sub_mod(drawq(W, p, d0 + 0), drawq(W, p, 3 + 4 * i + 2)), drawq(W, p, d0 + 5));
             break;
         default: {
             Sq r1 = drawq(W, p, d0 + 0), r4 = drawq(W, p, d0 + 1);
             // pix: Cint = C3 + C1 + C2; piy: Cint = C6 + C4
-            eq_respond(W, p, d0 + 27, c + 12, pa + 2912 + 144, lbv(4), drawq(W, p, d0 + 4), fe_add_mod(fe_add_mod(drawq(W, p, 3 + 4 * i + 2), r1), drawq(W, p, 1)));
-            eq_respond(W, p, d0 + 37, c + 15, pa + 3152 + 144, lbv(5), drawq(W, p, d0 + 5), fe_add_mod(drawq(W, p, 3 + 4 * i + 3), r4));
+            eq_respond(W, p, d0 + 27, c + 12, pa + ES, lbv(4), drawq(W, p, d0 + 4), fe_add_mod(fe_add_mod(drawq(W, p, 3 + 4 * i + 2), r1), drawq(W, p, 1)));
+            eq_respond(W, p, d0 + 37, c + 15, pa + ES + wr.eq, lbv(5), drawq(W, p, d0 + 5), fe_add_mod(drawq(W, p, 3 + 4 * i + 3), r4));
         }
     }
 }
@@ -349,38 +350,47 @@ ZK_DEV void put_p256_point(uint8_t* o, const Soa& ax, const Soa& ay, uint32_t e)
     store_scalar_be(o, soa_ld<ModQ, 1>(ax, e));
     store_scalar_be(o + 32, soa_ld<ModQ, 1>(ay, e));
 }
+// two consecutive Tom points of a list (slots a, b) at o (4-byte aligned): 2 x 72 bytes, or 132 packed
+ZK_DEV void put_tom_pair(const Wire& wr, uint8_t* o, const TomList& L, uint32_t a, uint32_t b) {
+    if (wr.tc == 36) {
+        put_tom_point(o, L, a);
+        put_tom_point(o + 72, L, b);
+    } else {
+        store_tom_pair_packed(o, soa_ld<ModT, 1>(L.ax, a), soa_ld<ModT, 1>(L.ay, a), soa_ld<ModT, 1>(L.ax, b), soa_ld<ModT, 1>(L.ay, b));
+    }
+}
 __global__ void __launch_bounds__(256) k_write_fixed(Workspace W, uint32_t count, uint8_t* out) {
     uint32_t t = gtid();
     uint32_t per = W.sec + 1;
     if (t >= count * per) return;
     uint32_t p = t / per, j = t % per;
     if (W.st[p] != ZK_OK) return;
+    const Wire& wr = W.wire;
     uint8_t* base = out + W.out_base[p];
     const uint32_t* c = W.chal + 4 * p;
     uint32_t la = p * (2 + 2 * W.sec), ea = p * per;
     if (j == W.sec) {
         uint32_t total = (uint32_t)(W.out_base[p + 1] - W.out_base[p]);
         uint32_t* h = (uint32_t*)base;
-        h[0] = 0x31414b5au;  // "ZKA1"
+        h[0] = wr.magic;  // "ZKA1" / "ZK1P"
         h[1] = bswap32(total), h[2] = bswap32(W.sec), h[3] = bswap32(W.n);
         uint32_t bits[4] = {c[0], c[1], c[2], 0};
         for (uint32_t b = W.sec; b < 128; b++) bits[b >> 5] &= ~(1u << (b & 31));
         store_be<4>(base + 16, bits);
         put_p256_point(base + 32, W.Rx, W.Ry, p);
         put_p256_point(base + 96, W.Ax, W.Ay, ea + W.sec);  // comS1
-        put_tom_point(base + 160, W.la, la + 0);
-        put_tom_point(base + 232, W.la, la + 1);
+        put_tom_pair(wr, base + 160, W.la, la + 0, la + 1);   // keyXcom, keyYcom
         return;
     }
-    uint8_t* rep = base + rep_offset(c, j);
+    uint8_t* rep = base + rep_offset_w(wr, c, j);
     put_p256_point(rep, W.Ax, W.Ay, ea + j);
-    put_tom_point(rep + 64, W.la, la + 2 + 2 * j);
-    put_tom_point(rep + 136, W.la, la + 3 + 2 * j);
+    put_tom_pair(wr, rep + 64, W.la, la + 2 + 2 * j, la + 3 + 2 * j);   // Tx_j, Ty_j
     if ((c[j >> 5] >> (j & 31)) & 1) {  // exp.ts:170-184: alpha, r, Tx.r, Ty.r
-        store_scalar_be(rep + 208, drawn(W, p, 3 + 4 * j));
-        store_scalar_be(rep + 240, drawn(W, p, 3 + 4 * j + 1));
-        store_scalar_be(rep + 272, drawq(W, p, 3 + 4 * j + 2));
-        store_scalar_be(rep + 304, drawq(W, p, 3 + 4 * j + 3));
+        uint8_t* rsc = rep + 64 + 4 * wr.tc;
+        store_scalar_be(rsc, drawn(W, p, 3 + 4 * j));
+        store_scalar_be(rsc + 32, drawn(W, p, 3 + 4 * j + 1));
+        store_scalar_be(rsc + 64, drawq(W, p, 3 + 4 * j + 2));
+        store_scalar_be(rsc + 96, drawq(W, p, 3 + 4 * j + 3));
     }
 }
 void launch_write_fixed(hipStream_t s, const Workspace& W, uint32_t count, uint8_t* out) {
@@ -396,18 +406,20 @@ void launch_write_fixed(hipStream_t s, const Workspace& W, uint32_t count, uint8
 #endif
 #define WP_WORDS (32 * 18)       // point words per item
 #define WP_STRIDE (WP_WORDS + 1)  // LDS item stride: odd, so that the 32 items of a phase-A row fall into 32 banks
-ZK_DEV uint32_t padd_point_off(uint32_t k) {  // byte offset of point k (0..31) inside the PointAdd block (pointAdd.ts:138-191 order)
-    return k < 4 ? 72 * k : k < 28 ? 288 + 656 * ((k - 4) / 6) + 72 * ((k - 4) % 6) : k < 30 ? 2912 + 72 * (k - 28) : 3152 + 72 * (k - 30);
+ZK_DEV uint32_t padd_point_off(const Wire& wr, uint32_t k) {  // byte offset of point k (0..31) inside the PointAdd block (pointAdd.ts:138-191 order)
+    const uint32_t pt = 2 * wr.tc;
+    return k < 4 ? pt * k : k < 28 ? 4 * pt + wr.mult * ((k - 4) / 6) + pt * ((k - 4) % 6) : k < 30 ? 4 * pt + 4 * wr.mult + pt * (k - 28) : 4 * pt + 4 * wr.mult + wr.eq + pt * (k - 30);
 }
 __global__ void __launch_bounds__(256) k_write_padd_points(Workspace W, uint32_t items, uint8_t* out) {
     __shared__ uint32_t words[WP_ITEMS * WP_STRIDE];
     __shared__ uint64_t base[WP_ITEMS];
+    const Wire& wr = W.wire;
     const uint32_t t = threadIdx.x, it0 = blockIdx.x * WP_ITEMS;
     const uint32_t li = t % WP_ITEMS, kk = t / WP_ITEMS, it = it0 + li;
     if (it < items) {
         if (kk == 0) {
             uint32_t p = W.item_proof[it], i = W.item_rep[it];
-            base[li] = W.out_base[p] + rep_offset(W.chal + 4 * p, i) + ZK_REP_HEAD;
+            base[li] = W.out_base[p] + rep_offset_w(wr, W.chal + 4 * p, i) + wr.rep_head;
         }
 #pragma unroll 1
         for (uint32_t k = kk; k < 32; k += 256 / WP_ITEMS) {
@@ -422,10 +434,31 @@ __global__ void __launch_bounds__(256) k_write_padd_points(Workspace W, uint32_t
         }
     }
     __syncthreads();
-    const uint32_t n = (items - it0 < WP_ITEMS ? items - it0 : WP_ITEMS) * WP_WORDS;
-    for (uint32_t e = t; e < n; e += 256) {
-        uint32_t i = e / WP_WORDS, d = e % WP_WORDS, k = d / 18;
-        *(uint32_t*)(out + base[i] + padd_point_off(k) + 4 * (d % 18)) = words[i * WP_STRIDE + d];
+    const uint32_t nit = items - it0 < WP_ITEMS ? items - it0 : WP_ITEMS;
+    if (wr.tc == 36) {
+        const uint32_t n = nit * WP_WORDS;
+        for (uint32_t e = t; e < n; e += 256) {
+            uint32_t i = e / WP_WORDS, d = e % WP_WORDS, k = d / 18;
+            *(uint32_t*)(out + base[i] + padd_point_off(wr, k) + 4 * (d % 18)) = words[i * WP_STRIDE + d];
+        }
+    } else {
+        // ZKA1P: the 32 points of an item are 32 x 66 bytes; every run of points starts on a multiple of 132 of that string and at a 4-byte
+        // aligned offset of the block, so output dword d holds bytes 4 d .. 4 d + 3 of the string and never straddles a run.  A coordinate's
+        // 33 bytes are bytes 3 .. 35 of its 36-byte big-endian image in LDS.
+        const uint8_t* lb8 = (const uint8_t*)words;
+        const uint32_t PW = 32 * 66 / 4;   // 528 dwords per item
+        const uint32_t n = nit * PW;
+        for (uint32_t e = t; e < n; e += 256) {
+            const uint32_t i = e / PW, q0 = 4 * (e % PW);
+            uint32_t v = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 4; b++) {
+                const uint32_t q = q0 + b, k = q / 66, r = q % 66;
+                v |= (uint32_t)lb8[4 * (i * WP_STRIDE + k * 18 + (r >= 33 ? 9 : 0)) + 3 + (r >= 33 ? r - 33 : r)] << (8 * b);
+            }
+            const uint32_t k0 = q0 / 66;
+            *(uint32_t*)(out + base[i] + padd_point_off(wr, k0) + q0 % 66) = v;
+        }
     }
 }
 void launch_write_padd_points(hipStream_t s, const Workspace& W, uint32_t items, uint8_t* out) {
@@ -498,8 +531,8 @@ __global__ void __launch_bounds__(64) k_gk_respond(Workspace W, ChunkIn in, uint
     uint32_t p = gtid();
     if (p >= in.count || W.st[p] != ZK_OK) return;
     uint32_t n = W.n, g0 = gk_g0(W, p);
-    uint8_t* gk = out + W.out_base[p] + ZK_FIXED + (uint64_t)ZK_REP_HEAD * W.sec + (uint64_t)ZK_PADD_SZ * W.zcnt[p];
-    uint8_t* sc = gk + 4 * 72 * n;
+    uint8_t* gk = out + W.out_base[p] + W.wire.fixed + (uint64_t)W.wire.rep_head * W.sec + (uint64_t)W.wire.padd * W.zcnt[p];
+    uint8_t* sc = gk + 8 * W.wire.tc * n;
     Sq x = chal_scalar(W.gk_x + 3 * p);
     auto xm = fe_to_mont(x);
     Sq rcom = drawq(W, p, 1);                                    // blinder of keyXcom
@@ -521,17 +554,17 @@ __global__ void __launch_bounds__(64) k_gk_respond(Workspace W, ChunkIn in, uint
     Sq zd = fe_sub_mod(fe_canon(xpow * rcom), acc);              // zd = r x^n - sum rho_i x^i
     store_scalar_be(sc + 32 * 3 * n, zd);
 }
-__global__ void __launch_bounds__(256) k_write_gk_points(Workspace W, uint32_t count, uint8_t* out) {
+__global__ void __launch_bounds__(256) k_write_gk_points(Workspace W, uint32_t count, uint8_t* out) {   // one thread per PAIR of the 4 n points
     uint32_t t = gtid();
-    if (t >= count * 4 * W.n) return;
-    uint32_t p = t / (4 * W.n), k = t % (4 * W.n);
+    if (t >= count * 2 * W.n) return;
+    uint32_t p = t / (2 * W.n), k = t % (2 * W.n);
     if (W.st[p] != ZK_OK) return;
-    uint8_t* gk = out + W.out_base[p] + ZK_FIXED + (uint64_t)ZK_REP_HEAD * W.sec + (uint64_t)ZK_PADD_SZ * W.zcnt[p];
-    put_tom_point(gk + 72 * k, W.lc, t);
+    uint8_t* gk = out + W.out_base[p] + W.wire.fixed + (uint64_t)W.wire.rep_head * W.sec + (uint64_t)W.wire.padd * W.zcnt[p];
+    put_tom_pair(W.wire, gk + 4 * W.wire.tc * k, W.lc, p * 4 * W.n + 2 * k, p * 4 * W.n + 2 * k + 1);
 }
 void launch_gk_respond(hipStream_t s, const Workspace& W, const ChunkIn& in, uint8_t* out) {
     hipLaunchKernelGGL(k_gk_respond, dim3((in.count + 63) / 64), dim3(64), 0, s, W, in, out);
-    uint32_t n = in.count * 4 * W.n;
+    uint32_t n = in.count * 2 * W.n;
     hipLaunchKernelGGL(k_write_gk_points, dim3((n + 255) / 256), dim3(256), 0, s, W, in.count, out);
 }
 // ---- plain fold (rings without table E, see k_gk.hip for the table path): a tile of 2^T ring elements per workgroup.

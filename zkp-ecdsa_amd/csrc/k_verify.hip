@@ -147,6 +147,134 @@ __global__ void __launch_bounds__(256) k_v_validate(VWork V, uint32_t count, con
     if (!ok) atomicCAS(&V.st[p], ZK_OK, ZK_E_BAD_ENCODING);
 }
 
+// ------------------------------------------------------------------ ZKA1P -> ZKA1 (include/zkattest.h: the packed wire layout)
+// The verifier's kernels read 36-byte Tom coordinates at 4-byte aligned offsets; packed proofs (33-byte coordinates) are expanded once per
+// chunk into a staging buffer and everything else runs unchanged on the expanded bytes.  k_v_unpack_scan: one workgroup per chunk, the
+// expanded length of every proof from its header -- a proof whose header is not a well-formed ZKA1P header of this context's secLevel
+// expands to its 32 header bytes alone, which k_v_header then refuses (ZK_E_BAD_ENCODING) -- and their prefix sums from `base`.
+// k_v_unpack: one workgroup per (proof, part): the repetitions, the fixed part, the membership proof.
+ZK_DEV bool v_packed_header_ok(const uint8_t* pr, uint64_t plen, uint32_t want_sec, uint32_t& sec, uint32_t& n, uint32_t& z, uint32_t bits[4]) {
+    if (plen < ZK_HDR) return false;
+    const uint32_t* h = (const uint32_t*)pr;
+    const uint32_t total = bswap32(h[1]);
+    sec = bswap32(h[2]), n = bswap32(h[3]);
+    bits[0] = bswap32(h[7]), bits[1] = bswap32(h[6]), bits[2] = bswap32(h[5]), bits[3] = bswap32(h[4]);
+    if (h[0] != ZK_MAGIC_ZKA1P || total != plen || sec != want_sec || n > 63) return false;
+    for (uint32_t b = sec; b < 128; b++)
+        if ((bits[b >> 5] >> (b & 31)) & 1) return false;
+    z = zeros_below(bits, sec);
+    return plen == wire_proof_size(wire_make(true), sec, n, z);
+}
+__global__ void __launch_bounds__(256) k_v_unpack_scan(uint32_t want_sec, uint32_t count, const uint8_t* packed, const uint64_t* poff, uint64_t first, uint64_t base,
+                                                       uint64_t* uoff /* [count + 1], entry p = proof first + p */) {
+    __shared__ uint64_t sb[256];
+    const uint32_t t = threadIdx.x, per = (count + 255) / 256;
+    const uint32_t lo = t * per, hi = lo + per < count ? lo + per : count;
+    uint64_t sum = 0;
+    for (uint32_t p = lo; p < hi; p++) {
+        const uint64_t o0 = poff[first + p], o1 = poff[first + p + 1];
+        uint32_t sec, n, z, bits[4];
+        const bool ok = o1 >= o0 && !(o0 & 3) && v_packed_header_ok(packed + o0, o1 - o0, want_sec, sec, n, z, bits);
+        sum += ok ? wire_proof_size(wire_make(false), sec, n, z) : ZK_HDR;
+    }
+    sb[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        uint64_t run = base;
+        for (int i = 0; i < 256; i++) {
+            const uint64_t v = sb[i];
+            sb[i] = run, run += v;
+        }
+    }
+    __syncthreads();
+    uint64_t run = sb[t];
+    for (uint32_t p = lo; p < hi; p++) {
+        const uint64_t o0 = poff[first + p], o1 = poff[first + p + 1];
+        uint32_t sec, n, z, bits[4];
+        const bool ok = o1 >= o0 && !(o0 & 3) && v_packed_header_ok(packed + o0, o1 - o0, want_sec, sec, n, z, bits);
+        uoff[p] = run;
+        run += ok ? wire_proof_size(wire_make(false), sec, n, z) : ZK_HDR;
+        if (p + 1 == count) uoff[count] = run;
+    }
+}
+// output dword u of a part made of segments: plain dwords copied, Tom coordinates expanded from 33 to 36 bytes
+struct UnpackSeg {
+    uint32_t tom;   // 1: `cnt` coordinates (9 output dwords from 33 source bytes each); 0: `cnt` plain dwords
+    uint32_t cnt;
+};
+ZK_DEV uint32_t unpack_dword(const uint8_t* src, const UnpackSeg* seg, uint32_t nseg, uint32_t u) {
+    uint32_t so = 0;
+    for (uint32_t k = 0; k < nseg; k++) {
+        const uint32_t dw = seg[k].tom ? 9 * seg[k].cnt : seg[k].cnt;
+        if (u < dw) {
+            if (!seg[k].tom) {
+                const uint8_t* q = src + so + 4 * u;
+                return (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24;
+            }
+            const uint8_t* q = src + so + 33 * (u / 9);
+            const uint32_t j = u % 9;
+            if (j == 0) return (uint32_t)q[0] << 24;
+            q += 1 + 4 * (j - 1);
+            return (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24;
+        }
+        u -= dw;
+        so += seg[k].tom ? 33 * seg[k].cnt : 4 * seg[k].cnt;
+    }
+    return 0;
+}
+__global__ void __launch_bounds__(256) k_v_unpack(uint32_t want_sec, uint32_t count, const uint8_t* packed, const uint64_t* poff, uint64_t first, uint8_t* out,
+                                                  const uint64_t* uoff /* entry p = proof first + p */) {
+    const uint32_t parts = want_sec + 2, p = blockIdx.x / parts, part = blockIdx.x % parts;
+    if (p >= count) return;
+    const uint64_t o0 = poff[first + p], o1 = poff[first + p + 1];
+    const uint8_t* src = packed + o0;
+    uint32_t* dst = (uint32_t*)(out + uoff[p]);
+    uint32_t sec, n, z, bits[4];
+    const bool ok = o1 >= o0 && !(o0 & 3) && v_packed_header_ok(src, o1 - o0, want_sec, sec, n, z, bits);
+    if (!ok) {   // the header alone, so that k_v_header sees a proof it must refuse
+        if (part == 0 && threadIdx.x < 8) {
+            uint32_t v = o1 >= o0 + ZK_HDR && !(o0 & 3) ? ((const uint32_t*)src)[threadIdx.x] : 0;
+            if (threadIdx.x == 0) v = ZK_MAGIC_ZKA1;
+            if (threadIdx.x == 1 && bswap32(v) == ZK_HDR) v = 0;   // never a consistent 32-byte "proof"
+            dst[threadIdx.x] = v;
+        }
+        return;
+    }
+    const Wire pw = wire_make(true), uw = wire_make(false);
+    UnpackSeg seg[16];
+    uint32_t nseg = 0, ndw = 0;
+    uint64_t so = 0, dof = 0;
+    if (part < sec) {   // repetition `part`: A, Tx, Ty, four scalars, and for a zero bit the PointAdd proof
+        so = rep_offset_w(pw, bits, part), dof = rep_offset_w(uw, bits, part);
+        seg[nseg++] = {0, 16}, seg[nseg++] = {1, 4}, seg[nseg++] = {0, 32};
+        ndw = 16 + 36 + 32;
+        if (!((bits[part >> 5] >> (part & 31)) & 1)) {
+            seg[nseg++] = {1, 8};
+            for (int m = 0; m < 4; m++) seg[nseg++] = {1, 12}, seg[nseg++] = {0, 56};
+            for (int e = 0; e < 2; e++) seg[nseg++] = {1, 4}, seg[nseg++] = {0, 24};
+            ndw += uw.padd / 4;
+        }
+    } else if (part == sec) {   // header, R, comS1, keyXcom, keyYcom
+        seg[nseg++] = {0, 8 + 32}, seg[nseg++] = {1, 4};
+        ndw = uw.fixed / 4;
+    } else {   // membership proof: 4 n points, 3 n + 1 scalars
+        so = pw.fixed + (uint64_t)pw.rep_head * sec + (uint64_t)pw.padd * z, dof = uw.fixed + (uint64_t)uw.rep_head * sec + (uint64_t)uw.padd * z;
+        seg[nseg++] = {1, 8 * n}, seg[nseg++] = {0, 8 * (3 * n + 1)};
+        ndw = (uw.gk_n * n + 32) / 4;
+    }
+    for (uint32_t u = threadIdx.x; u < ndw; u += 256) {
+        uint32_t v = unpack_dword(src + so, seg, nseg, u);
+        if (part == sec && u == 0) v = ZK_MAGIC_ZKA1;
+        if (part == sec && u == 1) v = bswap32((uint32_t)wire_proof_size(uw, sec, n, z));
+        dst[dof / 4 + u] = v;
+    }
+}
+void launch_v_unpack(hipStream_t s, uint32_t sec, uint32_t count, const uint8_t* packed, const uint64_t* poff, uint64_t first, uint64_t base, uint8_t* out, uint64_t* uoff) {
+    if (!count) return;
+    hipLaunchKernelGGL(k_v_unpack_scan, dim3(1), dim3(256), 0, s, sec, count, packed, poff, first, base, uoff);
+    hipLaunchKernelGGL(k_v_unpack, dim3(count * (sec + 2)), dim3(256), 0, s, sec, count, packed, poff, first, out, uoff);
+}
+
 // ------------------------------------------------------------------ front: R, Q (zkpAttestList.ts:153-164), kx, ky
 __global__ void __launch_bounds__(64) k_v_front(DevParams P, Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* msg, uint64_t first) {
     uint32_t p = gtid();
