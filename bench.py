@@ -64,6 +64,7 @@ def main():
     ap.add_argument('--device-stream', type=int, default=0, help='also time the steps as jobs kept in flight on the context (zk_prove_submit_device / zk_prove_wait, this many at a time, 2..4; every job its own output buffer): the pipeline does not drain between steps')
     ap.add_argument('--pool', action='store_true', help="ONE process, --gpus devices through the library's own zk_pool (RCCL ring broadcast, shards on host threads, page-locked host buffers): python bench.py --pool --gpus N")
     ap.add_argument('--pool-devices', default='', help='--pool: comma-separated device ids (default 0..gpus-1; a device may repeat: several contexts on one GPU)')
+    ap.add_argument('--host-io-packed', type=int, default=1, help='also stream the batches in the packed wire layout ZKA1P (0 = skip)')
     ap.add_argument('--host-io-pageable', action='store_true', help='also measure ordinary (pageable) host buffers')
     ap.add_argument('--mode', choices=['prove', 'verify'], default='prove',
                     help="verify: BASELINE configs[4] -- --batch proofs IN TOTAL over --ring keys, sharded over the ranks, generated and verified in streamed slabs")
@@ -388,6 +389,11 @@ def main():
                 line['value_pcie_inclusive_steady'] = st['prove']['proofs_per_s']
             if 'verifies_per_s' in (st.get('verify') or {}):
                 line['verify_pcie_inclusive_steady'] = st['verify']['verifies_per_s']
+            sp = host_io.get('stream_packed') or {}
+            if 'proofs_per_s' in (sp.get('prove') or {}):   # the same batches in the packed wire layout (zk_ctx_set_wire(ZK_WIRE_ZKA1P))
+                line['value_pcie_inclusive_steady_packed'] = sp['prove']['proofs_per_s']
+            if 'verifies_per_s' in (sp.get('verify') or {}):
+                line['verify_pcie_inclusive_steady_packed'] = sp['verify']['verifies_per_s']
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

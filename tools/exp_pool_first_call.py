@@ -60,7 +60,11 @@ def main():
     ap.add_argument('--clean-exit', type=int, default=0, help='1: destroy the pool and free the buffers before exiting (default: os._exit)')
     ap.add_argument('--probe', type=int, default=1, help='zk_ctx_copy_probe on the four copy streams at start and at the end')
     ap.add_argument('--hold', type=float, default=0, help='only create the pool, probe, and sleep this many seconds (a process that holds its queues)')
+    ap.add_argument('--torch-first', type=int, default=0, help='1: import torch (and touch the device) before the engine library: the process then runs on the HIP runtime bundled with the wheel')
     args = ap.parse_args()
+    if args.torch_first:
+        import torch
+        torch.zeros(1, device='cuda:0')
     import zkp_ecdsa_amd as Z
     B, sec = args.batch, 80
     t_start = time.time()
@@ -100,6 +104,7 @@ def main():
         rec['calls'].append({'kind': 'stream x%d' % args.stream, 'proofs_per_s': round(args.stream * B / dt), 'd2h_gbps': round(args.stream * nbytes / dt / 1e9, 1)})
         rec['other_buffers'] = [mapping_info(b.ptr) for b in bufs[1:]]
     rec['probe_at_start'] = probe0
+    rec['hip_runtime'] = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l or 'libhsa-runtime64' in l})
     if args.probe:
         e0.set_slice(0)
         rec['probe_at_end'] = [e0.copy_probe(l) for l in range(4)]
