@@ -332,6 +332,22 @@ def run_pool_mode(args, Z):
                 e.set_chunk(min(args.host_io_verify_chunk, Bg)), e.set_lanes(args.host_io_lanes), e.set_slice(0)
         except Exception as e:
             stream = {'error': repr(e)[:300]}
+    # the same call with the proofs left in each device's HBM (zk_pool_prove_batch_device): what the GPUs and their host threads do without the
+    # node's host memory in the path -- on N devices the ratio to `value` separates compute scaling from host-memory scaling
+    dev_out = None
+    try:
+        dbuf = [pool.device_alloc(i, per_shard) for i in range(G)]
+        pool.prove_batch_device_out(msg_a, sig_a, pk_a, which_a, seeds_a, dbuf, [per_shard] * G)
+        ddts = []
+        for _ in range(args.steps):
+            ddt, doff, dln, dst = pool.prove_batch_device_out(msg_a, sig_a, pk_a, which_a, seeds_a, dbuf, [per_shard] * G)
+            ddts.append(ddt)
+        assert not any(dst) and list(dln) == list(ln)
+        dev_out = {'proofs_per_s': round(B * args.steps / sum(ddts), 1), 'ms_per_step': round(sum(ddts) * 1e3 / args.steps, 2), 'shard_ms': pool.shard_ms()}
+        for i in range(G):
+            pool.device_free(i, dbuf[i])
+    except Exception as e:
+        dev_out = {'error': repr(e)[:300]}
     cpu = None
     if not args.no_cpu_baseline:
         sample = args.cpu_sample or 4 * host_cores()
@@ -356,6 +372,7 @@ def run_pool_mode(args, Z):
         'accepted': int(accepted), 'of': B, 'planted_forgeries_rejected': len(forged),
         'd2h_gbps_total': round(nbytes * args.steps / total / 1e9, 2), 'h2d_gbps_total': round(nbytes / vdt / 1e9, 2), 'cpu_baseline': cpu,
         'stream': stream, 'value_pcie_inclusive_steady': stream.get('proofs_per_s') if stream else None,
+        'device_resident_output': dev_out, 'ring_transport_note': pool.last_error() if transport != 'rccl' and G > 1 else None,
     }
     print(json.dumps(line))
     pin.free()

@@ -596,6 +596,10 @@ class Pool:
         except Exception:
             pass
 
+    def last_error(self):
+        """zk_pool_last_error: after set_ring also why RCCL was not used"""
+        return self.L.zk_pool_last_error(self.h).decode()
+
     def engine(self, i):
         """Per-device context (settings only: chunk, lanes, comb width, host taper); owned by the pool."""
         return Engine(_borrowed=self.L.zk_pool_ctx(self.h, i))
