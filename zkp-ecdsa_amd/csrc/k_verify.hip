@@ -197,30 +197,35 @@ __global__ void __launch_bounds__(256) k_v_unpack_scan(uint32_t want_sec, uint32
         if (p + 1 == count) uoff[count] = run;
     }
 }
-// output dword u of a part made of segments: plain dwords copied, Tom coordinates expanded from 33 to 36 bytes
-struct UnpackSeg {
-    uint32_t tom;   // 1: `cnt` coordinates (9 output dwords from 33 source bytes each); 0: `cnt` plain dwords
-    uint32_t cnt;
+// Output dword u of a part -> where it comes from in the packed part: a plain dword (copied) or word j of a Tom coordinate (33 source bytes ->
+// 9 dwords, the first one holding the top byte behind three zero bytes).  Pure arithmetic on the fixed shapes of the parts: no tables, no scratch.
+struct UnpackSrc {
+    uint32_t off;   // byte offset inside the packed part: of the dword, or of the coordinate's first byte
+    uint32_t j;     // 0xffffffff: plain dword; else word 0..8 of the coordinate
 };
-ZK_DEV uint32_t unpack_dword(const uint8_t* src, const UnpackSeg* seg, uint32_t nseg, uint32_t u) {
-    uint32_t so = 0;
-    for (uint32_t k = 0; k < nseg; k++) {
-        const uint32_t dw = seg[k].tom ? 9 * seg[k].cnt : seg[k].cnt;
-        if (u < dw) {
-            if (!seg[k].tom) {
-                const uint8_t* q = src + so + 4 * u;
-                return (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24;
-            }
-            const uint8_t* q = src + so + 33 * (u / 9);
-            const uint32_t j = u % 9;
-            if (j == 0) return (uint32_t)q[0] << 24;
-            q += 1 + 4 * (j - 1);
-            return (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24;
-        }
-        u -= dw;
-        so += seg[k].tom ? 33 * seg[k].cnt : 4 * seg[k].cnt;
+ZK_DEV UnpackSrc unpack_tom(uint32_t base, uint32_t w) { return UnpackSrc{base + 33 * (w / 9), w % 9}; }
+ZK_DEV UnpackSrc unpack_plain(uint32_t base, uint32_t w) { return UnpackSrc{base + 4 * w, 0xffffffffu}; }
+ZK_DEV UnpackSrc unpack_map_rep(uint32_t u) {   // A | Tx Ty | 4 scalars | C8 C10 C11 C13 | 4 x (6 points, 7 scalars) | 2 x (2 points, 3 scalars)
+    if (u < 16) return unpack_plain(0, u);
+    if (u < 52) return unpack_tom(64, u - 16);
+    if (u < 84) return unpack_plain(196, u - 52);
+    uint32_t v = u - 84;
+    const uint32_t pa = 324;
+    if (v < 72) return unpack_tom(pa, v);
+    v -= 72;
+    if (v < 4 * 164) {
+        const uint32_t m = v / 164, w = v % 164, b = pa + 264 + 620 * m;
+        return w < 108 ? unpack_tom(b, w) : unpack_plain(b + 396, w - 108);
     }
-    return 0;
+    v -= 4 * 164;
+    const uint32_t e = v / 60, w = v % 60, b = pa + 264 + 4 * 620 + 228 * e;
+    return w < 36 ? unpack_tom(b, w) : unpack_plain(b + 132, w - 36);
+}
+ZK_DEV uint32_t unpack_fetch(const uint8_t* src, const UnpackSrc& m) {
+    const uint8_t* q = src + m.off;
+    if (m.j == 0) return (uint32_t)q[0] << 24;
+    if (m.j != 0xffffffffu) q += 1 + 4 * (m.j - 1);
+    return (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24;
 }
 __global__ void __launch_bounds__(256) k_v_unpack(uint32_t want_sec, uint32_t count, const uint8_t* packed, const uint64_t* poff, uint64_t first, uint8_t* out,
                                                   const uint64_t* uoff /* entry p = proof first + p */) {
@@ -241,29 +246,23 @@ __global__ void __launch_bounds__(256) k_v_unpack(uint32_t want_sec, uint32_t co
         return;
     }
     const Wire pw = wire_make(true), uw = wire_make(false);
-    UnpackSeg seg[16];
-    uint32_t nseg = 0, ndw = 0;
+    uint32_t ndw;
     uint64_t so = 0, dof = 0;
     if (part < sec) {   // repetition `part`: A, Tx, Ty, four scalars, and for a zero bit the PointAdd proof
         so = rep_offset_w(pw, bits, part), dof = rep_offset_w(uw, bits, part);
-        seg[nseg++] = {0, 16}, seg[nseg++] = {1, 4}, seg[nseg++] = {0, 32};
-        ndw = 16 + 36 + 32;
-        if (!((bits[part >> 5] >> (part & 31)) & 1)) {
-            seg[nseg++] = {1, 8};
-            for (int m = 0; m < 4; m++) seg[nseg++] = {1, 12}, seg[nseg++] = {0, 56};
-            for (int e = 0; e < 2; e++) seg[nseg++] = {1, 4}, seg[nseg++] = {0, 24};
-            ndw += uw.padd / 4;
-        }
+        ndw = ((bits[part >> 5] >> (part & 31)) & 1) ? uw.rep_head / 4 : (uw.rep_head + uw.padd) / 4;
     } else if (part == sec) {   // header, R, comS1, keyXcom, keyYcom
-        seg[nseg++] = {0, 8 + 32}, seg[nseg++] = {1, 4};
         ndw = uw.fixed / 4;
     } else {   // membership proof: 4 n points, 3 n + 1 scalars
         so = pw.fixed + (uint64_t)pw.rep_head * sec + (uint64_t)pw.padd * z, dof = uw.fixed + (uint64_t)uw.rep_head * sec + (uint64_t)uw.padd * z;
-        seg[nseg++] = {1, 8 * n}, seg[nseg++] = {0, 8 * (3 * n + 1)};
         ndw = (uw.gk_n * n + 32) / 4;
     }
     for (uint32_t u = threadIdx.x; u < ndw; u += 256) {
-        uint32_t v = unpack_dword(src + so, seg, nseg, u);
+        UnpackSrc m;
+        if (part < sec) m = unpack_map_rep(u);
+        else if (part == sec) m = u < 40 ? unpack_plain(0, u) : unpack_tom(160, u - 40);
+        else m = u < 72 * n ? unpack_tom(0, u) : unpack_plain(264 * n, u - 72 * n);
+        uint32_t v = unpack_fetch(src + so, m);
         if (part == sec && u == 0) v = ZK_MAGIC_ZKA1;
         if (part == sec && u == 1) v = bswap32((uint32_t)wire_proof_size(uw, sec, n, z));
         dst[dof / 4 + u] = v;
