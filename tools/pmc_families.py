@@ -3,9 +3,10 @@
     python tools/pmc_families.py PROOFS <pmc dir> [<pmc dir> ...]
 Every directory holds one pass (counter_collection CSVs, any subset of: SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE FETCH_SIZE WRITE_SIZE) plus kernel_trace CSVs for the durations.  SQ_* cycle counters
-are quad-cycles summed over waves (MI355X_MICROARCH.md); GRBM_GUI_ACTIVE counts shader-clock cycles per dispatch, so
-    SIMD VALU busy = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE)
-is the share of SIMD-cycles in which a vector instruction was executing.  FETCH_SIZE / WRITE_SIZE are KiB at the L2's memory-side port, raw
+are quad-cycles summed over waves (MI355X_MICROARCH.md); GRBM_GUI_ACTIVE counts shader-clock cycles per dispatch and is reported summed over the
+eight XCDs (check: sum / 8 / kernel time = 2.0-2.1 GHz in a profiled run), so
+    SIMD VALU busy = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)
+is the share of SIMD-cycles in which a vector instruction was executing (k_tom_commit: 0.94 at two waves per SIMD).  FETCH_SIZE / WRITE_SIZE are KiB at the L2's memory-side port, raw
 (16-byte-per-lane loads are tallied at half their bytes on gfx950)."""
 import collections
 import csv
@@ -74,15 +75,15 @@ def main():
         kib = c.get('FETCH_SIZE', 0.0) + c.get('WRITE_SIZE', 0.0)
         print('%-16s %8.2f %10.0f %8.3f %8.3f %8.3f %9s %10.0f' % (
             fam, dur.get(fam, 0.0), c.get('SQ_INSTS_VALU', 0.0) / proofs, c.get('SQ_ACTIVE_INST_VALU', 0.0) / wc if wc else 0, c.get('SQ_WAIT_ANY', 0.0) / wc if wc else 0,
-            c.get('SQ_WAIT_INST_ANY', 0.0) / wc if wc else 0, '%.3f' % (4 * c.get('SQ_ACTIVE_INST_VALU', 0.0) / (1024 * g)) if g else '-', kib * 1024 / proofs))
+            c.get('SQ_WAIT_INST_ANY', 0.0) / wc if wc else 0, '%.3f' % (32 * c.get('SQ_ACTIVE_INST_VALU', 0.0) / (1024 * g)) if g else '-', kib * 1024 / proofs))
     wc, g = tot.get('SQ_WAVE_CYCLES', 0.0), tot.get('GRBM_GUI_ACTIVE', 0.0)
     print('%-16s %8.2f %10.0f %8.3f %8.3f %8.3f %9s %10.0f' % (
         'WHOLE STEP', tot['ms'], tot.get('SQ_INSTS_VALU', 0.0) / proofs, tot.get('SQ_ACTIVE_INST_VALU', 0.0) / wc if wc else 0, tot.get('SQ_WAIT_ANY', 0.0) / wc if wc else 0,
-        tot.get('SQ_WAIT_INST_ANY', 0.0) / wc if wc else 0, '%.3f' % (4 * tot.get('SQ_ACTIVE_INST_VALU', 0.0) / (1024 * g)) if g else '-',
+        tot.get('SQ_WAIT_INST_ANY', 0.0) / wc if wc else 0, '%.3f' % (32 * tot.get('SQ_ACTIVE_INST_VALU', 0.0) / (1024 * g)) if g else '-',
         (tot.get('FETCH_SIZE', 0.0) + tot.get('WRITE_SIZE', 0.0)) * 1024 / proofs))
     if g:
-        print('# whole step: sum SQ_ACTIVE_INST_VALU = %.4g quad-cycles, sum GRBM_GUI_ACTIVE = %.4g cycles, sum SQ_BUSY_CYCLES = %.4g' % (
-            tot.get('SQ_ACTIVE_INST_VALU', 0.0), g, tot.get('SQ_BUSY_CYCLES', 0.0)))
+        print('# whole step: sum SQ_ACTIVE_INST_VALU = %.4g quad-cycles, sum GRBM_GUI_ACTIVE = %.4g cycles over 8 XCDs (effective clock %.2f GHz), sum SQ_BUSY_CYCLES = %.4g' % (
+            tot.get('SQ_ACTIVE_INST_VALU', 0.0), g, g / 8 / (tot['ms'] * 1e-3) / 1e9 if tot['ms'] else 0, tot.get('SQ_BUSY_CYCLES', 0.0)))
 
 
 if __name__ == '__main__':
