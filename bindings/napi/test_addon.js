@@ -161,6 +161,14 @@ async function gpu() {
     assert.ok(again.every((p, i) => p.equals(proofs[i])))
     const viaJson = proofs.map((p) => readJson(SignatureProofList, writeJson(SignatureProofList, p)).bytes)
     assert.deepStrictEqual(eng.verifyBatch(wl.msg, viaJson), Array(B).fill(true))
+    // the packed wire form (ZKA1P, include/zkattest.h): same proofs, 33-byte Tom coordinates; the JSON text is the same text
+    eng.setOption('wire', 1)
+    const packed = eng.proveBatch(wl.msg, wl.sig, wl.pk, wl.which, wl.seeds)
+    assert.ok(packed.every((p, i) => p.slice(0, 4).toString('latin1') === 'ZK1P' && p.length < proofs[i].length))
+    assert.ok(packed.every((p, i) => writeJson(SignatureProofList, p) === writeJson(SignatureProofList, proofs[i])))
+    assert.deepStrictEqual(eng.verifyBatch(wl.msg, packed), Array(B).fill(true))
+    eng.setOption('wire', 0)                                                            // a context verifies the layout it is set to
+    assert.deepStrictEqual(eng.verifyBatch(wl.msg, packed), Array(B).fill(false))
     const forged = Buffer.from(proofs[2])
     forged[forged.length - 1] ^= 1
     const mixed = proofs.slice()

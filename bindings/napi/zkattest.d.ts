@@ -48,7 +48,7 @@ export class Engine {
     constructor(devices?: number | number[])
     close(): void
     info(): { devices: number; ringTransport: string; proofMaxSize: number }
-    setOption(name: 'chunk' | 'lanes' | 'combBits' | 'hostTaper' | 'batchVerify' | 'mode' | 'slice', value: number): void
+    setOption(name: 'chunk' | 'lanes' | 'combBits' | 'hostTaper' | 'batchVerify' | 'mode' | 'slice' | 'ringFold' | 'verifyGroups' | 'wire' | 'inflight', value: number): void
     setParams(p: EngineParams): void
     setRing(keys: Buffer | bigint[]): string
     keysToInts(pkxy: Buffer): { keys: Buffer; status: Buffer }

@@ -178,7 +178,7 @@ function generateParamsListHardened(secLevel = 80, tag = Buffer.alloc(0)) {
 // materialise the reference's members (R, comS1, keyXcom, keyYcom, expProof[], membershipProof: Points and Scalars) on demand.
 // ZKA1 framing (include/zkattest.h): magic, big-endian total length at byte 4 equal to the buffer's length, 4-byte granular.  Checked
 // before a proof may enter a packed batch: a proof with a wrong length would shift every later proof of the blob.
-function wellFormedProof(b) { return Buffer.isBuffer(b) && b.length >= 32 && b.length % 4 === 0 && b.slice(0, 4).toString('latin1') === 'ZKA1' && b.readUInt32BE(4) === b.length }
+function wellFormedProof(b) { return Buffer.isBuffer(b) && b.length >= 32 && b.length % 4 === 0 && (b.slice(0, 4).toString('latin1') === 'ZKA1' || b.slice(0, 4).toString('latin1') === 'ZK1P') && b.readUInt32BE(4) === b.length }
 function revive(v) {
     if (Array.isArray(v)) return v.map(revive)
     if (v && typeof v === 'object') {
@@ -295,7 +295,7 @@ class Engine {
     }
     close() { if (this.h) native.destroyPool(this.h); this.h = null }
     info() { return native.poolInfo(this.h) }
-    setOption(name, value) { native.setOption(this.h, name, value) }   // chunk, lanes, combBits (before setParams), hostTaper, batchVerify
+    setOption(name, value) { native.setOption(this.h, name, value) }   // chunk, lanes, combBits (before setParams), hostTaper, batchVerify, mode, slice, ringFold, verifyGroups, wire (0 ZKA1, 1 ZKA1P), inflight
     // params: { nistH: 64 B, tomG: 72 B, tomH: 72 B, secLevel } -- SystemParametersList as affine big-endian coordinates
     setParams(p) { native.setParams(this.h, p.nistH, p.tomG, p.tomH, p.secLevel || 80); this.params = p }
     setRing(keys) { return native.setRing(this.h, Buffer.isBuffer(keys) ? keys : Buffer.concat(keys.map(be32))) }

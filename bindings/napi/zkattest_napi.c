@@ -246,6 +246,7 @@ static napi_value SetOption(napi_env env, napi_callback_info info) {
                        : !strcmp(name, "slice")       ? zk_ctx_set_slice(c, val)
                        : !strcmp(name, "ringFold")    ? zk_ctx_set_ring_fold(c, val)
                        : !strcmp(name, "verifyGroups") ? zk_ctx_set_verify_groups(c, val)
+                       : !strcmp(name, "wire")        ? zk_ctx_set_wire(c, val)
                                                       : ZK_E_ARG;
         if (st != ZK_OK) return throw_text(env, st, name);
     }

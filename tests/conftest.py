@@ -9,5 +9,11 @@ for p in (ROOT, os.path.join(ROOT, 'oracle')):
         sys.path.insert(0, p)
 
 
+try:   # tests that hand torch tensors to the engine need ONE HIP runtime in the process: the wheel bundles its own libamdhip64 (same soname as
+    import torch   # /opt/rocm's), and whichever is loaded first serves both.  Loaded here, every subset of the suite runs like the whole suite.
+except ImportError:
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')

@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 import pytest
-import torch   # before the first engine of the process: the wheel bundles its own HIP runtime, which must be the one that initialises first
+import torch   # (tests/conftest.py has loaded it already: one HIP runtime per process)
 
 pytestmark = pytest.mark.gpu
 

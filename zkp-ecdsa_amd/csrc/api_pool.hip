@@ -249,8 +249,12 @@ extern "C" void zk_pool_host_free(void* mem);
 // the fastest of up to three candidates: see "slow pages" in api.hip
 extern "C" void* zk_pool_host_alloc(zk_pool* p, size_t bytes) {
     if (!p || !bytes) return nullptr;
+    int cur = -1;   // the candidates are timed from device 0; the caller's current device is put back
+    if (hipGetDevice(&cur) != hipSuccess) cur = -1, (void)hipGetLastError();
     (void)hipSetDevice(p->dev[0]);
-    return alloc_fast_pinned(bytes, [&]() { return pool_host_alloc_once(p, bytes); }, [](void* m) { zk_pool_host_free(m); });
+    void* m = alloc_fast_pinned(bytes, [&]() { return pool_host_alloc_once(p, bytes); }, [](void* q) { zk_pool_host_free(q); });
+    if (cur >= 0) (void)hipSetDevice(cur);
+    return m;
 }
 static void* pool_host_alloc_once(zk_pool* p, size_t bytes) {
     const size_t page = (size_t)sysconf(_SC_PAGESIZE);
