@@ -155,6 +155,11 @@ extern "C" void zk_ctx_destroy(zk_ctx* c) {
         hipFree(c->pl[l].arena), hipFree(c->pl[l].d_totals), hipFree(c->vl[l].arena);
         if (c->pl[l].h_scan) hipHostFree(c->pl[l].h_scan);
         if (c->vl[l].h_msm) hipHostFree(c->vl[l].h_msm);
+        if (c->vl[l].aux_fork) hipEventDestroy(c->vl[l].aux_fork);
+        for (int i = 0; i < V_AUX_STREAMS; i++) {
+            if (c->vl[l].aux_done[i]) hipEventDestroy(c->vl[l].aux_done[i]);
+            if (c->vl[l].aux[i]) hipStreamDestroy(c->vl[l].aux[i]);
+        }
         if (c->pl[l].copy_ev) hipEventDestroy(c->pl[l].copy_ev);
         if (c->pl[l].copy_stream && (l == 0 || c->pl[l].copy_stream != c->pl[0].copy_stream)) hipStreamDestroy(c->pl[l].copy_stream);
         if (c->pl[l].stream) hipStreamDestroy(c->pl[l].stream);

@@ -32,12 +32,14 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
     V.gk_terms = terms((size_t)C * nq * 8);
     V.misc_terms = terms((size_t)C * 3);
     V.slot_acc = soa4(ns * V_SLOT_SPLIT), V.gk_acc = soa4((size_t)C * nq), V.misc_acc = soa4((size_t)C * 3);
+    V.wide_acc = soa4(std::min<size_t>(C, V_WIDE_MAXP) * (VK * V_SLOT_TERMS + nq * V_WIDE_GK));
     V.sSg = k.soa(ns), V.sSh = k.soa(ns), V.sSkx = k.soa(ns), V.sSky = k.soa(ns), V.sSR = k.soa(ns), V.sSH = k.soa(ns), V.sSL = k.soa(ns);
     V.pSR = k.soa(C), V.pSH = k.soa(C), V.pSL = k.soa(C);
     V.pa_x = k.soa(ns), V.pa_y = k.soa(ns), V.pa_sc = k.soa(ns);
     V.pa_tab = (uint32_t*)k.take(ns * 8 * RTAB_ENTRY_WORDS * 4), V.pa_dig = (uint8_t*)k.take(ns * 33);
-    V.pacc = k.soa3((size_t)C * 4);
+    V.pacc = k.soa3(std::max<size_t>((size_t)C * (VK / 5 + 1), std::min<size_t>(C, V_WIDE_MAXP) * (VK + 1)));
     V.clx = k.soa(C), V.cly = k.soa(C);
+    V.cl_tab = (uint32_t*)k.take((size_t)C * 8 * RTAB_ENTRY_WORDS * 4), V.cl_dig = (uint8_t*)k.take((size_t)C * 35), V.p256_ok = (uint32_t*)k.take(4 * (size_t)C);
     M = MsmBuf{};
     if (want_msm) {   // batched Tom check (k_msm.hip): ~1.5 GB per lane, only where chunks are large enough to use it
         size_t cap = ns * V_SLOT_TERMS + (size_t)C * nq * 8 + (size_t)C * 3;
@@ -84,6 +86,11 @@ zk_status ensure_vworkspace(zk_ctx* c, uint32_t C, uint32_t nlanes) {
         }
         vcarve(L.V, L.res, L.res2, L.M, (uint8_t*)L.arena, C, sec, n, c->N, want_msm, c->verify_groups);
         if (!L.h_msm) HIPCHK(c, hipHostMalloc((void**)&L.h_msm, 1024, hipHostMallocMapped | hipHostMallocCoherent));
+        if (!L.aux_fork) HIPCHK(c, hipEventCreateWithFlags(&L.aux_fork, hipEventDisableTiming));
+        for (int i = 0; i < V_AUX_STREAMS; i++) {
+            if (!L.aux[i]) HIPCHK(c, hipStreamCreateWithFlags(&L.aux[i], hipStreamNonBlocking));
+            if (!L.aux_done[i]) HIPCHK(c, hipEventCreateWithFlags(&L.aux_done[i], hipEventDisableTiming));
+        }
         L.M.host = L.h_msm;
         L.ready = true;
     }
@@ -200,15 +207,18 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
         MaybeScope t(timed, c, "v_terms", s);
         launch_v_terms(s, W, V, cnt, d_proofs, d_off, d_vseeds, first);
     }
-    {
+    if (cnt > V_WIDE_MAXP) {   // (a small chunk's P-256 sums run in stage 2, one term per lane, beside its Tom-256 sums)
         MaybeScope t(timed, c, "v_straus_p256", s);
-        launch_v_p256_straus(s, V, cnt);
+        launch_v_p256_straus(s, V, cnt, 5);
     }
     return ZK_OK;
 }
 // Per-proof sums (windowed Straus + the two fixed-base commitments) of proofs [p0, p1) of a chunk: the unchanged kernels on
 // views of the term lists / accumulators that start at the range's first slot, gk group and proof.
-static void per_proof_range(zk_ctx* c, bool timed, hipStream_t s, const Workspace& W, const VWork& V, uint32_t p0, uint32_t p1, uint32_t range_no, uint32_t tsplit) {
+// At most V_WIDE_MAXP proofs (every call of a few proofs: the reference's own shape is ONE, zkpAttestList.ts:150-190): what the caller waits for is the
+// chain of dependent point operations of a lane, so every term gets a lane of its own (65 windows x (4 doublings + 1 addition) instead of x 13),
+// k_v_acc_tree folds the accumulators into the places k_v_final reads, and the independent sums run side by side on the lane's auxiliary streams.
+static void per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t lane, const Workspace& W, const VWork& V, uint32_t p0, uint32_t p1, uint32_t range_no, uint32_t tsplit) {
     const DevParams& P = c->P;
     const uint32_t nq = (c->n + 1) / 2;
     const uint32_t np = p1 - p0;
@@ -220,6 +230,30 @@ static void per_proof_range(zk_ctx* c, bool timed, hipStream_t s, const Workspac
         a.x.p += o, a.y.p += o, a.z.p += o, a.t.p += o;
         return a;
     };
+    TomList lc = W.lc;
+    {
+        const size_t o = (size_t)p0 * 4 * W.n;
+        for (Soa* a : {&lc.v, &lc.r, &lc.proj.x, &lc.proj.y, &lc.proj.z, &lc.ax, &lc.ay}) a->p += o;
+    }
+    if (np <= V_WIDE_MAXP) {
+        auto& A = c->vl[lane];
+        MaybeScope t(timed, c, "v_straus_tom", s);
+        hipEventRecord(A.aux_fork, s);
+        for (int i = 0; i < 3; i++) hipStreamWaitEvent(A.aux[i], A.aux_fork, 0);
+        const Soa4 wgk = acc_at(V.wide_acc, (size_t)np * VK * V_SLOT_TERMS);
+        launch_v_straus(A.aux[0], terms_at(V.gk_terms, (size_t)p0 * nq), np * nq, V.C * nq, 4, 4, wgk, nullptr, nullptr, V_WIDE_GK, V_WIDE_GK);
+        launch_v_acc_tree(A.aux[0], wgk, np, nq * V_WIDE_GK, acc_at(V.gk_acc, (size_t)p0 * nq), nq, nq - 1);
+        launch_v_straus(A.aux[1], terms_at(V.misc_terms, p0), np, 3 * V.C, 1, 0, acc_at(V.misc_acc, p0), nullptr, nullptr, 1, 1, 3, V.C);
+        launch_tom_commit(A.aux[2], P, lc, np * 2, 2, 4 * W.n);
+        const size_t so = (size_t)p0 * VK;
+        uint32_t* perm = V.slot_perm + so;
+        uint32_t* pc = V.slot_cnt + 2 * range_no;
+        launch_v_slot_perm(s, V.slot_class + so, np * VK, perm, pc);
+        launch_v_straus(s, terms_at(V.slot_terms, so), np * VK, V.C * VK, 10, 26, V.wide_acc, perm, pc, V_SLOT_TERMS, V_SLOT_TERMS);
+        launch_v_acc_tree(s, V.wide_acc, np * VK, V_SLOT_TERMS, acc_at(V.slot_acc, so * V_SLOT_SPLIT), V_SLOT_SPLIT, 0);
+        for (int i = 0; i < 3; i++) hipEventRecord(A.aux_done[i], A.aux[i]), hipStreamWaitEvent(s, A.aux_done[i], 0);
+        return;
+    }
     {
         MaybeScope t(timed, c, "v_straus_tom", s);
         const size_t so = (size_t)p0 * VK;
@@ -233,9 +267,6 @@ static void per_proof_range(zk_ctx* c, bool timed, hipStream_t s, const Workspac
     }
     {
         MaybeScope t(timed, c, "v_tom_fixed", s);
-        TomList lc = W.lc;
-        const size_t o = (size_t)p0 * 4 * W.n;
-        for (Soa* a : {&lc.v, &lc.r, &lc.proj.x, &lc.proj.y, &lc.proj.z, &lc.ax, &lc.ay}) a->p += o;
         launch_tom_commit(s, P, lc, np * 2, 2, 4 * W.n);
     }
 }
@@ -253,6 +284,21 @@ zk_status VerifyJob::stage2(uint64_t chunk_no) {
     // windowed sums only run for the groups whose total is not the identity -- some proof of theirs is bad -- to tell which
     const uint32_t G = c->vs_groups;   // 8 or 64 groups per chunk (zk_ctx_set_verify_groups)
     uint32_t flags[MSM_G_MAX], gsz = cnt;
+    const bool wide_chunk = cnt <= V_WIDE_MAXP;
+    auto& A = c->vl[lane];
+    if (wide_chunk) {   // the P-256 sums of a small chunk, one term per lane, beside everything below
+        hipEventRecord(A.aux_fork, s);
+        hipStreamWaitEvent(A.aux[3], A.aux_fork, 0);
+        {
+            MaybeScope t(timed, c, "v_straus_p256", A.aux[3]);
+            launch_v_p256_straus(A.aux[3], V, cnt, 1);
+        }
+        {
+            MaybeScope t(timed, c, "v_p256_total", A.aux[3]);
+            launch_v_p256_total(A.aux[3], P, W, V, cnt, 1);
+        }
+        hipEventRecord(A.aux_done[3], A.aux[3]);
+    }
     if (c->verify_batch_min && cnt >= c->verify_batch_min && M.cap) {
         MaybeScope t(timed, c, "v_msm_tom", s);
         TimerRec sub{"+v_msm_bucket", nullptr, nullptr};   // a part of v_msm_tom ('+': not added to the total again)
@@ -279,15 +325,18 @@ zk_status VerifyJob::stage2(uint64_t chunk_no) {
         while (g1 < G && (uint64_t)g1 * gsz < cnt && !flags[g1]) g1++;
         const uint32_t p0 = g * gsz, p1 = std::min<uint32_t>(cnt, g1 * gsz);
         // few slots: a slot's 36 terms over 4 lanes (the chain of one lane is ~12 ms long, the GPU is far from full)
-        const uint32_t tsplit = (uint64_t)(p1 - p0) * VK * V_SLOT_SPLIT <= 524288 ? V_SLOT_SPLIT : 1;   // up to two residencies of the GPU (4 waves per SIMD, 262 144 lanes)
-        per_proof_range(c, timed, s, W, V, p0, p1, ranges++, tsplit);
+        uint32_t tsplit = (uint64_t)(p1 - p0) * VK * V_SLOT_SPLIT <= 524288 ? V_SLOT_SPLIT : 1;   // up to two residencies of the GPU (4 waves per SIMD, 262 144 lanes)
+        per_proof_range(c, timed, s, lane, W, V, p0, p1, ranges++, tsplit);
+        if (p1 - p0 <= V_WIDE_MAXP) tsplit = 1;   // folded: one accumulator per slot
         c->dbg_recheck_proofs += p1 - p0;
         for (uint32_t k = g; k < g1; k++) gf.v[k] = V_RECHECK | tsplit;
         g = g1;
     }
+    if (wide_chunk) hipStreamWaitEvent(s, A.aux_done[3], 0);
     {
         MaybeScope t(timed, c, "v_final", s);
-        launch_v_final(s, P, W, V, cnt, d_ok, d_status, first, gf, gsz);
+        if (!wide_chunk) launch_v_p256_total(s, P, W, V, cnt, 5);
+        launch_v_final(s, W, V, cnt, d_ok, d_status, first, gf, gsz);
     }
     return ZK_OK;
 }

@@ -72,6 +72,8 @@ struct zk_ctx {
         Soa res{}, res2{};
         MsmBuf M{};               // batched Tom check buffers (k_msm.hip), carved with V
         uint32_t* h_msm = nullptr;   // page-locked read-back words of run_msm
+        hipStream_t aux[V_AUX_STREAMS] = {};   // small batches: the independent per-proof sums run side by side (api_verify.hip: per_proof_range)
+        hipEvent_t aux_fork = nullptr, aux_done[V_AUX_STREAMS] = {};
         bool ready = false;
     } vl[ZK_MAX_LANES];
     uint32_t vs_C = 0, vs_sec = 0, vs_n = 0;

@@ -171,6 +171,10 @@ struct Workspace {
 #define MSM_G_MAX 64
 #define MSM_NW_MAX 20
 #define V_SLOT_SPLIT 4      // slot accumulators per checked repetition (k_v_straus: a slot's terms over up to 4 lanes)
+#define V_WIDE_MAXP 256     // per-proof sums of at most this many proofs: ONE term per lane (a slot's 36 terms over 36 lanes, a membership group's 8 over 8), folded by
+                            // k_v_acc_tree, the five sums side by side on the lane's auxiliary streams -- the chain of a lane is what a small batch waits for
+#define V_WIDE_GK 8         // terms (= lanes) per membership group
+#define V_AUX_STREAMS 4
 #define V_RECHECK 0x100u    // group flag: per-proof sums were computed, low byte = lanes per slot
 struct VGroupFlags {        // per group of a chunk: 1 = passed the batched check, V_RECHECK | tsplit otherwise (kernel argument of k_v_final)
     uint32_t v[MSM_G_MAX];
@@ -211,13 +215,17 @@ struct VWork {
     uint32_t* slot_perm;  // [C*VK] per re-checked proof range: local slot ids, class-1 slots from the front, the others from the back
     uint32_t* slot_cnt;   // [2 * (MSM_G_MAX + 1)] how many of each, per range
     Soa4 slot_acc, gk_acc, misc_acc;
+    Soa4 wide_acc;        // [min(C, V_WIDE_MAXP) * (VK * 36 + nq * 8)] one accumulator per TERM of the slots, then of the membership groups (small batches)
     Soa sSg, sSh, sSkx, sSky, sSR, sSH, sSL;   // per slot partial sums
     Soa pSR, pSH, pSL;                         // per proof (mod n)
     Soa pa_x, pa_y, pa_sc;                     // P-256 A terms [C*VK]
     uint32_t* pa_tab;                          // [C*VK][8][28] multiples 1..8 of every A term (k_v_p256_straus)
     uint8_t* pa_dig;                           // [33][C*VK] signed 4-bit digits of the randomisers
-    Soa3 pacc;                                 // [C*4]
+    Soa3 pacc;                                 // [max(5 C, 21 min(C, V_WIDE_MAXP))] partial sums of k_v_p256_straus (5 lanes per proof, or 21 in a small chunk)
     Soa clx, cly;                              // Clambda (Montgomery affine)
+    uint32_t* cl_tab;                          // [C][8][28] multiples 1..8 of Clambda
+    uint8_t* cl_dig;                           // [35][C] signed 4-bit digits of SL
+    uint32_t* p256_ok;                         // [C] the P-256 relation holds (k_v_p256_total)
 };
 // ZKA1P -> ZKA1 for `count` proofs from proof `first` on: uoff[0 .. count] = their offsets in `out`, starting at `base` (k_verify.hip)
 void launch_v_unpack(hipStream_t s, uint32_t sec, uint32_t count, const uint8_t* packed, const uint64_t* poff, uint64_t first, uint64_t base, uint8_t* out, uint64_t* uoff);
@@ -243,11 +251,12 @@ void launch_gkm_etab_digits(hipStream_t s, const uint32_t* E, uint32_t nblocks, 
 void launch_gk_block_mfma(hipStream_t s, const Workspace& W, const ChunkIn& in, uint32_t nblocks, const Soa& res);
 void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first);
 void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out,
-                     const uint32_t* perm, const uint32_t* cnt, uint32_t tsplit = 1, uint32_t ostride = 1);
+                     const uint32_t* perm, const uint32_t* cnt, uint32_t tsplit = 1, uint32_t ostride = 1, uint32_t ny = 1, uint32_t ystride = 0);
+void launch_v_acc_tree(hipStream_t s, const Soa4& src, uint32_t nouter, uint32_t width, const Soa4& dst, uint32_t dstride, uint32_t fill);
 void launch_v_slot_perm(hipStream_t s, const uint8_t* slot_class, uint32_t nslots, uint32_t* perm, uint32_t* cnt);
-void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count);
-void launch_v_final(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first,
-                    const VGroupFlags& gf, uint32_t gsz);
+void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count, uint32_t per);   // per = A terms per lane: 5, or 1 for small batches
+void launch_v_p256_total(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t per);
+void launch_v_final(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first, const VGroupFlags& gf, uint32_t gsz);
 
 // chunk inputs (device pointers, already offset to the chunk's first proof)
 struct ChunkIn {

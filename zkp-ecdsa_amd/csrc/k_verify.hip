@@ -1149,11 +1149,11 @@ ZK_DEV void st_tab(const VTerms& L, uint32_t e, uint32_t idx, const TomPt& a) {
 #pragma unroll
     for (int i = 0; i < 9; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
-// thread t: term k = t / ngroups of group g = t % ngroups, at index k * ng_stride + g
-__global__ void __launch_bounds__(256, 2) k_v_term_tables(VTerms L, uint32_t ngroups, uint32_t ng_stride, uint32_t nt) {
-    uint32_t t = gtid();
+// thread t: term k = t / ngroups of group g = t % ngroups, at index k * ng_stride + g (+ blockIdx.y * ystride: several lists in one launch)
+__global__ void __launch_bounds__(256, 2) k_v_term_tables(VTerms L, uint32_t ngroups, uint32_t ng_stride, uint32_t nt, uint32_t ystride) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ngroups * nt) return;
-    uint32_t idx = (t / ngroups) * ng_stride + t % ngroups;
+    uint32_t idx = (t / ngroups) * ng_stride + t % ngroups + blockIdx.y * ystride;
     Sq sc = soa_ld<ModQ, 1>(L.sc, idx);
     uint32_t kw[8];
     words_from_limbs<8>(kw, sc.l);
@@ -1209,10 +1209,12 @@ ZK_DEV Fe<ModT, 4> ft_neg_sel(const Ft2& v, bool neg) {
 // tsplit > 1: a group's terms are dealt round-robin to tsplit lanes, each with its own accumulator (own doublings), written to
 // out[g * ostride + part]: a lane's chain of 65 windows x 36 additions is ~12 ms long on its own, so when only a few thousand
 // slots are re-checked (one failing group of the batched check) four short chains finish in a third of the time.
+// blockIdx.y: list y of several equally shaped ones, its terms and accumulators ystride entries further on (the three one-term sums of a proof).
 __global__ void __launch_bounds__(256) k_v_straus(VTerms L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, Soa4 out,
-                                                  const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cnt, uint32_t tsplit, uint32_t ostride) {
-    uint32_t lane = gtid();
+                                                  const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cnt, uint32_t tsplit, uint32_t ostride, uint32_t ystride) {
+    uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= ngroups * tsplit) return;
+    const uint32_t yo = blockIdx.y * ystride;
     const uint32_t gi = lane / tsplit, part = lane % tsplit;
     const uint32_t g = perm ? perm[gi] : gi;
     const bool full = !perm || gi < cnt[0];
@@ -1226,7 +1228,7 @@ __global__ void __launch_bounds__(256) k_v_straus(VTerms L, uint32_t ngroups, ui
         uint32_t kmax = w >= VW_NW128 ? n256 : nt;
 #pragma unroll 1
         for (uint32_t k = klo; k < kmax; k += kstep) {
-            uint32_t idx = k * ng_stride + g;
+            uint32_t idx = k * ng_stride + g + yo;
             uint32_t db = L.dig[(size_t)w * L.cap + idx];
             uint32_t d = db & 15;
             bool neg = (db & 0x80u) != 0;
@@ -1246,42 +1248,84 @@ __global__ void __launch_bounds__(256) k_v_straus(VTerms L, uint32_t ngroups, ui
             acc.t = fe_select(on, s.t, acc.t), acc.z = fe_select(on, s.z, acc.z);
         }
     }
-    const uint32_t o = g * ostride + part;
+    const uint32_t o = g * ostride + part + yo;
     soa_st(out.x, o, acc.x), soa_st(out.y, o, acc.y), soa_st(out.z, o, acc.z), soa_st(out.t, o, acc.t);
 }
 void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out,
-                     const uint32_t* perm, const uint32_t* cnt, uint32_t tsplit, uint32_t ostride) {
+                     const uint32_t* perm, const uint32_t* cnt, uint32_t tsplit, uint32_t ostride, uint32_t ny, uint32_t ystride) {
     if (!ngroups) return;
     const uint32_t nterms = ngroups * (n256 + n128);
-    hipLaunchKernelGGL(k_v_term_tables, dim3((nterms + 255) / 256), dim3(256), 0, s, L, ngroups, ng_stride, n256 + n128);
-    hipLaunchKernelGGL(k_v_straus, dim3((ngroups * tsplit + 255) / 256), dim3(256), 0, s, L, ngroups, ng_stride, n256, n128, out, perm, cnt, tsplit, ostride);
+    hipLaunchKernelGGL(k_v_term_tables, dim3((nterms + 255) / 256, ny), dim3(256), 0, s, L, ngroups, ng_stride, n256 + n128, ystride);
+    hipLaunchKernelGGL(k_v_straus, dim3((ngroups * tsplit + 255) / 256, ny), dim3(256), 0, s, L, ngroups, ng_stride, n256, n128, out, perm, cnt, tsplit, ostride, ystride);
+}
+// Sum of `width` consecutive accumulators per outer index, one wave each: src[o * width + q] -> dst[o * dstride], followed by `fill` identities
+// (the consumer adds a fixed number of accumulators per proof).  Lane q adds entries q, q + 64, ... and the 64 partial sums fold in six steps in LDS.
+__global__ void __launch_bounds__(64) k_v_acc_tree(Soa4 src, uint32_t width, Soa4 dst, uint32_t dstride, uint32_t fill) {
+    __shared__ uint32_t sh[36][64];
+    const uint32_t o = blockIdx.x, q = threadIdx.x;
+    TomPt acc = tom_identity();
+#pragma unroll 1
+    for (uint32_t k = q; k < width; k += 64) {
+        const uint32_t e = o * width + k;
+        TomPt a;
+        a.x = soa_ld<ModT, 2>(src.x, e), a.y = soa_ld<ModT, 2>(src.y, e), a.z = soa_ld<ModT, 2>(src.z, e), a.t = soa_ld<ModT, 2>(src.t, e);
+        acc = k == q ? a : tom_add(acc, a);
+    }
+#pragma unroll 1
+    for (uint32_t half = 32; half >= 1; half >>= 1) {
+        if (q >= half && q < 2 * half) {
+#pragma unroll
+            for (int l = 0; l < 9; l++) sh[l][q] = acc.x.l[l], sh[9 + l][q] = acc.y.l[l], sh[18 + l][q] = acc.z.l[l], sh[27 + l][q] = acc.t.l[l];
+        }
+        __syncthreads();
+        if (q < half) {
+            TomPt b;
+#pragma unroll
+            for (int l = 0; l < 9; l++) b.x.l[l] = sh[l][q + half], b.y.l[l] = sh[9 + l][q + half], b.z.l[l] = sh[18 + l][q + half], b.t.l[l] = sh[27 + l][q + half];
+            acc = tom_add(acc, b);
+        }
+        __syncthreads();
+    }
+    if (q <= fill) {
+        const TomPt r = q == 0 ? acc : tom_identity();
+        const uint32_t e = o * dstride + q;
+        soa_st(dst.x, e, r.x), soa_st(dst.y, e, r.y), soa_st(dst.z, e, r.z), soa_st(dst.t, e, r.t);
+    }
+}
+void launch_v_acc_tree(hipStream_t s, const Soa4& src, uint32_t nouter, uint32_t width, const Soa4& dst, uint32_t dstride, uint32_t fill) {
+    if (nouter) hipLaunchKernelGGL(k_v_acc_tree, dim3(nouter), dim3(64), 0, s, src, width, dst, dstride, fill);
 }
 // P-256: sum of rho_j * (-A_j) over the 20 checked repetitions, 5 terms per thread, 128-bit randomisers.  Signed 4-bit
 // windows like the Tom side: every thread first recodes its scalars (33 digits in [-7, 8]) and builds {1A..8A} for its
 // terms in global memory (projective, rtab.h entry format), then runs 33 windows of 4 doublings + 5 complete additions
 // (the bit-serial version computed 128 doublings + 640 additions per thread).
 #define VP_NW 33
-// one thread per term: digits of its randomiser and the multiples {1A..8A}
+#define VP_NW_CL 35   // SL * Clambda: SL is the sum of 20 128-bit values, < 2^133
+// one thread per term: digits of its scalar and the multiples {1A..8A}.  Threads [0, count * VK): the A terms; [count * VK, count * (VK + 1)): Clambda of
+// proof t - count * VK with the scalar SL (until round 4 a 136-step double-and-add inside k_v_final: 272 dependent additions where the window walk has 175)
 __global__ void __launch_bounds__(256, 2) k_v_p256_tables(VWork V, uint32_t count) {
-    uint32_t idx = gtid();
-    if (idx >= count * VK) return;
-    const uint32_t cap = V.C * VK;
+    uint32_t t = gtid();
+    if (t >= count * (VK + 1)) return;
+    const bool is_cl = t >= count * VK;
+    const uint32_t idx = is_cl ? t - count * VK : t;
+    const uint32_t cap = is_cl ? V.C : V.C * VK, nw = is_cl ? VP_NW_CL : VP_NW;
+    uint8_t* dig = is_cl ? V.cl_dig : V.pa_dig;
     uint32_t kw[8];
-    words_from_limbs<8>(kw, soa_ld<ModN, 1>(V.pa_sc, idx).l);
+    words_from_limbs<8>(kw, soa_ld<ModN, 1>(is_cl ? V.pSL : V.pa_sc, idx).l);
     uint32_t carry = 0;
 #pragma unroll 1
-    for (uint32_t w = 0; w < VP_NW; w++) {
+    for (uint32_t w = 0; w < nw; w++) {
         uint32_t d = (kw[0] & 15) + carry;
         shr256<4>(kw);
         bool neg = d > 8;
         carry = neg ? 1 : 0;
         if (neg) d = 16 - d;
-        V.pa_dig[(size_t)w * cap + idx] = (uint8_t)(d | (neg ? 0x80u : 0u));
+        dig[(size_t)w * cap + idx] = (uint8_t)(d | (neg ? 0x80u : 0u));
     }
     P256Aff a;
-    a.x = soa_ld<ModQ, 2>(V.pa_x, idx), a.y = soa_ld<ModQ, 2>(V.pa_y, idx);
+    a.x = soa_ld<ModQ, 2>(is_cl ? V.clx : V.pa_x, idx), a.y = soa_ld<ModQ, 2>(is_cl ? V.cly : V.pa_y, idx);
     P256Pt b = p256_from_affine(a), m = b;
-    uint32_t* e = V.pa_tab + (size_t)idx * 8 * RTAB_ENTRY_WORDS;
+    uint32_t* e = (is_cl ? V.cl_tab : V.pa_tab) + (size_t)idx * 8 * RTAB_ENTRY_WORDS;
     st_rtab(e, m);
     m = p256_dbl(b);
     st_rtab(e + RTAB_ENTRY_WORDS, m);
@@ -1291,28 +1335,66 @@ __global__ void __launch_bounds__(256, 2) k_v_p256_tables(VWork V, uint32_t coun
         st_rtab(e + d * RTAB_ENTRY_WORDS, m);
     }
 }
-// thread (p, q): windowed sum over terms 5q .. 5q+4 of proof p
-__global__ void __launch_bounds__(256) k_v_p256_straus(VWork V, uint32_t count) {
+// thread (p, q), q < parts: windowed sum over the A terms [q * per, q * per + per) of proof p; q == parts - 1: SL * Clambda.  per = 5 (five lanes per proof) for
+// chunks, per = 1 (21 lanes per proof) for small batches, where the length of a lane's chain is all that counts.  Result in pacc[p * parts + q].
+__global__ void __launch_bounds__(256) k_v_p256_straus(VWork V, uint32_t count, uint32_t per) {
     uint32_t t = gtid();
-    if (t >= count * 4) return;
-    uint32_t p = t / 4, q = t % 4;
-    const uint32_t cap = V.C * VK;
+    const uint32_t parts = VK / per + 1;
+    if (t >= count * parts) return;
+    uint32_t p = t / parts, q = t % parts;
+    const bool is_cl = q == parts - 1;
+    const uint32_t cap = is_cl ? V.C : V.C * VK, nterms = is_cl ? 1 : per;
+    const uint32_t i0 = is_cl ? p : p * VK + q * per;
+    const uint8_t* dig = is_cl ? V.cl_dig : V.pa_dig;
+    const uint32_t* tab = is_cl ? V.cl_tab : V.pa_tab;
     P256Pt acc = p256_identity();
 #pragma unroll 1
-    for (int w = VP_NW - 1; w >= 0; w--) {
+    for (int w = (is_cl ? VP_NW_CL : VP_NW) - 1; w >= 0; w--) {
 #pragma unroll 1
         for (int d = 0; d < 4; d++) acc = p256_dbl(acc);
 #pragma unroll 1
-        for (uint32_t k = 0; k < 5; k++) {
-            uint32_t idx = p * VK + q * 5 + k;
-            uint32_t db = V.pa_dig[(size_t)w * cap + idx], d = db & 15;
-            P256Pt e = ld_rtab(V.pa_tab + ((size_t)idx * 8 + (d ? d - 1 : 0)) * RTAB_ENTRY_WORDS);
+        for (uint32_t k = 0; k < nterms; k++) {
+            uint32_t idx = i0 + k;
+            uint32_t db = dig[(size_t)w * cap + idx], d = db & 15;
+            P256Pt e = ld_rtab(tab + ((size_t)idx * 8 + (d ? d - 1 : 0)) * RTAB_ENTRY_WORDS);
             e.y = fe_select((db & 0x80u) != 0, fq8_neg(e.y), e.y);
             P256Pt s = p256_add(acc, e);
             acc = p256_select(d != 0, s, acc);
         }
     }
     soa_st(V.pacc.x, t, acc.x), soa_st(V.pacc.y, t, acc.y), soa_st(V.pacc.z, t, acc.z);
+}
+// The P-256 relation of a proof: SR * R + SH * h_NIST + SL * Clambda + sum(-rho A) is the identity (weier.ts:117-119) -> p256_ok[p].  R through the
+// proof's own window table, h_NIST through its comb, the other `parts` sums from k_v_p256_straus.  Its own kernel since round 4: for a handful of
+// proofs it runs beside the Tom-256 sums on another stream.
+__global__ void __launch_bounds__(64, 2) k_v_p256_total(DevParams P, Workspace W, VWork V, uint32_t count, uint32_t parts) {
+    uint32_t p = gtid();
+    if (p >= count) return;
+    uint32_t ok = 0;
+    if (V.st[p] == ZK_OK && !(V.okflags[p] & 8)) {
+        uint32_t kw[8];
+        words_from_limbs<8>(kw, soa_ld<ModN, 1>(V.pSR, p).l);
+        P256Pt acc = p256_rtab_mul(W.rtab + (size_t)p * rtab_words(RTAB_VERIFY_BITS), kw, RTAB_VERIFY_BITS);
+        words_from_limbs<8>(kw, soa_ld<ModN, 1>(V.pSH, p).l);
+#pragma unroll 1
+        for (int w = 0; w < PFIX_NWIN; w++) {
+            uint32_t d = kw[0] & (PFIX_WIN_SIZE - 1);
+            shr256<PFIX_WIN_BITS>(kw);
+            const uint32_t* en = P.pfix_H + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + d);
+            P256Aff a;
+            for (int l = 0; l < 9; l++) a.x.l[l] = en[l], a.y.l[l] = en[9 + l];
+            P256Pt s = p256_add_mixed(acc, a);
+            acc = p256_select(d != 0, s, acc);
+        }
+#pragma unroll 1
+        for (uint32_t q = 0; q < parts; q++) {
+            P256Pt a;
+            a.x = soa_ld<ModQ, 8>(V.pacc.x, p * parts + q), a.y = soa_ld<ModQ, 8>(V.pacc.y, p * parts + q), a.z = soa_ld<ModQ, 8>(V.pacc.z, p * parts + q);
+            acc = p256_add(acc, a);
+        }
+        ok = fe_is_zero(fe_reduce(acc.x)) && fe_is_zero(fe_reduce(acc.z)) && !fe_is_zero(fe_reduce(acc.y));  // weier.ts:117-119
+    }
+    V.p256_ok[p] = ok;
 }
 
 // ------------------------------------------------------------------ final sums and verdict
@@ -1332,8 +1414,7 @@ ZK_DEV bool tom_is_identity(const TomPt& a) {  // edwards.ts:117-125 on the a=1 
 }
 // grp_ok[p / gsz] != 0: the batched check (k_msm.hip) found the Tom-256 total of the proof's group to be the identity, i.e. the
 // membership and Exp/Tom sums of every proof of the group are (their per-proof accumulators were not computed)
-__global__ void __launch_bounds__(64, 2) k_v_final(DevParams P, Workspace W, VWork V, uint32_t count, uint8_t* ok_out, int32_t* status_out, uint64_t first,
-                                                   VGroupFlags gf, uint32_t gsz) {
+__global__ void __launch_bounds__(64, 2) k_v_final(Workspace W, VWork V, uint32_t count, uint8_t* ok_out, int32_t* status_out, uint64_t first, VGroupFlags gf, uint32_t gsz) {
     uint32_t p = gtid();
     if (p >= count) return;
     const uint32_t flag = gf.v[p / gsz];          // 1: the group passed the batched check; else V_RECHECK | tsplit of its slot sums
@@ -1366,43 +1447,7 @@ __global__ void __launch_bounds__(64, 2) k_v_final(DevParams P, Workspace W, VWo
                     e = tom_add(e, ld_tom4(V.misc_acc, 2 * V.C + p));
                     okW = tom_is_identity(e);
                 }
-                // P-256: SR * R + SH * h_NIST + SL * Clambda + sum(-rho A)
-                P256Pt acc = p256_identity();
-                {
-                    uint32_t kw[8];
-                    words_from_limbs<8>(kw, soa_ld<ModN, 1>(V.pSR, p).l);
-                    acc = p256_rtab_mul(W.rtab + (size_t)p * rtab_words(RTAB_VERIFY_BITS), kw, RTAB_VERIFY_BITS);
-                    words_from_limbs<8>(kw, soa_ld<ModN, 1>(V.pSH, p).l);
-#pragma unroll 1
-                    for (int w = 0; w < PFIX_NWIN; w++) {
-                        uint32_t d = kw[0] & (PFIX_WIN_SIZE - 1);
-                        shr256<PFIX_WIN_BITS>(kw);
-                        const uint32_t* en = P.pfix_H + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + d);
-                        P256Aff a;
-                        for (int l = 0; l < 9; l++) a.x.l[l] = en[l], a.y.l[l] = en[9 + l];
-                        P256Pt s = p256_add_mixed(acc, a);
-                        acc = p256_select(d != 0, s, acc);
-                    }
-                    // SL * Clambda (SL < 2^133): double-and-add
-                    P256Aff cl;
-                    cl.x = soa_ld<ModQ, 2>(V.clx, p), cl.y = soa_ld<ModQ, 2>(V.cly, p);
-                    Sn sl = soa_ld<ModN, 1>(V.pSL, p);
-                    P256Pt c2 = p256_identity();
-#pragma unroll 1
-                    for (int b = 135; b >= 0; b--) {
-                        c2 = p256_dbl(c2);
-                        bool bit = (sl.l[b / 30] >> (b % 30)) & 1;
-                        P256Pt s = p256_add_mixed(c2, cl);
-                        c2 = p256_select(bit, s, c2);
-                    }
-                    acc = p256_add(acc, c2);
-                    for (uint32_t q = 0; q < 4; q++) {
-                        P256Pt a;
-                        a.x = soa_ld<ModQ, 8>(V.pacc.x, p * 4 + q), a.y = soa_ld<ModQ, 8>(V.pacc.y, p * 4 + q), a.z = soa_ld<ModQ, 8>(V.pacc.z, p * 4 + q);
-                        acc = p256_add(acc, a);
-                    }
-                }
-                bool okN = fe_is_zero(fe_reduce(acc.x)) && fe_is_zero(fe_reduce(acc.z)) && !fe_is_zero(fe_reduce(acc.y));  // weier.ts:117-119
+                const bool okN = V.p256_ok[p] != 0;   // k_v_p256_total
                 ok = (okW && okN) ? 1 : 0;
             }
         }
@@ -1462,11 +1507,13 @@ void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t 
     L1(k_v_proof_points, count * ((V.n + 1) / 2 * 8 + 3), 256, V, count, proofs, off, first);
     L1(k_v_proof_terms, count, 64, W, V, count, proofs, off, vseeds, first);
 }
-void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count) {
-    L1(k_v_p256_tables, count * VK, 256, V, count);
-    L1(k_v_p256_straus, count * 4, 256, V, count);
+void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count, uint32_t per) {
+    L1(k_v_p256_tables, count * (VK + 1), 256, V, count);
+    L1(k_v_p256_straus, count * (VK / per + 1), 256, V, count, per);
 }
-void launch_v_final(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first,
-                    const VGroupFlags& gf, uint32_t gsz) {
-    L1(k_v_final, count, 64, P, W, V, count, ok, status, first, gf, gsz);
+void launch_v_p256_total(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t per) {
+    L1(k_v_p256_total, count, 64, P, W, V, count, VK / per + 1);
+}
+void launch_v_final(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first, const VGroupFlags& gf, uint32_t gsz) {
+    L1(k_v_final, count, 64, W, V, count, ok, status, first, gf, gsz);
 }
