@@ -161,6 +161,9 @@ extern "C" void zk_ctx_destroy(zk_ctx* c) {
             if (c->vl[l].aux[i]) hipStreamDestroy(c->vl[l].aux[i]);
         }
         if (c->pl[l].copy_ev) hipEventDestroy(c->pl[l].copy_ev);
+        if (c->pl[l].side_fork) hipEventDestroy(c->pl[l].side_fork);
+        if (c->pl[l].side_done) hipEventDestroy(c->pl[l].side_done);
+        if (c->pl[l].side) hipStreamDestroy(c->pl[l].side);
         if (c->pl[l].copy_stream && (l == 0 || c->pl[l].copy_stream != c->pl[0].copy_stream)) hipStreamDestroy(c->pl[l].copy_stream);
         if (c->pl[l].stream) hipStreamDestroy(c->pl[l].stream);
     }
@@ -800,27 +803,41 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
         MaybeScope t(timed, c, "respond_write", s);
         launch_write_fixed(s, W, cnt, out);
     }
-    {
-        MaybeScope t(timed, c, "gk_fold", s);
-        launch_gk_scalars_fold(s, W, in, gk_am);
-        launch_gk_cd_scalars(s, W, cnt);
+    // A small chunk leaves the GPU idle and its phases are chains of latencies: the membership phase (list C, its own hash and responses) runs on the
+    // lane's side stream beside the PointAdd phase (list B); they share only what stage 1 and the scan left behind.
+    auto& PL = c->pl[pd.lane];
+    const bool beside = !sliced && cnt <= ZK_PROVE_SIDE_MAX;
+    hipStream_t sg = s;
+    if (beside) {
+        if (!PL.side) HIPCHK(c, hipStreamCreateWithFlags(&PL.side, hipStreamNonBlocking));
+        if (!PL.side_fork) HIPCHK(c, hipEventCreateWithFlags(&PL.side_fork, hipEventDisableTiming));
+        if (!PL.side_done) HIPCHK(c, hipEventCreateWithFlags(&PL.side_done, hipEventDisableTiming));
+        sg = PL.side;
+        HIPCHK(c, hipEventRecord(PL.side_fork, s));
+        HIPCHK(c, hipStreamWaitEvent(sg, PL.side_fork, 0));
     }
     {
-        MaybeScope t(timed, c, "tom_commit", s);
-        launch_tom_commit(s, P, W.lc, cnt * 4 * W.n, 1, 1);
+        MaybeScope t(timed, c, "gk_fold", sg);
+        launch_gk_scalars_fold(sg, W, in, gk_am);
+        launch_gk_cd_scalars(sg, W, cnt);
     }
     {
-        MaybeScope t(timed, c, "tom_normalize", s);
-        launch_tom_normalize(s, W.lc, cnt * 4 * W.n, 0, 1, 1);
+        MaybeScope t(timed, c, "tom_commit", sg);
+        launch_tom_commit(sg, P, W.lc, cnt * 4 * W.n, 1, 1);
     }
     {
-        MaybeScope t(timed, c, "hash", s);
-        launch_gk_hash(s, W, cnt, in.msg);
+        MaybeScope t(timed, c, "tom_normalize", sg);
+        launch_tom_normalize(sg, W.lc, cnt * 4 * W.n, 0, 1, 1);
     }
     {
-        MaybeScope t(timed, c, "respond_write", s);
-        launch_gk_respond(s, W, in, out);
+        MaybeScope t(timed, c, "hash", sg);
+        launch_gk_hash(sg, W, cnt, in.msg);
     }
+    {
+        MaybeScope t(timed, c, "respond_write", sg);
+        launch_gk_respond(sg, W, in, out);
+    }
+    if (beside) HIPCHK(c, hipEventRecord(PL.side_done, sg));
     std::vector<ChunkPlan> slices;
     if (sliced) slices = make_chunk_plan(cnt, S, 1, host_sink != nullptr && !more_follows, last_chunk ? ZK_SLICE_MIN / 2 : ZK_SLICE_MIN);   // the call's very last slices stay exposed
     else slices.push_back({0, cnt});
@@ -869,6 +886,7 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
                 launch_write_padd_points(s, Ws, items, out);
             }
         }
+        if (beside) HIPCHK(c, hipStreamWaitEvent(s, PL.side_done, 0));   // (not sliced: the one pass of this loop)
         if (host_sink) {   // every byte of proofs [p0, p1) is final: DMA them out behind the next slice's kernels
             const uint64_t b0 = sliced ? h_out_base[p0] : 0, b1 = sliced ? h_out_base[p1] : chunk_bytes;
             if (b1 > b0) {

@@ -37,7 +37,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
     V.pSR = k.soa(C), V.pSH = k.soa(C), V.pSL = k.soa(C);
     V.pa_x = k.soa(ns), V.pa_y = k.soa(ns), V.pa_sc = k.soa(ns);
     V.pa_tab = (uint32_t*)k.take(ns * 8 * RTAB_ENTRY_WORDS * 4), V.pa_dig = (uint8_t*)k.take(ns * 33);
-    V.pacc = k.soa3(std::max<size_t>((size_t)C * (VK / 5 + 1), std::min<size_t>(C, V_WIDE_MAXP) * (VK + 1)));
+    V.pacc = k.soa3(std::max<size_t>((size_t)C * (VK / 5 + 1), std::min<size_t>(C, V_SIDE_MAXP) * (VK + 1)));
     V.clx = k.soa(C), V.cly = k.soa(C);
     V.cl_tab = (uint32_t*)k.take((size_t)C * 8 * RTAB_ENTRY_WORDS * 4), V.cl_dig = (uint8_t*)k.take((size_t)C * 35), V.p256_ok = (uint32_t*)k.take(4 * (size_t)C);
     M = MsmBuf{};
@@ -173,15 +173,35 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
         if (d_packed) launch_v_unpack(s, V.sec, cnt, d_packed, d_poff, first, ubase[chunk_no], (uint8_t*)d_proofs, d_uoff + first + chunk_no);
         launch_v_header_validate(s, V, cnt, d_proofs, d_off, first);
     }
+    // A small chunk (per_proof_range below) is a chain of latencies: the two challenge hashes (one lane per proof, 16 KB each) and the membership
+    // total need nothing from the P-256 front end (R's window table: 256 doublings in a row) and run beside it on an auxiliary stream.
+    const bool small = cnt <= V_SIDE_MAXP;
+    auto& A = c->vl[lane];
+    hipStream_t sh = small ? A.aux[0] : s;
+    if (small) {
+        hipEventRecord(A.aux_fork, s);
+        hipStreamWaitEvent(sh, A.aux_fork, 0);
+    }
+    auto hash_and_gk = [&] {
+        {
+            MaybeScope t(timed, c, "v_hash", sh);
+            launch_v_challenges_sample(sh, V, cnt, d_proofs, d_off, d_vseeds, d_msg, first);
+        }
+        if (small) {
+            hipEventRecord(A.aux_done[0], sh);
+            MaybeScope t(timed, c, "v_gk_total", sh);
+            launch_v_gk_total(sh, V, W.ring, W.gk_etab, W.gk_kdig, cnt, W.N, d_proofs, d_off, first, vres, vres2);
+        }
+        if (small) hipEventRecord(A.aux_done[1], sh);
+    };
+    if (small) hash_and_gk();
     {
         MaybeScope t(timed, c, "v_p256_front_rtab", s);
         launch_v_front(s, P, W, V, cnt, d_proofs, d_off, d_msg, first);
         launch_rtab(s, W, cnt, RTAB_VERIFY_BITS);
     }
-    {
-        MaybeScope t(timed, c, "v_hash", s);
-        launch_v_challenges_sample(s, V, cnt, d_proofs, d_off, d_vseeds, d_msg, first);
-    }
+    if (small) hipStreamWaitEvent(s, A.aux_done[0], 0);   // challenges and sampled repetitions
+    else hash_and_gk();
     {
         MaybeScope t(timed, c, "v_p256_exp_points", s);
         launch_v_exp_points(s, W, V, cnt, d_proofs, d_off, first);
@@ -199,7 +219,8 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
         MaybeScope t(timed, c, "v_hash", s);
         launch_v_padd_hash(s, P, W, V, cnt, d_proofs, d_off, first);
     }
-    {
+    if (small) hipStreamWaitEvent(s, A.aux_done[1], 0);   // membership total
+    else {
         MaybeScope t(timed, c, "v_gk_total", s);
         launch_v_gk_total(s, V, W.ring, W.gk_etab, W.gk_kdig, cnt, W.N, d_proofs, d_off, first, vres, vres2);
     }
@@ -207,7 +228,7 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
         MaybeScope t(timed, c, "v_terms", s);
         launch_v_terms(s, W, V, cnt, d_proofs, d_off, d_vseeds, first);
     }
-    if (cnt > V_WIDE_MAXP) {   // (a small chunk's P-256 sums run in stage 2, one term per lane, beside its Tom-256 sums)
+    if (cnt > V_SIDE_MAXP) {   // (a small chunk's P-256 sums run in stage 2, one term per lane, beside its Tom-256 sums)
         MaybeScope t(timed, c, "v_straus_p256", s);
         launch_v_p256_straus(s, V, cnt, 5);
     }
@@ -284,7 +305,7 @@ zk_status VerifyJob::stage2(uint64_t chunk_no) {
     // windowed sums only run for the groups whose total is not the identity -- some proof of theirs is bad -- to tell which
     const uint32_t G = c->vs_groups;   // 8 or 64 groups per chunk (zk_ctx_set_verify_groups)
     uint32_t flags[MSM_G_MAX], gsz = cnt;
-    const bool wide_chunk = cnt <= V_WIDE_MAXP;
+    const bool wide_chunk = cnt <= V_SIDE_MAXP;
     auto& A = c->vl[lane];
     if (wide_chunk) {   // the P-256 sums of a small chunk, one term per lane, beside everything below
         hipEventRecord(A.aux_fork, s);

@@ -56,6 +56,8 @@ struct zk_ctx {
         size_t arena_bytes = 0;
         bool ready = false;
         uint32_t last_cnt = 0;          // proofs of the last chunk this lane started (zk_test_counter)
+        hipStream_t side = nullptr;     // small chunks: the membership phase of stage 2 runs beside the PointAdd phase (api.hip: ProveJob::stage2)
+        hipEvent_t side_fork = nullptr, side_done = nullptr;
         void* h_scan = nullptr;         // page-locked: the chunk's totals (4 x u32), item prefix sums (u32[C+1]) and byte prefix sums
         size_t h_scan_bytes = 0;        // (u64[C+1]) read back after the scan.  Pageable destinations made the runtime wait for
                                         // EVERY stream of the device (measured: the host sat 50 ms behind the other lane's kernels)
@@ -193,6 +195,7 @@ struct ChunkPlan {
     uint32_t cnt;
 };
 #define ZK_TAPER_MIN 2048u
+#define ZK_PROVE_SIDE_MAX 2048u   // chunks up to this size: stage 2's membership phase on the lane's side stream
 #define ZK_SLICE_MIN 1024u
 // sizes summing to B: the first `stagger` chunks grow C/stagger, 2C/stagger, ... (the lanes then finish out of phase), then
 // chunks of C, then (tail) halving chunks C/2, C/4, ... >= lo with the last size twice

@@ -171,8 +171,16 @@ struct Workspace {
 #define MSM_G_MAX 64
 #define MSM_NW_MAX 20
 #define V_SLOT_SPLIT 4      // slot accumulators per checked repetition (k_v_straus: a slot's terms over up to 4 lanes)
-#define V_WIDE_MAXP 256     // per-proof sums of at most this many proofs: ONE term per lane (a slot's 36 terms over 36 lanes, a membership group's 8 over 8), folded by
-                            // k_v_acc_tree, the five sums side by side on the lane's auxiliary streams -- the chain of a lane is what a small batch waits for
+// per-proof sums of at most V_WIDE_MAXP proofs: ONE term per lane (a slot's 36 terms over 36 lanes, a membership group's 8 over 8), folded by
+// k_v_acc_tree, the five sums side by side on the lane's auxiliary streams -- the chain of a lane is what a small batch waits for
+#ifndef V_WIDE_MAXP
+#define V_WIDE_MAXP 256
+#endif
+// chunks of at most V_SIDE_MAXP proofs leave the GPU mostly idle: the challenge hashes and the membership total run beside the P-256 front end, the P-256
+// sums (one term per lane) beside the Tom-256 sums, on the lane's auxiliary streams
+#ifndef V_SIDE_MAXP
+#define V_SIDE_MAXP 8192
+#endif
 #define V_WIDE_GK 8         // terms (= lanes) per membership group
 #define V_AUX_STREAMS 4
 #define V_RECHECK 0x100u    // group flag: per-proof sums were computed, low byte = lanes per slot
@@ -221,7 +229,7 @@ struct VWork {
     Soa pa_x, pa_y, pa_sc;                     // P-256 A terms [C*VK]
     uint32_t* pa_tab;                          // [C*VK][8][28] multiples 1..8 of every A term (k_v_p256_straus)
     uint8_t* pa_dig;                           // [33][C*VK] signed 4-bit digits of the randomisers
-    Soa3 pacc;                                 // [max(5 C, 21 min(C, V_WIDE_MAXP))] partial sums of k_v_p256_straus (5 lanes per proof, or 21 in a small chunk)
+    Soa3 pacc;                                 // [max(5 C, 21 min(C, V_SIDE_MAXP))] partial sums of k_v_p256_straus (5 lanes per proof, or 21 in a small chunk)
     Soa clx, cly;                              // Clambda (Montgomery affine)
     uint32_t* cl_tab;                          // [C][8][28] multiples 1..8 of Clambda
     uint8_t* cl_dig;                           // [35][C] signed 4-bit digits of SL
