@@ -806,7 +806,7 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
     // A small chunk leaves the GPU idle and its phases are chains of latencies: the membership phase (list C, its own hash and responses) runs on the
     // lane's side stream beside the PointAdd phase (list B); they share only what stage 1 and the scan left behind.
     auto& PL = c->pl[pd.lane];
-    const bool beside = !sliced && cnt <= ZK_PROVE_SIDE_MAX;
+    const bool beside = !sliced && plan.size() == 1 && cnt <= ZK_PROVE_SIDE_MAX;   // (chunks of a longer job overlap each other on the lanes already)
     hipStream_t sg = s;
     if (beside) {
         if (!PL.side) HIPCHK(c, hipStreamCreateWithFlags(&PL.side, hipStreamNonBlocking));

@@ -175,7 +175,7 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
     }
     // A small chunk (per_proof_range below) is a chain of latencies: the two challenge hashes (one lane per proof, 16 KB each) and the membership
     // total need nothing from the P-256 front end (R's window table: 256 doublings in a row) and run beside it on an auxiliary stream.
-    const bool small = cnt <= V_SIDE_MAXP;
+    const bool small = side_streams(cnt);
     auto& A = c->vl[lane];
     hipStream_t sh = small ? A.aux[0] : s;
     if (small) {
@@ -228,7 +228,7 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
         MaybeScope t(timed, c, "v_terms", s);
         launch_v_terms(s, W, V, cnt, d_proofs, d_off, d_vseeds, first);
     }
-    if (cnt > V_SIDE_MAXP) {   // (a small chunk's P-256 sums run in stage 2, one term per lane, beside its Tom-256 sums)
+    if (!small) {   // (a small chunk's P-256 sums run in stage 2, one term per lane, beside its Tom-256 sums)
         MaybeScope t(timed, c, "v_straus_p256", s);
         launch_v_p256_straus(s, V, cnt, 5);
     }
@@ -305,7 +305,7 @@ zk_status VerifyJob::stage2(uint64_t chunk_no) {
     // windowed sums only run for the groups whose total is not the identity -- some proof of theirs is bad -- to tell which
     const uint32_t G = c->vs_groups;   // 8 or 64 groups per chunk (zk_ctx_set_verify_groups)
     uint32_t flags[MSM_G_MAX], gsz = cnt;
-    const bool wide_chunk = cnt <= V_SIDE_MAXP;
+    const bool wide_chunk = side_streams(cnt);
     auto& A = c->vl[lane];
     if (wide_chunk) {   // the P-256 sums of a small chunk, one term per lane, beside everything below
         hipEventRecord(A.aux_fork, s);
