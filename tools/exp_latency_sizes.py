@@ -17,12 +17,13 @@ eng.set_comb_bits(16)
 eng.set_params(*eng.synth_params(2024), 80)
 ring, msg, sig, pk, which, seeds = eng.synth_workload(2024, nkeys, max(sizes))
 eng.set_ring(ring, nkeys)
-eng.set_lanes(1)
+lanes = int(os.environ.get('ZK_LAT_LANES', '1'))   # ZK_LAT_LANES=3: the call split into that many chunks on as many lanes
+eng.set_lanes(lanes)
 eng.set_batch_verify(bmin)
 pin = Z.PinnedBuffer(max(sizes) * 180000 + (1 << 20))
-out = {'lib': os.environ.get('ZKATTEST_LIB', 'main'), 'batch_verify_min': bmin}
+out = {'lib': os.environ.get('ZKATTEST_LIB', 'main'), 'batch_verify_min': bmin, 'lanes': lanes}
 for B in sizes:
-    eng.set_chunk(B)
+    eng.set_chunk((B + lanes - 1) // lanes)
     a = (msg[:32 * B], sig[:64 * B], pk[:64 * B], which[:B], seeds[:32 * B])
     tp, tv = [], []
     for k in range(6):

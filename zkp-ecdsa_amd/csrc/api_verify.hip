@@ -179,29 +179,31 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
     auto& A = c->vl[lane];
     hipStream_t sh = small ? A.aux[0] : s;
     if (small) {
-        hipEventRecord(A.aux_fork, s);
-        hipStreamWaitEvent(sh, A.aux_fork, 0);
+        HIPCHK(c, hipEventRecord(A.aux_fork, s));
+        HIPCHK(c, hipStreamWaitEvent(sh, A.aux_fork, 0));
     }
-    auto hash_and_gk = [&] {
+    auto hash_and_gk = [&]() -> hipError_t {
+        hipError_t e = hipSuccess;
         {
             MaybeScope t(timed, c, "v_hash", sh);
             launch_v_challenges_sample(sh, V, cnt, d_proofs, d_off, d_vseeds, d_msg, first);
         }
         if (small) {
-            hipEventRecord(A.aux_done[0], sh);
+            e = hipEventRecord(A.aux_done[0], sh);
             MaybeScope t(timed, c, "v_gk_total", sh);
             launch_v_gk_total(sh, V, W.ring, W.gk_etab, W.gk_kdig, cnt, W.N, d_proofs, d_off, first, vres, vres2);
         }
-        if (small) hipEventRecord(A.aux_done[1], sh);
+        if (small && e == hipSuccess) e = hipEventRecord(A.aux_done[1], sh);
+        return e;
     };
-    if (small) hash_and_gk();
+    if (small) HIPCHK(c, hash_and_gk());
     {
         MaybeScope t(timed, c, "v_p256_front_rtab", s);
         launch_v_front(s, P, W, V, cnt, d_proofs, d_off, d_msg, first);
         launch_rtab(s, W, cnt, RTAB_VERIFY_BITS);
     }
-    if (small) hipStreamWaitEvent(s, A.aux_done[0], 0);   // challenges and sampled repetitions
-    else hash_and_gk();
+    if (small) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[0], 0));   // challenges and sampled repetitions
+    else HIPCHK(c, hash_and_gk());
     {
         MaybeScope t(timed, c, "v_p256_exp_points", s);
         launch_v_exp_points(s, W, V, cnt, d_proofs, d_off, first);
@@ -219,7 +221,7 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
         MaybeScope t(timed, c, "v_hash", s);
         launch_v_padd_hash(s, P, W, V, cnt, d_proofs, d_off, first);
     }
-    if (small) hipStreamWaitEvent(s, A.aux_done[1], 0);   // membership total
+    if (small) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[1], 0));   // membership total
     else {
         MaybeScope t(timed, c, "v_gk_total", s);
         launch_v_gk_total(s, V, W.ring, W.gk_etab, W.gk_kdig, cnt, W.N, d_proofs, d_off, first, vres, vres2);
@@ -239,7 +241,7 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
 // At most V_WIDE_MAXP proofs (every call of a few proofs: the reference's own shape is ONE, zkpAttestList.ts:150-190): what the caller waits for is the
 // chain of dependent point operations of a lane, so every term gets a lane of its own (65 windows x (4 doublings + 1 addition) instead of x 13),
 // k_v_acc_tree folds the accumulators into the places k_v_final reads, and the independent sums run side by side on the lane's auxiliary streams.
-static void per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t lane, const Workspace& W, const VWork& V, uint32_t p0, uint32_t p1, uint32_t range_no, uint32_t tsplit) {
+static zk_status per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t lane, const Workspace& W, const VWork& V, uint32_t p0, uint32_t p1, uint32_t range_no, uint32_t tsplit) {
     const DevParams& P = c->P;
     const uint32_t nq = (c->n + 1) / 2;
     const uint32_t np = p1 - p0;
@@ -259,8 +261,8 @@ static void per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t lane,
     if (np <= V_WIDE_MAXP) {
         auto& A = c->vl[lane];
         MaybeScope t(timed, c, "v_straus_tom", s);
-        hipEventRecord(A.aux_fork, s);
-        for (int i = 0; i < 3; i++) hipStreamWaitEvent(A.aux[i], A.aux_fork, 0);
+        HIPCHK(c, hipEventRecord(A.aux_fork, s));
+        for (int i = 0; i < 3; i++) HIPCHK(c, hipStreamWaitEvent(A.aux[i], A.aux_fork, 0));
         const Soa4 wgk = acc_at(V.wide_acc, (size_t)np * VK * V_SLOT_TERMS);
         launch_v_straus(A.aux[0], terms_at(V.gk_terms, (size_t)p0 * nq), np * nq, V.C * nq, 4, 4, wgk, nullptr, nullptr, V_WIDE_GK, V_WIDE_GK);
         launch_v_acc_tree(A.aux[0], wgk, np, nq * V_WIDE_GK, acc_at(V.gk_acc, (size_t)p0 * nq), nq, nq - 1);
@@ -272,8 +274,11 @@ static void per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t lane,
         launch_v_slot_perm(s, V.slot_class + so, np * VK, perm, pc);
         launch_v_straus(s, terms_at(V.slot_terms, so), np * VK, V.C * VK, 10, 26, V.wide_acc, perm, pc, V_SLOT_TERMS, V_SLOT_TERMS);
         launch_v_acc_tree(s, V.wide_acc, np * VK, V_SLOT_TERMS, acc_at(V.slot_acc, so * V_SLOT_SPLIT), V_SLOT_SPLIT, 0);
-        for (int i = 0; i < 3; i++) hipEventRecord(A.aux_done[i], A.aux[i]), hipStreamWaitEvent(s, A.aux_done[i], 0);
-        return;
+        for (int i = 0; i < 3; i++) {
+            HIPCHK(c, hipEventRecord(A.aux_done[i], A.aux[i]));
+            HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[i], 0));
+        }
+        return ZK_OK;
     }
     {
         MaybeScope t(timed, c, "v_straus_tom", s);
@@ -290,6 +295,7 @@ static void per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t lane,
         MaybeScope t(timed, c, "v_tom_fixed", s);
         launch_tom_commit(s, P, lc, np * 2, 2, 4 * W.n);
     }
+    return ZK_OK;
 }
 zk_status VerifyJob::stage2(uint64_t chunk_no) {
     const DevParams& P = c->P;
@@ -308,8 +314,8 @@ zk_status VerifyJob::stage2(uint64_t chunk_no) {
     const bool wide_chunk = side_streams(cnt);
     auto& A = c->vl[lane];
     if (wide_chunk) {   // the P-256 sums of a small chunk, one term per lane, beside everything below
-        hipEventRecord(A.aux_fork, s);
-        hipStreamWaitEvent(A.aux[3], A.aux_fork, 0);
+        HIPCHK(c, hipEventRecord(A.aux_fork, s));
+        HIPCHK(c, hipStreamWaitEvent(A.aux[3], A.aux_fork, 0));
         {
             MaybeScope t(timed, c, "v_straus_p256", A.aux[3]);
             launch_v_p256_straus(A.aux[3], V, cnt, 1);
@@ -318,7 +324,7 @@ zk_status VerifyJob::stage2(uint64_t chunk_no) {
             MaybeScope t(timed, c, "v_p256_total", A.aux[3]);
             launch_v_p256_total(A.aux[3], P, W, V, cnt, 1);
         }
-        hipEventRecord(A.aux_done[3], A.aux[3]);
+        HIPCHK(c, hipEventRecord(A.aux_done[3], A.aux[3]));
     }
     if (c->verify_batch_min && cnt >= c->verify_batch_min && M.cap) {
         MaybeScope t(timed, c, "v_msm_tom", s);
@@ -347,13 +353,13 @@ zk_status VerifyJob::stage2(uint64_t chunk_no) {
         const uint32_t p0 = g * gsz, p1 = std::min<uint32_t>(cnt, g1 * gsz);
         // few slots: a slot's 36 terms over 4 lanes (the chain of one lane is ~12 ms long, the GPU is far from full)
         uint32_t tsplit = (uint64_t)(p1 - p0) * VK * V_SLOT_SPLIT <= 524288 ? V_SLOT_SPLIT : 1;   // up to two residencies of the GPU (4 waves per SIMD, 262 144 lanes)
-        per_proof_range(c, timed, s, lane, W, V, p0, p1, ranges++, tsplit);
+        if (zk_status zr = per_proof_range(c, timed, s, lane, W, V, p0, p1, ranges++, tsplit)) return zr;
         if (p1 - p0 <= V_WIDE_MAXP) tsplit = 1;   // folded: one accumulator per slot
         c->dbg_recheck_proofs += p1 - p0;
         for (uint32_t k = g; k < g1; k++) gf.v[k] = V_RECHECK | tsplit;
         g = g1;
     }
-    if (wide_chunk) hipStreamWaitEvent(s, A.aux_done[3], 0);
+    if (wide_chunk) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[3], 0));
     {
         MaybeScope t(timed, c, "v_final", s);
         if (!wide_chunk) launch_v_p256_total(s, P, W, V, cnt, 5);
@@ -424,7 +430,11 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
     }
     J.d_vseeds = d_vseeds;
     auto drain = [&] {   // nothing of this call may still be running when it returns
-        for (uint32_t l = 0; l < J.NL; l++) hipStreamSynchronize(c->pl[l].stream);
+        for (uint32_t l = 0; l < J.NL; l++) {
+            hipStreamSynchronize(c->pl[l].stream);
+            for (hipStream_t a : c->vl[l].aux)   // joined into the lane's stream by events on every regular path; an error may have cut a fork short
+                if (a) hipStreamSynchronize(a);
+        }
         if (host_src) hipStreamSynchronize(c->copy_stream);
     };
     zs = J.enqueue_h2d();
