@@ -77,3 +77,47 @@ def test_every_size_class_of_the_verifier_gives_the_same_verdicts():
         got = eng.verify_batch(msg, plist, vseeds=vs)
         assert got == want, (chunk, bmin, [i for i in range(B) if (got[0][i], got[1][i]) != (want[0][i], want[1][i])])
     eng.close()
+
+
+def test_soak_random_small_calls_against_precomputed_oracle_results():
+    """300 calls of random size and composition on ONE context, provers and verifiers interleaved, chunk size / lanes / bucket threshold changed in between:
+    the side streams of consecutive calls reuse the same events, accumulators and workspaces, so a missing join shows up as a wrong byte or verdict here.
+    A proof's verdict depends on its bytes and its verifier seed only (the engine's private randomisers change with its position in the batch, the outcome
+    must not): the oracle judges every (proof, seed) pair of the pool once."""
+    import random
+    import coracle as CO
+    import zkp_ecdsa_amd as Z
+    S, nkeys, NP = 6300, 64, 24
+    eng = Z.Engine(0)
+    nh, tg, th = eng.synth_params(S)
+    eng.set_comb_bits(16)
+    eng.set_params(nh, tg, th, 80)
+    ring, msg, sig, pk, which, seeds = eng.synth_workload(S, nkeys, NP)
+    eng.set_ring(ring, nkeys)
+    octx = CO.OracleCtx(nh, tg, th, 80)
+    octx.set_ring(ring, nkeys)
+    honest, st = octx.prove_batch(msg, sig, pk, which, seeds=seeds, nthreads=16)
+    assert st == [0] * NP
+    pool = []   # (message, proof bytes, verifier seed)
+    for i, p in enumerate(honest):
+        m = msg[32 * i:32 * i + 32]
+        pool.append((m, p, hashlib.sha256(b'soak-h' + bytes([i])).digest()))
+        pool.append((m, _forge(p, i % 5), hashlib.sha256(b'soak-f' + bytes([i])).digest()))
+    ok, vst = octx.verify_batch(b''.join(e[0] for e in pool), [e[1] for e in pool], nthreads=16, vseeds=b''.join(e[2] for e in pool))
+    assert ok[0::2] == [1] * NP and ok[1::2].count(0) >= NP // 2
+    rnd = random.Random(4)
+    cut = lambda buf, w, ids: b''.join(buf[w * i:w * i + w] for i in ids)
+    for call in range(300):
+        if call % 25 == 0:
+            eng.set_chunk(rnd.choice((4096, 16, 5)))
+            eng.set_lanes(rnd.choice((1, 2, 3)))
+            eng.set_batch_verify(rnd.choice((256, 0, 8)))
+        if call % 3 == 0:
+            ids = [rnd.randrange(NP) for _ in range(rnd.randint(1, 6))]
+            got, gst = eng.prove_batch(cut(msg, 32, ids), cut(sig, 64, ids), cut(pk, 64, ids), [which[i] for i in ids], seeds=cut(seeds, 32, ids))
+            assert gst == [0] * len(ids) and got == [honest[i] for i in ids], call
+        else:
+            ids = [rnd.randrange(len(pool)) for _ in range(rnd.randint(1, 40))]
+            g = eng.verify_batch(b''.join(pool[i][0] for i in ids), [pool[i][1] for i in ids], vseeds=b''.join(pool[i][2] for i in ids))
+            assert g == ([ok[i] for i in ids], [vst[i] for i in ids]), (call, ids)
+    eng.close()
