@@ -201,6 +201,26 @@ __global__ void __launch_bounds__(256) k_padd_inv(Workspace W, uint32_t items, u
 // 1..4 = openings of pi8, pi10, pi11, pi13; 5 = pix, piy.  Each part derives the witness values it needs from x1, y1, x2, y2, x3 and
 // i8 itself (at most two extra products), so no part holds more than a few scalars.
 #define PADD_PARTS 6
+// The six parts of an item read overlapping draws (the item's blinders d0 + 0..5, the repetition's and the proof's) and their neighbours in the same cache
+// lines.  ZK_PADD_TILED = 1 (default since round 4): a workgroup is six waves over the SAME 64 items, wave w = part w, so those lines are fetched once per
+// CU instead of once per part of a grid-wide sweep (part = t / items: the parts of an item ran a whole grid apart).  0 = the old mapping, for A/Bs.
+#ifndef ZK_PADD_TILED
+#define ZK_PADD_TILED 1
+#endif
+#if ZK_PADD_TILED
+#define PADD_BLOCK (64 * PADD_PARTS)
+#define PADD_GRID(items) dim3(((items) + 63) / 64)
+#define PADD_MAP(items, part, it)                                                                   \
+    const uint32_t part = threadIdx.x >> 6, it = blockIdx.x * 64 + (threadIdx.x & 63);             \
+    if (it >= (items)) return
+#else
+#define PADD_BLOCK 256
+#define PADD_GRID(items) dim3(((items) * PADD_PARTS + 255) / 256)
+#define PADD_MAP(items, part, it)                                                                   \
+    const uint32_t t_ = gtid();                                                                     \
+    if (t_ >= (items) * PADD_PARTS) return;                                                         \
+    const uint32_t part = t_ / (items), it = t_ % (items)
+#endif
 struct PaddIn {
     uint32_t p, i, d0;
     Sq x1, y1;
@@ -214,10 +234,8 @@ ZK_DEV PaddIn padd_in(const Workspace& W, uint32_t it) {
 }
 ZK_DEV Sq padd_i9(const Workspace& W, const PaddIn& a) { return fe_sub_mod(soa_ld<ModQ, 1>(W.pky, a.p), a.y1); }
 ZK_DEV Sq padd_i12(const Workspace& W, const PaddIn& a) { return fe_sub_mod(a.x1, soa_ld<ModQ, 1>(W.Tx, a.p * (W.sec + 1) + a.i)); }
-__global__ void __launch_bounds__(256) k_padd_scalars(Workspace W, uint32_t items) {
-    uint32_t t = gtid();
-    if (t >= items * PADD_PARTS) return;
-    uint32_t part = t / items, it = t % items;
+__global__ void __launch_bounds__(PADD_BLOCK) k_padd_scalars(Workspace W, uint32_t items) {
+    PADD_MAP(items, part, it);
     PaddIn a = padd_in(W, it);
     uint32_t p = a.p, d0 = a.d0;
     Sq i8 = fe_from_mont(soa_ld<ModQ, 2>(W.T1proj.y, it));
@@ -260,7 +278,7 @@ void launch_padd_scalars(hipStream_t s, const DevParams&, const Workspace& W, ui
     hipLaunchKernelGGL(k_padd_i7, dim3((items + 255) / 256), dim3(256), 0, s, W, items);
     uint32_t per = 16, nthreads = (items + per - 1) / per;
     hipLaunchKernelGGL(k_padd_inv, dim3((nthreads + 255) / 256), dim3(256), 0, s, W, items, nthreads, per);
-    hipLaunchKernelGGL(k_padd_scalars, dim3((items * PADD_PARTS + 255) / 256), dim3(256), 0, s, W, items);
+    hipLaunchKernelGGL(k_padd_scalars, PADD_GRID(items), dim3(PADD_BLOCK), 0, s, W, items);
 }
 
 // ---------------------------------------------------------------- PointAdd responses (mult.ts:122-130, equality.ts:73-77)
@@ -286,10 +304,8 @@ ZK_DEV void eq_respond(const Workspace& W, uint32_t p, uint32_t de, const uint32
     store_scalar_be(o + 64, fe_sub_mod(s2, fe_canon(cm * rc2)));
 }
 // Same split as k_padd_scalars: part 0 = the rep-level responses of a zero bit, 1..4 = pi8, pi10, pi11, pi13, 5 = pix, piy.
-__global__ void __launch_bounds__(256) k_padd_respond(Workspace W, uint32_t items, uint8_t* out) {
-    uint32_t t = gtid();
-    if (t >= items * PADD_PARTS) return;
-    uint32_t part = t / items, it = t % items;
+__global__ void __launch_bounds__(PADD_BLOCK) k_padd_respond(Workspace W, uint32_t items, uint8_t* out) {
+    PADD_MAP(items, part, it);
     uint32_t p = W.item_proof[it], i = W.item_rep[it];
     uint32_t d0 = 3 + 4 * W.sec + 40 * W.item_rank[it];
     const Wire& wr = W.wire;
@@ -336,9 +352,14 @@ __global__ void __launch_bounds__(256) k_padd_respond(Workspace W, uint32_t item
         }
     }
 }
+// Limit study (profiles/r04_ab_variants.txt (6)): -DZK_AB_SKIP_RESPOND=1 leaves the response / serialisation kernels out altogether -- the proofs are then
+// garbage -- to measure what the whole family costs the OVERLAPPED step, i.e. the most any rewrite of these kernels could win.  Never set in a product build.
+#ifndef ZK_AB_SKIP_RESPOND
+#define ZK_AB_SKIP_RESPOND 0
+#endif
 void launch_padd_respond(hipStream_t s, const Workspace& W, uint32_t items, uint8_t* out) {
-    if (!items) return;
-    hipLaunchKernelGGL(k_padd_respond, dim3((items * PADD_PARTS + 255) / 256), dim3(256), 0, s, W, items, out);
+    if (!items || ZK_AB_SKIP_RESPOND) return;
+    hipLaunchKernelGGL(k_padd_respond, PADD_GRID(items), dim3(PADD_BLOCK), 0, s, W, items, out);
 }
 
 // ---------------------------------------------------------------- ZKA1 fixed part and rep heads
@@ -394,6 +415,7 @@ __global__ void __launch_bounds__(256) k_write_fixed(Workspace W, uint32_t count
     }
 }
 void launch_write_fixed(hipStream_t s, const Workspace& W, uint32_t count, uint8_t* out) {
+    if (ZK_AB_SKIP_RESPOND) return;
     uint32_t n = count * (W.sec + 1);
     hipLaunchKernelGGL(k_write_fixed, dim3((n + 255) / 256), dim3(256), 0, s, W, count, out);
 }
@@ -462,7 +484,7 @@ __global__ void __launch_bounds__(256) k_write_padd_points(Workspace W, uint32_t
     }
 }
 void launch_write_padd_points(hipStream_t s, const Workspace& W, uint32_t items, uint8_t* out) {
-    if (!items) return;
+    if (!items || ZK_AB_SKIP_RESPOND) return;
     hipLaunchKernelGGL(k_write_padd_points, dim3((items + WP_ITEMS - 1) / WP_ITEMS), dim3(256), 0, s, W, items, out);
 }
 
@@ -563,6 +585,7 @@ __global__ void __launch_bounds__(256) k_write_gk_points(Workspace W, uint32_t c
     put_tom_pair(W.wire, gk + 4 * W.wire.tc * k, W.lc, p * 4 * W.n + 2 * k, p * 4 * W.n + 2 * k + 1);
 }
 void launch_gk_respond(hipStream_t s, const Workspace& W, const ChunkIn& in, uint8_t* out) {
+    if (ZK_AB_SKIP_RESPOND) return;
     hipLaunchKernelGGL(k_gk_respond, dim3((in.count + 63) / 64), dim3(64), 0, s, W, in, out);
     uint32_t n = in.count * 2 * W.n;
     hipLaunchKernelGGL(k_write_gk_points, dim3((n + 255) / 256), dim3(256), 0, s, W, in.count, out);
