@@ -937,7 +937,8 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
     J.c = c, J.B = B, J.d_msg = d_msg, J.d_sig = d_sig, J.d_pk = d_pk, J.d_which = d_which, J.rng_mode = rng_mode, J.d_rng = d_rng, J.stride = stride;
     J.d_out = d_out, J.out_cap = out_cap, J.d_out_off = d_out_off, J.d_status = d_status, J.host_sink = host_sink;
     J.C = (uint32_t)std::min<uint64_t>(c->chunk, B ? B : 1);
-    J.plan = make_chunk_plan(B, J.C, host_sink != nullptr && c->host_taper ? (c->host_taper == 1 ? c->lanes : c->host_taper) : 1, false);
+    static const int dev_stagger = [] { const char* e = getenv("ZK_DEVICE_STAGGER"); return e ? atoi(e) : 0; }();   // experiment (profiles/r04_ab_variants.txt (8))
+    J.plan = make_chunk_plan(B, J.C, host_sink != nullptr && c->host_taper ? (c->host_taper == 1 ? c->lanes : c->host_taper) : dev_stagger > 1 ? dev_stagger : 1, false);
     J.NL = (uint32_t)std::min<size_t>(c->lanes, J.plan.size() ? J.plan.size() : 1);  // chunks rotate over NL streams / workspaces
     zk_status zs = ensure_workspace(c, J.C, J.NL);
     if (zs) return zs;

@@ -207,6 +207,9 @@ __global__ void __launch_bounds__(256) k_padd_inv(Workspace W, uint32_t items, u
 #ifndef ZK_PADD_TILED
 #define ZK_PADD_TILED 1
 #endif
+#ifndef ZK_PADD_RESPOND_WAVES
+#define ZK_PADD_RESPOND_WAVES 3   // waves per SIMD k_padd_respond is compiled for (168 VGPRs)
+#endif
 #if ZK_PADD_TILED
 #define PADD_BLOCK (64 * PADD_PARTS)
 #define PADD_GRID(items) dim3(((items) + 63) / 64)
@@ -304,7 +307,7 @@ ZK_DEV void eq_respond(const Workspace& W, uint32_t p, uint32_t de, const uint32
     store_scalar_be(o + 64, fe_sub_mod(s2, fe_canon(cm * rc2)));
 }
 // Same split as k_padd_scalars: part 0 = the rep-level responses of a zero bit, 1..4 = pi8, pi10, pi11, pi13, 5 = pix, piy.
-__global__ void __launch_bounds__(PADD_BLOCK) k_padd_respond(Workspace W, uint32_t items, uint8_t* out) {
+__global__ void __launch_bounds__(PADD_BLOCK, ZK_PADD_RESPOND_WAVES) k_padd_respond(Workspace W, uint32_t items, uint8_t* out) {
     PADD_MAP(items, part, it);
     uint32_t p = W.item_proof[it], i = W.item_rep[it];
     uint32_t d0 = 3 + 4 * W.sec + 40 * W.item_rank[it];
