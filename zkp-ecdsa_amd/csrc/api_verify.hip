@@ -199,8 +199,16 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
     if (small) HIPCHK(c, hash_and_gk());
     {
         MaybeScope t(timed, c, "v_p256_front_rtab", s);
-        launch_v_front(s, P, W, V, cnt, d_proofs, d_off, d_msg, first);
+        launch_v_front_r(s, W, V, cnt, d_proofs, d_off, first);
+        hipStream_t sq = small ? A.aux[2] : s;   // Q = (z / R.x) G (an inversion and a comb walk) beside R's table
+        if (small) {
+            HIPCHK(c, hipEventRecord(A.aux_fork, s));
+            HIPCHK(c, hipStreamWaitEvent(sq, A.aux_fork, 0));
+        }
+        launch_v_front_q(sq, P, W, V, cnt, d_proofs, d_off, d_msg, first);
+        if (small) HIPCHK(c, hipEventRecord(A.aux_done[2], sq));
         launch_rtab(s, W, cnt, RTAB_VERIFY_BITS);
+        if (small) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[2], 0));
     }
     if (small) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[0], 0));   // challenges and sampled repetitions
     else HIPCHK(c, hash_and_gk());

@@ -146,6 +146,8 @@ struct Workspace {
     Soa gk_coef;                 // [(n+1)*C] final polynomial coefficients, index k*C + proof
     uint32_t gk_group;           // proofs per fold pass
     uint32_t* rng_fill;          // [C][nblk][8] the chunk's RNG fills as a stream (seed mode), see k_rng_prepass
+    uint8_t* exph_msg;           // [min(C, EXPH_MAXP)][blocks * 64] small chunks: the padded message of the Exp challenge (k_hash.hip: k_exph_*)
+    uint32_t* exph_wk;           // [min(C, EXPH_MAXP)][blocks][64] ... and its expanded schedule W_i + K_i
     uint32_t* gk_bufA;           // ping-pong level buffers
     uint32_t* gk_bufB;
     // block-transform path of the ring fold (k_gk.hip), used when the ring has a table E (9 <= n <= GK_ETAB_MAXN)
@@ -170,6 +172,7 @@ struct Workspace {
 // 16-bit windows or 64 groups with 13-bit windows (zk_ctx_set_verify_groups; k_msm.hip).
 #define MSM_G_MAX 64
 #define MSM_NW_MAX 20
+#define EXPH_MAXP 256       // chunks of at most this many proofs hash the Exp challenge through the three-kernel path (64 KB of schedule per proof)
 #define V_SLOT_SPLIT 4      // slot accumulators per checked repetition (k_v_straus: a slot's terms over up to 4 lanes)
 // per-proof sums of at most V_WIDE_MAXP proofs: ONE term per lane (a slot's 36 terms over 36 lanes, a membership group's 8 over 8), folded by
 // k_v_acc_tree, the five sums side by side on the lane's auxiliary streams -- the chain of a lane is what a small batch waits for
@@ -238,7 +241,8 @@ struct VWork {
 // ZKA1P -> ZKA1 for `count` proofs from proof `first` on: uoff[0 .. count] = their offsets in `out`, starting at `base` (k_verify.hip)
 void launch_v_unpack(hipStream_t s, uint32_t sec, uint32_t count, const uint8_t* packed, const uint64_t* poff, uint64_t first, uint64_t base, uint8_t* out, uint64_t* uoff);
 void launch_v_header_validate(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
-void launch_v_front(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* msg, uint64_t first);
+void launch_v_front_r(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);   // R (and W.st)
+void launch_v_front_q(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* msg, uint64_t first);   // Q, Clambda
 void launch_v_challenges_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, const uint8_t* msg, uint64_t first);
 void launch_v_exp_points(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_t1_scalars(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);

@@ -94,7 +94,114 @@ __global__ void __launch_bounds__(64) k_exp_challenge(Workspace W, uint32_t coun
         for (int i = 0; i < 4; i++) W.chal[4 * p + i] = c[i];
     }
 }
+// Small chunks (count <= EXPH_MAXP): the same digest in three kernels.  One lane per proof hashing 16 KB is a chain of 251 compressions, and of a
+// compression's ~1 650 instructions a third is the message schedule and a fifth the byte-wise absorption of 33-byte coordinates -- neither depends on the
+// chaining value.  k_exph_msg (one lane per point) writes the padded message, k_exph_sched (one lane per block) expands every block to its 64 words
+// W_i + K_i, k_exph_rounds (one lane per proof) runs the 64 rounds per block and nothing else: 1.33 -> 0.7 ms for one proof.
+ZK_DEV uint32_t exph_msg_bytes(uint32_t sec) { return 2 * 67 + sec * (65 + 2 * 67); }
+ZK_DEV uint32_t exph_blocks(uint32_t sec) { return (exph_msg_bytes(sec) + 9 + 63) / 64; }
+template <int NW>
+ZK_DEV void exph_put_coord(uint8_t* o, const uint32_t* w) {   // big-endian, (NW == 9 ? 33 : 32) bytes
+    constexpr int NB = NW == 9 ? 33 : 32;
+#pragma unroll
+    for (int i = 0; i < NB; i++) o[i] = (uint8_t)(w[(NB - 1 - i) >> 2] >> (8 * ((NB - 1 - i) & 3)));
+}
+__global__ void __launch_bounds__(256) k_exph_msg(Workspace W, uint32_t count) {
+    const uint32_t ne = 2 + 3 * W.sec + 1, t = gtid();
+    if (t >= count * ne) return;
+    const uint32_t p = t / ne, e = t % ne, nblk = exph_blocks(W.sec), len = exph_msg_bytes(W.sec);
+    uint8_t* m = W.exph_msg + (size_t)p * nblk * 64;
+    const uint32_t la = p * (2 + 2 * W.sec), ea = p * (W.sec + 1);
+    if (e == ne - 1) {   // padding: 0x80, zeros, the bit length in eight bytes
+        m[len] = 0x80;
+        for (uint32_t i = len + 1; i < nblk * 64 - 8; i++) m[i] = 0;
+        const uint64_t bits = (uint64_t)len * 8;
+        for (int i = 0; i < 8; i++) m[nblk * 64 - 1 - i] = (uint8_t)(bits >> (8 * i));
+        return;
+    }
+    uint32_t off, slot;
+    bool p256 = false;
+    if (e < 2) off = 67 * e, slot = la + e;
+    else {
+        const uint32_t j = (e - 2) / 3, k = (e - 2) % 3;
+        off = 134 + 199 * j + (k == 0 ? 0 : k == 1 ? 65 : 132);
+        p256 = k == 0, slot = p256 ? ea + j : la + 2 + 2 * j + (k - 1);
+    }
+    m[off] = 4;
+    if (p256) {
+        uint32_t w[8];
+        words_from_limbs<8>(w, soa_ld<ModQ, 1>(W.Ax, slot).l);
+        exph_put_coord<8>(m + off + 1, w);
+        words_from_limbs<8>(w, soa_ld<ModQ, 1>(W.Ay, slot).l);
+        exph_put_coord<8>(m + off + 33, w);
+    } else {
+        uint32_t w[9];
+        words_from_limbs<9>(w, soa_ld<ModT, 1>(W.la.ax, slot).l);
+        exph_put_coord<9>(m + off + 1, w);
+        words_from_limbs<9>(w, soa_ld<ModT, 1>(W.la.ay, slot).l);
+        exph_put_coord<9>(m + off + 34, w);
+    }
+}
+__global__ void __launch_bounds__(256) k_exph_sched(Workspace W, uint32_t count) {
+    const uint32_t nblk = exph_blocks(W.sec), t = gtid();
+    if (t >= count * nblk) return;
+    const uint4* src = (const uint4*)(W.exph_msg + (size_t)t * 64);
+    uint32_t w[64];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint4 v = src[i];
+        w[4 * i] = bswap32(v.x), w[4 * i + 1] = bswap32(v.y), w[4 * i + 2] = bswap32(v.z), w[4 * i + 3] = bswap32(v.w);
+    }
+#pragma unroll
+    for (int i = 16; i < 64; i++) {
+        const uint32_t w15 = w[i - 15], w2 = w[i - 2];
+        w[i] = w[i - 16] + zk_xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3) + w[i - 7] + zk_xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
+    }
+    uint4* dst = (uint4*)(W.exph_wk + (size_t)t * 64);
+#pragma unroll
+    for (int i = 0; i < 16; i++) dst[i] = make_uint4(w[4 * i] + SHA_K[4 * i], w[4 * i + 1] + SHA_K[4 * i + 1], w[4 * i + 2] + SHA_K[4 * i + 2], w[4 * i + 3] + SHA_K[4 * i + 3]);
+}
+__global__ void __launch_bounds__(64) k_exph_rounds(Workspace W, uint32_t count) {
+    const uint32_t p = gtid();
+    if (p >= count) return;
+    const uint32_t nblk = exph_blocks(W.sec);
+    const uint4* wk = (const uint4*)(W.exph_wk + (size_t)p * nblk * 64);
+    uint32_t h[8];
+    sha256_iv(h);
+    uint4 nx[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) nx[i] = wk[i];
+#pragma unroll 1
+    for (uint32_t b = 0; b < nblk; b++) {
+        uint32_t w[64];
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[4 * i] = nx[i].x, w[4 * i + 1] = nx[i].y, w[4 * i + 2] = nx[i].z, w[4 * i + 3] = nx[i].w;
+        if (b + 1 < nblk) {   // the next block's words travel while this block's rounds run
+#pragma unroll
+            for (int i = 0; i < 16; i++) nx[i] = wk[16 * (b + 1) + i];
+        }
+        uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+        for (int i = 0; i < 64; i++) {
+            const uint32_t t1 = hh + zk_xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25)) + zk_bfi(e, f, g) + w[i];
+            const uint32_t t2 = zk_xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22)) + zk_bfi(a ^ bb, c, bb);
+            hh = g, g = f, f = e, e = d + t1, d = c, c = bb, bb = a, a = t1 + t2;
+        }
+        h[0] += a, h[1] += bb, h[2] += c, h[3] += d, h[4] += e, h[5] += f, h[6] += g, h[7] += hh;
+    }
+    uint32_t cw[4];
+    challenge_words(h, cw);
+#pragma unroll
+    for (int i = 0; i < 4; i++) W.chal[4 * p + i] = cw[i];
+}
 void launch_exp_challenge(hipStream_t s, const Workspace& W, uint32_t count) {
+    if (count <= EXPH_MAXP && W.exph_wk) {
+        const uint32_t ne = 2 + 3 * W.sec + 1, nblk = (2 * 67 + W.sec * (65 + 2 * 67) + 9 + 63) / 64;
+        hipLaunchKernelGGL(k_exph_msg, dim3((count * ne + 255) / 256), dim3(256), 0, s, W, count);
+        hipLaunchKernelGGL(k_exph_sched, dim3((count * nblk + 255) / 256), dim3(256), 0, s, W, count);
+        hipLaunchKernelGGL(k_exph_rounds, dim3((count + 63) / 64), dim3(64), 0, s, W, count);
+        return;
+    }
     hipLaunchKernelGGL(k_exp_challenge, dim3((count + 63) / 64), dim3(64), 0, s, W, count);
 }
 

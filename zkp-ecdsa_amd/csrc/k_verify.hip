@@ -275,24 +275,35 @@ void launch_v_unpack(hipStream_t s, uint32_t sec, uint32_t count, const uint8_t*
 }
 
 // ------------------------------------------------------------------ front: R, Q (zkpAttestList.ts:153-164), kx, ky
-__global__ void __launch_bounds__(64) k_v_front(DevParams P, Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* msg, uint64_t first) {
+// R from the proof (what the window table of R needs), then Q = (z / R.x) G: two kernels, so that a small chunk can build R's table (256 doublings in a
+// row) while the second one inverts and walks the comb.
+__global__ void __launch_bounds__(64) k_v_front_r(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
     uint32_t p = gtid();
     if (p >= count) return;
     W.st[p] = V.st[p];
-    if (V.st[p] != ZK_OK || (V.okflags[p] & 8)) {
-        // keep later kernels on defined data: R = G
+    if (V.st[p] != ZK_OK || (V.okflags[p] & 8)) {   // keep later kernels on defined data: R = G
         soa_st(W.Rxm, p, fe_const<ModQ, 2>(P256_GX_M)), soa_st(W.Rym, p, fe_const<ModQ, 2>(P256_GY_M));
+        return;
+    }
+    const uint8_t* pr = proofs + off[first + p];
+    uint32_t xw[8], yw[8];
+    load_be32(pr + 32, xw);
+    load_be32(pr + 64, yw);
+    soa_st(W.Rxm, p, fe_to_mont(fe_from_words256_reduce<ModQ>(xw))), soa_st(W.Rym, p, fe_to_mont(fe_from_words256_reduce<ModQ>(yw)));
+}
+__global__ void __launch_bounds__(64) k_v_front_q(DevParams P, Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* msg, uint64_t first) {
+    uint32_t p = gtid();
+    if (p >= count) return;
+    if (V.st[p] != ZK_OK || (V.okflags[p] & 8)) {
         P256Pt id = p256_identity();
         soa_st(W.Q.x, p, id.x), soa_st(W.Q.y, p, id.y), soa_st(W.Q.z, p, id.z);
         return;
     }
     const uint8_t* pr = proofs + off[first + p];
-    uint32_t xw[8], yw[8], zw[8];
+    uint32_t xw[8], zw[8];
     load_be32(pr + 32, xw);
-    load_be32(pr + 64, yw);
     load_be32(msg + 32 * (first + p), zw);
-    Sq rx = fe_from_words256_reduce<ModQ>(xw), ry = fe_from_words256_reduce<ModQ>(yw);
-    soa_st(W.Rxm, p, fe_to_mont(rx)), soa_st(W.Rym, p, fe_to_mont(ry));
+    Sq rx = fe_from_words256_reduce<ModQ>(xw);
     // rinv = invMod(R.x, n); z1 = rinv * z; Q = G * z1
     uint32_t rxw[8];
     words_from_limbs<8>(rxw, rx.l);
@@ -1479,8 +1490,11 @@ void launch_v_header_validate(hipStream_t s, const VWork& V, uint32_t count, con
         hipLaunchKernelGGL(k_v_validate, dim3(count * ((per + 255) / 256)), dim3(256), 0, s, V, count, proofs, off, first);
     }
 }
-void launch_v_front(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* msg, uint64_t first) {
-    L1(k_v_front, count, 64, P, W, V, count, proofs, off, msg, first);
+void launch_v_front_r(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    L1(k_v_front_r, count, 64, W, V, count, proofs, off, first);
+}
+void launch_v_front_q(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* msg, uint64_t first) {
+    L1(k_v_front_q, count, 64, P, W, V, count, proofs, off, msg, first);
     L1(k_v_clambda, count, 64, V, count, proofs, off, first);
 }
 void launch_v_challenges_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, const uint8_t* msg, uint64_t first) {
