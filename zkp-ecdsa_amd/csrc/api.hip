@@ -686,6 +686,12 @@ zk_status ensure_copy_stream(zk_ctx* c) {   // the streams exist since zk_ctx_cr
 // lanes BEFORE the host blocks on a chunk's scan, so no stream runs dry while the host waits.
 // host_sink: page-locked destination of the proof bytes (or nullptr): every slice is copied out on its lane's copy stream as soon
 // as its last kernel has run, while the next slices / chunks are being proved.
+static zk_status ensure_side_stream(zk_ctx* c, zk_ctx::ProveLane& PL) {
+    if (!PL.side) HIPCHK(c, hipStreamCreateWithFlags(&PL.side, hipStreamNonBlocking));
+    if (!PL.side_fork) HIPCHK(c, hipEventCreateWithFlags(&PL.side_fork, hipEventDisableTiming));
+    if (!PL.side_done) HIPCHK(c, hipEventCreateWithFlags(&PL.side_done, hipEventDisableTiming));
+    return ZK_OK;
+}
 zk_status ProveJob::stage1(uint64_t chunk_no) {
     const ChunkPlan& cp = plan[chunk_no];
     const DevParams& P = c->P;
@@ -722,8 +728,18 @@ zk_status ProveJob::stage1(uint64_t chunk_no) {
     }
     {
         MaybeScope t(timed, c, "p256_normalize", s);
+        auto& PL = c->pl[lane];
+        const bool beside = plan.size() == 1 && cnt <= ZK_PROVE_SIDE_MAX;   // a small one-chunk call: the two lists (a workgroup inversion each) side by side
+        if (beside) {
+            zk_status zs = ensure_side_stream(c, PL);
+            if (zs) return zs;
+            HIPCHK(c, hipEventRecord(PL.side_fork, s));
+            HIPCHK(c, hipStreamWaitEvent(PL.side, PL.side_fork, 0));
+        }
+        launch_p256_normalize(beside ? PL.side : s, W.Aproj, cnt * (W.sec + 1), W.Ax, W.Ay, W.st, W.sec + 1, 0, nullptr);
+        if (beside) HIPCHK(c, hipEventRecord(PL.side_done, PL.side));
         launch_p256_normalize(s, W.Tproj, cnt * (W.sec + 1), W.Tx, W.Ty, W.st, W.sec + 1, ZK_ST_T_INF_LATE, nullptr);
-        launch_p256_normalize(s, W.Aproj, cnt * (W.sec + 1), W.Ax, W.Ay, W.st, W.sec + 1, 0, nullptr);
+        if (beside) HIPCHK(c, hipStreamWaitEvent(s, PL.side_done, 0));
     }
     uint32_t na = cnt * (2 + 2 * W.sec);
     {
@@ -813,9 +829,8 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
     const bool beside = !sliced && plan.size() == 1 && cnt <= ZK_PROVE_SIDE_MAX;   // (chunks of a longer job overlap each other on the lanes already)
     hipStream_t sg = s;
     if (beside) {
-        if (!PL.side) HIPCHK(c, hipStreamCreateWithFlags(&PL.side, hipStreamNonBlocking));
-        if (!PL.side_fork) HIPCHK(c, hipEventCreateWithFlags(&PL.side_fork, hipEventDisableTiming));
-        if (!PL.side_done) HIPCHK(c, hipEventCreateWithFlags(&PL.side_done, hipEventDisableTiming));
+        zk_status zs = ensure_side_stream(c, PL);
+        if (zs) return zs;
         sg = PL.side;
         HIPCHK(c, hipEventRecord(PL.side_fork, s));
         HIPCHK(c, hipStreamWaitEvent(sg, PL.side_fork, 0));

@@ -93,7 +93,14 @@ __global__ void __launch_bounds__(64, 2) k_front(DevParams P, Workspace W, Chunk
     Fn2 z = fe_to_mont(fe_from_words256_reduce<ModN>(zw));
     Fn2 r = fe_to_mont(fe_from_words256_reduce<ModN>(rw));
     Fn2 s = fe_to_mont(fe_from_words256_reduce<ModN>(sw));
-    Fn2 sinv = fe_inv<ModN>(s), rinv = fe_inv<ModN>(r);
+    // one Fermat inversion for both (Montgomery's trick): 1 / (s r), times r and times s.  invMod(0) = 0 (the reference's convention) is kept per
+    // operand: a zero operand is replaced by 1 inside the product and its inverse forced to 0 afterwards
+    const bool s0 = fe_is_zero(s), r0 = fe_is_zero(r);
+    const Fn2 one = fe_one_mont<ModN>().as<2>();
+    const Fn2 sn = fe_select(s0, one, s), rn = fe_select(r0, one, r);
+    const Fn2 inv_sr = fe_inv<ModN>(sn * rn);
+    const Fn2 zero2 = fe_zero<ModN>().as<2>();
+    Fn2 sinv = fe_select(s0, zero2, Fn2(inv_sr * rn)), rinv = fe_select(r0, zero2, Fn2(inv_sr * sn));
     Fe<ModN, 1> u1 = fe_from_mont(sinv * z), u2 = fe_from_mont(sinv * r);
     Fe<ModN, 1> s1 = fe_from_mont(rinv * s), z1 = fe_from_mont(rinv * z);
     soa_st(W.s1, p, s1);
