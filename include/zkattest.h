@@ -48,8 +48,8 @@ enum {
     ZK_E_INVALID_KEY = 2,        /* 'invalid public key'            src/zkpAttestList.ts:117 */
     ZK_E_T_INF = 3,              /* 'T[i] is at infinity'           src/exp/exp.ts:151 */
     ZK_E_T1_INF = 4,             /* 'T1 is at infinity'             src/exp/exp.ts:193 */
-    ZK_E_PADD_INF = 5,           /* 'P/Q/R is at infinity'          src/exp/pointAdd.ts:117-125 */
-    ZK_E_POINTS_DONT_ADD = 6,    /* "Points don't add up!"          src/exp/pointAdd.ts:105 */
+    ZK_E_PADD_INF = 5,           /* 'P/Q/R is at infinity'          src/exp/pointAdd.ts:117-125 (no input reaches it) */
+    ZK_E_POINTS_DONT_ADD = 6,    /* "Points don't add up!"          src/exp/pointAdd.ts:105 (a signature with r = 0 mod n: invMod(0) = 0) */
     ZK_E_R_INF = 7,              /* 'R is at infinity'              src/zkpAttestList.ts:159 */
     ZK_E_PARAMS_NOT_FOUND = 8,   /* 'params not found'              src/exp/exp.ts:270,302 */
     ZK_E_SECLEVEL = 9,           /* 'security level not achieved'   src/exp/exp.ts:244 */

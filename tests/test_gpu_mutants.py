@@ -97,8 +97,8 @@ def _stream(seed, nblocks, planted):
 def test_planted_fills_reach_the_provers_exceptions_like_the_oracle():
     """ZK_RNG_STREAM with planted draws.  alpha_i = 0 on a repetition i > 0: T_i = 0 * R is the identity, 'T[i] is at infinity'
     (exp.ts:151, status 3).  alpha_i = d / k for every i: T_i = pk, so T1 = T_i - pk is the identity at the first zero-bit
-    repetition, 'T1 is at infinity' (exp.ts:193, status 4).  Statuses 5 and 6 (pointAdd.ts:105-125) cannot be reached: P = T1 and R = T_i
-    were just checked, Q = pk is a valid key, and T1 + pk = T_i holds identically."""
+    repetition, 'T1 is at infinity' (exp.ts:193, status 4).  Status 5 (pointAdd.ts:117-125) cannot be reached: P = T1 and R = T_i were just
+    checked and Q = pk is a valid key; status 6 (pointAdd.ts:105) needs r = 0 mod n (tests/test_gpu_prove.py::test_error_statuses; DESIGN.md section 5)."""
     import coracle as CO
     import zkattest_ref as R
     import zkp_ecdsa_amd as Z

@@ -75,15 +75,17 @@ def test_engine_matches_golden(name):
 
 def test_error_statuses():
     """Per-proof statuses mirror the reference's thrown errors; a bad proof does not disturb its neighbours."""
-    eng, octx, (msg, sig, pk, which, seeds) = _setup(31, 8, 4)
+    eng, octx, (msg, sig, pk, which, seeds) = _setup(31, 8, 6)
     msg, sig, pk = bytearray(msg), bytearray(sig), bytearray(pk)
     pk[64 * 1 + 63] ^= 1                       # proof 1: public key off the curve
     sig[64 * 2 + 32:64 * 2 + 64] = bytes(32)   # proof 2: s = 0 -> R at infinity
-    which = list(which)
+    sig[64 * 4:64 * 4 + 32] = bytes(32)        # proof 4: r = 0 -> invMod(0) = 0 (big.ts:113-119): s1 = z1 = 0, T1 = T_i: "Points don't add up!"
+    which = list(which)                        # (pointAdd.ts:105; rounds 1-3 reported 3 here, DESIGN.md section 5)
+    sig[64 * 5:64 * 5 + 32] = (0xffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551).to_bytes(32, 'big')   # proof 5: r = n, the same
     got, st = eng.prove_batch(bytes(msg), bytes(sig), bytes(pk), which, seeds=seeds)
-    exp, est = octx.prove_batch(bytes(msg), bytes(sig), bytes(pk), which, seeds=seeds, nthreads=4)
-    assert st == est == [0, 1, 3, 0]
-    assert got[0] == exp[0] and got[3] == exp[3] and got[1] is None and got[2] is None
+    exp, est = octx.prove_batch(bytes(msg), bytes(sig), bytes(pk), which, seeds=seeds, nthreads=6)
+    assert st == est == [0, 1, 3, 0, 6, 6]
+    assert got[0] == exp[0] and got[3] == exp[3] and got[1] is None and got[2] is None and got[4] == exp[4]
     # stream too short -> randomness exhausted, not garbage
     blocks = b''.join(hashlib.sha256(b'blk%d' % k).digest() for k in range(100))
     _, st = eng.prove_batch(bytes(msg[:32]), bytes(sig[:64]), bytes(pk[:64]), which[:1], streams=blocks, stream_blocks=100)

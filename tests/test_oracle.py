@@ -248,3 +248,11 @@ def test_error_statuses_match_reference_throws():
     with pytest.raises(ValueError):
         R.proveSignatureList(R.synth_params(case['S'], case['sec']), msg, sig[:32] + bytes(32), b'\x04' + pk, 0,
                              [int(v, 16) for v in case['ring']], R.SeedRng(seed))
+    # r = 0 (and r = n): invMod(0) = 0 (big.ts:113-119) makes s1 = z1 = 0, T1 = T_i, and provePointAdd throws at the first zero-bit repetition
+    n_be = (0xffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551).to_bytes(32, 'big')
+    for r_bytes in (bytes(32), n_be):
+        _, st = c.prove_batch(msg, r_bytes + sig[32:], pk, [0], seeds=seed)
+        assert st == [6]                               # "Points don't add up!" (pointAdd.ts:105)
+        with pytest.raises(ValueError, match="Points don't add up"):
+            R.proveSignatureList(R.synth_params(case['S'], case['sec']), msg, r_bytes + sig[32:], b'\x04' + pk, 0,
+                                 [int(v, 16) for v in case['ring']], R.SeedRng(seed))

@@ -420,7 +420,7 @@ static size_t carve(zk_ctx* c, Workspace& W, Soa& gk_am, uint8_t* base, uint32_t
     W.Rxm = k.soa(C), W.Rym = k.soa(C), W.Rx = k.soa(C), W.Ry = k.soa(C);
     W.Q = k.soa3(C), W.s1 = k.soa(C);
     W.ktab = c->ktab, W.ktab_ok = c->ktab_ok;
-    W.kt_use = (uint8_t*)k.take((size_t)C), W.kt_key = (uint32_t*)k.take(4 * (size_t)C);
+    W.kt_use = (uint8_t*)k.take((size_t)C), W.kt_key = (uint32_t*)k.take(4 * (size_t)C), W.r_zero = (uint8_t*)k.take((size_t)C);
     W.u1m = k.soa(C), W.u2m = k.soa(C);
     W.rtab = (uint32_t*)k.take(sizeof(uint32_t) * (size_t)std::max(rtab_words(RTAB_PROVE_BITS), rtab_words(RTAB_VERIFY_BITS)) * C);
     W.rbase = k.soa3((size_t)C * RTAB_MAX_NWIN);

@@ -146,6 +146,7 @@ struct Workspace {
     Soa gk_coef;                 // [(n+1)*C] final polynomial coefficients, index k*C + proof
     uint32_t gk_group;           // proofs per fold pass
     uint32_t* rng_fill;          // [C][nblk][8] the chunk's RNG fills as a stream (seed mode), see k_rng_prepass
+    uint8_t* r_zero;             // [C] r = 0 mod n (k_front)
     uint8_t* exph_msg;           // [min(C, EXPH_MAXP)][blocks * 64] small chunks: the padded message of the Exp challenge (k_hash.hip: k_exph_*)
     uint32_t* exph_wk;           // [min(C, EXPH_MAXP)][blocks][64] ... and its expanded schedule W_i + K_i
     uint32_t* gk_bufA;           // ping-pong level buffers

@@ -117,6 +117,7 @@ __global__ void __launch_bounds__(64, 2) k_front(DevParams P, Workspace W, Chunk
         }
     }
     W.kt_use[p] = (uint8_t)use, W.kt_key[p] = in.which[p];
+    W.r_zero[p] = r0 ? 1 : 0;   // r = 0 mod n: s1 = z1 = 0 and the relation T1 + pk = T_i of k_t1 does not hold -- k_scan gives the proof the reference's exception
     soa_st(W.u1m, p, fe_canon(sinv * z)), soa_st(W.u2m, p, fe_canon(sinv * r));
     uint32_t* area = front_area(W, p);
     {
@@ -323,7 +324,10 @@ __global__ void __launch_bounds__(256) k_p256_normalize(Soa3 proj, uint32_t coun
             bool zero = fe_is_zero(z);
             if (zero) {
                 uint32_t o = owner ? owner[e] : e / per_proof;
-                if (err_code && atomicCAS(&st[o], ZK_OK, err_code) == ZK_E_ARG) atomicCAS(&st[o], ZK_E_ARG, err_code);   // `which` out of range is found last in the reference
+                // The prover's T list holds s1 * R as entry `sec` of a proof (k_exp_commit: comS1 = s1 R + r0 h).  The reference never takes its affine
+                // form (commit() adds the two products, weier.ts), so s1 = 0 -- r = 0 mod n, invMod(0) = 0 -- is no 'T[i] is at infinity' there.
+                const bool counts = !(err_code == ZK_ST_T_INF_LATE && e % per_proof == per_proof - 1);
+                if (err_code && counts && atomicCAS(&st[o], ZK_OK, err_code) == ZK_E_ARG) atomicCAS(&st[o], ZK_E_ARG, err_code);   // `which` out of range is found last in the reference
                 z = fe_one_mont<ModQ>().as<2>();
             }
             soa_st(ox, e, acc);
@@ -379,6 +383,8 @@ void launch_p256_normalize(hipStream_t s, const Soa3& proj, uint32_t count, cons
 }
 
 // ---------------------------------------------------------------- T1 = (alpha_i - s1) * R + Q  (exp.ts:186-191)
+// (r = 0 mod n is the one input for which the identity below fails -- invMod(0) = 0 makes s1 = z1 = 0, T1 = T_i, and provePointAdd throws
+// "Points don't add up!" at the first zero-bit repetition, pointAdd.ts:104-106: k_scan gives such a proof ZK_E_POINTS_DONT_ADD and no items.)
 // alpha_i * R is T_i, already in Tproj (k_exp_commit), and s1 * R = Q + pk identically (s1 = s/r, R = (z/s) G + (r/s) pk,
 // Q = (z/r) G: the relation the whole proof is about), so T1 = T_i - pk: one mixed addition instead of a second
 // 256-bit scalar multiplication per zero-bit repetition.  Same group element, hence the same affine bytes; T1 = identity

@@ -75,6 +75,9 @@ __global__ void __launch_bounds__(SCAN_T) k_scan(Workspace W, uint32_t count, ui
             else if (st == ZK_ST_T_INF_LATE) st = ZK_E_T_INF;
             W.st[p] = st;
         }
+        // r = 0 mod n (k_front): the first zero-bit repetition throws "Points don't add up!" (pointAdd.ts:104-106) -- after the commit phase's
+        // 'T[i] is at infinity' (above), before proveMembership's `which` (ZK_E_ARG)
+        if (W.r_zero[p] && (st == ZK_OK || st == ZK_E_ARG) && z > 0) W.st[p] = st = ZK_E_POINTS_DONT_ADD;
         if (st != ZK_OK) z = 0;
         W.zcnt[p] = z;
         items += z;
