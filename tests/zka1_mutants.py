@@ -247,6 +247,18 @@ def mutants(proofs, n, S, synth_S):
             zbad = (-sign * z1 * pow(k, -1, P256_N)) % P256_N
             for i in rnd.sample(lj.zero_reps, 3):
                 add('T1inf(%+d)-rep%d' % (sign, i), j, _put(proofs[j], lj.rep[i] + 208, zbad.to_bytes(32, 'big')))
+    # 16. the P-256 point with x = 0, (0, sqrt(b)): a valid point whose x has no inverse mod n -- as R it makes rinv = invMod(0) = 0 (big.ts:113-119), so
+    # z1 = 0 and Q = 0 * G is the identity (zkpAttestList.ts:156-163); also as comS1 and as the A of a repetition of either kind
+    y0 = pow(R.p256.b, (P + 1) // 4, P)
+    assert y0 * y0 % P == R.p256.b % P
+    for j in range(np_):
+        lj = L[j]
+        for yy, tag in ((y0, '+'), (P - y0, '-')):
+            pt = bytes(32) + yy.to_bytes(32, 'big')
+            add('R=(0,%ssqrt b)' % tag, j, _put(proofs[j], 32, pt))
+            add('comS1=(0,%ssqrt b)' % tag, j, _put(proofs[j], 96, pt))
+            add('A%d=(0,%ssqrt b)' % (lj.zero_reps[0], tag), j, _put(proofs[j], lj.rep[lj.zero_reps[0]], pt))
+            add('A%d=(0,%ssqrt b)' % (lj.one_reps[0], tag), j, _put(proofs[j], lj.rep[lj.one_reps[0]], pt))
     # 15. a whole repetition taken from the other proof (same kind), the whole GK proof of the other proof
     if np_ >= 2:
         for _ in range(4):
