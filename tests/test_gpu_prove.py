@@ -335,3 +335,40 @@ def test_key_tables_equal_the_per_proof_tables_and_fall_back_where_they_must(mon
     ok, vst = eng.verify_batch(msg, got)
     assert ok[:60] == [1] * 60 and not any(ok[60:]) and vst == [0] * B   # a proof for a slot that is not the signer's does not verify
     eng.close(), ref.close()
+
+
+def test_degenerate_prover_inputs_give_the_oracles_bytes_and_statuses():
+    """Inputs the reference does not reject and a service must not mis-handle: the reference validates neither the signature nor that the key sits at
+    `which` (zkpAttestList.ts:104-145 -- it proves whatever it is handed; such proofs simply do not verify), reduces what it needs mod n and keeps
+    invMod(0) = 0.  Whatever it makes of them, the engine makes the same bytes and statuses -- on the key-table path and without it."""
+    n = 0xffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551
+    for keytab in (1, 0):
+        import os
+        os.environ['ZKATTEST_KEYTAB'] = str(keytab)
+        try:
+            eng, octx, (msg, sig, pk, which, seeds) = _setup(88, 8, 8)
+        finally:
+            del os.environ['ZKATTEST_KEYTAB']
+        msg, sig, which = bytearray(msg), bytearray(sig), list(which)
+        msg[32 * 1:32 * 2] = bytes(32)                          # z = 0: u1 = 0, z1 = 0, Q = 0 * G
+        msg[32 * 2:32 * 3] = n.to_bytes(32, 'big')              # z = n: the same after reduction
+        msg[32 * 3:32 * 4] = b'\xff' * 32                       # z >= n
+        which[4] = (which[4] + 1) % 8                           # the key is not the one at `which`
+        s5 = int.from_bytes(sig[64 * 5 + 32:64 * 5 + 64], 'big')
+        sig[64 * 5 + 32:64 * 5 + 64] = (n - s5).to_bytes(32, 'big')   # s -> n - s (the other root: R -> -R)
+        sig[64 * 6:64 * 6 + 32] = b'\xff' * 32                  # r >= n: reduced
+        sig[64 * 7 + 32:64 * 7 + 64] = n.to_bytes(32, 'big')    # s = n = 0 mod n: R at infinity
+        args = (bytes(msg), bytes(sig), pk, which)
+        got, st = eng.prove_batch(*args, seeds=seeds)
+        exp, est = octx.prove_batch(*args, seeds=seeds, nthreads=8)
+        assert st == est, (keytab, st, est)
+        assert st[7] == 3 and st[0] == 0
+        for b in range(8):
+            assert got[b] == exp[b], (keytab, b)
+        live = [b for b in range(8) if st[b] == 0]
+        vs = b''.join(hashlib.sha256(b'dg%d' % b).digest() for b in live)
+        sub = lambda buf, w: b''.join(buf[w * b:w * b + w] for b in live)
+        gv = eng.verify_batch(sub(args[0], 32), [got[b] for b in live], vseeds=vs)
+        assert gv == octx.verify_batch(sub(args[0], 32), [got[b] for b in live], nthreads=8, vseeds=vs)
+        assert gv[0][0] == 1
+        eng.close()
