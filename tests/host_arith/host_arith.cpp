@@ -171,6 +171,17 @@ extern "C" int ha_p256_mul(uint64_t count, const uint8_t* xy64, const uint8_t* k
     return bad;
 }
 // complete addition on arbitrary pairs (P = Q, P = -Q included)
+// 2^nd * P through the Jacobian doubling chain of the per-proof window tables (curve.h: p256_jdbl) and back to the homogeneous form
+extern "C" int ha_p256_jdbl_chain(uint64_t count, const uint8_t* xy64, uint32_t nd, int from_identity, uint8_t* out64) {
+    for (uint64_t i = 0; i < count; i++) {
+        P256Aff A;
+        if (!p256_load(A, xy64 + 64 * i)) return 1;
+        P256Jac j = p256_jac_from(from_identity ? p256_identity() : p256_from_affine(A));
+        for (uint32_t k = 0; k < nd; k++) j = p256_jdbl(j);
+        p256_store(p256_from_jac(j), out64 + 64 * i);
+    }
+    return 0;
+}
 extern "C" int ha_p256_add(uint64_t count, const uint8_t* p64, const uint8_t* q64, uint8_t* out64) {
     int bad = 0;
     for (uint64_t i = 0; i < count; i++) {

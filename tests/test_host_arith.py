@@ -120,6 +120,21 @@ def test_p256_complete_formulas_on_the_host(ha):
     assert ha.ha_p256_mul(C.c_uint64(1), bytes(bad), (7).to_bytes(32, 'big'), C.create_string_buffer(64)) == 1
 
 
+def test_p256_jacobian_doubling_chain_on_the_host(ha):
+    """p256_jdbl (3M + 5S, k_rtab_base's chain of 256 doublings) and p256_from_jac against the oracle's 2^k * P; the identity stays the identity."""
+    rnd = random.Random(21)
+    g, n = R.p256, R.p256.order
+    pts = [g.generator().mul(g.newScalar(rnd.randrange(1, n))) for _ in range(6)] + [g.generator()]
+    cnt = len(pts)
+    for nd in (0, 1, 2, 4, 5, 64, 255, 256, 260):
+        out = C.create_string_buffer(64 * cnt)
+        assert ha.ha_p256_jdbl_chain(C.c_uint64(cnt), b''.join(_p_xy(p) for p in pts), nd, 0, out) == 0
+        for i in range(cnt):
+            assert out.raw[64 * i:64 * i + 64] == _p_xy(pts[i].mul(g.newScalar(pow(2, nd, n)))), (nd, i)
+    out = C.create_string_buffer(64)
+    assert ha.ha_p256_jdbl_chain(C.c_uint64(1), _p_xy(pts[0]), 9, 1, out) == 0 and out.raw == bytes(64)
+
+
 def test_sha256_byte_absorber_on_the_host(ha):
     import hashlib
     for ln in (0, 1, 3, 55, 56, 57, 63, 64, 65, 119, 120, 127, 128, 268, 603, 1000):

@@ -136,6 +136,48 @@ ZK_DEV P256Pt p256_dbl(const P256Pt& p) {
     r.z = z3f.template as<8>();
     return r;
 }
+// Jacobian doubling for a = -3 (x = X / Z^2, y = Y / Z^3; "dbl-2001-b": 3M + 5S against the 13 products of the complete doubling above).  Only for the
+// doubling CHAINS of the per-proof window tables of R (k_rtab_base: 256 doublings in a row, what a single verification waits for longest): their points
+// have odd prime order, which is all the formula needs (it is wrong for Y = 0, a point of order 2; the identity (X : Y : 0) stays (0 : Y' : 0), Y' != 0).
+// Magnitudes: the lazy subtractions at the end leave X, Y < 34 q and Z < 10 q; as inputs of the next doubling their products stay far inside
+// ModQ::kmax ((34 + 10)^2, (34 + 4)(34 + 2)), so the chain needs no reduction of its own.
+struct P256Jac {
+    Fe<ModQ, 34> x, y;
+    Fe<ModQ, 10> z;
+};
+ZK_DEV P256Jac p256_jac_from(const P256Pt& p) {   // a point with Z = 1 (p256_from_affine) or the identity (0 : 1 : 0): the same triple in both systems
+    P256Jac r;
+    r.x = p.x.as<34>(), r.y = p.y.as<34>(), r.z = p.z.as<10>();
+    return r;
+}
+ZK_DEV P256Jac p256_jdbl(const P256Jac& p) {
+    Fq2 delta, gamma, yz2;
+    fe_mul3<ZK_BATCH_P256 != 0>(delta, gamma, yz2, p.z, p.z, p.y, p.y, p.y + p.z, p.y + p.z);
+    Fq2 beta, a0, g2;
+    fe_mul3<ZK_BATCH_P256 != 0>(beta, a0, g2, p.x, gamma, p.x - delta, p.x + delta, gamma, gamma);
+    auto alpha = a0 + (a0 + a0);
+    auto b4 = (beta + beta) + (beta + beta);
+    auto g4 = (g2 + g2) + (g2 + g2);
+    Fq2 al2 = alpha * alpha;
+    auto x3 = fe_sub2(al2, b4, b4);
+    Fq2 m = alpha * (b4 - x3);
+    auto y3 = fe_sub2(m, g4, g4);
+    auto z3 = fe_sub2(yz2, gamma, delta);
+    P256Jac r;
+    r.x = x3, r.y = y3, r.z = z3;
+    return r;
+}
+ZK_DEV P256Pt p256_from_jac(const P256Jac& p) {   // (X : Y : Z) Jacobian -> (X Z : Y : Z^3) homogeneous, the form the complete additions take
+    Fq2 z2 = p.z * p.z;
+    Fq2 xz, z3;
+    fe_mul2<ZK_BATCH_P256 != 0>(xz, z3, p.x, p.z, z2, p.z);
+    Fq2 y = fe_reduce(p.y);   // the additions take coordinates < 8 q
+    P256Pt r;
+    r.x = xz.template as<8>();
+    r.y = y.as<8>();
+    r.z = z3.template as<8>();
+    return r;
+}
 ZK_DEV P256Pt p256_select(bool c, const P256Pt& a, const P256Pt& b) {
     P256Pt r;
     r.x = fe_select(c, a.x, b.x);

@@ -125,7 +125,7 @@ struct Workspace {
     uint8_t* kt_use;             // [C] 0: per-proof table of R (rtab.h); 1 / 2: pk = + / - the key table's base point
     Soa u1m, u2m;                // u1, u2 mod n in Montgomery form (proofs on the key-table path multiply their nonces into them)
     uint32_t* rtab;              // [C][rtab_words(bits)], sized for RTAB_PROVE_BITS
-    Soa3 rbase;                  // [C*RTAB_MAX_NWIN] window bases 2^(bits w) R, projective
+    Soa3 rbase;                  // [C*RTAB_MAX_NWIN] window bases 2^(bits w) R, JACOBIAN (X, Y < 34 q, Z < 10 q: k_rtab_base / k_rtab_fill)
     uint32_t* chal;              // [C][4] challenge words (80 bits in words 0..2)
     uint32_t* zcnt;              // [C]
     uint32_t* item_base;         // [C+1]

@@ -211,21 +211,28 @@ __global__ void __launch_bounds__(64) k_rtab_base(Workspace W, uint32_t count, u
     if (p >= count || (skip && skip[p])) return;
     P256Aff r;
     r.x = soa_ld<ModQ, 2>(W.Rxm, p), r.y = soa_ld<ModQ, 2>(W.Rym, p);
-    P256Pt b = p256_from_affine(r);
-    if (W.st[p] == ZK_E_T_INF) b = p256_identity();
+    P256Pt b0 = p256_from_affine(r);
+    if (W.st[p] == ZK_E_T_INF) b0 = p256_identity();
+    // 2^(bits w) R for every window: one chain of 256 doublings per proof -- the longest chain a single verification waits for -- in Jacobian
+    // coordinates (8 products per doubling instead of the complete formula's 13; R has odd prime order or is the identity: curve.h, p256_jdbl).
+    // k_rtab_fill converts the bases to the homogeneous form the additions take.
+    P256Jac b = p256_jac_from(b0);
     const uint32_t nwin = rtab_nwin(bits);
 #pragma unroll 1
     for (uint32_t w = 0; w < nwin; w++) {
-        st_proj(W.rbase, p * nwin + w, b);
+        const uint32_t e = p * nwin + w;
+        soa_st(W.rbase.x, e, b.x), soa_st(W.rbase.y, e, b.y), soa_st(W.rbase.z, e, b.z);
 #pragma unroll 1
-        for (uint32_t i = 0; i < bits; i++) b = p256_dbl(b);
+        for (uint32_t i = 0; i < bits; i++) b = p256_jdbl(b);
     }
 }
 __global__ void __launch_bounds__(256) k_rtab_fill(Workspace W, uint32_t count, uint32_t bits, const uint8_t* __restrict__ skip) {
     uint32_t t = gtid();
     const uint32_t nwin = rtab_nwin(bits), ent = rtab_entries(bits);
     if (t >= count * nwin || (skip && skip[t / nwin])) return;
-    P256Pt b = ld_proj(W.rbase, t);
+    P256Jac bj;
+    bj.x = soa_ld<ModQ, 34>(W.rbase.x, t), bj.y = soa_ld<ModQ, 34>(W.rbase.y, t), bj.z = soa_ld<ModQ, 10>(W.rbase.z, t);
+    P256Pt b = p256_from_jac(bj);
     uint32_t* e = W.rtab + (size_t)(t / nwin) * rtab_words(bits) + (size_t)(t % nwin) * ent * RTAB_ENTRY_WORDS;
     st_rtab(e, p256_identity());
     st_rtab(e + RTAB_ENTRY_WORDS, b);
