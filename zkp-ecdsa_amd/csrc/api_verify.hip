@@ -177,26 +177,24 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
     // total need nothing from the P-256 front end (R's window table: 256 doublings in a row) and run beside it on an auxiliary stream.
     const bool small = side_streams(cnt);
     auto& A = c->vl[lane];
-    hipStream_t sh = small ? A.aux[0] : s;
     if (small) {
         HIPCHK(c, hipEventRecord(A.aux_fork, s));
-        HIPCHK(c, hipStreamWaitEvent(sh, A.aux_fork, 0));
+        HIPCHK(c, hipStreamWaitEvent(A.aux[0], A.aux_fork, 0));
+        HIPCHK(c, hipStreamWaitEvent(A.aux[1], A.aux_fork, 0));
+        {   // aux 0: the Exp challenge (three kernels where the schedule buffer holds the chunk) and the sampled repetitions
+            MaybeScope t(timed, c, "v_hash", A.aux[0]);
+            if (cnt <= EXPH_MAXP && W.exph_wk) launch_v_exp_challenge_small(A.aux[0], W, V, cnt, d_proofs, d_off, first);
+            else launch_v_challenges(A.aux[0], V, cnt, d_proofs, d_off, d_msg, first, 1);
+            launch_v_sample(A.aux[0], V, cnt, d_vseeds, first);
+        }
+        HIPCHK(c, hipEventRecord(A.aux_done[0], A.aux[0]));
+        {   // aux 1: the membership challenge and total
+            MaybeScope t(timed, c, "v_gk_total", A.aux[1]);
+            launch_v_challenges(A.aux[1], V, cnt, d_proofs, d_off, d_msg, first, 2);
+            launch_v_gk_total(A.aux[1], V, W.ring, W.gk_etab, W.gk_kdig, cnt, W.N, d_proofs, d_off, first, vres, vres2);
+        }
+        HIPCHK(c, hipEventRecord(A.aux_done[1], A.aux[1]));
     }
-    auto hash_and_gk = [&]() -> hipError_t {
-        hipError_t e = hipSuccess;
-        {
-            MaybeScope t(timed, c, "v_hash", sh);
-            launch_v_challenges_sample(sh, V, cnt, d_proofs, d_off, d_vseeds, d_msg, first);
-        }
-        if (small) {
-            e = hipEventRecord(A.aux_done[0], sh);
-            MaybeScope t(timed, c, "v_gk_total", sh);
-            launch_v_gk_total(sh, V, W.ring, W.gk_etab, W.gk_kdig, cnt, W.N, d_proofs, d_off, first, vres, vres2);
-        }
-        if (small && e == hipSuccess) e = hipEventRecord(A.aux_done[1], sh);
-        return e;
-    };
-    if (small) HIPCHK(c, hash_and_gk());
     {
         MaybeScope t(timed, c, "v_p256_front_rtab", s);
         launch_v_front_r(s, W, V, cnt, d_proofs, d_off, first);
@@ -211,7 +209,11 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
         if (small) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[2], 0));
     }
     if (small) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[0], 0));   // challenges and sampled repetitions
-    else HIPCHK(c, hash_and_gk());
+    else {
+        MaybeScope t(timed, c, "v_hash", s);
+        launch_v_challenges(s, V, cnt, d_proofs, d_off, d_msg, first, 3);
+        launch_v_sample(s, V, cnt, d_vseeds, first);
+    }
     {
         MaybeScope t(timed, c, "v_p256_exp_points", s);
         launch_v_exp_points(s, W, V, cnt, d_proofs, d_off, first);

@@ -244,7 +244,12 @@ void launch_v_unpack(hipStream_t s, uint32_t sec, uint32_t count, const uint8_t*
 void launch_v_header_validate(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_front_r(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);   // R (and W.st)
 void launch_v_front_q(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* msg, uint64_t first);   // Q, Clambda
-void launch_v_challenges_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, const uint8_t* msg, uint64_t first);
+// parts: 1 = the Exp challenge, 2 = the Groth-Kohlweiss challenge, 3 = both (one lane per proof each); the Exp challenge of a small chunk alternatively
+// through the three-kernel path (message from the proof bytes, then launch_exph_hash into V.chal)
+void launch_v_challenges(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* msg, uint64_t first, uint32_t parts);
+void launch_v_exp_challenge_small(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
+void launch_v_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* vseeds, uint64_t first);
+void launch_exph_hash(hipStream_t s, const Workspace& W, uint32_t count, uint32_t* chal);   // k_hash.hip: schedule per block, rounds per proof -> chal[4 p ..]
 void launch_v_exp_points(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_t1_scalars(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_derived(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
@@ -512,6 +517,18 @@ ZK_DEV uint32_t zeros_below(const uint32_t* chal, uint32_t i) {  // number of 0 
         }
     }
     return i - ones;
+}
+// Exp challenge of a small chunk in three kernels (k_hash.hip: k_exph_*): the padded message of hashPoints(Px, Py, A_0, Tx_0, Ty_0, ...) -- two Tom
+// points (67 bytes each), then per repetition a P-256 point (65) and two Tom points -- and its length in 64-byte blocks
+ZK_DEV uint32_t exph_msg_bytes(uint32_t sec) { return 2 * 67 + sec * (65 + 2 * 67); }
+ZK_DEV uint32_t exph_blocks(uint32_t sec) { return (exph_msg_bytes(sec) + 9 + 63) / 64; }
+ZK_DEV uint32_t exph_elem_offset(uint32_t e) { return e < 2 ? 67 * e : 134 + 199 * ((e - 2) / 3) + ((e - 2) % 3 == 0 ? 0 : (e - 2) % 3 == 1 ? 65 : 132); }
+ZK_DEV void exph_put_padding(uint8_t* m, uint32_t sec) {   // 0x80, zeros, the bit length in eight bytes
+    const uint32_t len = exph_msg_bytes(sec), end = exph_blocks(sec) * 64;
+    m[len] = 0x80;
+    for (uint32_t i = len + 1; i < end - 8; i++) m[i] = 0;
+    const uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; i++) m[end - 1 - i] = (uint8_t)(bits >> (8 * i));
 }
 ZK_DEV uint64_t rep_offset(const uint32_t* chal, uint32_t i) { return ZK_FIXED + (uint64_t)ZK_REP_HEAD * i + (uint64_t)ZK_PADD_SZ * zeros_below(chal, i); }
 ZK_DEV uint64_t rep_offset_w(const Wire& w, const uint32_t* chal, uint32_t i) { return w.fixed + (uint64_t)w.rep_head * i + (uint64_t)w.padd * zeros_below(chal, i); }

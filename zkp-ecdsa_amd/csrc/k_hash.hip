@@ -98,8 +98,6 @@ __global__ void __launch_bounds__(64) k_exp_challenge(Workspace W, uint32_t coun
 // compression's ~1 650 instructions a third is the message schedule and a fifth the byte-wise absorption of 33-byte coordinates -- neither depends on the
 // chaining value.  k_exph_msg (one lane per point) writes the padded message, k_exph_sched (one lane per block) expands every block to its 64 words
 // W_i + K_i, k_exph_rounds (one lane per proof) runs the 64 rounds per block and nothing else: 1.33 -> 0.7 ms for one proof.
-ZK_DEV uint32_t exph_msg_bytes(uint32_t sec) { return 2 * 67 + sec * (65 + 2 * 67); }
-ZK_DEV uint32_t exph_blocks(uint32_t sec) { return (exph_msg_bytes(sec) + 9 + 63) / 64; }
 template <int NW>
 ZK_DEV void exph_put_coord(uint8_t* o, const uint32_t* w) {   // big-endian, (NW == 9 ? 33 : 32) bytes
     constexpr int NB = NW == 9 ? 33 : 32;
@@ -109,22 +107,19 @@ ZK_DEV void exph_put_coord(uint8_t* o, const uint32_t* w) {   // big-endian, (NW
 __global__ void __launch_bounds__(256) k_exph_msg(Workspace W, uint32_t count) {
     const uint32_t ne = 2 + 3 * W.sec + 1, t = gtid();
     if (t >= count * ne) return;
-    const uint32_t p = t / ne, e = t % ne, nblk = exph_blocks(W.sec), len = exph_msg_bytes(W.sec);
+    const uint32_t p = t / ne, e = t % ne, nblk = exph_blocks(W.sec);
     uint8_t* m = W.exph_msg + (size_t)p * nblk * 64;
     const uint32_t la = p * (2 + 2 * W.sec), ea = p * (W.sec + 1);
-    if (e == ne - 1) {   // padding: 0x80, zeros, the bit length in eight bytes
-        m[len] = 0x80;
-        for (uint32_t i = len + 1; i < nblk * 64 - 8; i++) m[i] = 0;
-        const uint64_t bits = (uint64_t)len * 8;
-        for (int i = 0; i < 8; i++) m[nblk * 64 - 1 - i] = (uint8_t)(bits >> (8 * i));
+    if (e == ne - 1) {
+        exph_put_padding(m, W.sec);
         return;
     }
-    uint32_t off, slot;
+    const uint32_t off = exph_elem_offset(e);
+    uint32_t slot;
     bool p256 = false;
-    if (e < 2) off = 67 * e, slot = la + e;
+    if (e < 2) slot = la + e;
     else {
         const uint32_t j = (e - 2) / 3, k = (e - 2) % 3;
-        off = 134 + 199 * j + (k == 0 ? 0 : k == 1 ? 65 : 132);
         p256 = k == 0, slot = p256 ? ea + j : la + 2 + 2 * j + (k - 1);
     }
     m[off] = 4;
@@ -161,7 +156,7 @@ __global__ void __launch_bounds__(256) k_exph_sched(Workspace W, uint32_t count)
 #pragma unroll
     for (int i = 0; i < 16; i++) dst[i] = make_uint4(w[4 * i] + SHA_K[4 * i], w[4 * i + 1] + SHA_K[4 * i + 1], w[4 * i + 2] + SHA_K[4 * i + 2], w[4 * i + 3] + SHA_K[4 * i + 3]);
 }
-__global__ void __launch_bounds__(64) k_exph_rounds(Workspace W, uint32_t count) {
+__global__ void __launch_bounds__(64) k_exph_rounds(Workspace W, uint32_t count, uint32_t* chal) {
     const uint32_t p = gtid();
     if (p >= count) return;
     const uint32_t nblk = exph_blocks(W.sec);
@@ -192,14 +187,18 @@ __global__ void __launch_bounds__(64) k_exph_rounds(Workspace W, uint32_t count)
     uint32_t cw[4];
     challenge_words(h, cw);
 #pragma unroll
-    for (int i = 0; i < 4; i++) W.chal[4 * p + i] = cw[i];
+    for (int i = 0; i < 4; i++) chal[4 * p + i] = cw[i];
+}
+void launch_exph_hash(hipStream_t s, const Workspace& W, uint32_t count, uint32_t* chal) {
+    const uint32_t nblk = (2 * 67 + W.sec * (65 + 2 * 67) + 9 + 63) / 64;
+    hipLaunchKernelGGL(k_exph_sched, dim3((count * nblk + 255) / 256), dim3(256), 0, s, W, count);
+    hipLaunchKernelGGL(k_exph_rounds, dim3((count + 63) / 64), dim3(64), 0, s, W, count, chal);
 }
 void launch_exp_challenge(hipStream_t s, const Workspace& W, uint32_t count) {
     if (count <= EXPH_MAXP && W.exph_wk) {
-        const uint32_t ne = 2 + 3 * W.sec + 1, nblk = (2 * 67 + W.sec * (65 + 2 * 67) + 9 + 63) / 64;
+        const uint32_t ne = 2 + 3 * W.sec + 1;
         hipLaunchKernelGGL(k_exph_msg, dim3((count * ne + 255) / 256), dim3(256), 0, s, W, count);
-        hipLaunchKernelGGL(k_exph_sched, dim3((count * nblk + 255) / 256), dim3(256), 0, s, W, count);
-        hipLaunchKernelGGL(k_exph_rounds, dim3((count + 63) / 64), dim3(64), 0, s, W, count);
+        launch_exph_hash(s, W, count, W.chal);
         return;
     }
     hipLaunchKernelGGL(k_exp_challenge, dim3((count + 63) / 64), dim3(64), 0, s, W, count);

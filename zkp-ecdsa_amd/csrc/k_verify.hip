@@ -360,7 +360,7 @@ ZK_DEV void v_challenge_words(const uint32_t h[8], uint32_t c[4]) {
     c[0] = (h[1] << 16) | (h[2] >> 16), c[1] = (h[0] << 16) | (h[1] >> 16), c[2] = h[0] >> 16, c[3] = 0;
 }
 // Exp challenge over ALL reps (exp.ts:253-260) and the GK challenge x (gk.ts:220-221)
-__global__ void __launch_bounds__(64) k_v_challenges(VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* __restrict__ msg, uint64_t first) {
+__global__ void __launch_bounds__(64) k_v_challenges(VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* __restrict__ msg, uint64_t first, uint32_t parts) {
     __shared__ uint32_t lds[16 * 64];
     uint32_t p = gtid();
     bool live = p < count;
@@ -369,22 +369,25 @@ __global__ void __launch_bounds__(64) k_v_challenges(VWork V, uint32_t count, co
     bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8);
     ShaStream s;
     uint32_t h[8], c[4];
-    s.init(lds, threadIdx.x, 64);
-    if (good) {
-        const uint32_t* hb = V.hbits + 4 * p;
-        absorb_tom_bytes(s, pr + 160);
-        absorb_tom_bytes(s, pr + 232);
-        for (uint32_t i = 0; i < V.sec; i++) {
-            const uint8_t* rep = pr + rep_offset(hb, i);
-            absorb_p256_bytes(s, rep);
-            absorb_tom_bytes(s, rep + 64);
-            absorb_tom_bytes(s, rep + 136);
+    if (parts & 1) {
+        s.init(lds, threadIdx.x, 64);
+        if (good) {
+            const uint32_t* hb = V.hbits + 4 * p;
+            absorb_tom_bytes(s, pr + 160);
+            absorb_tom_bytes(s, pr + 232);
+            for (uint32_t i = 0; i < V.sec; i++) {
+                const uint8_t* rep = pr + rep_offset(hb, i);
+                absorb_p256_bytes(s, rep);
+                absorb_tom_bytes(s, rep + 64);
+                absorb_tom_bytes(s, rep + 136);
+            }
         }
+        s.finish(h);
+        v_challenge_words(h, c);
+        if (live)
+            for (int i = 0; i < 4; i++) V.chal[4 * p + i] = c[i];
     }
-    s.finish(h);
-    v_challenge_words(h, c);
-    if (live)
-        for (int i = 0; i < 4; i++) V.chal[4 * p + i] = c[i];
+    if (!(parts & 2)) return;
     s.init(lds, threadIdx.x, 64);
     if (good) {
         const uint8_t* gk = v_gk_base(V, pr, p);
@@ -400,6 +403,46 @@ __global__ void __launch_bounds__(64) k_v_challenges(VWork V, uint32_t count, co
     if (live) V.gkx[3 * p] = c[0], V.gkx[3 * p + 1] = c[1], V.gkx[3 * p + 2] = c[2];
 }
 
+// The Exp challenge of a small chunk through the three-kernel path (k_hash.hip: k_exph_sched, k_exph_rounds): one lane per point writes the padded message
+// straight from the proof bytes -- a Tom coordinate is bytes 3..35 of its 36-byte image, a P-256 coordinate is hashed REDUCED (see absorb_p256_bytes) --;
+// a proof that did not parse gets a message of zeros (its challenge is never used, its bytes may not be there to read).
+__global__ void __launch_bounds__(256) k_v_exph_msg(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    const uint32_t ne = 2 + 3 * V.sec + 1, t = gtid();
+    if (t >= count * ne) return;
+    const uint32_t p = t / ne, e = t % ne;
+    uint8_t* m = W.exph_msg + (size_t)p * exph_blocks(V.sec) * 64;
+    if (e == ne - 1) {
+        exph_put_padding(m, V.sec);
+        return;
+    }
+    const bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8);
+    const uint32_t o = exph_elem_offset(e);
+    const bool p256 = e >= 2 && (e - 2) % 3 == 0;
+    const uint32_t nb = p256 ? 65 : 67;
+    if (!good) {
+        for (uint32_t i = 0; i < nb; i++) m[o + i] = 0;
+        return;
+    }
+    const uint8_t* pr = proofs + off[first + p];
+    const uint8_t* src;
+    if (e < 2) src = pr + 160 + 72 * e;
+    else {
+        const uint32_t j = (e - 2) / 3, k = (e - 2) % 3;
+        src = pr + rep_offset(V.hbits + 4 * p, j) + (k == 0 ? 0 : k == 1 ? 64 : 136);
+    }
+    m[o] = 4;
+    if (p256) {
+#pragma unroll 1
+        for (int c2 = 0; c2 < 2; c2++) {
+            uint32_t w[8];
+            load_be32(src + 32 * c2, w);
+            words_from_limbs<8>(w, fe_from_words256_reduce<ModQ>(w).l);
+            for (int i = 0; i < 32; i++) m[o + 1 + 32 * c2 + i] = (uint8_t)(w[(31 - i) >> 2] >> (8 * ((31 - i) & 3)));
+        }
+    } else {
+        for (int i = 0; i < 33; i++) m[o + 1 + i] = src[3 + i], m[o + 34 + i] = src[39 + i];
+    }
+}
 // ------------------------------------------------------------------ verifier randomness
 ZK_DEV void v_fill(const uint8_t* vseeds, uint64_t gp, uint32_t k, uint32_t w[8]) {  // fill k of the contract, as LE words
     const uint32_t* sd = (const uint32_t*)(vseeds + 32 * gp);
@@ -1497,8 +1540,14 @@ void launch_v_front_q(hipStream_t s, const DevParams& P, const Workspace& W, con
     L1(k_v_front_q, count, 64, P, W, V, count, proofs, off, msg, first);
     L1(k_v_clambda, count, 64, V, count, proofs, off, first);
 }
-void launch_v_challenges_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, const uint8_t* msg, uint64_t first) {
-    L1(k_v_challenges, count, 64, V, count, proofs, off, msg, first);
+void launch_v_challenges(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* msg, uint64_t first, uint32_t parts) {
+    L1(k_v_challenges, count, 64, V, count, proofs, off, msg, first, parts);
+}
+void launch_v_exp_challenge_small(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    L1(k_v_exph_msg, count * (2 + 3 * V.sec + 1), 256, W, V, count, proofs, off, first);
+    launch_exph_hash(s, W, count, V.chal);
+}
+void launch_v_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* vseeds, uint64_t first) {
     L1(k_v_sample_fills, count * VS_KMAX, 256, V, count, vseeds, first);
     L1(k_v_sample, count, 64, V, count, vseeds, first);
 }
