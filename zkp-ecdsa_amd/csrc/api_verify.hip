@@ -216,7 +216,7 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
     }
     {
         MaybeScope t(timed, c, "v_p256_exp_points", s);
-        launch_v_exp_points(s, W, V, cnt, d_proofs, d_off, first);
+        launch_v_exp_points(s, W, V, cnt, d_proofs, d_off, first, small ? 4 : 1);
         launch_p256_normalize(s, W.Tproj, cnt * VK, W.Tx, W.Ty, W.st, VK, 0, nullptr);   // identities were given their status by k_v_exp_status
     }
     {

@@ -568,9 +568,20 @@ __global__ void __launch_bounds__(64) k_v_sample(VWork V, uint32_t count, const 
 #undef PERM
 
 // ------------------------------------------------------------------ Exp: T = alpha*R or T1 = z*R + Q per checked rep (exp.ts:267,299,311)
-__global__ void __launch_bounds__(256) k_v_exp_points(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
-    uint32_t t = gtid();
-    if (t >= count * VK) return;
+// split = 1: one lane per checked repetition walks all 65 windows of R's table.  split = 4 (small chunks): four neighbouring lanes take 17 windows each and
+// add their partial sums through the wave's cross-lane moves (the table holds every 2^(4w) R: no doublings) -- 17 + 2 additions in a row instead of 65.
+ZK_DEV P256Pt p256_shfl_xor(const P256Pt& a, int m) {
+    P256Pt r;
+#pragma unroll
+    for (int l = 0; l < NLIMB; l++) {
+        r.x.l[l] = (uint32_t)__shfl_xor((int)a.x.l[l], m), r.y.l[l] = (uint32_t)__shfl_xor((int)a.y.l[l], m), r.z.l[l] = (uint32_t)__shfl_xor((int)a.z.l[l], m);
+    }
+    return r;
+}
+__global__ void __launch_bounds__(256) k_v_exp_points(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first, uint32_t split) {
+    const uint32_t tt = gtid();
+    const bool live = tt < count * VK * split;
+    const uint32_t t = live ? tt / split : count * VK - 1, part = live ? tt % split : 0;   // dead lanes of the last wave mirror the last slot: the cross-lane moves need every lane
     uint32_t p = t / VK;
     uint32_t iv = V.idx[t], i = iv & 255, bit = iv >> 8;
     const uint8_t* pr = proofs + off[first + p];
@@ -582,7 +593,19 @@ __global__ void __launch_bounds__(256) k_v_exp_points(Workspace W, VWork V, uint
         Sn s = ld_scalar_n(rep + 208);
         uint32_t kw[8];
         words_from_limbs<8>(kw, s.l);
-        acc = p256_rtab_mul(W.rtab + (size_t)p * rtab_words(RTAB_VERIFY_BITS), kw, RTAB_VERIFY_BITS);
+        const uint32_t* tab = W.rtab + (size_t)p * rtab_words(RTAB_VERIFY_BITS);
+        if (split == 1) acc = p256_rtab_mul(tab, kw, RTAB_VERIFY_BITS);
+        else {
+            const uint32_t per = (rtab_nwin(RTAB_VERIFY_BITS) + split - 1) / split;
+            acc = p256_rtab_mul_range(tab, kw, RTAB_VERIFY_BITS, part * per, per);
+        }
+    }
+    if (split == 4) {   // uniform for the kernel: every lane of the wave takes part
+        acc = p256_add(acc, p256_shfl_xor(acc, 1));
+        acc = p256_add(acc, p256_shfl_xor(acc, 2));
+    }
+    if (!live || part != 0) return;
+    if (good) {
         if (!bit) {
             P256Pt q;
             q.x = soa_ld<ModQ, 8>(W.Q.x, p), q.y = soa_ld<ModQ, 8>(W.Q.y, p), q.z = soa_ld<ModQ, 8>(W.Q.z, p);
@@ -1551,8 +1574,8 @@ void launch_v_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_
     L1(k_v_sample_fills, count * VS_KMAX, 256, V, count, vseeds, first);
     L1(k_v_sample, count, 64, V, count, vseeds, first);
 }
-void launch_v_exp_points(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
-    L1(k_v_exp_points, count * VK, 256, W, V, count, proofs, off, first);
+void launch_v_exp_points(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first, uint32_t split) {
+    L1(k_v_exp_points, count * VK * split, 256, W, V, count, proofs, off, first, split);
     L1(k_v_exp_status, count, 64, W, V, count);
 }
 void launch_v_t1_scalars(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {

@@ -59,3 +59,33 @@ ZK_DEV P256Pt p256_rtab_mul(const uint32_t* __restrict__ rtab, uint32_t kw[8], u
     }
     return acc;
 }
+// The same sum restricted to `per` windows from w0 on, for several lanes that take a range each and add their partial sums -- the table holds every
+// 2^(bits w) R, so no lane needs a doubling.  Two loops on purpose: the recoding of the windows below w0 (integer carries only) has a different trip
+// count per lane and costs next to nothing; the loop over the lane's own windows has the SAME trip count in every lane, so the wave executes `per`
+// additions, not nwin (a single loop from 0 with the additions masked per lane runs all nwin of them: measured, profiles/r04_ab_variants.txt (10)).
+ZK_DEV P256Pt p256_rtab_mul_range(const uint32_t* __restrict__ rtab, uint32_t kw[8], uint32_t bits, uint32_t w0, uint32_t per) {
+    const uint32_t nwin = rtab_nwin(bits), ent = rtab_entries(bits), half = 1u << (bits - 1), mask = (1u << bits) - 1;
+    uint32_t carry = 0;
+#pragma unroll 1
+    for (uint32_t w = 0; w < w0; w++) {
+        uint32_t d = (kw[0] & mask) + carry;
+        shr256_var(kw, bits);
+        carry = d > half ? 1 : 0;
+    }
+    P256Pt acc = p256_identity();
+#pragma unroll 1
+    for (uint32_t j = 0; j < per; j++) {
+        const uint32_t w = w0 + j;
+        uint32_t d = (kw[0] & mask) + carry;
+        shr256_var(kw, bits);
+        bool neg = d > half;
+        carry = neg ? 1 : 0;
+        if (neg) d = (1u << bits) - d;
+        const bool in = w < nwin;
+        P256Pt e = ld_rtab(rtab + (size_t)RTAB_ENTRY_WORDS * ((in ? w : 0) * ent + (in ? d : 0)));   // past the last window: entry 0 of window 0, the identity
+        Fq8 ny = fq8_neg(e.y);
+        e.y = fe_select(neg && in, ny, e.y);
+        acc = p256_add(acc, e);
+    }
+    return acc;
+}
