@@ -60,6 +60,11 @@ __attribute__((constructor)) static void zk_more_hw_queues() {
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
 }
 
+size_t heavy_lds_pad() {
+    const char* e = getenv("ZKATTEST_HEAVY_LDS_KB");   // (read per launch: tools/exp_overlap.py changes it between contexts of one process)
+    long kb = e ? atol(e) : 0;
+    return (size_t)(kb > 0 && kb <= 156 ? kb : 0) << 10;
+}
 static zk_status ctx_init(zk_ctx* c, int device_id);
 // *out is either a fully initialised context or NULL (then zk_last_error(NULL) has the reason): a caller never holds a half-built one
 extern "C" zk_status zk_ctx_create(int device_id, zk_ctx** out) {
@@ -79,10 +84,39 @@ extern "C" zk_status zk_ctx_create(int device_id, zk_ctx** out) {
 }
 static zk_status ctx_init(zk_ctx* c, int device_id) {
     HIPCHK(c, hipSetDevice(device_id));
+    // Stream priorities: hipDeviceGetStreamPriorityRange gives [-1 (served first), 1] on this runtime.  ZKATTEST_LANE_PRIO = "p0,p1,p2,p3" sets the
+    // lanes' compute streams (default 0 = plain hipStreamCreate).
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // (least, greatest): numerically prio_hi <= prio_lo
+    auto clamp_prio = [&](int p) { return p < prio_hi ? prio_hi : p > prio_lo ? prio_lo : p; };
+    int lane_prio[ZK_MAX_LANES] = {};
+    if (const char* e = getenv("ZKATTEST_LANE_PRIO")) {
+        int l = 0;
+        for (const char* q = e; *q && l < ZK_MAX_LANES; l++) {
+            lane_prio[l] = clamp_prio(atoi(q));
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+    }
     for (int base = 0; base < ZK_MAX_LANES; base += 2) {   // compute 0, compute 1, copy 0, copy 1; then the same for lanes 2, 3
-        for (int l = base; l < base + 2; l++) HIPCHK(c, hipStreamCreate(&c->pl[l].stream));
+        for (int l = base; l < base + 2; l++) {
+            if (lane_prio[l]) HIPCHK(c, hipStreamCreateWithPriority(&c->pl[l].stream, hipStreamDefault, lane_prio[l]));
+            else HIPCHK(c, hipStreamCreate(&c->pl[l].stream));
+        }
         for (int l = base; l < base + 2; l++) HIPCHK(c, hipStreamCreateWithFlags(&c->pl[l].copy_stream, hipStreamNonBlocking));
     }
+    // The heavy queue (ctx.h): ZKATTEST_HEAVY_FIFO = 1 (every commitment kernel) / 2 (the PointAdd commitments only), ZKATTEST_HEAVY_PRIO its
+    // priority (default: the lowest, so that whatever the lanes' streams hold is placed first), ZKATTEST_PHASE_MAJOR / ZKATTEST_GK_BESIDE: see ctx.h.
+    if (const char* e = getenv("ZKATTEST_HEAVY_FIFO")) c->heavy_mode = atoi(e);
+    if (c->heavy_mode) {
+        int hp = prio_lo;
+        if (const char* e = getenv("ZKATTEST_HEAVY_PRIO")) hp = clamp_prio(atoi(e));
+        HIPCHK(c, hipStreamCreateWithPriority(&c->heavy, hipStreamNonBlocking, hp));
+        for (int l = 0; l < ZK_MAX_LANES; l++)
+            for (hipEvent_t* ev : {&c->pl[l].hv_to, &c->pl[l].hv_from, &c->pl[l].hv_to2, &c->pl[l].hv_from2}) HIPCHK(c, hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    }
+    if (const char* e = getenv("ZKATTEST_PHASE_MAJOR")) c->phase_major = atoi(e) != 0;
+    if (const char* e = getenv("ZKATTEST_GK_BESIDE")) c->gk_beside = atoi(e) != 0;
     if (const char* e = getenv("ZKATTEST_COPY_STREAMS")) {   // experiment knob (tools/exp_pool_first_call.py): 1 = every lane copies out on lane 0's copy stream
         if (atoi(e) == 1)
             for (int l = 1; l < ZK_MAX_LANES; l++) {
@@ -164,9 +198,12 @@ extern "C" void zk_ctx_destroy(zk_ctx* c) {
         if (c->pl[l].side_fork) hipEventDestroy(c->pl[l].side_fork);
         if (c->pl[l].side_done) hipEventDestroy(c->pl[l].side_done);
         if (c->pl[l].side) hipStreamDestroy(c->pl[l].side);
+        for (hipEvent_t ev : {c->pl[l].hv_to, c->pl[l].hv_from, c->pl[l].hv_to2, c->pl[l].hv_from2})
+            if (ev) hipEventDestroy(ev);
         if (c->pl[l].copy_stream && (l == 0 || c->pl[l].copy_stream != c->pl[0].copy_stream)) hipStreamDestroy(c->pl[l].copy_stream);
         if (c->pl[l].stream) hipStreamDestroy(c->pl[l].stream);
     }
+    if (c->heavy) hipStreamDestroy(c->heavy);
     delete c;
 }
 
@@ -692,7 +729,7 @@ static zk_status ensure_side_stream(zk_ctx* c, zk_ctx::ProveLane& PL) {
     if (!PL.side_done) HIPCHK(c, hipEventCreateWithFlags(&PL.side_done, hipEventDisableTiming));
     return ZK_OK;
 }
-zk_status ProveJob::stage1(uint64_t chunk_no) {
+zk_status ProveJob::stage1(uint64_t chunk_no, int ph0, int ph1) {
     const ChunkPlan& cp = plan[chunk_no];
     const DevParams& P = c->P;
     const uint32_t lane = lane_of(chunk_no);
@@ -700,67 +737,98 @@ zk_status ProveJob::stage1(uint64_t chunk_no) {
     hipStream_t s = c->pl[lane].stream;
     const uint64_t first = cp.first;
     const uint32_t cnt = cp.cnt;
-    c->pl[lane].last_cnt = cnt;
-    if (io_dbg) fprintf(stderr, "host %7.1f ms: stage1 of chunk %u (%u proofs) -> lane %u\n", host_ms() - host_t0, (uint32_t)chunk_no, cnt, lane);
-    if (inputs_ready) HIPCHK(c, hipStreamWaitEvent(s, inputs_ready, 0));
-    ChunkIn in{d_msg + 32 * first, d_sig + 64 * first, d_pk + 64 * first, d_which + first, cnt};
-    W.rng.seeds = d_rng, W.rng.stream = d_rng, W.rng.stride_blocks = stride, W.rng.mode = rng_mode, W.rng.sec = (int)W.sec;
-    W.rng.proof_base = (uint32_t)first;
-    uint32_t nblk = 3 + 44 * W.sec + 5 * W.n + RNG_MAX_EXC;
-    {
-        MaybeScope t(timed, c, "rng_prepass", s);
-        launch_rng_prepass(s, W, cnt, 0, 3 + 4 * W.sec + RNG_MAX_EXC, nblk, rng_mode == 0 ? W.rng_fill : nullptr, false);  // + margin: rejected fills shift later draws
-    }
-    Workspace Wgen = W;  // RNG view of the generator (seed mode) for the second prepass stage
-    if (rng_mode == 0)   // from here on the chunk reads the fills the prepass wrote
-        W.rng.mode = 1, W.rng.stream = (const uint8_t*)W.rng_fill, W.rng.stride_blocks = nblk, W.rng.proof_base = 0;
-    {
-        MaybeScope t(timed, c, "p256_front", s);
-        launch_front(s, P, W, in);
-    }
-    {
-        MaybeScope t(timed, c, "p256_rtab", s);
-        launch_rtab(s, W, cnt, RTAB_PROVE_BITS, W.ktab ? W.kt_use : nullptr);   // proofs on the key-table path need no table of R
-    }
-    {
-        MaybeScope t(timed, c, "p256_exp_commit", s);
-        launch_exp_commit(s, P, W, cnt);
-    }
-    {
-        MaybeScope t(timed, c, "p256_normalize", s);
-        auto& PL = c->pl[lane];
-        const bool beside = plan.size() == 1 && cnt <= ZK_PROVE_SIDE_MAX;   // a small one-chunk call: the two lists (a workgroup inversion each) side by side
-        if (beside) {
-            zk_status zs = ensure_side_stream(c, PL);
-            if (zs) return zs;
-            HIPCHK(c, hipEventRecord(PL.side_fork, s));
-            HIPCHK(c, hipStreamWaitEvent(PL.side, PL.side_fork, 0));
-        }
-        launch_p256_normalize(beside ? PL.side : s, W.Aproj, cnt * (W.sec + 1), W.Ax, W.Ay, W.st, W.sec + 1, 0, nullptr);
-        if (beside) HIPCHK(c, hipEventRecord(PL.side_done, PL.side));
-        launch_p256_normalize(s, W.Tproj, cnt * (W.sec + 1), W.Tx, W.Ty, W.st, W.sec + 1, ZK_ST_T_INF_LATE, nullptr);
-        if (beside) HIPCHK(c, hipStreamWaitEvent(s, PL.side_done, 0));
-    }
-    uint32_t na = cnt * (2 + 2 * W.sec);
-    {
-        MaybeScope t(timed, c, "scalars", s);
-        launch_lista_scalars(s, W, cnt);
-    }
-    {
-        MaybeScope t(timed, c, "tom_commit", s);
-        launch_tom_commit(s, P, W.la, na, 1, 1);
-    }
-    {
-        MaybeScope t(timed, c, "tom_normalize", s);
-        launch_tom_normalize(s, W.la, na, 0, 1, 1);
-    }
-    {
-        MaybeScope t(timed, c, "hash", s);
-        launch_exp_challenge(s, W, cnt);
-    }
+    auto in_phase = [&](int ph) { return ph0 <= ph && ph < ph1; };
+    const ChunkIn in{d_msg + 32 * first, d_sig + 64 * first, d_pk + 64 * first, d_which + first, cnt};
+    const uint32_t nblk = 3 + 44 * W.sec + 5 * W.n + RNG_MAX_EXC;
     Pending& pd = pend[lane];
-    pd.lane = lane, pd.cnt = cnt, pd.first = first, pd.in = in, pd.Wgen = Wgen, pd.nblk = nblk;
+    if (in_phase(0)) {
+        c->pl[lane].last_cnt = cnt;
+        if (io_dbg) fprintf(stderr, "host %7.1f ms: stage1 of chunk %u (%u proofs) -> lane %u\n", host_ms() - host_t0, (uint32_t)chunk_no, cnt, lane);
+        if (inputs_ready) HIPCHK(c, hipStreamWaitEvent(s, inputs_ready, 0));
+        W.rng.seeds = d_rng, W.rng.stream = d_rng, W.rng.stride_blocks = stride, W.rng.mode = rng_mode, W.rng.sec = (int)W.sec;
+        W.rng.proof_base = (uint32_t)first;
+        {
+            MaybeScope t(timed, c, "rng_prepass", s);
+            launch_rng_prepass(s, W, cnt, 0, 3 + 4 * W.sec + RNG_MAX_EXC, nblk, rng_mode == 0 ? W.rng_fill : nullptr, false);  // + margin: rejected fills shift later draws
+        }
+        pd.lane = lane, pd.cnt = cnt, pd.first = first, pd.in = in, pd.nblk = nblk;
+        pd.Wgen = W;  // RNG view of the generator (seed mode) for the second prepass stage
+        if (rng_mode == 0)   // from here on the chunk reads the fills the prepass wrote
+            W.rng.mode = 1, W.rng.stream = (const uint8_t*)W.rng_fill, W.rng.stride_blocks = nblk, W.rng.proof_base = 0;
+        {
+            MaybeScope t(timed, c, "p256_front", s);
+            launch_front(s, P, W, in);
+        }
+        {
+            MaybeScope t(timed, c, "p256_rtab", s);
+            launch_rtab(s, W, cnt, RTAB_PROVE_BITS, W.ktab ? W.kt_use : nullptr);   // proofs on the key-table path need no table of R
+        }
+    }
+    if (in_phase(1)) {
+        hipStream_t h = heavy_begin(lane, s);
+        {
+            MaybeScope t(timed, c, "p256_exp_commit", h);
+            launch_exp_commit(h, P, W, cnt);
+        }
+        heavy_end(lane, s, h);
+    }
+    const uint32_t na = cnt * (2 + 2 * W.sec);
+    if (in_phase(2)) {
+        {
+            MaybeScope t(timed, c, "p256_normalize", s);
+            auto& PL = c->pl[lane];
+            const bool beside = plan.size() == 1 && cnt <= ZK_PROVE_SIDE_MAX;   // a small one-chunk call: the two lists (a workgroup inversion each) side by side
+            if (beside) {
+                zk_status zs = ensure_side_stream(c, PL);
+                if (zs) return zs;
+                HIPCHK(c, hipEventRecord(PL.side_fork, s));
+                HIPCHK(c, hipStreamWaitEvent(PL.side, PL.side_fork, 0));
+            }
+            launch_p256_normalize(beside ? PL.side : s, W.Aproj, cnt * (W.sec + 1), W.Ax, W.Ay, W.st, W.sec + 1, 0, nullptr);
+            if (beside) HIPCHK(c, hipEventRecord(PL.side_done, PL.side));
+            launch_p256_normalize(s, W.Tproj, cnt * (W.sec + 1), W.Tx, W.Ty, W.st, W.sec + 1, ZK_ST_T_INF_LATE, nullptr);
+            if (beside) HIPCHK(c, hipStreamWaitEvent(s, PL.side_done, 0));
+        }
+        {
+            MaybeScope t(timed, c, "scalars", s);
+            launch_lista_scalars(s, W, cnt);
+        }
+    }
+    if (in_phase(3)) {
+        hipStream_t h = heavy_begin(lane, s);
+        {
+            MaybeScope t(timed, c, "tom_commit", h);
+            launch_tom_commit(h, P, W.la, na, 1, 1);
+        }
+        heavy_end(lane, s, h);
+    }
+    if (in_phase(4)) {
+        {
+            MaybeScope t(timed, c, "tom_normalize", s);
+            launch_tom_normalize(s, W.la, na, 0, 1, 1);
+        }
+        {
+            MaybeScope t(timed, c, "hash", s);
+            launch_exp_challenge(s, W, cnt);
+        }
+    }
     return ZK_OK;
+}
+// Stage 1 of every chunk the look-ahead reaches (chunks next_s1 .. upto - 1).  With a heavy queue and c->phase_major the phases of these chunks are
+// enqueued phase by phase ACROSS the chunks, so that the heavy queue holds exp(0) exp(1) exp(2) listA(0) listA(1) ... and a lane's light kernels between
+// two of its heavy ones run under the other lanes' heavy kernels instead of holding the queue up.
+static zk_status prove_stage1_upto(ProveJob& J, uint64_t upto) {
+    zk_status zs = ZK_OK;
+    const uint64_t a = J.next_s1, b = std::min<uint64_t>(upto, J.plan.size());
+    if (b <= a) return ZK_OK;
+    if (J.c->heavy && J.c->phase_major && b - a > 1) {
+        for (int ph = 0; ph < ProveJob::S1_PHASES && !zs; ph++)
+            for (uint64_t k = a; k < b && !zs; k++) zs = J.stage1(k, ph, ph + 1);
+    } else {
+        for (uint64_t k = a; k < b && !zs; k++) zs = J.stage1(k);
+    }
+    J.next_s1 = b;
+    return zs;
 }
 // Stage 2.  Order: scan -> fixed part and rep heads -> the whole Groth-Kohlweiss phase -> the PointAdd phase (80 % of the
 // bytes) in proof-aligned slices.  None of the three depends on another (they share the chunk's RNG fills and the list-A
@@ -824,9 +892,12 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
         launch_write_fixed(s, W, cnt, out);
     }
     // A small chunk leaves the GPU idle and its phases are chains of latencies: the membership phase (list C, its own hash and responses) runs on the
-    // lane's side stream beside the PointAdd phase (list B); they share only what stage 1 and the scan left behind.
+    // lane's side stream beside the PointAdd phase (list B); they share only what stage 1 and the scan left behind.  With a heavy queue and c->gk_beside
+    // every unsliced chunk does this, and the membership phase is enqueued BEHIND the PointAdd commitments: its ring fold then runs under them and its own
+    // commitments do not hold the heavy queue up while the fold is still running.
     auto& PL = c->pl[pd.lane];
-    const bool beside = !sliced && plan.size() == 1 && cnt <= ZK_PROVE_SIDE_MAX;   // (chunks of a longer job overlap each other on the lanes already)
+    const bool gk_late = !sliced && c->heavy && c->gk_beside;
+    const bool beside = !sliced && ((plan.size() == 1 && cnt <= ZK_PROVE_SIDE_MAX) || gk_late);   // (chunks of a longer job overlap each other on the lanes already)
     hipStream_t sg = s;
     if (beside) {
         zk_status zs = ensure_side_stream(c, PL);
@@ -835,28 +906,39 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
         HIPCHK(c, hipEventRecord(PL.side_fork, s));
         HIPCHK(c, hipStreamWaitEvent(sg, PL.side_fork, 0));
     }
-    {
-        MaybeScope t(timed, c, "gk_fold", sg);
-        launch_gk_scalars_fold(sg, W, in, gk_am);
-        launch_gk_cd_scalars(sg, W, cnt);
+    auto membership_phase = [&]() -> zk_status {
+        {
+            MaybeScope t(timed, c, "gk_fold", sg);
+            launch_gk_scalars_fold(sg, W, in, gk_am);
+            launch_gk_cd_scalars(sg, W, cnt);
+        }
+        {
+            hipStream_t h = heavy_begin(pd.lane, sg, sg != s);
+            {
+                MaybeScope t(timed, c, "tom_commit", h);
+                launch_tom_commit(h, P, W.lc, cnt * 4 * W.n, 1, 1);
+            }
+            heavy_end(pd.lane, sg, h, sg != s);
+        }
+        {
+            MaybeScope t(timed, c, "tom_normalize", sg);
+            launch_tom_normalize(sg, W.lc, cnt * 4 * W.n, 0, 1, 1);
+        }
+        {
+            MaybeScope t(timed, c, "hash", sg);
+            launch_gk_hash(sg, W, cnt, in.msg);
+        }
+        {
+            MaybeScope t(timed, c, "respond_write", sg);
+            launch_gk_respond(sg, W, in, out);
+        }
+        if (beside) HIPCHK(c, hipEventRecord(PL.side_done, sg));
+        return ZK_OK;
+    };
+    if (!gk_late) {
+        zk_status zs = membership_phase();
+        if (zs) return zs;
     }
-    {
-        MaybeScope t(timed, c, "tom_commit", sg);
-        launch_tom_commit(sg, P, W.lc, cnt * 4 * W.n, 1, 1);
-    }
-    {
-        MaybeScope t(timed, c, "tom_normalize", sg);
-        launch_tom_normalize(sg, W.lc, cnt * 4 * W.n, 0, 1, 1);
-    }
-    {
-        MaybeScope t(timed, c, "hash", sg);
-        launch_gk_hash(sg, W, cnt, in.msg);
-    }
-    {
-        MaybeScope t(timed, c, "respond_write", sg);
-        launch_gk_respond(sg, W, in, out);
-    }
-    if (beside) HIPCHK(c, hipEventRecord(PL.side_done, sg));
     std::vector<ChunkPlan> slices;
     if (sliced) slices = make_chunk_plan(cnt, S, 1, host_sink != nullptr && !more_follows, last_chunk ? ZK_SLICE_MIN / 2 : ZK_SLICE_MIN);   // the call's very last slices stay exposed
     else slices.push_back({0, cnt});
@@ -883,8 +965,16 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
                 launch_padd_scalars(s, P, Ws, items);
             }
             {
-                MaybeScope t(timed, c, "tom_commit", s);
-                launch_tom_commit_listb(s, P, Ws.lb, items, Ws.items_cap);
+                hipStream_t h = heavy_begin(pd.lane, s, false, true);
+                {
+                    MaybeScope t(timed, c, "tom_commit", h);
+                    launch_tom_commit_listb(h, P, Ws.lb, items, Ws.items_cap);
+                }
+                heavy_end(pd.lane, s, h);
+            }
+            if (gk_late) {   // (unsliced: the one pass of this loop)
+                zk_status zs = membership_phase();
+                if (zs) return zs;
             }
             {
                 MaybeScope t(timed, c, "tom_normalize", s);
@@ -904,6 +994,10 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
                 launch_padd_respond(s, Ws, items, out);
                 launch_write_padd_points(s, Ws, items, out);
             }
+        }
+        if (gk_late && !items) {   // (a chunk without a single zero-bit repetition: cryptographically negligible, but the phase must run)
+            zk_status zs = membership_phase();
+            if (zs) return zs;
         }
         if (beside) HIPCHK(c, hipStreamWaitEvent(s, PL.side_done, 0));   // (not sliced: the one pass of this loop)
         if (host_sink) {   // every byte of proofs [p0, p1) is final: DMA them out behind the next slice's kernels
@@ -975,7 +1069,7 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
     }
     const uint64_t nchunks = J.plan.size();
     for (uint64_t k = 0; k < nchunks && !zs; k++) {
-        while (!zs && J.next_s1 < nchunks && J.next_s1 < k + J.NL) zs = J.stage1(J.next_s1++);
+        zs = prove_stage1_upto(J, k + J.NL);
         if (!zs) zs = J.stage2(k);
     }
     hipError_t e_sync = J.sync_lanes();   // nothing of this call may still be running (or writing into the caller's buffer) when it returns

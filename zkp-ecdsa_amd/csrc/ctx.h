@@ -64,8 +64,17 @@ struct zk_ctx {
         hipEvent_t copy_ev = nullptr;   // host-buffer entry points: "this lane's bytes are final" for the lane's copy stream
         hipStream_t copy_stream = nullptr;   // D2H of this lane's finished slices: one stream per lane, so a lane whose slices
                                              // are ready never queues behind the unfinished slices of another (FIFO per stream)
+        hipEvent_t hv_to = nullptr, hv_from = nullptr;     // heavy queue (below): lane stream -> heavy stream and back
+        hipEvent_t hv_to2 = nullptr, hv_from2 = nullptr;   // the same for the lane's side stream
     } pl[ZK_MAX_LANES];
     uint32_t lanes = 2;
+    // Heavy queue (ZKATTEST_HEAVY_FIFO): the commitment kernels -- each fills the GPU on its own at 2 waves per SIMD -- of ALL lanes
+    // run one after the other on this stream, in the order the host enqueues them, while the lanes' own streams carry the memory- and latency-bound
+    // kernels that fit beside them.  nullptr = every kernel on its lane's stream (rounds 1-4).
+    hipStream_t heavy = nullptr;
+    int heavy_mode = 0;            // 0 off, 1 = every commitment kernel, 2 = the PointAdd commitments of stage 2 only
+    bool phase_major = false;      // stage 1 of a call's first chunks is enqueued phase by phase across the lanes (the heavy queue's order then alternates lanes)
+    bool gk_beside = false;        // stage 2's membership phase on the lane's side stream for every unsliced chunk, enqueued behind the PointAdd commitments
     // verifier workspace
     struct VerifyLane {
         VWork V{};

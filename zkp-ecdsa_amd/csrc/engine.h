@@ -331,6 +331,15 @@ void launch_build_tom_table(hipStream_t s, const uint32_t* aff_xy_words /*18 wor
 size_t tom_table_scratch_words(uint32_t bits);
 void launch_build_pfix_table(hipStream_t s, const uint32_t* aff_xy_words /*16 words on device, or nullptr for G*/, uint32_t* tab, uint32_t* scratch, int32_t* ok);
 size_t pfix_table_scratch_words();
+// Dynamic LDS the GPU-filling commitment kernels ask for without using it (ZKATTEST_HEAVY_LDS_KB, default 0): above 80 KB only ONE of their workgroups
+// fits a CU's 160 KB, i.e. one commitment wave per SIMD instead of two, and ~300 VGPRs per SIMD stay free for the other lanes' kernels.
+size_t heavy_lds_pad();   // api.hip
+template <class K>
+static inline size_t heavy_lds_for(K kernel) {
+    const size_t pad = heavy_lds_pad();
+    if (pad > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+    return pad;
+}
 // k_tom.hip
 void launch_tom_commit(hipStream_t s, const DevParams& P, const TomList& L, uint32_t count, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride = 0);
 void launch_tom_commit_listb(hipStream_t s, const DevParams& P, const TomList& L, uint32_t items, uint32_t kstride);  // the 34 commitments of every PointAdd item

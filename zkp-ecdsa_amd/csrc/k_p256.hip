@@ -298,9 +298,9 @@ __global__ void __launch_bounds__(256) k_exp_commit_kt(DevParams P, Workspace W,
 void launch_exp_commit(hipStream_t s, const DevParams& P, const Workspace& W, uint32_t count) {
     uint32_t n = count * (W.sec + 1);
     if (W.ktab) {
-        hipLaunchKernelGGL(k_exp_commit_kt, dim3((n + 255) / 256), dim3(256), 0, s, P, W, count);
+        hipLaunchKernelGGL(k_exp_commit_kt, dim3((n + 255) / 256), dim3(256), heavy_lds_for(k_exp_commit_kt), s, P, W, count);
     }
-    hipLaunchKernelGGL(k_exp_commit, dim3((n + 255) / 256), dim3(256), 0, s, P, W, count);
+    hipLaunchKernelGGL(k_exp_commit, dim3((n + 255) / 256), dim3(256), heavy_lds_for(k_exp_commit), s, P, W, count);
 }
 
 // ---------------------------------------------------------------- batch normalisation (weier.ts:231-243)
