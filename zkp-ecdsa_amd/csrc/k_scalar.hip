@@ -240,7 +240,10 @@ ZK_DEV PaddIn padd_in(const Workspace& W, uint32_t it) {
 }
 ZK_DEV Sq padd_i9(const Workspace& W, const PaddIn& a) { return fe_sub_mod(soa_ld<ModQ, 1>(W.pky, a.p), a.y1); }
 ZK_DEV Sq padd_i12(const Workspace& W, const PaddIn& a) { return fe_sub_mod(a.x1, soa_ld<ModQ, 1>(W.Tx, a.p * (W.sec + 1) + a.i)); }
-__global__ void __launch_bounds__(PADD_BLOCK) k_padd_scalars(Workspace W, uint32_t items) {
+#ifndef ZK_PADD_SCALARS_WAVES
+#define ZK_PADD_SCALARS_WAVES 4   // waves per SIMD k_padd_scalars is compiled for
+#endif
+__global__ void __launch_bounds__(PADD_BLOCK, ZK_PADD_SCALARS_WAVES) k_padd_scalars(Workspace W, uint32_t items) {
     PADD_MAP(items, part, it);
     PaddIn a = padd_in(W, it);
     uint32_t p = a.p, d0 = a.d0;
