@@ -319,10 +319,29 @@ def main():
                                           'frac': round(ops / (bms * 1e-3) / 1e12 / VALU_MAD_PEAK_TOPS, 4),
                                           'note': 'one lane per bucket, lanes of a wave walk lists of equal length (buckets ordered by size); gathers of 128-byte entries'}
         roofline['others'] = others
+        if verify and 'k_msm_bucket' in others:
+            # the verify half priced like the prove half: its largest arithmetic kernel against the multiplier peak, and how much of the (serial) verify step is
+            # not modular arithmetic at all -- SHA-256 (challenges, sampler), the grouping of the bucket pass's keys, packing, parsing
+            vf = verify['gpu_ms_by_family_per_step']
+            vsum = sum(v for k, v in vf.items() if not k.startswith('+'))
+            non_arith = {k: vf[k] for k in ('v_hash', '+v_msm_group') if k in vf}
+            verify['roofline'] = {'bound': 'valu_int32', 'kernel': 'k_msm_bucket', 'achieved': others['k_msm_bucket']['achieved'], 'peak': VALU_MAD_PEAK_TOPS,
+                                  'unit': roofline['unit'], 'frac': others['k_msm_bucket']['frac'], 'ms_per_step': others['k_msm_bucket']['ms_per_step'],
+                                  'share_of_gpu_time': round(others['k_msm_bucket']['ms_per_step'] / vsum, 3) if vsum else None,
+                                  'serial_ms_per_step': round(vsum, 2), 'non_arithmetic_ms': non_arith,
+                                  'non_arithmetic_share': round(sum(non_arith.values()) / vsum, 3) if vsum else None,
+                                  'note': 'non_arithmetic = SHA-256 (both challenges, the sampler\'s fills) and the hand-written grouping of the bucket pass\'s keys '
+                                          '(k_msm_hist / _scatter / _binsort); v_parse_validate is arithmetic (one curve check per point)'}
         cpu = None
         if not args.no_cpu_baseline:   # rank 0, at every N (the other ranks wait at the final barrier)
             sample = args.cpu_sample or 4 * host_cores()
-            cpu, oproofs = cpu_baseline(nh, tg, th, ring, nkeys, msg, sig, pk, which, seeds, sec, min(sample, B))
+            cpu, oproofs = cpu_baseline(nh, tg, th, ring, nkeys, msg, sig, pk, which, seeds, sec, min(sample, B),
+                                        vseeds=rank_seeds(seeds, rank + 1000) if verify else None)
+            if '_verify_verdicts' in cpu:   # the oracle's verdicts and statuses for the sample against the engine's (same proofs, same verifier seeds)
+                ook, ovst = cpu.pop('_verify_verdicts')
+                ns = len(ook)
+                assert d_ok[:ns].cpu().tolist() == ook and d_vst[:ns].cpu().tolist() == ovst, 'GPU verdicts differ from the oracle'
+                cpu['verify']['checked_verdicts_equal'] = ns
             # spot-check: the first proofs of the last step against the oracle, byte for byte
             ncheck = min(args.check, len(oproofs))
             raw = d_out[:int(off[ncheck].item())].cpu().numpy().tobytes()
@@ -358,9 +377,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32 (9x30-bit limbs, 256/258-bit modular integers)',
             'data': 'synthetic',
-            'config': {'workload': 'batch=%d proofs per GPU per step, ring=%d keys (n=%d), secLevel=%d, P-256 + Tom-256, chunk=%d x %d lanes, comb=%d bits%s'
-                                   % (B, nkeys, n_log2, sec, eng_chunk(args, B), args.lanes, args.comb_bits,
-                                      ', per-key tables of the ring' if kt_count else ''),
+            'config': {'workload': 'B=%d proofs/GPU/step, ring=%d keys (n=%d)%s, secLevel=%d, P-256+Tom-256, %d-bit combs, chunk=%d x %d lanes'
+                                   % (B, nkeys, n_log2, ', per-key tables' if kt_count else '', sec, args.comb_bits, eng_chunk(args, B), args.lanes),
                        'parallelism': 'proofs sharded per GPU; ring broadcast over RCCL at set-up' if world > 1 else 'single GPU'},
             'set_params_s': round(t_tab, 3),
             'key_table_proofs_last_chunk': kt_count,   # zk_test_counter(ctx, 1): proofs of the last chunk whose multiples of the signer's key came from the per-key tables

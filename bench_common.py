@@ -84,7 +84,7 @@ def host_cores():
     return max(1, min(n, 256))
 
 
-def cpu_baseline(nh, tg, th, ring, nkeys, msg, sig, pk, which, seeds, sec, budget_proofs):
+def cpu_baseline(nh, tg, th, ring, nkeys, msg, sig, pk, which, seeds, sec, budget_proofs, vseeds=None):
     """Oracle (C restatement, reference-faithful algorithms) on this box's host cores, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import coracle as CO
@@ -96,8 +96,16 @@ def cpu_baseline(nh, tg, th, ring, nkeys, msg, sig, pk, which, seeds, sec, budge
     proofs, st = octx.prove_batch(msg[:32 * n], sig[:64 * n], pk[:64 * n], which[:n], seeds=seeds[:32 * n], nthreads=nthreads)
     dt = time.time() - t0
     assert all(s == 0 for s in st)
-    return {'value': n / dt, 'unit': 'proofs/s', 'cores': nthreads, 'kind': 'port',
-            'sample': '%d proofs of the same workload (ring=%d keys, secLevel %d), %d threads, %.1f s wall' % (n, nkeys, sec, nthreads, dt)}, proofs
+    rec = {'value': n / dt, 'unit': 'proofs/s', 'cores': nthreads, 'kind': 'port',
+           'sample': '%d proofs of the same workload (ring=%d keys, secLevel %d), %d threads, %.1f s wall' % (n, nkeys, sec, nthreads, dt)}
+    if vseeds is not None:   # the verify half (bench/zkpAttestList.bench.ts:56-62 times verifySignatureList beside prove): the same sample, the GPU's verifier seeds
+        t0 = time.time()
+        ok, vst = octx.verify_batch(msg[:32 * n], proofs, nthreads=nthreads, vseeds=vseeds[:32 * n])
+        vdt = time.time() - t0
+        rec['verify'] = {'value': n / vdt, 'unit': 'verifies/s', 'cores': nthreads, 'kind': 'port', 'accepted': int(sum(ok)), 'of': n,
+                         'sample': 'verifySignatureList over the same %d proofs with the verifier seeds of the GPU run, %d threads, %.2f s wall' % (n, nthreads, vdt)}
+        rec['_verify_verdicts'] = (ok, vst)
+    return rec, proofs
 
 
 def v8_bigint_indicator():

@@ -110,6 +110,16 @@ extern "C" int ha_tom_mul(uint64_t count, const uint8_t* xy72, const uint8_t* k3
     }
     return bad;
 }
+// the validation-only curve check on plain coordinates (k_verify.hip: tom_bytes_valid) beside the loader's check: out[i] = 2 * on_curve + loader_ok
+extern "C" int ha_tom_on_curve(uint64_t count, const uint8_t* xy72, uint8_t* out) {
+    for (uint64_t i = 0; i < count; i++) {
+        uint32_t xw[9], yw[9];
+        be_to_words(xy72 + 72 * i, 36, xw, 9), be_to_words(xy72 + 72 * i + 36, 36, yw, 9);
+        TomPt P;
+        out[i] = (uint8_t)(2 * (tom_words_on_curve(xw, yw) ? 1 : 0) + (tom_from_affine_words(P, xw, yw) ? 1 : 0));
+    }
+    return 0;
+}
 // P + Q - R through the comb's entry forms: from_niels (first step), add_niels, negated entry + add_niels_last (last step)
 extern "C" int ha_tom_combo(uint64_t count, const uint8_t* p72, const uint8_t* q72, const uint8_t* r72, uint8_t* out72) {
     int bad = 0;

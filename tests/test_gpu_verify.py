@@ -172,6 +172,43 @@ def test_batched_and_per_proof_verification_agree():
     eng.close()
 
 
+def test_key_grouping_of_the_batched_check_is_exact(monkeypatch):
+    """k_msm.hip groups the (window, group, digit) keys of all live terms with its own two counting passes (no library sort).  ZK_MSM_CHECK=1 makes
+    run_msm audit the result on the device before the bucket sums use it: every listed position holds a live term whose key owns that position, no term
+    twice, as many positions per window as there are non-zero digits.  Both shapes (8 groups x 16-bit windows, 64 x 13-bit), a ragged tiny chunk and
+    a chunk of 3 000 proofs; honest proofs accepted and forged ones found through the audited pass."""
+    monkeypatch.setenv('ZK_MSM_CHECK', '1')
+    eng, octx, msg, proofs = _setup(611, 12, 10)
+    vs = _vseeds(10)
+    bad = bytearray(proofs[3])
+    bad[-1] ^= 1
+    forged = proofs[:3] + [bytes(bad)] + proofs[4:]
+    for groups in (8, 64):
+        eng.set_verify_groups(groups)
+        for chunk in (10, 4):
+            eng.set_chunk(chunk)
+            eng.set_batch_verify(1)
+            assert eng.verify_batch(msg, proofs, vseeds=vs) == ([1] * 10, [0] * 10), (groups, chunk)
+            assert 'v_msm_tom' in eng.last_timing()[1]
+            assert eng.verify_batch(msg, forged, vseeds=vs) == ([1] * 3 + [0] + [1] * 6, [0] * 10), (groups, chunk)
+    eng.close()
+    import zkp_ecdsa_amd as Z
+    B, nkeys = 3000, 1024
+    eng = Z.Engine(0)
+    eng.set_params(*eng.synth_params(78), 80)
+    ring, msg, sig, pk, which, seeds = eng.synth_workload(78, nkeys, B)
+    eng.set_ring(ring, nkeys)
+    eng.set_chunk(B)
+    proofs, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert st == [0] * B
+    vs = _vseeds(B)
+    for groups in (8, 64):
+        eng.set_verify_groups(groups)
+        assert eng.verify_batch(msg, proofs, vseeds=vs) == ([1] * B, [0] * B), groups
+        assert 'v_straus_tom' not in eng.last_timing()[1]
+    eng.close()
+
+
 def test_one_forged_proof_only_sends_its_group_to_the_per_proof_sums():
     """The chunk-wide check sums MSM_G = 8 contiguous groups of proofs separately: one forged proof must cost about an eighth
     of the per-proof work of its chunk (not all of it), and the verdicts must not change.  Forgeries at a group boundary, in

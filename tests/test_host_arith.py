@@ -86,6 +86,25 @@ def test_tom256_formulas_on_the_host(ha):
     assert ha.ha_tom_mul(C.c_uint64(2), bytes(bad) + big, (3).to_bytes(32, 'big') * 2, out) == 2
 
 
+def test_tom256_plain_domain_curve_check_on_the_host(ha):
+    """tom_words_on_curve (five products on plain coordinates, what the verifier's validation pass runs) agrees with the loader's check and with the
+    reference's equation (edwards.ts:52-65) on points, near-points, non-canonical coordinates and the special points."""
+    rnd = random.Random(17)
+    g, q, t = R.tomEdwards256, R.tomEdwards256.order, R.tomEdwards256.p
+    cases = []
+    for _ in range(40):
+        x, y = g.generator().mul(g.newScalar(rnd.randrange(1, q))).toAffine()
+        cases += [(x, y), (x ^ 1, y), (x, y ^ (1 << rnd.randrange(256))), (t - x, y), (x, t - y), (y, x)]
+    cases += [(0, 1), (0, t - 1), (0, 0), (1, 0), (0, t), (t, 1), (0, 1 + t), (rnd.randrange(t), rnd.randrange(t)), ((1 << 288) - 1, 1)]
+    out = C.create_string_buffer(len(cases))
+    assert ha.ha_tom_on_curve(C.c_uint64(len(cases)), b''.join(x.to_bytes(36, 'big') + y.to_bytes(36, 'big') for x, y in cases), out) == 0
+    a, d = g.a, g.d
+    for (x, y), got in zip(cases, out.raw):
+        exp = x < t and y < t and (a * x * x + y * y - 1 - d * x * x * y * y) % t == 0
+        assert got == (3 if exp else 0), (hex(x), hex(y), got)
+    assert sum(out.raw) >= 3 * 80   # the sweep holds real points, not only rejects
+
+
 def _p_xy(pt):
     c = pt.toAffine()
     return bytes(64) if not c else c[0].to_bytes(32, 'big') + c[1].to_bytes(32, 'big')

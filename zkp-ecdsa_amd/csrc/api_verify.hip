@@ -48,11 +48,10 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
         // sized for either shape of the pass: 16 windows x (8 groups x 2^16 digits) or 20 windows x (64 groups x 2^13 digits)
         const size_t NW = want_groups == 64 ? 20 : 16, NBG = (size_t)1 << 19, NWG = NW * want_groups;
         const size_t L1 = want_groups == 64 ? 128 : 1024, L2 = L1 / 32;
-        M.keys_all = (uint32_t*)k.take(cap * 4 * NW), M.vals_in = (uint32_t*)k.take(cap * 4), M.keys_out = (uint32_t*)k.take(cap * 4);
+        M.keys_all = (uint32_t*)k.take(cap * 4 * NW), M.ids_bin = (uint32_t*)k.take(cap * 4 * NW);
         M.vals_out = (uint32_t*)k.take(cap * 4 * NW);
         M.start = (uint32_t*)k.take(4 * NW * NBG), M.end = (uint32_t*)k.take(4 * NW * NBG);
-        M.ord_key = (uint32_t*)k.take(4 * NW * NBG), M.ord_key2 = (uint32_t*)k.take(4 * NW * NBG);
-        M.ord_id = (uint32_t*)k.take(4 * NW * NBG), M.ord_id2 = (uint32_t*)k.take(4 * NW * NBG);
+        M.ord_id = (uint32_t*)k.take(4 * NW * NBG);
         M.counters = (uint32_t*)k.take(256), M.flag = (uint32_t*)k.take(256), M.big_list = (uint32_t*)k.take(4 * 4096), M.big_part = (uint32_t*)k.take((size_t)4096 * 128 * 144);
         M.buckets = (uint32_t*)k.take(NW * NBG * 144);
         M.F1 = (uint32_t*)k.take(NWG * L1 * 144), M.G1 = (uint32_t*)k.take(NWG * L1 * 144);
@@ -339,9 +338,10 @@ zk_status VerifyJob::stage2(uint64_t chunk_no) {
     if (c->verify_batch_min && cnt >= c->verify_batch_min && M.cap) {
         MaybeScope t(timed, c, "v_msm_tom", s);
         TimerRec sub{"+v_msm_bucket", nullptr, nullptr};   // a part of v_msm_tom ('+': not added to the total again)
-        if (timed) sub.e0 = get_event(c), sub.e1 = get_event(c);
-        hipError_t e = run_msm(s, P, W, V, cnt, nq, M, G, flags, &gsz, sub.e0, sub.e1);
-        if (timed && e == hipSuccess) c->trecs.push_back(sub);
+        TimerRec sub2{"+v_msm_group", nullptr, nullptr};   // the grouping of the keys (hand-written counting passes, k_msm.hip)
+        if (timed) sub.e0 = get_event(c), sub.e1 = get_event(c), sub2.e0 = get_event(c), sub2.e1 = get_event(c);
+        hipError_t e = run_msm(s, P, W, V, cnt, nq, M, G, flags, &gsz, sub.e0, sub.e1, sub2.e0, sub2.e1);
+        if (timed && e == hipSuccess) c->trecs.push_back(sub), c->trecs.push_back(sub2);
         if (e != hipSuccess) {
             c->err = std::string("batched verification failed: ") + hipGetErrorString(e);
             return ZK_E_DEVICE;

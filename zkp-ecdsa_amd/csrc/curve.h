@@ -302,6 +302,19 @@ ZK_DEV TomPt tom_neg(const TomPt& p) {  // edwards.ts:136-140
     r.z = p.z;
     return r;
 }
+// Is (x, y) -- plain 9-word coordinates -- a point of a*x^2 + y^2 = 1 + d*x^2*y^2 with both coordinates < t (edwards.ts:52-65, 74-77: what
+// deserialising a point checks)?  Validation only needs the verdict, so the coordinates are NOT taken to the Montgomery domain: every Montgomery
+// product of plain operands divides by R once, u = x^2/R, v = y^2/R, w = u*v/R = x^2 y^2/R^3, and the equation is compared scaled by 1/R:
+// u * (aR)/R + v  ==  w * (dR^3)/R + 1/R.  Five products instead of the seven of tom_from_affine_words (the verifier's validation pass
+// runs it on ~1 600 points per proof).
+ZK_DEV bool tom_words_on_curve(const uint32_t xw[9], const uint32_t yw[9]) {
+    if (words_geq<9>(xw, ModT::mod32) || words_geq<9>(yw, ModT::mod32)) return false;
+    const auto x = fe_from_words<ModT, 9>(xw), y = fe_from_words<ModT, 9>(yw);
+    const auto u = x * x, v = y * y;
+    const auto lhs = u * fe_const<ModT, 1>(TOM_A_M) + v;
+    const auto rhs = (u * v) * fe_const<ModT, 1>(TOM_D_R3) + fe_const<ModT, 1>(TOM_RINV);
+    return fe_eq(lhs, rhs);
+}
 // original-curve affine (plain 9-word x, y) -> a=1 image, extended Montgomery.  Returns false if a coordinate is
 // >= t (edwards.ts:74-77) or the point is off the curve a*x^2 + y^2 = 1 + d*x^2*y^2 (edwards.ts:52-65).
 ZK_DEV bool tom_from_affine_words(TomPt& r, const uint32_t xw[9], const uint32_t yw[9]) {

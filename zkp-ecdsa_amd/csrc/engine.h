@@ -289,12 +289,12 @@ struct ChunkIn {
 struct MsmBuf {
     uint32_t cap;          // term ids
     uint32_t* aos;         // [cap][32] niels entries of the live terms
-    uint32_t* keys_all;    // [16][cap] digit of every live term in every window
-    uint32_t *vals_in, *keys_out;             // live term ids; sorted keys of the window being processed
-    uint32_t* vals_out;    // [16][cap] term ids sorted by digit
+    uint32_t* keys_all;    // [windows][cap] keys (group << C | digit) of the live terms' non-zero digits, partitioned by bin (k_msm_scatter)
+    uint32_t* ids_bin;     // [windows][cap] ... and their term ids
+    uint32_t* vals_out;    // [windows][cap] term ids grouped by key (k_msm_binsort)
     uint32_t *start, *end; // [windows][2^19] segment of every (group, digit) value
-    uint32_t *ord_key, *ord_key2, *ord_id, *ord_id2;   // [windows * 2^19] buckets ordered by size (k_msm_sizes + one radix pass)
-    uint32_t *counters, *flag;   // counters[0..15]: pairs per window, counters[32]: oversized buckets
+    uint32_t* ord_id;      // [windows * 2^19] buckets in the order k_msm_bucket's lanes take them: by size within each bin
+    uint32_t *counters, *flag;   // counters[0]: live terms, counters[32]: oversized buckets
     uint32_t* big_list;    // [4096] window * 65536 + digit of the oversized buckets
     uint32_t* big_part;    // [4096][128][36] partial sums of their slices
     uint32_t* buckets;     // [windows][2^19][36]
@@ -310,7 +310,8 @@ struct MsmBuf {
 size_t msm_workspace_bytes(uint32_t cap);
 // host_flags[g] = 1: the Tom-256 total of group g (proofs [g * gsz, (g + 1) * gsz) of the chunk) is the identity; M.flag holds the same on the device
 hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t groups /*8 or 64*/,
-                   uint32_t* host_flags /*[groups]*/, uint32_t* gsz, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr /* recorded around k_msm_bucket */);
+                   uint32_t* host_flags /*[groups]*/, uint32_t* gsz, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr /* recorded around k_msm_bucket */,
+                   hipEvent_t ev2 = nullptr, hipEvent_t ev3 = nullptr /* ... around the grouping of the keys */);
 // group size of one k_gk_finish pass over `ntiles` polynomials of T+1 coefficients: <= 64, dynamic LDS below 60 KB
 static inline size_t gk_finish_lds(uint32_t T, uint32_t g) { return sizeof(uint32_t) * 9 * ((size_t)g * (T + 1) + (size_t)(g / 2) * (T + 2)); }
 static inline uint32_t gk_finish_gsz(uint32_t T, uint32_t ntiles) {

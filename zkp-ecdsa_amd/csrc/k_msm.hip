@@ -10,10 +10,15 @@
 // falls back to the per-proof sums to find out which ones failed -- the verdicts are the same either way, only the cost
 // of a chunk that contains a bad proof doubles.
 //
-// Pipeline per chunk (one HIP stream, two host round trips: the live count and the verdict):
+// Pipeline per chunk (one HIP stream, ONE host round trip: the verdicts):
 //   k_msm_pack      live terms -> 128-byte AoS niels entries (the bucket sums gather them)
-//   k_msm_compact   ids of the live terms + their sixteen 16-bit digits, one atomic per workgroup
-//   per window w:   rocprim::radix_sort_pairs (digit -> term id), k_msm_bounds first / last position of every digit
+//   grouping of the (window, group, digit) keys of all live terms, hand-written (round 5; rounds 2-4 ran 16 rocprim::radix_sort_pairs + 96 bounds
+//   kernels per chunk, 166 launches and 12 ms per 65 536 proofs): the key space is fixed (19 bits per window), so two counting passes do:
+//     k_msm_hist      per workgroup (a contiguous range of term ids) and window: LDS histogram of the keys' top 9 bits ("bins"); digit 0 is dropped
+//     k_msm_binscan1/2  where every (window, bin, workgroup) run starts
+//     k_msm_scatter   the same walk again: (key, term id) pairs into their bins, positions from LDS cursors (no global atomics)
+//     k_msm_binsort   one workgroup per (window, bin): counting sort by the key's low 10 bits in LDS; writes the sorted term ids, first / last position
+//                     of every (group, digit) value, and its 1024 buckets ordered by size (what k_msm_bucket's waves want)
 //   k_msm_bucket    thread (window, digit): sum of its terms (8 modmuls per term); buckets far above the average
 //                   (k_msm_bucket_big / _big2) are summed by slices over many workgroups
 //   k_msm_reduce1/2/3  sum_d d * B_d per window by two levels of running sums, times 2^(16 w)
@@ -22,7 +27,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 #include "engine.h"
 
 // Two shapes of the same pass, chosen per context (zk_ctx_set_verify_groups): 8 groups x 16-bit windows (16 windows) or 64 groups x
@@ -80,54 +84,223 @@ __global__ void __launch_bounds__(256) k_msm_pack(VWork V, MsmDims D, uint32_t* 
 #pragma unroll
     for (int i = 0; i < 7; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
-// Compaction of the live terms (scalar != 0): ids[pos] = term id and, for every window, keys[w * cap + pos] = group << 16 | its
-// 16-bit digit (0 included: digit 0 is simply a bucket nobody sums).  One atomic per workgroup.
+// ---------------------------------------------------------------- grouping of the keys (counting sort in two passes; no library sort)
+// A term's key in window w is  group << C | digit_w  (MSM_KEY_BITS = 19 bits); a term whose digit is 0 in a window takes no part in it (bucket 0 is
+// never summed).  Pass A partitions the (key, term id) pairs of every window by the key's top MSM_HB bits (a "bin"), pass B sorts every bin by
+// the remaining bits.  Both passes count in LDS and place by LDS cursors; between them only prefix sums travel.
+#define MSM_HB 9
+#define MSM_NBIN (1u << MSM_HB)                 // bins per window
+#define MSM_LB (MSM_KEY_BITS - MSM_HB)          // low key bits, sorted by pass B
+#define MSM_NLOW (1u << MSM_LB)                 // keys per bin
+#define MSM_SORT_G 512u                         // workgroups of pass A: each owns a contiguous range of term ids
+#define MSM_SORT_T 1024u                        // their threads
+// exclusive prefix sum over the workgroup (blockDim.x a multiple of 64, at most 1024); tot = the workgroup's total.  sh: 17 words of LDS.
+ZK_DEV uint32_t block_excl_scan(uint32_t v, uint32_t* sh, uint32_t& tot) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= (uint32_t)o) inc += t;
+    }
+    if (lane == 63) sh[wv] = inc;
+    __syncthreads();
+    if (wv == 0) {
+        const uint32_t sv = lane < nwv ? sh[lane] : 0;
+        uint32_t si = sv;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const uint32_t t = __shfl_up(si, o, 64);
+            if (lane >= (uint32_t)o) si += t;
+        }
+        if (lane < nwv) sh[lane] = si - sv;
+        if (lane == nwv - 1) sh[16] = si;
+    }
+    __syncthreads();
+    const uint32_t r = sh[wv] + inc - v;
+    tot = sh[16];
+    __syncthreads();
+    return r;
+}
+// the scalar of term `id` as eight 32-bit words if the term takes part in the chunk's sum (live group, scalar != 0)
+ZK_DEV bool msm_term_words(const VWork& V, const MsmDims& D, uint32_t id, uint32_t w8[8], uint32_t& proof) {
+    if (id >= D.n0 + D.n1 + D.n2) return false;
+    uint32_t idx;
+    bool live;
+    const VTerms& L = msm_list(V, D, id, idx, live, proof);
+    if (!live) return false;
+    const Fe<ModQ, 1> sc = soa_ld<ModQ, 1>(L.sc, idx);
+    if (fe_is_zero(sc)) return false;
+    words_from_limbs<8>(w8, sc.l);
+    return true;
+}
 template <int C>
-__global__ void __launch_bounds__(256) k_msm_compact(VWork V, MsmDims D, uint32_t cap, uint32_t* keys, uint32_t* ids, uint32_t* counter) {
+ZK_DEV uint32_t msm_digit(const uint32_t w8[8], int w) {   // bits [C w, C (w + 1)) of the 256-bit scalar (w is a constant after unrolling)
+    const int bit = C * w, k = bit >> 5, sh = bit & 31;
+    uint32_t d = w8[k] >> sh;
+    if (sh + C > 32 && k + 1 < 8) d |= w8[k + 1] << (32 - sh);
+    return d & (MsmShape<C>::nb - 1);
+}
+// Pass A, counting.  bin_cnt[g][w * MSM_NBIN + bin]: pairs of workgroup g's id range in bin `bin` of window w.  live_cnt[g]: its live terms.
+template <int C>
+__global__ void __launch_bounds__(MSM_SORT_T) k_msm_hist(VWork V, MsmDims D, uint32_t per_wg, uint32_t* bin_cnt, uint32_t* live_cnt) {
     typedef MsmShape<C> S;
-    __shared__ uint32_t wave_cnt[4], block_base;
-    uint32_t id = gtid();
-    uint32_t w8[8], proof = 0;
-    bool act = false;
-    if (id < D.n0 + D.n1 + D.n2) {
-        uint32_t idx;
-        bool live;
-        const VTerms& L = msm_list(V, D, id, idx, live, proof);
-        if (live) {
-            Fe<ModQ, 1> sc = soa_ld<ModQ, 1>(L.sc, idx);
-            act = !fe_is_zero(sc);
-            words_from_limbs<8>(w8, sc.l);
+    __shared__ uint32_t h[S::nw * MSM_NBIN];
+    __shared__ uint32_t nlive;
+    for (uint32_t i = threadIdx.x; i < S::nw * MSM_NBIN; i += MSM_SORT_T) h[i] = 0;
+    if (threadIdx.x == 0) nlive = 0;
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * per_wg, hi = lo + per_wg;
+    uint32_t mine = 0;
+    for (uint32_t id = lo + threadIdx.x; id < hi; id += MSM_SORT_T) {
+        uint32_t w8[8], proof;
+        if (!msm_term_words(V, D, id, w8, proof)) continue;
+        mine++;
+        const uint32_t grp = (proof / D.gsz) << S::c;
+#pragma unroll
+        for (int w = 0; w < (int)S::nw; w++) {
+            const uint32_t d = msm_digit<C>(w8, w);
+            if (d) atomicAdd(&h[w * MSM_NBIN + ((grp | d) >> MSM_LB)], 1u);
         }
     }
-    uint64_t mask = __ballot(act);
-    uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-    if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(mask);
+    if (mine) atomicAdd(&nlive, mine);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        block_base = tot ? atomicAdd(counter, tot) : 0;
-    }
-    __syncthreads();
-    if (!act) return;
-    uint32_t pos = block_base + below;
-    for (uint32_t k = 0; k < wv; k++) pos += wave_cnt[k];
-    ids[pos] = id;
-    const uint32_t grp = (proof / D.gsz) << S::c;
-#pragma unroll
-    for (int w = 0; w < (int)S::nw; w++) {   // bits [C w, C (w + 1)) of the 256-bit scalar: word index and shift are constants
-        const int bit = C * w, k = bit >> 5, sh = bit & 31;
-        uint32_t d = w8[k] >> sh;
-        if (sh + C > 32 && k + 1 < 8) d |= w8[k + 1] << (32 - sh);
-        keys[(size_t)w * cap + pos] = grp | (d & (S::nb - 1));
+    uint32_t* out = bin_cnt + (size_t)blockIdx.x * (S::nw * MSM_NBIN);
+    for (uint32_t i = threadIdx.x; i < S::nw * MSM_NBIN; i += MSM_SORT_T) out[i] = h[i];
+    if (threadIdx.x == 0) live_cnt[blockIdx.x] = nlive;
+}
+// bin_off[wb][g] = pairs of (window, bin) wb that the workgroups before g hold; bin_tot[wb] = all of them.  One workgroup of MSM_SORT_G threads per wb.
+__global__ void __launch_bounds__(MSM_SORT_G) k_msm_binscan1(const uint32_t* __restrict__ bin_cnt, uint32_t nwb, uint32_t* bin_off, uint32_t* bin_tot) {
+    __shared__ uint32_t sh[17];
+    const uint32_t wb = blockIdx.x, g = threadIdx.x;
+    const uint32_t v = bin_cnt[(size_t)g * nwb + wb];
+    uint32_t tot;
+    const uint32_t e = block_excl_scan(v, sh, tot);
+    bin_off[(size_t)wb * MSM_SORT_G + g] = e;
+    if (g == 0) bin_tot[wb] = tot;
+}
+// bin_start[w][0 .. MSM_NBIN]: where the bins of window w start in its pair arrays (entry MSM_NBIN = the window's pairs).  One workgroup of MSM_NBIN
+// threads per window; workgroup 0 also adds up the live terms (counters[0]: the bucket kernel's "oversized" threshold and the host's statistics).
+__global__ void __launch_bounds__(MSM_NBIN) k_msm_binscan2(const uint32_t* __restrict__ bin_tot, uint32_t* bin_start, const uint32_t* __restrict__ live_cnt, uint32_t* counters) {
+    __shared__ uint32_t sh[17];
+    const uint32_t w = blockIdx.x, b = threadIdx.x;
+    uint32_t tot;
+    const uint32_t e = block_excl_scan(bin_tot[w * MSM_NBIN + b], sh, tot);
+    bin_start[w * (MSM_NBIN + 1) + b] = e;
+    if (b == 0) bin_start[w * (MSM_NBIN + 1) + MSM_NBIN] = tot;
+    if (w == 0) {
+        uint32_t n;
+        (void)block_excl_scan(b < MSM_SORT_G ? live_cnt[b] : 0, sh, n);   // (MSM_SORT_G == MSM_NBIN threads)
+        if (b == 0) counters[0] = n;
     }
 }
-__global__ void __launch_bounds__(256) k_msm_bounds(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* start, uint32_t* end) {
-    uint32_t i = gtid();
-    if (i >= n) return;
-    uint32_t k = keys[i];
-    if (i == 0 || keys[i - 1] != k) start[k] = i;
-    if (i + 1 == n || keys[i + 1] != k) end[k] = i + 1;
+static_assert(MSM_SORT_G == MSM_NBIN, "k_msm_binscan2 sums live_cnt with one thread per workgroup of pass A");
+// Pass A, placing: the walk of k_msm_hist again; pair (key, id) of window w goes to position bin_start[w][bin] + bin_off[w, bin][g] + (its rank among this
+// workgroup's pairs of that bin, in whatever order the LDS cursor hands out: a bucket's sum does not depend on the order of its terms).
+template <int C>
+__global__ void __launch_bounds__(MSM_SORT_T) k_msm_scatter(VWork V, MsmDims D, uint32_t per_wg, uint32_t cap, const uint32_t* __restrict__ bin_start,
+                                                            const uint32_t* __restrict__ bin_off, uint32_t* keyA, uint32_t* idA) {
+    typedef MsmShape<C> S;
+    __shared__ uint32_t cur[S::nw * MSM_NBIN];
+    for (uint32_t i = threadIdx.x; i < S::nw * MSM_NBIN; i += MSM_SORT_T)
+        cur[i] = bin_start[(i / MSM_NBIN) * (MSM_NBIN + 1) + i % MSM_NBIN] + bin_off[(size_t)i * MSM_SORT_G + blockIdx.x];
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * per_wg, hi = lo + per_wg;
+    for (uint32_t id = lo + threadIdx.x; id < hi; id += MSM_SORT_T) {
+        uint32_t w8[8], proof;
+        if (!msm_term_words(V, D, id, w8, proof)) continue;
+        const uint32_t grp = (proof / D.gsz) << S::c;
+#pragma unroll
+        for (int w = 0; w < (int)S::nw; w++) {
+            const uint32_t d = msm_digit<C>(w8, w);
+            if (d) {
+                const uint32_t key = grp | d;
+                const uint32_t pos = atomicAdd(&cur[w * MSM_NBIN + (key >> MSM_LB)], 1u);
+                keyA[(size_t)w * cap + pos] = key, idA[(size_t)w * cap + pos] = id;
+            }
+        }
+    }
+}
+// Pass B: workgroup (bin, w) sorts its pairs by the low MSM_LB key bits.  vals[w][...]: term ids grouped by key; start / end [w * MSM_NBG + key]: the
+// group's positions (digit 0 and absent keys: empty); order[w * MSM_NBG + (bin << MSM_LB) + r]: this bin's MSM_NLOW buckets, largest first -- a lane of
+// k_msm_bucket sums one bucket, so a wave takes as long as its largest one: with Poisson-sized buckets (mean 27 in the low windows, 10 in the high
+// ones) 64 neighbouring digits wait for a bucket 1.5-1.8x the mean, 64 neighbours in this order do not, and the empty ones end up together.  (Rounds 2-4
+// ordered ALL buckets of the chunk with one more library sort; within a bin the sizes follow the same distribution, so the local order serves the waves as well.)
+__global__ void __launch_bounds__(256) k_msm_binsort(const uint32_t* __restrict__ keyA, const uint32_t* __restrict__ idA, uint32_t cap, const uint32_t* __restrict__ bin_start,
+                                                     uint32_t* vals, uint32_t* start, uint32_t* end, uint32_t* order) {
+    constexpr uint32_t PER = MSM_NLOW / 256;
+    static_assert(PER == 4, "four keys per thread: uint4 stores below");
+    __shared__ uint32_t h[MSM_NLOW], hs[256], sh[17];
+    const uint32_t bin = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
+    const uint32_t b0 = bin_start[w * (MSM_NBIN + 1) + bin], b1 = bin_start[w * (MSM_NBIN + 1) + bin + 1];
+    for (uint32_t k = t; k < MSM_NLOW; k += 256) h[k] = 0;
+    hs[t] = 0;
+    __syncthreads();
+    const uint32_t* kA = keyA + (size_t)w * cap;
+    const uint32_t* iA = idA + (size_t)w * cap;
+    for (uint32_t i = b0 + t; i < b1; i += 256) atomicAdd(&h[kA[i] & (MSM_NLOW - 1)], 1u);
+    __syncthreads();
+    uint32_t c[PER], sk[PER], sum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) {
+        c[j] = h[PER * t + j], sum += c[j];
+        sk[j] = 255u - (c[j] < 255u ? c[j] : 255u);
+        atomicAdd(&hs[sk[j]], 1u);
+    }
+    uint32_t tot;
+    uint32_t e = block_excl_scan(sum, sh, tot);
+    const size_t wd0 = (size_t)w * MSM_NBG + ((size_t)bin << MSM_LB);
+    uint32_t st4[PER], en4[PER];
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) {
+        h[PER * t + j] = e;   // the key's cursor, relative to b0
+        st4[j] = b0 + e, e += c[j], en4[j] = b0 + e;
+    }
+    *(uint4*)(start + wd0 + PER * t) = make_uint4(st4[0], st4[1], st4[2], st4[3]);
+    *(uint4*)(end + wd0 + PER * t) = make_uint4(en4[0], en4[1], en4[2], en4[3]);
+    const uint32_t hv = hs[t];    // (block_excl_scan's first barrier orders the atomics on hs before this read ... it ran above: hs is complete)
+    uint32_t tot2;
+    const uint32_t he = block_excl_scan(hv, sh, tot2);
+    hs[t] = he;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) order[wd0 + atomicAdd(&hs[sk[j]], 1u)] = (uint32_t)(wd0 + PER * t + j);
+    uint32_t* vo = vals + (size_t)w * cap + b0;
+    for (uint32_t i = b0 + t; i < b1; i += 256) vo[atomicAdd(&h[kA[i] & (MSM_NLOW - 1)], 1u)] = iA[i];
+}
+// ZK_MSM_CHECK=1 (tests): is the grouping exact?  Every position of a window's id list must hold a live term whose key owns that position, no term
+// twice (bitmap), as many positions as pairs were counted.  err[0]: violations, err[1 + w]: positions seen per window.
+template <int C>
+__global__ void __launch_bounds__(256) k_msm_check(VWork V, MsmDims D, uint32_t cap, const uint32_t* __restrict__ bin_start, const uint32_t* __restrict__ vals,
+                                                   const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t* seen, uint32_t* err) {
+    typedef MsmShape<C> S;
+    const uint32_t w = blockIdx.y, pos = gtid();
+    if (pos >= bin_start[w * (MSM_NBIN + 1) + MSM_NBIN]) return;
+    atomicAdd(&err[1 + w], 1u);
+    const uint32_t id = vals[(size_t)w * cap + pos];
+    uint32_t w8[8], proof;
+    if (!msm_term_words(V, D, id, w8, proof)) {
+        atomicAdd(&err[0], 1u);
+        return;
+    }
+    uint32_t d = 0;
+#pragma unroll
+    for (int k = 0; k < (int)S::nw; k++)
+        if (k == (int)w) d = msm_digit<C>(w8, k);
+    const uint32_t key = ((proof / D.gsz) << S::c) | d;
+    const size_t wd = (size_t)w * MSM_NBG + key;
+    if (!d || pos < start[wd] || pos >= end[wd]) atomicAdd(&err[0], 1u);
+    const size_t bit = (size_t)w * cap + id;
+    if (atomicOr(&seen[bit >> 5], 1u << (bit & 31)) & (1u << (bit & 31))) atomicAdd(&err[0], 1u);
+}
+template <int C>
+__global__ void __launch_bounds__(256) k_msm_check_count(VWork V, MsmDims D, uint32_t* err) {   // err[64 + w]: pairs window w must hold
+    typedef MsmShape<C> S;
+    uint32_t w8[8], proof;
+    if (!msm_term_words(V, D, gtid(), w8, proof)) return;
+#pragma unroll
+    for (int w = 0; w < (int)S::nw; w++)
+        if (msm_digit<C>(w8, w)) atomicAdd(&err[64 + w], 1u);
 }
 ZK_DEV TomNiels msm_ld(const uint32_t* e) {
     const uint4* q = (const uint4*)e;
@@ -157,20 +330,11 @@ ZK_DEV TomPt msm_ldp(const uint32_t* p) {
 // than `big` terms (8 x the window's average + 64) is left to k_msm_bucket_big, one workgroup per such bucket, so that no lane
 // walks a long list alone.
 #define MSM_BIG_MAX 4096u
-// A lane sums one bucket, so a wave takes as long as its largest bucket: with Poisson-sized buckets (mean 27 in the low windows, 10
-// in the high ones) a wave of 64 neighbouring digits waits for a bucket 1.5-1.8x the mean.  The buckets of all windows are therefore
-// ordered by size first (k_msm_sizes + ONE 8-bit radix pass over 8.4 M (key, id) pairs), largest first: the lanes of a wave get
-// buckets of the same size, the empty ones end up together at the end.
-template <int C>
-__global__ void __launch_bounds__(256) k_msm_sizes(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t* key, uint32_t* id) {
-    uint32_t wd = gtid();   // w * MSM_NBG + (group << C | digit)
-    uint32_t n = (wd & (MsmShape<C>::nb - 1)) != 0 ? end[wd] - start[wd] : 0;
-    key[wd] = 255u - (n < 255u ? n : 255u), id[wd] = wd;
-}
 template <int C>
 __global__ void __launch_bounds__(256) k_msm_bucket(const uint32_t* __restrict__ aos, const uint32_t* __restrict__ vals, uint32_t cap,
                                                     const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, const uint32_t* __restrict__ order,
-                                                    uint32_t* buckets, uint32_t* big_cnt, uint32_t* big_list, uint32_t big) {
+                                                    uint32_t* buckets, uint32_t* big_cnt, uint32_t* big_list, const uint32_t* __restrict__ nlive) {
+    const uint32_t big = 8 * ((*nlive + MSM_NBG - 1) / MSM_NBG) + 64;   // oversized: 8 x a window's average + 64
     uint32_t wd = order[gtid()], w = wd / MSM_NBG, d = wd % MSM_NBG;   // d = group << C | digit
     uint32_t s = start[wd], e = end[wd];
     TomPt acc = tom_identity();
@@ -343,17 +507,15 @@ __global__ void k_msm_final(const uint32_t* __restrict__ Tw, TomList one, uint32
     flag[g] = id ? 1u : 0u;
 }
 
-size_t msm_workspace_bytes(uint32_t cap) {
-    size_t tmp = 0;
-    rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, cap, 0, MSM_KEY_BITS);
-    size_t tmp2 = 0;   // the bucket ordering pass
-    rocprim::radix_sort_pairs(nullptr, tmp2, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, MSM_NW_MAX * MSM_NBG, 0, 8);
-    return tmp > tmp2 ? tmp : tmp2;
+// bytes of the grouping passes' scratch (MsmBuf::sort_tmp): bin_cnt and bin_off [MSM_SORT_G][windows * bins], bin_tot, bin_start, live_cnt
+size_t msm_workspace_bytes(uint32_t) {
+    const size_t nwb = (size_t)MSM_NW_MAX * MSM_NBIN;
+    return 4 * (2 * nwb * MSM_SORT_G + nwb + (size_t)MSM_NW_MAX * (MSM_NBIN + 1) + MSM_SORT_G) + 1024;
 }
 // returns through host_flags[groups] (after a stream synchronisation): 1 = the Tom total of that group of proofs is the identity
 template <int C>
 static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t* host_flags, uint32_t* gsz_out,
-                            hipEvent_t ev0, hipEvent_t ev1) {
+                            hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2, hipEvent_t ev3) {
     typedef MsmShape<C> S;
     MsmDims D;
     D.g0 = V.C * VK, D.g1 = V.C * nq, D.g2 = V.C;
@@ -365,38 +527,51 @@ static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& 
     const bool dbg = getenv("ZK_MSM_DEBUG") != nullptr;  // phase timings on stderr (adds stream synchronisations)
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
+    // scratch of the grouping passes
+    const uint32_t nwb = S::nw * MSM_NBIN;
+    uint32_t* bin_cnt = (uint32_t*)M.sort_tmp;
+    uint32_t* bin_off = bin_cnt + (size_t)MSM_SORT_G * nwb;
+    uint32_t* bin_tot = bin_off + (size_t)MSM_SORT_G * nwb;
+    uint32_t* bin_start = bin_tot + nwb;
+    uint32_t* live_cnt = bin_start + (size_t)S::nw * (MSM_NBIN + 1);
+    const uint32_t per_wg = ((total + MSM_SORT_G - 1) / MSM_SORT_G + MSM_SORT_T - 1) / MSM_SORT_T * MSM_SORT_T;   // ids per workgroup of pass A
     hipLaunchKernelGGL(k_msm_pack, dim3((total + 255) / 256), dim3(256), 0, s, V, D, M.aos);
-    hipMemsetAsync(M.start, 0, sizeof(uint32_t) * S::nw * MSM_NBG, s);
-    hipMemsetAsync(M.end, 0, sizeof(uint32_t) * S::nw * MSM_NBG, s);
-    hipMemsetAsync(M.counters, 0, sizeof(uint32_t) * 32, s);
-    hipLaunchKernelGGL(k_msm_compact<C>, dim3((total + 255) / 256), dim3(256), 0, s, V, D, M.cap, M.keys_all, M.vals_in, M.counters);
-    launch_words_to_host(s, M.host, M.counters, 1);
-    hipError_t e0 = hipStreamSynchronize(s);
-    if (e0 != hipSuccess) return e0;
-    const uint32_t n = M.host[0];
-    const uint32_t nmax = n;
-    if (dbg) fprintf(stderr, "msm: %u live terms, pack+compact %.2f ms\n", n, now() - t0), t0 = now();
-    for (uint32_t w = 0; w < S::nw && n; w++) {
-        size_t tmp = M.sort_tmp_bytes;
-        hipError_t e = rocprim::radix_sort_pairs(M.sort_tmp, tmp, M.keys_all + (size_t)w * M.cap, M.keys_out, M.vals_in, M.vals_out + (size_t)w * M.cap, n, 0,
-                                                 MSM_KEY_BITS, s);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_msm_bounds, dim3((n + 255) / 256), dim3(256), 0, s, M.keys_out, n, M.start + (size_t)w * MSM_NBG, M.end + (size_t)w * MSM_NBG);
-    }
+    hipMemsetAsync(M.counters, 0, sizeof(uint32_t) * 64, s);
+    if (ev2) hipEventRecord(ev2, s);   // the grouping of the keys alone (bench.py: verify.roofline.non_arithmetic)
+    hipLaunchKernelGGL(k_msm_hist<C>, dim3(MSM_SORT_G), dim3(MSM_SORT_T), 0, s, V, D, per_wg, bin_cnt, live_cnt);
+    hipLaunchKernelGGL(k_msm_binscan1, dim3(nwb), dim3(MSM_SORT_G), 0, s, bin_cnt, nwb, bin_off, bin_tot);
+    hipLaunchKernelGGL(k_msm_binscan2, dim3(S::nw), dim3(MSM_NBIN), 0, s, bin_tot, bin_start, live_cnt, M.counters);
+    hipLaunchKernelGGL(k_msm_scatter<C>, dim3(MSM_SORT_G), dim3(MSM_SORT_T), 0, s, V, D, per_wg, M.cap, bin_start, bin_off, M.keys_all, M.ids_bin);
+    hipLaunchKernelGGL(k_msm_binsort, dim3(MSM_NBIN, S::nw), dim3(256), 0, s, M.keys_all, M.ids_bin, M.cap, bin_start, M.vals_out, M.start, M.end, M.ord_id);
+    if (ev3) hipEventRecord(ev3, s);
     if (dbg) {
         hipStreamSynchronize(s);
-        fprintf(stderr, "msm: %u sorts + bounds %.2f ms\n", S::nw, now() - t0), t0 = now();
+        fprintf(stderr, "msm: pack + grouping of the keys %.2f ms\n", now() - t0), t0 = now();
     }
-    hipMemsetAsync(M.counters + 32, 0, 4, s);
-    {
-        hipLaunchKernelGGL(k_msm_sizes<C>, dim3(S::nw * MSM_NBG / 256), dim3(256), 0, s, M.start, M.end, M.ord_key, M.ord_id);
-        size_t tmp = M.sort_tmp_bytes;
-        hipError_t e = rocprim::radix_sort_pairs(M.sort_tmp, tmp, M.ord_key, M.ord_key2, M.ord_id, M.ord_id2, S::nw * MSM_NBG, 0, 8, s);
-        if (e != hipSuccess) return e;
+    if (getenv("ZK_MSM_CHECK")) {   // tests: the grouping against first principles (k_msm_check)
+        uint32_t *seen = nullptr, *err = nullptr;
+        const size_t seen_words = ((size_t)S::nw * M.cap + 31) / 32;
+        if (hipMalloc(&seen, seen_words * 4) != hipSuccess || hipMalloc(&err, 512) != hipSuccess) return hipErrorOutOfMemory;
+        hipMemsetAsync(seen, 0, seen_words * 4, s), hipMemsetAsync(err, 0, 512, s);
+        hipLaunchKernelGGL(k_msm_check<C>, dim3((M.cap + 255) / 256, S::nw), dim3(256), 0, s, V, D, M.cap, bin_start, M.vals_out, M.start, M.end, seen, err);
+        hipLaunchKernelGGL(k_msm_check_count<C>, dim3((total + 255) / 256), dim3(256), 0, s, V, D, err);
+        uint32_t h[128];
+        hipMemcpyAsync(h, err, 512, hipMemcpyDeviceToHost, s);
+        hipError_t ec = hipStreamSynchronize(s);
+        hipFree(seen), hipFree(err);
+        if (ec != hipSuccess) return ec;
+        bool bad = h[0] != 0;
+        for (uint32_t w = 0; w < S::nw; w++) bad = bad || h[1 + w] != h[64 + w];
+        if (bad) {
+            fprintf(stderr, "ZK_MSM_CHECK: grouping wrong: %u violations; pairs per window (listed / expected):", h[0]);
+            for (uint32_t w = 0; w < S::nw; w++) fprintf(stderr, " %u/%u", h[1 + w], h[64 + w]);
+            fprintf(stderr, "\n");
+            return hipErrorAssert;
+        }
     }
     if (ev0) hipEventRecord(ev0, s);   // the bucket sums alone (bench.py: roofline.others)
-    hipLaunchKernelGGL(k_msm_bucket<C>, dim3(S::nw * MSM_NBG / 256), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.ord_id2, M.buckets, M.counters + 32,
-                       M.big_list, 8 * ((nmax + MSM_NBG - 1) / MSM_NBG) + 64);
+    hipLaunchKernelGGL(k_msm_bucket<C>, dim3(S::nw * MSM_NBG / 256), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.ord_id, M.buckets, M.counters + 32,
+                       M.big_list, M.counters);
     if (ev1) hipEventRecord(ev1, s);
     hipLaunchKernelGGL(k_msm_bucket_big, dim3(MSM_NSLICE, 32), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.counters + 32, M.big_list, M.big_part);
     hipLaunchKernelGGL(k_msm_bucket_big2, dim3(64), dim3(256), 0, s, M.counters + 32, M.big_list, M.big_part, M.buckets);
@@ -407,13 +582,14 @@ static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& 
     hipLaunchKernelGGL(k_msm_coef, dim3(S::g), dim3(256), 0, s, W, count, D.gsz, M.one);
     launch_tom_commit(s, P, M.one, S::g, 1, 1);
     hipLaunchKernelGGL(k_msm_final<C>, dim3(1), dim3(64), 0, s, M.Tw, M.one, M.flag);
+    launch_words_to_host(s, M.host, M.counters, 1);   // live terms of the pass (statistics: zk_test_counter 2)
     launch_words_to_host(s, M.host + 8, M.flag, S::g);
     hipError_t e = hipStreamSynchronize(s);
     for (uint32_t g = 0; g < S::g; g++) host_flags[g] = M.host[8 + g];
-    if (dbg) fprintf(stderr, "msm tail (bucket .. final) %.2f ms\n", now() - t0);
+    if (dbg) fprintf(stderr, "msm: %u live terms; bucket .. final %.2f ms\n", M.host[0], now() - t0);
     return e;
 }
 hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t groups, uint32_t* host_flags,
-                   uint32_t* gsz_out, hipEvent_t ev0, hipEvent_t ev1) {
-    return groups == 64 ? run_msm_t<13>(s, P, W, V, count, nq, M, host_flags, gsz_out, ev0, ev1) : run_msm_t<16>(s, P, W, V, count, nq, M, host_flags, gsz_out, ev0, ev1);
+                   uint32_t* gsz_out, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2, hipEvent_t ev3) {
+    return groups == 64 ? run_msm_t<13>(s, P, W, V, count, nq, M, host_flags, gsz_out, ev0, ev1, ev2, ev3) : run_msm_t<16>(s, P, W, V, count, nq, M, host_flags, gsz_out, ev0, ev1, ev2, ev3);
 }

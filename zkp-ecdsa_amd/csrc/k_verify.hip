@@ -47,8 +47,7 @@ ZK_DEV bool tom_bytes_valid(const uint8_t* p) {  // edwards.ts:204-209 afterJson
     uint32_t xw[9], yw[9];
     ld_words_be<9>(p, xw);
     ld_words_be<9>(p + 36, yw);
-    TomPt t;
-    return tom_from_affine_words(t, xw, yw);
+    return tom_words_on_curve(xw, yw);
 }
 ZK_DEV bool p256_bytes_valid(const uint8_t* p) {  // weier.ts:256-260
     uint32_t xw[8], yw[8];
@@ -99,18 +98,48 @@ __global__ void __launch_bounds__(256) k_v_header(VWork V, uint32_t count, const
 #pragma unroll
     for (int i = 0; i < 4; i++) V.hbits[4 * p + i] = bits[i];
 }
-// every point of the proof must deserialise (on curve, coordinates in range).  One thread per POINT SLOT, P-256 slots
-// first (R, comS1, A_i), then the Tom-256 slots (keyXcom, keyYcom, 4n GK points and per repetition Tx, Ty + the 32
-// PointAdd points, which exist only for zero bits): consecutive lanes check consecutive strings of one kind, every lane
-// does the same amount of work and the branchy part only selects an ADDRESS (one copy of each curve check per wave).
-// A proof whose GKProof has another length n' than the ring's (okflags bit 3; never produced by an honest prover) keeps its
-// slots for everything else and has its 4 n' membership commitments walked by the thread of its keyXcom slot.
-#define V_REP_TOM_SLOTS 34
+// every point of the proof must deserialise (on curve, coordinates in range).  One thread per POINT that exists: the P-256 points first (R, comS1,
+// A_i), then the Tom-256 ones -- keyXcom, keyYcom, the 4n membership commitments, Tx_i and Ty_i of every repetition, and the 32 PointAdd points of
+// every ZERO-bit repetition, in the order of their rank among the zero bits -- so consecutive lanes check consecutive strings of one kind, every lane of
+// a wave has work (round 4 gave every repetition 34 slots and let the 32 PointAdd lanes of a one-bit repetition exit: 45 % of the Tom lanes idle),
+// and the branchy part only selects an ADDRESS (one copy of each curve check per wave).  The Tom check runs on plain coordinates
+// (curve.h: tom_words_on_curve, 5 products instead of 7).  A proof whose GKProof has another length n' than the ring's (okflags bit 3; never produced
+// by an honest prover) keeps its threads for everything else and has its 4 n' membership commitments walked by the thread of its keyXcom.
+ZK_DEV uint32_t kth_set_bit(uint32_t x, uint32_t k) {   // position of the k-th (0-based) set bit of x; x has more than k bits set
+    uint32_t pos = 0;
+#pragma unroll
+    for (int sh = 16; sh >= 1; sh >>= 1) {
+        const uint32_t lo = x & ((1u << sh) - 1), c = __popc(lo);
+        if (k >= c) k -= c, x >>= sh, pos += sh;
+        else x = lo;
+    }
+    return pos;
+}
+// the repetition whose challenge bit is the zr-th (0-based) ZERO among bits [0, sec) (there is one: zr < number of zero bits)
+ZK_DEV uint32_t zero_bit_rep(const uint32_t* hb, uint32_t sec, uint32_t zr) {
+    uint32_t j = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t lo = 32 * w;
+        if (sec <= lo) break;
+        const uint32_t nb = sec - lo >= 32 ? 32 : sec - lo;
+        const uint32_t z = ~hb[w] & (nb == 32 ? 0xffffffffu : ((1u << nb) - 1));
+        const uint32_t c = __popc(z);
+        if (zr < c) {
+            j = lo + kth_set_bit(z, zr);
+            break;
+        }
+        zr -= c;
+    }
+    return j;
+}
+ZK_DEV uint32_t v_validate_threads(uint32_t sec, uint32_t n) { return (2 + sec) + 2 + 4 * n + 2 * sec + 32 * sec; }   // per proof, all bits zero
 __global__ void __launch_bounds__(256) k_v_validate(VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
-    const uint32_t np = 2 + V.sec, nt = 2 + 4 * V.n + V_REP_TOM_SLOTS * V.sec, per = np + nt;
-    uint32_t blocks_per_proof = (per + 255) / 256;           // a workgroup never straddles two proofs
+    const uint32_t np = 2 + V.sec, ngk = 2 + 4 * V.n, per_max = v_validate_threads(V.sec, V.n);
+    uint32_t blocks_per_proof = (per_max + 255) / 256;           // a workgroup never straddles two proofs
     uint32_t p = blockIdx.x / blocks_per_proof, m = (blockIdx.x % blocks_per_proof) * 256 + threadIdx.x;
-    if (p >= count || m >= per) return;
+    if (p >= count) return;
+    if (m >= np + ngk + 2 * V.sec + 32 * V.zcnt[p]) return;     // (whole trailing waves: the PointAdd points of this proof's zero bits end here)
     if (V.st[p] != ZK_OK) return;
     const uint32_t other_n = V.okflags[p] & 8 ? V.okflags[p] >> 16 : 0xffffffffu;
     const uint8_t* pr = proofs + off[first + p];
@@ -128,19 +157,20 @@ __global__ void __launch_bounds__(256) k_v_validate(VWork V, uint32_t count, con
                 const uint8_t* gk = v_gk_base(V, pr, p);
                 for (uint32_t k = 0; k < 4 * other_n; k++) ok = ok && tom_bytes_valid(gk + 72 * k);
             }
-        } else if (u < 2 + 4 * V.n) {
+        } else if (u < ngk) {
             if (other_n != 0xffffffffu) return;
             ptr = v_gk_base(V, pr, p) + 72 * (u - 2);
-        } else {
-            uint32_t r = u - (2 + 4 * V.n), j = r / V_REP_TOM_SLOTS, k = r % V_REP_TOM_SLOTS;
-            bool one = (hb[j >> 5] >> (j & 31)) & 1;
-            if (k >= 2 && one) return;  // response1 has no PointAdd proof
-            const uint8_t* rep = pr + rep_offset(hb, j);
-            uint32_t q = k - 2;  // 0..3 C8..C13, 4..27 the six points of the four MultProofs, 28..31 A_1, A_2 of pi_x, pi_y
-            if (k < 2) ptr = rep + 64 + 72 * k;
-            else if (q < 4) ptr = rep + ZK_REP_HEAD + 72 * q;
-            else if (q < 28) ptr = rep + ZK_REP_HEAD + 288 + 656 * ((q - 4) / 6) + 72 * ((q - 4) % 6);
-            else ptr = rep + ZK_REP_HEAD + (q < 30 ? 2912 : 3152) + 72 * (q & 1);
+        } else if (u < ngk + 2 * V.sec) {   // Tx_j, Ty_j
+            const uint32_t r = u - ngk;
+            ptr = pr + rep_offset(hb, r >> 1) + 64 + 72 * (r & 1);
+        } else {   // point q of the PointAdd proof of the zr-th zero-bit repetition: zeros_below(j) = zr, so its offset needs no bit counting
+            const uint32_t r = u - ngk - 2 * V.sec, zr = r >> 5, q = r & 31;
+            const uint32_t j = zero_bit_rep(hb, V.sec, zr);
+            const uint8_t* pa = pr + ZK_FIXED + (uint64_t)ZK_REP_HEAD * (j + 1) + (uint64_t)ZK_PADD_SZ * zr;
+            // q: 0..3 C8..C13, 4..27 the six points of the four MultProofs, 28..31 A_1, A_2 of pi_x, pi_y
+            if (q < 4) ptr = pa + 72 * q;
+            else if (q < 28) ptr = pa + 288 + 656 * ((q - 4) / 6) + 72 * ((q - 4) % 6);
+            else ptr = pa + (q < 30 ? 2912 : 3152) + 72 * (q & 1);
         }
     }
     ok = ok && (is_p ? p256_bytes_valid(ptr) : tom_bytes_valid(ptr));
@@ -1552,7 +1582,7 @@ __global__ void k_v_clambda(VWork V, uint32_t count, const uint8_t* proofs, cons
 void launch_v_header_validate(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
     L1(k_v_header, count, 256, V, count, proofs, off, first);
     {
-        uint32_t per = 2 + V.sec + 2 + 4 * V.n + V_REP_TOM_SLOTS * V.sec;
+        uint32_t per = (2 + V.sec) + 2 + 4 * V.n + 2 * V.sec + 32 * V.sec;   // = v_validate_threads(V.sec, V.n)
         hipLaunchKernelGGL(k_v_validate, dim3(count * ((per + 255) / 256)), dim3(256), 0, s, V, count, proofs, off, first);
     }
 }
