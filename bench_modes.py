@@ -336,6 +336,11 @@ def run_pool_mode(args, Z):
     # node's host memory in the path -- on N devices the ratio to `value` separates compute scaling from host-memory scaling
     dev_out = None
     try:
+        # the device-resident shape of bench.py's `value` (round 4 measured this with the verify pass's 8 192-proof chunks on two lanes still set: the "8 %
+        # of the pool" of that round's review was the chunk size, not the pool)
+        for i in range(G):
+            e = pool.engine(i)
+            e.set_chunk(min(args.chunk, Bg)), e.set_lanes(args.lanes), e.set_slice(0)
         dbuf = [pool.device_alloc(i, per_shard) for i in range(G)]
         pool.prove_batch_device_out(msg_a, sig_a, pk_a, which_a, seeds_a, dbuf, [per_shard] * G)
         ddts = []
@@ -343,7 +348,8 @@ def run_pool_mode(args, Z):
             ddt, doff, dln, dst = pool.prove_batch_device_out(msg_a, sig_a, pk_a, which_a, seeds_a, dbuf, [per_shard] * G)
             ddts.append(ddt)
         assert not any(dst) and list(dln) == list(ln)
-        dev_out = {'proofs_per_s': round(B * args.steps / sum(ddts), 1), 'ms_per_step': round(sum(ddts) * 1e3 / args.steps, 2), 'shard_ms': pool.shard_ms()}
+        dev_out = {'proofs_per_s': round(B * args.steps / sum(ddts), 1), 'ms_per_step': round(sum(ddts) * 1e3 / args.steps, 2), 'shard_ms': pool.shard_ms(),
+                   'chunk': min(args.chunk, Bg), 'lanes': args.lanes}
         for i in range(G):
             pool.device_free(i, dbuf[i])
     except Exception as e:

@@ -278,6 +278,10 @@ int zk_pool_numa_node(const zk_pool *pool, int i);
  * returns the number of shards */
 int zk_pool_shard_ms(const zk_pool *pool, float *ms, int cap);
 const char *zk_pool_ring_transport(const zk_pool *pool);
+/* the file the nccl* entry points were taken from ("" while RCCL was never loaded).  zk_pool_set_ring looks for librccl in this order: the path in
+ * ZKATTEST_RCCL_LIB (if it cannot be loaded RCCL is not used at all); a librccl the process has already mapped (under PyTorch: the wheel's own, bound to
+ * the HIP runtime this library is then running on as well); the system's librccl.so.1.  ZKATTEST_NO_RCCL=1 goes straight to peer copies. */
+const char *zk_pool_rccl_library(const zk_pool *pool);
 void zk_pool_shard(const zk_pool *pool, uint64_t B, int i, uint64_t *first, uint64_t *count);
 zk_status zk_pool_set_params(zk_pool *pool, const uint8_t nist_h[64], const uint8_t tom_g[72], const uint8_t tom_h[72], uint32_t sec_level);
 zk_status zk_pool_set_ring(zk_pool *pool, const uint8_t *keys_be32, uint64_t n_keys);
@@ -371,9 +375,6 @@ zk_status zk_ctx_copy_probe(zk_ctx *ctx, uint32_t lane, size_t bytes, int numa_n
 /* Unit-test hooks (tests/ call these through the C ABI to compare single primitives with the oracle).
  * zk_pool_test_locality: NUMA node and local CPUs of a PCI address as the pool reads them from sysfs (ZKATTEST_SYSFS_ROOT). */
 int zk_pool_test_locality(const char *pci_bus_id, int *numa_node, int *cpus, int cap);
-/* the next zk_pool_prove_submit / zk_pool_verify_submit fails with ZK_E_DEVICE at device slot `slot`, after the earlier slots were
- * submitted (one shot): the half-submitted job is taken out of the queues again, older jobs stay in flight and waitable */
-void zk_pool_test_fail_submit(zk_pool *pool, int slot);
 /* work counters: 0 = proofs that went through the verifier's per-proof sums since the context was created (fallback of the batched check);
  * 1 = proofs of the last chunk on lane 0 whose scalar multiplications by the signer's key went through the per-key tables;
  * 2 = live terms that went through the verifier's batched Tom-256 check (bucket pass) since the context was created */

@@ -193,7 +193,7 @@ def test_key_grouping_of_the_batched_check_is_exact(monkeypatch):
             assert eng.verify_batch(msg, forged, vseeds=vs) == ([1] * 3 + [0] + [1] * 6, [0] * 10), (groups, chunk)
     eng.close()
     import zkp_ecdsa_amd as Z
-    B, nkeys = 3000, 1024
+    B, nkeys = 3000, 4096
     eng = Z.Engine(0)
     eng.set_params(*eng.synth_params(78), 80)
     ring, msg, sig, pk, which, seeds = eng.synth_workload(78, nkeys, B)

@@ -118,6 +118,46 @@ def test_the_prover_emits_the_packed_layout_natively(nkeys, B, chunk, lanes):
 
 
 @pytest.mark.gpu
+def test_device_side_offsets_of_packed_proofs_are_checked_before_the_expansion_is_sized():
+    """zk_verify_batch_device with ZKA1P proofs: the offsets live in HBM and the staging of the expanded proofs is sized from off[B] -- overlapping ranges
+    ([0, L, 0, L]: every proof expands again) would run past it.  A non-monotonic or misaligned device array is refused (ZK_E_ARG) before anything is
+    expanded; the well-formed array verifies."""
+    import torch
+    eng = Z.Engine(0)
+    eng.set_comb_bits(16)
+    eng.set_params(*eng.synth_params(72), 80)
+    ring, msg, sig, pk, which, seeds = eng.synth_workload(72, 8, 4)
+    eng.set_ring(ring, 8)
+    eng.set_wire(True)
+    packed, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert not any(st)
+    dev = torch.device('cuda', 0)
+    blob = b''.join(packed)
+    d_pr = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    d_msg = torch.frombuffer(bytearray(msg), dtype=torch.uint8).to(dev)
+    d_vs = torch.frombuffer(bytearray(_vseeds(4, b'o')), dtype=torch.uint8).to(dev)
+    d_ok, d_st = torch.zeros(4, dtype=torch.uint8, device=dev), torch.zeros(4, dtype=torch.int32, device=dev)
+    offs, o = [0], 0
+    for p_ in packed:
+        o += len(p_)
+        offs.append(o)
+
+    def run(off_list):
+        d_off = torch.tensor(off_list, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        eng.verify_batch_device(4, d_msg.data_ptr(), d_pr.data_ptr(), d_off.data_ptr(), d_vs.data_ptr(), d_ok.data_ptr(), d_st.data_ptr())
+        return d_ok.cpu().tolist(), d_st.cpu().tolist()
+    assert run(offs) == ([1] * 4, [0] * 4)
+    L = len(packed[0])
+    for bad in ([0, L, 0, L, 2 * L], [0, L, 2 * L, L, 4 * L], [0, L + 2, 2 * L, 3 * L, 4 * L]):
+        with pytest.raises(Z.ZkError) as e:
+            run(bad)
+        assert e.value.status == 14 and 'offsets' in str(e.value)
+    assert run(offs) == ([1] * 4, [0] * 4)   # the context is usable afterwards
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_packed_mutants_get_the_verdicts_of_their_expanded_form():
     """Every mutant of the sweep that still has a packed form (structure intact, coordinates below 2^264), packed: the engine on the packed bytes
     == the oracle on the ZKA1 bytes, exact status codes; plus damage done to the PACKED bytes themselves (length, magic, truncation)."""

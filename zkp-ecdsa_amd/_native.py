@@ -15,9 +15,9 @@ SYMBOLS = [
     'zk_ctx_set_ring_device', 'zk_keys_to_ints', 'zk_ctx_set_chunk', 'zk_ctx_set_lanes', 'zk_ctx_set_comb_bits', 'zk_ctx_set_batch_verify', 'zk_proof_max_size', 'zk_prove_batch', 'zk_prove_batch_device',
     'zk_verify_batch', 'zk_verify_batch_device', 'zk_synth_workload', 'zk_synth_params', 'zk_last_timing',
     'zk_proof_to_json', 'zk_proof_from_json', 'zk_host_alloc', 'zk_host_free', 'zk_ctx_set_host_taper', 'zk_ctx_set_slice', 'zk_ctx_set_mode', 'zk_ring_digest', 'zk_hardened_h',
-    'zk_pool_create', 'zk_pool_destroy', 'zk_pool_size', 'zk_pool_ctx', 'zk_pool_last_error', 'zk_pool_ring_transport', 'zk_pool_shard',
+    'zk_pool_create', 'zk_pool_destroy', 'zk_pool_size', 'zk_pool_ctx', 'zk_pool_last_error', 'zk_pool_ring_transport', 'zk_pool_rccl_library', 'zk_pool_shard',
     'zk_pool_set_params', 'zk_pool_set_ring', 'zk_pool_prove_batch', 'zk_pool_verify_batch',
-    'zk_pool_host_alloc', 'zk_pool_host_free', 'zk_pool_numa_node', 'zk_pool_test_locality', 'zk_pool_shard_ms', 'zk_pool_test_fail_submit', 'zk_ctx_copy_probe', 'zk_ctx_set_wire', 'zk_proof_pack', 'zk_proof_unpack', 'zk_pool_prove_batch_device', 'zk_pool_device_alloc', 'zk_pool_device_free',
+    'zk_pool_host_alloc', 'zk_pool_host_free', 'zk_pool_numa_node', 'zk_pool_test_locality', 'zk_pool_shard_ms', 'zk_ctx_copy_probe', 'zk_ctx_set_wire', 'zk_proof_pack', 'zk_proof_unpack', 'zk_pool_prove_batch_device', 'zk_pool_device_alloc', 'zk_pool_device_free',
     'zk_prove_submit', 'zk_prove_submit_device', 'zk_prove_wait', 'zk_verify_submit', 'zk_verify_wait', 'zk_test_counter', 'zk_ctx_set_key_tables',
     'zk_proofs_to_json_batch', 'zk_proofs_from_json_batch', 'zk_ctx_set_ring_fold',
     'zk_pool_prove_submit', 'zk_pool_prove_wait', 'zk_pool_verify_submit', 'zk_pool_verify_wait', 'zk_ctx_set_verify_groups',
@@ -99,6 +99,8 @@ def lib():
         L.zk_pool_last_error.restype = C.c_char_p
         L.zk_pool_ring_transport.argtypes = [vp]
         L.zk_pool_ring_transport.restype = C.c_char_p
+        L.zk_pool_rccl_library.argtypes = [vp]
+        L.zk_pool_rccl_library.restype = C.c_char_p
         L.zk_pool_shard.argtypes = [vp, u64, i32, C.POINTER(u64), C.POINTER(u64)]
         L.zk_pool_shard.restype = None
         L.zk_pool_set_params.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, u32]
@@ -130,8 +132,6 @@ def lib():
         L.zk_proof_pack.argtypes = [C.c_char_p, u64, vp, u64, C.POINTER(u64)]
         L.zk_proof_unpack.argtypes = [C.c_char_p, u64, vp, u64, C.POINTER(u64)]
         L.zk_ctx_copy_probe.argtypes = [vp, u32, C.c_size_t, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-        L.zk_pool_test_fail_submit.argtypes = [vp, i32]
-        L.zk_pool_test_fail_submit.restype = None
         L.zk_pool_host_alloc.argtypes = [vp, C.c_size_t]
         L.zk_pool_host_alloc.restype = vp
         L.zk_pool_host_free.argtypes = [vp]
@@ -600,6 +600,10 @@ class Pool:
         """zk_pool_last_error: after set_ring also why RCCL was not used"""
         return self.L.zk_pool_last_error(self.h).decode()
 
+    def rccl_library(self):
+        """zk_pool_rccl_library: the file the nccl* entry points came from ('' while RCCL was never loaded)"""
+        return self.L.zk_pool_rccl_library(self.h).decode()
+
     def engine(self, i):
         """Per-device context (settings only: chunk, lanes, comb width, host taper); owned by the pool."""
         return Engine(_borrowed=self.L.zk_pool_ctx(self.h, i))
@@ -677,8 +681,9 @@ class Pool:
         return t['off'], t['ln'], t['st']
 
     def test_fail_submit(self, slot):
-        """unit-test hook: the next streamed submit fails at device slot `slot` after the earlier slots were submitted"""
-        self.L.zk_pool_test_fail_submit(self.h, slot)
+        """fault injection (tests): the next streamed submit of the process fails at device slot `slot` after the earlier slots were submitted.  An
+        environment gate of the library (ZKATTEST_TEST_FAIL_SUBMIT, consumed by the submit), not an exported hook."""
+        os.environ['ZKATTEST_TEST_FAIL_SUBMIT'] = str(slot)
 
     def verify_submit(self, msg, proofs, off, ln, B, vseeds=None):
         t = {'B': B, 'proofs': proofs, 'off': off, 'ln': ln, 'ok': (C.c_uint8 * B)(), 'st': (C.c_int32 * B)(), 'msg': bytes(msg),

@@ -18,6 +18,7 @@ void launch_synth_param_scalars(hipStream_t s, uint64_t seed, uint8_t* kn_be, ui
 #include <cstdlib>
 #include <sys/syscall.h>
 #include <unistd.h>
+#include <atomic>
 #include "ctx.h"
 #include "jobs.h"
 
@@ -631,7 +632,15 @@ static float link_expected_gbps() {
 // 0.8 of what the link should carry (sysfs); where sysfs does not say, when it is within 25 % of the best rate this process has measured
 // on any page-locked buffer (the first large allocation then draws a second candidate for comparison).  Slow pages are a transient of
 // the allocator (recently released page-locked memory), so a pause precedes every further attempt.
-static float g_best_pinned_rate = 0.f;
+static std::atomic<float> g_best_pinned_rate{0.f};   // (both allocators may run on several host threads: zk_pool_host_alloc, callers' own threads)
+// Rejected candidates are HELD while the next one is drawn, so that the allocator cannot hand the same slow pages out again -- but never more than
+// ZKATTEST_HOST_ALLOC_HOLD_GB (default 48) of page-locked memory at once, this candidate included: beyond that the oldest rejected one goes back first (a
+// multi-GB request must not fail, or stall the host, because three copies of it were pinned beside it).
+static size_t host_alloc_hold_limit() {
+    const char* e = getenv("ZKATTEST_HOST_ALLOC_HOLD_GB");
+    const long gb = e ? atol(e) : 48;
+    return (size_t)(gb > 0 ? gb : 1) << 30;
+}
 void* alloc_fast_pinned(size_t bytes, const std::function<void*()>& alloc, const std::function<void(void*)>& release) {
     const bool probe = host_alloc_probe_enabled() && bytes >= (64u << 20);
     const float expected = probe ? link_expected_gbps() : 0.f;
@@ -639,13 +648,18 @@ void* alloc_fast_pinned(size_t bytes, const std::function<void*()>& alloc, const
     void *best = nullptr, *held[ZK_ALLOC_TRIES] = {};
     float best_r = -1.f;
     int nheld = 0;
+    const size_t hold_limit = host_alloc_hold_limit();
     for (int t = 0; t < ZK_ALLOC_TRIES; t++) {
+        while (nheld > 0 && ((size_t)nheld + (best ? 1 : 0) + 1) * bytes > hold_limit) release(held[--nheld]);
         void* p = alloc();
         if (!p) break;
         const float r = probe ? pinned_d2h_rate(p, bytes) : 0.f;
-        const bool had_yardstick = g_best_pinned_rate > 0.f;
-        if (dbg) fprintf(stderr, "alloc: candidate %d of %zu MB: %.1f GB/s device-to-host (link should carry %.1f, best seen so far %.1f)\n", t, bytes >> 20, r, expected, g_best_pinned_rate);
-        if (r > g_best_pinned_rate) g_best_pinned_rate = r;
+        float seen = g_best_pinned_rate.load(std::memory_order_relaxed);
+        const bool had_yardstick = seen > 0.f;
+        if (dbg) fprintf(stderr, "alloc: candidate %d of %zu MB: %.1f GB/s device-to-host (link should carry %.1f, best seen so far %.1f)\n", t, bytes >> 20, r, expected, seen);
+        while (r > seen && !g_best_pinned_rate.compare_exchange_weak(seen, r, std::memory_order_relaxed)) {
+        }
+        seen = seen > r ? seen : r;
         if (r > best_r) {
             if (best) held[nheld++] = best;
             best = p, best_r = r;
@@ -653,7 +667,7 @@ void* alloc_fast_pinned(size_t bytes, const std::function<void*()>& alloc, const
             held[nheld++] = p;
         }
         if (!probe || r == 0.f) break;   // not measuring (or could not)
-        if (expected > 0.f ? best_r >= 0.8f * expected : ((had_yardstick || t > 0) && best_r >= 0.75f * g_best_pinned_rate)) break;
+        if (expected > 0.f ? best_r >= 0.8f * expected : ((had_yardstick || t > 0) && best_r >= 0.75f * seen)) break;
         if (t + 1 < ZK_ALLOC_TRIES) usleep(300000u * (unsigned)(t + 1));
     }
     for (int i = 0; i < nheld; i++) release(held[i]);
@@ -779,6 +793,7 @@ zk_status ProveJob::stage1(uint64_t chunk_no, int ph0, int ph1) {
             auto& PL = c->pl[lane];
             const bool beside = plan.size() == 1 && cnt <= ZK_PROVE_SIDE_MAX;   // a small one-chunk call: the two lists (a workgroup inversion each) side by side
             if (beside) {
+                if (timed) c->timing_forked = true;
                 zk_status zs = ensure_side_stream(c, PL);
                 if (zs) return zs;
                 HIPCHK(c, hipEventRecord(PL.side_fork, s));
@@ -900,6 +915,7 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
     const bool beside = !sliced && ((plan.size() == 1 && cnt <= ZK_PROVE_SIDE_MAX) || gk_late);   // (chunks of a longer job overlap each other on the lanes already)
     hipStream_t sg = s;
     if (beside) {
+        if (timed) c->timing_forked = true;
         zk_status zs = ensure_side_stream(c, PL);
         if (zs) return zs;
         sg = PL.side;

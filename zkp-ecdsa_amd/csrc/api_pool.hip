@@ -33,13 +33,24 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string served_by;   // the file the entry points came from (zk_pool_rccl_library)
+    // Which librccl: (1) ZKATTEST_RCCL_LIB, an explicit path (the GPU tier's stub, tests/rccl_stub; a deployment's own build); (2) a librccl this process
+    // has ALREADY mapped (RTLD_NOLOAD) -- under PyTorch that is the wheel's bundled one, bound to the wheel's bundled HIP runtime, which is then also the
+    // runtime this library runs on: a second, system librccl next to it would talk to the other libamdhip64 (the mix DESIGN.md section 9 shows to
+    // misbehave); (3) the system one.
     bool load() {
         if (h) return true;
         if (getenv("ZKATTEST_NO_RCCL")) return false;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (h) break;
+        static const char* const names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        if (const char* e = getenv("ZKATTEST_RCCL_LIB")) {
+            h = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+            if (!h) return false;   // an explicit choice that cannot be loaded is not silently replaced
         }
+        for (int pass = 0; pass < 2 && !h; pass++)
+            for (const char* name : names) {
+                h = dlopen(name, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                if (h) break;
+            }
         if (!h) return false;
         CommInitAll = (decltype(CommInitAll))dlsym(h, "ncclCommInitAll");
         CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
@@ -51,6 +62,8 @@ struct Rccl {
             dlclose(h), h = nullptr;
             return false;
         }
+        Dl_info di;
+        served_by = dladdr((void*)CommInitAll, &di) && di.dli_fname ? di.dli_fname : "?";
         return true;
     }
 };
@@ -71,7 +84,7 @@ struct zk_pool {
     std::vector<int> numa;                // -1 = unknown
     bool affinity = true;                 // ZKATTEST_POOL_AFFINITY=0 switches it off
     std::vector<float> shard_ms;          // wall time of every shard's part of the last pool call (zk_pool_shard_ms)
-    int test_fail_slot = -1;              // zk_pool_test_fail_submit: the next streamed submit fails at this device slot (one shot)
+    int test_fail_slot = -1;              // ZKATTEST_TEST_FAIL_SUBMIT: the next streamed submit fails at this device slot (one shot)
 };
 
 // "0-15,128-143" -> cpu numbers (the format of sysfs cpulist files)
@@ -212,10 +225,14 @@ extern "C" void zk_pool_destroy(zk_pool* p) {
     for (auto c : p->ctx) zk_ctx_destroy(c);
     delete p;
 }
-// unit-test hook: the next zk_pool_prove_submit / zk_pool_verify_submit fails at device slot `slot` with ZK_E_DEVICE after the earlier
-// slots were submitted (tests/test_gpu_stream.py: the abandon path with older pool jobs in flight)
-extern "C" void zk_pool_test_fail_submit(zk_pool* p, int slot) {
-    if (p) p->test_fail_slot = slot;
+// Fault injection for tests/test_gpu_stream.py (the abandon path with older pool jobs in flight): with ZKATTEST_TEST_FAIL_SUBMIT=<slot> in the environment the
+// next zk_pool_prove_submit / zk_pool_verify_submit fails at that device slot with ZK_E_DEVICE after the earlier slots were submitted, and the variable is
+// removed (one shot).  An environment gate instead of an exported hook: nothing in the public header can make a production submit fail.
+static void pool_arm_injected_failure(zk_pool* p) {
+    if (const char* e = getenv("ZKATTEST_TEST_FAIL_SUBMIT")) {
+        p->test_fail_slot = atoi(e);
+        unsetenv("ZKATTEST_TEST_FAIL_SUBMIT");
+    }
 }
 extern "C" int zk_pool_size(const zk_pool* p) { return p ? (int)p->ctx.size() : 0; }
 extern "C" zk_ctx* zk_pool_ctx(zk_pool* p, int i) { return p && i >= 0 && i < (int)p->ctx.size() ? p->ctx[i] : nullptr; }
@@ -342,6 +359,7 @@ extern "C" void zk_pool_host_free(void* mem) {
     munmap(mem, len);
 }
 extern "C" const char* zk_pool_ring_transport(const zk_pool* p) { return p ? p->transport : ""; }
+extern "C" const char* zk_pool_rccl_library(const zk_pool* p) { return p ? p->rccl.served_by.c_str() : ""; }
 
 extern "C" void zk_pool_shard(const zk_pool* p, uint64_t B, int i, uint64_t* first, uint64_t* count) {
     const uint64_t G = p ? p->ctx.size() : 1;
@@ -388,6 +406,8 @@ extern "C" zk_status zk_pool_set_ring(zk_pool* p, const uint8_t* keys, uint64_t 
         bool distinct = true;
         for (int i = 0; i < G; i++)
             for (int j = 0; j < i; j++) distinct = distinct && p->dev[i] != p->dev[j];
+        // RCCL refuses two ranks on one device; tests/rccl_stub does not, and ZKATTEST_RCCL_SAME_DEVICE=1 lets the one-GPU tier drive this branch through it
+        if (!distinct && getenv("ZKATTEST_RCCL_SAME_DEVICE") && getenv("ZKATTEST_RCCL_LIB")) distinct = true;
         if (distinct && !p->comms_tried) {   // one communicator per device, created once per pool
             p->comms_tried = true;
             if (p->rccl.load()) {
@@ -545,6 +565,7 @@ extern "C" zk_status zk_pool_prove_submit(zk_pool* p, uint64_t B, const uint8_t*
     if (!p || !job || !rng || !out_off || !out_len || !status || !B || !msg || !sig || !pk || !which || !rng->data || !out) return ZK_E_ARG;
     *job = nullptr;
     const uint64_t G = p->ctx.size();
+    pool_arm_injected_failure(p);
     zk_pool_job* j = new zk_pool_job();
     j->B = B, j->shard.assign(G, nullptr), j->off.resize(G), j->region = (out_cap / G) & ~(uint64_t)255, j->out_off = out_off, j->out_len = out_len;
     for (uint64_t i = 0; i < G; i++) {
@@ -558,7 +579,7 @@ extern "C" zk_status zk_pool_prove_submit(zk_pool* p, uint64_t B, const uint8_t*
                                                    : zk_prove_submit(p->ctx[i], cnt, msg + 32 * first, sig + 64 * first, pk + 64 * first, which + first, &r,
                                                                      out + j->region * i, j->region, j->off[i].data(), status + first, &j->shard[i]);
         if (zs) {
-            if ((int)i == p->test_fail_slot) p->test_fail_slot = -1, p->ctx[i]->err = "(injected by zk_pool_test_fail_submit)";
+            if ((int)i == p->test_fail_slot) p->test_fail_slot = -1, p->ctx[i]->err = "(injected by ZKATTEST_TEST_FAIL_SUBMIT)";
             p->err = std::string("device slot ") + std::to_string(i) + ": " + zk_strerror(zs) + " " + zk_last_error(p->ctx[i]);
             pool_job_abandon(p, j);
             return zs;
@@ -587,6 +608,7 @@ extern "C" zk_status zk_pool_verify_submit(zk_pool* p, uint64_t B, const uint8_t
     if (!p || !job || !B || !msg || !proofs || !proof_off || !proof_len || !ok || !status) return ZK_E_ARG;
     *job = nullptr;
     const uint64_t G = p->ctx.size();
+    pool_arm_injected_failure(p);
     zk_pool_job* j = new zk_pool_job();
     j->kind = 1, j->B = B, j->shard.assign(G, nullptr), j->off.resize(G);
     for (uint64_t i = 0; i < G; i++) {
@@ -601,7 +623,7 @@ extern "C" zk_status zk_pool_verify_submit(zk_pool* p, uint64_t B, const uint8_t
             if (proof_off[first + k] - base != off[k]) zs = ZK_E_ARG;   // a gap or an overlap inside the shard
             off[k + 1] = off[k] + proof_len[first + k];
         }
-        if (!zs && (int)i == p->test_fail_slot) zs = ZK_E_DEVICE, p->test_fail_slot = -1, p->ctx[i]->err = "(injected by zk_pool_test_fail_submit)";
+        if (!zs && (int)i == p->test_fail_slot) zs = ZK_E_DEVICE, p->test_fail_slot = -1, p->ctx[i]->err = "(injected by ZKATTEST_TEST_FAIL_SUBMIT)";
         else if (!zs) zs = zk_verify_submit(p->ctx[i], cnt, msg + 32 * first, proofs + base, off.data(), vseeds ? vseeds + 32 * first : nullptr, ok + first, status + first, &j->shard[i]);
         if (zs) {
             p->err = std::string("device slot ") + std::to_string(i) + ": " + zk_strerror(zs) + " " + zk_last_error(p->ctx[i]);

@@ -97,13 +97,25 @@ static void job_free(zk_job* j) {
         if (e) hipEventDestroy(e);
     delete j;
 }
-void stream_abandon_jobs(zk_ctx* c) {   // zk_ctx_destroy with jobs still queued: nothing may run on, their buffers are released
-    if (c->jobs.empty()) return;
+// Every stream a job's stages may have put work on: the lanes' compute and copy streams, the forks of small one-chunk jobs (the prover's side stream, the
+// verifier's auxiliary streams), the heavy queue, the finisher.  A failed or abandoned job's buffers go back to the spare pools only after all of them are idle
+// -- a HIP error between a fork and its join would otherwise leave kernels on a forked stream writing into memory the next job is handed.
+static void sync_every_stream(zk_ctx* c) {
     for (auto& L : c->pl) {
         if (L.stream) hipStreamSynchronize(L.stream);
         if (L.copy_stream) hipStreamSynchronize(L.copy_stream);
+        if (L.side) hipStreamSynchronize(L.side);
     }
+    for (auto& L : c->vl)
+        for (auto a : L.aux)
+            if (a) hipStreamSynchronize(a);
+    if (c->heavy) hipStreamSynchronize(c->heavy);
     if (c->fin_stream) hipStreamSynchronize(c->fin_stream);
+    if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
+}
+void stream_abandon_jobs(zk_ctx* c) {   // zk_ctx_destroy with jobs still queued: nothing may run on, their buffers are released
+    if (c->jobs.empty()) return;
+    sync_every_stream(c);
     while (!c->jobs.empty()) {
         zk_job* j = c->jobs.back();
         c->jobs.pop_back();
@@ -290,10 +302,7 @@ static zk_status wait_common(zk_ctx* c, zk_job* j) {
             dbg_flush();
         }
     }
-    if (j->result != ZK_OK || e != hipSuccess) {   // leave nothing of this job running: its buffers go back to the pool
-        for (uint32_t l = 0; l < j->nl; l++) hipStreamSynchronize(c->pl[l].stream), hipStreamSynchronize(c->pl[l].copy_stream);
-        hipStreamSynchronize(c->fin_stream), hipStreamSynchronize(c->copy_stream);
-    }
+    if (j->result != ZK_OK || e != hipSuccess) sync_every_stream(c);   // leave nothing of this job running: its buffers go back to the pool
     zk_status zs = j->result;
     if (zs) c->err = j->err;
     else if (e != hipSuccess) {

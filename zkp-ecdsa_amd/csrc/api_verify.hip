@@ -124,6 +124,19 @@ zk_status VerifyJob::plan_unpack() {
     if (!d_packed) return ZK_OK;
     const uint64_t nchunks = plan.size();
     std::vector<uint64_t> pfirst(nchunks);
+    if (!host_off) {   // a device-side offset array was never seen by the host: the expansion's sizing rests on it being non-decreasing (host arrays are checked by their callers)
+        DevBuf flag;
+        uint32_t bad = 0;
+        HIPCHK(c, hipMalloc(&flag.p, 4));
+        HIPCHK(c, hipMemsetAsync(flag.p, 0, 4, c->stream));
+        launch_offsets_monotonic(c->stream, d_poff, B, flag.as<uint32_t>());
+        HIPCHK(c, hipMemcpyAsync(&bad, flag.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (bad) {
+            c->err = "proof offsets must be non-decreasing and 4-byte aligned";
+            return ZK_E_ARG;
+        }
+    }
     for (uint64_t k = 0; k < nchunks; k++) {
         if (host_off) pfirst[k] = host_off[plan[k].first];
         else HIPCHK(c, hipMemcpy(&pfirst[k], d_poff + plan[k].first, 8, hipMemcpyDeviceToHost));   // device-pointer call: one word per chunk
@@ -175,6 +188,7 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
     // A small chunk (per_proof_range below) is a chain of latencies: the two challenge hashes (one lane per proof, 16 KB each) and the membership
     // total need nothing from the P-256 front end (R's window table: 256 doublings in a row) and run beside it on an auxiliary stream.
     const bool small = side_streams(cnt);
+    if (small && timed) c->timing_forked = true;
     auto& A = c->vl[lane];
     if (small) {
         HIPCHK(c, hipEventRecord(A.aux_fork, s));
@@ -321,6 +335,7 @@ zk_status VerifyJob::stage2(uint64_t chunk_no) {
     const uint32_t G = c->vs_groups;   // 8 or 64 groups per chunk (zk_ctx_set_verify_groups)
     uint32_t flags[MSM_G_MAX], gsz = cnt;
     const bool wide_chunk = side_streams(cnt);
+    if (wide_chunk && timed) c->timing_forked = true;
     auto& A = c->vl[lane];
     if (wide_chunk) {   // the P-256 sums of a small chunk, one term per lane, beside everything below
         HIPCHK(c, hipEventRecord(A.aux_fork, s));

@@ -124,6 +124,7 @@ struct zk_ctx {
     size_t eused = 0;
     std::vector<std::pair<const char*, float>> last_timing;
     float last_total_ms = 0;
+    bool timing_forked = false;   // this call put timed scopes on forked streams (small one-chunk calls): its scopes overlap, the total is first start -> last end
 };
 
 #define HIPCHK(ctx, x)                                                                                      \
@@ -158,10 +159,11 @@ struct Scope {
         c->trecs.push_back(r);
     }
 };
-static inline void timing_begin(zk_ctx* c) { c->trecs.clear(), c->eused = 0; }
+static inline void timing_begin(zk_ctx* c) { c->trecs.clear(), c->eused = 0, c->timing_forked = false; }
 static inline void timing_end(zk_ctx* c) {
     c->last_timing.clear();
     c->last_total_ms = 0;
+    float wall = 0;
     for (auto& r : c->trecs) {
         float ms = 0;
         hipEventElapsedTime(&ms, r.e0, r.e1);
@@ -170,7 +172,12 @@ static inline void timing_end(zk_ctx* c) {
             if (p.first == r.name) p.second += ms, found = true;
         if (!found) c->last_timing.push_back({r.name, ms});
         if (r.name[0] != '+') c->last_total_ms += ms;   // '+name': a part of another scope
+        if (c->timing_forked) {   // scopes on forked streams run beside those of the lane's stream: the per-family figures stay, their sum is not a time
+            float end = 0;
+            if (hipEventElapsedTime(&end, c->trecs[0].e0, r.e1) == hipSuccess && end > wall) wall = end;
+        }
     }
+    if (c->timing_forked) c->last_total_ms = wall;
 }
 
 // device allocation released on every exit path of an entry point

@@ -240,6 +240,7 @@ struct VWork {
     uint32_t* p256_ok;                         // [C] the P-256 relation holds (k_v_p256_total)
 };
 // ZKA1P -> ZKA1 for `count` proofs from proof `first` on: uoff[0 .. count] = their offsets in `out`, starting at `base` (k_verify.hip)
+void launch_offsets_monotonic(hipStream_t s, const uint64_t* d_off, uint64_t B, uint32_t* d_bad /* |= 1 if off[i] > off[i + 1] or off[i] is not 4-byte aligned */);
 void launch_v_unpack(hipStream_t s, uint32_t sec, uint32_t count, const uint8_t* packed, const uint64_t* poff, uint64_t first, uint64_t base, uint8_t* out, uint64_t* uoff);
 void launch_v_header_validate(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_front_r(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);   // R (and W.st)

@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(MSM_SORT_T) k_msm_scatter(VWork V, MsmDims D, 
 // ones) 64 neighbouring digits wait for a bucket 1.5-1.8x the mean, 64 neighbours in this order do not, and the empty ones end up together.  (Rounds 2-4
 // ordered ALL buckets of the chunk with one more library sort; within a bin the sizes follow the same distribution, so the local order serves the waves as well.)
 __global__ void __launch_bounds__(256) k_msm_binsort(const uint32_t* __restrict__ keyA, const uint32_t* __restrict__ idA, uint32_t cap, const uint32_t* __restrict__ bin_start,
-                                                     uint32_t* vals, uint32_t* start, uint32_t* end, uint32_t* order) {
+                                                     uint32_t* vals, uint32_t* start, uint32_t* end, uint32_t* order, uint32_t* size_cnt /* [256][windows * bins] or nullptr */) {
     constexpr uint32_t PER = MSM_NLOW / 256;
     static_assert(PER == 4, "four keys per thread: uint4 stores below");
     __shared__ uint32_t h[MSM_NLOW], hs[256], sh[17];
@@ -258,7 +258,8 @@ __global__ void __launch_bounds__(256) k_msm_binsort(const uint32_t* __restrict_
     }
     *(uint4*)(start + wd0 + PER * t) = make_uint4(st4[0], st4[1], st4[2], st4[3]);
     *(uint4*)(end + wd0 + PER * t) = make_uint4(en4[0], en4[1], en4[2], en4[3]);
-    const uint32_t hv = hs[t];    // (block_excl_scan's first barrier orders the atomics on hs before this read ... it ran above: hs is complete)
+    const uint32_t hv = hs[t];    // buckets of this bin whose size key is t (the barriers of the scan above lie between the atomics on hs and this read)
+    if (size_cnt) size_cnt[(size_t)t * (gridDim.y * MSM_NBIN) + blockIdx.y * MSM_NBIN + bin] = hv;
     uint32_t tot2;
     const uint32_t he = block_excl_scan(hv, sh, tot2);
     hs[t] = he;
@@ -267,6 +268,52 @@ __global__ void __launch_bounds__(256) k_msm_binsort(const uint32_t* __restrict_
     for (uint32_t j = 0; j < PER; j++) order[wd0 + atomicAdd(&hs[sk[j]], 1u)] = (uint32_t)(wd0 + PER * t + j);
     uint32_t* vo = vals + (size_t)w * cap + b0;
     for (uint32_t i = b0 + t; i < b1; i += 256) vo[atomicAdd(&h[kA[i] & (MSM_NLOW - 1)], 1u)] = iA[i];
+}
+// The same order over ALL buckets of the chunk (ZKATTEST_MSM_ORDER=global): size key t = 255 - min(size, 255) first, then (window, bin), then whatever order
+// the cursors hand out.  k_msm_sizescan: workgroup t turns size_cnt[t][*] into exclusive offsets in place and leaves the key's total in size_tot[t];
+// k_msm_order: workgroup (window, bin) places its MSM_NLOW buckets.
+__global__ void __launch_bounds__(1024) k_msm_sizescan(uint32_t* size_cnt, uint32_t nwb, uint32_t* size_tot) {
+    __shared__ uint32_t sh[17];
+    uint32_t* row = size_cnt + (size_t)blockIdx.x * nwb;
+    const uint32_t per = (nwb + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < nwb ? lo + per : nwb;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += row[i];
+    uint32_t tot;
+    uint32_t e = block_excl_scan(sum, sh, tot);
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t v = row[i];
+        row[i] = e, e += v;
+    }
+    if (threadIdx.x == 0) size_tot[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(256) k_msm_order(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, const uint32_t* __restrict__ size_off,
+                                                   const uint32_t* __restrict__ size_tot, uint32_t* order) {
+    constexpr uint32_t PER = MSM_NLOW / 256;
+    __shared__ uint32_t cur[256], sh[17];
+    const uint32_t bin = blockIdx.x, w = blockIdx.y, t = threadIdx.x, nwb = gridDim.y * MSM_NBIN;
+    uint32_t tot;
+    const uint32_t base = block_excl_scan(size_tot[t], sh, tot);
+    cur[t] = base + size_off[(size_t)t * nwb + w * MSM_NBIN + bin];
+    __syncthreads();
+    const size_t wd0 = (size_t)w * MSM_NBG + ((size_t)bin << MSM_LB);
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) {
+        const size_t wd = wd0 + PER * t + j;
+        const uint32_t c = end[wd] - start[wd];
+        order[atomicAdd(&cur[255u - (c < 255u ? c : 255u)], 1u)] = (uint32_t)wd;
+    }
+}
+// ZK_MSM_DEBUG: what the lanes of k_msm_bucket's waves wait for: stat[0] += sum over waves of 64 x (largest bucket of the wave), stat[1] += sum of all sizes (64-bit)
+__global__ void __launch_bounds__(256) k_msm_order_stat(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, const uint32_t* __restrict__ order, unsigned long long* stat) {
+    const uint32_t wd = order[gtid()];
+    uint32_t c = end[wd] - start[wd], m = c;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint32_t v = __shfl_xor(m, o, 64);
+        m = v > m ? v : m;
+    }
+    atomicAdd(&stat[1], (unsigned long long)c);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&stat[0], 64ull * m);
 }
 // ZK_MSM_CHECK=1 (tests): is the grouping exact?  Every position of a window's id list must hold a live term whose key owns that position, no term
 // twice (bitmap), as many positions as pairs were counted.  err[0]: violations, err[1 + w]: positions seen per window.
@@ -510,7 +557,7 @@ __global__ void k_msm_final(const uint32_t* __restrict__ Tw, TomList one, uint32
 // bytes of the grouping passes' scratch (MsmBuf::sort_tmp): bin_cnt and bin_off [MSM_SORT_G][windows * bins], bin_tot, bin_start, live_cnt
 size_t msm_workspace_bytes(uint32_t) {
     const size_t nwb = (size_t)MSM_NW_MAX * MSM_NBIN;
-    return 4 * (2 * nwb * MSM_SORT_G + nwb + (size_t)MSM_NW_MAX * (MSM_NBIN + 1) + MSM_SORT_G) + 1024;
+    return 4 * (2 * nwb * MSM_SORT_G + nwb + (size_t)MSM_NW_MAX * (MSM_NBIN + 1) + MSM_SORT_G + 256 * nwb + 256) + 1024;   // + size_cnt, size_tot
 }
 // returns through host_flags[groups] (after a stream synchronisation): 1 = the Tom total of that group of proofs is the identity
 template <int C>
@@ -542,8 +589,29 @@ static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& 
     hipLaunchKernelGGL(k_msm_binscan1, dim3(nwb), dim3(MSM_SORT_G), 0, s, bin_cnt, nwb, bin_off, bin_tot);
     hipLaunchKernelGGL(k_msm_binscan2, dim3(S::nw), dim3(MSM_NBIN), 0, s, bin_tot, bin_start, live_cnt, M.counters);
     hipLaunchKernelGGL(k_msm_scatter<C>, dim3(MSM_SORT_G), dim3(MSM_SORT_T), 0, s, V, D, per_wg, M.cap, bin_start, bin_off, M.keys_all, M.ids_bin);
-    hipLaunchKernelGGL(k_msm_binsort, dim3(MSM_NBIN, S::nw), dim3(256), 0, s, M.keys_all, M.ids_bin, M.cap, bin_start, M.vals_out, M.start, M.end, M.ord_id);
+    // order of the buckets for k_msm_bucket's lanes: by size over the whole chunk (default), or within each bin only (ZKATTEST_MSM_ORDER=local: two launches fewer)
+    static const bool order_global = [] { const char* e = getenv("ZKATTEST_MSM_ORDER"); return !(e && !strcmp(e, "local")); }();
+    uint32_t* size_cnt = (uint32_t*)(live_cnt + MSM_SORT_G);   // [256][nwb], then size_tot[256]
+    uint32_t* size_tot = size_cnt + (size_t)256 * nwb;
+    hipLaunchKernelGGL(k_msm_binsort, dim3(MSM_NBIN, S::nw), dim3(256), 0, s, M.keys_all, M.ids_bin, M.cap, bin_start, M.vals_out, M.start, M.end, M.ord_id,
+                       order_global ? size_cnt : nullptr);
+    if (order_global) {
+        hipLaunchKernelGGL(k_msm_sizescan, dim3(256), dim3(1024), 0, s, size_cnt, nwb, size_tot);
+        hipLaunchKernelGGL(k_msm_order, dim3(MSM_NBIN, S::nw), dim3(256), 0, s, M.start, M.end, size_cnt, size_tot, M.ord_id);
+    }
     if (ev3) hipEventRecord(ev3, s);
+    if (dbg) {
+        unsigned long long* stat = nullptr;
+        if (hipMalloc(&stat, 16) == hipSuccess) {
+            hipMemsetAsync(stat, 0, 16, s);
+            hipLaunchKernelGGL(k_msm_order_stat, dim3(S::nw * MSM_NBG / 256), dim3(256), 0, s, M.start, M.end, M.ord_id, stat);
+            unsigned long long h2[2] = {0, 0};
+            hipMemcpyAsync(h2, stat, 16, hipMemcpyDeviceToHost, s);
+            hipStreamSynchronize(s);
+            hipFree(stat);
+            fprintf(stderr, "msm: bucket order %s: lanes wait for %.3f x the additions they make (%llu pairs)\n", order_global ? "global" : "local", h2[1] ? (double)h2[0] / (double)h2[1] : 0.0, h2[1]);
+        }
+    }
     if (dbg) {
         hipStreamSynchronize(s);
         fprintf(stderr, "msm: pack + grouping of the keys %.2f ms\n", now() - t0), t0 = now();

@@ -298,6 +298,15 @@ __global__ void __launch_bounds__(256) k_v_unpack(uint32_t want_sec, uint32_t co
         dst[dof / 4 + u] = v;
     }
 }
+// offsets handed over as a DEVICE array (zk_verify_batch_device with packed proofs): non-decreasing and 4-byte aligned?  The expansion buffer is sized from
+// off[B] and every proof's expanded size from its own off[i + 1] - off[i], so overlapping ranges ([0, L, 0, L, ...]) would add up past that buffer.
+__global__ void __launch_bounds__(256) k_offsets_monotonic(const uint64_t* __restrict__ off, uint64_t B, uint32_t* bad) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i < B && (off[i] > off[i + 1] || (off[i] & 3))) atomicOr(bad, 1u);
+}
+void launch_offsets_monotonic(hipStream_t s, const uint64_t* d_off, uint64_t B, uint32_t* d_bad) {
+    if (B) hipLaunchKernelGGL(k_offsets_monotonic, dim3((uint32_t)((B + 255) / 256)), dim3(256), 0, s, d_off, B, d_bad);
+}
 void launch_v_unpack(hipStream_t s, uint32_t sec, uint32_t count, const uint8_t* packed, const uint64_t* poff, uint64_t first, uint64_t base, uint8_t* out, uint64_t* uoff) {
     if (!count) return;
     hipLaunchKernelGGL(k_v_unpack_scan, dim3(1), dim3(256), 0, s, sec, count, packed, poff, first, base, uoff);
