@@ -499,8 +499,8 @@ static size_t carve(zk_ctx* c, Workspace& W, Soa& gk_am, uint8_t* base, uint32_t
     W.rng.exc_cnt = (uint32_t*)k.take(4 * (size_t)C);
     W.rng_fill = (uint32_t*)k.take(32 * (size_t)(3 + 44 * sec + 5 * n + RNG_MAX_EXC) * C);
     {
-        const size_t blocks = (2 * 67 + (size_t)sec * (65 + 2 * 67) + 9 + 63) / 64, np = std::min<size_t>(C, EXPH_MAXP);
-        W.exph_msg = (uint8_t*)k.take(np * blocks * 64), W.exph_wk = (uint32_t*)k.take(np * blocks * 256);
+        const size_t blocks = (2 * 67 + (size_t)sec * (65 + 2 * 67) + 9 + 63) / 64, np = std::min<size_t>(C, EXPH_CAP);
+        W.exph_msg = (uint8_t*)k.take(np * blocks * 64), W.exph_wk = (uint32_t*)k.take(np * blocks * 256), W.exph_cap = (uint32_t)np;
     }
     W.ring = Soa{c->ring_mem, (uint32_t)N};
     return k.off + 256;

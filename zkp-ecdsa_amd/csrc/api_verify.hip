@@ -48,7 +48,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
         // sized for either shape of the pass: 16 windows x (8 groups x 2^16 digits) or 20 windows x (64 groups x 2^13 digits)
         const size_t NW = want_groups == 64 ? 20 : 16, NBG = (size_t)1 << 19, NWG = NW * want_groups;
         const size_t L1 = want_groups == 64 ? 128 : 1024, L2 = L1 / 32;
-        M.keys_all = (uint32_t*)k.take(cap * 4 * NW), M.ids_bin = (uint32_t*)k.take(cap * 4 * NW);
+        M.pairs = (uint2*)k.take(cap * 8 * NW);
         M.vals_out = (uint32_t*)k.take(cap * 4 * NW);
         M.start = (uint32_t*)k.take(4 * NW * NBG), M.end = (uint32_t*)k.take(4 * NW * NBG);
         M.ord_id = (uint32_t*)k.take(4 * NW * NBG);
@@ -196,7 +196,7 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
         HIPCHK(c, hipStreamWaitEvent(A.aux[1], A.aux_fork, 0));
         {   // aux 0: the Exp challenge (three kernels where the schedule buffer holds the chunk) and the sampled repetitions
             MaybeScope t(timed, c, "v_hash", A.aux[0]);
-            if (cnt <= EXPH_MAXP && W.exph_wk) launch_v_exp_challenge_small(A.aux[0], W, V, cnt, d_proofs, d_off, first);
+            if (cnt <= W.exph_cap && W.exph_wk) launch_v_exp_challenge_small(A.aux[0], W, V, cnt, d_proofs, d_off, first);
             else launch_v_challenges(A.aux[0], V, cnt, d_proofs, d_off, d_msg, first, 1);
             launch_v_sample(A.aux[0], V, cnt, d_vseeds, first);
         }
@@ -224,7 +224,10 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
     if (small) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[0], 0));   // challenges and sampled repetitions
     else {
         MaybeScope t(timed, c, "v_hash", s);
-        launch_v_challenges(s, V, cnt, d_proofs, d_off, d_msg, first, 3);
+        if (cnt <= W.exph_cap && W.exph_wk) {   // the Exp challenge (16 KB per proof) through the three-kernel path, whatever the chunk's size (k_hash.hip)
+            launch_v_exp_challenge_small(s, W, V, cnt, d_proofs, d_off, first);
+            launch_v_challenges(s, V, cnt, d_proofs, d_off, d_msg, first, 2);
+        } else launch_v_challenges(s, V, cnt, d_proofs, d_off, d_msg, first, 3);
         launch_v_sample(s, V, cnt, d_vseeds, first);
     }
     {

@@ -147,8 +147,9 @@ struct Workspace {
     uint32_t gk_group;           // proofs per fold pass
     uint32_t* rng_fill;          // [C][nblk][8] the chunk's RNG fills as a stream (seed mode), see k_rng_prepass
     uint8_t* r_zero;             // [C] r = 0 mod n (k_front)
-    uint8_t* exph_msg;           // [min(C, EXPH_MAXP)][blocks * 64] small chunks: the padded message of the Exp challenge (k_hash.hip: k_exph_*)
-    uint32_t* exph_wk;           // [min(C, EXPH_MAXP)][blocks][64] ... and its expanded schedule W_i + K_i
+    uint8_t* exph_msg;           // [exph_cap][blocks * 64] the padded message of the Exp challenge (k_hash.hip: k_exph_*)
+    uint32_t* exph_wk;           // [blocks][16][count] x uint4: its expanded schedule W_i + K_i, proof-fastest (the lanes of k_exph_rounds are consecutive proofs)
+    uint32_t exph_cap;           // proofs these two hold: min(C, EXPH_CAP)
     uint32_t* gk_bufA;           // ping-pong level buffers
     uint32_t* gk_bufB;
     // block-transform path of the ring fold (k_gk.hip), used when the ring has a table E (9 <= n <= GK_ETAB_MAXN)
@@ -173,7 +174,8 @@ struct Workspace {
 // 16-bit windows or 64 groups with 13-bit windows (zk_ctx_set_verify_groups; k_msm.hip).
 #define MSM_G_MAX 64
 #define MSM_NW_MAX 20
-#define EXPH_MAXP 256       // chunks of at most this many proofs hash the Exp challenge through the three-kernel path (64 KB of schedule per proof)
+#define EXPH_MAXP 256       // a verifier chunk of at most this many proofs hashes its Exp challenge on an auxiliary stream (api_verify.hip: small one-chunk calls)
+#define EXPH_CAP 32768      // chunks of at most this many proofs hash the Exp challenge through the three-kernel path (16 + 64 KB of message and schedule per proof)
 #define V_SLOT_SPLIT 4      // slot accumulators per checked repetition (k_v_straus: a slot's terms over up to 4 lanes)
 // per-proof sums of at most V_WIDE_MAXP proofs: ONE term per lane (a slot's 36 terms over 36 lanes, a membership group's 8 over 8), folded by
 // k_v_acc_tree, the five sums side by side on the lane's auxiliary streams -- the chain of a lane is what a small batch waits for
@@ -290,8 +292,7 @@ struct ChunkIn {
 struct MsmBuf {
     uint32_t cap;          // term ids
     uint32_t* aos;         // [cap][32] niels entries of the live terms
-    uint32_t* keys_all;    // [windows][cap] keys (group << C | digit) of the live terms' non-zero digits, partitioned by bin (k_msm_scatter)
-    uint32_t* ids_bin;     // [windows][cap] ... and their term ids
+    uint2* pairs;          // [windows][cap] (key = group << C | digit, term id) of the live terms' non-zero digits, partitioned by bin (k_msm_scatter)
     uint32_t* vals_out;    // [windows][cap] term ids grouped by key (k_msm_binsort)
     uint32_t *start, *end; // [windows][2^19] segment of every (group, digit) value
     uint32_t* ord_id;      // [windows * 2^19] buckets in the order k_msm_bucket's lanes take them: by size within each bin

@@ -94,10 +94,12 @@ __global__ void __launch_bounds__(64) k_exp_challenge(Workspace W, uint32_t coun
         for (int i = 0; i < 4; i++) W.chal[4 * p + i] = c[i];
     }
 }
-// Small chunks (count <= EXPH_MAXP): the same digest in three kernels.  One lane per proof hashing 16 KB is a chain of 251 compressions, and of a
-// compression's ~1 650 instructions a third is the message schedule and a fifth the byte-wise absorption of 33-byte coordinates -- neither depends on the
-// chaining value.  k_exph_msg (one lane per point) writes the padded message, k_exph_sched (one lane per block) expands every block to its 64 words
-// W_i + K_i, k_exph_rounds (one lane per proof) runs the 64 rounds per block and nothing else: 1.33 -> 0.7 ms for one proof.
+// The same digest in three kernels (chunks of up to EXPH_CAP proofs: every chunk of the bench).  One lane per proof hashing 16 KB is a chain of 251
+// compressions, and of a compression's ~1 650 instructions a third is the message schedule and a fifth the byte-wise absorption of 33-byte coordinates --
+// neither depends on the chaining value.  k_exph_msg (one lane per point) writes the padded message, k_exph_sched (one lane per (block, proof)) expands every
+// block to its 64 words W_i + K_i, k_exph_rounds (one lane per proof) runs the 64 rounds per block and nothing else: 1.33 -> 0.7 ms for one proof (round 4).
+// Round 5: the schedule is stored proof-fastest ([block][uint4 i][proof]), so the 64 lanes of a rounds wave read 1 KB runs, and chunks of any size take this
+// path -- a 22 016-proof chunk is 344 such waves, one per SIMD, i.e. it takes what ONE proof takes instead of 1.8 ms (k_exp_challenge stays for larger chunks).
 template <int NW>
 ZK_DEV void exph_put_coord(uint8_t* o, const uint32_t* w) {   // big-endian, (NW == 9 ? 33 : 32) bytes
     constexpr int NB = NW == 9 ? 33 : 32;
@@ -140,7 +142,8 @@ __global__ void __launch_bounds__(256) k_exph_msg(Workspace W, uint32_t count) {
 __global__ void __launch_bounds__(256) k_exph_sched(Workspace W, uint32_t count) {
     const uint32_t nblk = exph_blocks(W.sec), t = gtid();
     if (t >= count * nblk) return;
-    const uint4* src = (const uint4*)(W.exph_msg + (size_t)t * 64);
+    const uint32_t b = t / count, p = t % count;   // consecutive lanes: consecutive proofs, the same block
+    const uint4* src = (const uint4*)(W.exph_msg + ((size_t)p * nblk + b) * 64);
     uint32_t w[64];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -152,20 +155,20 @@ __global__ void __launch_bounds__(256) k_exph_sched(Workspace W, uint32_t count)
         const uint32_t w15 = w[i - 15], w2 = w[i - 2];
         w[i] = w[i - 16] + zk_xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3) + w[i - 7] + zk_xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
     }
-    uint4* dst = (uint4*)(W.exph_wk + (size_t)t * 64);
+    uint4* dst = (uint4*)W.exph_wk + (size_t)b * 16 * count + p;
 #pragma unroll
-    for (int i = 0; i < 16; i++) dst[i] = make_uint4(w[4 * i] + SHA_K[4 * i], w[4 * i + 1] + SHA_K[4 * i + 1], w[4 * i + 2] + SHA_K[4 * i + 2], w[4 * i + 3] + SHA_K[4 * i + 3]);
+    for (int i = 0; i < 16; i++) dst[(size_t)i * count] = make_uint4(w[4 * i] + SHA_K[4 * i], w[4 * i + 1] + SHA_K[4 * i + 1], w[4 * i + 2] + SHA_K[4 * i + 2], w[4 * i + 3] + SHA_K[4 * i + 3]);
 }
 __global__ void __launch_bounds__(64) k_exph_rounds(Workspace W, uint32_t count, uint32_t* chal) {
     const uint32_t p = gtid();
     if (p >= count) return;
     const uint32_t nblk = exph_blocks(W.sec);
-    const uint4* wk = (const uint4*)(W.exph_wk + (size_t)p * nblk * 64);
+    const uint4* wk = (const uint4*)W.exph_wk + p;   // word group i of block b: wk[(16 b + i) * count]
     uint32_t h[8];
     sha256_iv(h);
     uint4 nx[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) nx[i] = wk[i];
+    for (int i = 0; i < 16; i++) nx[i] = wk[(size_t)i * count];
 #pragma unroll 1
     for (uint32_t b = 0; b < nblk; b++) {
         uint32_t w[64];
@@ -173,7 +176,7 @@ __global__ void __launch_bounds__(64) k_exph_rounds(Workspace W, uint32_t count,
         for (int i = 0; i < 16; i++) w[4 * i] = nx[i].x, w[4 * i + 1] = nx[i].y, w[4 * i + 2] = nx[i].z, w[4 * i + 3] = nx[i].w;
         if (b + 1 < nblk) {   // the next block's words travel while this block's rounds run
 #pragma unroll
-            for (int i = 0; i < 16; i++) nx[i] = wk[16 * (b + 1) + i];
+            for (int i = 0; i < 16; i++) nx[i] = wk[((size_t)16 * (b + 1) + i) * count];
         }
         uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
 #pragma unroll
@@ -195,7 +198,7 @@ void launch_exph_hash(hipStream_t s, const Workspace& W, uint32_t count, uint32_
     hipLaunchKernelGGL(k_exph_rounds, dim3((count + 63) / 64), dim3(64), 0, s, W, count, chal);
 }
 void launch_exp_challenge(hipStream_t s, const Workspace& W, uint32_t count) {
-    if (count <= EXPH_MAXP && W.exph_wk) {
+    if (count <= W.exph_cap && W.exph_wk) {
         const uint32_t ne = 2 + 3 * W.sec + 1;
         hipLaunchKernelGGL(k_exph_msg, dim3((count * ne + 255) / 256), dim3(256), 0, s, W, count);
         launch_exph_hash(s, W, count, W.chal);

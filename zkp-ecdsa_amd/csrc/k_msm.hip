@@ -134,6 +134,44 @@ ZK_DEV bool msm_term_words(const VWork& V, const MsmDims& D, uint32_t id, uint32
     words_from_limbs<8>(w8, sc.l);
     return true;
 }
+// Pass A walks the terms GROUP BY GROUP: the key's top bits are the group of the term's proof, so a workgroup that only sees terms of one group scatters
+// into MSM_NBIN / groups bins per window instead of MSM_NBIN -- 1 024 runs instead of 8 192 at 8 groups, each growing eight times as fast, so that a run's
+// cache line is complete before the L2 has to give it up (with id-ordered ranges k_msm_scatter took 3.6 ms per 14 M-term chunk on partial-line writes).
+// The live terms of group q, proofs [p0, p0 + np): every k of the three term lists over the group's contiguous slot / membership-group / proof range
+// ("virtual id" v < np * MSM_TERMS_PER_PROOF); reads stay coalesced (consecutive v = consecutive g of one k).
+ZK_DEV bool msm_group_term(const VWork& V, const MsmDims& D, uint32_t p0, uint32_t np, uint32_t v, uint32_t& id, uint32_t w8[8]) {
+    const uint32_t na = np * VK, sec0 = V_SLOT_TERMS * na, nb = np * D.nq, sec1 = 8 * nb;
+    const VTerms* L;
+    uint32_t idx;
+    if (v < sec0) {
+        idx = (v / na) * D.g0 + p0 * VK + v % na, id = idx, L = &V.slot_terms;
+    } else if (v < sec0 + sec1) {
+        const uint32_t u = v - sec0;
+        idx = (u / nb) * D.g1 + p0 * D.nq + u % nb, id = D.n0 + idx, L = &V.gk_terms;
+    } else {
+        const uint32_t u = v - sec0 - sec1;
+        if (u >= 3 * np) return false;
+        idx = (u / np) * D.g2 + p0 + u % np, id = D.n0 + D.n1 + idx, L = &V.misc_terms;
+    }
+    const Fe<ModQ, 1> sc = soa_ld<ModQ, 1>(L->sc, idx);
+    if (fe_is_zero(sc)) return false;
+    words_from_limbs<8>(w8, sc.l);
+    return true;
+}
+// workgroup -> (group q, its proofs [p0, p0 + np), its virtual ids [lo, hi))
+template <int C>
+ZK_DEV void msm_wg_range(const MsmDims& D, uint32_t& q, uint32_t& p0, uint32_t& np, uint32_t& lo, uint32_t& hi) {
+    constexpr uint32_t per_group = MSM_SORT_G / MsmShape<C>::g;   // workgroups per group
+    q = blockIdx.x / per_group;
+    p0 = q * D.gsz;
+    const uint32_t count = D.l2;
+    np = p0 >= count ? 0 : (p0 + D.gsz <= count ? D.gsz : count - p0);
+    const uint32_t total = np * (V_SLOT_TERMS * VK + 8 * D.nq + 3);
+    const uint32_t per = ((total + per_group - 1) / per_group + MSM_SORT_T - 1) / MSM_SORT_T * MSM_SORT_T;
+    lo = (blockIdx.x % per_group) * per;
+    hi = lo + per < total ? lo + per : total;
+    if (lo > hi) lo = hi;
+}
 template <int C>
 ZK_DEV uint32_t msm_digit(const uint32_t w8[8], int w) {   // bits [C w, C (w + 1)) of the 256-bit scalar (w is a constant after unrolling)
     const int bit = C * w, k = bit >> 5, sh = bit & 31;
@@ -141,22 +179,23 @@ ZK_DEV uint32_t msm_digit(const uint32_t w8[8], int w) {   // bits [C w, C (w + 
     if (sh + C > 32 && k + 1 < 8) d |= w8[k + 1] << (32 - sh);
     return d & (MsmShape<C>::nb - 1);
 }
-// Pass A, counting.  bin_cnt[g][w * MSM_NBIN + bin]: pairs of workgroup g's id range in bin `bin` of window w.  live_cnt[g]: its live terms.
+// Pass A, counting.  bin_cnt[g][w * MSM_NBIN + bin]: pairs of workgroup g's terms in bin `bin` of window w.  live_cnt[g]: its live terms.
 template <int C>
-__global__ void __launch_bounds__(MSM_SORT_T) k_msm_hist(VWork V, MsmDims D, uint32_t per_wg, uint32_t* bin_cnt, uint32_t* live_cnt) {
+__global__ void __launch_bounds__(MSM_SORT_T) k_msm_hist(VWork V, MsmDims D, uint32_t* bin_cnt, uint32_t* live_cnt) {
     typedef MsmShape<C> S;
     __shared__ uint32_t h[S::nw * MSM_NBIN];
     __shared__ uint32_t nlive;
     for (uint32_t i = threadIdx.x; i < S::nw * MSM_NBIN; i += MSM_SORT_T) h[i] = 0;
     if (threadIdx.x == 0) nlive = 0;
     __syncthreads();
-    const uint32_t lo = blockIdx.x * per_wg, hi = lo + per_wg;
+    uint32_t q, p0, np, lo, hi;
+    msm_wg_range<C>(D, q, p0, np, lo, hi);
+    const uint32_t grp = q << S::c;
     uint32_t mine = 0;
-    for (uint32_t id = lo + threadIdx.x; id < hi; id += MSM_SORT_T) {
-        uint32_t w8[8], proof;
-        if (!msm_term_words(V, D, id, w8, proof)) continue;
+    for (uint32_t v = lo + threadIdx.x; v < hi; v += MSM_SORT_T) {
+        uint32_t w8[8], id;
+        if (!msm_group_term(V, D, p0, np, v, id, w8)) continue;
         mine++;
-        const uint32_t grp = (proof / D.gsz) << S::c;
 #pragma unroll
         for (int w = 0; w < (int)S::nw; w++) {
             const uint32_t d = msm_digit<C>(w8, w);
@@ -195,79 +234,81 @@ __global__ void __launch_bounds__(MSM_NBIN) k_msm_binscan2(const uint32_t* __res
     }
 }
 static_assert(MSM_SORT_G == MSM_NBIN, "k_msm_binscan2 sums live_cnt with one thread per workgroup of pass A");
+static_assert(MSM_SORT_G % MSM_G_MAX == 0, "pass A gives every group the same number of workgroups");
 // Pass A, placing: the walk of k_msm_hist again; pair (key, id) of window w goes to position bin_start[w][bin] + bin_off[w, bin][g] + (its rank among this
-// workgroup's pairs of that bin, in whatever order the LDS cursor hands out: a bucket's sum does not depend on the order of its terms).
+// workgroup's pairs of that bin, in whatever order the LDS cursor hands out: a bucket's sum does not depend on the order of its terms).  One 8-byte store per pair.
 template <int C>
-__global__ void __launch_bounds__(MSM_SORT_T) k_msm_scatter(VWork V, MsmDims D, uint32_t per_wg, uint32_t cap, const uint32_t* __restrict__ bin_start,
-                                                            const uint32_t* __restrict__ bin_off, uint32_t* keyA, uint32_t* idA) {
+__global__ void __launch_bounds__(MSM_SORT_T) k_msm_scatter(VWork V, MsmDims D, uint32_t cap, const uint32_t* __restrict__ bin_start,
+                                                            const uint32_t* __restrict__ bin_off, uint2* pairs) {
     typedef MsmShape<C> S;
     __shared__ uint32_t cur[S::nw * MSM_NBIN];
     for (uint32_t i = threadIdx.x; i < S::nw * MSM_NBIN; i += MSM_SORT_T)
         cur[i] = bin_start[(i / MSM_NBIN) * (MSM_NBIN + 1) + i % MSM_NBIN] + bin_off[(size_t)i * MSM_SORT_G + blockIdx.x];
     __syncthreads();
-    const uint32_t lo = blockIdx.x * per_wg, hi = lo + per_wg;
-    for (uint32_t id = lo + threadIdx.x; id < hi; id += MSM_SORT_T) {
-        uint32_t w8[8], proof;
-        if (!msm_term_words(V, D, id, w8, proof)) continue;
-        const uint32_t grp = (proof / D.gsz) << S::c;
+    uint32_t q, p0, np, lo, hi;
+    msm_wg_range<C>(D, q, p0, np, lo, hi);
+    const uint32_t grp = q << S::c;
+    for (uint32_t v = lo + threadIdx.x; v < hi; v += MSM_SORT_T) {
+        uint32_t w8[8], id;
+        if (!msm_group_term(V, D, p0, np, v, id, w8)) continue;
 #pragma unroll
         for (int w = 0; w < (int)S::nw; w++) {
             const uint32_t d = msm_digit<C>(w8, w);
             if (d) {
                 const uint32_t key = grp | d;
                 const uint32_t pos = atomicAdd(&cur[w * MSM_NBIN + (key >> MSM_LB)], 1u);
-                keyA[(size_t)w * cap + pos] = key, idA[(size_t)w * cap + pos] = id;
+                pairs[(size_t)w * cap + pos] = make_uint2(key, id);
             }
         }
     }
 }
 // Pass B: workgroup (bin, w) sorts its pairs by the low MSM_LB key bits.  vals[w][...]: term ids grouped by key; start / end [w * MSM_NBG + key]: the
-// group's positions (digit 0 and absent keys: empty); order[w * MSM_NBG + (bin << MSM_LB) + r]: this bin's MSM_NLOW buckets, largest first -- a lane of
-// k_msm_bucket sums one bucket, so a wave takes as long as its largest one: with Poisson-sized buckets (mean 27 in the low windows, 10 in the high
-// ones) 64 neighbouring digits wait for a bucket 1.5-1.8x the mean, 64 neighbours in this order do not, and the empty ones end up together.  (Rounds 2-4
-// ordered ALL buckets of the chunk with one more library sort; within a bin the sizes follow the same distribution, so the local order serves the waves as well.)
-__global__ void __launch_bounds__(256) k_msm_binsort(const uint32_t* __restrict__ keyA, const uint32_t* __restrict__ idA, uint32_t cap, const uint32_t* __restrict__ bin_start,
-                                                     uint32_t* vals, uint32_t* start, uint32_t* end, uint32_t* order, uint32_t* size_cnt /* [256][windows * bins] or nullptr */) {
-    constexpr uint32_t PER = MSM_NLOW / 256;
-    static_assert(PER == 4, "four keys per thread: uint4 stores below");
+// group's positions (digit 0 and absent keys: empty); order[w * MSM_NBG + (bin << MSM_LB) + r] (ZKATTEST_MSM_ORDER=local only): this bin's MSM_NLOW buckets,
+// largest first; size_cnt[t][w, bin]: how many of them have size key t = 255 - min(size, 255) (the chunk-wide order: k_msm_sizescan, k_msm_order).
+// One workgroup of 1 024 threads per CU (it asks for most of the CU's LDS): a bin's ids -- 27 k in the low windows -- are placed in LDS and leave as
+// coalesced runs; 256 resident workgroups per XCD scattering single dwords over 110 KB each kept no line in the L2 until it was full (2.7 ms per chunk).
+#define MSM_STAGE_MAX 36000u   // pairs of a bin that are staged in LDS (144 000 bytes); a larger bin scatters straight to memory
+__global__ void __launch_bounds__(MSM_NLOW) k_msm_binsort(const uint2* __restrict__ pairs, uint32_t cap, const uint32_t* __restrict__ bin_start,
+                                                          uint32_t* vals, uint32_t* start, uint32_t* end, uint32_t* order, uint32_t* size_cnt /* [256][windows * bins] or nullptr */) {
+    static_assert(MSM_NLOW == 1024, "one key per thread");
+    extern __shared__ uint32_t stage[];   // [MSM_STAGE_MAX]
     __shared__ uint32_t h[MSM_NLOW], hs[256], sh[17];
     const uint32_t bin = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
-    const uint32_t b0 = bin_start[w * (MSM_NBIN + 1) + bin], b1 = bin_start[w * (MSM_NBIN + 1) + bin + 1];
-    for (uint32_t k = t; k < MSM_NLOW; k += 256) h[k] = 0;
-    hs[t] = 0;
+    const uint32_t b0 = bin_start[w * (MSM_NBIN + 1) + bin], b1 = bin_start[w * (MSM_NBIN + 1) + bin + 1], n = b1 - b0;
+    h[t] = 0;
+    if (t < 256) hs[t] = 0;
     __syncthreads();
-    const uint32_t* kA = keyA + (size_t)w * cap;
-    const uint32_t* iA = idA + (size_t)w * cap;
-    for (uint32_t i = b0 + t; i < b1; i += 256) atomicAdd(&h[kA[i] & (MSM_NLOW - 1)], 1u);
+    const uint2* pr = pairs + (size_t)w * cap;
+    for (uint32_t i = b0 + t; i < b1; i += MSM_NLOW) atomicAdd(&h[pr[i].x & (MSM_NLOW - 1)], 1u);
     __syncthreads();
-    uint32_t c[PER], sk[PER], sum = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < PER; j++) {
-        c[j] = h[PER * t + j], sum += c[j];
-        sk[j] = 255u - (c[j] < 255u ? c[j] : 255u);
-        atomicAdd(&hs[sk[j]], 1u);
-    }
+    const uint32_t c = h[t], sk = 255u - (c < 255u ? c : 255u);
+    atomicAdd(&hs[sk], 1u);
     uint32_t tot;
-    uint32_t e = block_excl_scan(sum, sh, tot);
+    const uint32_t e = block_excl_scan(c, sh, tot);
     const size_t wd0 = (size_t)w * MSM_NBG + ((size_t)bin << MSM_LB);
-    uint32_t st4[PER], en4[PER];
-#pragma unroll
-    for (uint32_t j = 0; j < PER; j++) {
-        h[PER * t + j] = e;   // the key's cursor, relative to b0
-        st4[j] = b0 + e, e += c[j], en4[j] = b0 + e;
-    }
-    *(uint4*)(start + wd0 + PER * t) = make_uint4(st4[0], st4[1], st4[2], st4[3]);
-    *(uint4*)(end + wd0 + PER * t) = make_uint4(en4[0], en4[1], en4[2], en4[3]);
-    const uint32_t hv = hs[t];    // buckets of this bin whose size key is t (the barriers of the scan above lie between the atomics on hs and this read)
-    if (size_cnt) size_cnt[(size_t)t * (gridDim.y * MSM_NBIN) + blockIdx.y * MSM_NBIN + bin] = hv;
+    h[t] = e;   // the key's cursor, relative to b0
+    start[wd0 + t] = b0 + e, end[wd0 + t] = b0 + e + c;
+    const uint32_t hv = t < 256 ? hs[t] : 0;   // buckets of this bin whose size key is t (the barriers of the scan above lie between the atomics on hs and this read)
+    if (size_cnt && t < 256) size_cnt[(size_t)t * (gridDim.y * MSM_NBIN) + blockIdx.y * MSM_NBIN + bin] = hv;
     uint32_t tot2;
     const uint32_t he = block_excl_scan(hv, sh, tot2);
-    hs[t] = he;
+    if (t < 256) hs[t] = he;
     __syncthreads();
-#pragma unroll
-    for (uint32_t j = 0; j < PER; j++) order[wd0 + atomicAdd(&hs[sk[j]], 1u)] = (uint32_t)(wd0 + PER * t + j);
+    if (!size_cnt) order[wd0 + atomicAdd(&hs[sk], 1u)] = (uint32_t)(wd0 + t);
     uint32_t* vo = vals + (size_t)w * cap + b0;
-    for (uint32_t i = b0 + t; i < b1; i += 256) vo[atomicAdd(&h[kA[i] & (MSM_NLOW - 1)], 1u)] = iA[i];
+    if (n <= MSM_STAGE_MAX) {
+        for (uint32_t i = b0 + t; i < b1; i += MSM_NLOW) {
+            const uint2 p = pr[i];
+            stage[atomicAdd(&h[p.x & (MSM_NLOW - 1)], 1u)] = p.y;
+        }
+        __syncthreads();
+        for (uint32_t i = t; i < n; i += MSM_NLOW) vo[i] = stage[i];
+    } else {
+        for (uint32_t i = b0 + t; i < b1; i += MSM_NLOW) {
+            const uint2 p = pr[i];
+            vo[atomicAdd(&h[p.x & (MSM_NLOW - 1)], 1u)] = p.y;
+        }
+    }
 }
 // The same order over ALL buckets of the chunk (ZKATTEST_MSM_ORDER=global): size key t = 255 - min(size, 255) first, then (window, bin), then whatever order
 // the cursors hand out.  k_msm_sizescan: workgroup t turns size_cnt[t][*] into exclusive offsets in place and leaves the key's total in size_tot[t];
@@ -581,19 +622,19 @@ static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& 
     uint32_t* bin_tot = bin_off + (size_t)MSM_SORT_G * nwb;
     uint32_t* bin_start = bin_tot + nwb;
     uint32_t* live_cnt = bin_start + (size_t)S::nw * (MSM_NBIN + 1);
-    const uint32_t per_wg = ((total + MSM_SORT_G - 1) / MSM_SORT_G + MSM_SORT_T - 1) / MSM_SORT_T * MSM_SORT_T;   // ids per workgroup of pass A
     hipLaunchKernelGGL(k_msm_pack, dim3((total + 255) / 256), dim3(256), 0, s, V, D, M.aos);
     hipMemsetAsync(M.counters, 0, sizeof(uint32_t) * 64, s);
     if (ev2) hipEventRecord(ev2, s);   // the grouping of the keys alone (bench.py: verify.roofline.non_arithmetic)
-    hipLaunchKernelGGL(k_msm_hist<C>, dim3(MSM_SORT_G), dim3(MSM_SORT_T), 0, s, V, D, per_wg, bin_cnt, live_cnt);
+    hipLaunchKernelGGL(k_msm_hist<C>, dim3(MSM_SORT_G), dim3(MSM_SORT_T), 0, s, V, D, bin_cnt, live_cnt);
     hipLaunchKernelGGL(k_msm_binscan1, dim3(nwb), dim3(MSM_SORT_G), 0, s, bin_cnt, nwb, bin_off, bin_tot);
     hipLaunchKernelGGL(k_msm_binscan2, dim3(S::nw), dim3(MSM_NBIN), 0, s, bin_tot, bin_start, live_cnt, M.counters);
-    hipLaunchKernelGGL(k_msm_scatter<C>, dim3(MSM_SORT_G), dim3(MSM_SORT_T), 0, s, V, D, per_wg, M.cap, bin_start, bin_off, M.keys_all, M.ids_bin);
+    hipLaunchKernelGGL(k_msm_scatter<C>, dim3(MSM_SORT_G), dim3(MSM_SORT_T), 0, s, V, D, M.cap, bin_start, bin_off, M.pairs);
     // order of the buckets for k_msm_bucket's lanes: by size over the whole chunk (default), or within each bin only (ZKATTEST_MSM_ORDER=local: two launches fewer)
     static const bool order_global = [] { const char* e = getenv("ZKATTEST_MSM_ORDER"); return !(e && !strcmp(e, "local")); }();
     uint32_t* size_cnt = (uint32_t*)(live_cnt + MSM_SORT_G);   // [256][nwb], then size_tot[256]
     uint32_t* size_tot = size_cnt + (size_t)256 * nwb;
-    hipLaunchKernelGGL(k_msm_binsort, dim3(MSM_NBIN, S::nw), dim3(256), 0, s, M.keys_all, M.ids_bin, M.cap, bin_start, M.vals_out, M.start, M.end, M.ord_id,
+    (void)hipFuncSetAttribute((const void*)k_msm_binsort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MSM_STAGE_MAX * 4));   // (per device: a pool calls this on each)
+    hipLaunchKernelGGL(k_msm_binsort, dim3(MSM_NBIN, S::nw), dim3(MSM_NLOW), MSM_STAGE_MAX * 4, s, M.pairs, M.cap, bin_start, M.vals_out, M.start, M.end, M.ord_id,
                        order_global ? size_cnt : nullptr);
     if (order_global) {
         hipLaunchKernelGGL(k_msm_sizescan, dim3(256), dim3(1024), 0, s, size_cnt, nwb, size_tot);
