@@ -321,10 +321,21 @@ extern "C" int ha_ktab_mul(const uint8_t* xy64, const uint8_t* start64, uint64_t
         if (!p256_load(S, start64)) return -2;
         start = p256_from_affine(S);
     }
+    int range_mismatch = 0;
     for (uint64_t i = 0; i < count; i++) {
         uint32_t kw[8];
         be_to_words(k32 + 32 * i, 32, kw, 8);
         p256_store(p256_ktab_mul_acc(start, tab.data(), kw, negs[i] != 0), out64 + 64 * i);
+        // the same sum as four lanes take it (k_front_wide, k_exp_commit_kt_wide): a quarter of the windows each from the identity, then added up
+        P256Pt sum = start;
+        const uint32_t per = (KTAB_NWIN + 3) / 4;
+        for (uint32_t part = 0; part < 4; part++) {
+            be_to_words(k32 + 32 * i, 32, kw, 8);
+            sum = p256_add(sum, p256_ktab_mul_range(p256_identity(), tab.data(), kw, negs[i] != 0, part * per, per));
+        }
+        uint8_t alt[64];
+        p256_store(sum, alt);
+        if (memcmp(alt, out64 + 64 * i, 64)) range_mismatch++;
     }
-    return 0;
+    return range_mismatch;
 }

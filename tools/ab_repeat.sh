@@ -3,7 +3,7 @@ reps=$1; shift
 mkdir -p gpurun_out/ab
 for r in $(seq 1 $reps); do
   for v in "$@"; do
-    lib=$PWD/zkp-ecdsa_amd/lib_exp/lib_$v.so
+    lib=$PWD/zkp-ecdsa_amd/build_ab/lib_$v.so
     [ "$v" = main ] && lib=$PWD/zkp-ecdsa_amd/lib/libzkattest_hip.so
     ZKATTEST_LIB=$lib timeout 300 python bench.py --no-cpu-baseline --steps 4 --warmup 1 ${AB_ARGS:---host-io 0} 2> gpurun_out/ab/$v.err | python -c "
 import json,sys

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Small-batch latency of zk_prove_batch / zk_verify_batch for one library build (ZKATTEST_LIB selects it): B = 1, 8, 64 proofs per call on a ring
 of 1024 keys, 16-bit combs, median of 9 calls; per-family GPU milliseconds of the last B = 1 call.
-  ZKATTEST_LIB=zkp-ecdsa_amd/lib_exp/lib_x.so python tools/exp_latency.py"""
+  ZKATTEST_LIB=zkp-ecdsa_amd/build_ab/lib_x.so python tools/exp_latency.py"""
 import json
 import os
 import sys

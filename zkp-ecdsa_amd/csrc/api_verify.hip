@@ -196,7 +196,7 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
         HIPCHK(c, hipStreamWaitEvent(A.aux[1], A.aux_fork, 0));
         {   // aux 0: the Exp challenge (three kernels where the schedule buffer holds the chunk) and the sampled repetitions
             MaybeScope t(timed, c, "v_hash", A.aux[0]);
-            if (cnt <= W.exph_cap && W.exph_wk) launch_v_exp_challenge_small(A.aux[0], W, V, cnt, d_proofs, d_off, first);
+            if (cnt <= EXPH_MAXP && cnt <= W.exph_cap && W.exph_wk) launch_v_exp_challenge_small(A.aux[0], W, V, cnt, d_proofs, d_off, first);
             else launch_v_challenges(A.aux[0], V, cnt, d_proofs, d_off, d_msg, first, 1);
             launch_v_sample(A.aux[0], V, cnt, d_vseeds, first);
         }
@@ -224,10 +224,9 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
     if (small) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[0], 0));   // challenges and sampled repetitions
     else {
         MaybeScope t(timed, c, "v_hash", s);
-        if (cnt <= W.exph_cap && W.exph_wk) {   // the Exp challenge (16 KB per proof) through the three-kernel path, whatever the chunk's size (k_hash.hip)
-            launch_v_exp_challenge_small(s, W, V, cnt, d_proofs, d_off, first);
-            launch_v_challenges(s, V, cnt, d_proofs, d_off, d_msg, first, 2);
-        } else launch_v_challenges(s, V, cnt, d_proofs, d_off, d_msg, first, 3);
+        // (a chunk of this size keeps one wave per SIMD busy with one lane per proof already: the three-kernel path of the small chunks measured 1.9 ms per
+        // 32 768 proofs against this kernel's 1.86, profiles/r05_ab_variants.txt)
+        launch_v_challenges(s, V, cnt, d_proofs, d_off, d_msg, first, 3);
         launch_v_sample(s, V, cnt, d_vseeds, first);
     }
     {

@@ -174,6 +174,12 @@ struct Workspace {
 // 16-bit windows or 64 groups with 13-bit windows (zk_ctx_set_verify_groups; k_msm.hip).
 #define MSM_G_MAX 64
 #define MSM_NW_MAX 20
+// Table sums of a SMALL chunk run "wide": several lanes per sum, a range of windows each, partial sums added through the wave's cross-lane moves (rtab.h).  Up to
+// this many sums per launch -- four lanes each fill one residency of the GPU at two to three register-heavy waves per SIMD; beyond it the one-lane kernels,
+// whose lanes all work, are faster (zk_ctx_set... none: a compile-time constant, measured in profiles/r05_latency.txt).
+#ifndef ZK_WIDE_MAX_UNITS
+#define ZK_WIDE_MAX_UNITS 32768u
+#endif
 #define EXPH_MAXP 256       // a verifier chunk of at most this many proofs hashes its Exp challenge on an auxiliary stream (api_verify.hip: small one-chunk calls)
 #define EXPH_CAP 32768      // chunks of at most this many proofs hash the Exp challenge through the three-kernel path (16 + 64 KB of message and schedule per proof)
 #define V_SLOT_SPLIT 4      // slot accumulators per checked repetition (k_v_straus: a slot's terms over up to 4 lanes)

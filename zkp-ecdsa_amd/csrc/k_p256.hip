@@ -9,19 +9,6 @@
 // All additions are the complete RCB formulas the reference uses.
 #include "rtab.h"   // engine.h (and with it ktab.h), the projective table entries of rtab.h
 
-ZK_DEV P256Aff ld_pfix(const uint32_t* e) {
-    const uint4* q = (const uint4*)e;
-    uint32_t w[20];
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-        uint4 v = q[i];
-        w[4 * i] = v.x, w[4 * i + 1] = v.y, w[4 * i + 2] = v.z, w[4 * i + 3] = v.w;
-    }
-    P256Aff a;
-#pragma unroll
-    for (int l = 0; l < 9; l++) a.x.l[l] = w[l], a.y.l[l] = w[9 + l];
-    return a;
-}
 // k * B for a fixed base with a PFIX_WIN_BITS-bit comb table; k given as 8 little-endian words (clobbered)
 ZK_DEV P256Pt p256_fixed_mul(const uint32_t* __restrict__ tab, uint32_t kw[8]) {
     P256Pt acc;
@@ -139,9 +126,45 @@ __global__ void __launch_bounds__(64, 2) k_front(DevParams P, Workspace W, Chunk
     }
     W.st[p] = status;
 }
-__global__ void __launch_bounds__(64, 2) k_front_table(DevParams P, Workspace W, uint32_t count) {
+// Small chunks: proofs on the key-table path get their three table sums -- u1 * G and u2 * pk for R, z1 * G for Q -- from EIGHT lanes each (k_front_wide:
+// four per sum, a quarter of the windows per lane, two cross-lane additions) instead of 13 + 33 + 13 additions in a row in one lane; k_front_table and
+// k_front_walk then only see the proofs that are off that path (skip_kt).
+__global__ void __launch_bounds__(256) k_front_wide(DevParams P, Workspace W, uint32_t count) {
+    const uint32_t tt = gtid();
+    const bool live = tt < count * 8;
+    const uint32_t p = live ? tt >> 3 : count - 1, part = tt & 3, which = live ? (tt >> 2) & 1 : 0;   // dead lanes of the last wave mirror a live sum: the cross-lane moves need every lane of a group
+    const uint32_t use = W.kt_use[p];
+    if (!use) return;   // (all eight lanes of the proof leave together)
+    const uint32_t* sc = front_area(W, p) + 10 * RTAB_ENTRY_WORDS;
+    Fe<ModN, 1> k;
+#pragma unroll
+    for (int l = 0; l < NLIMB; l++) k.l[l] = sc[(which ? NLIMB : 0) + l];   // u1 (R's sum) or z1 (Q's)
+    uint32_t kw[8];
+    words_from_limbs<8>(kw, k.l);
+    constexpr uint32_t gper = (PFIX_NWIN + 3) / 4, kper = (KTAB_NWIN + 3) / 4;
+    P256Pt acc = p256_fixed_mul_range(p256_identity(), P.pfix_G, kw, part * gper, gper);
+    if (!which) {
+        words_from_limbs<8>(kw, fe_from_mont(soa_ld<ModN, 1>(W.u2m, p).as<2>()).l);
+        acc = p256_ktab_mul_range(acc, W.ktab + (size_t)W.kt_key[p] * KTAB_KEY_WORDS, kw, use == 2, part * kper, kper);
+    }
+    acc = p256_quad_sum(acc);
+    if (!live || part) return;
+    if (which) {
+        st_proj(W.Q, p, acc);
+        return;
+    }
+    // R affine (output + base of the per-proof table), as in k_front_walk
+    Fq2 rz = fe_reduce(acc.z);
+    if (fe_is_zero(rz) && (W.st[p] == ZK_OK || W.st[p] == ZK_E_ARG)) W.st[p] = ZK_E_T_INF;
+    Fq2 zi = fe_inv<ModQ>(rz);
+    Fq2 rx = acc.x * zi, ry = acc.y * zi;
+    soa_st(W.Rxm, p, rx), soa_st(W.Rym, p, ry);
+    soa_st(W.Rx, p, fe_from_mont(rx)), soa_st(W.Ry, p, fe_from_mont(ry));
+}
+__global__ void __launch_bounds__(64, 2) k_front_table(DevParams P, Workspace W, uint32_t count, uint32_t skip_kt) {
     uint32_t p = gtid();
     if (p >= count) return;
+    if (skip_kt && W.kt_use[p]) return;
     uint32_t* area = front_area(W, p);
     if (!W.kt_use[p]) {
         P256Aff pk;
@@ -166,9 +189,10 @@ __global__ void __launch_bounds__(64, 2) k_front_table(DevParams P, Workspace W,
     words_from_limbs<8>(kw, z1.l);
     st_proj(W.Q, p, p256_fixed_mul(P.pfix_G, kw));
 }
-__global__ void __launch_bounds__(64, 2) k_front_walk(Workspace W, uint32_t count) {
+__global__ void __launch_bounds__(64, 2) k_front_walk(Workspace W, uint32_t count, uint32_t skip_kt) {
     uint32_t p = gtid();
     if (p >= count) return;
+    if (skip_kt && W.kt_use[p]) return;
     const uint32_t* area = front_area(W, p);
     const uint8_t* dig = (const uint8_t*)(area + 9 * RTAB_ENTRY_WORDS);
     P256Pt R;
@@ -201,8 +225,10 @@ __global__ void __launch_bounds__(64, 2) k_front_walk(Workspace W, uint32_t coun
 }
 void launch_front(hipStream_t s, const DevParams& P, const Workspace& W, const ChunkIn& in) {
     hipLaunchKernelGGL(k_front, dim3((in.count + 63) / 64), dim3(64), 0, s, P, W, in);
-    hipLaunchKernelGGL(k_front_table, dim3((in.count + 63) / 64), dim3(64), 0, s, P, W, in.count);
-    hipLaunchKernelGGL(k_front_walk, dim3((in.count + 63) / 64), dim3(64), 0, s, W, in.count);
+    const uint32_t wide = W.ktab && in.count <= ZK_WIDE_MAX_UNITS / 8 ? 1u : 0u;   // a small chunk: eight lanes per proof on the key-table path
+    if (wide) hipLaunchKernelGGL(k_front_wide, dim3((in.count * 8 + 255) / 256), dim3(256), 0, s, P, W, in.count);
+    hipLaunchKernelGGL(k_front_table, dim3((in.count + 63) / 64), dim3(64), 0, s, P, W, in.count, wide);
+    hipLaunchKernelGGL(k_front_walk, dim3((in.count + 63) / 64), dim3(64), 0, s, W, in.count, wide);
 }
 
 // ---------------------------------------------------------------- per-proof table of R (layout and use: rtab.h)
@@ -295,10 +321,36 @@ __global__ void __launch_bounds__(256) k_exp_commit_kt(DevParams P, Workspace W,
     st_proj(W.Tproj, t, T);
     st_proj(W.Aproj, t, p256_fixed_mul_acc(T, P.pfix_H, bw));   // A = T + r * h, the comb's additions straight onto T
 }
+// The same for a small chunk, FOUR lanes per (proof, repetition): each takes a quarter of the windows of G's comb, of the key's table and of h's comb
+// (4 + 9 + 4 gathered additions in a row instead of 13 + 33 + 13), the partial sums meet through the wave's cross-lane moves.  Same group elements,
+// hence the same affine coordinates and the same bytes.
+__global__ void __launch_bounds__(256) k_exp_commit_kt_wide(DevParams P, Workspace W, uint32_t count) {
+    const uint32_t tt = gtid(), per = W.sec + 1;
+    const bool live = tt < count * per * 4;
+    const uint32_t t = live ? tt >> 2 : count * per - 1, part = tt & 3;   // dead lanes of the last wave mirror the last sum
+    const uint32_t p = t / per, j = t % per;
+    const uint32_t use = W.kt_use[p];
+    if (!use) return;   // (the four lanes of a sum leave together)
+    uint32_t aw[8], bw[8], gw[8], kw[8];
+    exp_scalars(W, p, j, aw, bw, true, true);
+    Fe<ModN, 1> al;
+    limbs_from_words<8>(al.l, aw);
+    words_from_limbs<8>(gw, fe_canon(al.as<2>() * soa_ld<ModN, 1>(W.u1m, p).as<2>()).l);   // plain x Montgomery = plain
+    words_from_limbs<8>(kw, fe_canon(al.as<2>() * soa_ld<ModN, 1>(W.u2m, p).as<2>()).l);
+    constexpr uint32_t gper = (PFIX_NWIN + 3) / 4, kper = (KTAB_NWIN + 3) / 4;
+    P256Pt T = p256_fixed_mul_range(p256_identity(), P.pfix_G, gw, part * gper, gper);
+    T = p256_ktab_mul_range(T, W.ktab + (size_t)W.kt_key[p] * KTAB_KEY_WORDS, kw, use == 2, part * kper, kper);
+    P256Pt U = p256_fixed_mul_range(p256_identity(), P.pfix_H, bw, part * gper, gper);
+    T = p256_quad_sum(T), U = p256_quad_sum(U);
+    if (!live || part) return;
+    st_proj(W.Tproj, t, T);
+    st_proj(W.Aproj, t, p256_add(T, U));
+}
 void launch_exp_commit(hipStream_t s, const DevParams& P, const Workspace& W, uint32_t count) {
     uint32_t n = count * (W.sec + 1);
     if (W.ktab) {
-        hipLaunchKernelGGL(k_exp_commit_kt, dim3((n + 255) / 256), dim3(256), heavy_lds_for(k_exp_commit_kt), s, P, W, count);
+        if (n <= ZK_WIDE_MAX_UNITS) hipLaunchKernelGGL(k_exp_commit_kt_wide, dim3((n * 4 + 255) / 256), dim3(256), 0, s, P, W, count);
+        else hipLaunchKernelGGL(k_exp_commit_kt, dim3((n + 255) / 256), dim3(256), heavy_lds_for(k_exp_commit_kt), s, P, W, count);
     }
     hipLaunchKernelGGL(k_exp_commit, dim3((n + 255) / 256), dim3(256), heavy_lds_for(k_exp_commit), s, P, W, count);
 }

@@ -159,8 +159,69 @@ __global__ void __launch_bounds__(256, 2) k_tom_commit_pairs(const uint32_t* __r
     A = tom_comb_acc<false, true, SGN>(G, tab_h, w8, bits, nwin);
     soa_st(L.proj.x, slot1, A.x), soa_st(L.proj.y, slot1, A.y), soa_st(L.proj.z, slot1, A.z);
 }
+// ---- the same commitments for a SMALL launch, four lanes each (engine.h: ZK_WIDE_MAX_UNITS).  The comb tables hold every window multiple, so lane `part`
+// takes windows [part * per, part * per + per) of v's g-part and r's h-part -- 3 + 3 table additions at 24 bits instead of 11 + 11 in a row -- and the four
+// partial points are added through the wave's cross-lane moves (two complete extended additions).  Same group element, hence the same affine
+// coordinates once the list is normalised.  Unsigned combs only (a signed comb's zero digit is not the identity entry; those widths keep one lane).
+ZK_DEV TomPt tom_shfl_xor(const TomPt& a, int m) {
+    TomPt r;
+#pragma unroll
+    for (int l = 0; l < NLIMB; l++) {
+        r.x.l[l] = (uint32_t)__shfl_xor((int)a.x.l[l], m), r.y.l[l] = (uint32_t)__shfl_xor((int)a.y.l[l], m);
+        r.t.l[l] = (uint32_t)__shfl_xor((int)a.t.l[l], m), r.z.l[l] = (uint32_t)__shfl_xor((int)a.z.l[l], m);
+    }
+    return r;
+}
+// acc + sum over windows [w0, w0 + per) of tab[w][digit_w(k)]; windows past the last one (and what the scalar has no bits for) add entry 0 of window 0, the identity
+ZK_DEV TomPt tom_comb_range(TomPt acc, const uint32_t* __restrict__ tab, const uint32_t kw[8], uint32_t bits, uint32_t nwin, uint32_t w0, uint32_t per) {
+    CombDigits dg;
+    dg.init(bits);
+#pragma unroll
+    for (int i = 0; i < 8; i++) dg.w[i] = kw[i];
+    const uint32_t ent = tom_win_entries(bits);
+    uint32_t d;
+    bool sg;
+#pragma unroll 1
+    for (uint32_t w = 0; w < w0; w++) dg.next(d, sg);
+#pragma unroll 1
+    for (uint32_t j = 0; j < per; j++) {
+        const uint32_t w = w0 + j;
+        dg.next(d, sg);
+        const bool in = w < nwin;
+        TomNiels e = ld_niels(tab + (size_t)TOM_ENTRY_WORDS * (in ? (size_t)w * ent + d : 0));
+        niels_pin(e);
+        acc = tom_add_niels(acc, e);
+    }
+    return acc;
+}
+__global__ void __launch_bounds__(256) k_tom_commit_wide(const uint32_t* __restrict__ tab_g, const uint32_t* __restrict__ tab_h, TomList L, uint32_t count, uint32_t per_group,
+                                                         uint32_t slots_per_group, uint32_t kstride, uint32_t bits, uint32_t nwin) {
+    const uint32_t tt = gtid();
+    const bool live = tt < count * 4;
+    const uint32_t c = live ? tt >> 2 : count - 1, part = tt & 3;   // dead lanes of the last wave mirror the last commitment: the cross-lane moves need every lane of a group
+    const uint32_t kk = c / per_group;
+    const uint32_t slot = kstride ? kk * kstride + (c % per_group) : kk * slots_per_group + (c % per_group);
+    uint32_t vw[8], rw[8];
+    words_from_limbs<8>(vw, soa_ld<ModQ, 1>(L.v, slot).l);
+    words_from_limbs<8>(rw, soa_ld<ModQ, 1>(L.r, slot).l);
+    const uint32_t per = (nwin + 3) / 4;
+    TomPt acc = tom_comb_range(tom_identity(), tab_g, vw, bits, nwin, part * per, per);
+    acc = tom_comb_range(acc, tab_h, rw, bits, nwin, part * per, per);
+    acc = tom_add(acc, tom_shfl_xor(acc, 1));
+    acc = tom_add(acc, tom_shfl_xor(acc, 2));
+    if (!live || part) return;
+    soa_st(L.proj.x, slot, acc.x);
+    soa_st(L.proj.y, slot, acc.y);
+    soa_st(L.proj.z, slot, acc.z);
+}
+static bool tom_wide(const DevParams& P, uint32_t count) { return !tom_signed(P.tom_bits) && count <= ZK_WIDE_MAX_UNITS; }
 void launch_tom_commit_listb(hipStream_t s, const DevParams& P, const TomList& L, uint32_t items, uint32_t kstride) {
     if (!items) return;
+    if (tom_wide(P, items * LB_COMMITS)) {   // all 34 slots of every item as independent commitments (the pairs' shared v * g is recomputed: the GPU is idle anyway)
+        hipLaunchKernelGGL(k_tom_commit_wide, dim3((items * LB_COMMITS * 4 + 255) / 256), dim3(256), 0, s, P.tom_tab_g, P.tom_tab_h, L, items * LB_COMMITS, items, 0u, kstride,
+                           P.tom_bits, tom_nwin(P.tom_bits));
+        return;
+    }
     uint32_t nwin = tom_nwin(P.tom_bits);
     uint32_t n1 = items * LB_UNITS_SINGLE, n2 = items * LB_UNITS_PAIR;
     if (tom_signed(P.tom_bits)) {
@@ -173,6 +234,11 @@ void launch_tom_commit_listb(hipStream_t s, const DevParams& P, const TomList& L
 }
 void launch_tom_commit(hipStream_t s, const DevParams& P, const TomList& L, uint32_t count, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride) {
     if (!count) return;
+    if (tom_wide(P, count)) {
+        hipLaunchKernelGGL(k_tom_commit_wide, dim3((count * 4 + 255) / 256), dim3(256), 0, s, P.tom_tab_g, P.tom_tab_h, L, count, per_group, slots_per_group, kstride, P.tom_bits,
+                           tom_nwin(P.tom_bits));
+        return;
+    }
     dim3 g((count + 255) / 256), b(256);
     if (tom_signed(P.tom_bits)) hipLaunchKernelGGL((k_tom_commit<2, true>), g, b, heavy_lds_for(k_tom_commit<2, true>), s, P.tom_tab_g, P.tom_tab_h, L, count, per_group, slots_per_group, kstride, P.tom_bits, tom_nwin(P.tom_bits), 0u);
     else hipLaunchKernelGGL((k_tom_commit<2, false>), g, b, heavy_lds_for(k_tom_commit<2, false>), s, P.tom_tab_g, P.tom_tab_h, L, count, per_group, slots_per_group, kstride, P.tom_bits, tom_nwin(P.tom_bits), 0u);

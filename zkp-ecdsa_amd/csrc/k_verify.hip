@@ -478,8 +478,16 @@ __global__ void __launch_bounds__(256) k_v_exph_msg(Workspace W, VWork V, uint32
             words_from_limbs<8>(w, fe_from_words256_reduce<ModQ>(w).l);
             for (int i = 0; i < 32; i++) m[o + 1 + 32 * c2 + i] = (uint8_t)(w[(31 - i) >> 2] >> (8 * ((31 - i) & 3)));
         }
-    } else {
-        for (int i = 0; i < 33; i++) m[o + 1 + i] = src[3 + i], m[o + 34 + i] = src[39 + i];
+    } else {   // the 72-byte string as 18 dwords (wide loads), its bytes 3..35 and 39..71 out of registers (byte LOADS at a 72-byte lane stride cost 6 ms per 32 768 proofs)
+        uint32_t sw[18];
+        const uint32_t* q = (const uint32_t*)src;
+#pragma unroll
+        for (int i = 0; i < 18; i++) sw[i] = q[i];
+#pragma unroll
+        for (int i = 0; i < 33; i++) {
+            m[o + 1 + i] = (uint8_t)(sw[(3 + i) >> 2] >> (8 * ((3 + i) & 3)));
+            m[o + 34 + i] = (uint8_t)(sw[(39 + i) >> 2] >> (8 * ((39 + i) & 3)));
+        }
     }
 }
 // ------------------------------------------------------------------ verifier randomness
@@ -609,14 +617,6 @@ __global__ void __launch_bounds__(64) k_v_sample(VWork V, uint32_t count, const 
 // ------------------------------------------------------------------ Exp: T = alpha*R or T1 = z*R + Q per checked rep (exp.ts:267,299,311)
 // split = 1: one lane per checked repetition walks all 65 windows of R's table.  split = 4 (small chunks): four neighbouring lanes take 17 windows each and
 // add their partial sums through the wave's cross-lane moves (the table holds every 2^(4w) R: no doublings) -- 17 + 2 additions in a row instead of 65.
-ZK_DEV P256Pt p256_shfl_xor(const P256Pt& a, int m) {
-    P256Pt r;
-#pragma unroll
-    for (int l = 0; l < NLIMB; l++) {
-        r.x.l[l] = (uint32_t)__shfl_xor((int)a.x.l[l], m), r.y.l[l] = (uint32_t)__shfl_xor((int)a.y.l[l], m), r.z.l[l] = (uint32_t)__shfl_xor((int)a.z.l[l], m);
-    }
-    return r;
-}
 __global__ void __launch_bounds__(256) k_v_exp_points(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first, uint32_t split) {
     const uint32_t tt = gtid();
     const bool live = tt < count * VK * split;
@@ -1513,6 +1513,39 @@ __global__ void __launch_bounds__(64, 2) k_v_p256_total(DevParams P, Workspace W
     V.p256_ok[p] = ok;
 }
 
+// The same for a handful of proofs, EIGHT lanes each: four take a quarter of the 65 windows of R's table, four a quarter of h_NIST's comb, each adds its share
+// of the `parts` partial sums of k_v_p256_straus, and the eight points meet through the wave's cross-lane moves: 17 + 3 + 3 additions in a row instead of
+// 65 + 13 + 21.
+__global__ void __launch_bounds__(256) k_v_p256_total_wide(DevParams P, Workspace W, VWork V, uint32_t count, uint32_t parts) {
+    const uint32_t tt = gtid();
+    const bool live = tt < count * 8;
+    const uint32_t p = live ? tt >> 3 : count - 1, sub = tt & 7;   // dead lanes of the last wave mirror the last proof: the cross-lane moves need every lane of a group
+    const bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8);
+    P256Pt acc = p256_identity();
+    if (good) {
+        uint32_t kw[8];
+        if (sub < 4) {
+            words_from_limbs<8>(kw, soa_ld<ModN, 1>(V.pSR, p).l);
+            const uint32_t per = (rtab_nwin(RTAB_VERIFY_BITS) + 3) / 4;
+            acc = p256_rtab_mul_range(W.rtab + (size_t)p * rtab_words(RTAB_VERIFY_BITS), kw, RTAB_VERIFY_BITS, sub * per, per);
+        } else {
+            words_from_limbs<8>(kw, soa_ld<ModN, 1>(V.pSH, p).l);
+            constexpr uint32_t gper = (PFIX_NWIN + 3) / 4;
+            acc = p256_fixed_mul_range(acc, P.pfix_H, kw, (sub - 4) * gper, gper);
+        }
+#pragma unroll 1
+        for (uint32_t q = sub; q < parts; q += 8) {
+            P256Pt a;
+            a.x = soa_ld<ModQ, 8>(V.pacc.x, p * parts + q), a.y = soa_ld<ModQ, 8>(V.pacc.y, p * parts + q), a.z = soa_ld<ModQ, 8>(V.pacc.z, p * parts + q);
+            acc = p256_add(acc, a);
+        }
+    }
+    acc = p256_quad_sum(acc);
+    acc = p256_add(acc, p256_shfl_xor(acc, 4));
+    if (!live || sub) return;
+    V.p256_ok[p] = good && fe_is_zero(fe_reduce(acc.x)) && fe_is_zero(fe_reduce(acc.z)) && !fe_is_zero(fe_reduce(acc.y)) ? 1u : 0u;  // weier.ts:117-119
+}
+
 // ------------------------------------------------------------------ final sums and verdict
 ZK_DEV TomPt ld_tom4(const Soa4& a, uint32_t e) {
     TomPt r;
@@ -1637,7 +1670,8 @@ void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count, uint32_
     L1(k_v_p256_straus, count * (VK / per + 1), 256, V, count, per);
 }
 void launch_v_p256_total(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t per) {
-    L1(k_v_p256_total, count, 64, P, W, V, count, VK / per + 1);
+    if (count * 8 <= ZK_WIDE_MAX_UNITS) L1(k_v_p256_total_wide, count * 8, 256, P, W, V, count, VK / per + 1);   // a handful of proofs: eight lanes each
+    else L1(k_v_p256_total, count, 64, P, W, V, count, VK / per + 1);
 }
 void launch_v_final(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first, const VGroupFlags& gf, uint32_t gsz) {
     L1(k_v_final, count, 64, W, V, count, ok, status, first, gf, gsz);

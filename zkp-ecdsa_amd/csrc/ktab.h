@@ -68,3 +68,23 @@ ZK_DEV P256Pt p256_ktab_mul_acc(P256Pt acc, const uint32_t* __restrict__ kt, uin
     }
     return acc;
 }
+// The same sum restricted to windows [w0, w0 + per): the table holds every window multiple, so several lanes can take a range each (rtab.h:
+// p256_rtab_mul_range has the reasoning behind the two loops: the carries below w0 are integer work with a per-lane trip count, the additions have one
+// trip count for the whole wave).  Windows past the last one contribute nothing.
+ZK_DEV P256Pt p256_ktab_mul_range(P256Pt acc, const uint32_t* __restrict__ kt, uint32_t kw[8], bool neg, uint32_t w0, uint32_t per) {
+    KeyDigits kd;
+    kd.init();
+#pragma unroll
+    for (int i = 0; i < 8; i++) kd.w[i] = kw[i];
+    uint32_t d;
+    bool dn;
+#pragma unroll 1
+    for (uint32_t w = 0; w < w0; w++) kd.next(d, dn);
+#pragma unroll 1
+    for (uint32_t j = 0; j < per; j++) {
+        const uint32_t w = w0 + j;
+        kd.next(d, dn);
+        if (w < KTAB_NWIN && d != 0) acc = p256_add_mixed(acc, ld_ktab(kt + ((size_t)w * KTAB_ENT + d - 1) * KTAB_ENTRY_WORDS, neg != dn));
+    }
+    return acc;
+}

@@ -89,3 +89,47 @@ ZK_DEV P256Pt p256_rtab_mul_range(const uint32_t* __restrict__ rtab, uint32_t kw
     }
     return acc;
 }
+
+// ---- sums over tables that hold EVERY window multiple need no doubling, so several lanes can take a range of windows each and add their partial sums through
+// the wave's cross-lane moves (round 4: k_v_exp_points; round 5: the prover's table sums of a small chunk, k_p256.hip / k_tom.hip "wide" kernels).
+#if !defined(ZK_HOST_BUILD)
+ZK_DEV P256Pt p256_shfl_xor(const P256Pt& a, int m) {
+    P256Pt r;
+#pragma unroll
+    for (int l = 0; l < NLIMB; l++) {
+        r.x.l[l] = (uint32_t)__shfl_xor((int)a.x.l[l], m), r.y.l[l] = (uint32_t)__shfl_xor((int)a.y.l[l], m), r.z.l[l] = (uint32_t)__shfl_xor((int)a.z.l[l], m);
+    }
+    return r;
+}
+ZK_DEV P256Aff ld_pfix(const uint32_t* e) {
+    const uint4* q = (const uint4*)e;
+    uint32_t w[20];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        uint4 v = q[i];
+        w[4 * i] = v.x, w[4 * i + 1] = v.y, w[4 * i + 2] = v.z, w[4 * i + 3] = v.w;
+    }
+    P256Aff a;
+#pragma unroll
+    for (int l = 0; l < 9; l++) a.x.l[l] = w[l], a.y.l[l] = w[9 + l];
+    return a;
+}
+// acc + (the comb's windows [w0, w0 + per) of k) * B: one lane's share when four lanes split a fixed-base multiplication (k_p256.hip: k_exp_commit_kt_wide, k_front_wide; k_verify.hip: k_v_p256_total_wide)
+ZK_DEV P256Pt p256_fixed_mul_range(P256Pt acc, const uint32_t* __restrict__ tab, uint32_t kw[8], uint32_t w0, uint32_t per) {
+#pragma unroll 1
+    for (uint32_t w = 0; w < w0; w++) shr256<PFIX_WIN_BITS>(kw);
+#pragma unroll 1
+    for (uint32_t j = 0; j < per; j++) {
+        const uint32_t w = w0 + j;
+        uint32_t d = kw[0] & (PFIX_WIN_SIZE - 1);
+        shr256<PFIX_WIN_BITS>(kw);
+        if (w < PFIX_NWIN && d != 0) acc = p256_add_mixed(acc, ld_pfix(tab + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + d)));
+    }
+    return acc;
+}
+// the sum over the lanes of an aligned group of four (every lane of the group must take part)
+ZK_DEV P256Pt p256_quad_sum(P256Pt a) {
+    a = p256_add(a, p256_shfl_xor(a, 1));
+    return p256_add(a, p256_shfl_xor(a, 2));
+}
+#endif
