@@ -61,3 +61,7 @@ export class Engine {
     verifyStream(msg: Buffer, blob: Buffer, offsets: Buffer, lengths: Buffer, seeds?: Buffer): Promise<{ ok: boolean[]; status: Int32Array }>
     verifyBatchAsync(msg: Buffer, proofs: Buffer[], seeds?: Buffer): Promise<Verdicts>
 }
+/** Wire layout of the proofs proveSignatureList / proveSignatureListBatch return: 'zka1' (default) or 'zka1p' (33-byte Tom coordinates, 5.3 % fewer bytes; env ZKATTEST_WIRE).
+ *  verifySignatureList / ...Batch accept either layout per proof; writeJson gives the same text for both. */
+export function setWireLayout(name: 'zka1' | 'zka1p'): void
+export function getWireLayout(): 'zka1' | 'zka1p'

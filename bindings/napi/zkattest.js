@@ -192,7 +192,12 @@ function revive(v) {
 }
 class SignatureProofList { // src/zkpAttestList.ts:27-60
     constructor(bytes) { if (!wellFormedProof(bytes)) throw new Error('error deserializing'); this.bytes = bytes }
-    eq(o) { return o instanceof SignatureProofList && this.bytes.equals(o.bytes) }   // the encoding is canonical: equal members <=> equal bytes
+    // the encoding is canonical: equal members <=> equal bytes of ONE layout; a ZKA1 and a ZK1P image of the same proof are equal through their (layout-free) JSON text
+    eq(o) {
+        if (!(o instanceof SignatureProofList)) return false
+        if (this.bytes.slice(0, 4).equals(o.bytes.slice(0, 4))) return this.bytes.equals(o.bytes)
+        return this.toJson() === o.toJson()
+    }
     toJson() { return native.proofToJson(this.bytes) }
     get members() { if (!this._m) Object.defineProperty(this, '_m', { value: revive(JSON.parse(this.toJson())) }); return this._m }
     get R() { return this.members.R }
@@ -395,6 +400,19 @@ function engineFor(params, keys) {
     return { engine: slot.engine, withRing }
 }
 function shutdown() { for (const s of engines.values()) s.engine.close(); engines.clear() }
+// The wire layout of the proofs the reference-shaped calls below PRODUCE: 'zka1' (default; 36-byte Tom coordinates) or 'zka1p' (33-byte, 5.3 % fewer bytes
+// to move: include/zkattest.h "packed wire layout"; ZKATTEST_WIRE sets the default).  Verification takes either layout, per proof, whatever this is set
+// to; the JSON text of a proof does not depend on it.
+let wireLayout = /^zka1p$/i.test(process.env.ZKATTEST_WIRE || '') ? 1 : 0
+function setWireLayout(name) {
+    if (!/^zka1p?$/i.test(name)) throw new TypeError("wire layout: 'zka1' or 'zka1p'")
+    wireLayout = /p$/i.test(name) ? 1 : 0
+}
+function getWireLayout() { return wireLayout ? 'zka1p' : 'zka1' }
+function useWire(slotEngine, wire) {   // inside a queued unit of the engine (nothing of it is in flight)
+    if (slotEngine._wire !== wire) { slotEngine.setOption('wire', wire); slotEngine._wire = wire }
+}
+const isPacked = (b) => Buffer.isBuffer(b) && b.length >= 4 && b.slice(0, 4).toString('latin1') === 'ZK1P'
 
 // ---------------------------------------------------------------- the reference's API
 // publicKey: a WebCrypto CryptoKey (where crypto.subtle exists), a Node KeyObject, or the 65-byte 'raw' export 04 || X || Y
@@ -427,15 +445,28 @@ async function proveSignatureListBatch(params, msgHashes, sigs, publicKeys, whic
     for (const r of raws) if (r.length !== 65 || r[0] !== 4) throw new Error('invalid public key')
     const msg = Buffer.concat(msgHashes.map((m) => Buffer.from(m))), sig = Buffer.concat(sigs.map((s) => Buffer.from(s)))
     checkRingSize(Buffer.isBuffer(keys) ? keys.length / 32 : keys.length, true)
-    const proofs = await engineFor(params, keys).withRing((engine) => engine._proveNow(msg, sig, Buffer.concat(raws.map((r) => r.slice(1))), whichs))
+    const wire = wireLayout
+    const proofs = await engineFor(params, keys).withRing((engine) => { useWire(engine, wire); return engine._proveNow(msg, sig, Buffer.concat(raws.map((r) => r.slice(1))), whichs) })
     return proofs.map((b) => new SignatureProofList(b))
 }
 async function verifySignatureListBatch(params, msgHashes, keys, proofs) {
     const msg = Buffer.concat(msgHashes.map((m) => Buffer.from(m))), raw = proofs.map((p) => (p instanceof SignatureProofList ? p.bytes : p))
     checkRingSize(Buffer.isBuffer(keys) ? keys.length / 32 : keys.length, false)
-    return engineFor(params, keys).withRing((engine) => engine._verifyNow(msg, raw))
+    // a context verifies ONE layout at a time (zk_ctx_set_wire): the batch is split by the proofs' magic and the verdicts are put back in order
+    const idx = [[], []]
+    raw.forEach((b, i) => idx[isPacked(b) ? 1 : 0].push(i))
+    const out = new Array(raw.length), errors = new Array(raw.length)
+    for (const wire of [0, 1]) {
+        const sel = idx[wire]
+        if (!sel.length) continue
+        const m = sel.length === raw.length ? msg : Buffer.concat(sel.map((i) => msg.slice(32 * i, 32 * i + 32)))
+        const r = await engineFor(params, keys).withRing((engine) => { useWire(engine, wire); return engine._verifyNow(m, sel.map((i) => raw[i])) })
+        sel.forEach((i, k) => { out[i] = r[k]; errors[i] = r.errors[k] })
+    }
+    Object.defineProperty(out, 'errors', { value: errors })
+    return out
 }
 
 module.exports = { generateParamsList, generateParamsListHardened, keyToInt, proveSignatureList, verifySignatureList, proveSignatureListBatch, verifySignatureListBatch,
     writeJson, readJson, writeJsonBatch, readJsonBatch, SignatureProofList, SystemParametersList, PedersenParams, generatePedersenParams, p256, tomEdwards256, ALL_GROUPS,
-    Group, Point, Scalar, Engine, shutdown, native }
+    Group, Point, Scalar, Engine, shutdown, setWireLayout, getWireLayout, native }

@@ -33,6 +33,29 @@ def test_prove_matches_oracle_small(nkeys, B):
     eng.close()
 
 
+def test_uniform_control_flow_build_makes_the_same_bytes():
+    """lib/libzkattest_hip_uniform.so (csrc/Makefile `uniform`, -DZK_UNIFORM_CF=1: the prover's table sums compute and discard the addition of a zero digit
+    instead of branching around it, k_tom_commit never skips a window) is the same engine: same bytes from the one-lane and from the wide kernels.  Each
+    library in its own process (one process holds one build); the cost of the uniform build is printed."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import zkp_ecdsa_amd as Z
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    uni = os.path.join(os.path.dirname(Z.LIB_PATH), 'libzkattest_hip_uniform.so')
+    if not os.path.exists(uni):
+        pytest.skip('the uniform build is not there (make -C zkp-ecdsa_amd/csrc uniform)')
+    recs = []
+    for lib in (Z.LIB_PATH, uni):
+        env = dict(os.environ, ZKATTEST_LIB=lib)
+        out = subprocess.run([sys.executable, os.path.join(root, 'tests', 'uniform_check.py')], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert out.returncode == 0, out.stderr.decode()[-2000:]
+        recs.append(json.loads(out.stdout.decode().strip().splitlines()[-1]))
+    print(json.dumps(recs))
+    assert recs[0]['sha256'] == recs[1]['sha256'] and recs[1]['lib'].endswith('_uniform.so')
+
+
 def test_prove_ring_1024_sample():
     """BASELINE config 2 shape at reduced batch: ring 2^10, 64 proofs, all diffed against the oracle."""
     eng, octx, (msg, sig, pk, which, seeds) = _setup(7, 1024, 64)

@@ -185,6 +185,27 @@ ZK_DEV P256Pt p256_select(bool c, const P256Pt& a, const P256Pt& b) {
     r.z = fe_select(c, a.z, b.z);
     return r;
 }
+// A table sum skips the addition of a ZERO digit.  Default build: with a branch -- the lane idles while its neighbours add, which is what keeps the table
+// sums at 124-140 registers and three waves per SIMD, but makes control flow depend on digits of secret scalars (nonces, blinders).  -DZK_UNIFORM_CF=1
+// (`make uniform`: lib/libzkattest_hip_uniform.so): the addition is always computed, on a valid entry, and discarded by a select; control flow and the
+// set of executed instructions no longer depend on secret data (addresses of the table gathers still do: see INTEGRATION.md, "side channels").
+#ifndef ZK_UNIFORM_CF
+#define ZK_UNIFORM_CF 0
+#endif
+#if ZK_UNIFORM_CF
+#define ZK_ADD_IF(cond, acc, sum_expr)                 \
+    do {                                               \
+        const bool c__ = (cond);                       \
+        const P256Pt s__ = (sum_expr);                 \
+        (acc) = p256_select(c__, s__, (acc));          \
+    } while (0)
+#else
+#define ZK_ADD_IF(cond, acc, sum_expr)                 \
+    do {                                               \
+        if (cond) (acc) = (sum_expr);                  \
+    } while (0)
+#endif
+
 // y^2 == x^3 - 3x + b  (weier.ts:56-70 with Z = 1)
 ZK_DEV bool p256_on_curve(const P256Aff& a) {
     const auto b = fe_const<ModQ, 1>(P256_B_M);

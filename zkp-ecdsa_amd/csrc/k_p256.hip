@@ -21,7 +21,7 @@ ZK_DEV P256Pt p256_fixed_mul(const uint32_t* __restrict__ tab, uint32_t kw[8]) {
     for (int w = 1; w < PFIX_NWIN; w++) {
         uint32_t d = kw[0] & (PFIX_WIN_SIZE - 1);
         shr256<PFIX_WIN_BITS>(kw);
-        if (d != 0) acc = p256_add_mixed(acc, ld_pfix(tab + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + d)));   // a zero digit (2^-20) idles its lane
+        ZK_ADD_IF(d != 0, acc, p256_add_mixed(acc, ld_pfix(tab + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + (d ? d : 1)))));   // a zero digit (2^-20) idles its lane (rtab.h: ZK_UNIFORM_CF)
     }
     return acc;
 }
@@ -31,7 +31,7 @@ ZK_DEV P256Pt p256_fixed_mul_acc(P256Pt acc, const uint32_t* __restrict__ tab, u
     for (int w = 0; w < PFIX_NWIN; w++) {
         uint32_t d = kw[0] & (PFIX_WIN_SIZE - 1);
         shr256<PFIX_WIN_BITS>(kw);
-        if (d != 0) acc = p256_add_mixed(acc, ld_pfix(tab + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + d)));   // a zero digit (2^-20) idles its lane
+        ZK_ADD_IF(d != 0, acc, p256_add_mixed(acc, ld_pfix(tab + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + (d ? d : 1)))));   // a zero digit (2^-20) idles its lane (rtab.h: ZK_UNIFORM_CF)
     }
     return acc;
 }

@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256, OCC) k_tom_commit(const uint32_t* __restr
         }
         if (w + 1 < nwin) {
             dgv.next(dv, sv);
-            g_live = SGN || __ballot(dv != 0) != 0;   // wave-uniform
+            g_live = SGN || ZK_UNIFORM_CF || __ballot(dv != 0) != 0;   // wave-uniform; the uniform build (curve.h: ZK_UNIFORM_CF) never skips: the digits are secret
             if (g_live) ng = ld_niels(tab_g + (size_t)TOM_ENTRY_WORDS * (base + ent + dv));
         }
         niels_pin(nh);

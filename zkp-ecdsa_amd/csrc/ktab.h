@@ -64,7 +64,7 @@ ZK_DEV P256Pt p256_ktab_mul_acc(P256Pt acc, const uint32_t* __restrict__ kt, uin
         uint32_t d;
         bool dn;
         kd.next(d, dn);
-        if (d != 0) acc = p256_add_mixed(acc, ld_ktab(kt + ((size_t)w * KTAB_ENT + d - 1) * KTAB_ENTRY_WORDS, neg != dn));   // a zero digit (2^-8) idles its lane
+        ZK_ADD_IF(d != 0, acc, p256_add_mixed(acc, ld_ktab(kt + ((size_t)w * KTAB_ENT + (d ? d - 1 : 0)) * KTAB_ENTRY_WORDS, neg != dn)));   // a zero digit (2^-8) idles its lane (curve.h: ZK_UNIFORM_CF)
     }
     return acc;
 }
@@ -84,7 +84,7 @@ ZK_DEV P256Pt p256_ktab_mul_range(P256Pt acc, const uint32_t* __restrict__ kt, u
     for (uint32_t j = 0; j < per; j++) {
         const uint32_t w = w0 + j;
         kd.next(d, dn);
-        if (w < KTAB_NWIN && d != 0) acc = p256_add_mixed(acc, ld_ktab(kt + ((size_t)w * KTAB_ENT + d - 1) * KTAB_ENTRY_WORDS, neg != dn));
+        ZK_ADD_IF(w < KTAB_NWIN && d != 0, acc, p256_add_mixed(acc, ld_ktab(kt + ((size_t)(w < KTAB_NWIN ? w : 0) * KTAB_ENT + (d ? d - 1 : 0)) * KTAB_ENTRY_WORDS, neg != dn)));
     }
     return acc;
 }

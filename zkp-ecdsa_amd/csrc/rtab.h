@@ -123,7 +123,7 @@ ZK_DEV P256Pt p256_fixed_mul_range(P256Pt acc, const uint32_t* __restrict__ tab,
         const uint32_t w = w0 + j;
         uint32_t d = kw[0] & (PFIX_WIN_SIZE - 1);
         shr256<PFIX_WIN_BITS>(kw);
-        if (w < PFIX_NWIN && d != 0) acc = p256_add_mixed(acc, ld_pfix(tab + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + d)));
+        ZK_ADD_IF(w < PFIX_NWIN && d != 0, acc, p256_add_mixed(acc, ld_pfix(tab + (size_t)PFIX_ENTRY_WORDS * ((w < PFIX_NWIN ? w : 0) * PFIX_WIN_SIZE + (d ? d : 1)))));
     }
     return acc;
 }
