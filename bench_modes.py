@@ -103,6 +103,8 @@ def host_io_rates(Z, eng, args, B, sec, msg, sig, pk, which, seeds, dev, device_
         try:
             host_io['stream'] = host_io_stream(Z, eng, args, nb, chunk, vchunk, hm, hs, hp, hw, hseed, pin, device_rate, device_vrate, host_io['pcie'])
         except Exception as e:  # an auxiliary measurement must never cost the bench line
+            import sys
+            print('host_io stream failed: %r' % (e,), file=sys.stderr)
             host_io['stream'] = {'error': repr(e)[:300]}
     if args.host_io_stream > 1 and args.host_io_packed and 'proofs_per_s' in (host_io.get('stream', {}).get('prove') or {}):
         # the same streamed batches in the packed wire layout (ZKA1P, zk_ctx_set_wire): 5.3 % fewer bytes across the link in both directions
@@ -131,10 +133,20 @@ def host_io_stream(Z, eng, args, nb, chunk, vchunk, hm, hs, hp, hw, hseed, pin, 
     rec = {'batches': nj, 'proofs_per_batch': nb, 'in_flight': F, 'prove_configs': [], 'verify_configs': []}
     seeds = [hseed] + [rank_seeds(hseed, 7000 + k) for k in range(1, nj)]
     offs = [None] * nj
+    pending = []   # tickets submitted and not yet waited for: a configuration that fails must not leave jobs queued on the context (every setter would refuse)
+
     def guarded(cfg, run):   # one configuration running out of memory (workspaces of more lanes) must not cost the others
         try:
             return run()
         except Exception as e:
+            import sys
+            print('host_io_stream: configuration %s failed: %r' % (cfg, e), file=sys.stderr)
+            for kind, t in pending:
+                try:
+                    (eng.prove_wait if kind == 'p' else eng.verify_wait)(t)
+                except Exception:
+                    pass
+            del pending[:]
             return {'config': cfg, 'error': repr(e)[:200]}
 
     def prove_cfg(cfg):
@@ -147,12 +159,15 @@ def host_io_stream(Z, eng, args, nb, chunk, vchunk, hm, hs, hp, hw, hseed, pin, 
             tk, waits = [], []
             for k in range(min(F, nj)):
                 tk.append(eng.prove_submit(hm, hs, hp, hw, seeds[k], bufs[k % F]))
+                pending.append(('p', tk[-1]))
             for k in range(nj):
+                pending.pop(0)
                 offs[k], st = eng.prove_wait(tk[k])
                 waits.append(time.time())
                 assert not any(st)
                 if k + F < nj:   # job k's buffer is free again
                     tk.append(eng.prove_submit(hm, hs, hp, hw, seeds[k + F], bufs[(k + F) % F]))
+                    pending.append(('p', tk[-1]))
         total_bytes = sum(int(o[nb]) for o in offs)
         return {'chunk': min(c_, nb), 'lanes': l_, 'slice': s_, 'proofs_per_s': round(nj * nb / (waits[-1] - t0), 1),
                 'steady_proofs_per_s': round((nj - 1) * nb / (waits[-1] - waits[0]), 1), 'd2h_gbps': round(total_bytes / (waits[-1] - t0) / 1e9, 2),
@@ -174,12 +189,15 @@ def host_io_stream(Z, eng, args, nb, chunk, vchunk, hm, hs, hp, hw, hseed, pin, 
             tk, waits, acc = [], [], 0
             for k in range(min(Fv, nj)):
                 tk.append(eng.verify_submit(hm, bufs[src(k) % F], offs[src(k)], nb))
+                pending.append(('v', tk[-1]))
             for k in range(nj):
+                pending.pop(0)
                 ok, vst = eng.verify_wait(tk[k])
                 waits.append(time.time())
                 acc += sum(ok)
                 if k + Fv < nj:
                     tk.append(eng.verify_submit(hm, bufs[src(k + Fv) % F], offs[src(k + Fv)], nb))
+                    pending.append(('v', tk[-1]))
             assert acc == nj * nb, (acc, nj * nb)
         vbytes = sum(int(offs[src(k)][nb]) for k in range(nj))
         return {'chunk': min(c_, nb), 'lanes': l_, 'in_flight': Fv, 'verifies_per_s': round(nj * nb / (waits[-1] - t0), 1),

@@ -473,7 +473,10 @@ static size_t carve(zk_ctx* c, Workspace& W, Soa& gk_am, uint8_t* base, uint32_t
     W.T1proj = k.soa3(items_cap), W.T1x = k.soa(items_cap), W.T1y = k.soa(items_cap);
     W.padd_c = (uint32_t*)k.take(4 * 18 * items_cap);
     W.la = k.list((size_t)C * (2 + 2 * sec));
+    uint8_t* const lb_begin = (uint8_t*)k.take(0);   // list B's seven arrays lie back to back from here
+    const size_t lb_off0 = k.off;
     W.lb = k.list(items_cap * LB_SLOTS);
+    const size_t lb_bytes = k.off - lb_off0;
     W.lc = k.list((size_t)C * 4 * n);
     W.gk_x = (uint32_t*)k.take(12 * (size_t)C);
     W.gk_coef = k.soa((size_t)(n + 1) * C);
@@ -499,8 +502,14 @@ static size_t carve(zk_ctx* c, Workspace& W, Soa& gk_am, uint8_t* base, uint32_t
     W.rng.exc_cnt = (uint32_t*)k.take(4 * (size_t)C);
     W.rng_fill = (uint32_t*)k.take(32 * (size_t)(3 + 44 * sec + 5 * n + RNG_MAX_EXC) * C);
     {
-        const size_t blocks = (2 * 67 + (size_t)sec * (65 + 2 * 67) + 9 + 63) / 64, np = std::min<size_t>(C, EXPH_CAP);
+        // the Exp challenge's message and schedule buffers (k_hash.hip: k_exph_*): their own memory for chunks of up to EXPH_MAXP proofs (the verifier's
+        // small chunks use them while list B may be live); a prover chunk of any size borrows LIST B, which nothing touches before stage 2 -- 80 KB of
+        // the 397 KB a proof's list B takes, so the three-kernel path costs no HBM
+        const size_t blocks = (2 * 67 + (size_t)sec * (65 + 2 * 67) + 9 + 63) / 64, np = std::min<size_t>(C, EXPH_MAXP);
         W.exph_msg = (uint8_t*)k.take(np * blocks * 64), W.exph_wk = (uint32_t*)k.take(np * blocks * 256), W.exph_cap = (uint32_t)np;
+        const size_t big_msg = ((size_t)C * blocks * 64 + 255) & ~(size_t)255;
+        if (lb_bytes >= big_msg + (size_t)C * blocks * 256) W.exph_big_msg = lb_begin, W.exph_big_wk = (uint32_t*)(lb_begin ? lb_begin + big_msg : nullptr), W.exph_big_cap = C;
+        else W.exph_big_msg = nullptr, W.exph_big_wk = nullptr, W.exph_big_cap = 0;
     }
     W.ring = Soa{c->ring_mem, (uint32_t)N};
     return k.off + 256;

@@ -53,7 +53,9 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
         M.start = (uint32_t*)k.take(4 * NW * NBG), M.end = (uint32_t*)k.take(4 * NW * NBG);
         M.ord_id = (uint32_t*)k.take(4 * NW * NBG);
         M.counters = (uint32_t*)k.take(256), M.flag = (uint32_t*)k.take(256), M.big_list = (uint32_t*)k.take(4 * 4096), M.big_part = (uint32_t*)k.take((size_t)4096 * 128 * 144);
-        M.buckets = (uint32_t*)k.take(NW * NBG * 144);
+        // the buckets are written after the last reader of the (key, id) pairs has run (k_msm_binsort): where the pairs' memory is large enough they share it
+        if (cap * 8 * NW >= NW * NBG * 144) M.buckets = (uint32_t*)M.pairs;
+        else M.buckets = (uint32_t*)k.take(NW * NBG * 144);
         M.F1 = (uint32_t*)k.take(NWG * L1 * 144), M.G1 = (uint32_t*)k.take(NWG * L1 * 144);
         M.F2 = (uint32_t*)k.take(NWG * L2 * 144), M.G2 = (uint32_t*)k.take(NWG * L2 * 144), M.H2 = (uint32_t*)k.take(NWG * L2 * 144);
         M.Tw = (uint32_t*)k.take(NWG * 144);
@@ -196,7 +198,7 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
         HIPCHK(c, hipStreamWaitEvent(A.aux[1], A.aux_fork, 0));
         {   // aux 0: the Exp challenge (three kernels where the schedule buffer holds the chunk) and the sampled repetitions
             MaybeScope t(timed, c, "v_hash", A.aux[0]);
-            if (cnt <= EXPH_MAXP && cnt <= W.exph_cap && W.exph_wk) launch_v_exp_challenge_small(A.aux[0], W, V, cnt, d_proofs, d_off, first);
+            if (cnt <= W.exph_cap && W.exph_wk) launch_v_exp_challenge_small(A.aux[0], W, V, cnt, d_proofs, d_off, first);
             else launch_v_challenges(A.aux[0], V, cnt, d_proofs, d_off, d_msg, first, 1);
             launch_v_sample(A.aux[0], V, cnt, d_vseeds, first);
         }

@@ -149,7 +149,10 @@ struct Workspace {
     uint8_t* r_zero;             // [C] r = 0 mod n (k_front)
     uint8_t* exph_msg;           // [exph_cap][blocks * 64] the padded message of the Exp challenge (k_hash.hip: k_exph_*)
     uint32_t* exph_wk;           // [blocks][16][count] x uint4: its expanded schedule W_i + K_i, proof-fastest (the lanes of k_exph_rounds are consecutive proofs)
-    uint32_t exph_cap;           // proofs these two hold: min(C, EXPH_CAP)
+    uint32_t exph_cap;           // proofs these two hold: min(C, EXPH_MAXP)
+    uint8_t* exph_big_msg;       // the same two for a prover chunk of any size, borrowed from list B (idle until stage 2): api.hip carve
+    uint32_t* exph_big_wk;
+    uint32_t exph_big_cap;       // proofs they hold (C, or 0 where list B is too small)
     uint32_t* gk_bufA;           // ping-pong level buffers
     uint32_t* gk_bufB;
     // block-transform path of the ring fold (k_gk.hip), used when the ring has a table E (9 <= n <= GK_ETAB_MAXN)
@@ -181,7 +184,6 @@ struct Workspace {
 #define ZK_WIDE_MAX_UNITS 32768u
 #endif
 #define EXPH_MAXP 256       // a verifier chunk of at most this many proofs hashes its Exp challenge on an auxiliary stream (api_verify.hip: small one-chunk calls)
-#define EXPH_CAP 32768      // chunks of at most this many proofs hash the Exp challenge through the three-kernel path (16 + 64 KB of message and schedule per proof)
 #define V_SLOT_SPLIT 4      // slot accumulators per checked repetition (k_v_straus: a slot's terms over up to 4 lanes)
 // per-proof sums of at most V_WIDE_MAXP proofs: ONE term per lane (a slot's 36 terms over 36 lanes, a membership group's 8 over 8), folded by
 // k_v_acc_tree, the five sums side by side on the lane's auxiliary streams -- the chain of a lane is what a small batch waits for

@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(64) k_exp_challenge(Workspace W, uint32_t coun
         for (int i = 0; i < 4; i++) W.chal[4 * p + i] = c[i];
     }
 }
-// The same digest in three kernels (chunks of up to EXPH_CAP proofs: every chunk of the bench).  One lane per proof hashing 16 KB is a chain of 251
+// The same digest in three kernels (prover chunks of any size: the buffers are borrowed from list B, api.hip carve).  One lane per proof hashing 16 KB is a chain of 251
 // compressions, and of a compression's ~1 650 instructions a third is the message schedule and a fifth the byte-wise absorption of 33-byte coordinates --
 // neither depends on the chaining value.  k_exph_msg (one lane per point) writes the padded message, k_exph_sched (one lane per (block, proof)) expands every
 // block to its 64 words W_i + K_i, k_exph_rounds (one lane per proof) runs the 64 rounds per block and nothing else: 1.33 -> 0.7 ms for one proof (round 4).
@@ -198,10 +198,13 @@ void launch_exph_hash(hipStream_t s, const Workspace& W, uint32_t count, uint32_
     hipLaunchKernelGGL(k_exph_rounds, dim3((count + 63) / 64), dim3(64), 0, s, W, count, chal);
 }
 void launch_exp_challenge(hipStream_t s, const Workspace& W, uint32_t count) {
-    if (count <= W.exph_cap && W.exph_wk) {
+    const bool small = count <= W.exph_cap && W.exph_wk, big = !small && count <= W.exph_big_cap && W.exph_big_wk;
+    if (small || big) {
+        Workspace Wb = W;
+        if (big) Wb.exph_msg = W.exph_big_msg, Wb.exph_wk = W.exph_big_wk;   // list B's memory: free until stage 2 of this chunk
         const uint32_t ne = 2 + 3 * W.sec + 1;
-        hipLaunchKernelGGL(k_exph_msg, dim3((count * ne + 255) / 256), dim3(256), 0, s, W, count);
-        launch_exph_hash(s, W, count, W.chal);
+        hipLaunchKernelGGL(k_exph_msg, dim3((count * ne + 255) / 256), dim3(256), 0, s, Wb, count);
+        launch_exph_hash(s, Wb, count, W.chal);
         return;
     }
     hipLaunchKernelGGL(k_exp_challenge, dim3((count + 63) / 64), dim3(64), 0, s, W, count);
