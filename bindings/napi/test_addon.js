@@ -145,7 +145,11 @@ async function gpu() {
         assert.strictEqual(zk.getWireLayout(), 'zka1p')
         const packedProof = await proveSignatureList(params, msgHash, signature, keyPair.publicKey, 0, testArray)
         assert.strictEqual(packedProof.bytes.slice(0, 4).toString('latin1'), 'ZK1P')
-        assert.ok(packedProof.bytes.length < proof.bytes.length && packedProof.bytes.length > 0.9 * proof.bytes.length)
+        const sameAsZka1 = readJson(SignatureProofList, writeJson(SignatureProofList, packedProof))      // the reader emits ZKA1: the same proof in the other layout
+        assert.strictEqual(sameAsZka1.bytes.slice(0, 4).toString('latin1'), 'ZKA1')
+        assert.ok(packedProof.bytes.length < sameAsZka1.bytes.length && packedProof.bytes.length > 0.9 * sameAsZka1.bytes.length)
+        assert.ok(packedProof.eq(sameAsZka1) && sameAsZka1.eq(packedProof) && !packedProof.eq(proof))                // eq() is layout-free, not proof-free
+        assert.strictEqual(await verifySignatureList(params, msgHash, testArray, sameAsZka1), true)
         assert.strictEqual(await verifySignatureList(params, msgHash, testArray, packedProof), true)
         assert.strictEqual(await verifySignatureList(params, msgHash, otherRing, packedProof), false)
         assert.strictEqual(packedProof.expProof.length, proof.expProof.length)

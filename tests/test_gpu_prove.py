@@ -33,6 +33,36 @@ def test_prove_matches_oracle_small(nkeys, B):
     eng.close()
 
 
+def test_lane_scheduling_knobs_do_not_change_the_bytes(monkeypatch):
+    """The opt-in schedules of round 5 (profiles/r05_overlap.txt; read by zk_ctx_create): the commitment kernels of all lanes on one low-priority
+    "heavy queue", stage 1 enqueued phase by phase across the lanes, the membership phase on the side stream behind the PointAdd commitments, lanes at
+    another priority, the commitment kernels padded to one workgroup per CU.  Same proofs as the default schedule, sliced and unsliced."""
+    import zkp_ecdsa_amd as Z
+
+    def run(env):
+        for k in ('ZKATTEST_HEAVY_FIFO', 'ZKATTEST_PHASE_MAJOR', 'ZKATTEST_GK_BESIDE', 'ZKATTEST_LANE_PRIO', 'ZKATTEST_HEAVY_LDS_KB', 'ZKATTEST_HEAVY_PRIO'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = Z.Engine(0)
+        eng.set_comb_bits(16)
+        eng.set_params(*eng.synth_params(321), 80)
+        ring, msg, sig, pk, which, seeds = eng.synth_workload(321, 512, 200)
+        eng.set_ring(ring, 512)
+        eng.set_chunk(48), eng.set_lanes(3)
+        a, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+        assert not any(st)
+        eng.set_slice(16)
+        b, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+        assert not any(st) and a == b
+        eng.close()
+        return a
+    ref = run({})
+    assert run({'ZKATTEST_HEAVY_FIFO': '1', 'ZKATTEST_PHASE_MAJOR': '1', 'ZKATTEST_GK_BESIDE': '1', 'ZKATTEST_LANE_PRIO': '-1,-1,-1,-1'}) == ref
+    assert run({'ZKATTEST_HEAVY_FIFO': '2', 'ZKATTEST_GK_BESIDE': '1', 'ZKATTEST_HEAVY_PRIO': '0'}) == ref
+    assert run({'ZKATTEST_LANE_PRIO': '-1,0,1', 'ZKATTEST_HEAVY_LDS_KB': '84'}) == ref
+
+
 def test_uniform_control_flow_build_makes_the_same_bytes():
     """lib/libzkattest_hip_uniform.so (csrc/Makefile `uniform`, -DZK_UNIFORM_CF=1: the prover's table sums compute and discard the addition of a zero digit
     instead of branching around it, k_tom_commit never skips a window) is the same engine: same bytes from the one-lane and from the wide kernels.  Each

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Regenerates profiles/r04_* on an MI355X box (run from the repo root, e.g. through gpurun; outputs under gpurun_out/, to be copied into
+# Regenerates profiles/r05_* on an MI355X box (run from the repo root, e.g. through gpurun; outputs under gpurun_out/, to be copied into
 # profiles/).  ROUND=r04 by default.  Counters are collected in their own runs, never together with tracing domains other than --kernel-trace.
-# About 12 minutes of GPU time.
+# About 13 minutes of GPU time.
 set -e
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 export GPU_MAX_HW_QUEUES=8
 mkdir -p gpurun_out
 ROOT=$PWD
@@ -28,6 +28,9 @@ python tools/kernel_meta.py --csv > gpurun_out/${R}_kernel_resources.csv
 python bench.py --ring 100001 --host-io 0 --json-sample 0 2>/dev/null | grep '"metric"' > gpurun_out/${R}_bench_line_ring100001.json
 python bench.py --mode verify --batch 131072 --ring 1048576 --steps 1 --warmup 1 2>/dev/null | grep '"metric"' > gpurun_out/${R}_bench_line_verify_2e20.json
 python bench.py --pool --gpus 1 --steps 2 --warmup 1 2>/dev/null | grep '"metric"' > gpurun_out/${R}_bench_line_pool.json
+# the build without secret-dependent control flow (INTEGRATION.md "side channels"): what it costs, same box
+ZKATTEST_LIB=$ROOT/zkp-ecdsa_amd/lib/libzkattest_hip_uniform.so python bench.py --host-io 0 --json-sample 0 --latency 0 --no-cpu-baseline 2>/dev/null | grep '"metric"' > gpurun_out/${R}_bench_line_uniform.json
+python bench.py --host-io 0 --json-sample 0 --latency 0 --no-cpu-baseline 2>/dev/null | grep '"metric"' > gpurun_out/${R}_bench_line_default_again.json
 make -s -C bindings/napi OUT=/tmp/zk.node && (cd bindings/napi && ZKATTEST_NODE=/tmp/zk.node node latency.js 7 > $ROOT/gpurun_out/${R}_facade_latency.json 2>/dev/null) || true
 rm -rf gpurun_out/prof_default gpurun_out/prof_lanes1 gpurun_out/pmc_SQ_WAVES gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
 ls -la gpurun_out/${R}_*
