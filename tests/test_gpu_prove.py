@@ -47,12 +47,12 @@ def test_lane_scheduling_knobs_do_not_change_the_bytes(monkeypatch):
         eng = Z.Engine(0)
         eng.set_comb_bits(16)
         eng.set_params(*eng.synth_params(321), 80)
-        ring, msg, sig, pk, which, seeds = eng.synth_workload(321, 512, 200)
-        eng.set_ring(ring, 512)
-        eng.set_chunk(48), eng.set_lanes(3)
+        ring, msg, sig, pk, which, seeds = eng.synth_workload(321, 2048, 1200)
+        eng.set_ring(ring, 2048)
+        eng.set_chunk(400), eng.set_lanes(3)         # three chunks on three lanes
         a, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
         assert not any(st)
-        eng.set_slice(16)
+        eng.set_chunk(1200), eng.set_slice(512)      # one chunk whose PointAdd phase runs in three slices
         b, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
         assert not any(st) and a == b
         eng.close()

@@ -12,7 +12,7 @@
 //   scalar {group: {name}, k}     (reduce before serialisation)     src/curves/group.ts:155-161
 //   bigint "0x" + lowercase hex without leading zeros               src/bignum/big.ts:230-239
 // typedjson itself is not in /root/reference (package.json:64-66), so the byte-level JSON shape is UNPINNED
-// (SURVEY.md section 8c): the emitter follows typedjson's documented behaviour -- members in declaration order,
+// (SURVEY.md section 8d): the emitter follows typedjson's documented behaviour -- members in declaration order,
 // undefined optional members omitted, and a trailing "__type" hint on values whose runtime class differs from the
 // declared one (Group -> WeierstrassGroup / TEdwards, Group.Point -> WeierstrassPoint / TEdwardsPoint).  The parser is
 // deliberately tolerant: member order is free, "__type" and unknown members are ignored, so real typedjson output
