@@ -277,7 +277,7 @@ def main():
                                    'the kernel issues 1.39 VALU instructions per multiplier instruction on top (profiles/r03_valu_peak_microbench.txt, DESIGN.md section 8)'},
             'traffic': int(commits_per_step / max(1, launches_per_step) * pmc_bytes) if pmc_bytes else None,
             'traffic_note': ('bytes per launch = units per launch x %d B (FETCH_SIZE + WRITE_SIZE per commitment, separate rocprofv3 --pmc passes, '
-                             'profiles/r04_pmc_summary.txt); table gathers, not the 180 algorithmic bytes, dominate' % pmc_bytes) if pmc_bytes
+                             'profiles/r05_pmc_summary.txt); table gathers, not the 180 algorithmic bytes, dominate' % pmc_bytes) if pmc_bytes
                             else 'no PMC pass recorded for this comb width',
             'valu_active_per_wave': TOM_COMMIT_VALU_ACTIVE_PER_WAVE.get(args.comb_bits),
             'pmc_source': PMC_SOURCE,

@@ -40,13 +40,13 @@ def tom_commit_modmuls(comb_bits):
 
 TOM_COMMIT_NOMINAL = 4064      # reference: 256 dbl + 160 add (src/curves/group.ts:97-132)
 TOM_COMMIT_BYTES = 2 * 36 + 3 * 36  # algorithmic HBM bytes per commitment: read (v, r), write (X, Y, Z)
-# PMC passes (profiles/r04_pmc_summary.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate runs at the bench's own shape, batch 65536 in
+# PMC passes (profiles/r05_pmc_summary.txt (r04_... before it): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate runs at the bench's own shape, batch 65536 in
 # chunks of 22016, tools/repro_profiles.sh), bytes per commitment through the L2's memory-side port, keyed by comb width.  24 bits (128-byte table
 # entries, 47 GB of tables): k_tom_commit + k_tom_commit_pairs fetch (7.673e7 + 5.016e7) KB for 103.88 M commitments = 1251 B raw, i.e. 2 x 1251 B
 # (gfx950 tallies 16-byte-per-lane loads at half their bytes, MI355X_MICROARCH.md section HBM; 20.3 gathers x 128 B = 2600 B expected; round 3's pass at
 # batch 16384 read 2 x 1310) + 111 B written.  16 bits (112-byte entries, 235 MB; round-1 pass): 3238 B (raw) + 111 B.
 TOM_COMMIT_PMC_BYTES = {24: 2502 + 111, 16: 3238 + 111}
-PMC_SOURCE = 'profiles/r04_pmc_summary.txt (separate rocprofv3 --pmc passes at batch 65536, chunk 22016; constants of bench.py, NOT measured in this run)'
+PMC_SOURCE = 'profiles/r05_pmc_summary.txt (separate rocprofv3 --pmc passes at batch 65536, chunk 22016; constants of bench.py, NOT measured in this run)'
 # same passes, SQ counters at 24 bits: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave at 2 waves per SIMD over both kernels, (3.251e10 + 2.157e10) /
 # (6.678e10 + 4.226e10) (VALU pipe busy 99 % of the time), SQ_WAIT_INST_ANY 0.377, SQ_WAIT_ANY (memory) 0.117
 TOM_COMMIT_VALU_ACTIVE_PER_WAVE = {24: 0.496}

@@ -19,7 +19,7 @@ FAMILIES = [
     ('tom_commit', r'k_tom_commit'),
     ('p256_exp_commit', r'k_exp_commit'),
     ('gk_fold', r'k_gk_(scalars|sort|asub|block|finish|cd_scalars|tile|level)|k_gkm_asub'),
-    ('hash', r'k_exp_challenge|k_gk_hash|k_padd_hash'),
+    ('hash', r'k_exp_challenge|k_exph_|k_gk_hash|k_padd_hash'),
     ('respond_write', r'k_write_|k_gk_respond|k_padd_respond|k_status_out'),
     ('tom_normalize', r'k_tom_normalize'),
     ('rng_prepass', r'k_rng_prepass'),
