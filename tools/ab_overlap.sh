@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5, GPU call 1: lane-scheduling A/Bs of the prover on one box + kernel traces of the baseline and of the heavy-queue schedule.
+# Round 5: lane-scheduling A/Bs of the prover on one box + kernel traces of the baseline and of the heavy-queue schedule.
 export GPU_MAX_HW_QUEUES=8
 mkdir -p gpurun_out/r05
 ROOT=$PWD
