@@ -14,7 +14,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
     V.gkx = (uint32_t*)k.take(12 * (size_t)C);
     size_t ns = (size_t)C * VK;
     V.idx = (uint32_t*)k.take(4 * ns);
-    V.vbytes = (uint8_t*)k.take(1536 * (size_t)C);
+    V.vbytes = (uint8_t*)k.take(V_SAMPLE_FILLS * (size_t)C);
     V.vc = (uint32_t*)k.take(4 * 18 * ns);
     V.vd = k.list(ns * 5);
     V.gk_f = k.soa((size_t)n * C), V.gk_g = k.soa((size_t)n * C);

@@ -183,6 +183,7 @@ struct Workspace {
 #ifndef ZK_WIDE_MAX_UNITS
 #define ZK_WIDE_MAX_UNITS 32768u
 #endif
+#define V_SAMPLE_FILLS 256  // verifier: one-byte fills of the sampler hashed up front per proof (k_verify.hip: k_v_sample_fills; the walk needs ~106 of them)
 #define EXPH_MAXP 256       // a verifier chunk of at most this many proofs hashes its Exp challenge on an auxiliary stream (api_verify.hip: small one-chunk calls)
 #define V_SLOT_SPLIT 4      // slot accumulators per checked repetition (k_v_straus: a slot's terms over up to 4 lanes)
 // per-proof sums of at most V_WIDE_MAXP proofs: ONE term per lane (a slot's 36 terms over 36 lanes, a membership group's 8 over 8), folded by

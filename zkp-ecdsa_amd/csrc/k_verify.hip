@@ -532,7 +532,11 @@ ZK_DEV void v_rho_range(const uint8_t* vseeds, uint64_t gp, uint32_t tag, Sq* ou
 // big.ts:171-181): about 256 * (H_80 - H_2) = 890 fills per proof, i.e. 890 SHA-256 blocks in sequence if computed on demand.
 // They do not depend on each other, so the first VS_KMAX fills of every proof are hashed in parallel here and k_v_sample
 // only walks the stored bytes (falling back to hashing on demand past VS_KMAX).
-#define VS_KMAX 1536
+// Round 5: only the FIRST VK entries of the permutation are ever read (exp.ts:261-264: `indices[j]`, j < secparam = 20), and Algorithm P fixes position i at
+// step i -- later steps swap positions >= i only -- so the walk stops after VK steps: ~73 one-byte draws over ranges 80..61 instead of ~890 over 80..3 (the
+// reference consumes the rest of its stream too, but nothing observable is drawn from it afterwards: the relation multipliers of multimult.ts only
+// randomise a boolean).  VS_KMAX = the fills hashed up front per proof: 2n + 1 + ~73 on average (sd ~14); past it the walk hashes on demand.
+#define VS_KMAX V_SAMPLE_FILLS
 __global__ void __launch_bounds__(256) k_v_sample_fills(VWork V, uint32_t count, const uint8_t* vseeds, uint64_t first) {
     uint32_t t = gtid();
     if (t >= count * VS_KMAX) return;
@@ -578,8 +582,9 @@ __global__ void __launch_bounds__(64) k_v_sample(VWork V, uint32_t count, const 
     for (uint32_t i = 0; i < V.sec; i++) PERM(i) = (uint8_t)i;
     // one byte per loop iteration for every lane (a nested retry loop would make each step wait for the unluckiest lane);
     // the stored bytes first, hashing on demand only past VS_KMAX (kept out of the hot loop)
+    const uint32_t steps = V.sec - 2 < VK ? V.sec - 2 : VK;   // positions 0 .. VK-1 are final after that many steps
     uint32_t i = 0;
-    while (i + 2 < V.sec && k < VS_KMAX) {
+    while (i < steps && k < VS_KMAX) {
         uint32_t range = V.sec - i, v = vb.get(k++);
         if (v < range) {
             uint8_t t = PERM(i);
@@ -587,7 +592,7 @@ __global__ void __launch_bounds__(64) k_v_sample(VWork V, uint32_t count, const 
             i++;
         }
     }
-    while (i + 2 < V.sec) {
+    while (i < steps) {
         v_fill(vseeds, gp, k++, w);
         uint32_t range = V.sec - i, v = w[7] >> 24;  // first byte of the fill
         if (v < range) {
