@@ -14,6 +14,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
     V.gkx = (uint32_t*)k.take(12 * (size_t)C);
     size_t ns = (size_t)C * VK;
     V.idx = (uint32_t*)k.take(4 * ns);
+    V.t1_act = (uint32_t*)k.take(8 * ns), V.t1_cnt = (uint32_t*)k.take(256);
     V.vbytes = (uint8_t*)k.take(V_SAMPLE_FILLS * (size_t)C);
     V.vc = (uint32_t*)k.take(4 * 18 * ns);
     V.vd = k.list(ns * 5);
@@ -239,7 +240,10 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
     {
         MaybeScope t(timed, c, "v_tom_fixed", s);
         launch_v_t1_scalars(s, W, V, cnt, d_proofs, d_off, first);
-        launch_tom_commit(s, P, W.la, cnt * 2 * VK, 2 * VK, 2 + 2 * W.sec);
+        // only the zero-bit repetitions have a T1 (exp.ts:299-330): k_v_t1_scalars lists their slots (about half of the 2 VK per proof) and gives the others the
+        // identity directly; a small chunk keeps the plain launch (its commitments run four lanes wide)
+        if (cnt * 2 * VK > ZK_WIDE_MAX_UNITS) launch_tom_commit_list(s, P, W.la, V.t1_act, V.t1_cnt, cnt * 2 * VK);
+        else launch_tom_commit(s, P, W.la, cnt * 2 * VK, 2 * VK, 2 + 2 * W.sec);
         launch_tom_normalize(s, W.la, cnt * 2 * VK, 0, 2 * VK, 2 + 2 * W.sec);
         launch_v_derived(s, W, V, cnt, d_proofs, d_off, first);
         launch_tom_normalize(s, V.vd, cnt * VK * 5, 0, 1, 1);

@@ -226,6 +226,8 @@ struct VWork {
     uint32_t* chal;       // [C][4] recomputed Exp challenge
     uint32_t* gkx;        // [C][3]
     uint32_t* idx;        // [C][VK] checked rep index | bit << 8
+    uint32_t* t1_act;     // [2 C VK] list-A slots whose commitment T1x / T1y the verifier must compute (zero-bit sampled repetitions of good proofs), compacted
+    uint32_t* t1_cnt;     // [1] their number (k_v_t1_scalars)
     uint8_t* vbytes;      // [C][1536] first byte of the verifier-RNG fills (k_v_sample_fills)
     uint32_t* vc;         // [C*VK][6][3] sub-proof challenges
     TomList vd;           // [C*VK*5] derived commitments (proj + affine)
@@ -354,6 +356,8 @@ static inline size_t heavy_lds_for(K kernel) {
 }
 // k_tom.hip
 void launch_tom_commit(hipStream_t s, const DevParams& P, const TomList& L, uint32_t count, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride = 0);
+// the commitments of the listed slots only (`list[i]`, i < *count_dev <= max_count: the verifier's T1x / T1y exist for zero-bit repetitions only)
+void launch_tom_commit_list(hipStream_t s, const DevParams& P, const TomList& L, const uint32_t* list, const uint32_t* count_dev, uint32_t max_count);
 void launch_tom_commit_listb(hipStream_t s, const DevParams& P, const TomList& L, uint32_t items, uint32_t kstride);  // the 34 commitments of every PointAdd item
 void launch_tom_normalize(hipStream_t s, const TomList& L, uint32_t count, uint32_t first, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride = 0);
 void launch_padd_derived(hipStream_t s, const Workspace& W, uint32_t items);

@@ -232,6 +232,26 @@ void launch_tom_commit_listb(hipStream_t s, const DevParams& P, const TomList& L
         hipLaunchKernelGGL(k_tom_commit_pairs<false>, dim3((n2 + 255) / 256), dim3(256), heavy_lds_for(k_tom_commit_pairs<false>), s, P.tom_tab_g, P.tom_tab_h, L, items, kstride, P.tom_bits, nwin);
     }
 }
+// k_tom_commit over a compacted list of slots (see launch_tom_commit_list): the grid covers the largest possible list, lanes past *count_dev leave at once
+template <bool SGN>
+__global__ void __launch_bounds__(256, 2) k_tom_commit_list(const uint32_t* __restrict__ tab_g, const uint32_t* __restrict__ tab_h, TomList L, const uint32_t* __restrict__ list,
+                                                            const uint32_t* __restrict__ count_dev, uint32_t bits, uint32_t nwin) {
+    const uint32_t c = gtid();
+    if (c >= *count_dev) return;
+    const uint32_t slot = list[c];
+    uint32_t vw[8], rw[8];
+    words_from_limbs<8>(vw, soa_ld<ModQ, 1>(L.v, slot).l);
+    words_from_limbs<8>(rw, soa_ld<ModQ, 1>(L.r, slot).l);
+    TomPt G = tom_comb_acc<true, false, SGN>(tom_identity(), tab_g, vw, bits, nwin);
+    TomPt A = tom_comb_acc<false, true, SGN>(G, tab_h, rw, bits, nwin);
+    soa_st(L.proj.x, slot, A.x), soa_st(L.proj.y, slot, A.y), soa_st(L.proj.z, slot, A.z);
+}
+void launch_tom_commit_list(hipStream_t s, const DevParams& P, const TomList& L, const uint32_t* list, const uint32_t* count_dev, uint32_t max_count) {
+    if (!max_count) return;
+    dim3 g((max_count + 255) / 256), b(256);
+    if (tom_signed(P.tom_bits)) hipLaunchKernelGGL(k_tom_commit_list<true>, g, b, 0, s, P.tom_tab_g, P.tom_tab_h, L, list, count_dev, P.tom_bits, tom_nwin(P.tom_bits));
+    else hipLaunchKernelGGL(k_tom_commit_list<false>, g, b, 0, s, P.tom_tab_g, P.tom_tab_h, L, list, count_dev, P.tom_bits, tom_nwin(P.tom_bits));
+}
 void launch_tom_commit(hipStream_t s, const DevParams& P, const TomList& L, uint32_t count, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride) {
     if (!count) return;
     if (tom_wide(P, count)) {

@@ -684,13 +684,29 @@ __global__ void __launch_bounds__(256) k_v_t1_scalars(Workspace W, VWork V, uint
     uint32_t e = t, slot = p * (2 + 2 * W.sec) + 2 * j;
     Sq zero = fe_zero<ModQ>();
     bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8) && V.exp_st[p] == ZK_OK;
-    if (good && !bit) {
+    const bool act = good && !bit;
+    if (act) {
         const uint8_t* rep = proofs + off[first + p] + rep_offset(V.hbits + 4 * p, i);
         soa_st(W.la.v, slot, soa_ld<ModQ, 1>(W.Tx, e)), soa_st(W.la.r, slot, ld_scalar_q(rep + 272));
         soa_st(W.la.v, slot + 1, soa_ld<ModQ, 1>(W.Ty, e)), soa_st(W.la.r, slot + 1, ld_scalar_q(rep + 304));
-    } else {
-        soa_st(W.la.v, slot, zero), soa_st(W.la.r, slot, zero);
-        soa_st(W.la.v, slot + 1, zero), soa_st(W.la.r, slot + 1, zero);
+    } else {   // commit(0; 0) = the identity: written here, so that the commitment kernel may leave these slots out (launch_tom_commit_list)
+        const TomPt id = tom_identity();
+        for (uint32_t q = 0; q < 2; q++) {
+            soa_st(W.la.v, slot + q, zero), soa_st(W.la.r, slot + q, zero);
+            soa_st(W.la.proj.x, slot + q, id.x), soa_st(W.la.proj.y, slot + q, id.y), soa_st(W.la.proj.z, slot + q, id.z);
+        }
+    }
+    // the slots that need a commitment, compacted (one atomic per wave; the order inside the list is irrelevant)
+    const uint64_t m = __ballot(act);
+    if (m) {
+        const uint32_t lane = threadIdx.x & 63;
+        uint32_t base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(V.t1_cnt, 2u * (uint32_t)__popcll(m));
+        base = __shfl(base, __builtin_ctzll(m), 64);
+        if (act) {
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            V.t1_act[base + 2 * below] = slot, V.t1_act[base + 2 * below + 1] = slot + 1;
+        }
     }
 }
 // derived commitments needed as hash inputs (pointAdd.ts:210-213,237,250): vd slot (p*VK+j)*5 + {C7, C9, C12, CintX, CintY}
@@ -1656,6 +1672,7 @@ void launch_v_exp_points(hipStream_t s, const Workspace& W, const VWork& V, uint
     L1(k_v_exp_status, count, 64, W, V, count);
 }
 void launch_v_t1_scalars(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    hipMemsetAsync(V.t1_cnt, 0, 4, s);
     L1(k_v_t1_scalars, count * VK, 256, W, V, count, proofs, off, first);
 }
 void launch_v_derived(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
