@@ -179,7 +179,7 @@ struct Workspace {
 #define MSM_NW_MAX 20
 // Table sums of a SMALL chunk run "wide": several lanes per sum, a range of windows each, partial sums added through the wave's cross-lane moves (rtab.h).  Up to
 // this many sums per launch -- four lanes each fill one residency of the GPU at two to three register-heavy waves per SIMD; beyond it the one-lane kernels,
-// whose lanes all work, are faster (zk_ctx_set... none: a compile-time constant, measured in profiles/r05_latency.txt).
+// whose lanes all work, are faster (a compile-time constant; same-box A/B and the size sweep in profiles/r05_ab_variants.txt (2)).
 #ifndef ZK_WIDE_MAX_UNITS
 #define ZK_WIDE_MAX_UNITS 32768u
 #endif
