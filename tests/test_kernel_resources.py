@@ -18,7 +18,6 @@ spec.loader.exec_module(kernel_meta)
 
 # kernels that may own a scratch frame: (substring of the mangled name, max bytes, reason)
 SCRATCH_OK = [
-    ('rocprim', 96, 'rocPRIM radix sort of the MSM keys (library code)'),
     ('k_synth_proofs', 96, 'workload generator of bench/tests, not on the prove/verify path'),
     ('k_v_gk_small', 192, 'rings of <= 4 keys only: dynamically indexed fold buffer'),
     # the out-of-line SHA-256 compression saves one callee-saved VGPR in its frame
@@ -51,6 +50,12 @@ def test_no_kernel_uses_agprs_or_spills_vgprs(kernels):
     assert not bad, bad
     mm = [k for n, k in kernels.items() if any(m in n for m in MATRIX_CORE)]
     assert len(mm) == 2 and all(k['agpr'] >= 252 and k['scratch'] == 0 and k['vgpr_spill'] == 0 for k in mm), mm
+
+
+def test_no_library_sort_in_the_code_object(kernels):
+    # round 5: the MSM keys are grouped by the engine's own counting passes (k_msm.hip); rounds 2-4 linked rocprim::radix_sort_pairs
+    assert not [n for n in kernels if 'rocprim' in n or 'hipcub' in n]
+    assert any('k_msm_binsort' in n for n in kernels) and any('k_msm_scatter' in n for n in kernels)
 
 
 def test_every_kernel_fits_two_waves_per_simd(kernels):
