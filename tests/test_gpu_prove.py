@@ -36,11 +36,12 @@ def test_prove_matches_oracle_small(nkeys, B):
 def test_lane_scheduling_knobs_do_not_change_the_bytes(monkeypatch):
     """The opt-in schedules of round 5 (profiles/r05_overlap.txt; read by zk_ctx_create): the commitment kernels of all lanes on one low-priority
     "heavy queue", stage 1 enqueued phase by phase across the lanes, the membership phase on the side stream behind the PointAdd commitments, lanes at
-    another priority, the commitment kernels padded to one workgroup per CU.  Same proofs as the default schedule, sliced and unsliced."""
+    another priority, the commitment kernels padded to one workgroup per CU, CU masks.  Same proofs as the default schedule, sliced and unsliced."""
     import zkp_ecdsa_amd as Z
 
     def run(env):
-        for k in ('ZKATTEST_HEAVY_FIFO', 'ZKATTEST_PHASE_MAJOR', 'ZKATTEST_GK_BESIDE', 'ZKATTEST_LANE_PRIO', 'ZKATTEST_HEAVY_LDS_KB', 'ZKATTEST_HEAVY_PRIO'):
+        for k in ('ZKATTEST_HEAVY_FIFO', 'ZKATTEST_PHASE_MAJOR', 'ZKATTEST_GK_BESIDE', 'ZKATTEST_LANE_PRIO', 'ZKATTEST_HEAVY_LDS_KB', 'ZKATTEST_HEAVY_PRIO',
+                  'ZKATTEST_LANE_CUS', 'ZKATTEST_HEAVY_CUS'):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -61,6 +62,7 @@ def test_lane_scheduling_knobs_do_not_change_the_bytes(monkeypatch):
     assert run({'ZKATTEST_HEAVY_FIFO': '1', 'ZKATTEST_PHASE_MAJOR': '1', 'ZKATTEST_GK_BESIDE': '1', 'ZKATTEST_LANE_PRIO': '-1,-1,-1,-1'}) == ref
     assert run({'ZKATTEST_HEAVY_FIFO': '2', 'ZKATTEST_GK_BESIDE': '1', 'ZKATTEST_HEAVY_PRIO': '0'}) == ref
     assert run({'ZKATTEST_LANE_PRIO': '-1,0,1', 'ZKATTEST_HEAVY_LDS_KB': '84'}) == ref
+    assert run({'ZKATTEST_HEAVY_FIFO': '1', 'ZKATTEST_HEAVY_CUS': '0-192', 'ZKATTEST_LANE_CUS': '192-256'}) == ref   # CU masks
 
 
 def test_uniform_control_flow_build_makes_the_same_bytes():

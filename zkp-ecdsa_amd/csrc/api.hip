@@ -99,9 +99,22 @@ static zk_status ctx_init(zk_ctx* c, int device_id) {
             if (*q == ',') q++;
         }
     }
+    // CU masks (experiment): ZKATTEST_LANE_CUS / ZKATTEST_HEAVY_CUS = "lo-hi" restrict the lanes' compute streams / the heavy queue to the
+    // mask bits [lo, hi) of 256 (the driver deals consecutive bits round-robin over the 8 XCDs, so a range of k bits is k / 8 CUs of every XCD).
+    auto cu_mask = [&](const char* name, uint32_t m[8]) -> bool {
+        const char* e = getenv(name);
+        int lo = 0, hi = 0;
+        if (!e || sscanf(e, "%d-%d", &lo, &hi) != 2 || lo < 0 || hi > 256 || lo >= hi) return false;
+        for (int i = 0; i < 8; i++) m[i] = 0;
+        for (int b = lo; b < hi; b++) m[b >> 5] |= 1u << (b & 31);
+        return true;
+    };
+    uint32_t lane_mask[8], heavy_mask[8];
+    const bool lanes_masked = cu_mask("ZKATTEST_LANE_CUS", lane_mask), heavy_masked = cu_mask("ZKATTEST_HEAVY_CUS", heavy_mask);
     for (int base = 0; base < ZK_MAX_LANES; base += 2) {   // compute 0, compute 1, copy 0, copy 1; then the same for lanes 2, 3
         for (int l = base; l < base + 2; l++) {
-            if (lane_prio[l]) HIPCHK(c, hipStreamCreateWithPriority(&c->pl[l].stream, hipStreamDefault, lane_prio[l]));
+            if (lanes_masked) HIPCHK(c, hipExtStreamCreateWithCUMask(&c->pl[l].stream, 8, lane_mask));
+            else if (lane_prio[l]) HIPCHK(c, hipStreamCreateWithPriority(&c->pl[l].stream, hipStreamDefault, lane_prio[l]));
             else HIPCHK(c, hipStreamCreate(&c->pl[l].stream));
         }
         for (int l = base; l < base + 2; l++) HIPCHK(c, hipStreamCreateWithFlags(&c->pl[l].copy_stream, hipStreamNonBlocking));
@@ -112,7 +125,8 @@ static zk_status ctx_init(zk_ctx* c, int device_id) {
     if (c->heavy_mode) {
         int hp = prio_lo;
         if (const char* e = getenv("ZKATTEST_HEAVY_PRIO")) hp = clamp_prio(atoi(e));
-        HIPCHK(c, hipStreamCreateWithPriority(&c->heavy, hipStreamNonBlocking, hp));
+        if (heavy_masked) HIPCHK(c, hipExtStreamCreateWithCUMask(&c->heavy, 8, heavy_mask));
+        else HIPCHK(c, hipStreamCreateWithPriority(&c->heavy, hipStreamNonBlocking, hp));
         for (int l = 0; l < ZK_MAX_LANES; l++)
             for (hipEvent_t* ev : {&c->pl[l].hv_to, &c->pl[l].hv_from, &c->pl[l].hv_to2, &c->pl[l].hv_from2}) HIPCHK(c, hipEventCreateWithFlags(ev, hipEventDisableTiming));
     }
