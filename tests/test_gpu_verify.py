@@ -374,3 +374,81 @@ def test_sixty_four_groups_give_the_same_verdicts_and_a_finer_fallback():
     # forged proofs sit in groups {0} + {0 or 1} + {3} + {7} of 8 (1024 proofs each) and in {0}, {0 or 1}, {31}, {63}, ... of 64 (128 each)
     assert res[64][1] < res[8][1] and res[64][1] <= 6 * (B // 64) and res[8][1] >= 3 * (B // 8)
     eng.close()
+
+
+def _rep_offsets(p, sec=80):
+    bits = int.from_bytes(p[16:32], 'big')
+    out, off = [], 304
+    for i in range(sec):
+        out.append(off)
+        off += 336 + (0 if (bits >> i) & 1 else 3392)
+    return out
+
+
+def _bad_p256_only(p):
+    """second response scalar of EVERY repetition (s_H of the P-256 relation, exp.ts:270-276 / 305-317): whichever repetitions the verifier samples,
+    the proof's P-256 sum is off while its Tom-256 relations may all hold"""
+    b = bytearray(p)
+    for o in _rep_offsets(p):
+        b[o + 240 + 31] ^= 1
+    return bytes(b)
+
+
+def test_p256_relations_summed_across_proofs_give_the_same_verdicts(monkeypatch):
+    """k_pmsm.hip (the P-256 half): chunks of at least ZKATTEST_P256_BATCH proofs (forced to 1 here) sum their P-256 relations per GROUP of
+    proofs with the bucket method.  Honest chunks must be settled by that pass alone (counter 3, no per-proof P-256 family in the timing); a proof whose
+    P-256 relation alone is broken must be found through the fallback; ragged chunks, empty groups, one and two lanes, 8 and 64 groups; the oracle agrees."""
+    monkeypatch.setenv('ZKATTEST_P256_BATCH', '1')
+    eng, octx, msg, proofs = _setup(4712, 32, 24)
+    monkeypatch.delenv('ZKATTEST_P256_BATCH')
+    B = 24
+    vs = _vseeds(B)
+    forged = list(proofs)
+    forged[5], forged[20] = _bad_p256_only(proofs[5]), _bad_p256_only(proofs[20])
+    want = ([0 if i in (5, 20) else 1 for i in range(B)], [0] * B)
+    eng.set_batch_verify(1)
+    for groups in (8, 64):
+        eng.set_verify_groups(groups)
+        for chunk, lanes in ((12, 1), (12, 2), (7, 2)):
+            eng.set_chunk(chunk), eng.set_lanes(lanes)
+            c3, c0 = eng.test_counter(3), eng.test_counter(0)
+            assert eng.verify_batch(msg, proofs, vseeds=vs) == ([1] * B, [0] * B), (groups, chunk, lanes)
+            fam = eng.last_timing()[1]
+            assert eng.test_counter(3) - c3 == B and eng.test_counter(0) == c0 and 'v_msm_p256' in fam and 'v_straus_p256' not in fam, (groups, chunk, lanes, fam)
+            c3 = eng.test_counter(3)
+            assert eng.verify_batch(msg, forged, vseeds=vs) == want, (groups, chunk, lanes)
+            good_chunks = sum(min(chunk, B - s) for s in range(0, B, chunk) if not (s <= 5 < s + chunk or s <= 20 < s + chunk))
+            assert eng.test_counter(3) - c3 == good_chunks and 'v_straus_p256' in eng.last_timing()[1]
+            assert eng.verify_batch(msg, proofs) == ([1] * B, [0] * B)   # OS-random seeds
+    assert octx.verify_batch(msg, forged, nthreads=8, vseeds=vs) == want
+    eng.close()
+
+
+def test_p256_cross_proof_pass_at_its_default_size():
+    """Two chunks of 8 192 proofs (the default threshold): groups of 1 024 proofs fill the buckets like the bench does -- the windows above bit 128 hold only
+    SL >> 128, a handful of values, so their buckets take the oversized path (k_pm_big).  Honest: settled by the pass; forgeries of the P-256 relation in the
+    first, a middle and the last group: found, and only their chunk pays the per-proof sums."""
+    import zkp_ecdsa_amd as Z
+    B, nkeys = 16384, 16384
+    eng = Z.Engine(0)
+    eng.set_comb_bits(16)
+    eng.set_params(*eng.synth_params(91), 80)
+    ring, msg, sig, pk, which, seeds = eng.synth_workload(91, nkeys, B)
+    eng.set_ring(ring, nkeys)
+    eng.set_chunk(8192), eng.set_lanes(2)
+    proofs, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert st == [0] * B
+    vs = _vseeds(B)
+    c3 = eng.test_counter(3)
+    assert eng.verify_batch(msg, proofs, vseeds=vs) == ([1] * B, [0] * B)
+    fam = eng.last_timing()[1]
+    assert eng.test_counter(3) - c3 == B and 'v_msm_p256' in fam and 'v_straus_p256' not in fam, fam
+    for bad in ((0,), (8191 + 3000,), (B - 1,), (1023, 1024)):
+        forged = list(proofs)
+        for b in bad:
+            forged[b] = _bad_p256_only(proofs[b])
+        c3 = eng.test_counter(3)
+        ok, vst = eng.verify_batch(msg, forged, vseeds=vs)
+        assert [b for b in range(B) if not ok[b]] == list(bad) and vst == [0] * B
+        assert eng.test_counter(3) - c3 == 8192   # the other chunk
+    eng.close()

@@ -151,6 +151,7 @@ static zk_status ctx_init(zk_ctx* c, int device_id) {
     if (const char* e = getenv("ZKATTEST_GK_MFMA_PROVE")) c->gk_mfma_prove = atoi(e) != 0;
     if (const char* e = getenv("ZKATTEST_VERIFY_GROUPS")) c->verify_groups = atoi(e) == 64 ? 64 : 8;
     if (const char* e = getenv("ZKATTEST_VERIFY_BATCH")) c->verify_batch_min = (uint32_t)atoi(e);
+    if (const char* e = getenv("ZKATTEST_P256_BATCH")) c->p256_batch_min = (uint32_t)atoi(e);   // chunk size from which the P-256 relations are summed across proofs (0 = never)
     if (const char* e = getenv("ZKATTEST_LANES")) {
         int l = atoi(e);
         if (l >= 1 && l <= ZK_MAX_LANES) c->lanes = (uint32_t)l;

@@ -556,5 +556,5 @@ extern "C" uint64_t zk_test_counter(const zk_ctx* c, int which) {
         for (uint8_t v : u) n += v != 0;
         return n;
     }
-    return which == 0 ? c->dbg_recheck_proofs : which == 2 ? c->dbg_msm_terms : 0;
+    return which == 0 ? c->dbg_recheck_proofs : which == 2 ? c->dbg_msm_terms : which == 3 ? c->dbg_p256_batched : 0;
 }

@@ -2,7 +2,8 @@
 #include "ctx.h"
 #include "jobs.h"
 
-static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, uint32_t C, uint32_t sec, uint32_t n, uint64_t N, bool want_msm, uint32_t want_groups) {
+static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, PMsmBuf& PM, uint8_t* base, uint32_t C, uint32_t sec, uint32_t n, uint64_t N, bool want_msm, bool want_pm,
+                     uint32_t want_groups) {
     Carver k(base);
     V.C = C, V.sec = sec, V.n = n;
     V.st = (int32_t*)k.take(4 * (size_t)C);
@@ -41,6 +42,12 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
     V.pacc = k.soa3(std::max<size_t>((size_t)C * (VK / 5 + 1), std::min<size_t>(C, V_SIDE_MAXP) * (VK + 1)));
     V.clx = k.soa(C), V.cly = k.soa(C);
     V.cl_tab = (uint32_t*)k.take((size_t)C * 8 * RTAB_ENTRY_WORDS * 4), V.cl_dig = (uint8_t*)k.take((size_t)C * 35), V.p256_ok = (uint32_t*)k.take(4 * (size_t)C);
+    PM = PMsmBuf{};
+    if (want_pm) {   // cross-proof P-256 pass (k_pmsm.hip): it runs INSTEAD of the per-proof window tables, so it lives in their memory where that is large enough
+        const size_t need = pmsm_carve(nullptr, nullptr, C, want_groups), have = ns * 8 * RTAB_ENTRY_WORDS * 4;
+        uint8_t* at = need <= have ? (uint8_t*)V.pa_tab : (uint8_t*)k.take(need);
+        if (base) pmsm_carve(&PM, at, C, want_groups);
+    }
     M = MsmBuf{};
     if (want_msm) {   // batched Tom check (k_msm.hip): ~1.5 GB per lane, only where chunks are large enough to use it
         size_t cap = ns * V_SLOT_TERMS + (size_t)C * nq * 8 + (size_t)C * 3;
@@ -72,21 +79,22 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, uint8_t* base, ui
 zk_status ensure_vworkspace(zk_ctx* c, uint32_t C, uint32_t nlanes) {
     uint32_t sec = c->P.sec, n = c->n;
     const bool want_msm = c->verify_batch_min && C >= c->verify_batch_min;   // the chunk-wide sums never run on smaller chunks
-    if (!(c->vs_C == C && c->vs_sec == sec && c->vs_n == n && c->vs_msm == want_msm && c->vs_groups == c->verify_groups)) {
+    const bool want_pm = want_msm && c->p256_batch_min && C >= c->p256_batch_min;
+    if (!(c->vs_C == C && c->vs_sec == sec && c->vs_n == n && c->vs_msm == want_msm && c->vs_pm == want_pm && c->vs_groups == c->verify_groups)) {
         for (auto& L : c->vl) L.ready = false;
-        c->vs_C = C, c->vs_sec = sec, c->vs_n = n, c->vs_msm = want_msm, c->vs_groups = c->verify_groups;
+        c->vs_C = C, c->vs_sec = sec, c->vs_n = n, c->vs_msm = want_msm, c->vs_pm = want_pm, c->vs_groups = c->verify_groups;
     }
     for (uint32_t l = 0; l < nlanes && l < ZK_MAX_LANES; l++) {
         auto& L = c->vl[l];
         if (L.ready) continue;
-        size_t need = vcarve(L.V, L.res, L.res2, L.M, nullptr, C, sec, n, c->N, want_msm, c->verify_groups);
+        size_t need = vcarve(L.V, L.res, L.res2, L.M, L.PM, nullptr, C, sec, n, c->N, want_msm, want_pm, c->verify_groups);
         if (need > L.arena_bytes) {
             if (L.arena) HIPCHK(c, hipFree(L.arena));
             L.arena = nullptr, L.arena_bytes = 0;
             HIPCHK(c, malloc_or_shed(c, &L.arena, need));
             L.arena_bytes = need;
         }
-        vcarve(L.V, L.res, L.res2, L.M, (uint8_t*)L.arena, C, sec, n, c->N, want_msm, c->verify_groups);
+        vcarve(L.V, L.res, L.res2, L.M, L.PM, (uint8_t*)L.arena, C, sec, n, c->N, want_msm, want_pm, c->verify_groups);
         if (!L.h_msm) HIPCHK(c, hipHostMalloc((void**)&L.h_msm, 1024, hipHostMallocMapped | hipHostMallocCoherent));
         if (!L.aux_fork) HIPCHK(c, hipEventCreateWithFlags(&L.aux_fork, hipEventDisableTiming));
         for (int i = 0; i < V_AUX_STREAMS; i++) {
@@ -261,7 +269,7 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
         MaybeScope t(timed, c, "v_terms", s);
         launch_v_terms(s, W, V, cnt, d_proofs, d_off, d_vseeds, first);
     }
-    if (!small) {   // (a small chunk's P-256 sums run in stage 2, one term per lane, beside its Tom-256 sums)
+    if (!small && !p256_batched(cnt, lane)) {   // (a small chunk's P-256 sums run in stage 2, one term per lane, beside its Tom-256 sums; a large one's across proofs)
         MaybeScope t(timed, c, "v_straus_p256", s);
         launch_v_p256_straus(s, V, cnt, 5);
     }
@@ -358,6 +366,20 @@ zk_status VerifyJob::stage2(uint64_t chunk_no) {
         }
         HIPCHK(c, hipEventRecord(A.aux_done[3], A.aux[3]));
     }
+    // P-256 relation: one bucket-method sum per group as well (k_pmsm.hip), on an auxiliary stream beside the Tom-256 pass; its verdicts arrive with that
+    // pass's (one host round trip).  A group that fails sends the chunk through the per-proof sums.
+    const bool pm = p256_batched(cnt, lane);
+    uint32_t* pm_flags = A.h_msm + 128;
+    if (pm) {
+        if (timed) c->timing_forked = true;
+        HIPCHK(c, hipEventRecord(A.aux_fork, s));
+        HIPCHK(c, hipStreamWaitEvent(A.aux[3], A.aux_fork, 0));
+        {
+            MaybeScope t(timed, c, "v_msm_p256", A.aux[3]);
+            run_pmsm(A.aux[3], P, W, V, cnt, A.PM, G, pm_flags);
+        }
+        HIPCHK(c, hipEventRecord(A.aux_done[3], A.aux[3]));
+    }
     if (c->verify_batch_min && cnt >= c->verify_batch_min && M.cap) {
         MaybeScope t(timed, c, "v_msm_tom", s);
         TimerRec sub{"+v_msm_bucket", nullptr, nullptr};   // a part of v_msm_tom ('+': not added to the total again)
@@ -393,9 +415,22 @@ zk_status VerifyJob::stage2(uint64_t chunk_no) {
         g = g1;
     }
     if (wide_chunk) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[3], 0));
+    bool pm_passed = false;
+    if (pm) {
+        HIPCHK(c, hipEventSynchronize(A.aux_done[3]));
+        HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[3], 0));
+        pm_passed = true;
+        for (uint32_t g = 0; g < G && (uint64_t)g * gsz < cnt; g++) pm_passed = pm_passed && pm_flags[g] == 1;
+        c->dbg_p256_batched += pm_passed ? cnt : 0;
+        if (pm_passed) launch_pm_all_ok(s, V, cnt);
+        else {
+            MaybeScope t(timed, c, "v_straus_p256", s);
+            launch_v_p256_straus(s, V, cnt, 5);
+        }
+    }
     {
         MaybeScope t(timed, c, "v_final", s);
-        if (!wide_chunk) launch_v_p256_total(s, P, W, V, cnt, 5);
+        if (!wide_chunk && !pm_passed) launch_v_p256_total(s, P, W, V, cnt, 5);
         launch_v_final(s, W, V, cnt, d_ok, d_status, first, gf, gsz);
     }
     return ZK_OK;

@@ -83,13 +83,16 @@ struct zk_ctx {
         Soa res{}, res2{};
         MsmBuf M{};               // batched Tom check buffers (k_msm.hip), carved with V
         uint32_t* h_msm = nullptr;   // page-locked read-back words of run_msm
+        PMsmBuf PM{};             // cross-proof P-256 pass (k_pmsm.hip); PM.aos == nullptr: not carved (chunks below p256_batch_min)
         hipStream_t aux[V_AUX_STREAMS] = {};   // small batches: the independent per-proof sums run side by side (api_verify.hip: per_proof_range)
         hipEvent_t aux_fork = nullptr, aux_done[V_AUX_STREAMS] = {};
         bool ready = false;
     } vl[ZK_MAX_LANES];
     uint32_t vs_C = 0, vs_sec = 0, vs_n = 0;
+    uint32_t p256_batch_min = 8192;   // chunks of at least this many proofs sum their P-256 relations across proofs too (ZKATTEST_P256_BATCH; 0 = never)
     uint32_t verify_groups = 8;   // groups per chunk of the batched Tom check: 8 (16-bit windows) or 64 (13-bit windows); zk_ctx_set_verify_groups
     uint32_t vs_groups = 8;       // ... the lanes' workspaces were carved for
+    bool vs_pm = false;           // ... and of the cross-proof P-256 pass
     bool vs_msm = false;          // the lanes' workspaces hold the buffers of the batched Tom check
     uint32_t verify_batch_min = 256;   // zk_ctx_set_batch_verify: chunks of at least this many proofs get the batched check (0 = never)
     // host-buffer entry points: DMA stream for page-locked caller buffers (zk_host_alloc), one event per lane
@@ -117,6 +120,7 @@ struct zk_ctx {
     std::vector<Spare> spare_dev, spare_pinned;
     // unit-test counters (zk_test_counter): work done, so that tests can assert on counts instead of timings
     uint64_t dbg_recheck_proofs = 0;   // proofs that went through the verifier's per-proof sums since the context was created
+    uint64_t dbg_p256_batched = 0;     // proofs whose P-256 relation was accepted by the cross-proof pass (k_pmsm.hip) since the context was created
     uint64_t dbg_msm_terms = 0;        // live terms that went through the batched Tom-256 check (k_msm.hip) since the context was created
     // timing
     std::vector<TimerRec> trecs;

@@ -318,7 +318,26 @@ struct MsmBuf {
     uint32_t* host;        // page-locked host words (live-term count, group verdicts): a pageable destination makes the runtime
                            // wait for every stream of the device, i.e. for the other lanes' kernels
 };
+// buffers of the cross-proof P-256 pass (k_pmsm.hip)
+#define PM_NW_MAX 14
+struct PMsmBuf {
+    uint32_t ncap, gcap;       // term ids (C * 21); ids per (window, group) list
+    uint32_t* aos;             // [ncap][16] affine entries (ktab.h format)
+    uint16_t* dig;             // [windows][ncap] digits
+    uint32_t* vals;            // [windows * groups][gcap] term ids grouped by digit
+    uint32_t *start, *end;     // [windows * groups * 2^C] a bucket's segment of its (window, group) list
+    uint32_t* order;           // [windows * groups * 2^C] buckets of a (window, group), largest first
+    uint32_t* buckets;         // [windows * groups * 2^C][28]
+    uint32_t* big_list;        // oversized buckets
+    uint32_t* Tw;              // [windows * groups][28]
+    uint32_t *rpart, *shpart;  // per 64 proofs of a group: sum of SR * R, sum of SH
+    uint32_t *counters, *flag; // counters[1]: a scalar beyond the windows, counters[2]: oversized buckets; flag[g]
+};
 // ------------------------------------------------------------------ launch wrappers (one per kernel family)
+// k_pmsm.hip: carve (base == nullptr: size only); enqueue the pass (no host round trip of its own: host_flags_pinned[g] is valid once s has drained)
+size_t pmsm_carve(PMsmBuf* M, uint8_t* base, uint32_t Ccap, uint32_t groups);
+void run_pmsm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const PMsmBuf& M, uint32_t groups, uint32_t* host_flags_pinned);
+void launch_pm_all_ok(hipStream_t s, const VWork& V, uint32_t count);
 // k_msm.hip
 size_t msm_workspace_bytes(uint32_t cap);
 // host_flags[g] = 1: the Tom-256 total of group g (proofs [g * gsz, (g + 1) * gsz) of the chunk) is the identity; M.flag holds the same on the device
@@ -498,6 +517,34 @@ ZK_DEV uint32_t lbi(const Workspace& W, uint32_t item, uint32_t k) { return k * 
 
 // ------------------------------------------------------------------ small device helpers shared by TUs
 ZK_DEV uint32_t gtid() { return blockIdx.x * blockDim.x + threadIdx.x; }
+// exclusive prefix sum over the workgroup (blockDim.x a multiple of 64, at most 1024); tot = the workgroup's total.  sh: 17 words of LDS.
+ZK_DEV uint32_t block_excl_scan(uint32_t v, uint32_t* sh, uint32_t& tot) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= (uint32_t)o) inc += t;
+    }
+    if (lane == 63) sh[wv] = inc;
+    __syncthreads();
+    if (wv == 0) {
+        const uint32_t sv = lane < nwv ? sh[lane] : 0;
+        uint32_t si = sv;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const uint32_t t = __shfl_up(si, o, 64);
+            if (lane >= (uint32_t)o) si += t;
+        }
+        if (lane < nwv) sh[lane] = si - sv;
+        if (lane == nwv - 1) sh[16] = si;
+    }
+    __syncthreads();
+    const uint32_t r = sh[wv] + inc - v;
+    tot = sh[16];
+    __syncthreads();
+    return r;
+}
 // big-endian load of a 32-byte integer into 8 little-endian words
 ZK_DEV void load_be32(const uint8_t* p, uint32_t w[8]) {
     const uint32_t* q = (const uint32_t*)p;

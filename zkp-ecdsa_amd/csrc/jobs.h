@@ -124,6 +124,10 @@ struct VerifyJob {
     // a call of ONE small chunk is a chain of latencies on an idle GPU: its independent phases go to the lane's auxiliary streams.  (Chunks of a longer job
     // overlap each other on the lanes already; there the extra streams only compete with the copy stream: 294 k -> 196 k verifies/s at 8 x 8192 proofs.)
     bool side_streams(uint32_t cnt) const { return plan.size() == 1 && cnt <= V_SIDE_MAXP; }
+    // the chunk's P-256 relations are summed across proofs (k_pmsm.hip) instead of per proof
+    bool p256_batched(uint32_t cnt, uint32_t lane) const {
+        return !side_streams(cnt) && c->verify_batch_min && cnt >= c->verify_batch_min && c->p256_batch_min && cnt >= c->p256_batch_min && c->vl[lane].PM.aos && c->vl[lane].M.cap;
+    }
     const uint64_t* off_of(uint64_t k) const { return d_packed ? d_uoff + k : d_off; }   // what the kernels index with [first + p]
     zk_status plan_unpack();             // ubase from the packed offsets of the chunks' first proofs (host copy, or read back from d_poff)
     zk_status enqueue_h2d();             // all chunks' bytes up front, one event per chunk

@@ -94,34 +94,6 @@ __global__ void __launch_bounds__(256) k_msm_pack(VWork V, MsmDims D, uint32_t* 
 #define MSM_NLOW (1u << MSM_LB)                 // keys per bin
 #define MSM_SORT_G 512u                         // workgroups of pass A: each owns a contiguous range of term ids
 #define MSM_SORT_T 1024u                        // their threads
-// exclusive prefix sum over the workgroup (blockDim.x a multiple of 64, at most 1024); tot = the workgroup's total.  sh: 17 words of LDS.
-ZK_DEV uint32_t block_excl_scan(uint32_t v, uint32_t* sh, uint32_t& tot) {
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o, 64);
-        if (lane >= (uint32_t)o) inc += t;
-    }
-    if (lane == 63) sh[wv] = inc;
-    __syncthreads();
-    if (wv == 0) {
-        const uint32_t sv = lane < nwv ? sh[lane] : 0;
-        uint32_t si = sv;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            const uint32_t t = __shfl_up(si, o, 64);
-            if (lane >= (uint32_t)o) si += t;
-        }
-        if (lane < nwv) sh[lane] = si - sv;
-        if (lane == nwv - 1) sh[16] = si;
-    }
-    __syncthreads();
-    const uint32_t r = sh[wv] + inc - v;
-    tot = sh[16];
-    __syncthreads();
-    return r;
-}
 // the scalar of term `id` as eight 32-bit words if the term takes part in the chunk's sum (live group, scalar != 0)
 ZK_DEV bool msm_term_words(const VWork& V, const MsmDims& D, uint32_t id, uint32_t w8[8], uint32_t& proof) {
     if (id >= D.n0 + D.n1 + D.n2) return false;
