@@ -269,7 +269,10 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
         MaybeScope t(timed, c, "v_terms", s);
         launch_v_terms(s, W, V, cnt, d_proofs, d_off, d_vseeds, first);
     }
-    if (!small && !p256_batched(cnt, lane)) {   // (a small chunk's P-256 sums run in stage 2, one term per lane, beside its Tom-256 sums; a large one's across proofs)
+    if (p256_batched(cnt, lane)) {   // a large chunk sums its P-256 relations across proofs (k_pmsm.hip): entries, digits, counting sort and the R parts here
+        MaybeScope t(timed, c, "v_msm_p256", s);
+        pmsm_prepare(s, W, V, cnt, A.PM, c->vs_groups);
+    } else if (!small) {   // (a small chunk's P-256 sums run in stage 2, one term per lane, beside its Tom-256 sums)
         MaybeScope t(timed, c, "v_straus_p256", s);
         launch_v_p256_straus(s, V, cnt, 5);
     }
@@ -370,13 +373,13 @@ zk_status VerifyJob::stage2(uint64_t chunk_no) {
     // pass's (one host round trip).  A group that fails sends the chunk through the per-proof sums.
     const bool pm = p256_batched(cnt, lane);
     uint32_t* pm_flags = A.h_msm + 128;
-    if (pm) {
+    if (pm) {   // the bucket sums are arithmetic: they run beside the Tom-256 pass's grouping kernels, which are not
         if (timed) c->timing_forked = true;
         HIPCHK(c, hipEventRecord(A.aux_fork, s));
         HIPCHK(c, hipStreamWaitEvent(A.aux[3], A.aux_fork, 0));
         {
             MaybeScope t(timed, c, "v_msm_p256", A.aux[3]);
-            run_pmsm(A.aux[3], P, W, V, cnt, A.PM, G, pm_flags);
+            pmsm_sums(A.aux[3], P, cnt, A.PM, G, pm_flags);
         }
         HIPCHK(c, hipEventRecord(A.aux_done[3], A.aux[3]));
     }

@@ -334,9 +334,11 @@ struct PMsmBuf {
     uint32_t *counters, *flag; // counters[1]: a scalar beyond the windows, counters[2]: oversized buckets; flag[g]
 };
 // ------------------------------------------------------------------ launch wrappers (one per kernel family)
-// k_pmsm.hip: carve (base == nullptr: size only); enqueue the pass (no host round trip of its own: host_flags_pinned[g] is valid once s has drained)
+// k_pmsm.hip: carve (base == nullptr: size only); the pass in two parts (no host round trip of its own: host_flags_pinned[g] is valid once the stream of
+// pmsm_sums has drained)
 size_t pmsm_carve(PMsmBuf* M, uint8_t* base, uint32_t Ccap, uint32_t groups);
-void run_pmsm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const PMsmBuf& M, uint32_t groups, uint32_t* host_flags_pinned);
+void pmsm_prepare(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const PMsmBuf& M, uint32_t groups);
+void pmsm_sums(hipStream_t s, const DevParams& P, uint32_t count, const PMsmBuf& M, uint32_t groups, uint32_t* host_flags_pinned);
 void launch_pm_all_ok(hipStream_t s, const VWork& V, uint32_t count);
 // k_msm.hip
 size_t msm_workspace_bytes(uint32_t cap);

@@ -24,7 +24,7 @@
 #define PM_TERMS (VK + 1)
 #define PM_SCALAR_BITS 134u   // SL is the sum of at most 20 values below 2^128; k_pm_pack checks the bound on every scalar
 #define PM_PT_WORDS 28
-#define PM_BIG 192u           // terms above which a bucket is summed by a workgroup
+#define PM_BIG 64u            // terms above which a bucket is summed by a workgroup
 #define PM_BIG_MAX 2048u
 template <int C>
 struct PmShape {
@@ -187,7 +187,7 @@ template <int C>
 __global__ void __launch_bounds__(256) k_pm_reduce(PMsmBuf M) {
     typedef PmShape<C> S;
     constexpr uint32_t PER = S::nb / 256;
-    __shared__ uint32_t shF[27 * 128], shG[27 * 128];
+    __shared__ uint32_t sh[27 * 128];   // (F and G take turns: 13.8 KB fit on a CU beside a workgroup of the Tom-256 pass's k_msm_binsort, 27.6 would not)
     const uint32_t wg = blockIdx.x, t = threadIdx.x;
     const uint32_t* b = M.buckets + ((size_t)wg * S::nb + (size_t)t * PER) * PM_PT_WORDS;
     P256Pt run = p256_identity(), acc = p256_identity();
@@ -203,14 +203,18 @@ __global__ void __launch_bounds__(256) k_pm_reduce(PMsmBuf M) {
     for (uint32_t o = 1; o < 256; o <<= 1, logm++) {   // segments of o threads: the right one of each pair hands (F, G) to the left one
         const bool right = (t & (2 * o - 1)) == o, left = (t & (2 * o - 1)) == 0;
         __syncthreads();
-        if (right) pm_sh_st(shF, 128, t / (2 * o), acc), pm_sh_st(shG, 128, t / (2 * o), run);
+        if (right) pm_sh_st(sh, 128, t / (2 * o), run);
+        __syncthreads();
+        P256Pt gr = p256_identity();
+        if (left) gr = pm_sh_ld(sh, 128, t / (2 * o));
+        __syncthreads();
+        if (right) pm_sh_st(sh, 128, t / (2 * o), acc);
         __syncthreads();
         if (left) {
-            P256Pt gr = pm_sh_ld(shG, 128, t / (2 * o));
             run = p256_add(run, gr);
 #pragma unroll 1
             for (uint32_t k = 0; k < logm; k++) gr = p256_dbl(gr);
-            acc = p256_add(p256_add(acc, pm_sh_ld(shF, 128, t / (2 * o))), gr);
+            acc = p256_add(p256_add(acc, pm_sh_ld(sh, 128, t / (2 * o))), gr);
         }
     }
     if (t == 0) pm_st(M.Tw + (size_t)wg * PM_PT_WORDS, acc);
@@ -343,24 +347,36 @@ size_t pmsm_carve(PMsmBuf* M, uint8_t* base, uint32_t Ccap, uint32_t groups) {
     if (M) *M = m;
     return off;
 }
+// part 1 (stage 1 of the chunk, on its stream): everything that needs no arithmetic throughput -- entries and digits, the counting sort, the R parts
 template <int C>
-static void run_pmsm_t(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t G, PMsmBuf M, uint32_t* host_flags_pinned) {
+static void pmsm_prepare_t(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, uint32_t G, PMsmBuf M) {
     typedef PmShape<C> S;
     const uint32_t gsz = (count + G - 1) / G, PB = (gsz + 63) / 64;
     M.gcap = gsz * PM_TERMS;
     hipMemsetAsync(M.counters, 0, 256, s);
     hipLaunchKernelGGL(k_pm_pack<C>, dim3((count * PM_TERMS + 255) / 256), dim3(256), 0, s, V, count, M);
     hipLaunchKernelGGL(k_pm_group<C>, dim3(S::nw, G), dim3(1024), 0, s, V, count, gsz, M);
+    hipLaunchKernelGGL(k_pm_rpart, dim3(PB, G), dim3(64), 0, s, W, V, count, gsz, M);
+}
+// part 2 (stage 2, beside the Tom-256 pass): the bucket sums and their reduction
+template <int C>
+static void pmsm_sums_t(hipStream_t s, const DevParams& P, uint32_t count, uint32_t G, PMsmBuf M, uint32_t* host_flags_pinned) {
+    typedef PmShape<C> S;
+    const uint32_t gsz = (count + G - 1) / G, PB = (gsz + 63) / 64;
+    M.gcap = gsz * PM_TERMS;
     hipLaunchKernelGGL(k_pm_bucket<C>, dim3(S::nw * G * S::nb / 256), dim3(256), 0, s, M);
     hipLaunchKernelGGL(k_pm_big<C>, dim3(256), dim3(256), 0, s, M);
     hipLaunchKernelGGL(k_pm_reduce<C>, dim3(S::nw * G), dim3(256), 0, s, M);
-    hipLaunchKernelGGL(k_pm_rpart, dim3(PB, G), dim3(64), 0, s, W, V, count, gsz, M);
     hipLaunchKernelGGL(k_pm_final<C>, dim3(G), dim3(128), 0, s, P, PB, G, M);
     launch_words_to_host(s, host_flags_pinned, M.flag, G);
 }
-// Enqueues the pass on s; host_flags_pinned[g] (page-locked) = 1 once s has drained: the P-256 total of group g (proofs [g * gsz, (g + 1) * gsz), gsz =
-// ceil(count / groups) as in run_msm) is the identity.
-void run_pmsm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const PMsmBuf& M, uint32_t groups, uint32_t* host_flags_pinned) {
-    if (groups == 64) run_pmsm_t<10>(s, P, W, V, count, groups, M, host_flags_pinned);
-    else run_pmsm_t<13>(s, P, W, V, count, groups, M, host_flags_pinned);
+void pmsm_prepare(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const PMsmBuf& M, uint32_t groups) {
+    if (groups == 64) pmsm_prepare_t<10>(s, W, V, count, groups, M);
+    else pmsm_prepare_t<13>(s, W, V, count, groups, M);
+}
+// host_flags_pinned[g] (page-locked) = 1 once s has drained: the P-256 total of group g (proofs [g * gsz, (g + 1) * gsz), gsz = ceil(count / groups) as in
+// run_msm) is the identity.  No host round trip of its own.
+void pmsm_sums(hipStream_t s, const DevParams& P, uint32_t count, const PMsmBuf& M, uint32_t groups, uint32_t* host_flags_pinned) {
+    if (groups == 64) pmsm_sums_t<10>(s, P, count, groups, M, host_flags_pinned);
+    else pmsm_sums_t<13>(s, P, count, groups, M, host_flags_pinned);
 }
