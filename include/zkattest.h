@@ -135,7 +135,10 @@ zk_status zk_ctx_set_slice(zk_ctx *ctx, uint32_t proofs);
  * a chunk is cut into 8 (or 64: zk_ctx_set_verify_groups) contiguous groups of proofs whose sums come out of the same pass, and only
  * the groups whose sum is not the identity -- some proof of theirs is bad -- go through the per-proof sums to tell which.  ok[] and the
  * statuses are the same either way; a forged proof costs the per-proof sums of its group, and the chunk-wide sum has a fixed
- * cost of a few milliseconds, hence the threshold.  0 = never, 1 = always.  (ZKATTEST_VERIFY_BATCH) */
+ * cost of a few milliseconds, hence the threshold.  0 = never, 1 = always.  (ZKATTEST_VERIFY_BATCH)
+ * Chunks of at least 8192 proofs (ZKATTEST_P256_BATCH, read by zk_ctx_create; 0 = never) that take this path sum their P-256 relations the same way, per group,
+ * beside the Tom-256 sums; if a group's P-256 total is not the identity the chunk's P-256 relations are checked per proof (zk_test_counter 3 counts the
+ * proofs settled by the pass). */
 zk_status zk_ctx_set_batch_verify(zk_ctx *ctx, uint32_t min_chunk);
 /* Groups per chunk of that check: 8 (default; 16-bit windows) or 64 (13-bit windows: 25 % more bucket additions and four more sorts on
  * every chunk -- about 8 % of the device-resident verification rate at the headline shape, nothing where the PCIe link is the
