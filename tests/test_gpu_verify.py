@@ -451,4 +451,12 @@ def test_p256_cross_proof_pass_at_its_default_size():
         ok, vst = eng.verify_batch(msg, forged, vseeds=vs)
         assert [b for b in range(B) if not ok[b]] == list(bad) and vst == [0] * B
         assert eng.test_counter(3) - c3 == 8192   # the other chunk
+    # the same with 64 groups of 128 proofs (10-bit digits, 14 windows)
+    eng.set_verify_groups(64)
+    c3 = eng.test_counter(3)
+    assert eng.verify_batch(msg, proofs, vseeds=vs) == ([1] * B, [0] * B) and eng.test_counter(3) - c3 == B
+    forged = list(proofs)
+    forged[127], forged[B - 129] = _bad_p256_only(proofs[127]), _bad_p256_only(proofs[B - 129])
+    ok, vst = eng.verify_batch(msg, forged, vseeds=vs)
+    assert [b for b in range(B) if not ok[b]] == [127, B - 129] and vst == [0] * B
     eng.close()
