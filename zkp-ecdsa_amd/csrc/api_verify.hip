@@ -23,12 +23,18 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, PMsmBuf& PM, uint
     V.gk_total = k.soa(C);
     V.gk_csub = (uint32_t*)k.take(n >= GK_ETAB_MINN && n <= GK_ETAB_MAXN ? std::max<size_t>(36 * 256 * (size_t)C, n >= GKM_MINN ? gkm_coef_frag_bytes(C) : 0) : 16);
     V.gk_swap = (uint32_t*)k.take(4 * (size_t)n * C);
+    size_t nq = (n + 1) / 2;
+    // the points of the three term lists are ONE array of 128-byte entries (slot terms, membership terms, the three per proof): a term's number in it is
+    // its id in the bucket pass (k_msm.hip), which gathers these entries as they are
+    const size_t tcap = ns * V_SLOT_TERMS + (size_t)C * nq * 8 + (size_t)C * 3;
+    uint32_t* pts = (uint32_t*)k.take(tcap * VT_ENTRY_WORDS * 4);
+    size_t pts_off = 0;
     auto terms = [&](size_t cnt) {
-        VTerms t{k.soa(cnt), k.soa(cnt), k.soa(cnt), k.soa(cnt), (uint32_t*)k.take(cnt * 8 * 36 * 4), (uint8_t*)k.take(cnt * 65), (uint32_t)cnt};
+        VTerms t{pts ? pts + pts_off * VT_ENTRY_WORDS : nullptr, k.soa(cnt), (uint32_t*)k.take(cnt * 8 * 36 * 4), (uint8_t*)k.take(cnt * 65), (uint32_t)cnt};
+        pts_off += cnt;
         return t;
     };
     auto soa4 = [&](size_t cnt) { return Soa4{k.soa(cnt), k.soa(cnt), k.soa(cnt), k.soa(cnt)}; };
-    size_t nq = (n + 1) / 2;
     V.slot_terms = terms(ns * V_SLOT_TERMS);
     V.slot_class = (uint8_t*)k.take(ns), V.slot_perm = (uint32_t*)k.take(4 * ns), V.slot_cnt = (uint32_t*)k.take(8 * (MSM_G_MAX + 1));
     V.gk_terms = terms((size_t)C * nq * 8);
@@ -52,7 +58,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, PMsmBuf& PM, uint
     if (want_msm) {   // batched Tom check (k_msm.hip): ~1.5 GB per lane, only where chunks are large enough to use it
         size_t cap = ns * V_SLOT_TERMS + (size_t)C * nq * 8 + (size_t)C * 3;
         M.cap = (uint32_t)cap;
-        M.aos = (uint32_t*)k.take(cap * 128);
+        M.aos = pts;   // (== V.slot_terms.pts: no copy)
         // sized for either shape of the pass: 16 windows x (8 groups x 2^16 digits) or 20 windows x (64 groups x 2^13 digits)
         const size_t NW = want_groups == 64 ? 20 : 16, NBG = (size_t)1 << 19, NWG = NW * want_groups;
         const size_t L1 = want_groups == 64 ? 128 : 1024, L2 = L1 / 32;
@@ -288,7 +294,7 @@ static zk_status per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t 
     const uint32_t nq = (c->n + 1) / 2;
     const uint32_t np = p1 - p0;
     auto terms_at = [](VTerms t, size_t o) {
-        t.nx.p += o, t.ny.p += o, t.ndt.p += o, t.sc.p += o, t.tab += o * 8 * 36, t.dig += o;
+        t.pts += o * VT_ENTRY_WORDS, t.sc.p += o, t.tab += o * 8 * 36, t.dig += o;
         return t;
     };
     auto acc_at = [](Soa4 a, size_t o) {

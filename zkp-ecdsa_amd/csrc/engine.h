@@ -208,8 +208,11 @@ struct VGroupFlags {        // per group of a chunk: 1 = passed the batched chec
 struct Soa4 {
     Soa x, y, z, t;
 };
+#define VT_ENTRY_WORDS 32 // a term's point: 128-byte entry (x', y, d'x'y: 27 limbs, Montgomery) -- what the bucket sums of k_msm.hip gather, written once by the kernels
+                          // that parse the proofs (until round 5 they wrote three SoA arrays and k_msm_pack copied every live term: 1.6 ms per 32 768 proofs)
 struct VTerms {           // terms of the "sum s_i P_i = identity" checks: niels point on the a=1 image + plain scalar
-    Soa nx, ny, ndt, sc;
+    uint32_t* pts;        // [cap][VT_ENTRY_WORDS]; the three lists of a workspace are consecutive, so a term's id in k_msm.hip is its entry number from slot_terms.pts on
+    Soa sc;
     uint32_t* tab;        // window tables, AoS: multiples 1..8 of term idx, 36 words (X, Y, d'T, Z) each, at tab[(idx*8 + e)*36]
     uint8_t* dig;         // signed 4-bit digits of the scalars: dig[w * cap + idx] = |d| (0..8) | sign << 7, w = 0..64
     uint32_t cap;         // terms the arrays were carved for

@@ -11,7 +11,7 @@
 // of a chunk that contains a bad proof doubles.
 //
 // Pipeline per chunk (one HIP stream, ONE host round trip: the verdicts):
-//   k_msm_pack      live terms -> 128-byte AoS niels entries (the bucket sums gather them)
+//   (the terms' 128-byte niels entries are written by the kernels that parse the proofs, k_verify.hip: vt_st; rounds 2-4 copied them here, k_msm_pack)
 //   grouping of the (window, group, digit) keys of all live terms, hand-written (round 5; rounds 2-4 ran 16 rocprim::radix_sort_pairs + 96 bounds
 //   kernels per chunk, 166 launches and 12 ms per 65 536 proofs): the key space is fixed (19 bits per window), so two counting passes do:
 //     k_msm_hist      per workgroup (a contiguous range of term ids) and window: LDS histogram of the keys' top 9 bits ("bins"); digit 0 is dropped
@@ -67,22 +67,6 @@ ZK_DEV const VTerms& msm_list(const VWork& V, const MsmDims& D, uint32_t id, uin
     idx = id - D.n0 - D.n1;
     proof = idx % D.g2, live = proof < D.l2;
     return V.misc_terms;
-}
-__global__ void __launch_bounds__(256) k_msm_pack(VWork V, MsmDims D, uint32_t* aos) {
-    uint32_t id = gtid();
-    if (id >= D.n0 + D.n1 + D.n2) return;
-    uint32_t idx, proof;
-    bool live;
-    const VTerms& L = msm_list(V, D, id, idx, live, proof);
-    if (!live || fe_is_zero(soa_ld<ModQ, 1>(L.sc, idx))) return;
-    Ft2 x = soa_ld<ModT, 2>(L.nx, idx), y = soa_ld<ModT, 2>(L.ny, idx), dt = soa_ld<ModT, 2>(L.ndt, idx);
-    uint32_t w[28];
-#pragma unroll
-    for (int l = 0; l < 9; l++) w[l] = x.l[l], w[9 + l] = y.l[l], w[18 + l] = dt.l[l];
-    w[27] = 0;
-    uint4* q = (uint4*)(aos + (size_t)id * MSM_ENTRY_WORDS);
-#pragma unroll
-    for (int i = 0; i < 7; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
 // ---------------------------------------------------------------- grouping of the keys (counting sort in two passes; no library sort)
 // A term's key in window w is  group << C | digit_w  (MSM_KEY_BITS = 19 bits); a term whose digit is 0 in a window takes no part in it (bucket 0 is
@@ -594,7 +578,6 @@ static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& 
     uint32_t* bin_tot = bin_off + (size_t)MSM_SORT_G * nwb;
     uint32_t* bin_start = bin_tot + nwb;
     uint32_t* live_cnt = bin_start + (size_t)S::nw * (MSM_NBIN + 1);
-    hipLaunchKernelGGL(k_msm_pack, dim3((total + 255) / 256), dim3(256), 0, s, V, D, M.aos);
     hipMemsetAsync(M.counters, 0, sizeof(uint32_t) * 64, s);
     if (ev2) hipEventRecord(ev2, s);   // the grouping of the keys alone (bench.py: verify.roofline.non_arithmetic)
     hipLaunchKernelGGL(k_msm_hist<C>, dim3(MSM_SORT_G), dim3(MSM_SORT_T), 0, s, V, D, bin_cnt, live_cnt);

@@ -949,12 +949,55 @@ void launch_v_gk_total(hipStream_t s, const VWork& V, const Soa& ring, const uin
 // ------------------------------------------------------------------ term construction
 // A Tom term = niels form of the point on the a=1 image (x', y, d'x'y, Montgomery) + a plain scalar.  Group gidx owns
 // terms [k * ngroups + gidx]; the first n256 terms of a group have 256-bit scalars, the rest 128-bit.
+ZK_DEV void vt_st_at(uint32_t* pts, uint32_t idx, const Ft2& x, const Ft2& y, const Ft2& dt) {
+    uint32_t w[28];
+#pragma unroll
+    for (int l = 0; l < 9; l++) w[l] = x.l[l], w[9 + l] = y.l[l], w[18 + l] = dt.l[l];
+    w[27] = 0;
+    uint4* q = (uint4*)(pts + (size_t)idx * VT_ENTRY_WORDS);
+#pragma unroll
+    for (int i = 0; i < 7; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+ZK_DEV void vt_st(const VTerms& L, uint32_t idx, const Ft2& x, const Ft2& y, const Ft2& dt) { vt_st_at(L.pts, idx, x, y, dt); }
+// The same store by a whole wave (every lane of every wave of the workgroup must call it; valid = false: nothing of this lane's is stored): the 64 entries go
+// through LDS and leave as FULL 128-byte lines, eight lanes per entry -- one lane's seven 16-byte stores touch 64 different lines per instruction, which cost
+// k_v_slot_points 0.6 ms per 32 768 proofs.  stage: 64 * 29 words of LDS of this wave.
+ZK_DEV void vt_st_wave(uint32_t* pts, uint32_t idx, bool valid, const Ft2& x, const Ft2& y, const Ft2& dt, uint32_t* stage) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t* m = stage + lane * 29;
+#pragma unroll
+    for (int l = 0; l < 9; l++) m[l] = x.l[l], m[9 + l] = y.l[l], m[18 + l] = dt.l[l];
+    m[27] = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < 8; r++) {
+        const uint32_t j = r * 8 + (lane >> 3), part = lane & 7;
+        const uint32_t jidx = (uint32_t)__shfl((int)idx, (int)j, 64);
+        const bool jvalid = __shfl((int)valid, (int)j, 64) != 0;
+        const uint32_t* e = stage + j * 29 + part * 4;
+        const uint4 v = part < 7 ? make_uint4(e[0], e[1], e[2], e[3]) : make_uint4(0, 0, 0, 0);
+        if (jvalid) ((uint4*)(pts + (size_t)jidx * VT_ENTRY_WORDS))[part] = v;
+    }
+    __syncthreads();
+}
+ZK_DEV void vt_st_identity(const VTerms& L, uint32_t idx) { vt_st(L, idx, fe_zero<ModT>().as<2>(), fe_one_mont<ModT>().as<2>(), fe_zero<ModT>().as<2>()); }
+ZK_DEV void vt_ld_xy(const VTerms& L, uint32_t idx, Ft2& x, Ft2& y) {
+    const uint4* q = (const uint4*)(L.pts + (size_t)idx * VT_ENTRY_WORDS);
+    uint32_t w[20];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const uint4 v = q[i];
+        w[4 * i] = v.x, w[4 * i + 1] = v.y, w[4 * i + 2] = v.z, w[4 * i + 3] = v.w;
+    }
+#pragma unroll
+    for (int l = 0; l < 9; l++) x.l[l] = w[l], y.l[l] = w[9 + l];
+}
 ZK_DEV void put_term(const VTerms& L, uint32_t idx, const St& xp, const St& yp, bool negate, const Sq& sc) {
     Ft2 x = fe_to_mont(xp) * fe_const<ModT, 1>(TOM_S_M);
     Ft2 y = fe_to_mont(yp);
     if (negate) x = fe_reduce(fe_neg(x));
     Ft2 dt = (x * y) * fe_const<ModT, 1>(TOM_D1_M);
-    soa_st(L.nx, idx, x), soa_st(L.ny, idx, y), soa_st(L.ndt, idx, dt), soa_st(L.sc, idx, sc);
+    vt_st(L, idx, x, y, dt), soa_st(L.sc, idx, sc);
 }
 ZK_DEV void put_term_bytes(const VTerms& L, uint32_t idx, const uint8_t* p72, bool negate, const Sq& sc) {
     St x, y;
@@ -962,7 +1005,7 @@ ZK_DEV void put_term_bytes(const VTerms& L, uint32_t idx, const uint8_t* p72, bo
     put_term(L, idx, x, y, negate, sc);
 }
 ZK_DEV void put_term_point_null(const VTerms& L, uint32_t idx) {  // identity; the scalar is written by the scalar kernel
-    soa_st(L.nx, idx, fe_zero<ModT>().as<2>()), soa_st(L.ny, idx, fe_one_mont<ModT>().as<2>()), soa_st(L.ndt, idx, fe_zero<ModT>().as<2>());
+    vt_st_identity(L, idx);
 }
 // niels form of the 72-byte point at p72 (nullptr: the identity)
 ZK_DEV void term_point(const uint8_t* p72, bool negate, Ft2& x, Ft2& y, Ft2& dt) {
@@ -980,11 +1023,10 @@ ZK_DEV void term_point(const uint8_t* p72, bool negate, Ft2& x, Ft2& y, Ft2& dt)
 ZK_DEV void put_term_point(const VTerms& L, uint32_t idx, const uint8_t* p72, bool negate) {
     Ft2 x, y, dt;
     term_point(p72, negate, x, y, dt);
-    soa_st(L.nx, idx, x), soa_st(L.ny, idx, y), soa_st(L.ndt, idx, dt);
+    vt_st(L, idx, x, y, dt);
 }
 ZK_DEV void put_term_null(const VTerms& L, uint32_t idx) {  // identity with scalar 0
-    soa_st(L.nx, idx, fe_zero<ModT>().as<2>()), soa_st(L.ny, idx, fe_one_mont<ModT>().as<2>());
-    soa_st(L.ndt, idx, fe_zero<ModT>().as<2>()), soa_st(L.sc, idx, fe_zero<ModQ>());
+    vt_st_identity(L, idx), soa_st(L.sc, idx, fe_zero<ModQ>());
 }
 // mod-q product between two scheduling fences: the term kernels are chains of independent products, and without the fences the
 // compiler interleaves them until the live set spills (256 VGPRs + scratch); in order they fit two or more waves per SIMD.
@@ -1040,10 +1082,12 @@ ZK_DEV void v_eq(const VTerms& L, uint32_t gidx, uint32_t ng, uint32_t i128, con
 // Layout of a slot group (group gidx = slot): 256-bit terms 0..9 = C8, C10, C11, C13, Tx, Ty, C4 x4; 128-bit terms 10..35 =
 // 4 x (Ax, Ay, Az, A41, A42), pix A1, A2, piy A1, A2, then Tx, Ty of a bit-1 slot.
 //
-// Points: one thread per (term, slot), term-major so that the stores are coalesced.  Three Tom products per thread.
+// Points: one thread per (term, slot), term-major; a wave stores its 64 entries together (vt_st_wave).  Three Tom products per thread.
 __global__ void __launch_bounds__(256) k_v_slot_points(VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
-    uint32_t t = gtid(), ns = count * VK, ng = V.C * VK;
-    if (t >= ns * V_SLOT_TERMS) return;
+    __shared__ uint32_t stage[4][64 * 29];
+    const uint32_t t0 = gtid(), ns = count * VK, ng = V.C * VK;
+    const bool valid = t0 < ns * V_SLOT_TERMS;
+    const uint32_t t = valid ? t0 : ns * V_SLOT_TERMS - 1;   // (the last workgroup's spare lanes mirror the last term: the store below is the whole wave's)
     uint32_t k = t / ns, sl = t % ns, p = sl / VK;
     uint32_t iv = V.idx[sl], i = iv & 255, bit = iv >> 8;
     const VTerms& L = V.slot_terms;
@@ -1061,7 +1105,9 @@ __global__ void __launch_bounds__(256) k_v_slot_points(VWork V, uint32_t count, 
         else if (k < 30) src = pa + 288 + 656 * ((k - 10) / 5) + 72 * ((k - 10) % 5 + 1), neg = true;
         else if (k < 34) src = pa + (k < 32 ? 2912 : 3152) + 72 * (k & 1), neg = true;
     }
-    put_term_point(L, k * ng + sl, src, neg);
+    Ft2 x, y, dt;
+    term_point(src, neg, x, y, dt);
+    vt_st_wave(L.pts, k * ng + sl, valid, x, y, dt, stage[threadIdx.x >> 6]);
 }
 // Scalars: one thread per checked slot: the scalars of the slot's terms, partial sums for shared points, and the slot's P-256
 // contribution.  Only mod-q arithmetic here; sums that are complete are stored at once so that few values stay live.
@@ -1196,8 +1242,7 @@ __global__ void __launch_bounds__(256) k_v_proof_points(VWork V, uint32_t count,
     }
     Ft2 x, y, dt;
     term_point(src, neg, x, y, dt);
-    if (t < ngl * 8) soa_st(V.gk_terms.nx, idx, x), soa_st(V.gk_terms.ny, idx, y), soa_st(V.gk_terms.ndt, idx, dt);
-    else soa_st(V.misc_terms.nx, idx, x), soa_st(V.misc_terms.ny, idx, y), soa_st(V.misc_terms.ndt, idx, dt);
+    vt_st_at(t < ngl * 8 ? V.gk_terms.pts : V.misc_terms.pts, idx, x, y, dt);
 }
 // Scalars: one thread per proof.
 __global__ void __launch_bounds__(64, 2) k_v_proof_terms(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
@@ -1306,7 +1351,7 @@ __global__ void __launch_bounds__(256, 2) k_v_term_tables(VTerms L, uint32_t ngr
     }
     if (fe_is_zero(sc)) return;  // null term: every digit is 0 and its table is never used
     TomPt p;
-    p.x = soa_ld<ModT, 2>(L.nx, idx), p.y = soa_ld<ModT, 2>(L.ny, idx);
+    vt_ld_xy(L, idx, p.x, p.y);
     p.t = p.x * p.y, p.z = fe_one_mont<ModT>().as<2>();
     TomPt m = p;
     st_tab(L, 0, idx, m);
