@@ -12,11 +12,14 @@
 // 32 768 proofs), C = 10 with 64 groups.  The top window of the rho_j is 11 (8) bits wide -- buckets there are twice (four times) as full -- and the windows
 // above bit 128 see only SL >> 128, a handful of values: those buckets are "big" and get a workgroup each.
 //
+// Part 1 (pmsm_prepare; closes stage 1 of the chunk on its own stream -- latency-bound, 0.8 ms per 32 768 proofs):
 //   k_pm_pack     term -> 64-byte affine entry + its digits (uint16, window-major)
 //   k_pm_group    workgroup (window, group): counting sort of the group's terms by digit in LDS -> id lists, bucket bounds, buckets ordered by size
+//   k_pm_rpart    SR * R per proof through its table, summed per 64 proofs; the SH of the same proofs summed mod n
+// Part 2 (pmsm_sums; an auxiliary stream forked at the start of stage 2: arithmetic beside the Tom-256 pass's grouping kernels, which are not; measured
+// placements in profiles/r05_p256_pass_ab.txt):
 //   k_pm_bucket   thread per bucket, in size order: complete mixed additions (RCB 2016 algorithm 5); k_pm_big: a workgroup per oversized bucket
 //   k_pm_reduce   workgroup (window, group): sum_d d * B_d by per-thread running sums and a tree of (F, G) segments
-//   k_pm_rpart    SR * R per proof through its table, summed per 64 proofs; the SH of the same proofs summed mod n
 //   k_pm_final    per group: windows (Horner, C doublings each) + R parts + (sum SH) * h_NIST == identity ?
 #include "rtab.h"
 #include "ktab.h"
