@@ -345,7 +345,7 @@ static zk_status per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t 
     }
     return ZK_OK;
 }
-zk_status VerifyJob::stage2(uint64_t chunk_no) {
+zk_status VerifyJob::stage2a(uint64_t chunk_no) {
     const DevParams& P = c->P;
     const uint64_t first = plan[chunk_no].first;
     const uint32_t cnt = plan[chunk_no].cnt;
@@ -358,10 +358,11 @@ zk_status VerifyJob::stage2(uint64_t chunk_no) {
     // Tom-256 relations: one bucket-method sum per group of the chunk's proofs (8 or 64 groups, one pass); the per-proof
     // windowed sums only run for the groups whose total is not the identity -- some proof of theirs is bad -- to tell which
     const uint32_t G = c->vs_groups;   // 8 or 64 groups per chunk (zk_ctx_set_verify_groups)
-    uint32_t flags[MSM_G_MAX], gsz = cnt;
+    uint32_t gsz = cnt;
     const bool wide_chunk = side_streams(cnt);
     if (wide_chunk && timed) c->timing_forked = true;
     auto& A = c->vl[lane];
+    A.msm_pending = A.pm_pending = false;   // (a failed call may have left them set)
     if (wide_chunk) {   // the P-256 sums of a small chunk, one term per lane, beside everything below
         HIPCHK(c, hipEventRecord(A.aux_fork, s));
         HIPCHK(c, hipStreamWaitEvent(A.aux[3], A.aux_fork, 0));
@@ -394,12 +395,41 @@ zk_status VerifyJob::stage2(uint64_t chunk_no) {
         TimerRec sub{"+v_msm_bucket", nullptr, nullptr};   // a part of v_msm_tom ('+': not added to the total again)
         TimerRec sub2{"+v_msm_group", nullptr, nullptr};   // the grouping of the keys (hand-written counting passes, k_msm.hip)
         if (timed) sub.e0 = get_event(c), sub.e1 = get_event(c), sub2.e0 = get_event(c), sub2.e1 = get_event(c);
-        hipError_t e = run_msm(s, P, W, V, cnt, nq, M, G, flags, &gsz, sub.e0, sub.e1, sub2.e0, sub2.e1);
+        hipError_t e = run_msm(s, P, W, V, cnt, nq, M, G, &gsz, sub.e0, sub.e1, sub2.e0, sub2.e1);
         if (timed && e == hipSuccess) c->trecs.push_back(sub), c->trecs.push_back(sub2);
         if (e != hipSuccess) {
             c->err = std::string("batched verification failed: ") + hipGetErrorString(e);
             return ZK_E_DEVICE;
         }
+        A.msm_pending = true;
+    }
+    A.pm_pending = pm, A.msm_gsz = gsz;
+    if (!A.msm_done) HIPCHK(c, hipEventCreateWithFlags(&A.msm_done, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(A.msm_done, s));
+    return ZK_OK;
+}
+zk_status VerifyJob::stage2b(uint64_t chunk_no) {
+    const DevParams& P = c->P;
+    const uint64_t first = plan[chunk_no].first;
+    const uint32_t cnt = plan[chunk_no].cnt;
+    const uint32_t lane = lane_of(chunk_no);
+    Workspace& W = c->pl[lane].W;
+    VWork& V = c->vl[lane].V;
+    const MsmBuf& M = c->vl[lane].M;
+    hipStream_t s = c->pl[lane].stream;
+    const uint32_t G = c->vs_groups;
+    auto& A = c->vl[lane];
+    const bool wide_chunk = side_streams(cnt), pm = A.pm_pending;
+    uint32_t* pm_flags = A.h_msm + 128;
+    uint32_t flags[MSM_G_MAX], gsz = A.msm_gsz;
+    if (A.msm_pending) {
+        hipError_t e = hipEventSynchronize(A.msm_done);
+        A.msm_pending = false;
+        if (e != hipSuccess) {
+            c->err = std::string("batched verification failed: ") + hipGetErrorString(e);
+            return ZK_E_DEVICE;
+        }
+        msm_read_flags(M, G, flags);
         c->dbg_msm_terms += M.host[0];   // live terms of this chunk's bucket pass (zk_test_counter 2)
     } else {
         for (auto& f : flags) f = 0;   // every proof goes through the per-proof sums
@@ -521,9 +551,12 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
     }
     const uint64_t nchunks = J.plan.size();
     // stage 1 of the next NL - 1 chunks is enqueued on the other lanes before the host blocks on this chunk's batched check
+    // ... and so are the batched passes of those chunks (stage2a: no host round trip), so that the reductions that end one chunk's pass -- dependent chains, 3 ms with
+    // the GPU nearly idle -- run beside the next chunk's bucket sums; the host blocks in stage2b of the oldest chunk only
     for (uint64_t k = 0; k < nchunks && !zs; k++) {
         while (!zs && J.next_s1 < nchunks && J.next_s1 < k + J.NL) zs = J.stage1(J.next_s1++);
-        if (!zs) zs = J.stage2(k);
+        while (!zs && J.next_s2a < J.next_s1) zs = J.stage2a(J.next_s2a++);
+        if (!zs) zs = J.stage2b(k);
     }
     hipError_t e1 = hipSuccess;
     for (uint32_t l = 0; l < J.NL; l++) {

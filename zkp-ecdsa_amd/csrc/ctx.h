@@ -83,6 +83,9 @@ struct zk_ctx {
         Soa res{}, res2{};
         MsmBuf M{};               // batched Tom check buffers (k_msm.hip), carved with V
         uint32_t* h_msm = nullptr;   // page-locked read-back words of run_msm
+        hipEvent_t msm_done = nullptr;   // recorded behind a chunk's batched passes (stage2a); stage2b waits for it before it reads the verdicts
+        bool msm_pending = false, pm_pending = false;   // ... which passes of the chunk between stage2a and stage2b are in flight
+        uint32_t msm_gsz = 0;
         PMsmBuf PM{};             // cross-proof P-256 pass (k_pmsm.hip); PM.aos == nullptr: not carved (chunks below p256_batch_min)
         hipStream_t aux[V_AUX_STREAMS] = {};   // small batches: the independent per-proof sums run side by side (api_verify.hip: per_proof_range)
         hipEvent_t aux_fork = nullptr, aux_done[V_AUX_STREAMS] = {};

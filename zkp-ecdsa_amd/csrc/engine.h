@@ -345,10 +345,12 @@ void pmsm_sums(hipStream_t s, const DevParams& P, uint32_t count, const PMsmBuf&
 void launch_pm_all_ok(hipStream_t s, const VWork& V, uint32_t count);
 // k_msm.hip
 size_t msm_workspace_bytes(uint32_t cap);
-// host_flags[g] = 1: the Tom-256 total of group g (proofs [g * gsz, (g + 1) * gsz) of the chunk) is the identity; M.flag holds the same on the device
+// run_msm enqueues the pass on s (no host round trip); once s has drained that far, msm_read_flags gives host_flags[g] = 1: the Tom-256 total of group g (proofs
+// [g * gsz, (g + 1) * gsz) of the chunk) is the identity; M.flag holds the same on the device, M.host[0] the live terms of the pass
 hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t groups /*8 or 64*/,
-                   uint32_t* host_flags /*[groups]*/, uint32_t* gsz, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr /* recorded around k_msm_bucket */,
+                   uint32_t* gsz, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr /* recorded around k_msm_bucket */,
                    hipEvent_t ev2 = nullptr, hipEvent_t ev3 = nullptr /* ... around the grouping of the keys */);
+void msm_read_flags(const MsmBuf& M, uint32_t groups, uint32_t* host_flags /*[groups]*/);
 // group size of one k_gk_finish pass over `ntiles` polynomials of T+1 coefficients: <= 64, dynamic LDS below 60 KB
 static inline size_t gk_finish_lds(uint32_t T, uint32_t g) { return sizeof(uint32_t) * 9 * ((size_t)g * (T + 1) + (size_t)(g / 2) * (T + 2)); }
 static inline uint32_t gk_finish_gsz(uint32_t T, uint32_t ntiles) {

@@ -132,7 +132,16 @@ struct VerifyJob {
     zk_status plan_unpack();             // ubase from the packed offsets of the chunks' first proofs (host copy, or read back from d_poff)
     zk_status enqueue_h2d();             // all chunks' bytes up front, one event per chunk
     zk_status stage1(uint64_t chunk_no);
-    zk_status stage2(uint64_t chunk_no);
+    // stage 2 in two halves: 2a enqueues the chunk's batched passes (Tom-256 and P-256 bucket sums, no host round trip), 2b waits for their verdicts and enqueues
+    // the per-proof sums of the groups that failed and the final kernel.  verify_device enqueues 2a of every chunk whose stage 1 is in before it blocks in 2b of
+    // the oldest one: the dependent chains at the end of one chunk's pass (the bucket reductions, 3 ms) then run beside the next chunk's bucket sums.
+    zk_status stage2a(uint64_t chunk_no);
+    zk_status stage2b(uint64_t chunk_no);
+    zk_status stage2(uint64_t chunk_no) {
+        zk_status z = stage2a(chunk_no);
+        return z ? z : stage2b(chunk_no);
+    }
+    uint64_t next_s2a = 0;
 };
 zk_status ensure_vworkspace(zk_ctx* c, uint32_t C, uint32_t nlanes);   // api_verify.hip
 // bytes of the expansion staging and entries of the offset array for a ZKA1P batch of B proofs, `total` packed bytes, chunks of C proofs

@@ -556,9 +556,10 @@ size_t msm_workspace_bytes(uint32_t) {
     const size_t nwb = (size_t)MSM_NW_MAX * MSM_NBIN;
     return 4 * (2 * nwb * MSM_SORT_G + nwb + (size_t)MSM_NW_MAX * (MSM_NBIN + 1) + MSM_SORT_G + 256 * nwb + 256) + 1024;   // + size_cnt, size_tot
 }
-// returns through host_flags[groups] (after a stream synchronisation): 1 = the Tom total of that group of proofs is the identity
+// Enqueues the pass on s and returns; once s has drained to this point M.host holds the live-term count and the groups' verdicts (msm_read_flags): 1 = the Tom
+// total of that group of proofs is the identity.  No host round trip in here: the caller enqueues the passes of several chunks before it waits for the first.
 template <int C>
-static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t* host_flags, uint32_t* gsz_out,
+static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t* gsz_out,
                             hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2, hipEvent_t ev3) {
     typedef MsmShape<C> S;
     MsmDims D;
@@ -648,12 +649,17 @@ static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& 
     hipLaunchKernelGGL(k_msm_final<C>, dim3(1), dim3(64), 0, s, M.Tw, M.one, M.flag);
     launch_words_to_host(s, M.host, M.counters, 1);   // live terms of the pass (statistics: zk_test_counter 2)
     launch_words_to_host(s, M.host + 8, M.flag, S::g);
-    hipError_t e = hipStreamSynchronize(s);
-    for (uint32_t g = 0; g < S::g; g++) host_flags[g] = M.host[8 + g];
-    if (dbg) fprintf(stderr, "msm: %u live terms; bucket .. final %.2f ms\n", M.host[0], now() - t0);
+    hipError_t e = hipSuccess;
+    if (dbg) {
+        e = hipStreamSynchronize(s);
+        fprintf(stderr, "msm: %u live terms; bucket .. final %.2f ms\n", M.host[0], now() - t0);
+    }
     return e;
 }
-hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t groups, uint32_t* host_flags,
+hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t groups,
                    uint32_t* gsz_out, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2, hipEvent_t ev3) {
-    return groups == 64 ? run_msm_t<13>(s, P, W, V, count, nq, M, host_flags, gsz_out, ev0, ev1, ev2, ev3) : run_msm_t<16>(s, P, W, V, count, nq, M, host_flags, gsz_out, ev0, ev1, ev2, ev3);
+    return groups == 64 ? run_msm_t<13>(s, P, W, V, count, nq, M, gsz_out, ev0, ev1, ev2, ev3) : run_msm_t<16>(s, P, W, V, count, nq, M, gsz_out, ev0, ev1, ev2, ev3);
+}
+void msm_read_flags(const MsmBuf& M, uint32_t groups, uint32_t* host_flags) {
+    for (uint32_t g = 0; g < groups; g++) host_flags[g] = M.host[8 + g];
 }
