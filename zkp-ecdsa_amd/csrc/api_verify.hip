@@ -61,7 +61,6 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, PMsmBuf& PM, uint
         M.aos = pts;   // (== V.slot_terms.pts: no copy)
         // sized for either shape of the pass: 16 windows x (8 groups x 2^16 digits) or 20 windows x (64 groups x 2^13 digits)
         const size_t NW = want_groups == 64 ? 20 : 16, NBG = (size_t)1 << 19, NWG = NW * want_groups;
-        const size_t L1 = want_groups == 64 ? 128 : 1024, L2 = L1 / 32;
         M.pairs = (uint2*)k.take(cap * 8 * NW);
         M.vals_out = (uint32_t*)k.take(cap * 4 * NW);
         M.start = (uint32_t*)k.take(4 * NW * NBG), M.end = (uint32_t*)k.take(4 * NW * NBG);
@@ -70,8 +69,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, PMsmBuf& PM, uint
         // the buckets are written after the last reader of the (key, id) pairs has run (k_msm_binsort): where the pairs' memory is large enough they share it
         if (cap * 8 * NW >= NW * NBG * 144) M.buckets = (uint32_t*)M.pairs;
         else M.buckets = (uint32_t*)k.take(NW * NBG * 144);
-        M.F1 = (uint32_t*)k.take(NWG * L1 * 144), M.G1 = (uint32_t*)k.take(NWG * L1 * 144);
-        M.F2 = (uint32_t*)k.take(NWG * L2 * 144), M.G2 = (uint32_t*)k.take(NWG * L2 * 144), M.H2 = (uint32_t*)k.take(NWG * L2 * 144);
+        M.red = (uint32_t*)k.take(msm_red_words(want_groups) * 4);
         M.Tw = (uint32_t*)k.take(NWG * 144);
         M.sort_tmp_bytes = msm_workspace_bytes((uint32_t)cap);
         M.sort_tmp = k.take(M.sort_tmp_bytes);

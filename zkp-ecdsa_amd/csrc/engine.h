@@ -314,7 +314,8 @@ struct MsmBuf {
     uint32_t* big_list;    // [4096] window * 65536 + digit of the oversized buckets
     uint32_t* big_part;    // [4096][128][36] partial sums of their slices
     uint32_t* buckets;     // [windows][2^19][36]
-    uint32_t *F1, *G1, *F2, *G2, *H2, *Tw;
+    uint32_t* red;         // the levels of the bucket reduction (k_msm.hip: launch_msm_reduce), msm_red_words(groups) words
+    uint32_t* Tw;          // [windows * groups][36] sum_d d * B_d, times 2^(C w)
     void* sort_tmp;
     size_t sort_tmp_bytes;
     TomList one;           // [groups] the groups' fixed-base commitments
@@ -345,6 +346,7 @@ void pmsm_sums(hipStream_t s, const DevParams& P, uint32_t count, const PMsmBuf&
 void launch_pm_all_ok(hipStream_t s, const VWork& V, uint32_t count);
 // k_msm.hip
 size_t msm_workspace_bytes(uint32_t cap);
+size_t msm_red_words(uint32_t groups);
 // run_msm enqueues the pass on s (no host round trip); once s has drained that far, msm_read_flags gives host_flags[g] = 1: the Tom-256 total of group g (proofs
 // [g * gsz, (g + 1) * gsz) of the chunk) is the identity; M.flag holds the same on the device, M.host[0] the live terms of the pass
 hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t groups /*8 or 64*/,

@@ -21,7 +21,7 @@
 //                     of every (group, digit) value, and its 1024 buckets ordered by size (what k_msm_bucket's waves want)
 //   k_msm_bucket    thread (window, digit): sum of its terms (8 modmuls per term); buckets far above the average
 //                   (k_msm_bucket_big / _big2) are summed by slices over many workgroups
-//   k_msm_reduce1/2/3  sum_d d * B_d per window by two levels of running sums, times 2^(16 w)
+//   k_msm_red1 / _redk x 3 / _red_last  sum_d d * B_d per (window, group) by four levels of running sums over sixteen entries each, times 2^(16 w)
 //   k_msm_coef, one fixed-base commitment, k_msm_final: windows + fixed-base part == identity ?
 #include <chrono>
 #include <cstdio>
@@ -40,9 +40,7 @@ template <int C>
 struct MsmShape {
     static constexpr uint32_t c = C, nb = 1u << C, nw = (256 + C - 1) / C, gbits = MSM_KEY_BITS - C, g = 1u << gbits;
     static constexpr uint32_t nwg = nw * g;        // (window, group) pairs: the reductions treat each as a window of its own
-    static constexpr uint32_t l1 = nb / 64;        // level-1 ranges of 64 buckets per (window, group)
-    static constexpr uint32_t l2 = l1 / 32;        // level-2 ranges of 32 level-1 ranges
-    static_assert(nw <= MSM_NW_MAX && g <= MSM_G_MAX && l2 >= 1, "shape");
+    static_assert(nw <= MSM_NW_MAX && g <= MSM_G_MAX, "shape");
 };
 
 // term id space: [0, n0) slot_terms, [n0, n0 + n1) gk_terms, [n0 + n1, n0 + n1 + n2) misc_terms
@@ -448,67 +446,107 @@ __global__ void __launch_bounds__(256) k_msm_bucket_big2(const uint32_t* __restr
         if (threadIdx.x == 0) msm_st(buckets + (size_t)big_list[b] * 36, acc);
     }
 }
-// level 1: 64 buckets per thread.  F1 = sum_j j * B_{64 r + j}, G1 = sum_j B_{64 r + j}
+// sum_d d * B_d per (window, group) in FOUR levels of sixteen (until round 5: 64 / 32 / 32, 361 dependent point operations in a row -- 3.3 ms per chunk during
+// which the GPU did next to nothing else; now 4 x 31 + 15):
+//   level 1: a thread takes 16 buckets:  F = sum_j j B_j (running sums), G = sum_j B_j
+//   level l: a thread takes 16 (the last level: what is left) entries of level l - 1.  Role 0 (blockIdx.y): F' = sum_j j G_j, G' = sum_j G_j; role k >= 1: the plain
+//            sum of the k-th carried array -- the F of level l - 1, and the plain sums carried so far.  All roles of a level run in ONE launch, so a level is 31
+//            operations long whatever it carries.
+//   last:    sum_d d B_d = P_0 + 16 (P_1 + 16 (P_2 + 16 F_4)),  P_0 = sum of all F_1, P_1 = sum of all F_2, P_2 = sum of all F_3;  times 2^(C w)
+#define MSM_RED_R 16u
+struct MsmRedLevel {
+    const uint32_t* Gin;
+    const uint32_t* Pin[3];   // carried arrays (Pin[0] = F of the level below), nin entries per (window, group) each
+    uint32_t *Fout, *Gout, *Pout[3];
+    uint32_t nin, r, nwg;     // entries per (window, group) on the way in; entries a thread takes; (window, group) pairs
+};
 template <int C>
-__global__ void __launch_bounds__(256) k_msm_reduce1(const uint32_t* __restrict__ buckets, uint32_t* F1, uint32_t* G1) {
+__global__ void __launch_bounds__(256) k_msm_red1(const uint32_t* __restrict__ buckets, uint32_t* F1, uint32_t* G1) {
     typedef MsmShape<C> S;
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;  // r < l1; w = window * groups + group
-    if (r >= S::l1) return;
-    const uint32_t* b = buckets + ((size_t)w * S::nb + 64 * r) * 36;
+    constexpr uint32_t n1 = S::nb / MSM_RED_R;
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;   // w = window * groups + group
+    if (r >= n1) return;
+    const uint32_t* b = buckets + ((size_t)w * S::nb + MSM_RED_R * r) * 36;
     TomPt run = tom_identity(), acc = tom_identity();
 #pragma unroll 1
-    for (int j = 63; j >= 1; j--) {
+    for (int j = MSM_RED_R - 1; j >= 1; j--) {
         run = tom_add(run, msm_ldp(b + 36 * j));
         acc = tom_add(acc, run);
     }
     run = tom_add(run, msm_ldp(b));
-    msm_st(F1 + ((size_t)w * S::l1 + r) * 36, acc);
-    msm_st(G1 + ((size_t)w * S::l1 + r) * 36, run);
+    msm_st(F1 + ((size_t)w * n1 + r) * 36, acc);
+    msm_st(G1 + ((size_t)w * n1 + r) * 36, run);
 }
-// level 2: 32 level-1 ranges per thread.  F2 = sum_j j * G1_{32 s + j}, G2 = sum_j G1_{32 s + j}, H2 = sum_j F1_{32 s + j}
-template <int C>
-__global__ void __launch_bounds__(64) k_msm_reduce2(const uint32_t* __restrict__ F1, const uint32_t* __restrict__ G1, uint32_t* F2, uint32_t* G2, uint32_t* H2) {
-    typedef MsmShape<C> S;
-    uint32_t t = gtid();
-    if (t >= S::nwg * S::l2) return;
-    uint32_t w = t / S::l2, s = t % S::l2;
-    const uint32_t* g = G1 + ((size_t)w * S::l1 + 32 * s) * 36;
-    const uint32_t* f = F1 + ((size_t)w * S::l1 + 32 * s) * 36;
-    TomPt run = tom_identity(), acc = tom_identity(), h = tom_identity();
+__global__ void __launch_bounds__(64) k_msm_redk(MsmRedLevel L) {
+    const uint32_t nout = L.nin / L.r, t = gtid(), role = blockIdx.y;
+    if (t >= L.nwg * nout) return;
+    const size_t base = ((size_t)(t / nout) * L.nin + (size_t)(t % nout) * L.r) * 36;
+    if (role == 0) {
+        const uint32_t* g = L.Gin + base;
+        TomPt run = tom_identity(), acc = tom_identity();
 #pragma unroll 1
-    for (int j = 31; j >= 1; j--) {
-        run = tom_add(run, msm_ldp(g + 36 * j));
-        acc = tom_add(acc, run);
-        h = tom_add(h, msm_ldp(f + 36 * j));
-    }
-    run = tom_add(run, msm_ldp(g));
-    h = tom_add(h, msm_ldp(f));
-    msm_st(F2 + (size_t)t * 36, acc), msm_st(G2 + (size_t)t * 36, run), msm_st(H2 + (size_t)t * 36, h);
-}
-// level 3: one thread per window.  sum_d d B_d = H + 64 (GF2 + 32 FG2);  result times 2^(16 w)
-template <int C>
-__global__ void __launch_bounds__(64) k_msm_reduce3(const uint32_t* __restrict__ F2, const uint32_t* __restrict__ G2, const uint32_t* __restrict__ H2, uint32_t* Tw) {
-    typedef MsmShape<C> S;
-    uint32_t w = gtid();   // window * groups + group
-    if (w >= S::nwg) return;
-    TomPt run = tom_identity(), fg = tom_identity(), gf = tom_identity(), gh = tom_identity();
-#pragma unroll 1
-    for (int s = (int)S::l2 - 1; s >= 0; s--) {
-        size_t o = ((size_t)w * S::l2 + s) * 36;
-        if (s >= 1) {
-            run = tom_add(run, msm_ldp(G2 + o));
-            fg = tom_add(fg, run);
+        for (int j = (int)L.r - 1; j >= 1; j--) {
+            run = tom_add(run, msm_ldp(g + 36 * j));
+            acc = tom_add(acc, run);
         }
-        gf = tom_add(gf, msm_ldp(F2 + o));
-        gh = tom_add(gh, msm_ldp(H2 + o));
+        run = tom_add(run, msm_ldp(g));
+        msm_st(L.Fout + (size_t)t * 36, acc), msm_st(L.Gout + (size_t)t * 36, run);
+    } else {
+        const uint32_t* p = L.Pin[role - 1] + base;
+        TomPt h = msm_ldp(p);
+#pragma unroll 1
+        for (uint32_t j = 1; j < L.r; j++) h = tom_add(h, msm_ldp(p + 36 * j));
+        msm_st(L.Pout[role - 1] + (size_t)t * 36, h);
     }
-    for (int i = 0; i < 5; i++) fg = tom_dbl(fg);
-    TomPt t = tom_add(gf, fg);
-    for (int i = 0; i < 6; i++) t = tom_dbl(t);
-    t = tom_add(t, gh);
+}
+// one thread per (window, group): F4 and the three carried sums -> sum_d d B_d, times 2^(C w)
+template <int C>
+__global__ void __launch_bounds__(64) k_msm_red_last(const uint32_t* __restrict__ F4, const uint32_t* __restrict__ P2, const uint32_t* __restrict__ P1, const uint32_t* __restrict__ P0,
+                                                    uint32_t* Tw) {
+    typedef MsmShape<C> S;
+    const uint32_t w = gtid();   // window * groups + group
+    if (w >= S::nwg) return;
+    TomPt t = msm_ldp(F4 + (size_t)w * 36);
+    const uint32_t* carried[3] = {P2, P1, P0};
+#pragma unroll 1
+    for (int k = 0; k < 3; k++) {
+        for (int i = 0; i < 4; i++) t = tom_dbl(t);   // x 16
+        t = tom_add(t, msm_ldp(carried[k] + (size_t)w * 36));
+    }
 #pragma unroll 1
     for (uint32_t i = 0; i < S::c * (w / S::g); i++) t = tom_dbl(t);
     msm_st(Tw + (size_t)w * 36, t);
+}
+// entries of MsmBuf::red per (window, group): level 1 (F, G), level 2 (F, G, P), level 3 (F, G, 2 P), level 4 (F, G, 3 P)
+template <int C>
+struct MsmRedPlan {
+    static constexpr uint32_t n1 = MsmShape<C>::nb / MSM_RED_R, n2 = n1 / MSM_RED_R, n3 = n2 / MSM_RED_R;   // 4096 / 256 / 16 at C = 16, 512 / 32 / 2 at C = 13
+    static_assert(n3 >= 1 && n3 <= MSM_RED_R, "four levels");
+    static constexpr size_t per_wg = 2 * (size_t)n1 + 3 * n2 + 4 * n3 + 5;
+};
+size_t msm_red_words(uint32_t groups) {
+    return groups == 64 ? MsmRedPlan<13>::per_wg * MsmShape<13>::nwg * 36 : MsmRedPlan<16>::per_wg * MsmShape<16>::nwg * 36;
+}
+template <int C>
+static void launch_msm_reduce(hipStream_t s, const MsmBuf& M) {
+    typedef MsmShape<C> S;
+    typedef MsmRedPlan<C> R;
+    const size_t W = (size_t)S::nwg * 36;
+    uint32_t* p = M.red;
+    auto take = [&](size_t n) { uint32_t* q = p; p += n * W; return q; };
+    uint32_t *F1 = take(R::n1), *G1 = take(R::n1);
+    uint32_t *F2 = take(R::n2), *G2 = take(R::n2), *P2a = take(R::n2);
+    uint32_t *F3 = take(R::n3), *G3 = take(R::n3), *P3a = take(R::n3), *P3b = take(R::n3);
+    uint32_t *F4 = take(1), *G4 = take(1), *P4a = take(1), *P4b = take(1), *P4c = take(1);
+    constexpr uint32_t bt = R::n1 < 256 ? R::n1 : 256;
+    hipLaunchKernelGGL(k_msm_red1<C>, dim3(R::n1 / bt, S::nwg), dim3(bt), 0, s, M.buckets, F1, G1);
+    MsmRedLevel L2{G1, {F1, nullptr, nullptr}, F2, G2, {P2a, nullptr, nullptr}, R::n1, MSM_RED_R, S::nwg};
+    hipLaunchKernelGGL(k_msm_redk, dim3((S::nwg * R::n2 + 63) / 64, 2), dim3(64), 0, s, L2);
+    MsmRedLevel L3{G2, {F2, P2a, nullptr}, F3, G3, {P3a, P3b, nullptr}, R::n2, MSM_RED_R, S::nwg};
+    hipLaunchKernelGGL(k_msm_redk, dim3((S::nwg * R::n3 + 63) / 64, 3), dim3(64), 0, s, L3);
+    MsmRedLevel L4{G3, {F3, P3a, P3b}, F4, G4, {P4a, P4b, P4c}, R::n3, R::n3, S::nwg};
+    hipLaunchKernelGGL(k_msm_redk, dim3((S::nwg + 63) / 64, 4), dim3(64), 0, s, L4);
+    hipLaunchKernelGGL(k_msm_red_last<C>, dim3((S::nwg + 63) / 64), dim3(64), 0, s, F4, P4a, P4b, P4c, M.Tw);
 }
 // coefficient sums of the fixed bases over a group's proofs (block g): list C slots p * 4n + {0, 1} hold (mg, mh), (eg, eh)
 __global__ void __launch_bounds__(256) k_msm_coef(Workspace W, uint32_t count, uint32_t gsz, TomList one) {
@@ -640,10 +678,7 @@ static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& 
     if (ev1) hipEventRecord(ev1, s);
     hipLaunchKernelGGL(k_msm_bucket_big, dim3(MSM_NSLICE, 32), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.counters + 32, M.big_list, M.big_part);
     hipLaunchKernelGGL(k_msm_bucket_big2, dim3(64), dim3(256), 0, s, M.counters + 32, M.big_list, M.big_part, M.buckets);
-    constexpr uint32_t bt = S::l1 < 256 ? S::l1 : 256;
-    hipLaunchKernelGGL(k_msm_reduce1<C>, dim3(S::l1 / bt, S::nwg), dim3(bt), 0, s, M.buckets, M.F1, M.G1);
-    hipLaunchKernelGGL(k_msm_reduce2<C>, dim3((S::nwg * S::l2 + 63) / 64), dim3(64), 0, s, M.F1, M.G1, M.F2, M.G2, M.H2);
-    hipLaunchKernelGGL(k_msm_reduce3<C>, dim3((S::nwg + 63) / 64), dim3(64), 0, s, M.F2, M.G2, M.H2, M.Tw);
+    launch_msm_reduce<C>(s, M);
     hipLaunchKernelGGL(k_msm_coef, dim3(S::g), dim3(256), 0, s, W, count, D.gsz, M.one);
     launch_tom_commit(s, P, M.one, S::g, 1, 1);
     hipLaunchKernelGGL(k_msm_final<C>, dim3(1), dim3(64), 0, s, M.Tw, M.one, M.flag);
