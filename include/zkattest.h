@@ -111,7 +111,8 @@ zk_status zk_ctx_set_lanes(zk_ctx *ctx, uint32_t lanes);
 /* Experimental schedules of the lanes, read from the environment by zk_ctx_create, all OFF by default and none changing a byte (DESIGN.md section 5e,
  * profiles/r05_overlap.txt: measured, none beats the default): ZKATTEST_LANE_PRIO="p0,p1,p2,p3" (stream priorities, -1 is served first),
  * ZKATTEST_HEAVY_FIFO=1|2 (the GPU-filling commitment kernels of all lanes on one extra stream; ZKATTEST_HEAVY_PRIO its priority),
- * ZKATTEST_PHASE_MAJOR=1, ZKATTEST_GK_BESIDE=1, ZKATTEST_HEAVY_LDS_KB=<n>, ZKATTEST_LANE_CUS / ZKATTEST_HEAVY_CUS="lo-hi" (CU masks, bits of 256).  The verifier's bucket pass orders its buckets by size over the whole chunk;
+ * ZKATTEST_PHASE_MAJOR=1, ZKATTEST_GK_BESIDE=1, ZKATTEST_HEAVY_LDS_KB=<n>, ZKATTEST_LANE_CUS / ZKATTEST_HEAVY_CUS="lo-hi" (CU masks, bits of 256), ZKATTEST_LANE_STAGGER=<1..5> (the lanes' first chunks start one stage-1 phase after
+ * the other).  The verifier's bucket pass orders its buckets by size over the whole chunk;
  * ZKATTEST_MSM_ORDER=local orders them within each bin only (two launches fewer, slower bucket sums). */
 /* Width W (8..26 bits, default 16) of the fixed-base comb tables of the Tom-256 bases g and h: a commitment
  * v*g + r*h (PedersenParams.commit, src/commit/pedersen.ts:53-58) costs 2*ceil(256/W) table additions, the tables

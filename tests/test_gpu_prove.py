@@ -41,7 +41,7 @@ def test_lane_scheduling_knobs_do_not_change_the_bytes(monkeypatch):
 
     def run(env):
         for k in ('ZKATTEST_HEAVY_FIFO', 'ZKATTEST_PHASE_MAJOR', 'ZKATTEST_GK_BESIDE', 'ZKATTEST_LANE_PRIO', 'ZKATTEST_HEAVY_LDS_KB', 'ZKATTEST_HEAVY_PRIO',
-                  'ZKATTEST_LANE_CUS', 'ZKATTEST_HEAVY_CUS'):
+                  'ZKATTEST_LANE_CUS', 'ZKATTEST_HEAVY_CUS', 'ZKATTEST_LANE_STAGGER'):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -63,6 +63,7 @@ def test_lane_scheduling_knobs_do_not_change_the_bytes(monkeypatch):
     assert run({'ZKATTEST_HEAVY_FIFO': '2', 'ZKATTEST_GK_BESIDE': '1', 'ZKATTEST_HEAVY_PRIO': '0'}) == ref
     assert run({'ZKATTEST_LANE_PRIO': '-1,0,1', 'ZKATTEST_HEAVY_LDS_KB': '84'}) == ref
     assert run({'ZKATTEST_HEAVY_FIFO': '1', 'ZKATTEST_HEAVY_CUS': '0-192', 'ZKATTEST_LANE_CUS': '192-256'}) == ref   # CU masks
+    assert run({'ZKATTEST_LANE_STAGGER': '4'}) == ref   # the lanes' first chunks start one after the other
 
 
 def test_uniform_control_flow_build_makes_the_same_bytes():

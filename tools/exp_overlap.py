@@ -16,7 +16,7 @@ import time
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-KNOBS = ['ZKATTEST_LANE_PRIO', 'ZKATTEST_HEAVY_FIFO', 'ZKATTEST_HEAVY_PRIO', 'ZKATTEST_PHASE_MAJOR', 'ZKATTEST_GK_BESIDE', 'ZKATTEST_HEAVY_LDS_KB', 'ZKATTEST_LANE_CUS', 'ZKATTEST_HEAVY_CUS']
+KNOBS = ['ZKATTEST_LANE_STAGGER', 'ZKATTEST_LANE_PRIO', 'ZKATTEST_HEAVY_FIFO', 'ZKATTEST_HEAVY_PRIO', 'ZKATTEST_PHASE_MAJOR', 'ZKATTEST_GK_BESIDE', 'ZKATTEST_HEAVY_LDS_KB', 'ZKATTEST_LANE_CUS', 'ZKATTEST_HEAVY_CUS']
 
 
 def main():

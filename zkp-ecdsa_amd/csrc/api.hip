@@ -864,7 +864,24 @@ static zk_status prove_stage1_upto(ProveJob& J, uint64_t upto) {
         for (int ph = 0; ph < ProveJob::S1_PHASES && !zs; ph++)
             for (uint64_t k = a; k < b && !zs; k++) zs = J.stage1(k, ph, ph + 1);
     } else {
-        for (uint64_t k = a; k < b && !zs; k++) zs = J.stage1(k);
+        // ZKATTEST_LANE_STAGGER = p (1..5; experiment): the first chunk of lane l + 1 starts on the GPU when the first chunk of lane l has finished p of
+        // stage 1's five phases -- the lanes then run out of phase without smaller chunks (an event wait on the stream, the host does not block)
+        const char* stagger_env = getenv("ZKATTEST_LANE_STAGGER");
+        const int stagger = stagger_env ? atoi(stagger_env) : 0;
+        for (uint64_t k = a; k < b && !zs; k++) {
+            if (stagger > 0 && stagger <= ProveJob::S1_PHASES && J.NL > 1 && k < J.NL) {
+                zk_ctx* c = J.c;
+                const uint32_t lane = J.lane_of(k);
+                auto& PL = c->pl[lane];
+                if (!PL.stagger_ev && hipEventCreateWithFlags(&PL.stagger_ev, hipEventDisableTiming) != hipSuccess) return ZK_E_DEVICE;
+                if (k > 0 && hipStreamWaitEvent(PL.stream, c->pl[J.lane_of(k - 1)].stagger_ev, 0) != hipSuccess) return ZK_E_DEVICE;
+                zs = J.stage1(k, 0, stagger);
+                if (!zs && hipEventRecord(PL.stagger_ev, PL.stream) != hipSuccess) return ZK_E_DEVICE;
+                if (!zs && stagger < ProveJob::S1_PHASES) zs = J.stage1(k, stagger, ProveJob::S1_PHASES);
+            } else {
+                zs = J.stage1(k);
+            }
+        }
     }
     J.next_s1 = b;
     return zs;

@@ -56,6 +56,7 @@ struct zk_ctx {
         size_t arena_bytes = 0;
         bool ready = false;
         uint32_t last_cnt = 0;          // proofs of the last chunk this lane started (zk_test_counter)
+        hipEvent_t stagger_ev = nullptr;   // ZKATTEST_LANE_STAGGER (experiment): recorded behind a phase of the lane's first chunk, the next lane's first chunk waits for it
         hipStream_t side = nullptr;     // small chunks: the membership phase of stage 2 runs beside the PointAdd phase (api.hip: ProveJob::stage2)
         hipEvent_t side_fork = nullptr, side_done = nullptr;
         void* h_scan = nullptr;         // page-locked: the chunk's totals (4 x u32), item prefix sums (u32[C+1]) and byte prefix sums
