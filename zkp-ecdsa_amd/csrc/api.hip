@@ -1118,7 +1118,7 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return ZK_OK;
     }
-    J.io_dbg = host_sink && getenv("ZK_IO_DEBUG");
+    J.io_dbg = getenv("ZK_IO_DEBUG") && (host_sink || atoi(getenv("ZK_IO_DEBUG")) >= 2);   // 2: the host / GPU timeline of a device-pointer call as well
     J.host_t0 = ProveJob::host_ms();
     if (J.io_dbg) {
         hipEventCreate(&J.io_t0);
