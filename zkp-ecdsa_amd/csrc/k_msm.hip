@@ -672,6 +672,9 @@ static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& 
             return hipErrorAssert;
         }
     }
+    // the groups' fixed-base parts need nothing from the buckets: before the long kernel, not in the chain of small ones behind it
+    hipLaunchKernelGGL(k_msm_coef, dim3(S::g), dim3(256), 0, s, W, count, D.gsz, M.one);
+    launch_tom_commit(s, P, M.one, S::g, 1, 1);
     if (ev0) hipEventRecord(ev0, s);   // the bucket sums alone (bench.py: roofline.others)
     hipLaunchKernelGGL(k_msm_bucket<C>, dim3(S::nw * MSM_NBG / 256), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.ord_id, M.buckets, M.counters + 32,
                        M.big_list, M.counters);
@@ -679,8 +682,6 @@ static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& 
     hipLaunchKernelGGL(k_msm_bucket_big, dim3(MSM_NSLICE, 32), dim3(256), 0, s, M.aos, M.vals_out, M.cap, M.start, M.end, M.counters + 32, M.big_list, M.big_part);
     hipLaunchKernelGGL(k_msm_bucket_big2, dim3(64), dim3(256), 0, s, M.counters + 32, M.big_list, M.big_part, M.buckets);
     launch_msm_reduce<C>(s, M);
-    hipLaunchKernelGGL(k_msm_coef, dim3(S::g), dim3(256), 0, s, W, count, D.gsz, M.one);
-    launch_tom_commit(s, P, M.one, S::g, 1, 1);
     hipLaunchKernelGGL(k_msm_final<C>, dim3(1), dim3(64), 0, s, M.Tw, M.one, M.flag);
     launch_words_to_host(s, M.host, M.counters, 1);   // live terms of the pass (statistics: zk_test_counter 2)
     launch_words_to_host(s, M.host + 8, M.flag, S::g);
