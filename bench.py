@@ -328,6 +328,9 @@ def main():
             verify['roofline'] = {'bound': 'valu_int32', 'kernel': 'k_msm_bucket', 'achieved': others['k_msm_bucket']['achieved'], 'peak': VALU_MAD_PEAK_TOPS,
                                   'unit': roofline['unit'], 'frac': others['k_msm_bucket']['frac'], 'ms_per_step': others['k_msm_bucket']['ms_per_step'],
                                   'share_of_gpu_time': round(others['k_msm_bucket']['ms_per_step'] / vsum, 3) if vsum else None,
+                                  'traffic': 19015000000, 'traffic_note': 'bytes fetched per launch of a 32 768-proof chunk (FETCH_SIZE, its own rocprofv3 --pmc pass, raw: '
+                                  'profiles/r05_pmc_verify.txt; a constant of bench.py, NOT measured in this run): the 137 M gathered 128-byte entries and their ids (18.2 GB), nothing re-read; '
+                                  'SIMD busy 0.945',
                                   'serial_ms_per_step': round(vsum, 2), 'non_arithmetic_ms': non_arith,
                                   'non_arithmetic_share': round(sum(non_arith.values()) / vsum, 3) if vsum else None,
                                   'note': 'non_arithmetic = SHA-256 (both challenges, the sampler\'s fills) and the hand-written grouping of the bucket pass\'s keys '
