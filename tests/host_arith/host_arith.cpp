@@ -5,6 +5,7 @@
 #define ZK_HOST_BUILD 1
 #include <cstring>
 #include "curve.h"
+#include "coop.h"
 #include "rng.h"
 #include "comb_digits.h"
 #include "ktab.h"
@@ -41,7 +42,8 @@ static void field_one(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) 
     if (op == 0) r = fe_mul_mod(x, y);
     else if (op == 1) r = fe_add_mod(x, y);
     else if (op == 2) r = fe_sub_mod(x, y);
-    else if (op == 3) r = fe_from_mont(fe_inv<M>(fe_to_mont(x)));
+    else if (op == 3) r = fe_from_mont(fe_inv_fermat<M>(fe_to_mont(x)));
+    else if (op == 7) r = fe_from_mont(fe_inv_gcd<M>(fe_to_mont(x)));   // divsteps inversion
     else if (op == 4) {  // x*y - x - y through fe_sub2
         auto xm = fe_to_mont(x), ym = fe_to_mont(y);
         r = fe_from_mont(fe_sub2(xm * ym, xm, ym));
@@ -338,4 +340,128 @@ extern "C" int ha_ktab_mul(const uint8_t* xy64, const uint8_t* start64, uint64_t
         if (memcmp(alt, out64 + 64 * i, 64)) range_mismatch++;
     }
     return range_mismatch;
+}
+
+// ---------------------------------------------------------------- lane-cooperative arithmetic (coop.h) through its SIMT emulation
+// Four operand pairs at a time, one per row.  op 0: a * b;  1: a + b;  2: a - b;  3: a lazy chain ((a + b) + (a + b)) * (a - b) - (b * b + a) as in field op 5;
+// 4: a^(M - 2).  Operands and results are plain canonical values (40-byte big-endian), the arithmetic runs in the Montgomery domain.
+template <class M>
+static void co_field_four(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    uint32_t am[4][NLIMB], bm[4][NLIMB], rm[4][NLIMB];
+    for (int r = 0; r < 4; r++) {
+        uint32_t aw[10], bw[10];
+        be40_to_words(a + 40 * r, aw), be40_to_words(b + 40 * r, bw);
+        Fe<M, 2> x = fe_to_mont(fe_from_words<M, 9>(aw)), y = fe_to_mont(fe_from_words<M, 9>(bw));
+        for (int i = 0; i < NLIMB; i++) am[r][i] = x.l[i], bm[r][i] = y.l[i];
+    }
+    const CoU32 mj = co_limbs(M::mod);
+    const auto x = co_load4<M, 2>(am[0], am[1], am[2], am[3]), y = co_load4<M, 2>(bm[0], bm[1], bm[2], bm[3]);
+    CoFe<M, 2> res;
+    if (op == 0) res = co_mul(x, y, mj);
+    else if (op == 1) res = co_mul(co_add(x, y), co_load4<M, 1>(M::one, M::one, M::one, M::one), mj);
+    else if (op == 2) res = co_mul(co_sub(x, y), co_load4<M, 1>(M::one, M::one, M::one, M::one), mj);
+    else if (op == 3) {
+        const auto s = co_add(co_add(x, y), co_add(x, y));
+        const auto d = co_sub(x, y);
+        const auto t = co_sub(co_mul(s, d, mj), co_add(co_mul(y, y, mj), x));
+        res = co_mul(t, co_load4<M, 1>(M::one, M::one, M::one, M::one), mj);
+    } else res = co_pow_words<M>(x, M::exp_m2, mj);
+    co_store4(res, rm[0], rm[1], rm[2], rm[3]);
+    for (int r = 0; r < 4; r++) {
+        Fe<M, 2> v;
+        for (int i = 0; i < NLIMB; i++) v.l[i] = rm[r][i];
+        uint32_t rw[10];
+        words_from_limbs<9>(rw, fe_from_mont(v).l);
+        rw[9] = 0;
+        words_to_be(rw, 10, out + 40 * r);
+    }
+}
+extern "C" int ha_co_field_op(int which, int op, uint64_t count /* multiple of 4 */, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    for (uint64_t i = 0; i + 4 <= count; i += 4) {
+        if (which == 0) co_field_four<ModQ>(op, a + 40 * i, b + 40 * i, out + 40 * i);
+        else if (which == 1) co_field_four<ModN>(op, a + 40 * i, b + 40 * i, out + 40 * i);
+        else co_field_four<ModT>(op, a + 40 * i, b + 40 * i, out + 40 * i);
+    }
+    return 0;
+}
+static CoTom co_tom_from(const TomPt& p) {
+    CoTom c;
+    c.v = co_load4<ModT, 2>(p.x.l, p.y.l, p.t.l, p.z.l);
+    return c;
+}
+static TomPt co_tom_to(const CoTom& c) {
+    TomPt p;
+    co_store4(c.v, p.x.l, p.y.l, p.t.l, p.z.l);
+    return p;
+}
+// k * P by double-and-add with the cooperative doubling and addition (rows X, Y, T, Z of one wave)
+extern "C" int ha_co_tom_mul(uint64_t count, const uint8_t* xy72, const uint8_t* k32, uint8_t* out72) {
+    int bad = 0;
+    const CoU32 mj = co_limbs(ModT::mod);
+    for (uint64_t i = 0; i < count; i++) {
+        TomPt P;
+        if (!tom_load(P, xy72 + 72 * i)) {
+            bad++;
+            memset(out72 + 72 * i, 0xff, 72);
+            continue;
+        }
+        const CoTom cp = co_tom_from(P);
+        CoTom acc = co_tom_from(tom_identity());
+        for (int bit = 255; bit >= 0; bit--) {
+            acc = co_tom_dbl(acc, mj);
+            if ((k32[32 * i + 31 - bit / 8] >> (bit % 8)) & 1) acc = co_tom_add(acc, cp, mj);
+        }
+        tom_store(co_tom_to(acc), out72 + 72 * i);
+    }
+    return bad;
+}
+static CoP256 co_p256_from(const P256Pt& p) {
+    CoP256 c;
+    const uint32_t zero[NLIMB] = {0};
+    c.v = co_load4<ModQ, 8>(p.x.l, p.y.l, p.z.l, zero);
+    return c;
+}
+static P256Pt co_p256_to(const CoP256& c) {
+    P256Pt p;
+    co_store4(c.v, p.x.l, p.y.l, p.z.l, nullptr);
+    return p;
+}
+// k * P by double-and-add with the cooperative complete laws (rows X, Y, Z); the accumulator starts at the identity, so O + P, P + P and P + O all occur
+extern "C" int ha_co_p256_mul(uint64_t count, const uint8_t* xy64, const uint8_t* k32, uint8_t* out64) {
+    const CoU32 mj = co_limbs(ModQ::mod);
+    for (uint64_t i = 0; i < count; i++) {
+        P256Aff A;
+        if (!p256_load(A, xy64 + 64 * i)) return 1;
+        const CoP256 cp = co_p256_from(p256_from_affine(A));
+        CoP256 acc = co_p256_from(p256_identity());
+        for (int bit = 255; bit >= 0; bit--) {
+            acc = co_p256_dbl(acc, mj);
+            if ((k32[32 * i + 31 - bit / 8] >> (bit % 8)) & 1) acc = co_p256_add(acc, cp, mj);
+        }
+        p256_store(co_p256_to(acc), out64 + 64 * i);
+    }
+    return 0;
+}
+extern "C" int ha_co_p256_add(uint64_t count, const uint8_t* p64, const uint8_t* q64, uint8_t* out64) {
+    const CoU32 mj = co_limbs(ModQ::mod);
+    for (uint64_t i = 0; i < count; i++) {
+        P256Aff A, B;
+        if (!p256_load(A, p64 + 64 * i) || !p256_load(B, q64 + 64 * i)) return 1;
+        p256_store(co_p256_to(co_p256_add(co_p256_from(p256_from_affine(A)), co_p256_from(p256_from_affine(B)), mj)), out64 + 64 * i);
+    }
+    return 0;
+}
+// 2^nd * P through the cooperative Jacobian-with-ZZ doubling chain (k_rtab_base), back to the homogeneous form (X Z : Y : Z ZZ)
+extern "C" int ha_co_p256_jdbl_chain(uint64_t count, const uint8_t* xy64, uint32_t nd, int from_identity, uint8_t* out64) {
+    const CoU32 mj = co_limbs(ModQ::mod);
+    for (uint64_t i = 0; i < count; i++) {
+        P256Aff A;
+        if (!p256_load(A, xy64 + 64 * i)) return 1;
+        const P256Pt s = from_identity ? p256_identity() : p256_from_affine(A);
+        CoP256J j;
+        j.v = co_load4<ModQ, 10>(s.x.l, s.y.l, s.z.l, s.z.l);   // Z in {0, 1}: ZZ = Z
+        for (uint32_t k = 0; k < nd; k++) j = co_p256_jdbl(j, mj);
+        p256_store(co_p256_to(co_p256_from_jac(j, mj)), out64 + 64 * i);
+    }
+    return 0;
 }

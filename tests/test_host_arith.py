@@ -291,3 +291,92 @@ def test_key_table_multiplication_on_the_host(ha):
             if start is not None:
                 want = want.add(start)
             assert out.raw[64 * i:64 * i + 64] == _p_xy(want), (i, hex(k), negs[i])
+
+
+def test_divsteps_inversion_on_the_host(ha):
+    """field.h: fe_inv_gcd (Bernstein-Yang divsteps in the radix-2^30 limbs) against pow(x, -1, m); inv(0) = 0 like big.ts:113-119."""
+    rnd = random.Random(23)
+    for which, m in enumerate([R.p256.p, R.p256.order, R.tomEdwards256.p]):
+        a = [rnd.randrange(m) for _ in range(600)] + [0, 1, 2, 3, m - 1, m - 2, (m + 1) // 2, (1 << 255) % m, (1 << 30) - 1, 1 << 30, (1 << 240) % m]
+        a += [rnd.randrange(1 << k) for k in (1, 8, 29, 30, 31, 60, 61, 200, 240, 241)]
+        assert _field(ha, which, 7, a, a) == [pow(x, -1, m) if x else 0 for x in a]
+
+
+def _co_field(ha, which, op, a, b):
+    n = len(a)
+    assert n % 4 == 0
+    ab = b''.join(x.to_bytes(40, 'big') for x in a)
+    bb = b''.join(x.to_bytes(40, 'big') for x in b)
+    out = C.create_string_buffer(40 * n)
+    assert ha.ha_co_field_op(which, op, C.c_uint64(n), ab, bb, out) == 0
+    return [int.from_bytes(out.raw[40 * i:40 * i + 40], 'big') for i in range(n)]
+
+
+def test_lane_cooperative_field_arithmetic_on_the_host(ha):
+    """coop.h (one element per 16-lane row, one limb per lane; DPP broadcasts and shifts emulated lane by lane): the Montgomery product, add / sub with the
+    parallel carry step, a lazy chain at large magnitudes and a Fermat power, four elements per wave, against Python integers."""
+    rnd = random.Random(29)
+    for which, m in enumerate([R.p256.p, R.p256.order, R.tomEdwards256.p]):
+        a = [rnd.randrange(m) for _ in range(200)] + [0, 1, m - 1, m - 1, 0, 2, m - 2, (1 << 255) % m]
+        b = [rnd.randrange(m) for _ in range(200)] + [0, m - 1, m - 1, 1, m - 1, m - 2, 2, m - 1]
+        # limbs of all ones / carries that ripple through every limb
+        a += [(1 << 240) - 1, (1 << 256) % m, m - 1, ((1 << 30) - 1) << 30]
+        b += [1, m - 1, 1, (1 << 210) + 1]
+        assert _co_field(ha, which, 0, a, b) == [x * y % m for x, y in zip(a, b)]
+        assert _co_field(ha, which, 1, a, b) == [(x + y) % m for x, y in zip(a, b)]
+        assert _co_field(ha, which, 2, a, b) == [(x - y) % m for x, y in zip(a, b)]
+        assert _co_field(ha, which, 3, a, b) == [(2 * (x + y) * (x - y) - (y * y + x)) % m for x, y in zip(a, b)]
+        assert _co_field(ha, which, 4, a[:8] + a[-8:], b[:16]) == [pow(x, m - 2, m) for x in a[:8] + a[-8:]]
+
+
+def test_lane_cooperative_tom256_formulas_on_the_host(ha):
+    """co_tom_dbl / co_tom_add (rows X, Y, T, Z; ds_bpermute row moves emulated) in a double-and-add against the oracle's scalar multiplication."""
+    rnd = random.Random(31)
+    g, q = R.tomEdwards256, R.tomEdwards256.order
+    bases = [g.generator().mul(g.newScalar(rnd.randrange(1, q))) for _ in range(3)]
+    ks = [rnd.randrange(1 << 256) for _ in range(3)] + [0, 1, 2, q - 1, q, q + 1]
+    pts = [bases[i % len(bases)] for i in range(len(ks))]
+    n = len(pts)
+    out = C.create_string_buffer(72 * n)
+    assert ha.ha_co_tom_mul(C.c_uint64(n), b''.join(_tom_xy(p) for p in pts), b''.join(k.to_bytes(32, 'big') for k in ks), out) == 0
+    for i in range(n):
+        assert out.raw[72 * i:72 * i + 72] == _tom_xy(pts[i].mul(g.newScalar(ks[i]))), (i, hex(ks[i]))
+
+
+def _p256_xy(pt):
+    x, y = pt.toAffine()
+    return x.to_bytes(32, 'big') + y.to_bytes(32, 'big')
+
+
+def test_lane_cooperative_p256_formulas_on_the_host(ha):
+    """co_p256_dbl / co_p256_add (the complete laws of weier.ts:133-230 in four passes of four rows) and the Jacobian-with-ZZ doubling chain of k_rtab_base,
+    against the oracle: scalar multiples from the identity (O + P, P + P, P + O on the way), P + (-P), and 2^n P incl. the identity."""
+    rnd = random.Random(37)
+    g, q = R.p256, R.p256.order
+    bases = [g.generator().mul(g.newScalar(rnd.randrange(1, q))) for _ in range(3)]
+    ks = [rnd.randrange(1 << 256) for _ in range(3)] + [1, 2, 3, q - 1, q + 1]
+    pts = [bases[i % len(bases)] for i in range(len(ks))]
+    n = len(pts)
+    out = C.create_string_buffer(64 * n)
+    assert ha.ha_co_p256_mul(C.c_uint64(n), b''.join(_p256_xy(p) for p in pts), b''.join(k.to_bytes(32, 'big') for k in ks), out) == 0
+    for i in range(n):
+        assert out.raw[64 * i:64 * i + 64] == _p256_xy(pts[i].mul(g.newScalar(ks[i]))), (i, hex(ks[i]))
+    # k = q: the identity (64 zero bytes from the harness's store)
+    out = C.create_string_buffer(64)
+    assert ha.ha_co_p256_mul(C.c_uint64(1), _p256_xy(bases[0]), q.to_bytes(32, 'big'), out) == 0
+    assert out.raw == bytes(64)
+    P = [bases[0], bases[0], bases[1], bases[2]]
+    Q = [bases[0], bases[0].neg(), bases[2], bases[1].add(bases[2]).neg()]
+    out = C.create_string_buffer(64 * len(P))
+    assert ha.ha_co_p256_add(C.c_uint64(len(P)), b''.join(map(_p256_xy, P)), b''.join(map(_p256_xy, Q)), out) == 0
+    for i in range(len(P)):
+        s = P[i].add(Q[i])
+        assert out.raw[64 * i:64 * i + 64] == (bytes(64) if s.isIdentity() else _p256_xy(s)), i
+    for nd in (1, 2, 13, 256):
+        out = C.create_string_buffer(64 * 3)
+        assert ha.ha_co_p256_jdbl_chain(C.c_uint64(3), b''.join(map(_p256_xy, bases)), nd, 0, out) == 0
+        for i in range(3):
+            assert out.raw[64 * i:64 * i + 64] == _p256_xy(bases[i].mul(g.newScalar(pow(2, nd, q)))), (nd, i)
+    out = C.create_string_buffer(64)
+    assert ha.ha_co_p256_jdbl_chain(C.c_uint64(1), _p256_xy(bases[0]), 40, 1, out) == 0
+    assert out.raw == bytes(64)

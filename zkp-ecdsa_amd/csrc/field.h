@@ -552,10 +552,91 @@ ZK_DEV_NOINLINE Fe<M, 2> fe_pow_words(Fe<M, 2> a, const uint32_t e[NLIMB]) {
     }
     return acc;
 }
-// Montgomery-domain inverse by Fermat (a^(M-2)); inv(0) = 0 like the reference's invMod (big.ts:113-119).
+// Montgomery-domain inverse by Fermat (a^(M-2)); inv(0) = 0 like the reference's invMod (big.ts:113-119).  Until round 6 THE inversion of the engine; now the
+// cross-check of fe_inv_gcd below (tests/test_host_arith.py, tools/coop_bench.hip: 164 us against 38 us for one inversion in one lane).
+template <class M>
+ZK_DEV Fe<M, 2> fe_inv_fermat(const Fe<M, 2>& a) {
+    return fe_pow_words<M>(a, M::exp_m2);
+}
+
+// Inverse by DIVSTEPS (Bernstein-Yang 2019, "Fast constant-time gcd computation and modular inversion") instead of Fermat's ~390 dependent
+// products: where ONE lane inverts while a workgroup -- at one proof per call, the whole GPU -- waits (block_inverse, the front ends), the chain
+// length is the cost.  Rounds of 30 divsteps on the low 32 bits of (f, g) = (M, x) give a 2x2 transition matrix with entries |.| <= 2^30, applied
+// to the full-length (f, g) and, modulo M, to (d, e) = (0, 1): the radix-2^30 limbs of this file are exactly the digits that takes (signed top
+// limb).  d f^-1 = x^-1 once g = 0.  (49 * 258 + 57) / 17 = 747 divsteps suffice for inputs below 2^258 (Theorem 11.2 there), i.e. 25 rounds;
+// random inputs need 18-19 and the default build stops at g = 0 (-DZK_UNIFORM_CF=1: always 25 rounds, no data-dependent branch in here).
+// |d|, |e| grow by at most M per round (the multiple of M that clears the low limb is < 2^30 M), so they stay below 26 M.
+// inv(0) = 0 like the reference's invMod (big.ts:113-119): g = 0 from the start leaves d = 0.
+#ifndef ZK_UNIFORM_CF
+#define ZK_UNIFORM_CF 0
+#endif
+template <class M>
+ZK_DEV_NOINLINE Fe<M, 2> fe_inv_gcd(const Fe<M, 2> a) {
+    const Fe<M, 1> x = fe_canon(a);
+    int32_t f[NLIMB], g[NLIMB], d[NLIMB], e[NLIMB];
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) f[i] = (int32_t)M::mod[i], g[i] = (int32_t)x.l[i], d[i] = 0, e[i] = 0;
+    e[0] = 1;
+    int32_t eta = -1;
+#pragma unroll 1
+    for (int round = 0; round < 25; round++) {
+#if !ZK_UNIFORM_CF
+        uint32_t any = 0;
+#pragma unroll
+        for (int i = 0; i < NLIMB; i++) any |= (uint32_t)g[i];
+        if (any == 0) break;
+#endif
+        uint32_t fw = (uint32_t)f[0] | ((uint32_t)f[1] << LIMB_BITS), gw = (uint32_t)g[0] | ((uint32_t)g[1] << LIMB_BITS);
+        uint32_t u = 1, v = 0, q = 0, r = 1;
+#pragma unroll 6
+        for (int i = 0; i < LIMB_BITS; i++) {
+            uint32_t c1 = (uint32_t)(eta >> 31);            // eta < 0
+            const uint32_t c2 = 0u - (gw & 1u);             // g odd
+            const uint32_t xf = (fw ^ c1) - c1, xu = (u ^ c1) - c1, xv = (v ^ c1) - c1;   // (f, u, v), negated if eta < 0
+            gw += xf & c2, q += xu & c2, r += xv & c2;
+            c1 &= c2;                                       // eta < 0 and g odd: swap
+            eta = (int32_t)(((uint32_t)eta ^ c1) - (c1 + 1u));
+            fw += gw & c1, u += q & c1, v += r & c1;
+            gw >>= 1, u <<= 1, v <<= 1;
+        }
+        const int64_t su = (int32_t)u, sv = (int32_t)v, sq = (int32_t)q, sr = (int32_t)r;
+        // (f, g) <- matrix * (f, g) / 2^30, exactly
+        int64_t cf = su * f[0] + sv * g[0], cg = sq * f[0] + sr * g[0];
+        cf >>= LIMB_BITS, cg >>= LIMB_BITS;
+#pragma unroll
+        for (int k = 1; k < NLIMB; k++) {
+            cf += su * f[k] + sv * g[k], cg += sq * f[k] + sr * g[k];
+            f[k - 1] = (int32_t)((uint32_t)cf & LIMB_MASK), g[k - 1] = (int32_t)((uint32_t)cg & LIMB_MASK);
+            cf >>= LIMB_BITS, cg >>= LIMB_BITS;
+        }
+        f[NLIMB - 1] = (int32_t)cf, g[NLIMB - 1] = (int32_t)cg;
+        // (d, e) <- matrix * (d, e) / 2^30 mod M: add the multiple of M that clears the low limb (the Montgomery quotient digit)
+        int64_t cd = su * d[0] + sv * e[0], ce = sq * d[0] + sr * e[0];
+        const int64_t md = (int64_t)(((uint32_t)cd * M::n0) & LIMB_MASK), me = (int64_t)(((uint32_t)ce * M::n0) & LIMB_MASK);
+        cd += md * (int64_t)M::mod[0], ce += me * (int64_t)M::mod[0];
+        cd >>= LIMB_BITS, ce >>= LIMB_BITS;
+#pragma unroll
+        for (int k = 1; k < NLIMB; k++) {
+            cd += su * d[k] + sv * e[k] + md * (int64_t)M::mod[k], ce += sq * d[k] + sr * e[k] + me * (int64_t)M::mod[k];
+            d[k - 1] = (int32_t)((uint32_t)cd & LIMB_MASK), e[k - 1] = (int32_t)((uint32_t)ce & LIMB_MASK);
+            cd >>= LIMB_BITS, ce >>= LIMB_BITS;
+        }
+        d[NLIMB - 1] = (int32_t)cd, e[NLIMB - 1] = (int32_t)ce;
+    }
+    // f = +-1 (or M when x = 0, d = 0): x^-1 = f d.  +-d + 32 M is positive (|d| < 26 M) and < 64 M; one product by R^3 reduces it and brings the
+    // result to the domain of the input: (x R)^-1 R^2 = x^-1 R.
+    const bool neg = f[NLIMB - 1] < 0;
+    Fe<M, 64> t;
+#pragma unroll
+    for (int i = 0; i < NLIMB; i++) t.l[i] = M::sub32[i] + (uint32_t)(neg ? -d[i] : d[i]);
+    limbs_normalize(t.l);
+    return t * fe_const<M, 1>(M::r3);
+}
+
+// Montgomery-domain inverse, inv(0) = 0: what every caller uses (block_inverse, the front ends, the table builders).
 template <class M>
 ZK_DEV Fe<M, 2> fe_inv(const Fe<M, 2>& a) {
-    return fe_pow_words<M>(a, M::exp_m2);
+    return fe_inv_gcd<M>(a);
 }
 
 // ---- plain 32-bit-word <-> 30-bit-limb conversions ----
