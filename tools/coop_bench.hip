@@ -78,6 +78,68 @@ __global__ void k_canon9(uint32_t* io, uint32_t chains) {
     for (int l = 0; l < 9; l++) io[e * 9 + l] = c.l[l];
 }
 
+// pure product chain: x <- x * x, n times (timing only; the cooperative kernel squares four elements at once)
+__global__ void __launch_bounds__(64) k_sqr_lane(const uint32_t* in, uint32_t* out, uint32_t n) {
+    if (threadIdx.x) return;
+    Ft2 x;
+    for (int l = 0; l < 9; l++) x.l[l] = in[l];
+#pragma unroll 1
+    for (uint32_t i = 0; i < n; i++) x = x * x;
+    for (int l = 0; l < 9; l++) out[l] = x.l[l];
+}
+__global__ void __launch_bounds__(64) k_sqr_coop(const uint32_t* in, uint32_t* out, uint32_t n) {
+    const CoU32 mj = co_limbs(ModT::mod);
+    auto x = co_load4<ModT, 2>(in, in + 9, in + 18, in + 27);
+#pragma unroll 1
+    for (uint32_t i = 0; i < n; i++) x = co_mul(x, x, mj);
+    co_store4(x, out, out + 9, out + 18, out + 27);
+}
+// P-256: n Jacobian doublings (k_rtab_base's chain), n complete additions acc <- acc + P
+__global__ void __launch_bounds__(64) k_pj_lane(const uint32_t* in, uint32_t* out, uint32_t n) {
+    if (threadIdx.x) return;
+    P256Jac p;
+    for (int l = 0; l < 9; l++) p.x.l[l] = in[l], p.y.l[l] = in[9 + l], p.z.l[l] = ModQ::one[l];
+#pragma unroll 1
+    for (uint32_t i = 0; i < n; i++) p = p256_jdbl(p);
+    for (int l = 0; l < 9; l++) out[l] = p.x.l[l], out[9 + l] = p.y.l[l], out[18 + l] = p.z.l[l];
+}
+__global__ void __launch_bounds__(64) k_pj_coop(const uint32_t* in, uint32_t* out, uint32_t n) {
+    const CoU32 mj = co_limbs(ModQ::mod);
+    CoP256J p;
+    p.v = co_load4<ModQ, 10>(in, in + 9, ModQ::one, ModQ::one);
+#pragma unroll 1
+    for (uint32_t i = 0; i < n; i++) p = co_p256_jdbl(p, mj);
+    co_store4(p.v, out, out + 9, out + 18, out + 27);
+}
+__global__ void __launch_bounds__(64) k_pa_lane(const uint32_t* in, uint32_t* out, uint32_t n, int dbl) {
+    if (threadIdx.x) return;
+    P256Pt p, acc;
+    for (int l = 0; l < 9; l++) p.x.l[l] = in[l], p.y.l[l] = in[9 + l], p.z.l[l] = ModQ::one[l];
+    acc = p;
+#pragma unroll 1
+    for (uint32_t i = 0; i < n; i++) acc = dbl ? p256_dbl(acc) : p256_add(acc, p);
+    const auto x = fe_canon(fe_reduce(acc.x)), y = fe_canon(fe_reduce(acc.y)), z = fe_canon(fe_reduce(acc.z));
+    for (int l = 0; l < 9; l++) out[l] = x.l[l], out[9 + l] = y.l[l], out[18 + l] = z.l[l];
+}
+__global__ void __launch_bounds__(64) k_pa_coop(const uint32_t* in, uint32_t* out, uint32_t n, int dbl) {
+    const CoU32 mj = co_limbs(ModQ::mod);
+    CoP256 p, acc;
+    p.v = co_load4<ModQ, 8>(in, in + 9, ModQ::one, ModQ::one);
+    acc = p;
+#pragma unroll 1
+    for (uint32_t i = 0; i < n; i++) acc = dbl ? co_p256_dbl(acc, mj) : co_p256_add(acc, p, mj);
+    CoFe<ModQ, 2> red = co_mul(acc.v, co_const<ModQ>(ModQ::one), mj);
+    co_store4(red, out, out + 9, out + 18, nullptr);
+}
+__global__ void k_canon_q(uint32_t* io, uint32_t n) {
+    const uint32_t e = threadIdx.x;
+    if (e >= n) return;
+    Fq2 v;
+    for (int l = 0; l < 9; l++) v.l[l] = io[e * 9 + l];
+    const auto c = fe_canon(v);
+    for (int l = 0; l < 9; l++) io[e * 9 + l] = c.l[l];
+}
+
 template <class F>
 static float time_ms(F launch, int reps) {
     hipEvent_t e0, e1;
@@ -154,6 +216,32 @@ int main() {
         const float a = time_ms([&] { hipLaunchKernelGGL((k_inv_lane<ModQ, 0>), dim3(1), dim3(64), 0, 0, in, o1, 1u, reps); }, 5);
         const float b = time_ms([&] { hipLaunchKernelGGL((k_inv_lane<ModQ, 1>), dim3(1), dim3(64), 0, 0, in, o2, 1u, reps); }, 5);
         printf("inversion mod q,    1 chain : Fermat one lane %8.1f us   divsteps one lane %8.1f us (ratio %.2f)\n", a * 1e3 / reps, b * 1e3 / reps, a / b);
+    }
+    {
+        const uint32_t n = 1000;
+        const float a = time_ms([&] { hipLaunchKernelGGL(k_sqr_lane, dim3(1), dim3(64), 0, 0, in, o1, n); }, 5);
+        const float b = time_ms([&] { hipLaunchKernelGGL(k_sqr_coop, dim3(1), dim3(64), 0, 0, in, o2, n); }, 5);
+        printf("Montgomery product mod t, a chain of %u: one lane %.3f us per product, cooperative row %.3f us per product (four at once), ratio %.2f\n", n, a * 1e3 / n, b * 1e3 / n, a / b);
+    }
+    {
+        // values, not only times: the same points through both forms (P-256 inputs need not be on the curve for the formulas to agree)
+        for (int dbl = 0; dbl < 2; dbl++) {
+            hipLaunchKernelGGL(k_pa_lane, dim3(1), dim3(64), 0, 0, in, o1, 21u, dbl);
+            hipLaunchKernelGGL(k_pa_coop, dim3(1), dim3(64), 0, 0, in, o2, 21u, dbl);
+            hipLaunchKernelGGL(k_canon_q, dim3(1), dim3(64), 0, 0, o2, 3u);
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipMemcpy(r1.data(), o1, 27 * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(r2.data(), o2, 27 * 4, hipMemcpyDeviceToHost));
+            printf("P-256 complete %s x 21: cooperative == one-lane: %s\n", dbl ? "doubling" : "addition", memcmp(r1.data(), r2.data(), 27 * 4) ? "NO" : "yes");
+        }
+        const uint32_t n = 256;
+        float a = time_ms([&] { hipLaunchKernelGGL(k_pj_lane, dim3(1), dim3(64), 0, 0, in, o1, n); }, 5);
+        float b = time_ms([&] { hipLaunchKernelGGL(k_pj_coop, dim3(1), dim3(64), 0, 0, in, o2, n); }, 5);
+        printf("P-256 Jacobian doubling x %u: one lane (p256_jdbl, 8 products) %.1f us, cooperative wave (ZZ form, 9 products in 3 passes) %.1f us, ratio %.2f\n", n, a * 1e3, b * 1e3, a / b);
+        for (int dbl = 0; dbl < 2; dbl++) {
+            a = time_ms([&] { hipLaunchKernelGGL(k_pa_lane, dim3(1), dim3(64), 0, 0, in, o1, n, dbl); }, 5);
+            b = time_ms([&] { hipLaunchKernelGGL(k_pa_coop, dim3(1), dim3(64), 0, 0, in, o2, n, dbl); }, 5);
+            printf("P-256 complete %s x %u: one lane %.2f us each, cooperative wave (4 passes) %.2f us each, ratio %.2f\n", dbl ? "doubling" : "addition", n, a * 1e3 / n, b * 1e3 / n, a / b);
+        }
     }
     return 0;
 }

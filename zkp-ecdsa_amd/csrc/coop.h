@@ -488,3 +488,4 @@ ZK_DEV CoP256 co_p256_from_jac(const CoP256J& p, const CoU32& mj) {
     r.v = co_mul(a, b, mj).template as<8>();
     return r;
 }
+

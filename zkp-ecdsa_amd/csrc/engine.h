@@ -288,6 +288,14 @@ void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t 
 void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out,
                      const uint32_t* perm, const uint32_t* cnt, uint32_t tsplit = 1, uint32_t ostride = 1, uint32_t ny = 1, uint32_t ystride = 0);
 void launch_v_acc_tree(hipStream_t s, const Soa4& src, uint32_t nouter, uint32_t width, const Soa4& dst, uint32_t dstride, uint32_t fill);
+// k_coop.hip: the same sums on cooperating waves (one wave per chain), chosen by the launch wrappers when a launch has at most ZK_COOP_MAX_CHAINS chains
+#ifndef ZK_COOP_MAX_CHAINS
+#define ZK_COOP_MAX_CHAINS 16384u
+#endif
+void launch_v_straus_co(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out, const uint32_t* perm,
+                        const uint32_t* cnt, uint32_t tsplit, uint32_t ostride, uint32_t ny, uint32_t ystride);
+void launch_v_p256_straus_co(hipStream_t s, const VWork& V, uint32_t count);
+void launch_rtab_base_co(hipStream_t s, const Workspace& W, uint32_t count, uint32_t bits, const uint8_t* skip);
 void launch_v_slot_perm(hipStream_t s, const uint8_t* slot_class, uint32_t nslots, uint32_t* perm, uint32_t* cnt);
 void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count, uint32_t per);   // per = A terms per lane: 5, or 1 for small batches
 void launch_v_p256_total(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t per);

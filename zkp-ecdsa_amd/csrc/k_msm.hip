@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "engine.h"
+#include "coop_dev.h"
 
 // Two shapes of the same pass, chosen per context (zk_ctx_set_verify_groups): 8 groups x 16-bit windows (16 windows) or 64 groups x
 // 13-bit windows (20 windows).  Either way a window has 2^19 (group, digit) buckets and the sort keys are 19 bits wide, so every
@@ -517,6 +518,29 @@ __global__ void __launch_bounds__(64) k_msm_red_last(const uint32_t* __restrict_
     for (uint32_t i = 0; i < S::c * (w / S::g); i++) t = tom_dbl(t);
     msm_st(Tw + (size_t)w * 36, t);
 }
+// The same on a cooperating wave per (window, group) (coop.h): up to 16 w doublings in a row are what the last chunk of a call waits for -- 0.57 us per doubling
+// against 3.85 us in one lane (profiles/r06_coop_microbench.txt).
+template <int C>
+__global__ void __launch_bounds__(64) k_msm_red_last_co(const uint32_t* __restrict__ F4, const uint32_t* __restrict__ P2, const uint32_t* __restrict__ P1, const uint32_t* __restrict__ P0,
+                                                       uint32_t* Tw) {
+    typedef MsmShape<C> S;
+    const uint32_t w = blockIdx.x;   // window * groups + group
+    const CoU32 mj = co_limbs(ModT::mod);
+    CoTom t;
+    t.v = co_load_aos<ModT, 2, 4>(F4 + (size_t)w * 36);
+    const uint32_t* carried[3] = {P2, P1, P0};
+#pragma unroll 1
+    for (int k = 0; k < 3; k++) {
+        CoTom c;
+        c.v = co_load_aos<ModT, 2, 4>(carried[k] + (size_t)w * 36);
+#pragma unroll 1
+        for (int i = 0; i < 4; i++) t = co_tom_dbl(t, mj);   // x 16
+        t = co_tom_add(t, c, mj);
+    }
+#pragma unroll 1
+    for (uint32_t i = 0; i < S::c * (w / S::g); i++) t = co_tom_dbl(t, mj);
+    co_store_aos<ModT, 2, 4>(Tw + (size_t)w * 36, t.v);
+}
 // entries of MsmBuf::red per (window, group): level 1 (F, G), level 2 (F, G, P), level 3 (F, G, 2 P), level 4 (F, G, 3 P)
 template <int C>
 struct MsmRedPlan {
@@ -546,7 +570,9 @@ static void launch_msm_reduce(hipStream_t s, const MsmBuf& M) {
     hipLaunchKernelGGL(k_msm_redk, dim3((S::nwg * R::n3 + 63) / 64, 3), dim3(64), 0, s, L3);
     MsmRedLevel L4{G3, {F3, P3a, P3b}, F4, G4, {P4a, P4b, P4c}, R::n3, R::n3, S::nwg};
     hipLaunchKernelGGL(k_msm_redk, dim3((S::nwg + 63) / 64, 4), dim3(64), 0, s, L4);
-    hipLaunchKernelGGL(k_msm_red_last<C>, dim3((S::nwg + 63) / 64), dim3(64), 0, s, F4, P4a, P4b, P4c, M.Tw);
+    static const bool one_lane = getenv("ZKATTEST_ONE_LANE_CHAINS") != nullptr;   // A/B: the round-5 one-lane chains (profiles/r06_ab_variants.txt)
+    if (one_lane) hipLaunchKernelGGL(k_msm_red_last<C>, dim3((S::nwg + 63) / 64), dim3(64), 0, s, F4, P4a, P4b, P4c, M.Tw);
+    else hipLaunchKernelGGL(k_msm_red_last_co<C>, dim3(S::nwg), dim3(64), 0, s, F4, P4a, P4b, P4c, M.Tw);
 }
 // coefficient sums of the fixed bases over a group's proofs (block g): list C slots p * 4n + {0, 1} hold (mg, mh), (eg, eh)
 __global__ void __launch_bounds__(256) k_msm_coef(Workspace W, uint32_t count, uint32_t gsz, TomList one) {

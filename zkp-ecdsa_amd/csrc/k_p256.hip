@@ -270,7 +270,8 @@ __global__ void __launch_bounds__(256) k_rtab_fill(Workspace W, uint32_t count, 
     }
 }
 void launch_rtab(hipStream_t s, const Workspace& W, uint32_t count, uint32_t bits, const uint8_t* skip) {
-    hipLaunchKernelGGL(k_rtab_base, dim3((count + 63) / 64), dim3(64), 0, s, W, count, bits, skip);
+    if (count <= ZK_COOP_MAX_CHAINS / 8) launch_rtab_base_co(s, W, count, bits, skip);   // few proofs: the 256 doublings on a cooperating wave per proof (k_coop.hip)
+    else hipLaunchKernelGGL(k_rtab_base, dim3((count + 63) / 64), dim3(64), 0, s, W, count, bits, skip);
     hipLaunchKernelGGL(k_rtab_fill, dim3((count * rtab_nwin(bits) + 255) / 256), dim3(256), 0, s, W, count, bits, skip);
 }
 

@@ -22,6 +22,7 @@
 //   k_pm_reduce   workgroup (window, group): sum_d d * B_d by per-thread running sums and a tree of (F, G) segments
 //   k_pm_final    per group: windows (Horner, C doublings each) + R parts + (sum SH) * h_NIST == identity ?
 #include "rtab.h"
+#include "coop_dev.h"
 #include "ktab.h"
 
 #define PM_TERMS (VK + 1)
@@ -256,7 +257,7 @@ __global__ void __launch_bounds__(64) k_pm_rpart(Workspace W, VWork V, uint32_t 
         for (int l = 0; l < 9; l++) M.shpart[((size_t)g * PB + blockIdx.x) * 9 + l] = shs[l][0];
     }
 }
-// Workgroup g, 128 threads: wave 0 adds up the group's R parts and SH and walks h_NIST's comb; thread 64 joins the windows (Horner); thread 0 checks.
+// Workgroup g, 128 threads: wave 0 adds up the group's R parts and SH and walks h_NIST's comb; wave 1 joins the windows (Horner); thread 0 checks.
 template <int C>
 __global__ void __launch_bounds__(128) k_pm_final(DevParams P, uint32_t PB, uint32_t G, PMsmBuf M) {
     typedef PmShape<C> S;
@@ -276,15 +277,19 @@ __global__ void __launch_bounds__(128) k_pm_final(DevParams P, uint32_t PB, uint
 #pragma unroll
         for (int l = 0; l < 9; l++) shs[l][t] = shv.l[l];
     }
-    if (t == 64) {
-        P256Pt hw = ld_rtab(M.Tw + ((size_t)(S::nw - 1) * G + g) * PM_PT_WORDS);
+    if (t >= 64) {   // wave 1, cooperating (coop.h: one limb per lane, X, Y, Z in rows): (nw - 1) x (C doublings + 1 addition) in a row
+        const CoU32 mj = co_limbs(ModQ::mod);
+        CoP256 hw;
+        hw.v = co_load_aos<ModQ, 8, 3>(M.Tw + ((size_t)(S::nw - 1) * G + g) * PM_PT_WORDS);
 #pragma unroll 1
         for (int w = (int)S::nw - 2; w >= 0; w--) {
+            CoP256 tw;
+            tw.v = co_load_aos<ModQ, 8, 3>(M.Tw + ((size_t)w * G + g) * PM_PT_WORDS);
 #pragma unroll 1
-            for (int k = 0; k < C; k++) hw = p256_dbl(hw);
-            hw = p256_add(hw, ld_rtab(M.Tw + ((size_t)w * G + g) * PM_PT_WORDS));
+            for (int k = 0; k < C; k++) hw = co_p256_dbl(hw, mj);
+            hw = co_p256_add(hw, tw, mj);
         }
-        pm_sh_st(shw, 1, 0, hw);
+        co_store_aos<ModQ, 8, 3>(shw, hw.v);   // the layout pm_sh_ld(shw, 1, 0) reads
     }
     // (the tree's barriers are reached by all 128 threads; only the first 64 hold anything)
     acc = pm_block_sum(acc, 64, sh);
