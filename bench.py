@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 from bench_common import (DEFAULT_COMB_BITS, EXP_ADD_MACS, EXP_KT_ADDS, EXP_RTAB_ADDS, HBM_PEAK_GBPS, MACS_PER_MODMUL, PMC_SOURCE, TOM_COMMIT_BYTES, TOM_COMMIT_NOMINAL, TOM_COMMIT_PMC_BYTES,  # noqa: E402,F401
-                          TOM_COMMIT_VALU_ACTIVE_PER_WAVE, VALU_MAD_8CHAIN_TOPS, VALU_MAD_PEAK_TOPS, cpu_baseline, host_cores, nominal_modmuls, rank_seeds,
+                          TOM_COMMIT_VALU_ACTIVE_PER_WAVE, VALU_MAD_8CHAIN_TOPS, VALU_MAD_PEAK_TOPS, VERIFY_PMC_SOURCE, VERIFY_WHOLE_STEP_SIMD_BUSY, cpu_baseline, host_cores, nominal_modmuls, rank_seeds,
                           tom_commit_modmuls, v8_bigint_indicator)
 from bench_modes import host_io_rates, json_batch_rates, latency_table, run_pool_mode, run_verify_mode  # noqa: E402
 
@@ -49,7 +49,8 @@ def main():
     ap.add_argument('--verify-chunk', type=int, default=32768, help='proofs per pipeline pass of the verify half (0 = --chunk): the cross-proof sums like large chunks')
     ap.add_argument('--verify-lanes', type=int, default=2, help='chunks in flight of the verify half (0 = --lanes)')
     ap.add_argument('--roofline-steps', type=int, default=1, help='extra single-lane passes used only for per-kernel timings')
-    ap.add_argument('--verify-steps', type=int, default=1, help='timed verifySignatureList passes over the produced proofs (0 = skip)')
+    ap.add_argument('--verify-steps', type=int, default=-1, help='timed verifySignatureList passes over the produced proofs, each timed on its own (default: max(5, --steps); 0 = skip)')
+    ap.add_argument('--verify-warmup', type=int, default=1, help='untimed verify passes before the timed ones (the first allocates the verifier workspace)')
     ap.add_argument('--host-io', type=int, default=1 << 30, help='proofs of the zk_prove_batch / zk_verify_batch calls on HOST buffers (PCIe-inclusive rates; default: the whole batch; 0 = skip)')
     ap.add_argument('--host-io-chunk', type=int, default=16384, help='proofs per chunk of the zk_prove_batch --host-io calls (the PointAdd phase of a chunk runs in slices of 4096 proofs, each followed by its D2H)')
     ap.add_argument('--host-io-verify-chunk', type=int, default=8192, help='proofs per chunk of the zk_verify_batch --host-io calls (H2D-bound: smaller chunks start earlier and leave less work behind the last transfer)')
@@ -74,6 +75,18 @@ def main():
     ap.add_argument('--check', type=int, default=1 << 30, help='proofs of the last step diffed against the oracle on rank 0 (at most the CPU sample)')
     args = ap.parse_args()
 
+    if args.verify_steps < 0:
+        args.verify_steps = max(5, args.steps)
+    # A bare `python3 bench.py --gpus N` (N > 1, no launcher in the environment) starts its own ranks: the documented launch line, one rank per GPU.
+    if args.gpus > 1 and not args.pool and 'WORLD_SIZE' not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1', '--master-port', str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        print('bench.py: --gpus %d without WORLD_SIZE: re-executing as `%s`' % (args.gpus, ' '.join(cmd[1:])), file=sys.stderr, flush=True)
+        os.execv(sys.executable, cmd)
     import zkp_ecdsa_amd as Z
     if args.pool:
         return run_pool_mode(args, Z)
@@ -92,7 +105,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local_rank)
         dist.init_process_group('gloo' if one_device else 'nccl', rank=rank, world_size=world)
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    assert world == args.gpus, 'WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d (or without a launcher: bench.py starts its own ranks)' % (world, args.gpus, args.gpus)
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 
@@ -219,12 +232,16 @@ def main():
 
         def vstep():
             eng.verify_batch_device(B, d_msg.data_ptr(), d_out.data_ptr(), d_off.data_ptr(), d_vseeds.data_ptr(), d_ok.data_ptr(), d_vst.data_ptr())
-        vstep()  # warm-up (allocates the verifier workspace)
+        for _ in range(max(1, args.verify_warmup)):   # warm-up (the first call allocates the verifier workspace)
+            vstep()
         barrier()
         terms0 = eng.test_counter(2)
         tv0 = time.time()
+        vtimes = []   # every call returns with its verdicts in place (zk_verify_batch_device is synchronous): a step is one call
         for _ in range(args.verify_steps):
+            ts = time.time()
             vstep()
+            vtimes.append(time.time() - ts)
         barrier()
         vdt = time.time() - tv0
         msm_terms = (eng.test_counter(2) - terms0) // max(1, args.verify_steps)   # live terms of one step's batched Tom-256 check
@@ -232,6 +249,7 @@ def main():
         eng.set_lanes(1)
         vstep()
         _, vfam = eng.last_timing()
+        vwall = eng.last_wall_ms()   # first start -> last end of that pass (the families' sum counts v_msm_p256 twice: it runs beside v_msm_tom on an auxiliary stream)
         eng.set_lanes(args.lanes)
         eng.set_chunk(min(args.chunk, B))
         if world > 1:
@@ -239,10 +257,14 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             vdt = float(t.item())
         n_ok = int(d_ok.sum().item())
-        verify = {'value': round(world * B * args.verify_steps / vdt, 2), 'unit': 'verifies/s', 'steps': args.verify_steps,
-                  'ms_per_step': round(vdt * 1e3 / args.verify_steps, 2), 'accepted': n_ok, 'of': B, 'chunk': vchunk, 'lanes': vlanes, 'msm_live_terms': int(msm_terms),
+        vs = sorted(vtimes)
+        verify = {'value': round(world * B * args.verify_steps / vdt, 2), 'unit': 'verifies/s', 'steps': args.verify_steps, 'warmup': max(1, args.verify_warmup),
+                  'ms_per_step': round(vdt * 1e3 / args.verify_steps, 2), 'min_ms': round(vs[0] * 1e3, 2), 'median_ms': round(vs[len(vs) // 2] * 1e3, 2), 'max_ms': round(vs[-1] * 1e3, 2),
+                  'accepted': n_ok, 'of': B, 'chunk': vchunk, 'lanes': vlanes, 'msm_live_terms': int(msm_terms),
                   'gpu_ms_by_family_per_step': {k: round(v, 2) for k, v in sorted(vfam.items(), key=lambda kv: -kv[1])},
-                  'gpu_ms_note': 'serial single-lane pass; the timed passes overlap %d chunks on %d streams' % (vlanes, vlanes)}
+                  'gpu_ms_single_lane_wall': round(vwall, 2),
+                  'gpu_ms_note': 'single-lane pass (chunks one after the other; gpu_ms_single_lane_wall = its first kernel start to last kernel end); the timed passes overlap '
+                                 '%d chunks on %d streams' % (vlanes, vlanes)}
 
     free_b, total_b = torch.cuda.mem_get_info()
     hbm_used = total_b - free_b
@@ -331,7 +353,10 @@ def main():
                                   'traffic': 19015000000, 'traffic_note': 'bytes fetched per launch of a 32 768-proof chunk (FETCH_SIZE, its own rocprofv3 --pmc pass, raw: '
                                   'profiles/r05_pmc_verify.txt; a constant of bench.py, NOT measured in this run): the 137 M gathered 128-byte entries and their ids (18.2 GB), nothing re-read; '
                                   'SIMD busy 0.945',
-                                  'serial_ms_per_step': round(vsum, 2), 'non_arithmetic_ms': non_arith,
+                                  'family_sum_ms_per_step': round(vsum, 2), 'single_lane_wall_ms_per_step': verify.get('gpu_ms_single_lane_wall'),
+                                  'overlapped_families': ['v_msm_p256'],   # on an auxiliary stream beside v_msm_tom even with one lane: the family sum exceeds the wall time by that overlap
+                                  'whole_step_simd_busy': VERIFY_WHOLE_STEP_SIMD_BUSY, 'whole_step_source': VERIFY_PMC_SOURCE,
+                                  'non_arithmetic_ms': non_arith,
                                   'non_arithmetic_share': round(sum(non_arith.values()) / vsum, 3) if vsum else None,
                                   'note': 'non_arithmetic = SHA-256 (both challenges, the sampler\'s fills) and the hand-written grouping of the bucket pass\'s keys '
                                           '(k_msm_hist / _scatter / _binsort); v_parse_validate is arithmetic (one curve check per point)'}

@@ -108,12 +108,8 @@ zk_status zk_ctx_set_chunk(zk_ctx *ctx, uint32_t proofs_per_chunk);
  * kernels of the others; 1 = strictly serial kernels (what bench.py uses for its per-kernel roofline pass).  Every lane holds
  * a workspace of `chunk` proofs. */
 zk_status zk_ctx_set_lanes(zk_ctx *ctx, uint32_t lanes);
-/* Experimental schedules of the lanes, read from the environment by zk_ctx_create, all OFF by default and none changing a byte (DESIGN.md section 5e,
- * profiles/r05_overlap.txt: measured, none beats the default): ZKATTEST_LANE_PRIO="p0,p1,p2,p3" (stream priorities, -1 is served first),
- * ZKATTEST_HEAVY_FIFO=1|2 (the GPU-filling commitment kernels of all lanes on one extra stream; ZKATTEST_HEAVY_PRIO its priority),
- * ZKATTEST_PHASE_MAJOR=1, ZKATTEST_GK_BESIDE=1, ZKATTEST_HEAVY_LDS_KB=<n>, ZKATTEST_LANE_CUS / ZKATTEST_HEAVY_CUS="lo-hi" (CU masks, bits of 256), ZKATTEST_LANE_STAGGER=<1..5> (the lanes' first chunks start one stage-1 phase after
- * the other).  The verifier's bucket pass orders its buckets by size over the whole chunk;
- * ZKATTEST_MSM_ORDER=local orders them within each bin only (two launches fewer, slower bucket sums). */
+/* (The lane-scheduling experiments of round 5 -- a "heavy queue", stream priorities, CU masks, staggered starts: none beat this default -- are recorded in
+ * profiles/r05_overlap.txt; their switches are gone from the library.) */
 /* Width W (8..26 bits, default 16) of the fixed-base comb tables of the Tom-256 bases g and h: a commitment
  * v*g + r*h (PedersenParams.commit, src/commit/pedersen.ts:53-58) costs 2*ceil(256/W) table additions, the tables
  * take 2 * ceil(256/W) * 2^W * 128 bytes of HBM (0.27 GB at 16, 3.5 GB at 20, 47 GB at 24); 25 and 26 select SIGNED
@@ -338,6 +334,13 @@ zk_status zk_pool_verify_wait(zk_pool *pool, zk_pool_job *job);
  *       be64(N) || SHA-256 of every 256 consecutive entries of the padded ring).  Prover and verifier must use the same mode. */
 enum { ZK_MODE_REFERENCE = 0, ZK_MODE_HARDENED = 1 };
 zk_status zk_ctx_set_mode(zk_ctx *ctx, uint32_t mode);
+
+/* Zeroes the witness-derived device memory of the context: the prover lanes' workspaces (per proof: the RNG stream -- 116 KB --, the nonces, s1 = s / r, the
+ * blinders of every commitment) and the staging copy of the inputs of the host-pointer calls (signatures, seeds).  The library does this by itself in
+ * zk_ctx_destroy and when a prove call fails; a successful call leaves the memory to be overwritten by the next one, and a host that wants it gone earlier
+ * calls this (cost: one memset of the workspaces, ~4 ms per lane at 22 016 proofs per chunk).  No streamed job may be in flight.  The reference has no
+ * counterpart (src/zkpAttestList.ts:104-145 leaves its BigInts to the garbage collector). */
+zk_status zk_ctx_wipe(zk_ctx *ctx);
 zk_status zk_ring_digest(zk_ctx *ctx, uint8_t digest[32]);
 zk_status zk_hardened_h(const uint8_t *tag, uint64_t tag_len, uint8_t nist_h[64], uint8_t tom_h[72]);
 
@@ -370,9 +373,12 @@ zk_status zk_proofs_to_json_batch(uint64_t n, const uint8_t *proofs, const uint6
 zk_status zk_proofs_from_json_batch(uint64_t n, const char *texts, const uint64_t *text_off /*n+1*/, uint8_t *out, uint64_t out_cap,
                                     uint64_t *proof_off /*n+1*/, int32_t *per_proof_status /*n*/, uint32_t threads);
 
-/* Timing of the last prove/verify call: total GPU milliseconds between the first and last kernel (HIP events
- * on the engine's stream) and, per kernel family, the accumulated milliseconds.  names[i] are static strings. */
+/* Timing of the last prove/verify call from HIP events around every kernel family: per family the accumulated GPU milliseconds (names[i] are static
+ * strings; a name that starts with '+' is a part of another family), and *total_ms = their SUM ('+' parts excluded).  With one lane and a large chunk the
+ * families run one after the other and the sum is the GPU time of the call; with several lanes, and in small calls that fork work onto side streams, the
+ * families overlap and the sum exceeds the time that passed -- zk_last_wall_ms gives that: earliest start to latest end over the same events. */
 uint32_t zk_last_timing(const zk_ctx *ctx, float *total_ms, const char **names, float *ms, uint32_t cap);
+float zk_last_wall_ms(const zk_ctx *ctx);
 
 /* Diagnostic: the rate (GB/s) a page-locked copy of `bytes` (at least 1 MiB) reaches on the copy stream of pipeline lane `lane` (0..3), device
  * to host and host to device, measured with HIP events.  ~57 GB/s is what the link carries on MI355X boxes; ~27 GB/s says that the runtime of this

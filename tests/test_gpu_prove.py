@@ -33,37 +33,25 @@ def test_prove_matches_oracle_small(nkeys, B):
     eng.close()
 
 
-def test_lane_scheduling_knobs_do_not_change_the_bytes(monkeypatch):
-    """The opt-in schedules of round 5 (profiles/r05_overlap.txt; read by zk_ctx_create): the commitment kernels of all lanes on one low-priority
-    "heavy queue", stage 1 enqueued phase by phase across the lanes, the membership phase on the side stream behind the PointAdd commitments, lanes at
-    another priority, the commitment kernels padded to one workgroup per CU, CU masks.  Same proofs as the default schedule, sliced and unsliced."""
-    import zkp_ecdsa_amd as Z
-
-    def run(env):
-        for k in ('ZKATTEST_HEAVY_FIFO', 'ZKATTEST_PHASE_MAJOR', 'ZKATTEST_GK_BESIDE', 'ZKATTEST_LANE_PRIO', 'ZKATTEST_HEAVY_LDS_KB', 'ZKATTEST_HEAVY_PRIO',
-                  'ZKATTEST_LANE_CUS', 'ZKATTEST_HEAVY_CUS', 'ZKATTEST_LANE_STAGGER'):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        eng = Z.Engine(0)
-        eng.set_comb_bits(16)
-        eng.set_params(*eng.synth_params(321), 80)
-        ring, msg, sig, pk, which, seeds = eng.synth_workload(321, 2048, 1200)
-        eng.set_ring(ring, 2048)
-        eng.set_chunk(400), eng.set_lanes(3)         # three chunks on three lanes
-        a, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
-        assert not any(st)
-        eng.set_chunk(1200), eng.set_slice(512)      # one chunk whose PointAdd phase runs in three slices
-        b, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
-        assert not any(st) and a == b
-        eng.close()
-        return a
-    ref = run({})
-    assert run({'ZKATTEST_HEAVY_FIFO': '1', 'ZKATTEST_PHASE_MAJOR': '1', 'ZKATTEST_GK_BESIDE': '1', 'ZKATTEST_LANE_PRIO': '-1,-1,-1,-1'}) == ref
-    assert run({'ZKATTEST_HEAVY_FIFO': '2', 'ZKATTEST_GK_BESIDE': '1', 'ZKATTEST_HEAVY_PRIO': '0'}) == ref
-    assert run({'ZKATTEST_LANE_PRIO': '-1,0,1', 'ZKATTEST_HEAVY_LDS_KB': '84'}) == ref
-    assert run({'ZKATTEST_HEAVY_FIFO': '1', 'ZKATTEST_HEAVY_CUS': '0-192', 'ZKATTEST_LANE_CUS': '192-256'}) == ref   # CU masks
-    assert run({'ZKATTEST_LANE_STAGGER': '4'}) == ref   # the lanes' first chunks start one after the other
+def test_one_lane_and_cooperative_chains_make_the_same_bytes():
+    """ZKATTEST_ONE_LANE_CHAINS (the round-5 one-lane kernels for the dependent chains: A/B switch of profiles/r06_ab_variants.txt) against the default
+    (cooperating waves, csrc/coop.h): the same proofs and the same verdicts / statuses for honest and tampered proofs, each build of the switch in its own
+    process (it is read once)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    recs = []
+    for one_lane in (False, True):
+        env = dict(os.environ)
+        env.pop('ZKATTEST_ONE_LANE_CHAINS', None)
+        if one_lane:
+            env['ZKATTEST_ONE_LANE_CHAINS'] = '1'
+        out = subprocess.run([sys.executable, os.path.join(root, 'tests', 'chains_check.py')], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert out.returncode == 0, out.stderr.decode()[-2000:]
+        recs.append(json.loads(out.stdout.decode().strip().splitlines()[-1]))
+    assert recs[0]['one_lane'] is False and recs[1]['one_lane'] is True
+    assert recs[0]['sha256'] == recs[1]['sha256'] and recs[0]['verdicts'] == recs[1]['verdicts']
 
 
 def test_uniform_control_flow_build_makes_the_same_bytes():

@@ -81,6 +81,68 @@ def test_baseline_config3_batch65536_ring65536_verify_all_diff_one_percent():
     eng.close()
 
 
+def test_the_bench_configuration_itself_matches_the_oracle():
+    """bench.py's headline configuration as a test: 24-bit combs, per-key tables, 65 536 proofs over a ring of 2^16 keys, chunks of 22 016 on three lanes,
+    inputs and proofs resident in HBM (zk_prove_batch_device), then zk_verify_batch_device in chunks of 32 768 on two lanes.  64 seeded proofs are diffed
+    byte for byte against the oracle and their verdicts / statuses compared for the bench's verifier seeds; every proof must verify.  (The bench asserts the
+    same after its timed region; here a kernel regression at the headline shape turns the tier red.)"""
+    import torch
+    import zkp_ecdsa_amd as Z
+    from bench_common import DEFAULT_COMB_BITS, rank_seeds
+    assert DEFAULT_COMB_BITS == 24
+    B, nkeys, sec = 65536, 65536, 80
+    dev = torch.device('cuda', 0)
+    eng = Z.Engine(0)
+    params = eng.synth_params(2024)
+    eng.set_comb_bits(DEFAULT_COMB_BITS)
+    eng.set_params(*params, sec)
+    eng.set_chunk(22016)
+    eng.set_lanes(3)
+    ring, msg, sig, pk, which, seeds = eng.synth_workload(2024, nkeys, B)
+    tb = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d_ring = tb(ring)
+    eng.set_ring_device(d_ring.data_ptr(), nkeys)
+    my_seeds, vseeds = rank_seeds(seeds, 0), rank_seeds(seeds, 1000)
+    d_msg, d_sig, d_pk, d_seeds, d_vseeds = tb(msg), tb(sig), tb(pk), tb(my_seeds), tb(vseeds)
+    d_which = torch.tensor(which, dtype=torch.int32, device=dev)
+    cap = int(B * (304 + 336 * sec + 3392 * (sec // 2 + 4) + (4 * 72 + 96) * 20 + 32) + (64 << 20))
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_off = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    d_st = torch.empty(B, dtype=torch.int32, device=dev)
+    eng.prove_batch_device(B, d_msg.data_ptr(), d_sig.data_ptr(), d_pk.data_ptr(), d_which.data_ptr(), d_seeds.data_ptr(), d_out.data_ptr(), cap, d_off.data_ptr(), d_st.data_ptr())
+    torch.cuda.synchronize()
+    assert int((d_st != 0).sum().item()) == 0
+    assert eng.test_counter(1) > 0            # the last chunk's multiples of the signers' keys came from the per-key tables
+    off = d_off.cpu().tolist()
+    d_ok = torch.empty(B, dtype=torch.uint8, device=dev)
+    d_vst = torch.empty(B, dtype=torch.int32, device=dev)
+    eng.set_chunk(32768)
+    eng.set_lanes(2)
+    eng.verify_batch_device(B, d_msg.data_ptr(), d_out.data_ptr(), d_off.data_ptr(), d_vseeds.data_ptr(), d_ok.data_ptr(), d_vst.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_ok.sum().item()) == B and int((d_vst != 0).sum().item()) == 0
+    # 64 seeded proofs (the first of every chunk and lane boundary among them) against the oracle
+    rnd = random.Random(24)
+    sample = sorted(set([0, 22015, 22016, 44031, 44032, 65535, 32767, 32768]) | set(rnd.sample(range(B), 56)))
+    sub = lambda buf, w: b''.join(buf[w * b:w * b + w] for b in sample)
+    octx = _oracle(params, ring, nkeys, sec)
+    exp, est = octx.prove_batch(sub(msg, 32), sub(sig, 64), sub(pk, 64), [which[b] for b in sample], seeds=sub(my_seeds, 32), nthreads=64)
+    assert est == [0] * len(sample)
+    raw = {b: d_out[off[b]:off[b + 1]].cpu().numpy().tobytes() for b in sample}
+    bad = [b for j, b in enumerate(sample) if raw[b] != exp[j]]
+    assert not bad, bad[:8]
+    ook, ovst = octx.verify_batch(sub(msg, 32), [raw[b] for b in sample], nthreads=64, vseeds=sub(vseeds, 32))[:2]
+    ok, vst = d_ok.cpu().tolist(), d_vst.cpu().tolist()
+    assert [ok[b] for b in sample] == ook and [vst[b] for b in sample] == ovst
+    # a forged proof at the headline shape: the batched check fails for its group, the per-proof sums find it, the verdicts of the others stand
+    victim = sample[7]
+    d_out[off[victim + 1] - 9] ^= 0x10
+    eng.verify_batch_device(B, d_msg.data_ptr(), d_out.data_ptr(), d_off.data_ptr(), d_vseeds.data_ptr(), d_ok.data_ptr(), d_vst.data_ptr())
+    torch.cuda.synchronize()
+    assert (d_ok == 0).nonzero().flatten().tolist() == [victim]
+    eng.close()
+
+
 def test_baseline_config5_shape_ring_2_20_verify_4096():
     import zkp_ecdsa_amd as Z
     B, nkeys = 4096, 1 << 20
@@ -386,6 +448,24 @@ def test_tapered_chunk_plan_of_the_host_pointer_calls_keeps_the_bytes():
     assert [bytes(page[off2[b]:off2[b + 1]]) for b in pick] == exp
     pin.free()
     eng.close()
+
+
+def test_bench_starts_its_own_ranks_from_a_bare_gpus_line():
+    """`python3 bench.py --gpus 2` with no launcher in the environment (what a driver types): bench.py re-executes itself under torch.distributed.run, one
+    rank per GPU, and rank 0 prints ONE line with n_gpus = 2.  Both ranks share cuda:0 here (ZK_BENCH_ONE_DEVICE, gloo group)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['ZK_BENCH_ONE_DEVICE'] = '1'
+    import json
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--batch', '2048', '--ring', '4096', '--chunk', '1024', '--lanes', '2',
+                          '--verify-chunk', '1024', '--comb-bits', '16', '--host-io', '0', '--cpu-sample', '2', '--json-sample', '0', '--latency', '0'],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')]
+    assert res.returncode == 0 and len(lines) == 1, res.stdout[-2000:] + res.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['failed_proofs'] == 0 and d['verify']['accepted'] == d['verify']['of'] and d['verify']['steps'] >= 5
+    assert 're-executing' in res.stderr
 
 
 @pytest.mark.parametrize('mode', ['prove', 'verify'])

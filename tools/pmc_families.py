@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Per-family and whole-step view of rocprofv3 --pmc passes over the prover (the families of bench.py's gpu_ms_by_family_per_step).
-    python tools/pmc_families.py PROOFS <pmc dir> [<pmc dir> ...]
+"""Per-family and whole-step view of rocprofv3 --pmc passes over the prover (the families of bench.py's gpu_ms_by_family_per_step) or, with --verify,
+over the verifier (the families of verify.gpu_ms_by_family_per_step: only the dispatches from the first k_v_header on are counted, divided by --steps).
+    python tools/pmc_families.py [--verify] [--steps N] PROOFS <pmc dir> [<pmc dir> ...]
 Every directory holds one pass (counter_collection CSVs, any subset of: SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE FETCH_SIZE WRITE_SIZE) plus kernel_trace CSVs for the durations.  SQ_* cycle counters
 are quad-cycles summed over waves (MI355X_MICROARCH.md); GRBM_GUI_ACTIVE counts shader-clock cycles per dispatch and is reported summed over the
@@ -31,6 +32,19 @@ FAMILIES = [
     ('scan', r'k_scan|k_items|k_words_to_host'),
     ('p256_t1', r'k_t1\b'),
 ]
+VFAMILIES = [
+    ('v_msm_tom', r'k_msm_'),
+    ('v_msm_p256', r'k_pm_'),
+    ('v_p256_exp_points', r'k_v_exp_points|k_v_exp_status|k_p256_normalize'),
+    ('v_hash', r'k_v_challenges|k_v_exph_msg|k_exph_|k_v_sample|k_v_padd_hash'),
+    ('v_terms', r'k_v_slot_|k_v_proof_'),
+    ('v_parse_validate', r'k_v_header|k_v_validate|k_v_unpack|k_offsets_monotonic'),
+    ('v_gk_total', r'k_v_gk_|k_gkm_|k_v_clambda'),
+    ('v_p256_front_rtab', r'k_v_front_|k_rtab_'),
+    ('v_tom_fixed', r'k_v_t1_scalars|k_tom_commit|k_tom_normalize|k_v_derived'),
+    ('v_per_proof_sums', r'k_v_straus|k_v_term_tables|k_v_acc_tree|k_v_p256_'),
+    ('v_final', r'k_v_final|k_words_to_host|k_default_vseeds'),
+]
 SETUP = r'k_tomtab|k_pfix|k_ktab|k_gk_etab|k_gkm_(ring|etab)|k_ring|k_synth|k_build|fillBuffer|copyBuffer|k_bytes_to|k_affine_to'
 
 
@@ -44,22 +58,42 @@ def family(name):
 
 
 def main():
-    proofs = int(sys.argv[1])
+    global FAMILIES
+    argv = sys.argv[1:]
+    verify = '--verify' in argv
+    if verify:
+        argv.remove('--verify')
+        FAMILIES = VFAMILIES
+    steps = 1
+    if '--steps' in argv:
+        i = argv.index('--steps')
+        steps = int(argv[i + 1])
+        del argv[i:i + 2]
+    proofs = int(argv[0])
     cnt = collections.defaultdict(lambda: collections.defaultdict(float))
     dur = collections.defaultdict(float)
     seen_dur = False
-    for d in sys.argv[2:]:
+    for d in argv[1:]:
         for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
-            for r in csv.DictReader(open(f)):
-                fam = family(r.get('Kernel_Name', r.get('Kernel Name', '?')))
+            rows = list(csv.DictReader(open(f)))
+            name_of = lambda r: r.get('Kernel_Name', r.get('Kernel Name', '?'))
+            first_v = min([int(r['Dispatch_Id']) for r in rows if name_of(r).startswith('k_v_header')] or [0]) if verify else 0
+            for r in rows:
+                if verify and int(r['Dispatch_Id']) < first_v:
+                    continue
+                fam = family(name_of(r))
                 if fam:
-                    cnt[fam][r['Counter_Name']] += float(r['Counter_Value'])
+                    cnt[fam][r['Counter_Name']] += float(r['Counter_Value']) / steps
         if not seen_dur:
             for f in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True):
-                for r in csv.DictReader(open(f)):
+                rows = list(csv.DictReader(open(f)))
+                t_v = min([float(r['Start_Timestamp']) for r in rows if r.get('Kernel_Name', '?').startswith('k_v_header')] or [0]) if verify else 0
+                for r in rows:
+                    if verify and float(r['Start_Timestamp']) < t_v:
+                        continue
                     fam = family(r.get('Kernel_Name', '?'))
                     if fam:
-                        dur[fam] += (float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e6
+                        dur[fam] += (float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e6 / steps
                         seen_dur = True
     tot = collections.defaultdict(float)
     print('%-16s %8s %10s %8s %8s %8s %9s %10s' % ('family', 'ms', 'VALU/proof', 'valu/wv', 'wait_mem', 'wait_iss', 'SIMD busy', 'B/proof'))

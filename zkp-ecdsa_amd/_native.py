@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 # every symbol include/zkattest.h declares
 SYMBOLS = [
     'zk_ctx_create', 'zk_ctx_destroy', 'zk_strerror', 'zk_last_error', 'zk_ctx_set_params', 'zk_ctx_set_ring',
-    'zk_ctx_set_ring_device', 'zk_keys_to_ints', 'zk_ctx_set_chunk', 'zk_ctx_set_lanes', 'zk_ctx_set_comb_bits', 'zk_ctx_set_batch_verify', 'zk_proof_max_size', 'zk_prove_batch', 'zk_prove_batch_device',
+    'zk_ctx_set_ring_device', 'zk_ctx_wipe', 'zk_last_wall_ms', 'zk_keys_to_ints', 'zk_ctx_set_chunk', 'zk_ctx_set_lanes', 'zk_ctx_set_comb_bits', 'zk_ctx_set_batch_verify', 'zk_proof_max_size', 'zk_prove_batch', 'zk_prove_batch_device',
     'zk_verify_batch', 'zk_verify_batch_device', 'zk_synth_workload', 'zk_synth_params', 'zk_last_timing',
     'zk_proof_to_json', 'zk_proof_from_json', 'zk_host_alloc', 'zk_host_free', 'zk_ctx_set_host_taper', 'zk_ctx_set_slice', 'zk_ctx_set_mode', 'zk_ring_digest', 'zk_hardened_h',
     'zk_pool_create', 'zk_pool_destroy', 'zk_pool_size', 'zk_pool_ctx', 'zk_pool_last_error', 'zk_pool_ring_transport', 'zk_pool_rccl_library', 'zk_pool_shard',
@@ -377,6 +377,12 @@ class Engine:
         """Comb width of the Tom-256 fixed-base tables (8..24 unsigned, 25/26 signed digits); call before set_params."""
         self._chk(self.L.zk_ctx_set_comb_bits(self.h, bits))
 
+    def wipe(self):
+        """zero the witness-derived device memory of the context (prover workspaces, staged inputs); also done by close() and after a failed prove call"""
+        self.L.zk_ctx_wipe.argtypes = [C.c_void_p]
+        self.L.zk_ctx_wipe.restype = C.c_int
+        self._chk(self.L.zk_ctx_wipe(self.h))
+
     def set_batch_verify(self, min_chunk):
         """Chunks of >= min_chunk proofs (default 256; 0 never, 1 always) get the chunk-wide bucket-method check of the
         Tom-256 relations first; the per-proof sums only run when it fails."""
@@ -526,6 +532,12 @@ class Engine:
         ms = (C.c_float * 32)()
         n = self.L.zk_last_timing(self.h, C.byref(total), names, ms, 32)
         return total.value, {names[i].decode(): ms[i] for i in range(min(n, 32))}
+
+    def last_wall_ms(self):
+        """earliest start -> latest end of the last call's timed kernel families (last_timing()[0] is their sum, which overlapping families exceed)"""
+        self.L.zk_last_wall_ms.argtypes = [C.c_void_p]
+        self.L.zk_last_wall_ms.restype = C.c_float
+        return float(self.L.zk_last_wall_ms(self.h))
 
     # ---- unit-test hooks
     def test_field_op(self, which, op, a_list, b_list):
@@ -681,9 +693,13 @@ class Pool:
         return t['off'], t['ln'], t['st']
 
     def test_fail_submit(self, slot):
-        """fault injection (tests): the next streamed submit of the process fails at device slot `slot` after the earlier slots were submitted.  An
-        environment gate of the library (ZKATTEST_TEST_FAIL_SUBMIT, consumed by the submit), not an exported hook."""
-        os.environ['ZKATTEST_TEST_FAIL_SUBMIT'] = str(slot)
+        """fault injection (tests): the next streamed submit of this pool fails at device slot `slot` after the earlier slots were submitted.  Only the test
+        build of the library has the entry point (csrc/Makefile `testhooks`: lib/libzkattest_hip_testhooks.so, selected with ZKATTEST_LIB)."""
+        if not hasattr(self.L, 'zk_test_pool_fail_next_submit'):
+            raise RuntimeError('this build has no fault injection (load lib/libzkattest_hip_testhooks.so through ZKATTEST_LIB)')
+        self.L.zk_test_pool_fail_next_submit.argtypes = [C.c_void_p, C.c_int]
+        self.L.zk_test_pool_fail_next_submit.restype = None
+        self.L.zk_test_pool_fail_next_submit(self.h, int(slot))
 
     def verify_submit(self, msg, proofs, off, ln, B, vseeds=None):
         t = {'B': B, 'proofs': proofs, 'off': off, 'ln': ln, 'ok': (C.c_uint8 * B)(), 'st': (C.c_int32 * B)(), 'msg': bytes(msg),

@@ -61,11 +61,6 @@ __attribute__((constructor)) static void zk_more_hw_queues() {
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
 }
 
-size_t heavy_lds_pad() {
-    const char* e = getenv("ZKATTEST_HEAVY_LDS_KB");   // (read per launch: tools/exp_overlap.py changes it between contexts of one process)
-    long kb = e ? atol(e) : 0;
-    return (size_t)(kb > 0 && kb <= 156 ? kb : 0) << 10;
-}
 static zk_status ctx_init(zk_ctx* c, int device_id);
 // *out is either a fully initialised context or NULL (then zk_last_error(NULL) has the reason): a caller never holds a half-built one
 extern "C" zk_status zk_ctx_create(int device_id, zk_ctx** out) {
@@ -85,59 +80,9 @@ extern "C" zk_status zk_ctx_create(int device_id, zk_ctx** out) {
 }
 static zk_status ctx_init(zk_ctx* c, int device_id) {
     HIPCHK(c, hipSetDevice(device_id));
-    // Stream priorities: hipDeviceGetStreamPriorityRange gives [-1 (served first), 1] on this runtime.  ZKATTEST_LANE_PRIO = "p0,p1,p2,p3" sets the
-    // lanes' compute streams (default 0 = plain hipStreamCreate).
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // (least, greatest): numerically prio_hi <= prio_lo
-    auto clamp_prio = [&](int p) { return p < prio_hi ? prio_hi : p > prio_lo ? prio_lo : p; };
-    int lane_prio[ZK_MAX_LANES] = {};
-    if (const char* e = getenv("ZKATTEST_LANE_PRIO")) {
-        int l = 0;
-        for (const char* q = e; *q && l < ZK_MAX_LANES; l++) {
-            lane_prio[l] = clamp_prio(atoi(q));
-            while (*q && *q != ',') q++;
-            if (*q == ',') q++;
-        }
-    }
-    // CU masks (experiment): ZKATTEST_LANE_CUS / ZKATTEST_HEAVY_CUS = "lo-hi" restrict the lanes' compute streams / the heavy queue to the
-    // mask bits [lo, hi) of 256 (the driver deals consecutive bits round-robin over the 8 XCDs, so a range of k bits is k / 8 CUs of every XCD).
-    auto cu_mask = [&](const char* name, uint32_t m[8]) -> bool {
-        const char* e = getenv(name);
-        int lo = 0, hi = 0;
-        if (!e || sscanf(e, "%d-%d", &lo, &hi) != 2 || lo < 0 || hi > 256 || lo >= hi) return false;
-        for (int i = 0; i < 8; i++) m[i] = 0;
-        for (int b = lo; b < hi; b++) m[b >> 5] |= 1u << (b & 31);
-        return true;
-    };
-    uint32_t lane_mask[8], heavy_mask[8];
-    const bool lanes_masked = cu_mask("ZKATTEST_LANE_CUS", lane_mask), heavy_masked = cu_mask("ZKATTEST_HEAVY_CUS", heavy_mask);
     for (int base = 0; base < ZK_MAX_LANES; base += 2) {   // compute 0, compute 1, copy 0, copy 1; then the same for lanes 2, 3
-        for (int l = base; l < base + 2; l++) {
-            if (lanes_masked) HIPCHK(c, hipExtStreamCreateWithCUMask(&c->pl[l].stream, 8, lane_mask));
-            else if (lane_prio[l]) HIPCHK(c, hipStreamCreateWithPriority(&c->pl[l].stream, hipStreamDefault, lane_prio[l]));
-            else HIPCHK(c, hipStreamCreate(&c->pl[l].stream));
-        }
+        for (int l = base; l < base + 2; l++) HIPCHK(c, hipStreamCreate(&c->pl[l].stream));
         for (int l = base; l < base + 2; l++) HIPCHK(c, hipStreamCreateWithFlags(&c->pl[l].copy_stream, hipStreamNonBlocking));
-    }
-    // The heavy queue (ctx.h): ZKATTEST_HEAVY_FIFO = 1 (every commitment kernel) / 2 (the PointAdd commitments only), ZKATTEST_HEAVY_PRIO its
-    // priority (default: the lowest, so that whatever the lanes' streams hold is placed first), ZKATTEST_PHASE_MAJOR / ZKATTEST_GK_BESIDE: see ctx.h.
-    if (const char* e = getenv("ZKATTEST_HEAVY_FIFO")) c->heavy_mode = atoi(e);
-    if (c->heavy_mode) {
-        int hp = prio_lo;
-        if (const char* e = getenv("ZKATTEST_HEAVY_PRIO")) hp = clamp_prio(atoi(e));
-        if (heavy_masked) HIPCHK(c, hipExtStreamCreateWithCUMask(&c->heavy, 8, heavy_mask));
-        else HIPCHK(c, hipStreamCreateWithPriority(&c->heavy, hipStreamNonBlocking, hp));
-        for (int l = 0; l < ZK_MAX_LANES; l++)
-            for (hipEvent_t* ev : {&c->pl[l].hv_to, &c->pl[l].hv_from, &c->pl[l].hv_to2, &c->pl[l].hv_from2}) HIPCHK(c, hipEventCreateWithFlags(ev, hipEventDisableTiming));
-    }
-    if (const char* e = getenv("ZKATTEST_PHASE_MAJOR")) c->phase_major = atoi(e) != 0;
-    if (const char* e = getenv("ZKATTEST_GK_BESIDE")) c->gk_beside = atoi(e) != 0;
-    if (const char* e = getenv("ZKATTEST_COPY_STREAMS")) {   // experiment knob (tools/exp_pool_first_call.py): 1 = every lane copies out on lane 0's copy stream
-        if (atoi(e) == 1)
-            for (int l = 1; l < ZK_MAX_LANES; l++) {
-                hipStreamDestroy(c->pl[l].copy_stream);
-                c->pl[l].copy_stream = c->pl[0].copy_stream;
-            }
     }
     c->stream = c->pl[0].stream;
     c->copy_stream = c->pl[0].copy_stream;   // H2D of the verifier's proofs
@@ -190,12 +135,35 @@ extern "C" zk_status zk_ctx_set_comb_bits(zk_ctx* c, uint32_t bits) {
 }
 void stream_release_spares(zk_ctx* c);   // api_stream.hip
 void stream_abandon_jobs(zk_ctx* c);
+// Witness-derived device memory of a context: the prover lanes' workspaces (the RNG stream of every proof -- 116 KB each --, nonces, s1 = s / r, blinders,
+// responses before they are written out) and the staging buffer of the host-pointer calls (signatures, seeds).  Zeroed when the context is destroyed, when a
+// prove call fails, and on request (zk_ctx_wipe); a successful call leaves them as they are -- the next call overwrites them, and wiping 2.5 GB of RNG
+// stream per 22 016-proof chunk would cost ~0.5 ms of every call.  (The reference leaves its BigInts to the garbage collector.)  Nothing may be in flight.
+static void wipe_witness(zk_ctx* c) {
+    for (int l = 0; l < ZK_MAX_LANES; l++)
+        if (c->pl[l].arena && c->pl[l].stream) (void)hipMemsetAsync(c->pl[l].arena, 0, c->pl[l].arena_bytes, c->pl[l].stream);
+    if (c->in_buf && c->stream) (void)hipMemsetAsync(c->in_buf, 0, c->in_bytes, c->stream);
+    for (int l = 0; l < ZK_MAX_LANES; l++)
+        if (c->pl[l].stream) (void)hipStreamSynchronize(c->pl[l].stream);
+    (void)hipGetLastError();
+}
+extern "C" zk_status zk_ctx_wipe(zk_ctx* c) {
+    if (!c) return ZK_E_ARG;
+    if (c->stream_busy) {
+        c->err = "streamed jobs are in flight on this context (zk_prove_wait / zk_verify_wait them first)";
+        return ZK_E_ARG;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    wipe_witness(c);
+    return ZK_OK;
+}
 extern "C" void zk_ctx_destroy(zk_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     stream_abandon_jobs(c);
     stream_release_spares(c);
+    wipe_witness(c);
     for (auto e : c->epool) hipEventDestroy(e);
     hipFree(c->P.tom_tab_g), hipFree(c->P.tom_tab_h), hipFree(c->tom_tab_gen), hipFree(c->P.pfix_G), hipFree(c->P.pfix_H);
     hipFree(c->gk_kdig), hipFree(c->gk_edig), hipFree(c->ktab), hipFree(c->ktab_ok);
@@ -214,12 +182,10 @@ extern "C" void zk_ctx_destroy(zk_ctx* c) {
         if (c->pl[l].side_fork) hipEventDestroy(c->pl[l].side_fork);
         if (c->pl[l].side_done) hipEventDestroy(c->pl[l].side_done);
         if (c->pl[l].side) hipStreamDestroy(c->pl[l].side);
-        for (hipEvent_t ev : {c->pl[l].hv_to, c->pl[l].hv_from, c->pl[l].hv_to2, c->pl[l].hv_from2})
-            if (ev) hipEventDestroy(ev);
-        if (c->pl[l].copy_stream && (l == 0 || c->pl[l].copy_stream != c->pl[0].copy_stream)) hipStreamDestroy(c->pl[l].copy_stream);
+        if (c->vl[l].msm_done) hipEventDestroy(c->vl[l].msm_done);
+        if (c->pl[l].copy_stream) hipStreamDestroy(c->pl[l].copy_stream);
         if (c->pl[l].stream) hipStreamDestroy(c->pl[l].stream);
     }
-    if (c->heavy) hipStreamDestroy(c->heavy);
     delete c;
 }
 
@@ -668,7 +634,6 @@ static size_t host_alloc_hold_limit() {
 void* alloc_fast_pinned(size_t bytes, const std::function<void*()>& alloc, const std::function<void(void*)>& release) {
     const bool probe = host_alloc_probe_enabled() && bytes >= (64u << 20);
     const float expected = probe ? link_expected_gbps() : 0.f;
-    const bool dbg = getenv("ZK_ALLOC_DEBUG") != nullptr;
     void *best = nullptr, *held[ZK_ALLOC_TRIES] = {};
     float best_r = -1.f;
     int nheld = 0;
@@ -680,7 +645,6 @@ void* alloc_fast_pinned(size_t bytes, const std::function<void*()>& alloc, const
         const float r = probe ? pinned_d2h_rate(p, bytes) : 0.f;
         float seen = g_best_pinned_rate.load(std::memory_order_relaxed);
         const bool had_yardstick = seen > 0.f;
-        if (dbg) fprintf(stderr, "alloc: candidate %d of %zu MB: %.1f GB/s device-to-host (link should carry %.1f, best seen so far %.1f)\n", t, bytes >> 20, r, expected, seen);
         while (r > seen && !g_best_pinned_rate.compare_exchange_weak(seen, r, std::memory_order_relaxed)) {
         }
         seen = seen > r ? seen : r;
@@ -767,7 +731,7 @@ static zk_status ensure_side_stream(zk_ctx* c, zk_ctx::ProveLane& PL) {
     if (!PL.side_done) HIPCHK(c, hipEventCreateWithFlags(&PL.side_done, hipEventDisableTiming));
     return ZK_OK;
 }
-zk_status ProveJob::stage1(uint64_t chunk_no, int ph0, int ph1) {
+zk_status ProveJob::stage1(uint64_t chunk_no) {
     const ChunkPlan& cp = plan[chunk_no];
     const DevParams& P = c->P;
     const uint32_t lane = lane_of(chunk_no);
@@ -775,11 +739,10 @@ zk_status ProveJob::stage1(uint64_t chunk_no, int ph0, int ph1) {
     hipStream_t s = c->pl[lane].stream;
     const uint64_t first = cp.first;
     const uint32_t cnt = cp.cnt;
-    auto in_phase = [&](int ph) { return ph0 <= ph && ph < ph1; };
     const ChunkIn in{d_msg + 32 * first, d_sig + 64 * first, d_pk + 64 * first, d_which + first, cnt};
     const uint32_t nblk = 3 + 44 * W.sec + 5 * W.n + RNG_MAX_EXC;
     Pending& pd = pend[lane];
-    if (in_phase(0)) {
+    {
         c->pl[lane].last_cnt = cnt;
         if (io_dbg) fprintf(stderr, "host %7.1f ms: stage1 of chunk %u (%u proofs) -> lane %u\n", host_ms() - host_t0, (uint32_t)chunk_no, cnt, lane);
         if (inputs_ready) HIPCHK(c, hipStreamWaitEvent(s, inputs_ready, 0));
@@ -802,16 +765,12 @@ zk_status ProveJob::stage1(uint64_t chunk_no, int ph0, int ph1) {
             launch_rtab(s, W, cnt, RTAB_PROVE_BITS, W.ktab ? W.kt_use : nullptr);   // proofs on the key-table path need no table of R
         }
     }
-    if (in_phase(1)) {
-        hipStream_t h = heavy_begin(lane, s);
-        {
-            MaybeScope t(timed, c, "p256_exp_commit", h);
-            launch_exp_commit(h, P, W, cnt);
-        }
-        heavy_end(lane, s, h);
+    {
+        MaybeScope t(timed, c, "p256_exp_commit", s);
+        launch_exp_commit(s, P, W, cnt);
     }
     const uint32_t na = cnt * (2 + 2 * W.sec);
-    if (in_phase(2)) {
+    {
         {
             MaybeScope t(timed, c, "p256_normalize", s);
             auto& PL = c->pl[lane];
@@ -833,15 +792,11 @@ zk_status ProveJob::stage1(uint64_t chunk_no, int ph0, int ph1) {
             launch_lista_scalars(s, W, cnt);
         }
     }
-    if (in_phase(3)) {
-        hipStream_t h = heavy_begin(lane, s);
-        {
-            MaybeScope t(timed, c, "tom_commit", h);
-            launch_tom_commit(h, P, W.la, na, 1, 1);
-        }
-        heavy_end(lane, s, h);
+    {
+        MaybeScope t(timed, c, "tom_commit", s);
+        launch_tom_commit(s, P, W.la, na, 1, 1);
     }
-    if (in_phase(4)) {
+    {
         {
             MaybeScope t(timed, c, "tom_normalize", s);
             launch_tom_normalize(s, W.la, na, 0, 1, 1);
@@ -853,37 +808,12 @@ zk_status ProveJob::stage1(uint64_t chunk_no, int ph0, int ph1) {
     }
     return ZK_OK;
 }
-// Stage 1 of every chunk the look-ahead reaches (chunks next_s1 .. upto - 1).  With a heavy queue and c->phase_major the phases of these chunks are
-// enqueued phase by phase ACROSS the chunks, so that the heavy queue holds exp(0) exp(1) exp(2) listA(0) listA(1) ... and a lane's light kernels between
-// two of its heavy ones run under the other lanes' heavy kernels instead of holding the queue up.
+// Stage 1 of every chunk the look-ahead reaches (chunks next_s1 .. upto - 1), each on its lane's stream.
 static zk_status prove_stage1_upto(ProveJob& J, uint64_t upto) {
     zk_status zs = ZK_OK;
     const uint64_t a = J.next_s1, b = std::min<uint64_t>(upto, J.plan.size());
-    if (b <= a) return ZK_OK;
-    if (J.c->heavy && J.c->phase_major && b - a > 1) {
-        for (int ph = 0; ph < ProveJob::S1_PHASES && !zs; ph++)
-            for (uint64_t k = a; k < b && !zs; k++) zs = J.stage1(k, ph, ph + 1);
-    } else {
-        // ZKATTEST_LANE_STAGGER = p (1..5; experiment): the first chunk of lane l + 1 starts on the GPU when the first chunk of lane l has finished p of
-        // stage 1's five phases -- the lanes then run out of phase without smaller chunks (an event wait on the stream, the host does not block)
-        const char* stagger_env = getenv("ZKATTEST_LANE_STAGGER");
-        const int stagger = stagger_env ? atoi(stagger_env) : 0;
-        for (uint64_t k = a; k < b && !zs; k++) {
-            if (stagger > 0 && stagger <= ProveJob::S1_PHASES && J.NL > 1 && k < J.NL) {
-                zk_ctx* c = J.c;
-                const uint32_t lane = J.lane_of(k);
-                auto& PL = c->pl[lane];
-                if (!PL.stagger_ev && hipEventCreateWithFlags(&PL.stagger_ev, hipEventDisableTiming) != hipSuccess) return ZK_E_DEVICE;
-                if (k > 0 && hipStreamWaitEvent(PL.stream, c->pl[J.lane_of(k - 1)].stagger_ev, 0) != hipSuccess) return ZK_E_DEVICE;
-                zs = J.stage1(k, 0, stagger);
-                if (!zs && hipEventRecord(PL.stagger_ev, PL.stream) != hipSuccess) return ZK_E_DEVICE;
-                if (!zs && stagger < ProveJob::S1_PHASES) zs = J.stage1(k, stagger, ProveJob::S1_PHASES);
-            } else {
-                zs = J.stage1(k);
-            }
-        }
-    }
-    J.next_s1 = b;
+    for (uint64_t k = a; k < b && !zs; k++) zs = J.stage1(k);
+    if (b > a) J.next_s1 = b;
     return zs;
 }
 // Stage 2.  Order: scan -> fixed part and rep heads -> the whole Groth-Kohlweiss phase -> the PointAdd phase (80 % of the
@@ -948,12 +878,9 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
         launch_write_fixed(s, W, cnt, out);
     }
     // A small chunk leaves the GPU idle and its phases are chains of latencies: the membership phase (list C, its own hash and responses) runs on the
-    // lane's side stream beside the PointAdd phase (list B); they share only what stage 1 and the scan left behind.  With a heavy queue and c->gk_beside
-    // every unsliced chunk does this, and the membership phase is enqueued BEHIND the PointAdd commitments: its ring fold then runs under them and its own
-    // commitments do not hold the heavy queue up while the fold is still running.
+    // lane's side stream beside the PointAdd phase (list B); they share only what stage 1 and the scan left behind.
     auto& PL = c->pl[pd.lane];
-    const bool gk_late = !sliced && c->heavy && c->gk_beside;
-    const bool beside = !sliced && ((plan.size() == 1 && cnt <= ZK_PROVE_SIDE_MAX) || gk_late);   // (chunks of a longer job overlap each other on the lanes already)
+    const bool beside = !sliced && plan.size() == 1 && cnt <= ZK_PROVE_SIDE_MAX;   // (chunks of a longer job overlap each other on the lanes already)
     hipStream_t sg = s;
     if (beside) {
         if (timed) c->timing_forked = true;
@@ -970,12 +897,8 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
             launch_gk_cd_scalars(sg, W, cnt);
         }
         {
-            hipStream_t h = heavy_begin(pd.lane, sg, sg != s);
-            {
-                MaybeScope t(timed, c, "tom_commit", h);
-                launch_tom_commit(h, P, W.lc, cnt * 4 * W.n, 1, 1);
-            }
-            heavy_end(pd.lane, sg, h, sg != s);
+            MaybeScope t(timed, c, "tom_commit", sg);
+            launch_tom_commit(sg, P, W.lc, cnt * 4 * W.n, 1, 1);
         }
         {
             MaybeScope t(timed, c, "tom_normalize", sg);
@@ -992,10 +915,7 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
         if (beside) HIPCHK(c, hipEventRecord(PL.side_done, sg));
         return ZK_OK;
     };
-    if (!gk_late) {
-        zk_status zs = membership_phase();
-        if (zs) return zs;
-    }
+    if (zk_status zs = membership_phase()) return zs;
     std::vector<ChunkPlan> slices;
     if (sliced) slices = make_chunk_plan(cnt, S, 1, host_sink != nullptr && !more_follows, last_chunk ? ZK_SLICE_MIN / 2 : ZK_SLICE_MIN);   // the call's very last slices stay exposed
     else slices.push_back({0, cnt});
@@ -1022,16 +942,8 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
                 launch_padd_scalars(s, P, Ws, items);
             }
             {
-                hipStream_t h = heavy_begin(pd.lane, s, false, true);
-                {
-                    MaybeScope t(timed, c, "tom_commit", h);
-                    launch_tom_commit_listb(h, P, Ws.lb, items, Ws.items_cap);
-                }
-                heavy_end(pd.lane, s, h);
-            }
-            if (gk_late) {   // (unsliced: the one pass of this loop)
-                zk_status zs = membership_phase();
-                if (zs) return zs;
+                MaybeScope t(timed, c, "tom_commit", s);
+                launch_tom_commit_listb(s, P, Ws.lb, items, Ws.items_cap);
             }
             {
                 MaybeScope t(timed, c, "tom_normalize", s);
@@ -1052,10 +964,6 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
                 launch_write_padd_points(s, Ws, items, out);
             }
         }
-        if (gk_late && !items) {   // (a chunk without a single zero-bit repetition: cryptographically negligible, but the phase must run)
-            zk_status zs = membership_phase();
-            if (zs) return zs;
-        }
         if (beside) HIPCHK(c, hipStreamWaitEvent(s, PL.side_done, 0));   // (not sliced: the one pass of this loop)
         if (host_sink) {   // every byte of proofs [p0, p1) is final: DMA them out behind the next slice's kernels
             const uint64_t b0 = sliced ? h_out_base[p0] : 0, b1 = sliced ? h_out_base[p1] : chunk_bytes;
@@ -1070,12 +978,7 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
                 HIPCHK(c, hipEventRecord(ev, s));
                 HIPCHK(c, hipStreamWaitEvent(c->pl[pd.lane].copy_stream, ev, 0));
                 if (io_dbg) hipEventRecord(r.c0, c->pl[pd.lane].copy_stream);
-                // in pieces: ZKATTEST_COPY_PIECE_MB (default 512) bounds one DMA command
-                static const uint64_t piece = [] {
-                    const char* e = getenv("ZKATTEST_COPY_PIECE_MB");
-                    uint64_t mb = e ? strtoull(e, nullptr, 10) : 512;
-                    return (mb ? mb : 512) << 20;
-                }();
+                const uint64_t piece = 512ull << 20;   // one DMA command moves at most this much
                 for (uint64_t o = b0; o < b1; o += piece)
                     HIPCHK(c, hipMemcpyAsync(host_sink + cursor + o, out + o, std::min<uint64_t>(piece, b1 - o), hipMemcpyDeviceToHost, c->pl[pd.lane].copy_stream));
                 if (io_dbg) {
@@ -1107,8 +1010,7 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
     J.c = c, J.B = B, J.d_msg = d_msg, J.d_sig = d_sig, J.d_pk = d_pk, J.d_which = d_which, J.rng_mode = rng_mode, J.d_rng = d_rng, J.stride = stride;
     J.d_out = d_out, J.out_cap = out_cap, J.d_out_off = d_out_off, J.d_status = d_status, J.host_sink = host_sink;
     J.C = (uint32_t)std::min<uint64_t>(c->chunk, B ? B : 1);
-    static const int dev_stagger = [] { const char* e = getenv("ZK_DEVICE_STAGGER"); return e ? atoi(e) : 0; }();   // experiment (profiles/r04_ab_variants.txt (8))
-    J.plan = make_chunk_plan(B, J.C, host_sink != nullptr && c->host_taper ? (c->host_taper == 1 ? c->lanes : c->host_taper) : dev_stagger > 1 ? dev_stagger : 1, false);
+    J.plan = make_chunk_plan(B, J.C, host_sink != nullptr && c->host_taper ? (c->host_taper == 1 ? c->lanes : c->host_taper) : 1, false);
     J.NL = (uint32_t)std::min<size_t>(c->lanes, J.plan.size() ? J.plan.size() : 1);  // chunks rotate over NL streams / workspaces
     zk_status zs = ensure_workspace(c, J.C, J.NL);
     if (zs) return zs;
@@ -1118,7 +1020,8 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return ZK_OK;
     }
-    J.io_dbg = getenv("ZK_IO_DEBUG") && (host_sink || atoi(getenv("ZK_IO_DEBUG")) >= 2);   // 2: the host / GPU timeline of a device-pointer call as well
+    const char* io_env = getenv("ZK_IO_DEBUG");   // the host / GPU timeline of the call on stderr (tools/exp_io_timeline.py); 2: of a device-pointer call as well
+    J.io_dbg = io_env && (host_sink || atoi(io_env) >= 2);   // 2: the host / GPU timeline of a device-pointer call as well
     J.host_t0 = ProveJob::host_ms();
     if (J.io_dbg) {
         hipEventCreate(&J.io_t0);
@@ -1150,6 +1053,7 @@ static zk_status prove_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const
         }
         hipEventDestroy(J.io_t0);
     }
+    if (zs || e_sync != hipSuccess) wipe_witness(c);   // a failed call leaves no nonce, blinder or RNG block behind
     if (zs) return zs;
     HIPCHK(c, e_sync);
     HIPCHK(c, hipGetLastError());
@@ -1295,6 +1199,8 @@ extern "C" uint32_t zk_last_timing(const zk_ctx* c, float* total_ms, const char*
     }
     return n;
 }
+
+extern "C" float zk_last_wall_ms(const zk_ctx* c) { return c ? c->last_wall_ms : 0.f; }
 
 // ------------------------------------------------------------------ synthetic workload
 extern "C" zk_status zk_synth_workload(zk_ctx* c, uint64_t seed, uint64_t nkeys, uint64_t B, uint8_t* ring, uint8_t* msg, uint8_t* sig, uint8_t* pk,

@@ -84,7 +84,7 @@ struct zk_pool {
     std::vector<int> numa;                // -1 = unknown
     bool affinity = true;                 // ZKATTEST_POOL_AFFINITY=0 switches it off
     std::vector<float> shard_ms;          // wall time of every shard's part of the last pool call (zk_pool_shard_ms)
-    int test_fail_slot = -1;              // ZKATTEST_TEST_FAIL_SUBMIT: the next streamed submit fails at this device slot (one shot)
+    int test_fail_slot = -1;              // test build only (zk_test_pool_fail_next_submit): the next streamed submit fails at this device slot (one shot)
 };
 
 // "0-15,128-143" -> cpu numbers (the format of sysfs cpulist files)
@@ -225,15 +225,17 @@ extern "C" void zk_pool_destroy(zk_pool* p) {
     for (auto c : p->ctx) zk_ctx_destroy(c);
     delete p;
 }
-// Fault injection for tests/test_gpu_stream.py (the abandon path with older pool jobs in flight): with ZKATTEST_TEST_FAIL_SUBMIT=<slot> in the environment the
-// next zk_pool_prove_submit / zk_pool_verify_submit fails at that device slot with ZK_E_DEVICE after the earlier slots were submitted, and the variable is
-// removed (one shot).  An environment gate instead of an exported hook: nothing in the public header can make a production submit fail.
-static void pool_arm_injected_failure(zk_pool* p) {
-    if (const char* e = getenv("ZKATTEST_TEST_FAIL_SUBMIT")) {
-        p->test_fail_slot = atoi(e);
-        unsetenv("ZKATTEST_TEST_FAIL_SUBMIT");
-    }
+// Fault injection for tests/test_gpu_stream.py (the abandon path with older pool jobs in flight), compiled ONLY into the test build (`make testhooks`:
+// lib/libzkattest_hip_testhooks.so, -DZK_TEST_HOOKS): the next zk_pool_prove_submit / zk_pool_verify_submit fails at device slot `slot` with ZK_E_DEVICE after the
+// earlier slots were submitted (one shot).  The product library has neither the entry point nor the branch: nothing can make a production submit fail.
+#ifdef ZK_TEST_HOOKS
+extern "C" void zk_test_pool_fail_next_submit(zk_pool* p, int slot) {
+    if (p) p->test_fail_slot = slot;
 }
+#define POOL_INJECTED(p, i) ((int)(i) == (p)->test_fail_slot)
+#else
+#define POOL_INJECTED(p, i) false
+#endif
 extern "C" int zk_pool_size(const zk_pool* p) { return p ? (int)p->ctx.size() : 0; }
 extern "C" zk_ctx* zk_pool_ctx(zk_pool* p, int i) { return p && i >= 0 && i < (int)p->ctx.size() ? p->ctx[i] : nullptr; }
 extern "C" const char* zk_pool_last_error(const zk_pool* p) { return p ? p->err.c_str() : g_pool_create_err.c_str(); }
@@ -251,16 +253,7 @@ extern "C" int zk_pool_numa_node(const zk_pool* p, int i) { return p && i >= 0 &
 // locality is unknown.  Free with zk_pool_host_free (NOT zk_host_free).
 static std::mutex g_regs_mu;
 static std::map<void*, size_t> g_regs;
-// ZKATTEST_POOL_ALLOC (tools/exp_pool_first_call.py: the experiment behind DESIGN.md section 9 "first-call anomaly"):
-//   register (default)  mmap + mbind per shard region + first touch + hipHostRegister
-//   nohuge              the same without MADV_HUGEPAGE
-//   hostmalloc          plain hipHostMalloc (the runtime's own pinned allocator: no per-shard placement)
-//   numauser            set_mempolicy(MPOL_PREFERRED, node of device 0) around hipHostMalloc(hipHostMallocNumaUser)
-static int pool_alloc_mode() {
-    const char* e = getenv("ZKATTEST_POOL_ALLOC");
-    if (!e) return 0;
-    return !strcmp(e, "nohuge") ? 1 : !strcmp(e, "hostmalloc") ? 2 : !strcmp(e, "numauser") ? 3 : 0;
-}
+// (Other strategies were measured and dropped -- plain hipHostMalloc, hipHostMallocNumaUser under a preferred-node policy, no huge pages: profiles/r04_first_call_anomaly.txt.)
 static void* pool_host_alloc_once(zk_pool* p, size_t bytes);
 extern "C" void zk_pool_host_free(void* mem);
 // the fastest of up to three candidates: see "slow pages" in api.hip
@@ -276,28 +269,9 @@ extern "C" void* zk_pool_host_alloc(zk_pool* p, size_t bytes) {
 static void* pool_host_alloc_once(zk_pool* p, size_t bytes) {
     const size_t page = (size_t)sysconf(_SC_PAGESIZE);
     const size_t len = (bytes + page - 1) / page * page;
-    const int mode = pool_alloc_mode();
-    if (mode >= 2) {
-        void* hp = nullptr;
-        unsigned long mask[16] = {0};
-        const int node = p->numa.empty() ? -1 : p->numa[0];
-        if (mode == 3 && node >= 0 && node < 1024) {
-            mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
-            (void)syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, 1024ul);
-        }
-        hipError_t e = hipHostMalloc(&hp, len, mode == 3 ? hipHostMallocNumaUser : hipHostMallocDefault);
-        if (mode == 3) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-        std::lock_guard<std::mutex> g(g_regs_mu);
-        g_regs[hp] = 0;   // length 0: hipHostFree, not munmap
-        return hp;
-    }
     void* mem = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (mem == MAP_FAILED) return nullptr;
-    if (mode != 1) (void)madvise(mem, len, MADV_HUGEPAGE);
+    (void)madvise(mem, len, MADV_HUGEPAGE);
     const size_t G = p->ctx.size(), region = (bytes / G) & ~(size_t)255;
     // placement: an explicit memory policy per shard region (mbind, MPOL_PREFERRED: the device's node if it has room) -- first touch
     // alone depends on where the touching thread happens to run when the cpuset does not grant the device's CPUs -- and the touch
@@ -565,7 +539,6 @@ extern "C" zk_status zk_pool_prove_submit(zk_pool* p, uint64_t B, const uint8_t*
     if (!p || !job || !rng || !out_off || !out_len || !status || !B || !msg || !sig || !pk || !which || !rng->data || !out) return ZK_E_ARG;
     *job = nullptr;
     const uint64_t G = p->ctx.size();
-    pool_arm_injected_failure(p);
     zk_pool_job* j = new zk_pool_job();
     j->B = B, j->shard.assign(G, nullptr), j->off.resize(G), j->region = (out_cap / G) & ~(uint64_t)255, j->out_off = out_off, j->out_len = out_len;
     for (uint64_t i = 0; i < G; i++) {
@@ -575,11 +548,11 @@ extern "C" zk_status zk_pool_prove_submit(zk_pool* p, uint64_t B, const uint8_t*
         zk_rng r = *rng;
         r.data = rng->data + (rng->mode == ZK_RNG_SEED ? 32 * first : 32 * first * rng->stride_blocks);
         j->off[i].assign(cnt + 1, 0);
-        zk_status zs = (int)i == p->test_fail_slot ? (zk_status)ZK_E_DEVICE
+        zk_status zs = POOL_INJECTED(p, i) ? (zk_status)ZK_E_DEVICE
                                                    : zk_prove_submit(p->ctx[i], cnt, msg + 32 * first, sig + 64 * first, pk + 64 * first, which + first, &r,
                                                                      out + j->region * i, j->region, j->off[i].data(), status + first, &j->shard[i]);
         if (zs) {
-            if ((int)i == p->test_fail_slot) p->test_fail_slot = -1, p->ctx[i]->err = "(injected by ZKATTEST_TEST_FAIL_SUBMIT)";
+            if (POOL_INJECTED(p, i)) p->test_fail_slot = -1, p->ctx[i]->err = "(injected by zk_test_pool_fail_next_submit)";
             p->err = std::string("device slot ") + std::to_string(i) + ": " + zk_strerror(zs) + " " + zk_last_error(p->ctx[i]);
             pool_job_abandon(p, j);
             return zs;
@@ -608,7 +581,6 @@ extern "C" zk_status zk_pool_verify_submit(zk_pool* p, uint64_t B, const uint8_t
     if (!p || !job || !B || !msg || !proofs || !proof_off || !proof_len || !ok || !status) return ZK_E_ARG;
     *job = nullptr;
     const uint64_t G = p->ctx.size();
-    pool_arm_injected_failure(p);
     zk_pool_job* j = new zk_pool_job();
     j->kind = 1, j->B = B, j->shard.assign(G, nullptr), j->off.resize(G);
     for (uint64_t i = 0; i < G; i++) {
@@ -623,7 +595,7 @@ extern "C" zk_status zk_pool_verify_submit(zk_pool* p, uint64_t B, const uint8_t
             if (proof_off[first + k] - base != off[k]) zs = ZK_E_ARG;   // a gap or an overlap inside the shard
             off[k + 1] = off[k] + proof_len[first + k];
         }
-        if (!zs && (int)i == p->test_fail_slot) zs = ZK_E_DEVICE, p->test_fail_slot = -1, p->ctx[i]->err = "(injected by ZKATTEST_TEST_FAIL_SUBMIT)";
+        if (!zs && POOL_INJECTED(p, i)) zs = ZK_E_DEVICE, p->test_fail_slot = -1, p->ctx[i]->err = "(injected by zk_test_pool_fail_next_submit)";
         else if (!zs) zs = zk_verify_submit(p->ctx[i], cnt, msg + 32 * first, proofs + base, off.data(), vseeds ? vseeds + 32 * first : nullptr, ok + first, status + first, &j->shard[i]);
         if (zs) {
             p->err = std::string("device slot ") + std::to_string(i) + ": " + zk_strerror(zs) + " " + zk_last_error(p->ctx[i]);

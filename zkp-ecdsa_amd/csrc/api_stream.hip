@@ -77,9 +77,9 @@ static zk_status get_pinned(zk_ctx* c, size_t bytes, void** p, size_t* got) {
     return ZK_OK;
 }
 void* stream_take_spare_dev(zk_ctx* c, size_t bytes, size_t* got) { return take_spare(c->spare_dev, bytes, got); }   // ensure_io_buf (api.hip)
-void stream_release_spares(zk_ctx* c) {   // zk_ctx_destroy
-    for (auto& s : c->spare_dev) hipFree(s.p);
-    for (auto& s : c->spare_pinned) hipHostFree(s.p);
+void stream_release_spares(zk_ctx* c) {   // zk_ctx_destroy: the jobs' staged inputs (signatures, seeds) are zeroed before the memory goes back
+    for (auto& s : c->spare_dev) (void)hipMemset(s.p, 0, s.bytes), hipFree(s.p);
+    for (auto& s : c->spare_pinned) memset(s.p, 0, s.bytes), hipHostFree(s.p);
     c->spare_dev.clear(), c->spare_pinned.clear();
     c->fin_stream = nullptr;   // borrowed: the last lane's copy stream
 }
@@ -109,7 +109,6 @@ static void sync_every_stream(zk_ctx* c) {
     for (auto& L : c->vl)
         for (auto a : L.aux)
             if (a) hipStreamSynchronize(a);
-    if (c->heavy) hipStreamSynchronize(c->heavy);
     if (c->fin_stream) hipStreamSynchronize(c->fin_stream);
     if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
 }
@@ -215,37 +214,6 @@ static void lookahead(zk_ctx* c, size_t ji, uint64_t horizon) {
         if (Q->next_s1() < Q->nchunks()) break;
     }
 }
-// ZK_STREAM_DEBUG=1: host-side timeline of the queue on stderr (ms since the first submit) plus, per chunk, GPU timestamps of the
-// end of stage 1, the end of stage 2 and the end of its last copy
-struct StreamDbg {
-    bool on = false;
-    double t0 = 0;
-    hipEvent_t g0 = nullptr;
-    struct Rec {
-        uint64_t gchunk;
-        uint32_t lane, cnt;
-        hipEvent_t s1, s2, cp;
-    };
-    std::vector<Rec> recs;
-    static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-    double ms() const { return now() - t0; }
-};
-static StreamDbg g_dbg;
-static void dbg_start(zk_ctx* c) {
-    if (g_dbg.g0 || !getenv("ZK_STREAM_DEBUG")) return;
-    g_dbg.on = true, g_dbg.t0 = StreamDbg::now();
-    hipEventCreate(&g_dbg.g0);
-    hipEventRecord(g_dbg.g0, c->pl[0].stream);
-}
-static void dbg_flush() {
-    for (auto& r : g_dbg.recs) {
-        float a = 0, b = 0, d = 0;
-        hipEventElapsedTime(&a, g_dbg.g0, r.s1), hipEventElapsedTime(&b, g_dbg.g0, r.s2), hipEventElapsedTime(&d, g_dbg.g0, r.cp);
-        fprintf(stderr, "gpu: chunk %3llu lane %u %6u proofs  stage1 done %8.1f  stage2 done %8.1f  copies done %8.1f ms\n", (unsigned long long)r.gchunk, r.lane, r.cnt, a, b, d);
-        hipEventDestroy(r.s1), hipEventDestroy(r.s2), hipEventDestroy(r.cp);
-    }
-    g_dbg.recs.clear();
-}
 static void drive(zk_ctx* c, zk_job* upto, uint32_t ahead) {
     const uint32_t NL = upto->nl;   // the lanes the queued jobs were planned over, not whatever c->lanes says now
     bool past = false;
@@ -260,19 +228,8 @@ static void drive(zk_ctx* c, zk_job* upto, uint32_t ahead) {
             if (J->all_enqueued) break;
             const uint64_t k2 = J->next_s2();
             const uint32_t lane2 = (uint32_t)((J->lane_base() + k2) % NL);
-            StreamDbg::Rec rec{J->lane_base() + k2, lane2, J->kind ? J->vj.plan[k2].cnt : J->pj.plan[k2].cnt, nullptr, nullptr, nullptr};
-            if (g_dbg.on) {
-                hipEventCreate(&rec.s1), hipEventCreate(&rec.s2), hipEventCreate(&rec.cp);
-                hipEventRecord(rec.s1, c->pl[lane2].stream);
-                fprintf(stderr, "host %8.1f ms: stage2 of global chunk %llu (lane %u) begins\n", g_dbg.ms(), (unsigned long long)rec.gchunk, lane2);
-            }
             zk_status zs = J->stage2(k2);
             J->next_s2()++;
-            if (g_dbg.on) {
-                hipEventRecord(rec.s2, c->pl[lane2].stream), hipEventRecord(rec.cp, c->pl[lane2].copy_stream);
-                g_dbg.recs.push_back(rec);
-                fprintf(stderr, "host %8.1f ms: stage2 of global chunk %llu enqueued\n", g_dbg.ms(), (unsigned long long)rec.gchunk);
-            }
             if (zs) job_fail(J, zs);
         }
         if (J->next_s2() >= J->nchunks()) J->all_enqueued = true;
@@ -291,17 +248,8 @@ static zk_status wait_common(zk_ctx* c, zk_job* j) {
         return ZK_E_ARG;
     }
     HIPCHK(c, hipSetDevice(c->device));
-    if (g_dbg.on) fprintf(stderr, "host %8.1f ms: wait begins\n", g_dbg.ms());
     drive(c, j, j->nl - 1);
-    if (g_dbg.on) fprintf(stderr, "host %8.1f ms: wait blocks on the job's completion\n", g_dbg.ms());
     hipError_t e = j->finisher_enqueued ? hipEventSynchronize(j->done) : hipSuccess;
-    if (g_dbg.on) {
-        fprintf(stderr, "host %8.1f ms: job complete\n", g_dbg.ms());
-        if (c->jobs.size() == 1) {
-            for (uint32_t l = 0; l < j->nl; l++) hipStreamSynchronize(c->pl[l].stream), hipStreamSynchronize(c->pl[l].copy_stream);
-            dbg_flush();
-        }
-    }
     if (j->result != ZK_OK || e != hipSuccess) sync_every_stream(c);   // leave nothing of this job running: its buffers go back to the pool
     zk_status zs = j->result;
     if (zs) c->err = j->err;
@@ -358,8 +306,6 @@ extern "C" zk_status zk_prove_submit(zk_ctx* c, uint64_t B, const uint8_t* msg, 
     }
     zk_status zs = stream_common(c, 0);
     if (zs) return zs;
-    dbg_start(c);
-    if (g_dbg.on) fprintf(stderr, "host %8.1f ms: prove submit of %llu proofs\n", g_dbg.ms(), (unsigned long long)B);
     const size_t rng_bytes = rng->mode == ZK_RNG_SEED ? 32 * B : 32 * B * rng->stride_blocks;
     const uint64_t cap_dev = std::min<uint64_t>(out_cap, zk_proof_max_size(c) * B);
     zk_job* j = new zk_job();
@@ -422,7 +368,6 @@ extern "C" zk_status zk_prove_submit_device(zk_ctx* c, uint64_t B, const uint8_t
     HIPCHK(c, hipSetDevice(c->device));
     zk_status zs = stream_common(c, 0);
     if (zs) return zs;
-    dbg_start(c);
     zk_job* j = new zk_job();
     j->kind = 0, j->c = c;
     if ((zs = job_events(j))) {

@@ -452,22 +452,45 @@ zk_status VerifyJob::stage2b(uint64_t chunk_no) {
         g = g1;
     }
     if (wide_chunk) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[3], 0));
-    bool pm_passed = false;
     if (pm) {
         HIPCHK(c, hipEventSynchronize(A.aux_done[3]));
         HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[3], 0));
-        pm_passed = true;
-        for (uint32_t g = 0; g < G && (uint64_t)g * gsz < cnt; g++) pm_passed = pm_passed && pm_flags[g] == 1;
-        c->dbg_p256_batched += pm_passed ? cnt : 0;
-        if (pm_passed) launch_pm_all_ok(s, V, cnt);
-        else {
-            MaybeScope t(timed, c, "v_straus_p256", s);
-            launch_v_p256_straus(s, V, cnt, 5);
+        // Every proof of a group whose total is the identity has its verdict (k_pm_all_ok); the per-proof sums run over the failing groups' proofs only, as
+        // maximal runs like the Tom-256 side -- one forged proof costs its group (an eighth of the chunk) the pass's gain, not the whole chunk.
+        launch_pm_all_ok(s, V, cnt);
+        const uint32_t parts = VK / 5 + 1;
+        for (uint32_t g = 0; g < G && (uint64_t)g * gsz < cnt;) {
+            if (pm_flags[g] == 1) {
+                c->dbg_p256_batched += std::min<uint32_t>(cnt, (g + 1) * gsz) - g * gsz;
+                g++;
+                continue;
+            }
+            uint32_t g1 = g;
+            while (g1 < G && (uint64_t)g1 * gsz < cnt && pm_flags[g1] != 1) g1++;
+            const uint32_t p0 = g * gsz, p1 = std::min<uint32_t>(cnt, g1 * gsz);
+            VWork Vr = V;   // the unchanged kernels on views that start at proof p0 (strides stay those of the chunk)
+            Workspace Wr = W;
+            const size_t a = (size_t)p0 * VK;
+            Vr.pa_dig += a, Vr.cl_dig += p0, Vr.pa_tab += a * 8 * RTAB_ENTRY_WORDS, Vr.cl_tab += (size_t)p0 * 8 * RTAB_ENTRY_WORDS;
+            for (Soa* q : {&Vr.pa_sc, &Vr.pa_x, &Vr.pa_y}) q->p += a;
+            for (Soa* q : {&Vr.pSL, &Vr.pSR, &Vr.pSH, &Vr.clx, &Vr.cly}) q->p += p0;
+            for (Soa* q : {&Vr.pacc.x, &Vr.pacc.y, &Vr.pacc.z}) q->p += (size_t)p0 * parts;
+            Vr.st += p0, Vr.okflags += p0, Vr.p256_ok += p0;
+            Wr.rtab += (size_t)p0 * rtab_words(RTAB_VERIFY_BITS);
+            {
+                MaybeScope t(timed, c, "v_straus_p256", s);
+                launch_v_p256_straus(s, Vr, p1 - p0, 5);
+            }
+            {
+                MaybeScope t(timed, c, "v_p256_total", s);
+                launch_v_p256_total(s, P, Wr, Vr, p1 - p0, 5);
+            }
+            g = g1;
         }
     }
     {
         MaybeScope t(timed, c, "v_final", s);
-        if (!wide_chunk && !pm_passed) launch_v_p256_total(s, P, W, V, cnt, 5);
+        if (!wide_chunk && !pm) launch_v_p256_total(s, P, W, V, cnt, 5);
         launch_v_final(s, W, V, cnt, d_ok, d_status, first, gf, gsz);
     }
     return ZK_OK;
@@ -562,6 +585,7 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
         if (e1 == hipSuccess) e1 = e;
     }
     hipError_t e3 = host_src ? hipStreamSynchronize(c->copy_stream) : hipSuccess;
+    if (zs || e1 != hipSuccess) drain();   // an error between a fork and its join may have left kernels on an auxiliary stream: they finish before the buffers go
     if (zs) return zs;
     HIPCHK(c, e1);
     HIPCHK(c, e3);

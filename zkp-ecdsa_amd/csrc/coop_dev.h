@@ -19,20 +19,23 @@ ZK_DEV void co_store_aos(uint32_t* __restrict__ e, const CoFe<M, K>& a) {
     const uint32_t lane = __lane_id(), row = lane >> 4, j = lane & 15u;
     if (j < NLIMB && row < (uint32_t)NROWS) e[row * NLIMB + j] = n.v;
 }
-// row r -> limb-major array a_r at element e (engine.h: Soa); a null array skips the row
+// row r -> limb-major array a_r at element e (engine.h: Soa); an array with a null pointer skips the row.  (By value: pointers to kernel arguments would
+// park the structs in scratch.)
 template <class M, int K>
-ZK_DEV void co_store_soa(const CoFe<M, K>& a, uint32_t e, const Soa* a0, const Soa* a1, const Soa* a2, const Soa* a3) {
+ZK_DEV void co_store_soa(const CoFe<M, K>& a, uint32_t e, Soa a0, Soa a1, Soa a2, Soa a3) {
     const CoFe<M, K> n = co_normalize(a);
     const uint32_t lane = __lane_id(), row = lane >> 4, j = lane & 15u;
-    const Soa* s = row == 0 ? a0 : row == 1 ? a1 : row == 2 ? a2 : a3;
-    if (j < NLIMB && s) s->p[(size_t)j * s->stride + e] = n.v;
+    uint32_t* p = row == 0 ? a0.p : row == 1 ? a1.p : row == 2 ? a2.p : a3.p;
+    const uint32_t stride = row == 0 ? a0.stride : row == 1 ? a1.stride : row == 2 ? a2.stride : a3.stride;
+    if (j < NLIMB && p) p[(size_t)j * stride + e] = n.v;
 }
 template <class M, int K>
-ZK_DEV CoFe<M, K> co_load_soa(uint32_t e, const Soa* a0, const Soa* a1, const Soa* a2, const Soa* a3) {
+ZK_DEV CoFe<M, K> co_load_soa(uint32_t e, Soa a0, Soa a1, Soa a2, Soa a3) {
     const uint32_t lane = __lane_id(), row = lane >> 4, j = lane & 15u;
-    const Soa* s = row == 0 ? a0 : row == 1 ? a1 : row == 2 ? a2 : a3;
+    const uint32_t* p = row == 0 ? a0.p : row == 1 ? a1.p : row == 2 ? a2.p : a3.p;
+    const uint32_t stride = row == 0 ? a0.stride : row == 1 ? a1.stride : row == 2 ? a2.stride : a3.stride;
     CoFe<M, K> r;
-    r.v = (j < NLIMB && s) ? s->p[(size_t)j * s->stride + e] : 0u;
+    r.v = (j < NLIMB && p) ? p[(size_t)j * stride + e] : 0u;
     return r;
 }
 ZK_DEV CoTom co_tom_identity() {   // (0 : 1 : 0 : 1), rows X, Y, T, Z

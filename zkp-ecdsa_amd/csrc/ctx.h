@@ -56,7 +56,6 @@ struct zk_ctx {
         size_t arena_bytes = 0;
         bool ready = false;
         uint32_t last_cnt = 0;          // proofs of the last chunk this lane started (zk_test_counter)
-        hipEvent_t stagger_ev = nullptr;   // ZKATTEST_LANE_STAGGER (experiment): recorded behind a phase of the lane's first chunk, the next lane's first chunk waits for it
         hipStream_t side = nullptr;     // small chunks: the membership phase of stage 2 runs beside the PointAdd phase (api.hip: ProveJob::stage2)
         hipEvent_t side_fork = nullptr, side_done = nullptr;
         void* h_scan = nullptr;         // page-locked: the chunk's totals (4 x u32), item prefix sums (u32[C+1]) and byte prefix sums
@@ -65,17 +64,8 @@ struct zk_ctx {
         hipEvent_t copy_ev = nullptr;   // host-buffer entry points: "this lane's bytes are final" for the lane's copy stream
         hipStream_t copy_stream = nullptr;   // D2H of this lane's finished slices: one stream per lane, so a lane whose slices
                                              // are ready never queues behind the unfinished slices of another (FIFO per stream)
-        hipEvent_t hv_to = nullptr, hv_from = nullptr;     // heavy queue (below): lane stream -> heavy stream and back
-        hipEvent_t hv_to2 = nullptr, hv_from2 = nullptr;   // the same for the lane's side stream
     } pl[ZK_MAX_LANES];
     uint32_t lanes = 2;
-    // Heavy queue (ZKATTEST_HEAVY_FIFO): the commitment kernels -- each fills the GPU on its own at 2 waves per SIMD -- of ALL lanes
-    // run one after the other on this stream, in the order the host enqueues them, while the lanes' own streams carry the memory- and latency-bound
-    // kernels that fit beside them.  nullptr = every kernel on its lane's stream (rounds 1-4).
-    hipStream_t heavy = nullptr;
-    int heavy_mode = 0;            // 0 off, 1 = every commitment kernel, 2 = the PointAdd commitments of stage 2 only
-    bool phase_major = false;      // stage 1 of a call's first chunks is enqueued phase by phase across the lanes (the heavy queue's order then alternates lanes)
-    bool gk_beside = false;        // stage 2's membership phase on the lane's side stream for every unsliced chunk, enqueued behind the PointAdd commitments
     // verifier workspace
     struct VerifyLane {
         VWork V{};
@@ -131,7 +121,7 @@ struct zk_ctx {
     std::vector<hipEvent_t> epool;
     size_t eused = 0;
     std::vector<std::pair<const char*, float>> last_timing;
-    float last_total_ms = 0;
+    float last_total_ms = 0, last_wall_ms = 0;   // sum of the timed scopes ('+' parts excluded); first start -> last end of the same call
     bool timing_forked = false;   // this call put timed scopes on forked streams (small one-chunk calls): its scopes overlap, the total is first start -> last end
 };
 
@@ -170,8 +160,13 @@ struct Scope {
 static inline void timing_begin(zk_ctx* c) { c->trecs.clear(), c->eused = 0, c->timing_forked = false; }
 static inline void timing_end(zk_ctx* c) {
     c->last_timing.clear();
-    c->last_total_ms = 0;
+    c->last_total_ms = 0, c->last_wall_ms = 0;
     float wall = 0;
+    hipEvent_t first = c->trecs.empty() ? nullptr : c->trecs[0].e0;
+    for (auto& r : c->trecs) {   // the earliest start over all records: scopes of different lanes and forked streams are not in start order
+        float d = 0;
+        if (hipEventElapsedTime(&d, r.e0, first) == hipSuccess && d > 0) first = r.e0;
+    }
     for (auto& r : c->trecs) {
         float ms = 0;
         hipEventElapsedTime(&ms, r.e0, r.e1);
@@ -180,12 +175,10 @@ static inline void timing_end(zk_ctx* c) {
             if (p.first == r.name) p.second += ms, found = true;
         if (!found) c->last_timing.push_back({r.name, ms});
         if (r.name[0] != '+') c->last_total_ms += ms;   // '+name': a part of another scope
-        if (c->timing_forked) {   // scopes on forked streams run beside those of the lane's stream: the per-family figures stay, their sum is not a time
-            float end = 0;
-            if (hipEventElapsedTime(&end, c->trecs[0].e0, r.e1) == hipSuccess && end > wall) wall = end;
-        }
+        float end = 0;
+        if (hipEventElapsedTime(&end, first, r.e1) == hipSuccess && end > wall) wall = end;
     }
-    if (c->timing_forked) c->last_total_ms = wall;
+    c->last_wall_ms = wall;   // first start -> last end; last_total_ms stays the SUM of the scopes (forked scopes overlap: the sum is then not a time)
 }
 
 // device allocation released on every exit path of an entry point

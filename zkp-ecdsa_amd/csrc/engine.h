@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 #include "../../include/zkattest.h"
 #include "curve.h"
 #include "rng.h"
@@ -292,6 +293,11 @@ void launch_v_acc_tree(hipStream_t s, const Soa4& src, uint32_t nouter, uint32_t
 #ifndef ZK_COOP_MAX_CHAINS
 #define ZK_COOP_MAX_CHAINS 16384u
 #endif
+// ZKATTEST_ONE_LANE_CHAINS (any value): every dependent chain stays in one lane (the kernels of round 5) -- the A/B switch behind profiles/r06_ab_variants.txt
+static inline bool zk_one_lane_chains() {
+    static const bool v = getenv("ZKATTEST_ONE_LANE_CHAINS") != nullptr;
+    return v;
+}
 void launch_v_straus_co(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out, const uint32_t* perm,
                         const uint32_t* cnt, uint32_t tsplit, uint32_t ostride, uint32_t ny, uint32_t ystride);
 void launch_v_p256_straus_co(hipStream_t s, const VWork& V, uint32_t count);
@@ -381,15 +387,6 @@ void launch_build_tom_table(hipStream_t s, const uint32_t* aff_xy_words /*18 wor
 size_t tom_table_scratch_words(uint32_t bits);
 void launch_build_pfix_table(hipStream_t s, const uint32_t* aff_xy_words /*16 words on device, or nullptr for G*/, uint32_t* tab, uint32_t* scratch, int32_t* ok);
 size_t pfix_table_scratch_words();
-// Dynamic LDS the GPU-filling commitment kernels ask for without using it (ZKATTEST_HEAVY_LDS_KB, default 0): above 80 KB only ONE of their workgroups
-// fits a CU's 160 KB, i.e. one commitment wave per SIMD instead of two, and ~300 VGPRs per SIMD stay free for the other lanes' kernels.
-size_t heavy_lds_pad();   // api.hip
-template <class K>
-static inline size_t heavy_lds_for(K kernel) {
-    const size_t pad = heavy_lds_pad();
-    if (pad > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
-    return pad;
-}
 // k_tom.hip
 void launch_tom_commit(hipStream_t s, const DevParams& P, const TomList& L, uint32_t count, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride = 0);
 // the commitments of the listed slots only (`list[i]`, i < *count_dev <= max_count: the verifier's T1x / T1y exist for zero-bit repetitions only)

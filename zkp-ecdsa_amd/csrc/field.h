@@ -634,9 +634,17 @@ ZK_DEV_NOINLINE Fe<M, 2> fe_inv_gcd(const Fe<M, 2> a) {
 }
 
 // Montgomery-domain inverse, inv(0) = 0: what every caller uses (block_inverse, the front ends, the table builders).
+// (-DZK_INV_FERMAT=1 builds round 5's Fermat inversions back in: the A/B library of profiles/r06_ab_variants.txt.)
+#ifndef ZK_INV_FERMAT
+#define ZK_INV_FERMAT 0
+#endif
 template <class M>
 ZK_DEV Fe<M, 2> fe_inv(const Fe<M, 2>& a) {
+#if ZK_INV_FERMAT
+    return fe_inv_fermat<M>(a);
+#else
     return fe_inv_gcd<M>(a);
+#endif
 }
 
 // ---- plain 32-bit-word <-> 30-bit-limb conversions ----

@@ -54,29 +54,9 @@ struct ProveJob {
             hipError_t e = hipStreamSynchronize(c->pl[l].stream);
             if (r == hipSuccess) r = e;
         }
-        if (c->heavy) {   // (a lane's stream waits for every heavy launch of its chunks: only an error path leaves something here)
-            hipError_t e = hipStreamSynchronize(c->heavy);
-            if (r == hipSuccess) r = e;
-        }
         return r;
     }
-    // Heavy queue (ctx.h): the launches between heavy_begin and heavy_end go to c->heavy, ordered behind what `from` (the lane's stream, or its side
-    // stream with side = true) holds so far; afterwards `from` waits for them.  Without a heavy queue both are no-ops and the launches stay on `from`.
-    hipStream_t heavy_begin(uint32_t lane, hipStream_t from, bool side = false, bool stage2_padd = false) {
-        if (!c->heavy || (c->heavy_mode == 2 && !stage2_padd)) return from;
-        hipEvent_t ev = side ? c->pl[lane].hv_to2 : c->pl[lane].hv_to;
-        hipEventRecord(ev, from);
-        hipStreamWaitEvent(c->heavy, ev, 0);
-        return c->heavy;
-    }
-    void heavy_end(uint32_t lane, hipStream_t from, hipStream_t used, bool side = false) {
-        if (used == from) return;
-        hipEvent_t ev = side ? c->pl[lane].hv_from2 : c->pl[lane].hv_from;
-        hipEventRecord(ev, used);
-        hipStreamWaitEvent(from, ev, 0);
-    }
-    static constexpr int S1_PHASES = 5;   // stage 1 in phases: front end | [heavy] Exp commitments | normalise, scalars | [heavy] list A | normalise, challenge
-    zk_status stage1(uint64_t chunk_no, int ph0 = 0, int ph1 = S1_PHASES);
+    zk_status stage1(uint64_t chunk_no);
     zk_status stage2(uint64_t chunk_no);
 };
 struct MaybeScope {   // a timed scope, or nothing

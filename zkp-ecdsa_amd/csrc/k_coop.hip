@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(64) k_v_straus_co(VTerms L, uint32_t ngroups, 
             if (db & 15) acc = co_tom_add_tab(acc, ent, (db & 0x80u) != 0, mj);   // wave-uniform: one term at a time
         }
     }
-    co_store_soa(acc.v, g * ostride + part + yo, &out.x, &out.y, &out.t, &out.z);
+    co_store_soa(acc.v, g * ostride + part + yo, out.x, out.y, out.t, out.z);
 }
 void launch_v_straus_co(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out, const uint32_t* perm,
                         const uint32_t* cnt, uint32_t tsplit, uint32_t ostride, uint32_t ny, uint32_t ystride) {
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(64) k_v_p256_straus_co(VWork V, uint32_t count
             acc = co_p256_add(acc, e, mj);
         }
     }
-    co_store_soa(acc.v, t, &V.pacc.x, &V.pacc.y, &V.pacc.z, nullptr);
+    co_store_soa(acc.v, t, V.pacc.x, V.pacc.y, V.pacc.z, Soa{nullptr, 0});
 }
 void launch_v_p256_straus_co(hipStream_t s, const VWork& V, uint32_t count) {
     if (count) hipLaunchKernelGGL(k_v_p256_straus_co, dim3(count * (VK + 1)), dim3(64), 0, s, V, count);
@@ -93,14 +93,15 @@ __global__ void __launch_bounds__(64) k_rtab_base_co(Workspace W, uint32_t count
         b.v.v = co_row_index() == 1 ? co_limbs(ModQ::one) : 0u;                                  // (0 : 1 : 0 : 0)
     } else {
         const uint32_t row = __lane_id() >> 4, j = __lane_id() & 15u;
-        const Soa& src = row == 0 ? W.Rxm : W.Rym;
+        const uint32_t* srcp = row == 0 ? W.Rxm.p : W.Rym.p;
+        const uint32_t srcs = row == 0 ? W.Rxm.stride : W.Rym.stride;
         const CoU32 one = co_limbs(ModQ::one);
-        b.v.v = j >= NLIMB ? 0u : row < 2 ? src.p[(size_t)j * src.stride + p] : one;                // (x : y : 1 : 1)
+        b.v.v = j >= NLIMB ? 0u : row < 2 ? srcp[(size_t)j * srcs + p] : one;                // (x : y : 1 : 1)
     }
     const uint32_t nwin = rtab_nwin(bits);
 #pragma unroll 1
     for (uint32_t w = 0; w < nwin; w++) {
-        co_store_soa(b.v, p * nwin + w, &W.rbase.x, &W.rbase.y, &W.rbase.z, nullptr);
+        co_store_soa(b.v, p * nwin + w, W.rbase.x, W.rbase.y, W.rbase.z, Soa{nullptr, 0});
 #pragma unroll 1
         for (uint32_t i = 0; i < bits; i++) b = co_p256_jdbl(b, mj);
     }

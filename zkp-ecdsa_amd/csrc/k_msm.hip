@@ -299,18 +299,6 @@ __global__ void __launch_bounds__(256) k_msm_order(const uint32_t* __restrict__ 
         order[atomicAdd(&cur[255u - (c < 255u ? c : 255u)], 1u)] = (uint32_t)wd;
     }
 }
-// ZK_MSM_DEBUG: what the lanes of k_msm_bucket's waves wait for: stat[0] += sum over waves of 64 x (largest bucket of the wave), stat[1] += sum of all sizes (64-bit)
-__global__ void __launch_bounds__(256) k_msm_order_stat(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, const uint32_t* __restrict__ order, unsigned long long* stat) {
-    const uint32_t wd = order[gtid()];
-    uint32_t c = end[wd] - start[wd], m = c;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const uint32_t v = __shfl_xor(m, o, 64);
-        m = v > m ? v : m;
-    }
-    atomicAdd(&stat[1], (unsigned long long)c);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&stat[0], 64ull * m);
-}
 // ZK_MSM_CHECK=1 (tests): is the grouping exact?  Every position of a window's id list must hold a live term whose key owns that position, no term
 // twice (bitmap), as many positions as pairs were counted.  err[0]: violations, err[1 + w]: positions seen per window.
 template <int C>
@@ -570,8 +558,7 @@ static void launch_msm_reduce(hipStream_t s, const MsmBuf& M) {
     hipLaunchKernelGGL(k_msm_redk, dim3((S::nwg * R::n3 + 63) / 64, 3), dim3(64), 0, s, L3);
     MsmRedLevel L4{G3, {F3, P3a, P3b}, F4, G4, {P4a, P4b, P4c}, R::n3, R::n3, S::nwg};
     hipLaunchKernelGGL(k_msm_redk, dim3((S::nwg + 63) / 64, 4), dim3(64), 0, s, L4);
-    static const bool one_lane = getenv("ZKATTEST_ONE_LANE_CHAINS") != nullptr;   // A/B: the round-5 one-lane chains (profiles/r06_ab_variants.txt)
-    if (one_lane) hipLaunchKernelGGL(k_msm_red_last<C>, dim3((S::nwg + 63) / 64), dim3(64), 0, s, F4, P4a, P4b, P4c, M.Tw);
+    if (zk_one_lane_chains()) hipLaunchKernelGGL(k_msm_red_last<C>, dim3((S::nwg + 63) / 64), dim3(64), 0, s, F4, P4a, P4b, P4c, M.Tw);
     else hipLaunchKernelGGL(k_msm_red_last_co<C>, dim3(S::nwg), dim3(64), 0, s, F4, P4a, P4b, P4c, M.Tw);
 }
 // coefficient sums of the fixed bases over a group's proofs (block g): list C slots p * 4n + {0, 1} hold (mg, mh), (eg, eh)
@@ -633,9 +620,6 @@ static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& 
     D.nq = nq, D.gsz = (count + S::g - 1) / S::g;
     *gsz_out = D.gsz;
     const uint32_t total = D.n0 + D.n1 + D.n2;
-    const bool dbg = getenv("ZK_MSM_DEBUG") != nullptr;  // phase timings on stderr (adds stream synchronisations)
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t0 = now();
     // scratch of the grouping passes
     const uint32_t nwb = S::nw * MSM_NBIN;
     uint32_t* bin_cnt = (uint32_t*)M.sort_tmp;
@@ -649,34 +633,16 @@ static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& 
     hipLaunchKernelGGL(k_msm_binscan1, dim3(nwb), dim3(MSM_SORT_G), 0, s, bin_cnt, nwb, bin_off, bin_tot);
     hipLaunchKernelGGL(k_msm_binscan2, dim3(S::nw), dim3(MSM_NBIN), 0, s, bin_tot, bin_start, live_cnt, M.counters);
     hipLaunchKernelGGL(k_msm_scatter<C>, dim3(MSM_SORT_G), dim3(MSM_SORT_T), 0, s, V, D, M.cap, bin_start, bin_off, M.pairs);
-    // order of the buckets for k_msm_bucket's lanes: by size over the whole chunk (default), or within each bin only (ZKATTEST_MSM_ORDER=local: two launches fewer)
-    static const bool order_global = [] { const char* e = getenv("ZKATTEST_MSM_ORDER"); return !(e && !strcmp(e, "local")); }();
+    // order of the buckets for k_msm_bucket's lanes: by size over the whole chunk (within each bin only, two launches fewer, cost 8 ms of bucket sums per
+    // step: profiles/r05_ab_variants.txt (1))
     uint32_t* size_cnt = (uint32_t*)(live_cnt + MSM_SORT_G);   // [256][nwb], then size_tot[256]
     uint32_t* size_tot = size_cnt + (size_t)256 * nwb;
     (void)hipFuncSetAttribute((const void*)k_msm_binsort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MSM_STAGE_MAX * 4));   // (per device: a pool calls this on each)
     hipLaunchKernelGGL(k_msm_binsort, dim3(MSM_NBIN, S::nw), dim3(MSM_NLOW), MSM_STAGE_MAX * 4, s, M.pairs, M.cap, bin_start, M.vals_out, M.start, M.end, M.ord_id,
-                       order_global ? size_cnt : nullptr);
-    if (order_global) {
-        hipLaunchKernelGGL(k_msm_sizescan, dim3(256), dim3(1024), 0, s, size_cnt, nwb, size_tot);
-        hipLaunchKernelGGL(k_msm_order, dim3(MSM_NBIN, S::nw), dim3(256), 0, s, M.start, M.end, size_cnt, size_tot, M.ord_id);
-    }
+                       size_cnt);
+    hipLaunchKernelGGL(k_msm_sizescan, dim3(256), dim3(1024), 0, s, size_cnt, nwb, size_tot);
+    hipLaunchKernelGGL(k_msm_order, dim3(MSM_NBIN, S::nw), dim3(256), 0, s, M.start, M.end, size_cnt, size_tot, M.ord_id);
     if (ev3) hipEventRecord(ev3, s);
-    if (dbg) {
-        unsigned long long* stat = nullptr;
-        if (hipMalloc(&stat, 16) == hipSuccess) {
-            hipMemsetAsync(stat, 0, 16, s);
-            hipLaunchKernelGGL(k_msm_order_stat, dim3(S::nw * MSM_NBG / 256), dim3(256), 0, s, M.start, M.end, M.ord_id, stat);
-            unsigned long long h2[2] = {0, 0};
-            hipMemcpyAsync(h2, stat, 16, hipMemcpyDeviceToHost, s);
-            hipStreamSynchronize(s);
-            hipFree(stat);
-            fprintf(stderr, "msm: bucket order %s: lanes wait for %.3f x the additions they make (%llu pairs)\n", order_global ? "global" : "local", h2[1] ? (double)h2[0] / (double)h2[1] : 0.0, h2[1]);
-        }
-    }
-    if (dbg) {
-        hipStreamSynchronize(s);
-        fprintf(stderr, "msm: pack + grouping of the keys %.2f ms\n", now() - t0), t0 = now();
-    }
     if (getenv("ZK_MSM_CHECK")) {   // tests: the grouping against first principles (k_msm_check)
         uint32_t *seen = nullptr, *err = nullptr;
         const size_t seen_words = ((size_t)S::nw * M.cap + 31) / 32;
@@ -711,12 +677,7 @@ static hipError_t run_msm_t(hipStream_t s, const DevParams& P, const Workspace& 
     hipLaunchKernelGGL(k_msm_final<C>, dim3(1), dim3(64), 0, s, M.Tw, M.one, M.flag);
     launch_words_to_host(s, M.host, M.counters, 1);   // live terms of the pass (statistics: zk_test_counter 2)
     launch_words_to_host(s, M.host + 8, M.flag, S::g);
-    hipError_t e = hipSuccess;
-    if (dbg) {
-        e = hipStreamSynchronize(s);
-        fprintf(stderr, "msm: %u live terms; bucket .. final %.2f ms\n", M.host[0], now() - t0);
-    }
-    return e;
+    return hipSuccess;
 }
 hipError_t run_msm(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t nq, const MsmBuf& M, uint32_t groups,
                    uint32_t* gsz_out, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2, hipEvent_t ev3) {

@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) k_rtab_fill(Workspace W, uint32_t count, 
     }
 }
 void launch_rtab(hipStream_t s, const Workspace& W, uint32_t count, uint32_t bits, const uint8_t* skip) {
-    if (count <= ZK_COOP_MAX_CHAINS / 8) launch_rtab_base_co(s, W, count, bits, skip);   // few proofs: the 256 doublings on a cooperating wave per proof (k_coop.hip)
+    if (count <= ZK_COOP_MAX_CHAINS / 8 && !zk_one_lane_chains()) launch_rtab_base_co(s, W, count, bits, skip);   // few proofs: the 256 doublings on a cooperating wave per proof (k_coop.hip)
     else hipLaunchKernelGGL(k_rtab_base, dim3((count + 63) / 64), dim3(64), 0, s, W, count, bits, skip);
     hipLaunchKernelGGL(k_rtab_fill, dim3((count * rtab_nwin(bits) + 255) / 256), dim3(256), 0, s, W, count, bits, skip);
 }
@@ -351,9 +351,9 @@ void launch_exp_commit(hipStream_t s, const DevParams& P, const Workspace& W, ui
     uint32_t n = count * (W.sec + 1);
     if (W.ktab) {
         if (n <= ZK_WIDE_MAX_UNITS) hipLaunchKernelGGL(k_exp_commit_kt_wide, dim3((n * 4 + 255) / 256), dim3(256), 0, s, P, W, count);
-        else hipLaunchKernelGGL(k_exp_commit_kt, dim3((n + 255) / 256), dim3(256), heavy_lds_for(k_exp_commit_kt), s, P, W, count);
+        else hipLaunchKernelGGL(k_exp_commit_kt, dim3((n + 255) / 256), dim3(256), 0, s, P, W, count);
     }
-    hipLaunchKernelGGL(k_exp_commit, dim3((n + 255) / 256), dim3(256), heavy_lds_for(k_exp_commit), s, P, W, count);
+    hipLaunchKernelGGL(k_exp_commit, dim3((n + 255) / 256), dim3(256), 0, s, P, W, count);
 }
 
 // ---------------------------------------------------------------- batch normalisation (weier.ts:231-243)

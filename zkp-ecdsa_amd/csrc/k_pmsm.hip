@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(64) k_pm_rpart(Workspace W, VWork V, uint32_t 
 }
 // Workgroup g, 128 threads: wave 0 adds up the group's R parts and SH and walks h_NIST's comb; wave 1 joins the windows (Horner); thread 0 checks.
 template <int C>
-__global__ void __launch_bounds__(128) k_pm_final(DevParams P, uint32_t PB, uint32_t G, PMsmBuf M) {
+__global__ void __launch_bounds__(128) k_pm_final(DevParams P, uint32_t PB, uint32_t G, PMsmBuf M, bool one_lane) {
     typedef PmShape<C> S;
     __shared__ uint32_t sh[27 * 32], shs[9][64], shw[27];
     const uint32_t g = blockIdx.x, t = threadIdx.x;
@@ -277,7 +277,18 @@ __global__ void __launch_bounds__(128) k_pm_final(DevParams P, uint32_t PB, uint
 #pragma unroll
         for (int l = 0; l < 9; l++) shs[l][t] = shv.l[l];
     }
-    if (t >= 64) {   // wave 1, cooperating (coop.h: one limb per lane, X, Y, Z in rows): (nw - 1) x (C doublings + 1 addition) in a row
+    if (one_lane) {
+        if (t == 64) {   // round 5's form (A/B only): one lane walks the windows
+            P256Pt hw = ld_rtab(M.Tw + ((size_t)(S::nw - 1) * G + g) * PM_PT_WORDS);
+#pragma unroll 1
+            for (int w = (int)S::nw - 2; w >= 0; w--) {
+#pragma unroll 1
+                for (int k = 0; k < C; k++) hw = p256_dbl(hw);
+                hw = p256_add(hw, ld_rtab(M.Tw + ((size_t)w * G + g) * PM_PT_WORDS));
+            }
+            pm_sh_st(shw, 1, 0, hw);
+        }
+    } else if (t >= 64) {   // wave 1, cooperating (coop.h: one limb per lane, X, Y, Z in rows): (nw - 1) x (C doublings + 1 addition) in a row
         const CoU32 mj = co_limbs(ModQ::mod);
         CoP256 hw;
         hw.v = co_load_aos<ModQ, 8, 3>(M.Tw + ((size_t)(S::nw - 1) * G + g) * PM_PT_WORDS);
@@ -375,7 +386,7 @@ static void pmsm_sums_t(hipStream_t s, const DevParams& P, uint32_t count, uint3
     hipLaunchKernelGGL(k_pm_bucket<C>, dim3(S::nw * G * S::nb / 256), dim3(256), 0, s, M);
     hipLaunchKernelGGL(k_pm_big<C>, dim3(256), dim3(256), 0, s, M);
     hipLaunchKernelGGL(k_pm_reduce<C>, dim3(S::nw * G), dim3(256), 0, s, M);
-    hipLaunchKernelGGL(k_pm_final<C>, dim3(G), dim3(128), 0, s, P, PB, G, M);
+    hipLaunchKernelGGL(k_pm_final<C>, dim3(G), dim3(128), 0, s, P, PB, G, M, zk_one_lane_chains());
     launch_words_to_host(s, host_flags_pinned, M.flag, G);
 }
 void pmsm_prepare(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const PMsmBuf& M, uint32_t groups) {

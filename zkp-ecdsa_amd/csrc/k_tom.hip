@@ -225,11 +225,11 @@ void launch_tom_commit_listb(hipStream_t s, const DevParams& P, const TomList& L
     uint32_t nwin = tom_nwin(P.tom_bits);
     uint32_t n1 = items * LB_UNITS_SINGLE, n2 = items * LB_UNITS_PAIR;
     if (tom_signed(P.tom_bits)) {
-        hipLaunchKernelGGL((k_tom_commit<2, true>), dim3((n1 + 255) / 256), dim3(256), heavy_lds_for(k_tom_commit<2, true>), s, P.tom_tab_g, P.tom_tab_h, L, n1, items, 0u, kstride, P.tom_bits, nwin, 1u);
-        hipLaunchKernelGGL(k_tom_commit_pairs<true>, dim3((n2 + 255) / 256), dim3(256), heavy_lds_for(k_tom_commit_pairs<true>), s, P.tom_tab_g, P.tom_tab_h, L, items, kstride, P.tom_bits, nwin);
+        hipLaunchKernelGGL((k_tom_commit<2, true>), dim3((n1 + 255) / 256), dim3(256), 0, s, P.tom_tab_g, P.tom_tab_h, L, n1, items, 0u, kstride, P.tom_bits, nwin, 1u);
+        hipLaunchKernelGGL(k_tom_commit_pairs<true>, dim3((n2 + 255) / 256), dim3(256), 0, s, P.tom_tab_g, P.tom_tab_h, L, items, kstride, P.tom_bits, nwin);
     } else {
-        hipLaunchKernelGGL((k_tom_commit<2, false>), dim3((n1 + 255) / 256), dim3(256), heavy_lds_for(k_tom_commit<2, false>), s, P.tom_tab_g, P.tom_tab_h, L, n1, items, 0u, kstride, P.tom_bits, nwin, 1u);
-        hipLaunchKernelGGL(k_tom_commit_pairs<false>, dim3((n2 + 255) / 256), dim3(256), heavy_lds_for(k_tom_commit_pairs<false>), s, P.tom_tab_g, P.tom_tab_h, L, items, kstride, P.tom_bits, nwin);
+        hipLaunchKernelGGL((k_tom_commit<2, false>), dim3((n1 + 255) / 256), dim3(256), 0, s, P.tom_tab_g, P.tom_tab_h, L, n1, items, 0u, kstride, P.tom_bits, nwin, 1u);
+        hipLaunchKernelGGL(k_tom_commit_pairs<false>, dim3((n2 + 255) / 256), dim3(256), 0, s, P.tom_tab_g, P.tom_tab_h, L, items, kstride, P.tom_bits, nwin);
     }
 }
 // k_tom_commit over a compacted list of slots (see launch_tom_commit_list): the grid covers the largest possible list, lanes past *count_dev leave at once
@@ -260,8 +260,8 @@ void launch_tom_commit(hipStream_t s, const DevParams& P, const TomList& L, uint
         return;
     }
     dim3 g((count + 255) / 256), b(256);
-    if (tom_signed(P.tom_bits)) hipLaunchKernelGGL((k_tom_commit<2, true>), g, b, heavy_lds_for(k_tom_commit<2, true>), s, P.tom_tab_g, P.tom_tab_h, L, count, per_group, slots_per_group, kstride, P.tom_bits, tom_nwin(P.tom_bits), 0u);
-    else hipLaunchKernelGGL((k_tom_commit<2, false>), g, b, heavy_lds_for(k_tom_commit<2, false>), s, P.tom_tab_g, P.tom_tab_h, L, count, per_group, slots_per_group, kstride, P.tom_bits, tom_nwin(P.tom_bits), 0u);
+    if (tom_signed(P.tom_bits)) hipLaunchKernelGGL((k_tom_commit<2, true>), g, b, 0, s, P.tom_tab_g, P.tom_tab_h, L, count, per_group, slots_per_group, kstride, P.tom_bits, tom_nwin(P.tom_bits), 0u);
+    else hipLaunchKernelGGL((k_tom_commit<2, false>), g, b, 0, s, P.tom_tab_g, P.tom_tab_h, L, count, per_group, slots_per_group, kstride, P.tom_bits, tom_nwin(P.tom_bits), 0u);
 }
 
 // Batch normalisation: (X:Y:Z) on the a=1 image -> affine (x, y) of the ORIGINAL curve, plain canonical limbs

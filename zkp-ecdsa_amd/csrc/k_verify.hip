@@ -1438,7 +1438,7 @@ void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t 
     if (!ngroups) return;
     const uint32_t nterms = ngroups * (n256 + n128);
     hipLaunchKernelGGL(k_v_term_tables, dim3((nterms + 255) / 256, ny), dim3(256), 0, s, L, ngroups, ng_stride, n256 + n128, ystride);
-    if ((uint64_t)ngroups * tsplit * ny <= ZK_COOP_MAX_CHAINS) {   // few chains: their length is the cost -- a cooperating wave per chain (k_coop.hip)
+    if ((uint64_t)ngroups * tsplit * ny <= ZK_COOP_MAX_CHAINS && !zk_one_lane_chains()) {   // few chains: their length is the cost -- a cooperating wave per chain (k_coop.hip)
         launch_v_straus_co(s, L, ngroups, ng_stride, n256, n128, out, perm, cnt, tsplit, ostride, ny, ystride);
         return;
     }
@@ -1738,7 +1738,7 @@ void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t 
 }
 void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count, uint32_t per) {
     L1(k_v_p256_tables, count * (VK + 1), 256, V, count);
-    if (per == 1 && (uint64_t)count * (VK + 1) <= ZK_COOP_MAX_CHAINS) launch_v_p256_straus_co(s, V, count);   // k_coop.hip
+    if (per == 1 && (uint64_t)count * (VK + 1) <= ZK_COOP_MAX_CHAINS && !zk_one_lane_chains()) launch_v_p256_straus_co(s, V, count);   // k_coop.hip
     else L1(k_v_p256_straus, count * (VK / per + 1), 256, V, count, per);
 }
 void launch_v_p256_total(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t per) {
