@@ -1,5 +1,6 @@
 """-m gpu: proveSignatureList on the HIP engine vs the oracle, byte for byte (ZKA1), under the RNG contract."""
 import hashlib
+import os
 
 import pytest
 
