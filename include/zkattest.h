@@ -393,7 +393,9 @@ int zk_pool_test_locality(const char *pci_bus_id, int *numa_node, int *cpus, int
 /* work counters: 0 = proofs that went through the verifier's per-proof sums since the context was created (fallback of the batched check);
  * 1 = proofs of the last chunk on lane 0 whose scalar multiplications by the signer's key went through the per-key tables;
  * 2 = live terms that went through the verifier's batched Tom-256 check (bucket pass) since the context was created;
- * 3 = proofs whose P-256 relation was accepted by the cross-proof P-256 pass (chunks of at least ZKATTEST_P256_BATCH proofs, default 8192) */
+ * 3 = proofs whose P-256 relation was accepted by the cross-proof P-256 pass (chunks of at least ZKATTEST_P256_BATCH proofs, default 8192): every GROUP
+ *     without a failing proof counts (a failing group, not its chunk, goes through the per-proof sums);
+ * 4 = dependent chains of small calls handed to cooperating waves so far (k_coop.hip: Straus sums, the table of R), process-wide */
 uint64_t zk_test_counter(const zk_ctx *ctx, int which);
 /*
  * which_field: 0 = F_q (p256.p), 1 = Z_n, 2 = F_t;  op: 0 mul, 1 add, 2 sub, 3 inverse, 4 a*b - a - b (fused double subtraction), 5 (a + b)^2 (dedicated squaring).  count x 40-byte BE operands. */

@@ -167,3 +167,32 @@ def test_a_one_key_ring_is_refused():
         eng.set_ring(ring, 1)
     assert e.value.status == 14
     eng.close()
+
+
+def test_mutants_in_small_calls_take_the_cooperating_wave_kernels_and_keep_their_statuses():
+    """The sweep above verifies its mutants in ONE call of several hundred proofs: the batched checks first, then one-lane per-proof sums.  A call of a few proofs
+    takes another path -- every term's Straus chain, both curves, and the doublings of R's table on cooperating waves (csrc/k_coop.hip; one proof per call is the
+    reference's only shape, zkpAttestList.ts:147-184).  Every fourth mutant, eight per call and one per call, against the oracle: exact (ok, status) pairs, and
+    zk_test_counter(4) proves the cooperative kernels were the ones that ran."""
+    nkeys, S = 1024, 9002
+    eng, octx, msg, proofs = _setup(S, nkeys, 2)
+    muts = mutants(proofs, (nkeys - 1).bit_length(), S, S)[::4]
+    assert len(muts) >= 100
+    names = [m[0] for m in muts]
+    msgs = [msg[32 * m[1]:32 * m[1] + 32] for m in muts]
+    plist = [m[2] for m in muts]
+    vs = _vseeds(len(plist), b'sc')
+    o = octx.verify_batch(b''.join(msgs), plist, nthreads=16, vseeds=vs)
+    c4 = eng.test_counter(4)
+    got_ok, got_st = [], []
+    for a in range(0, len(plist), 8):
+        ok, st = eng.verify_batch(b''.join(msgs[a:a + 8]), plist[a:a + 8], vseeds=vs[32 * a:32 * a + 256])
+        got_ok += ok
+        got_st += st
+    assert eng.test_counter(4) > c4, 'the small calls did not reach the cooperative kernels'
+    bad = [(names[i], (got_ok[i], got_st[i]), (o[0][i], o[1][i])) for i in range(len(plist)) if (got_ok[i], got_st[i]) != (o[0][i], o[1][i])]
+    assert not bad, (len(bad), bad[:12])
+    assert {(1, 0), (0, 0)} <= set(zip(got_ok, got_st))
+    for i in range(0, len(plist), 5):   # one proof per call
+        assert eng.verify_batch(msgs[i], [plist[i]], vseeds=vs[32 * i:32 * i + 32]) == ([o[0][i]], [o[1][i]]), names[i]
+    eng.close()
