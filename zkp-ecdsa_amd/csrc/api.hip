@@ -2,8 +2,6 @@
 // One context = one GPU = one HIP stream.  A batch is processed in chunks of `chunk` proofs; every phase of a chunk
 // is one kernel over all proofs (or all zero-bit reps) of the chunk -- see DESIGN.md for the phase list.
 #include <algorithm>
-#include <array>
-#include <map>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -853,23 +851,7 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
         launch_words_to_host(s, h_out_base, W.out_base, 2 * ((size_t)cnt + 1));
     }
     if (io_dbg) fprintf(stderr, "host %7.1f ms: stage2 lane %u waits for its scan\n", host_ms() - host_t0, pd.lane);
-#ifdef ZK_EXP_CACHED_SCAN
-    // EXPERIMENT ONLY (never in the product library; profiles/r06_ab_variants.txt (5)): the upper bound of "the host out of the stage 1 -> stage 2 hand-over".  A repeated
-    // identical call (bench.py's steps) finds its chunk totals in a cache and does NOT wait for the scan: every lane runs from stage 1 into stage 2 without the host.
-    static std::map<std::pair<uint64_t, uint32_t>, std::array<uint32_t, 4>> scan_cache;
-    static uint32_t cached_totals[ZK_MAX_LANES][4];
-    const auto key = std::make_pair(first, cnt);
-    const auto hit = scan_cache.find(key);
-    if (hit != scan_cache.end() && !host_sink && !sliced) {
-        for (int i = 0; i < 4; i++) cached_totals[pd.lane][i] = hit->second[i];
-        totals = cached_totals[pd.lane];
-    } else {
-        HIPCHK(c, hipStreamSynchronize(s));
-        scan_cache[key] = {totals[0], totals[1], totals[2], totals[3]};
-    }
-#else
     HIPCHK(c, hipStreamSynchronize(s));
-#endif
     if (io_dbg) fprintf(stderr, "host %7.1f ms: scan done\n", host_ms() - host_t0);
     if (totals[1]) {
         c->err = "output buffer too small";
