@@ -261,6 +261,7 @@ async function gpu() {
     const k = eng.keysToInts(wl.pk)
     assert.ok(i32(k.status).every((v) => v === 0) && k.keys.slice(0, 32).equals(wl.pk.slice(0, 32)))
     const h = eng.h
+    eng.wipe()                                                                           // zk_ctx_wipe on every device
     eng.close()
     eng.close()                                                                          // idempotent
     assert.throws(() => zk.native.setRing(h, wl.ring), /destroyed/)

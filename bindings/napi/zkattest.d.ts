@@ -49,6 +49,8 @@ export class Engine {
     close(): void
     info(): { devices: number; ringTransport: string; proofMaxSize: number }
     setOption(name: 'chunk' | 'lanes' | 'combBits' | 'hostTaper' | 'batchVerify' | 'mode' | 'slice' | 'ringFold' | 'verifyGroups' | 'wire' | 'inflight', value: number): void
+    /** zero the witness-derived device memory (prover workspaces, staged signatures and seeds) of every device now; close() and a failed prove do it by themselves */
+    wipe(): void
     setParams(p: EngineParams): void
     setRing(keys: Buffer | bigint[]): string
     keysToInts(pkxy: Buffer): { keys: Buffer; status: Buffer }

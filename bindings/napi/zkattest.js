@@ -301,6 +301,7 @@ class Engine {
     close() { if (this.h) native.destroyPool(this.h); this.h = null }
     info() { return native.poolInfo(this.h) }
     setOption(name, value) { native.setOption(this.h, name, value) }   // chunk, lanes, combBits (before setParams), hostTaper, batchVerify, mode, slice, ringFold, verifyGroups, wire (0 ZKA1, 1 ZKA1P), inflight
+    wipe() { native.setOption(this.h, 'wipe', 0) }   // zk_ctx_wipe on every device: prover workspaces and staged inputs zeroed (also done by close() and after a failed prove)
     // params: { nistH: 64 B, tomG: 72 B, tomH: 72 B, secLevel } -- SystemParametersList as affine big-endian coordinates
     setParams(p) { native.setParams(this.h, p.nistH, p.tomG, p.tomH, p.secLevel || 80); this.params = p }
     setRing(keys) { return native.setRing(this.h, Buffer.isBuffer(keys) ? keys : Buffer.concat(keys.map(be32))) }

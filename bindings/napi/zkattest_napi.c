@@ -247,6 +247,7 @@ static napi_value SetOption(napi_env env, napi_callback_info info) {
                        : !strcmp(name, "ringFold")    ? zk_ctx_set_ring_fold(c, val)
                        : !strcmp(name, "verifyGroups") ? zk_ctx_set_verify_groups(c, val)
                        : !strcmp(name, "wire")        ? zk_ctx_set_wire(c, val)
+                       : !strcmp(name, "wipe")        ? zk_ctx_wipe(c) /* value ignored: zero the witness-derived device memory of every context now */
                                                       : ZK_E_ARG;
         if (st != ZK_OK) return throw_text(env, st, name);
     }

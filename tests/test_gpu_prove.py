@@ -417,3 +417,25 @@ def test_degenerate_prover_inputs_give_the_oracles_bytes_and_statuses():
         assert gv == octx.verify_batch(sub(args[0], 32), [got[b] for b in live], nthreads=8, vseeds=vs)
         assert gv[0][0] == 1
         eng.close()
+
+
+def test_wipe_zeroes_the_workspaces_and_changes_nothing_else():
+    """zk_ctx_wipe (also run by zk_ctx_destroy and after a failed prove call): the prover lanes' workspaces -- RNG stream, nonces, s1, blinders -- and the staged
+    inputs are zeroed; the next call makes the same bytes; refused while a streamed job is in flight."""
+    import zkp_ecdsa_amd as Z
+    eng, octx, (msg, sig, pk, which, seeds) = _setup(515, 64, 6)
+    a, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert st == [0] * 6
+    eng.wipe()
+    b, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert st == [0] * 6 and a == b
+    assert eng.verify_batch(msg, b) == ([1] * 6, [0] * 6)
+    eng.wipe()
+    eng.wipe()   # idempotent
+    # a failed call (output buffer too small) wipes by itself and leaves the context usable
+    import ctypes as C
+    with pytest.raises(Z.ZkError):
+        eng.prove_batch_host_raw(msg, sig, pk, which, seeds, out=(C.c_uint8 * 1000)())
+    c, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert c == a
+    eng.close()

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Regenerates profiles/r05_* on an MI355X box (run from the repo root, e.g. through gpurun; outputs under gpurun_out/, to be copied into
-# profiles/).  ROUND=r04 by default.  Counters are collected in their own runs, never together with tracing domains other than --kernel-trace.
+# Regenerates profiles/r06_* on an MI355X box (run from the repo root, e.g. through gpurun; outputs under gpurun_out/, to be copied into
+# profiles/).  ROUND=r06 by default.  Counters are collected in their own runs, never together with tracing domains other than --kernel-trace.
 # About 13 minutes of GPU time.
 set -e
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 export GPU_MAX_HW_QUEUES=8
 mkdir -p gpurun_out
 ROOT=$PWD
