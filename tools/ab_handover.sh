@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 6 experiment (profiles/r06_ab_variants.txt (5)): what would the prover gain if the host were out of the stage 1 -> stage 2 hand-over?  Upper bound by a library built with
-# -DZK_EXP_CACHED_SCAN (build_ab/lib_cachedscan.so: a repeated identical call takes its chunk totals from a cache and never waits for a scan) against the shipped library, same box,
+# -DZK_EXP_CACHED_SCAN (build_ab/lib_cachedscan.so: a repeated identical call takes its chunk totals from a cache and never waits for a scan; the #ifdef lives in commit f4b3401's
+# api.hip only -- check that commit out to rebuild it) against the shipped library, same box,
 # interleaved.  The cached library is an experiment, not a product: its totals are only right because bench.py repeats one workload.
 export GPU_MAX_HW_QUEUES=8
 O=gpurun_out/r06ab
