@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(64) k_exph_rounds(Workspace W, uint32_t count,
 #pragma unroll
         for (int i = 0; i < 64; i++) {
             const uint32_t t1 = hh + zk_xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25)) + zk_bfi(e, f, g) + w[i];
-            const uint32_t t2 = zk_xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22)) + zk_bfi(a ^ bb, c, bb);
+            const uint32_t t2 = zk_xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22)) + zk_maj(a, bb, c);
             hh = g, g = f, f = e, e = d + t1, d = c, c = bb, bb = a, a = t1 + t2;
         }
         h[0] += a, h[1] += bb, h[2] += c, h[3] += d, h[4] += e, h[5] += f, h[6] += g, h[7] += hh;

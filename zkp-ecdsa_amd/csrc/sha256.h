@@ -36,7 +36,7 @@ ZK_DEV void sha256_compress(uint32_t h[8], uint32_t w[16]) {
         uint32_t ch = zk_bfi(e, f, g);
         uint32_t t1 = hh + S1 + ch + SHA_K[i] + w[i & 15];
         uint32_t S0 = zk_xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
-        uint32_t mj = zk_bfi(a ^ b, c, b);
+        uint32_t mj = zk_maj(a, b, c);
         uint32_t t2 = S0 + mj;
         hh = g, g = f, f = e, e = d + t1, d = c, c = b, b = a, a = t1 + t2;
     }
