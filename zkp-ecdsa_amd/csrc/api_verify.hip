@@ -318,8 +318,12 @@ static zk_status per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t 
         uint32_t* perm = V.slot_perm + so;
         uint32_t* pc = V.slot_cnt + 2 * range_no;
         launch_v_slot_perm(s, V.slot_class + so, np * VK, perm, pc);
-        launch_v_straus(s, terms_at(V.slot_terms, so), np * VK, V.C * VK, 10, 26, V.wide_acc, perm, pc, V_SLOT_TERMS, V_SLOT_TERMS);
-        launch_v_acc_tree(s, V.wide_acc, np * VK, V_SLOT_TERMS, acc_at(V.slot_acc, so * V_SLOT_SPLIT), V_SLOT_SPLIT, 0);
+        // one term per chain while the chains fit the cooperating waves (k_coop.hip: <= ZK_COOP_MAX_CHAINS per launch, about 20 proofs); beyond that nine terms per
+        // chain keep a call of up to ~200 proofs on them (4 doublings + 9 additions per window on a wave: 0.5 ms a chain, against 1.3-1.9 ms for one term in one lane)
+        const uint64_t slots = (uint64_t)np * VK;
+        const uint32_t ts = slots * V_SLOT_TERMS > ZK_COOP_MAX_CHAINS && slots * V_SLOT_SPLIT <= ZK_COOP_MAX_CHAINS && !zk_one_lane_chains() ? V_SLOT_SPLIT : V_SLOT_TERMS;
+        launch_v_straus(s, terms_at(V.slot_terms, so), np * VK, V.C * VK, 10, 26, V.wide_acc, perm, pc, ts, ts);
+        launch_v_acc_tree(s, V.wide_acc, np * VK, ts, acc_at(V.slot_acc, so * V_SLOT_SPLIT), V_SLOT_SPLIT, 0);
         for (int i = 0; i < 3; i++) {
             HIPCHK(c, hipEventRecord(A.aux_done[i], A.aux[i]));
             HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[i], 0));

@@ -432,9 +432,34 @@ __global__ void __launch_bounds__(256) k_p256_normalize(Soa3 proj, uint32_t coun
     }
 #endif
 }
+// one thread per point with its own divsteps inversion: the small launches (k_tom.hip: k_tom_normalize_each has the reasoning); same statuses, same canonical values
+#ifndef ZK_NORM_EACH_MAX
+#define ZK_NORM_EACH_MAX 16384u
+#endif
+__global__ void __launch_bounds__(256) k_p256_normalize_each(Soa3 proj, uint32_t count, Soa ox, Soa oy, int32_t* st, uint32_t per_proof, int32_t err_code, const uint32_t* owner) {
+    const uint32_t e = gtid();
+    if (e >= count) return;
+    Fq2 z = fe_reduce(soa_ld<ModQ, 8>(proj.z, e));
+    if (fe_is_zero(z)) {   // the identity: status as in k_p256_normalize, coordinates (0, 0) (x = X / 1, y = Y / 1 with X = 0 ... the batch form yields the same: Z sanitised to 1)
+        const uint32_t o = owner ? owner[e] : e / per_proof;
+        const bool counts = !(err_code == ZK_ST_T_INF_LATE && e % per_proof == per_proof - 1);
+        if (err_code && counts && atomicCAS(&st[o], ZK_OK, err_code) == ZK_E_ARG) atomicCAS(&st[o], ZK_E_ARG, err_code);
+        z = fe_one_mont<ModQ>().as<2>();
+    }
+    Fe<ModQ, 1> one = fe_zero<ModQ>();
+    one.l[0] = 1;
+    const Fq2 zi = fe_inv<ModQ>(z) * one;
+    const Fq2 x = soa_ld<ModQ, 8>(proj.x, e) * zi, y = soa_ld<ModQ, 8>(proj.y, e) * zi;
+    soa_st(ox, e, fe_canon(x));
+    soa_st(oy, e, fe_canon(y));
+}
 void launch_p256_normalize(hipStream_t s, const Soa3& proj, uint32_t count, const Soa& ox, const Soa& oy, int32_t* st, uint32_t per_proof,
                            int32_t err_code, const uint32_t* owner) {
     if (!count) return;
+    if (count <= ZK_NORM_EACH_MAX && !zk_one_lane_chains()) {
+        hipLaunchKernelGGL(k_p256_normalize_each, dim3((count + 255) / 256), dim3(256), 0, s, proj, count, ox, oy, st, per_proof, err_code, owner);
+        return;
+    }
     uint32_t per = count / ZK_NORM_MIN_THREADS;
     if (per < 4) per = 4;
     if (per > ZK_NORM_PER_MAX) per = ZK_NORM_PER_MAX;

@@ -349,8 +349,30 @@ __global__ void __launch_bounds__(256) k_tom_normalize(TomList L, uint32_t count
     }
 #endif
 }
+// A launch of a few thousand points (every normaliser of a small call) is a chain of latencies: prefix products, eight scan rounds with barriers, the workgroup's
+// inversion, the backward pass.  One thread per point with its OWN divsteps inversion (38 us whatever the number of lanes, tools/coop_bench.hip) is shorter: the same
+// affine values -- an inverse is an inverse -- in canonical limbs, hence the same bytes.  Above ZK_NORM_EACH_MAX points the shared inversion wins on throughput.
+#ifndef ZK_NORM_EACH_MAX
+#define ZK_NORM_EACH_MAX 16384u
+#endif
+__global__ void __launch_bounds__(256) k_tom_normalize_each(TomList L, uint32_t count, uint32_t first, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride) {
+    const uint32_t c = gtid();
+    if (c >= count) return;
+    const uint32_t e = norm_slot(c, first, per_group, slots_per_group, kstride);
+    Fe<ModT, 1> one = fe_zero<ModT>();
+    one.l[0] = 1;
+    const Ft2 zi = fe_inv<ModT>(soa_ld<ModT, 2>(L.proj.z, e)) * one;   // plain 1 / z: the products below come out plain (see k_tom_normalize)
+    const Ft2 x = soa_ld<ModT, 2>(L.proj.x, e) * (zi * fe_const<ModT, 1>(TOM_SINV_M));
+    const Ft2 y = soa_ld<ModT, 2>(L.proj.y, e) * zi;
+    soa_st(L.ax, e, fe_canon(x));
+    soa_st(L.ay, e, fe_canon(y));
+}
 void launch_tom_normalize(hipStream_t s, const TomList& L, uint32_t count, uint32_t first, uint32_t per_group, uint32_t slots_per_group, uint32_t kstride) {
     if (!count) return;
+    if (count <= ZK_NORM_EACH_MAX && !zk_one_lane_chains()) {
+        hipLaunchKernelGGL(k_tom_normalize_each, dim3((count + 255) / 256), dim3(256), 0, s, L, count, first, per_group, slots_per_group, kstride);
+        return;
+    }
     uint32_t per = count / ZK_NORM_MIN_THREADS;
     if (per < 4) per = 4;
     if (per > ZK_NORM_PER_MAX) per = ZK_NORM_PER_MAX;
