@@ -161,10 +161,22 @@ ZK_DEV void mod_limbs(uint32_t md[NLIMB]) {
 #ifndef ZK_SINGLE_CHAIN
 #define ZK_SINGLE_CHAIN 1
 #endif
+// ZK_MAD_VOLATILE=1 (experiment, per translation unit): the empty asm statements of mad64c are volatile, so the machine scheduler may not move one chain's multiply-adds
+// past another's.  Without it the scheduler sometimes strings a product's whole chain together to get registers back: the FIRST table walk of k_exp_commit_kt has 1 046
+// hazard nops per loop body against ~200 in the two walks behind it, k_msm_bucket 592 at 96 VGPRs against 153 at 128.  Measured, same box (profiles/r06_ab_variants.txt (8)):
+// no gain -- at three to five waves per SIMD the other waves cover a serialised chain (p256_exp_commit 29.2 -> 29.2 ms, bucket sums 17.6 -> 16.9 ms but the P-256 pass beside
+// them 9.5 -> 10.7).  Default off.
+#ifndef ZK_MAD_VOLATILE
+#define ZK_MAD_VOLATILE 0
+#endif
 ZK_DEV uint64_t mad64c(uint32_t a, uint32_t b, uint64_t c) {
     uint64_t r = (uint64_t)a * b + c;
 #if ZK_SINGLE_CHAIN && !defined(ZK_HOST_BUILD)
+#if ZK_MAD_VOLATILE
+    asm volatile("" : "+v"(r));   // ... and, volatile, it keeps its place among the other chains' sums: the lock-step order of the source IS the schedule
+#else
     asm("" : "+v"(r));   // no instruction: the sum is opaque to the reassociation pass
+#endif
 #endif
     return r;
 }
