@@ -882,7 +882,8 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
     // A small chunk leaves the GPU idle and its phases are chains of latencies: the membership phase (list C, its own hash and responses) runs on the
     // lane's side stream beside the PointAdd phase (list B); they share only what stage 1 and the scan left behind.
     auto& PL = c->pl[pd.lane];
-    const bool beside = !sliced && plan.size() == 1 && cnt <= ZK_PROVE_SIDE_MAX;   // (chunks of a longer job overlap each other on the lanes already)
+    const bool beside = !sliced && plan.size() == 1 && cnt <= ZK_PROVE_SIDE_MAX;   // (chunks of a longer job overlap each other on the lanes already: doing it for every
+                                                                                    // chunk measured -0.6 % proofs/s, profiles/r06_ab_variants.txt (9))
     hipStream_t sg = s;
     if (beside) {
         if (timed) c->timing_forked = true;
