@@ -88,6 +88,54 @@ ZK_DEV void gkm_mfma_row(int u, const v4i& a, const v4i (&b)[GKM_ND], v4i (&acc)
         else acc[GKM_NDIAG - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a << 4, b[v] << 4, acc[GKM_NDIAG - 1], 0, 0, 0);   // u = v = 32: bytes 0 / 1 -> 16
     }
 }
+// the same against the digits [V0, V0 + NV) of B only, held in b[0 .. NV): one half of the planes (GKM_DOUBLE_BUFFER)
+template <int V0, int NV>
+ZK_DEV void gkm_mfma_row_part(int u, const v4i& a, const v4i (&b)[NV], v4i (&acc)[GKM_NDIAG]) {
+#pragma unroll
+    for (int v = V0; v < V0 + NV; v++) {
+        if (u + v < GKM_NDIAG) acc[u + v] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b[v - V0], acc[u + v], 0, 0, 0);
+        else acc[GKM_NDIAG - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a << 4, b[v - V0] << 4, acc[GKM_NDIAG - 1], 0, 0, 0);
+    }
+}
+// EXPERIMENT, default off (round 5's review item 6; profiles/r06_ab_variants.txt (10)).  One chunk of 64 values of i with the B planes in two halves (17 + 16): while the
+// matrix pipe works through one half against all 33 planes of A, the other half's registers are free and take the NEXT chunk's planes, so that the 33 loads that head every
+// chunk no longer stand in front of its first matrix instruction.  The price decides it: A is streamed TWICE per chunk, one 1 KB plane per 17 matrix instructions instead of
+// per 33 -- 15 bytes per cycle and CU from the L2, about 9 TB/s chip-wide -- and the kernels become operand-bound: gk_fold 15.6 -> 21.6 ms per step, v_gk_total 6.4 -> 10.0 ms,
+// verification at ring 2^20 409 -> 330 k/s (same box, twice).  Same results (the matrix-pipe tests pass on it); not used.
+#ifndef GKM_DOUBLE_BUFFER
+#define GKM_DOUBLE_BUFFER 0
+#endif
+#define GKM_H0 17
+#define GKM_H1 (GKM_ND - GKM_H0)
+ZK_DEV void gkm_chunk_halves(const int8_t* ak, const int8_t* bnext, uint32_t lane, v4i (&b0)[GKM_H0], v4i (&b1)[GKM_H1], v4i (&acc)[GKM_NDIAG]) {
+    {
+        v4i a0 = gkm_ld(ak, lane), a1 = gkm_ld(ak + GKM_FRAG, lane), a2;
+#pragma unroll
+        for (int u = 0; u < GKM_ND; u++) {
+            if (u + 2 < GKM_ND) a2 = gkm_ld(ak + (size_t)(u + 2) * GKM_FRAG, lane);
+            gkm_mfma_row_part<0, GKM_H0>(u, a0, b0, acc);
+            a0 = a1, a1 = a2;
+        }
+    }
+    if (bnext) {
+#pragma unroll
+        for (int v = 0; v < GKM_H0; v++) b0[v] = gkm_ld(bnext + (size_t)v * GKM_FRAG, lane);
+    }
+    {
+        v4i a0 = gkm_ld(ak, lane), a1 = gkm_ld(ak + GKM_FRAG, lane), a2;
+#pragma unroll
+        for (int u = 0; u < GKM_ND; u++) {
+            if (u + 2 < GKM_ND) a2 = gkm_ld(ak + (size_t)(u + 2) * GKM_FRAG, lane);
+            gkm_mfma_row_part<GKM_H0, GKM_H1>(u, a0, b1, acc);
+            a0 = a1, a1 = a2;
+        }
+    }
+    if (bnext) {
+#pragma unroll
+        for (int v = 0; v < GKM_H1; v++) b1[v] = gkm_ld(bnext + (size_t)(GKM_H0 + v) * GKM_FRAG, lane);
+    }
+}
+
 // 64 diagonal sums -> the 18-limb radix-2^30 integer sum_d D_d 256^d (non-negative: it IS sum_i c_i key_i)
 ZK_DEV void gkm_recombine(const int32_t D[GKM_NDIAG], uint32_t t30[18]) {
     uint8_t by[72];
@@ -193,6 +241,18 @@ __global__ void __launch_bounds__(256, 1) k_v_gk_block_mfma(uint32_t count, cons
     for (int d = 0; d < GKM_NDIAG; d++) acc[d] = (v4i){0, 0, 0, 0};
     const int8_t* ap = afrag + (size_t)tile_p * GKM_TILE_BYTES;
     const int8_t* bp = bfrag + (size_t)tile_b * GKM_TILE_BYTES;
+#if GKM_DOUBLE_BUFFER
+    {
+        v4i b0[GKM_H0], b1[GKM_H1];
+#pragma unroll
+        for (int v = 0; v < GKM_H0; v++) b0[v] = gkm_ld(bp + (size_t)v * GKM_FRAG, lane);
+#pragma unroll
+        for (int v = 0; v < GKM_H1; v++) b1[v] = gkm_ld(bp + (size_t)(GKM_H0 + v) * GKM_FRAG, lane);
+#pragma unroll 1
+        for (uint32_t kc = 0; kc < nkc; kc++)
+            gkm_chunk_halves(ap + (size_t)kc * GKM_ND * GKM_FRAG, kc + 1 < nkc ? bp + (size_t)(kc + 1) * GKM_ND * GKM_FRAG : nullptr, lane, b0, b1, acc);
+    }
+#else
 #pragma unroll 1
     for (uint32_t kc = 0; kc < nkc; kc++) {
         const int8_t* ak = ap + (size_t)kc * GKM_ND * GKM_FRAG;
@@ -208,6 +268,7 @@ __global__ void __launch_bounds__(256, 1) k_v_gk_block_mfma(uint32_t count, cons
             a0 = a1, a1 = a2;
         }
     }
+#endif
     // D layout: lane l, register r <-> proof 4 (l >> 4) + r, block l & 15; two proofs at a time in lock step (see gkm_recombine_n)
     const uint32_t pb = tile_p * 16 + 4 * (lane >> 4), block = tile_b * 16 + (lane & 15);
 #pragma unroll 1
@@ -326,6 +387,19 @@ __global__ void __launch_bounds__(256, 1) k_gk_block_mfma(Workspace W, ChunkIn i
     v4i acc[GKM_NDIAG];
 #pragma unroll
     for (int d = 0; d < GKM_NDIAG; d++) acc[d] = (v4i){0, 0, 0, 0};
+#if GKM_DOUBLE_BUFFER
+    {
+        const int8_t* bk0 = bp + (size_t)c0 * GKM_ND * GKM_FRAG;
+        v4i b0[GKM_H0], b1[GKM_H1];
+#pragma unroll
+        for (int v = 0; v < GKM_H0; v++) b0[v] = gkm_ld(bk0 + (size_t)v * GKM_FRAG, lane);
+#pragma unroll
+        for (int v = 0; v < GKM_H1; v++) b1[v] = gkm_ld(bk0 + (size_t)(GKM_H0 + v) * GKM_FRAG, lane);
+#pragma unroll 1
+        for (uint32_t c = c0; c < c1; c++)
+            gkm_chunk_halves(ap + (size_t)c * GKM_ND * GKM_FRAG, c + 1 < c1 ? bp + (size_t)(c + 1) * GKM_ND * GKM_FRAG : nullptr, lane, b0, b1, acc);
+    }
+#else
 #pragma unroll 1
     for (uint32_t c = c0; c < c1; c++) {
         const int8_t* ak = ap + (size_t)c * GKM_ND * GKM_FRAG;
@@ -341,6 +415,7 @@ __global__ void __launch_bounds__(256, 1) k_gk_block_mfma(Workspace W, ChunkIn i
             a0 = a1, a1 = a2;
         }
     }
+#endif
     // D layout: lane l, register r <-> row 4 (l >> 4) + r of the tile, block l & 15
     const uint32_t rowb = row0 + 4 * (lane >> 4), block = tile_b * 16 + (lane & 15);
     // epilogue at ONE wave per SIMD, where nothing hides a dependent chain: the lane's rows two at a time in lock step (tools/valu_peak.hip:
