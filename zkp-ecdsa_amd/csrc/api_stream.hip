@@ -227,7 +227,6 @@ static void drive(zk_ctx* c, zk_job* upto, uint32_t ahead) {
             lookahead(c, ji, J->lane_base() + J->next_s2() + NL);   // global chunks below that may have their stage 1 enqueued
             if (J->all_enqueued) break;
             const uint64_t k2 = J->next_s2();
-            const uint32_t lane2 = (uint32_t)((J->lane_base() + k2) % NL);
             zk_status zs = J->stage2(k2);
             J->next_s2()++;
             if (zs) job_fail(J, zs);
