@@ -489,7 +489,7 @@ extern "C" zk_status zk_verify_wait(zk_ctx* c, zk_job* job) { return wait_common
 
 extern "C" uint64_t zk_test_counter(const zk_ctx* c, int which) {
     if (!c) return 0;
-    if (which == 4) return g_coop_chains;   // chains of the small-call paths handed to cooperating waves (k_coop.hip), process-wide
+    if (which == 4) return g_coop_chains.load(std::memory_order_relaxed);   // chains of the small-call paths handed to cooperating waves (k_coop.hip), process-wide
     if (which == 1) {   // proofs of lane 0's last chunk that took the key-table path (k_ktab.hip)
         const auto& L = c->pl[0];
         if (!L.ready || !L.last_cnt || !L.W.kt_use) return 0;

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <cstdlib>
 #include "../../include/zkattest.h"
 #include "curve.h"
@@ -294,7 +295,7 @@ void launch_v_acc_tree(hipStream_t s, const Soa4& src, uint32_t nouter, uint32_t
 #define ZK_COOP_MAX_CHAINS 16384u
 #endif
 // ZKATTEST_ONE_LANE_CHAINS (any value): every dependent chain stays in one lane (the kernels of round 5) -- the A/B switch behind profiles/r06_ab_variants.txt
-extern uint64_t g_coop_chains;   // k_coop.hip: chains handed to cooperating waves by this process so far (zk_test_counter 4; tests only, not synchronised)
+extern std::atomic<uint64_t> g_coop_chains;   // k_coop.hip: chains handed to cooperating waves by this process so far (zk_test_counter 4; tests only)
 static inline bool zk_one_lane_chains() {
     static const bool v = getenv("ZKATTEST_ONE_LANE_CHAINS") != nullptr;
     return v;

@@ -9,7 +9,7 @@
 #include "coop_dev.h"
 #include "rtab.h"
 
-uint64_t g_coop_chains = 0;
+std::atomic<uint64_t> g_coop_chains{0};
 #define VW_ENT 8
 #define VW_NW256 65
 #define VW_NW128 33
@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(64) k_v_straus_co(VTerms L, uint32_t ngroups, 
 }
 void launch_v_straus_co(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out, const uint32_t* perm,
                         const uint32_t* cnt, uint32_t tsplit, uint32_t ostride, uint32_t ny, uint32_t ystride) {
-    g_coop_chains += (uint64_t)ngroups * tsplit * ny;
+    g_coop_chains.fetch_add((uint64_t)ngroups * tsplit * ny, std::memory_order_relaxed);
     hipLaunchKernelGGL(k_v_straus_co, dim3(ngroups * tsplit, ny), dim3(64), 0, s, L, ngroups, ng_stride, n256, n128, out, perm, cnt, tsplit, ostride, ystride);
 }
 
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(64) k_v_p256_straus_co(VWork V, uint32_t count
     co_store_soa(acc.v, t, V.pacc.x, V.pacc.y, V.pacc.z, Soa{nullptr, 0});
 }
 void launch_v_p256_straus_co(hipStream_t s, const VWork& V, uint32_t count) {
-    g_coop_chains += (uint64_t)count * (VK + 1);
+    g_coop_chains.fetch_add((uint64_t)count * (VK + 1), std::memory_order_relaxed);
     if (count) hipLaunchKernelGGL(k_v_p256_straus_co, dim3(count * (VK + 1)), dim3(64), 0, s, V, count);
 }
 
@@ -110,6 +110,6 @@ __global__ void __launch_bounds__(64) k_rtab_base_co(Workspace W, uint32_t count
     }
 }
 void launch_rtab_base_co(hipStream_t s, const Workspace& W, uint32_t count, uint32_t bits, const uint8_t* skip) {
-    g_coop_chains += count;
+    g_coop_chains.fetch_add(count, std::memory_order_relaxed);
     if (count) hipLaunchKernelGGL(k_rtab_base_co, dim3(count), dim3(64), 0, s, W, count, bits, skip);
 }
