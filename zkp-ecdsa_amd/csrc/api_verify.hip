@@ -209,13 +209,11 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
         HIPCHK(c, hipEventRecord(A.aux_fork, s));
         HIPCHK(c, hipStreamWaitEvent(A.aux[0], A.aux_fork, 0));
         HIPCHK(c, hipStreamWaitEvent(A.aux[1], A.aux_fork, 0));
-        {   // aux 0: the Exp challenge (three kernels where the schedule buffer holds the chunk) and the sampled repetitions
+        {   // aux 0: the Exp challenge (three kernels where the schedule buffer holds the chunk): 0.45 ms in one lane, needed only to CHECK the header's bits
             MaybeScope t(timed, c, "v_hash", A.aux[0]);
             if (cnt <= W.exph_cap && W.exph_wk) launch_v_exp_challenge_small(A.aux[0], W, V, cnt, d_proofs, d_off, first);
             else launch_v_challenges(A.aux[0], V, cnt, d_proofs, d_off, d_msg, first, 1);
-            launch_v_sample(A.aux[0], V, cnt, d_vseeds, first);
         }
-        HIPCHK(c, hipEventRecord(A.aux_done[0], A.aux[0]));
         {   // aux 1: the membership challenge and total
             MaybeScope t(timed, c, "v_gk_total", A.aux[1]);
             launch_v_challenges(A.aux[1], V, cnt, d_proofs, d_off, d_msg, first, 2);
@@ -232,21 +230,32 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
             HIPCHK(c, hipStreamWaitEvent(sq, A.aux_fork, 0));
         }
         launch_v_front_q(sq, P, W, V, cnt, d_proofs, d_off, d_msg, first);
-        if (small) HIPCHK(c, hipEventRecord(A.aux_done[2], sq));
+        if (small) {   // the sampled repetitions (the header's bits: k_v_sample) behind Q; the comparison with the recomputed challenge behind both, on the hash's stream
+            {
+                MaybeScope t2(timed, c, "v_hash", sq);
+                launch_v_sample(sq, V, cnt, d_vseeds, first);
+            }
+            HIPCHK(c, hipEventRecord(A.aux_done[2], sq));
+            HIPCHK(c, hipStreamWaitEvent(A.aux[0], A.aux_done[2], 0));
+            launch_v_sample_check(A.aux[0], V, cnt);
+            HIPCHK(c, hipEventRecord(A.aux_done[0], A.aux[0]));
+        }
         launch_rtab(s, W, cnt, RTAB_VERIFY_BITS);
         if (small) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[2], 0));
     }
-    if (small) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[0], 0));   // challenges and sampled repetitions
-    else {
+    if (!small) {
         MaybeScope t(timed, c, "v_hash", s);
         // (a chunk of this size keeps one wave per SIMD busy with one lane per proof already: the three-kernel path of the small chunks measured 1.9 ms per
         // 32 768 proofs against this kernel's 1.86, profiles/r05_ab_variants.txt)
         launch_v_challenges(s, V, cnt, d_proofs, d_off, d_msg, first, 3);
         launch_v_sample(s, V, cnt, d_vseeds, first);
+        launch_v_sample_check(s, V, cnt);
     }
     {
         MaybeScope t(timed, c, "v_p256_exp_points", s);
         launch_v_exp_points(s, W, V, cnt, d_proofs, d_off, first, small ? 4 : 1);
+        if (small) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[0], 0));   // the recomputed challenge against the header's bits: first needed by the exception order
+        launch_v_exp_status(s, W, V, cnt);
         launch_p256_normalize(s, W.Tproj, cnt * VK, W.Tx, W.Ty, W.st, VK, 0, nullptr);   // identities were given their status by k_v_exp_status
     }
     {

@@ -268,6 +268,8 @@ void launch_v_front_q(hipStream_t s, const DevParams& P, const Workspace& W, con
 void launch_v_challenges(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* msg, uint64_t first, uint32_t parts);
 void launch_v_exp_challenge_small(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* vseeds, uint64_t first);
+void launch_v_sample_check(hipStream_t s, const VWork& V, uint32_t count);
+void launch_v_exp_status(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count);
 void launch_exph_hash(hipStream_t s, const Workspace& W, uint32_t count, uint32_t* chal);   // k_hash.hip: schedule per block, rounds per proof -> chal[4 p ..]
 void launch_v_exp_points(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first, uint32_t split = 1);   // split: 1, or 4 lanes per checked repetition (small chunks)
 void launch_v_t1_scalars(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);

@@ -601,23 +601,33 @@ __global__ void __launch_bounds__(64) k_v_sample(VWork V, uint32_t count, const 
             i++;
         }
     }
-    const uint32_t* c = V.chal + 4 * p;
+    // The sampled repetitions with the bit the proof's HEADER claims for each: the header bits are what the proof's layout follows, so every later kernel parses
+    // consistently, and they need nothing from the 16 KB hash that recomputes the challenge -- in a small call that hash (0.45 ms in one lane) runs beside R's
+    // window table and the sampled points instead of in front of them.  k_v_sample_check compares the two once the hash is there.
     const uint32_t* hb = V.hbits + 4 * p;
-    // verifyExp walks the sampled repetitions in order and throws at the FIRST one that fails (exp.ts:265-346): 'params not found' where
-    // the response's type does not match the recomputed challenge bit (exp.ts:269-271,301-303), 'T is at infinity' / 'T1 is at infinity'
-    // (exp.ts:274,312) where the point is the identity.  jm = first slot whose type mismatches; the slots before it still get their
-    // point computed, and k_v_exp_status picks the earliest exception.
-    uint32_t jm = VK;
     for (uint32_t j = 0; j < VK; j++) {
         uint32_t i = PERM(j);
-        uint32_t bit = (c[i >> 5] >> (i & 31)) & 1, hbit = (hb[i >> 5] >> (i & 31)) & 1;
-        V.idx[p * VK + j] = i | (bit << 8);
+        V.idx[p * VK + j] = i | (((hb[i >> 5] >> (i & 31)) & 1) << 8);
+    }
+}
+#undef PERM
+// verifyExp walks the sampled repetitions in order and throws at the FIRST one that fails (exp.ts:265-346): 'params not found' where the response's type (the
+// header bit) does not match the recomputed challenge bit (exp.ts:269-271,301-303), 'T is at infinity' / 'T1 is at infinity' (exp.ts:274,312) where the point is
+// the identity.  jm = first slot whose type mismatches (VK: none); the slots behind it are never looked at by the reference, and k_v_exp_status picks the
+// earliest exception among the slots before it and the mismatch itself.  Needs V.chal (the recomputed challenge) and V.idx.
+__global__ void __launch_bounds__(64) k_v_sample_check(VWork V, uint32_t count) {
+    const uint32_t p = gtid();
+    if (p >= count) return;
+    const uint32_t* c = V.chal + 4 * p;
+    uint32_t jm = VK;
+    for (uint32_t j = 0; j < VK; j++) {
+        const uint32_t iv = V.idx[p * VK + j], i = iv & 255, hbit = iv >> 8;
+        const uint32_t bit = (c[i >> 5] >> (i & 31)) & 1;
         if (bit != hbit && jm == VK) jm = j;
     }
     V.exp_st[p] = jm < VK ? ZK_E_PARAMS_NOT_FOUND : ZK_OK;
     V.okflags[p] = (V.okflags[p] & 0xffff00ffu) | (jm << 8);
 }
-#undef PERM
 
 // ------------------------------------------------------------------ Exp: T = alpha*R or T1 = z*R + Q per checked rep (exp.ts:267,299,311)
 // split = 1: one lane per checked repetition walks all 65 windows of R's table.  split = 4 (small chunks): four neighbouring lanes take 17 windows each and
@@ -630,8 +640,9 @@ __global__ void __launch_bounds__(256) k_v_exp_points(Workspace W, VWork V, uint
     uint32_t iv = V.idx[t], i = iv & 255, bit = iv >> 8;
     const uint8_t* pr = proofs + off[first + p];
     P256Pt acc = p256_identity();
-    // every slot before the first type mismatch (all of them in an honest proof): an identity there is thrown before the mismatch is seen
-    bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8) && t % VK < ((V.okflags[p] >> 8) & 0xffu);
+    // every sampled slot, parsed by its header bit: where the recomputed challenge disagrees (k_v_sample_check, possibly still running) the slots from the first
+    // mismatch on are ignored by k_v_exp_status, as the reference never reaches them
+    bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8);
     if (good) {
         const uint8_t* rep = pr + rep_offset(V.hbits + 4 * p, i);
         Sn s = ld_scalar_n(rep + 208);
@@ -1712,12 +1723,17 @@ void launch_v_exp_challenge_small(hipStream_t s, const Workspace& W, const VWork
     L1(k_v_exph_msg, count * (2 + 3 * V.sec + 1), 256, W, V, count, proofs, off, first);
     launch_exph_hash(s, W, count, V.chal);
 }
-void launch_v_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* vseeds, uint64_t first) {
+void launch_v_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* vseeds, uint64_t first) {   // needs the header only
     L1(k_v_sample_fills, count * VS_KMAX, 256, V, count, vseeds, first);
     L1(k_v_sample, count, 64, V, count, vseeds, first);
 }
+void launch_v_sample_check(hipStream_t s, const VWork& V, uint32_t count) {   // needs the recomputed challenge and the sampled slots
+    L1(k_v_sample_check, count, 64, V, count);
+}
 void launch_v_exp_points(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first, uint32_t split) {
     L1(k_v_exp_points, count * VK * split, 256, W, V, count, proofs, off, first, split);
+}
+void launch_v_exp_status(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count) {   // needs k_v_sample_check's verdict and the points
     L1(k_v_exp_status, count, 64, W, V, count);
 }
 void launch_v_t1_scalars(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
