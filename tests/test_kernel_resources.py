@@ -26,7 +26,7 @@ SCRATCH_OK = [
     ('k_test_sha256', 8, 'sha frame'),
 ]
 # verifier / prover kernels the round-1 review named: they must fit two waves per SIMD in architectural VGPRs alone
-NAMED = ['k_v_slot_terms', 'k_v_slot_points', 'k_v_proof_terms', 'k_v_proof_points', 'k_v_p256_straus', 'k_v_p256_tables', 'k_v_term_tables',
+NAMED = ['k_v_slot_terms', 'k_v_slot_points', 'k_v_proof_terms', 'k_v_proof_sums', 'k_v_proof_points', 'k_v_p256_straus', 'k_v_p256_tables', 'k_v_term_tables',
          'k_v_straus', 'k_v_final', 'k_padd_scalars', 'k_padd_respond', 'k_tom_commit', 'k_exp_commit']
 
 

@@ -5,7 +5,7 @@
 export GPU_MAX_HW_QUEUES=8
 O=gpurun_out/r06ab
 mkdir -p $O
-timeout 1500 python -m pytest tests/test_gpu_mutants.py tests/test_gpu_small_batches.py tests/test_gpu_verify.py tests/test_wire_packed.py -q -m gpu -x > $O/sample_tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/sample_tests.log
+mkdir -p $O; timeout 1500 python -m pytest tests/test_gpu_mutants.py tests/test_gpu_small_batches.py tests/test_gpu_verify.py tests/test_wire_packed.py -q -m gpu -x > $O/sample_tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/sample_tests.log
 for rep in 1 2 3; do
   for v in base main; do
     lib=$PWD/zkp-ecdsa_amd/build_ab/lib_$v.so; [ $v = main ] && lib=$PWD/zkp-ecdsa_amd/lib/libzkattest_hip.so

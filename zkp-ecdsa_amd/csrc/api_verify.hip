@@ -8,6 +8,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, PMsmBuf& PM, uint
     V.C = C, V.sec = sec, V.n = n;
     V.st = (int32_t*)k.take(4 * (size_t)C);
     V.exp_st = (int32_t*)k.take(4 * (size_t)C);
+    V.exp_jm = (uint32_t*)k.take(4 * (size_t)C), V.exp_jz = (uint32_t*)k.take(4 * (size_t)C);
     V.okflags = (uint32_t*)k.take(4 * (size_t)C);
     V.zcnt = (uint32_t*)k.take(4 * (size_t)C);
     V.hbits = (uint32_t*)k.take(16 * (size_t)C);
@@ -45,7 +46,7 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, PMsmBuf& PM, uint
     V.pSR = k.soa(C), V.pSH = k.soa(C), V.pSL = k.soa(C);
     V.pa_x = k.soa(ns), V.pa_y = k.soa(ns), V.pa_sc = k.soa(ns);
     V.pa_tab = (uint32_t*)k.take(ns * 8 * RTAB_ENTRY_WORDS * 4), V.pa_dig = (uint8_t*)k.take(ns * 33);
-    V.pacc = k.soa3(std::max<size_t>((size_t)C * (VK / 5 + 1), std::min<size_t>(C, V_SIDE_MAXP) * (VK + 1)));
+    V.pacc = k.soa3(std::max<size_t>((size_t)C * (VK / 5 + 1), std::min<size_t>(C, V_SIDE_MAXP) * (VK + 2)));
     V.clx = k.soa(C), V.cly = k.soa(C);
     V.cl_tab = (uint32_t*)k.take((size_t)C * 8 * RTAB_ENTRY_WORDS * 4), V.cl_dig = (uint8_t*)k.take((size_t)C * 35), V.p256_ok = (uint32_t*)k.take(4 * (size_t)C);
     PM = PMsmBuf{};
@@ -206,42 +207,53 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
     if (small && timed) c->timing_forked = true;
     auto& A = c->vl[lane];
     if (small) {
-        HIPCHK(c, hipEventRecord(A.aux_fork, s));
+        // Host order = the longest chain first: a launch costs about 5 us of host time, and the main stream's chain (R's table: 256 doublings in a row, then the sampled
+        // points) is what the call waits for -- with the side streams' fourteen launches in front of it the table started 0.14 ms late (profiles/r06_ab_variants.txt (13)).
+        HIPCHK(c, hipEventRecord(A.aux_fork, s));   // header read and validated
         HIPCHK(c, hipStreamWaitEvent(A.aux[0], A.aux_fork, 0));
         HIPCHK(c, hipStreamWaitEvent(A.aux[1], A.aux_fork, 0));
+        hipStream_t sq = A.aux[2];
+        {
+            MaybeScope t(timed, c, "v_p256_front_rtab", s);
+            launch_v_front_r(s, W, V, cnt, d_proofs, d_off, first);
+            HIPCHK(c, hipEventRecord(A.aux_fork, s));   // R
+            HIPCHK(c, hipStreamWaitEvent(sq, A.aux_fork, 0));
+            launch_rtab(s, W, cnt, RTAB_VERIFY_BITS);
+        }
+        {   // aux 2: Q = (z / R.x) G (an inversion and a comb walk) beside R's table, then the sampled repetitions as the header's bits give them (k_v_sample)
+            MaybeScope t(timed, c, "v_p256_front_rtab", sq);
+            launch_v_front_q(sq, P, W, V, cnt, d_proofs, d_off, d_msg, first);
+        }
+        {
+            MaybeScope t(timed, c, "v_hash", sq);
+            launch_v_sample(sq, V, cnt, d_vseeds, first);
+        }
+        HIPCHK(c, hipEventRecord(A.aux_done[2], sq));
         {   // aux 0: the Exp challenge (three kernels where the schedule buffer holds the chunk): 0.45 ms in one lane, needed only to CHECK the header's bits
             MaybeScope t(timed, c, "v_hash", A.aux[0]);
             if (cnt <= W.exph_cap && W.exph_wk) launch_v_exp_challenge_small(A.aux[0], W, V, cnt, d_proofs, d_off, first);
             else launch_v_challenges(A.aux[0], V, cnt, d_proofs, d_off, d_msg, first, 1);
+            HIPCHK(c, hipStreamWaitEvent(A.aux[0], A.aux_done[2], 0));
+            launch_v_sample_check(A.aux[0], V, cnt);   // waited for in stage 2, in front of k_v_final
         }
+        HIPCHK(c, hipEventRecord(A.aux_done[0], A.aux[0]));
         {   // aux 1: the membership challenge and total
             MaybeScope t(timed, c, "v_gk_total", A.aux[1]);
             launch_v_challenges(A.aux[1], V, cnt, d_proofs, d_off, d_msg, first, 2);
             launch_v_gk_total(A.aux[1], V, W.ring, W.gk_etab, W.gk_kdig, cnt, W.N, d_proofs, d_off, first, vres, vres2);
         }
+        {   // ... and the membership proof's terms (points and scalars), which need nothing else
+            MaybeScope t(timed, c, "v_terms", A.aux[1]);
+            launch_v_proof_points(A.aux[1], V, cnt, d_proofs, d_off, first, 1);
+            launch_v_proof_terms(A.aux[1], W, V, cnt, d_proofs, d_off, d_vseeds, first);
+        }
         HIPCHK(c, hipEventRecord(A.aux_done[1], A.aux[1]));
-    }
-    {
+        HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[2], 0));   // Q and the sampled repetitions
+    } else {
         MaybeScope t(timed, c, "v_p256_front_rtab", s);
         launch_v_front_r(s, W, V, cnt, d_proofs, d_off, first);
-        hipStream_t sq = small ? A.aux[2] : s;   // Q = (z / R.x) G (an inversion and a comb walk) beside R's table
-        if (small) {
-            HIPCHK(c, hipEventRecord(A.aux_fork, s));
-            HIPCHK(c, hipStreamWaitEvent(sq, A.aux_fork, 0));
-        }
-        launch_v_front_q(sq, P, W, V, cnt, d_proofs, d_off, d_msg, first);
-        if (small) {   // the sampled repetitions (the header's bits: k_v_sample) behind Q; the comparison with the recomputed challenge behind both, on the hash's stream
-            {
-                MaybeScope t2(timed, c, "v_hash", sq);
-                launch_v_sample(sq, V, cnt, d_vseeds, first);
-            }
-            HIPCHK(c, hipEventRecord(A.aux_done[2], sq));
-            HIPCHK(c, hipStreamWaitEvent(A.aux[0], A.aux_done[2], 0));
-            launch_v_sample_check(A.aux[0], V, cnt);
-            HIPCHK(c, hipEventRecord(A.aux_done[0], A.aux[0]));
-        }
+        launch_v_front_q(s, P, W, V, cnt, d_proofs, d_off, d_msg, first);
         launch_rtab(s, W, cnt, RTAB_VERIFY_BITS);
-        if (small) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[2], 0));
     }
     if (!small) {
         MaybeScope t(timed, c, "v_hash", s);
@@ -254,8 +266,18 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
     {
         MaybeScope t(timed, c, "v_p256_exp_points", s);
         launch_v_exp_points(s, W, V, cnt, d_proofs, d_off, first, small ? 4 : 1);
-        if (small) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[0], 0));   // the recomputed challenge against the header's bits: first needed by the exception order
-        launch_v_exp_status(s, W, V, cnt);
+        // a small chunk does not wait for the recomputed challenge here: a proof whose header disagrees with it is carried along as the header reads (defined data all the
+        // way) and k_v_final, behind the wait in stage 2, gives it verifyExp's exception
+        launch_v_exp_status(s, W, V, cnt, !small);
+        if (small) {   // the slots' term points are read off the proof: beside the commitments T1 and the derived points, on Q's stream
+            HIPCHK(c, hipEventRecord(A.aux_fork, s));
+            HIPCHK(c, hipStreamWaitEvent(A.aux[2], A.aux_fork, 0));
+            {
+                MaybeScope t2(timed, c, "v_terms", A.aux[2]);
+                launch_v_slot_points(A.aux[2], V, cnt, d_proofs, d_off, first);
+            }
+            HIPCHK(c, hipEventRecord(A.aux_done[2], A.aux[2]));
+        }
         launch_p256_normalize(s, W.Tproj, cnt * VK, W.Tx, W.Ty, W.st, VK, 0, nullptr);   // identities were given their status by k_v_exp_status
     }
     {
@@ -273,14 +295,24 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
         MaybeScope t(timed, c, "v_hash", s);
         launch_v_padd_hash(s, P, W, V, cnt, d_proofs, d_off, first);
     }
-    if (small) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[1], 0));   // membership total
-    else {
+    if (!small) {
         MaybeScope t(timed, c, "v_gk_total", s);
         launch_v_gk_total(s, V, W.ring, W.gk_etab, W.gk_kdig, cnt, W.N, d_proofs, d_off, first, vres, vres2);
     }
     {
         MaybeScope t(timed, c, "v_terms", s);
-        launch_v_terms(s, W, V, cnt, d_proofs, d_off, d_vseeds, first);
+        if (!small) launch_v_slot_points(s, V, cnt, d_proofs, d_off, first);
+        launch_v_slot_terms(s, W, V, cnt, d_proofs, d_off, d_vseeds, first);
+        if (small) launch_v_proof_points(s, V, cnt, d_proofs, d_off, first, 2);
+        else {
+            launch_v_proof_points(s, V, cnt, d_proofs, d_off, first, 3);
+            launch_v_proof_terms(s, W, V, cnt, d_proofs, d_off, d_vseeds, first);
+        }
+        launch_v_proof_sums(s, W, V, cnt);
+    }
+    if (small) {   // the membership proof's total and terms (aux 1), the slots' points (aux 2)
+        HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[1], 0));
+        HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[2], 0));
     }
     if (p256_batched(cnt, lane)) {   // a large chunk sums its P-256 relations across proofs (k_pmsm.hip): entries, digits, counting sort and the R parts here
         MaybeScope t(timed, c, "v_msm_p256", s);
@@ -318,11 +350,7 @@ static zk_status per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t 
         MaybeScope t(timed, c, "v_straus_tom", s);
         HIPCHK(c, hipEventRecord(A.aux_fork, s));
         for (int i = 0; i < 3; i++) HIPCHK(c, hipStreamWaitEvent(A.aux[i], A.aux_fork, 0));
-        const Soa4 wgk = acc_at(V.wide_acc, (size_t)np * VK * V_SLOT_TERMS);
-        launch_v_straus(A.aux[0], terms_at(V.gk_terms, (size_t)p0 * nq), np * nq, V.C * nq, 4, 4, wgk, nullptr, nullptr, V_WIDE_GK, V_WIDE_GK);
-        launch_v_acc_tree(A.aux[0], wgk, np, nq * V_WIDE_GK, acc_at(V.gk_acc, (size_t)p0 * nq), nq, nq - 1);
-        launch_v_straus(A.aux[1], terms_at(V.misc_terms, p0), np, 3 * V.C, 1, 0, acc_at(V.misc_acc, p0), nullptr, nullptr, 1, 1, 3, V.C);
-        launch_tom_commit(A.aux[2], P, lc, np * 2, 2, 4 * W.n);
+        // host order: the longest chain first (the slots' 720 terms per proof on the main stream), the short ones last -- a launch costs about 5 us of host time
         const size_t so = (size_t)p0 * VK;
         uint32_t* perm = V.slot_perm + so;
         uint32_t* pc = V.slot_cnt + 2 * range_no;
@@ -332,7 +360,12 @@ static zk_status per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t 
         const uint64_t slots = (uint64_t)np * VK;
         const uint32_t ts = slots * V_SLOT_TERMS > ZK_COOP_MAX_CHAINS && slots * V_SLOT_SPLIT <= ZK_COOP_MAX_CHAINS && !zk_one_lane_chains() ? V_SLOT_SPLIT : V_SLOT_TERMS;
         launch_v_straus(s, terms_at(V.slot_terms, so), np * VK, V.C * VK, 10, 26, V.wide_acc, perm, pc, ts, ts);
-        launch_v_acc_tree(s, V.wide_acc, np * VK, ts, acc_at(V.slot_acc, so * V_SLOT_SPLIT), V_SLOT_SPLIT, 0);
+        const Soa4 wgk = acc_at(V.wide_acc, (size_t)np * VK * V_SLOT_TERMS);
+        launch_v_straus(A.aux[0], terms_at(V.gk_terms, (size_t)p0 * nq), np * nq, V.C * nq, 4, 4, wgk, nullptr, nullptr, V_WIDE_GK, V_WIDE_GK);
+        launch_v_straus(A.aux[1], terms_at(V.misc_terms, p0), np, 3 * V.C, 1, 0, acc_at(V.misc_acc, p0), nullptr, nullptr, 1, 1, 3, V.C);
+        launch_v_acc_tree(s, V.wide_acc, np, VK * ts, acc_at(V.slot_acc, so * V_SLOT_SPLIT), VK * V_SLOT_SPLIT, 0);   // a proof's VK * ts accumulators are consecutive
+        launch_v_acc_tree(A.aux[0], wgk, np, nq * V_WIDE_GK, acc_at(V.gk_acc, (size_t)p0 * nq), nq, 0);   // one sum per proof (V_FOLDED)
+        launch_tom_commit(A.aux[2], P, lc, np * 2, 2, 4 * W.n);
         for (int i = 0; i < 3; i++) {
             HIPCHK(c, hipEventRecord(A.aux_done[i], A.aux[i]));
             HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[i], 0));
@@ -356,6 +389,29 @@ static zk_status per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t 
     }
     return ZK_OK;
 }
+// The P-256 relation of a small chunk (<= V_SIDE_MAXP proofs) on the lane's streams 2 and 3, which already wait for stage 1 (stage2a): one term per lane.
+static zk_status small_chunk_p256(zk_ctx* c, bool timed, uint32_t lane, uint32_t cnt) {
+    const DevParams& P = c->P;
+    const Workspace& W = c->pl[lane].W;
+    const VWork& V = c->vl[lane].V;
+    auto& A = c->vl[lane];
+    {
+        MaybeScope t(timed, c, "v_straus_p256", A.aux[3]);
+        launch_v_p256_straus(A.aux[3], V, cnt, 1);
+    }
+    {   // SR * R + SH * h_NIST (two table walks) beside the sums of the A_j
+        MaybeScope t(timed, c, "v_p256_total", A.aux[2]);
+        launch_v_p256_total_fixed(A.aux[2], P, W, V, cnt);
+    }
+    HIPCHK(c, hipEventRecord(A.aux_done[2], A.aux[2]));
+    HIPCHK(c, hipStreamWaitEvent(A.aux[3], A.aux_done[2], 0));
+    {
+        MaybeScope t(timed, c, "v_p256_total", A.aux[3]);
+        launch_v_p256_total_sum(A.aux[3], P, W, V, cnt);
+    }
+    HIPCHK(c, hipEventRecord(A.aux_done[3], A.aux[3]));
+    return ZK_OK;
+}
 zk_status VerifyJob::stage2a(uint64_t chunk_no) {
     const DevParams& P = c->P;
     const uint64_t first = plan[chunk_no].first;
@@ -374,18 +430,13 @@ zk_status VerifyJob::stage2a(uint64_t chunk_no) {
     if (wide_chunk && timed) c->timing_forked = true;
     auto& A = c->vl[lane];
     A.msm_pending = A.pm_pending = false;   // (a failed call may have left them set)
-    if (wide_chunk) {   // the P-256 sums of a small chunk, one term per lane, beside everything below
+    if (wide_chunk) {   // the P-256 sums of a small chunk, one term per lane, beside everything below: streams 2 and 3 start from here ...
         HIPCHK(c, hipEventRecord(A.aux_fork, s));
         HIPCHK(c, hipStreamWaitEvent(A.aux[3], A.aux_fork, 0));
-        {
-            MaybeScope t(timed, c, "v_straus_p256", A.aux[3]);
-            launch_v_p256_straus(A.aux[3], V, cnt, 1);
-        }
-        {
-            MaybeScope t(timed, c, "v_p256_total", A.aux[3]);
-            launch_v_p256_total(A.aux[3], P, W, V, cnt, 1);
-        }
-        HIPCHK(c, hipEventRecord(A.aux_done[3], A.aux[3]));
+        HIPCHK(c, hipStreamWaitEvent(A.aux[2], A.aux_fork, 0));
+        // ... and a call of a few proofs launches them BEHIND the Tom-256 sums' kernels (stage2b): those chains are the longer ones, and a launch costs 5 us of host time
+        if (cnt > V_WIDE_MAXP)
+            if (zk_status zr = small_chunk_p256(c, timed, lane, cnt)) return zr;
     }
     // P-256 relation: one bucket-method sum per group as well (k_pmsm.hip), on an auxiliary stream beside the Tom-256 pass; its verdicts arrive with that
     // pass's (one host round trip).  A group that fails sends the chunk through the per-proof sums.
@@ -459,11 +510,13 @@ zk_status VerifyJob::stage2b(uint64_t chunk_no) {
         // few slots: a slot's 36 terms over 4 lanes (the chain of one lane is ~12 ms long, the GPU is far from full)
         uint32_t tsplit = (uint64_t)(p1 - p0) * VK * V_SLOT_SPLIT <= 524288 ? V_SLOT_SPLIT : 1;   // up to two residencies of the GPU (4 waves per SIMD, 262 144 lanes)
         if (zk_status zr = per_proof_range(c, timed, s, lane, W, V, p0, p1, ranges++, tsplit)) return zr;
-        if (p1 - p0 <= V_WIDE_MAXP) tsplit = 1;   // folded: one accumulator per slot
+        if (p1 - p0 <= V_WIDE_MAXP) tsplit = 1 | V_FOLDED;   // folded: one accumulator per proof
         c->dbg_recheck_proofs += p1 - p0;
         for (uint32_t k = g; k < g1; k++) gf.v[k] = V_RECHECK | tsplit;
         g = g1;
     }
+    if (wide_chunk && cnt <= V_WIDE_MAXP)
+        if (zk_status zr = small_chunk_p256(c, timed, lane, cnt)) return zr;
     if (wide_chunk) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[3], 0));
     if (pm) {
         HIPCHK(c, hipEventSynchronize(A.aux_done[3]));
@@ -501,6 +554,7 @@ zk_status VerifyJob::stage2b(uint64_t chunk_no) {
             g = g1;
         }
     }
+    if (side_streams(cnt)) HIPCHK(c, hipStreamWaitEvent(s, c->vl[lane].aux_done[0], 0));   // k_v_sample_check (stage 1): the recomputed challenge against the header's bits
     {
         MaybeScope t(timed, c, "v_final", s);
         if (!wide_chunk && !pm) launch_v_p256_total(s, P, W, V, cnt, 5);

@@ -201,6 +201,7 @@ struct Workspace {
 #define V_WIDE_GK 8         // terms (= lanes) per membership group
 #define V_AUX_STREAMS 4
 #define V_RECHECK 0x100u    // group flag: per-proof sums were computed, low byte = lanes per slot
+#define V_FOLDED 0x200u     // ... and folded to ONE accumulator per proof for the slots and one for the membership groups (k_v_acc_tree; calls of a few proofs)
 struct VGroupFlags {        // per group of a chunk: 1 = passed the batched check, V_RECHECK | tsplit otherwise (kernel argument of k_v_final)
     uint32_t v[MSM_G_MAX];
 };
@@ -224,7 +225,9 @@ struct VWork {
     uint32_t hardened;           // as in Workspace
     const uint32_t* ring_digest;
     int32_t* st;          // [C] structural status (deserialisation)
-    int32_t* exp_st;      // [C] exceptions of verifyExp
+    int32_t* exp_st;      // [C] exceptions of verifyExp (k_v_exp_status; k_v_final folds exp_jm in)
+    uint32_t* exp_jm;     // [C] first sampled slot whose response type differs from the recomputed challenge bit, VK: none (k_v_sample_check)
+    uint32_t* exp_jz;     // [C] the sampled slot exp_st's identity was found at, VK: none
     uint32_t* okflags;    // [C] bit 3: GKProof length mismatch (verifyMembership returns false)
     uint32_t* zcnt;       // [C]
     uint32_t* hbits;      // [C][4] challenge bits of the header (layout)
@@ -251,7 +254,7 @@ struct VWork {
     Soa pa_x, pa_y, pa_sc;                     // P-256 A terms [C*VK]
     uint32_t* pa_tab;                          // [C*VK][8][28] multiples 1..8 of every A term (k_v_p256_straus)
     uint8_t* pa_dig;                           // [33][C*VK] signed 4-bit digits of the randomisers
-    Soa3 pacc;                                 // [max(5 C, 21 min(C, V_SIDE_MAXP))] partial sums of k_v_p256_straus (5 lanes per proof, or 21 in a small chunk)
+    Soa3 pacc;                                 // [max(5 C, 22 min(C, V_SIDE_MAXP))] partial sums of k_v_p256_straus (5 lanes per proof, or 21 in a small chunk + the table walks' sum)
     Soa clx, cly;                              // Clambda (Montgomery affine)
     uint32_t* cl_tab;                          // [C][8][28] multiples 1..8 of Clambda
     uint8_t* cl_dig;                           // [35][C] signed 4-bit digits of SL
@@ -269,7 +272,7 @@ void launch_v_challenges(hipStream_t s, const VWork& V, uint32_t count, const ui
 void launch_v_exp_challenge_small(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_v_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* vseeds, uint64_t first);
 void launch_v_sample_check(hipStream_t s, const VWork& V, uint32_t count);
-void launch_v_exp_status(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count);
+void launch_v_exp_status(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, bool have_jm);
 void launch_exph_hash(hipStream_t s, const Workspace& W, uint32_t count, uint32_t* chal);   // k_hash.hip: schedule per block, rounds per proof -> chal[4 p ..]
 void launch_v_exp_points(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first, uint32_t split = 1);   // split: 1, or 4 lanes per checked repetition (small chunks)
 void launch_v_t1_scalars(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
@@ -288,7 +291,11 @@ size_t gkm_etab_frag_bytes(uint64_t N);
 size_t gkm_asub_frag_bytes(uint32_t C);
 void launch_gkm_etab_digits(hipStream_t s, const uint32_t* E, uint32_t nblocks, int8_t* edig);
 void launch_gk_block_mfma(hipStream_t s, const Workspace& W, const ChunkIn& in, uint32_t nblocks, const Soa& res);
-void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first);
+void launch_v_slot_points(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
+void launch_v_slot_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first);
+void launch_v_proof_points(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first, uint32_t which);
+void launch_v_proof_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first);
+void launch_v_proof_sums(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count);
 void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out,
                      const uint32_t* perm, const uint32_t* cnt, uint32_t tsplit = 1, uint32_t ostride = 1, uint32_t ny = 1, uint32_t ystride = 0);
 void launch_v_acc_tree(hipStream_t s, const Soa4& src, uint32_t nouter, uint32_t width, const Soa4& dst, uint32_t dstride, uint32_t fill);
@@ -309,6 +316,8 @@ void launch_rtab_base_co(hipStream_t s, const Workspace& W, uint32_t count, uint
 void launch_v_slot_perm(hipStream_t s, const uint8_t* slot_class, uint32_t nslots, uint32_t* perm, uint32_t* cnt);
 void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count, uint32_t per);   // per = A terms per lane: 5, or 1 for small batches
 void launch_v_p256_total(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t per);
+void launch_v_p256_total_fixed(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count);
+void launch_v_p256_total_sum(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count);
 void launch_v_final(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first, const VGroupFlags& gf, uint32_t gsz);
 
 // chunk inputs (device pointers, already offset to the chunk's first proof)

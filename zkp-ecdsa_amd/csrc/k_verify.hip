@@ -609,12 +609,14 @@ __global__ void __launch_bounds__(64) k_v_sample(VWork V, uint32_t count, const 
         uint32_t i = PERM(j);
         V.idx[p * VK + j] = i | (((hb[i >> 5] >> (i & 31)) & 1) << 8);
     }
+    V.exp_jz[p] = VK;   // k_v_exp_points lowers it to the first sampled slot whose point is the identity
 }
 #undef PERM
 // verifyExp walks the sampled repetitions in order and throws at the FIRST one that fails (exp.ts:265-346): 'params not found' where the response's type (the
 // header bit) does not match the recomputed challenge bit (exp.ts:269-271,301-303), 'T is at infinity' / 'T1 is at infinity' (exp.ts:274,312) where the point is
-// the identity.  jm = first slot whose type mismatches (VK: none); the slots behind it are never looked at by the reference, and k_v_exp_status picks the
-// earliest exception among the slots before it and the mismatch itself.  Needs V.chal (the recomputed challenge) and V.idx.
+// the identity.  jm = first slot whose type mismatches (VK: none); the slots behind it are never looked at by the reference: k_v_exp_status (a large chunk: this
+// kernel has run by then) or k_v_final (a small chunk: the hash runs beside the points) picks the earlier of the mismatch and the first identity.  Needs V.chal
+// (the recomputed challenge) and V.idx.
 __global__ void __launch_bounds__(64) k_v_sample_check(VWork V, uint32_t count) {
     const uint32_t p = gtid();
     if (p >= count) return;
@@ -625,9 +627,10 @@ __global__ void __launch_bounds__(64) k_v_sample_check(VWork V, uint32_t count) 
         const uint32_t bit = (c[i >> 5] >> (i & 31)) & 1;
         if (bit != hbit && jm == VK) jm = j;
     }
-    V.exp_st[p] = jm < VK ? ZK_E_PARAMS_NOT_FOUND : ZK_OK;
-    V.okflags[p] = (V.okflags[p] & 0xffff00ffu) | (jm << 8);
+    V.exp_jm[p] = jm;
 }
+// verifyExp's exception from the first identity (slot jz, status est; VK / ZK_OK: none) and the first type mismatch (slot jm): a slot's type is looked at before its point
+ZK_DEV int32_t v_exp_exception(int32_t est, uint32_t jz, uint32_t jm) { return jm < VK && (est == ZK_OK || jm <= jz) ? ZK_E_PARAMS_NOT_FOUND : est; }
 
 // ------------------------------------------------------------------ Exp: T = alpha*R or T1 = z*R + Q per checked rep (exp.ts:267,299,311)
 // split = 1: one lane per checked repetition walks all 65 windows of R's table.  split = 4 (small chunks): four neighbouring lanes take 17 windows each and
@@ -641,7 +644,7 @@ __global__ void __launch_bounds__(256) k_v_exp_points(Workspace W, VWork V, uint
     const uint8_t* pr = proofs + off[first + p];
     P256Pt acc = p256_identity();
     // every sampled slot, parsed by its header bit: where the recomputed challenge disagrees (k_v_sample_check, possibly still running) the slots from the first
-    // mismatch on are ignored by k_v_exp_status, as the reference never reaches them
+    // mismatch on are ignored by v_exp_exception, as the reference never reaches them
     bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8);
     if (good) {
         const uint8_t* rep = pr + rep_offset(V.hbits + 4 * p, i);
@@ -666,6 +669,7 @@ __global__ void __launch_bounds__(256) k_v_exp_points(Workspace W, VWork V, uint
             q.x = soa_ld<ModQ, 8>(W.Q.x, p), q.y = soa_ld<ModQ, 8>(W.Q.y, p), q.z = soa_ld<ModQ, 8>(W.Q.z, p);
             acc = p256_add(acc, q);
         }
+        if (fe_is_zero(fe_reduce(acc.z))) atomicMin(V.exp_jz + p, t % VK);   // 'T is at infinity' / 'T1 is at infinity' (exp.ts:274,312): the first such slot counts
     } else {
         acc.x = fe_const<ModQ, 8>(P256_GX_M), acc.y = fe_const<ModQ, 8>(P256_GY_M), acc.z = fe_one_mont<ModQ>().as<8>();
     }
@@ -674,17 +678,15 @@ __global__ void __launch_bounds__(256) k_v_exp_points(Workspace W, VWork V, uint
 }
 // the exception verifyExp throws, if any: the first sampled slot, in order, with T = identity (bit 1, exp.ts:274), T1 = identity
 // (bit 0, exp.ts:312) or a response of the wrong type.  Runs between k_v_exp_points and the normaliser (which maps Z = 0 to (0, 0)).
-__global__ void __launch_bounds__(64) k_v_exp_status(Workspace W, VWork V, uint32_t count) {
+// have_jm: k_v_sample_check has run (large chunks), exp_st is final; otherwise exp_st holds the first identity only and k_v_final folds the mismatch in.
+__global__ void __launch_bounds__(64) k_v_exp_status(Workspace W, VWork V, uint32_t count, bool have_jm) {
     uint32_t p = gtid();
     if (p >= count) return;
+    if (p == 0) V.t1_cnt[0] = 0;   // k_v_t1_scalars' list, next on the stream
     if (V.st[p] != ZK_OK || (V.okflags[p] & 8)) return;
-    const uint32_t jm = (V.okflags[p] >> 8) & 0xffu;
-    int32_t st = jm < VK ? ZK_E_PARAMS_NOT_FOUND : ZK_OK;
-    for (int j = (int)(jm < VK ? jm : VK) - 1; j >= 0; j--) {
-        const uint32_t e = p * VK + j;
-        if (fe_is_zero(fe_reduce(soa_ld<ModQ, 8>(W.Tproj.z, e)))) st = (V.idx[e] >> 8) ? ZK_E_T_INF : ZK_E_T1_INF;
-    }
-    V.exp_st[p] = st;
+    const uint32_t jz = V.exp_jz[p];   // k_v_exp_points: the first sampled slot whose point is the identity
+    const int32_t st = jz >= VK ? ZK_OK : (V.idx[p * VK + jz] >> 8) ? ZK_E_T_INF : ZK_E_T1_INF;
+    V.exp_st[p] = have_jm ? v_exp_exception(st, jz, V.exp_jm[p]) : st;
 }
 // T1x = sx*g + r1*h, T1y = sy*g + r2*h for zero-bit slots (exp.ts:329-330); (0, 0) otherwise
 __global__ void __launch_bounds__(256) k_v_t1_scalars(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
@@ -1220,9 +1222,9 @@ __global__ void __launch_bounds__(256) k_v_slot_perm(const uint8_t* __restrict__
     if (slot_class[sl]) perm[atomicAdd(&cnt[0], 1u)] = sl;
     else perm[nslots - 1 - atomicAdd(&cnt[1], 1u)] = sl;
 }
+// (cnt: zeroed by k_v_proof_sums -- a memset node between two kernels of a stream costs a call of one proof 30-50 us of idle GPU)
 void launch_v_slot_perm(hipStream_t s, const uint8_t* slot_class, uint32_t nslots, uint32_t* perm, uint32_t* cnt) {
     if (!nslots) return;
-    hipMemsetAsync(cnt, 0, 8, s);
     hipLaunchKernelGGL(k_v_slot_perm, dim3((nslots + 255) / 256), dim3(256), 0, s, slot_class, nslots, perm, cnt);
 }
 // GK relations (gk.ts:223-259) -> groups of the gk list (4 per pair of bit positions: cl, cd 256-bit; ca, cb 128-bit) and the
@@ -1230,10 +1232,12 @@ void launch_v_slot_perm(hipStream_t s, const uint8_t* slot_class, uint32_t nslot
 // gk group q (q < ceil(n/2)) holds i = 2q, 2q+1: 256-bit terms {cl_i, cd_i} x2 = 0..3, 128-bit {ca_i, cb_i} x2 = 4..7.
 // misc group (index = p): 256-bit terms: 0 = Px (membership coefficient), 1 = Px (Exp), 2 = Py (Exp).
 //
-// Points: one thread per (term, group), term-major.
-__global__ void __launch_bounds__(256) k_v_proof_points(VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+// Points: one thread per (term, group), term-major.  which: bit 0 = the membership proof's points (the gk groups and misc term 0: nothing of verifyExp in them),
+// bit 1 = misc terms 1, 2 (Px, Py of the Exp relations: they follow exp_st) -- a small chunk converts the former beside the P-256 front end.
+__global__ void __launch_bounds__(256) k_v_proof_points(VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first, uint32_t which) {
     uint32_t t = gtid(), n = V.n, nq = (n + 1) / 2, ngk = V.C * nq, nm = V.C, ngl = count * nq;
     if (t >= ngl * 8 + count * 3) return;
+    if (!((which >> (t < ngl * 8 + count ? 0 : 1)) & 1)) return;
     const uint8_t* src = nullptr;
     bool neg = false;
     uint32_t idx;
@@ -1255,11 +1259,12 @@ __global__ void __launch_bounds__(256) k_v_proof_points(VWork V, uint32_t count,
     term_point(src, neg, x, y, dt);
     vt_st_at(t < ngl * 8 ? V.gk_terms.pts : V.misc_terms.pts, idx, x, y, dt);
 }
-// Scalars: one thread per proof.
-__global__ void __launch_bounds__(64, 2) k_v_proof_terms(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
+// Scalars of the Exp relations' shared points: one thread per proof sums its slots' parts (k_v_slot_terms).
+__global__ void __launch_bounds__(64, 2) k_v_proof_sums(Workspace W, VWork V, uint32_t count) {
     uint32_t p = gtid();
     if (p >= count) return;
-    uint32_t n = V.n, nq = (n + 1) / 2, ngk = V.C * nq, nm = V.C;
+    for (uint32_t i = p; i < 2 * (MSM_G_MAX + 1); i += count) V.slot_cnt[i] = 0;   // k_v_slot_perm's counters of stage 2, per range
+    uint32_t n = V.n, nm = V.C;
     bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8);
     Sq zero = fe_zero<ModQ>();
     {
@@ -1279,6 +1284,14 @@ __global__ void __launch_bounds__(64, 2) k_v_proof_terms(Workspace W, VWork V, u
         soa_st(V.misc_terms.sc, 1 * nm + p, e ? ekx : zero);
         soa_st(V.misc_terms.sc, 2 * nm + p, e ? eky : zero);
     }
+}
+// Scalars of the membership proof's terms: one thread per proof.  Needs the membership challenge and total (k_v_challenges, k_v_gk_*), nothing of verifyExp.
+__global__ void __launch_bounds__(64, 2) k_v_proof_terms(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
+    uint32_t p = gtid();
+    if (p >= count) return;
+    uint32_t n = V.n, nq = (n + 1) / 2, ngk = V.C * nq, nm = V.C;
+    bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8);
+    Sq zero = fe_zero<ModQ>();
     Sq mg = zero, mh = zero;    // membership g, h coefficients
     if (good) {
         const uint8_t* pr = proofs + off[first + p];
@@ -1456,20 +1469,22 @@ void launch_v_straus(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t 
     hipLaunchKernelGGL(k_v_straus, dim3((ngroups * tsplit + 255) / 256, ny), dim3(256), 0, s, L, ngroups, ng_stride, n256, n128, out, perm, cnt, tsplit, ostride, ystride);
 }
 // Sum of `width` consecutive accumulators per outer index, one wave each: src[o * width + q] -> dst[o * dstride], followed by `fill` identities
-// (the consumer adds a fixed number of accumulators per proof).  Lane q adds entries q, q + 64, ... and the 64 partial sums fold in six steps in LDS.
-__global__ void __launch_bounds__(64) k_v_acc_tree(Soa4 src, uint32_t width, Soa4 dst, uint32_t dstride, uint32_t fill) {
-    __shared__ uint32_t sh[36][64];
+// (the consumer adds a fixed number of accumulators per proof).  Lane q adds entries q, q + NT, ... and the NT partial sums fold in log2 NT steps in LDS
+// (NT = 256 for the 720 term accumulators of a proof's slots: 2 + 8 additions in a row).
+template <uint32_t NT>
+__global__ void __launch_bounds__(NT) k_v_acc_tree(Soa4 src, uint32_t width, Soa4 dst, uint32_t dstride, uint32_t fill) {
+    __shared__ uint32_t sh[36][NT];
     const uint32_t o = blockIdx.x, q = threadIdx.x;
     TomPt acc = tom_identity();
 #pragma unroll 1
-    for (uint32_t k = q; k < width; k += 64) {
+    for (uint32_t k = q; k < width; k += NT) {
         const uint32_t e = o * width + k;
         TomPt a;
         a.x = soa_ld<ModT, 2>(src.x, e), a.y = soa_ld<ModT, 2>(src.y, e), a.z = soa_ld<ModT, 2>(src.z, e), a.t = soa_ld<ModT, 2>(src.t, e);
         acc = k == q ? a : tom_add(acc, a);
     }
 #pragma unroll 1
-    for (uint32_t half = 32; half >= 1; half >>= 1) {
+    for (uint32_t half = NT / 2; half >= 1; half >>= 1) {
         if (q >= half && q < 2 * half) {
 #pragma unroll
             for (int l = 0; l < 9; l++) sh[l][q] = acc.x.l[l], sh[9 + l][q] = acc.y.l[l], sh[18 + l][q] = acc.z.l[l], sh[27 + l][q] = acc.t.l[l];
@@ -1490,7 +1505,9 @@ __global__ void __launch_bounds__(64) k_v_acc_tree(Soa4 src, uint32_t width, Soa
     }
 }
 void launch_v_acc_tree(hipStream_t s, const Soa4& src, uint32_t nouter, uint32_t width, const Soa4& dst, uint32_t dstride, uint32_t fill) {
-    if (nouter) hipLaunchKernelGGL(k_v_acc_tree, dim3(nouter), dim3(64), 0, s, src, width, dst, dstride, fill);
+    if (!nouter) return;
+    if (width > 128) hipLaunchKernelGGL(k_v_acc_tree<256>, dim3(nouter), dim3(256), 0, s, src, width, dst, dstride, fill);
+    else hipLaunchKernelGGL(k_v_acc_tree<64>, dim3(nouter), dim3(64), 0, s, src, width, dst, dstride, fill);
 }
 // P-256: sum of rho_j * (-A_j) over the 20 checked repetitions, 5 terms per thread, 128-bit randomisers.  Signed 4-bit
 // windows like the Tom side: every thread first recodes its scalars (33 digits in [-7, 8]) and builds {1A..8A} for its
@@ -1597,6 +1614,9 @@ __global__ void __launch_bounds__(64, 2) k_v_p256_total(DevParams P, Workspace W
 // The same for a handful of proofs, EIGHT lanes each: four take a quarter of the 65 windows of R's table, four a quarter of h_NIST's comb, each adds its share
 // of the `parts` partial sums of k_v_p256_straus, and the eight points meet through the wave's cross-lane moves: 17 + 3 + 3 additions in a row instead of
 // 65 + 13 + 21.
+// MODE 1 / 2: the two halves of it as kernels of their own for a small chunk (api_verify.hip stage2a) -- the table walks (1: SR * R + SH * h_NIST, kept at
+// pacc[count * parts + p]) need nothing from k_v_p256_straus and run beside it, 2 adds the partial sums and gives the verdict: 263 + 50 us in a row instead of 263 + 194.
+template <int MODE>
 __global__ void __launch_bounds__(256) k_v_p256_total_wide(DevParams P, Workspace W, VWork V, uint32_t count, uint32_t parts) {
     const uint32_t tt = gtid();
     const bool live = tt < count * 8;
@@ -1605,25 +1625,35 @@ __global__ void __launch_bounds__(256) k_v_p256_total_wide(DevParams P, Workspac
     P256Pt acc = p256_identity();
     if (good) {
         uint32_t kw[8];
-        if (sub < 4) {
-            words_from_limbs<8>(kw, soa_ld<ModN, 1>(V.pSR, p).l);
-            const uint32_t per = (rtab_nwin(RTAB_VERIFY_BITS) + 3) / 4;
-            acc = p256_rtab_mul_range(W.rtab + (size_t)p * rtab_words(RTAB_VERIFY_BITS), kw, RTAB_VERIFY_BITS, sub * per, per);
-        } else {
-            words_from_limbs<8>(kw, soa_ld<ModN, 1>(V.pSH, p).l);
-            constexpr uint32_t gper = (PFIX_NWIN + 3) / 4;
-            acc = p256_fixed_mul_range(acc, P.pfix_H, kw, (sub - 4) * gper, gper);
+        if (MODE != 2) {
+            if (sub < 4) {
+                words_from_limbs<8>(kw, soa_ld<ModN, 1>(V.pSR, p).l);
+                const uint32_t per = (rtab_nwin(RTAB_VERIFY_BITS) + 3) / 4;
+                acc = p256_rtab_mul_range(W.rtab + (size_t)p * rtab_words(RTAB_VERIFY_BITS), kw, RTAB_VERIFY_BITS, sub * per, per);
+            } else {
+                words_from_limbs<8>(kw, soa_ld<ModN, 1>(V.pSH, p).l);
+                constexpr uint32_t gper = (PFIX_NWIN + 3) / 4;
+                acc = p256_fixed_mul_range(acc, P.pfix_H, kw, (sub - 4) * gper, gper);
+            }
         }
+        if (MODE != 1) {
 #pragma unroll 1
-        for (uint32_t q = sub; q < parts; q += 8) {
-            P256Pt a;
-            a.x = soa_ld<ModQ, 8>(V.pacc.x, p * parts + q), a.y = soa_ld<ModQ, 8>(V.pacc.y, p * parts + q), a.z = soa_ld<ModQ, 8>(V.pacc.z, p * parts + q);
-            acc = p256_add(acc, a);
+            for (uint32_t q = sub; q < parts + (MODE == 2 ? 1 : 0); q += 8) {
+                const uint32_t e = q < parts ? p * parts + q : count * parts + p;   // (MODE 2: the table walks' sum after the straus lanes')
+                P256Pt a;
+                a.x = soa_ld<ModQ, 8>(V.pacc.x, e), a.y = soa_ld<ModQ, 8>(V.pacc.y, e), a.z = soa_ld<ModQ, 8>(V.pacc.z, e);
+                acc = p256_add(acc, a);
+            }
         }
     }
     acc = p256_quad_sum(acc);
     acc = p256_add(acc, p256_shfl_xor(acc, 4));
     if (!live || sub) return;
+    if (MODE == 1) {
+        const uint32_t e = count * parts + p;
+        soa_st(V.pacc.x, e, acc.x), soa_st(V.pacc.y, e, acc.y), soa_st(V.pacc.z, e, acc.z);
+        return;
+    }
     V.p256_ok[p] = good && fe_is_zero(fe_reduce(acc.x)) && fe_is_zero(fe_reduce(acc.z)) && !fe_is_zero(fe_reduce(acc.y)) ? 1u : 0u;  // weier.ts:117-119
 }
 
@@ -1647,8 +1677,8 @@ ZK_DEV bool tom_is_identity(const TomPt& a) {  // edwards.ts:117-125 on the a=1 
 __global__ void __launch_bounds__(64, 2) k_v_final(Workspace W, VWork V, uint32_t count, uint8_t* ok_out, int32_t* status_out, uint64_t first, VGroupFlags gf, uint32_t gsz) {
     uint32_t p = gtid();
     if (p >= count) return;
-    const uint32_t flag = gf.v[p / gsz];          // 1: the group passed the batched check; else V_RECHECK | tsplit of its slot sums
-    const bool tom_all_ok = flag == 1;
+    const uint32_t flag = gf.v[p / gsz];          // 1: the group passed the batched check; else V_RECHECK | tsplit of its slot sums (| V_FOLDED: one sum per proof)
+    const bool tom_all_ok = flag == 1, folded = flag & V_FOLDED;
     const uint32_t tsplit = flag & 0xff;
     int32_t st = V.st[p];  // structural errors; W.st additionally carries a late "T is at infinity"
     uint8_t ok = 0;
@@ -1658,20 +1688,20 @@ __global__ void __launch_bounds__(64, 2) k_v_final(Workspace W, VWork V, uint32_
         bool memb = true;
         if (!tom_all_ok) {
             TomPt m = ld_tom_proj3(W.lc.proj, p * 4 * n);
-            for (uint32_t q = 0; q < nq; q++) m = tom_add(m, ld_tom4(V.gk_acc, p * nq + q));
+            for (uint32_t q = 0; q < (folded ? 1 : nq); q++) m = tom_add(m, ld_tom4(V.gk_acc, p * nq + q));
             m = tom_add(m, ld_tom4(V.misc_acc, 0 * V.C + p));
             memb = tom_is_identity(m);
         }
         if (memb) {
             // exceptions of verifyExp only surface when membership passed (zkpAttestList.ts:165-183)
-            int32_t est = V.exp_st[p];
+            int32_t est = v_exp_exception(V.exp_st[p], V.exp_jz[p], V.exp_jm[p]);
             if (est == ZK_OK && W.st[p] != ZK_OK) est = W.st[p];
             if (est != ZK_OK) st = est;
             else {
                 bool okW = true;
                 if (!tom_all_ok) {
                     TomPt e = ld_tom_proj3(W.lc.proj, p * 4 * n + 1);
-                    for (uint32_t j = 0; j < VK; j++)
+                    for (uint32_t j = 0; j < (folded ? 1 : VK); j++)
                         for (uint32_t q = 0; q < tsplit; q++) e = tom_add(e, ld_tom4(V.slot_acc, (p * VK + j) * V_SLOT_SPLIT + q));
                     e = tom_add(e, ld_tom4(V.misc_acc, 1 * V.C + p));
                     e = tom_add(e, ld_tom4(V.misc_acc, 2 * V.C + p));
@@ -1733,12 +1763,11 @@ void launch_v_sample_check(hipStream_t s, const VWork& V, uint32_t count) {   //
 void launch_v_exp_points(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first, uint32_t split) {
     L1(k_v_exp_points, count * VK * split, 256, W, V, count, proofs, off, first, split);
 }
-void launch_v_exp_status(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count) {   // needs k_v_sample_check's verdict and the points
-    L1(k_v_exp_status, count, 64, W, V, count);
+void launch_v_exp_status(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, bool have_jm) {   // needs the points, and k_v_sample_check's verdict if have_jm
+    L1(k_v_exp_status, count, 64, W, V, count, have_jm);
 }
 void launch_v_t1_scalars(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
-    hipMemsetAsync(V.t1_cnt, 0, 4, s);
-    L1(k_v_t1_scalars, count * VK, 256, W, V, count, proofs, off, first);
+    L1(k_v_t1_scalars, count * VK, 256, W, V, count, proofs, off, first);   // (t1_cnt: zeroed by k_v_exp_status)
 }
 void launch_v_derived(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
     L1(k_v_derived, count * VK * 5, 256, W, V, count, proofs, off, first);
@@ -1746,11 +1775,22 @@ void launch_v_derived(hipStream_t s, const Workspace& W, const VWork& V, uint32_
 void launch_v_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
     L1(k_v_padd_hash, count * VK * 6, 256, P, W, V, count, proofs, off, first);
 }
-void launch_v_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
+// The term lists of a chunk in four pieces (a large chunk runs them in this order on one stream, `which` = 3 in one launch; a small chunk runs the membership
+// piece beside the P-256 front end and the slots' points beside the commitments T1 -- api_verify.hip stage1).
+void launch_v_slot_points(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {   // needs idx, exp_st
     L1(k_v_slot_points, count * VK * V_SLOT_TERMS, 256, V, count, proofs, off, first);
-    L1(k_v_slot_terms, count * VK, 64, W, V, count, proofs, off, vseeds, first);
-    L1(k_v_proof_points, count * ((V.n + 1) / 2 * 8 + 3), 256, V, count, proofs, off, first);
-    L1(k_v_proof_terms, count, 64, W, V, count, proofs, off, vseeds, first);
+}
+void launch_v_slot_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
+    L1(k_v_slot_terms, count * VK, 64, W, V, count, proofs, off, vseeds, first);   // needs T, the derived commitments' challenges (k_v_padd_hash)
+}
+void launch_v_proof_points(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first, uint32_t which) {
+    L1(k_v_proof_points, count * ((V.n + 1) / 2 * 8 + 3), 256, V, count, proofs, off, first, which);
+}
+void launch_v_proof_terms(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, const uint8_t* vseeds, uint64_t first) {
+    L1(k_v_proof_terms, count, 64, W, V, count, proofs, off, vseeds, first);   // needs the membership total
+}
+void launch_v_proof_sums(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count) {   // needs k_v_slot_terms
+    L1(k_v_proof_sums, count, 64, W, V, count);
 }
 void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count, uint32_t per) {
     L1(k_v_p256_tables, count * (VK + 1), 256, V, count);
@@ -1758,8 +1798,15 @@ void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count, uint32_
     else L1(k_v_p256_straus, count * (VK / per + 1), 256, V, count, per);
 }
 void launch_v_p256_total(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, uint32_t per) {
-    if (count * 8 <= ZK_WIDE_MAX_UNITS) L1(k_v_p256_total_wide, count * 8, 256, P, W, V, count, VK / per + 1);   // a handful of proofs: eight lanes each
+    if (count * 8 <= ZK_WIDE_MAX_UNITS) L1(k_v_p256_total_wide<0>, count * 8, 256, P, W, V, count, VK / per + 1);   // a handful of proofs: eight lanes each
     else L1(k_v_p256_total, count, 64, P, W, V, count, VK / per + 1);
+}
+// a small chunk (<= V_SIDE_MAXP proofs, one term per lane in k_v_p256_straus): the table walks, and the sum of everything
+void launch_v_p256_total_fixed(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count) {
+    L1(k_v_p256_total_wide<1>, count * 8, 256, P, W, V, count, VK + 1);
+}
+void launch_v_p256_total_sum(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count) {
+    L1(k_v_p256_total_wide<2>, count * 8, 256, P, W, V, count, VK + 1);
 }
 void launch_v_final(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, uint8_t* ok, int32_t* status, uint64_t first, const VGroupFlags& gf, uint32_t gsz) {
     L1(k_v_final, count, 64, W, V, count, ok, status, first, gf, gsz);
