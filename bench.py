@@ -113,6 +113,7 @@ def main():
         return run_verify_mode(args, torch, Z, world, rank, local_rank, dev)
     B, nkeys, sec = args.batch, args.ring, args.sec
     eng = Z.Engine(local_rank)
+    eng.set_timing(1)   # the per-family tables below come from HIP events around every kernel family; the latency table switches them off (the product's default for small calls)
     nh, tg, th = eng.synth_params(args.seed)
     eng.set_comb_bits(args.comb_bits)
     t_tab = time.time()

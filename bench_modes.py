@@ -238,6 +238,7 @@ def latency_table(Z, eng, args, nh, tg, th, sec, ring, nkeys, msg, sig, pk, whic
         rings.append((small_ring, r2, m2, s2, p2, w2, sd2))
     lanes0 = args.lanes
     eng.set_lanes(1)
+    eng.set_timing(2)   # the default: no per-family events in a call of <= 8 192 proofs (0.15-0.45 ms of a small call)
     for nk, rg, m, s_, p, w, sd in rings:
         if nk != nkeys:
             eng.set_ring(rg, nk)
@@ -263,6 +264,7 @@ def latency_table(Z, eng, args, nh, tg, th, sec, ring, nkeys, msg, sig, pk, whic
     if len(rings) > 1:
         eng.set_ring(ring, nkeys)
     eng.set_lanes(lanes0)
+    eng.set_timing(1)
     pin.free()
     return out
 
@@ -416,6 +418,7 @@ def run_verify_mode(args, torch, Z, world, rank, local_rank, dev):
     slab = min(args.slab, shard)
     nslabs = (shard + slab - 1) // slab
     eng = Z.Engine(local_rank)
+    eng.set_timing(1)
     nh, tg, th = eng.synth_params(args.seed)
     eng.set_comb_bits(args.comb_bits)
     eng.set_params(nh, tg, th, sec)

@@ -376,7 +376,14 @@ zk_status zk_proofs_from_json_batch(uint64_t n, const char *texts, const uint64_
 /* Timing of the last prove/verify call from HIP events around every kernel family: per family the accumulated GPU milliseconds (names[i] are static
  * strings; a name that starts with '+' is a part of another family), and *total_ms = their SUM ('+' parts excluded).  With one lane and a large chunk the
  * families run one after the other and the sum is the GPU time of the call; with several lanes, and in small calls that fork work onto side streams, the
- * families overlap and the sum exceeds the time that passed -- zk_last_wall_ms gives that: earliest start to latest end over the same events. */
+ * families overlap and the sum exceeds the time that passed -- zk_last_wall_ms gives that: earliest start to latest end over the same events.
+ * The events sit between the kernels of a stream and cost a call of a few proofs 0.15-0.45 ms (two per family and chunk): by default (ZK_TIMING_AUTO) only
+ * blocking calls of more than 8 192 proofs record them, and after a smaller call zk_last_timing reports no families (returns 0, *total_ms = 0);
+ * zk_ctx_set_timing(ctx, ZK_TIMING_ON) records them in every blocking call, ZK_TIMING_OFF in none.  Streamed jobs (zk_prove_submit ...) never record them. */
+#define ZK_TIMING_OFF 0
+#define ZK_TIMING_ON 1
+#define ZK_TIMING_AUTO 2
+zk_status zk_ctx_set_timing(zk_ctx *ctx, int mode);
 uint32_t zk_last_timing(const zk_ctx *ctx, float *total_ms, const char **names, float *ms, uint32_t cap);
 float zk_last_wall_ms(const zk_ctx *ctx);
 

@@ -11,6 +11,7 @@ def _setup(S, nkeys, B, sec=80):
     import coracle as CO
     import zkp_ecdsa_amd as Z
     eng = Z.Engine(0)
+    eng.set_timing(1)   # the tests below read which kernel families ran off zk_last_timing
     nh, tg, th = eng.synth_params(S)
     eng.set_params(nh, tg, th, sec)
     ring, msg, sig, pk, which, seeds = eng.synth_workload(S, nkeys, B)
@@ -195,6 +196,7 @@ def test_key_grouping_of_the_batched_check_is_exact(monkeypatch):
     import zkp_ecdsa_amd as Z
     B, nkeys = 3000, 4096
     eng = Z.Engine(0)
+    eng.set_timing(1)   # the tests below read which kernel families ran off zk_last_timing
     eng.set_params(*eng.synth_params(78), 80)
     ring, msg, sig, pk, which, seeds = eng.synth_workload(78, nkeys, B)
     eng.set_ring(ring, nkeys)
@@ -216,6 +218,7 @@ def test_one_forged_proof_only_sends_its_group_to_the_per_proof_sums():
     import zkp_ecdsa_amd as Z
     B, nkeys = 8192, 8192
     eng = Z.Engine(0)
+    eng.set_timing(1)   # the tests below read which kernel families ran off zk_last_timing
     params = eng.synth_params(77)
     eng.set_params(*params, 80)
     ring, msg, sig, pk, which, seeds = eng.synth_workload(77, nkeys, B)
@@ -314,6 +317,7 @@ def test_ring_fold_on_the_matrix_pipe_equals_the_vector_form(nkeys, B):
     honest proofs, forged membership responses and a proof made for another ring position; batch sizes that leave ragged tiles."""
     import zkp_ecdsa_amd as Z
     eng = Z.Engine(0)
+    eng.set_timing(1)   # the tests below read which kernel families ran off zk_last_timing
     eng.set_comb_bits(16)
     params = eng.synth_params(1212)
     eng.set_params(*params, 80)
@@ -345,6 +349,7 @@ def test_sixty_four_groups_give_the_same_verdicts_and_a_finer_fallback():
     import zkp_ecdsa_amd as Z
     B, nkeys = 8192, 8192
     eng = Z.Engine(0)
+    eng.set_timing(1)   # the tests below read which kernel families ran off zk_last_timing
     eng.set_comb_bits(16)
     params = eng.synth_params(64)
     eng.set_params(*params, 80)
@@ -436,6 +441,7 @@ def test_p256_cross_proof_pass_at_its_default_size():
     import zkp_ecdsa_amd as Z
     B, nkeys = 16384, 16384
     eng = Z.Engine(0)
+    eng.set_timing(1)   # the tests below read which kernel families ran off zk_last_timing
     eng.set_comb_bits(16)
     eng.set_params(*eng.synth_params(91), 80)
     ring, msg, sig, pk, which, seeds = eng.synth_workload(91, nkeys, B)

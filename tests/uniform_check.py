@@ -12,6 +12,7 @@ import zkp_ecdsa_amd as Z
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1200
 eng = Z.Engine(0)
+eng.set_timing(1)
 eng.set_comb_bits(16)
 eng.set_params(*eng.synth_params(99), 80)
 ring, msg, sig, pk, which, seeds = eng.synth_workload(99, 2048, B)

@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import zkp_ecdsa_amd as Z
 
 eng = Z.Engine(0)
+eng.set_timing(1)
 eng.set_comb_bits(16)
 eng.set_params(*eng.synth_params(2024), 80)
 ring, msg, sig, pk, which, seeds = eng.synth_workload(2024, 1024, 64)

@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 # every symbol include/zkattest.h declares
 SYMBOLS = [
     'zk_ctx_create', 'zk_ctx_destroy', 'zk_strerror', 'zk_last_error', 'zk_ctx_set_params', 'zk_ctx_set_ring',
-    'zk_ctx_set_ring_device', 'zk_ctx_wipe', 'zk_last_wall_ms', 'zk_keys_to_ints', 'zk_ctx_set_chunk', 'zk_ctx_set_lanes', 'zk_ctx_set_comb_bits', 'zk_ctx_set_batch_verify', 'zk_proof_max_size', 'zk_prove_batch', 'zk_prove_batch_device',
+    'zk_ctx_set_ring_device', 'zk_ctx_wipe', 'zk_last_wall_ms', 'zk_ctx_set_timing', 'zk_keys_to_ints', 'zk_ctx_set_chunk', 'zk_ctx_set_lanes', 'zk_ctx_set_comb_bits', 'zk_ctx_set_batch_verify', 'zk_proof_max_size', 'zk_prove_batch', 'zk_prove_batch_device',
     'zk_verify_batch', 'zk_verify_batch_device', 'zk_synth_workload', 'zk_synth_params', 'zk_last_timing',
     'zk_proof_to_json', 'zk_proof_from_json', 'zk_host_alloc', 'zk_host_free', 'zk_ctx_set_host_taper', 'zk_ctx_set_slice', 'zk_ctx_set_mode', 'zk_ring_digest', 'zk_hardened_h',
     'zk_pool_create', 'zk_pool_destroy', 'zk_pool_size', 'zk_pool_ctx', 'zk_pool_last_error', 'zk_pool_ring_transport', 'zk_pool_rccl_library', 'zk_pool_shard',
@@ -532,6 +532,12 @@ class Engine:
         ms = (C.c_float * 32)()
         n = self.L.zk_last_timing(self.h, C.byref(total), names, ms, 32)
         return total.value, {names[i].decode(): ms[i] for i in range(min(n, 32))}
+
+    def set_timing(self, mode):
+        """zk_ctx_set_timing: 0 never, 1 per-family events in every blocking call, 2 (default) only in calls of more than 8 192 proofs"""
+        self.L.zk_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
+        self.L.zk_ctx_set_timing.restype = C.c_int
+        self._chk(self.L.zk_ctx_set_timing(self.h, int(mode)))
 
     def last_wall_ms(self):
         """earliest start -> latest end of the last call's timed kernel families (last_timing()[0] is their sum, which overlapping families exceed)"""

@@ -120,7 +120,10 @@ static bool os_random(uint8_t* out, size_t n) {
     fclose(f);
     return got == n;
 }
-__global__ void k_default_vseeds(uint64_t B, const uint8_t* master, uint8_t* out) {
+struct VMaster {
+    uint32_t w[8];
+};
+__global__ void k_default_vseeds(uint64_t B, VMaster master, uint8_t* out) {
     // verifier seeds when the caller supplies none: SHA-256("zkv\x01" || be64(b) || master), master = 32 bytes of OS
     // randomness drawn for this call (the reference's verifier draws from crypto.getRandomValues: the checked subset and the
     // multipliers must not be predictable from public data)
@@ -128,8 +131,7 @@ __global__ void k_default_vseeds(uint64_t B, const uint8_t* master, uint8_t* out
     if (b >= B) return;
     uint32_t m[16], h[8];
     m[0] = 0x7a6b7600u | 0x01, m[1] = (uint32_t)(b >> 32), m[2] = (uint32_t)b;
-    const uint32_t* q = (const uint32_t*)master;
-    for (int i = 0; i < 8; i++) m[3 + i] = bswap32(q[i]);
+    for (int i = 0; i < 8; i++) m[3 + i] = bswap32(master.w[i]);
     m[11] = 0x80000000u, m[12] = 0, m[13] = 0, m[14] = 0, m[15] = 44 * 8;
     sha256_iv(h);
     sha256_compress(h, m);
@@ -287,7 +289,6 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
         // identity directly; a small chunk keeps the plain launch (its commitments run four lanes wide)
         if (cnt * 2 * VK > ZK_WIDE_MAX_UNITS) launch_tom_commit_list(s, P, W.la, V.t1_act, V.t1_cnt, cnt * 2 * VK);
         else launch_tom_commit(s, P, W.la, cnt * 2 * VK, 2 * VK, 2 + 2 * W.sec);
-        launch_tom_normalize(s, W.la, cnt * 2 * VK, 0, 2 * VK, 2 + 2 * W.sec);
         launch_v_derived(s, W, V, cnt, d_proofs, d_off, first);
         launch_tom_normalize(s, V.vd, cnt * VK * 5, 0, 1, 1);
     }
@@ -348,8 +349,11 @@ static zk_status per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t 
     if (np <= V_WIDE_MAXP) {
         auto& A = c->vl[lane];
         MaybeScope t(timed, c, "v_straus_tom", s);
-        HIPCHK(c, hipEventRecord(A.aux_fork, s));
-        for (int i = 0; i < 3; i++) HIPCHK(c, hipStreamWaitEvent(A.aux[i], A.aux_fork, 0));
+        if (!A.stage2_forked) {   // (a small chunk's streams left the main one in stage2a, which covers its FIRST range: a later range's sums reuse wide_acc,
+            HIPCHK(c, hipEventRecord(A.aux_fork, s));   // so its streams start behind the range before it)
+            for (int i = 0; i < 3; i++) HIPCHK(c, hipStreamWaitEvent(A.aux[i], A.aux_fork, 0));
+        }
+        A.stage2_forked = false;
         // host order: the longest chain first (the slots' 720 terms per proof on the main stream), the short ones last -- a launch costs about 5 us of host time
         const size_t so = (size_t)p0 * VK;
         uint32_t* perm = V.slot_perm + so;
@@ -429,13 +433,14 @@ zk_status VerifyJob::stage2a(uint64_t chunk_no) {
     const bool wide_chunk = side_streams(cnt);
     if (wide_chunk && timed) c->timing_forked = true;
     auto& A = c->vl[lane];
-    A.msm_pending = A.pm_pending = false;   // (a failed call may have left them set)
+    A.msm_pending = A.pm_pending = A.stage2_forked = false;   // (a failed call may have left them set)
     if (wide_chunk) {   // the P-256 sums of a small chunk, one term per lane, beside everything below: streams 2 and 3 start from here ...
         HIPCHK(c, hipEventRecord(A.aux_fork, s));
-        HIPCHK(c, hipStreamWaitEvent(A.aux[3], A.aux_fork, 0));
-        HIPCHK(c, hipStreamWaitEvent(A.aux[2], A.aux_fork, 0));
+        for (int i = 0; i < 4; i++) HIPCHK(c, hipStreamWaitEvent(A.aux[i], A.aux_fork, 0));
+        A.stage2_forked = true;   // one fork per chunk: an event between two kernels of the main stream costs a call of one proof 10-20 us each
         // ... and a call of a few proofs launches them BEHIND the Tom-256 sums' kernels (stage2b): those chains are the longer ones, and a launch costs 5 us of host time
-        if (cnt > V_WIDE_MAXP)
+        A.p256_launched = cnt > V_WIDE_MAXP || (c->verify_batch_min && cnt >= c->verify_batch_min && M.cap);   // (... unless the host is going to wait for the bucket pass first)
+        if (A.p256_launched)
             if (zk_status zr = small_chunk_p256(c, timed, lane, cnt)) return zr;
     }
     // P-256 relation: one bucket-method sum per group as well (k_pmsm.hip), on an auxiliary stream beside the Tom-256 pass; its verdicts arrive with that
@@ -466,8 +471,10 @@ zk_status VerifyJob::stage2a(uint64_t chunk_no) {
         A.msm_pending = true;
     }
     A.pm_pending = pm, A.msm_gsz = gsz;
-    if (!A.msm_done) HIPCHK(c, hipEventCreateWithFlags(&A.msm_done, hipEventDisableTiming));
-    HIPCHK(c, hipEventRecord(A.msm_done, s));
+    if (A.msm_pending) {   // the host waits for this one and reads the groups' verdicts
+        if (!A.msm_done) HIPCHK(c, hipEventCreateWithFlags(&A.msm_done, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(A.msm_done, s));
+    }
     return ZK_OK;
 }
 zk_status VerifyJob::stage2b(uint64_t chunk_no) {
@@ -515,9 +522,10 @@ zk_status VerifyJob::stage2b(uint64_t chunk_no) {
         for (uint32_t k = g; k < g1; k++) gf.v[k] = V_RECHECK | tsplit;
         g = g1;
     }
-    if (wide_chunk && cnt <= V_WIDE_MAXP)
+    if (wide_chunk && !A.p256_launched)
         if (zk_status zr = small_chunk_p256(c, timed, lane, cnt)) return zr;
     if (wide_chunk) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[3], 0));
+    A.stage2_forked = false;
     if (pm) {
         HIPCHK(c, hipEventSynchronize(A.aux_done[3]));
         HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[3], 0));
@@ -564,20 +572,22 @@ zk_status VerifyJob::stage2b(uint64_t chunk_no) {
 }
 
 // verifier seeds when the caller supplies none: derived on the device from 32 bytes of OS randomness drawn for this call
-zk_status make_default_vseeds(zk_ctx* c, uint64_t B, uint8_t* d_seeds /* 32 * B + 32 bytes */, hipStream_t s) {
-    uint8_t master[32];
-    if (!os_random(master, sizeof master)) {
+// Enqueued on s, not waited for: the master travels as a kernel argument (no copy), and whoever reads the seeds orders itself behind s.
+zk_status make_default_vseeds(zk_ctx* c, uint64_t B, uint8_t* d_seeds /* 32 * B bytes */, hipStream_t s) {
+    VMaster master;
+    if (!os_random((uint8_t*)master.w, sizeof master.w)) {
         c->err = "no OS randomness for the verifier (getrandom / /dev/urandom failed)";
         return ZK_E_DEVICE;
     }
-    HIPCHK(c, hipMemcpyAsync(d_seeds + 32 * B, master, 32, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_default_vseeds, dim3((uint32_t)((B + 255) / 256)), dim3(256), 0, s, B, d_seeds + 32 * B, d_seeds);
-    HIPCHK(c, hipStreamSynchronize(s));
+    hipLaunchKernelGGL(k_default_vseeds, dim3((uint32_t)((B + 255) / 256)), dim3(256), 0, s, B, master, d_seeds);
+    volatile uint32_t* w = master.w;
+    for (int i = 0; i < 8; i++) w[i] = 0;
+    HIPCHK(c, hipGetLastError());
     return ZK_OK;
 }
 
 static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, const uint8_t* d_proofs, const uint64_t* d_off, const uint8_t* d_vseeds, uint8_t* d_ok,
-                               int32_t* d_status, const uint8_t* host_src = nullptr, const uint64_t* host_off = nullptr) {
+                               int32_t* d_status, const uint8_t* host_src = nullptr, const uint64_t* host_off = nullptr, bool inputs_on_stream = false) {
     if (!c->params_set || !c->N) return ZK_E_BUFFER;
     if (c->P.sec < VK) return ZK_E_SECLEVEL;
     if (B == 0) return ZK_OK;
@@ -587,6 +597,7 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
     }
     VerifyJob J;
     J.c = c, J.B = B, J.d_msg = d_msg, J.d_proofs = d_proofs, J.d_off = d_off, J.d_ok = d_ok, J.d_status = d_status, J.host_src = host_src, J.host_off = host_off;
+    J.timed = zk_timed(c, B);
     J.C = (uint32_t)std::min<uint64_t>(c->chunk, B);
     J.plan = make_chunk_plan(B, J.C, 1, false);   // uniform: see ctx.h
     J.NL = (uint32_t)std::min<size_t>(c->lanes, J.plan.size());   // chunks rotate over NL streams / workspaces
@@ -616,14 +627,25 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
     zs = ensure_vworkspace(c, J.C, J.NL);
     if (zs) return zs;
     timing_begin(c);
-    DevBuf own_seeds_buf;   // released on every exit path
-    if (!d_vseeds) {
-        HIPCHK(c, hipMalloc(&own_seeds_buf.p, 32 * B + 32));
-        zs = make_default_vseeds(c, B, own_seeds_buf.as<uint8_t>(), c->stream);
+    if (!d_vseeds) {   // the verifier's own seeds: the context's grow-only buffer, derived on c->stream (no allocation, copy or host wait per call)
+        if (c->seed_bytes < 32 * B) {
+            if (c->seed_buf) HIPCHK(c, hipFree(c->seed_buf));
+            c->seed_buf = nullptr, c->seed_bytes = 0;
+            HIPCHK(c, hipMalloc(&c->seed_buf, 32 * B + 32 * B / 4 + 4096));
+            c->seed_bytes = 32 * B + 32 * B / 4 + 4096;
+        }
+        zs = make_default_vseeds(c, B, (uint8_t*)c->seed_buf, c->stream);
         if (zs) return zs;
-        d_vseeds = own_seeds_buf.as<uint8_t>();
+        d_vseeds = (const uint8_t*)c->seed_buf;
+        inputs_on_stream = true;
     }
     J.d_vseeds = d_vseeds;
+    if (inputs_on_stream) {   // the lanes order themselves behind what c->stream carries for this call (input copies, the seeds' kernel)
+        zs = ensure_h_stage(c, 0);
+        if (zs) return zs;
+        HIPCHK(c, hipEventRecord(c->in_ready, c->stream));
+        J.inputs_ready = c->in_ready;
+    }
     auto drain = [&] {   // nothing of this call may still be running when it returns
         for (uint32_t l = 0; l < J.NL; l++) {
             hipStreamSynchronize(c->pl[l].stream);
@@ -706,13 +728,37 @@ extern "C" zk_status zk_verify_batch(zk_ctx* c, uint64_t B, const uint8_t* msg, 
     } else {
         HIPCHK(c, hipMemcpy(d_proofs, proofs, total, hipMemcpyHostToDevice));
     }
-    HIPCHK(c, hipMemcpyAsync(d_msg, msg, 32 * B, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_off, off, 8 * (B + 1), hipMemcpyHostToDevice, c->stream));
-    if (vseeds) HIPCHK(c, hipMemcpyAsync(d_seeds, vseeds, 32 * B, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // both lanes read these arrays
-    zs = verify_device(c, B, d_msg, d_proofs, d_off, vseeds ? d_seeds : nullptr, d_ok, d_st, pinned ? proofs : nullptr, pinned ? off : nullptr);
-    if (zs) return zs;
-    HIPCHK(c, hipMemcpy(ok, d_ok, B, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(status, d_st, 4 * B, hipMemcpyDeviceToHost));
+    // A call of a few proofs: messages, offsets and seeds cross in ONE copy out of the context's page-locked mirror of in_buf, and the lanes wait for its event
+    // instead of the host (api.hip: zk_prove_batch does the same); verdicts and statuses come back in one.
+    const size_t in_end = (size_t)(d_ok - (uint8_t*)c->in_buf), res_end = (size_t)((uint8_t*)(d_st + B) - (uint8_t*)c->in_buf);
+    const bool staged = k1.off <= ZK_STAGE_MAX;
+    if (staged) {
+        if ((zs = ensure_h_stage(c, k1.off))) return zs;
+        auto at = [&](const void* d) { return c->h_stage + ((const uint8_t*)d - (const uint8_t*)c->in_buf); };
+        memcpy(at(d_msg), msg, 32 * B), memcpy(at(d_off), off, 8 * (B + 1));
+        HIPCHK(c, hipMemcpyAsync(c->in_buf, c->h_stage, in_end, hipMemcpyHostToDevice, c->stream));
+        if (vseeds) {
+            memcpy(at(d_seeds), vseeds, 32 * B);
+            HIPCHK(c, hipMemcpyAsync(d_seeds, at(d_seeds), 32 * B, hipMemcpyHostToDevice, c->stream));
+        }
+    } else {
+        HIPCHK(c, hipMemcpyAsync(d_msg, msg, 32 * B, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_off, off, 8 * (B + 1), hipMemcpyHostToDevice, c->stream));
+        if (vseeds) HIPCHK(c, hipMemcpyAsync(d_seeds, vseeds, 32 * B, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // both lanes read these arrays
+    }
+    zs = verify_device(c, B, d_msg, d_proofs, d_off, vseeds ? d_seeds : nullptr, d_ok, d_st, pinned ? proofs : nullptr, pinned ? off : nullptr, staged);
+    if (zs) {
+        if (staged) (void)hipStreamSynchronize(c->stream);   // the mirror is reused by the next call
+        return zs;
+    }
+    if (staged) {   // verdicts and statuses lie next to each other in in_buf
+        HIPCHK(c, hipMemcpy(c->h_stage + in_end, d_ok, res_end - in_end, hipMemcpyDeviceToHost));
+        memcpy(ok, c->h_stage + in_end, B);
+        memcpy(status, c->h_stage + ((uint8_t*)d_st - (uint8_t*)c->in_buf), 4 * B);
+    } else {
+        HIPCHK(c, hipMemcpy(ok, d_ok, B, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(status, d_st, 4 * B, hipMemcpyDeviceToHost));
+    }
     return ZK_OK;
 }

@@ -80,6 +80,8 @@ struct zk_ctx {
         PMsmBuf PM{};             // cross-proof P-256 pass (k_pmsm.hip); PM.aos == nullptr: not carved (chunks below p256_batch_min)
         hipStream_t aux[V_AUX_STREAMS] = {};   // small batches: the independent per-proof sums run side by side (api_verify.hip: per_proof_range)
         hipEvent_t aux_fork = nullptr, aux_done[V_AUX_STREAMS] = {};
+        bool p256_launched = false;   // stage2a launched the small chunk's P-256 sums (else stage2b does, behind the Tom-256 sums' kernels)
+        bool stage2_forked = false;   // the auxiliary streams already wait for this chunk's stage 1 (stage2a of a small chunk)
         bool ready = false;
     } vl[ZK_MAX_LANES];
     uint32_t vs_C = 0, vs_sec = 0, vs_n = 0;
@@ -93,6 +95,11 @@ struct zk_ctx {
     hipStream_t copy_stream = nullptr;
     void* io_buf = nullptr;        // device staging of the proof bytes for the host-pointer entry points (grow-only: a
     size_t io_bytes = 0;           // multi-GB hipMalloc/hipFree per call costs as much as the transfer itself)
+    uint8_t* h_stage = nullptr;    // page-locked mirror of in_buf's head for calls of a few proofs: the input arrays cross in ONE copy that no host thread waits for, and
+    size_t h_stage_bytes = 0;      // the offsets / statuses / verdicts come back in one (api.hip: ensure_h_stage; wiped with the witness)
+    hipEvent_t in_ready = nullptr; // ... the lanes wait for this event instead (the job's inputs_ready)
+    void* seed_buf = nullptr;      // the verifier's own seeds when the caller gives none (32 B + 32 bytes, grow-only)
+    size_t seed_bytes = 0;
     void* in_buf = nullptr;        // device copies of the small per-proof arrays of the host-pointer entry points (inputs,
     size_t in_bytes = 0;           // offsets, statuses, verdicts), grow-only for the same reason
     uint32_t wire = 0;             // zk_ctx_set_wire: 0 = ZKA1 (36-byte Tom coordinates), 1 = ZKA1P (33-byte): what the prover emits and the verifier is handed
@@ -122,6 +129,7 @@ struct zk_ctx {
     size_t eused = 0;
     std::vector<std::pair<const char*, float>> last_timing;
     float last_total_ms = 0, last_wall_ms = 0;   // sum of the timed scopes ('+' parts excluded); first start -> last end of the same call
+    int timing_mode = ZK_TIMING_AUTO;   // zk_ctx_set_timing
     bool timing_forked = false;   // this call put timed scopes on forked streams (small one-chunk calls): its scopes overlap, the total is first start -> last end
 };
 
@@ -157,6 +165,9 @@ struct Scope {
         c->trecs.push_back(r);
     }
 };
+// Per-family events of a blocking call of B proofs?  Two events per family and chunk cost a call of a few proofs 0.15-0.45 ms of idle GPU between kernels
+// (profiles/r06_ab_variants.txt (14)); a call of more than V_SIDE_MAXP proofs does not notice them.
+static inline bool zk_timed(const zk_ctx* c, uint64_t B) { return c->timing_mode == ZK_TIMING_ON || (c->timing_mode == ZK_TIMING_AUTO && B > V_SIDE_MAXP); }
 static inline void timing_begin(zk_ctx* c) { c->trecs.clear(), c->eused = 0, c->timing_forked = false; }
 static inline void timing_end(zk_ctx* c) {
     c->last_timing.clear();
@@ -194,6 +205,8 @@ struct DevBuf {
 zk_status ensure_workspace(zk_ctx* c, uint32_t C, uint32_t nlanes = 1);   // api.hip: prover workspaces of lanes 0..nlanes-1
 hipError_t malloc_or_shed(zk_ctx* c, void** p, size_t bytes);   // api.hip: a workspace allocation that sheds the optional per-ring tables first
 zk_status ensure_in_buf(zk_ctx* c, size_t bytes);  // api.hip: c->in_buf of at least `bytes`
+#define ZK_STAGE_MAX (1u << 20)   // input arrays up to this size take the page-locked mirror
+zk_status ensure_h_stage(zk_ctx* c, size_t bytes);  // api.hip: c->h_stage of at least `bytes`, c->in_ready
 
 // One pipeline pass = one chunk of consecutive proofs.  Device-pointer calls use uniform chunks of C proofs.  Host-pointer
 // calls on page-locked buffers move ~169 KB per proof across PCIe on a copy stream under the kernels of the neighbouring

@@ -312,6 +312,7 @@ static inline bool zk_one_lane_chains() {
 void launch_v_straus_co(hipStream_t s, const VTerms& L, uint32_t ngroups, uint32_t ng_stride, uint32_t n256, uint32_t n128, const Soa4& out, const uint32_t* perm,
                         const uint32_t* cnt, uint32_t tsplit, uint32_t ostride, uint32_t ny, uint32_t ystride);
 void launch_v_p256_straus_co(hipStream_t s, const VWork& V, uint32_t count);
+void launch_v_exp_points_co(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);
 void launch_rtab_base_co(hipStream_t s, const Workspace& W, uint32_t count, uint32_t bits, const uint8_t* skip);
 void launch_v_slot_perm(hipStream_t s, const uint8_t* slot_class, uint32_t nslots, uint32_t* perm, uint32_t* cnt);
 void launch_v_p256_straus(hipStream_t s, const VWork& V, uint32_t count, uint32_t per);   // per = A terms per lane: 5, or 1 for small batches

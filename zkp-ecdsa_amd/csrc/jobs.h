@@ -22,7 +22,7 @@ struct ProveJob {
     uint32_t C = 0;            // chunk size of the plan
     uint32_t NL = 1;           // lanes the chunks rotate over
     uint64_t lane_base = 0;    // global number of this job's chunk 0: chunk k runs on lane (lane_base + k) % NL
-    bool timed = true;         // per-family HIP events (off for streamed jobs: the events of overlapping jobs would interleave)
+    bool timed = false;        // per-family HIP events (zk_timed: zk_ctx_set_timing; never for streamed jobs: the events of overlapping jobs would interleave)
     bool more_follows = false; // streamed: another job is queued behind this one (its work hides this job's last copies)
     hipEvent_t inputs_ready = nullptr;   // streamed: the H2D of this job's input arrays; stage 1 waits for it
     std::vector<ChunkPlan> plan;
@@ -91,7 +91,7 @@ struct VerifyJob {
     const uint64_t* host_off = nullptr;  // the bytes of chunk k travel on c->copy_stream while earlier chunks are being verified
     uint32_t C = 0, NL = 1;
     uint64_t lane_base = 0;
-    bool timed = true;
+    bool timed = false;
     hipEvent_t inputs_ready = nullptr;
     std::vector<ChunkPlan> plan;
     std::vector<hipEvent_t> arrived;     // host_src: one event per chunk, recorded on the copy stream behind the chunk's bytes

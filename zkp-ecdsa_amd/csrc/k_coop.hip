@@ -86,6 +86,78 @@ void launch_v_p256_straus_co(hipStream_t s, const VWork& V, uint32_t count) {
     if (count) hipLaunchKernelGGL(k_v_p256_straus_co, dim3(count * (VK + 1)), dim3(64), 0, s, V, count);
 }
 
+// T = alpha R / T1 = z R + Q of a sampled repetition (exp.ts:267,299,311; k_verify.hip: k_v_exp_points) for a call of a few proofs: one workgroup per slot, its four
+// waves walk a quarter of the 65 windows of R's table each -- the table holds every 2^(4w) R, so there are no doublings: 17 additions in a row at 1.2 us instead
+// of one lane's 5.4 -- and meet in LDS (three more, then Q).  The first slot whose point is the identity lowers V.exp_jz[p] (k_v_exp_status).
+__global__ void __launch_bounds__(256) k_v_exp_points_co(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    __shared__ uint32_t part[3][64];
+    const uint32_t t = blockIdx.x, p = t / VK, q = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t iv = V.idx[t], i = iv & 255, bit = iv >> 8;
+    const bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8);
+    const CoU32 mj = co_limbs(ModQ::mod);
+    const CoU32 s8 = co_sub_const<ModQ, 8>();
+    CoP256 acc = co_p256_identity();
+    if (good) {   // uniform for the workgroup
+        const uint8_t* rep = proofs + off[first + p] + rep_offset(V.hbits + 4 * p, i);
+        uint32_t kw[8];
+        {
+            uint32_t w[8];
+            load_be32(rep + 208, w);
+            words_from_limbs<8>(kw, fe_from_words256_reduce<ModN>(w).l);   // the scalar as verifyExp reads it (k_verify.hip: ld_scalar_n)
+        }
+        const uint32_t* tab = W.rtab + (size_t)p * rtab_words(RTAB_VERIFY_BITS);
+        constexpr uint32_t bits = RTAB_VERIFY_BITS, nwin = (257 + bits - 1) / bits, ent = (1u << (bits - 1)) + 1, half = 1u << (bits - 1), mask = (1u << bits) - 1, per = (nwin + 3) / 4;   // engine.h: rtab_nwin, rtab_entries
+        uint32_t carry = 0;
+#pragma unroll 1
+        for (uint32_t w = 0; w < q * per; w++) {   // signed recoding of the windows below this wave's (rtab.h: p256_rtab_mul_range)
+            const uint32_t d = (kw[0] & mask) + carry;
+            shr256_var(kw, bits);
+            carry = d > half ? 1 : 0;
+        }
+#pragma unroll 1
+        for (uint32_t w = q * per; w < (q + 1) * per && w < nwin; w++) {
+            uint32_t d = (kw[0] & mask) + carry;
+            shr256_var(kw, bits);
+            const bool neg = d > half;
+            carry = neg ? 1 : 0;
+            if (neg) d = (1u << bits) - d;
+            if (!d) continue;   // entry 0 is the identity
+            CoP256 e;
+            e.v = co_load_aos<ModQ, 8, 3>(tab + (size_t)RTAB_ENTRY_WORDS * (w * ent + d));
+            if (neg && co_row_index() == 1) e.v.v = co_carry(s8 - e.v.v);   // -Y = 8 q - Y <= 8 q (rtab.h: fq8_neg)
+            acc = co_p256_add(acc, e, mj);
+        }
+    }
+    if (q) part[q - 1][lane] = acc.v.v;
+    __syncthreads();
+    if (q) return;
+#pragma unroll 1
+    for (uint32_t k = 0; k < 3; k++) {
+        CoP256 o;
+        o.v.v = part[k][lane];
+        acc = co_p256_add(acc, o, mj);
+    }
+    if (good) {
+        if (!bit) {
+            CoP256 qq;
+            qq.v = co_load_soa<ModQ, 8>(p, W.Q.x, W.Q.y, W.Q.z, Soa{nullptr, 0});
+            acc = co_p256_add(acc, qq, mj);
+        }
+        // 'T is at infinity' / 'T1 is at infinity' (exp.ts:274,312): Z = 0 or q (a product's value is below 2 q); the first such slot counts
+        const uint32_t z = co_normalize(acc.v).v;
+        const uint32_t is0 = (uint32_t)(__ballot(z == 0u) >> 32) & 0xffffu, isq = (uint32_t)(__ballot(z == mj) >> 32) & 0xffffu;
+        if (lane == 0 && (is0 == 0xffffu || isq == 0xffffu)) atomicMin(V.exp_jz + p, t % VK);
+    } else {   // keep later kernels on defined data: G
+        const uint32_t row = co_row_index();
+        acc.v.v = row == 0 ? co_limbs(P256_GX_M) : row == 1 ? co_limbs(P256_GY_M) : row == 2 ? co_limbs(ModQ::one) : 0u;
+    }
+    co_store_soa(acc.v, t, W.Tproj.x, W.Tproj.y, W.Tproj.z, Soa{nullptr, 0});
+}
+void launch_v_exp_points_co(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    g_coop_chains.fetch_add((uint64_t)count * VK * 4, std::memory_order_relaxed);
+    if (count) hipLaunchKernelGGL(k_v_exp_points_co, dim3(count * VK), dim3(256), 0, s, W, V, count, proofs, off, first);
+}
+
 // one wave per proof: W.rbase entry p * nwin + w <- 2^(bits w) R in Jacobian coordinates (k_rtab_fill takes them to the homogeneous form)
 __global__ void __launch_bounds__(64) k_rtab_base_co(Workspace W, uint32_t count, uint32_t bits, const uint8_t* __restrict__ skip) {
     const uint32_t p = blockIdx.x;

@@ -737,6 +737,12 @@ ZK_DEV TomPt v_tom_from_bytes(const uint8_t* p72) {
     ld_tom_bytes(p72, x, y);
     return v_tom_from_plain(x, y);
 }
+ZK_DEV TomPt ld_tom_proj3(const Soa3& a, uint32_t e) {  // (X:Y:Z) without T -> (XZ : YZ : XY : Z^2)
+    Ft2 x = soa_ld<ModT, 2>(a.x, e), y = soa_ld<ModT, 2>(a.y, e), z = soa_ld<ModT, 2>(a.z, e);
+    TomPt r;
+    r.x = x * z, r.y = y * z, r.t = x * y, r.z = z * z;
+    return r;
+}
 __global__ void __launch_bounds__(256) k_v_derived(Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
     uint32_t t = gtid();
     if (t >= count * VK * 5) return;
@@ -751,7 +757,7 @@ __global__ void __launch_bounds__(256) k_v_derived(Workspace W, VWork V, uint32_
         // C7 = Px - T1x | C9 = Py - T1y | C12 = T1x - Tx | CintX = Tx + T1x + Px | CintY = C4 + C6 = T1y + Ty: one T1 coordinate
         // commitment and one point of the proof, either of them negated, selected by k so that there is one code path
         uint32_t lai = la + (k == 1 || k == 4 ? 1 : 0);
-        TomPt a = v_tom_from_plain(soa_ld<ModT, 1>(W.la.ax, lai), soa_ld<ModT, 1>(W.la.ay, lai));
+        TomPt a = ld_tom_proj3(W.la.proj, lai);   // T1x / T1y as k_tom_commit left them: only their sums are hashed, so list A is never normalised
         TomPt b = v_tom_from_bytes(k == 0 ? pr + 160 : k == 1 ? pr + 232 : k == 4 ? rep + 136 : rep + 64);
         if (k < 2) a = tom_neg(a);
         if (k == 2) b = tom_neg(b);
@@ -1663,12 +1669,6 @@ ZK_DEV TomPt ld_tom4(const Soa4& a, uint32_t e) {
     r.x = soa_ld<ModT, 2>(a.x, e), r.y = soa_ld<ModT, 2>(a.y, e), r.z = soa_ld<ModT, 2>(a.z, e), r.t = soa_ld<ModT, 2>(a.t, e);
     return r;
 }
-ZK_DEV TomPt ld_tom_proj3(const Soa3& a, uint32_t e) {  // (X:Y:Z) without T -> (XZ : YZ : XY : Z^2)
-    Ft2 x = soa_ld<ModT, 2>(a.x, e), y = soa_ld<ModT, 2>(a.y, e), z = soa_ld<ModT, 2>(a.z, e);
-    TomPt r;
-    r.x = x * z, r.y = y * z, r.t = x * y, r.z = z * z;
-    return r;
-}
 ZK_DEV bool tom_is_identity(const TomPt& a) {  // edwards.ts:117-125 on the a=1 image
     return fe_is_zero(a.x) && fe_eq(a.y, a.z) && !fe_is_zero(a.z);
 }
@@ -1761,7 +1761,8 @@ void launch_v_sample_check(hipStream_t s, const VWork& V, uint32_t count) {   //
     L1(k_v_sample_check, count, 64, V, count);
 }
 void launch_v_exp_points(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first, uint32_t split) {
-    L1(k_v_exp_points, count * VK * split, 256, W, V, count, proofs, off, first, split);
+    if (split == 4 && (uint64_t)count * VK * 4 <= ZK_COOP_MAX_CHAINS && !zk_one_lane_chains()) launch_v_exp_points_co(s, W, V, count, proofs, off, first);   // k_coop.hip
+    else L1(k_v_exp_points, count * VK * split, 256, W, V, count, proofs, off, first, split);
 }
 void launch_v_exp_status(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, bool have_jm) {   // needs the points, and k_v_sample_check's verdict if have_jm
     L1(k_v_exp_status, count, 64, W, V, count, have_jm);
