@@ -38,6 +38,29 @@ ZK_DEV CoFe<M, K> co_load_soa(uint32_t e, Soa a0, Soa a1, Soa a2, Soa a3) {
     r.v = (j < NLIMB && p) ? p[(size_t)j * stride + e] : 0u;
     return r;
 }
+// Affine table entries as points (X, Y, 1) in rows 0..2.  P-256 fixed-base comb (engine.h: PFIX_ENTRY_WORDS = 20: nine Montgomery limbs of x, nine of y):
+ZK_DEV CoFe<ModQ, 8> co_load_pfix(const uint32_t* __restrict__ e) {
+    const uint32_t lane = __lane_id(), row = lane >> 4, j = lane & 15u;
+    CoFe<ModQ, 8> r;
+    r.v = j >= NLIMB ? 0u : row < 2 ? e[row * NLIMB + j] : row == 2 ? co_limbs(ModQ::one) : 0u;
+    return r;
+}
+// ... and a ring key's table (ktab.h: 8 + 8 canonical 32-bit words of x, y in Montgomery form): lane j cuts limb j out of the words; neg: Y <- 4 q - Y (ld_ktab takes
+// (x, q - y): the same residue, so the same point and the same bytes later)
+ZK_DEV CoFe<ModQ, 8> co_load_ktab(const uint32_t* __restrict__ e, bool neg) {
+    const uint32_t lane = __lane_id(), row = lane >> 4, j = lane & 15u;
+    const uint32_t bit = LIMB_BITS * (j < NLIMB ? j : 0), k = bit >> 5, sh = bit & 31u;
+    uint32_t v = 0;
+    if (row < 2 && j < NLIMB) {
+        const uint32_t* w = e + 8 * row;
+        const uint32_t lo = w[k], hi = k < 7 ? w[k + 1] : 0u;
+        v = (sh ? (lo >> sh) | (hi << (32 - sh)) : lo) & ((1u << LIMB_BITS) - 1);
+    }
+    CoFe<ModQ, 8> r;
+    r.v = row == 2 && j < NLIMB ? co_limbs(ModQ::one) : v;
+    if (neg && row == 1) r.v = co_carry(co_sub_const<ModQ, 4>() - r.v);
+    return r;
+}
 ZK_DEV CoTom co_tom_identity() {   // (0 : 1 : 0 : 1), rows X, Y, T, Z
     CoTom r;
     r.v.v = (co_row_index() & 1u) ? co_limbs(ModT::one) : 0u;

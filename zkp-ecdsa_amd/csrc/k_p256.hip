@@ -8,6 +8,7 @@
 // per-proof signed-digit table of R (rtab.h), shared by the sec + 1 multiplications by R of one proof (43 complete additions each).
 // All additions are the complete RCB formulas the reference uses.
 #include "rtab.h"   // engine.h (and with it ktab.h), the projective table entries of rtab.h
+#include "coop_dev.h"   // the table sums of a call of a few proofs on cooperating waves (k_front_co, k_exp_commit_kt_co)
 
 // k * B for a fixed base with a PFIX_WIN_BITS-bit comb table; k given as 8 little-endian words (clobbered)
 ZK_DEV P256Pt p256_fixed_mul(const uint32_t* __restrict__ tab, uint32_t kw[8]) {
@@ -223,10 +224,12 @@ __global__ void __launch_bounds__(64, 2) k_front_walk(Workspace W, uint32_t coun
     soa_st(W.Rxm, p, rx), soa_st(W.Rym, p, ry);
     soa_st(W.Rx, p, fe_from_mont(rx)), soa_st(W.Ry, p, fe_from_mont(ry));
 }
+void launch_front_co(hipStream_t s, const DevParams& P, const Workspace& W, uint32_t count);
 void launch_front(hipStream_t s, const DevParams& P, const Workspace& W, const ChunkIn& in) {
     hipLaunchKernelGGL(k_front, dim3((in.count + 63) / 64), dim3(64), 0, s, P, W, in);
     const uint32_t wide = W.ktab && in.count <= ZK_WIDE_MAX_UNITS / 8 ? 1u : 0u;   // a small chunk: eight lanes per proof on the key-table path
-    if (wide) hipLaunchKernelGGL(k_front_wide, dim3((in.count * 8 + 255) / 256), dim3(256), 0, s, P, W, in.count);
+    if (wide && (uint64_t)in.count * 8 <= ZK_COOP_MAX_CHAINS && !zk_one_lane_chains()) launch_front_co(s, P, W, in.count);   // below: the same sums on cooperating waves
+    else if (wide) hipLaunchKernelGGL(k_front_wide, dim3((in.count * 8 + 255) / 256), dim3(256), 0, s, P, W, in.count);
     hipLaunchKernelGGL(k_front_table, dim3((in.count + 63) / 64), dim3(64), 0, s, P, W, in.count, wide);
     hipLaunchKernelGGL(k_front_walk, dim3((in.count + 63) / 64), dim3(64), 0, s, W, in.count, wide);
 }
@@ -347,10 +350,149 @@ __global__ void __launch_bounds__(256) k_exp_commit_kt_wide(DevParams P, Workspa
     st_proj(W.Tproj, t, T);
     st_proj(W.Aproj, t, p256_add(T, U));
 }
+// ---------------------------------------------------------------- a call of a few proofs: the table sums on cooperating waves (coop.h)
+// One sum = one workgroup of four waves: wave q adds the entries of a quarter of the comb's windows (and of the key table's) at 1.2 us an addition instead of
+// one lane's 5.4-8, the four partial sums meet in LDS.  Same group elements as the one-lane kernels, hence the same affine coordinates and the same bytes
+// (tests/test_gpu_prove.py: one-lane against cooperative chains, byte for byte).  ZK_UNIFORM_CF: a zero digit's addition is computed and discarded here too.
+ZK_DEV CoP256 co_add_if(bool cond, const CoP256& acc, const CoFe<ModQ, 8>& ent, const CoU32& mj) {
+    CoP256 e;
+    e.v = ent;
+#if ZK_UNIFORM_CF
+    const CoP256 s = co_p256_add(acc, e, mj);
+    CoP256 r;
+    r.v = co_pick((uint32_t)cond, s.v, acc.v);
+    return r;
+#else
+    return cond ? co_p256_add(acc, e, mj) : acc;
+#endif
+}
+// acc + (windows [w0, w0 + per) of k) * B through B's comb (rtab.h: p256_fixed_mul_range)
+ZK_DEV CoP256 co_fixed_mul_range(CoP256 acc, const uint32_t* __restrict__ tab, uint32_t kw[8], uint32_t w0, uint32_t per, const CoU32& mj) {
+#pragma unroll 1
+    for (uint32_t w = 0; w < w0; w++) shr256<PFIX_WIN_BITS>(kw);
+#pragma unroll 1
+    for (uint32_t w = w0; w < w0 + per && w < PFIX_NWIN; w++) {
+        const uint32_t d = kw[0] & (PFIX_WIN_SIZE - 1);
+        shr256<PFIX_WIN_BITS>(kw);
+        acc = co_add_if(d != 0, acc, co_load_pfix(tab + (size_t)PFIX_ENTRY_WORDS * (w * PFIX_WIN_SIZE + (d ? d : 1))), mj);
+    }
+    return acc;
+}
+// ... and through a ring key's table (ktab.h: p256_ktab_mul_range)
+ZK_DEV CoP256 co_ktab_mul_range(CoP256 acc, const uint32_t* __restrict__ kt, const uint32_t kw[8], bool neg, uint32_t w0, uint32_t per, const CoU32& mj) {
+    KeyDigits kd;
+    kd.init();
+#pragma unroll
+    for (int i = 0; i < 8; i++) kd.w[i] = kw[i];
+    uint32_t d;
+    bool dn;
+#pragma unroll 1
+    for (uint32_t w = 0; w < w0; w++) kd.next(d, dn);
+#pragma unroll 1
+    for (uint32_t w = w0; w < w0 + per && w < KTAB_NWIN; w++) {
+        kd.next(d, dn);
+        acc = co_add_if(d != 0, acc, co_load_ktab(kt + ((size_t)w * KTAB_ENT + (d ? d - 1 : 0)) * KTAB_ENTRY_WORDS, neg != dn), mj);
+    }
+    return acc;
+}
+// the sum of the four waves' points: waves 1..3 park theirs in LDS, wave 0 returns the total (the others return their own)
+ZK_DEV CoP256 co_wg4_sum(CoP256 acc, uint32_t (*part)[64], uint32_t q, const CoU32& mj) {
+    const uint32_t lane = threadIdx.x & 63u;
+    __syncthreads();   // (the buffer may still be read from the sum before)
+    if (q) part[q - 1][lane] = acc.v.v;
+    __syncthreads();
+    if (q) return acc;
+#pragma unroll 1
+    for (uint32_t k = 0; k < 3; k++) {
+        CoP256 o;
+        o.v.v = part[k][lane];
+        acc = co_p256_add(acc, o, mj);
+    }
+    return acc;
+}
+// k_exp_commit_kt_wide's sums: workgroup t = (proof, repetition)
+__global__ void __launch_bounds__(256) k_exp_commit_kt_co(DevParams P, Workspace W, uint32_t count) {
+    __shared__ uint32_t part[3][64];
+    const uint32_t t = blockIdx.x, per = W.sec + 1, q = threadIdx.x >> 6;
+    const uint32_t p = t / per, j = t % per;
+    const uint32_t use = W.kt_use[p];
+    if (!use) return;   // (uniform for the workgroup)
+    const CoU32 mj = co_limbs(ModQ::mod);
+    uint32_t aw[8], bw[8], gw[8], kw[8];
+    exp_scalars(W, p, j, aw, bw, true, true);
+    Fe<ModN, 1> al;
+    limbs_from_words<8>(al.l, aw);
+    words_from_limbs<8>(gw, fe_canon(al.as<2>() * soa_ld<ModN, 1>(W.u1m, p).as<2>()).l);   // plain x Montgomery = plain
+    words_from_limbs<8>(kw, fe_canon(al.as<2>() * soa_ld<ModN, 1>(W.u2m, p).as<2>()).l);
+    constexpr uint32_t gper = (PFIX_NWIN + 3) / 4, kper = (KTAB_NWIN + 3) / 4;
+    CoP256 T = co_fixed_mul_range(co_p256_identity(), P.pfix_G, gw, q * gper, gper, mj);
+    T = co_ktab_mul_range(T, W.ktab + (size_t)W.kt_key[p] * KTAB_KEY_WORDS, kw, use == 2, q * kper, kper, mj);
+    CoP256 U = co_fixed_mul_range(co_p256_identity(), P.pfix_H, bw, q * gper, gper, mj);
+    T = co_wg4_sum(T, part, q, mj);
+    U = co_wg4_sum(U, part, q, mj);
+    if (q) return;
+    co_store_soa(T.v, t, W.Tproj.x, W.Tproj.y, W.Tproj.z, Soa{nullptr, 0});
+    co_store_soa(co_p256_add(T, U, mj).v, t, W.Aproj.x, W.Aproj.y, W.Aproj.z, Soa{nullptr, 0});
+}
+// k_front_wide's sums: workgroup = proof, eight waves -- 0..3 R = u1 G + u2 pk, 4..7 Q = z1 G; lane 0 then takes R to affine form as k_front_wide does
+__global__ void __launch_bounds__(512) k_front_co(DevParams P, Workspace W, uint32_t count) {
+    __shared__ uint32_t part[2][3][64];
+    __shared__ uint32_t rsum[64];
+    const uint32_t p = blockIdx.x, q = threadIdx.x >> 6, which = q >> 2, pt = q & 3, lane = threadIdx.x & 63u;
+    const uint32_t use = W.kt_use[p];
+    if (!use) return;   // (uniform for the workgroup)
+    const CoU32 mj = co_limbs(ModQ::mod);
+    const uint32_t* sc = front_area(W, p) + 10 * RTAB_ENTRY_WORDS;
+    Fe<ModN, 1> k;
+#pragma unroll
+    for (int l = 0; l < NLIMB; l++) k.l[l] = sc[(which ? NLIMB : 0) + l];   // u1 (R's sum) or z1 (Q's)
+    uint32_t kw[8];
+    words_from_limbs<8>(kw, k.l);
+    constexpr uint32_t gper = (PFIX_NWIN + 3) / 4, kper = (KTAB_NWIN + 3) / 4;
+    CoP256 acc = co_fixed_mul_range(co_p256_identity(), P.pfix_G, kw, pt * gper, gper, mj);
+    if (!which) {
+        words_from_limbs<8>(kw, fe_from_mont(soa_ld<ModN, 1>(W.u2m, p).as<2>()).l);
+        acc = co_ktab_mul_range(acc, W.ktab + (size_t)W.kt_key[p] * KTAB_KEY_WORDS, kw, use == 2, pt * kper, kper, mj);
+    }
+    if (pt) part[which][pt - 1][lane] = acc.v.v;
+    __syncthreads();
+    if (pt) return;
+#pragma unroll 1
+    for (uint32_t i = 0; i < 3; i++) {
+        CoP256 o;
+        o.v.v = part[which][i][lane];
+        acc = co_p256_add(acc, o, mj);
+    }
+    if (which) {
+        co_store_soa(acc.v, p, W.Q.x, W.Q.y, W.Q.z, Soa{nullptr, 0});
+        return;
+    }
+    rsum[lane] = co_normalize(acc.v).v;   // wave 0 only from here on: rows X, Y, Z of R
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (lane) return;
+    Fe<ModQ, 8> X, Y, Z;
+#pragma unroll
+    for (int l = 0; l < NLIMB; l++) X.l[l] = rsum[l], Y.l[l] = rsum[16 + l], Z.l[l] = rsum[32 + l];
+    // R affine (output + base of the per-proof table), as in k_front_walk
+    Fq2 rz = fe_reduce(Z);
+    if (fe_is_zero(rz) && (W.st[p] == ZK_OK || W.st[p] == ZK_E_ARG)) W.st[p] = ZK_E_T_INF;
+    Fq2 zi = fe_inv<ModQ>(rz);
+    Fq2 rx = X * zi, ry = Y * zi;
+    soa_st(W.Rxm, p, rx), soa_st(W.Rym, p, ry);
+    soa_st(W.Rx, p, fe_from_mont(rx)), soa_st(W.Ry, p, fe_from_mont(ry));
+}
+void launch_front_co(hipStream_t s, const DevParams& P, const Workspace& W, uint32_t count) {
+    g_coop_chains.fetch_add((uint64_t)count * 8, std::memory_order_relaxed);
+    hipLaunchKernelGGL(k_front_co, dim3(count), dim3(512), 0, s, P, W, count);
+}
 void launch_exp_commit(hipStream_t s, const DevParams& P, const Workspace& W, uint32_t count) {
     uint32_t n = count * (W.sec + 1);
     if (W.ktab) {
-        if (n <= ZK_WIDE_MAX_UNITS) hipLaunchKernelGGL(k_exp_commit_kt_wide, dim3((n * 4 + 255) / 256), dim3(256), 0, s, P, W, count);
+        if ((uint64_t)n * 4 <= ZK_COOP_MAX_CHAINS && !zk_one_lane_chains()) {
+            g_coop_chains.fetch_add((uint64_t)n * 4, std::memory_order_relaxed);
+            hipLaunchKernelGGL(k_exp_commit_kt_co, dim3(n), dim3(256), 0, s, P, W, count);
+        } else if (n <= ZK_WIDE_MAX_UNITS) hipLaunchKernelGGL(k_exp_commit_kt_wide, dim3((n * 4 + 255) / 256), dim3(256), 0, s, P, W, count);
         else hipLaunchKernelGGL(k_exp_commit_kt, dim3((n + 255) / 256), dim3(256), 0, s, P, W, count);
     }
     hipLaunchKernelGGL(k_exp_commit, dim3((n + 255) / 256), dim3(256), 0, s, P, W, count);
