@@ -192,10 +192,65 @@ __global__ void __launch_bounds__(64) k_exph_rounds(Workspace W, uint32_t count,
 #pragma unroll
     for (int i = 0; i < 4; i++) chal[4 * p + i] = cw[i];
 }
+// The rounds on a PAIR of lanes per proof.  One wave issues one vector instruction every ~4.6 cycles whatever it is, so a lone chain is as long as its instruction
+// count: 14 per round in one lane.  Lane E holds (e, f, g, h), lane A holds (a, b, c, d); with per-lane rotation amounts the SAME three v_alignbit + xor3 give
+// Sigma1(e) on E and Sigma0(a) on A, and Maj(a, b, c) = Ch(~(a ^ b), b, c) lets one bitop3 + one bfi give Ch on E and Maj on A.  E adds h and W_i + K_i, the
+// lanes swap T1 for d through a DPP move, and each has its new first word: 11 instructions per round.  (E's schedule words are real, A reads a zero cell.)
+static bool getenv_exph_one_lane() { return zk_one_lane_chains(); }   // ZKATTEST_ONE_LANE_CHAINS: the A/B switch of the cooperative kernels covers this one too
+__device__ const uint4 g_exph_zero16 = {0, 0, 0, 0};
+__global__ void __launch_bounds__(64) k_exph_rounds2(Workspace W, uint32_t count, uint32_t* chal) {
+    const uint32_t t = gtid(), p0 = t >> 1;
+    const bool live = p0 < count;
+    const uint32_t p = live ? p0 : count - 1;   // (a dead pair mirrors the last proof: the DPP moves need both lanes of a pair)
+    const bool isA = t & 1;
+    const uint32_t nblk = exph_blocks(W.sec);
+    const uint32_t m = isA ? 0xffffffffu : 0u, nm = ~m;
+    const uint32_t s1 = isA ? 2 : 6, s2 = isA ? 13 : 11, s3 = isA ? 22 : 25;
+    // word group i of block b: wk[(16 b + i) * count + p] on E, the zero cell on A
+    const uint4* wk = isA ? &g_exph_zero16 : (const uint4*)W.exph_wk + p;
+    const size_t step = isA ? 0 : count;
+    uint32_t iv[8];
+    sha256_iv(iv);
+    uint32_t hc0 = isA ? iv[0] : iv[4], hc1 = isA ? iv[1] : iv[5], hc2 = isA ? iv[2] : iv[6], hc3 = isA ? iv[3] : iv[7];
+    uint4 nx[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) nx[i] = wk[(size_t)i * step];
+#pragma unroll 1
+    for (uint32_t b = 0; b < nblk; b++) {
+        uint32_t w[64];
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[4 * i] = nx[i].x, w[4 * i + 1] = nx[i].y, w[4 * i + 2] = nx[i].z, w[4 * i + 3] = nx[i].w;
+        if (b + 1 < nblk) {   // the next block's words travel while this block's rounds run
+#pragma unroll
+            for (int i = 0; i < 16; i++) nx[i] = wk[((size_t)16 * (b + 1) + i) * step];
+        }
+        uint32_t r0 = hc0, r1 = hc1, r2 = hc2, r3 = hc3;
+#pragma unroll
+        for (int i = 0; i < 64; i++) {
+            const uint32_t sg = zk_xor3(__builtin_amdgcn_alignbit(r0, r0, s1), __builtin_amdgcn_alignbit(r0, r0, s2), __builtin_amdgcn_alignbit(r0, r0, s3));
+            const uint32_t x = __builtin_amdgcn_bitop3_b32(r0, r1, m, 0xd2);   // m ? ~(r0 ^ r1) : r0 -- E: e; A: ~(a ^ b)   (truth table over a = 0xf0, b = 0xcc, c = 0xaa)
+            const uint32_t ch = zk_bfi(x, r1, r2);                     // E: Ch(e, f, g); A: Maj(a, b, c)
+            const uint32_t z = sg + ch + w[i] + (r3 & nm);             // E: T1 = h + Sigma1 + Ch + W_i + K_i; A: T2 = Sigma0 + Maj   (w = 0 on A)
+            const uint32_t y = isA ? r3 : z;                           // what the other lane needs: E's T1, A's d
+            const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0xB1, 0xf, 0xf, true);   // quad_perm [1, 0, 3, 2]: the pair's other lane
+            r3 = r2, r2 = r1, r1 = r0, r0 = z + o;                     // E: e' = d + T1; A: a' = T2 + T1
+        }
+        hc0 += r0, hc1 += r1, hc2 += r2, hc3 += r3;
+    }
+    // the challenge is cut out of digest words 0..2: lane A has them
+    if (!live || !isA) return;
+    const uint32_t h[8] = {hc0, hc1, hc2, hc3, 0, 0, 0, 0};
+    uint32_t cw[4];
+    challenge_words(h, cw);
+#pragma unroll
+    for (int i = 0; i < 4; i++) chal[4 * p + i] = cw[i];
+}
 void launch_exph_hash(hipStream_t s, const Workspace& W, uint32_t count, uint32_t* chal) {
     const uint32_t nblk = (2 * 67 + W.sec * (65 + 2 * 67) + 9 + 63) / 64;
     hipLaunchKernelGGL(k_exph_sched, dim3((count * nblk + 255) / 256), dim3(256), 0, s, W, count);
-    hipLaunchKernelGGL(k_exph_rounds, dim3((count + 63) / 64), dim3(64), 0, s, W, count, chal);
+    // up to one wave per SIMD the chain's length is the cost: two lanes per proof; beyond that the lanes are, and the one-lane form has fewer of them
+    if (count <= 32768 && !getenv_exph_one_lane()) hipLaunchKernelGGL(k_exph_rounds2, dim3((2 * count + 63) / 64), dim3(64), 0, s, W, count, chal);
+    else hipLaunchKernelGGL(k_exph_rounds, dim3((count + 63) / 64), dim3(64), 0, s, W, count, chal);
 }
 void launch_exp_challenge(hipStream_t s, const Workspace& W, uint32_t count) {
     const bool small = count <= W.exph_cap && W.exph_wk, big = !small && count <= W.exph_big_cap && W.exph_big_wk;
