@@ -225,13 +225,17 @@ __global__ void __launch_bounds__(64) k_exph_rounds2(Workspace W, uint32_t count
             for (int i = 0; i < 16; i++) nx[i] = wk[((size_t)16 * (b + 1) + i) * step];
         }
         uint32_t r0 = hc0, r1 = hc1, r2 = hc2, r3 = hc3;
+        uint32_t pre = w[0] + (r3 & nm);                               // E: h + W_0 + K_0; A: 0
 #pragma unroll
         for (int i = 0; i < 64; i++) {
             const uint32_t sg = zk_xor3(__builtin_amdgcn_alignbit(r0, r0, s1), __builtin_amdgcn_alignbit(r0, r0, s2), __builtin_amdgcn_alignbit(r0, r0, s3));
             const uint32_t x = __builtin_amdgcn_bitop3_b32(r0, r1, m, 0xd2);   // m ? ~(r0 ^ r1) : r0 -- E: e; A: ~(a ^ b)   (truth table over a = 0xf0, b = 0xcc, c = 0xaa)
             const uint32_t ch = zk_bfi(x, r1, r2);                     // E: Ch(e, f, g); A: Maj(a, b, c)
-            const uint32_t z = sg + ch + w[i] + (r3 & nm);             // E: T1 = h + Sigma1 + Ch + W_i + K_i; A: T2 = Sigma0 + Maj   (w = 0 on A)
+            const uint32_t z = sg + ch + pre;                          // E: T1 = h + Sigma1 + Ch + W_i + K_i; A: T2 = Sigma0 + Maj
             const uint32_t y = isA ? r3 : z;                           // what the other lane needs: E's T1, A's d
+            // the next round's h + W + K (the new h is this round's g) needs nothing of this round's result: its two instructions fill the two wait states a DPP
+            // read of y needs after y was written, where the compiler would otherwise put s_nops
+            if (i < 63) pre = w[i + 1] + (r2 & nm);
             const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0xB1, 0xf, 0xf, true);   // quad_perm [1, 0, 3, 2]: the pair's other lane
             r3 = r2, r2 = r1, r1 = r0, r0 = z + o;                     // E: e' = d + T1; A: a' = T2 + T1
         }
