@@ -139,8 +139,8 @@ __global__ void __launch_bounds__(256) k_exph_msg(Workspace W, uint32_t count) {
         exph_put_coord<9>(m + off + 34, w);
     }
 }
-__global__ void __launch_bounds__(256) k_exph_sched(Workspace W, uint32_t count) {
-    const uint32_t nblk = exph_blocks(W.sec), t = gtid();
+__global__ void __launch_bounds__(256) k_exph_sched(Workspace W, uint32_t count, uint32_t nblk) {
+    const uint32_t t = gtid();
     if (t >= count * nblk) return;
     const uint32_t b = t / count, p = t % count;   // consecutive lanes: consecutive proofs, the same block
     const uint4* src = (const uint4*)(W.exph_msg + ((size_t)p * nblk + b) * 64);
@@ -159,10 +159,9 @@ __global__ void __launch_bounds__(256) k_exph_sched(Workspace W, uint32_t count)
 #pragma unroll
     for (int i = 0; i < 16; i++) dst[(size_t)i * count] = make_uint4(w[4 * i] + SHA_K[4 * i], w[4 * i + 1] + SHA_K[4 * i + 1], w[4 * i + 2] + SHA_K[4 * i + 2], w[4 * i + 3] + SHA_K[4 * i + 3]);
 }
-__global__ void __launch_bounds__(64) k_exph_rounds(Workspace W, uint32_t count, uint32_t* chal) {
+__global__ void __launch_bounds__(64) k_exph_rounds(Workspace W, uint32_t count, uint32_t* chal, uint32_t nblk, uint32_t ostride) {
     const uint32_t p = gtid();
     if (p >= count) return;
-    const uint32_t nblk = exph_blocks(W.sec);
     const uint4* wk = (const uint4*)W.exph_wk + p;   // word group i of block b: wk[(16 b + i) * count]
     uint32_t h[8];
     sha256_iv(h);
@@ -189,8 +188,7 @@ __global__ void __launch_bounds__(64) k_exph_rounds(Workspace W, uint32_t count,
     }
     uint32_t cw[4];
     challenge_words(h, cw);
-#pragma unroll
-    for (int i = 0; i < 4; i++) chal[4 * p + i] = cw[i];
+    for (uint32_t i = 0; i < ostride; i++) chal[ostride * p + i] = cw[i];
 }
 // The rounds on a PAIR of lanes per proof.  One wave issues one vector instruction every ~4.6 cycles whatever it is, so a lone chain is as long as its instruction
 // count: 14 per round in one lane.  Lane E holds (e, f, g, h), lane A holds (a, b, c, d); with per-lane rotation amounts the SAME three v_alignbit + xor3 give
@@ -198,12 +196,11 @@ __global__ void __launch_bounds__(64) k_exph_rounds(Workspace W, uint32_t count,
 // lanes swap T1 for d through a DPP move, and each has its new first word: 11 instructions per round.  (E's schedule words are real, A reads a zero cell.)
 static bool getenv_exph_one_lane() { return zk_one_lane_chains(); }   // ZKATTEST_ONE_LANE_CHAINS: the A/B switch of the cooperative kernels covers this one too
 __device__ const uint4 g_exph_zero16 = {0, 0, 0, 0};
-__global__ void __launch_bounds__(64) k_exph_rounds2(Workspace W, uint32_t count, uint32_t* chal) {
+__global__ void __launch_bounds__(64) k_exph_rounds2(Workspace W, uint32_t count, uint32_t* chal, uint32_t nblk, uint32_t ostride) {
     const uint32_t t = gtid(), p0 = t >> 1;
     const bool live = p0 < count;
     const uint32_t p = live ? p0 : count - 1;   // (a dead pair mirrors the last proof: the DPP moves need both lanes of a pair)
     const bool isA = t & 1;
-    const uint32_t nblk = exph_blocks(W.sec);
     const uint32_t m = isA ? 0xffffffffu : 0u, nm = ~m;
     const uint32_t s1 = isA ? 2 : 6, s2 = isA ? 13 : 11, s3 = isA ? 22 : 25;
     // word group i of block b: wk[(16 b + i) * count + p] on E, the zero cell on A
@@ -246,15 +243,17 @@ __global__ void __launch_bounds__(64) k_exph_rounds2(Workspace W, uint32_t count
     const uint32_t h[8] = {hc0, hc1, hc2, hc3, 0, 0, 0, 0};
     uint32_t cw[4];
     challenge_words(h, cw);
-#pragma unroll
-    for (int i = 0; i < 4; i++) chal[4 * p + i] = cw[i];
+    for (uint32_t i = 0; i < ostride; i++) chal[ostride * p + i] = cw[i];
+}
+// schedule per block, rounds per message: nblk blocks of 64 bytes per message at W.exph_msg, the challenge's ostride (3 or 4) words to chal[ostride p ..]
+static void launch_sha_msgs(hipStream_t s, const Workspace& W, uint32_t count, uint32_t* chal, uint32_t nblk, uint32_t ostride) {
+    hipLaunchKernelGGL(k_exph_sched, dim3((count * nblk + 255) / 256), dim3(256), 0, s, W, count, nblk);
+    // up to one wave per SIMD the chain's length is the cost: two lanes per proof; beyond that the lanes are, and the one-lane form has fewer of them
+    if (count <= 32768 && !getenv_exph_one_lane()) hipLaunchKernelGGL(k_exph_rounds2, dim3((2 * count + 63) / 64), dim3(64), 0, s, W, count, chal, nblk, ostride);
+    else hipLaunchKernelGGL(k_exph_rounds, dim3((count + 63) / 64), dim3(64), 0, s, W, count, chal, nblk, ostride);
 }
 void launch_exph_hash(hipStream_t s, const Workspace& W, uint32_t count, uint32_t* chal) {
-    const uint32_t nblk = (2 * 67 + W.sec * (65 + 2 * 67) + 9 + 63) / 64;
-    hipLaunchKernelGGL(k_exph_sched, dim3((count * nblk + 255) / 256), dim3(256), 0, s, W, count);
-    // up to one wave per SIMD the chain's length is the cost: two lanes per proof; beyond that the lanes are, and the one-lane form has fewer of them
-    if (count <= 32768 && !getenv_exph_one_lane()) hipLaunchKernelGGL(k_exph_rounds2, dim3((2 * count + 63) / 64), dim3(64), 0, s, W, count, chal);
-    else hipLaunchKernelGGL(k_exph_rounds, dim3((count + 63) / 64), dim3(64), 0, s, W, count, chal);
+    launch_sha_msgs(s, W, count, chal, (2 * 67 + W.sec * (65 + 2 * 67) + 9 + 63) / 64, 4);
 }
 void launch_exp_challenge(hipStream_t s, const Workspace& W, uint32_t count) {
     const bool small = count <= W.exph_cap && W.exph_wk, big = !small && count <= W.exph_big_cap && W.exph_big_wk;
@@ -330,7 +329,63 @@ __global__ void __launch_bounds__(64) k_gk_hash(Workspace W, uint32_t count, con
     challenge_words(h, c);
     if (live) W.gk_x[3 * p] = c[0], W.gk_x[3 * p + 1] = c[1], W.gk_x[3 * p + 2] = c[2];
 }
+// The same digest for a call of a few proofs through the Exp challenge's three kernels (its buffers are free in stage 2): one lane per point writes the message
+// (4 n points of 67 bytes; hardened: the statement behind them), one lane per block expands the schedule, a pair of lanes per proof runs the rounds --
+// 68 blocks at 1.5 us instead of 2.5, and nobody absorbs 4 KB byte by byte in one lane.
+__global__ void __launch_bounds__(256) k_gk_msg(Workspace W, uint32_t count, const uint8_t* __restrict__ msg, uint32_t nblk) {
+    const uint32_t ne = 4 * W.n + 1, t = gtid();
+    if (t >= count * ne) return;
+    const uint32_t p = t / ne, e = t % ne;
+    uint8_t* m = W.exph_msg + (size_t)p * nblk * 64;
+    uint32_t w[9];
+    if (e < 4 * W.n) {
+        uint8_t* o = m + 67 * e;
+        o[0] = 4;
+        words_from_limbs<9>(w, soa_ld<ModT, 1>(W.lc.ax, p * 4 * W.n + e).l);
+        exph_put_coord<9>(o + 1, w);
+        words_from_limbs<9>(w, soa_ld<ModT, 1>(W.lc.ay, p * 4 * W.n + e).l);
+        exph_put_coord<9>(o + 34, w);
+        return;
+    }
+    uint32_t len = 67 * 4 * W.n;
+    if (W.hardened) {   // the statement: which ring, which message, which R, which committed key (sha256.h: sha_put_gk_statement_head, then R and keyXcom as points)
+        const char tag[] = "ZKAttest-GK-statement-v1";
+        for (int i = 0; i < 24; i++) m[len + i] = (uint8_t)tag[i];
+        len += 24;
+        for (int i = 0; i < 8; i++) {
+            const uint32_t v = W.ring_digest[i];
+            m[len + 4 * i] = (uint8_t)(v >> 24), m[len + 4 * i + 1] = (uint8_t)(v >> 16), m[len + 4 * i + 2] = (uint8_t)(v >> 8), m[len + 4 * i + 3] = (uint8_t)v;
+        }
+        len += 32;
+        for (int i = 0; i < 32; i++) m[len + i] = msg[32 * (size_t)p + i];
+        len += 32;
+        m[len] = 4;
+        words_from_limbs<8>(w, soa_ld<ModQ, 1>(W.Rx, p).l);
+        exph_put_coord<8>(m + len + 1, w);
+        words_from_limbs<8>(w, soa_ld<ModQ, 1>(W.Ry, p).l);
+        exph_put_coord<8>(m + len + 33, w);
+        len += 65;
+        m[len] = 4;
+        words_from_limbs<9>(w, soa_ld<ModT, 1>(W.la.ax, p * (2 + 2 * W.sec)).l);
+        exph_put_coord<9>(m + len + 1, w);
+        words_from_limbs<9>(w, soa_ld<ModT, 1>(W.la.ay, p * (2 + 2 * W.sec)).l);
+        exph_put_coord<9>(m + len + 34, w);
+        len += 67;
+    }
+    m[len] = 0x80;   // padding: 0x80, zeros, the bit length in eight bytes
+    for (uint32_t i = len + 1; i < nblk * 64 - 8; i++) m[i] = 0;
+    const uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; i++) m[nblk * 64 - 1 - i] = (uint8_t)(bits >> (8 * i));
+}
 void launch_gk_hash(hipStream_t s, const Workspace& W, uint32_t count, const uint8_t* msg) {
+    if (count <= W.exph_cap && W.exph_wk && count <= 512 && !getenv_exph_one_lane()) {
+        const uint32_t len = 67 * 4 * W.n + (W.hardened ? 24 + 32 + 32 + 65 + 67 : 0), nblk = (len + 9 + 63) / 64;
+        if (nblk <= (2 * 67 + W.sec * (65 + 2 * 67) + 9 + 63) / 64) {   // (the buffers were carved for the Exp challenge's blocks)
+            hipLaunchKernelGGL(k_gk_msg, dim3((count * (4 * W.n + 1) + 255) / 256), dim3(256), 0, s, W, count, msg, nblk);
+            launch_sha_msgs(s, W, count, W.gk_x, nblk, 3);
+            return;
+        }
+    }
     hipLaunchKernelGGL(k_gk_hash, dim3((count + 63) / 64), dim3(64), 0, s, W, count, msg);
 }
 
