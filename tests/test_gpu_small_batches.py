@@ -121,3 +121,68 @@ def test_soak_random_small_calls_against_precomputed_oracle_results():
             g = eng.verify_batch(b''.join(pool[i][0] for i in ids), [pool[i][1] for i in ids], vseeds=b''.join(pool[i][2] for i in ids))
             assert g == ([ok[i] for i in ids], [vst[i] for i in ids]), (call, ids)
     eng.close()
+
+
+def test_one_chunk_through_the_bucket_pass_with_several_failing_ranges():
+    """A small one-chunk call that takes the bucket pass (threshold 8) and fails it in several separate runs of groups: every run's per-proof sums reuse the
+    same per-term accumulators, so a run has to start behind the one before it.  (Round 6's one-fork-per-chunk change got that wrong for the second run; the
+    soak test above found it in 1 of 4 runs -- this one places the failing groups so that the regions overlap and fails on that version every time.)"""
+    import coracle as CO
+    import zkp_ecdsa_amd as Z
+    S, nkeys, B = 6400, 64, 40
+    eng = Z.Engine(0)
+    nh, tg, th = eng.synth_params(S)
+    eng.set_comb_bits(16)
+    eng.set_params(nh, tg, th, 80)
+    ring, msg, sig, pk, which, seeds = eng.synth_workload(S, nkeys, B)
+    eng.set_ring(ring, nkeys)
+    proofs, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert st == [0] * B
+    # groups of 5 proofs (8 groups): the runs {0, 1}, {4}, {7} fail -- a LONGER run first, so that the next run's membership accumulators (they lie behind the
+    # run's own slot accumulators in the shared array) land inside the region the first run's slot sums are still using
+    plist = [(_forge(p, 0) if i in (2, 8, 22, 37, 38) else p) for i, p in enumerate(proofs)]
+    vs = _vseeds(B, b'rg')
+    octx = CO.OracleCtx(nh, tg, th, 80)
+    octx.set_ring(ring, nkeys)
+    want = octx.verify_batch(msg, plist, nthreads=16, vseeds=vs)
+    assert want[0].count(0) == 5
+    eng.set_chunk(4096)
+    eng.set_batch_verify(8)
+    for lanes in (1, 2):
+        eng.set_lanes(lanes)
+        for rep in range(12):
+            c0 = eng.test_counter(0)
+            got = eng.verify_batch(msg, plist, vseeds=vs)
+            assert got == want, (lanes, rep, [i for i in range(B) if (got[0][i], got[1][i]) != (want[0][i], want[1][i])])
+            assert eng.test_counter(0) - c0 == 20   # groups 0, 1, 4, 7 of five proofs each were re-checked proof by proof, the other four passed the bucket pass
+    eng.close()
+
+
+def test_per_family_events_only_when_asked_for_in_small_calls():
+    """zk_ctx_set_timing (include/zkattest.h): AUTO records the per-family events only in calls of more than 8 192 proofs, ON in every blocking call, OFF never;
+    the bytes and verdicts do not depend on it."""
+    import zkp_ecdsa_amd as Z
+    S, nkeys, B = 6500, 64, 3
+    eng = Z.Engine(0)
+    nh, tg, th = eng.synth_params(S)
+    eng.set_comb_bits(16)
+    eng.set_params(nh, tg, th, 80)
+    ring, msg, sig, pk, which, seeds = eng.synth_workload(S, nkeys, B)
+    eng.set_ring(ring, nkeys)
+    p0, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert st == [0] * B and eng.last_timing() == (0.0, {})
+    vs = _vseeds(B, b'tm')
+    assert eng.verify_batch(msg, p0, vseeds=vs) == ([1] * B, [0] * B) and eng.last_timing() == (0.0, {})
+    eng.set_timing(1)
+    p1, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    tot, fam = eng.last_timing()
+    assert p1 == p0 and tot > 0 and 'tom_commit' in fam and 'hash' in fam
+    assert eng.verify_batch(msg, p0, vseeds=vs) == ([1] * B, [0] * B)
+    tot, fam = eng.last_timing()
+    assert tot > 0 and 'v_hash' in fam and eng.last_wall_ms() > 0
+    eng.set_timing(0)
+    p2, st = eng.prove_batch(msg, sig, pk, which, seeds=seeds)
+    assert p2 == p0 and eng.last_timing() == (0.0, {})
+    with pytest.raises(Exception):
+        eng.set_timing(3)
+    eng.close()
