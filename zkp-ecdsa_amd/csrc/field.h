@@ -600,6 +600,7 @@ ZK_DEV_NOINLINE Fe<M, 2> fe_inv_gcd(const Fe<M, 2> a) {
 #endif
         uint32_t fw = (uint32_t)f[0] | ((uint32_t)f[1] << LIMB_BITS), gw = (uint32_t)g[0] | ((uint32_t)g[1] << LIMB_BITS);
         uint32_t u = 1, v = 0, q = 0, r = 1;
+#if ZK_UNIFORM_CF
 #pragma unroll 6
         for (int i = 0; i < LIMB_BITS; i++) {
             uint32_t c1 = (uint32_t)(eta >> 31);            // eta < 0
@@ -611,6 +612,29 @@ ZK_DEV_NOINLINE Fe<M, 2> fe_inv_gcd(const Fe<M, 2> a) {
             fw += gw & c1, u += q & c1, v += r & c1;
             gw >>= 1, u <<= 1, v <<= 1;
         }
+#else
+        // The same 30 divsteps, several per iteration (the default build's control flow depends on data anyway): a run of even g's is one shift; with g odd and
+        // delta <= 0 (eta >= 0) the next eta + 1 steps are "add f if odd, halve", i.e. g <- (g + w f) / 2^k with the w that clears k low bits -- up to six at a
+        // time here, w = -g f^-1 mod 2^k from one Newton step on f (f f = 1 mod 8); delta > 0 and g odd is the swap (f, g) <- (g, -f) followed by the same.
+        // About 8 iterations of ~20 instructions instead of 30 of 17: one inversion in one lane 38 -> 27 us.
+        for (int i = LIMB_BITS;;) {
+            const int z = __builtin_ctz(gw | (0xffffffffu << i));
+            gw >>= z, u <<= z, v <<= z, eta -= z, i -= z;
+            if (i == 0) break;
+            if (eta < 0) {
+                eta = -eta;
+                uint32_t t = fw;
+                fw = gw, gw = 0u - t;
+                t = u, u = q, q = 0u - t;
+                t = v, v = r, r = 0u - t;
+            }
+            const int limit = eta + 1 > i ? i : eta + 1;
+            const uint32_t m = (0xffffffffu >> (32 - limit)) & 63u;
+            const uint32_t fi = fw * (2u - fw * fw);            // f^-1 mod 2^6
+            const uint32_t w = (0u - gw * fi) & m;
+            gw += fw * w, q += u * w, r += v * w;
+        }
+#endif
         const int64_t su = (int32_t)u, sv = (int32_t)v, sq = (int32_t)q, sr = (int32_t)r;
         // (f, g) <- matrix * (f, g) / 2^30, exactly
         int64_t cf = su * f[0] + sv * g[0], cg = sq * f[0] + sr * g[0];
