@@ -582,7 +582,9 @@ ZK_DEV Fe<M, 2> fe_inv_fermat(const Fe<M, 2>& a) {
 #ifndef ZK_UNIFORM_CF
 #define ZK_UNIFORM_CF 0
 #endif
-template <class M>
+// LOCKSTEP: every lane of the wave inverts its own element (the per-point normalisers of a small call): the fixed 30-step loop, because lanes that take
+// different numbers of iterations make the wave run their union (256 chains: 39.2 us fixed, 41.1 us variable; one chain: 37.3 -> 30.6 us variable).
+template <class M, bool LOCKSTEP = false>
 ZK_DEV_NOINLINE Fe<M, 2> fe_inv_gcd(const Fe<M, 2> a) {
     const Fe<M, 1> x = fe_canon(a);
     int32_t f[NLIMB], g[NLIMB], d[NLIMB], e[NLIMB];
@@ -600,7 +602,7 @@ ZK_DEV_NOINLINE Fe<M, 2> fe_inv_gcd(const Fe<M, 2> a) {
 #endif
         uint32_t fw = (uint32_t)f[0] | ((uint32_t)f[1] << LIMB_BITS), gw = (uint32_t)g[0] | ((uint32_t)g[1] << LIMB_BITS);
         uint32_t u = 1, v = 0, q = 0, r = 1;
-#if ZK_UNIFORM_CF
+        if constexpr (LOCKSTEP || ZK_UNIFORM_CF) {
 #pragma unroll 6
         for (int i = 0; i < LIMB_BITS; i++) {
             uint32_t c1 = (uint32_t)(eta >> 31);            // eta < 0
@@ -612,7 +614,7 @@ ZK_DEV_NOINLINE Fe<M, 2> fe_inv_gcd(const Fe<M, 2> a) {
             fw += gw & c1, u += q & c1, v += r & c1;
             gw >>= 1, u <<= 1, v <<= 1;
         }
-#else
+        } else {
         // The same 30 divsteps, several per iteration (the default build's control flow depends on data anyway): a run of even g's is one shift; with g odd and
         // delta <= 0 (eta >= 0) the next eta + 1 steps are "add f if odd, halve", i.e. g <- (g + w f) / 2^k with the w that clears k low bits -- up to six at a
         // time here, w = -g f^-1 mod 2^k from one Newton step on f (f f = 1 mod 8); delta > 0 and g odd is the swap (f, g) <- (g, -f) followed by the same.
@@ -634,7 +636,7 @@ ZK_DEV_NOINLINE Fe<M, 2> fe_inv_gcd(const Fe<M, 2> a) {
             const uint32_t w = (0u - gw * fi) & m;
             gw += fw * w, q += u * w, r += v * w;
         }
-#endif
+        }
         const int64_t su = (int32_t)u, sv = (int32_t)v, sq = (int32_t)q, sr = (int32_t)r;
         // (f, g) <- matrix * (f, g) / 2^30, exactly
         int64_t cf = su * f[0] + sv * g[0], cg = sq * f[0] + sr * g[0];
@@ -674,12 +676,12 @@ ZK_DEV_NOINLINE Fe<M, 2> fe_inv_gcd(const Fe<M, 2> a) {
 #ifndef ZK_INV_FERMAT
 #define ZK_INV_FERMAT 0
 #endif
-template <class M>
+template <class M, bool LOCKSTEP = false>
 ZK_DEV Fe<M, 2> fe_inv(const Fe<M, 2>& a) {
 #if ZK_INV_FERMAT
     return fe_inv_fermat<M>(a);
 #else
-    return fe_inv_gcd<M>(a);
+    return fe_inv_gcd<M, LOCKSTEP>(a);
 #endif
 }
 

@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(256) k_p256_normalize_each(Soa3 proj, uint32_t
     }
     Fe<ModQ, 1> one = fe_zero<ModQ>();
     one.l[0] = 1;
-    const Fq2 zi = fe_inv<ModQ>(z) * one;
+    const Fq2 zi = fe_inv<ModQ, true>(z) * one;   // (every lane its own point: field.h, LOCKSTEP)
     const Fq2 x = soa_ld<ModQ, 8>(proj.x, e) * zi, y = soa_ld<ModQ, 8>(proj.y, e) * zi;
     soa_st(ox, e, fe_canon(x));
     soa_st(oy, e, fe_canon(y));

@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(256) k_tom_normalize_each(TomList L, uint32_t 
     const uint32_t e = norm_slot(c, first, per_group, slots_per_group, kstride);
     Fe<ModT, 1> one = fe_zero<ModT>();
     one.l[0] = 1;
-    const Ft2 zi = fe_inv<ModT>(soa_ld<ModT, 2>(L.proj.z, e)) * one;   // plain 1 / z: the products below come out plain (see k_tom_normalize)
+    const Ft2 zi = fe_inv<ModT, true>(soa_ld<ModT, 2>(L.proj.z, e)) * one;   // plain 1 / z: the products below come out plain (see k_tom_normalize)
     const Ft2 x = soa_ld<ModT, 2>(L.proj.x, e) * (zi * fe_const<ModT, 1>(TOM_SINV_M));
     const Ft2 y = soa_ld<ModT, 2>(L.proj.y, e) * zi;
     soa_st(L.ax, e, fe_canon(x));
