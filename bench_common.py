@@ -48,7 +48,7 @@ TOM_COMMIT_BYTES = 2 * 36 + 3 * 36  # algorithmic HBM bytes per commitment: read
 TOM_COMMIT_PMC_BYTES = {24: 2502 + 111, 16: 3238 + 111}
 # whole verify step (65 536 proofs, 2 chunks of 32 768, one lane): 32 * sum SQ_ACTIVE_INST_VALU / (1024 SIMDs * sum GRBM_GUI_ACTIVE) over every kernel of the step
 # (tools/pmc_families.py --verify, tools/pmc_verify.sh)
-VERIFY_WHOLE_STEP_SIMD_BUSY = 0.608
+VERIFY_WHOLE_STEP_SIMD_BUSY = 0.606
 VERIFY_PMC_SOURCE = 'profiles/r06_pmc_families_verify.txt (separate rocprofv3 --pmc passes over one verify step; a constant of bench.py, NOT measured in this run)'
 PMC_SOURCE = 'profiles/r05_pmc_summary.txt (separate rocprofv3 --pmc passes at batch 65536, chunk 22016; constants of bench.py, NOT measured in this run)'
 # same passes, SQ counters at 24 bits: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave at 2 waves per SIMD over both kernels, (3.251e10 + 2.157e10) /
