@@ -19,6 +19,10 @@ static size_t vcarve(VWork& V, Soa& res, Soa& res2, MsmBuf& M, PMsmBuf& PM, uint
     V.t1_act = (uint32_t*)k.take(8 * ns), V.t1_cnt = (uint32_t*)k.take(256);
     V.vbytes = (uint8_t*)k.take(V_SAMPLE_FILLS * (size_t)C);
     V.vc = (uint32_t*)k.take(4 * 18 * ns);
+    {
+        const size_t nm = std::min<size_t>(C, V_PH_MAXP) * VK * 6;
+        V.ph_msg = (uint8_t*)k.take(nm * V_PH_BLOCKS * 64), V.ph_wk = (uint32_t*)k.take(nm * V_PH_BLOCKS * 256), V.ph_nblk = (uint8_t*)k.take(nm);
+    }
     V.vd = k.list(ns * 5);
     V.gk_f = k.soa((size_t)n * C), V.gk_g = k.soa((size_t)n * C);
     V.gk_total = k.soa(C);
@@ -329,7 +333,19 @@ zk_status VerifyJob::stage1(uint64_t chunk_no) {
 // At most V_WIDE_MAXP proofs (every call of a few proofs: the reference's own shape is ONE, zkpAttestList.ts:150-190): what the caller waits for is the
 // chain of dependent point operations of a lane, so every term gets a lane of its own (65 windows x (4 doublings + 1 addition) instead of x 13),
 // k_v_acc_tree folds the accumulators into the places k_v_final reads, and the independent sums run side by side on the lane's auxiliary streams.
-static zk_status per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t lane, const Workspace& W, const VWork& V, uint32_t p0, uint32_t p1, uint32_t range_no, uint32_t tsplit) {
+static zk_status host_wait(zk_ctx* c, hipEvent_t ev) {   // the host spins until `ev` has happened (a blocking call: its thread has nothing else to do)
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return ZK_OK;
+        if (e != hipErrorNotReady) {
+            c->err = std::string("hipEventQuery failed: ") + hipGetErrorString(e);
+            return ZK_E_DEVICE;
+        }
+    }
+}
+// release: the event behind stage 1 (VerifyJob::host_release) -- the auxiliary streams do not wait for it, the host does before it launches their kernels
+static zk_status per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t lane, const Workspace& W, const VWork& V, uint32_t p0, uint32_t p1, uint32_t range_no, uint32_t tsplit,
+                                 hipEvent_t release = nullptr) {
     const DevParams& P = c->P;
     const uint32_t nq = (c->n + 1) / 2;
     const uint32_t np = p1 - p0;
@@ -349,7 +365,8 @@ static zk_status per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t 
     if (np <= V_WIDE_MAXP) {
         auto& A = c->vl[lane];
         MaybeScope t(timed, c, "v_straus_tom", s);
-        if (!A.stage2_forked) {   // (a small chunk's streams left the main one in stage2a, which covers its FIRST range: a later range's sums reuse wide_acc,
+        const bool forked = A.stage2_forked;
+        if (!forked) {   // (a small chunk's streams left the main one in stage2a, which covers its FIRST range: a later range's sums reuse wide_acc,
             HIPCHK(c, hipEventRecord(A.aux_fork, s));   // so its streams start behind the range before it)
             for (int i = 0; i < 3; i++) HIPCHK(c, hipStreamWaitEvent(A.aux[i], A.aux_fork, 0));
         }
@@ -365,9 +382,13 @@ static zk_status per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t 
         const uint32_t ts = slots * V_SLOT_TERMS > ZK_COOP_MAX_CHAINS && slots * V_SLOT_SPLIT <= ZK_COOP_MAX_CHAINS && !zk_one_lane_chains() ? V_SLOT_SPLIT : V_SLOT_TERMS;
         launch_v_straus(s, terms_at(V.slot_terms, so), np * VK, V.C * VK, 10, 26, V.wide_acc, perm, pc, ts, ts);
         const Soa4 wgk = acc_at(V.wide_acc, (size_t)np * VK * V_SLOT_TERMS);
+        if (forked && release) {   // the main stream's chain is queued to its end; the other streams' kernels follow when stage 1 is over
+            launch_v_acc_tree(s, V.wide_acc, np, VK * ts, acc_at(V.slot_acc, so * V_SLOT_SPLIT), VK * V_SLOT_SPLIT, 0);
+            if (zk_status zr = host_wait(c, release)) return zr;
+        }
         launch_v_straus(A.aux[0], terms_at(V.gk_terms, (size_t)p0 * nq), np * nq, V.C * nq, 4, 4, wgk, nullptr, nullptr, V_WIDE_GK, V_WIDE_GK);
         launch_v_straus(A.aux[1], terms_at(V.misc_terms, p0), np, 3 * V.C, 1, 0, acc_at(V.misc_acc, p0), nullptr, nullptr, 1, 1, 3, V.C);
-        launch_v_acc_tree(s, V.wide_acc, np, VK * ts, acc_at(V.slot_acc, so * V_SLOT_SPLIT), VK * V_SLOT_SPLIT, 0);   // a proof's VK * ts accumulators are consecutive
+        if (!(forked && release)) launch_v_acc_tree(s, V.wide_acc, np, VK * ts, acc_at(V.slot_acc, so * V_SLOT_SPLIT), VK * V_SLOT_SPLIT, 0);   // a proof's VK * ts accumulators are consecutive
         launch_v_acc_tree(A.aux[0], wgk, np, nq * V_WIDE_GK, acc_at(V.gk_acc, (size_t)p0 * nq), nq, 0);   // one sum per proof (V_FOLDED)
         launch_tom_commit(A.aux[2], P, lc, np * 2, 2, 4 * W.n);
         for (int i = 0; i < 3; i++) {
@@ -433,13 +454,15 @@ zk_status VerifyJob::stage2a(uint64_t chunk_no) {
     const bool wide_chunk = side_streams(cnt);
     if (wide_chunk && timed) c->timing_forked = true;
     auto& A = c->vl[lane];
-    A.msm_pending = A.pm_pending = A.stage2_forked = false;   // (a failed call may have left them set)
+    A.msm_pending = A.pm_pending = A.stage2_forked = A.released_by_host = false;   // (a failed call may have left them set)
     if (wide_chunk) {   // the P-256 sums of a small chunk, one term per lane, beside everything below: streams 2 and 3 start from here ...
         HIPCHK(c, hipEventRecord(A.aux_fork, s));
-        for (int i = 0; i < 4; i++) HIPCHK(c, hipStreamWaitEvent(A.aux[i], A.aux_fork, 0));
         A.stage2_forked = true;   // one fork per chunk: an event between two kernels of the main stream costs a call of one proof 10-20 us each
         // ... and a call of a few proofs launches them BEHIND the Tom-256 sums' kernels (stage2b): those chains are the longer ones, and a launch costs 5 us of host time
         A.p256_launched = cnt > V_WIDE_MAXP || (c->verify_batch_min && cnt >= c->verify_batch_min && M.cap);   // (... unless the host is going to wait for the bucket pass first)
+        A.released_by_host = host_release && !A.p256_launched;   // stage2b's host waits for the event; no queue holds a wait while stage 1's tail runs
+        if (!A.released_by_host)
+            for (int i = 0; i < 4; i++) HIPCHK(c, hipStreamWaitEvent(A.aux[i], A.aux_fork, 0));
         if (A.p256_launched)
             if (zk_status zr = small_chunk_p256(c, timed, lane, cnt)) return zr;
     }
@@ -516,14 +539,17 @@ zk_status VerifyJob::stage2b(uint64_t chunk_no) {
         const uint32_t p0 = g * gsz, p1 = std::min<uint32_t>(cnt, g1 * gsz);
         // few slots: a slot's 36 terms over 4 lanes (the chain of one lane is ~12 ms long, the GPU is far from full)
         uint32_t tsplit = (uint64_t)(p1 - p0) * VK * V_SLOT_SPLIT <= 524288 ? V_SLOT_SPLIT : 1;   // up to two residencies of the GPU (4 waves per SIMD, 262 144 lanes)
-        if (zk_status zr = per_proof_range(c, timed, s, lane, W, V, p0, p1, ranges++, tsplit)) return zr;
+        if (zk_status zr = per_proof_range(c, timed, s, lane, W, V, p0, p1, ranges++, tsplit, wide_chunk && A.released_by_host ? A.aux_fork : nullptr)) return zr;
         if (p1 - p0 <= V_WIDE_MAXP) tsplit = 1 | V_FOLDED;   // folded: one accumulator per proof
         c->dbg_recheck_proofs += p1 - p0;
         for (uint32_t k = g; k < g1; k++) gf.v[k] = V_RECHECK | tsplit;
         g = g1;
     }
-    if (wide_chunk && !A.p256_launched)
+    if (wide_chunk && !A.p256_launched) {
+        if (A.released_by_host && !ranges)   // (no range went through per_proof_range, which waits: cannot happen below the batched check's size, kept for safety)
+            if (zk_status zr = host_wait(c, A.aux_fork)) return zr;
         if (zk_status zr = small_chunk_p256(c, timed, lane, cnt)) return zr;
+    }
     if (wide_chunk) HIPCHK(c, hipStreamWaitEvent(s, A.aux_done[3], 0));
     A.stage2_forked = false;
     if (pm) {
@@ -601,6 +627,10 @@ static zk_status verify_device(zk_ctx* c, uint64_t B, const uint8_t* d_msg, cons
     J.C = (uint32_t)std::min<uint64_t>(c->chunk, B);
     J.plan = make_chunk_plan(B, J.C, 1, false);   // uniform: see ctx.h
     J.NL = (uint32_t)std::min<size_t>(c->lanes, J.plan.size());   // chunks rotate over NL streams / workspaces
+    {
+        static const bool no_release = getenv("ZKATTEST_NO_HOST_RELEASE") != nullptr;   // A/B switch (tools/ab_release.sh)
+        J.host_release = J.plan.size() == 1 && B <= V_WIDE_MAXP && !no_release && !zk_one_lane_chains();
+    }
     if (c->wire == ZK_WIRE_ZKA1P) {   // the proofs handed in are packed: every chunk is expanded into the context's staging first
         uint64_t total = 0;
         if (host_off) total = host_off[B];

@@ -82,6 +82,7 @@ struct zk_ctx {
         hipEvent_t aux_fork = nullptr, aux_done[V_AUX_STREAMS] = {};
         bool p256_launched = false;   // stage2a launched the small chunk's P-256 sums (else stage2b does, behind the Tom-256 sums' kernels)
         bool stage2_forked = false;   // the auxiliary streams already wait for this chunk's stage 1 (stage2a of a small chunk)
+        bool released_by_host = false;   // ... or the host waits for it in stage2b and launches their kernels then (VerifyJob::host_release)
         bool ready = false;
     } vl[ZK_MAX_LANES];
     uint32_t vs_C = 0, vs_sec = 0, vs_n = 0;

@@ -238,6 +238,9 @@ struct VWork {
     uint32_t* t1_cnt;     // [1] their number (k_v_t1_scalars)
     uint8_t* vbytes;      // [C][1536] first byte of the verifier-RNG fills (k_v_sample_fills)
     uint32_t* vc;         // [C*VK][6][3] sub-proof challenges
+    uint8_t* ph_msg;      // [min(C, V_PH_MAXP) * VK * 6][V_PH_BLOCKS * 64] the padded messages of those challenges in a call of a few proofs (k_v_padd_msg) ...
+    uint32_t* ph_wk;      // ... their expanded schedules (k_hash.hip: launch_sha_msgs) ...
+    uint8_t* ph_nblk;     // ... and how many blocks each has (10, 5, or 1 for a slot that has no PointAdd proof)
     TomList vd;           // [C*VK*5] derived commitments (proj + affine)
     Soa gk_f, gk_g;       // [n*C] rho_j = f_j/g_j and the level's scale factor g_j (Montgomery); see k_v_gk_fg
     uint32_t* gk_swap;    // [n*C] 1 where g_j = 0 (x = f_j): the level keeps the odd branch, scale f_j
@@ -273,6 +276,10 @@ void launch_v_exp_challenge_small(hipStream_t s, const Workspace& W, const VWork
 void launch_v_sample(hipStream_t s, const VWork& V, uint32_t count, const uint8_t* vseeds, uint64_t first);
 void launch_v_sample_check(hipStream_t s, const VWork& V, uint32_t count);
 void launch_v_exp_status(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, bool have_jm);
+#define V_PH_MAXP 64      // proofs per call whose PointAdd challenges go through the message / schedule / two-lane rounds kernels
+#define V_PH_BLOCKS 10    // 9 points of 67 bytes + padding
+// k_hash.hip: `count` messages of up to nblk 64-byte blocks at W.exph_msg (message p at p * nblk * 64; nblk_of[p] blocks if given) -> challenge words chal[ostride p ..]
+void launch_sha_msgs(hipStream_t s, const Workspace& W, uint32_t count, uint32_t* chal, uint32_t nblk, uint32_t ostride, const uint8_t* nblk_of = nullptr);
 void launch_exph_hash(hipStream_t s, const Workspace& W, uint32_t count, uint32_t* chal);   // k_hash.hip: schedule per block, rounds per proof -> chal[4 p ..]
 void launch_v_exp_points(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first, uint32_t split = 1);   // split: 1, or 4 lanes per checked repetition (small chunks)
 void launch_v_t1_scalars(hipStream_t s, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first);

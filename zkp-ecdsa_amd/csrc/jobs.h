@@ -92,6 +92,10 @@ struct VerifyJob {
     uint32_t C = 0, NL = 1;
     uint64_t lane_base = 0;
     bool timed = false;
+    // A blocking call of a few proofs (<= V_WIDE_MAXP): the auxiliary streams' stage-2 kernels are launched when the HOST has seen stage 1's last kernel end, instead of
+    // being queued early behind a wait for its event.  Two or more queues that hold a wait slow every OTHER queue of the device down by ~17 us per kernel boundary
+    // (tools/sha_bench.hip: 21 -> 57 us per pair of small kernels), and stage 1's tail is a chain of ten small kernels on the main stream.
+    bool host_release = false;
     hipEvent_t inputs_ready = nullptr;
     std::vector<ChunkPlan> plan;
     std::vector<hipEvent_t> arrived;     // host_src: one event per chunk, recorded on the copy stream behind the chunk's bytes

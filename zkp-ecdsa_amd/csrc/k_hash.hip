@@ -159,9 +159,12 @@ __global__ void __launch_bounds__(256) k_exph_sched(Workspace W, uint32_t count,
 #pragma unroll
     for (int i = 0; i < 16; i++) dst[(size_t)i * count] = make_uint4(w[4 * i] + SHA_K[4 * i], w[4 * i + 1] + SHA_K[4 * i + 1], w[4 * i + 2] + SHA_K[4 * i + 2], w[4 * i + 3] + SHA_K[4 * i + 3]);
 }
-__global__ void __launch_bounds__(64) k_exph_rounds(Workspace W, uint32_t count, uint32_t* chal, uint32_t nblk, uint32_t ostride) {
+template <bool VAR>   // VAR: message p has nblk_of[p] <= nblk blocks
+__global__ void __launch_bounds__(64) k_exph_rounds(Workspace W, uint32_t count, uint32_t* chal, uint32_t nblk, uint32_t ostride, const uint8_t* __restrict__ nblk_of) {
     const uint32_t p = gtid();
     if (p >= count) return;
+    const uint32_t mine = VAR ? nblk_of[p] : nblk;   // VAR: every lane runs nblk blocks and keeps the chaining value after its own last one (see k_exph_rounds2)
+    uint32_t keep[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const uint4* wk = (const uint4*)W.exph_wk + p;   // word group i of block b: wk[(16 b + i) * count]
     uint32_t h[8];
     sha256_iv(h);
@@ -185,6 +188,14 @@ __global__ void __launch_bounds__(64) k_exph_rounds(Workspace W, uint32_t count,
             hh = g, g = f, f = e, e = d + t1, d = c, c = bb, bb = a, a = t1 + t2;
         }
         h[0] += a, h[1] += bb, h[2] += c, h[3] += d, h[4] += e, h[5] += f, h[6] += g, h[7] += hh;
+        if (VAR && b + 1 == mine) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) keep[i] = h[i];
+        }
+    }
+    if (VAR) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) h[i] = keep[i];
     }
     uint32_t cw[4];
     challenge_words(h, cw);
@@ -196,11 +207,16 @@ __global__ void __launch_bounds__(64) k_exph_rounds(Workspace W, uint32_t count,
 // lanes swap T1 for d through a DPP move, and each has its new first word: 11 instructions per round.  (E's schedule words are real, A reads a zero cell.)
 static bool getenv_exph_one_lane() { return zk_one_lane_chains(); }   // ZKATTEST_ONE_LANE_CHAINS: the A/B switch of the cooperative kernels covers this one too
 __device__ const uint4 g_exph_zero16 = {0, 0, 0, 0};
-__global__ void __launch_bounds__(64) k_exph_rounds2(Workspace W, uint32_t count, uint32_t* chal, uint32_t nblk, uint32_t ostride) {
+template <bool VAR>
+__global__ void __launch_bounds__(64) k_exph_rounds2(Workspace W, uint32_t count, uint32_t* chal, uint32_t nblk, uint32_t ostride, const uint8_t* __restrict__ nblk_of) {
     const uint32_t t = gtid(), p0 = t >> 1;
     const bool live = p0 < count;
     const uint32_t p = live ? p0 : count - 1;   // (a dead pair mirrors the last proof: the DPP moves need both lanes of a pair)
     const bool isA = t & 1;
+    // VAR: message p ends after nblk_of[p] <= nblk blocks.  Every pair still runs the launch's nblk blocks (a loop count in a scalar register keeps the loads of the
+    // next block in front of this block's rounds) and keeps the chaining value it had after its own last block.
+    const uint32_t mine = VAR ? nblk_of[p] : nblk;   // (both lanes of a pair read the same count)
+    uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0;
     const uint32_t m = isA ? 0xffffffffu : 0u, nm = ~m;
     const uint32_t s1 = isA ? 2 : 6, s2 = isA ? 13 : 11, s3 = isA ? 22 : 25;
     // word group i of block b: wk[(16 b + i) * count + p] on E, the zero cell on A
@@ -237,7 +253,9 @@ __global__ void __launch_bounds__(64) k_exph_rounds2(Workspace W, uint32_t count
             r3 = r2, r2 = r1, r1 = r0, r0 = z + o;                     // E: e' = d + T1; A: a' = T2 + T1
         }
         hc0 += r0, hc1 += r1, hc2 += r2, hc3 += r3;
+        if (VAR && b + 1 == mine) k0 = hc0, k1 = hc1, k2 = hc2, k3 = hc3;
     }
+    if (VAR) hc0 = k0, hc1 = k1, hc2 = k2, hc3 = k3;
     // the challenge is cut out of digest words 0..2: lane A has them
     if (!live || !isA) return;
     const uint32_t h[8] = {hc0, hc1, hc2, hc3, 0, 0, 0, 0};
@@ -246,11 +264,15 @@ __global__ void __launch_bounds__(64) k_exph_rounds2(Workspace W, uint32_t count
     for (uint32_t i = 0; i < ostride; i++) chal[ostride * p + i] = cw[i];
 }
 // schedule per block, rounds per message: nblk blocks of 64 bytes per message at W.exph_msg, the challenge's ostride (3 or 4) words to chal[ostride p ..]
-static void launch_sha_msgs(hipStream_t s, const Workspace& W, uint32_t count, uint32_t* chal, uint32_t nblk, uint32_t ostride) {
+void launch_sha_msgs(hipStream_t s, const Workspace& W, uint32_t count, uint32_t* chal, uint32_t nblk, uint32_t ostride, const uint8_t* nblk_of) {
     hipLaunchKernelGGL(k_exph_sched, dim3((count * nblk + 255) / 256), dim3(256), 0, s, W, count, nblk);
     // up to one wave per SIMD the chain's length is the cost: two lanes per proof; beyond that the lanes are, and the one-lane form has fewer of them
-    if (count <= 32768 && !getenv_exph_one_lane()) hipLaunchKernelGGL(k_exph_rounds2, dim3((2 * count + 63) / 64), dim3(64), 0, s, W, count, chal, nblk, ostride);
-    else hipLaunchKernelGGL(k_exph_rounds, dim3((count + 63) / 64), dim3(64), 0, s, W, count, chal, nblk, ostride);
+    const bool two = count <= 32768 && !getenv_exph_one_lane();
+    const dim3 grid(((two ? 2 : 1) * count + 63) / 64);
+    if (two && nblk_of) hipLaunchKernelGGL(k_exph_rounds2<true>, grid, dim3(64), 0, s, W, count, chal, nblk, ostride, nblk_of);
+    else if (two) hipLaunchKernelGGL(k_exph_rounds2<false>, grid, dim3(64), 0, s, W, count, chal, nblk, ostride, nblk_of);
+    else if (nblk_of) hipLaunchKernelGGL(k_exph_rounds<true>, grid, dim3(64), 0, s, W, count, chal, nblk, ostride, nblk_of);
+    else hipLaunchKernelGGL(k_exph_rounds<false>, grid, dim3(64), 0, s, W, count, chal, nblk, ostride, nblk_of);
 }
 void launch_exph_hash(hipStream_t s, const Workspace& W, uint32_t count, uint32_t* chal) {
     launch_sha_msgs(s, W, count, chal, (2 * 67 + W.sec * (65 + 2 * 67) + 9 + 63) / 64, 4);

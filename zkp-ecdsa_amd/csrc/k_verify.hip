@@ -811,6 +811,76 @@ __global__ void __launch_bounds__(256) k_v_padd_hash(DevParams P, Workspace W, V
     }
 }
 
+// The same six digests per zero-bit slot for a call of a few proofs (<= V_PH_MAXP): one lane per point writes the padded messages -- the points of the proof are
+// copied as they stand (a 72-byte encoding holds two 36-byte big-endian coordinates; hashPoints takes the low 33 bytes of each) -- and k_hash.hip's schedule
+// and two-lane rounds kernels hash them: 123 -> ~35 us on the chain one verification waits for.  Message m = slot * 6 + h, element k at byte 67 k.
+ZK_DEV void ph_tom_bytes(uint8_t* b, const uint32_t* x9, const uint32_t* y9) {   // the 66 coordinate bytes of hashPoints' encoding (33 big-endian each)
+    uint32_t w[9];
+    words_from_limbs<9>(w, x9);
+#pragma unroll
+    for (int i = 0; i < 33; i++) b[i] = (uint8_t)(w[(32 - i) >> 2] >> (8 * ((32 - i) & 3)));
+    words_from_limbs<9>(w, y9);
+#pragma unroll
+    for (int i = 0; i < 33; i++) b[33 + i] = (uint8_t)(w[(32 - i) >> 2] >> (8 * ((32 - i) & 3)));
+}
+__global__ void __launch_bounds__(256) k_v_padd_msg(DevParams P, Workspace W, VWork V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    const uint32_t t = gtid(), nsl = count * VK;
+    if (t >= nsl * 6 * 10) return;
+    const uint32_t m = t / 10, k = t % 10, sl = m / 6, h = m % 6, p = sl / VK;
+    const uint32_t iv = V.idx[sl], i = iv & 255, bit = iv >> 8;
+    const bool good = V.st[p] == ZK_OK && !(V.okflags[p] & 8) && V.exp_st[p] == ZK_OK && !bit;
+    const uint32_t ne = !good ? 0 : h < 4 ? 9 : 4;
+    uint8_t* msg = V.ph_msg + (size_t)m * V_PH_BLOCKS * 64;
+    if (k == 9) {   // padding: 0x80, zeros, the bit length in eight bytes
+        const uint32_t len = 67 * ne, nb = (len + 9 + 63) / 64;
+        V.ph_nblk[m] = (uint8_t)nb;
+        msg[len] = 0x80;
+        for (uint32_t j = len + 1; j < nb * 64 - 8; j++) msg[j] = 0;
+        const uint64_t bits = (uint64_t)len * 8;
+        for (int j = 0; j < 8; j++) msg[nb * 64 - 1 - j] = (uint8_t)(bits >> (8 * j));
+        return;
+    }
+    if (k >= ne) return;
+    const uint8_t* pa = proofs + off[first + p] + rep_offset(V.hbits + 4 * p, i) + ZK_REP_HEAD;
+    const uint8_t *c8 = pa, *c10 = pa + 72, *c11 = pa + 144, *c13 = pa + 216;
+    const uint32_t d = sl * 5;
+    const uint8_t* src = nullptr;   // a point of the proof ...
+    uint32_t vd = 0xffffffffu;      // ... or a derived commitment (V.vd) ...
+    bool g = false;                 // ... or the generator
+    if (h < 4) {
+        if (k >= 3) src = pa + 288 + 656 * h + 72 * (k - 3);
+        else if (h == 0) {
+            if (k == 0) vd = d + 0;
+            else if (k == 1) src = c8;
+            else g = true;
+        } else if (h == 1) {
+            if (k == 0) src = c8;
+            else if (k == 1) vd = d + 1;
+            else src = c10;
+        } else if (h == 2) src = k < 2 ? c10 : c11;
+        else {
+            if (k == 0) src = c10;
+            else if (k == 1) vd = d + 2;
+            else src = c13;
+        }
+    } else {
+        const uint8_t* e = pa + (h == 4 ? 2912 : 3152);
+        if (k == 0) src = h == 4 ? c11 : c13;
+        else if (k == 1) vd = d + (h == 4 ? 3 : 4);
+        else src = e + 72 * (k - 2);
+    }
+    uint8_t b[66];   // every load before the first store (the compiler cannot know that the proof and the message do not overlap)
+    if (src) {
+#pragma unroll
+        for (int j = 0; j < 33; j++) b[j] = src[3 + j], b[33 + j] = src[39 + j];
+    } else if (g) ph_tom_bytes(b, P.tom_g_aff, P.tom_g_aff + 9);
+    else ph_tom_bytes(b, soa_ld<ModT, 1>(V.vd.ax, vd).l, soa_ld<ModT, 1>(V.vd.ay, vd).l);
+    uint8_t* __restrict__ o = msg + 67 * k;
+    o[0] = 4;
+#pragma unroll
+    for (int j = 0; j < 66; j++) o[1 + j] = b[j];
+}
+
 // ------------------------------------------------------------------ GK total (gk.ts:239-250), fold form:
 // layer' [i] = (x - f_j) * layer[2i] + f_j * layer[2i+1]; tile of 2^T ring elements per workgroup, levels through LDS
 #define VGK_T 13   // 256 lanes x 32 elements per tile
@@ -1774,6 +1844,13 @@ void launch_v_derived(hipStream_t s, const Workspace& W, const VWork& V, uint32_
     L1(k_v_derived, count * VK * 5, 256, W, V, count, proofs, off, first);
 }
 void launch_v_padd_hash(hipStream_t s, const DevParams& P, const Workspace& W, const VWork& V, uint32_t count, const uint8_t* proofs, const uint64_t* off, uint64_t first) {
+    if (count <= V_PH_MAXP && !zk_one_lane_chains()) {
+        L1(k_v_padd_msg, count * VK * 6 * 10, 256, P, W, V, count, proofs, off, first);
+        Workspace Wb = W;
+        Wb.exph_msg = V.ph_msg, Wb.exph_wk = V.ph_wk;
+        launch_sha_msgs(s, Wb, count * VK * 6, V.vc, V_PH_BLOCKS, 3, V.ph_nblk);
+        return;
+    }
     L1(k_v_padd_hash, count * VK * 6, 256, P, W, V, count, proofs, off, first);
 }
 // The term lists of a chunk in four pieces (a large chunk runs them in this order on one stream, `which` = 3 in one launch; a small chunk runs the membership
