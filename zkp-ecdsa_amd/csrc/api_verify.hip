@@ -343,9 +343,10 @@ static zk_status host_wait(zk_ctx* c, hipEvent_t ev) {   // the host spins until
         }
     }
 }
+static zk_status small_chunk_p256(zk_ctx* c, bool timed, uint32_t lane, uint32_t cnt);
 // release: the event behind stage 1 (VerifyJob::host_release) -- the auxiliary streams do not wait for it, the host does before it launches their kernels
 static zk_status per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t lane, const Workspace& W, const VWork& V, uint32_t p0, uint32_t p1, uint32_t range_no, uint32_t tsplit,
-                                 hipEvent_t release = nullptr) {
+                                 hipEvent_t release = nullptr, uint32_t chunk_cnt = 0) {
     const DevParams& P = c->P;
     const uint32_t nq = (c->n + 1) / 2;
     const uint32_t np = p1 - p0;
@@ -385,6 +386,11 @@ static zk_status per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t 
         if (forked && release) {   // the main stream's chain is queued to its end; the other streams' kernels follow when stage 1 is over
             launch_v_acc_tree(s, V.wide_acc, np, VK * ts, acc_at(V.slot_acc, so * V_SLOT_SPLIT), VK * V_SLOT_SPLIT, 0);
             if (zk_status zr = host_wait(c, release)) return zr;
+            // host order from here: the longest chain first -- the P-256 relation (tables, sums, total: ~0.35 ms), then the membership sums, the rest
+            if (!A.p256_launched) {
+                if (zk_status zr = small_chunk_p256(c, timed, lane, chunk_cnt)) return zr;
+                A.p256_launched = true;
+            }
         }
         launch_v_straus(A.aux[0], terms_at(V.gk_terms, (size_t)p0 * nq), np * nq, V.C * nq, 4, 4, wgk, nullptr, nullptr, V_WIDE_GK, V_WIDE_GK);
         launch_v_straus(A.aux[1], terms_at(V.misc_terms, p0), np, 3 * V.C, 1, 0, acc_at(V.misc_acc, p0), nullptr, nullptr, 1, 1, 3, V.C);
@@ -539,7 +545,7 @@ zk_status VerifyJob::stage2b(uint64_t chunk_no) {
         const uint32_t p0 = g * gsz, p1 = std::min<uint32_t>(cnt, g1 * gsz);
         // few slots: a slot's 36 terms over 4 lanes (the chain of one lane is ~12 ms long, the GPU is far from full)
         uint32_t tsplit = (uint64_t)(p1 - p0) * VK * V_SLOT_SPLIT <= 524288 ? V_SLOT_SPLIT : 1;   // up to two residencies of the GPU (4 waves per SIMD, 262 144 lanes)
-        if (zk_status zr = per_proof_range(c, timed, s, lane, W, V, p0, p1, ranges++, tsplit, wide_chunk && A.released_by_host ? A.aux_fork : nullptr)) return zr;
+        if (zk_status zr = per_proof_range(c, timed, s, lane, W, V, p0, p1, ranges++, tsplit, wide_chunk && A.released_by_host ? A.aux_fork : nullptr, cnt)) return zr;
         if (p1 - p0 <= V_WIDE_MAXP) tsplit = 1 | V_FOLDED;   // folded: one accumulator per proof
         c->dbg_recheck_proofs += p1 - p0;
         for (uint32_t k = g; k < g1; k++) gf.v[k] = V_RECHECK | tsplit;
