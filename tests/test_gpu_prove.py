@@ -43,16 +43,20 @@ def test_one_lane_and_cooperative_chains_make_the_same_bytes():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     recs = []
-    for one_lane in (False, True):
+    # third run: the default kernels with the small verify calls' auxiliary streams waiting for stage 1 on the device (ZKATTEST_NO_HOST_RELEASE) instead of
+    # being released by the host (api_verify.hip: VerifyJob::host_release; the one-lane run takes the waiting path too)
+    for switch in (None, 'ZKATTEST_ONE_LANE_CHAINS', 'ZKATTEST_NO_HOST_RELEASE'):
         env = dict(os.environ)
         env.pop('ZKATTEST_ONE_LANE_CHAINS', None)
-        if one_lane:
-            env['ZKATTEST_ONE_LANE_CHAINS'] = '1'
+        env.pop('ZKATTEST_NO_HOST_RELEASE', None)
+        if switch:
+            env[switch] = '1'
         out = subprocess.run([sys.executable, os.path.join(root, 'tests', 'chains_check.py')], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert out.returncode == 0, out.stderr.decode()[-2000:]
         recs.append(json.loads(out.stdout.decode().strip().splitlines()[-1]))
-    assert recs[0]['one_lane'] is False and recs[1]['one_lane'] is True
-    assert recs[0]['sha256'] == recs[1]['sha256'] and recs[0]['verdicts'] == recs[1]['verdicts']
+    assert recs[0]['one_lane'] is False and recs[1]['one_lane'] is True and recs[2]['one_lane'] is False
+    for r in recs[1:]:
+        assert recs[0]['sha256'] == r['sha256'] and recs[0]['verdicts'] == r['verdicts']
 
 
 def test_uniform_control_flow_build_makes_the_same_bytes():

@@ -14,11 +14,11 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 eng = Z.Engine(0)
 eng.set_comb_bits(16)
 eng.set_params(*eng.synth_params(2024), 80)
-ring, msg, sig, pk, which, seeds = eng.synth_workload(2024, nk, 256)
+ring, msg, sig, pk, which, seeds = eng.synth_workload(2024, nk, max(256, B))
 eng.set_ring(ring, nk)
 eng.set_lanes(1)
 eng.set_chunk(B)
-pin = Z.PinnedBuffer(64 << 20)
+pin = Z.PinnedBuffer(max(64 << 20, B * 180000))
 a = (msg[:32 * B], sig[:64 * B], pk[:64 * B], which[:B], seeds[:32 * B])
 tp, tv = [], []
 for k in range(reps + 5):

@@ -343,7 +343,7 @@ static zk_status host_wait(zk_ctx* c, hipEvent_t ev) {   // the host spins until
         }
     }
 }
-static zk_status small_chunk_p256(zk_ctx* c, bool timed, uint32_t lane, uint32_t cnt);
+static zk_status small_chunk_p256(zk_ctx* c, bool timed, uint32_t lane, uint32_t cnt, bool one_stream = false);
 // release: the event behind stage 1 (VerifyJob::host_release) -- the auxiliary streams do not wait for it, the host does before it launches their kernels
 static zk_status per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t lane, const Workspace& W, const VWork& V, uint32_t p0, uint32_t p1, uint32_t range_no, uint32_t tsplit,
                                  hipEvent_t release = nullptr, uint32_t chunk_cnt = 0) {
@@ -421,21 +421,24 @@ static zk_status per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t 
     return ZK_OK;
 }
 // The P-256 relation of a small chunk (<= V_SIDE_MAXP proofs) on the lane's streams 2 and 3, which already wait for stage 1 (stage2a): one term per lane.
-static zk_status small_chunk_p256(zk_ctx* c, bool timed, uint32_t lane, uint32_t cnt) {
+static zk_status small_chunk_p256(zk_ctx* c, bool timed, uint32_t lane, uint32_t cnt, bool one_stream) {
     const DevParams& P = c->P;
     const Workspace& W = c->pl[lane].W;
     const VWork& V = c->vl[lane].V;
     auto& A = c->vl[lane];
+    hipStream_t fixed_s = one_stream ? A.aux[3] : A.aux[2];   // one_stream: only aux 3 holds a wait for stage 1 (stage2a), the table walks run behind the sums
     {
         MaybeScope t(timed, c, "v_straus_p256", A.aux[3]);
         launch_v_p256_straus(A.aux[3], V, cnt, 1);
     }
     {   // SR * R + SH * h_NIST (two table walks) beside the sums of the A_j
-        MaybeScope t(timed, c, "v_p256_total", A.aux[2]);
-        launch_v_p256_total_fixed(A.aux[2], P, W, V, cnt);
+        MaybeScope t(timed, c, "v_p256_total", fixed_s);
+        launch_v_p256_total_fixed(fixed_s, P, W, V, cnt);
     }
-    HIPCHK(c, hipEventRecord(A.aux_done[2], A.aux[2]));
-    HIPCHK(c, hipStreamWaitEvent(A.aux[3], A.aux_done[2], 0));
+    if (!one_stream) {
+        HIPCHK(c, hipEventRecord(A.aux_done[2], A.aux[2]));
+        HIPCHK(c, hipStreamWaitEvent(A.aux[3], A.aux_done[2], 0));
+    }
     {
         MaybeScope t(timed, c, "v_p256_total", A.aux[3]);
         launch_v_p256_total_sum(A.aux[3], P, W, V, cnt);
@@ -467,10 +470,14 @@ zk_status VerifyJob::stage2a(uint64_t chunk_no) {
         // ... and a call of a few proofs launches them BEHIND the Tom-256 sums' kernels (stage2b): those chains are the longer ones, and a launch costs 5 us of host time
         A.p256_launched = cnt > V_WIDE_MAXP || (c->verify_batch_min && cnt >= c->verify_batch_min && M.cap);   // (... unless the host is going to wait for the bucket pass first)
         A.released_by_host = host_release && !A.p256_launched;   // stage2b's host waits for the event; no queue holds a wait while stage 1's tail runs
-        if (!A.released_by_host)
+        if (A.p256_launched) {
+            // ONE queue waits (two or more waiting queues cost every other queue ~17 us per kernel boundary): the P-256 relation's kernels in a row on
+            // aux 3, beside the bucket pass; a range that fails the pass forks the other streams itself (per_proof_range)
+            HIPCHK(c, hipStreamWaitEvent(A.aux[3], A.aux_fork, 0));
+            A.stage2_forked = false;
+            if (zk_status zr = small_chunk_p256(c, timed, lane, cnt, true)) return zr;
+        } else if (!A.released_by_host)
             for (int i = 0; i < 4; i++) HIPCHK(c, hipStreamWaitEvent(A.aux[i], A.aux_fork, 0));
-        if (A.p256_launched)
-            if (zk_status zr = small_chunk_p256(c, timed, lane, cnt)) return zr;
     }
     // P-256 relation: one bucket-method sum per group as well (k_pmsm.hip), on an auxiliary stream beside the Tom-256 pass; its verdicts arrive with that
     // pass's (one host round trip).  A group that fails sends the chunk through the per-proof sums.
