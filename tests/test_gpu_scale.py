@@ -440,6 +440,13 @@ def test_tapered_chunk_plan_of_the_host_pointer_calls_keeps_the_bytes():
     _, _, off2, st = eng.prove_batch_host_raw(msg, sig, pk, which, seeds, out=page)
     digests.append(hashlib.sha256(bytes(page)).hexdigest() + ':%d' % off2[B])
     assert len(set(digests)) == 1, digests
+    # a call that is ONE chunk of at most 8192 proofs on a page-locked buffer slices its PointAdd phase by 512 (<= 2048 proofs) or 1024 (api.hip: stage2): same bytes
+    eng.set_host_taper(1), eng.set_chunk(4096)
+    for nb in (3000, 1500, 700):
+        C.memset(pin.ptr, 0x5A, 1 << 20)
+        _, _, offn, st = eng.prove_batch_host_raw(msg[:32 * nb], sig[:64 * nb], pk[:64 * nb], which[:nb], seeds[:32 * nb], out=pin)
+        assert not any(st) and list(offn[:nb + 1]) == list(off2[:nb + 1])
+        assert bytes(pin.view[:offn[nb]]) == bytes(page[:off2[nb]]), nb
     octx = _oracle(params, ring, nkeys, sec)
     pick = [0, 2047, 2048, 4095, 8999]
     exp, _ = octx.prove_batch(b''.join(msg[32 * b:32 * b + 32] for b in pick), b''.join(sig[64 * b:64 * b + 64] for b in pick),

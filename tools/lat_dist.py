@@ -18,6 +18,8 @@ ring, msg, sig, pk, which, seeds = eng.synth_workload(2024, nk, max(256, B))
 eng.set_ring(ring, nk)
 eng.set_lanes(1)
 eng.set_chunk(B)
+if os.environ.get('LAT_SLICE'):
+    eng.set_slice(int(os.environ['LAT_SLICE']))   # proofs per PointAdd slice of the prover (default: 4096 with a page-locked sink)
 pin = Z.PinnedBuffer(max(64 << 20, B * 180000))
 a = (msg[:32 * B], sig[:64 * B], pk[:64 * B], which[:B], seeds[:32 * B])
 tp, tv = [], []

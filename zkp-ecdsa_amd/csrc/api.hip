@@ -861,7 +861,10 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
         MaybeScope t(timed, c, "scan", s);
         launch_scan(s, W, cnt, cursor, out_cap, d_out_off, d_status, d_totals, first);
     }
-    const uint32_t S = c->slice ? c->slice : (host_sink ? 4096u : 0u);
+    // proofs per slice (zk_ctx_set_slice; 0 = automatic): 4096 with a page-locked sink -- and 512 / 1024 when the call is ONE chunk of at most 2048 / 8192 proofs: nothing else
+    // covers its output's way over the link (169 KB per proof: 15 ms of a 31 ms call of 4096 proofs), so more, smaller slices do (tools/slice_sweep.sh: -11 % at 1024
+    // proofs per call, -20 % at 2048, -25 % at 4096, -15 % at 8192)
+    const uint32_t S = c->slice ? c->slice : !host_sink ? 0u : plan.size() == 1 && cnt <= 2048 ? 512u : plan.size() == 1 && cnt <= 8192 ? 1024u : 4096u;
     const bool sliced = S && cnt > S;
     const bool last_chunk = first + cnt == B && !more_follows;
     launch_words_to_host(s, totals, d_totals, 4);
