@@ -16,8 +16,8 @@ eng.set_comb_bits(16)
 eng.set_params(*eng.synth_params(2024), 80)
 ring, msg, sig, pk, which, seeds = eng.synth_workload(2024, nk, max(256, B))
 eng.set_ring(ring, nk)
-eng.set_lanes(1)
-eng.set_chunk(B)
+eng.set_lanes(int(os.environ.get('LAT_LANES', '1')))
+eng.set_chunk(int(os.environ.get('LAT_CHUNK', B)))   # LAT_CHUNK / LAT_LANES: the call as several chunks on several lanes
 if os.environ.get('LAT_SLICE'):
     eng.set_slice(int(os.environ['LAT_SLICE']))   # proofs per PointAdd slice of the prover (default: 4096 with a page-locked sink)
 pin = Z.PinnedBuffer(max(64 << 20, B * 180000))
