@@ -420,7 +420,8 @@ static zk_status per_proof_range(zk_ctx* c, bool timed, hipStream_t s, uint32_t 
     }
     return ZK_OK;
 }
-// The P-256 relation of a small chunk (<= V_SIDE_MAXP proofs) on the lane's streams 2 and 3, which already wait for stage 1 (stage2a): one term per lane.
+// The P-256 relation of a small chunk (<= V_SIDE_MAXP proofs), one term per lane, on the lane's auxiliary streams 2 and 3 -- which wait for stage 1 (stage2a), or are handed
+// these kernels by the host when stage 1 is over (VerifyJob::host_release) -- or on stream 3 alone (one_stream: a chunk that takes the batched checks first).
 static zk_status small_chunk_p256(zk_ctx* c, bool timed, uint32_t lane, uint32_t cnt, bool one_stream) {
     const DevParams& P = c->P;
     const Workspace& W = c->pl[lane].W;
