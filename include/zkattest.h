@@ -124,8 +124,8 @@ zk_status zk_ctx_set_comb_bits(zk_ctx *ctx, uint32_t bits);
 zk_status zk_ctx_set_host_taper(zk_ctx *ctx, uint32_t on);
 /* The prover runs a chunk's PointAdd phase (src/exp/pointAdd.ts:92-163: 80 % of the proof bytes) in slices of `proofs`
  * consecutive proofs; with a page-locked `out` every slice is followed by the DMA of the proofs it completed.  0 (default) =
- * 4096 for page-locked output (512 / 1024 in a chunk of at most 2048 / 8192 proofs, whose output's transfer is a large part of
- * its time), no slicing otherwise; at least 64.  The proof bytes do not depend on it. */
+ * 4096 for page-locked output (512 / 1024 in the small chunks of short calls -- one chunk of at most 2048 / 8192 proofs, or chunks
+ * of at most 2048 / 4096 in a call of at most 32768 -- whose output's transfer is a large part of their time), no slicing otherwise; at least 64.  The proof bytes do not depend on it. */
 zk_status zk_ctx_set_slice(zk_ctx *ctx, uint32_t proofs);
 
 /* Verifier strategy for the Tom-256 relations: in a chunk of at least min_chunk proofs (default 256) the relations of ALL

@@ -861,11 +861,14 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
         MaybeScope t(timed, c, "scan", s);
         launch_scan(s, W, cnt, cursor, out_cap, d_out_off, d_status, d_totals, first);
     }
-    // proofs per slice (zk_ctx_set_slice; 0 = automatic): 4096 with a page-locked sink -- and 512 / 1024 for a chunk of at most 2048 / 8192 proofs: the output of such a chunk
-    // (169 KB per proof: 15 ms for 4096 proofs) is a large part of its time, and what is not covered by the next slice's kernels is exposed at the end of the call or delays the
-    // lane's next chunk (tools/slice_sweep.sh, one chunk per call: -11 % at 1024 proofs, -20 % at 2048, -25 % at 4096, -15 % at 8192; the default chunk of 4096 on two lanes:
-    // -19 % at 8192 proofs per call, -11 % at 16 384, -6 % at 32 768; profiles/r06_ab_variants.txt (22))
-    const uint32_t S = c->slice ? c->slice : !host_sink ? 0u : cnt <= 2048 ? 512u : cnt <= 8192 ? 1024u : 4096u;
+    // proofs per slice (zk_ctx_set_slice; 0 = automatic): 4096 with a page-locked sink -- and 512 / 1024 for the small chunks of short calls, whose output (169 KB per proof:
+    // 15 ms for 4096 proofs) is a large part of their time and is exposed at the end of the call or delays the lane's next chunk: a call that is ONE chunk of at most 2048 / 8192
+    // proofs (tools/slice_sweep.sh: -11 % at 1024 proofs per call, -20 % at 2048, -25 % at 4096, -15 % at 8192), and the chunks of at most 2048 / 4096 proofs of a call of at
+    // most 32 768 (the default chunk of 4096 on two lanes: -19 % at 8192 proofs per call, -11 % at 16 384, -5 % at 32 768).  Not beyond: chunks of 8192 in a longer call lose
+    // 1 %, and the tapered first and last chunks of a 65 536-proof call lose 6-12 % -- the neighbouring chunks hide the transfers there, and small grids cost more than they gain
+    // (profiles/r06_ab_variants.txt (22)).
+    const uint32_t small_max = plan.size() == 1 ? 8192u : B <= 32768 ? 4096u : 0u;
+    const uint32_t S = c->slice ? c->slice : !host_sink ? 0u : cnt <= small_max ? (cnt <= 2048 ? 512u : 1024u) : 4096u;
     const bool sliced = S && cnt > S;
     const bool last_chunk = first + cnt == B && !more_follows;
     launch_words_to_host(s, totals, d_totals, 4);
