@@ -20,8 +20,9 @@ def run():
     eng = Z.Engine(0)
     eng.set_comb_bits(16)
     eng.set_params(*eng.synth_params(2024), 80)
-    ring, msg, sig, pk, which, seeds = eng.synth_workload(2024, 1024, 4)
-    eng.set_ring(ring, 1024)
+    nk = int(os.environ.get('B1_RING', '1024'))   # B1_RING=65536: the bench's ring
+    ring, msg, sig, pk, which, seeds = eng.synth_workload(2024, nk, 4)
+    eng.set_ring(ring, nk)
     eng.set_lanes(1)
     eng.set_chunk(1)
     pin = Z.PinnedBuffer(8 << 20)
