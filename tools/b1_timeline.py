@@ -27,7 +27,7 @@ def run():
     eng.set_chunk(1)
     pin = Z.PinnedBuffer(8 << 20)
     a = (msg[:32], sig[:64], pk[:64], which[:1], seeds[:32])
-    for k in range(6):
+    for k in range(int(os.environ.get('B1_CALLS', '6'))):
         dt, hout, hoff, hst = eng.prove_batch_host_raw(*a, out=pin)
         vdt, vok, vst = eng.verify_batch_host_raw(a[0], hout, hoff, 1)
         assert sum(vok) == 1
@@ -80,8 +80,34 @@ def parse(path):
             print('%-44s x%-3d %9.1f us' % (n[:44], c, d / 1e3))
 
 
+def modes(path):
+    """The shortest and the longest prove call of a trace side by side (start offset and duration of every kernel): what differs between the calls of one process."""
+    db = sqlite3.connect(path)
+    rows = [(short(n), st, s, e) for n, st, s, e in db.execute('select name, stream, start, end from kernels order by start').fetchall()]
+    calls, cur = [], []
+    for r in rows:   # a prove call: k_rng_prepass (its first kernel behind the input copy) .. k_status_out
+        if r[0].startswith('k_rng_prepass') and not any(x[0].startswith('k_scan') for x in cur):
+            cur = [r]
+        elif cur:
+            cur.append(r)
+            if r[0].startswith('k_status_out'):
+                calls.append(cur)
+                cur = []
+    calls = [c for c in calls[2:] if not any(x[0].startswith('k_v_') for x in c)]
+    span = lambda c: (c[-1][3] - c[0][2]) / 1e3
+    calls.sort(key=span)
+    print('%d prove calls, first kernel -> k_status_out: %s us' % (len(calls), ' '.join('%.0f' % span(c) for c in calls)))
+    a, b = calls[0], calls[-1]
+    print('%-28s %8s | %9s %8s | %9s %8s' % ('kernel', 'stream', 'start', 'dur', 'start', 'dur'))
+    for x, y in zip(a, b):
+        flag = '  <--' if abs((y[3] - y[2]) - (x[3] - x[2])) > 8e3 or abs((y[2] - b[0][2]) - (x[2] - a[0][2])) > 30e3 else ''
+        print('%-28s %8s | %9.1f %8.1f | %9.1f %8.1f   %s%s' % (x[0][:28], x[1], (x[2] - a[0][2]) / 1e3, (x[3] - x[2]) / 1e3, (y[2] - b[0][2]) / 1e3, (y[3] - y[2]) / 1e3, y[0][:20] if y[0] != x[0] else '', flag))
+
+
 if __name__ == '__main__':
     if sys.argv[1] == 'run':
         run()
+    elif sys.argv[1] == 'modes':
+        modes(sys.argv[2])
     else:
         parse(sys.argv[2])

@@ -876,35 +876,6 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
         launch_words_to_host(s, h_item_base, W.item_base, (size_t)cnt + 1);
         launch_words_to_host(s, h_out_base, W.out_base, 2 * ((size_t)cnt + 1));
     }
-    if (io_dbg) fprintf(stderr, "host %7.1f ms: stage2 lane %u waits for its scan\n", host_ms() - host_t0, pd.lane);
-    HIPCHK(c, hipStreamSynchronize(s));
-    if (io_dbg) fprintf(stderr, "host %7.1f ms: scan done\n", host_ms() - host_t0);
-    if (totals[1]) {
-        c->err = "output buffer too small";
-        sync_lanes();
-        return ZK_E_BUFFER;
-    }
-    const uint32_t items_all = totals[0];
-    if (items_all > W.items_cap) {
-        // cannot happen for hash-derived challenges (cap = mean + 8 sigma) unless chunk*sec is tiny, where cap = chunk*sec
-        c->err = "zero-bit rep count exceeds workspace capacity";
-        sync_lanes();
-        return ZK_E_BUFFER;
-    }
-    uint8_t* out = d_out + cursor;
-    const uint64_t chunk_bytes = (uint64_t)totals[2] | ((uint64_t)totals[3] << 32);
-    {
-        MaybeScope t(timed, c, "scan", s);
-        launch_items(s, W, cnt);
-    }
-    {
-        MaybeScope t(timed, c, "rng_prepass", s);  // second stage: only the blocks a proof with z zero bits can reach
-        launch_rng_prepass(s, Wgen, cnt, 3 + 4 * W.sec + RNG_MAX_EXC, nblk, nblk, rng_mode == 0 ? W.rng_fill : nullptr, true);
-    }
-    {
-        MaybeScope t(timed, c, "respond_write", s);
-        launch_write_fixed(s, W, cnt, out);
-    }
     // A small chunk leaves the GPU idle and its phases are chains of latencies: the membership phase (list C, its own hash and responses) runs on the
     // lane's side stream beside the PointAdd phase (list B); they share only what stage 1 and the scan left behind.
     auto& PL = c->pl[pd.lane];
@@ -916,35 +887,78 @@ zk_status ProveJob::stage2(uint64_t chunk_no) {
         zk_status zs = ensure_side_stream(c, PL);
         if (zs) return zs;
         sg = PL.side;
-        HIPCHK(c, hipEventRecord(PL.side_fork, s));
-        HIPCHK(c, hipStreamWaitEvent(sg, PL.side_fork, 0));
     }
-    auto membership_phase = [&]() -> zk_status {
-        {
+    // part 0: all of it; 1: everything that stays inside the workspace (ring fold, commitments, challenge); 2: the responses and points written into the proofs
+    auto membership_phase = [&](int part) -> zk_status {
+        if (part != 2) {
             MaybeScope t(timed, c, "gk_fold", sg);
             launch_gk_scalars_fold(sg, W, in, gk_am);
             launch_gk_cd_scalars(sg, W, cnt);
         }
-        {
+        if (part != 2) {
             MaybeScope t(timed, c, "tom_commit", sg);
             launch_tom_commit(sg, P, W.lc, cnt * 4 * W.n, 1, 1);
         }
-        {
+        if (part != 2) {
             MaybeScope t(timed, c, "tom_normalize", sg);
             launch_tom_normalize(sg, W.lc, cnt * 4 * W.n, 0, 1, 1);
         }
-        {
+        if (part != 2) {
             MaybeScope t(timed, c, "hash", sg);
             launch_gk_hash(sg, W, cnt, in.msg);
         }
+        if (part == 1) return ZK_OK;
         {
             MaybeScope t(timed, c, "respond_write", sg);
-            launch_gk_respond(sg, W, in, out);
+            launch_gk_respond(sg, W, in, d_out + cursor);
         }
         if (beside) HIPCHK(c, hipEventRecord(PL.side_done, sg));
         return ZK_OK;
     };
-    if (zk_status zs = membership_phase()) return zs;
+    // A small one-chunk call: what needs nothing from the host -- the second RNG prepass and the membership phase up to its challenge -- is on the device BEFORE the host waits
+    // for the scan's totals: the device does not fall idle during the host's round trip, and the side stream's chain starts ~0.1 ms earlier.
+    const bool early = beside;
+    if (early) {
+        {
+            MaybeScope t(timed, c, "rng_prepass", s);
+            launch_rng_prepass(s, Wgen, cnt, 3 + 4 * W.sec + RNG_MAX_EXC, nblk, nblk, rng_mode == 0 ? W.rng_fill : nullptr, true);
+        }
+        HIPCHK(c, hipEventRecord(PL.side_fork, s));
+        HIPCHK(c, hipStreamWaitEvent(sg, PL.side_fork, 0));
+        if (zk_status zs = membership_phase(1)) return zs;
+    }
+    if (io_dbg) fprintf(stderr, "host %7.1f ms: stage2 lane %u waits for its scan\n", host_ms() - host_t0, pd.lane);
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (io_dbg) fprintf(stderr, "host %7.1f ms: scan done\n", host_ms() - host_t0);
+    if (totals[1]) {
+        c->err = "output buffer too small";
+        sync_lanes();
+        if (early) (void)hipStreamSynchronize(sg);   // (the membership phase's first part is on the side stream already: workspace only)
+        return ZK_E_BUFFER;
+    }
+    const uint32_t items_all = totals[0];
+    if (items_all > W.items_cap) {
+        // cannot happen for hash-derived challenges (cap = mean + 8 sigma) unless chunk*sec is tiny, where cap = chunk*sec
+        c->err = "zero-bit rep count exceeds workspace capacity";
+        sync_lanes();
+        if (early) (void)hipStreamSynchronize(sg);
+        return ZK_E_BUFFER;
+    }
+    uint8_t* out = d_out + cursor;
+    const uint64_t chunk_bytes = (uint64_t)totals[2] | ((uint64_t)totals[3] << 32);
+    {
+        MaybeScope t(timed, c, "scan", s);
+        launch_items(s, W, cnt);
+    }
+    if (!early) {
+        MaybeScope t(timed, c, "rng_prepass", s);  // second stage: only the blocks a proof with z zero bits can reach
+        launch_rng_prepass(s, Wgen, cnt, 3 + 4 * W.sec + RNG_MAX_EXC, nblk, nblk, rng_mode == 0 ? W.rng_fill : nullptr, true);
+    }
+    {
+        MaybeScope t(timed, c, "respond_write", s);
+        launch_write_fixed(s, W, cnt, out);
+    }
+    if (zk_status zs = membership_phase(early ? 2 : 0)) return zs;
     std::vector<ChunkPlan> slices;
     if (sliced) slices = make_chunk_plan(cnt, S, 1, host_sink != nullptr && !more_follows, last_chunk ? ZK_SLICE_MIN / 2 : ZK_SLICE_MIN);   // the call's very last slices stay exposed
     else slices.push_back({0, cnt});
